@@ -1,0 +1,111 @@
+/*
+ * imsegm_hip.h -- C ABI of libimsegm_hip.so: the MI355X (gfx950) implementation of pyImSegm's
+ * SLIC -> per-superpixel descriptors -> alpha-expansion GraphCut hot path.
+ *
+ * Conventions: every function returns 0 on success and a negative value on error; the message is
+ * available from imsegm_last_error() (thread local).  All host arrays are C-contiguous and owned
+ * by the caller; the library never keeps a host pointer past the return of a call.  The HIP
+ * runtime is initialised lazily by the first call that needs it (never at load time), so the
+ * library is safe to load before a fork() (reference: imsegm/utilities/experiments.py:392-403).
+ *
+ * Each entry point names the interface of the reference (Borda/pyImSegm @ /root/reference) or of
+ * its third-party native dependency that it replaces.
+ */
+#ifndef IMSEGM_HIP_H
+#define IMSEGM_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define IMSEGM_API __attribute__((visibility("default")))
+
+#define IMSEGM_U8 0
+#define IMSEGM_F64 1
+#define IMSEGM_F32 2
+
+typedef struct imsegm_ctx imsegm_ctx;           /* one device + one stream */
+typedef struct imsegm_image2d imsegm_image2d;   /* device-resident state of one H x W image */
+
+IMSEGM_API const char *imsegm_last_error(void);
+IMSEGM_API int imsegm_version(void);
+IMSEGM_API int imsegm_device_count(int *count_out);
+
+IMSEGM_API int imsegm_ctx_create(int device, imsegm_ctx **ctx_out);
+IMSEGM_API void imsegm_ctx_destroy(imsegm_ctx *ctx);
+IMSEGM_API int imsegm_ctx_synchronize(imsegm_ctx *ctx);
+
+/* HIP-event timing of the kernels launched on the context's stream (bench.py roofline leg).
+ * group: 0 = SLIC assignment(+accumulate) kernel, 1 = whole SLIC stage, 2 = connectivity,
+ *        3 = colour statistics, 4 = adjacency + centres, 5 = alpha expansion, 6 = gathers,
+ *        7 = SLIC pre-processing.  Returns accumulated milliseconds and launch count since reset. */
+IMSEGM_API int imsegm_ctx_profile_enable(imsegm_ctx *ctx, int enable);
+IMSEGM_API int imsegm_ctx_profile_reset(imsegm_ctx *ctx);
+IMSEGM_API int imsegm_ctx_profile_get(imsegm_ctx *ctx, int group, double *total_ms_out, int *count_out);
+
+/* ---------------------------------------------------------------------------------------------
+ * device-resident pipeline object (keeps image, Lab planes, label map, ... in HBM between stages)
+ * ------------------------------------------------------------------------------------------- */
+IMSEGM_API int imsegm_image2d_create(imsegm_ctx *ctx, int height, int width, imsegm_image2d **img_out);
+IMSEGM_API void imsegm_image2d_destroy(imsegm_image2d *img);
+
+/* H2D copy of an H x W x 3 interleaved colour image (dtype IMSEGM_U8 / IMSEGM_F32 / IMSEGM_F64). */
+IMSEGM_API int imsegm_image2d_upload(imsegm_image2d *img, const void *host_pixels, int dtype);
+
+/* Replaces skimage.segmentation.slic(image, n_segments, compactness, sigma, enforce_connectivity=True)
+ * as called at imsegm/superpixels.py:61-63, with the min-max scaling of superpixels.py:53-54 folded
+ * in (minmax_normalize: 1 = always, 0 = never, 2 = as the reference: unless min == 0 and max == 1).
+ * taps_*: half kernels (taps[0] = centre, radius taps follow) of scipy.ndimage.gaussian_filter1d for
+ * sigma / spacing per axis; radius < 0 disables the axis.  max_candidates: 0 = default (debug knob
+ * that forces the kernel's global-memory fallback when small).  Labels stay on the device. */
+IMSEGM_API int imsegm_image2d_slic(imsegm_image2d *img, int minmax_normalize, int n_segments, double compactness,
+                        const double *taps_z, int radius_z, const double *taps_y, int radius_y,
+                        const double *taps_x, int radius_x, int max_iter, int enforce_connectivity,
+                        double min_size_factor, double max_size_factor, int start_label,
+                        int max_candidates, int *n_labels_out);
+
+/* copy the current label map to the host as int64 (dtype leaked by skimage, superpixels.py:69) */
+IMSEGM_API int imsegm_image2d_get_labels(imsegm_image2d *img, int64_t *labels_out);
+/* install an arbitrary label map (int32, values in [0, n_labels)) -- stage-level entry for the
+ * descriptor / graph functions that take a user segmentation */
+IMSEGM_API int imsegm_image2d_set_labels(imsegm_image2d *img, const int32_t *labels, int n_labels);
+/* inspection for the parity tests: pre-processed Lab planes [3][H][W] and raw k-means assignment */
+IMSEGM_API int imsegm_image2d_get_lab(imsegm_image2d *img, double *lab_out);
+IMSEGM_API int imsegm_image2d_get_nearest(imsegm_image2d *img, int32_t *nearest_out);
+
+/* Replaces imsegm.features_cython.computeColorImage2dMean / Energy / Variance + normColorFeatures
+ * (imsegm/features_cython.pyx:59-141) on the uploaded image and the current label map.
+ * Outputs are n_labels x 3 float64 (NULL = not wanted); variance uses the float32-rounded means as
+ * descriptors.py:293 does. */
+IMSEGM_API int imsegm_image2d_color_stats(imsegm_image2d *img, double *mean_out, double *energy_out, double *var_out);
+
+/* Replaces make_graph_segm_connect_grid2d_conn4 (imsegm/superpixels.py:157-177) and
+ * superpixel_centers (superpixels.py:205-242) on the current label map.
+ * edges_out: capacity x 2 int32, pairs [a, b] with a < b ordered by (b, a); *n_edges_out receives the
+ * real count (may exceed capacity: call again).  centres_out: n_labels x 2 (row, col), -1 for labels
+ * without pixels; present_out: n_labels flags (the `vertices` of the reference). */
+IMSEGM_API int imsegm_image2d_graph(imsegm_image2d *img, int32_t *edges_out, int edge_capacity, int *n_edges_out,
+                         double *centres_out, uint8_t *present_out);
+
+/* Replaces the LUT gathers graph_labels[slic] and proba[slic] (imsegm/pipelines.py:104,109).
+ * Either output may be NULL. segm_out: H x W int32; soft_out: H x W x n_classes float64. */
+IMSEGM_API int imsegm_image2d_gather(imsegm_image2d *img, const int32_t *graph_labels, const double *proba,
+                          int n_classes, int32_t *segm_out, double *soft_out);
+
+/* ---------------------------------------------------------------------------------------------
+ * stand-alone stage
+ * ------------------------------------------------------------------------------------------- */
+/* Replaces gco.cut_general_graph(edges, edge_weights, unary_cost, pairwise_cost, n_iter,
+ * algorithm='expansion') (gco-wrapper >= 3.0.8) as called at imsegm/graph_cuts.py:735-744.
+ * edges: E x 2 int32 with edges[:,0] < edges[:,1]; edge_weights: E; unary: K x C; pairwise: C x C
+ * symmetric.  Float costs are converted to integer energies exactly as pyGCO does. */
+IMSEGM_API int imsegm_cut_general_graph(imsegm_ctx *ctx, const int32_t *edges, int n_edges, const double *edge_weights,
+                             const double *unary_cost, int n_sites, int n_labels, const double *pairwise_cost,
+                             int n_iter, int32_t *labels_out, int64_t *energy_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* IMSEGM_HIP_H */

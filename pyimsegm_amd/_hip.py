@@ -1,0 +1,313 @@
+"""Thin ctypes binding of ``libimsegm_hip.so`` (C ABI declared in ``include/imsegm_hip.h``).
+
+The library holds every compute kernel of the package (hand-written HIP for gfx950).  There is no
+CPU fallback: if the shared library or a GPU is missing, the calls raise ``HipUnavailableError``.
+The HIP runtime is initialised lazily, per process, on the first call that needs the device, so
+importing the package before ``multiprocessing`` forks workers (the reference's only parallelism,
+``imsegm/utilities/experiments.py:392-403``) is safe.
+"""
+import ctypes as C
+import os
+import threading
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libimsegm_hip.so')
+
+U8, F64, F32 = 0, 1, 2
+PROFILE_GROUPS = {
+    'slic_assign': 0,
+    'slic': 1,
+    'connectivity': 2,
+    'color_stats': 3,
+    'graph': 4,
+    'graphcut': 5,
+    'gather': 6,
+    'slic_preprocess': 7,
+}
+
+
+class HipUnavailableError(RuntimeError):
+    """the HIP library or a HIP device is not available (no CPU fallback exists)"""
+
+
+class HipError(RuntimeError):
+    """a C-ABI call returned an error status"""
+
+
+_lib = None
+_lib_lock = threading.Lock()
+
+_vp = C.c_void_p
+_ip = C.POINTER(C.c_int)
+
+_SIGNATURES = {
+    'imsegm_last_error': (C.c_char_p, []),
+    'imsegm_version': (C.c_int, []),
+    'imsegm_device_count': (C.c_int, [_ip]),
+    'imsegm_ctx_create': (C.c_int, [C.c_int, C.POINTER(_vp)]),
+    'imsegm_ctx_destroy': (None, [_vp]),
+    'imsegm_ctx_synchronize': (C.c_int, [_vp]),
+    'imsegm_ctx_profile_enable': (C.c_int, [_vp, C.c_int]),
+    'imsegm_ctx_profile_reset': (C.c_int, [_vp]),
+    'imsegm_ctx_profile_get': (C.c_int, [_vp, C.c_int, C.POINTER(C.c_double), _ip]),
+    'imsegm_image2d_create': (C.c_int, [_vp, C.c_int, C.c_int, C.POINTER(_vp)]),
+    'imsegm_image2d_destroy': (None, [_vp]),
+    'imsegm_image2d_upload': (C.c_int, [_vp, _vp, C.c_int]),
+    'imsegm_image2d_slic': (C.c_int, [_vp, C.c_int, C.c_int, C.c_double, _vp, C.c_int, _vp, C.c_int, _vp, C.c_int,
+                                      C.c_int, C.c_int, C.c_double, C.c_double, C.c_int, C.c_int, _ip]),
+    'imsegm_image2d_get_labels': (C.c_int, [_vp, _vp]),
+    'imsegm_image2d_set_labels': (C.c_int, [_vp, _vp, C.c_int]),
+    'imsegm_image2d_get_lab': (C.c_int, [_vp, _vp]),
+    'imsegm_image2d_get_nearest': (C.c_int, [_vp, _vp]),
+    'imsegm_image2d_color_stats': (C.c_int, [_vp, _vp, _vp, _vp]),
+    'imsegm_image2d_graph': (C.c_int, [_vp, _vp, C.c_int, _ip, _vp, _vp]),
+    'imsegm_image2d_gather': (C.c_int, [_vp, _vp, _vp, C.c_int, _vp, _vp]),
+    'imsegm_cut_general_graph': (C.c_int, [_vp, _vp, C.c_int, _vp, _vp, C.c_int, C.c_int, _vp, C.c_int, _vp,
+                                           C.POINTER(C.c_int64)]),
+}
+
+#: every symbol ``include/imsegm_hip.h`` declares
+EXPORTED_SYMBOLS = tuple(_SIGNATURES)
+
+
+def load_library():
+    """load ``libimsegm_hip.so`` and declare the signatures (no device is touched)"""
+    global _lib
+    with _lib_lock:
+        if _lib is None:
+            if not os.path.exists(LIB_PATH):
+                raise HipUnavailableError(
+                    'libimsegm_hip.so is not built (%s); run `python -m pyimsegm_amd.build`' % LIB_PATH)
+            try:
+                lib = C.CDLL(LIB_PATH)
+            except OSError as ex:
+                raise HipUnavailableError('cannot load %s: %s' % (LIB_PATH, ex))
+            for name, (res, args) in _SIGNATURES.items():
+                fn = getattr(lib, name)
+                fn.restype = res
+                fn.argtypes = args
+            _lib = lib
+    return _lib
+
+
+def _check(status):
+    if status != 0:
+        raise HipError(load_library().imsegm_last_error().decode('utf-8', 'replace'))
+
+
+def device_count():
+    n = C.c_int(0)
+    load_library().imsegm_device_count(C.byref(n))
+    return n.value
+
+
+def _ptr(arr):
+    return None if arr is None else arr.ctypes.data_as(_vp)
+
+
+class Context(object):
+    """one HIP device + one stream"""
+
+    def __init__(self, device=0):
+        lib = load_library()
+        if device_count() < 1:
+            raise HipUnavailableError('no HIP device is visible: the imsegm HIP path cannot run (no CPU fallback)')
+        self._h = _vp()
+        self.device = device
+        self.pid = os.getpid()
+        _check(lib.imsegm_ctx_create(device, C.byref(self._h)))
+
+    def synchronize(self):
+        _check(load_library().imsegm_ctx_synchronize(self._h))
+
+    def profile_enable(self, enable=True):
+        _check(load_library().imsegm_ctx_profile_enable(self._h, int(enable)))
+
+    def profile_reset(self):
+        _check(load_library().imsegm_ctx_profile_reset(self._h))
+
+    def profile_get(self, group):
+        ms, n = C.c_double(0), C.c_int(0)
+        _check(load_library().imsegm_ctx_profile_get(self._h, PROFILE_GROUPS[group], C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
+    def close(self):
+        if self._h and self.pid == os.getpid():
+            load_library().imsegm_ctx_destroy(self._h)
+        self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+_default_ctx = {}
+
+
+def default_context():
+    """per-process, per-device lazily created context (re-created in forked children)"""
+    device = int(os.environ.get('IMSEGM_HIP_DEVICE', os.environ.get('LOCAL_RANK', '0')))
+    n = device_count()
+    if n > 0:
+        device %= n
+    key = (os.getpid(), device)
+    ctx = _default_ctx.get(key)
+    if ctx is None:
+        ctx = Context(device)
+        _default_ctx[key] = ctx
+    return ctx
+
+
+def gaussian_taps(sigma, truncate=4.0):
+    """half of the kernel of ``scipy.ndimage.gaussian_filter1d(sigma)`` (taps[0] = centre), computed
+    with the very numpy expressions of ``scipy.ndimage._filters._gaussian_kernel1d``; None: no blur"""
+    sigma = float(sigma)
+    if not sigma > 0:
+        return None
+    radius = int(truncate * sigma + 0.5)
+    sigma2 = sigma * sigma
+    x = np.arange(-radius, radius + 1)
+    phi_x = np.exp(-0.5 / sigma2 * x**2)
+    phi_x = phi_x / phi_x.sum()
+    return np.ascontiguousarray(phi_x[::-1][radius:], dtype=np.float64)
+
+
+_DTYPES = {np.dtype(np.uint8): U8, np.dtype(np.float64): F64, np.dtype(np.float32): F32}
+
+
+class Image2D(object):
+    """device-resident pipeline state of one H x W colour image"""
+
+    def __init__(self, height, width, ctx=None):
+        self.ctx = ctx or default_context()
+        self.shape = (int(height), int(width))
+        self._h = _vp()
+        self.n_labels = 0
+        _check(load_library().imsegm_image2d_create(self.ctx._h, self.shape[0], self.shape[1], C.byref(self._h)))
+
+    def close(self):
+        if self._h and self.ctx is not None and self.ctx._h and self.ctx.pid == os.getpid():
+            load_library().imsegm_image2d_destroy(self._h)
+        self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def upload(self, image):
+        """H x W x 3 image; uint8 / float32 / float64 go up as they are, anything else as float64"""
+        image = np.asarray(image)
+        if image.ndim != 3 or image.shape[2] != 3 or image.shape[:2] != self.shape:
+            raise ValueError('expected an image of shape %r + (3,), got %r' % (self.shape, image.shape))
+        if image.dtype not in _DTYPES:
+            image = image.astype(np.float64)
+        image = np.ascontiguousarray(image)
+        _check(load_library().imsegm_image2d_upload(self._h, _ptr(image), _DTYPES[image.dtype]))
+        return self
+
+    def slic(self, n_segments, compactness, sigma=1., normalize=2, max_iter=10, enforce_connectivity=True,
+             min_size_factor=0.5, max_size_factor=3., start_label=0, max_candidates=0):
+        taps = gaussian_taps(sigma)
+        r = -1 if taps is None else len(taps) - 1
+        n_out = C.c_int(0)
+        _check(load_library().imsegm_image2d_slic(
+            self._h, int(normalize), int(n_segments), float(compactness), _ptr(taps), r, _ptr(taps), r, _ptr(taps), r,
+            int(max_iter), int(bool(enforce_connectivity)), float(min_size_factor), float(max_size_factor),
+            int(start_label), int(max_candidates), C.byref(n_out)))
+        self.n_labels = n_out.value
+        return self.n_labels
+
+    def get_labels(self):
+        out = np.empty(self.shape, dtype=np.int64)
+        _check(load_library().imsegm_image2d_get_labels(self._h, _ptr(out)))
+        return out
+
+    def set_labels(self, labels, n_labels=None):
+        labels = np.ascontiguousarray(labels, dtype=np.int32)
+        if labels.shape != self.shape:
+            raise ValueError('label map %r does not match image %r' % (labels.shape, self.shape))
+        if labels.size and labels.min() < 0:
+            raise ValueError('labels must be non-negative')
+        if n_labels is None:
+            n_labels = int(labels.max()) + 1
+        _check(load_library().imsegm_image2d_set_labels(self._h, _ptr(labels), int(n_labels)))
+        self.n_labels = int(n_labels)
+        return self
+
+    def get_lab(self):
+        out = np.empty((3,) + self.shape, dtype=np.float64)
+        _check(load_library().imsegm_image2d_get_lab(self._h, _ptr(out)))
+        return out
+
+    def get_nearest(self):
+        out = np.empty(self.shape, dtype=np.int32)
+        _check(load_library().imsegm_image2d_get_nearest(self._h, _ptr(out)))
+        return out
+
+    def color_stats(self, mean=True, energy=True, var=True):
+        k = self.n_labels
+        m = np.empty((k, 3), dtype=np.float64) if mean else None
+        e = np.empty((k, 3), dtype=np.float64) if energy else None
+        v = np.empty((k, 3), dtype=np.float64) if var else None
+        _check(load_library().imsegm_image2d_color_stats(self._h, _ptr(m), _ptr(e), _ptr(v)))
+        return m, e, v
+
+    def graph(self):
+        """(edges int32 E x 2 ordered by (b, a); centres K x 2; present flags K)"""
+        k = self.n_labels
+        cap = max(64, 4 * k)
+        centres = np.empty((k, 2), dtype=np.float64)
+        present = np.empty(k, dtype=np.uint8)
+        while True:
+            edges = np.empty((cap, 2), dtype=np.int32)
+            ne = C.c_int(0)
+            _check(load_library().imsegm_image2d_graph(self._h, _ptr(edges), cap, C.byref(ne), _ptr(centres),
+                                                       _ptr(present)))
+            if ne.value <= cap:
+                return edges[:ne.value], centres, present.astype(bool)
+            cap = ne.value
+
+    def gather(self, graph_labels=None, proba=None, to_host=True):
+        """``graph_labels[slic]`` (int32 H x W) and ``proba[slic]`` (float64 H x W x C)"""
+        segm = soft = None
+        gl = pr = None
+        nc = 0
+        if graph_labels is not None:
+            gl = np.ascontiguousarray(graph_labels, dtype=np.int32)
+            if gl.shape[0] < self.n_labels:
+                raise ValueError('label LUT shorter than the number of superpixels')
+            segm = np.empty(self.shape, dtype=np.int32) if to_host else None
+        if proba is not None:
+            pr = np.ascontiguousarray(proba, dtype=np.float64)
+            if pr.ndim != 2 or pr.shape[0] < self.n_labels:
+                raise ValueError('proba LUT shorter than the number of superpixels')
+            nc = pr.shape[1]
+            soft = np.empty(self.shape + (nc,), dtype=np.float64) if to_host else None
+        _check(load_library().imsegm_image2d_gather(self._h, _ptr(gl), _ptr(pr), nc, _ptr(segm), _ptr(soft)))
+        return segm, soft
+
+
+def cut_general_graph(edges, edge_weights, unary_cost, pairwise_cost, n_iter=-1, algorithm='expansion',
+                      return_energy=False, ctx=None):
+    """drop-in for ``gco.cut_general_graph`` (gco-wrapper), expansion algorithm, on the GPU"""
+    if algorithm != 'expansion':
+        raise NotImplementedError('only algorithm="expansion" is implemented on the HIP path')
+    ctx = ctx or default_context()
+    edges = np.ascontiguousarray(np.asarray(edges).reshape(-1, 2), dtype=np.int32)
+    ew = np.ascontiguousarray(edge_weights, dtype=np.float64)
+    un = np.ascontiguousarray(unary_cost, dtype=np.float64)
+    pw = np.ascontiguousarray(pairwise_cost, dtype=np.float64)
+    if un.ndim != 2 or pw.shape != (un.shape[1], un.shape[1]) or len(ew) != len(edges):
+        raise ValueError('shape mismatch among edges %r, weights %r, unary %r, pairwise %r' %
+                         (edges.shape, ew.shape, un.shape, pw.shape))
+    labels = np.empty(un.shape[0], dtype=np.int32)
+    energy = C.c_int64(0)
+    _check(load_library().imsegm_cut_general_graph(ctx._h, _ptr(edges), len(edges), _ptr(ew), _ptr(un), un.shape[0],
+                                                   un.shape[1], _ptr(pw), int(n_iter), _ptr(labels), C.byref(energy)))
+    return (labels, energy.value) if return_energy else labels

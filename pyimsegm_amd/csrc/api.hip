@@ -1,0 +1,737 @@
+// api.hip -- C ABI (include/imsegm_hip.h) and host-side orchestration of libimsegm_hip.so.
+#include "../../include/imsegm_hip.h"
+#include "slic.h"
+
+#include <cstdio>
+#include <cstring>
+#include <vector>
+
+namespace imsegm {
+
+static thread_local std::string g_error;
+
+void set_error(const std::string &msg) { g_error = msg; }
+
+bool hip_ok(hipError_t e, const char *what, const char *file, int line)
+{
+    if (e == hipSuccess) return true;
+    char buf[512];
+    snprintf(buf, sizeof(buf), "HIP error %d (%s) in `%s` at %s:%d", (int)e, hipGetErrorString(e), what, file, line);
+    g_error = buf;
+    return false;
+}
+
+// growable device buffer
+struct DevBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+    int ensure(size_t bytes)
+    {
+        if (bytes <= cap) return 0;
+        if (p) HIP_TRY(hipFree(p));
+        p = nullptr;
+        cap = 0;
+        size_t want = bytes + bytes / 8 + 256;
+        HIP_TRY(hipMalloc(&p, want));
+        cap = want;
+        return 0;
+    }
+    void release()
+    {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+    template <typename T> T *as() { return reinterpret_cast<T *>(p); }
+};
+
+enum { PG_ASSIGN = 0, PG_SLIC = 1, PG_CONN = 2, PG_STATS = 3, PG_GRAPH = 4, PG_GC = 5, PG_GATHER = 6, PG_PRE = 7, PG_COUNT = 8 };
+
+struct Span {
+    int group;
+    hipEvent_t a, b;
+};
+
+}  // namespace imsegm
+
+using namespace imsegm;
+
+struct imsegm_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool profile = false;
+    std::vector<Span> spans;
+    std::vector<hipEvent_t> pool;
+    double acc_ms[PG_COUNT] = { 0 };
+    int acc_n[PG_COUNT] = { 0 };
+    DevBuf gc_buf;   // scratch of imsegm_cut_general_graph
+
+    hipEvent_t get_event()
+    {
+        if (!pool.empty()) {
+            hipEvent_t e = pool.back();
+            pool.pop_back();
+            return e;
+        }
+        hipEvent_t e;
+        (void)hipEventCreate(&e);
+        return e;
+    }
+    int begin(int group)
+    {
+        if (!profile) return -1;
+        Span s;
+        s.group = group;
+        s.a = get_event();
+        s.b = get_event();
+        (void)hipEventRecord(s.a, stream);
+        spans.push_back(s);
+        return (int)spans.size() - 1;
+    }
+    void end(int id)
+    {
+        if (id >= 0) (void)hipEventRecord(spans[id].b, stream);
+    }
+    void collect()
+    {
+        if (spans.empty()) return;
+        (void)hipStreamSynchronize(stream);
+        for (auto &s : spans) {
+            float ms = 0;
+            if (hipEventElapsedTime(&ms, s.a, s.b) == hipSuccess) {
+                acc_ms[s.group] += ms;
+                acc_n[s.group] += 1;
+            }
+            pool.push_back(s.a);
+            pool.push_back(s.b);
+        }
+        spans.clear();
+    }
+};
+
+struct imsegm_image2d {
+    imsegm_ctx *ctx = nullptr;
+    int H = 0, W = 0;
+    size_t n = 0;
+    int dtype = -1;
+    int n_labels = 0;
+    bool have_labels = false;
+    DevBuf img, labA, labB, nearest, labels, conn_i32, conn_u8, small, cent, feat, graph, gather_lut, gather_out_i, gather_out_f;
+};
+
+static int bind(imsegm_ctx *ctx)
+{
+    if (!ctx) {
+        set_error("null context");
+        return -1;
+    }
+    HIP_TRY(hipSetDevice(ctx->device));
+    return 0;
+}
+
+// skimage.util.regular_grid (util/_regular_grid.py, 0.18) for a 3-D shape
+struct GridAxis {
+    long start, step;
+    bool all;
+};
+static void regular_grid3(const long shape[3], long n_points, GridAxis out[3])
+{
+    int order[3] = { 0, 1, 2 };
+    std::stable_sort(order, order + 3, [&](int a, int b) { return shape[a] < shape[b]; });
+    double sorted_dims[3] = { (double)shape[order[0]], (double)shape[order[1]], (double)shape[order[2]] };
+    double space = sorted_dims[0] * sorted_dims[1] * sorted_dims[2];
+    if (space <= (double)n_points) {
+        for (int i = 0; i < 3; ++i) out[i] = { 0, 1, true };
+        return;
+    }
+    double steps[3];
+    for (int i = 0; i < 3; ++i) steps[i] = pow(space / (double)n_points, 1.0 / 3);
+    bool any_small = false;
+    for (int i = 0; i < 3; ++i) any_small |= sorted_dims[i] < steps[i];
+    if (any_small) {
+        for (int dim = 0; dim < 3; ++dim) {
+            steps[dim] = sorted_dims[dim];
+            double sp = 1.0;
+            for (int j = dim + 1; j < 3; ++j) sp *= sorted_dims[j];
+            if (dim < 2) {
+                double s = pow(sp / (double)n_points, 1.0 / (3 - dim - 1));
+                for (int j = dim + 1; j < 3; ++j) steps[j] = s;
+            }
+            bool ok = true;
+            for (int j = 0; j < 3; ++j) ok &= sorted_dims[j] >= steps[j];
+            if (ok) break;
+        }
+    }
+    for (int i = 0; i < 3; ++i) {
+        long start = (long)floor(steps[i] / 2.0);
+        long step = (long)nearbyint(steps[i]);
+        out[order[i]] = { start, step, false };
+    }
+}
+
+static int fill_taps(Taps &t, const double *w, int r)
+{
+    t.r = -1;
+    for (int i = 0; i < 17; ++i) t.w[i] = 0;
+    if (r < 0 || !w) return 0;
+    if (r > 16) {
+        set_error("gaussian kernel radius > 16 is not supported");
+        return -1;
+    }
+    t.r = r;
+    for (int i = 0; i <= r; ++i) t.w[i] = w[i];
+    return 0;
+}
+
+extern "C" {
+
+const char *imsegm_last_error(void) { return g_error.c_str(); }
+int imsegm_version(void) { return 100; }
+
+int imsegm_device_count(int *count_out)
+{
+    int c = 0;
+    hipError_t e = hipGetDeviceCount(&c);
+    if (e != hipSuccess) {
+        c = 0;
+        (void)hipGetLastError();
+    }
+    *count_out = c;
+    return 0;
+}
+
+int imsegm_ctx_create(int device, imsegm_ctx **ctx_out)
+{
+    int c = 0;
+    HIP_TRY(hipGetDeviceCount(&c));
+    if (device < 0 || device >= c) {
+        set_error("no such HIP device");
+        return -1;
+    }
+    HIP_TRY(hipSetDevice(device));
+    imsegm_ctx *ctx = new imsegm_ctx();
+    ctx->device = device;
+    HIP_TRY(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+    *ctx_out = ctx;
+    return 0;
+}
+
+void imsegm_ctx_destroy(imsegm_ctx *ctx)
+{
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    ctx->collect();
+    for (auto e : ctx->pool) (void)hipEventDestroy(e);
+    ctx->gc_buf.release();
+    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+int imsegm_ctx_synchronize(imsegm_ctx *ctx)
+{
+    if (bind(ctx)) return -1;
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+int imsegm_ctx_profile_enable(imsegm_ctx *ctx, int enable)
+{
+    if (bind(ctx)) return -1;
+    ctx->collect();
+    ctx->profile = enable != 0;
+    return 0;
+}
+
+int imsegm_ctx_profile_reset(imsegm_ctx *ctx)
+{
+    if (bind(ctx)) return -1;
+    ctx->collect();
+    for (int i = 0; i < PG_COUNT; ++i) {
+        ctx->acc_ms[i] = 0;
+        ctx->acc_n[i] = 0;
+    }
+    return 0;
+}
+
+int imsegm_ctx_profile_get(imsegm_ctx *ctx, int group, double *total_ms_out, int *count_out)
+{
+    if (bind(ctx)) return -1;
+    if (group < 0 || group >= PG_COUNT) {
+        set_error("bad profile group");
+        return -1;
+    }
+    ctx->collect();
+    *total_ms_out = ctx->acc_ms[group];
+    *count_out = ctx->acc_n[group];
+    return 0;
+}
+
+int imsegm_image2d_create(imsegm_ctx *ctx, int height, int width, imsegm_image2d **img_out)
+{
+    if (bind(ctx)) return -1;
+    if (height <= 0 || width <= 0 || (long)height * width > 0x3fffffffL) {
+        set_error("bad image size");
+        return -1;
+    }
+    imsegm_image2d *im = new imsegm_image2d();
+    im->ctx = ctx;
+    im->H = height;
+    im->W = width;
+    im->n = (size_t)height * width;
+    *img_out = im;
+    return 0;
+}
+
+void imsegm_image2d_destroy(imsegm_image2d *im)
+{
+    if (!im) return;
+    (void)hipSetDevice(im->ctx->device);
+    (void)hipStreamSynchronize(im->ctx->stream);
+    DevBuf *all[] = { &im->img, &im->labA, &im->labB, &im->nearest, &im->labels, &im->conn_i32, &im->conn_u8, &im->small,
+                      &im->cent, &im->feat, &im->graph, &im->gather_lut, &im->gather_out_i, &im->gather_out_f };
+    for (auto b : all) b->release();
+    delete im;
+}
+
+int imsegm_image2d_upload(imsegm_image2d *im, const void *host_pixels, int dtype)
+{
+    if (!im || bind(im->ctx)) return -1;
+    size_t es = dtype == IMSEGM_U8 ? 1 : dtype == IMSEGM_F32 ? 4 : dtype == IMSEGM_F64 ? 8 : 0;
+    if (!es) {
+        set_error("unsupported dtype");
+        return -1;
+    }
+    size_t bytes = im->n * 3 * es;
+    if (im->img.ensure(bytes + 16)) return -1;
+    HIP_TRY(hipMemcpyAsync(im->img.p, host_pixels, bytes, hipMemcpyHostToDevice, im->ctx->stream));
+    HIP_TRY(hipStreamSynchronize(im->ctx->stream));
+    im->dtype = dtype;
+    return 0;
+}
+
+int imsegm_image2d_slic(imsegm_image2d *im, int minmax_normalize, int n_segments, double compactness,
+                        const double *taps_z, int radius_z, const double *taps_y, int radius_y,
+                        const double *taps_x, int radius_x, int max_iter, int enforce_connectivity,
+                        double min_size_factor, double max_size_factor, int start_label, int max_candidates,
+                        int *n_labels_out)
+{
+    if (!im || bind(im->ctx)) return -1;
+    if (im->dtype < 0) {
+        set_error("no image uploaded");
+        return -1;
+    }
+    if (!(compactness > 0) || n_segments < 1 || max_iter < 1) {
+        set_error("slic: n_segments, compactness and max_iter must be positive");
+        return -1;
+    }
+    if (start_label != 0 && start_label != 1) {
+        set_error("start_label should be 0 or 1.");
+        return -1;
+    }
+    imsegm_ctx *ctx = im->ctx;
+    hipStream_t st = ctx->stream;
+    const int H = im->H, W = im->W;
+    const size_t n = im->n;
+    Taps tz, ty, tx;
+    if (fill_taps(tz, taps_z, radius_z) || fill_taps(ty, taps_y, radius_y) || fill_taps(tx, taps_x, radius_x)) return -1;
+
+    // centroid grid (slic_superpixels.py _get_grid_centroids) and integer steps (_slic.pyx)
+    long shape[3] = { 1, H, W };
+    GridAxis ax[3];
+    regular_grid3(shape, n_segments, ax);
+    std::vector<double> init;
+    for (long y = ax[1].start; y < H; y += ax[1].step)
+        for (long x = ax[2].start; x < W; x += ax[2].step) {
+            init.push_back((double)y);
+            init.push_back((double)x);
+        }
+    // (depth axis: one z = 0 plane, z start is always 0 for a length-1 axis)
+    const int K = (int)(init.size() / 2);
+    if (K < 1) {
+        set_error("slic: empty centroid grid");
+        return -1;
+    }
+    double fsteps[3];
+    for (int i = 0; i < 3; ++i) fsteps[i] = ax[i].all ? 1.0 : (double)ax[i].step;
+    float step = (float)std::max(fsteps[0], std::max(fsteps[1], fsteps[2]));
+    GridAxis axk[3];
+    regular_grid3(shape, K, axk);
+
+    // buffers
+    if (im->labA.ensure(3 * n * sizeof(double)) || im->labB.ensure(3 * n * sizeof(double))) return -1;
+    if (im->nearest.ensure(n * 4) || im->labels.ensure(n * 4)) return -1;
+    size_t cent_bytes = (size_t)K * (5 * 8 + 16 + 9 * 8 + 16) + 256;
+    if (im->cent.ensure(cent_bytes)) return -1;
+    if (im->small.ensure(4096)) return -1;
+
+    unsigned long long *keys = im->small.as<unsigned long long>();
+    double *minmax = reinterpret_cast<double *>(keys + 2);
+
+    int sp_all = ctx->begin(PG_SLIC);
+    int sp = ctx->begin(PG_PRE);
+    if (launch_minmax(im->img.p, im->dtype, n * 3, keys, minmax, st)) return -1;
+    if (launch_preprocess_color2d(im->img.p, im->dtype, H, W, minmax_normalize, minmax, tz, ty, tx, 1.0 / compactness,
+                                  im->labA.as<double>(), im->labB.as<double>(), st))
+        return -1;
+    ctx->end(sp);
+
+    SlicState s;
+    s.H = H; s.W = W; s.K = K;
+    s.step_y = axk[1].all ? 1 : (int)axk[1].step;
+    s.step_x = axk[2].all ? 1 : (int)axk[2].step;
+    s.spatial_weight = 1.0 / ((double)step * (double)step);
+    unsigned char *cb = im->cent.as<unsigned char>();
+    s.acc = reinterpret_cast<long long *>(cb); cb += (size_t)K * 9 * 8;
+    s.cy = reinterpret_cast<double *>(cb); cb += (size_t)K * 8;
+    s.cx = reinterpret_cast<double *>(cb); cb += (size_t)K * 8;
+    s.cL = reinterpret_cast<double *>(cb); cb += (size_t)K * 8;
+    s.ca = reinterpret_cast<double *>(cb); cb += (size_t)K * 8;
+    s.cb = reinterpret_cast<double *>(cb); cb += (size_t)K * 8;
+    s.win = reinterpret_cast<int4 *>(cb); cb += (size_t)K * 16;
+    double *init_dev = reinterpret_cast<double *>(cb);   // K * 2 doubles
+    HIP_TRY(hipMemcpyAsync(init_dev, init.data(), init.size() * sizeof(double), hipMemcpyHostToDevice, st));
+    HIP_TRY(hipStreamSynchronize(st));   // `init` is a stack-owned host vector
+
+    ProfHook hook;
+    if (ctx->profile) {
+        hook.user = ctx;
+        hook.begin = [](void *u, int g) { return static_cast<imsegm_ctx *>(u)->begin(g); };
+        hook.end = [](void *u, int id) { static_cast<imsegm_ctx *>(u)->end(id); };
+    }
+    if (launch_slic_iterations(s, im->labA.as<double>(), init_dev, im->nearest.as<int32_t>(), max_iter, max_candidates, hook, st))
+        return -1;
+
+    int n_labels = K + start_label;
+    if (enforce_connectivity) {
+        double segment_size = (double)n / (double)K;
+        long min_size = (long)(min_size_factor * segment_size);
+        long max_size = (long)(max_size_factor * segment_size);
+        if (im->conn_i32.ensure(n * 4 * 6 + ((n / 4096) + 64) * 4 + 256) || im->conn_u8.ensure(2 * n + 64)) return -1;
+        ConnWork w;
+        int32_t *b = im->conn_i32.as<int32_t>();
+        w.parent = b; b += n;
+        w.csize = b; b += n;
+        w.newlabel = b; b += n;
+        w.adjptr = b; b += n;
+        w.queue = b; b += n;
+        w.list = b; b += n;
+        w.blocksum = b; b += (n / 4096) + 32;
+        w.counters = b;
+        w.visited = im->conn_u8.as<uint8_t>();
+        int spc = ctx->begin(PG_CONN);
+        // the raw assignment carries no start_label offset; the reference adds it before the
+        // connectivity pass, which only matters through mask_label = start_label - 1 (no masked
+        // pixels here), so the raw labels can be used as they are
+        if (launch_enforce_connectivity(im->nearest.as<int32_t>(), H, W, min_size, max_size, start_label, w,
+                                        im->labels.as<int32_t>(), &n_labels, st))
+            return -1;
+        ctx->end(spc);
+    } else {
+        if (start_label != 0) {
+            set_error("enforce_connectivity=False is only supported with start_label=0");
+            return -1;
+        }
+        HIP_TRY(hipMemcpyAsync(im->labels.p, im->nearest.p, n * 4, hipMemcpyDeviceToDevice, st));
+    }
+    ctx->end(sp_all);
+    im->n_labels = n_labels;
+    im->have_labels = true;
+    if (n_labels_out) *n_labels_out = n_labels;
+    return 0;
+}
+
+int imsegm_image2d_get_labels(imsegm_image2d *im, int64_t *labels_out)
+{
+    if (!im || bind(im->ctx)) return -1;
+    if (!im->have_labels) {
+        set_error("no label map");
+        return -1;
+    }
+    std::vector<int32_t> tmp(im->n);
+    HIP_TRY(hipMemcpyAsync(tmp.data(), im->labels.p, im->n * 4, hipMemcpyDeviceToHost, im->ctx->stream));
+    HIP_TRY(hipStreamSynchronize(im->ctx->stream));
+    for (size_t i = 0; i < im->n; ++i) labels_out[i] = tmp[i];
+    return 0;
+}
+
+int imsegm_image2d_set_labels(imsegm_image2d *im, const int32_t *labels, int n_labels)
+{
+    if (!im || bind(im->ctx)) return -1;
+    if (n_labels < 1) {
+        set_error("n_labels must be positive");
+        return -1;
+    }
+    if (im->labels.ensure(im->n * 4)) return -1;
+    HIP_TRY(hipMemcpyAsync(im->labels.p, labels, im->n * 4, hipMemcpyHostToDevice, im->ctx->stream));
+    HIP_TRY(hipStreamSynchronize(im->ctx->stream));
+    im->n_labels = n_labels;
+    im->have_labels = true;
+    return 0;
+}
+
+int imsegm_image2d_get_lab(imsegm_image2d *im, double *lab_out)
+{
+    if (!im || bind(im->ctx)) return -1;
+    if (im->labA.cap < 3 * im->n * 8) {
+        set_error("slic has not been run");
+        return -1;
+    }
+    HIP_TRY(hipMemcpyAsync(lab_out, im->labA.p, 3 * im->n * 8, hipMemcpyDeviceToHost, im->ctx->stream));
+    HIP_TRY(hipStreamSynchronize(im->ctx->stream));
+    return 0;
+}
+
+int imsegm_image2d_get_nearest(imsegm_image2d *im, int32_t *nearest_out)
+{
+    if (!im || bind(im->ctx)) return -1;
+    if (im->nearest.cap < im->n * 4) {
+        set_error("slic has not been run");
+        return -1;
+    }
+    HIP_TRY(hipMemcpyAsync(nearest_out, im->nearest.p, im->n * 4, hipMemcpyDeviceToHost, im->ctx->stream));
+    HIP_TRY(hipStreamSynchronize(im->ctx->stream));
+    return 0;
+}
+
+int imsegm_image2d_color_stats(imsegm_image2d *im, double *mean_out, double *energy_out, double *var_out)
+{
+    if (!im || bind(im->ctx)) return -1;
+    if (!im->have_labels || im->dtype < 0) {
+        set_error("color_stats needs an uploaded image and a label map");
+        return -1;
+    }
+    imsegm_ctx *ctx = im->ctx;
+    hipStream_t st = ctx->stream;
+    const int K = im->n_labels;
+    double maxabs = 255.0;
+    if (im->dtype != IMSEGM_U8) {
+        if (im->small.ensure(4096)) return -1;
+        unsigned long long *keys = im->small.as<unsigned long long>();
+        double *minmax = reinterpret_cast<double *>(keys + 2);
+        if (launch_minmax(im->img.p, im->dtype, im->n * 3, keys, minmax, st)) return -1;
+        double mm[2];
+        HIP_TRY(hipMemcpyAsync(mm, minmax, 16, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        maxabs = std::max(fabs(mm[0]), fabs(mm[1]));
+        if (!(maxabs < 1e300)) maxabs = 1e300;
+    }
+    size_t fb = (size_t)K * (13 * 8 + 3 * 3 * 8 + 3 * 4) + 256;
+    if (im->feat.ensure(fb)) return -1;
+    unsigned char *b = im->feat.as<unsigned char>();
+    long long *acc = reinterpret_cast<long long *>(b); b += (size_t)K * 13 * 8;
+    double *d_mean = reinterpret_cast<double *>(b); b += (size_t)K * 3 * 8;
+    double *d_energy = reinterpret_cast<double *>(b); b += (size_t)K * 3 * 8;
+    double *d_var = reinterpret_cast<double *>(b); b += (size_t)K * 3 * 8;
+    float *d_mean32 = reinterpret_cast<float *>(b);
+    int sp = ctx->begin(PG_STATS);
+    if (launch_color_stats(im->img.p, im->dtype, im->labels.as<int32_t>(), im->H, im->W, K, maxabs, var_out != nullptr, acc,
+                           d_mean, d_energy, d_var, d_mean32, st))
+        return -1;
+    ctx->end(sp);
+    size_t ob = (size_t)K * 3 * 8;
+    if (mean_out) HIP_TRY(hipMemcpyAsync(mean_out, d_mean, ob, hipMemcpyDeviceToHost, st));
+    if (energy_out) HIP_TRY(hipMemcpyAsync(energy_out, d_energy, ob, hipMemcpyDeviceToHost, st));
+    if (var_out) HIP_TRY(hipMemcpyAsync(var_out, d_var, ob, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    return 0;
+}
+
+int imsegm_image2d_graph(imsegm_image2d *im, int32_t *edges_out, int edge_capacity, int *n_edges_out,
+                         double *centres_out, uint8_t *present_out)
+{
+    if (!im || bind(im->ctx)) return -1;
+    if (!im->have_labels) {
+        set_error("graph needs a label map");
+        return -1;
+    }
+    imsegm_ctx *ctx = im->ctx;
+    hipStream_t st = ctx->stream;
+    const int K = im->n_labels;
+    if (K > 65536) {
+        set_error("adjacency bitmap supports at most 65536 labels");
+        return -1;
+    }
+    if (edge_capacity < 0) edge_capacity = 0;
+    size_t words = (size_t)cdiv(K, 32);
+    size_t bytes = (size_t)K * words * 4 + (size_t)K * 3 * 8 + (size_t)edge_capacity * 8 + (size_t)K * 2 * 8 + (size_t)K * 4 + K + 512;
+    if (im->graph.ensure(bytes)) return -1;
+    unsigned char *b = im->graph.as<unsigned char>();
+    long long *cacc = reinterpret_cast<long long *>(b); b += (size_t)K * 3 * 8;
+    double *centres = reinterpret_cast<double *>(b); b += (size_t)K * 2 * 8;
+    uint32_t *bitmap = reinterpret_cast<uint32_t *>(b); b += (size_t)K * words * 4;
+    int32_t *edges = reinterpret_cast<int32_t *>(b); b += (size_t)edge_capacity * 8;
+    int32_t *rowcount = reinterpret_cast<int32_t *>(b); b += (size_t)K * 4;
+    int32_t *n_edges_dev = reinterpret_cast<int32_t *>(b); b += 16;
+    uint8_t *present = b;
+    int sp = ctx->begin(PG_GRAPH);
+    if (launch_adjacency_centres(im->labels.as<int32_t>(), im->H, im->W, K, bitmap, cacc, edges, edge_capacity, n_edges_dev,
+                                 centres, present, rowcount, st))
+        return -1;
+    ctx->end(sp);
+    int ne = 0;
+    HIP_TRY(hipMemcpyAsync(&ne, n_edges_dev, 4, hipMemcpyDeviceToHost, st));
+    if (centres_out) HIP_TRY(hipMemcpyAsync(centres_out, centres, (size_t)K * 16, hipMemcpyDeviceToHost, st));
+    if (present_out) HIP_TRY(hipMemcpyAsync(present_out, present, K, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    if (edges_out && ne > 0) {
+        int m = std::min(ne, edge_capacity);
+        HIP_TRY(hipMemcpyAsync(edges_out, edges, (size_t)m * 8, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+    }
+    *n_edges_out = ne;
+    return 0;
+}
+
+int imsegm_image2d_gather(imsegm_image2d *im, const int32_t *graph_labels, const double *proba, int n_classes,
+                          int32_t *segm_out, double *soft_out)
+{
+    if (!im || bind(im->ctx)) return -1;
+    if (!im->have_labels) {
+        set_error("gather needs a label map");
+        return -1;
+    }
+    imsegm_ctx *ctx = im->ctx;
+    hipStream_t st = ctx->stream;
+    const int K = im->n_labels;
+    const size_t n = im->n;
+    size_t lut_bytes = (size_t)K * 4 + 64 + (proba ? (size_t)K * n_classes * 8 : 0);
+    if (im->gather_lut.ensure(lut_bytes)) return -1;
+    double *d_proba = im->gather_lut.as<double>();
+    int32_t *d_gl = reinterpret_cast<int32_t *>(im->gather_lut.as<unsigned char>() + (proba ? (size_t)K * n_classes * 8 : 0));
+    if (graph_labels) {
+        if (im->gather_out_i.ensure(n * 4)) return -1;
+        HIP_TRY(hipMemcpyAsync(d_gl, graph_labels, (size_t)K * 4, hipMemcpyHostToDevice, st));
+    }
+    if (proba) {
+        if (n_classes < 1) {
+            set_error("n_classes must be positive");
+            return -1;
+        }
+        if (im->gather_out_f.ensure(n * n_classes * 8)) return -1;
+        HIP_TRY(hipMemcpyAsync(d_proba, proba, (size_t)K * n_classes * 8, hipMemcpyHostToDevice, st));
+    }
+    HIP_TRY(hipStreamSynchronize(st));   // the host arrays belong to the caller
+    int sp = ctx->begin(PG_GATHER);
+    if (graph_labels && launch_gather_labels(d_gl, im->labels.as<int32_t>(), n, im->gather_out_i.as<int32_t>(), st)) return -1;
+    if (proba && launch_gather_proba(d_proba, n_classes, im->labels.as<int32_t>(), n, im->gather_out_f.as<double>(), st)) return -1;
+    ctx->end(sp);
+    if (graph_labels && segm_out) HIP_TRY(hipMemcpyAsync(segm_out, im->gather_out_i.p, n * 4, hipMemcpyDeviceToHost, st));
+    if (proba && soft_out) HIP_TRY(hipMemcpyAsync(soft_out, im->gather_out_f.p, n * n_classes * 8, hipMemcpyDeviceToHost, st));
+    if ((graph_labels && segm_out) || (proba && soft_out)) HIP_TRY(hipStreamSynchronize(st));
+    return 0;
+}
+
+int imsegm_cut_general_graph(imsegm_ctx *ctx, const int32_t *edges, int n_edges, const double *edge_weights,
+                             const double *unary_cost, int n_sites, int n_labels, const double *pairwise_cost,
+                             int n_iter, int32_t *labels_out, int64_t *energy_out)
+{
+    if (bind(ctx)) return -1;
+    const int K = n_sites, C = n_labels, E = n_edges;
+    if (K < 1 || C < 1 || E < 0) {
+        set_error("cut_general_graph: bad sizes");
+        return -1;
+    }
+    for (int j = 0; j < E; ++j) {
+        int a = edges[2 * j], b = edges[2 * j + 1];
+        if (a < 0 || b >= K || a >= b) {
+            set_error("cut_general_graph: edges must satisfy 0 <= edges[:,0] < edges[:,1] < n_sites");
+            return -1;
+        }
+    }
+    for (int a = 0; a < C; ++a)
+        for (int b = 0; b < C; ++b)
+            if (pairwise_cost[a * C + b] != pairwise_cost[b * C + a]) {
+                set_error("Cost matrix not square or not symmetric");
+                return -1;
+            }
+    // pyGCO (gco/pygco.py): down_weight_factor and float -> int conversion (truncation)
+    double mu = 0, mw = 0, mp = -DBL_MAX;
+    for (size_t i = 0; i < (size_t)K * C; ++i) mu = std::max(mu, fabs(unary_cost[i]));
+    for (int i = 0; i < E; ++i) mw = std::max(mw, fabs(edge_weights[i]));
+    for (int i = 0; i < C * C; ++i) mp = std::max(mp, pairwise_cost[i]);
+    double dwf = ((E > 0 && mw * mp > mu) ? mw * mp : mu) + 1e-10;
+    std::vector<int32_t> ui((size_t)K * C), wi(std::max(E, 1)), si((size_t)C * C);
+    for (size_t i = 0; i < (size_t)K * C; ++i) ui[i] = (int32_t)((unary_cost[i] / dwf) * 100000);
+    for (int i = 0; i < E; ++i) wi[i] = (int32_t)((edge_weights[i] / dwf) * 1000);
+    for (int i = 0; i < C * C; ++i) si[i] = (int32_t)(pairwise_cost[i] * 100);
+    // GCO refuses energy terms above GCO_MAX_ENERGYTERM = 10000000
+    int smax = 0;
+    for (int i = 0; i < C * C; ++i) smax = std::max(smax, std::abs(si[i]));
+    for (int i = 0; i < E; ++i)
+        if ((long long)std::abs(wi[i]) * smax > 10000000LL) {
+            set_error("cut_general_graph: smoothness term is larger than GCO_MAX_ENERGYTERM");
+            return -1;
+        }
+    // CSR over directed arcs
+    std::vector<int32_t> arc_start(K + 1, 0), arc_to(2 * (size_t)std::max(E, 1)), arc_rev(2 * (size_t)std::max(E, 1)),
+        edge_arc(2 * (size_t)std::max(E, 1));
+    for (int j = 0; j < E; ++j) {
+        arc_start[edges[2 * j] + 1]++;
+        arc_start[edges[2 * j + 1] + 1]++;
+    }
+    for (int i = 0; i < K; ++i) arc_start[i + 1] += arc_start[i];
+    {
+        std::vector<int32_t> fill(arc_start.begin(), arc_start.end() - 1);
+        for (int j = 0; j < E; ++j) {
+            int a = edges[2 * j], b = edges[2 * j + 1];
+            int ia = fill[a]++, ib = fill[b]++;
+            arc_to[ia] = b;
+            arc_to[ib] = a;
+            arc_rev[ia] = ib;
+            arc_rev[ib] = ia;
+            edge_arc[2 * j] = ia;
+            edge_arc[2 * j + 1] = ib;
+        }
+    }
+    hipStream_t st = ctx->stream;
+    size_t work_bytes = alpha_expansion_work_bytes(K, E);
+    size_t sz_u = (size_t)K * C * 4, sz_w = (size_t)std::max(E, 1) * 4, sz_s = (size_t)C * C * 4, sz_e = (size_t)std::max(E, 1) * 8;
+    size_t sz_as = (size_t)(K + 1) * 4, sz_a = (size_t)std::max(E, 1) * 8;
+    auto al = [](size_t v) { return (v + 63) & ~(size_t)63; };
+    size_t total = al(work_bytes) + al(sz_u) + al(sz_w) + al(sz_s) + al(sz_e) + al(sz_as) + 3 * al(sz_a) + al((size_t)K * 4) + 256;
+    if (ctx->gc_buf.ensure(total)) return -1;
+    unsigned char *b = ctx->gc_buf.as<unsigned char>();
+    void *work = b; b += al(work_bytes);
+    int32_t *d_u = (int32_t *)b; b += al(sz_u);
+    int32_t *d_w = (int32_t *)b; b += al(sz_w);
+    int32_t *d_s = (int32_t *)b; b += al(sz_s);
+    int32_t *d_e = (int32_t *)b; b += al(sz_e);
+    int32_t *d_as = (int32_t *)b; b += al(sz_as);
+    int32_t *d_at = (int32_t *)b; b += al(sz_a);
+    int32_t *d_ar = (int32_t *)b; b += al(sz_a);
+    int32_t *d_ea = (int32_t *)b; b += al(sz_a);
+    int32_t *d_lab = (int32_t *)b; b += al((size_t)K * 4);
+    long long *d_energy = (long long *)b; b += 64;
+    int32_t *d_status = (int32_t *)b;
+    HIP_TRY(hipMemcpyAsync(d_u, ui.data(), sz_u, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(d_s, si.data(), sz_s, hipMemcpyHostToDevice, st));
+    if (E > 0) {
+        HIP_TRY(hipMemcpyAsync(d_w, wi.data(), (size_t)E * 4, hipMemcpyHostToDevice, st));
+        HIP_TRY(hipMemcpyAsync(d_e, edges, (size_t)E * 8, hipMemcpyHostToDevice, st));
+        HIP_TRY(hipMemcpyAsync(d_at, arc_to.data(), (size_t)E * 8, hipMemcpyHostToDevice, st));
+        HIP_TRY(hipMemcpyAsync(d_ar, arc_rev.data(), (size_t)E * 8, hipMemcpyHostToDevice, st));
+        HIP_TRY(hipMemcpyAsync(d_ea, edge_arc.data(), (size_t)E * 8, hipMemcpyHostToDevice, st));
+    }
+    HIP_TRY(hipMemcpyAsync(d_as, arc_start.data(), sz_as, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemsetAsync(d_status, 0, 4, st));
+    GcProblem p;
+    p.K = K; p.C = C; p.E = E;
+    p.edges = d_e; p.w = d_w; p.unary = d_u; p.smooth = d_s;
+    int sp = ctx->begin(PG_GC);
+    if (launch_alpha_expansion(p, d_as, d_at, d_ar, d_ea, n_iter, d_lab, d_energy, d_status, work, st)) return -1;
+    ctx->end(sp);
+    long long energy = 0;
+    int32_t status = 0;
+    HIP_TRY(hipMemcpyAsync(labels_out, d_lab, (size_t)K * 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(&energy, d_energy, 8, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(&status, d_status, 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    if (status != 0) {
+        set_error("alpha_expansion: max-flow did not converge");
+        return -1;
+    }
+    if (energy_out) *energy_out = energy;
+    return 0;
+}
+
+}  // extern "C"

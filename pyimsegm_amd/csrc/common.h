@@ -1,0 +1,144 @@
+// common.h -- shared declarations of libimsegm_hip (gfx950 only).
+//
+// Device arithmetic helpers here define the bit-exact contract with the CPU oracle
+// (oracle/imsegm_oracle.c): the library is compiled with -ffp-contract=off, so every expression
+// below rounds exactly once per operation, as the gcc-compiled oracle does.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+
+#define IMSEGM_WAVE 64
+
+namespace imsegm {
+
+void set_error(const std::string &msg);
+bool hip_ok(hipError_t e, const char *what, const char *file, int line);
+
+#define HIP_TRY(expr)                                                                   \
+    do {                                                                                \
+        if (!::imsegm::hip_ok((expr), #expr, __FILE__, __LINE__)) return -1;            \
+    } while (0)
+
+static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+
+// ---------------------------------------------------------------------------------------------
+// deterministic elementary functions (mirror of oracle det_rcbrt / orc_det_cbrt / orc_det_pow24)
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ double det_cbrt(double x)
+{
+    long long i = __double_as_longlong(x);
+    i = 0x553ef0ff289dd796LL - i / 3;
+    double y = __longlong_as_double(i);
+    const double third = 1.0 / 3.0;
+#pragma unroll
+    for (int it = 0; it < 5; ++it) {
+        double y3 = y * y * y;
+        double r = 1.0 - x * y3;
+        y = y + y * (r * third);
+    }
+    double yy = y * y;
+    double c = x * yy;
+    double e = c * c * c - x;
+    c = c - e * (yy * third);
+    return c;
+}
+
+__device__ __forceinline__ double det_pow24(double t)
+{
+    long long i = __double_as_longlong(t);
+    i = 0x4cb8a8c154c985f0LL - i / 5;
+    double y = __longlong_as_double(i);
+#pragma unroll
+    for (int it = 0; it < 5; ++it) {
+        double y2 = y * y;
+        double y5 = y2 * y2 * y;
+        double r = 1.0 - t * y5;
+        y = y + y * (r * 0.2);
+    }
+    double p = t * y;
+    return p * p * p;
+}
+
+// skimage.color.rgb2lab (colorconv.py, D65 / 2 deg), one pixel in [0, 1]
+__device__ __forceinline__ void rgb2lab_px(double r, double g, double b, double &L, double &A, double &B)
+{
+    double lin[3] = { r, g, b };
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        double v = lin[c];
+        lin[c] = (v > 0.04045) ? det_pow24((v + 0.055) / 1.055) : v / 12.92;
+    }
+    double X = lin[0] * 0.412453 + lin[1] * 0.357580 + lin[2] * 0.180423;
+    double Y = lin[0] * 0.212671 + lin[1] * 0.715160 + lin[2] * 0.072169;
+    double Z = lin[0] * 0.019334 + lin[1] * 0.119193 + lin[2] * 0.950227;
+    double f[3] = { X / 0.95047, Y / 1.0, Z / 1.08883 };
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        double t = f[c];
+        f[c] = (t > 0.008856) ? det_cbrt(t) : 7.787 * t + 16.0 / 116.0;
+    }
+    L = (116.0 * f[1]) - 16.0;
+    A = 500.0 * (f[0] - f[1]);
+    B = 200.0 * (f[1] - f[2]);
+}
+
+// ---------------------------------------------------------------------------------------------
+// exact order-independent fixed-point accumulation:  v * 2^30 = hi + lo * 2^-32 (+ dropped bits)
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void fix_split(double v, long long &hi, long long &lo)
+{
+    double t = v * 1073741824.0;
+    long long h = (long long)t;
+    double r = t - (double)h;
+    hi = h;
+    lo = (long long)(r * 4294967296.0);
+}
+
+__host__ __device__ __forceinline__ double i64_to_double(long long v)
+{
+    int h = (int)(v >> 32);
+    unsigned int l = (unsigned int)(v & 0xffffffffLL);
+    return (double)h * 4294967296.0 + (double)l;
+}
+
+__host__ __device__ __forceinline__ double fix_join(long long hi, long long lo)
+{
+    double s = i64_to_double(hi) + i64_to_double(lo) * (1.0 / 4294967296.0);
+    return s * (1.0 / 1073741824.0);
+}
+
+// ---------------------------------------------------------------------------------------------
+// wave64 helpers
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ long long wave_sum_i64(long long v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+__device__ __forceinline__ int wave_sum_i32(int v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+__device__ __forceinline__ double wave_min_f64(double v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = fmin(v, __shfl_xor(v, off, 64));
+    return v;
+}
+__device__ __forceinline__ double wave_max_f64(double v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = fmax(v, __shfl_xor(v, off, 64));
+    return v;
+}
+
+__device__ __forceinline__ void atomic_add_i64(long long *p, long long v)
+{
+    atomicAdd(reinterpret_cast<unsigned long long *>(p), (unsigned long long)v);
+}
+
+}  // namespace imsegm

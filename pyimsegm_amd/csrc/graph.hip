@@ -1,0 +1,196 @@
+// graph.hip -- superpixel adjacency graph, superpixel centres and the final LUT gathers.
+//
+// Replaces (reference, per-pixel Python / numpy):
+//   make_graph_segm_connect_grid2d_conn4 + make_graph_segment_connect_edges
+//       /root/reference/imsegm/superpixels.py:115-177   (dict relabel loop, sort, hash, np.unique)
+//   superpixel_centers                                   superpixels.py:205-242 (regionprops)
+//   proba[slic], graph_labels[slic]                      pipelines.py:104,109
+//
+// Adjacency: every pixel compares its label with the right and lower neighbour; differing pairs
+// set one bit in a K x K bitmap (row = larger id b, column = smaller id a).  Reading the bitmap in
+// row-major order yields the edges sorted by (b, a) -- exactly the order the reference obtains from
+// np.unique(a + nb_vertices * b).  Centres are exact int64 coordinate sums / counts.
+#include "slic.h"
+
+namespace imsegm {
+
+constexpr int GR_PX = 4;
+
+__global__ void __launch_bounds__(256)
+k_adjacency_centres(const int32_t *__restrict__ labels, int H, int W, int K, int words, uint32_t *bitmap,
+                    long long *__restrict__ cacc)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int y = blockIdx.y * 4 + wave;
+    const int x0 = (blockIdx.x * 64 + lane) * GR_PX;
+    int lab[GR_PX];
+#pragma unroll
+    for (int i = 0; i < GR_PX; ++i) {
+        int x = x0 + i;
+        bool ok = y < H && x < W;
+        lab[i] = ok ? labels[(size_t)y * W + x] : -1;
+    }
+#pragma unroll
+    for (int i = 0; i < GR_PX; ++i) {
+        int x = x0 + i;
+        if (lab[i] < 0) continue;
+        int nb[2];
+        nb[0] = (x + 1 < W) ? ((i + 1 < GR_PX) ? lab[i + 1] : labels[(size_t)y * W + x + 1]) : lab[i];
+        nb[1] = (y + 1 < H) ? labels[(size_t)(y + 1) * W + x] : lab[i];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            if (nb[j] == lab[i]) continue;
+            int a = min(lab[i], nb[j]), b = max(lab[i], nb[j]);
+            uint32_t *wp = bitmap + (size_t)b * words + (a >> 5);
+            uint32_t bit = 1u << (a & 31);
+            if (!(*wp & bit)) atomicOr(wp, bit);
+        }
+    }
+    // centre sums: one wave pass per distinct label
+    while (true) {
+        int first = -1;
+#pragma unroll
+        for (int i = GR_PX - 1; i >= 0; --i)
+            if (lab[i] >= 0) first = lab[i];
+        unsigned long long vote = __ballot(first >= 0);
+        if (!vote) break;
+        int k = __shfl(first, __ffsll((long long)vote) - 1, 64);
+        int n = 0, sx = 0;
+#pragma unroll
+        for (int i = 0; i < GR_PX; ++i)
+            if (lab[i] == k) {
+                n += 1;
+                sx += x0 + i;
+                lab[i] = -1;
+            }
+        n = wave_sum_i32(n);
+        long long sxl = wave_sum_i64((long long)sx);
+        if (lane == 0) {
+            atomic_add_i64(cacc + (size_t)k * 3 + 0, n);
+            atomic_add_i64(cacc + (size_t)k * 3 + 1, (long long)n * y);
+            atomic_add_i64(cacc + (size_t)k * 3 + 2, sxl);
+        }
+    }
+}
+
+__global__ void k_centres_finalize(const long long *__restrict__ cacc, int K, double *centres, uint8_t *present)
+{
+    int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= K) return;
+    long long n = cacc[(size_t)k * 3];
+    present[k] = n > 0;
+    // labels without pixels -> [-1, -1] (superpixels.py:218)
+    centres[2 * k + 0] = n > 0 ? i64_to_double(cacc[(size_t)k * 3 + 1]) / (double)n : -1.0;
+    centres[2 * k + 1] = n > 0 ? i64_to_double(cacc[(size_t)k * 3 + 2]) / (double)n : -1.0;
+}
+
+__global__ void k_edge_rowcount(const uint32_t *__restrict__ bitmap, int K, int words, int32_t *rowcount)
+{
+    int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= K) return;
+    int c = 0;
+    for (int w = 0; w < words; ++w) c += __popc(bitmap[(size_t)b * words + w]);
+    rowcount[b] = c;
+}
+
+// exclusive scan of rowcount by one workgroup (K is small); total -> n_edges
+__global__ void __launch_bounds__(256) k_edge_scan(int32_t *rowcount, int K, int32_t *n_edges)
+{
+    __shared__ int wsum[4];
+    __shared__ int carry;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int base = 0; base < K; base += 256) {
+        int i = base + threadIdx.x;
+        int v = i < K ? rowcount[i] : 0;
+        int incl = v;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            int t = __shfl_up(incl, off, 64);
+            if (lane >= off) incl += t;
+        }
+        if (lane == 63) wsum[wave] = incl;
+        __syncthreads();
+        int pre = carry;
+        for (int w = 0; w < wave; ++w) pre += wsum[w];
+        if (i < K) rowcount[i] = pre + incl - v;
+        __syncthreads();
+        if (threadIdx.x == 255) carry = pre + incl;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *n_edges = carry;
+}
+
+__global__ void k_edge_emit(const uint32_t *__restrict__ bitmap, int K, int words, const int32_t *__restrict__ offsets,
+                            int32_t *edges, int capacity)
+{
+    int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= K) return;
+    int o = offsets[b];
+    for (int w = 0; w < words; ++w) {
+        uint32_t bits = bitmap[(size_t)b * words + w];
+        while (bits) {
+            int t = __ffs(bits) - 1;
+            bits &= bits - 1;
+            if (o < capacity) {
+                edges[2 * o + 0] = w * 32 + t;
+                edges[2 * o + 1] = b;
+            }
+            ++o;
+        }
+    }
+}
+
+int launch_adjacency_centres(const int32_t *labels, int H, int W, int K, uint32_t *bitmap, long long *cacc,
+                             int32_t *edges_out, int edge_capacity, int32_t *n_edges_dev, double *centres_out,
+                             uint8_t *present_out, int32_t *rowcount, hipStream_t st)
+{
+    int words = cdiv(K, 32);
+    HIP_TRY(hipMemsetAsync(bitmap, 0, (size_t)K * words * sizeof(uint32_t), st));
+    HIP_TRY(hipMemsetAsync(cacc, 0, (size_t)K * 3 * sizeof(long long), st));
+    dim3 grid(cdiv(W, 64 * GR_PX), cdiv(H, 4));
+    hipLaunchKernelGGL(k_adjacency_centres, grid, 256, 0, st, labels, H, W, K, words, bitmap, cacc);
+    hipLaunchKernelGGL(k_centres_finalize, cdiv(K, 256), 256, 0, st, cacc, K, centres_out, present_out);
+    hipLaunchKernelGGL(k_edge_rowcount, cdiv(K, 256), 256, 0, st, bitmap, K, words, rowcount);
+    hipLaunchKernelGGL(k_edge_scan, 1, 256, 0, st, rowcount, K, n_edges_dev);
+    hipLaunchKernelGGL(k_edge_emit, cdiv(K, 256), 256, 0, st, bitmap, K, words, rowcount, edges_out, edge_capacity);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+// ---- LUT gathers --------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+k_gather_i32(const int32_t *__restrict__ lut, const int32_t *__restrict__ idx, size_t n, int32_t *__restrict__ out)
+{
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = lut[idx[i]];
+}
+
+__global__ void __launch_bounds__(256)
+k_gather_f64(const double *__restrict__ lut, int C, const int32_t *__restrict__ idx, size_t total,
+             double *__restrict__ out)
+{
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    size_t p = i / C;
+    int c = (int)(i - p * C);
+    out[i] = lut[(size_t)idx[p] * C + c];
+}
+
+int launch_gather_labels(const int32_t *lut, const int32_t *idx, size_t n, int32_t *out, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_gather_i32, cdiv((long)n, 256), 256, 0, st, lut, idx, n, out);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int launch_gather_proba(const double *lut, int C, const int32_t *idx, size_t n, double *out, hipStream_t st)
+{
+    size_t total = n * C;
+    hipLaunchKernelGGL(k_gather_f64, cdiv((long)total, 256), 256, 0, st, lut, C, idx, total, out);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+}  // namespace imsegm

@@ -1,0 +1,368 @@
+// graphcut.hip -- alpha-expansion over the superpixel adjacency graph as ONE persistent workgroup:
+// label schedule, binary-energy construction, lock-free push-relabel max-flow and the energy test
+// all run on the device without host round trips.
+//
+// Replaces the native boundary `gco.cut_general_graph(edges, edge_weights, unary_cost,
+// pairwise_cost, algorithm='expansion', n_iter=-1)` called at
+// /root/reference/imsegm/graph_cuts.py:735-744 (gco-wrapper: pyGCO -> GCO-v3 -> BK maxflow).
+// Integer energies exactly as pyGCO builds them (see api.hip); binary move energy as
+// Kolmogorov's energy.h (add_term1 / add_term2); cut convention of maxflow-v3 `what_segment(i,
+// SOURCE)`: a site keeps its label only if it can still reach the sink in the residual graph, which
+// makes the result independent of the max-flow algorithm (oracle: gco_alpha_expansion).
+//
+// Max-flow: Hong & He's lock-free push-relabel (one owner thread per node, atomics on residual
+// capacities / excesses) with periodic global relabelling (reverse BFS from the sink).  Terminals
+// are implicit: excess < 0 == remaining capacity towards the sink.  Only phase 1 (maximum
+// preflow) is needed, because the minimal sink side of a min cut is already determined by it.
+// The mutable arrays (residual capacities, heights, excesses) live in LDS when they fit
+// (K ~ 2e3 nodes, E ~ 6e3 edges -> ~75 KB), otherwise in a global scratch buffer.
+#include "slic.h"
+
+namespace imsegm {
+
+constexpr int GC_THREADS = 1024;
+constexpr int GC_MAX_LABELS = 64;
+constexpr int GC_PUSH_ROUNDS = 24;        // lock-free push/relabel sweeps between global relabels
+
+struct GcDevice {
+    int K, C, E, n_iter;
+    const int32_t *edges;      // [E][2]
+    const int32_t *w;          // [E]
+    const int32_t *unary;      // [K][C]
+    const int32_t *smooth;     // [C][C]
+    const int32_t *arc_start;  // [K+1] CSR over directed arcs
+    const int32_t *arc_to;     // [2E]
+    const int32_t *arc_rev;    // [2E] index of the reverse arc
+    const int32_t *edge_arc;   // [E][2] arc index of a->b and of b->a
+    int32_t *labels;           // [K] in/out (starts at 0 = GCO default labelling)
+    int32_t *prop;             // [K] proposed labelling
+    long long *energy_out;     // [1]
+    int32_t *g_cap;            // [2E] global fallbacks
+    int32_t *g_height;         // [K]
+    long long *g_excess;       // [K]
+    int use_lds;
+    int32_t *status;           // [1] 0 ok, 1 = max-flow iteration cap hit
+};
+
+// Accessors for the arrays that other threads modify with atomics.  In the LDS case the scope is
+// irrelevant; in the global-scratch case agent scope keeps the loads out of the (non-coherent for
+// atomics) vector L1.
+__device__ __forceinline__ int ld(const int *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ long long ld(const long long *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st(int *p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st(long long *p, long long v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+__device__ __forceinline__ long long block_sum_i64(long long v, long long *scratch)
+{
+    v = wave_sum_i64(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) scratch[threadIdx.x >> 6] = v;
+    __syncthreads();
+    long long t = 0;
+    for (int i = 0; i < GC_THREADS / 64; ++i) t += scratch[i];
+    return t;
+}
+
+__device__ long long gc_energy(const GcDevice &g, const int32_t *lab, long long *scratch)
+{
+    long long e = 0;
+    for (int i = threadIdx.x; i < g.K; i += GC_THREADS) e += g.unary[(size_t)i * g.C + lab[i]];
+    for (int j = threadIdx.x; j < g.E; j += GC_THREADS) {
+        int a = g.edges[2 * j], b = g.edges[2 * j + 1];
+        e += (long long)g.w[j] * g.smooth[lab[a] * g.C + lab[b]];
+    }
+    return block_sum_i64(e, scratch);
+}
+
+// reverse BFS from the sink over residual arcs: height = exact distance to the sink, HMAX if none
+__device__ void gc_global_relabel(const GcDevice &g, int *cap, int *height, long long *excess, int alpha, int *flag)
+{
+    const int HMAX = g.K + 2;
+    for (int u = threadIdx.x; u < g.K; u += GC_THREADS)
+        st(&height[u], (g.labels[u] != alpha && ld(&excess[u]) < 0) ? 1 : HMAX);
+    __syncthreads();
+    for (int level = 1; level < HMAX; ++level) {
+        if (threadIdx.x == 0) *flag = 0;
+        __syncthreads();
+        int changed = 0;
+        for (int u = threadIdx.x; u < g.K; u += GC_THREADS) {
+            if (ld(&height[u]) != HMAX || g.labels[u] == alpha) continue;
+            for (int a = g.arc_start[u]; a < g.arc_start[u + 1]; ++a) {
+                if (ld(&cap[a]) > 0 && ld(&height[g.arc_to[a]]) == level) {
+                    st(&height[u], level + 1);
+                    changed = 1;
+                    break;
+                }
+            }
+        }
+        if (changed) *flag = 1;
+        __syncthreads();
+        int any = *flag;
+        __syncthreads();
+        if (!any) break;
+    }
+}
+
+// one expansion move; returns (uniformly) whether the energy strictly decreased
+__device__ bool gc_expand(const GcDevice &g, int alpha, int *cap, int *height, long long *excess, long long *energy,
+                          int *flag, long long *scratch)
+{
+    const int HMAX = g.K + 2;
+    // any active site at all?
+    if (threadIdx.x == 0) *flag = 0;
+    __syncthreads();
+    int mine = 0;
+    for (int u = threadIdx.x; u < g.K; u += GC_THREADS) {
+        int l = g.labels[u];
+        st(&excess[u], (l != alpha) ? (long long)g.unary[(size_t)u * g.C + l] - (long long)g.unary[(size_t)u * g.C + alpha] : 0LL);
+        mine |= (l != alpha);
+    }
+    if (mine) *flag = 1;
+    __syncthreads();
+    if (!*flag) return false;
+    __syncthreads();
+    // pairwise terms (energy.h add_term2 / add_term1)
+    for (int j = threadIdx.x; j < g.E; j += GC_THREADS) {
+        int p = g.edges[2 * j], q = g.edges[2 * j + 1];
+        long long w = g.w[j];
+        int lp = g.labels[p], lq = g.labels[q];
+        int apq = g.edge_arc[2 * j], aqp = g.edge_arc[2 * j + 1];
+        int cpq = 0, cqp = 0;
+        bool ap = lp != alpha, aq = lq != alpha;
+        const int32_t *V = g.smooth;
+        if (ap && aq) {
+            long long A = w * V[alpha * g.C + alpha], B = w * V[alpha * g.C + lq];
+            long long Cc = w * V[lp * g.C + alpha], D = w * V[lp * g.C + lq];
+            long long trp = D - A, trq = 0;
+            B -= A;
+            Cc -= D;
+            if (B < 0) {
+                trp -= B;
+                trq += B;
+                cqp = (int)(B + Cc);
+            } else if (Cc < 0) {
+                trp += Cc;
+                trq -= Cc;
+                cpq = (int)(B + Cc);
+            } else {
+                cpq = (int)B;
+                cqp = (int)Cc;
+            }
+            if (trp) atomic_add_i64(&excess[p], trp);
+            if (trq) atomic_add_i64(&excess[q], trq);
+        } else if (ap) {
+            long long d = w * V[lp * g.C + lq] - w * V[alpha * g.C + lq];
+            if (d) atomic_add_i64(&excess[p], d);
+        } else if (aq) {
+            long long d = w * V[lp * g.C + lq] - w * V[lp * g.C + alpha];
+            if (d) atomic_add_i64(&excess[q], d);
+        }
+        st(&cap[apq], cpq);
+        st(&cap[aqp], cqp);
+    }
+    __syncthreads();
+
+    // maximum preflow
+    for (int outer = 0;; ++outer) {
+        if (outer > (1 << 20)) {
+            if (threadIdx.x == 0) *g.status = 1;
+            break;
+        }
+        gc_global_relabel(g, cap, height, excess, alpha, flag);
+        if (threadIdx.x == 0) *flag = 0;
+        __syncthreads();
+        int active = 0;
+        for (int u = threadIdx.x; u < g.K; u += GC_THREADS)
+            if (ld(&excess[u]) > 0 && ld(&height[u]) < HMAX) active = 1;
+        if (active) *flag = 1;
+        __syncthreads();
+        int any = *flag;
+        __syncthreads();
+        if (!any) break;
+        for (int round = 0; round < GC_PUSH_ROUNDS; ++round) {
+            for (int u = threadIdx.x; u < g.K; u += GC_THREADS) {
+                long long e = ld(&excess[u]);
+                int hu = ld(&height[u]);
+                if (e <= 0 || hu >= HMAX) continue;
+                int best_h = 0x7fffffff, best_a = -1;
+                for (int a = g.arc_start[u]; a < g.arc_start[u + 1]; ++a) {
+                    if (ld(&cap[a]) > 0) {
+                        int h = ld(&height[g.arc_to[a]]);
+                        if (h < best_h) {
+                            best_h = h;
+                            best_a = a;
+                        }
+                    }
+                }
+                if (best_a < 0) {
+                    st(&height[u], HMAX);
+                } else if (hu > best_h) {
+                    int c = ld(&cap[best_a]);
+                    int d = (e < (long long)c) ? (int)e : c;
+                    int v = g.arc_to[best_a];
+                    atomicSub(&cap[best_a], d);
+                    atomicAdd(&cap[g.arc_rev[best_a]], d);
+                    atomic_add_i64(&excess[u], -(long long)d);
+                    atomic_add_i64(&excess[v], (long long)d);
+                } else {
+                    st(&height[u], best_h + 1 < HMAX ? best_h + 1 : HMAX);
+                }
+            }
+            __syncthreads();
+        }
+    }
+    // (the loop above always ends on a fresh global relabel: height < HMAX <=> can reach the sink)
+    for (int u = threadIdx.x; u < g.K; u += GC_THREADS) {
+        int l = g.labels[u];
+        g.prop[u] = (l != alpha && ld(&height[u]) >= HMAX) ? alpha : l;
+    }
+    __syncthreads();
+    long long after = gc_energy(g, g.prop, scratch);
+    bool accept = after < *energy;
+    __syncthreads();
+    if (accept) {
+        for (int u = threadIdx.x; u < g.K; u += GC_THREADS) g.labels[u] = g.prop[u];
+        if (threadIdx.x == 0) *energy = after;
+    }
+    __syncthreads();
+    return accept;
+}
+
+__global__ void __launch_bounds__(GC_THREADS) k_alpha_expansion(GcDevice g)
+{
+    extern __shared__ __align__(16) unsigned char dyn[];
+    __shared__ long long scratch[GC_THREADS / 64];
+    __shared__ long long energy;
+    __shared__ int flag;
+    __shared__ int table[GC_MAX_LABELS];
+    __shared__ int queue_sizes[GC_MAX_LABELS + 2];
+
+    long long *excess;
+    int *cap, *height;
+    if (g.use_lds) {
+        excess = reinterpret_cast<long long *>(dyn);
+        cap = reinterpret_cast<int *>(dyn + (size_t)g.K * 8);
+        height = cap + 2 * (size_t)g.E;
+    } else {
+        excess = g.g_excess;
+        cap = g.g_cap;
+        height = g.g_height;
+    }
+    for (int u = threadIdx.x; u < g.K; u += GC_THREADS) g.labels[u] = 0;
+    if (threadIdx.x < g.C) table[threadIdx.x] = threadIdx.x;
+    __syncthreads();
+    long long e0 = gc_energy(g, g.labels, scratch);
+    if (threadIdx.x == 0) energy = e0;
+    __syncthreads();
+
+    if (g.n_iter == -1) {
+        // GCoptimization::expansion(-1): adaptive cycles (see oracle orc_alpha_expansion_int)
+        int nq = 1, next = 0;
+        if (threadIdx.x == 0) queue_sizes[0] = g.C;
+        __syncthreads();
+        do {
+            int queue_size = queue_sizes[nq - 1];
+            int start = next;
+            do {
+                int alpha = table[next];
+                bool ok = gc_expand(g, alpha, cap, height, excess, &energy, &flag, scratch);
+                if (!ok) {
+                    --queue_size;
+                    __syncthreads();
+                    if (threadIdx.x == 0) {
+                        int t = table[next];
+                        table[next] = table[queue_size];
+                        table[queue_size] = t;
+                    }
+                    __syncthreads();
+                } else {
+                    ++next;
+                }
+            } while (next < queue_size);
+            int back = queue_sizes[nq - 1];
+            __syncthreads();
+            if (next == start) {
+                next = back;
+                nq--;
+            } else if (queue_size < back / 2) {
+                next = 0;
+                if (threadIdx.x == 0) queue_sizes[nq] = queue_size;
+                nq++;
+            } else {
+                next = 0;
+            }
+            __syncthreads();
+        } while (nq > 0);
+    } else {
+        for (int cycle = 0; cycle < g.n_iter; ++cycle) {
+            long long before = energy;
+            __syncthreads();
+            for (int l = 0; l < g.C; ++l) gc_expand(g, table[l], cap, height, excess, &energy, &flag, scratch);
+            if (!(energy < before)) break;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) *g.energy_out = energy;
+}
+
+// data costs only (GCO solveSpecialCases): independent argmin, first minimum wins
+__global__ void k_unary_argmin(const int32_t *unary, int K, int C, int32_t *labels, long long *energy_out)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= K) return;
+    int best = 0;
+    for (int l = 1; l < C; ++l)
+        if (unary[(size_t)i * C + l] < unary[(size_t)i * C + best]) best = l;
+    labels[i] = best;
+    atomic_add_i64(energy_out, unary[(size_t)i * C + best]);
+}
+
+size_t alpha_expansion_work_bytes(int K, int E)
+{
+    // prop[K] | g_cap[2E] | g_height[K] | g_excess[K] (8-byte aligned first)
+    return (size_t)K * 8 + ((size_t)K * 2 + (size_t)E * 2) * 4 + 64;
+}
+
+int launch_alpha_expansion(GcProblem p, const int32_t *arc_start, const int32_t *arc_to, const int32_t *arc_rev,
+                           const int32_t *edge_arc, int n_iter, int32_t *labels_dev, long long *energy_dev,
+                           int32_t *status_dev, void *work, hipStream_t st)
+{
+    if (p.C > GC_MAX_LABELS) {
+        set_error("alpha_expansion: more than 64 labels are not supported by the single-workgroup kernel");
+        return -1;
+    }
+    if (p.E == 0) {
+        HIP_TRY(hipMemsetAsync(energy_dev, 0, sizeof(long long), st));
+        hipLaunchKernelGGL(k_unary_argmin, cdiv(p.K, 256), 256, 0, st, p.unary, p.K, p.C, labels_dev, energy_dev);
+        HIP_TRY(hipGetLastError());
+        return 0;
+    }
+    GcDevice g;
+    g.K = p.K; g.C = p.C; g.E = p.E; g.n_iter = n_iter;
+    g.edges = p.edges; g.w = p.w; g.unary = p.unary; g.smooth = p.smooth;
+    g.arc_start = arc_start; g.arc_to = arc_to; g.arc_rev = arc_rev; g.edge_arc = edge_arc;
+    g.labels = labels_dev;
+    g.energy_out = energy_dev;
+    g.status = status_dev;
+    unsigned char *wb = (unsigned char *)work;
+    g.g_excess = (long long *)wb;
+    g.prop = (int32_t *)(wb + (size_t)p.K * 8);
+    g.g_height = g.prop + p.K;
+    g.g_cap = g.g_height + p.K;
+    size_t lds_need = (size_t)p.K * 8 + ((size_t)2 * p.E + p.K) * 4;
+    g.use_lds = lds_need <= 150 * 1024;
+    size_t dyn = g.use_lds ? lds_need : 0;
+    if (dyn > 48 * 1024) {
+        static bool attr_set = false;
+        if (!attr_set) {
+            HIP_TRY(hipFuncSetAttribute((const void *)k_alpha_expansion, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        150 * 1024));
+            attr_set = true;
+        }
+    }
+    hipLaunchKernelGGL(k_alpha_expansion, 1, GC_THREADS, dyn, st, g);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+}  // namespace imsegm

@@ -1,0 +1,84 @@
+// slic.h -- internal (C++) interface between the C-ABI layer (api.hip) and the kernel files.
+#pragma once
+#include "common.h"
+#include <algorithm>
+#include <cfloat>
+#include <cmath>
+
+namespace imsegm {
+
+enum { DT_U8 = 0, DT_F64 = 1, DT_F32 = 2 };
+
+// half of a symmetric correlation kernel, w[0] = centre tap; r < 0: axis not filtered
+struct Taps {
+    int r;
+    double w[17];
+};
+
+// device-side SLIC state for one 2-D image (all pointers are device pointers)
+struct SlicState {
+    int H, W, K;
+    int step_y, step_x;
+    double spatial_weight;          // 1 / step^2  (_slic.pyx "invxywt")
+    double *cy, *cx, *cL, *ca, *cb; // centroid table, SoA fp64 [K]
+    int4 *win;                      // integer search window {ymin, ymax, xmin, xmax} [K]
+    long long *acc;                 // [K][9] = n, sum y, sum x, (hi, lo) fixed-point sums of L, a, b
+};
+
+int launch_minmax(const void *src, int dtype, size_t n, unsigned long long *keys, double *out2, hipStream_t st);
+int launch_preprocess_color2d(const void *img, int dtype, int H, int W, int normalize, const double *minmax_dev,
+                              const Taps &tz, const Taps &ty, const Taps &tx, double ratio, double *bufA,
+                              double *bufB, hipStream_t st);
+// optional HIP-event hooks around the dominant kernel (api.hip profiler)
+struct ProfHook {
+    void *user = nullptr;
+    int (*begin)(void *, int) = nullptr;
+    void (*end)(void *, int) = nullptr;
+};
+int launch_slic_iterations(SlicState s, const double *lab, const double *init_yx_dev, int32_t *labels, int max_iter,
+                           int max_cand, const ProfHook &prof, hipStream_t st);
+
+// connectivity.hip ------------------------------------------------------------------------------
+struct ConnWork {
+    int32_t *parent;      // [N] union-find forest / component id (root = min raster index)
+    int32_t *csize;       // [N] component size, valid at roots
+    int32_t *newlabel;    // [N] final label per root
+    int32_t *adjptr;      // [N] small component -> root of the component it merges into (-1: none)
+    int32_t *queue;       // [N] BFS queues
+    uint8_t *visited;     // [N]
+    int32_t *blocksum;    // [nblocks + 1]
+    int32_t *list;        // [N] compacted list of component roots
+    int32_t *counters;    // [16] misc device counters
+};
+int launch_enforce_connectivity(const int32_t *labels_in, int H, int W, long min_size, long max_size,
+                                int start_label, ConnWork w, int32_t *labels_out, int *n_labels_out_host,
+                                hipStream_t st);
+
+// stats.hip ---------------------------------------------------------------------------------------
+// per-superpixel colour statistics (features_cython.pyx:59-141): sums of v, v*v (float32 product)
+// and (v - mean32)^2 (float32), exact fixed-point accumulation. acc: [K][13] int64 scratch.
+int launch_color_stats(const void *img, int dtype, const int32_t *labels, int H, int W, int K, double maxabs,
+                       int want_var, long long *acc, double *mean_out, double *energy_out, double *var_out,
+                       float *mean32_scratch, hipStream_t st);
+
+// graph.hip ---------------------------------------------------------------------------------------
+int launch_adjacency_centres(const int32_t *labels, int H, int W, int K, uint32_t *bitmap, long long *cacc,
+                             int32_t *edges_out, int edge_capacity, int32_t *n_edges_dev, double *centres_out,
+                             uint8_t *present_out, int32_t *rowcount, hipStream_t st);
+int launch_gather_labels(const int32_t *lut, const int32_t *idx, size_t n, int32_t *out, hipStream_t st);
+int launch_gather_proba(const double *lut, int C, const int32_t *idx, size_t n, double *out, hipStream_t st);
+
+// graphcut.hip ------------------------------------------------------------------------------------
+struct GcProblem {
+    int K, C, E;
+    const int32_t *edges;   // [E][2], a < b
+    const int32_t *w;       // [E]
+    const int32_t *unary;   // [K][C]
+    const int32_t *smooth;  // [C][C]
+};
+int launch_alpha_expansion(GcProblem p, const int32_t *arc_start, const int32_t *arc_to, const int32_t *arc_rev,
+                           const int32_t *edge_arc, int n_iter, int32_t *labels_dev, long long *energy_dev,
+                           int32_t *status_dev, void *work, hipStream_t st);
+size_t alpha_expansion_work_bytes(int K, int E);
+
+}  // namespace imsegm

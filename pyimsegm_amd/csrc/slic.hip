@@ -1,0 +1,554 @@
+// slic.hip -- SLIC superpixel kernels for gfx950 (wave64, LDS-staged centroid tiles).
+//
+// Replaces the native boundary `skimage.segmentation.slic` called at
+// /root/reference/imsegm/superpixels.py:61-63 (2D colour).  Arithmetic contract: bit-identical
+// to oracle/imsegm_oracle.c (orc_slic_preprocess_color2d, orc_slic_iterate).
+//
+// Data layout in HBM: Lab image as three fp64 planes [3][H][W] (one 8-byte element per lane ->
+// fully coalesced 512-byte wave loads); labels int32 [H][W]; centroid table SoA (cy, cx, cL, ca,
+// cb as fp64[K], integer search windows int4[K]); accumulators int64 [K][9].
+#include "slic.h"
+
+namespace imsegm {
+
+// ---------------------------------------------------------------------------------------------
+// min / max of the input (superpixels.py:53-54), order-preserving uint64 keys + atomics
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned long long f64_key(double x)
+{
+    long long b = __double_as_longlong(x);
+    return b < 0 ? ~(unsigned long long)b : ((unsigned long long)b | 0x8000000000000000ULL);
+}
+__host__ __device__ __forceinline__ double key_f64(unsigned long long k)
+{
+    unsigned long long b = (k & 0x8000000000000000ULL) ? (k & 0x7fffffffffffffffULL) : ~k;
+    union { unsigned long long u; double d; } cv;
+    cv.u = b;
+    return cv.d;
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) k_minmax(const T *__restrict__ src, size_t n, unsigned long long *keys)
+{
+    double mn = INFINITY, mx = -INFINITY;
+    size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        double v = (double)src[i];
+        mn = fmin(mn, v);
+        mx = fmax(mx, v);
+    }
+    mn = wave_min_f64(mn);
+    mx = wave_max_f64(mx);
+    if ((threadIdx.x & 63) == 0) {
+        atomicMin(&keys[0], f64_key(mn));
+        atomicMax(&keys[1], f64_key(mx));
+    }
+}
+
+// uint8 variant: 16 bytes per lane
+__global__ void __launch_bounds__(256) k_minmax_u8(const uint8_t *__restrict__ src, size_t n, unsigned long long *keys)
+{
+    unsigned mn = 255, mx = 0;
+    size_t nvec = n / 16;
+    const uint4 *v4 = reinterpret_cast<const uint4 *>(src);
+    size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += stride) {
+        uint4 q = v4[i];
+        unsigned w[4] = { q.x, q.y, q.z, q.w };
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                unsigned v = (w[j] >> (8 * b)) & 0xff;
+                mn = min(mn, v);
+                mx = max(mx, v);
+            }
+    }
+    if (blockIdx.x == 0)
+        for (size_t i = nvec * 16 + threadIdx.x; i < n; i += blockDim.x) {
+            unsigned v = src[i];
+            mn = min(mn, v);
+            mx = max(mx, v);
+        }
+    double dmn = wave_min_f64((double)mn), dmx = wave_max_f64((double)mx);
+    if ((threadIdx.x & 63) == 0) {
+        atomicMin(&keys[0], f64_key(dmn));
+        atomicMax(&keys[1], f64_key(dmx));
+    }
+}
+
+__global__ void k_minmax_init(unsigned long long *keys)
+{
+    keys[0] = ~0ULL;
+    keys[1] = 0ULL;
+}
+__global__ void k_minmax_decode(const unsigned long long *keys, double *out)
+{
+    out[0] = key_f64(keys[0]);
+    out[1] = key_f64(keys[1]);
+}
+
+int launch_minmax(const void *src, int dtype, size_t n, unsigned long long *keys, double *out2, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_minmax_init, 1, 1, 0, st, keys);
+    int grid = (int)std::min<size_t>(2048, (n + 256 * 16 - 1) / (256 * 16));
+    if (grid < 1) grid = 1;
+    if (dtype == DT_U8)
+        hipLaunchKernelGGL(k_minmax_u8, grid, 256, 0, st, (const uint8_t *)src, n, keys);
+    else if (dtype == DT_F32)
+        hipLaunchKernelGGL(k_minmax<float>, grid, 256, 0, st, (const float *)src, n, keys);
+    else
+        hipLaunchKernelGGL(k_minmax<double>, grid, 256, 0, st, (const double *)src, n, keys);
+    hipLaunchKernelGGL(k_minmax_decode, 1, 1, 0, st, keys, out2);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// pre-processing pass 1: normalise -> rgb2lab -> z-axis blur tap (depth 1) -> planar fp64
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ double zblur_point(double v, const Taps &tz)
+{
+    // scipy correlate1d on a length-1 axis with 'reflect': every neighbour equals v
+    if (tz.r < 0) return v;
+    double tmp = v * tz.w[0];
+    for (int j = tz.r; j >= 1; --j) tmp += (v + v) * tz.w[j];
+    return tmp;
+}
+
+// uint8 input: the sRGB linearisation collapses to a 256-entry table (built per block in LDS with
+// the same det_pow24 as the per-pixel path).  minmax = {vmin, vmax} on device.
+__global__ void __launch_bounds__(256)
+k_pre_lab_u8(const uint8_t *__restrict__ img, int n, int normalize, const double *__restrict__ minmax,
+             Taps tz, double *__restrict__ out)
+{
+    __shared__ double lut[256];
+    {
+        int v = threadIdx.x;
+        double x;
+        const bool norm = normalize == 1 || (normalize == 2 && (minmax[0] != 0.0 || minmax[1] != 1.0));
+        if (norm) {
+            double vmin = minmax[0], range = minmax[1] - minmax[0];
+            x = (double)(uint8_t)(v - (int)vmin) / range;
+        } else {
+            x = (double)v * (1.0 / 255);
+        }
+        lut[v] = (x > 0.04045) ? det_pow24((x + 0.055) / 1.055) : x / 12.92;
+    }
+    __syncthreads();
+    int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    double lin0 = lut[img[3 * (size_t)p + 0]], lin1 = lut[img[3 * (size_t)p + 1]], lin2 = lut[img[3 * (size_t)p + 2]];
+    double X = lin0 * 0.412453 + lin1 * 0.357580 + lin2 * 0.180423;
+    double Y = lin0 * 0.212671 + lin1 * 0.715160 + lin2 * 0.072169;
+    double Z = lin0 * 0.019334 + lin1 * 0.119193 + lin2 * 0.950227;
+    double f[3] = { X / 0.95047, Y / 1.0, Z / 1.08883 };
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        double t = f[c];
+        f[c] = (t > 0.008856) ? det_cbrt(t) : 7.787 * t + 16.0 / 116.0;
+    }
+    double L = (116.0 * f[1]) - 16.0;
+    double A = 500.0 * (f[0] - f[1]);
+    double B = 200.0 * (f[1] - f[2]);
+    out[p] = zblur_point(L, tz);
+    out[(size_t)n + p] = zblur_point(A, tz);
+    out[2 * (size_t)n + p] = zblur_point(B, tz);
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256)
+k_pre_lab_f(const T *__restrict__ img, int n, int normalize, const double *__restrict__ minmax, Taps tz,
+            double *__restrict__ out)
+{
+    int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    double rgb[3];
+    const bool norm = normalize == 1 || (normalize == 2 && (minmax[0] != 0.0 || minmax[1] != 1.0));
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        double v = (double)img[3 * (size_t)p + c];
+        if (norm) v = (v - minmax[0]) / (minmax[1] - minmax[0]);
+        rgb[c] = v;
+    }
+    double L, A, B;
+    rgb2lab_px(rgb[0], rgb[1], rgb[2], L, A, B);
+    out[p] = zblur_point(L, tz);
+    out[(size_t)n + p] = zblur_point(A, tz);
+    out[2 * (size_t)n + p] = zblur_point(B, tz);
+}
+
+__device__ __forceinline__ int reflect_idx(int i, int n)
+{
+    if (n == 1) return 0;
+    int p = 2 * n;
+    i %= p;
+    if (i < 0) i += p;
+    if (i >= n) i = p - 1 - i;
+    return i;
+}
+
+// pass 2 / 3: one scipy correlate1d pass along y (axis = 0) or x (axis = 1) of each [H][W] plane;
+// the x pass also applies the final `image * (1 / compactness)`.
+template <int AXIS>
+__global__ void __launch_bounds__(256)
+k_blur_axis(const double *__restrict__ src, double *__restrict__ dst, int H, int W, Taps t, double ratio, int scale)
+{
+    int x = blockIdx.x * 64 + (threadIdx.x & 63);
+    int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    int plane = blockIdx.z;
+    if (x >= W || y >= H) return;
+    const double *s = src + (size_t)plane * H * W;
+    double v;
+    if (t.r < 0) {
+        v = s[(size_t)y * W + x];
+    } else {
+        v = s[(size_t)y * W + x] * t.w[0];
+        for (int j = t.r; j >= 1; --j) {
+            double a, b;
+            if (AXIS == 0) {
+                a = s[(size_t)reflect_idx(y - j, H) * W + x];
+                b = s[(size_t)reflect_idx(y + j, H) * W + x];
+            } else {
+                a = s[(size_t)y * W + reflect_idx(x - j, W)];
+                b = s[(size_t)y * W + reflect_idx(x + j, W)];
+            }
+            v += (a + b) * t.w[j];
+        }
+    }
+    if (scale) v = v * ratio;
+    dst[(size_t)plane * H * W + (size_t)y * W + x] = v;
+}
+
+int launch_preprocess_color2d(const void *img, int dtype, int H, int W, int normalize, const double *minmax_dev,
+                              const Taps &tz, const Taps &ty, const Taps &tx, double ratio, double *bufA,
+                              double *bufB, hipStream_t st)
+{
+    int n = H * W;
+    int grid = cdiv(n, 256);
+    if (dtype == DT_U8)
+        hipLaunchKernelGGL(k_pre_lab_u8, grid, 256, 0, st, (const uint8_t *)img, n, normalize, minmax_dev, tz, bufA);
+    else if (dtype == DT_F32)
+        hipLaunchKernelGGL(k_pre_lab_f<float>, grid, 256, 0, st, (const float *)img, n, normalize, minmax_dev, tz, bufA);
+    else
+        hipLaunchKernelGGL(k_pre_lab_f<double>, grid, 256, 0, st, (const double *)img, n, normalize, minmax_dev, tz, bufA);
+    dim3 g(cdiv(W, 64), cdiv(H, 4), 3);
+    hipLaunchKernelGGL(k_blur_axis<0>, g, 256, 0, st, bufA, bufB, H, W, ty, ratio, 0);
+    hipLaunchKernelGGL(k_blur_axis<1>, g, 256, 0, st, bufB, bufA, H, W, tx, ratio, 1);
+    HIP_TRY(hipGetLastError());
+    return 0;   // result in bufA
+}
+
+// ---------------------------------------------------------------------------------------------
+// centroid table
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ int4 search_window(double cy, double cx, int step_y, int step_x, int H, int W)
+{
+    // _slic.pyx: y_min = <Py_ssize_t>max(cy - 2 * step_y, 0); y_max = <Py_ssize_t>min(cy + 2 * step_y + 1, height)
+    double a;
+    int4 w;
+    a = cy - (double)(2 * step_y);
+    w.x = (int)(a > 0 ? a : 0.0);
+    a = cy + (double)(2 * step_y);
+    a = a + 1.0;
+    w.y = (int)(a < (double)H ? a : (double)H);
+    a = cx - (double)(2 * step_x);
+    w.z = (int)(a > 0 ? a : 0.0);
+    a = cx + (double)(2 * step_x);
+    a = a + 1.0;
+    w.w = (int)(a < (double)W ? a : (double)W);
+    return w;
+}
+
+__global__ void k_centroid_init(SlicState s, const double *__restrict__ init_yx)
+{
+    int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= s.K) return;
+    double cy = init_yx[2 * k], cx = init_yx[2 * k + 1];
+    s.cy[k] = cy;
+    s.cx[k] = cx;
+    s.cL[k] = 0.0;
+    s.ca[k] = 0.0;
+    s.cb[k] = 0.0;
+    s.win[k] = search_window(cy, cx, s.step_y, s.step_x, s.H, s.W);
+    for (int j = 0; j < 9; ++j) s.acc[(size_t)k * 9 + j] = 0;
+}
+
+// divide the accumulated sums, recompute the integer search windows, clear the accumulators.
+// A centroid that received no pixel is dead from now on (NaN position in skimage): empty window.
+__global__ void k_centroid_finalize(SlicState s)
+{
+    int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= s.K) return;
+    long long *a = s.acc + (size_t)k * 9;
+    long long n = a[0];
+    if (n == 0) {   // no pixel carries label k any more: it can never be assigned again
+        s.win[k] = make_int4(0, 0, 0, 0);
+    } else {
+        double nn = (double)n;
+        double cy = i64_to_double(a[1]) / nn;
+        double cx = i64_to_double(a[2]) / nn;
+        s.cy[k] = cy;
+        s.cx[k] = cx;
+        s.cL[k] = fix_join(a[3], a[4]) / nn;
+        s.ca[k] = fix_join(a[5], a[6]) / nn;
+        s.cb[k] = fix_join(a[7], a[8]) / nn;
+        s.win[k] = search_window(cy, cx, s.step_y, s.step_x, s.H, s.W);
+    }
+#pragma unroll
+    for (int j = 0; j < 9; ++j) a[j] = 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// assignment + fused accumulation
+// ---------------------------------------------------------------------------------------------
+constexpr int TILE_X = 64;     // one pixel column per lane
+constexpr int ROWS = 8;        // rows per lane
+constexpr int WAVES = 4;       // waves per workgroup
+constexpr int TILE_Y = ROWS * WAVES;
+constexpr int MAXC = 192;      // LDS-resident candidate centroids per tile
+
+struct Cand {
+    double cy, cx, cL, ca, cb;
+    int4 win;
+    int k;
+    int pad;
+};
+
+// direct (slow, always correct) accumulation of one pixel into the global accumulators
+__device__ __forceinline__ void accumulate_global(long long *acc, int k, int y, int x, double L, double A, double B)
+{
+    long long *a = acc + (size_t)k * 9;
+    long long hi, lo;
+    atomic_add_i64(a + 0, 1);
+    atomic_add_i64(a + 1, y);
+    atomic_add_i64(a + 2, x);
+    fix_split(L, hi, lo);
+    atomic_add_i64(a + 3, hi);
+    atomic_add_i64(a + 4, lo);
+    fix_split(A, hi, lo);
+    atomic_add_i64(a + 5, hi);
+    atomic_add_i64(a + 6, lo);
+    fix_split(B, hi, lo);
+    atomic_add_i64(a + 7, hi);
+    atomic_add_i64(a + 8, lo);
+}
+
+// ACCUM: also accumulate the centroid sums (all iterations but the last)
+template <bool ACCUM>
+__global__ void __launch_bounds__(256)
+k_slic_assign(SlicState s, const double *__restrict__ lab, int32_t *__restrict__ labels, int max_cand)
+{
+    __shared__ Cand cand[MAXC];
+    __shared__ long long lacc[MAXC][9];
+    __shared__ int n_cand;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int tx0 = blockIdx.x * TILE_X, ty0 = blockIdx.y * TILE_Y;
+    const int tx1 = min(tx0 + TILE_X, s.W), ty1 = min(ty0 + TILE_Y, s.H);
+    const size_t plane = (size_t)s.H * s.W;
+
+    if (tid == 0) n_cand = 0;
+    __syncthreads();
+    for (int k = tid; k < s.K; k += 256) {
+        int4 w = s.win[k];
+        if (w.x < ty1 && w.y > ty0 && w.z < tx1 && w.w > tx0) {
+            int slot = atomicAdd(&n_cand, 1);
+            if (slot < max_cand) cand[slot].k = k;
+        }
+    }
+    __syncthreads();
+    const int total = n_cand;
+    const bool overflow = total > max_cand;      // block-uniform
+    const int nc = overflow ? 0 : total;
+    for (int c = tid; c < nc; c += 256) {
+        int k = cand[c].k;
+        cand[c].cy = s.cy[k];
+        cand[c].cx = s.cx[k];
+        cand[c].cL = s.cL[k];
+        cand[c].ca = s.ca[k];
+        cand[c].cb = s.cb[k];
+        cand[c].win = s.win[k];
+        if (ACCUM) {
+#pragma unroll
+            for (int j = 0; j < 9; ++j) lacc[c][j] = 0;
+        }
+    }
+    __syncthreads();
+
+    const int x = tx0 + lane;
+    const int wy0 = ty0 + wave * ROWS;
+    const bool xin = x < s.W;
+    const double fx = (double)x;
+    const double sw = s.spatial_weight;
+
+    double pL[ROWS], pA[ROWS], pB[ROWS], best_d[ROWS];
+    int best_s[ROWS], best_k[ROWS];
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r) {
+        int y = wy0 + r;
+        bool ok = xin && y < s.H;
+        size_t p = (size_t)(ok ? y : 0) * s.W + (ok ? x : 0);
+        pL[r] = lab[p];
+        pA[r] = lab[plane + p];
+        pB[r] = lab[2 * plane + p];
+        best_d[r] = DBL_MAX;
+        best_s[r] = -1;
+        best_k[r] = 0x7fffffff;
+    }
+
+    if (!overflow) {
+        for (int c = 0; c < nc; ++c) {
+            const int4 w = cand[c].win;
+            if (w.x >= wy0 + ROWS || w.y <= wy0) continue;   // wave-uniform: no row of this wave in the window
+            const int k = cand[c].k;
+            const double cy = cand[c].cy, cx = cand[c].cx, cL = cand[c].cL, ca = cand[c].ca, cb = cand[c].cb;
+            const bool inx = (x >= w.z) && (x < w.w);
+            const double tx = cx - fx;
+            const double dx2 = tx * tx;
+#pragma unroll
+            for (int r = 0; r < ROWS; ++r) {
+                const int y = wy0 + r;
+                if (y < w.x || y >= w.y) continue;            // wave-uniform
+                const double ty = cy - (double)y;
+                const double dy2 = ty * ty;
+                double d = (dy2 + dx2) * sw;
+                double t0 = pL[r] - cL, t1 = pA[r] - ca, t2 = pB[r] - cb;
+                double col = t0 * t0;
+                col = col + t1 * t1;
+                col = col + t2 * t2;
+                d = d + col;
+                bool better = inx && ((best_d[r] > d) || (best_d[r] == d && k < best_k[r]));
+                if (better) {
+                    best_d[r] = d;
+                    best_s[r] = c;
+                    best_k[r] = k;
+                }
+            }
+        }
+    } else {
+        // more candidate centroids than LDS slots (pathological clustering, or forced by tests):
+        // scan the whole table from global memory
+        for (int k = 0; k < s.K; ++k) {
+            const int4 w = s.win[k];
+            if (!(w.x < wy0 + ROWS && w.y > wy0 && w.z < tx1 && w.w > tx0)) continue;
+            const double cy = s.cy[k], cx = s.cx[k], cL = s.cL[k], ca = s.ca[k], cb = s.cb[k];
+            const bool inx = (x >= w.z) && (x < w.w);
+            const double tx = cx - fx;
+            const double dx2 = tx * tx;
+#pragma unroll
+            for (int r = 0; r < ROWS; ++r) {
+                const int y = wy0 + r;
+                if (y < w.x || y >= w.y) continue;
+                const double ty = cy - (double)y;
+                const double dy2 = ty * ty;
+                double d = (dy2 + dx2) * sw;
+                double t0 = pL[r] - cL, t1 = pA[r] - ca, t2 = pB[r] - cb;
+                double col = t0 * t0;
+                col = col + t1 * t1;
+                col = col + t2 * t2;
+                d = d + col;
+                bool better = inx && (best_d[r] > d);     // ascending k: strict '>' keeps the lowest k
+                if (better) {
+                    best_d[r] = d;
+                    best_s[r] = -2;                       // "assigned, but no LDS slot"
+                    best_k[r] = k;
+                }
+            }
+        }
+    }
+
+    // labels: a pixel no window covers keeps its previous assignment (nearest_segments persists in _slic.pyx)
+    unsigned pending = 0;
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r) {
+        int y = wy0 + r;
+        if (!(xin && y < s.H)) continue;
+        size_t p = (size_t)y * s.W + x;
+        if (best_s[r] == -1) {
+            int prev = labels[p];
+            best_k[r] = prev;
+            if (ACCUM && prev >= 0) accumulate_global(s.acc, prev, y, x, pL[r], pA[r], pB[r]);
+        } else {
+            labels[p] = best_k[r];
+            if (best_s[r] == -2) {
+                if (ACCUM) accumulate_global(s.acc, best_k[r], y, x, pL[r], pA[r], pB[r]);
+            } else {
+                pending |= 1u << r;
+            }
+        }
+    }
+    if (!ACCUM) return;
+
+    // wave-level segmented reduction: one pass per distinct LDS slot present in this wave
+    while (true) {
+        int first = -1;
+#pragma unroll
+        for (int r = ROWS - 1; r >= 0; --r)
+            if (pending & (1u << r)) first = best_s[r];
+        unsigned long long vote = __ballot(first >= 0);
+        if (vote == 0) break;
+        int leader = __ffsll((long long)vote) - 1;
+        int slot = __shfl(first, leader, 64);
+        int n = 0, sy = 0, sx = 0;
+        long long Lh = 0, Ll = 0, Ah = 0, Al = 0, Bh = 0, Bl = 0;
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r) {
+            if ((pending & (1u << r)) && best_s[r] == slot) {
+                long long hi, lo;
+                n += 1;
+                sy += wy0 + r;
+                sx += x;
+                fix_split(pL[r], hi, lo); Lh += hi; Ll += lo;
+                fix_split(pA[r], hi, lo); Ah += hi; Al += lo;
+                fix_split(pB[r], hi, lo); Bh += hi; Bl += lo;
+                pending &= ~(1u << r);
+            }
+        }
+        n = wave_sum_i32(n);
+        sy = wave_sum_i32(sy);
+        sx = wave_sum_i32(sx);
+        Lh = wave_sum_i64(Lh); Ll = wave_sum_i64(Ll);
+        Ah = wave_sum_i64(Ah); Al = wave_sum_i64(Al);
+        Bh = wave_sum_i64(Bh); Bl = wave_sum_i64(Bl);
+        if (lane == 0) {
+            long long *a = lacc[slot];
+            atomic_add_i64(a + 0, n); atomic_add_i64(a + 1, sy); atomic_add_i64(a + 2, sx);
+            atomic_add_i64(a + 3, Lh); atomic_add_i64(a + 4, Ll);
+            atomic_add_i64(a + 5, Ah); atomic_add_i64(a + 6, Al);
+            atomic_add_i64(a + 7, Bh); atomic_add_i64(a + 8, Bl);
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < nc * 9; i += 256) {
+        int c = i / 9, j = i - 9 * c;
+        if (lacc[c][0] != 0) {
+            long long v = lacc[c][j];
+            if (v != 0) atomic_add_i64(s.acc + (size_t)cand[c].k * 9 + j, v);
+        }
+    }
+}
+
+int launch_slic_iterations(SlicState s, const double *lab, const double *init_yx_dev, int32_t *labels, int max_iter,
+                           int max_cand, const ProfHook &prof, hipStream_t st)
+{
+    if (max_cand <= 0 || max_cand > MAXC) max_cand = MAXC;
+    size_t n = (size_t)s.H * s.W;
+    HIP_TRY(hipMemsetAsync(labels, 0xff, n * sizeof(int32_t), st));       // nearest = -1
+    hipLaunchKernelGGL(k_centroid_init, cdiv(s.K, 256), 256, 0, st, s, init_yx_dev);
+    dim3 grid(cdiv(s.W, TILE_X), cdiv(s.H, TILE_Y));
+    for (int it = 0; it < max_iter; ++it) {
+        int span = prof.begin ? prof.begin(prof.user, 0) : -1;
+        if (it + 1 < max_iter)
+            hipLaunchKernelGGL(k_slic_assign<true>, grid, 256, 0, st, s, lab, labels, max_cand);
+        else
+            hipLaunchKernelGGL(k_slic_assign<false>, grid, 256, 0, st, s, lab, labels, max_cand);
+        if (prof.end) prof.end(prof.user, span);
+        if (it + 1 < max_iter) hipLaunchKernelGGL(k_centroid_finalize, cdiv(s.K, 256), 256, 0, st, s);
+    }
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+}  // namespace imsegm

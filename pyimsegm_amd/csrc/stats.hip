@@ -1,0 +1,232 @@
+// stats.hip -- per-superpixel colour statistics as segmented reductions (wave64 shuffles + LDS).
+//
+// Replaces the native boundary /root/reference/imsegm/features_cython.pyx:59-141
+// (normColorFeatures, computeColorImage2dMean / Energy / Variance) and :144-219 (gray 3D).
+// Semantics mirrored from the Cython code: the image is staged as float32
+// (descriptors.py:233,261,293), `val * val` and `(img - mean)^2` are evaluated in float32 and
+// accumulated in 64-bit; labels without pixels keep 0.
+//
+// The reference adds in raster order into an fp64 scalar.  Here every float32 term is converted to
+// an exact two-limb fixed-point integer and summed with integer adds (associative), so the result
+// does not depend on the reduction tree or on atomic ordering; it equals the exactly rounded sum,
+// which differs from the reference's running fp64 sum by at most a few ulp (bit-identical whenever
+// the terms are integers, e.g. uint8 images: mean and energy).
+#include "slic.h"
+
+namespace imsegm {
+
+constexpr int ST_PX = 4;          // consecutive pixels per lane
+constexpr int ST_ROWS = 16;       // rows per workgroup (4 per wave)
+constexpr int ST_SLOTS = 64;      // LDS hash slots (distinct labels per workgroup tile)
+
+// fixed point with a caller-chosen scale: v * 2^sh = hi + lo * 2^-32
+__device__ __forceinline__ void fix_split_sh(double v, double scale, long long &hi, long long &lo)
+{
+    double t = v * scale;
+    long long h = (long long)t;
+    double r = t - (double)h;
+    hi = h;
+    lo = (long long)(r * 4294967296.0);
+}
+
+template <typename T> __device__ __forceinline__ float load_f32(const T *p, size_t i) { return (float)p[i]; }
+
+struct StatParams {
+    int H, W, K;
+    double scale_v, scale_e;      // 2^shift for the value / squared-value sums
+};
+
+// NV = number of accumulated quantities per channel group: PASS 1 -> n + 3 x (v, v*v); PASS 2 -> 3 x (v - m)^2
+template <typename T, int PASS>
+__global__ void __launch_bounds__(256)
+k_color_stats(const T *__restrict__ img, const int32_t *__restrict__ labels, StatParams sp,
+              const float *__restrict__ mean32, long long *__restrict__ acc)
+{
+    constexpr int NQ = (PASS == 1) ? 13 : 6;
+    __shared__ int keys[ST_SLOTS];
+    __shared__ long long lacc[ST_SLOTS][13];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid < ST_SLOTS) {
+        keys[tid] = -1;
+        for (int j = 0; j < NQ; ++j) lacc[tid][j] = 0;
+    }
+    __syncthreads();
+    const int x0 = (blockIdx.x * 64 + lane) * ST_PX;
+    for (int rr = 0; rr < ST_ROWS / 4; ++rr) {
+        const int y = blockIdx.y * ST_ROWS + wave * (ST_ROWS / 4) + rr;
+        int lab[ST_PX];
+        float v[ST_PX][3];
+#pragma unroll
+        for (int i = 0; i < ST_PX; ++i) {
+            int x = x0 + i;
+            bool ok = (y < sp.H) && (x < sp.W);
+            size_t p = ok ? (size_t)y * sp.W + x : 0;
+            lab[i] = ok ? labels[p] : -1;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) v[i][c] = load_f32(img, 3 * p + c);
+        }
+        // one pass per distinct label in the wave
+        while (true) {
+            int first = -1;
+#pragma unroll
+            for (int i = ST_PX - 1; i >= 0; --i)
+                if (lab[i] >= 0) first = lab[i];
+            unsigned long long vote = __ballot(first >= 0);
+            if (!vote) break;
+            int k = __shfl(first, __ffsll((long long)vote) - 1, 64);
+            int n = 0;
+            long long q[12];
+#pragma unroll
+            for (int j = 0; j < 12; ++j) q[j] = 0;
+#pragma unroll
+            for (int i = 0; i < ST_PX; ++i) {
+                if (lab[i] != k) continue;
+                lab[i] = -1;
+                n += 1;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    long long hi, lo;
+                    if (PASS == 1) {
+                        float val = v[i][c];
+                        float sq = __fmul_rn(val, val);
+                        fix_split_sh((double)val, sp.scale_v, hi, lo);
+                        q[2 * c] += hi; q[2 * c + 1] += lo;
+                        fix_split_sh((double)sq, sp.scale_e, hi, lo);
+                        q[6 + 2 * c] += hi; q[6 + 2 * c + 1] += lo;
+                    } else {
+                        float d = __fsub_rn(v[i][c], mean32[3 * k + c]);
+                        float sq = __fmul_rn(d, d);
+                        fix_split_sh((double)sq, sp.scale_e, hi, lo);
+                        q[2 * c] += hi; q[2 * c + 1] += lo;
+                    }
+                }
+            }
+            n = wave_sum_i32(n);
+            constexpr int NS = (PASS == 1) ? 12 : 6;
+#pragma unroll
+            for (int j = 0; j < NS; ++j) q[j] = wave_sum_i64(q[j]);
+            if (lane == 0) {
+                // LDS open-addressing slot for label k; full table -> straight to global memory
+                int slot = k & (ST_SLOTS - 1), probes = 0;
+                while (probes < ST_SLOTS) {
+                    int old = atomicCAS(&keys[slot], -1, k);
+                    if (old == -1 || old == k) break;
+                    slot = (slot + 1) & (ST_SLOTS - 1);
+                    ++probes;
+                }
+                if (probes < ST_SLOTS) {
+                    if (PASS == 1) {
+                        atomic_add_i64(&lacc[slot][0], n);
+                        for (int j = 0; j < 12; ++j) atomic_add_i64(&lacc[slot][1 + j], q[j]);
+                    } else {
+                        for (int j = 0; j < 6; ++j) atomic_add_i64(&lacc[slot][j], q[j]);
+                    }
+                } else {
+                    long long *a = acc + (size_t)k * 13;
+                    if (PASS == 1) {
+                        atomic_add_i64(a, n);
+                        for (int j = 0; j < 12; ++j) atomic_add_i64(a + 1 + j, q[j]);
+                    } else {
+                        for (int j = 0; j < 6; ++j) atomic_add_i64(a + 7 + j, q[j]);   // reuse the v*v columns
+                    }
+                }
+            }
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < ST_SLOTS * NQ; i += 256) {
+        int slot = i / NQ, j = i - slot * NQ;
+        int k = keys[slot];
+        if (k < 0) continue;
+        long long val = lacc[slot][j];
+        if (val == 0) continue;
+        int col = (PASS == 1) ? j : 7 + j;
+        atomic_add_i64(acc + (size_t)k * 13 + col, val);
+    }
+}
+
+__global__ void k_stats_clear(long long *acc, int K, int from, int to)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= K) return;
+    for (int j = from; j < to; ++j) acc[(size_t)i * 13 + j] = 0;
+}
+
+// normColorFeatures (features_cython.pyx:59-78): divide by the pixel count where count > 0
+__global__ void k_stats_finalize1(const long long *__restrict__ acc, StatParams sp, double *mean_out, double *energy_out,
+                                  float *mean32)
+{
+    int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= sp.K) return;
+    const long long *a = acc + (size_t)k * 13;
+    long long n = a[0];
+    for (int c = 0; c < 3; ++c) {
+        double sv = (i64_to_double(a[1 + 2 * c]) + i64_to_double(a[2 + 2 * c]) * (1.0 / 4294967296.0)) / sp.scale_v;
+        double se = (i64_to_double(a[7 + 2 * c]) + i64_to_double(a[8 + 2 * c]) * (1.0 / 4294967296.0)) / sp.scale_e;
+        double m = n > 0 ? sv / (double)n : 0.0;
+        double e = n > 0 ? se / (double)n : 0.0;
+        if (mean_out) mean_out[3 * k + c] = m;
+        if (energy_out) energy_out[3 * k + c] = e;
+        mean32[3 * k + c] = (float)m;        // np.array(means, dtype=np.float32), descriptors.py:293
+    }
+}
+
+__global__ void k_stats_finalize2(const long long *__restrict__ acc, StatParams sp, double *var_out)
+{
+    int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= sp.K) return;
+    const long long *a = acc + (size_t)k * 13;
+    long long n = a[0];
+    for (int c = 0; c < 3; ++c) {
+        double s = (i64_to_double(a[7 + 2 * c]) + i64_to_double(a[8 + 2 * c]) * (1.0 / 4294967296.0)) / sp.scale_e;
+        var_out[3 * k + c] = n > 0 ? s / (double)n : 0.0;
+    }
+}
+
+template <typename T>
+static void launch_pass(int pass, const T *img, const int32_t *labels, StatParams sp, const float *mean32,
+                        long long *acc, hipStream_t st)
+{
+    dim3 grid(cdiv(sp.W, 64 * ST_PX), cdiv(sp.H, ST_ROWS));
+    if (pass == 1)
+        hipLaunchKernelGGL((k_color_stats<T, 1>), grid, 256, 0, st, img, labels, sp, mean32, acc);
+    else
+        hipLaunchKernelGGL((k_color_stats<T, 2>), grid, 256, 0, st, img, labels, sp, mean32, acc);
+}
+
+static double pow2_scale(double n_pixels, double maxabs)
+{
+    // largest power of two with n_pixels * maxabs * scale < 2^62, capped at 2^30
+    int e_n, e_m;
+    frexp(n_pixels, &e_n);
+    frexp(maxabs > 1.0 ? maxabs : 1.0, &e_m);
+    int sh = 62 - e_n - e_m;
+    if (sh > 30) sh = 30;
+    return ldexp(1.0, sh);
+}
+
+int launch_color_stats(const void *img, int dtype, const int32_t *labels, int H, int W, int K, double maxabs,
+                       int want_var, long long *acc, double *mean_out, double *energy_out, double *var_out,
+                       float *mean32_scratch, hipStream_t st)
+{
+    StatParams sp;
+    sp.H = H; sp.W = W; sp.K = K;
+    sp.scale_v = pow2_scale((double)H * W, maxabs);
+    sp.scale_e = pow2_scale((double)H * W, 4.0 * maxabs * maxabs);
+    hipLaunchKernelGGL(k_stats_clear, cdiv(K, 256), 256, 0, st, acc, K, 0, 13);
+    if (dtype == DT_U8) launch_pass<uint8_t>(1, (const uint8_t *)img, labels, sp, mean32_scratch, acc, st);
+    else if (dtype == DT_F32) launch_pass<float>(1, (const float *)img, labels, sp, mean32_scratch, acc, st);
+    else launch_pass<double>(1, (const double *)img, labels, sp, mean32_scratch, acc, st);
+    hipLaunchKernelGGL(k_stats_finalize1, cdiv(K, 256), 256, 0, st, acc, sp, mean_out, energy_out, mean32_scratch);
+    if (want_var) {
+        hipLaunchKernelGGL(k_stats_clear, cdiv(K, 256), 256, 0, st, acc, K, 7, 13);
+        if (dtype == DT_U8) launch_pass<uint8_t>(2, (const uint8_t *)img, labels, sp, mean32_scratch, acc, st);
+        else if (dtype == DT_F32) launch_pass<float>(2, (const float *)img, labels, sp, mean32_scratch, acc, st);
+        else launch_pass<double>(2, (const double *)img, labels, sp, mean32_scratch, acc, st);
+        hipLaunchKernelGGL(k_stats_finalize2, cdiv(K, 256), 256, 0, st, acc, sp, var_out);
+    }
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+}  // namespace imsegm

@@ -1,0 +1,201 @@
+"""GPU parity tests: every HIP stage (called through the C ABI) against the CPU oracle on the same
+seeded inputs.  Integer outputs (label maps, edges, graph-cut labels) must be bit-exact; float
+descriptors within 1e-5 of the reference semantics (in fact ~1e-12 / bit-exact for uint8 images)."""
+import numpy as np
+import pytest
+
+from pyimsegm_amd.utilities.synthetic import disc_image, voronoi_image
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def hip():
+    from pyimsegm_amd import _hip
+    _hip.default_context()
+    return _hip
+
+
+def _params(img, sp_size, regul):
+    n_seg = int(np.prod(img.shape[:2]) / (sp_size**2))
+    compact = (sp_size * regul)**1.5
+    return n_seg, compact
+
+
+CASES = [
+    ('disc256', lambda: disc_image(256), 18, 0.2),
+    ('vor512', lambda: voronoi_image(512, 512), 23, 0.2),         # has an oversize component
+    ('vor_ragged', lambda: voronoi_image(301, 517, seed=3), 15, 0.3),
+    ('float_img', lambda: np.random.default_rng(0).random((125, 150, 3)), 20, 0.2),
+]
+
+
+@pytest.mark.parametrize('name,make,sp,regul', CASES, ids=[c[0] for c in CASES])
+def test_slic_bit_exact(hip, oracle, name, make, sp, regul):
+    img = make()
+    ref_labels, info = oracle.segment_slic_img2d(img, sp, regul, return_internals=True)
+    n_seg, compact = _params(img, sp, regul)
+    im = hip.Image2D(*img.shape[:2]).upload(img)
+    k = im.slic(n_seg, compact, sigma=1., normalize=2)
+    lab = im.get_lab()
+    assert np.array_equal(lab, info['pre'].reshape(lab.shape)), 'pre-processed Lab planes differ'
+    nearest = im.get_nearest()
+    assert np.array_equal(nearest, info['nearest'][0]), 'k-means assignment differs'
+    labels = im.get_labels()
+    assert labels.dtype == np.int64
+    assert np.array_equal(labels, ref_labels), 'connectivity-enforced label map differs'
+    assert k == ref_labels.max() + 1
+
+
+def test_slic_candidate_overflow_path(hip, oracle):
+    """force the kernel's global-memory fallback (more candidates than LDS slots)"""
+    img = disc_image(256)
+    ref_labels = oracle.segment_slic_img2d(img, 18, 0.2)
+    n_seg, compact = _params(img, 18, 0.2)
+    im = hip.Image2D(256, 256).upload(img)
+    im.slic(n_seg, compact, sigma=1., normalize=2, max_candidates=3)
+    assert np.array_equal(im.get_labels(), ref_labels)
+
+
+def test_slic_start_label_and_no_blur(hip, oracle):
+    img = voronoi_image(200, 240, seed=9)
+    n_seg, compact = _params(img, 16, 0.25)
+    ref = oracle.slic(img, n_seg, compact, sigma=0., normalize=(float(img.min()), float(img.max())), start_label=1)
+    im = hip.Image2D(200, 240).upload(img)
+    im.slic(n_seg, compact, sigma=0., normalize=1, start_label=1)
+    assert np.array_equal(im.get_labels(), ref)
+
+
+@pytest.mark.parametrize('dtype', ['u8', 'f32', 'f64'])
+def test_color_stats(hip, oracle, dtype):
+    rng = np.random.default_rng(11)
+    h, w, k = 150, 203, 37
+    if dtype == 'u8':
+        img = rng.integers(0, 256, (h, w, 3)).astype(np.uint8)
+    elif dtype == 'f32':
+        img = rng.random((h, w, 3)).astype(np.float32)
+    else:
+        img = rng.random((h, w, 3)) * 3 - 1
+    seg = (rng.integers(0, k, (h // 10 + 1, w // 10 + 1)).repeat(10, 0).repeat(10, 1)[:h, :w] * 2).astype(np.int32)
+    im = hip.Image2D(h, w).upload(img).set_labels(seg)
+    mean, energy, var = im.color_stats()
+    img32 = np.asarray(img, dtype=np.float32)
+    mean_ref = oracle.color2d_mean(img32, seg)
+    energy_ref = oracle.color2d_energy(img32, seg)
+    var_ref = oracle.color2d_variance(img32, seg, mean_ref.astype(np.float32))
+    if dtype == 'u8':
+        assert np.array_equal(mean, mean_ref) and np.array_equal(energy, energy_ref)
+    assert np.allclose(mean, mean_ref, rtol=1e-12, atol=1e-14)
+    assert np.allclose(energy, energy_ref, rtol=1e-12, atol=1e-14)
+    assert np.allclose(var, var_ref, rtol=1e-10, atol=1e-12)
+    assert np.all(mean[1::2] == 0)     # odd labels are empty -> stay 0 (features_cython.pyx:76)
+
+
+def test_graph_and_centres(hip, oracle):
+    img = voronoi_image(301, 517, seed=3)
+    labels = oracle.segment_slic_img2d(img, 15, 0.3)
+    im = hip.Image2D(301, 517).upload(img).set_labels(labels)
+    edges, centres, present = im.graph()
+    v_ref, e_ref = oracle.adjacency(labels)
+    assert edges.tolist() == e_ref
+    assert np.flatnonzero(present).tolist() == v_ref.tolist()
+    assert np.array_equal(centres, oracle.centers(labels))
+    # label map with holes in the id range
+    sparse = (labels * 3).astype(np.int32)
+    im.set_labels(sparse)
+    edges, centres, present = im.graph()
+    v_ref, e_ref = oracle.adjacency(sparse)
+    assert edges.tolist() == e_ref and np.flatnonzero(present).tolist() == v_ref.tolist()
+    assert np.array_equal(centres, oracle.centers(sparse))
+
+
+def test_graphcut_doctest_vector(hip):
+    """graph_cuts.py:700-703 through the C ABI"""
+    np.random.seed(0)
+    segments = np.array([[0] * 3 + [2] * 3 + [4] * 3 + [6] * 3 + [8] * 3, [1] * 3 + [3] * 3 + [5] * 3 + [7] * 3 + [9] * 3])
+    proba = np.array([[0.1] * 6 + [0.9] * 4, [0.9] * 6 + [0.1] * 4], dtype=float).T
+    proba += (0.5 - np.random.random(proba.shape)) * 0.2
+    p = np.clip(proba, 0.01, 0.99)
+    unary = np.abs(-np.log(p))
+    im = hip.Image2D(*segments.shape).set_labels(segments)
+    edges, centres, _ = im.graph()
+    d = np.sqrt(((centres[edges[:, 0]] - centres[edges[:, 1]])**2).sum(axis=1))
+    weights = np.clip(1. / (d / d.mean()), 1e-3, 1e3)
+    labels = hip.cut_general_graph(edges, weights, unary, 1. - np.eye(2))
+    assert labels.dtype == np.int32
+    assert np.array_equal(labels[segments], np.array([[1] * 9 + [0] * 6] * 2))
+
+
+@pytest.mark.parametrize('seed,K,C', [(0, 40, 2), (1, 300, 3), (2, 2000, 3), (3, 500, 5), (4, 64, 8)])
+def test_graphcut_random_graphs(hip, oracle, seed, K, C):
+    rng = np.random.default_rng(seed)
+    side = int(np.ceil(np.sqrt(K)))
+    ids = np.arange(side * side).reshape(side, side)
+    pairs = np.vstack([np.c_[ids[:, :-1].ravel(), ids[:, 1:].ravel()], np.c_[ids[:-1, :].ravel(), ids[1:, :].ravel()]])
+    pairs = pairs[(pairs < K).all(axis=1)]
+    extra = rng.integers(0, K, (K // 3, 2))
+    extra = extra[extra[:, 0] != extra[:, 1]]
+    pairs = np.unique(np.sort(np.vstack([pairs, extra]), axis=1), axis=0).astype(np.int32)
+    weights = np.clip(rng.lognormal(0, 1, len(pairs)), 1e-3, 1e3)
+    proba = rng.dirichlet(np.ones(C) * 0.6, K)
+    unary = np.abs(-np.log(np.clip(proba, 0.01, 0.99)))
+    pairwise = 2.0 * (1 - np.eye(C))
+    ref, e_ref = oracle.cut_general_graph(pairs, weights, unary, pairwise, return_energy=True)
+    out, e = hip.cut_general_graph(pairs, weights, unary, pairwise, return_energy=True)
+    assert e == e_ref
+    assert np.array_equal(out, ref)
+
+
+def test_graphcut_no_edges_and_errors(hip):
+    unary = np.array([[3., 1., 2.], [0.5, 0.5, 0.1], [1., 1., 1.]])
+    out = hip.cut_general_graph(np.zeros((0, 2), dtype=np.int32), np.zeros(0), unary, 1 - np.eye(3))
+    assert out.tolist() == [1, 2, 0]
+    with pytest.raises(hip.HipError):
+        hip.cut_general_graph(np.array([[1, 0]]), np.ones(1), unary, 1 - np.eye(3))
+    with pytest.raises(hip.HipError):
+        hip.cut_general_graph(np.array([[0, 1]]), np.ones(1), unary, np.array([[0, 1, 2], [0, 0, 1], [2, 1, 0.]]))
+
+
+def test_gathers(hip, oracle):
+    rng = np.random.default_rng(5)
+    labels = rng.integers(0, 50, (97, 131)).astype(np.int32)
+    gl = rng.integers(0, 3, 50).astype(np.int32)
+    proba = rng.random((50, 3))
+    im = hip.Image2D(97, 131).set_labels(labels)
+    segm, soft = im.gather(gl, proba)
+    assert np.array_equal(segm, gl[labels]) and segm.dtype == np.int32
+    assert np.array_equal(soft, proba[labels])
+
+
+def test_full_size_properties(hip):
+    """BASELINE config 2 size (2048 x 2048): size-independent properties of the label map"""
+    from scipy import ndimage as ndi
+    img = voronoi_image(2048, 2048)
+    n_seg, compact = _params(img, 46, 0.2)
+    im = hip.Image2D(2048, 2048).upload(img)
+    k = im.slic(n_seg, compact)
+    labels = im.get_labels()
+    assert labels.min() == 0 and labels.max() == k - 1
+    counts = np.bincount(labels.ravel(), minlength=k)
+    min_size = int(0.5 * 2048 * 2048 / 2025)
+    assert counts.min() >= min_size                      # every kept superpixel is at least min_size
+    # every superpixel is 4-connected: components of equal-label regions == number of labels
+    same_r = labels[:, 1:] == labels[:, :-1]
+    same_d = labels[1:, :] == labels[:-1, :]
+    n = labels.size
+    idx = np.arange(n).reshape(labels.shape)
+    import scipy.sparse as sp
+    import scipy.sparse.csgraph as csg
+    rows = np.concatenate([idx[:, :-1][same_r], idx[:-1, :][same_d]])
+    cols = np.concatenate([idx[:, 1:][same_r], idx[1:, :][same_d]])
+    ncomp, _ = csg.connected_components(sp.coo_matrix((np.ones(len(rows), dtype=np.int8), (rows, cols)), shape=(n, n)),
+                                        directed=False)
+    assert ncomp == k
+    # idempotence of the deterministic pipeline: a second run gives the identical map
+    im2 = hip.Image2D(2048, 2048).upload(img)
+    im2.slic(n_seg, compact)
+    assert np.array_equal(im2.get_labels(), labels)
+    # descriptors: mean of per-superpixel means weighted by size == global mean (linearity)
+    mean, energy, var = im.color_stats()
+    glob = img.reshape(-1, 3).astype(np.float64).mean(axis=0)
+    assert np.allclose((mean * counts[:, None]).sum(axis=0) / n, glob, rtol=1e-12)
