@@ -1,0 +1,217 @@
+#!/usr/bin/env python
+"""bench.py -- headline benchmark of the SLIC -> descriptors -> GraphCut hot path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+
+Workload (BASELINE.json configs[1]): one synthetic 2048 x 2048 RGB uint8 image per GPU, SLIC
+(sp_size 46 -> n_segments 1982, K = 2025 grid centroids) + colour mean/std/energy descriptors +
+3-class alpha-expansion GraphCut (gc_regul 2.0, edge type 'model') with a class model fitted once
+during warm-up (the reference's `segment_color2d_slic_features_model_graphcut`,
+imsegm/pipelines.py:160).  One step = one pass of that function over the resident image: the
+input image is already in HBM when the timed region starts and the outputs (segm H x W int32,
+segm_soft H x W x 3 float64) stay in HBM; the scikit-learn `predict_proba` and the numpy edge-weight
+formulas of the reference run on the host inside the timed region, as do the K x F / E / K x C
+transfers between the stages.  N > 1: one process per GPU (torch.distributed / RCCL), every rank
+segments its own image (weak scaling, no data-path collective) and the label maps are gathered on
+rank 0 with one RCCL gather per step.
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+SP_SIZE, SP_REGUL, NB_CLASSES, GC_REGUL, EDGE_TYPE = 46, 0.2, 3, 2.0, 'model'
+HEIGHT = WIDTH = 2048
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s
+ASSIGN_BYTES_PER_PX = 28.0     # read fp64 Lab 3 x 8 B + write int32 label 4 B per pixel per sweep
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--size', type=int, default=HEIGHT, help='image edge (default: the BASELINE 2048)')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    return ap.parse_args()
+
+
+def cpu_baseline(image, model):
+    """the CPU oracle (port of the reference path) timed on one host core, one full image"""
+    from oracle import oracle as orc
+    from pyimsegm_amd import graph_cuts as gc
+    orc.lib()
+    t0 = time.perf_counter()
+    slic = orc.segment_slic_img2d(image, SP_SIZE, SP_REGUL)
+    t1 = time.perf_counter()
+    img32 = np.asarray(image, dtype=np.float32)
+    seg32 = slic.astype(np.int32)
+    mean = orc.color2d_mean(img32, seg32)
+    std = np.sqrt(orc.color2d_variance(img32, seg32, mean.astype(np.float32)))
+    energy = orc.color2d_energy(img32, seg32)
+    features = np.nan_to_num(np.hstack([mean, std, energy]))
+    t2 = time.perf_counter()
+    proba = model.predict_proba(features)
+    _, edges = orc.adjacency(seg32)
+    edges = np.array(edges, dtype=np.int32)
+    centres = orc.centers(seg32)
+    weights = gc.compute_edge_model(edges, proba, 'lT')
+    weights = weights / gc.compute_spatial_dist([tuple(c) for c in centres], edges, relative=True)
+    weights = np.clip(weights, 1e-3, 1e3)
+    unary = gc.compute_unary_cost(proba)
+    pairwise = gc.compute_pairwise_cost(GC_REGUL, proba.shape)
+    t3 = time.perf_counter()
+    labels = orc.cut_general_graph(edges, weights, unary, pairwise, n_iter=-1)
+    t4 = time.perf_counter()
+    segm = labels[slic]
+    soft = proba[slic]
+    t5 = time.perf_counter()
+    total = t5 - t0
+    return {
+        'value': round(image.shape[0] * image.shape[1] / total / 1e6, 4),
+        'unit': 'Mpixels/s',
+        'cores': 1,
+        'kind': 'port',
+        'sample': 'one full %dx%d image, 1 pass: oracle C SLIC %.2fs + descriptors %.2fs + graph/weights %.2fs + '
+                  'GC %.3fs + gathers %.2fs' % (image.shape[0], image.shape[1], t1 - t0, t2 - t1, t3 - t2, t4 - t3, t5 - t4),
+    }, segm, soft
+
+
+def main():
+    args = parse_args()
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    dist = None
+    torch = None
+    if world > 1 or 'RANK' in os.environ:
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+    os.environ['IMSEGM_HIP_DEVICE'] = str(local_rank)
+
+    from pyimsegm_amd import _hip
+    from pyimsegm_amd import pipelines as pipe
+    from pyimsegm_amd.descriptors import FEATURES_SET_COLOR
+    from pyimsegm_amd.graph_cuts import estim_class_model
+    from pyimsegm_amd.superpixels import _open_session
+    from pyimsegm_amd.utilities.synthetic import voronoi_image
+
+    size = args.size
+    image = voronoi_image(size, size, seed=1 + rank)
+    ctx = _hip.default_context()
+    sess, mode = _open_session(image)           # H2D once: the image is resident from here on
+
+    def step(model, to_host=False):
+        res = pipe._ResidentImage(image, FEATURES_SET_COLOR, SP_SIZE, SP_REGUL, session=(sess, mode))
+        proba = model.predict_proba(res.features)
+        return res.segment(proba, GC_REGUL, EDGE_TYPE, to_host=to_host), res
+
+    # model fit once (outside the timed region): the reference's group-model flow, run_segm...:476-514
+    np.random.seed(0)
+    res0 = pipe._ResidentImage(image, FEATURES_SET_COLOR, SP_SIZE, SP_REGUL, session=(sess, mode))
+    model = estim_class_model(res0.features, NB_CLASSES, 'GMM', None, True)
+
+    def barrier():
+        ctx.synchronize()
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    gather_buf = None
+    if dist is not None and world > 1:
+        gather_buf = [torch.empty((size, size), dtype=torch.int32, device='cuda') for _ in range(world)] \
+            if rank == 0 else None
+
+    def gather_labels(segm_host):
+        t = torch.from_numpy(segm_host).to('cuda', non_blocking=False)
+        dist.gather(t, gather_buf, dst=0)
+
+    for _ in range(args.warmup):
+        (segm, _), _ = step(model, to_host=world > 1)
+        if world > 1:
+            gather_labels(segm)
+    ctx.profile_enable(True)
+    ctx.profile_reset()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        (segm, _), _ = step(model, to_host=world > 1)
+        if world > 1:
+            gather_labels(segm)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    assign_ms, assign_n = ctx.profile_get('slic_assign')
+    stage_ms = {g: ctx.profile_get(g) for g in _hip.PROFILE_GROUPS}
+    ctx.profile_enable(False)
+
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        npx = size * size
+        value = world * args.steps * npx / elapsed / 1e6
+        avg_assign_s = assign_ms / max(assign_n, 1) / 1e3
+        achieved = ASSIGN_BYTES_PER_PX * npx / avg_assign_s / 1e9 if assign_n else 0.0
+        out = {
+            'metric': 'Mpixels/s end-to-end SLIC+fts+GC, 2048x2048 RGB; % HBM roofline',
+            'value': round(value, 3),
+            'unit': 'Mpixels/s',
+            'n_gpus': world,
+            'steps': args.steps,
+            'warmup': args.warmup,
+            'ms_per_step': round(elapsed / args.steps * 1e3, 4),
+            'higher_is_better': True,
+            'scaling': 'weak',
+            'vs_baseline': None,
+            'dtype': 'f64',
+            'data': 'synthetic',
+            'config': {
+                'workload': 'single %dx%d RGB uint8 per GPU, SLIC(sp_size=46, n_segments=1982, K=2025, 10 sweeps) + '
+                            'colour mean/std/energy + 3-class alpha-expansion GC (gc_regul=2.0, edge=model), '
+                            'pre-fitted GMM (BASELINE configs[1])' % (size, size),
+                'images_per_step_per_gpu': 1,
+                'parallelism': 'images sharded over %d GPU(s), RCCL gather of label maps' % world,
+            },
+            'roofline': {
+                'bound': 'hbm',
+                'kernel': 'k_slic_assign (assignment + fused centroid accumulation)',
+                'achieved': round(achieved, 2),
+                'peak': HBM_PEAK_GBS,
+                'unit': 'GB/s',
+                'frac': round(achieved / HBM_PEAK_GBS, 5),
+                'traffic': None,
+                'avg_kernel_us': round(avg_assign_s * 1e6, 3),
+                'launches': assign_n,
+                'algorithmic_bytes_per_launch': ASSIGN_BYTES_PER_PX * npx,
+            },
+            'stage_ms_per_step': {g: round(ms / args.steps, 4) for g, (ms, n) in stage_ms.items()},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                base, segm_cpu, _ = cpu_baseline(image, model)
+                out['cpu_baseline'] = base
+                (segm_gpu, _), _ = step(model, to_host=True)
+                out['gpu_equals_cpu_oracle'] = bool(np.array_equal(segm_gpu, segm_cpu))
+                out['speedup_vs_cpu_baseline'] = round(value / base['value'], 2)
+            except Exception as ex:   # the baseline is a reported extra, never a reason to lose the line
+                out['cpu_baseline'] = {'error': repr(ex)}
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,208 @@
+"""Pipelines: SLIC superpixels -> descriptors -> class model -> GraphCut.
+
+Host-side mirror of the unsupervised part of the reference module ``imsegm/pipelines.py``
+(``pipe_color2d_slic_features_model_graphcut`` :46, ``estim_model_classes_group`` :113,
+``segment_color2d_slic_features_model_graphcut`` :160, ``compute_color2d_superpixels_features``
+:244).  One image is uploaded once; superpixels, descriptors, adjacency graph, graph cut and the
+final ``proba[slic]`` / ``labels[slic]`` gathers all work on the device-resident session, only
+K x F features, E edges and K x C probabilities cross the PCIe bus in between (the class model is
+scikit-learn on the host, as in the reference).
+"""
+import logging
+
+import numpy as np
+
+from pyimsegm_amd import _hip
+from pyimsegm_amd.descriptors import FEATURES_SET_COLOR, _selected_features_color2d, compute_selected_features_img2d
+from pyimsegm_amd.graph_cuts import estim_class_model, segment_graph_cut_general
+from pyimsegm_amd.superpixels import _open_session, _run_slic
+
+#: select basic features extracted from superpixels
+FTS_SET_SIMPLE = FEATURES_SET_COLOR
+#: default modeling / clustering for unsupervised segmentation
+CLUSTER_METHOD = 'GMM'
+#: default number of workers (kept for API compatibility: images are processed one after another on
+#: the GPU of this process; see :func:`segment_batch_sharded` for the multi-GPU path)
+NB_WORKERS = 1
+
+
+class _ResidentImage(object):
+    """one image on the device: superpixels + features, graph cut, gathers"""
+
+    def __init__(self, image, dict_features, sp_size, sp_regul, session=None):
+        """``session``: (Image2D, normalize_mode) of an image that is already uploaded (bench loop)"""
+        if sp_regul <= 0.:
+            raise ValueError('slic. regularisation must be positive')
+        image = np.asarray(image)
+        self.image = image
+        logging.debug('run Superpixel clustering.')
+        self.own_session = session is None
+        self.sess, mode = _open_session(image) if session is None else session
+        self.nb_labels = _run_slic(self.sess, mode, sp_size, sp_regul)
+        logging.debug('extract slic/superpixels features.')
+        self._slic = None
+        if image.ndim == 3 and set(dict_features) == {'color'} and image.dtype in (np.uint8, np.float64) \
+                and set(dict_features['color']) <= {'mean', 'std', 'energy'}:
+            # everything stays on the device: statistics of the uploaded image on the resident labels
+            features, _ = _selected_features_color2d(image, None, dict_features, sess=self.sess)
+        else:
+            features, _ = compute_selected_features_img2d(image, self.slic, dict_features)
+        features[np.isnan(features)] = 0
+        self.features = features
+
+    @property
+    def slic(self):
+        if self._slic is None:
+            self._slic = self.sess.get_labels()
+        return self._slic
+
+    def segment(self, proba, gc_regul, gc_edge_type, debug_visual=None, classes=None, to_host=True):
+        image = self.image
+        # the graph stage only reads the label map of the session; `segments` is passed for its
+        # ndim / debug output and is only materialised on the host when somebody needs it
+        segments = self.slic if (debug_visual is not None or gc_edge_type == 'color') else _ShapeOnly(self.sess.shape)
+        graph_labels = segment_graph_cut_general(segments, proba, image, self.features, gc_regul, gc_edge_type,
+                                                 debug_visual=debug_visual, _session=self.sess)
+        if classes is not None:
+            graph_labels = np.asarray(classes)[graph_labels]
+        segm, segm_soft = self.sess.gather(graph_labels, proba, to_host=to_host)
+        if to_host and classes is not None and np.asarray(classes).dtype != np.int32:
+            segm = segm.astype(np.asarray(classes).dtype)
+        return segm, segm_soft
+
+    def close(self):
+        if self.own_session:
+            self.sess.close()
+
+
+class _ShapeOnly(object):
+    """stand-in for a label map whose pixels live on the device"""
+
+    def __init__(self, shape):
+        self.shape = shape
+        self.ndim = len(shape)
+
+    def __array__(self, *args, **kwargs):
+        raise RuntimeError('the label map is device resident')
+
+
+def compute_color2d_superpixels_features(image, dict_features, sp_size=30, sp_regul=0.2):
+    """ SLIC superpixels of an image and the selected features per superpixel
+
+    :param ndarray image: input RGB image
+    :param dict(list(str)) dict_features: features to be extracted, e.g. ``{'color': ['mean']}``
+    :param int sp_size: initial size of a superpixel (edge length)
+    :param float sp_regul: regularisation in (0, 1): 0 elastic, 1 nearly square segments
+    :return tuple(ndarray,ndarray): superpixel label map, features K x F
+    """
+    res = _ResidentImage(image, dict_features, sp_size, sp_regul)
+    slic, features = res.slic, res.features
+    res.close()
+    logging.debug('list of features RAW: %r', features.shape)
+    return slic, features
+
+
+def pipe_color2d_slic_features_model_graphcut(
+    image,
+    nb_classes,
+    dict_features,
+    sp_size=30,
+    sp_regul=0.2,
+    pca_coef=None,
+    use_scaler=True,
+    estim_model='GMM',
+    gc_regul=1.,
+    gc_edge_type='model',
+    debug_visual=None,
+):
+    """ complete unsupervised pipeline: superpixels, features, mixture model, GraphCut
+
+    :param ndarray image: input RGB image
+    :param int nb_classes: number of classes to be segmented (indexing from 0)
+    :param dict dict_features: {clr: list(str)}
+    :param int sp_size: initial size of a superpixel (edge length)
+    :param float sp_regul: regularisation in (0, 1)
+    :param float pca_coef: range (0, 1) or None
+    :param bool use_scaler: use a standard scaler in front of the model
+    :param str estim_model: estimating model, see :func:`graph_cuts.estim_class_model`
+    :param float gc_regul: GraphCut regularisation
+    :param str gc_edge_type: GraphCut edge type
+    :param dict debug_visual: filled with intermediate results if given
+    :return tuple(ndarray,ndarray): segmentation H x W, soft segmentation H x W x nb_classes
+
+    >>> np.random.seed(0)
+    >>> image = np.random.random((125, 150, 3)) / 2.
+    >>> image[:, :75] += 0.5
+    >>> segm, seg_soft = pipe_color2d_slic_features_model_graphcut(image, 2, {'color': ['mean']})  # doctest: +SKIP
+    >>> segm.shape  # doctest: +SKIP
+    (125, 150)
+    """
+    logging.info('PIPELINE Superpixels-Features-GMM-GraphCut')
+    res = _ResidentImage(image, dict_features, sp_size, sp_regul)
+    if debug_visual is not None:
+        debug_visual['image'] = res.image if res.image.ndim == 3 else np.repeat(res.image[:, :, None], 3, axis=2)
+        debug_visual['slic'] = res.slic
+    model = estim_class_model(res.features, nb_classes, estim_model, pca_coef, use_scaler)
+    proba = model.predict_proba(res.features)
+    logging.debug('list of probabilities: %r', proba.shape)
+    segm, segm_soft = res.segment(proba, gc_regul, gc_edge_type, debug_visual)
+    res.close()
+    return segm, segm_soft
+
+
+def estim_model_classes_group(
+    list_images,
+    nb_classes,
+    dict_features,
+    sp_size=30,
+    sp_regul=0.2,
+    use_scaler=True,
+    pca_coef=None,
+    model_type='GMM',
+    nb_workers=NB_WORKERS,
+):
+    """ estimate one class model from the superpixel features of a sequence of images
+
+    :return tuple(model, list(ndarray)): fitted scikit-learn pipeline, features per image
+    """
+    list_features = []
+    for image in list_images:
+        _, features = compute_color2d_superpixels_features(image, dict_features, sp_size=sp_size, sp_regul=sp_regul)
+        list_features.append(features)
+    features = np.nan_to_num(np.concatenate(tuple(list_features), axis=0))
+    model = estim_class_model(features, nb_classes, model_type, pca_coef, use_scaler)
+    return model, list_features
+
+
+def segment_color2d_slic_features_model_graphcut(
+    image,
+    model_pipeline,
+    dict_features,
+    sp_size=30,
+    sp_regul=0.2,
+    gc_regul=1.,
+    gc_edge_type='model',
+    debug_visual=None,
+):
+    """ segmentation with a given (pre-trained) model: superpixels, features, predict, GraphCut
+
+    :param ndarray image: input RGB image
+    :param obj model_pipeline: fitted model with ``predict_proba``
+    :return tuple(ndarray,ndarray): segmentation H x W, soft segmentation H x W x nb_classes
+    """
+    logging.info('PIPELINE Superpixels-Features-Model-GraphCut')
+    res = _ResidentImage(image, dict_features, sp_size, sp_regul)
+    if debug_visual is not None:
+        debug_visual['image'] = res.image if res.image.ndim == 3 else np.repeat(res.image[:, :, None], 3, axis=2)
+        debug_visual['slic'] = res.slic
+    proba = model_pipeline.predict_proba(res.features)
+    logging.debug('list of probabilities: %r', proba.shape)
+    classes = getattr(model_pipeline, 'classes_', None)
+    segm, segm_soft = res.segment(proba, gc_regul, gc_edge_type, debug_visual, classes=classes)
+    res.close()
+    return segm, segm_soft
+
+
+def pipe_gray3d_slic_features_model_graphcut(*args, **kwargs):
+    """ 3D gray pipeline (reference ``pipelines.py:382-431``): not on the HIP path yet """
+    raise NotImplementedError('the 3D supervoxel pipeline is not implemented by the HIP path yet')

@@ -1,0 +1,162 @@
+"""GPU tests of the host-side mirror of the reference API (pyimsegm_amd.superpixels / descriptors /
+graph_cuts / pipelines): the reference's own doctest vectors, evaluated through the HIP path."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _doctest_image():
+    image = np.zeros((2, 10, 3))
+    image[:, 2:6, 0] = 1
+    image[:, 3:7, 1] = 3
+    image[:, 4:9, 2] = 2
+    segm = np.array([[0, 0, 0, 0, 0, 1, 1, 1, 1, 1], [0, 0, 0, 0, 0, 1, 1, 1, 1, 1]])
+    return image, segm
+
+
+def test_descriptor_doctests():
+    from pyimsegm_amd import descriptors as D
+    image, segm = _doctest_image()
+    # descriptors.py:225-226, 253-254, 282-283
+    assert np.array_equal(D.cython_img2d_color_mean(image, segm), [[0.6, 1.2, 0.4], [0.2, 1.2, 1.6]])
+    assert np.array_equal(D.cython_img2d_color_energy(image, segm), [[0.6, 3.6, 0.8], [0.2, 3.6, 3.2]])
+    std = D.cython_img2d_color_std(image, segm)
+    assert np.allclose(std, [[0.48989794, 1.46969383, 0.80000003], [0.40000001, 1.46969383, 0.80000001]], atol=5e-9, rtol=0)
+    # descriptors.py:796-813 (15 columns)
+    features, names = D.compute_image2d_color_statistic(image, segm)
+    assert names[:3] == ['color-ch1_mean', 'color-ch2_mean', 'color-ch3_mean'] and len(names) == 15
+    expect = [[0.6, 1.2, 0.4, 0.5, 1.5, 0.8, 0.6, 3.6, 0.8, 1.0, 0.0, 0.0, 0.2, 0.6, 0.4],
+              [0.2, 1.2, 1.6, 0.4, 1.5, 0.8, 0.2, 3.6, 3.2, 0.0, 0.0, 2.0, -0.2, -0.6, -0.6]]
+    assert np.round(features, 1).tolist() == expect
+    # descriptors.py:1215-1239
+    fts, _ = D.compute_selected_features_color2d(image, segm, {'color': ('mean', 'std', 'median')})
+    assert np.allclose(np.round(fts, 3), [[0.6, 1.2, 0.4, 0.49, 1.47, 0.8, 1., 0., 0.], [0.2, 1.2, 1.6, 0.4, 1.47, 0.8, 0., 0., 2.]])
+    fts, _ = D.compute_selected_features_color2d(image, segm, {'color_hsv': ('mean', 'std')})
+    assert np.allclose(np.round(fts, 3), [[0.139, 0.533, 1.4, 0.176, 0.452, 1.356], [0.439, 0.733, 2., 0.244, 0.389, 1.095]])
+    fts, _ = D.compute_selected_features_color2d(image, segm, {'tLM_short': ('mean', 'energy')})
+    assert fts.shape == (2, 90)
+    with pytest.raises(TypeError):
+        D.cython_img2d_color_mean(np.zeros((125, 150, 3)), np.zeros((150, 125), dtype=int))
+
+
+def test_texture_doctest_shapes():
+    from pyimsegm_amd import descriptors as D
+    h, w, step = 30, 20, 5
+    np.random.seed(0)
+    seg = (np.arange(h)[:, None] // step) * (w // step) + np.arange(w)[None, :] // step
+    img = np.random.random((h, w, 3))
+    features, names = D.compute_texture_desc_lm_img2d_clr(img, seg, ['mean', 'std', 'median'], bank_type='short')
+    assert features.shape == (24, 135)                         # descriptors.py:1063-1064
+    assert names[0] == 'tLM_sigma1.4-edge-ch1_mean' and names[-1] == 'tLM_sigma4.0-GaussLap2-ch3_median'
+
+
+def test_superpixels_api(oracle):
+    from pyimsegm_amd import superpixels as S
+    np.random.seed(0)
+    img = np.random.random((100, 150, 3))
+    slic = S.segment_slic_img2d(img, 20, 0.2)                   # superpixels.py:32-36
+    assert slic.shape == (100, 150) and slic.dtype == np.int64
+    assert np.array_equal(slic, oracle.segment_slic_img2d(img, 20, 0.2))
+    gray = np.random.random((150, 100))
+    slic = S.segment_slic_img2d(gray, 20, 0.2)                  # superpixels.py:37-40
+    assert slic.shape == (150, 100)
+    assert np.array_equal(slic, oracle.segment_slic_img2d(gray, 20, 0.2))
+    grid = np.array([[0] * 5 + [1] * 5, [2] * 5 + [3] * 5])
+    v, edges = S.make_graph_segm_connect_grid2d_conn4(grid)     # superpixels.py:163-168
+    assert v.tolist() == [0, 1, 2, 3] and edges == [[0, 1], [0, 2], [1, 3], [2, 3]]
+    segm = np.array([[0] * 6 + [1] * 5, [0] * 6 + [2] * 5])
+    assert S.superpixel_centers(segm) == [(0.5, 2.5), (0.0, 8.0), (1.0, 8.0)]     # superpixels.py:211-213
+    assert S.superpixel_centers(np.array([segm, segm, segm])) == [[1.0, 0.5, 2.5], [1.0, 0.0, 8.0], [1.0, 1.0, 8.0]]
+
+
+def test_edge_weight_doctests():
+    """graph_cuts.py:587-609: every edge type on seeded inputs"""
+    from pyimsegm_amd import graph_cuts as G
+    segments = np.array([[0] * 3 + [1] * 5 + [2] * 4, [4] * 4 + [5] * 5 + [6] * 3])
+    np.random.seed(0)
+    img = np.random.random(segments.shape + (3, )) * 255
+    features = np.random.random((segments.max() + 1, 15)) * 10
+    proba = np.random.random((segments.max() + 1, 2))
+    edges, weights = G.compute_edge_weights(segments)
+    assert edges.dtype == np.int32
+    assert edges.tolist() == [[0, 1], [1, 2], [0, 4], [1, 4], [1, 5], [2, 5], [4, 5], [2, 6], [5, 6]]
+    assert np.round(weights, 2).tolist() == [1.0] * 9
+    _, weights = G.compute_edge_weights(segments, image=img, edge_type='spatial')
+    assert np.round(weights, 3).tolist() == [0.776, 0.69, 2.776, 0.853, 2.194, 0.853, 0.69, 2.776, 0.776]
+    _, weights = G.compute_edge_weights(segments, image=img, edge_type='color')
+    assert np.round(weights, 3).tolist() == [0.06, 0.002, 0.001, 0.001, 0.001, 0.009, 0.001, 0.019, 0.044]
+    _, weights = G.compute_edge_weights(segments, features=features, edge_type='features')
+    assert np.round(weights, 3).tolist() == [0.031, 0.005, 0.051, 0.032, 0.096, 0.013, 0.018, 0.033, 0.013]
+    _, weights = G.compute_edge_weights(segments, proba=proba, edge_type='model')
+    assert np.round(weights, 3).tolist() == [0.001, 0.028, 1.122, 0.038, 0.117, 0.688, 0.487, 1.152, 0.282]
+    with pytest.raises(ValueError):
+        G.compute_edge_weights(segments, edge_type='model')
+    with pytest.raises(RuntimeError):
+        G.compute_edge_weights(segments, edge_type='color')
+
+
+def test_segment_graph_cut_general_doctests():
+    """graph_cuts.py:680-713"""
+    from pyimsegm_amd import graph_cuts as G
+    np.random.seed(0)
+    segments = np.array([[0] * 3 + [2] * 3 + [4] * 3 + [6] * 3 + [8] * 3, [1] * 3 + [3] * 3 + [5] * 3 + [7] * 3 + [9] * 3])
+    proba = np.array([[0.1] * 6 + [0.9] * 4, [0.9] * 6 + [0.1] * 4], dtype=float).T
+    proba += (0.5 - np.random.random(proba.shape)) * 0.2
+    out = G.segment_graph_cut_general(segments, proba, gc_regul=0., edge_type='')
+    assert out.tolist() == [1, 1, 1, 1, 1, 1, 0, 0, 0, 0]
+    labels = G.segment_graph_cut_general(segments, proba, gc_regul=1., edge_type='spatial')
+    assert labels.dtype == np.int32
+    assert np.array_equal(labels[segments], [[1] * 9 + [0] * 6] * 2)
+    dbg = {}
+    G.segment_graph_cut_general(segments, proba, gc_regul=1., edge_type='model', debug_visual=dbg)
+    assert {'segments', 'edges', 'edge_weights'} <= set(dbg)
+    transitions = G.count_label_transitions_connected_segments(
+        {'a': np.array([[0] * 3 + [1] * 3 + [2] * 3 + [3] * 3 + [4] * 3, [5] * 3 + [6] * 3 + [7] * 3 + [8] * 3 + [9] * 3])},
+        {'a': np.array([0, 0, 1, 1, 2, 0, 1, 1, 0, 2])})
+    assert transitions.tolist() == [[2., 5., 1.], [5., 3., 1.], [1., 1., 1.]]     # graph_cuts.py:768-771
+
+
+def _oracle_pipeline(oracle, image, model, sp_size, sp_regul, gc_regul):
+    from pyimsegm_amd import graph_cuts as G
+    slic = oracle.segment_slic_img2d(image, sp_size, sp_regul)
+    img32, seg32 = np.asarray(image, dtype=np.float32), slic.astype(np.int32)
+    mean = oracle.color2d_mean(img32, seg32)
+    std = np.sqrt(oracle.color2d_variance(img32, seg32, mean.astype(np.float32)))
+    energy = oracle.color2d_energy(img32, seg32)
+    features = np.nan_to_num(np.hstack([mean, std, energy]))
+    proba = model.predict_proba(features)
+    _, edges = oracle.adjacency(seg32)
+    edges = np.array(edges, dtype=np.int32)
+    weights = G.compute_edge_model(edges, proba, 'lT')
+    weights = weights / G.compute_spatial_dist([tuple(c) for c in oracle.centers(seg32)], edges, relative=True)
+    weights = np.clip(weights, 1e-3, 1e3)
+    labels = oracle.cut_general_graph(edges, weights, G.compute_unary_cost(proba), G.compute_pairwise_cost(gc_regul, proba.shape))
+    return slic, features, labels[slic], proba[slic]
+
+
+@pytest.mark.parametrize('size,sp', [(256, 18), (600, 25)])
+def test_pipeline_equals_oracle_pipeline(oracle, size, sp):
+    """end to end: same model -> identical segmentation and soft segmentation as the CPU oracle path"""
+    from pyimsegm_amd import pipelines as P
+    from pyimsegm_amd.descriptors import FEATURES_SET_COLOR
+    from pyimsegm_amd.utilities.synthetic import voronoi_image
+    image = voronoi_image(size, size + 40, seed=7)
+    np.random.seed(0)
+    model, list_features = P.estim_model_classes_group([image], 3, FEATURES_SET_COLOR, sp_size=sp, sp_regul=0.2)
+    segm, soft = P.segment_color2d_slic_features_model_graphcut(image, model, FEATURES_SET_COLOR, sp_size=sp,
+                                                                sp_regul=0.2, gc_regul=2.0, gc_edge_type='model')
+    slic_ref, fts_ref, segm_ref, soft_ref = _oracle_pipeline(oracle, image, model, sp, 0.2, 2.0)
+    assert np.allclose(list_features[0], fts_ref, rtol=1e-10, atol=1e-12)
+    assert np.array_equal(segm, segm_ref)
+    assert np.allclose(soft, soft_ref, rtol=1e-9, atol=1e-12)
+    assert soft.shape == image.shape[:2] + (3, )
+    # doctest of pipelines.py:76-83
+    np.random.seed(0)
+    img = np.random.random((125, 150, 3)) / 2.
+    img[:, :75] += 0.5
+    segm, seg_soft = P.pipe_color2d_slic_features_model_graphcut(img, 2, {'color': ['mean']})
+    assert segm.shape == (125, 150) and seg_soft.shape == (125, 150, 2)
+    assert len(np.unique(segm[:, :60])) == 1 and len(np.unique(segm[:, 90:])) == 1 and segm[0, 0] != segm[0, -1]
+    with pytest.raises(ValueError):
+        P.compute_color2d_superpixels_features(img, {'color': ['mean']}, sp_regul=0.)
