@@ -97,10 +97,17 @@ def _check(status):
         raise HipError(load_library().imsegm_last_error().decode('utf-8', 'replace'))
 
 
+_device_count = {}
+
+
 def device_count():
-    n = C.c_int(0)
-    load_library().imsegm_device_count(C.byref(n))
-    return n.value
+    """number of visible HIP devices (cached per process: forked children ask again)"""
+    pid = os.getpid()
+    if pid not in _device_count:
+        n = C.c_int(0)
+        load_library().imsegm_device_count(C.byref(n))
+        _device_count[pid] = n.value
+    return _device_count[pid]
 
 
 def _ptr(arr):
@@ -150,13 +157,13 @@ _default_ctx = {}
 
 def default_context():
     """per-process, per-device lazily created context (re-created in forked children)"""
-    device = int(os.environ.get('IMSEGM_HIP_DEVICE', os.environ.get('LOCAL_RANK', '0')))
-    n = device_count()
-    if n > 0:
-        device %= n
-    key = (os.getpid(), device)
+    key = (os.getpid(), os.environ.get('IMSEGM_HIP_DEVICE', os.environ.get('LOCAL_RANK', '0')))
     ctx = _default_ctx.get(key)
     if ctx is None:
+        device = int(key[1])
+        n = device_count()
+        if n > 0:
+            device %= n
         ctx = Context(device)
         _default_ctx[key] = ctx
     return ctx

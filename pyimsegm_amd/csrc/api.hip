@@ -116,7 +116,7 @@ struct imsegm_image2d {
     int dtype = -1;
     int n_labels = 0;
     bool have_labels = false;
-    DevBuf img, labA, labB, nearest, labels, conn_i32, conn_u8, small, cent, feat, graph, gather_lut, gather_out_i, gather_out_f;
+    DevBuf img, labA, labB, nearest, labels, conn_i32, conn_u8, small, cent, tiles, feat, graph, gather_lut, gather_out_i, gather_out_f;
 };
 
 static int bind(imsegm_ctx *ctx)
@@ -288,7 +288,7 @@ void imsegm_image2d_destroy(imsegm_image2d *im)
     (void)hipSetDevice(im->ctx->device);
     (void)hipStreamSynchronize(im->ctx->stream);
     DevBuf *all[] = { &im->img, &im->labA, &im->labB, &im->nearest, &im->labels, &im->conn_i32, &im->conn_u8, &im->small,
-                      &im->cent, &im->feat, &im->graph, &im->gather_lut, &im->gather_out_i, &im->gather_out_f };
+                      &im->cent, &im->tiles, &im->feat, &im->graph, &im->gather_lut, &im->gather_out_i, &im->gather_out_f };
     for (auto b : all) b->release();
     delete im;
 }
@@ -362,6 +362,8 @@ int imsegm_image2d_slic(imsegm_image2d *im, int minmax_normalize, int n_segments
     if (im->nearest.ensure(n * 4) || im->labels.ensure(n * 4)) return -1;
     size_t cent_bytes = (size_t)K * (5 * 8 + 16 + 9 * 8 + 16) + 256;
     if (im->cent.ensure(cent_bytes)) return -1;
+    const size_t n_tiles = (size_t)cdiv(W, SLIC_TILE_X) * cdiv(H, SLIC_TILE_Y);
+    if (im->tiles.ensure(n_tiles * (SLIC_MAXC * sizeof(Cand) + sizeof(int)) + n * 4 + 512)) return -1;
     if (im->small.ensure(4096)) return -1;
 
     unsigned long long *keys = im->small.as<unsigned long long>();
@@ -389,6 +391,10 @@ int imsegm_image2d_slic(imsegm_image2d *im, int minmax_normalize, int n_segments
     s.cb = reinterpret_cast<double *>(cb); cb += (size_t)K * 8;
     s.win = reinterpret_cast<int4 *>(cb); cb += (size_t)K * 16;
     double *init_dev = reinterpret_cast<double *>(cb);   // K * 2 doubles
+    s.tile_cands = im->tiles.as<Cand>();
+    s.tile_count = reinterpret_cast<int *>(im->tiles.as<unsigned char>() + n_tiles * SLIC_MAXC * sizeof(Cand));
+    s.leftover_count = s.tile_count + n_tiles + 16;
+    s.leftover = s.leftover_count + 16;
     HIP_TRY(hipMemcpyAsync(init_dev, init.data(), init.size() * sizeof(double), hipMemcpyHostToDevice, st));
     HIP_TRY(hipStreamSynchronize(st));   // `init` is a stack-owned host vector
 
@@ -406,7 +412,7 @@ int imsegm_image2d_slic(imsegm_image2d *im, int minmax_normalize, int n_segments
         double segment_size = (double)n / (double)K;
         long min_size = (long)(min_size_factor * segment_size);
         long max_size = (long)(max_size_factor * segment_size);
-        if (im->conn_i32.ensure(n * 4 * 6 + ((n / 4096) + 64) * 4 + 256) || im->conn_u8.ensure(2 * n + 64)) return -1;
+        if (im->conn_i32.ensure(n * 4 * 8 + ((n / 4096) + 64) * 4 + 256) || im->conn_u8.ensure(2 * n + 64)) return -1;
         ConnWork w;
         int32_t *b = im->conn_i32.as<int32_t>();
         w.parent = b; b += n;
@@ -415,6 +421,8 @@ int imsegm_image2d_slic(imsegm_image2d *im, int minmax_normalize, int n_segments
         w.adjptr = b; b += n;
         w.queue = b; b += n;
         w.list = b; b += n;
+        w.slotmap = b; b += n;
+        w.bbox = b; b += n;
         w.blocksum = b; b += (n / 4096) + 32;
         w.counters = b;
         w.visited = im->conn_u8.as<uint8_t>();

@@ -136,6 +136,99 @@ __device__ __forceinline__ double wave_max_f64(double v)
     return v;
 }
 
+// Transposed multi-value reductions: sum M int64 values over the 64 lanes with M/2 + M/4 + ... + 1
+// (+ log2(64/M) butterfly) exchanges instead of 6 * M.  On return every lane holds the complete
+// total of ONE of the values: value index = (lane >> 3) for M = 8, (lane >> 2) for M = 16, so
+// the M lanes {0, 64/M, 2*64/M, ...} can issue the M atomics in parallel.
+__device__ __forceinline__ long long wave_reduce8_i64(const long long (&v)[8])
+{
+    const int lane = threadIdx.x & 63;
+    bool up = lane & 32;
+    long long a[4], b[2];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        long long send = up ? v[j] : v[j + 4], keep = up ? v[j + 4] : v[j];
+        a[j] = keep + __shfl_xor(send, 32, 64);
+    }
+    up = lane & 16;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        long long send = up ? a[j] : a[j + 2], keep = up ? a[j + 2] : a[j];
+        b[j] = keep + __shfl_xor(send, 16, 64);
+    }
+    up = lane & 8;
+    long long send = up ? b[0] : b[1], keep = up ? b[1] : b[0];
+    long long c = keep + __shfl_xor(send, 8, 64);
+    c += __shfl_xor(c, 4, 64);
+    c += __shfl_xor(c, 2, 64);
+    c += __shfl_xor(c, 1, 64);
+    return c;
+}
+
+// same exchange pattern for 8 values of which v[0..5] carry fp64 bit patterns (added as doubles,
+// exact while the sums stay below 2^53) and v[6..7] are int64
+__device__ __forceinline__ long long wave_reduce8_mixed(const long long (&v)[8])
+{
+    const int lane = threadIdx.x & 63;
+    auto addm = [](long long a, long long b, bool is_f64) -> long long {
+        return is_f64 ? __double_as_longlong(__longlong_as_double(a) + __longlong_as_double(b)) : a + b;
+    };
+    bool up = lane & 32;
+    long long a[4], b[2];
+    // after step 1 lanes with bit 5 set hold indices 4..7 (4, 5 fp64; 6, 7 int), the others 0..3 (fp64)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        long long send = up ? v[j] : v[j + 4], keep = up ? v[j + 4] : v[j];
+        long long recv = __shfl_xor(send, 32, 64);
+        a[j] = addm(keep, recv, !(up && j >= 2));
+    }
+    bool up2 = lane & 16;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        long long send = up2 ? a[j] : a[j + 2], keep = up2 ? a[j + 2] : a[j];
+        long long recv = __shfl_xor(send, 16, 64);
+        b[j] = addm(keep, recv, !(up && up2));          // indices 6, 7 live where bits 5 and 4 are set
+    }
+    bool up3 = lane & 8;
+    const bool is_f64 = !(up && up2);
+    long long send = up3 ? b[0] : b[1], keep = up3 ? b[1] : b[0];
+    long long c = addm(keep, __shfl_xor(send, 8, 64), is_f64);
+    c = addm(c, __shfl_xor(c, 4, 64), is_f64);
+    c = addm(c, __shfl_xor(c, 2, 64), is_f64);
+    c = addm(c, __shfl_xor(c, 1, 64), is_f64);
+    return c;
+}
+
+__device__ __forceinline__ long long wave_reduce16_i64(const long long (&v)[16])
+{
+    const int lane = threadIdx.x & 63;
+    bool up = lane & 32;
+    long long a[8], b[4], c[2];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        long long send = up ? v[j] : v[j + 8], keep = up ? v[j + 8] : v[j];
+        a[j] = keep + __shfl_xor(send, 32, 64);
+    }
+    up = lane & 16;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        long long send = up ? a[j] : a[j + 4], keep = up ? a[j + 4] : a[j];
+        b[j] = keep + __shfl_xor(send, 16, 64);
+    }
+    up = lane & 8;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        long long send = up ? b[j] : b[j + 2], keep = up ? b[j + 2] : b[j];
+        c[j] = keep + __shfl_xor(send, 8, 64);
+    }
+    up = lane & 4;
+    long long send = up ? c[0] : c[1], keep = up ? c[1] : c[0];
+    long long d = keep + __shfl_xor(send, 4, 64);
+    d += __shfl_xor(d, 2, 64);
+    d += __shfl_xor(d, 1, 64);
+    return d;
+}
+
 __device__ __forceinline__ void atomic_add_i64(long long *p, long long v)
 {
     atomicAdd(reinterpret_cast<unsigned long long *>(p), (unsigned long long)v);

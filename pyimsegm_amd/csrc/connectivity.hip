@@ -24,7 +24,7 @@
 namespace imsegm {
 
 enum { ST_ACTIVE = 0, ST_FINAL = 1 };
-enum { CNT_OVER = 0, CNT_SMALL = 1, CNT_CURSOR = 2, CNT_KEPT = 3, CNT_OVERLIST = 4 };
+enum { CNT_OVER = 0, CNT_SMALL = 1, CNT_CURSOR = 2, CNT_KEPT = 3, CNT_FALLBACK = 4 };
 
 __device__ __forceinline__ int uf_find(const int32_t *parent, int a)
 {
@@ -54,10 +54,27 @@ __device__ __forceinline__ void uf_union(int32_t *parent, int a, int b)
     }
 }
 
-__global__ void __launch_bounds__(256) k_ccl_init(int32_t *parent, const uint8_t *state, int n)
+// Run-based initialisation: every active pixel points at the leftmost pixel of its horizontal run
+// inside its 64-pixel wave segment (ballot + count-leading-zeros, no memory traffic), so the
+// union-find forest starts with paths of length <= 1 and the merge pass only has to join runs.
+__device__ __forceinline__ bool run_continues(const int32_t *labels, const uint8_t *state, int p, int x)
+{
+    return x > 0 && state[p - 1] == ST_ACTIVE && labels[p - 1] == labels[p];
+}
+
+__global__ void __launch_bounds__(256)
+k_ccl_init(const int32_t *__restrict__ labels, const uint8_t *__restrict__ state, int32_t *parent, int n, int W)
 {
     int p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p < n && state[p] == ST_ACTIVE) parent[p] = p;
+    const int lane = threadIdx.x & 63;
+    bool active = p < n && state[p] == ST_ACTIVE;
+    bool cont = false;
+    if (active) cont = run_continues(labels, state, p, p % W);
+    unsigned long long starts = __ballot(active && !cont);
+    if (!active) return;
+    unsigned long long below = starts & ((lane == 63) ? ~0ULL : ((2ULL << lane) - 1ULL));
+    int start_lane = below ? 63 - __clzll((long long)below) : 0;
+    parent[p] = p - (lane - start_lane);
 }
 
 __global__ void __launch_bounds__(256)
@@ -67,8 +84,15 @@ k_ccl_merge(const int32_t *__restrict__ labels, const uint8_t *__restrict__ stat
     if (p >= H * W || state[p] != ST_ACTIVE) return;
     int y = p / W, x = p - y * W;
     int l = labels[p];
-    if (x > 0 && state[p - 1] == ST_ACTIVE && labels[p - 1] == l) uf_union(parent, p, p - 1);
-    if (y > 0 && state[p - W] == ST_ACTIVE && labels[p - W] == l) uf_union(parent, p, p - W);
+    bool cont = x > 0 && state[p - 1] == ST_ACTIVE && labels[p - 1] == l;
+    // horizontal: only the first lane of a wave segment still has to be tied to its left neighbour
+    if (cont && (threadIdx.x & 63) == 0) uf_union(parent, p, p - 1);
+    // vertical: one union per pair of overlapping runs is enough -- skip it when the left
+    // neighbour pair (p-1, p-W-1) carries the same two runs (it, or a pixel further left, does it)
+    if (y > 0 && state[p - W] == ST_ACTIVE && labels[p - W] == l) {
+        bool left_pair_same = cont && state[p - W - 1] == ST_ACTIVE && labels[p - W - 1] == l;
+        if (!left_pair_same) uf_union(parent, p, p - W);
+    }
 }
 
 __global__ void __launch_bounds__(256) k_ccl_flatten(int32_t *parent, const uint8_t *state, int32_t *csize, int n)
@@ -237,68 +261,207 @@ k_list_small(const int32_t *__restrict__ parent, const int32_t *__restrict__ csi
     }
 }
 
-// one thread = one small component: the reference's BFS (neighbour order +x, -x, +y, -y), recording
-// the component of the last already-labelled (smaller root) foreign neighbour
-__global__ void __launch_bounds__(64)
-k_small_bfs(const int32_t *__restrict__ list, const int32_t *__restrict__ counters, const int32_t *__restrict__ parent,
-            const int32_t *__restrict__ csize, int H, int W, int32_t *queue, uint8_t *visited, int32_t *cursor,
-            int32_t *adjptr)
-{
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= counters[CNT_SMALL]) return;
-    int root = list[i];
-    int size = csize[root];
-    int adj = -1;
-    if (size == 1) {
-        int p = root;
-        int y = p / W, x = p - y * W;
-        int nb[4] = { x + 1 < W ? p + 1 : -1, x > 0 ? p - 1 : -1, y + 1 < H ? p + W : -1, y > 0 ? p - W : -1 };
-        for (int j = 0; j < 4; ++j)
-            if (nb[j] >= 0) {
-                int c = parent[nb[j]];
-                if (c < root) adj = c;
-            }
-        adjptr[root] = adj;
-        return;
-    }
-    int base = atomicAdd(cursor, size);
-    int32_t *q = queue + base;
-    q[0] = root;
-    visited[root] = 1;
-    int qs = 1;
-    for (int v = 0; v < qs; ++v) {
-        int p = q[v];
-        int y = p / W, x = p - y * W;
-        int nb[4] = { x + 1 < W ? p + 1 : -1, x > 0 ? p - 1 : -1, y + 1 < H ? p + W : -1, y > 0 ? p - W : -1 };
-        for (int j = 0; j < 4; ++j) {
-            int t = nb[j];
-            if (t < 0) continue;
-            int c = parent[t];
-            if (c == root) {
-                if (!visited[t]) {
-                    visited[t] = 1;
-                    q[qs++] = t;
-                }
-            } else if (c < root) {
-                adj = c;
-            }
-        }
-    }
-    adjptr[root] = adj;
-}
-
 __global__ void __launch_bounds__(64)
 k_small_resolve(const int32_t *__restrict__ list, const int32_t *__restrict__ counters,
                 const int32_t *__restrict__ csize, const int32_t *__restrict__ adjptr, int min_size,
                 int32_t *newlabel)
 {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= counters[CNT_SMALL]) return;
-    int root = list[i];
-    int r = adjptr[root];
-    while (r >= 0 && csize[r] < min_size) r = adjptr[r];
-    // `adjacent = 0` when the BFS met no labelled neighbour (_slic.pyx); r is a kept root here
-    newlabel[root] = (r >= 0) ? newlabel[r] : 0;
+    const int n_small = counters[CNT_SMALL];
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n_small; i += gridDim.x * blockDim.x) {
+        int root = list[i];
+        int r = adjptr[root];
+        while (r >= 0 && csize[r] < min_size) r = adjptr[r];
+        // `adjacent = 0` when the BFS met no labelled neighbour (_slic.pyx); r is a kept root here
+        newlabel[root] = (r >= 0) ? newlabel[r] : 0;
+    }
+}
+
+// ---- cooperative BFS: one wave per small component -----------------------------------------------
+// bounding boxes of the small components (only their few pixels take part)
+__global__ void __launch_bounds__(256)
+k_small_bbox_init(int32_t *bbox, const int32_t *__restrict__ list, const int32_t *__restrict__ counters,
+                  int32_t *slotmap, int capacity)
+{
+    const int n_small = min(counters[CNT_SMALL], capacity);
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n_small; i += gridDim.x * blockDim.x) {
+        bbox[4 * i + 0] = 0x7fffffff;   // min y
+        bbox[4 * i + 1] = -1;           // max y
+        bbox[4 * i + 2] = 0x7fffffff;   // min x
+        bbox[4 * i + 3] = -1;           // max x
+        slotmap[list[i]] = i;
+    }
+}
+
+__global__ void __launch_bounds__(256)
+k_small_bbox(const int32_t *__restrict__ parent, const int32_t *__restrict__ csize, int n, int W, int min_size,
+             const int32_t *__restrict__ slotmap, int32_t *bbox, const int32_t *__restrict__ counters, int capacity)
+{
+    int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    int r = parent[p];
+    if (csize[r] >= min_size) return;
+    if (counters[CNT_SMALL] > capacity) return;     // table too small: the thread-BFS fallback takes all
+    int i = slotmap[r];
+    int y = p / W, x = p - y * W;
+    atomicMin(&bbox[4 * i + 0], y);
+    atomicMax(&bbox[4 * i + 1], y);
+    atomicMin(&bbox[4 * i + 2], x);
+    atomicMax(&bbox[4 * i + 3], x);
+}
+
+// Exact emulation of the reference's BFS (queue order, neighbour order +x, -x, +y, -y) by one wave:
+// level-synchronous, the frontier is kept in BFS-rank order.  Frontier element i proposes key
+// 4*i + d to each unvisited member neighbour (LDS atomicMin); the minimum key of a cell is its
+// first discovery, and compacting the winning keys in ascending order (ballot + popcount) yields
+// the next frontier in exactly the order the sequential queue would hold it.  `adjacent` is the
+// component of the foreign, already-labelled (smaller root) neighbour with the largest
+// (level, 4*i + d).  The bounding box (+1 ring) of the component is staged in LDS first.
+template <int CELLS, int FMAX>
+__global__ void __launch_bounds__(64)
+k_small_bfs_wave(const int32_t *__restrict__ list, int32_t *counters,
+                 const int32_t *__restrict__ parent, const int32_t *__restrict__ bbox, int H, int W, int lo_cells,
+                 int capacity, int32_t *adjptr, int32_t *fallback_list)
+{
+    __shared__ unsigned int prop[CELLS];
+    __shared__ uint8_t cls[CELLS];       // 0 other, 1 member unvisited, 2 earlier foreign, 3 member visited
+    __shared__ uint16_t fr[2][FMAX];
+    const int lane = threadIdx.x;
+    const int n_small = counters[CNT_SMALL];
+    if (n_small > capacity) return;
+    for (int ci = blockIdx.x; ci < n_small; ci += gridDim.x) {
+        const int root = list[ci];
+        const int y0 = max(bbox[4 * ci + 0] - 1, 0), y1 = min(bbox[4 * ci + 1] + 1, H - 1);
+        const int x0 = max(bbox[4 * ci + 2] - 1, 0), x1 = min(bbox[4 * ci + 3] + 1, W - 1);
+        const int bw = x1 - x0 + 1, bh = y1 - y0 + 1;
+        const int cells = bw * bh;
+        if (cells <= lo_cells) continue;           // handled by the launch with the smaller LDS tile
+        if (cells > CELLS) {
+            if (CELLS >= 8192 && lane == 0) fallback_list[atomicAdd(&counters[CNT_FALLBACK], 1)] = root;
+            continue;
+        }
+        __syncthreads();
+        for (int c = lane; c < cells; c += 64) {
+            int cy = c / bw, cx = c - cy * bw;
+            int q = parent[(size_t)(y0 + cy) * W + x0 + cx];
+            cls[c] = (q == root) ? 1 : (q < root ? 2 : 0);
+            prop[c] = 0xffffffffu;
+        }
+        const int ry = root / W, rx = root - ry * W;
+        const int seed = (ry - y0) * bw + (rx - x0);
+        __syncthreads();
+        if (lane == 0) {
+            fr[0][0] = (uint16_t)seed;
+            cls[seed] = 3;
+        }
+        int f = 1, cur = 0;
+        int adj_cell = -1;
+        bool failed = false;
+        __syncthreads();
+        while (f > 0) {
+            const int nkeys = 4 * f;
+            int best_key = -1, best_cell = -1;
+            // phase A: proposals + foreign neighbours
+            for (int key = lane; key < nkeys; key += 64) {
+                int c = fr[cur][key >> 2], d = key & 3;
+                int cy = c / bw, cx = c - cy * bw;
+                int ny = cy + (d == 2) - (d == 3), nx = cx + (d == 0) - (d == 1);
+                if (ny < 0 || ny >= bh || nx < 0 || nx >= bw) continue;
+                int nc = ny * bw + nx;
+                int t = cls[nc];
+                if (t == 1) atomicMin(&prop[nc], (unsigned int)key);
+                else if (t == 2) { best_key = key; best_cell = nc; }     // keys ascend per lane
+            }
+            // the last foreign contact of this level (largest key) overrides earlier levels
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) {
+                int ok = __shfl_xor(best_key, off, 64), oc = __shfl_xor(best_cell, off, 64);
+                if (ok > best_key) { best_key = ok; best_cell = oc; }
+            }
+            if (best_key >= 0) adj_cell = best_cell;
+            __syncthreads();
+            // phase B: winners, compacted in key order
+            int base = 0;
+            for (int k0 = 0; k0 < nkeys; k0 += 64) {
+                int key = k0 + lane;
+                bool win = false;
+                int nc = 0;
+                if (key < nkeys) {
+                    int c = fr[cur][key >> 2], d = key & 3;
+                    int cy = c / bw, cx = c - cy * bw;
+                    int ny = cy + (d == 2) - (d == 3), nx = cx + (d == 0) - (d == 1);
+                    if (ny >= 0 && ny < bh && nx >= 0 && nx < bw) {
+                        nc = ny * bw + nx;
+                        win = (cls[nc] == 1) && (prop[nc] == (unsigned int)key);
+                    }
+                }
+                unsigned long long m = __ballot(win);
+                if (win) {
+                    int pos = base + __popcll(m & ((1ULL << lane) - 1ULL));
+                    if (pos < FMAX) fr[cur ^ 1][pos] = (uint16_t)nc;
+                }
+                base += __popcll(m);
+            }
+            __syncthreads();
+            if (base > FMAX) { failed = true; break; }
+            for (int i = lane; i < base; i += 64) cls[fr[cur ^ 1][i]] = 3;
+            __syncthreads();
+            f = base;
+            cur ^= 1;
+        }
+        if (failed) {
+            if (lane == 0) fallback_list[atomicAdd(&counters[CNT_FALLBACK], 1)] = root;
+            continue;
+        }
+        if (lane == 0) {
+            int adj = -1;
+            if (adj_cell >= 0) {
+                int cy = adj_cell / bw, cx = adj_cell - cy * bw;
+                adj = parent[(size_t)(y0 + cy) * W + x0 + cx];
+            }
+            adjptr[root] = adj;
+        }
+    }
+}
+
+// thread-sequential BFS for the components the wave kernel could not take (huge bounding box)
+__global__ void __launch_bounds__(64)
+k_small_bfs_fallback(const int32_t *__restrict__ list_all, const int32_t *__restrict__ fallback_list,
+                     const int32_t *__restrict__ counters, const int32_t *__restrict__ parent,
+                     const int32_t *__restrict__ csize, int H, int W, int capacity, int32_t *queue, uint8_t *visited,
+                     int32_t *cursor, int32_t *adjptr)
+{
+    const bool all = counters[CNT_SMALL] > capacity;
+    const int count = all ? counters[CNT_SMALL] : counters[CNT_FALLBACK];
+    const int32_t *list = all ? list_all : fallback_list;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < count; i += gridDim.x * blockDim.x) {
+        int root = list[i];
+        int size = csize[root];
+        int adj = -1;
+        int base = atomicAdd(cursor, size);
+        int32_t *q = queue + base;
+        q[0] = root;
+        visited[root] = 1;
+        int qs = 1;
+        for (int v = 0; v < qs; ++v) {
+            int p = q[v];
+            int y = p / W, x = p - y * W;
+            int nb[4] = { x + 1 < W ? p + 1 : -1, x > 0 ? p - 1 : -1, y + 1 < H ? p + W : -1, y > 0 ? p - W : -1 };
+            for (int j = 0; j < 4; ++j) {
+                int t = nb[j];
+                if (t < 0) continue;
+                int c = parent[t];
+                if (c == root) {
+                    if (!visited[t]) {
+                        visited[t] = 1;
+                        q[qs++] = t;
+                    }
+                } else if (c < root) {
+                    adj = c;
+                }
+            }
+        }
+        adjptr[root] = adj;
+    }
 }
 
 __global__ void __launch_bounds__(256)
@@ -307,6 +470,53 @@ k_write_labels(const int32_t *__restrict__ parent, const int32_t *__restrict__ n
     int p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= n) return;
     out[p] = newlabel[parent[p]];
+}
+
+// CCL + sizes + oversize detection for the currently active pixels
+static void conn_ccl_round(const int32_t *labels_in, int H, int W, int max_size, const ConnWork &w, uint8_t *state,
+                           hipStream_t st)
+{
+    const int n = H * W, grid = cdiv(n, 256);
+    hipLaunchKernelGGL(k_ccl_init, grid, 256, 0, st, labels_in, state, w.parent, n, W);
+    hipLaunchKernelGGL(k_ccl_merge, grid, 256, 0, st, labels_in, state, w.parent, H, W);
+    hipLaunchKernelGGL(k_ccl_flatten, grid, 256, 0, st, w.parent, state, w.csize, n);
+    hipLaunchKernelGGL(k_comp_size, grid, 256, 0, st, w.parent, state, w.csize, n);
+    hipLaunchKernelGGL(k_find_oversize, grid, 256, 0, st, w.parent, state, w.csize, n, max_size, w.list, w.counters);
+}
+
+// everything after the component structure is final: consecutive labels for kept components,
+// `adjacent` of the small ones (exact BFS emulation), pointer resolution, label write.
+// No host round trip: list lengths stay on the device, the kernels loop over them.
+static int conn_tail(const int32_t *csize_final, int32_t *adjptr, int H, int W, int min_size, int start_label,
+                     const ConnWork &w, int32_t *labels_out, hipStream_t st)
+{
+    const int n = H * W, grid = cdiv(n, 256);
+    const int nblocks = cdiv(n, SCAN_BLOCK);
+    const int capacity = n / 8;                       // bbox table: 4 ints per small component
+    int32_t *bbox = w.bbox;
+    int32_t *fallback_list = w.bbox + (size_t)4 * capacity;
+    hipLaunchKernelGGL(k_kept_scan<false>, nblocks, 256, 0, st, w.parent, csize_final, n, min_size, w.blocksum,
+                       w.newlabel, start_label);
+    hipLaunchKernelGGL(k_scan_blocksums, 1, 256, 0, st, w.blocksum, nblocks, w.counters);
+    hipLaunchKernelGGL(k_kept_scan<true>, nblocks, 256, 0, st, w.parent, csize_final, n, min_size, w.blocksum,
+                       w.newlabel, start_label);
+    HIP_TRY(hipMemsetAsync(w.visited, 0, n, st));
+    HIP_TRY(hipMemsetAsync(w.counters + CNT_SMALL, 0, 2 * sizeof(int32_t), st));
+    HIP_TRY(hipMemsetAsync(w.counters + CNT_FALLBACK, 0, sizeof(int32_t), st));
+    hipLaunchKernelGGL(k_list_small, grid, 256, 0, st, w.parent, csize_final, n, min_size, w.list, w.counters);
+    hipLaunchKernelGGL(k_small_bbox_init, 64, 256, 0, st, bbox, w.list, w.counters, w.slotmap, capacity);
+    hipLaunchKernelGGL(k_small_bbox, grid, 256, 0, st, w.parent, csize_final, n, W, min_size, w.slotmap, bbox,
+                       w.counters, capacity);
+    hipLaunchKernelGGL((k_small_bfs_wave<1024, 256>), 2048, 64, 0, st, w.list, w.counters, w.parent, bbox, H, W, 0,
+                       capacity, adjptr, fallback_list);
+    hipLaunchKernelGGL((k_small_bfs_wave<8192, 2048>), 256, 64, 0, st, w.list, w.counters, w.parent, bbox, H, W, 1024,
+                       capacity, adjptr, fallback_list);
+    hipLaunchKernelGGL(k_small_bfs_fallback, 64, 64, 0, st, w.list, fallback_list, w.counters, w.parent, csize_final, H,
+                       W, capacity, w.queue, w.visited, w.counters + CNT_CURSOR, adjptr);
+    hipLaunchKernelGGL(k_small_resolve, 64, 64, 0, st, w.list, w.counters, csize_final, adjptr, min_size, w.newlabel);
+    hipLaunchKernelGGL(k_write_labels, grid, 256, 0, st, w.parent, w.newlabel, n, labels_out);
+    HIP_TRY(hipGetLastError());
+    return 0;
 }
 
 int launch_enforce_connectivity(const int32_t *labels_in, int H, int W, long min_size_l, long max_size_l,
@@ -318,62 +528,50 @@ int launch_enforce_connectivity(const int32_t *labels_in, int H, int W, long min
     const int min_size = (int)std::min<long>(min_size_l, 0x7fffffff);
     const int max_size = (int)std::min<long>(max_size_l, 0x7fffffff);
     uint8_t *state = w.visited + n;       // second half of the byte scratch (2 * n bytes)
-    int32_t *csize_final = w.adjptr;      // reused: final sizes are gathered here during the rounds
+    int32_t host_counters[16];
+
+    // fast path, speculating that no component reaches max_size: one CCL round, then the tail;
+    // a single host synchronisation at the very end reads the counters
     HIP_TRY(hipMemsetAsync(state, ST_ACTIVE, n, st));
     HIP_TRY(hipMemsetAsync(w.counters, 0, 16 * sizeof(int32_t), st));
-    int32_t host_counters[16];
-    for (int round = 0;; ++round) {
-        HIP_TRY(hipMemsetAsync(w.visited, 0, n, st));
-        HIP_TRY(hipMemsetAsync(w.counters, 0, 3 * sizeof(int32_t), st));
-        hipLaunchKernelGGL(k_ccl_init, grid, 256, 0, st, w.parent, state, n);
-        hipLaunchKernelGGL(k_ccl_merge, grid, 256, 0, st, labels_in, state, w.parent, H, W);
-        hipLaunchKernelGGL(k_ccl_flatten, grid, 256, 0, st, w.parent, state, w.csize, n);
-        hipLaunchKernelGGL(k_comp_size, grid, 256, 0, st, w.parent, state, w.csize, n);
-        hipLaunchKernelGGL(k_find_oversize, grid, 256, 0, st, w.parent, state, w.csize, n, max_size, w.list, w.counters);
-        HIP_TRY(hipMemcpyAsync(host_counters, w.counters, 4 * sizeof(int32_t), hipMemcpyDeviceToHost, st));
-        HIP_TRY(hipStreamSynchronize(st));
-        int n_over = host_counters[CNT_OVER];
-        if (n_over > 0) {
-            if ((long)n_over * max_size > (long)n) {
-                set_error("enforce_connectivity: internal queue overflow");
+    conn_ccl_round(labels_in, H, W, max_size, w, state, st);
+    if (conn_tail(w.csize, w.adjptr, H, W, min_size, start_label, w, labels_out, st)) return -1;
+    HIP_TRY(hipMemcpyAsync(host_counters, w.counters, 8 * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+
+    if (host_counters[CNT_OVER] > 0) {
+        // general path: truncate oversize components to their first max_size pixels in BFS order
+        // (exact sequential BFS by one thread each), re-label the left-overs, repeat
+        int32_t *csize_final = w.adjptr;      // final sizes are gathered here during the rounds
+        HIP_TRY(hipMemsetAsync(state, ST_ACTIVE, n, st));
+        for (int round = 0;; ++round) {
+            HIP_TRY(hipMemsetAsync(w.visited, 0, n, st));
+            HIP_TRY(hipMemsetAsync(w.counters, 0, 3 * sizeof(int32_t), st));
+            conn_ccl_round(labels_in, H, W, max_size, w, state, st);
+            HIP_TRY(hipMemcpyAsync(host_counters, w.counters, 4 * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipStreamSynchronize(st));
+            int n_over = host_counters[CNT_OVER];
+            if (n_over > 0) {
+                if ((long)n_over * max_size > (long)n) {
+                    set_error("enforce_connectivity: internal queue overflow");
+                    return -1;
+                }
+                hipLaunchKernelGGL(k_oversize_bfs, cdiv(n_over, 64), 64, 0, st, w.list, n_over, w.parent, state, H, W,
+                                   max_size, w.queue, w.visited, w.counters);
+            }
+            hipLaunchKernelGGL(k_oversize_commit, grid, 256, 0, st, w.parent, state, csize_final, w.csize, w.visited, n,
+                               max_size);
+            if (n_over == 0) break;
+            if (round > n) {
+                set_error("enforce_connectivity: did not converge");
                 return -1;
             }
-            hipLaunchKernelGGL(k_oversize_bfs, cdiv(n_over, 64), 64, 0, st, w.list, n_over, w.parent, state, H, W,
-                               max_size, w.queue, w.visited, w.counters);
         }
-        hipLaunchKernelGGL(k_oversize_commit, grid, 256, 0, st, w.parent, state, csize_final, w.csize, w.visited, n,
-                           max_size);
-        if (n_over == 0) break;
-        if (round > n) {
-            set_error("enforce_connectivity: did not converge");
-            return -1;
-        }
+        if (conn_tail(csize_final, w.csize, H, W, min_size, start_label, w, labels_out, st)) return -1;
+        HIP_TRY(hipMemcpyAsync(host_counters, w.counters, 8 * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
     }
-    // from here on: parent[p] = root of the final component, csize_final[root] = its size
-    const int nblocks = cdiv(n, SCAN_BLOCK);
-    hipLaunchKernelGGL(k_kept_scan<false>, nblocks, 256, 0, st, w.parent, csize_final, n, min_size, w.blocksum,
-                       w.newlabel, start_label);
-    hipLaunchKernelGGL(k_scan_blocksums, 1, 256, 0, st, w.blocksum, nblocks, w.counters);
-    hipLaunchKernelGGL(k_kept_scan<true>, nblocks, 256, 0, st, w.parent, csize_final, n, min_size, w.blocksum,
-                       w.newlabel, start_label);
-    HIP_TRY(hipMemsetAsync(w.visited, 0, n, st));
-    HIP_TRY(hipMemsetAsync(w.counters + CNT_SMALL, 0, 2 * sizeof(int32_t), st));
-    hipLaunchKernelGGL(k_list_small, grid, 256, 0, st, w.parent, csize_final, n, min_size, w.list, w.counters);
-    // the number of small components is only known on the device: launch for the worst case the
-    // grid can hold cheaply and let surplus threads exit (list length is read from counters)
-    HIP_TRY(hipMemcpyAsync(host_counters, w.counters, 4 * sizeof(int32_t), hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipStreamSynchronize(st));
-    int n_small = host_counters[CNT_SMALL];
     int n_kept = host_counters[CNT_KEPT];
-    if (n_small > 0) {
-        // adjptr aliases csize_final, so the BFS writes its result into w.csize (free now)
-        hipLaunchKernelGGL(k_small_bfs, cdiv(n_small, 64), 64, 0, st, w.list, w.counters, w.parent, csize_final, H, W,
-                           w.queue, w.visited, w.counters + CNT_CURSOR, w.csize);
-        hipLaunchKernelGGL(k_small_resolve, cdiv(n_small, 64), 64, 0, st, w.list, w.counters, csize_final, w.csize,
-                           min_size, w.newlabel);
-    }
-    hipLaunchKernelGGL(k_write_labels, grid, 256, 0, st, w.parent, w.newlabel, n, labels_out);
-    HIP_TRY(hipGetLastError());
     *n_labels_out_host = n_kept > 0 ? start_label + n_kept : 1;
     return 0;
 }

@@ -15,6 +15,15 @@ struct Taps {
     double w[17];
 };
 
+// tile geometry of the assignment kernel and the per-tile candidate records (64 bytes each)
+constexpr int SLIC_TILE_X = 64, SLIC_TILE_Y = 32, SLIC_MAXC = 64;
+struct Cand {
+    double cy, cx, cL, ca, cb;
+    int4 win;
+    int k;
+    int pad;
+};
+
 // device-side SLIC state for one 2-D image (all pointers are device pointers)
 struct SlicState {
     int H, W, K;
@@ -23,6 +32,10 @@ struct SlicState {
     double *cy, *cx, *cL, *ca, *cb; // centroid table, SoA fp64 [K]
     int4 *win;                      // integer search window {ymin, ymax, xmin, xmax} [K]
     long long *acc;                 // [K][9] = n, sum y, sum x, (hi, lo) fixed-point sums of L, a, b
+    Cand *tile_cands;               // [n_tiles][SLIC_MAXC] nearest-first candidate centroids per tile
+    int *tile_count;                // [n_tiles] list length (negative: more than the list holds)
+    int *leftover;                  // [N] pixels to be accumulated by k_slic_leftover
+    int *leftover_count;            // [1]
 };
 
 int launch_minmax(const void *src, int dtype, size_t n, unsigned long long *keys, double *out2, hipStream_t st);
@@ -49,6 +62,8 @@ struct ConnWork {
     int32_t *blocksum;    // [nblocks + 1]
     int32_t *list;        // [N] compacted list of component roots
     int32_t *counters;    // [16] misc device counters
+    int32_t *slotmap;     // [N] root -> index in the small-component list
+    int32_t *bbox;        // [N] bounding boxes of small components (N/8 x 4) + fallback list (N/2)
 };
 int launch_enforce_connectivity(const int32_t *labels_in, int H, int W, long min_size, long max_size,
                                 int start_label, ConnWork w, int32_t *labels_out, int *n_labels_out_host,

@@ -27,6 +27,26 @@ __host__ __device__ __forceinline__ double key_f64(unsigned long long k)
     return cv.d;
 }
 
+// wave reduce, block reduce through LDS, then ONE atomic pair per block (a per-wave atomic on the
+// same two words serialises at ~12 ns each)
+__device__ __forceinline__ void block_minmax_commit(double mn, double mx, unsigned long long *keys)
+{
+    __shared__ double smn[4], smx[4];
+    mn = wave_min_f64(mn);
+    mx = wave_max_f64(mx);
+    if ((threadIdx.x & 63) == 0) {
+        smn[threadIdx.x >> 6] = mn;
+        smx[threadIdx.x >> 6] = mx;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        mn = fmin(fmin(smn[0], smn[1]), fmin(smn[2], smn[3]));
+        mx = fmax(fmax(smx[0], smx[1]), fmax(smx[2], smx[3]));
+        atomicMin(&keys[0], f64_key(mn));
+        atomicMax(&keys[1], f64_key(mx));
+    }
+}
+
 template <typename T>
 __global__ void __launch_bounds__(256) k_minmax(const T *__restrict__ src, size_t n, unsigned long long *keys)
 {
@@ -37,12 +57,7 @@ __global__ void __launch_bounds__(256) k_minmax(const T *__restrict__ src, size_
         mn = fmin(mn, v);
         mx = fmax(mx, v);
     }
-    mn = wave_min_f64(mn);
-    mx = wave_max_f64(mx);
-    if ((threadIdx.x & 63) == 0) {
-        atomicMin(&keys[0], f64_key(mn));
-        atomicMax(&keys[1], f64_key(mx));
-    }
+    block_minmax_commit(mn, mx, keys);
 }
 
 // uint8 variant: 16 bytes per lane
@@ -70,11 +85,7 @@ __global__ void __launch_bounds__(256) k_minmax_u8(const uint8_t *__restrict__ s
             mn = min(mn, v);
             mx = max(mx, v);
         }
-    double dmn = wave_min_f64((double)mn), dmx = wave_max_f64((double)mx);
-    if ((threadIdx.x & 63) == 0) {
-        atomicMin(&keys[0], f64_key(dmn));
-        atomicMax(&keys[1], f64_key(dmx));
-    }
+    block_minmax_commit((double)mn, (double)mx, keys);
 }
 
 __global__ void k_minmax_init(unsigned long long *keys)
@@ -91,7 +102,7 @@ __global__ void k_minmax_decode(const unsigned long long *keys, double *out)
 int launch_minmax(const void *src, int dtype, size_t n, unsigned long long *keys, double *out2, hipStream_t st)
 {
     hipLaunchKernelGGL(k_minmax_init, 1, 1, 0, st, keys);
-    int grid = (int)std::min<size_t>(2048, (n + 256 * 16 - 1) / (256 * 16));
+    int grid = (int)std::min<size_t>(512, (n + 256 * 16 - 1) / (256 * 16));
     if (grid < 1) grid = 1;
     if (dtype == DT_U8)
         hipLaunchKernelGGL(k_minmax_u8, grid, 256, 0, st, (const uint8_t *)src, n, keys);
@@ -272,6 +283,7 @@ __global__ void k_centroid_init(SlicState s, const double *__restrict__ init_yx)
     s.cb[k] = 0.0;
     s.win[k] = search_window(cy, cx, s.step_y, s.step_x, s.H, s.W);
     for (int j = 0; j < 9; ++j) s.acc[(size_t)k * 9 + j] = 0;
+    if (k == 0) *s.leftover_count = 0;
 }
 
 // divide the accumulated sums, recompute the integer search windows, clear the accumulators.
@@ -279,6 +291,7 @@ __global__ void k_centroid_init(SlicState s, const double *__restrict__ init_yx)
 __global__ void k_centroid_finalize(SlicState s)
 {
     int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k == 0) *s.leftover_count = 0;
     if (k >= s.K) return;
     long long *a = s.acc + (size_t)k * 9;
     long long n = a[0];
@@ -302,18 +315,69 @@ __global__ void k_centroid_finalize(SlicState s)
 // ---------------------------------------------------------------------------------------------
 // assignment + fused accumulation
 // ---------------------------------------------------------------------------------------------
-constexpr int TILE_X = 64;     // one pixel column per lane
-constexpr int ROWS = 8;        // rows per lane
-constexpr int WAVES = 4;       // waves per workgroup
+constexpr int TILE_X = SLIC_TILE_X;   // one pixel column per lane
+constexpr int ROWS = 8;              // rows per lane
+constexpr int WAVES = 4;             // waves per workgroup
 constexpr int TILE_Y = ROWS * WAVES;
-constexpr int MAXC = 192;      // LDS-resident candidate centroids per tile
+static_assert(TILE_Y == SLIC_TILE_Y, "tile geometry");
+constexpr int MAXC = SLIC_MAXC;
 
-struct Cand {
-    double cy, cx, cL, ca, cb;
-    int4 win;
-    int k;
-    int pad;
-};
+// ---- per-tile candidate lists ----------------------------------------------------------------
+// One wave per 64 x 32 pixel tile collects the centroids whose search window intersects the tile,
+// sorts them nearest-first and writes them as 64-byte records.  The assignment kernel then walks
+// its list with wave-uniform (scalar) loads: no LDS staging, no barriers in front of the hot loop.
+__global__ void __launch_bounds__(64)
+k_slic_bin(SlicState s, int tiles_x, int max_cand, Cand *__restrict__ tile_cands, int *__restrict__ tile_count)
+{
+    __shared__ int ck[MAXC];
+    __shared__ float ckey[MAXC];
+    const int lane = threadIdx.x;
+    const int tile = blockIdx.x;
+    const int tx0 = (tile % tiles_x) * TILE_X, ty0 = (tile / tiles_x) * TILE_Y;
+    const int tx1 = min(tx0 + TILE_X, s.W), ty1 = min(ty0 + TILE_Y, s.H);
+    int count = 0;
+    for (int k0 = 0; k0 < s.K; k0 += 64) {
+        int k = k0 + lane;
+        bool hit = false;
+        float key = 0.f;
+        if (k < s.K) {
+            int4 w = s.win[k];
+            hit = w.x < ty1 && w.y > ty0 && w.z < tx1 && w.w > tx0;
+            // heuristic sort key: squared distance of the window centre to the tile centre
+            float my = 0.5f * (float)(w.x + w.y) - 0.5f * (float)(ty0 + ty1);
+            float mx = 0.5f * (float)(w.z + w.w) - 0.5f * (float)(tx0 + tx1);
+            key = my * my + mx * mx;
+        }
+        unsigned long long m = __ballot(hit);
+        if (hit) {
+            int pos = count + __popcll(m & ((1ULL << lane) - 1ULL));
+            if (pos < MAXC) {
+                ck[pos] = k;
+                ckey[pos] = key;
+            }
+        }
+        count += __popcll(m);
+    }
+    __syncthreads();
+    const bool overflow = count > max_cand;
+    if (lane == 0) tile_count[tile] = overflow ? -count : count;
+    if (overflow) return;
+    for (int c = lane; c < count; c += 64) {
+        const float key = ckey[c];
+        int rank = 0;
+        for (int j = 0; j < count; ++j) {
+            float kj = ckey[j];
+            rank += (kj < key) || (kj == key && j < c);
+        }
+        const int k = ck[c];
+        Cand cd;
+        cd.cy = s.cy[k]; cd.cx = s.cx[k]; cd.cL = s.cL[k]; cd.ca = s.ca[k]; cd.cb = s.cb[k];
+        cd.win = s.win[k];
+        cd.k = k;
+        cd.pad = 0;
+        tile_cands[(size_t)tile * MAXC + rank] = cd;
+    }
+}
 
 // direct (slow, always correct) accumulation of one pixel into the global accumulators
 __device__ __forceinline__ void accumulate_global(long long *acc, int k, int y, int x, double L, double A, double B)
@@ -334,48 +398,75 @@ __device__ __forceinline__ void accumulate_global(long long *acc, int k, int y, 
     atomic_add_i64(a + 8, lo);
 }
 
+// One distance evaluation of _slic.pyx (2-D, unit spacing) -- the operation order IS the contract:
+//   dist_center = (dy*dy + dx*dx) * spatial_weight;  dist_color = ((dL*dL) + da*da) + db*db;
+//   dist_center += dist_color
+// Pruning (exact): colour distance >= 0 and rounding is monotone, hence d >= dc = (dy2 + dx2) * sw.
+// A candidate whose dc exceeds the best distance found so far can never win and is skipped without
+// touching its colour; `<=` keeps ties (resolved by the lowest centroid index, as the ascending-k
+// loop with a strict `>` of the reference does).
+#define SLIC_EVAL_ROW(r)                                                                          \
+    {                                                                                             \
+        const int y = wy0 + (r);                                                                  \
+        if (y >= w.x && y < w.y) {                                                                \
+            const double ty = cy - (double)y;                                                     \
+            const double dy2 = ty * ty;                                                           \
+            const double dc = (dy2 + dx2) * sw;                                                   \
+            const bool pass = inx && (dc <= best_d[r]);                                           \
+            if (__any(pass)) {                                                                    \
+                double t0 = pL[r] - cL, t1 = pA[r] - ca, t2 = pB[r] - cb;                         \
+                double col = t0 * t0;                                                             \
+                col = col + t1 * t1;                                                              \
+                col = col + t2 * t2;                                                              \
+                const double d = dc + col;                                                        \
+                bool better = pass && (best_d[r] > d);                                            \
+                if (pass && best_d[r] == d) better = k < cand[best_s[r]].k;   /* exact tie: rare */ \
+                if (better) {                                                                     \
+                    best_d[r] = d;                                                                \
+                    best_s[r] = c;                                                                \
+                }                                                                                 \
+            }                                                                                     \
+        }                                                                                         \
+    }
+
+// pixels the assignment kernel could not accumulate through its LDS slots (see there)
+__global__ void __launch_bounds__(256)
+k_slic_leftover(SlicState s, const double *__restrict__ lab, const int32_t *__restrict__ labels)
+{
+    const int count = *s.leftover_count;
+    const size_t plane = (size_t)s.H * s.W;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < count; i += gridDim.x * blockDim.x) {
+        int p = s.leftover[i];
+        int k = labels[p];
+        if (k < 0) continue;            // never assigned so far: counted nowhere (as in the oracle)
+        int y = p / s.W, x = p - y * s.W;
+        accumulate_global(s.acc, k, y, x, lab[p], lab[plane + p], lab[2 * plane + p]);
+    }
+}
+
 // ACCUM: also accumulate the centroid sums (all iterations but the last)
 template <bool ACCUM>
 __global__ void __launch_bounds__(256)
-k_slic_assign(SlicState s, const double *__restrict__ lab, int32_t *__restrict__ labels, int max_cand)
+k_slic_assign(SlicState s, const double *__restrict__ lab, int32_t *__restrict__ labels,
+              const Cand *__restrict__ tile_cands, const int *__restrict__ tile_count)
 {
-    __shared__ Cand cand[MAXC];
     __shared__ long long lacc[MAXC][9];
-    __shared__ int n_cand;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
+    const int tile = blockIdx.y * gridDim.x + blockIdx.x;
     const int tx0 = blockIdx.x * TILE_X, ty0 = blockIdx.y * TILE_Y;
-    const int tx1 = min(tx0 + TILE_X, s.W), ty1 = min(ty0 + TILE_Y, s.H);
+    const int tx1 = min(tx0 + TILE_X, s.W);
     const size_t plane = (size_t)s.H * s.W;
+    const Cand *__restrict__ cand = tile_cands + (size_t)tile * MAXC;
 
-    if (tid == 0) n_cand = 0;
-    __syncthreads();
-    for (int k = tid; k < s.K; k += 256) {
-        int4 w = s.win[k];
-        if (w.x < ty1 && w.y > ty0 && w.z < tx1 && w.w > tx0) {
-            int slot = atomicAdd(&n_cand, 1);
-            if (slot < max_cand) cand[slot].k = k;
-        }
-    }
-    __syncthreads();
-    const int total = n_cand;
-    const bool overflow = total > max_cand;      // block-uniform
+    const int total = tile_count[tile];
+    const bool overflow = total < 0;             // block-uniform
     const int nc = overflow ? 0 : total;
-    for (int c = tid; c < nc; c += 256) {
-        int k = cand[c].k;
-        cand[c].cy = s.cy[k];
-        cand[c].cx = s.cx[k];
-        cand[c].cL = s.cL[k];
-        cand[c].ca = s.ca[k];
-        cand[c].cb = s.cb[k];
-        cand[c].win = s.win[k];
-        if (ACCUM) {
-#pragma unroll
-            for (int j = 0; j < 9; ++j) lacc[c][j] = 0;
-        }
+    if (ACCUM) {
+        for (int i = tid; i < nc * 9; i += 256) (&lacc[0][0])[i] = 0;
+        __syncthreads();
     }
-    __syncthreads();
 
     const int x = tx0 + lane;
     const int wy0 = ty0 + wave * ROWS;
@@ -384,7 +475,7 @@ k_slic_assign(SlicState s, const double *__restrict__ lab, int32_t *__restrict__
     const double sw = s.spatial_weight;
 
     double pL[ROWS], pA[ROWS], pB[ROWS], best_d[ROWS];
-    int best_s[ROWS], best_k[ROWS];
+    int best_s[ROWS];      // slot in the tile's candidate list; -1 none yet; <= -2: centroid -(k + 2) (no list)
 #pragma unroll
     for (int r = 0; r < ROWS; ++r) {
         int y = wy0 + r;
@@ -395,41 +486,40 @@ k_slic_assign(SlicState s, const double *__restrict__ lab, int32_t *__restrict__
         pB[r] = lab[2 * plane + p];
         best_d[r] = DBL_MAX;
         best_s[r] = -1;
-        best_k[r] = 0x7fffffff;
     }
 
     if (!overflow) {
+        constexpr int PHASE1 = 4;     // candidates evaluated before the per-lane bound is formed
+        double mb = DBL_MAX;          // upper bound of this lane's best distances (stale = still valid)
         for (int c = 0; c < nc; ++c) {
             const int4 w = cand[c].win;
+            if (c == PHASE1) {
+                mb = best_d[0];
+#pragma unroll
+                for (int r = 1; r < ROWS; ++r) mb = fmax(mb, best_d[r]);
+            }
             if (w.x >= wy0 + ROWS || w.y <= wy0) continue;   // wave-uniform: no row of this wave in the window
             const int k = cand[c].k;
-            const double cy = cand[c].cy, cx = cand[c].cx, cL = cand[c].cL, ca = cand[c].ca, cb = cand[c].cb;
+            const double cy = cand[c].cy, cx = cand[c].cx;
             const bool inx = (x >= w.z) && (x < w.w);
             const double tx = cx - fx;
             const double dx2 = tx * tx;
-#pragma unroll
-            for (int r = 0; r < ROWS; ++r) {
-                const int y = wy0 + r;
-                if (y < w.x || y >= w.y) continue;            // wave-uniform
-                const double ty = cy - (double)y;
-                const double dy2 = ty * ty;
-                double d = (dy2 + dx2) * sw;
-                double t0 = pL[r] - cL, t1 = pA[r] - ca, t2 = pB[r] - cb;
-                double col = t0 * t0;
-                col = col + t1 * t1;
-                col = col + t2 * t2;
-                d = d + col;
-                bool better = inx && ((best_d[r] > d) || (best_d[r] == d && k < best_k[r]));
-                if (better) {
-                    best_d[r] = d;
-                    best_s[r] = c;
-                    best_k[r] = k;
-                }
+            if (c >= PHASE1) {
+                // exact lower bound of dc over the rows of this wave: |cy - y| is smallest at the row
+                // nearest to cy (0 if cy lies inside the row range); same operations, monotone rounding
+                double tyb = 0.0;
+                if (cy < (double)wy0) tyb = cy - (double)wy0;
+                else if (cy > (double)(wy0 + ROWS - 1)) tyb = cy - (double)(wy0 + ROWS - 1);
+                const double lb = (tyb * tyb + dx2) * sw;
+                if (!__any(inx && lb <= mb)) continue;
             }
+            const double cL = cand[c].cL, ca = cand[c].ca, cb = cand[c].cb;
+            SLIC_EVAL_ROW(0) SLIC_EVAL_ROW(1) SLIC_EVAL_ROW(2) SLIC_EVAL_ROW(3)
+            SLIC_EVAL_ROW(4) SLIC_EVAL_ROW(5) SLIC_EVAL_ROW(6) SLIC_EVAL_ROW(7)
         }
     } else {
         // more candidate centroids than LDS slots (pathological clustering, or forced by tests):
-        // scan the whole table from global memory
+        // scan the whole table from global memory in ascending k (strict '>' keeps the lowest k)
         for (int k = 0; k < s.K; ++k) {
             const int4 w = s.win[k];
             if (!(w.x < wy0 + ROWS && w.y > wy0 && w.z < tx1 && w.w > tx0)) continue;
@@ -449,39 +539,37 @@ k_slic_assign(SlicState s, const double *__restrict__ lab, int32_t *__restrict__
                 col = col + t1 * t1;
                 col = col + t2 * t2;
                 d = d + col;
-                bool better = inx && (best_d[r] > d);     // ascending k: strict '>' keeps the lowest k
-                if (better) {
+                if (inx && (best_d[r] > d)) {
                     best_d[r] = d;
-                    best_s[r] = -2;                       // "assigned, but no LDS slot"
-                    best_k[r] = k;
+                    best_s[r] = -(k + 2);                 // assigned, but no list slot
                 }
             }
         }
     }
 
-    // labels: a pixel no window covers keeps its previous assignment (nearest_segments persists in _slic.pyx)
+    // labels: a pixel no window covers keeps its previous assignment (nearest_segments persists in
+    // _slic.pyx).  Such pixels, and the pixels of tiles without an LDS candidate list, are queued for
+    // k_slic_leftover, which adds them to the centroid sums with plain global atomics (rare).
     unsigned pending = 0;
 #pragma unroll
     for (int r = 0; r < ROWS; ++r) {
         int y = wy0 + r;
         if (!(xin && y < s.H)) continue;
-        size_t p = (size_t)y * s.W + x;
-        if (best_s[r] == -1) {
-            int prev = labels[p];
-            best_k[r] = prev;
-            if (ACCUM && prev >= 0) accumulate_global(s.acc, prev, y, x, pL[r], pA[r], pB[r]);
-        } else {
-            labels[p] = best_k[r];
-            if (best_s[r] == -2) {
-                if (ACCUM) accumulate_global(s.acc, best_k[r], y, x, pL[r], pA[r], pB[r]);
-            } else {
-                pending |= 1u << r;
-            }
+        int p = y * s.W + x;
+        if (best_s[r] >= 0) {
+            labels[p] = cand[best_s[r]].k;
+            pending |= 1u << r;
+        } else if (best_s[r] <= -2) {
+            labels[p] = -(best_s[r] + 2);
         }
+        if (best_s[r] >= 0) continue;
+        if (ACCUM) s.leftover[atomicAdd(s.leftover_count, 1)] = p;
     }
     if (!ACCUM) return;
 
-    // wave-level segmented reduction: one pass per distinct LDS slot present in this wave
+    // wave-level segmented reduction: one pass per distinct LDS slot present in this wave; the eight
+    // partial sums are reduced with the transposed scheme (10 exchanges) and lanes 0, 8, .., 56 each
+    // add one of them into the workgroup's LDS accumulators
     while (true) {
         int first = -1;
 #pragma unroll
@@ -491,42 +579,47 @@ k_slic_assign(SlicState s, const double *__restrict__ lab, int32_t *__restrict__
         if (vote == 0) break;
         int leader = __ffsll((long long)vote) - 1;
         int slot = __shfl(first, leader, 64);
-        int n = 0, sy = 0, sx = 0;
-        long long Lh = 0, Ll = 0, Ah = 0, Al = 0, Bh = 0, Bl = 0;
+        // Per-lane partial sums.  The two fixed-point limbs of every colour value are integer-valued
+        // doubles (|limb| < 2^45), so their sums over the <= 512 pixels of this wave are exact in
+        // fp64 and are only converted to int64 once, by the lane that owns the wave total.
+        double qd[6] = { 0, 0, 0, 0, 0, 0 };
+        long long qn = 0, qx = 0;
 #pragma unroll
         for (int r = 0; r < ROWS; ++r) {
             if ((pending & (1u << r)) && best_s[r] == slot) {
-                long long hi, lo;
-                n += 1;
-                sy += wy0 + r;
-                sx += x;
-                fix_split(pL[r], hi, lo); Lh += hi; Ll += lo;
-                fix_split(pA[r], hi, lo); Ah += hi; Al += lo;
-                fix_split(pB[r], hi, lo); Bh += hi; Bl += lo;
+                double t, h;
+                t = pL[r] * 1073741824.0; h = trunc(t); qd[0] += h; qd[1] += trunc((t - h) * 4294967296.0);
+                t = pA[r] * 1073741824.0; h = trunc(t); qd[2] += h; qd[3] += trunc((t - h) * 4294967296.0);
+                t = pB[r] * 1073741824.0; h = trunc(t); qd[4] += h; qd[5] += trunc((t - h) * 4294967296.0);
+                qn += 1 + ((long long)(wy0 + r) << 12);      // n (<= 512 per wave) | sum y << 12
+                qx += x;
                 pending &= ~(1u << r);
             }
         }
-        n = wave_sum_i32(n);
-        sy = wave_sum_i32(sy);
-        sx = wave_sum_i32(sx);
-        Lh = wave_sum_i64(Lh); Ll = wave_sum_i64(Ll);
-        Ah = wave_sum_i64(Ah); Al = wave_sum_i64(Al);
-        Bh = wave_sum_i64(Bh); Bl = wave_sum_i64(Bl);
-        if (lane == 0) {
+        long long q[8];
+#pragma unroll
+        for (int j = 0; j < 6; ++j) q[j] = __double_as_longlong(qd[j]);
+        q[6] = qn;
+        q[7] = qx;
+        long long tot = wave_reduce8_mixed(q);
+        if ((lane & 7) == 0) {
             long long *a = lacc[slot];
-            atomic_add_i64(a + 0, n); atomic_add_i64(a + 1, sy); atomic_add_i64(a + 2, sx);
-            atomic_add_i64(a + 3, Lh); atomic_add_i64(a + 4, Ll);
-            atomic_add_i64(a + 5, Ah); atomic_add_i64(a + 6, Al);
-            atomic_add_i64(a + 7, Bh); atomic_add_i64(a + 8, Bl);
+            int j = lane >> 3;
+            if (j < 6) {
+                atomic_add_i64(a + 3 + j, (long long)__longlong_as_double(tot));
+            } else if (j == 6) {
+                atomic_add_i64(a + 0, tot & 0xfff);
+                atomic_add_i64(a + 1, tot >> 12);
+            } else {
+                atomic_add_i64(a + 2, tot);
+            }
         }
     }
     __syncthreads();
     for (int i = tid; i < nc * 9; i += 256) {
         int c = i / 9, j = i - 9 * c;
-        if (lacc[c][0] != 0) {
-            long long v = lacc[c][j];
-            if (v != 0) atomic_add_i64(s.acc + (size_t)cand[c].k * 9 + j, v);
-        }
+        long long v = lacc[c][j];
+        if (v != 0) atomic_add_i64(s.acc + (size_t)cand[c].k * 9 + j, v);
     }
 }
 
@@ -538,14 +631,19 @@ int launch_slic_iterations(SlicState s, const double *lab, const double *init_yx
     HIP_TRY(hipMemsetAsync(labels, 0xff, n * sizeof(int32_t), st));       // nearest = -1
     hipLaunchKernelGGL(k_centroid_init, cdiv(s.K, 256), 256, 0, st, s, init_yx_dev);
     dim3 grid(cdiv(s.W, TILE_X), cdiv(s.H, TILE_Y));
+    const int n_tiles = grid.x * grid.y;
     for (int it = 0; it < max_iter; ++it) {
+        hipLaunchKernelGGL(k_slic_bin, n_tiles, 64, 0, st, s, (int)grid.x, max_cand, s.tile_cands, s.tile_count);
         int span = prof.begin ? prof.begin(prof.user, 0) : -1;
         if (it + 1 < max_iter)
-            hipLaunchKernelGGL(k_slic_assign<true>, grid, 256, 0, st, s, lab, labels, max_cand);
+            hipLaunchKernelGGL(k_slic_assign<true>, grid, 256, 0, st, s, lab, labels, s.tile_cands, s.tile_count);
         else
-            hipLaunchKernelGGL(k_slic_assign<false>, grid, 256, 0, st, s, lab, labels, max_cand);
+            hipLaunchKernelGGL(k_slic_assign<false>, grid, 256, 0, st, s, lab, labels, s.tile_cands, s.tile_count);
         if (prof.end) prof.end(prof.user, span);
-        if (it + 1 < max_iter) hipLaunchKernelGGL(k_centroid_finalize, cdiv(s.K, 256), 256, 0, st, s);
+        if (it + 1 < max_iter) {
+            hipLaunchKernelGGL(k_slic_leftover, 64, 256, 0, st, s, lab, labels);
+            hipLaunchKernelGGL(k_centroid_finalize, cdiv(s.K, 256), 256, 0, st, s);
+        }
     }
     HIP_TRY(hipGetLastError());
     return 0;

@@ -74,15 +74,17 @@ k_color_stats(const T *__restrict__ img, const int32_t *__restrict__ labels, Sta
             unsigned long long vote = __ballot(first >= 0);
             if (!vote) break;
             int k = __shfl(first, __ffsll((long long)vote) - 1, 64);
-            int n = 0;
-            long long q[12];
+            // partial sums of this lane: PASS 1 -> q[0..5] sums of v, q[6..11] sums of v*v, q[12] count
+            //                            PASS 2 -> q[0..5] sums of (v - mean32)^2
+            constexpr int NV = (PASS == 1) ? 16 : 8;
+            long long q[NV];
 #pragma unroll
-            for (int j = 0; j < 12; ++j) q[j] = 0;
+            for (int j = 0; j < NV; ++j) q[j] = 0;
 #pragma unroll
             for (int i = 0; i < ST_PX; ++i) {
                 if (lab[i] != k) continue;
                 lab[i] = -1;
-                n += 1;
+                if (PASS == 1) q[12] += 1;
 #pragma unroll
                 for (int c = 0; c < 3; ++c) {
                     long long hi, lo;
@@ -101,35 +103,39 @@ k_color_stats(const T *__restrict__ img, const int32_t *__restrict__ labels, Sta
                     }
                 }
             }
-            n = wave_sum_i32(n);
-            constexpr int NS = (PASS == 1) ? 12 : 6;
-#pragma unroll
-            for (int j = 0; j < NS; ++j) q[j] = wave_sum_i64(q[j]);
+            // transposed wave reduction: lane (64 / NV) * j ends up with the total of q[j]
+            long long tot;
+            int j;
+            bool owner;
+            if (PASS == 1) {
+                tot = wave_reduce16_i64(reinterpret_cast<const long long (&)[16]>(q));
+                j = lane >> 2;
+                owner = (lane & 3) == 0 && j < 13;
+            } else {
+                tot = wave_reduce8_i64(reinterpret_cast<const long long (&)[8]>(q));
+                j = lane >> 3;
+                owner = (lane & 7) == 0 && j < 6;
+            }
+            // LDS open-addressing slot for label k (found by lane 0); full table -> global memory
+            int slot = -1;
             if (lane == 0) {
-                // LDS open-addressing slot for label k; full table -> straight to global memory
-                int slot = k & (ST_SLOTS - 1), probes = 0;
+                int sidx = k & (ST_SLOTS - 1), probes = 0;
                 while (probes < ST_SLOTS) {
-                    int old = atomicCAS(&keys[slot], -1, k);
+                    int old = atomicCAS(&keys[sidx], -1, k);
                     if (old == -1 || old == k) break;
-                    slot = (slot + 1) & (ST_SLOTS - 1);
+                    sidx = (sidx + 1) & (ST_SLOTS - 1);
                     ++probes;
                 }
-                if (probes < ST_SLOTS) {
-                    if (PASS == 1) {
-                        atomic_add_i64(&lacc[slot][0], n);
-                        for (int j = 0; j < 12; ++j) atomic_add_i64(&lacc[slot][1 + j], q[j]);
-                    } else {
-                        for (int j = 0; j < 6; ++j) atomic_add_i64(&lacc[slot][j], q[j]);
-                    }
-                } else {
-                    long long *a = acc + (size_t)k * 13;
-                    if (PASS == 1) {
-                        atomic_add_i64(a, n);
-                        for (int j = 0; j < 12; ++j) atomic_add_i64(a + 1 + j, q[j]);
-                    } else {
-                        for (int j = 0; j < 6; ++j) atomic_add_i64(a + 7 + j, q[j]);   // reuse the v*v columns
-                    }
-                }
+                slot = probes < ST_SLOTS ? sidx : -1;
+            }
+            slot = __shfl(slot, 0, 64);
+            if (owner && tot != 0) {
+                // accumulator columns: [0] count, [1..6] value sums, [7..12] squared / variance sums
+                int col = (PASS == 1) ? (j == 12 ? 0 : 1 + j) : j;
+                if (slot >= 0)
+                    atomic_add_i64(&lacc[slot][col], tot);
+                else
+                    atomic_add_i64(acc + (size_t)k * 13 + ((PASS == 1) ? col : 7 + col), tot);
             }
         }
     }

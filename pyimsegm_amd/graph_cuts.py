@@ -223,12 +223,15 @@ def compute_spatial_dist(centres, edges, relative=False):
     """
     if np.max(edges) >= len(centres):
         raise ValueError('max vertex %i exceed size of centres %i' % (np.max(edges), len(centres)))
-    centres = list(centres)
-    ndim = np.max([len(c) for c in centres if c is not None])
-    for i, c in enumerate(centres):
-        if c is None or len(c) == 0:
-            centres[i] = [np.nan] * ndim
-    centres = np.nan_to_num(np.asarray(centres, dtype=np.float64))
+    if isinstance(centres, np.ndarray) and centres.ndim == 2 and centres.dtype == np.float64:
+        centres = np.nan_to_num(centres)      # dense table straight from the device
+    else:
+        centres = list(centres)
+        ndim = np.max([len(c) for c in centres if c is not None])
+        for i, c in enumerate(centres):
+            if c is None or len(c) == 0:
+                centres[i] = [np.nan] * ndim
+        centres = np.nan_to_num(np.asarray(centres, dtype=np.float64))
     edges = np.asarray(edges)
     dist = metrics.pairwise.paired_euclidean_distances(centres[edges[:, 0]], centres[edges[:, 1]])
     if relative:
@@ -396,9 +399,8 @@ def compute_edge_weights(segments, image=None, features=None, proba=None, edge_t
 
     edge_weights = np.array(edge_weights, dtype=float)
     if edge_type in ['model', 'features', 'color', 'spatial']:
-        if centre_list is None:
-            centre_list = [tuple(c) if ok else [-1, -1] for c, ok in zip(centres.tolist(), present)]
-        edge_weights /= compute_spatial_dist(centre_list, edges, relative=True)
+        # device centres already hold [-1, -1] for unused labels (superpixels.py:218 semantics)
+        edge_weights /= compute_spatial_dist(centres if centre_list is None else centre_list, edges, relative=True)
 
     edge_weights[edge_weights < 1. / MIN_MAX_EDGE_WEIGHT] = 1. / MIN_MAX_EDGE_WEIGHT
     edge_weights[edge_weights > MIN_MAX_EDGE_WEIGHT] = MIN_MAX_EDGE_WEIGHT
