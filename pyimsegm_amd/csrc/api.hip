@@ -3,6 +3,7 @@
 #include "slic.h"
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -382,6 +383,19 @@ int imsegm_image2d_slic(imsegm_image2d *im, int minmax_normalize, int n_segments
     s.step_y = axk[1].all ? 1 : (int)axk[1].step;
     s.step_x = axk[2].all ? 1 : (int)axk[2].step;
     s.spatial_weight = 1.0 / ((double)step * (double)step);
+    s.debug = getenv("IMSEGM_DEBUG_ASSIGN") ? atoi(getenv("IMSEGM_DEBUG_ASSIGN")) : 0;
+    {
+        // fp32 pre-selection margin (k_slic_assign): valid when the image entering rgb2lab lies in
+        // [0, 1] (then |L|, |a|, |b| <= 108 before and after the convex blur), i.e. whenever the
+        // min-max scaling is applied or the data already spans exactly [0, 1]
+        const double u = 5.9604644775390625e-8;                      // 2^-24
+        const double M = 108.0 * (1.0 / compactness) * 1.001;
+        const double R = 2.0 * std::max(s.step_y, s.step_x) + 1.0;
+        const double E = 3.0 * R + 64.0;
+        const double G = sqrt(2.0 * s.spatial_weight) * E + sqrt(3.0) * 4.0 * M + 16.0;
+        s.kappa = (float)(2.0 * u * (G + 1.0) * 1.0001);
+        s.fast32 = (minmax_normalize != 0 && max_candidates >= 0 && s.kappa < 1e-2f) ? 1 : 0;
+    }
     unsigned char *cb = im->cent.as<unsigned char>();
     s.acc = reinterpret_cast<long long *>(cb); cb += (size_t)K * 9 * 8;
     s.cy = reinterpret_cast<double *>(cb); cb += (size_t)K * 8;

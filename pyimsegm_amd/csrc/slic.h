@@ -18,10 +18,12 @@ struct Taps {
 // tile geometry of the assignment kernel and the per-tile candidate records (64 bytes each)
 constexpr int SLIC_TILE_X = 64, SLIC_TILE_Y = 32, SLIC_MAXC = 64;
 struct Cand {
-    double cy, cx, cL, ca, cb;
-    int4 win;
-    int k;
-    int pad;
+    double cy, cx, cL, ca, cb;   // exact (fp64) centroid
+    int4 win;                    // search window {ymin, ymax, xmin, xmax}
+    int k;                       // centroid index
+    float ry, rx;                // fp32 position relative to the tile origin
+    float fL, fa, fb;            // fp32 colour
+    int pad[2];
 };
 
 // device-side SLIC state for one 2-D image (all pointers are device pointers)
@@ -36,6 +38,9 @@ struct SlicState {
     int *tile_count;                // [n_tiles] list length (negative: more than the list holds)
     int *leftover;                  // [N] pixels to be accumulated by k_slic_leftover
     int *leftover_count;            // [1]
+    int fast32;                     // 1: fp32 pre-selection allowed (Lab bounded by lab_bound)
+    float kappa;                    // relative decision margin of the fp32 pass (see k_slic_assign)
+    int debug;                      // profiling aid (env IMSEGM_DEBUG_ASSIGN): ablation bits, results invalid
 };
 
 int launch_minmax(const void *src, int dtype, size_t n, unsigned long long *keys, double *out2, hipStream_t st);

@@ -312,19 +312,13 @@ __global__ void k_centroid_finalize(SlicState s)
     for (int j = 0; j < 9; ++j) a[j] = 0;
 }
 
-// ---------------------------------------------------------------------------------------------
-// assignment + fused accumulation
-// ---------------------------------------------------------------------------------------------
 constexpr int TILE_X = SLIC_TILE_X;   // one pixel column per lane
-constexpr int ROWS = 8;              // rows per lane
-constexpr int WAVES = 4;             // waves per workgroup
-constexpr int TILE_Y = ROWS * WAVES;
-static_assert(TILE_Y == SLIC_TILE_Y, "tile geometry");
+constexpr int TILE_Y = SLIC_TILE_Y;   // rows of a candidate-bin tile
 constexpr int MAXC = SLIC_MAXC;
 
 // ---- per-tile candidate lists ----------------------------------------------------------------
 // One wave per 64 x 32 pixel tile collects the centroids whose search window intersects the tile,
-// sorts them nearest-first and writes them as 64-byte records.  The assignment kernel then walks
+// sorts them nearest-first and writes them as 96-byte records.  The assignment kernel then walks
 // its list with wave-uniform (scalar) loads: no LDS staging, no barriers in front of the hot loop.
 __global__ void __launch_bounds__(64)
 k_slic_bin(SlicState s, int tiles_x, int max_cand, Cand *__restrict__ tile_cands, int *__restrict__ tile_count)
@@ -374,62 +368,51 @@ k_slic_bin(SlicState s, int tiles_x, int max_cand, Cand *__restrict__ tile_cands
         cd.cy = s.cy[k]; cd.cx = s.cx[k]; cd.cL = s.cL[k]; cd.ca = s.ca[k]; cd.cb = s.cb[k];
         cd.win = s.win[k];
         cd.k = k;
-        cd.pad = 0;
+        // fp32 copies for the pre-selection pass; positions relative to the tile origin so that
+        // their rounding error is u * O(2 * step) instead of u * O(image size)
+        cd.ry = (float)(cd.cy - (double)ty0);
+        cd.rx = (float)(cd.cx - (double)tx0);
+        cd.fL = (float)cd.cL; cd.fa = (float)cd.ca; cd.fb = (float)cd.cb;
+        cd.pad[0] = cd.pad[1] = 0;
         tile_cands[(size_t)tile * MAXC + rank] = cd;
     }
 }
 
-// direct (slow, always correct) accumulation of one pixel into the global accumulators
-__device__ __forceinline__ void accumulate_global(long long *acc, int k, int y, int x, double L, double A, double B)
-{
-    long long *a = acc + (size_t)k * 9;
-    long long hi, lo;
-    atomic_add_i64(a + 0, 1);
-    atomic_add_i64(a + 1, y);
-    atomic_add_i64(a + 2, x);
-    fix_split(L, hi, lo);
-    atomic_add_i64(a + 3, hi);
-    atomic_add_i64(a + 4, lo);
-    fix_split(A, hi, lo);
-    atomic_add_i64(a + 5, hi);
-    atomic_add_i64(a + 6, lo);
-    fix_split(B, hi, lo);
-    atomic_add_i64(a + 7, hi);
-    atomic_add_i64(a + 8, lo);
-}
-
-// One distance evaluation of _slic.pyx (2-D, unit spacing) -- the operation order IS the contract:
+// ---------------------------------------------------------------------------------------------
+// assignment + fused accumulation
+// ---------------------------------------------------------------------------------------------
+// Geometry: a workgroup = 4 waves = a 64 x 16 pixel tile; a lane owns one pixel column and ROWS = 4
+// rows, so a wave load of one row of one Lab plane is a single 512-byte coalesced request.  Two
+// vertically adjacent workgroups share the candidate list of their 64 x 32 bin tile.
+//
+// Exact fp64 distance (operation order of _slic.pyx, 2-D, unit spacing -- this IS the contract):
 //   dist_center = (dy*dy + dx*dx) * spatial_weight;  dist_color = ((dL*dL) + da*da) + db*db;
-//   dist_center += dist_color
-// Pruning (exact): colour distance >= 0 and rounding is monotone, hence d >= dc = (dy2 + dx2) * sw.
-// A candidate whose dc exceeds the best distance found so far can never win and is skipped without
-// touching its colour; `<=` keeps ties (resolved by the lowest centroid index, as the ascending-k
-// loop with a strict `>` of the reference does).
-#define SLIC_EVAL_ROW(r)                                                                          \
-    {                                                                                             \
-        const int y = wy0 + (r);                                                                  \
-        if (y >= w.x && y < w.y) {                                                                \
-            const double ty = cy - (double)y;                                                     \
-            const double dy2 = ty * ty;                                                           \
-            const double dc = (dy2 + dx2) * sw;                                                   \
-            const bool pass = inx && (dc <= best_d[r]);                                           \
-            if (__any(pass)) {                                                                    \
-                double t0 = pL[r] - cL, t1 = pA[r] - ca, t2 = pB[r] - cb;                         \
-                double col = t0 * t0;                                                             \
-                col = col + t1 * t1;                                                              \
-                col = col + t2 * t2;                                                              \
-                const double d = dc + col;                                                        \
-                bool better = pass && (best_d[r] > d);                                            \
-                if (pass && best_d[r] == d) better = k < cand[best_s[r]].k;   /* exact tie: rare */ \
-                if (better) {                                                                     \
-                    best_d[r] = d;                                                                \
-                    best_s[r] = c;                                                                \
-                }                                                                                 \
-            }                                                                                     \
-        }                                                                                         \
-    }
+//   dist_center += dist_color;          ties -> lowest centroid index
+//
+// fp32 pre-selection.  Every candidate is first evaluated in fp32 (half the issue cost, branch
+// free), tracking per pixel the best (b1, slot) and the second-best value b2.  With
+//   u = 2^-24, M >= |any Lab value or centroid colour|, R = 2*step+1 (window half width),
+//   E = 3R + 64 (fp32 error of tile-relative coordinate differences, in units of u),
+//   G = sqrt(2*sw)*E + sqrt(3)*4*M + 16
+// the fp32 value d32 and the real-arithmetic value D of the same formula obey
+//   |d32 - D| <= u*G*(D + 1); the fp64 reference value differs from D by < 1e-14*(D + 1).
+// With kappa = 2*u*(G+1) (factor 2 = safety):  b - a > kappa*(a + b + 2)  =>  candidate a beats b
+// in fp64 as well.  Hence
+//   * b2 clear of b1   -> the fp32 winner is the exact argmin                     (~99.99 % of pixels)
+//   * b2 inside        -> that row is decided by the exact fp64 loop over all its candidates
+// First sweep: all centroids sit on the integer grid with colour 0, which puts whole lines of pixels
+// on exact ties; it has its own path (FIRST) that orders the candidates by the integer squared
+// distance n = dy^2 + dx^2: d = fl(fl(n*sw) + |pixel|^2) is strictly increasing in n (sw >> ulp), so
+// argmin d == argmin n with ties -> lowest index, exactly what the fp64 evaluation yields.
+// Candidates skipped by the lower-bound test satisfy lb32 - b1 > kappa*(lb32 + b1 + 2) for every
+// row, i.e. they can neither win nor lie inside the margin, so not tracking them is harmless.
+constexpr int ROWS = 4;               // rows per lane
+constexpr int WAVES = 4;              // waves per workgroup
+constexpr int WG_Y = ROWS * WAVES;    // 16 rows per workgroup, two workgroups per bin tile
+static_assert(2 * WG_Y == SLIC_TILE_Y, "tile geometry");
 
-// pixels the assignment kernel could not accumulate through its LDS slots (see there)
+// pixels the assignment kernel could not accumulate through its LDS slots (uncovered pixels that keep
+// their previous label, tiles without a candidate list): plain global atomics, rare
 __global__ void __launch_bounds__(256)
 k_slic_leftover(SlicState s, const double *__restrict__ lab, const int32_t *__restrict__ labels)
 {
@@ -440,12 +423,102 @@ k_slic_leftover(SlicState s, const double *__restrict__ lab, const int32_t *__re
         int k = labels[p];
         if (k < 0) continue;            // never assigned so far: counted nowhere (as in the oracle)
         int y = p / s.W, x = p - y * s.W;
-        accumulate_global(s.acc, k, y, x, lab[p], lab[plane + p], lab[2 * plane + p]);
+        long long *a = s.acc + (size_t)k * 9;
+        long long hi, lo;
+        atomic_add_i64(a + 0, 1);
+        atomic_add_i64(a + 1, y);
+        atomic_add_i64(a + 2, x);
+        fix_split(lab[p], hi, lo);
+        atomic_add_i64(a + 3, hi);
+        atomic_add_i64(a + 4, lo);
+        fix_split(lab[plane + p], hi, lo);
+        atomic_add_i64(a + 5, hi);
+        atomic_add_i64(a + 6, lo);
+        fix_split(lab[2 * plane + p], hi, lo);
+        atomic_add_i64(a + 7, hi);
+        atomic_add_i64(a + 8, lo);
     }
 }
 
-// ACCUM: also accumulate the centroid sums (all iterations but the last)
-template <bool ACCUM>
+__device__ __forceinline__ double exact_dist(const Cand &cd, double fy, double fx, double sw, double L, double A, double B)
+{
+    const double ty = cd.cy - fy, tx = cd.cx - fx;
+    double d = (ty * ty + tx * tx) * sw;
+    const double t0 = L - cd.cL, t1 = A - cd.ca, t2 = B - cd.cb;
+    double col = t0 * t0;
+    col = col + t1 * t1;
+    col = col + t2 * t2;
+    return d + col;
+}
+
+// exact argmin over the whole candidate list of one pixel row (wave-uniform y)
+__device__ __forceinline__ int exact_row(const Cand *__restrict__ cand, int nc, int y, int x, double sw, double L,
+                                         double A, double B)
+{
+    double bd = DBL_MAX;
+    int bs = -1, bk = 0x7fffffff;
+    const double fy = (double)y, fx = (double)x;
+    for (int c = 0; c < nc; ++c) {
+        const int4 w = cand[c].win;
+        if (y < w.x || y >= w.y) continue;
+        const bool inx = (x >= w.z) && (x < w.w);
+        const double d = exact_dist(cand[c], fy, fx, sw, L, A, B);
+        const int k = cand[c].k;
+        if (inx && ((bd > d) || (bd == d && k < bk))) {
+            bd = d;
+            bs = c;
+            bk = k;
+        }
+    }
+    return bs;
+}
+
+// no candidate list for this tile (more than SLIC_MAXC centroids reach it): scan the whole table
+// in ascending k, strict '>' keeps the lowest k.  Returns -(k + 2), or -1 if nothing covers the pixel.
+__device__ __forceinline__ int exact_row_global(const SlicState &s, int y, int x, double L, double A, double B)
+{
+    double bd = DBL_MAX;
+    int res = -1;
+    const double fy = (double)y, fx = (double)x;
+    for (int k = 0; k < s.K; ++k) {
+        const int4 w = s.win[k];
+        if (y < w.x || y >= w.y || x < w.z || x >= w.w) continue;
+        Cand cd;
+        cd.cy = s.cy[k]; cd.cx = s.cx[k]; cd.cL = s.cL[k]; cd.ca = s.ca[k]; cd.cb = s.cb[k];
+        const double d = exact_dist(cd, fy, fx, s.spatial_weight, L, A, B);
+        if (bd > d) {
+            bd = d;
+            res = -(k + 2);
+        }
+    }
+    return res;
+}
+
+// wave sum through DPP (row_shr 1/2/4/8, row_bcast 15/31): no LDS traffic; total valid in lane 63
+__device__ __forceinline__ int wave_sum_dpp_lane63(int v)
+{
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);
+    return v;
+}
+
+// sum of an integer-valued double (|x| < 2^47) over the wave as int64: split into a 24-bit low chunk
+// and a high chunk (both exact), reduce as int32 through DPP, recombine; valid in lane 63
+__device__ __forceinline__ long long wave_sum_limb_lane63(double x)
+{
+    const double h = floor(x * (1.0 / 16777216.0));
+    const double l = x - h * 16777216.0;
+    const int hs = wave_sum_dpp_lane63((int)h);
+    const int ls = wave_sum_dpp_lane63((int)l);
+    return ((long long)hs << 24) + (long long)ls;
+}
+
+// ACCUM: also accumulate the centroid sums (all sweeps but the last)
+template <bool ACCUM, bool FIRST>
 __global__ void __launch_bounds__(256)
 k_slic_assign(SlicState s, const double *__restrict__ lab, int32_t *__restrict__ labels,
               const Cand *__restrict__ tile_cands, const int *__restrict__ tile_count)
@@ -453,29 +526,22 @@ k_slic_assign(SlicState s, const double *__restrict__ lab, int32_t *__restrict__
     __shared__ long long lacc[MAXC][9];
 
     const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
-    const int tile = blockIdx.y * gridDim.x + blockIdx.x;
-    const int tx0 = blockIdx.x * TILE_X, ty0 = blockIdx.y * TILE_Y;
-    const int tx1 = min(tx0 + TILE_X, s.W);
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);          // scalar: keeps the row tests on the SALU
+    const int tile = (blockIdx.y >> 1) * gridDim.x + blockIdx.x;       // 64 x 32 bin tile
+    const int tx0 = blockIdx.x * TILE_X;
+    const int wy0 = blockIdx.y * WG_Y + wave * ROWS;                    // first row of this wave
+    const int rel0 = (blockIdx.y & 1) * WG_Y + wave * ROWS;             // ... relative to the bin tile
     const size_t plane = (size_t)s.H * s.W;
     const Cand *__restrict__ cand = tile_cands + (size_t)tile * MAXC;
 
-    const int total = tile_count[tile];
-    const bool overflow = total < 0;             // block-uniform
-    const int nc = overflow ? 0 : total;
-    if (ACCUM) {
-        for (int i = tid; i < nc * 9; i += 256) (&lacc[0][0])[i] = 0;
-        __syncthreads();
-    }
-
     const int x = tx0 + lane;
-    const int wy0 = ty0 + wave * ROWS;
     const bool xin = x < s.W;
-    const double fx = (double)x;
     const double sw = s.spatial_weight;
 
-    double pL[ROWS], pA[ROWS], pB[ROWS], best_d[ROWS];
-    int best_s[ROWS];      // slot in the tile's candidate list; -1 none yet; <= -2: centroid -(k + 2) (no list)
+    // pixel loads first: their HBM latency overlaps the candidate-table set-up below
+    double pL[ROWS], pA[ROWS], pB[ROWS];
+    int best_s[ROWS];      // slot in the candidate list; -1: nothing covers the pixel; <= -2: centroid -(k+2)
 #pragma unroll
     for (int r = 0; r < ROWS; ++r) {
         int y = wy0 + r;
@@ -484,71 +550,148 @@ k_slic_assign(SlicState s, const double *__restrict__ lab, int32_t *__restrict__
         pL[r] = lab[p];
         pA[r] = lab[plane + p];
         pB[r] = lab[2 * plane + p];
-        best_d[r] = DBL_MAX;
         best_s[r] = -1;
     }
 
-    if (!overflow) {
-        constexpr int PHASE1 = 4;     // candidates evaluated before the per-lane bound is formed
-        double mb = DBL_MAX;          // upper bound of this lane's best distances (stale = still valid)
-        for (int c = 0; c < nc; ++c) {
-            const int4 w = cand[c].win;
-            if (c == PHASE1) {
-                mb = best_d[0];
-#pragma unroll
-                for (int r = 1; r < ROWS; ++r) mb = fmax(mb, best_d[r]);
-            }
-            if (w.x >= wy0 + ROWS || w.y <= wy0) continue;   // wave-uniform: no row of this wave in the window
-            const int k = cand[c].k;
-            const double cy = cand[c].cy, cx = cand[c].cx;
-            const bool inx = (x >= w.z) && (x < w.w);
-            const double tx = cx - fx;
-            const double dx2 = tx * tx;
-            if (c >= PHASE1) {
-                // exact lower bound of dc over the rows of this wave: |cy - y| is smallest at the row
-                // nearest to cy (0 if cy lies inside the row range); same operations, monotone rounding
-                double tyb = 0.0;
-                if (cy < (double)wy0) tyb = cy - (double)wy0;
-                else if (cy > (double)(wy0 + ROWS - 1)) tyb = cy - (double)(wy0 + ROWS - 1);
-                const double lb = (tyb * tyb + dx2) * sw;
-                if (!__any(inx && lb <= mb)) continue;
-            }
-            const double cL = cand[c].cL, ca = cand[c].ca, cb = cand[c].cb;
-            SLIC_EVAL_ROW(0) SLIC_EVAL_ROW(1) SLIC_EVAL_ROW(2) SLIC_EVAL_ROW(3)
-            SLIC_EVAL_ROW(4) SLIC_EVAL_ROW(5) SLIC_EVAL_ROW(6) SLIC_EVAL_ROW(7)
+    const int total = tile_count[tile];
+    const bool overflow = total < 0;             // block-uniform
+    const int nc = overflow ? 0 : total;
+    // candidate table in registers: lane c holds the fp32 record of candidate c (nc <= 64); the hot
+    // loop fetches fields with v_readlane -- no memory latency in the loop at all
+    int4 my_win = make_int4(0, 0, 0, 0);
+    float my_ry = 0.f, my_rx = 0.f, my_fL = 0.f, my_fa = 0.f, my_fb = 0.f;
+    int my_iy = 0, my_ix = 0, my_k = 0;
+    if (lane < nc) {
+        my_win = cand[lane].win;
+        if (FIRST) {
+            my_iy = (int)cand[lane].cy;
+            my_ix = (int)cand[lane].cx;
+            my_k = cand[lane].k;
         }
-    } else {
-        // more candidate centroids than LDS slots (pathological clustering, or forced by tests):
-        // scan the whole table from global memory in ascending k (strict '>' keeps the lowest k)
-        for (int k = 0; k < s.K; ++k) {
-            const int4 w = s.win[k];
-            if (!(w.x < wy0 + ROWS && w.y > wy0 && w.z < tx1 && w.w > tx0)) continue;
-            const double cy = s.cy[k], cx = s.cx[k], cL = s.cL[k], ca = s.ca[k], cb = s.cb[k];
+        my_ry = cand[lane].ry; my_rx = cand[lane].rx;
+        my_fL = cand[lane].fL; my_fa = cand[lane].fa; my_fb = cand[lane].fb;
+    }
+    if (ACCUM) {
+        for (int i = tid; i < nc * 9; i += 256) (&lacc[0][0])[i] = 0;
+        __syncthreads();
+    }
+
+    if (overflow) {
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r) best_s[r] = exact_row_global(s, wy0 + r, x, pL[r], pA[r], pB[r]);
+    } else if (!s.fast32) {
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r) best_s[r] = exact_row(cand, nc, wy0 + r, x, sw, pL[r], pA[r], pB[r]);
+    } else if (FIRST) {
+        // integer distances (see header): centroid positions are exact integers in the first sweep
+        int bn[ROWS], bk[ROWS];
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r) bn[r] = bk[r] = 0x7fffffff;
+        for (int c = 0; c < nc; ++c) {
+            const int4 w = make_int4(__builtin_amdgcn_readlane(my_win.x, c), __builtin_amdgcn_readlane(my_win.y, c),
+                                     __builtin_amdgcn_readlane(my_win.z, c), __builtin_amdgcn_readlane(my_win.w, c));
+            if (w.x >= wy0 + ROWS || w.y <= wy0) continue;
+            const int ciy = __builtin_amdgcn_readlane(my_iy, c), cix = __builtin_amdgcn_readlane(my_ix, c);
+            const int ck = __builtin_amdgcn_readlane(my_k, c);
             const bool inx = (x >= w.z) && (x < w.w);
-            const double tx = cx - fx;
-            const double dx2 = tx * tx;
+            const int dx = cix - x;
+            const int dx2 = dx * dx;
 #pragma unroll
             for (int r = 0; r < ROWS; ++r) {
                 const int y = wy0 + r;
                 if (y < w.x || y >= w.y) continue;
-                const double ty = cy - (double)y;
-                const double dy2 = ty * ty;
-                double d = (dy2 + dx2) * sw;
-                double t0 = pL[r] - cL, t1 = pA[r] - ca, t2 = pB[r] - cb;
-                double col = t0 * t0;
-                col = col + t1 * t1;
-                col = col + t2 * t2;
-                d = d + col;
-                if (inx && (best_d[r] > d)) {
-                    best_d[r] = d;
-                    best_s[r] = -(k + 2);                 // assigned, but no list slot
+                const int dy = ciy - y;
+                const int n = dy * dy + dx2;
+                if (inx && (n < bn[r] || (n == bn[r] && ck < bk[r]))) {
+                    bn[r] = n;
+                    bk[r] = ck;
+                    best_s[r] = c;
                 }
             }
+        }
+    } else if (s.debug & 1) {
+        // (profiling aid) no candidate loop at all: pure load + store
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r) best_s[r] = nc > 0 ? 0 : -1;
+    } else {
+        constexpr int PHASE1 = 4;            // candidates evaluated before the per-lane bound is formed
+        const float INF = __builtin_inff();
+        const float sw32 = (float)sw;
+        const float kappa = s.kappa;
+        float fL[ROWS], fA[ROWS], fB[ROWS], b1[ROWS], b2[ROWS];
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r) {
+            fL[r] = (float)pL[r];
+            fA[r] = (float)pA[r];
+            fB[r] = (float)pB[r];
+            b1[r] = b2[r] = INF;
+        }
+        const float flane = (float)lane;
+        const float frow0 = (float)rel0;
+        float mb = INF;                      // upper bound of this lane's best distances (stale = still valid)
+#define RL_I(v) __builtin_amdgcn_readlane((v), c)
+#define RL_F(v) __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), c))
+        for (int c = 0; c < nc; ++c) {
+            const int4 w = make_int4(RL_I(my_win.x), RL_I(my_win.y), RL_I(my_win.z), RL_I(my_win.w));
+            if (c == PHASE1) {
+                mb = b1[0];
+#pragma unroll
+                for (int r = 1; r < ROWS; ++r) mb = fmaxf(mb, b1[r]);
+            }
+            if (w.x >= wy0 + ROWS || w.y <= wy0) continue;   // wave-uniform: no row of this wave in the window
+            const bool inx = (x >= w.z) && (x < w.w);
+            const float ry = RL_F(my_ry) - frow0;             // centroid row relative to this wave's first row
+            const float tx = RL_F(my_rx) - flane;
+            const float dx2 = tx * tx;
+            if (c >= PHASE1) {
+                // lower bound over this lane's rows: |ry - r| is smallest at the row nearest to ry
+                float tyb = 0.f;
+                if (ry < 0.f) tyb = ry;
+                else if (ry > (float)(ROWS - 1)) tyb = ry - (float)(ROWS - 1);
+                const float lb = (tyb * tyb + dx2) * sw32;
+                if (!__any(inx && (lb - mb <= kappa * (lb + mb + 2.f)))) continue;
+            }
+            const float cL = RL_F(my_fL), ca = RL_F(my_fa), cb = RL_F(my_fb);
+#define SLIC_EVAL32(r)                                                                    \
+    {                                                                                     \
+        const float ty = ry - (float)(r);                                                 \
+        const float t0 = fL[r] - cL, t1 = fA[r] - ca, t2 = fB[r] - cb;                    \
+        float d = (ty * ty + dx2) * sw32 + (t0 * t0 + t1 * t1 + t2 * t2);                 \
+        d = inx ? d : INF;                                                                \
+        const bool lt1 = d < b1[r];                                                       \
+        b2[r] = lt1 ? b1[r] : fminf(b2[r], d);                                            \
+        b1[r] = fminf(b1[r], d);                                                          \
+        best_s[r] = lt1 ? c : best_s[r];                                                  \
+    }
+            if (w.x <= wy0 && w.y >= wy0 + ROWS) {
+                // the window covers every row of this wave (the common case): one branch-free block,
+                // the four independent rows interleave in the VALU pipeline
+                SLIC_EVAL32(0) SLIC_EVAL32(1) SLIC_EVAL32(2) SLIC_EVAL32(3)
+            } else {
+#pragma unroll
+                for (int r = 0; r < ROWS; ++r) {
+                    const int y = wy0 + r;
+                    if (y < w.x || y >= w.y) continue;        // wave-uniform
+                    SLIC_EVAL32(r)
+                }
+            }
+#undef SLIC_EVAL32
+        }
+#undef RL_I
+#undef RL_F
+        // near ties (second best inside the margin for some pixel of the row): exact fp64 loop
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r) {
+            if (s.debug & 2) break;          // (profiling aid)
+            const bool near2 = best_s[r] >= 0 && b2[r] < INF && !(b2[r] - b1[r] > kappa * (b1[r] + b2[r] + 2.f));
+            if (!__any(near2)) continue;
+            int e = exact_row(cand, nc, wy0 + r, x, sw, pL[r], pA[r], pB[r]);
+            if (near2) best_s[r] = e;
         }
     }
 
     // labels: a pixel no window covers keeps its previous assignment (nearest_segments persists in
-    // _slic.pyx).  Such pixels, and the pixels of tiles without an LDS candidate list, are queued for
+    // _slic.pyx).  Such pixels, and the pixels of tiles without a candidate list, are queued for
     // k_slic_leftover, which adds them to the centroid sums with plain global atomics (rare).
     unsigned pending = 0;
 #pragma unroll
@@ -559,17 +702,17 @@ k_slic_assign(SlicState s, const double *__restrict__ lab, int32_t *__restrict__
         if (best_s[r] >= 0) {
             labels[p] = cand[best_s[r]].k;
             pending |= 1u << r;
-        } else if (best_s[r] <= -2) {
-            labels[p] = -(best_s[r] + 2);
+            continue;
         }
-        if (best_s[r] >= 0) continue;
+        if (best_s[r] <= -2) labels[p] = -(best_s[r] + 2);
         if (ACCUM) s.leftover[atomicAdd(s.leftover_count, 1)] = p;
     }
-    if (!ACCUM) return;
+    if (!ACCUM || (s.debug & 4)) return;
 
-    // wave-level segmented reduction: one pass per distinct LDS slot present in this wave; the eight
-    // partial sums are reduced with the transposed scheme (10 exchanges) and lanes 0, 8, .., 56 each
-    // add one of them into the workgroup's LDS accumulators
+    // wave-level segmented reduction, one pass per distinct slot present in this wave.  The two
+    // fixed-point limbs of every colour value are integer-valued doubles (|limb| < 2^45), so the
+    // per-lane sums over ROWS pixels are exact in fp64; across the wave they are summed as int32
+    // chunks through DPP and lane 63 adds the nine int64 totals into the workgroup's LDS slot.
     while (true) {
         int first = -1;
 #pragma unroll
@@ -577,13 +720,9 @@ k_slic_assign(SlicState s, const double *__restrict__ lab, int32_t *__restrict__
             if (pending & (1u << r)) first = best_s[r];
         unsigned long long vote = __ballot(first >= 0);
         if (vote == 0) break;
-        int leader = __ffsll((long long)vote) - 1;
-        int slot = __shfl(first, leader, 64);
-        // Per-lane partial sums.  The two fixed-point limbs of every colour value are integer-valued
-        // doubles (|limb| < 2^45), so their sums over the <= 512 pixels of this wave are exact in
-        // fp64 and are only converted to int64 once, by the lane that owns the wave total.
+        const int slot = __shfl(first, __ffsll((long long)vote) - 1, 64);
         double qd[6] = { 0, 0, 0, 0, 0, 0 };
-        long long qn = 0, qx = 0;
+        int qn = 0, qy = 0, qx = 0;
 #pragma unroll
         for (int r = 0; r < ROWS; ++r) {
             if ((pending & (1u << r)) && best_s[r] == slot) {
@@ -591,28 +730,22 @@ k_slic_assign(SlicState s, const double *__restrict__ lab, int32_t *__restrict__
                 t = pL[r] * 1073741824.0; h = trunc(t); qd[0] += h; qd[1] += trunc((t - h) * 4294967296.0);
                 t = pA[r] * 1073741824.0; h = trunc(t); qd[2] += h; qd[3] += trunc((t - h) * 4294967296.0);
                 t = pB[r] * 1073741824.0; h = trunc(t); qd[4] += h; qd[5] += trunc((t - h) * 4294967296.0);
-                qn += 1 + ((long long)(wy0 + r) << 12);      // n (<= 512 per wave) | sum y << 12
+                qn += 1;
+                qy += wy0 + r;
                 qx += x;
                 pending &= ~(1u << r);
             }
         }
-        long long q[8];
+        if (s.debug & 8) continue;           // (profiling aid) no cross-lane reduction
+        long long tot[9];
+        tot[0] = wave_sum_dpp_lane63(qn);
+        tot[1] = wave_sum_dpp_lane63(qy);
+        tot[2] = wave_sum_dpp_lane63(qx);
 #pragma unroll
-        for (int j = 0; j < 6; ++j) q[j] = __double_as_longlong(qd[j]);
-        q[6] = qn;
-        q[7] = qx;
-        long long tot = wave_reduce8_mixed(q);
-        if ((lane & 7) == 0) {
-            long long *a = lacc[slot];
-            int j = lane >> 3;
-            if (j < 6) {
-                atomic_add_i64(a + 3 + j, (long long)__longlong_as_double(tot));
-            } else if (j == 6) {
-                atomic_add_i64(a + 0, tot & 0xfff);
-                atomic_add_i64(a + 1, tot >> 12);
-            } else {
-                atomic_add_i64(a + 2, tot);
-            }
+        for (int j = 0; j < 6; ++j) tot[3 + j] = wave_sum_limb_lane63(qd[j]);
+        if (lane == 63) {
+#pragma unroll
+            for (int j = 0; j < 9; ++j) atomic_add_i64(&lacc[slot][j], tot[j]);
         }
     }
     __syncthreads();
@@ -630,15 +763,25 @@ int launch_slic_iterations(SlicState s, const double *lab, const double *init_yx
     size_t n = (size_t)s.H * s.W;
     HIP_TRY(hipMemsetAsync(labels, 0xff, n * sizeof(int32_t), st));       // nearest = -1
     hipLaunchKernelGGL(k_centroid_init, cdiv(s.K, 256), 256, 0, st, s, init_yx_dev);
-    dim3 grid(cdiv(s.W, TILE_X), cdiv(s.H, TILE_Y));
-    const int n_tiles = grid.x * grid.y;
+    dim3 grid(cdiv(s.W, TILE_X), 2 * cdiv(s.H, TILE_Y));     // two 64 x 16 workgroups per bin tile
+    const int n_tiles = grid.x * cdiv(s.H, TILE_Y);
     for (int it = 0; it < max_iter; ++it) {
         hipLaunchKernelGGL(k_slic_bin, n_tiles, 64, 0, st, s, (int)grid.x, max_cand, s.tile_cands, s.tile_count);
         int span = prof.begin ? prof.begin(prof.user, 0) : -1;
-        if (it + 1 < max_iter)
-            hipLaunchKernelGGL(k_slic_assign<true>, grid, 256, 0, st, s, lab, labels, s.tile_cands, s.tile_count);
-        else
-            hipLaunchKernelGGL(k_slic_assign<false>, grid, 256, 0, st, s, lab, labels, s.tile_cands, s.tile_count);
+        // first sweep: integer-grid centroids with zero colour -> exact integer path (needs the
+        // fast-path preconditions and a spatial weight far above the fp64 resolution)
+        const bool first = it == 0 && s.fast32 && s.spatial_weight > 1e-9;
+        if (it + 1 < max_iter) {
+            if (first)
+                hipLaunchKernelGGL((k_slic_assign<true, true>), grid, 256, 0, st, s, lab, labels, s.tile_cands, s.tile_count);
+            else
+                hipLaunchKernelGGL((k_slic_assign<true, false>), grid, 256, 0, st, s, lab, labels, s.tile_cands, s.tile_count);
+        } else {
+            if (first)
+                hipLaunchKernelGGL((k_slic_assign<false, true>), grid, 256, 0, st, s, lab, labels, s.tile_cands, s.tile_count);
+            else
+                hipLaunchKernelGGL((k_slic_assign<false, false>), grid, 256, 0, st, s, lab, labels, s.tile_cands, s.tile_count);
+        }
         if (prof.end) prof.end(prof.user, span);
         if (it + 1 < max_iter) {
             hipLaunchKernelGGL(k_slic_leftover, 64, 256, 0, st, s, lab, labels);
