@@ -87,17 +87,9 @@ def cpu_baseline(image, model):
 
 def main():
     args = parse_args()
-    world = int(os.environ.get('WORLD_SIZE', '1'))
-    rank = int(os.environ.get('RANK', '0'))
-    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    dist = None
-    torch = None
-    if world > 1 or 'RANK' in os.environ:
-        import torch
-        import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
-    os.environ['IMSEGM_HIP_DEVICE'] = str(local_rank)
+    from pyimsegm_amd.distributed import Group
+    group = Group()                      # torch.distributed (RCCL) only when launched by torchrun
+    world, rank = group.world, group.rank
 
     from pyimsegm_amd import _hip
     from pyimsegm_amd import pipelines as pipe
@@ -123,41 +115,31 @@ def main():
 
     def barrier():
         ctx.synchronize()
-        if dist is not None:
-            dist.barrier()
-            torch.cuda.synchronize()
+        group.barrier()
 
-    gather_buf = None
-    if dist is not None and world > 1:
-        gather_buf = [torch.empty((size, size), dtype=torch.int32, device='cuda') for _ in range(world)] \
-            if rank == 0 else None
-
-    def gather_labels(segm_host):
-        t = torch.from_numpy(segm_host).to('cuda', non_blocking=False)
-        dist.gather(t, gather_buf, dst=0)
+    def gather_labels():
+        # one RCCL gather of the label maps per step, zero copy from the session's HBM buffer
+        return group.gather_arrays(_hip.segm_device_array(sess), dst=0, keep_on_device=True)
 
     for _ in range(args.warmup):
-        (segm, _), _ = step(model, to_host=world > 1)
+        step(model)
         if world > 1:
-            gather_labels(segm)
+            gather_labels()
     ctx.profile_enable(True)
     ctx.profile_reset()
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        (segm, _), _ = step(model, to_host=world > 1)
+        step(model)
         if world > 1:
-            gather_labels(segm)
+            gather_labels()
     barrier()
     elapsed = time.perf_counter() - t0
     assign_ms, assign_n = ctx.profile_get('slic_assign')
     stage_ms = {g: ctx.profile_get(g) for g in _hip.PROFILE_GROUPS}
     ctx.profile_enable(False)
 
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = group.max_over_ranks(elapsed)
 
     if rank == 0:
         npx = size * size
@@ -208,9 +190,7 @@ def main():
             except Exception as ex:   # the baseline is a reported extra, never a reason to lose the line
                 out['cpu_baseline'] = {'error': repr(ex)}
         print(json.dumps(out), flush=True)
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+    group.close()
 
 
 if __name__ == '__main__':

@@ -94,6 +94,12 @@ IMSEGM_API int imsegm_image2d_graph(imsegm_image2d *img, int32_t *edges_out, int
 IMSEGM_API int imsegm_image2d_gather(imsegm_image2d *img, const int32_t *graph_labels, const double *proba,
                           int n_classes, int32_t *segm_out, double *soft_out);
 
+/* Device address of a result buffer of the session (valid until the next call that rewrites it):
+ * which = 0: label map int32 H x W; 1: gathered segmentation int32 H x W; 2: gathered soft
+ * segmentation float64 H x W x C.  For zero-copy hand-over to a collective library (RCCL) running on
+ * the same HIP runtime; call imsegm_ctx_synchronize first. */
+IMSEGM_API int imsegm_image2d_device_ptr(imsegm_image2d *img, int which, void **ptr_out);
+
 /* ---------------------------------------------------------------------------------------------
  * stand-alone stage
  * ------------------------------------------------------------------------------------------- */

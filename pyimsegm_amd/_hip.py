@@ -64,6 +64,7 @@ _SIGNATURES = {
     'imsegm_image2d_color_stats': (C.c_int, [_vp, _vp, _vp, _vp]),
     'imsegm_image2d_graph': (C.c_int, [_vp, _vp, C.c_int, _ip, _vp, _vp]),
     'imsegm_image2d_gather': (C.c_int, [_vp, _vp, _vp, C.c_int, _vp, _vp]),
+    'imsegm_image2d_device_ptr': (C.c_int, [_vp, C.c_int, C.POINTER(_vp)]),
     'imsegm_cut_general_graph': (C.c_int, [_vp, _vp, C.c_int, _vp, _vp, C.c_int, C.c_int, _vp, C.c_int, _vp,
                                            C.POINTER(C.c_int64)]),
 }
@@ -298,6 +299,28 @@ class Image2D(object):
             soft = np.empty(self.shape + (nc,), dtype=np.float64) if to_host else None
         _check(load_library().imsegm_image2d_gather(self._h, _ptr(gl), _ptr(pr), nc, _ptr(segm), _ptr(soft)))
         return segm, soft
+
+
+class DeviceArray(object):
+    """a result buffer in HBM, exposed through ``__cuda_array_interface__`` (zero-copy hand-over to
+    ``torch.as_tensor(..., device='cuda')`` / RCCL on the same HIP runtime)"""
+
+    def __init__(self, ptr, shape, typestr, owner):
+        self.owner = owner          # keeps the session alive
+        self.__cuda_array_interface__ = {'shape': tuple(shape), 'typestr': typestr, 'data': (int(ptr), False),
+                                         'version': 2, 'strides': None}
+
+
+def _device_array(sess, which, shape, typestr):
+    ptr = _vp()
+    _check(load_library().imsegm_image2d_device_ptr(sess._h, which, C.byref(ptr)))
+    sess.ctx.synchronize()
+    return DeviceArray(ptr.value, shape, typestr, sess)
+
+
+def segm_device_array(sess):
+    """the gathered segmentation (``graph_labels[slic]``, int32 H x W) as a device array"""
+    return _device_array(sess, 1, sess.shape, '<i4')
 
 
 def cut_general_graph(edges, edge_weights, unary_cost, pairwise_cost, n_iter=-1, algorithm='expansion',

@@ -643,6 +643,21 @@ int imsegm_image2d_gather(imsegm_image2d *im, const int32_t *graph_labels, const
     return 0;
 }
 
+int imsegm_image2d_device_ptr(imsegm_image2d *im, int which, void **ptr_out)
+{
+    if (!im || !ptr_out) {
+        set_error("null argument");
+        return -1;
+    }
+    DevBuf *b = which == 0 ? &im->labels : which == 1 ? &im->gather_out_i : which == 2 ? &im->gather_out_f : nullptr;
+    if (!b || !b->p) {
+        set_error("device_ptr: buffer not available");
+        return -1;
+    }
+    *ptr_out = b->p;
+    return 0;
+}
+
 int imsegm_cut_general_graph(imsegm_ctx *ctx, const int32_t *edges, int n_edges, const double *edge_weights,
                              const double *unary_cost, int n_sites, int n_labels, const double *pairwise_cost,
                              int n_iter, int32_t *labels_out, int64_t *energy_out)

@@ -203,6 +203,34 @@ def segment_color2d_slic_features_model_graphcut(
     return segm, segm_soft
 
 
+def segment_batch_color2d_slic_features_model_graphcut(list_images, model_pipeline, dict_features, sp_size=30,
+                                                       sp_regul=0.2, gc_regul=1., gc_edge_type='model', group=None):
+    """ segment a batch of equally-sized images with a given model, sharded over the GPUs of one node
+
+    Multi-GPU counterpart of mapping :func:`segment_color2d_slic_features_model_graphcut` over a
+    process pool (reference ``run_segm_slic_model_graphcut.py:505-514``): one process per GPU
+    (``torchrun``), image *i* goes to rank ``i mod world``, the label maps are gathered on rank 0
+    over RCCL.  Without a process group it simply loops over the images on this GPU.
+
+    :return list(ndarray): label maps on rank 0 (``None`` on the other ranks)
+    """
+    from pyimsegm_amd.distributed import Group, segment_batch_sharded
+    own = group is None
+    if own:
+        group = Group()
+
+    def _segment(image):
+        segm, _ = segment_color2d_slic_features_model_graphcut(image, model_pipeline, dict_features, sp_size=sp_size,
+                                                               sp_regul=sp_regul, gc_regul=gc_regul,
+                                                               gc_edge_type=gc_edge_type)
+        return segm
+
+    out = segment_batch_sharded(list_images, _segment, group)
+    if own:
+        group.close()
+    return out
+
+
 def pipe_gray3d_slic_features_model_graphcut(*args, **kwargs):
     """ 3D gray pipeline (reference ``pipelines.py:382-431``): not on the HIP path yet """
     raise NotImplementedError('the 3D supervoxel pipeline is not implemented by the HIP path yet')

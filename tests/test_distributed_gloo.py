@@ -1,0 +1,46 @@
+"""N > 1 path on CPU: 2 processes, gloo backend -- sharding, per-round gather, max-over-ranks."""
+import os
+import subprocess
+import sys
+import textwrap
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+WORKER = textwrap.dedent('''
+    import sys, numpy as np
+    sys.path.insert(0, %r)
+    from pyimsegm_amd.distributed import Group, segment_batch_sharded
+    g = Group(backend='gloo')
+    assert g.world == 2
+    images = [np.full((6, 8, 3), i, dtype=np.uint8) for i in range(5)]      # ragged: 5 images, 2 ranks
+    assert g.shard(5) == ([0, 2, 4] if g.rank == 0 else [1, 3])
+    seen = []
+    def fake_segment(img):
+        seen.append(int(img[0, 0, 0]))
+        return np.full(img.shape[:2], 10 * int(img[0, 0, 0]) + g.rank, dtype=np.int32)
+    out = segment_batch_sharded(images, fake_segment, g)
+    t = g.max_over_ranks(1.0 + g.rank)
+    assert t == 2.0
+    feats = g.gather_objects(np.ones((2 + g.rank, 3)) * g.rank)
+    model = g.broadcast_object({'fitted_on': None if feats is None else sum(len(f) for f in feats)})
+    assert model['fitted_on'] == 5
+    if g.rank == 0:
+        assert [int(o[0, 0]) for o in out] == [0, 11, 20, 31, 40], [int(o[0, 0]) for o in out]
+        assert all(o.shape == (6, 8) and o.dtype == np.int32 for o in out)
+        print('RANK0_OK')
+    else:
+        assert out is None
+    assert seen == g.shard(5)
+    g.close()
+''') % ROOT
+
+
+def test_two_rank_gloo(tmp_path):
+    script = tmp_path / 'worker.py'
+    script.write_text(WORKER)
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=2', '--master-addr', '127.0.0.1',
+           '--master-port', '29617', str(script)]
+    env = dict(os.environ, OMP_NUM_THREADS='1')
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=240, env=env)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
+    assert 'RANK0_OK' in res.stdout
