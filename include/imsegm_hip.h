@@ -94,6 +94,24 @@ IMSEGM_API int imsegm_image2d_graph(imsegm_image2d *img, int32_t *edges_out, int
 IMSEGM_API int imsegm_image2d_gather(imsegm_image2d *img, const int32_t *graph_labels, const double *proba,
                           int n_classes, int32_t *segm_out, double *soft_out);
 
+/* Leung-Malik texture responses (imsegm/descriptors.py:951-1106, scipy.ndimage in the reference).
+ * lm_prepare: planes = image - gaussian_filter(image, sigma) with `taps` = half kernel of
+ *   scipy.ndimage.gaussian_filter1d(sigma) (taps[0] centre) for the two image axes and `channel_mix`
+ *   the 3 x 3 matrix the same filter amounts to along the 3-element channel axis (descriptors.py:1078).
+ * lm_battery: one filter battery = n_kernels (1, 2, 4, 8) square kernels of side 2*radius+1; `weights` is
+ *   laid out [kx][ky][kernel] and already FLIPPED, i.e. response = max_k correlate(plane, weights[..k]) ==
+ *   max_k ndimage.convolve(plane, kernel_k, mode='reflect') (descriptors.py:960-963), clipped at `clip`
+ *   (:1088); returns the sum of squares over the three channels (for the norm of :1090).
+ * response_stats: per-superpixel mean / energy / variance of (response * mul) / div (:1094-1096),
+ *   float32 staging as imsegm_image2d_color_stats. */
+IMSEGM_API int imsegm_image2d_lm_prepare(imsegm_image2d *img, const double *taps, int radius, const double *channel_mix);
+IMSEGM_API int imsegm_image2d_lm_battery(imsegm_image2d *img, const double *weights, int n_kernels, int radius,
+                                         double clip, double *sum_squares_out);
+IMSEGM_API int imsegm_image2d_response_stats(imsegm_image2d *img, double mul, double div, double *mean_out,
+                                             double *energy_out, double *var_out);
+/* inspection for the parity tests: the current filter response as [3][H][W] planes */
+IMSEGM_API int imsegm_image2d_get_response(imsegm_image2d *img, double *planes_out);
+
 /* Device address of a result buffer of the session (valid until the next call that rewrites it):
  * which = 0: label map int32 H x W; 1: gathered segmentation int32 H x W; 2: gathered soft
  * segmentation float64 H x W x C.  For zero-copy hand-over to a collective library (RCCL) running on

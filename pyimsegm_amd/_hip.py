@@ -64,6 +64,10 @@ _SIGNATURES = {
     'imsegm_image2d_color_stats': (C.c_int, [_vp, _vp, _vp, _vp]),
     'imsegm_image2d_graph': (C.c_int, [_vp, _vp, C.c_int, _ip, _vp, _vp]),
     'imsegm_image2d_gather': (C.c_int, [_vp, _vp, _vp, C.c_int, _vp, _vp]),
+    'imsegm_image2d_lm_prepare': (C.c_int, [_vp, _vp, C.c_int, _vp]),
+    'imsegm_image2d_lm_battery': (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_double, C.POINTER(C.c_double)]),
+    'imsegm_image2d_response_stats': (C.c_int, [_vp, C.c_double, C.c_double, _vp, _vp, _vp]),
+    'imsegm_image2d_get_response': (C.c_int, [_vp, _vp]),
     'imsegm_image2d_device_ptr': (C.c_int, [_vp, C.c_int, C.POINTER(_vp)]),
     'imsegm_cut_general_graph': (C.c_int, [_vp, _vp, C.c_int, _vp, _vp, C.c_int, C.c_int, _vp, C.c_int, _vp,
                                            C.POINTER(C.c_int64)]),
@@ -265,6 +269,50 @@ class Image2D(object):
         v = np.empty((k, 3), dtype=np.float64) if var else None
         _check(load_library().imsegm_image2d_color_stats(self._h, _ptr(m), _ptr(e), _ptr(v)))
         return m, e, v
+
+    # -- Leung-Malik texture responses ------------------------------------------------------------
+    def lm_prepare(self, sigma=150.):
+        """planes = image - gaussian_filter(image.astype(float), sigma)   (descriptors.py:1078)"""
+        taps = gaussian_taps(sigma)
+        radius = len(taps) - 1
+        full = np.concatenate([taps[:0:-1], taps])
+        mix = np.zeros((3, 3))
+        for c_out in range(3):          # the same filter along the 3-element channel axis, 'reflect'
+            for j in range(-radius, radius + 1):
+                i = (c_out + j) % 6
+                mix[c_out, i if i < 3 else 5 - i] += full[j + radius]
+        _check(load_library().imsegm_image2d_lm_prepare(self._h, _ptr(taps), radius, _ptr(np.ascontiguousarray(mix))))
+        return self
+
+    def lm_battery(self, battery, clip):
+        """response of one filter battery (k x S x S convolution kernels) -> L2 norm over the channels"""
+        battery = np.asarray(battery, dtype=np.float64)
+        nk, side = battery.shape[0], battery.shape[1]
+        if battery.ndim != 3 or battery.shape[2] != side or side % 2 != 1:
+            raise ValueError('wrong battery dim %r' % (battery.shape, ))
+        pad = {1: 1, 2: 2, 3: 4, 4: 4, 5: 8, 6: 8, 7: 8, 8: 8}.get(nk)
+        if pad is None:
+            raise ValueError('at most 8 kernels per battery')
+        if pad != nk:                    # repeat the last kernel: the maximum is unchanged
+            battery = np.concatenate([battery, np.repeat(battery[-1:], pad - nk, axis=0)], axis=0)
+        # true convolution == correlation with the flipped kernel; layout [kx][ky][kernel]
+        weights = np.ascontiguousarray(battery[:, ::-1, ::-1].transpose(2, 1, 0))
+        ssq = C.c_double(0)
+        _check(load_library().imsegm_image2d_lm_battery(self._h, _ptr(weights), pad, side // 2, float(clip), C.byref(ssq)))
+        return float(np.sqrt(ssq.value))
+
+    def response_stats(self, mul, div, mean=True, energy=True, var=True):
+        k = self.n_labels
+        m = np.empty((k, 3), dtype=np.float64) if mean else None
+        e = np.empty((k, 3), dtype=np.float64) if energy else None
+        v = np.empty((k, 3), dtype=np.float64) if var else None
+        _check(load_library().imsegm_image2d_response_stats(self._h, float(mul), float(div), _ptr(m), _ptr(e), _ptr(v)))
+        return m, e, v
+
+    def get_response(self):
+        out = np.empty((3, ) + self.shape, dtype=np.float64)
+        _check(load_library().imsegm_image2d_get_response(self._h, _ptr(out)))
+        return out
 
     def graph(self):
         """(edges int32 E x 2 ordered by (b, a); centres K x 2; present flags K)"""

@@ -117,7 +117,9 @@ struct imsegm_image2d {
     int dtype = -1;
     int n_labels = 0;
     bool have_labels = false;
-    DevBuf img, labA, labB, nearest, labels, conn_i32, conn_u8, small, cent, tiles, feat, graph, gather_lut, gather_out_i, gather_out_f;
+    bool tex_ready = false;
+    DevBuf img, labA, labB, nearest, labels, conn_i32, conn_u8, small, cent, tiles, feat, graph, gather_lut, gather_out_i, gather_out_f,
+        tex_planes, tex_resp, tex_small;
 };
 
 static int bind(imsegm_ctx *ctx)
@@ -289,7 +291,8 @@ void imsegm_image2d_destroy(imsegm_image2d *im)
     (void)hipSetDevice(im->ctx->device);
     (void)hipStreamSynchronize(im->ctx->stream);
     DevBuf *all[] = { &im->img, &im->labA, &im->labB, &im->nearest, &im->labels, &im->conn_i32, &im->conn_u8, &im->small,
-                      &im->cent, &im->tiles, &im->feat, &im->graph, &im->gather_lut, &im->gather_out_i, &im->gather_out_f };
+                      &im->cent, &im->tiles, &im->feat, &im->graph, &im->gather_lut, &im->gather_out_i, &im->gather_out_f,
+                      &im->tex_planes, &im->tex_resp, &im->tex_small };
     for (auto b : all) b->release();
     delete im;
 }
@@ -297,6 +300,7 @@ void imsegm_image2d_destroy(imsegm_image2d *im)
 int imsegm_image2d_upload(imsegm_image2d *im, const void *host_pixels, int dtype)
 {
     if (!im || bind(im->ctx)) return -1;
+    im->tex_ready = false;
     size_t es = dtype == IMSEGM_U8 ? 1 : dtype == IMSEGM_F32 ? 4 : dtype == IMSEGM_F64 ? 8 : 0;
     if (!es) {
         set_error("unsupported dtype");
@@ -515,6 +519,9 @@ int imsegm_image2d_get_nearest(imsegm_image2d *im, int32_t *nearest_out)
     return 0;
 }
 
+static int stats_run(imsegm_image2d *im, const void *src, int dtype, double maxabs, int planar, int prescale, double mul,
+                     double div, double *mean_out, double *energy_out, double *var_out);
+
 int imsegm_image2d_color_stats(imsegm_image2d *im, double *mean_out, double *energy_out, double *var_out)
 {
     if (!im || bind(im->ctx)) return -1;
@@ -524,7 +531,6 @@ int imsegm_image2d_color_stats(imsegm_image2d *im, double *mean_out, double *ene
     }
     imsegm_ctx *ctx = im->ctx;
     hipStream_t st = ctx->stream;
-    const int K = im->n_labels;
     double maxabs = 255.0;
     if (im->dtype != IMSEGM_U8) {
         if (im->small.ensure(4096)) return -1;
@@ -537,25 +543,7 @@ int imsegm_image2d_color_stats(imsegm_image2d *im, double *mean_out, double *ene
         maxabs = std::max(fabs(mm[0]), fabs(mm[1]));
         if (!(maxabs < 1e300)) maxabs = 1e300;
     }
-    size_t fb = (size_t)K * (13 * 8 + 3 * 3 * 8 + 3 * 4) + 256;
-    if (im->feat.ensure(fb)) return -1;
-    unsigned char *b = im->feat.as<unsigned char>();
-    long long *acc = reinterpret_cast<long long *>(b); b += (size_t)K * 13 * 8;
-    double *d_mean = reinterpret_cast<double *>(b); b += (size_t)K * 3 * 8;
-    double *d_energy = reinterpret_cast<double *>(b); b += (size_t)K * 3 * 8;
-    double *d_var = reinterpret_cast<double *>(b); b += (size_t)K * 3 * 8;
-    float *d_mean32 = reinterpret_cast<float *>(b);
-    int sp = ctx->begin(PG_STATS);
-    if (launch_color_stats(im->img.p, im->dtype, im->labels.as<int32_t>(), im->H, im->W, K, maxabs, var_out != nullptr, acc,
-                           d_mean, d_energy, d_var, d_mean32, st))
-        return -1;
-    ctx->end(sp);
-    size_t ob = (size_t)K * 3 * 8;
-    if (mean_out) HIP_TRY(hipMemcpyAsync(mean_out, d_mean, ob, hipMemcpyDeviceToHost, st));
-    if (energy_out) HIP_TRY(hipMemcpyAsync(energy_out, d_energy, ob, hipMemcpyDeviceToHost, st));
-    if (var_out) HIP_TRY(hipMemcpyAsync(var_out, d_var, ob, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipStreamSynchronize(st));
-    return 0;
+    return stats_run(im, im->img.p, im->dtype, maxabs, 0, 0, 1.0, 1.0, mean_out, energy_out, var_out);
 }
 
 int imsegm_image2d_graph(imsegm_image2d *im, int32_t *edges_out, int edge_capacity, int *n_edges_out,
@@ -640,6 +628,115 @@ int imsegm_image2d_gather(imsegm_image2d *im, const int32_t *graph_labels, const
     if (graph_labels && segm_out) HIP_TRY(hipMemcpyAsync(segm_out, im->gather_out_i.p, n * 4, hipMemcpyDeviceToHost, st));
     if (proba && soft_out) HIP_TRY(hipMemcpyAsync(soft_out, im->gather_out_f.p, n * n_classes * 8, hipMemcpyDeviceToHost, st));
     if ((graph_labels && segm_out) || (proba && soft_out)) HIP_TRY(hipStreamSynchronize(st));
+    return 0;
+}
+
+static int stats_run(imsegm_image2d *im, const void *src, int dtype, double maxabs, int planar, int prescale, double mul,
+                     double div, double *mean_out, double *energy_out, double *var_out)
+{
+    imsegm_ctx *ctx = im->ctx;
+    hipStream_t st = ctx->stream;
+    const int K = im->n_labels;
+    size_t fb = (size_t)K * (13 * 8 + 3 * 3 * 8 + 3 * 4) + 256;
+    if (im->feat.ensure(fb)) return -1;
+    unsigned char *b = im->feat.as<unsigned char>();
+    long long *acc = reinterpret_cast<long long *>(b); b += (size_t)K * 13 * 8;
+    double *d_mean = reinterpret_cast<double *>(b); b += (size_t)K * 3 * 8;
+    double *d_energy = reinterpret_cast<double *>(b); b += (size_t)K * 3 * 8;
+    double *d_var = reinterpret_cast<double *>(b); b += (size_t)K * 3 * 8;
+    float *d_mean32 = reinterpret_cast<float *>(b);
+    int sp = ctx->begin(PG_STATS);
+    if (launch_color_stats(src, dtype, im->labels.as<int32_t>(), im->H, im->W, K, maxabs, var_out != nullptr, acc, d_mean,
+                           d_energy, d_var, d_mean32, st, planar, prescale, mul, div))
+        return -1;
+    ctx->end(sp);
+    size_t ob = (size_t)K * 3 * 8;
+    if (mean_out) HIP_TRY(hipMemcpyAsync(mean_out, d_mean, ob, hipMemcpyDeviceToHost, st));
+    if (energy_out) HIP_TRY(hipMemcpyAsync(energy_out, d_energy, ob, hipMemcpyDeviceToHost, st));
+    if (var_out) HIP_TRY(hipMemcpyAsync(var_out, d_var, ob, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    return 0;
+}
+
+int imsegm_image2d_lm_prepare(imsegm_image2d *im, const double *taps, int radius, const double *channel_mix)
+{
+    if (!im || bind(im->ctx)) return -1;
+    if (im->dtype < 0) {
+        set_error("no image uploaded");
+        return -1;
+    }
+    if (radius < 0 || !taps || !channel_mix) {
+        set_error("lm_prepare: bad arguments");
+        return -1;
+    }
+    hipStream_t st = im->ctx->stream;
+    const size_t n = im->n;
+    if (im->tex_planes.ensure(3 * n * 8) || im->labA.ensure(3 * n * 8) || im->labB.ensure(3 * n * 8)) return -1;
+    if (im->tex_small.ensure(((size_t)radius + 1 + 9) * 8 + 1024 * 8 + 4096)) return -1;
+    double *d_taps = im->tex_small.as<double>();
+    double *d_mix = d_taps + radius + 1;
+    HIP_TRY(hipMemcpyAsync(d_taps, taps, ((size_t)radius + 1) * 8, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(d_mix, channel_mix, 9 * 8, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    if (launch_texture_prepare(im->img.p, im->dtype, im->H, im->W, d_taps, radius, d_mix, im->tex_planes.as<double>(),
+                               im->labA.as<double>(), im->labB.as<double>(), st))
+        return -1;
+    im->tex_ready = true;
+    return 0;
+}
+
+int imsegm_image2d_lm_battery(imsegm_image2d *im, const double *weights, int n_kernels, int radius, double clip,
+                              double *sum_squares_out)
+{
+    if (!im || bind(im->ctx)) return -1;
+    if (!im->tex_ready) {
+        set_error("lm_battery: call imsegm_image2d_lm_prepare first");
+        return -1;
+    }
+    hipStream_t st = im->ctx->stream;
+    const size_t n = im->n;
+    const size_t S = 2 * (size_t)radius + 1;
+    const size_t wbytes = S * S * n_kernels * 8;
+    if (im->tex_resp.ensure(3 * n * 8 + wbytes + 1024 * 8 + 64)) return -1;
+    double *resp = im->tex_resp.as<double>();
+    double *d_w = resp + 3 * n;
+    double *partial = d_w + S * S * n_kernels;
+    double *d_sum = partial + 1024;
+    HIP_TRY(hipMemcpyAsync(d_w, weights, wbytes, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    if (launch_filter_battery(im->tex_planes.as<double>(), im->H, im->W, d_w, n_kernels, radius, clip, resp, partial, d_sum, st))
+        return -1;
+    HIP_TRY(hipMemcpyAsync(sum_squares_out, d_sum, 8, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    return 0;
+}
+
+int imsegm_image2d_response_stats(imsegm_image2d *im, double mul, double div, double *mean_out, double *energy_out,
+                                  double *var_out)
+{
+    if (!im || bind(im->ctx)) return -1;
+    if (!im->tex_ready || !im->have_labels || im->tex_resp.cap < 3 * im->n * 8) {
+        set_error("response_stats needs a filter response and a label map");
+        return -1;
+    }
+    double maxabs = fabs(mul / div) * 1.0;     // |response| <= its own L2 norm == div
+    if (!(div != 0.0)) {
+        set_error("response_stats: zero norm");
+        return -1;
+    }
+    maxabs = fabs(mul);                        // |r| <= norm = div  =>  |r * mul / div| <= |mul|
+    return stats_run(im, im->tex_resp.p, IMSEGM_F64, maxabs, 1, 1, mul, div, mean_out, energy_out, var_out);
+}
+
+int imsegm_image2d_get_response(imsegm_image2d *im, double *planes_out)
+{
+    if (!im || bind(im->ctx)) return -1;
+    if (im->tex_resp.cap < 3 * im->n * 8) {
+        set_error("no filter response");
+        return -1;
+    }
+    HIP_TRY(hipMemcpyAsync(planes_out, im->tex_resp.p, 3 * im->n * 8, hipMemcpyDeviceToHost, im->ctx->stream));
+    HIP_TRY(hipStreamSynchronize(im->ctx->stream));
     return 0;
 }
 

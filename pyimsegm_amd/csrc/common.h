@@ -229,6 +229,62 @@ __device__ __forceinline__ long long wave_reduce16_i64(const long long (&v)[16])
     return d;
 }
 
+// fp64 variants of the transposed reductions (used with integer-valued doubles, i.e. exact sums)
+__device__ __forceinline__ double wave_reduce8_f64(const double (&v)[8])
+{
+    const int lane = threadIdx.x & 63;
+    bool up = lane & 32;
+    double a[4], b[2];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        double send = up ? v[j] : v[j + 4], keep = up ? v[j + 4] : v[j];
+        a[j] = keep + __shfl_xor(send, 32, 64);
+    }
+    up = lane & 16;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        double send = up ? a[j] : a[j + 2], keep = up ? a[j + 2] : a[j];
+        b[j] = keep + __shfl_xor(send, 16, 64);
+    }
+    up = lane & 8;
+    double send = up ? b[0] : b[1], keep = up ? b[1] : b[0];
+    double c = keep + __shfl_xor(send, 8, 64);
+    c += __shfl_xor(c, 4, 64);
+    c += __shfl_xor(c, 2, 64);
+    c += __shfl_xor(c, 1, 64);
+    return c;
+}
+
+__device__ __forceinline__ double wave_reduce16_f64(const double (&v)[16])
+{
+    const int lane = threadIdx.x & 63;
+    bool up = lane & 32;
+    double a[8], b[4], c[2];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        double send = up ? v[j] : v[j + 8], keep = up ? v[j + 8] : v[j];
+        a[j] = keep + __shfl_xor(send, 32, 64);
+    }
+    up = lane & 16;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        double send = up ? a[j] : a[j + 4], keep = up ? a[j + 4] : a[j];
+        b[j] = keep + __shfl_xor(send, 16, 64);
+    }
+    up = lane & 8;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        double send = up ? b[j] : b[j + 2], keep = up ? b[j + 2] : b[j];
+        c[j] = keep + __shfl_xor(send, 8, 64);
+    }
+    up = lane & 4;
+    double send = up ? c[0] : c[1], keep = up ? c[1] : c[0];
+    double d = keep + __shfl_xor(send, 4, 64);
+    d += __shfl_xor(d, 2, 64);
+    d += __shfl_xor(d, 1, 64);
+    return d;
+}
+
 __device__ __forceinline__ void atomic_add_i64(long long *p, long long v)
 {
     atomicAdd(reinterpret_cast<unsigned long long *>(p), (unsigned long long)v);

@@ -79,7 +79,14 @@ int launch_enforce_connectivity(const int32_t *labels_in, int H, int W, long min
 // and (v - mean32)^2 (float32), exact fixed-point accumulation. acc: [K][13] int64 scratch.
 int launch_color_stats(const void *img, int dtype, const int32_t *labels, int H, int W, int K, double maxabs,
                        int want_var, long long *acc, double *mean_out, double *energy_out, double *var_out,
-                       float *mean32_scratch, hipStream_t st);
+                       float *mean32_scratch, hipStream_t st, int planar = 0, int prescale = 0, double mul = 1.0,
+                       double div = 1.0);
+
+// texture.hip -------------------------------------------------------------------------------------
+int launch_texture_prepare(const void *img, int dtype, int H, int W, const double *taps_dev, int radius,
+                           const double *mix_dev, double *planes, double *tmpA, double *tmpB, hipStream_t st);
+int launch_filter_battery(const double *planes, int H, int W, const double *wgt_dev, int nk, int radius, double clip,
+                          double *resp, double *partial, double *sumsq_dev, hipStream_t st);
 
 // graph.hip ---------------------------------------------------------------------------------------
 int launch_adjacency_centres(const int32_t *labels, int H, int W, int K, uint32_t *bitmap, long long *cacc,

@@ -320,13 +320,23 @@ constexpr int MAXC = SLIC_MAXC;
 // One wave per 64 x 32 pixel tile collects the centroids whose search window intersects the tile,
 // sorts them nearest-first and writes them as 96-byte records.  The assignment kernel then walks
 // its list with wave-uniform (scalar) loads: no LDS staging, no barriers in front of the hot loop.
-__global__ void __launch_bounds__(64)
-k_slic_bin(SlicState s, int tiles_x, int max_cand, Cand *__restrict__ tile_cands, int *__restrict__ tile_count)
+constexpr int BIN_TILES_PER_BLOCK = 4;     // one wave per tile, four tiles share one LDS copy of the windows
+constexpr int BIN_MAX_K_LDS = 4096;        // centroids whose windows fit the LDS copy (64 KB)
+
+__global__ void __launch_bounds__(256)
+k_slic_bin(SlicState s, int tiles_x, int n_tiles, int max_cand, Cand *__restrict__ tile_cands,
+           int *__restrict__ tile_count)
 {
-    __shared__ int ck[MAXC];
-    __shared__ float ckey[MAXC];
-    const int lane = threadIdx.x;
-    const int tile = blockIdx.x;
+    extern __shared__ int4 lds_win[];                 // [min(K, BIN_MAX_K_LDS)]
+    __shared__ int ck[BIN_TILES_PER_BLOCK][MAXC];
+    __shared__ float ckey[BIN_TILES_PER_BLOCK][MAXC];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int klds = min(s.K, BIN_MAX_K_LDS);
+    for (int k = threadIdx.x; k < klds; k += 256) lds_win[k] = s.win[k];
+    __syncthreads();
+    const int tile = blockIdx.x * BIN_TILES_PER_BLOCK + wave;
+    if (tile >= n_tiles) return;
     const int tx0 = (tile % tiles_x) * TILE_X, ty0 = (tile / tiles_x) * TILE_Y;
     const int tx1 = min(tx0 + TILE_X, s.W), ty1 = min(ty0 + TILE_Y, s.H);
     int count = 0;
@@ -335,7 +345,7 @@ k_slic_bin(SlicState s, int tiles_x, int max_cand, Cand *__restrict__ tile_cands
         bool hit = false;
         float key = 0.f;
         if (k < s.K) {
-            int4 w = s.win[k];
+            int4 w = k < klds ? lds_win[k] : s.win[k];
             hit = w.x < ty1 && w.y > ty0 && w.z < tx1 && w.w > tx0;
             // heuristic sort key: squared distance of the window centre to the tile centre
             float my = 0.5f * (float)(w.x + w.y) - 0.5f * (float)(ty0 + ty1);
@@ -346,24 +356,25 @@ k_slic_bin(SlicState s, int tiles_x, int max_cand, Cand *__restrict__ tile_cands
         if (hit) {
             int pos = count + __popcll(m & ((1ULL << lane) - 1ULL));
             if (pos < MAXC) {
-                ck[pos] = k;
-                ckey[pos] = key;
+                ck[wave][pos] = k;
+                ckey[wave][pos] = key;
             }
         }
         count += __popcll(m);
     }
-    __syncthreads();
+    // (single wave per tile from here on: LDS writes above are ordered with the reads below)
+    __builtin_amdgcn_s_waitcnt(0);
     const bool overflow = count > max_cand;
     if (lane == 0) tile_count[tile] = overflow ? -count : count;
     if (overflow) return;
     for (int c = lane; c < count; c += 64) {
-        const float key = ckey[c];
+        const float key = ckey[wave][c];
         int rank = 0;
         for (int j = 0; j < count; ++j) {
-            float kj = ckey[j];
+            float kj = ckey[wave][j];
             rank += (kj < key) || (kj == key && j < c);
         }
-        const int k = ck[c];
+        const int k = ck[wave][c];
         Cand cd;
         cd.cy = s.cy[k]; cd.cx = s.cx[k]; cd.cL = s.cL[k]; cd.ca = s.ca[k]; cd.cb = s.cb[k];
         cd.win = s.win[k];
@@ -765,8 +776,16 @@ int launch_slic_iterations(SlicState s, const double *lab, const double *init_yx
     hipLaunchKernelGGL(k_centroid_init, cdiv(s.K, 256), 256, 0, st, s, init_yx_dev);
     dim3 grid(cdiv(s.W, TILE_X), 2 * cdiv(s.H, TILE_Y));     // two 64 x 16 workgroups per bin tile
     const int n_tiles = grid.x * cdiv(s.H, TILE_Y);
+    static bool bin_attr = false;
+    if (!bin_attr) {
+        HIP_TRY(hipFuncSetAttribute((const void *)k_slic_bin, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    BIN_MAX_K_LDS * (int)sizeof(int4)));
+        bin_attr = true;
+    }
     for (int it = 0; it < max_iter; ++it) {
-        hipLaunchKernelGGL(k_slic_bin, n_tiles, 64, 0, st, s, (int)grid.x, max_cand, s.tile_cands, s.tile_count);
+        hipLaunchKernelGGL(k_slic_bin, cdiv(n_tiles, BIN_TILES_PER_BLOCK), 256,
+                           (size_t)std::min(s.K, BIN_MAX_K_LDS) * sizeof(int4), st, s, (int)grid.x, n_tiles, max_cand,
+                           s.tile_cands, s.tile_count);
         int span = prof.begin ? prof.begin(prof.user, 0) : -1;
         // first sweep: integer-grid centroids with zero colour -> exact integer path (needs the
         // fast-path preconditions and a spatial weight far above the fp64 resolution)

@@ -34,6 +34,9 @@ template <typename T> __device__ __forceinline__ float load_f32(const T *p, size
 struct StatParams {
     int H, W, K;
     double scale_v, scale_e;      // 2^shift for the value / squared-value sums
+    int planar;                   // 0: H x W x 3 interleaved, 1: [3][H][W] planes
+    int prescale;                 // 1: value = (raw * mul) / div before the float32 staging
+    double mul, div;              //    (descriptors.py:1094 `(response * (log(1 + norm) / 0.03)) / norm`)
 };
 
 // NV = number of accumulated quantities per channel group: PASS 1 -> n + 3 x (v, v*v); PASS 2 -> 3 x (v - m)^2
@@ -63,7 +66,10 @@ k_color_stats(const T *__restrict__ img, const int32_t *__restrict__ labels, Sta
             size_t p = ok ? (size_t)y * sp.W + x : 0;
             lab[i] = ok ? labels[p] : -1;
 #pragma unroll
-            for (int c = 0; c < 3; ++c) v[i][c] = load_f32(img, 3 * p + c);
+            for (int c = 0; c < 3; ++c) {
+                const size_t idx = sp.planar ? (size_t)c * sp.H * sp.W + p : 3 * p + c;
+                v[i][c] = sp.prescale ? (float)(((double)img[idx] * sp.mul) / sp.div) : load_f32(img, idx);
+            }
         }
         // one pass per distinct label in the wave
         while (true) {
@@ -76,30 +82,33 @@ k_color_stats(const T *__restrict__ img, const int32_t *__restrict__ labels, Sta
             int k = __shfl(first, __ffsll((long long)vote) - 1, 64);
             // partial sums of this lane: PASS 1 -> q[0..5] sums of v, q[6..11] sums of v*v, q[12] count
             //                            PASS 2 -> q[0..5] sums of (v - mean32)^2
+            // The fixed-point limbs are kept as integer-valued doubles (|limb| * pixels-per-wave < 2^53 by
+            // the choice of the scales), so the per-lane and per-wave sums are exact in fp64 and only
+            // the owner lane converts its total to int64 -- no 64-bit integer conversions per pixel.
             constexpr int NV = (PASS == 1) ? 16 : 8;
-            long long q[NV];
+            double q[NV];
 #pragma unroll
             for (int j = 0; j < NV; ++j) q[j] = 0;
 #pragma unroll
             for (int i = 0; i < ST_PX; ++i) {
                 if (lab[i] != k) continue;
                 lab[i] = -1;
-                if (PASS == 1) q[12] += 1;
+                if (PASS == 1) q[12] += 1.0;
 #pragma unroll
                 for (int c = 0; c < 3; ++c) {
-                    long long hi, lo;
+                    double t, h;
                     if (PASS == 1) {
                         float val = v[i][c];
                         float sq = __fmul_rn(val, val);
-                        fix_split_sh((double)val, sp.scale_v, hi, lo);
-                        q[2 * c] += hi; q[2 * c + 1] += lo;
-                        fix_split_sh((double)sq, sp.scale_e, hi, lo);
-                        q[6 + 2 * c] += hi; q[6 + 2 * c + 1] += lo;
+                        t = (double)val * sp.scale_v; h = trunc(t);
+                        q[2 * c] += h; q[2 * c + 1] += trunc((t - h) * 4294967296.0);
+                        t = (double)sq * sp.scale_e; h = trunc(t);
+                        q[6 + 2 * c] += h; q[6 + 2 * c + 1] += trunc((t - h) * 4294967296.0);
                     } else {
                         float d = __fsub_rn(v[i][c], mean32[3 * k + c]);
                         float sq = __fmul_rn(d, d);
-                        fix_split_sh((double)sq, sp.scale_e, hi, lo);
-                        q[2 * c] += hi; q[2 * c + 1] += lo;
+                        t = (double)sq * sp.scale_e; h = trunc(t);
+                        q[2 * c] += h; q[2 * c + 1] += trunc((t - h) * 4294967296.0);
                     }
                 }
             }
@@ -108,11 +117,11 @@ k_color_stats(const T *__restrict__ img, const int32_t *__restrict__ labels, Sta
             int j;
             bool owner;
             if (PASS == 1) {
-                tot = wave_reduce16_i64(reinterpret_cast<const long long (&)[16]>(q));
+                tot = (long long)wave_reduce16_f64(reinterpret_cast<const double (&)[16]>(q));
                 j = lane >> 2;
                 owner = (lane & 3) == 0 && j < 13;
             } else {
-                tot = wave_reduce8_i64(reinterpret_cast<const long long (&)[8]>(q));
+                tot = (long long)wave_reduce8_f64(reinterpret_cast<const double (&)[8]>(q));
                 j = lane >> 3;
                 owner = (lane & 7) == 0 && j < 6;
             }
@@ -202,21 +211,24 @@ static void launch_pass(int pass, const T *img, const int32_t *labels, StatParam
 
 static double pow2_scale(double n_pixels, double maxabs)
 {
-    // largest power of two with n_pixels * maxabs * scale < 2^62, capped at 2^30
+    // largest power of two with n_pixels * maxabs * scale < 2^62 (int64 accumulators) and
+    // 256 * maxabs * scale < 2^52 (exact fp64 sums inside one wave), capped at 2^30
     int e_n, e_m;
     frexp(n_pixels, &e_n);
     frexp(maxabs > 1.0 ? maxabs : 1.0, &e_m);
     int sh = 62 - e_n - e_m;
+    if (sh > 44 - e_m) sh = 44 - e_m;
     if (sh > 30) sh = 30;
     return ldexp(1.0, sh);
 }
 
 int launch_color_stats(const void *img, int dtype, const int32_t *labels, int H, int W, int K, double maxabs,
                        int want_var, long long *acc, double *mean_out, double *energy_out, double *var_out,
-                       float *mean32_scratch, hipStream_t st)
+                       float *mean32_scratch, hipStream_t st, int planar, int prescale, double mul, double div)
 {
     StatParams sp;
     sp.H = H; sp.W = W; sp.K = K;
+    sp.planar = planar; sp.prescale = prescale; sp.mul = mul; sp.div = div;
     sp.scale_v = pow2_scale((double)H * W, maxabs);
     sp.scale_e = pow2_scale((double)H * W, 4.0 * maxabs * maxabs);
     hipLaunchKernelGGL(k_stats_clear, cdiv(K, 256), 256, 0, st, acc, K, 0, 13);

@@ -631,10 +631,14 @@ def compute_texture_desc_lm_img2d_clr(img, seg, feature_flags, bank_type='normal
     img, seg = np.asarray(img), np.asarray(seg)
     _check_color_image(img)
     logging.debug('compute texture descriptors using Leung-Malik')
+    filters, fl_names = _select_bank(bank_type)
+    on_device = set(feature_flags) <= {'mean', 'std', 'energy'} and all(len(f) <= 8 for f in filters)
+    if on_device:
+        return _texture_desc_lm_device(img, seg, feature_flags, filters, fl_names)
+    # host path (median / meanGrad need the response on the host): scipy as the reference
     # scalar sigma on all three axes, channel axis included (descriptors.py:1078)
     img = img - ndimage.gaussian_filter(img.astype(float), 150)
     img_roll = np.rollaxis(img, -1, 0)
-    filters, fl_names = _select_bank(bank_type)
     sess = _hip.Image2D(seg.shape[0], seg.shape[1]).set_labels(seg)
     features, names = [], []
     for battery, fl_name in zip(filters, fl_names):
@@ -645,12 +649,52 @@ def compute_texture_desc_lm_img2d_clr(img, seg, feature_flags, bank_type='normal
         features.append(fts)
         names += ns
     sess.close()
+    return _finish_texture(features, names)
+
+
+def _finish_texture(features, names):
     features = np.nan_to_num(np.concatenate(tuple(features), axis=1))
     features[features == 0] = 0
     names = ['tLM_%s' % name for name in names]
     if features.shape[1] != len(names):
         raise ValueError('features: %r and names %r' % (features.shape, names))
     return features, names
+
+
+def _texture_desc_lm_device(img, seg, feature_flags, filters, fl_names, sess=None):
+    """Leung-Malik statistics entirely on the GPU: high-pass, filter batteries with orientation
+    maximum, global norm, per-superpixel statistics (texture.hip + stats.hip)"""
+    own = sess is None
+    if own:
+        sess = _hip.Image2D(seg.shape[0], seg.shape[1]).upload(np.nan_to_num(img)).set_labels(seg)
+    sess.lm_prepare(150.)
+    want = [f in feature_flags for f in ('mean', 'std', 'energy')]
+    features, names = [], []
+    for battery, fl_name in zip(filters, fl_names):
+        norm = sess.lm_battery(battery, MAX_SIGNAL_RESPONSE)
+        nb = sess.n_labels
+        if norm == 0 or abs(norm) == np.inf:
+            mean = energy = var = np.zeros((nb, 3))
+        else:
+            mean, energy, var = sess.response_stats(np.log(1 + norm) / 0.03, norm, mean=want[0], energy=want[2],
+                                                    var=want[1])
+        blocks = []
+        if want[0]:
+            blocks.append(mean)
+        if want[1]:
+            blocks.append(np.sqrt(var))
+        if want[2]:
+            blocks.append(energy)
+        fts = np.nan_to_num(np.hstack(blocks))
+        fts[fts == 0] = 0
+        features.append(fts)
+        ch_names = ['%s-ch%i' % (fl_name, i + 1) for i in range(3)]
+        names += list(itertools.chain.from_iterable(['%s_%s' % (n, f) for n in ch_names] for f in NAMES_FEATURE_FLAGS
+                                                    if f in feature_flags))
+    _check_unrecognised_feature_names(feature_flags)
+    if own:
+        sess.close()
+    return _finish_texture(features, names)
 
 
 # ------------------------------------------------------------------------------------------------

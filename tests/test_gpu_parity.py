@@ -199,3 +199,45 @@ def test_full_size_properties(hip):
     mean, energy, var = im.color_stats()
     glob = img.reshape(-1, 3).astype(np.float64).mean(axis=0)
     assert np.allclose((mean * counts[:, None]).sum(axis=0) / n, glob, rtol=1e-12)
+
+
+EDGE_CASES = [
+    ('ovary_slice_size', lambda: voronoi_image(647, 1024, seed=100), 35, 0.2),    # BASELINE config 4 image shape
+    ('tiny_20x30', lambda: voronoi_image(20, 30, seed=5, nb_seeds=4), 6, 0.3),     # smaller than one tile
+    ('one_superpixel', lambda: voronoi_image(40, 50, seed=6, nb_seeds=3), 40, 0.2),  # K = 1
+    ('thin_strip', lambda: voronoi_image(9, 400, seed=8, nb_seeds=6), 8, 0.25),
+    ('low_compactness', lambda: voronoi_image(150, 170, seed=9), 12, 0.02),         # large colour weight
+    ('binary_0_1', lambda: (voronoi_image(96, 96, seed=2) > 100).astype(np.uint8), 10, 0.2),   # min 0, max 1: no scaling
+]
+
+
+@pytest.mark.parametrize('name,make,sp,regul', EDGE_CASES, ids=[c[0] for c in EDGE_CASES])
+def test_slic_edge_cases_bit_exact(hip, oracle, name, make, sp, regul):
+    img = make()
+    ref_labels = oracle.segment_slic_img2d(img, sp, regul)
+    n_seg, compact = _params(img, sp, regul)
+    im = hip.Image2D(*img.shape[:2]).upload(img)
+    k = im.slic(n_seg, compact, sigma=1., normalize=2)
+    assert np.array_equal(im.get_labels(), ref_labels)
+    assert k == ref_labels.max() + 1
+    # the rest of the stage chain on the same label map
+    edges, centres, present = im.graph()
+    v_ref, e_ref = oracle.adjacency(ref_labels)
+    assert edges.tolist() == e_ref and np.flatnonzero(present).tolist() == v_ref.tolist()
+    assert np.array_equal(centres, oracle.centers(ref_labels))
+    mean, energy, var = im.color_stats()
+    img32 = img.astype(np.float32)
+    assert np.array_equal(mean, oracle.color2d_mean(img32, ref_labels))
+    assert np.array_equal(energy, oracle.color2d_energy(img32, ref_labels))
+
+
+def test_slic_exact_path_matches_fast_path(hip, oracle):
+    """normalize=0 disables the fp32 pre-selection (exact fp64 loop for every pixel): same labels"""
+    img = voronoi_image(200, 230, seed=12).astype(np.float64) / 255.
+    n_seg, compact = _params(img, 14, 0.2)
+    ref = oracle.slic(img, n_seg, compact, sigma=1.)
+    im = hip.Image2D(200, 230).upload(img)
+    im.slic(n_seg, compact, sigma=1., normalize=0)
+    exact = im.get_labels()
+    im.slic(n_seg, compact, sigma=1., normalize=2)      # data spans [0, 1] only approximately -> scaled
+    assert np.array_equal(exact, ref)
