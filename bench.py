@@ -146,6 +146,14 @@ def main():
         value = world * args.steps * npx / elapsed / 1e6
         avg_assign_s = assign_ms / max(assign_n, 1) / 1e3
         achieved = ASSIGN_BYTES_PER_PX * npx / avg_assign_s / 1e9 if assign_n else 0.0
+        traffic = None
+        try:   # HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
+            with open(os.path.join(ROOT, 'profiles', 'pmc_traffic.json')) as fp:
+                pmc = json.load(fp)
+            if size == HEIGHT:
+                traffic = pmc['hbm_bytes_per_launch']
+        except Exception:
+            pass
         out = {
             'metric': 'Mpixels/s end-to-end SLIC+fts+GC, 2048x2048 RGB; % HBM roofline',
             'value': round(value, 3),
@@ -173,7 +181,8 @@ def main():
                 'peak': HBM_PEAK_GBS,
                 'unit': 'GB/s',
                 'frac': round(achieved / HBM_PEAK_GBS, 5),
-                'traffic': None,
+                'traffic': traffic,
+                'traffic_source': 'profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)',
                 'avg_kernel_us': round(avg_assign_s * 1e6, 3),
                 'launches': assign_n,
                 'algorithmic_bytes_per_launch': ASSIGN_BYTES_PER_PX * npx,

@@ -66,6 +66,32 @@ struct imsegm_ctx {
     double acc_ms[PG_COUNT] = { 0 };
     int acc_n[PG_COUNT] = { 0 };
     DevBuf gc_buf;   // scratch of imsegm_cut_general_graph
+    void *pinned = nullptr;          // page-locked staging for the small host <-> device transfers
+    size_t pinned_cap = 0;
+    hipEvent_t pinned_ev = nullptr;   // recorded after an H2D out of `pinned` that nobody waits for
+    bool pinned_busy = false;
+    void mark_stage_in_flight()
+    {
+        if (!pinned_ev) (void)hipEventCreateWithFlags(&pinned_ev, hipEventDisableTiming);
+        (void)hipEventRecord(pinned_ev, stream);
+        pinned_busy = true;
+    }
+    void *stage(size_t bytes)
+    {
+        if (pinned_busy) {
+            (void)hipEventSynchronize(pinned_ev);
+            pinned_busy = false;
+        }
+        if (bytes > pinned_cap) {
+            if (pinned) (void)hipHostFree(pinned);
+            pinned = nullptr;
+            pinned_cap = 0;
+            size_t want = bytes + bytes / 2 + 4096;
+            if (hipHostMalloc(&pinned, want, hipHostMallocDefault) != hipSuccess) return nullptr;
+            pinned_cap = want;
+        }
+        return pinned;
+    }
 
     hipEvent_t get_event()
     {
@@ -226,6 +252,8 @@ void imsegm_ctx_destroy(imsegm_ctx *ctx)
     ctx->collect();
     for (auto e : ctx->pool) (void)hipEventDestroy(e);
     ctx->gc_buf.release();
+    if (ctx->pinned_ev) (void)hipEventDestroy(ctx->pinned_ev);
+    if (ctx->pinned) (void)hipHostFree(ctx->pinned);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -344,14 +372,11 @@ int imsegm_image2d_slic(imsegm_image2d *im, int minmax_normalize, int n_segments
     long shape[3] = { 1, H, W };
     GridAxis ax[3];
     regular_grid3(shape, n_segments, ax);
-    std::vector<double> init;
-    for (long y = ax[1].start; y < H; y += ax[1].step)
-        for (long x = ax[2].start; x < W; x += ax[2].step) {
-            init.push_back((double)y);
-            init.push_back((double)x);
-        }
+    long ny = 0, nx = 0;
+    for (long y = ax[1].start; y < H; y += ax[1].step) ny++;
+    for (long x = ax[2].start; x < W; x += ax[2].step) nx++;
     // (depth axis: one z = 0 plane, z start is always 0 for a length-1 axis)
-    const int K = (int)(init.size() / 2);
+    const int K = (int)(ny * nx);
     if (K < 1) {
         set_error("slic: empty centroid grid");
         return -1;
@@ -408,13 +433,13 @@ int imsegm_image2d_slic(imsegm_image2d *im, int minmax_normalize, int n_segments
     s.ca = reinterpret_cast<double *>(cb); cb += (size_t)K * 8;
     s.cb = reinterpret_cast<double *>(cb); cb += (size_t)K * 8;
     s.win = reinterpret_cast<int4 *>(cb); cb += (size_t)K * 16;
-    double *init_dev = reinterpret_cast<double *>(cb);   // K * 2 doubles
+    s.grid_y0 = (int)ax[1].start; s.grid_dy = (int)ax[1].step;
+    s.grid_x0 = (int)ax[2].start; s.grid_dx = (int)ax[2].step; s.grid_nx = (int)nx;
+    double *init_dev = nullptr;                            // the grid is generated on the device
     s.tile_cands = im->tiles.as<Cand>();
     s.tile_count = reinterpret_cast<int *>(im->tiles.as<unsigned char>() + n_tiles * SLIC_MAXC * sizeof(Cand));
     s.leftover_count = s.tile_count + n_tiles + 16;
     s.leftover = s.leftover_count + 16;
-    HIP_TRY(hipMemcpyAsync(init_dev, init.data(), init.size() * sizeof(double), hipMemcpyHostToDevice, st));
-    HIP_TRY(hipStreamSynchronize(st));   // `init` is a stack-owned host vector
 
     ProfHook hook;
     if (ctx->profile) {
@@ -578,16 +603,24 @@ int imsegm_image2d_graph(imsegm_image2d *im, int32_t *edges_out, int edge_capaci
                                  centres, present, rowcount, st))
         return -1;
     ctx->end(sp);
-    int ne = 0;
-    HIP_TRY(hipMemcpyAsync(&ne, n_edges_dev, 4, hipMemcpyDeviceToHost, st));
-    if (centres_out) HIP_TRY(hipMemcpyAsync(centres_out, centres, (size_t)K * 16, hipMemcpyDeviceToHost, st));
-    if (present_out) HIP_TRY(hipMemcpyAsync(present_out, present, K, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipStreamSynchronize(st));
-    if (edges_out && ne > 0) {
-        int m = std::min(ne, edge_capacity);
-        HIP_TRY(hipMemcpyAsync(edges_out, edges, (size_t)m * 8, hipMemcpyDeviceToHost, st));
-        HIP_TRY(hipStreamSynchronize(st));
+    // one D2H of the whole result block through pinned memory: centres | edges | rowcount | n_edges | present
+    size_t off_edges = (size_t)K * 16 + (size_t)K * words * 4;
+    (void)off_edges;
+    size_t sz_c = (size_t)K * 16, sz_e = (size_t)edge_capacity * 8, sz_p = (size_t)K;
+    unsigned char *host = static_cast<unsigned char *>(ctx->stage(sz_c + sz_e + sz_p + 64));
+    if (!host) {
+        set_error("cannot allocate pinned staging memory");
+        return -1;
     }
+    HIP_TRY(hipMemcpyAsync(host, n_edges_dev, 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(host + 64, centres, sz_c, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(host + 64 + sz_c, present, sz_p, hipMemcpyDeviceToHost, st));
+    if (edge_capacity > 0) HIP_TRY(hipMemcpyAsync(host + 64 + sz_c + sz_p, edges, sz_e, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    int ne = *reinterpret_cast<int *>(host);
+    if (centres_out) memcpy(centres_out, host + 64, sz_c);
+    if (present_out) memcpy(present_out, host + 64 + sz_c, sz_p);
+    if (edges_out && ne > 0) memcpy(edges_out, host + 64 + sz_c + sz_p, (size_t)std::min(ne, edge_capacity) * 8);
     *n_edges_out = ne;
     return 0;
 }
@@ -608,19 +641,23 @@ int imsegm_image2d_gather(imsegm_image2d *im, const int32_t *graph_labels, const
     if (im->gather_lut.ensure(lut_bytes)) return -1;
     double *d_proba = im->gather_lut.as<double>();
     int32_t *d_gl = reinterpret_cast<int32_t *>(im->gather_lut.as<unsigned char>() + (proba ? (size_t)K * n_classes * 8 : 0));
-    if (graph_labels) {
-        if (im->gather_out_i.ensure(n * 4)) return -1;
-        HIP_TRY(hipMemcpyAsync(d_gl, graph_labels, (size_t)K * 4, hipMemcpyHostToDevice, st));
+    if (proba && n_classes < 1) {
+        set_error("n_classes must be positive");
+        return -1;
     }
-    if (proba) {
-        if (n_classes < 1) {
-            set_error("n_classes must be positive");
-            return -1;
-        }
-        if (im->gather_out_f.ensure(n * n_classes * 8)) return -1;
-        HIP_TRY(hipMemcpyAsync(d_proba, proba, (size_t)K * n_classes * 8, hipMemcpyHostToDevice, st));
+    if (graph_labels && im->gather_out_i.ensure(n * 4)) return -1;
+    if (proba && im->gather_out_f.ensure(n * n_classes * 8)) return -1;
+    // both LUTs travel in one pinned block: [proba K x C f64 | labels K i32]
+    const size_t pb = proba ? (size_t)K * n_classes * 8 : 0, lb = graph_labels ? (size_t)K * 4 : 0;
+    unsigned char *host = static_cast<unsigned char *>(ctx->stage(pb + lb + 64));
+    if (!host) {
+        set_error("cannot allocate pinned staging memory");
+        return -1;
     }
-    HIP_TRY(hipStreamSynchronize(st));   // the host arrays belong to the caller
+    if (proba) memcpy(host, proba, pb);
+    if (graph_labels) memcpy(host + pb, graph_labels, lb);
+    HIP_TRY(hipMemcpyAsync(im->gather_lut.p, host, pb + lb, hipMemcpyHostToDevice, st));
+    ctx->mark_stage_in_flight();
     int sp = ctx->begin(PG_GATHER);
     if (graph_labels && launch_gather_labels(d_gl, im->labels.as<int32_t>(), n, im->gather_out_i.as<int32_t>(), st)) return -1;
     if (proba && launch_gather_proba(d_proba, n_classes, im->labels.as<int32_t>(), n, im->gather_out_f.as<double>(), st)) return -1;
@@ -651,10 +688,16 @@ static int stats_run(imsegm_image2d *im, const void *src, int dtype, double maxa
         return -1;
     ctx->end(sp);
     size_t ob = (size_t)K * 3 * 8;
-    if (mean_out) HIP_TRY(hipMemcpyAsync(mean_out, d_mean, ob, hipMemcpyDeviceToHost, st));
-    if (energy_out) HIP_TRY(hipMemcpyAsync(energy_out, d_energy, ob, hipMemcpyDeviceToHost, st));
-    if (var_out) HIP_TRY(hipMemcpyAsync(var_out, d_var, ob, hipMemcpyDeviceToHost, st));
+    double *host = static_cast<double *>(ctx->stage(3 * ob));
+    if (!host) {
+        set_error("cannot allocate pinned staging memory");
+        return -1;
+    }
+    HIP_TRY(hipMemcpyAsync(host, d_mean, 3 * ob, hipMemcpyDeviceToHost, st));     // mean | energy | var
     HIP_TRY(hipStreamSynchronize(st));
+    if (mean_out) memcpy(mean_out, host, ob);
+    if (energy_out) memcpy(energy_out, host + (size_t)K * 3, ob);
+    if (var_out) memcpy(var_out, host + (size_t)K * 6, ob);
     return 0;
 }
 
@@ -778,13 +821,31 @@ int imsegm_cut_general_graph(imsegm_ctx *ctx, const int32_t *edges, int n_edges,
                 set_error("Cost matrix not square or not symmetric");
                 return -1;
             }
+    // device layout: [work | unary | w | smooth | edges | arc_start | arc_to | arc_rev | edge_arc | labels | energy | status];
+    // the upload part (unary .. edge_arc) is assembled in ONE pinned host block with the same offsets
+    hipStream_t st = ctx->stream;
+    const size_t En = (size_t)std::max(E, 1);
+    auto al = [](size_t v) { return (v + 63) & ~(size_t)63; };
+    const size_t work_bytes = al(alpha_expansion_work_bytes(K, E));
+    const size_t o_u = 0, o_w = o_u + al((size_t)K * C * 4), o_s = o_w + al(En * 4), o_e = o_s + al((size_t)C * C * 4);
+    const size_t o_as = o_e + al(En * 8), o_at = o_as + al((size_t)(K + 1) * 4), o_ar = o_at + al(En * 8);
+    const size_t o_ea = o_ar + al(En * 8), up_bytes = o_ea + al(En * 8);
+    const size_t o_lab = up_bytes, o_en = o_lab + al((size_t)K * 4), o_st = o_en + 64, io_bytes = o_st + 64;
+    if (ctx->gc_buf.ensure(work_bytes + io_bytes + 256)) return -1;
+    unsigned char *host = static_cast<unsigned char *>(ctx->stage(io_bytes));
+    if (!host) {
+        set_error("cannot allocate pinned staging memory");
+        return -1;
+    }
+    int32_t *ui = (int32_t *)(host + o_u), *wi = (int32_t *)(host + o_w), *si = (int32_t *)(host + o_s);
+    int32_t *he = (int32_t *)(host + o_e), *arc_start = (int32_t *)(host + o_as), *arc_to = (int32_t *)(host + o_at);
+    int32_t *arc_rev = (int32_t *)(host + o_ar), *edge_arc = (int32_t *)(host + o_ea);
     // pyGCO (gco/pygco.py): down_weight_factor and float -> int conversion (truncation)
     double mu = 0, mw = 0, mp = -DBL_MAX;
     for (size_t i = 0; i < (size_t)K * C; ++i) mu = std::max(mu, fabs(unary_cost[i]));
     for (int i = 0; i < E; ++i) mw = std::max(mw, fabs(edge_weights[i]));
     for (int i = 0; i < C * C; ++i) mp = std::max(mp, pairwise_cost[i]);
     double dwf = ((E > 0 && mw * mp > mu) ? mw * mp : mu) + 1e-10;
-    std::vector<int32_t> ui((size_t)K * C), wi(std::max(E, 1)), si((size_t)C * C);
     for (size_t i = 0; i < (size_t)K * C; ++i) ui[i] = (int32_t)((unary_cost[i] / dwf) * 100000);
     for (int i = 0; i < E; ++i) wi[i] = (int32_t)((edge_weights[i] / dwf) * 1000);
     for (int i = 0; i < C * C; ++i) si[i] = (int32_t)(pairwise_cost[i] * 100);
@@ -797,15 +858,15 @@ int imsegm_cut_general_graph(imsegm_ctx *ctx, const int32_t *edges, int n_edges,
             return -1;
         }
     // CSR over directed arcs
-    std::vector<int32_t> arc_start(K + 1, 0), arc_to(2 * (size_t)std::max(E, 1)), arc_rev(2 * (size_t)std::max(E, 1)),
-        edge_arc(2 * (size_t)std::max(E, 1));
+    if (E > 0) memcpy(he, edges, (size_t)E * 8);
+    for (int i = 0; i <= K; ++i) arc_start[i] = 0;
     for (int j = 0; j < E; ++j) {
         arc_start[edges[2 * j] + 1]++;
         arc_start[edges[2 * j + 1] + 1]++;
     }
     for (int i = 0; i < K; ++i) arc_start[i + 1] += arc_start[i];
     {
-        std::vector<int32_t> fill(arc_start.begin(), arc_start.end() - 1);
+        std::vector<int32_t> fill(arc_start, arc_start + K);
         for (int j = 0; j < E; ++j) {
             int a = edges[2 * j], b = edges[2 * j + 1];
             int ia = fill[a]++, ib = fill[b]++;
@@ -817,49 +878,27 @@ int imsegm_cut_general_graph(imsegm_ctx *ctx, const int32_t *edges, int n_edges,
             edge_arc[2 * j + 1] = ib;
         }
     }
-    hipStream_t st = ctx->stream;
-    size_t work_bytes = alpha_expansion_work_bytes(K, E);
-    size_t sz_u = (size_t)K * C * 4, sz_w = (size_t)std::max(E, 1) * 4, sz_s = (size_t)C * C * 4, sz_e = (size_t)std::max(E, 1) * 8;
-    size_t sz_as = (size_t)(K + 1) * 4, sz_a = (size_t)std::max(E, 1) * 8;
-    auto al = [](size_t v) { return (v + 63) & ~(size_t)63; };
-    size_t total = al(work_bytes) + al(sz_u) + al(sz_w) + al(sz_s) + al(sz_e) + al(sz_as) + 3 * al(sz_a) + al((size_t)K * 4) + 256;
-    if (ctx->gc_buf.ensure(total)) return -1;
-    unsigned char *b = ctx->gc_buf.as<unsigned char>();
-    void *work = b; b += al(work_bytes);
-    int32_t *d_u = (int32_t *)b; b += al(sz_u);
-    int32_t *d_w = (int32_t *)b; b += al(sz_w);
-    int32_t *d_s = (int32_t *)b; b += al(sz_s);
-    int32_t *d_e = (int32_t *)b; b += al(sz_e);
-    int32_t *d_as = (int32_t *)b; b += al(sz_as);
-    int32_t *d_at = (int32_t *)b; b += al(sz_a);
-    int32_t *d_ar = (int32_t *)b; b += al(sz_a);
-    int32_t *d_ea = (int32_t *)b; b += al(sz_a);
-    int32_t *d_lab = (int32_t *)b; b += al((size_t)K * 4);
-    long long *d_energy = (long long *)b; b += 64;
-    int32_t *d_status = (int32_t *)b;
-    HIP_TRY(hipMemcpyAsync(d_u, ui.data(), sz_u, hipMemcpyHostToDevice, st));
-    HIP_TRY(hipMemcpyAsync(d_s, si.data(), sz_s, hipMemcpyHostToDevice, st));
-    if (E > 0) {
-        HIP_TRY(hipMemcpyAsync(d_w, wi.data(), (size_t)E * 4, hipMemcpyHostToDevice, st));
-        HIP_TRY(hipMemcpyAsync(d_e, edges, (size_t)E * 8, hipMemcpyHostToDevice, st));
-        HIP_TRY(hipMemcpyAsync(d_at, arc_to.data(), (size_t)E * 8, hipMemcpyHostToDevice, st));
-        HIP_TRY(hipMemcpyAsync(d_ar, arc_rev.data(), (size_t)E * 8, hipMemcpyHostToDevice, st));
-        HIP_TRY(hipMemcpyAsync(d_ea, edge_arc.data(), (size_t)E * 8, hipMemcpyHostToDevice, st));
-    }
-    HIP_TRY(hipMemcpyAsync(d_as, arc_start.data(), sz_as, hipMemcpyHostToDevice, st));
+    unsigned char *dev = ctx->gc_buf.as<unsigned char>();
+    void *work = dev;
+    unsigned char *io = dev + work_bytes;
+    int32_t *d_lab = (int32_t *)(io + o_lab);
+    long long *d_energy = (long long *)(io + o_en);
+    int32_t *d_status = (int32_t *)(io + o_st);
+    HIP_TRY(hipMemcpyAsync(io, host, up_bytes, hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemsetAsync(d_status, 0, 4, st));
     GcProblem p;
     p.K = K; p.C = C; p.E = E;
-    p.edges = d_e; p.w = d_w; p.unary = d_u; p.smooth = d_s;
+    p.edges = (int32_t *)(io + o_e); p.w = (int32_t *)(io + o_w); p.unary = (int32_t *)(io + o_u); p.smooth = (int32_t *)(io + o_s);
     int sp = ctx->begin(PG_GC);
-    if (launch_alpha_expansion(p, d_as, d_at, d_ar, d_ea, n_iter, d_lab, d_energy, d_status, work, st)) return -1;
+    if (launch_alpha_expansion(p, (int32_t *)(io + o_as), (int32_t *)(io + o_at), (int32_t *)(io + o_ar), (int32_t *)(io + o_ea),
+                               n_iter, d_lab, d_energy, d_status, work, st))
+        return -1;
     ctx->end(sp);
-    long long energy = 0;
-    int32_t status = 0;
-    HIP_TRY(hipMemcpyAsync(labels_out, d_lab, (size_t)K * 4, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipMemcpyAsync(&energy, d_energy, 8, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipMemcpyAsync(&status, d_status, 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(host + o_lab, d_lab, io_bytes - o_lab, hipMemcpyDeviceToHost, st));   // labels | energy | status
     HIP_TRY(hipStreamSynchronize(st));
+    memcpy(labels_out, host + o_lab, (size_t)K * 4);
+    long long energy = *reinterpret_cast<long long *>(host + o_en);
+    int32_t status = *reinterpret_cast<int32_t *>(host + o_st);
     if (status != 0) {
         set_error("alpha_expansion: max-flow did not converge");
         return -1;

@@ -40,6 +40,7 @@ struct SlicState {
     int *leftover_count;            // [1]
     int fast32;                     // 1: fp32 pre-selection allowed (Lab bounded by lab_bound)
     float kappa;                    // relative decision margin of the fp32 pass (see k_slic_assign)
+    int grid_y0, grid_dy, grid_x0, grid_dx, grid_nx;   // initial centroid grid (skimage regular_grid)
     int debug;                      // profiling aid (env IMSEGM_DEBUG_ASSIGN): ablation bits, results invalid
 };
 

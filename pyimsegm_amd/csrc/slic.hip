@@ -271,11 +271,14 @@ __device__ __forceinline__ int4 search_window(double cy, double cx, int step_y, 
     return w;
 }
 
+// regular grid of skimage.util.regular_grid: centroid k = (iy, ix) in row-major order
 __global__ void k_centroid_init(SlicState s, const double *__restrict__ init_yx)
 {
     int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= s.K) return;
-    double cy = init_yx[2 * k], cx = init_yx[2 * k + 1];
+    (void)init_yx;
+    const int iy = k / s.grid_nx, ix = k - iy * s.grid_nx;
+    double cy = (double)(s.grid_y0 + iy * s.grid_dy), cx = (double)(s.grid_x0 + ix * s.grid_dx);
     s.cy[k] = cy;
     s.cx[k] = cx;
     s.cL[k] = 0.0;
