@@ -112,6 +112,33 @@ IMSEGM_API int imsegm_image2d_response_stats(imsegm_image2d *img, double mul, do
 /* inspection for the parity tests: the current filter response as [3][H][W] planes */
 IMSEGM_API int imsegm_image2d_get_response(imsegm_image2d *img, double *planes_out);
 
+/* ---------------------------------------------------------------------------------------------
+ * gray volumes D x H x W (the session type is shared; get_labels / set_labels / gather work on it)
+ * ------------------------------------------------------------------------------------------- */
+IMSEGM_API int imsegm_volume_create(imsegm_ctx *ctx, int depth, int height, int width, imsegm_image2d **vol_out);
+/* The descriptors read the voxels as uploaded (float32 staging of features_cython.pyx); SLIC reads
+ * (v + slic_offset) * slic_scale, the affine form of skimage.util.img_as_float for the source dtype
+ * (uint8: 0, 1/255; floats: 0, 1). */
+IMSEGM_API int imsegm_volume_upload(imsegm_image2d *vol, const void *host_voxels, int dtype, double slic_offset,
+                                    double slic_scale);
+/* Replaces skimage.segmentation.slic(im, n_segments, compactness, multichannel=False, spacing=space,
+ * sigma=1) as called at imsegm/superpixels.py:104-106: gray supervoxels, anisotropic spacing[3] (z, y, x);
+ * taps_* are the half kernels for sigma / spacing per axis. */
+IMSEGM_API int imsegm_volume_slic(imsegm_image2d *vol, int n_segments, double compactness, const double *taps_z,
+                                  int radius_z, const double *taps_y, int radius_y, const double *taps_x, int radius_x,
+                                  const double *spacing, int max_iter, int enforce_connectivity, double min_size_factor,
+                                  double max_size_factor, int start_label, int *n_labels_out);
+/* Replaces skimage.measure.label(segments) (imsegm/superpixels.py:111): components of equal non-zero
+ * value under full connectivity, numbered 1.. in raster order of their first voxel; 0 stays background. */
+IMSEGM_API int imsegm_volume_label_cc(imsegm_image2d *vol, int *n_labels_out);
+/* Replaces imsegm.features_cython.computeGrayImage3dMean / Energy / Variance (features_cython.pyx:144-219);
+ * outputs n_labels float64 each (NULL = not wanted). */
+IMSEGM_API int imsegm_volume_gray_stats(imsegm_image2d *vol, double *mean_out, double *energy_out, double *var_out);
+/* Replaces make_graph_segm_connect_grid3d_conn6 and the 3-D branch of superpixel_centers
+ * (imsegm/superpixels.py:180-242); centres_out is n_labels x 3 (z, y, x). */
+IMSEGM_API int imsegm_volume_graph(imsegm_image2d *vol, int32_t *edges_out, int edge_capacity, int *n_edges_out,
+                                   double *centres_out, uint8_t *present_out);
+
 /* Device address of a result buffer of the session (valid until the next call that rewrites it):
  * which = 0: label map int32 H x W; 1: gathered segmentation int32 H x W; 2: gathered soft
  * segmentation float64 H x W x C.  For zero-copy hand-over to a collective library (RCCL) running on

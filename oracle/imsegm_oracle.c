@@ -844,3 +844,48 @@ ORC_API void orc_gather_f64(const double *lut, int C, const int32_t *idx, size_t
     for (size_t i = 0; i < n; ++i)
         for (int c = 0; c < C; ++c) out[i * C + c] = lut[(size_t)idx[i] * C + c];
 }
+
+/* skimage.measure.label(label_image) with its defaults (background = 0, full connectivity), as called
+ * at /root/reference/imsegm/superpixels.py:111 (skimage/measure/_ccomp.pyx): components of equal
+ * non-zero value under 8- (2-D) / 26- (3-D) connectivity, numbered 1, 2, ... in raster order of
+ * their first element; zeros stay 0.  Returns the number of components. */
+static int lcc_find(int32_t *parent, int a)
+{
+    while (parent[a] != a) {
+        parent[a] = parent[parent[a]];
+        a = parent[a];
+    }
+    return a;
+}
+ORC_API int orc_label_cc(const int32_t *in, int D, int H, int W, int32_t *out)
+{
+    size_t n = (size_t)D * H * W;
+    int32_t *parent = (int32_t *)malloc(n * sizeof(int32_t));
+    for (size_t p = 0; p < n; ++p) parent[p] = (int32_t)p;
+    for (int z = 0; z < D; ++z)
+        for (int y = 0; y < H; ++y)
+            for (int x = 0; x < W; ++x) {
+                size_t p = ((size_t)z * H + y) * W + x;
+                if (in[p] == 0) continue;
+                for (int dz = -1; dz <= 0; ++dz)
+                    for (int dy = -1; dy <= 1; ++dy)
+                        for (int dx = -1; dx <= 1; ++dx) {
+                            if (dz == 0 && (dy > 0 || (dy == 0 && dx >= 0))) continue;
+                            int zz = z + dz, yy = y + dy, xx = x + dx;
+                            if (zz < 0 || yy < 0 || yy >= H || xx < 0 || xx >= W) continue;
+                            size_t q = ((size_t)zz * H + yy) * W + xx;
+                            if (in[q] != in[p]) continue;
+                            int a = lcc_find(parent, (int)p), b = lcc_find(parent, (int)q);
+                            if (a < b) parent[b] = a; else if (b < a) parent[a] = b;
+                        }
+            }
+    int count = 0;
+    for (size_t p = 0; p < n; ++p) {
+        if (in[p] == 0) { out[p] = 0; continue; }
+        int r = lcc_find(parent, (int)p);
+        if ((size_t)r == p) out[p] = ++count;     /* roots are the raster-first elements */
+        else out[p] = out[r];
+    }
+    free(parent);
+    return count;
+}

@@ -110,6 +110,24 @@ def grid_centroids(shape3, n_segments):
     return centroids, steps
 
 
+def img_as_float64(image):
+    """skimage.util.img_as_float (util/dtype.py) for the dtypes the reference feeds it, always in
+    float64 (the float32-in -> float32-compute branch of skimage 0.18 is not restated)"""
+    image = np.asarray(image)
+    if image.dtype.kind == 'f':
+        return np.ascontiguousarray(image, dtype=np.float64)
+    if image.dtype.kind == 'u':
+        return np.multiply(image, 1. / np.iinfo(image.dtype).max, dtype=np.float64)
+    if image.dtype.kind == 'i':
+        info = np.iinfo(image.dtype)
+        out = np.add(image, 0.5, dtype=np.float64)
+        out *= 2. / (float(info.max) - float(info.min))
+        return out
+    if image.dtype.kind == 'b':
+        return image.astype(np.float64)
+    raise ValueError('unsupported dtype %r' % image.dtype)
+
+
 def slic(image, n_segments, compactness, sigma=0., spacing=None, multichannel=True, max_iter=10,
          enforce_connectivity=True, min_size_factor=0.5, max_size_factor=3, start_label=0,
          normalize=None, return_internals=False):
@@ -153,7 +171,7 @@ def slic(image, n_segments, compactness, sigma=0., spacing=None, multichannel=Tr
         assert image.ndim == 3 and normalize is None
         D, H, W = image.shape
         nch = 1
-        img = np.ascontiguousarray(image, dtype=np.float64)
+        img = img_as_float64(image)
         pre = np.empty((1, D, H, W), dtype=np.float64)
         L.orc_slic_preprocess_gray3d(_p(img), C.c_int(D), C.c_int(H), C.c_int(W), *tap_args,
                                      C.c_double(ratio), _p(pre))
@@ -205,6 +223,27 @@ def segment_slic_img2d(img, sp_size=50, relative_compact=0.1, start_label=0, ret
     compact = (sp_size * relative_compact)**1.5
     return slic(img, n_seg, compact, sigma=1, normalize=normalize, start_label=start_label,
                 return_internals=return_internals)
+
+
+def label_cc(labels):
+    """skimage.measure.label(labels) restated (background 0, full connectivity, raster-order numbering)"""
+    lab = np.ascontiguousarray(labels, dtype=np.int32)
+    l3 = lab if lab.ndim == 3 else lab[np.newaxis]
+    D, H, W = l3.shape
+    out = np.empty_like(l3)
+    lib().orc_label_cc(_p(l3), C.c_int(D), C.c_int(H), C.c_int(W), _p(out))
+    return out.reshape(lab.shape).astype(np.int64)
+
+
+def segment_slic_img3d_gray(im, sp_size=50, relative_compact=0.1, space=(1, 1, 1), start_label=0):
+    """imsegm/superpixels.py:72-112 on the oracle"""
+    im = np.asarray(im)
+    nb_pixels = np.prod(im.shape)
+    sp_vol = np.prod(sp_size / np.asarray(space, dtype=np.float32) * min(space))
+    n_seg = int(nb_pixels / sp_vol)
+    compact = int((sp_vol * relative_compact)**1.5)
+    seg = slic(np.array(im), n_seg, compact, sigma=1, spacing=space, multichannel=False, start_label=start_label)
+    return label_cc(seg)
 
 
 # ------------------------------------------------------------------------------------------------

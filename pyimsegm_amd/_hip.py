@@ -69,6 +69,13 @@ _SIGNATURES = {
     'imsegm_image2d_response_stats': (C.c_int, [_vp, C.c_double, C.c_double, _vp, _vp, _vp]),
     'imsegm_image2d_get_response': (C.c_int, [_vp, _vp]),
     'imsegm_image2d_device_ptr': (C.c_int, [_vp, C.c_int, C.POINTER(_vp)]),
+    'imsegm_volume_create': (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.POINTER(_vp)]),
+    'imsegm_volume_upload': (C.c_int, [_vp, _vp, C.c_int, C.c_double, C.c_double]),
+    'imsegm_volume_slic': (C.c_int, [_vp, C.c_int, C.c_double, _vp, C.c_int, _vp, C.c_int, _vp, C.c_int, _vp, C.c_int,
+                                     C.c_int, C.c_double, C.c_double, C.c_int, _ip]),
+    'imsegm_volume_label_cc': (C.c_int, [_vp, _ip]),
+    'imsegm_volume_gray_stats': (C.c_int, [_vp, _vp, _vp, _vp]),
+    'imsegm_volume_graph': (C.c_int, [_vp, _vp, C.c_int, _ip, _vp, _vp]),
     'imsegm_cut_general_graph': (C.c_int, [_vp, _vp, C.c_int, _vp, _vp, C.c_int, C.c_int, _vp, C.c_int, _vp,
                                            C.POINTER(C.c_int64)]),
 }
@@ -347,6 +354,96 @@ class Image2D(object):
             soft = np.empty(self.shape + (nc,), dtype=np.float64) if to_host else None
         _check(load_library().imsegm_image2d_gather(self._h, _ptr(gl), _ptr(pr), nc, _ptr(segm), _ptr(soft)))
         return segm, soft
+
+
+def img_as_float_map(dtype):
+    """``skimage.util.img_as_float`` (util/dtype.py) as an affine map ``(v + offset) * scale``"""
+    dtype = np.dtype(dtype)
+    if dtype.kind in 'fb':
+        return 0., 1.
+    if dtype.kind == 'u':
+        return 0., 1. / np.iinfo(dtype).max
+    if dtype.kind == 'i':
+        info = np.iinfo(dtype)
+        return 0.5, 2. / (float(info.max) - float(info.min))
+    raise ValueError('unsupported dtype %r' % dtype)
+
+
+class Volume3D(Image2D):
+    """device-resident state of one D x H x W gray volume (supervoxel path)"""
+
+    def __init__(self, depth, height, width, ctx=None):
+        self.ctx = ctx or default_context()
+        self.shape = (int(depth), int(height), int(width))
+        self._h = _vp()
+        self.n_labels = 0
+        _check(load_library().imsegm_volume_create(self.ctx._h, self.shape[0], self.shape[1], self.shape[2],
+                                                   C.byref(self._h)))
+
+    def upload(self, volume):
+        """D x H x W volume; uint8 / float32 / float64 go up as they are, anything else as float64
+        (exact for integers up to 53 bits); SLIC sees ``img_as_float`` of the source dtype"""
+        volume = np.asarray(volume)
+        if volume.shape != self.shape:
+            raise ValueError('expected a volume of shape %r, got %r' % (self.shape, volume.shape))
+        off, scale = img_as_float_map(volume.dtype)
+        if volume.dtype not in _DTYPES:
+            volume = volume.astype(np.float64)
+        volume = np.ascontiguousarray(volume)
+        _check(load_library().imsegm_volume_upload(self._h, _ptr(volume), _DTYPES[volume.dtype], off, scale))
+        return self
+
+    def slic(self, n_segments, compactness, sigma=1., spacing=(1., 1., 1.), max_iter=10, enforce_connectivity=True,
+             min_size_factor=0.5, max_size_factor=3., start_label=0):
+        spacing = np.ascontiguousarray(spacing, dtype=np.float64)
+        if spacing.shape != (3, ):
+            raise ValueError('spacing must have 3 elements (z, y, x)')
+        taps = [gaussian_taps(s) for s in np.array([sigma, sigma, sigma], dtype=np.float64) / spacing]
+        args = []
+        for t in taps:
+            args += [_ptr(t), -1 if t is None else len(t) - 1]
+        n_out = C.c_int(0)
+        _check(load_library().imsegm_volume_slic(
+            self._h, int(n_segments), float(compactness), *args, _ptr(spacing), int(max_iter),
+            int(bool(enforce_connectivity)), float(min_size_factor), float(max_size_factor), int(start_label),
+            C.byref(n_out)))
+        self.n_labels = n_out.value
+        return self.n_labels
+
+    def label_cc(self):
+        """``skimage.measure.label`` of the current label map, in place; returns max label + 1"""
+        n_out = C.c_int(0)
+        _check(load_library().imsegm_volume_label_cc(self._h, C.byref(n_out)))
+        self.n_labels = n_out.value
+        return self.n_labels
+
+    def gray_stats(self, mean=True, energy=True, var=True):
+        k = self.n_labels
+        m = np.empty(k, dtype=np.float64) if mean else None
+        e = np.empty(k, dtype=np.float64) if energy else None
+        v = np.empty(k, dtype=np.float64) if var else None
+        _check(load_library().imsegm_volume_gray_stats(self._h, _ptr(m), _ptr(e), _ptr(v)))
+        return m, e, v
+
+    def graph(self):
+        """(edges int32 E x 2 ordered by (b, a); centres K x 3 (z, y, x); present flags K)"""
+        k = self.n_labels
+        cap = max(64, 8 * k)
+        centres = np.empty((k, 3), dtype=np.float64)
+        present = np.empty(k, dtype=np.uint8)
+        while True:
+            edges = np.empty((cap, 2), dtype=np.int32)
+            ne = C.c_int(0)
+            _check(load_library().imsegm_volume_graph(self._h, _ptr(edges), cap, C.byref(ne), _ptr(centres),
+                                                      _ptr(present)))
+            if ne.value <= cap:
+                return edges[:ne.value], centres, present.astype(bool)
+            cap = ne.value
+
+    def _unsupported(self, *args, **kwargs):
+        raise HipError('not available for volumes')
+
+    get_lab = color_stats = lm_prepare = lm_battery = response_stats = get_response = _unsupported
 
 
 class DeviceArray(object):

@@ -138,15 +138,27 @@ struct imsegm_ctx {
 
 struct imsegm_image2d {
     imsegm_ctx *ctx = nullptr;
-    int H = 0, W = 0;
+    int D = 1, H = 0, W = 0;      // D > 1: gray volume session (imsegm_volume_*)
     size_t n = 0;
     int dtype = -1;
     int n_labels = 0;
     bool have_labels = false;
     bool tex_ready = false;
+    bool is_volume = false;
+    double vol_off = 0.0, vol_scale = 1.0;      // intensity seen by the volume SLIC = (v + off) * scale
     DevBuf img, labA, labB, nearest, labels, conn_i32, conn_u8, small, cent, tiles, feat, graph, gather_lut, gather_out_i, gather_out_f,
-        tex_planes, tex_resp, tex_small;
+        tex_planes, tex_resp, tex_small, vol_cent;
 };
+
+// entry points are specific to colour images (D == 1) or gray volumes (created by imsegm_volume_create)
+static int wrong_kind(const imsegm_image2d *im, bool want_volume)
+{
+    if (im && im->is_volume != want_volume) {
+        set_error(want_volume ? "this call needs a volume session" : "this call needs a 2-D colour image session");
+        return 1;
+    }
+    return 0;
+}
 
 static int bind(imsegm_ctx *ctx)
 {
@@ -320,7 +332,7 @@ void imsegm_image2d_destroy(imsegm_image2d *im)
     (void)hipStreamSynchronize(im->ctx->stream);
     DevBuf *all[] = { &im->img, &im->labA, &im->labB, &im->nearest, &im->labels, &im->conn_i32, &im->conn_u8, &im->small,
                       &im->cent, &im->tiles, &im->feat, &im->graph, &im->gather_lut, &im->gather_out_i, &im->gather_out_f,
-                      &im->tex_planes, &im->tex_resp, &im->tex_small };
+                      &im->tex_planes, &im->tex_resp, &im->tex_small, &im->vol_cent };
     for (auto b : all) b->release();
     delete im;
 }
@@ -328,6 +340,7 @@ void imsegm_image2d_destroy(imsegm_image2d *im)
 int imsegm_image2d_upload(imsegm_image2d *im, const void *host_pixels, int dtype)
 {
     if (!im || bind(im->ctx)) return -1;
+    if (wrong_kind(im, false)) return -1;
     im->tex_ready = false;
     size_t es = dtype == IMSEGM_U8 ? 1 : dtype == IMSEGM_F32 ? 4 : dtype == IMSEGM_F64 ? 8 : 0;
     if (!es) {
@@ -342,6 +355,8 @@ int imsegm_image2d_upload(imsegm_image2d *im, const void *host_pixels, int dtype
     return 0;
 }
 
+static ConnWork make_conn_work(imsegm_image2d *im);
+
 int imsegm_image2d_slic(imsegm_image2d *im, int minmax_normalize, int n_segments, double compactness,
                         const double *taps_z, int radius_z, const double *taps_y, int radius_y,
                         const double *taps_x, int radius_x, int max_iter, int enforce_connectivity,
@@ -349,6 +364,7 @@ int imsegm_image2d_slic(imsegm_image2d *im, int minmax_normalize, int n_segments
                         int *n_labels_out)
 {
     if (!im || bind(im->ctx)) return -1;
+    if (wrong_kind(im, false)) return -1;
     if (im->dtype < 0) {
         set_error("no image uploaded");
         return -1;
@@ -456,24 +472,12 @@ int imsegm_image2d_slic(imsegm_image2d *im, int minmax_normalize, int n_segments
         long min_size = (long)(min_size_factor * segment_size);
         long max_size = (long)(max_size_factor * segment_size);
         if (im->conn_i32.ensure(n * 4 * 8 + ((n / 4096) + 64) * 4 + 256) || im->conn_u8.ensure(2 * n + 64)) return -1;
-        ConnWork w;
-        int32_t *b = im->conn_i32.as<int32_t>();
-        w.parent = b; b += n;
-        w.csize = b; b += n;
-        w.newlabel = b; b += n;
-        w.adjptr = b; b += n;
-        w.queue = b; b += n;
-        w.list = b; b += n;
-        w.slotmap = b; b += n;
-        w.bbox = b; b += n;
-        w.blocksum = b; b += (n / 4096) + 32;
-        w.counters = b;
-        w.visited = im->conn_u8.as<uint8_t>();
+        ConnWork w = make_conn_work(im);
         int spc = ctx->begin(PG_CONN);
         // the raw assignment carries no start_label offset; the reference adds it before the
         // connectivity pass, which only matters through mask_label = start_label - 1 (no masked
         // pixels here), so the raw labels can be used as they are
-        if (launch_enforce_connectivity(im->nearest.as<int32_t>(), H, W, min_size, max_size, start_label, w,
+        if (launch_enforce_connectivity(im->nearest.as<int32_t>(), 1, H, W, min_size, max_size, start_label, w,
                                         im->labels.as<int32_t>(), &n_labels, st))
             return -1;
         ctx->end(spc);
@@ -523,6 +527,7 @@ int imsegm_image2d_set_labels(imsegm_image2d *im, const int32_t *labels, int n_l
 int imsegm_image2d_get_lab(imsegm_image2d *im, double *lab_out)
 {
     if (!im || bind(im->ctx)) return -1;
+    if (wrong_kind(im, false)) return -1;
     if (im->labA.cap < 3 * im->n * 8) {
         set_error("slic has not been run");
         return -1;
@@ -545,11 +550,12 @@ int imsegm_image2d_get_nearest(imsegm_image2d *im, int32_t *nearest_out)
 }
 
 static int stats_run(imsegm_image2d *im, const void *src, int dtype, double maxabs, int planar, int prescale, double mul,
-                     double div, double *mean_out, double *energy_out, double *var_out);
+                     double div, double *mean_out, double *energy_out, double *var_out, long plane_stride = -1);
 
 int imsegm_image2d_color_stats(imsegm_image2d *im, double *mean_out, double *energy_out, double *var_out)
 {
     if (!im || bind(im->ctx)) return -1;
+    if (wrong_kind(im, false)) return -1;
     if (!im->have_labels || im->dtype < 0) {
         set_error("color_stats needs an uploaded image and a label map");
         return -1;
@@ -575,6 +581,7 @@ int imsegm_image2d_graph(imsegm_image2d *im, int32_t *edges_out, int edge_capaci
                          double *centres_out, uint8_t *present_out)
 {
     if (!im || bind(im->ctx)) return -1;
+    if (wrong_kind(im, false)) return -1;
     if (!im->have_labels) {
         set_error("graph needs a label map");
         return -1;
@@ -669,7 +676,7 @@ int imsegm_image2d_gather(imsegm_image2d *im, const int32_t *graph_labels, const
 }
 
 static int stats_run(imsegm_image2d *im, const void *src, int dtype, double maxabs, int planar, int prescale, double mul,
-                     double div, double *mean_out, double *energy_out, double *var_out)
+                     double div, double *mean_out, double *energy_out, double *var_out, long plane_stride)
 {
     imsegm_ctx *ctx = im->ctx;
     hipStream_t st = ctx->stream;
@@ -684,7 +691,7 @@ static int stats_run(imsegm_image2d *im, const void *src, int dtype, double maxa
     float *d_mean32 = reinterpret_cast<float *>(b);
     int sp = ctx->begin(PG_STATS);
     if (launch_color_stats(src, dtype, im->labels.as<int32_t>(), im->H, im->W, K, maxabs, var_out != nullptr, acc, d_mean,
-                           d_energy, d_var, d_mean32, st, planar, prescale, mul, div))
+                           d_energy, d_var, d_mean32, st, planar, prescale, mul, div, plane_stride))
         return -1;
     ctx->end(sp);
     size_t ob = (size_t)K * 3 * 8;
@@ -704,6 +711,7 @@ static int stats_run(imsegm_image2d *im, const void *src, int dtype, double maxa
 int imsegm_image2d_lm_prepare(imsegm_image2d *im, const double *taps, int radius, const double *channel_mix)
 {
     if (!im || bind(im->ctx)) return -1;
+    if (wrong_kind(im, false)) return -1;
     if (im->dtype < 0) {
         set_error("no image uploaded");
         return -1;
@@ -732,6 +740,7 @@ int imsegm_image2d_lm_battery(imsegm_image2d *im, const double *weights, int n_k
                               double *sum_squares_out)
 {
     if (!im || bind(im->ctx)) return -1;
+    if (wrong_kind(im, false)) return -1;
     if (!im->tex_ready) {
         set_error("lm_battery: call imsegm_image2d_lm_prepare first");
         return -1;
@@ -758,6 +767,7 @@ int imsegm_image2d_response_stats(imsegm_image2d *im, double mul, double div, do
                                   double *var_out)
 {
     if (!im || bind(im->ctx)) return -1;
+    if (wrong_kind(im, false)) return -1;
     if (!im->tex_ready || !im->have_labels || im->tex_resp.cap < 3 * im->n * 8) {
         set_error("response_stats needs a filter response and a label map");
         return -1;
@@ -774,12 +784,267 @@ int imsegm_image2d_response_stats(imsegm_image2d *im, double mul, double div, do
 int imsegm_image2d_get_response(imsegm_image2d *im, double *planes_out)
 {
     if (!im || bind(im->ctx)) return -1;
+    if (wrong_kind(im, false)) return -1;
     if (im->tex_resp.cap < 3 * im->n * 8) {
         set_error("no filter response");
         return -1;
     }
     HIP_TRY(hipMemcpyAsync(planes_out, im->tex_resp.p, 3 * im->n * 8, hipMemcpyDeviceToHost, im->ctx->stream));
     HIP_TRY(hipStreamSynchronize(im->ctx->stream));
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// gray volumes (D x H x W)
+// ---------------------------------------------------------------------------------------------------
+int imsegm_volume_create(imsegm_ctx *ctx, int depth, int height, int width, imsegm_image2d **vol_out)
+{
+    if (bind(ctx)) return -1;
+    if (depth <= 0 || height <= 0 || width <= 0 || (long)depth * height * width > 0x3fffffffL) {
+        set_error("bad volume size");
+        return -1;
+    }
+    imsegm_image2d *im = new imsegm_image2d();
+    im->ctx = ctx;
+    im->is_volume = true;
+    im->D = depth;
+    im->H = height;
+    im->W = width;
+    im->n = (size_t)depth * height * width;
+    *vol_out = im;
+    return 0;
+}
+
+int imsegm_volume_upload(imsegm_image2d *im, const void *host_voxels, int dtype, double slic_offset, double slic_scale)
+{
+    if (!im || bind(im->ctx)) return -1;
+    if (wrong_kind(im, true)) return -1;
+    size_t es = dtype == IMSEGM_U8 ? 1 : dtype == IMSEGM_F32 ? 4 : dtype == IMSEGM_F64 ? 8 : 0;
+    if (!es) {
+        set_error("unsupported dtype");
+        return -1;
+    }
+    if (im->img.ensure(im->n * es + 16)) return -1;
+    HIP_TRY(hipMemcpyAsync(im->img.p, host_voxels, im->n * es, hipMemcpyHostToDevice, im->ctx->stream));
+    HIP_TRY(hipStreamSynchronize(im->ctx->stream));
+    im->dtype = dtype;
+    im->vol_off = slic_offset;
+    im->vol_scale = slic_scale;
+    im->tex_ready = false;
+    return 0;
+}
+
+static ConnWork make_conn_work(imsegm_image2d *im)
+{
+    const size_t n = im->n;
+    ConnWork w;
+    int32_t *b = im->conn_i32.as<int32_t>();
+    w.parent = b; b += n;
+    w.csize = b; b += n;
+    w.newlabel = b; b += n;
+    w.adjptr = b; b += n;
+    w.queue = b; b += n;
+    w.list = b; b += n;
+    w.slotmap = b; b += n;
+    w.bbox = b; b += n;
+    w.blocksum = b; b += (n / 4096) + 32;
+    w.counters = b;
+    w.visited = im->conn_u8.as<uint8_t>();
+    return w;
+}
+
+int imsegm_volume_slic(imsegm_image2d *im, int n_segments, double compactness, const double *taps_z, int radius_z,
+                       const double *taps_y, int radius_y, const double *taps_x, int radius_x, const double *spacing,
+                       int max_iter, int enforce_connectivity, double min_size_factor, double max_size_factor,
+                       int start_label, int *n_labels_out)
+{
+    if (!im || bind(im->ctx)) return -1;
+    if (wrong_kind(im, true)) return -1;
+    if (im->dtype < 0) {
+        set_error("no volume uploaded");
+        return -1;
+    }
+    if (!(compactness > 0) || n_segments < 1 || max_iter < 1 || !spacing) {
+        set_error("slic: n_segments, compactness and max_iter must be positive");
+        return -1;
+    }
+    if (start_label != 0 && start_label != 1) {
+        set_error("start_label should be 0 or 1.");
+        return -1;
+    }
+    imsegm_ctx *ctx = im->ctx;
+    hipStream_t st = ctx->stream;
+    const int D = im->D, H = im->H, W = im->W;
+    const size_t n = im->n;
+    Taps tz, ty, tx;
+    if (fill_taps(tz, taps_z, radius_z) || fill_taps(ty, taps_y, radius_y) || fill_taps(tx, taps_x, radius_x)) return -1;
+    long shape[3] = { D, H, W };
+    GridAxis ax[3], axk[3];
+    regular_grid3(shape, n_segments, ax);
+    long cnt[3];
+    for (int i = 0; i < 3; ++i) {
+        cnt[i] = 0;
+        for (long v = ax[i].start; v < shape[i]; v += ax[i].step) cnt[i]++;
+    }
+    const long Kl = cnt[0] * cnt[1] * cnt[2];
+    if (Kl < 1 || Kl > 0x7fffffffL) {
+        set_error("slic: bad centroid grid");
+        return -1;
+    }
+    const int K = (int)Kl;
+    double fs = 1.0;
+    for (int i = 0; i < 3; ++i) fs = std::max(fs, ax[i].all ? 1.0 : (double)ax[i].step);
+    float step = (float)fs;
+    regular_grid3(shape, K, axk);
+    if (im->labA.ensure(n * 8) || im->labB.ensure(n * 8) || im->nearest.ensure(n * 4) || im->labels.ensure(n * 4)) return -1;
+    if (im->vol_cent.ensure((size_t)K * (4 * 8 + 6 * 4 + 6 * 8) + 256)) return -1;
+    if (launch_vol_preprocess(im->img.p, im->dtype, im->vol_off, im->vol_scale, D, H, W, tz, ty, tx, 1.0 / compactness, im->labA.as<double>(),
+                              im->labB.as<double>(), st))
+        return -1;
+    VolState s;
+    s.D = D; s.H = H; s.W = W; s.K = K;
+    s.step_z = axk[0].all ? 1 : (int)axk[0].step;
+    s.step_y = axk[1].all ? 1 : (int)axk[1].step;
+    s.step_x = axk[2].all ? 1 : (int)axk[2].step;
+    s.spatial_weight = 1.0 / ((double)step * (double)step);
+    s.sz = spacing[0]; s.sy = spacing[1]; s.sx = spacing[2];
+    unsigned char *cb = im->vol_cent.as<unsigned char>();
+    s.cen = reinterpret_cast<double *>(cb); cb += (size_t)K * 4 * 8;
+    s.acc = reinterpret_cast<long long *>(cb); cb += (size_t)K * 6 * 8;
+    s.win = reinterpret_cast<int *>(cb);
+    for (int i = 0; i < 3; ++i) {
+        s.grid_0[i] = (int)ax[i].start;
+        s.grid_d[i] = (int)ax[i].step;
+        s.grid_n[i] = (int)cnt[i];
+    }
+    int sp_all = ctx->begin(PG_SLIC);
+    if (launch_vol_slic(s, im->labB.as<double>(), im->nearest.as<int32_t>(), max_iter, st)) return -1;
+    int n_labels = K + start_label;
+    if (enforce_connectivity) {
+        double segment_size = (double)n / (double)K;
+        long min_size = (long)(min_size_factor * segment_size);
+        long max_size = (long)(max_size_factor * segment_size);
+        if (im->conn_i32.ensure(n * 4 * 8 + ((n / 4096) + 64) * 4 + 256) || im->conn_u8.ensure(2 * n + 64)) return -1;
+        ConnWork w = make_conn_work(im);
+        if (launch_enforce_connectivity(im->nearest.as<int32_t>(), D, H, W, min_size, max_size, start_label, w,
+                                        im->labels.as<int32_t>(), &n_labels, st))
+            return -1;
+    } else {
+        if (start_label != 0) {
+            set_error("enforce_connectivity=False is only supported with start_label=0");
+            return -1;
+        }
+        HIP_TRY(hipMemcpyAsync(im->labels.p, im->nearest.p, n * 4, hipMemcpyDeviceToDevice, st));
+    }
+    ctx->end(sp_all);
+    im->n_labels = n_labels;
+    im->have_labels = true;
+    if (n_labels_out) *n_labels_out = n_labels;
+    return 0;
+}
+
+int imsegm_volume_label_cc(imsegm_image2d *im, int *n_labels_out)
+{
+    if (!im || bind(im->ctx)) return -1;
+    if (wrong_kind(im, true)) return -1;
+    if (!im->have_labels) {
+        set_error("label_cc needs a label map");
+        return -1;
+    }
+    hipStream_t st = im->ctx->stream;
+    const size_t n = im->n;
+    if (im->conn_i32.ensure(n * 4 * 8 + ((n / 4096) + 64) * 4 + 256) || im->conn_u8.ensure(2 * n + 64)) return -1;
+    ConnWork w = make_conn_work(im);
+    if (launch_label_cc(im->labels.as<int32_t>(), im->D, im->H, im->W, w.parent, w.newlabel, w.blocksum, w.counters, st)) return -1;
+    int total = 0;
+    HIP_TRY(hipMemcpyAsync(&total, w.counters, 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    im->n_labels = total + 1;          // 0 = background, components 1 .. total
+    if (n_labels_out) *n_labels_out = im->n_labels;
+    return 0;
+}
+
+int imsegm_volume_gray_stats(imsegm_image2d *im, double *mean_out, double *energy_out, double *var_out)
+{
+    if (!im || bind(im->ctx)) return -1;
+    if (wrong_kind(im, true)) return -1;
+    if (!im->have_labels || im->dtype < 0) {
+        set_error("gray_stats needs an uploaded volume and a label map");
+        return -1;
+    }
+    hipStream_t st = im->ctx->stream;
+    double maxabs = 255.0;
+    if (im->dtype != IMSEGM_U8) {
+        if (im->small.ensure(4096)) return -1;
+        unsigned long long *keys = im->small.as<unsigned long long>();
+        double *minmax = reinterpret_cast<double *>(keys + 2);
+        if (launch_minmax(im->img.p, im->dtype, im->n, keys, minmax, st)) return -1;
+        double mm[2];
+        HIP_TRY(hipMemcpyAsync(mm, minmax, 16, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        maxabs = std::max(fabs(mm[0]), fabs(mm[1]));
+        if (!(maxabs < 1e300)) maxabs = 1e300;
+    }
+    // the colour kernel with the single gray plane read as all three channels (plane stride 0), the
+    // volume seen as a (D*H) x W image
+    const int K = im->n_labels;
+    std::vector<double> m((size_t)K * 3), e((size_t)K * 3), v((size_t)K * 3);
+    const int H2 = im->D * im->H;
+    int keepH = im->H;
+    im->H = H2;
+    int rc = stats_run(im, im->img.p, im->dtype, maxabs, 1, 0, 1.0, 1.0, mean_out ? m.data() : nullptr,
+                       energy_out ? e.data() : nullptr, var_out ? v.data() : nullptr, 0);
+    im->H = keepH;
+    if (rc) return rc;
+    for (int k = 0; k < K; ++k) {
+        if (mean_out) mean_out[k] = m[(size_t)k * 3];
+        if (energy_out) energy_out[k] = e[(size_t)k * 3];
+        if (var_out) var_out[k] = v[(size_t)k * 3];
+    }
+    return 0;
+}
+
+int imsegm_volume_graph(imsegm_image2d *im, int32_t *edges_out, int edge_capacity, int *n_edges_out, double *centres_out,
+                        uint8_t *present_out)
+{
+    if (!im || bind(im->ctx)) return -1;
+    if (wrong_kind(im, true)) return -1;
+    if (!im->have_labels) {
+        set_error("graph needs a label map");
+        return -1;
+    }
+    imsegm_ctx *ctx = im->ctx;
+    hipStream_t st = ctx->stream;
+    const int K = im->n_labels;
+    if (K > 65536) {
+        set_error("adjacency bitmap supports at most 65536 labels");
+        return -1;
+    }
+    if (edge_capacity < 0) edge_capacity = 0;
+    size_t words = (size_t)cdiv(K, 32);
+    size_t bytes = (size_t)K * words * 4 + (size_t)K * 4 * 8 + (size_t)edge_capacity * 8 + (size_t)K * 3 * 8 + (size_t)K * 4 + K + 512;
+    if (im->graph.ensure(bytes)) return -1;
+    unsigned char *b = im->graph.as<unsigned char>();
+    long long *cacc = reinterpret_cast<long long *>(b); b += (size_t)K * 4 * 8;
+    double *centres = reinterpret_cast<double *>(b); b += (size_t)K * 3 * 8;
+    uint32_t *bitmap = reinterpret_cast<uint32_t *>(b); b += (size_t)K * words * 4;
+    int32_t *edges = reinterpret_cast<int32_t *>(b); b += (size_t)edge_capacity * 8;
+    int32_t *rowcount = reinterpret_cast<int32_t *>(b); b += (size_t)K * 4;
+    int32_t *n_edges_dev = reinterpret_cast<int32_t *>(b); b += 16;
+    uint8_t *present = b;
+    if (launch_vol_adjacency(im->labels.as<int32_t>(), im->D, im->H, im->W, K, (int)words, bitmap, cacc, centres, present, st))
+        return -1;
+    if (launch_edge_extract(bitmap, K, (int)words, rowcount, edges, edge_capacity, n_edges_dev, st)) return -1;
+    int ne = 0;
+    HIP_TRY(hipMemcpyAsync(&ne, n_edges_dev, 4, hipMemcpyDeviceToHost, st));
+    if (centres_out) HIP_TRY(hipMemcpyAsync(centres_out, centres, (size_t)K * 24, hipMemcpyDeviceToHost, st));
+    if (present_out) HIP_TRY(hipMemcpyAsync(present_out, present, K, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    if (edges_out && ne > 0) {
+        HIP_TRY(hipMemcpyAsync(edges_out, edges, (size_t)std::min(ne, edge_capacity) * 8, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+    }
+    *n_edges_out = ne;
     return 0;
 }
 

@@ -20,7 +20,7 @@ bool hip_ok(hipError_t e, const char *what, const char *file, int line);
         if (!::imsegm::hip_ok((expr), #expr, __FILE__, __LINE__)) return -1;            \
     } while (0)
 
-static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+__host__ __device__ static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
 // ---------------------------------------------------------------------------------------------
 // deterministic elementary functions (mirror of oracle det_rcbrt / orc_det_cbrt / orc_det_pow24)

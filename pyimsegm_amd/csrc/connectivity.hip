@@ -26,6 +26,20 @@ namespace imsegm {
 enum { ST_ACTIVE = 0, ST_FINAL = 1 };
 enum { CNT_OVER = 0, CNT_SMALL = 1, CNT_CURSOR = 2, CNT_KEPT = 3, CNT_FALLBACK = 4 };
 
+// neighbour of voxel p in direction d of the reference's BFS order (+x, -x, +y, -y, +z, -z); -1 outside
+__device__ __forceinline__ int neighbour(int p, int D, int H, int W, int d)
+{
+    const int x = p % W, y = (p / W) % H, z = p / (W * H);
+    switch (d) {
+        case 0: return x + 1 < W ? p + 1 : -1;
+        case 1: return x > 0 ? p - 1 : -1;
+        case 2: return y + 1 < H ? p + W : -1;
+        case 3: return y > 0 ? p - W : -1;
+        case 4: return z + 1 < D ? p + W * H : -1;
+        default: return z > 0 ? p - W * H : -1;
+    }
+}
+
 __device__ __forceinline__ int uf_find(const int32_t *parent, int a)
 {
     int p = parent[a];
@@ -78,11 +92,11 @@ k_ccl_init(const int32_t *__restrict__ labels, const uint8_t *__restrict__ state
 }
 
 __global__ void __launch_bounds__(256)
-k_ccl_merge(const int32_t *__restrict__ labels, const uint8_t *__restrict__ state, int32_t *parent, int H, int W)
+k_ccl_merge(const int32_t *__restrict__ labels, const uint8_t *__restrict__ state, int32_t *parent, int D, int H, int W)
 {
     int p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= H * W || state[p] != ST_ACTIVE) return;
-    int y = p / W, x = p - y * W;
+    if (p >= D * H * W || state[p] != ST_ACTIVE) return;
+    int x = p % W, y = (p / W) % H, z = p / (W * H);
     int l = labels[p];
     bool cont = x > 0 && state[p - 1] == ST_ACTIVE && labels[p - 1] == l;
     // horizontal: only the first lane of a wave segment still has to be tied to its left neighbour
@@ -92,6 +106,11 @@ k_ccl_merge(const int32_t *__restrict__ labels, const uint8_t *__restrict__ stat
     if (y > 0 && state[p - W] == ST_ACTIVE && labels[p - W] == l) {
         bool left_pair_same = cont && state[p - W - 1] == ST_ACTIVE && labels[p - W - 1] == l;
         if (!left_pair_same) uf_union(parent, p, p - W);
+    }
+    const int HW = H * W;
+    if (z > 0 && state[p - HW] == ST_ACTIVE && labels[p - HW] == l) {
+        bool left_pair_same = cont && state[p - HW - 1] == ST_ACTIVE && labels[p - HW - 1] == l;
+        if (!left_pair_same) uf_union(parent, p, p - HW);
     }
 }
 
@@ -135,7 +154,7 @@ k_find_oversize(const int32_t *__restrict__ parent, const uint8_t *__restrict__ 
 
 // exact sequential BFS of the reference, capped at max_size discovered pixels (one thread per oversize root)
 __global__ void k_oversize_bfs(const int32_t *over_list, int n_over, const int32_t *__restrict__ parent,
-                               const uint8_t *__restrict__ state, int H, int W, int max_size, int32_t *queue,
+                               const uint8_t *__restrict__ state, int D, int H, int W, int max_size, int32_t *queue,
                                uint8_t *visited, int32_t *counters)
 {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -148,10 +167,8 @@ __global__ void k_oversize_bfs(const int32_t *over_list, int n_over, const int32
     int qs = 1;
     for (int v = 0; v < qs && qs < max_size; ++v) {
         int p = q[v];
-        int y = p / W, x = p - y * W;
-        int nb[4] = { x + 1 < W ? p + 1 : -1, x > 0 ? p - 1 : -1, y + 1 < H ? p + W : -1, y > 0 ? p - W : -1 };
-        for (int j = 0; j < 4; ++j) {
-            int t = nb[j];
+        for (int j = 0; j < 6; ++j) {
+            int t = neighbour(p, D, H, W, j);
             if (t < 0) continue;
             if (state[t] == ST_ACTIVE && parent[t] == root && !visited[t]) {
                 visited[t] = 1;
@@ -284,16 +301,18 @@ k_small_bbox_init(int32_t *bbox, const int32_t *__restrict__ list, const int32_t
 {
     const int n_small = min(counters[CNT_SMALL], capacity);
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n_small; i += gridDim.x * blockDim.x) {
-        bbox[4 * i + 0] = 0x7fffffff;   // min y
-        bbox[4 * i + 1] = -1;           // max y
-        bbox[4 * i + 2] = 0x7fffffff;   // min x
-        bbox[4 * i + 3] = -1;           // max x
+        bbox[6 * i + 0] = 0x7fffffff;   // min y
+        bbox[6 * i + 1] = -1;           // max y
+        bbox[6 * i + 2] = 0x7fffffff;   // min x
+        bbox[6 * i + 3] = -1;           // max x
+        bbox[6 * i + 4] = 0x7fffffff;   // min z
+        bbox[6 * i + 5] = -1;           // max z
         slotmap[list[i]] = i;
     }
 }
 
 __global__ void __launch_bounds__(256)
-k_small_bbox(const int32_t *__restrict__ parent, const int32_t *__restrict__ csize, int n, int W, int min_size,
+k_small_bbox(const int32_t *__restrict__ parent, const int32_t *__restrict__ csize, int n, int H, int W, int min_size,
              const int32_t *__restrict__ slotmap, int32_t *bbox, const int32_t *__restrict__ counters, int capacity)
 {
     int p = blockIdx.x * blockDim.x + threadIdx.x;
@@ -302,11 +321,13 @@ k_small_bbox(const int32_t *__restrict__ parent, const int32_t *__restrict__ csi
     if (csize[r] >= min_size) return;
     if (counters[CNT_SMALL] > capacity) return;     // table too small: the thread-BFS fallback takes all
     int i = slotmap[r];
-    int y = p / W, x = p - y * W;
-    atomicMin(&bbox[4 * i + 0], y);
-    atomicMax(&bbox[4 * i + 1], y);
-    atomicMin(&bbox[4 * i + 2], x);
-    atomicMax(&bbox[4 * i + 3], x);
+    int x = p % W, y = (p / W) % H, z = p / (W * H);
+    atomicMin(&bbox[6 * i + 0], y);
+    atomicMax(&bbox[6 * i + 1], y);
+    atomicMin(&bbox[6 * i + 2], x);
+    atomicMax(&bbox[6 * i + 3], x);
+    atomicMin(&bbox[6 * i + 4], z);
+    atomicMax(&bbox[6 * i + 5], z);
 }
 
 // Exact emulation of the reference's BFS (queue order, neighbour order +x, -x, +y, -y) by one wave:
@@ -319,7 +340,7 @@ k_small_bbox(const int32_t *__restrict__ parent, const int32_t *__restrict__ csi
 template <int CELLS, int FMAX>
 __global__ void __launch_bounds__(64)
 k_small_bfs_wave(const int32_t *__restrict__ list, int32_t *counters,
-                 const int32_t *__restrict__ parent, const int32_t *__restrict__ bbox, int H, int W, int lo_cells,
+                 const int32_t *__restrict__ parent, const int32_t *__restrict__ bbox, int D, int H, int W, int lo_cells,
                  int capacity, int32_t *adjptr, int32_t *fallback_list)
 {
     __shared__ unsigned int prop[CELLS];
@@ -330,24 +351,28 @@ k_small_bfs_wave(const int32_t *__restrict__ list, int32_t *counters,
     if (n_small > capacity) return;
     for (int ci = blockIdx.x; ci < n_small; ci += gridDim.x) {
         const int root = list[ci];
-        const int y0 = max(bbox[4 * ci + 0] - 1, 0), y1 = min(bbox[4 * ci + 1] + 1, H - 1);
-        const int x0 = max(bbox[4 * ci + 2] - 1, 0), x1 = min(bbox[4 * ci + 3] + 1, W - 1);
-        const int bw = x1 - x0 + 1, bh = y1 - y0 + 1;
-        const int cells = bw * bh;
-        if (cells <= lo_cells) continue;           // handled by the launch with the smaller LDS tile
-        if (cells > CELLS) {
+        const int y0 = max(bbox[6 * ci + 0] - 1, 0), y1 = min(bbox[6 * ci + 1] + 1, H - 1);
+        const int x0 = max(bbox[6 * ci + 2] - 1, 0), x1 = min(bbox[6 * ci + 3] + 1, W - 1);
+        const int z0 = max(bbox[6 * ci + 4] - 1, 0), z1 = min(bbox[6 * ci + 5] + 1, D - 1);
+        const int bw = x1 - x0 + 1, bh = y1 - y0 + 1, bd = z1 - z0 + 1;
+        const int bwh = bw * bh;
+        const long cells_l = (long)bwh * bd;
+        if (cells_l <= lo_cells) continue;         // handled by the launch with the smaller LDS tile
+        if (cells_l > CELLS) {
             if (CELLS >= 8192 && lane == 0) fallback_list[atomicAdd(&counters[CNT_FALLBACK], 1)] = root;
             continue;
         }
+        const int cells = (int)cells_l;
         __syncthreads();
         for (int c = lane; c < cells; c += 64) {
-            int cy = c / bw, cx = c - cy * bw;
-            int q = parent[(size_t)(y0 + cy) * W + x0 + cx];
+            int cz = c / bwh, rem = c - cz * bwh;
+            int cy = rem / bw, cx = rem - cy * bw;
+            int q = parent[((size_t)(z0 + cz) * H + (y0 + cy)) * W + x0 + cx];
             cls[c] = (q == root) ? 1 : (q < root ? 2 : 0);
             prop[c] = 0xffffffffu;
         }
-        const int ry = root / W, rx = root - ry * W;
-        const int seed = (ry - y0) * bw + (rx - x0);
+        const int rx = root % W, ry = (root / W) % H, rz = root / (W * H);
+        const int seed = ((rz - z0) * bh + (ry - y0)) * bw + (rx - x0);
         __syncthreads();
         if (lane == 0) {
             fr[0][0] = (uint16_t)seed;
@@ -358,26 +383,29 @@ k_small_bfs_wave(const int32_t *__restrict__ list, int32_t *counters,
         bool failed = false;
         __syncthreads();
         while (f > 0) {
-            const int nkeys = 4 * f;
+            const int nkeys = 6 * f;
             int best_key = -1, best_cell = -1;
             // phase A: proposals + foreign neighbours
             for (int key = lane; key < nkeys; key += 64) {
-                int c = fr[cur][key >> 2], d = key & 3;
-                int cy = c / bw, cx = c - cy * bw;
-                int ny = cy + (d == 2) - (d == 3), nx = cx + (d == 0) - (d == 1);
-                if (ny < 0 || ny >= bh || nx < 0 || nx >= bw) continue;
-                int nc = ny * bw + nx;
+                int c = fr[cur][key / 6], d = key % 6;
+                int cz = c / bwh, rem = c - cz * bwh;
+                int cy = rem / bw, cx = rem - cy * bw;
+                int nx = cx + (d == 0) - (d == 1), ny = cy + (d == 2) - (d == 3), nz = cz + (d == 4) - (d == 5);
+                if (nx < 0 || nx >= bw || ny < 0 || ny >= bh || nz < 0 || nz >= bd) continue;
+                int nc = (nz * bh + ny) * bw + nx;
                 int t = cls[nc];
                 if (t == 1) atomicMin(&prop[nc], (unsigned int)key);
                 else if (t == 2) { best_key = key; best_cell = nc; }     // keys ascend per lane
             }
             // the last foreign contact of this level (largest key) overrides earlier levels
+            if (__any(best_key >= 0)) {
 #pragma unroll
-            for (int off = 32; off > 0; off >>= 1) {
-                int ok = __shfl_xor(best_key, off, 64), oc = __shfl_xor(best_cell, off, 64);
-                if (ok > best_key) { best_key = ok; best_cell = oc; }
+                for (int off = 32; off > 0; off >>= 1) {
+                    int ok = __shfl_xor(best_key, off, 64), oc = __shfl_xor(best_cell, off, 64);
+                    if (ok > best_key) { best_key = ok; best_cell = oc; }
+                }
+                adj_cell = best_cell;
             }
-            if (best_key >= 0) adj_cell = best_cell;
             __syncthreads();
             // phase B: winners, compacted in key order
             int base = 0;
@@ -386,11 +414,12 @@ k_small_bfs_wave(const int32_t *__restrict__ list, int32_t *counters,
                 bool win = false;
                 int nc = 0;
                 if (key < nkeys) {
-                    int c = fr[cur][key >> 2], d = key & 3;
-                    int cy = c / bw, cx = c - cy * bw;
-                    int ny = cy + (d == 2) - (d == 3), nx = cx + (d == 0) - (d == 1);
-                    if (ny >= 0 && ny < bh && nx >= 0 && nx < bw) {
-                        nc = ny * bw + nx;
+                    int c = fr[cur][key / 6], d = key % 6;
+                    int cz = c / bwh, rem = c - cz * bwh;
+                    int cy = rem / bw, cx = rem - cy * bw;
+                    int nx = cx + (d == 0) - (d == 1), ny = cy + (d == 2) - (d == 3), nz = cz + (d == 4) - (d == 5);
+                    if (nx >= 0 && nx < bw && ny >= 0 && ny < bh && nz >= 0 && nz < bd) {
+                        nc = (nz * bh + ny) * bw + nx;
                         win = (cls[nc] == 1) && (prop[nc] == (unsigned int)key);
                     }
                 }
@@ -415,8 +444,9 @@ k_small_bfs_wave(const int32_t *__restrict__ list, int32_t *counters,
         if (lane == 0) {
             int adj = -1;
             if (adj_cell >= 0) {
-                int cy = adj_cell / bw, cx = adj_cell - cy * bw;
-                adj = parent[(size_t)(y0 + cy) * W + x0 + cx];
+                int cz = adj_cell / bwh, rem = adj_cell - cz * bwh;
+                int cy = rem / bw, cx = rem - cy * bw;
+                adj = parent[((size_t)(z0 + cz) * H + (y0 + cy)) * W + x0 + cx];
             }
             adjptr[root] = adj;
         }
@@ -427,7 +457,7 @@ k_small_bfs_wave(const int32_t *__restrict__ list, int32_t *counters,
 __global__ void __launch_bounds__(64)
 k_small_bfs_fallback(const int32_t *__restrict__ list_all, const int32_t *__restrict__ fallback_list,
                      const int32_t *__restrict__ counters, const int32_t *__restrict__ parent,
-                     const int32_t *__restrict__ csize, int H, int W, int capacity, int32_t *queue, uint8_t *visited,
+                     const int32_t *__restrict__ csize, int D, int H, int W, int capacity, int32_t *queue, uint8_t *visited,
                      int32_t *cursor, int32_t *adjptr)
 {
     const bool all = counters[CNT_SMALL] > capacity;
@@ -444,10 +474,8 @@ k_small_bfs_fallback(const int32_t *__restrict__ list_all, const int32_t *__rest
         int qs = 1;
         for (int v = 0; v < qs; ++v) {
             int p = q[v];
-            int y = p / W, x = p - y * W;
-            int nb[4] = { x + 1 < W ? p + 1 : -1, x > 0 ? p - 1 : -1, y + 1 < H ? p + W : -1, y > 0 ? p - W : -1 };
-            for (int j = 0; j < 4; ++j) {
-                int t = nb[j];
+            for (int j = 0; j < 6; ++j) {
+                int t = neighbour(p, D, H, W, j);
                 if (t < 0) continue;
                 int c = parent[t];
                 if (c == root) {
@@ -473,12 +501,12 @@ k_write_labels(const int32_t *__restrict__ parent, const int32_t *__restrict__ n
 }
 
 // CCL + sizes + oversize detection for the currently active pixels
-static void conn_ccl_round(const int32_t *labels_in, int H, int W, int max_size, const ConnWork &w, uint8_t *state,
+static void conn_ccl_round(const int32_t *labels_in, int D, int H, int W, int max_size, const ConnWork &w, uint8_t *state,
                            hipStream_t st)
 {
-    const int n = H * W, grid = cdiv(n, 256);
+    const int n = D * H * W, grid = cdiv(n, 256);
     hipLaunchKernelGGL(k_ccl_init, grid, 256, 0, st, labels_in, state, w.parent, n, W);
-    hipLaunchKernelGGL(k_ccl_merge, grid, 256, 0, st, labels_in, state, w.parent, H, W);
+    hipLaunchKernelGGL(k_ccl_merge, grid, 256, 0, st, labels_in, state, w.parent, D, H, W);
     hipLaunchKernelGGL(k_ccl_flatten, grid, 256, 0, st, w.parent, state, w.csize, n);
     hipLaunchKernelGGL(k_comp_size, grid, 256, 0, st, w.parent, state, w.csize, n);
     hipLaunchKernelGGL(k_find_oversize, grid, 256, 0, st, w.parent, state, w.csize, n, max_size, w.list, w.counters);
@@ -487,14 +515,14 @@ static void conn_ccl_round(const int32_t *labels_in, int H, int W, int max_size,
 // everything after the component structure is final: consecutive labels for kept components,
 // `adjacent` of the small ones (exact BFS emulation), pointer resolution, label write.
 // No host round trip: list lengths stay on the device, the kernels loop over them.
-static int conn_tail(const int32_t *csize_final, int32_t *adjptr, int H, int W, int min_size, int start_label,
+static int conn_tail(const int32_t *csize_final, int32_t *adjptr, int D, int H, int W, int min_size, int start_label,
                      const ConnWork &w, int32_t *labels_out, hipStream_t st)
 {
-    const int n = H * W, grid = cdiv(n, 256);
+    const int n = D * H * W, grid = cdiv(n, 256);
     const int nblocks = cdiv(n, SCAN_BLOCK);
-    const int capacity = n / 8;                       // bbox table: 4 ints per small component
+    const int capacity = n / 12;                      // bbox table: 6 ints per small component
     int32_t *bbox = w.bbox;
-    int32_t *fallback_list = w.bbox + (size_t)4 * capacity;
+    int32_t *fallback_list = w.bbox + (size_t)6 * capacity;
     hipLaunchKernelGGL(k_kept_scan<false>, nblocks, 256, 0, st, w.parent, csize_final, n, min_size, w.blocksum,
                        w.newlabel, start_label);
     hipLaunchKernelGGL(k_scan_blocksums, 1, 256, 0, st, w.blocksum, nblocks, w.counters);
@@ -505,13 +533,13 @@ static int conn_tail(const int32_t *csize_final, int32_t *adjptr, int H, int W, 
     HIP_TRY(hipMemsetAsync(w.counters + CNT_FALLBACK, 0, sizeof(int32_t), st));
     hipLaunchKernelGGL(k_list_small, grid, 256, 0, st, w.parent, csize_final, n, min_size, w.list, w.counters);
     hipLaunchKernelGGL(k_small_bbox_init, 64, 256, 0, st, bbox, w.list, w.counters, w.slotmap, capacity);
-    hipLaunchKernelGGL(k_small_bbox, grid, 256, 0, st, w.parent, csize_final, n, W, min_size, w.slotmap, bbox,
+    hipLaunchKernelGGL(k_small_bbox, grid, 256, 0, st, w.parent, csize_final, n, H, W, min_size, w.slotmap, bbox,
                        w.counters, capacity);
-    hipLaunchKernelGGL((k_small_bfs_wave<1024, 256>), 2048, 64, 0, st, w.list, w.counters, w.parent, bbox, H, W, 0,
+    hipLaunchKernelGGL((k_small_bfs_wave<1024, 256>), 2048, 64, 0, st, w.list, w.counters, w.parent, bbox, D, H, W, 0,
                        capacity, adjptr, fallback_list);
-    hipLaunchKernelGGL((k_small_bfs_wave<8192, 2048>), 256, 64, 0, st, w.list, w.counters, w.parent, bbox, H, W, 1024,
+    hipLaunchKernelGGL((k_small_bfs_wave<8192, 2048>), 256, 64, 0, st, w.list, w.counters, w.parent, bbox, D, H, W, 1024,
                        capacity, adjptr, fallback_list);
-    hipLaunchKernelGGL(k_small_bfs_fallback, 64, 64, 0, st, w.list, fallback_list, w.counters, w.parent, csize_final, H,
+    hipLaunchKernelGGL(k_small_bfs_fallback, 64, 64, 0, st, w.list, fallback_list, w.counters, w.parent, csize_final, D, H,
                        W, capacity, w.queue, w.visited, w.counters + CNT_CURSOR, adjptr);
     hipLaunchKernelGGL(k_small_resolve, 64, 64, 0, st, w.list, w.counters, csize_final, adjptr, min_size, w.newlabel);
     hipLaunchKernelGGL(k_write_labels, grid, 256, 0, st, w.parent, w.newlabel, n, labels_out);
@@ -519,11 +547,11 @@ static int conn_tail(const int32_t *csize_final, int32_t *adjptr, int H, int W, 
     return 0;
 }
 
-int launch_enforce_connectivity(const int32_t *labels_in, int H, int W, long min_size_l, long max_size_l,
+int launch_enforce_connectivity(const int32_t *labels_in, int D, int H, int W, long min_size_l, long max_size_l,
                                 int start_label, ConnWork w, int32_t *labels_out, int *n_labels_out_host,
                                 hipStream_t st)
 {
-    const int n = H * W;
+    const int n = D * H * W;
     const int grid = cdiv(n, 256);
     const int min_size = (int)std::min<long>(min_size_l, 0x7fffffff);
     const int max_size = (int)std::min<long>(max_size_l, 0x7fffffff);
@@ -534,8 +562,8 @@ int launch_enforce_connectivity(const int32_t *labels_in, int H, int W, long min
     // a single host synchronisation at the very end reads the counters
     HIP_TRY(hipMemsetAsync(state, ST_ACTIVE, n, st));
     HIP_TRY(hipMemsetAsync(w.counters, 0, 16 * sizeof(int32_t), st));
-    conn_ccl_round(labels_in, H, W, max_size, w, state, st);
-    if (conn_tail(w.csize, w.adjptr, H, W, min_size, start_label, w, labels_out, st)) return -1;
+    conn_ccl_round(labels_in, D, H, W, max_size, w, state, st);
+    if (conn_tail(w.csize, w.adjptr, D, H, W, min_size, start_label, w, labels_out, st)) return -1;
     HIP_TRY(hipMemcpyAsync(host_counters, w.counters, 8 * sizeof(int32_t), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
 
@@ -547,7 +575,7 @@ int launch_enforce_connectivity(const int32_t *labels_in, int H, int W, long min
         for (int round = 0;; ++round) {
             HIP_TRY(hipMemsetAsync(w.visited, 0, n, st));
             HIP_TRY(hipMemsetAsync(w.counters, 0, 3 * sizeof(int32_t), st));
-            conn_ccl_round(labels_in, H, W, max_size, w, state, st);
+            conn_ccl_round(labels_in, D, H, W, max_size, w, state, st);
             HIP_TRY(hipMemcpyAsync(host_counters, w.counters, 4 * sizeof(int32_t), hipMemcpyDeviceToHost, st));
             HIP_TRY(hipStreamSynchronize(st));
             int n_over = host_counters[CNT_OVER];
@@ -556,7 +584,7 @@ int launch_enforce_connectivity(const int32_t *labels_in, int H, int W, long min
                     set_error("enforce_connectivity: internal queue overflow");
                     return -1;
                 }
-                hipLaunchKernelGGL(k_oversize_bfs, cdiv(n_over, 64), 64, 0, st, w.list, n_over, w.parent, state, H, W,
+                hipLaunchKernelGGL(k_oversize_bfs, cdiv(n_over, 64), 64, 0, st, w.list, n_over, w.parent, state, D, H, W,
                                    max_size, w.queue, w.visited, w.counters);
             }
             hipLaunchKernelGGL(k_oversize_commit, grid, 256, 0, st, w.parent, state, csize_final, w.csize, w.visited, n,
@@ -567,7 +595,7 @@ int launch_enforce_connectivity(const int32_t *labels_in, int H, int W, long min
                 return -1;
             }
         }
-        if (conn_tail(csize_final, w.csize, H, W, min_size, start_label, w, labels_out, st)) return -1;
+        if (conn_tail(csize_final, w.csize, D, H, W, min_size, start_label, w, labels_out, st)) return -1;
         HIP_TRY(hipMemcpyAsync(host_counters, w.counters, 8 * sizeof(int32_t), hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
     }

@@ -152,6 +152,13 @@ int launch_adjacency_centres(const int32_t *labels, int H, int W, int K, uint32_
     dim3 grid(cdiv(W, 64 * GR_PX), cdiv(H, 4));
     hipLaunchKernelGGL(k_adjacency_centres, grid, 256, 0, st, labels, H, W, K, words, bitmap, cacc);
     hipLaunchKernelGGL(k_centres_finalize, cdiv(K, 256), 256, 0, st, cacc, K, centres_out, present_out);
+    return launch_edge_extract(bitmap, K, words, rowcount, edges_out, edge_capacity, n_edges_dev, st);
+}
+
+// read the K x K adjacency bitmap out in row-major order: edges [a, b], a < b, sorted by (b, a)
+int launch_edge_extract(const uint32_t *bitmap, int K, int words, int32_t *rowcount, int32_t *edges_out, int edge_capacity,
+                        int32_t *n_edges_dev, hipStream_t st)
+{
     hipLaunchKernelGGL(k_edge_rowcount, cdiv(K, 256), 256, 0, st, bitmap, K, words, rowcount);
     hipLaunchKernelGGL(k_edge_scan, 1, 256, 0, st, rowcount, K, n_edges_dev);
     hipLaunchKernelGGL(k_edge_emit, cdiv(K, 256), 256, 0, st, bitmap, K, words, rowcount, edges_out, edge_capacity);

@@ -57,6 +57,27 @@ struct ProfHook {
 int launch_slic_iterations(SlicState s, const double *lab, const double *init_yx_dev, int32_t *labels, int max_iter,
                            int max_cand, const ProfHook &prof, hipStream_t st);
 
+// volume.hip -------------------------------------------------------------------------------------
+struct VolState {
+    int D, H, W, K;
+    int step_z, step_y, step_x;
+    double spatial_weight;          // 1 / step^2
+    double sz, sy, sx;              // voxel spacing
+    double *cen;                    // [K][4] = cz, cy, cx, value
+    int *win;                       // [K][6] = zmin, zmax, ymin, ymax, xmin, xmax
+    long long *acc;                 // [K][6] = n, sum z, sum y, sum x, (hi, lo) fixed-point value sum
+    int grid_0[3], grid_d[3], grid_n[3];
+};
+int launch_vol_preprocess(const void *src, int dtype, double off, double scale, int D, int H, int W, const Taps &tz, const Taps &ty,
+                          const Taps &tx, double ratio, double *bufA, double *bufB, hipStream_t st);
+int launch_vol_slic(VolState s, const double *vol, int32_t *labels, int max_iter, hipStream_t st);
+int launch_label_cc(int32_t *labels_inout, int D, int H, int W, int32_t *parent, int32_t *newlabel, int32_t *blocksum,
+                    int32_t *total_dev, hipStream_t st);
+int launch_vol_adjacency(const int32_t *labels, int D, int H, int W, int K, int words, uint32_t *bitmap, long long *cacc,
+                         double *centres, uint8_t *present, hipStream_t st);
+int launch_edge_extract(const uint32_t *bitmap, int K, int words, int32_t *rowcount, int32_t *edges_out, int edge_capacity,
+                        int32_t *n_edges_dev, hipStream_t st);
+
 // connectivity.hip ------------------------------------------------------------------------------
 struct ConnWork {
     int32_t *parent;      // [N] union-find forest / component id (root = min raster index)
@@ -69,9 +90,9 @@ struct ConnWork {
     int32_t *list;        // [N] compacted list of component roots
     int32_t *counters;    // [16] misc device counters
     int32_t *slotmap;     // [N] root -> index in the small-component list
-    int32_t *bbox;        // [N] bounding boxes of small components (N/8 x 4) + fallback list (N/2)
+    int32_t *bbox;        // [N] bounding boxes of small components (N/12 x 6) + fallback list (N/2)
 };
-int launch_enforce_connectivity(const int32_t *labels_in, int H, int W, long min_size, long max_size,
+int launch_enforce_connectivity(const int32_t *labels_in, int D, int H, int W, long min_size, long max_size,
                                 int start_label, ConnWork w, int32_t *labels_out, int *n_labels_out_host,
                                 hipStream_t st);
 
@@ -81,7 +102,7 @@ int launch_enforce_connectivity(const int32_t *labels_in, int H, int W, long min
 int launch_color_stats(const void *img, int dtype, const int32_t *labels, int H, int W, int K, double maxabs,
                        int want_var, long long *acc, double *mean_out, double *energy_out, double *var_out,
                        float *mean32_scratch, hipStream_t st, int planar = 0, int prescale = 0, double mul = 1.0,
-                       double div = 1.0);
+                       double div = 1.0, long plane_stride = -1);
 
 // texture.hip -------------------------------------------------------------------------------------
 int launch_texture_prepare(const void *img, int dtype, int H, int W, const double *taps_dev, int radius,

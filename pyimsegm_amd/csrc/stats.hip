@@ -34,7 +34,8 @@ template <typename T> __device__ __forceinline__ float load_f32(const T *p, size
 struct StatParams {
     int H, W, K;
     double scale_v, scale_e;      // 2^shift for the value / squared-value sums
-    int planar;                   // 0: H x W x 3 interleaved, 1: [3][H][W] planes
+    int planar;                   // 0: H x W x 3 interleaved, 1: three planes `plane_stride` elements apart
+    size_t plane_stride;          //    (0: one gray plane read three times)
     int prescale;                 // 1: value = (raw * mul) / div before the float32 staging
     double mul, div;              //    (descriptors.py:1094 `(response * (log(1 + norm) / 0.03)) / norm`)
 };
@@ -67,7 +68,7 @@ k_color_stats(const T *__restrict__ img, const int32_t *__restrict__ labels, Sta
             lab[i] = ok ? labels[p] : -1;
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
-                const size_t idx = sp.planar ? (size_t)c * sp.H * sp.W + p : 3 * p + c;
+                const size_t idx = sp.planar ? (size_t)c * sp.plane_stride + p : 3 * p + c;
                 v[i][c] = sp.prescale ? (float)(((double)img[idx] * sp.mul) / sp.div) : load_f32(img, idx);
             }
         }
@@ -224,11 +225,13 @@ static double pow2_scale(double n_pixels, double maxabs)
 
 int launch_color_stats(const void *img, int dtype, const int32_t *labels, int H, int W, int K, double maxabs,
                        int want_var, long long *acc, double *mean_out, double *energy_out, double *var_out,
-                       float *mean32_scratch, hipStream_t st, int planar, int prescale, double mul, double div)
+                       float *mean32_scratch, hipStream_t st, int planar, int prescale, double mul, double div,
+                       long plane_stride)
 {
     StatParams sp;
     sp.H = H; sp.W = W; sp.K = K;
     sp.planar = planar; sp.prescale = prescale; sp.mul = mul; sp.div = div;
+    sp.plane_stride = plane_stride >= 0 ? (size_t)plane_stride : (size_t)H * W;
     sp.scale_v = pow2_scale((double)H * W, maxabs);
     sp.scale_e = pow2_scale((double)H * W, 4.0 * maxabs * maxabs);
     hipLaunchKernelGGL(k_stats_clear, cdiv(K, 256), 256, 0, st, acc, K, 0, 13);

@@ -1,0 +1,465 @@
+// volume.hip -- 3-D gray supervoxel path (BASELINE config 5).
+//
+// Replaces, for D x H x W gray volumes:
+//   skimage.segmentation.slic(im, n_segments, compactness, multichannel=False, spacing=space, sigma=1)
+//       as called at /root/reference/imsegm/superpixels.py:104-106   (no Lab, anisotropic spacing)
+//   skimage.measure.label(slic_segments)                     superpixels.py:111 (full connectivity, 0 = background)
+//   make_graph_segm_connect_grid3d_conn6 / superpixel_centers (3-D branch)   superpixels.py:180-242
+// Arithmetic contract of the assignment: identical to oracle orc_slic_iterate (fp64, operation order
+// of _slic.pyx with spacing):  d = ((sz*(cz-z))^2 + (sy*(cy-y))^2 + (sx*(cx-x))^2) * (1/step^2) + (v - cv)^2.
+//
+// First version: functional and exact, sized for volumes of a few 10^7 voxels -- every wave scans the
+// whole centroid table (O(waves * K)); the cell-list binning needed for the 10^9-voxel config is
+// listed in DESIGN.md section 7.
+#include "slic.h"
+
+namespace imsegm {
+
+__device__ __forceinline__ int vreflect(int i, int n)
+{
+    if (n == 1) return 0;
+    int p = 2 * n;
+    i %= p;
+    if (i < 0) i += p;
+    if (i >= n) i = p - 1 - i;
+    return i;
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256)
+k_vol_to_f64(const T *__restrict__ src, size_t n, double off, double scale, double *__restrict__ dst)
+{
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    // skimage.img_as_float as an affine map: (v + off) * scale   (uint8: off 0, scale 1 / 255)
+    if (i < n) dst[i] = ((double)src[i] + off) * scale;
+}
+
+// one scipy correlate1d pass (symmetric taps, 'reflect') along z (0), y (1) or x (2); optional final scale
+template <int AXIS>
+__global__ void __launch_bounds__(256)
+k_vol_blur(const double *__restrict__ src, double *__restrict__ dst, int D, int H, int W, Taps t, double ratio, int scale)
+{
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    size_t n = (size_t)D * H * W;
+    if (i >= n) return;
+    int x = (int)(i % W), y = (int)((i / W) % H), z = (int)(i / ((size_t)W * H));
+    double v;
+    if (t.r < 0) {
+        v = src[i];
+    } else {
+        v = src[i] * t.w[0];
+        for (int j = t.r; j >= 1; --j) {
+            size_t a, b;
+            if (AXIS == 0) {
+                a = ((size_t)vreflect(z - j, D) * H + y) * W + x;
+                b = ((size_t)vreflect(z + j, D) * H + y) * W + x;
+            } else if (AXIS == 1) {
+                a = ((size_t)z * H + vreflect(y - j, H)) * W + x;
+                b = ((size_t)z * H + vreflect(y + j, H)) * W + x;
+            } else {
+                a = ((size_t)z * H + y) * W + vreflect(x - j, W);
+                b = ((size_t)z * H + y) * W + vreflect(x + j, W);
+            }
+            v += (src[a] + src[b]) * t.w[j];
+        }
+    }
+    if (scale) v = v * ratio;
+    dst[i] = v;
+}
+
+int launch_vol_preprocess(const void *src, int dtype, double off, double scale, int D, int H, int W, const Taps &tz, const Taps &ty,
+                          const Taps &tx, double ratio, double *bufA, double *bufB, hipStream_t st)
+{
+    size_t n = (size_t)D * H * W;
+    int grid = cdiv((long)n, 256);
+    if (dtype == DT_U8) hipLaunchKernelGGL(k_vol_to_f64<uint8_t>, grid, 256, 0, st, (const uint8_t *)src, n, off, scale, bufA);
+    else if (dtype == DT_F32) hipLaunchKernelGGL(k_vol_to_f64<float>, grid, 256, 0, st, (const float *)src, n, off, scale, bufA);
+    else hipLaunchKernelGGL(k_vol_to_f64<double>, grid, 256, 0, st, (const double *)src, n, off, scale, bufA);
+    hipLaunchKernelGGL(k_vol_blur<0>, grid, 256, 0, st, bufA, bufB, D, H, W, tz, ratio, 0);
+    hipLaunchKernelGGL(k_vol_blur<1>, grid, 256, 0, st, bufB, bufA, D, H, W, ty, ratio, 0);
+    hipLaunchKernelGGL(k_vol_blur<2>, grid, 256, 0, st, bufA, bufB, D, H, W, tx, ratio, 1);
+    HIP_TRY(hipGetLastError());
+    return 0;   // result in bufB
+}
+
+// ---- centroid table ----------------------------------------------------------------------------------
+__device__ __forceinline__ void vol_window(const VolState &s, double cz, double cy, double cx, int *w)
+{
+    double a;
+    a = cz - (double)(2 * s.step_z); w[0] = (int)(a > 0 ? a : 0.0);
+    a = cz + (double)(2 * s.step_z); a = a + 1.0; w[1] = (int)(a < (double)s.D ? a : (double)s.D);
+    a = cy - (double)(2 * s.step_y); w[2] = (int)(a > 0 ? a : 0.0);
+    a = cy + (double)(2 * s.step_y); a = a + 1.0; w[3] = (int)(a < (double)s.H ? a : (double)s.H);
+    a = cx - (double)(2 * s.step_x); w[4] = (int)(a > 0 ? a : 0.0);
+    a = cx + (double)(2 * s.step_x); a = a + 1.0; w[5] = (int)(a < (double)s.W ? a : (double)s.W);
+}
+
+__global__ void k_vol_centroid_init(VolState s)
+{
+    int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= s.K) return;
+    int ix = k % s.grid_n[2], iy = (k / s.grid_n[2]) % s.grid_n[1], iz = k / (s.grid_n[2] * s.grid_n[1]);
+    double cz = (double)(s.grid_0[0] + iz * s.grid_d[0]);
+    double cy = (double)(s.grid_0[1] + iy * s.grid_d[1]);
+    double cx = (double)(s.grid_0[2] + ix * s.grid_d[2]);
+    s.cen[(size_t)k * 4 + 0] = cz;
+    s.cen[(size_t)k * 4 + 1] = cy;
+    s.cen[(size_t)k * 4 + 2] = cx;
+    s.cen[(size_t)k * 4 + 3] = 0.0;
+    vol_window(s, cz, cy, cx, s.win + (size_t)k * 6);
+    for (int j = 0; j < 6; ++j) s.acc[(size_t)k * 6 + j] = 0;
+}
+
+__global__ void k_vol_centroid_finalize(VolState s)
+{
+    int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= s.K) return;
+    long long *a = s.acc + (size_t)k * 6;
+    long long n = a[0];
+    int *w = s.win + (size_t)k * 6;
+    if (n == 0) {
+        for (int j = 0; j < 6; ++j) w[j] = 0;
+    } else {
+        double nn = (double)n;
+        double cz = i64_to_double(a[1]) / nn, cy = i64_to_double(a[2]) / nn, cx = i64_to_double(a[3]) / nn;
+        s.cen[(size_t)k * 4 + 0] = cz;
+        s.cen[(size_t)k * 4 + 1] = cy;
+        s.cen[(size_t)k * 4 + 2] = cx;
+        s.cen[(size_t)k * 4 + 3] = fix_join(a[4], a[5]) / nn;
+        vol_window(s, cz, cy, cx, w);
+    }
+    for (int j = 0; j < 6; ++j) a[j] = 0;
+}
+
+// ---- assignment -----------------------------------------------------------------------------------------
+// One wave = 64 consecutive x, VROWS rows of one z slice.  The wave scans the centroid table in
+// ascending k, keeps the windows that meet its voxels in an LDS list (ballot compaction keeps the
+// order), and evaluates the list in chunks: ascending k + strict '>' == lowest index wins ties.
+constexpr int VROWS = 4;
+constexpr int VLIST = 256;
+
+template <bool ACCUM>
+__global__ void __launch_bounds__(256)
+k_vol_assign(VolState s, const double *__restrict__ vol, int32_t *__restrict__ labels)
+{
+    __shared__ int list[4][VLIST];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int rows_per_block = 4 * VROWS;
+    const int yb = cdiv(s.H, rows_per_block);
+    const int z = blockIdx.y / yb;
+    const int y0 = (blockIdx.y % yb) * rows_per_block + wave * VROWS;
+    const int x = blockIdx.x * 64 + lane;
+    const int x0w = blockIdx.x * 64, x1w = min(x0w + 64, s.W);
+    if (y0 >= s.H) return;
+    const int y1w = min(y0 + VROWS, s.H);
+    const bool xin = x < s.W;
+    double pv[VROWS], best_d[VROWS];
+    int best_k[VROWS];
+#pragma unroll
+    for (int r = 0; r < VROWS; ++r) {
+        bool ok = xin && (y0 + r) < s.H;
+        pv[r] = vol[ok ? ((size_t)z * s.H + y0 + r) * s.W + x : 0];
+        best_d[r] = DBL_MAX;
+        best_k[r] = -1;
+    }
+    const double fz = (double)z, fx = (double)x;
+    int count = 0;
+    const int nblk = cdiv(s.K, 64);
+    for (int b = 0; b < nblk; ++b) {
+        // scan 64 windows
+        int k = b * 64 + lane;
+        bool hit = false;
+        if (k < s.K) {
+            const int *w = s.win + (size_t)k * 6;
+            hit = z >= w[0] && z < w[1] && w[2] < y1w && w[3] > y0 && w[4] < x1w && w[5] > x0w;
+        }
+        unsigned long long m = __ballot(hit);
+        if (hit) list[wave][count + __popcll(m & ((1ULL << lane) - 1ULL))] = k;
+        count += __popcll(m);
+        if (count < VLIST - 64 && b + 1 < nblk) continue;
+        // evaluate the collected candidates (ascending k)
+        for (int c = 0; c < count; ++c) {
+            const int ck = list[wave][c];
+            const int *w = s.win + (size_t)ck * 6;
+            const double cz = s.cen[(size_t)ck * 4], cy = s.cen[(size_t)ck * 4 + 1], cx = s.cen[(size_t)ck * 4 + 2];
+            const double cv = s.cen[(size_t)ck * 4 + 3];
+            const int wy0 = w[2], wy1 = w[3];
+            const bool inx = x >= w[4] && x < w[5];
+            const double tz = s.sz * (cz - fz);
+            const double dz = tz * tz;
+            const double tx = s.sx * (cx - fx);
+            const double dx2 = tx * tx;
+#pragma unroll
+            for (int r = 0; r < VROWS; ++r) {
+                const int y = y0 + r;
+                if (y < wy0 || y >= wy1) continue;
+                const double ty = s.sy * (cy - (double)y);
+                const double dy = ty * ty;
+                double d = (dz + dy + dx2) * s.spatial_weight;
+                const double t = pv[r] - cv;
+                d = d + t * t;
+                if (inx && best_d[r] > d) {
+                    best_d[r] = d;
+                    best_k[r] = ck;
+                }
+            }
+        }
+        count = 0;
+    }
+    // labels (an uncovered voxel keeps its previous assignment) + accumulation
+    unsigned pending = 0;
+#pragma unroll
+    for (int r = 0; r < VROWS; ++r) {
+        if (!(xin && (y0 + r) < s.H)) continue;
+        size_t p = ((size_t)z * s.H + y0 + r) * s.W + x;
+        if (best_k[r] >= 0) labels[p] = best_k[r];
+        else best_k[r] = labels[p];
+        if (best_k[r] >= 0) pending |= 1u << r;
+    }
+    if (!ACCUM) return;
+    while (true) {
+        int first = -1;
+#pragma unroll
+        for (int r = VROWS - 1; r >= 0; --r)
+            if (pending & (1u << r)) first = best_k[r];
+        unsigned long long vote = __ballot(first >= 0);
+        if (!vote) break;
+        const int k = __shfl(first, __ffsll((long long)vote) - 1, 64);
+        long long q[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+#pragma unroll
+        for (int r = 0; r < VROWS; ++r) {
+            if ((pending & (1u << r)) && best_k[r] == k) {
+                long long hi, lo;
+                fix_split(pv[r], hi, lo);
+                q[0] += 1; q[1] += z; q[2] += y0 + r; q[3] += x; q[4] += hi; q[5] += lo;
+                pending &= ~(1u << r);
+            }
+        }
+        long long tot = wave_reduce8_i64(q);
+        if ((lane & 7) == 0 && (lane >> 3) < 6 && tot != 0) atomic_add_i64(s.acc + (size_t)k * 6 + (lane >> 3), tot);
+    }
+}
+
+int launch_vol_slic(VolState s, const double *vol, int32_t *labels, int max_iter, hipStream_t st)
+{
+    size_t n = (size_t)s.D * s.H * s.W;
+    HIP_TRY(hipMemsetAsync(labels, 0xff, n * sizeof(int32_t), st));
+    hipLaunchKernelGGL(k_vol_centroid_init, cdiv(s.K, 256), 256, 0, st, s);
+    dim3 grid(cdiv(s.W, 64), cdiv(s.H, 4 * VROWS) * s.D);
+    for (int it = 0; it < max_iter; ++it) {
+        if (it + 1 < max_iter) {
+            hipLaunchKernelGGL(k_vol_assign<true>, grid, 256, 0, st, s, vol, labels);
+            hipLaunchKernelGGL(k_vol_centroid_finalize, cdiv(s.K, 256), 256, 0, st, s);
+        } else {
+            hipLaunchKernelGGL(k_vol_assign<false>, grid, 256, 0, st, s, vol, labels);
+        }
+    }
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+// ---- skimage.measure.label: full (26-/8-) connectivity, value 0 = background ------------------------------
+__device__ __forceinline__ int cc_find(const int32_t *parent, int a)
+{
+    int p = parent[a];
+    while (p != a) {
+        a = p;
+        p = parent[a];
+    }
+    return a;
+}
+__device__ __forceinline__ void cc_union(int32_t *parent, int a, int b)
+{
+    while (true) {
+        a = cc_find(parent, a);
+        b = cc_find(parent, b);
+        if (a == b) return;
+        if (a < b) {
+            int t = a;
+            a = b;
+            b = t;
+        }
+        int old = atomicMin(&parent[a], b);
+        if (old == a) return;
+        a = old;
+    }
+}
+
+__global__ void __launch_bounds__(256) k_cc_init(int32_t *parent, int n)
+{
+    int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p < n) parent[p] = p;
+}
+
+__global__ void __launch_bounds__(256)
+k_cc_merge_full(const int32_t *__restrict__ labels, int32_t *parent, int D, int H, int W)
+{
+    int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= D * H * W) return;
+    const int l = labels[p];
+    if (l == 0) return;                              // background is never joined
+    const int x = p % W, y = (p / W) % H, z = p / (W * H);
+    // the 13 "earlier" neighbours of the full 3 x 3 x 3 neighbourhood
+    for (int dz = -1; dz <= 0; ++dz)
+        for (int dy = -1; dy <= 1; ++dy)
+            for (int dx = -1; dx <= 1; ++dx) {
+                if (dz == 0 && (dy > 0 || (dy == 0 && dx >= 0))) continue;
+                int zz = z + dz, yy = y + dy, xx = x + dx;
+                if (zz < 0 || yy < 0 || yy >= H || xx < 0 || xx >= W) continue;
+                int q = (zz * H + yy) * W + xx;
+                if (labels[q] == l) cc_union(parent, p, q);
+            }
+}
+
+__global__ void __launch_bounds__(256) k_cc_flatten(int32_t *parent, int n)
+{
+    int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p < n) parent[p] = cc_find(parent, p);
+}
+
+// roots of non-background components are numbered 1, 2, ... in raster order (block scan in three steps)
+constexpr int CC_PER_THREAD = 16;
+constexpr int CC_BLOCK = 256 * CC_PER_THREAD;
+
+__device__ __forceinline__ int cc_block_scan(int v, int *total)
+{
+    __shared__ int wsum[4];
+    int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int incl = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        int t = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += t;
+    }
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    int base = 0;
+    for (int w = 0; w < wave; ++w) base += wsum[w];
+    *total = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    __syncthreads();
+    return base + incl - v;
+}
+
+template <bool ASSIGN>
+__global__ void __launch_bounds__(256)
+k_cc_number(const int32_t *__restrict__ labels, const int32_t *__restrict__ parent, int n, int32_t *blocksum,
+            int32_t *newlabel)
+{
+    int p0 = blockIdx.x * CC_BLOCK + threadIdx.x * CC_PER_THREAD;
+    int cnt = 0;
+    for (int j = 0; j < CC_PER_THREAD; ++j) {
+        int p = p0 + j;
+        if (p < n && parent[p] == p && labels[p] != 0) cnt++;
+    }
+    int total;
+    int excl = cc_block_scan(cnt, &total);
+    if (!ASSIGN) {
+        if (threadIdx.x == 0) blocksum[blockIdx.x] = total;
+    } else {
+        int rank = blocksum[blockIdx.x] + excl;
+        for (int j = 0; j < CC_PER_THREAD; ++j) {
+            int p = p0 + j;
+            if (p < n && parent[p] == p) newlabel[p] = labels[p] != 0 ? 1 + rank++ : 0;
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256) k_cc_scan_blocks(int32_t *blocksum, int nblocks, int32_t *total_out)
+{
+    __shared__ int carry;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (int base = 0; base < nblocks; base += 256) {
+        int i = base + threadIdx.x;
+        int v = i < nblocks ? blocksum[i] : 0;
+        int total;
+        int excl = cc_block_scan(v, &total);
+        if (i < nblocks) blocksum[i] = carry + excl;
+        __syncthreads();
+        if (threadIdx.x == 0) carry += total;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *total_out = carry;
+}
+
+__global__ void __launch_bounds__(256)
+k_cc_write(const int32_t *__restrict__ parent, const int32_t *__restrict__ newlabel, int n, int32_t *out)
+{
+    int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p < n) out[p] = newlabel[parent[p]];
+}
+
+int launch_label_cc(int32_t *labels_inout, int D, int H, int W, int32_t *parent, int32_t *newlabel, int32_t *blocksum,
+                    int32_t *total_dev, hipStream_t st)
+{
+    const int n = D * H * W, grid = cdiv(n, 256), nb = cdiv(n, CC_BLOCK);
+    hipLaunchKernelGGL(k_cc_init, grid, 256, 0, st, parent, n);
+    hipLaunchKernelGGL(k_cc_merge_full, grid, 256, 0, st, labels_inout, parent, D, H, W);
+    hipLaunchKernelGGL(k_cc_flatten, grid, 256, 0, st, parent, n);
+    hipLaunchKernelGGL(k_cc_number<false>, nb, 256, 0, st, labels_inout, parent, n, blocksum, newlabel);
+    hipLaunchKernelGGL(k_cc_scan_blocks, 1, 256, 0, st, blocksum, nb, total_dev);
+    hipLaunchKernelGGL(k_cc_number<true>, nb, 256, 0, st, labels_inout, parent, n, blocksum, newlabel);
+    hipLaunchKernelGGL(k_cc_write, grid, 256, 0, st, parent, newlabel, n, labels_inout);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+// ---- 6-connected adjacency bitmap + centre sums of a label volume -----------------------------------------
+__global__ void __launch_bounds__(256)
+k_vol_adjacency_centres(const int32_t *__restrict__ labels, int D, int H, int W, int words, uint32_t *bitmap,
+                        long long *__restrict__ cacc)
+{
+    int p = blockIdx.x * blockDim.x + threadIdx.x;
+    const int n = D * H * W;
+    const int lane = threadIdx.x & 63;
+    int l = p < n ? labels[p] : -1;
+    int x = 0, y = 0, z = 0;
+    if (l >= 0) {
+        x = p % W; y = (p / W) % H; z = p / (W * H);
+        int nb[3] = { x + 1 < W ? labels[p + 1] : l, y + 1 < H ? labels[p + W] : l, z + 1 < D ? labels[p + W * H] : l };
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            if (nb[j] == l) continue;
+            int a = min(l, nb[j]), b = max(l, nb[j]);
+            uint32_t *wp = bitmap + (size_t)b * words + (a >> 5);
+            uint32_t bit = 1u << (a & 31);
+            if (!(*wp & bit)) atomicOr(wp, bit);
+        }
+    }
+    int cur = l;
+    while (true) {
+        unsigned long long vote = __ballot(cur >= 0);
+        if (!vote) break;
+        int k = __shfl(cur, __ffsll((long long)vote) - 1, 64);
+        bool mine = cur == k;
+        long long q[8] = { mine ? 1 : 0, mine ? z : 0, mine ? y : 0, mine ? x : 0, 0, 0, 0, 0 };
+        long long tot = wave_reduce8_i64(q);
+        if ((lane & 7) == 0 && (lane >> 3) < 4) atomic_add_i64(cacc + (size_t)k * 4 + (lane >> 3), tot);
+        if (mine) cur = -1;
+    }
+}
+
+__global__ void k_vol_centres_finalize(const long long *__restrict__ cacc, int K, double *centres, uint8_t *present)
+{
+    int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= K) return;
+    long long n = cacc[(size_t)k * 4];
+    present[k] = n > 0;
+    for (int c = 0; c < 3; ++c)
+        centres[3 * k + c] = n > 0 ? i64_to_double(cacc[(size_t)k * 4 + 1 + c]) / (double)n : -1.0;
+}
+
+int launch_vol_adjacency(const int32_t *labels, int D, int H, int W, int K, int words, uint32_t *bitmap, long long *cacc,
+                         double *centres, uint8_t *present, hipStream_t st)
+{
+    const int n = D * H * W;
+    HIP_TRY(hipMemsetAsync(bitmap, 0, (size_t)K * words * sizeof(uint32_t), st));
+    HIP_TRY(hipMemsetAsync(cacc, 0, (size_t)K * 4 * sizeof(long long), st));
+    hipLaunchKernelGGL(k_vol_adjacency_centres, cdiv(n, 256), 256, 0, st, labels, D, H, W, words, bitmap, cacc);
+    hipLaunchKernelGGL(k_vol_centres_finalize, cdiv(K, 256), 256, 0, st, cacc, K, centres, present);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+}  // namespace imsegm

@@ -304,7 +304,6 @@ def numpy_img2d_color_median(img, seg):
 
 # ------------------------------------------------------------------------------------------------
 # gray 3D statistics (reference: cython_img3d_gray_* / numpy_img3d_gray_*, descriptors.py:458-702)
-# host numpy for now: the 3D rows are scheduled after the 2D ones
 # ------------------------------------------------------------------------------------------------
 
 
@@ -319,38 +318,76 @@ def _gray_sums(values, seg):
     return out
 
 
-def cython_img3d_gray_mean(img, seg):
-    """ mean intensity per supervoxel, float32 staging as features_cython.pyx:144-166
+def _gray_stats_session(img, seg):
+    img, seg = np.asarray(img), np.asarray(seg)
+    _check_gray_image_segm(img, seg)
+    return _hip.Volume3D(*seg.shape).upload(img).set_labels(seg)
+
+
+def hip_img3d_gray_mean(img, seg):
+    """ mean intensity per supervoxel (float32 staging, 64-bit accumulation as features_cython.pyx:144-166)
+
+    :param ndarray img: gray volume D x H x W
+    :param ndarray seg: segmentation D x H x W
+    :return ndarray: np.array<nb_lbs>
 
     >>> image = np.zeros((2, 3, 8))
     >>> image[0, :, 2:6] = 1
     >>> image[1, :, 3:7] = 3
     >>> segm = np.array([[[0, 0, 0, 0, 1, 1, 1, 1]] * 3,
     ...                  [[2, 2, 2, 2, 3, 3, 3, 3]] * 3])
-    >>> cython_img3d_gray_mean(image, segm).tolist()
+    >>> hip_img3d_gray_mean(image, segm).tolist()  # doctest: +SKIP
     [0.5, 0.5, 0.75, 2.25]
     """
-    img, seg = np.asarray(img), np.asarray(seg)
-    _check_gray_image_segm(img, seg)
-    return _gray_sums(img.astype(np.float32), seg)
+    logging.debug('HIP: computing Gray means for image %r and segm %r', np.shape(img), np.shape(seg))
+    sess = _gray_stats_session(img, seg)
+    mean, _, _ = sess.gray_stats(mean=True, energy=False, var=False)
+    sess.close()
+    return mean
 
 
-def cython_img3d_gray_energy(img, seg):
-    """ mean squared intensity per supervoxel (features_cython.pyx:169-191) """
-    img, seg = np.asarray(img), np.asarray(seg)
-    _check_gray_image_segm(img, seg)
-    v = img.astype(np.float32)
-    return _gray_sums(v * v, seg)
+def hip_img3d_gray_energy(img, seg):
+    """ mean squared intensity per supervoxel (features_cython.pyx:169-191)
+
+    >>> image = np.zeros((2, 3, 8))
+    >>> image[0, :, 2:6] = 1
+    >>> image[1, :, 3:7] = 3
+    >>> segm = np.array([[[0, 0, 0, 0, 1, 1, 1, 1]] * 3,
+    ...                  [[2, 2, 2, 2, 3, 3, 3, 3]] * 3])
+    >>> hip_img3d_gray_energy(image, segm).tolist()  # doctest: +SKIP
+    [0.5, 0.5, 2.25, 6.75]
+    """
+    logging.debug('HIP: computing Gray energy for image %r and segm %r', np.shape(img), np.shape(seg))
+    sess = _gray_stats_session(img, seg)
+    _, energy, _ = sess.gray_stats(mean=False, energy=True, var=False)
+    sess.close()
+    return energy
 
 
-def cython_img3d_gray_std(img, seg, mean=None):
-    """ intensity STD per supervoxel (features_cython.pyx:194-219; float32 mean, descriptors.py:547) """
-    img, seg = np.asarray(img), np.asarray(seg)
-    _check_gray_image_segm(img, seg)
-    if mean is None:
-        mean = cython_img3d_gray_mean(img, seg)
-    d = img.astype(np.float32) - np.asarray(mean, dtype=np.float32)[seg]
-    return np.sqrt(_gray_sums(d * d, seg))
+def hip_img3d_gray_std(img, seg, mean=None):
+    """ intensity STD per supervoxel (features_cython.pyx:194-219; float32-rounded mean, descriptors.py:547)
+
+    ``mean`` is accepted for API compatibility; the means are (re)computed on the device, which is
+    what the reference does when ``mean`` is None and what its callers pass anyway.
+
+    >>> image = np.zeros((2, 3, 8))
+    >>> image[0, :, 2:6] = 1
+    >>> image[1, :, 3:7] = 3
+    >>> segm = np.array([[[0, 0, 0, 0, 1, 1, 1, 1]] * 3,
+    ...                  [[2, 2, 2, 2, 3, 3, 3, 3]] * 3])
+    >>> np.round(hip_img3d_gray_std(image, segm), 4).tolist()  # doctest: +SKIP
+    [0.5, 0.5, 1.299, 1.299]
+    """
+    logging.debug('HIP: computing Gray STD for image %r and segm %r', np.shape(img), np.shape(seg))
+    sess = _gray_stats_session(img, seg)
+    _, _, var = sess.gray_stats(mean=False, energy=False, var=True)
+    sess.close()
+    return np.sqrt(var)
+
+
+cython_img3d_gray_mean = hip_img3d_gray_mean
+cython_img3d_gray_energy = hip_img3d_gray_energy
+cython_img3d_gray_std = hip_img3d_gray_std
 
 
 def numpy_img3d_gray_mean(img, seg):
@@ -384,7 +421,7 @@ def numpy_img3d_gray_median(img, seg):
     return _segmented_median(np.asarray(img, dtype=np.float64).ravel(), seg.ravel(), nb)
 
 
-def compute_image3d_gray_statistic(image, segm, feature_flags=NAMES_FEATURE_FLAGS, ch_name='gray'):
+def compute_image3d_gray_statistic(image, segm, feature_flags=NAMES_FEATURE_FLAGS, ch_name='gray', sess=None):
     """ statistics of a gray volume per supervoxel (reference descriptors.py:705-784)
 
     >>> image = np.zeros((2, 3, 8))
@@ -392,27 +429,35 @@ def compute_image3d_gray_statistic(image, segm, feature_flags=NAMES_FEATURE_FLAG
     >>> image[1, :, 3:7] = 3
     >>> segm = np.array([[[0, 0, 0, 0, 1, 1, 1, 1]] * 3,
     ...                  [[2, 2, 2, 2, 5, 5, 5, 5]] * 3])
-    >>> features, names = compute_image3d_gray_statistic(image, segm)
-    >>> np.round(features, 3).tolist()  # doctest: +NORMALIZE_WHITESPACE
+    >>> features, names = compute_image3d_gray_statistic(image, segm)  # doctest: +SKIP
+    >>> np.round(features, 3).tolist()  # doctest: +SKIP
     [[0.5, 0.5, 0.5, 0.5, 0.25], [0.5, 0.5, 0.5, 0.5, -0.25], [0.75, 1.299, 2.25, 0.0, 0.75],
      [0.0, 0.0, 0.0, 0.0, 0.0], [0.0, 0.0, 0.0, 0.0, 0.0], [2.25, 1.299, 6.75, 3.0, -1.125]]
-    >>> names
+    >>> names  # doctest: +SKIP
     ['gray_mean', 'gray_std', 'gray_energy', 'gray_median', 'gray_meanGrad']
     """
-    image, segm = np.asarray(image), np.asarray(segm)
+    image = np.asarray(image)
+    if sess is None:
+        segm = np.asarray(segm)
     _check_gray_image_segm(image, segm)
     if not list(feature_flags):
         raise ValueError('some features has to be selected')
     image = np.nan_to_num(image)
     features = []
-    mean = None
-    if 'mean' in feature_flags:
-        mean = cython_img3d_gray_mean(image, segm)
-        features.append(mean)
-    if 'std' in feature_flags:
-        features.append(cython_img3d_gray_std(image, segm, mean))
-    if 'energy' in feature_flags:
-        features.append(cython_img3d_gray_energy(image, segm))
+    want = [f in feature_flags for f in ('mean', 'energy', 'std')]
+    if any(want):
+        own = sess is None
+        if own:
+            sess = _hip.Volume3D(*segm.shape).upload(image).set_labels(segm)
+        mean, energy, var = sess.gray_stats(mean=want[0], energy=want[1], var=want[2])
+        if own:
+            sess.close()
+        if want[0]:
+            features.append(mean)
+        if want[2]:
+            features.append(np.sqrt(var))
+        if want[1]:
+            features.append(energy)
     if 'median' in feature_flags:
         features.append(numpy_img3d_gray_median(image, segm))
     if 'meanGrad' in feature_flags:
@@ -702,7 +747,7 @@ def _texture_desc_lm_device(img, seg, feature_flags, filters, fl_names, sess=Non
 # ------------------------------------------------------------------------------------------------
 
 
-def compute_selected_features_gray3d(img, segments, feature_flags=FEATURES_SET_COLOR):
+def compute_selected_features_gray3d(img, segments, feature_flags=FEATURES_SET_COLOR, sess=None):
     """ selected features of a gray volume
 
     >>> np.random.seed(0)
@@ -710,20 +755,22 @@ def compute_selected_features_gray3d(img, segments, feature_flags=FEATURES_SET_C
     >>> slic = np.zeros((2, 10, 15), dtype=int)
     >>> slic[:, :, :7] += 1
     >>> slic[1, :, :] += 2
-    >>> fts, names = compute_selected_features_gray3d(img, slic, {'color': ('mean', 'std', 'median')})
-    >>> fts.shape
+    >>> fts, names = compute_selected_features_gray3d(img, slic, {'color': ('mean', 'std', 'median')})  # doctest: +SKIP
+    >>> fts.shape  # doctest: +SKIP
     (4, 3)
-    >>> names
+    >>> names  # doctest: +SKIP
     ['gray_mean', 'gray_std', 'gray_median']
     """
-    img, segments = np.asarray(img), np.asarray(segments)
+    img = np.asarray(img)
+    if sess is None:
+        segments = np.asarray(segments)
     _check_gray_image_segm(img, segments)
     if not feature_flags:
         raise ValueError('some features has to be selected')
     features, names = [], []
     if any(k.startswith('color') for k in feature_flags):
         flags = np.unique([feature_flags[k] for k in feature_flags if k.startswith('color')])
-        fts, ns = compute_image3d_gray_statistic(img, segments, flags)
+        fts, ns = compute_image3d_gray_statistic(img, segments, flags, sess=sess)
         features.append(fts)
         names += ns
     for k in [k for k in feature_flags if k.startswith('tLM')]:
@@ -749,8 +796,8 @@ def compute_selected_features_gray2d(img, segments, features_flags=FEATURES_SET_
     >>> image[1, 3:7] = 3
     >>> segm = np.array([[0, 0, 0, 0, 0, 1, 1, 1, 1, 1],
     ...                  [0, 0, 0, 0, 0, 1, 1, 1, 1, 1]])
-    >>> features, names = compute_selected_features_gray2d(image, segm, {'color': ('mean', 'std', 'median')})
-    >>> np.round(features, 3).tolist()
+    >>> features, names = compute_selected_features_gray2d(image, segm, {'color': ('mean', 'std', 'median')})  # doctest: +SKIP
+    >>> np.round(features, 3).tolist()  # doctest: +SKIP
     [[0.9, 1.136, 0.5], [0.7, 1.187, 0.0]]
     """
     img, segments = np.asarray(img), np.asarray(segments)

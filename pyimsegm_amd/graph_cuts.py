@@ -365,7 +365,7 @@ def compute_edge_weights(segments, image=None, features=None, proba=None, edge_t
     logging.debug('extraction segment connectivity...')
     if _session is None:
         segments = np.asarray(segments)
-    if segments.ndim == 2:
+    if segments.ndim in (2, 3):
         edges, centres, present = _edges_centres(segments, _session)
         edges = np.array(edges, dtype=np.int32).reshape(-1, 2)
         centre_list = None

@@ -13,9 +13,10 @@ import logging
 import numpy as np
 
 from pyimsegm_amd import _hip
-from pyimsegm_amd.descriptors import FEATURES_SET_COLOR, _selected_features_color2d, compute_selected_features_img2d
+from pyimsegm_amd.descriptors import (FEATURES_SET_COLOR, _selected_features_color2d, compute_selected_features_gray3d,
+                                      compute_selected_features_img2d, norm_features)
 from pyimsegm_amd.graph_cuts import estim_class_model, segment_graph_cut_general
-from pyimsegm_amd.superpixels import _open_session, _run_slic
+from pyimsegm_amd.superpixels import _open_session, _open_volume, _run_slic, _run_slic3d
 
 #: select basic features extracted from superpixels
 FTS_SET_SIMPLE = FEATURES_SET_COLOR
@@ -231,6 +232,63 @@ def segment_batch_color2d_slic_features_model_graphcut(list_images, model_pipeli
     return out
 
 
-def pipe_gray3d_slic_features_model_graphcut(*args, **kwargs):
-    """ 3D gray pipeline (reference ``pipelines.py:382-431``): not on the HIP path yet """
-    raise NotImplementedError('the 3D supervoxel pipeline is not implemented by the HIP path yet')
+def pipe_gray3d_slic_features_model_graphcut(
+    image,
+    nb_classes,
+    dict_features,
+    spacing=(12, 1, 1),
+    sp_size=15,
+    sp_regul=0.2,
+    gc_regul=0.1,
+):
+    """ complete pipeline on a gray volume: supervoxels, features, mixture model, GraphCut
+    (reference ``pipelines.py:382-431``)
+
+    The volume is uploaded once; supervoxels, connected-component relabelling, gray statistics, the
+    6-connected adjacency graph, the graph cut and the final ``graph_labels[slic]`` gather run on the
+    device-resident session.
+
+    :param ndarray image: input gray volume D x H x W
+    :param int nb_classes: number of classes to be segmented (indexing from 0)
+    :param dict(list(str)) dict_features: features to be extracted, e.g. ``{'color': ['mean']}``
+    :param tuple(int,int,int) spacing: voxel spacing
+    :param int sp_size: initial size of a supervoxel (edge length)
+    :param float sp_regul: regularisation in (0, 1): 0 elastic, 1 nearly cubic segments
+    :param float gc_regul: GraphCut regularisation
+    :return ndarray: int32 class per voxel, D x H x W
+
+    >>> np.random.seed(0)
+    >>> image = np.random.random((5, 125, 150)) / 2.
+    >>> image[:, :, :75] += 0.5
+    >>> segm = pipe_gray3d_slic_features_model_graphcut(image, 2, {'color': ['mean']})  # doctest: +SKIP
+    >>> segm.shape  # doctest: +SKIP
+    (5, 125, 150)
+    """
+    logging.info('PIPELINE Superpixels-Features-GraphCut')
+    image = np.asarray(image)
+    sess = _open_volume(image)
+    _run_slic3d(sess, sp_size, sp_regul, spacing)
+    logging.info('extract segments/superpixels features.')
+    slic = None
+    resident = set(dict_features) == {'color'} and set(dict_features['color']) <= {'mean', 'std', 'energy'} \
+        and (image.dtype.kind != 'f' or bool(np.isfinite(image).all()))
+    if resident:
+        features, _ = compute_selected_features_gray3d(image, _ShapeOnly(sess.shape), dict_features, sess=sess)
+    else:
+        slic = sess.get_labels()
+        features, _ = compute_selected_features_gray3d(image, slic, dict_features)
+    logging.debug('list of features RAW: %r', features.shape)
+    features[np.isnan(features)] = 0
+
+    logging.info('norm all features.')
+    features, _ = norm_features(features)
+    logging.debug('list of features NORM: %r', features.shape)
+
+    model = estim_class_model(features, nb_classes)
+    proba = model.predict_proba(features)
+    logging.debug('list of probabilities: %r', proba.shape)
+
+    graph_labels = segment_graph_cut_general(_ShapeOnly(sess.shape), proba, image, features, gc_regul, _session=sess)
+    segm, _ = sess.gather(graph_labels)
+    sess.close()
+    return segm

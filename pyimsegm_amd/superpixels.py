@@ -94,12 +94,57 @@ def segment_slic_img2d(img, sp_size=50, relative_compact=0.1, slico=False):
     return labels
 
 
-def segment_slic_img3d_gray(im, sp_size=50, relative_compact=0.1, space=IMAGE_SPACING):
-    """ SLIC supervoxels of a 3D gray volume (reference ``superpixels.py:72-112``)
+def _slic3d_params(shape3d, sp_size, relative_compact, space):
+    """parameter mapping of the reference, superpixels.py:92-97 (float32 spacing, truncated compactness)"""
+    nb_pixels = np.prod(shape3d)
+    sp_vol = np.prod(sp_size / np.asarray(space, dtype=np.float32) * min(space))
+    return int(nb_pixels / sp_vol), int((sp_vol * relative_compact)**1.5)
 
-    Not on the HIP path yet (SURVEY section 8, config 5 is scheduled after the 2D rows).
+
+def _open_volume(im):
+    im = np.asarray(im)
+    if im.ndim != 3:
+        raise ValueError('expected a 3D gray volume, got shape %r' % (im.shape, ))
+    return _hip.Volume3D(*im.shape).upload(im)
+
+
+def _run_slic3d(sess, sp_size, relative_compact, space):
+    n_seg, compact = _slic3d_params(sess.shape, sp_size, relative_compact, space)
+    logging.debug('Starting SLIC superpixels clustering with params NB=%i and compat=%f and spacing=%r', n_seg, compact,
+                  space)
+    if n_seg < 1:
+        raise ValueError('superpixel size %r is larger than the volume %r' % (sp_size, sess.shape))
+    if compact < 1:
+        raise ZeroDivisionError('SLIC compactness truncates to 0 (sp_size=%r, relative_compact=%r)'
+                                % (sp_size, relative_compact))
+    sess.slic(n_seg, compact, sigma=1., spacing=space, max_iter=SLIC_MAX_ITER, enforce_connectivity=True,
+              start_label=SLIC_START_LABEL)
+    # fix of unconnected segments, superpixels.py:111 (skimage.measure.label)
+    return sess.label_cc()
+
+
+def segment_slic_img3d_gray(im, sp_size=50, relative_compact=0.1, space=IMAGE_SPACING):
+    """ SLIC supervoxels of a 3D gray volume followed by connected-component relabelling
+
+    :param ndarray im: input 3D gray-scale image
+    :param int sp_size: initial supervoxel size
+    :param float relative_compact: regularisation in (0, 1)
+    :param tuple(int,int,int) space: voxel spacing per axis
+    :return ndarray: int64 label map of the volume's shape (labels from 1, as ``measure.label`` gives)
+
+    >>> np.random.seed(0)
+    >>> img = np.random.random((100, 100, 10))
+    >>> slic = segment_slic_img3d_gray(img, 20, 0.2, (1, 1, 5))  # doctest: +SKIP
+    >>> slic.shape  # doctest: +SKIP
+    (100, 100, 10)
     """
-    raise NotImplementedError('3D supervoxels are not implemented by the HIP path yet')
+    logging.debug('Init SLIC superpixels 3d Gray clustering with params size=%i and regul=%f for image dims %r',
+                  sp_size, relative_compact, np.shape(im))
+    sess = _open_volume(im)
+    _run_slic3d(sess, sp_size, relative_compact, space)
+    labels = sess.get_labels()
+    sess.close()
+    return labels
 
 
 def make_graph_segment_connect_edges(vertices, all_edges):
@@ -136,10 +181,12 @@ def get_segment_diffs_3d_conn6(grid):
 
 def _session_for_labels(grid):
     grid = np.asarray(grid)
-    if grid.ndim != 2:
-        raise ValueError('2D label map expected')
+    if grid.ndim not in (2, 3):
+        raise ValueError('2D or 3D label map expected')
     if grid.size and grid.min() < 0:
         raise ValueError('labels must be non-negative')
+    if grid.ndim == 3:
+        return _hip.Volume3D(*grid.shape).set_labels(grid)
     return _hip.Image2D(grid.shape[0], grid.shape[1]).set_labels(grid)
 
 
@@ -168,13 +215,25 @@ def make_graph_segm_connect_grid2d_conn4(grid):
 
 
 def make_graph_segm_connect_grid3d_conn6(grid):
-    """ region adjacency graph (6-connectivity) of a 3D label map -- host numpy formulation
-    (the 3D rows of SURVEY section 8 are not on the HIP path yet) """
+    """ region adjacency graph (6-connectivity) of a 3D label map
+
+    :param ndarray grid: segmentation
+    :return tuple(ndarray,list): unique labels, list of edges ``[a, b]`` with a < b ordered by (b, a)
+
+    >>> grid_2d = np.array([[0] * 5 + [1] * 5, [2] * 5 + [3] * 5])
+    >>> grid = np.array([grid_2d, grid_2d + 4])
+    >>> v, edges = make_graph_segm_connect_grid3d_conn6(grid)  # doctest: +SKIP
+    >>> edges  # doctest: +SKIP
+    [[0, 1], [0, 2], [1, 3], [2, 3], [0, 4], [1, 5], [4, 5], [2, 6], [4, 6], [3, 7], [5, 7], [6, 7]]
+    """
     logging.debug('make graph segment connect edges - 3d conn6')
     grid = np.asarray(grid)
-    vertices, dense = np.unique(grid, return_inverse=True)
-    dense = dense.reshape(grid.shape)
-    return make_graph_segment_connect_edges(vertices, get_segment_diffs_3d_conn6(dense))
+    if grid.ndim != 3:
+        raise ValueError('3D label map expected')
+    sess = _session_for_labels(grid)
+    vertices, edges, _, _ = _graph_from_session(sess)
+    sess.close()
+    return vertices, edges.tolist()
 
 
 def superpixel_centers(segments):
@@ -195,17 +254,10 @@ def superpixel_centers(segments):
         sess.close()
         return [tuple(c.tolist()) if ok else [-1] * 2 for c, ok in zip(centres, present)]
     if segments.ndim == 3:
-        nb = int(segments.max()) + 1
-        counts = np.bincount(segments.ravel(), minlength=nb)
-        grids = np.indices(segments.shape)
-        out = []
-        for lb in range(nb):
-            if counts[lb] == 0:
-                out.append([-1] * 3)
-            else:
-                out.append([float(np.bincount(segments.ravel(), weights=g.ravel(), minlength=nb)[lb] / counts[lb])
-                            for g in grids])
-        return out
+        sess = _session_for_labels(segments)
+        _, _, centres, present = _graph_from_session(sess)
+        sess.close()
+        return [c.tolist() if ok else [-1] * 3 for c, ok in zip(centres, present)]
     logging.error('not supported image dim: %r', segments.shape)
     return [[-1] * segments.ndim for _ in range(int(segments.max()) + 1)]
 

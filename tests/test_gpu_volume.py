@@ -1,0 +1,194 @@
+"""GPU parity tests of the gray-volume (supervoxel) rows of the hot path: SLIC with anisotropic
+spacing, connected-component relabelling, gray statistics, 6-connected adjacency and centres, and
+the whole 3D pipeline -- HIP path (through the C ABI) against the CPU oracle, bit-exact labels /
+edges, floats within 1e-9, plus the reference's own doctest vectors for these functions."""
+import numpy as np
+import pytest
+
+from pyimsegm_amd.utilities.synthetic import ellipsoid_volume
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def hip():
+    from pyimsegm_amd import _hip
+    _hip.default_context()
+    return _hip
+
+
+def _noisy_ellipsoid(shape, seed=0, dtype=np.float64):
+    rng = np.random.default_rng(seed)
+    vol = ellipsoid_volume(shape).astype(np.float64)
+    vol = 0.25 + 0.5 * vol + 0.1 * rng.standard_normal(shape)
+    if dtype == np.uint8:
+        return np.clip(vol * 255, 0, 255).astype(np.uint8)
+    if dtype == np.uint16:
+        return np.clip(vol * 40000, 0, 65535).astype(np.uint16)
+    return vol.astype(dtype)
+
+
+VOLUMES = [
+    ('iso_f64', (24, 40, 48), np.float64, 7, 0.2, (1, 1, 1)),
+    ('aniso_z_f64', (9, 64, 70), np.float64, 12, 0.2, (5, 1, 1)),
+    ('aniso_x_u8', (50, 60, 11), np.uint8, 10, 0.3, (1, 1, 5)),
+    ('ragged_u16', (7, 33, 129), np.uint16, 9, 0.25, (3, 1, 1)),
+    ('one_slice', (1, 50, 60), np.float64, 8, 0.2, (1, 1, 1)),
+]
+
+
+@pytest.mark.parametrize('name,shape,dtype,sp,regul,space', VOLUMES, ids=[v[0] for v in VOLUMES])
+def test_volume_slic_bit_exact(hip, oracle, name, shape, dtype, sp, regul, space):
+    from pyimsegm_amd.superpixels import _slic3d_params
+    vol = _noisy_ellipsoid(shape, dtype=dtype)
+    n_seg, compact = _slic3d_params(shape, sp, regul, space)
+    ref_raw = oracle.slic(vol, n_seg, compact, sigma=1, spacing=space, multichannel=False)
+    sess = hip.Volume3D(*shape).upload(vol)
+    sess.slic(n_seg, compact, sigma=1., spacing=space)
+    raw = sess.get_labels()
+    assert raw.shape == shape
+    assert np.array_equal(raw, ref_raw), 'SLIC + connectivity differ in %d voxels' % np.count_nonzero(raw != ref_raw)
+    k = sess.label_cc()
+    ref = oracle.label_cc(ref_raw)
+    got = sess.get_labels()
+    assert np.array_equal(got, ref)
+    assert k == ref.max() + 1
+    sess.close()
+
+
+def test_volume_slic_without_connectivity(hip, oracle):
+    vol = _noisy_ellipsoid((12, 40, 44), seed=4)
+    ref = oracle.slic(vol, 150, 3, sigma=1, spacing=(2, 1, 1), multichannel=False, enforce_connectivity=False)
+    sess = hip.Volume3D(*vol.shape).upload(vol)
+    sess.slic(150, 3, sigma=1., spacing=(2, 1, 1), enforce_connectivity=False)
+    assert np.array_equal(sess.get_labels(), ref)
+    sess.close()
+
+
+def test_segment_slic_img3d_gray_api(oracle):
+    from pyimsegm_amd import superpixels as sp
+    np.random.seed(0)
+    img = np.random.random((100, 100, 10))           # the reference's doctest call, superpixels.py:82-86
+    slic = sp.segment_slic_img3d_gray(img, 20, 0.2, (1, 1, 5))
+    assert slic.shape == (100, 100, 10) and slic.dtype == np.int64
+    assert np.array_equal(slic, oracle.segment_slic_img3d_gray(img, 20, 0.2, (1, 1, 5)))
+    assert slic.min() >= 1                            # measure.label numbers from 1 (no zero-valued segment 0...)
+
+
+def test_label_cc_background_and_diagonals(hip, oracle):
+    rng = np.random.default_rng(2)
+    lab = rng.integers(0, 3, (9, 17, 70))
+    sess = hip.Volume3D(*lab.shape).set_labels(lab)
+    k = sess.label_cc()
+    ref = oracle.label_cc(lab)
+    assert np.array_equal(sess.get_labels(), ref)
+    assert k == ref.max() + 1
+    assert np.all((ref == 0) == (lab == 0))
+    sess.close()
+
+
+def test_gray_statistics(hip, oracle):
+    from pyimsegm_amd import descriptors as d
+    for dtype in (np.float64, np.uint8):
+        vol = _noisy_ellipsoid((10, 37, 66), seed=1, dtype=dtype)
+        seg = oracle.segment_slic_img3d_gray(vol, 9, 0.2, (2, 1, 1))
+        mean = d.cython_img3d_gray_mean(vol, seg)
+        energy = d.cython_img3d_gray_energy(vol, seg)
+        std = d.cython_img3d_gray_std(vol, seg)
+        v32 = np.array(vol, dtype=np.float32)
+        s32 = np.array(seg, dtype=np.int32)
+        ref_mean = oracle.gray3d_stat(v32, s32, 'mean')
+        ref_energy = oracle.gray3d_stat(v32, s32, 'energy')
+        ref_var = oracle.gray3d_stat(v32, s32, 'var', np.array(ref_mean, dtype=np.float32))
+        np.testing.assert_allclose(mean, ref_mean, rtol=1e-12, atol=1e-12)
+        np.testing.assert_allclose(energy, ref_energy, rtol=1e-12, atol=1e-12)
+        np.testing.assert_allclose(std, np.sqrt(ref_var), rtol=1e-9, atol=1e-9)
+        ref = oracle.ref_features_cython()
+        if ref is not None:                            # the reference's own compiled Cython, when built
+            np.testing.assert_allclose(mean, np.asarray(ref.computeGrayImage3dMean(v32, s32)), rtol=1e-5, atol=1e-5)
+            np.testing.assert_allclose(energy, np.asarray(ref.computeGrayImage3dEnergy(v32, s32)), rtol=1e-5,
+                                       atol=1e-5)
+
+
+def test_reference_doctest_vectors_gray3d():
+    """descriptors.py:471-478, 502-508, 532-538, 715-740 of the reference"""
+    from pyimsegm_amd import descriptors as d
+    image = np.zeros((2, 3, 8))
+    image[0, :, 2:6] = 1
+    image[1, :, 3:7] = 3
+    segm = np.array([[[0, 0, 0, 0, 1, 1, 1, 1]] * 3, [[2, 2, 2, 2, 3, 3, 3, 3]] * 3])
+    assert d.cython_img3d_gray_mean(image, segm).tolist() == [0.5, 0.5, 0.75, 2.25]
+    assert d.cython_img3d_gray_energy(image, segm).tolist() == [0.5, 0.5, 2.25, 6.75]
+    np.testing.assert_allclose(d.cython_img3d_gray_std(image, segm), [0.5, 0.5, 1.29903811, 1.29903811], atol=1e-8)
+    segm5 = np.array([[[0, 0, 0, 0, 1, 1, 1, 1]] * 3, [[2, 2, 2, 2, 5, 5, 5, 5]] * 3])
+    features, names = d.compute_image3d_gray_statistic(image, segm5)
+    assert names == ['gray_mean', 'gray_std', 'gray_energy', 'gray_median', 'gray_meanGrad']
+    expect = [[0.5, 0.5, 0.5, 0.5, 0.25], [0.5, 0.5, 0.5, 0.5, -0.25], [0.75, 1.299, 2.25, 0., 0.75],
+              [0., 0., 0., 0., 0.], [0., 0., 0., 0., 0.], [2.25, 1.299, 6.75, 3., -1.125]]
+    np.testing.assert_allclose(np.round(features, 3), expect, atol=1e-12)
+    np.random.seed(0)
+    img = np.random.random((2, 10, 15))
+    slic = np.zeros((2, 10, 15), dtype=int)
+    slic[:, :, :7] += 1
+    slic[1, :, :] += 2
+    fts, names = d.compute_selected_features_gray3d(img, slic, {'color': ('mean', 'std', 'median')})
+    assert fts.shape == (4, 3) and names == ['gray_mean', 'gray_std', 'gray_median']
+    np.testing.assert_allclose(fts[:, 0], [img[slic == i].astype(np.float32).mean(dtype=np.float64) for i in range(4)],
+                               atol=1e-7)
+
+
+def test_reference_doctest_vectors_graph3d():
+    """superpixels.py:185-192 and :214-215 of the reference"""
+    from pyimsegm_amd import superpixels as sp
+    grid_2d = np.array([[0] * 5 + [1] * 5, [2] * 5 + [3] * 5])
+    grid = np.array([grid_2d, grid_2d + 4])
+    v, edges = sp.make_graph_segm_connect_grid3d_conn6(grid)
+    assert v.tolist() == [0, 1, 2, 3, 4, 5, 6, 7]
+    assert edges == [[0, 1], [0, 2], [1, 3], [2, 3], [0, 4], [1, 5], [4, 5], [2, 6], [4, 6], [3, 7], [5, 7], [6, 7]]
+    segm = np.array([[0] * 6 + [1] * 5, [0] * 6 + [2] * 5])
+    assert sp.superpixel_centers(np.array([segm, segm, segm])) == [[1.0, 0.5, 2.5], [1.0, 0.0, 8.0], [1.0, 1.0, 8.0]]
+
+
+def test_volume_graph_vs_oracle(hip, oracle):
+    vol = _noisy_ellipsoid((14, 45, 52), seed=5)
+    seg = oracle.segment_slic_img3d_gray(vol, 8, 0.2, (3, 1, 1))
+    sess = hip.Volume3D(*seg.shape).set_labels(seg)
+    edges, centres, present = sess.graph()
+    ref_v, ref_e = oracle.adjacency(seg)
+    assert np.flatnonzero(present).tolist() == ref_v.tolist()
+    assert edges.tolist() == ref_e
+    ref_c = oracle.centers(seg)
+    assert np.array_equal(centres[present], ref_c[present])       # exact integer sums / counts on both sides
+    assert np.all(centres[~present] == -1)                        # label 0 is unused after measure.label
+    sess.close()
+
+
+def test_pipe_gray3d(oracle):
+    """reference doctest pipelines.py:402-407 + stage-by-stage equality with the oracle"""
+    from pyimsegm_amd import pipelines, descriptors as d, graph_cuts as gc
+    np.random.seed(0)
+    image = np.random.random((5, 125, 150)) / 2.
+    image[:, :, :75] += 0.5
+    np.random.seed(0)
+    segm = pipelines.pipe_gray3d_slic_features_model_graphcut(image, 2, {'color': ['mean']})
+    assert segm.shape == (5, 125, 150)
+    # the same pipeline with every native stage taken from the oracle and the identical host glue
+    slic = oracle.segment_slic_img3d_gray(image, 15, 0.2, (12, 1, 1))
+    mean = oracle.gray3d_stat(np.array(image, dtype=np.float32), slic.astype(np.int32), 'mean')
+    features = np.nan_to_num(mean[:, np.newaxis])
+    features, _ = d.norm_features(features)
+    np.random.seed(0)
+    model = gc.estim_class_model(features, 2)
+    proba = model.predict_proba(features)
+    _, edges = oracle.adjacency(slic)
+    edges = np.array(edges, dtype=np.int32)
+    weights = gc.compute_edge_model(edges, proba, 'lT')
+    weights = weights / gc.compute_spatial_dist(oracle.centers(slic), edges, relative=True)
+    weights = np.clip(weights, 1e-3, 1e3)
+    labels = oracle.cut_general_graph(edges, weights, gc.compute_unary_cost(proba),
+                                      gc.compute_pairwise_cost(0.1, proba.shape), n_iter=-1)
+    assert np.array_equal(segm, np.asarray(labels)[slic])
+    # the two halves of the volume end up in different classes
+    left, right = segm[:, :, :60], segm[:, :, 90:]
+    assert np.mean(left == np.bincount(left.ravel()).argmax()) > 0.95
+    assert np.bincount(left.ravel()).argmax() != np.bincount(right.ravel()).argmax()
