@@ -72,7 +72,8 @@ def test_segment_slic_img3d_gray_api(oracle):
     slic = sp.segment_slic_img3d_gray(img, 20, 0.2, (1, 1, 5))
     assert slic.shape == (100, 100, 10) and slic.dtype == np.int64
     assert np.array_equal(slic, oracle.segment_slic_img3d_gray(img, 20, 0.2, (1, 1, 5)))
-    assert slic.min() >= 1                            # measure.label numbers from 1 (no zero-valued segment 0...)
+    # SLIC segment 0 is background to measure.label and keeps the value 0; components count from 1
+    assert slic.min() == 0 and len(np.unique(slic)) == slic.max() + 1
 
 
 def test_label_cc_background_and_diagonals(hip, oracle):
@@ -159,7 +160,7 @@ def test_volume_graph_vs_oracle(hip, oracle):
     assert edges.tolist() == ref_e
     ref_c = oracle.centers(seg)
     assert np.array_equal(centres[present], ref_c[present])       # exact integer sums / counts on both sides
-    assert np.all(centres[~present] == -1)                        # label 0 is unused after measure.label
+    assert np.all(centres[~present] == -1)
     sess.close()
 
 

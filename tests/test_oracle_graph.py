@@ -55,3 +55,39 @@ def test_graph_against_numpy_restatement(oracle):
     v, edges = oracle.adjacency(grid)
     assert v.tolist() == vertices.tolist()
     assert edges == [[int(a), int(b)] for a, b in expect]
+
+
+def test_label_cc_matches_scipy(oracle):
+    """oracle restatement of skimage.measure.label (superpixels.py:111) against scipy.ndimage.label run
+    per value with the full 26-neighbourhood, renumbered by first occurrence in raster order"""
+    from scipy import ndimage as ndi
+    rng = np.random.default_rng(0)
+    for shape in [(6, 9, 11), (1, 20, 30), (4, 4, 4)]:
+        lab = rng.integers(0, 4, shape)
+        out = oracle.label_cc(lab)
+        comp = np.zeros(shape, dtype=np.int64)
+        off = 0
+        for v in np.unique(lab):
+            if v == 0:
+                continue
+            cc, n = ndi.label(lab == v, ndi.generate_binary_structure(3, 3))
+            comp[cc > 0] = cc[cc > 0] + off
+            off += n
+        first = {}
+        for c in comp.ravel():
+            if c and c not in first:
+                first[c] = len(first) + 1
+        ref = np.vectorize(lambda c: first.get(c, 0))(comp)
+        assert np.array_equal(out, ref)
+        assert np.all((out == 0) == (lab == 0))
+
+
+def test_oracle_slic3d_properties(oracle):
+    """no skimage here to pin the 3D label map: check the structural guarantees of the restatement"""
+    rng = np.random.default_rng(1)
+    vol = rng.random((8, 40, 44))
+    seg = oracle.segment_slic_img3d_gray(vol, 9, 0.2, (3, 1, 1))
+    assert seg.shape == vol.shape and seg.min() == 0
+    assert len(np.unique(seg)) == seg.max() + 1
+    # measure.label output is a fixed point of measure.label
+    assert np.array_equal(oracle.label_cc(seg), seg)
