@@ -409,7 +409,8 @@ int imsegm_image2d_slic(imsegm_image2d *im, int minmax_normalize, int n_segments
     size_t cent_bytes = (size_t)K * (5 * 8 + 16 + 9 * 8 + 16) + 256;
     if (im->cent.ensure(cent_bytes)) return -1;
     const size_t n_tiles = (size_t)cdiv(W, SLIC_TILE_X) * cdiv(H, SLIC_TILE_Y);
-    if (im->tiles.ensure(n_tiles * (SLIC_MAXC * sizeof(Cand) + sizeof(int)) + n * 4 + 512)) return -1;
+    if (im->tiles.ensure(n_tiles * (SLIC_MAXC * (sizeof(Cand) + sizeof(Rec32) + sizeof(int)) + sizeof(TileInfo) + sizeof(int)) + n * 4 + 1024))
+        return -1;
     if (im->small.ensure(4096)) return -1;
 
     unsigned long long *keys = im->small.as<unsigned long long>();
@@ -429,6 +430,16 @@ int imsegm_image2d_slic(imsegm_image2d *im, int minmax_normalize, int n_segments
     s.step_x = axk[2].all ? 1 : (int)axk[2].step;
     s.spatial_weight = 1.0 / ((double)step * (double)step);
     s.debug = getenv("IMSEGM_DEBUG_ASSIGN") ? atoi(getenv("IMSEGM_DEBUG_ASSIGN")) : 0;
+    s.phase_prof = nullptr;
+    static long long *phase_buf = nullptr;
+    const size_t PHASE_SLOTS = 1 << 16;                    // workgroups of the assignment grid (profiling aid)
+    if (getenv("IMSEGM_PHASE_PROF")) {
+        if (!phase_buf) {
+            HIP_TRY(hipMalloc(&phase_buf, PHASE_SLOTS * 32 * sizeof(long long)));
+            HIP_TRY(hipMemset(phase_buf, 0, PHASE_SLOTS * 32 * sizeof(long long)));
+        }
+        s.phase_prof = phase_buf;
+    }
     {
         // fp32 pre-selection margin (k_slic_assign): valid when the image entering rgb2lab lies in
         // [0, 1] (then |L|, |a|, |b| <= 108 before and after the convex blur), i.e. whenever the
@@ -439,7 +450,7 @@ int imsegm_image2d_slic(imsegm_image2d *im, int minmax_normalize, int n_segments
         const double E = 3.0 * R + 64.0;
         const double G = sqrt(2.0 * s.spatial_weight) * E + sqrt(3.0) * 4.0 * M + 16.0;
         s.kappa = (float)(2.0 * u * (G + 1.0) * 1.0001);
-        s.fast32 = (minmax_normalize != 0 && max_candidates >= 0 && s.kappa < 1e-2f) ? 1 : 0;
+        s.fast32 = (minmax_normalize != 0 && max_candidates >= 0 && s.kappa < 1e-2f && M < 4096.0) ? 1 : 0;
     }
     unsigned char *cb = im->cent.as<unsigned char>();
     s.acc = reinterpret_cast<long long *>(cb); cb += (size_t)K * 9 * 8;
@@ -453,7 +464,13 @@ int imsegm_image2d_slic(imsegm_image2d *im, int minmax_normalize, int n_segments
     s.grid_x0 = (int)ax[2].start; s.grid_dx = (int)ax[2].step; s.grid_nx = (int)nx;
     double *init_dev = nullptr;                            // the grid is generated on the device
     s.tile_cands = im->tiles.as<Cand>();
-    s.tile_count = reinterpret_cast<int *>(im->tiles.as<unsigned char>() + n_tiles * SLIC_MAXC * sizeof(Cand));
+    {
+        unsigned char *tb = im->tiles.as<unsigned char>() + n_tiles * SLIC_MAXC * sizeof(Cand);
+        s.tile_rec = reinterpret_cast<Rec32 *>(tb); tb += n_tiles * SLIC_MAXC * sizeof(Rec32);
+        s.tile_info = reinterpret_cast<TileInfo *>(tb); tb += n_tiles * sizeof(TileInfo);
+        s.tile_k = reinterpret_cast<int *>(tb); tb += n_tiles * SLIC_MAXC * sizeof(int);
+        s.tile_count = reinterpret_cast<int *>(tb);
+    }
     s.leftover_count = s.tile_count + n_tiles + 16;
     s.leftover = s.leftover_count + 16;
 
@@ -466,6 +483,29 @@ int imsegm_image2d_slic(imsegm_image2d *im, int minmax_normalize, int n_segments
     if (launch_slic_iterations(s, im->labA.as<double>(), init_dev, im->nearest.as<int32_t>(), max_iter, max_candidates, hook, st))
         return -1;
 
+    if (s.phase_prof) {
+        std::vector<long long> all((size_t)PHASE_SLOTS * 32);
+        HIP_TRY(hipMemcpy(all.data(), s.phase_prof, all.size() * 8, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemset(s.phase_prof, 0, all.size() * 8));
+        bool any = false;
+        for (size_t i = 15; i < all.size() && !any; i += 16) any = all[i] != 0;
+        if (any && getenv("IMSEGM_PHASE_DUMP")) {
+            FILE *f = fopen(getenv("IMSEGM_PHASE_DUMP"), "wb");
+            if (f) {
+                fwrite(all.data(), 8, all.size(), f);
+                fclose(f);
+            }
+        }
+        long long h[32] = { 0 };
+        for (size_t i = 0; i < all.size(); ++i) h[i % 32] += all[i];
+        for (int v = 0; v < 2; ++v) {
+            const long long *q = h + v * 16;
+            if (!q[15]) continue;
+            fprintf(stderr, "[phase prof %s] waves=%lld  cycles/wave:", v ? "accum" : "last ", q[15]);
+            for (int j = 0; j < 10; ++j) fprintf(stderr, " p%d=%.0f", j, (double)q[j] / (double)q[15]);
+            fprintf(stderr, "\n");
+        }
+    }
     int n_labels = K + start_label;
     if (enforce_connectivity) {
         double segment_size = (double)n / (double)K;

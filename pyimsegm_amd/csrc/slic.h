@@ -26,6 +26,22 @@ struct Cand {
     int pad[2];
 };
 
+// compact fp32 record of the same candidate for the pre-selection loop of k_slic_assign_dot (32 bytes, read
+// with one scalar load).  Coordinates are relative to the centre (row 16, column 32) of the 64 x 32 bin
+// tile, colours relative to the tile's reference colour; the distance of pixel (Y, X, f) is, up to a term
+// that does not depend on the candidate,  q0 + qy*Y + qx*X + qL*fL + qa*fa + qb*fb.
+struct Rec32 {
+    float q0, qx, qy, qL, qa, qb;
+    float lbt;                   // lower bound of the distance over the whole tile (sort key, ascending)
+    uint32_t meta;               // window relative to the tile: rlo | rhi << 8 | xlo << 16 | xhi << 24
+};
+// per-tile header of the record table
+struct TileInfo {
+    double ref[3];               // reference colour (exact) subtracted from pixels and centroids
+    float Qy, Qx, QL, Qa, Qb;    // max |qy|, |qx|, |qL|, |qa|, |qb| over the candidates of the tile
+    int count;                   // same as tile_count
+};
+
 // device-side SLIC state for one 2-D image (all pointers are device pointers)
 struct SlicState {
     int H, W, K;
@@ -36,11 +52,15 @@ struct SlicState {
     long long *acc;                 // [K][9] = n, sum y, sum x, (hi, lo) fixed-point sums of L, a, b
     Cand *tile_cands;               // [n_tiles][SLIC_MAXC] nearest-first candidate centroids per tile
     int *tile_count;                // [n_tiles] list length (negative: more than the list holds)
+    Rec32 *tile_rec;                // [n_tiles][SLIC_MAXC] fp32 records, same slot order as tile_cands
+    TileInfo *tile_info;            // [n_tiles]
+    int *tile_k;                    // [n_tiles][SLIC_MAXC] centroid index per slot (coalesced copy of Cand::k)
     int *leftover;                  // [N] pixels to be accumulated by k_slic_leftover
     int *leftover_count;            // [1]
     int fast32;                     // 1: fp32 pre-selection allowed (Lab bounded by lab_bound)
     float kappa;                    // relative decision margin of the fp32 pass (see k_slic_assign)
     int grid_y0, grid_dy, grid_x0, grid_dx, grid_nx;   // initial centroid grid (skimage regular_grid)
+    long long *phase_prof;          // profiling aid (env IMSEGM_PHASE_PROF): per-phase cycle sums, or null
     int debug;                      // profiling aid (env IMSEGM_DEBUG_ASSIGN): ablation bits, results invalid
 };
 

@@ -8,6 +8,7 @@
 // fully coalesced 512-byte wave loads); labels int32 [H][W]; centroid table SoA (cy, cx, cL, ca,
 // cb as fp64[K], integer search windows int4[K]); accumulators int64 [K][9].
 #include "slic.h"
+#include <cstdio>
 
 namespace imsegm {
 
@@ -333,6 +334,7 @@ k_slic_bin(SlicState s, int tiles_x, int n_tiles, int max_cand, Cand *__restrict
     extern __shared__ int4 lds_win[];                 // [min(K, BIN_MAX_K_LDS)]
     __shared__ int ck[BIN_TILES_PER_BLOCK][MAXC];
     __shared__ float ckey[BIN_TILES_PER_BLOCK][MAXC];
+    __shared__ float clb[BIN_TILES_PER_BLOCK][MAXC];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int klds = min(s.K, BIN_MAX_K_LDS);
@@ -368,27 +370,72 @@ k_slic_bin(SlicState s, int tiles_x, int n_tiles, int max_cand, Cand *__restrict
     // (single wave per tile from here on: LDS writes above are ordered with the reads below)
     __builtin_amdgcn_s_waitcnt(0);
     const bool overflow = count > max_cand;
-    if (lane == 0) tile_count[tile] = overflow ? -count : count;
+    if (lane == 0) {
+        tile_count[tile] = overflow ? -count : count;
+        s.tile_info[tile].count = overflow ? -count : count;
+    }
     if (overflow) return;
-    for (int c = lane; c < count; c += 64) {
-        const float key = ckey[wave][c];
-        int rank = 0;
-        for (int j = 0; j < count; ++j) {
-            float kj = ckey[wave][j];
-            rank += (kj < key) || (kj == key && j < c);
-        }
-        const int k = ck[wave][c];
-        Cand cd;
-        cd.cy = s.cy[k]; cd.cx = s.cx[k]; cd.cL = s.cL[k]; cd.ca = s.ca[k]; cd.cb = s.cb[k];
-        cd.win = s.win[k];
-        cd.k = k;
-        // fp32 copies for the pre-selection pass; positions relative to the tile origin so that
-        // their rounding error is u * O(2 * step) instead of u * O(image size)
-        cd.ry = (float)(cd.cy - (double)ty0);
-        cd.rx = (float)(cd.cx - (double)tx0);
-        cd.fL = (float)cd.cL; cd.fa = (float)cd.ca; cd.fb = (float)cd.cb;
-        cd.pad[0] = cd.pad[1] = 0;
+    // count <= 64: lane c owns candidate c from here on.  Sort key: lower bound of the distance over the
+    // whole tile (ascending -- k_slic_assign_dot stops at the first candidate beyond its bound), ties by
+    // the distance of the window centre to the tile centre.
+    const bool have = lane < count;
+    const int k = have ? ck[wave][lane] : 0;
+    Cand cd;
+    cd.cy = s.cy[k]; cd.cx = s.cx[k]; cd.cL = s.cL[k]; cd.ca = s.ca[k]; cd.cb = s.cb[k];
+    cd.win = s.win[k];
+    cd.k = k;
+    const double sw = s.spatial_weight;
+    // coordinates relative to the tile centre (row 16, column 32): |Y| <= 16, |X| <= 32 for every pixel
+    const double ryc = cd.cy - (double)(ty0 + 16), rxc = cd.cx - (double)(tx0 + 32);
+    double dy = fmax(fmax(-16.0 - ryc, ryc - 15.0), 0.0), dx = fmax(fmax(-32.0 - rxc, rxc - 31.0), 0.0);
+    const float lbt = __double2float_rd((dy * dy + dx * dx) * sw * 0.999999);
+    const float key2 = have ? ckey[wave][lane] : 0.f;
+    if (have) clb[wave][lane] = lbt;
+    __builtin_amdgcn_s_waitcnt(0);
+    __builtin_amdgcn_wave_barrier();
+    int rank = 0;
+    for (int j = 0; j < count; ++j) {
+        const float kj = clb[wave][j], k2j = ckey[wave][j];
+        rank += (kj < lbt) || (kj == lbt && (k2j < key2 || (k2j == key2 && j < lane)));
+    }
+    // reference colour of the tile: the colour of the first candidate (exact)
+    const unsigned long long first = __ballot(have && rank == 0);
+    const int src = first ? __ffsll((long long)first) - 1 : 0;
+    const double ref0 = __shfl(cd.cL, src, 64), ref1 = __shfl(cd.ca, src, 64), ref2 = __shfl(cd.cb, src, 64);
+    const double c0 = cd.cL - ref0, c1 = cd.ca - ref1, c2 = cd.cb - ref2;
+    Rec32 rc;
+    rc.q0 = (float)(sw * (ryc * ryc + rxc * rxc) + (c0 * c0 + c1 * c1 + c2 * c2));
+    rc.qy = (float)(-2.0 * sw * ryc);
+    rc.qx = (float)(-2.0 * sw * rxc);
+    rc.qL = (float)(-2.0 * c0);
+    rc.qa = (float)(-2.0 * c1);
+    rc.qb = (float)(-2.0 * c2);
+    rc.lbt = lbt;
+    {
+        const int rlo = min(max(cd.win.x - ty0, 0), TILE_Y), rhi = min(max(cd.win.y - ty0, 0), TILE_Y);
+        const int xlo = min(max(cd.win.z - tx0, 0), TILE_X), xhi = min(max(cd.win.w - tx0, 0), TILE_X);
+        rc.meta = (uint32_t)rlo | ((uint32_t)rhi << 8) | ((uint32_t)xlo << 16) | ((uint32_t)xhi << 24);
+    }
+    // fp32 copies of the older record layout (exact / first-sweep paths)
+    cd.ry = (float)(cd.cy - (double)ty0);
+    cd.rx = (float)(cd.cx - (double)tx0);
+    cd.fL = (float)cd.cL; cd.fa = (float)cd.ca; cd.fb = (float)cd.cb;
+    cd.pad[0] = cd.pad[1] = 0;
+    if (have) {
         tile_cands[(size_t)tile * MAXC + rank] = cd;
+        s.tile_rec[(size_t)tile * MAXC + rank] = rc;
+        s.tile_k[(size_t)tile * MAXC + rank] = k;
+    }
+    float qm[5] = { have ? fabsf(rc.qy) : 0.f, have ? fabsf(rc.qx) : 0.f, have ? fabsf(rc.qL) : 0.f,
+                    have ? fabsf(rc.qa) : 0.f, have ? fabsf(rc.qb) : 0.f };
+#pragma unroll
+    for (int j = 0; j < 5; ++j)
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) qm[j] = fmaxf(qm[j], __shfl_xor(qm[j], off, 64));
+    if (lane == 0) {
+        TileInfo &ti = s.tile_info[tile];
+        ti.ref[0] = ref0; ti.ref[1] = ref1; ti.ref[2] = ref2;
+        ti.Qy = qm[0]; ti.Qx = qm[1]; ti.QL = qm[2]; ti.Qa = qm[3]; ti.Qb = qm[4];
     }
 }
 
@@ -770,6 +817,380 @@ k_slic_assign(SlicState s, const double *__restrict__ lab, int32_t *__restrict__
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// assignment, second formulation (all sweeps but the first, fast path)
+// ---------------------------------------------------------------------------------------------
+// With Y, X the pixel position relative to the tile centre, f = p - ref its colour relative to the tile's
+// reference colour and (ry, rx, c) the same for a centroid, the _slic.pyx distance is
+//     D = sw*((ry-Y)^2 + (rx-X)^2) + |c - f|^2
+//       = [sw*(ry^2+rx^2) + |c|^2] - 2*sw*ry*Y - 2*sw*rx*X - 2*c.f  +  [sw*(Y^2+X^2) + |f|^2]
+//       =  q0 + qy*Y + qx*X + qL*fL + qa*fa + qb*fb                  +  P(pixel)
+// P does not depend on the candidate, so the arg-min needs only the 5-term dot product d = D - P: one fma
+// per lane and candidate for the X term and four fmas per pixel, issued as packed v_pk_fma_f32 on row
+// pairs.  Coefficients come from k_slic_bin as 32-byte records read with scalar loads.
+//
+// Error bound (u = 2^-24).  Every coefficient and feature is the fp32 rounding of an exact fp64 value and
+// the chain has five fmas, so |d32 - d*| <= 8*u*T with T = |q0| + |qy*Y| + |qx*X| + |qL*fL| + |qa*fa| +
+// |qb*fb|.  With xb >= the sum of the five cross terms (|Y| <= 16, |X| <= 32, tile maxima of |q.|):
+// q0 = d* - cross <= d* + xb, hence T <= d* + 2*xb, and for two candidates a, b of one pixel
+//     |(d32_b - d32_a) - (D_b - D_a)| <= 8*u*(d_a + d_b + 4*xb).
+// The kernel uses margin = 16*u*1.01*(b1 + b2 + 4*xb): a gap above it carries over to exact arithmetic
+// with at least half the margin left, far above the ~1e-15 relative noise of the fp64 evaluation; anything
+// closer sends the row to the exact fp64 loop (exact_row).
+//
+// Candidates are sorted by lbt = lower bound of D over the whole tile.  After PH1 (and again after PH2)
+// candidates the wave forms W >= max over its pixels of (best D + margin); the first candidate with
+// lbt > W ends the loop: it and all later ones can neither win nor come within the margin anywhere in the wave.
+typedef float f2 __attribute__((ext_vector_type(2)));
+
+// sum eight doubles per lane over each 16-lane row: 4 + 2 + 1 transposed exchanges + 1 plain (DPP
+// row_mirror / row_half_mirror / quad_perm; no LDS traffic).  Returns, in every lane, the row total of the
+// value with index ((lane >> 3) & 1) * 4 + ((lane >> 2) & 1) * 2 + ((lane >> 1) & 1).
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double v)
+{
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)b, CTRL, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), CTRL, 0xf, 0xf, false);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+__device__ __forceinline__ double row16_reduce8_f64(const double (&v)[8], int lane)
+{
+    double a[4], b[2];
+    bool up = lane & 8;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const double send = up ? v[j] : v[j + 4], keep = up ? v[j + 4] : v[j];
+        a[j] = keep + dpp_f64<0x140>(send);                 // row_mirror: lane i <-> 15 - i
+    }
+    up = lane & 4;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const double send = up ? a[j] : a[j + 2], keep = up ? a[j + 2] : a[j];
+        b[j] = keep + dpp_f64<0x141>(send);                 // row_half_mirror: i <-> 7 - i
+    }
+    up = lane & 2;
+    const double send = up ? b[0] : b[1], keep = up ? b[1] : b[0];
+    double c = keep + dpp_f64<0x1b>(send);                  // quad_perm [3,2,1,0]: i <-> 3 - i
+    c += dpp_f64<0xb1>(c);                                  // quad_perm [1,0,3,2]: i <-> i ^ 1
+    return c;
+}
+
+// (profiling aid) cycles between successive marks of every wave, summed per phase
+#define PHASE_MARK(j)                                                                              \
+    if (s.phase_prof) {                                                                            \
+        __builtin_amdgcn_s_waitcnt(0);                                                             \
+        const long long now_ = (long long)__builtin_readcyclecounter();                            \
+        if (tid == 0) prof_slot[j] += now_ - t_prev;                                               \
+        t_prev = now_;                                                                             \
+    }
+#define PHASE_FLUSH()                                                                              \
+    if (s.phase_prof && tid == 0) {                                                                \
+        prof_slot[15] += 1;                                                                        \
+        prof_slot[11] = (long long)wall_clock64();                                                 \
+    }
+
+// FIRST: first sweep.  All centroids sit on the regular grid (y0 + iy*dy, x0 + ix*dx) with colour 0, the
+// distance is fl(fl(n*sw) + |p|^2) with n = dy^2 + dx^2 an integer, strictly increasing in n (sw >> ulp):
+// the winner is the nearest grid node per axis, ties to the lower index (= lowest centroid index, what
+// the strict '<' of _slic.pyx keeps).  The launcher only selects this variant when every pixel lies inside
+// the search window of its nearest node.
+template <bool ACCUM, bool FIRST>
+__global__ void __launch_bounds__(256)
+k_slic_assign_dot(SlicState s, const double *__restrict__ lab, int32_t *__restrict__ labels)
+{
+    __shared__ long long lacc[MAXC][9];
+    __shared__ int lk[MAXC];
+    long long t_prev = s.phase_prof ? (long long)__builtin_readcyclecounter() : 0;
+    long long *prof_slot = s.phase_prof + ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 2 + (ACCUM ? 1 : 0)) * 16;
+    if (s.phase_prof && threadIdx.x == 0) {
+        prof_slot[10] = (long long)wall_clock64();                     // start, 100 MHz (overwritten by every launch)
+        prof_slot[12] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));    // HW_ID
+        prof_slot[13] = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11));   // XCC_ID
+    }
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tile = (blockIdx.y >> 1) * gridDim.x + blockIdx.x;       // 64 x 32 bin tile
+    const int tx0 = blockIdx.x * TILE_X;
+    const int wy0 = blockIdx.y * WG_Y + wave * ROWS;                    // first row of this wave
+    const int rel0 = (blockIdx.y & 1) * WG_Y + wave * ROWS;             // ... relative to the bin tile
+    const size_t plane = (size_t)s.H * s.W;
+    const Cand *__restrict__ cand = s.tile_cands + (size_t)tile * MAXC;
+    const Rec32 *__restrict__ rec = s.tile_rec + (size_t)tile * MAXC;
+    const TileInfo *__restrict__ ti = s.tile_info + tile;
+
+    const int x = tx0 + lane;
+    const bool xin = x < s.W;
+    const double sw = s.spatial_weight;
+
+    double pL[ROWS], pA[ROWS], pB[ROWS];
+    int best_s[ROWS];      // slot in the candidate list; -1: nothing covers the pixel; <= -2: centroid -(k+2)
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r) {
+        const int y = wy0 + r;
+        const bool ok = xin && y < s.H;
+        const size_t p = (size_t)(ok ? y : 0) * s.W + (ok ? x : 0);
+        pL[r] = lab[p];
+        pA[r] = lab[plane + p];
+        pB[r] = lab[2 * plane + p];
+        best_s[r] = -1;
+    }
+    const int my_k = s.tile_k[(size_t)tile * MAXC + lane];
+    // candidate table in registers: lane c holds the record of candidate c; the loop fetches the fields
+    // with v_readlane, i.e. without any memory latency between two candidates
+    const float4 my_ra = reinterpret_cast<const float4 *>(rec + lane)[0];      // q0, qx, qy, qL
+    const float4 my_rb = reinterpret_cast<const float4 *>(rec + lane)[1];      // qa, qb, lbt, meta
+    const int total = ti->count;
+    const bool overflow = total < 0;             // block-uniform
+    const int nc = overflow ? 0 : total;
+    PHASE_MARK(0)                                  // all loads have landed
+    if (ACCUM) {
+        for (int i = tid; i < nc * 9; i += 256) (&lacc[0][0])[i] = 0;
+        if (tid < MAXC) lk[tid] = my_k;
+        __syncthreads();
+    }
+    PHASE_MARK(1)                                  // LDS clear + barrier
+
+    if (overflow) {
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r) best_s[r] = exact_row_global(s, wy0 + r, x, pL[r], pA[r], pB[r]);
+    } else if (FIRST) {
+        const int ny = s.K / s.grid_nx;
+        auto nearest = [](int t, int d, int n) {             // node index nearest to offset t, ties -> lower
+            int i = t <= 0 ? 0 : t / d;
+            const int rem = t - i * d;
+            if (t > 0 && 2 * rem > d) ++i;
+            return min(i, n - 1);
+        };
+        const int ix = nearest(x - s.grid_x0, s.grid_dx, s.grid_nx);
+        int want[ROWS];
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r) want[r] = nearest(wy0 + r - s.grid_y0, s.grid_dy, ny) * s.grid_nx + ix;
+        // centroid index -> slot of the tile list, one distinct index at a time
+        unsigned todo = (1u << ROWS) - 1;
+        while (true) {
+            int mine = -1;
+#pragma unroll
+            for (int r = ROWS - 1; r >= 0; --r)
+                if (todo & (1u << r)) mine = want[r];
+            const unsigned long long vote = __ballot(mine >= 0);
+            if (vote == 0) break;
+            const int kt = __builtin_amdgcn_readlane(mine, __ffsll((long long)vote) - 1);
+            const unsigned long long hit = __ballot(my_k == kt && lane < nc);
+            const int slot = hit ? __ffsll((long long)hit) - 1 : -(kt + 2);
+#pragma unroll
+            for (int r = 0; r < ROWS; ++r)
+                if ((todo & (1u << r)) && want[r] == kt) {
+                    best_s[r] = slot;
+                    todo &= ~(1u << r);
+                }
+        }
+    } else if (nc > 0) {
+        constexpr int PH1 = 4, PH2 = 8;
+        const float INF = __builtin_inff();
+        const float sw32 = (float)sw;
+        const double ref0 = ti->ref[0], ref1 = ti->ref[1], ref2 = ti->ref[2];
+        f2 fL[2], fA[2], fB[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            fL[h] = (f2){ (float)(pL[2 * h] - ref0), (float)(pL[2 * h + 1] - ref0) };
+            fA[h] = (f2){ (float)(pA[2 * h] - ref1), (float)(pA[2 * h + 1] - ref1) };
+            fB[h] = (f2){ (float)(pB[2 * h] - ref2), (float)(pB[2 * h + 1] - ref2) };
+        }
+        const float X = (float)(lane - TILE_X / 2);
+        const float Y0 = (float)(rel0 - TILE_Y / 2);
+        const f2 Yp[2] = { (f2){ Y0, Y0 + 1.f }, (f2){ Y0 + 2.f, Y0 + 3.f } };
+        // bound of the cross terms of this pixel over all candidates of the tile
+        float xb[ROWS];
+        {
+            const float base = 16.f * ti->Qy + 32.f * ti->Qx, QL = ti->QL, Qa = ti->Qa, Qb = ti->Qb;
+#pragma unroll
+            for (int r = 0; r < ROWS; ++r) {
+                const float l = r & 1 ? fL[r >> 1].y : fL[r >> 1].x, a = r & 1 ? fA[r >> 1].y : fA[r >> 1].x,
+                            b = r & 1 ? fB[r >> 1].y : fB[r >> 1].x;
+                xb[r] = fmaf(QL, fabsf(l), fmaf(Qa, fabsf(a), fmaf(Qb, fabsf(b), base)));
+            }
+        }
+        float b1[ROWS], b2[ROWS];
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r) b1[r] = b2[r] = INF;
+        const int rows_valid = min(ROWS, s.H - wy0), lanes_valid = min(TILE_X, s.W - tx0);
+        unsigned wbound = 0x7f800000u;           // float bits of the break threshold (uniform)
+        int c_end = nc;
+#define RL_F(v) __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), c))
+        for (int c = 0; c < nc; ++c) {
+            if (c == PH1 || c == PH2) {
+                float wl = 0.f;
+#pragma unroll
+                for (int r = 0; r < ROWS; ++r) {
+                    const float l = r & 1 ? fL[r >> 1].y : fL[r >> 1].x, a = r & 1 ? fA[r >> 1].y : fA[r >> 1].x,
+                                b = r & 1 ? fB[r >> 1].y : fB[r >> 1].x;
+                    const float Yr = Y0 + (float)r;
+                    const float P = fmaf(sw32, fmaf(Yr, Yr, X * X), fmaf(l, l, fmaf(a, a, b * b)));
+                    const float v = fmaf(fmaxf(b1[r] + P, 0.f), 1.002f, 0.002f * (xb[r] + 1.f));
+                    if (xin && r < rows_valid) wl = fmaxf(wl, v);
+                }
+                int wi = __float_as_int(wl);                  // wl >= 0: integer order == float order
+                wi = max(wi, __builtin_amdgcn_update_dpp(0, wi, 0x111, 0xf, 0xf, false));
+                wi = max(wi, __builtin_amdgcn_update_dpp(0, wi, 0x112, 0xf, 0xf, false));
+                wi = max(wi, __builtin_amdgcn_update_dpp(0, wi, 0x114, 0xf, 0xf, false));
+                wi = max(wi, __builtin_amdgcn_update_dpp(0, wi, 0x118, 0xf, 0xf, false));
+                wi = max(wi, __builtin_amdgcn_update_dpp(0, wi, 0x142, 0xa, 0xf, false));
+                wi = max(wi, __builtin_amdgcn_update_dpp(0, wi, 0x143, 0xc, 0xf, false));
+                wbound = (unsigned)__builtin_amdgcn_readlane(wi, 63);
+            }
+            if ((unsigned)__builtin_amdgcn_readlane(__float_as_int(my_rb.z), c) > wbound) {
+                c_end = c;
+                break;
+            }
+            const unsigned meta = (unsigned)__builtin_amdgcn_readlane(__float_as_int(my_rb.w), c);
+            const int rlo = meta & 0xff, rhi = (meta >> 8) & 0xff, xlo = (meta >> 16) & 0xff, xhi = meta >> 24;
+            if (rhi > rel0 && rlo < rel0 + ROWS) {
+                Rec32 cur;
+                cur.q0 = RL_F(my_ra.x); cur.qx = RL_F(my_ra.y); cur.qy = RL_F(my_ra.z); cur.qL = RL_F(my_ra.w);
+                cur.qa = RL_F(my_rb.x); cur.qb = RL_F(my_rb.y);
+                const float e = fmaf(cur.qx, X, cur.q0);
+#define SLIC_SELECT(r, dval)                                                                       \
+    {                                                                                              \
+        const float d_ = (dval);                                                                   \
+        const bool lt_ = d_ < b1[r];                                                               \
+        b2[r] = __builtin_amdgcn_fmed3f(b1[r], b2[r], d_);                                         \
+        b1[r] = lt_ ? d_ : b1[r];                                                                  \
+        best_s[r] = lt_ ? c : best_s[r];                                                           \
+    }
+                if (rlo <= rel0 && rhi >= rel0 + rows_valid && xlo == 0 && xhi >= lanes_valid) {
+                    // the window covers every pixel of this wave (the common case): packed, branch free
+                    const f2 e2 = (f2){ e, e };
+                    f2 d01 = __builtin_elementwise_fma((f2){ cur.qy, cur.qy }, Yp[0], e2);
+                    f2 d23 = __builtin_elementwise_fma((f2){ cur.qy, cur.qy }, Yp[1], e2);
+                    d01 = __builtin_elementwise_fma((f2){ cur.qL, cur.qL }, fL[0], d01);
+                    d23 = __builtin_elementwise_fma((f2){ cur.qL, cur.qL }, fL[1], d23);
+                    d01 = __builtin_elementwise_fma((f2){ cur.qa, cur.qa }, fA[0], d01);
+                    d23 = __builtin_elementwise_fma((f2){ cur.qa, cur.qa }, fA[1], d23);
+                    d01 = __builtin_elementwise_fma((f2){ cur.qb, cur.qb }, fB[0], d01);
+                    d23 = __builtin_elementwise_fma((f2){ cur.qb, cur.qb }, fB[1], d23);
+                    SLIC_SELECT(0, d01.x) SLIC_SELECT(1, d01.y) SLIC_SELECT(2, d23.x) SLIC_SELECT(3, d23.y)
+                } else {
+                    const bool inx = lane >= xlo && lane < xhi;
+#pragma unroll
+                    for (int r = 0; r < ROWS; ++r) {
+                        if (rel0 + r < rlo || rel0 + r >= rhi) continue;        // wave-uniform
+                        const float l = r & 1 ? fL[r >> 1].y : fL[r >> 1].x, a = r & 1 ? fA[r >> 1].y : fA[r >> 1].x,
+                                    b = r & 1 ? fB[r >> 1].y : fB[r >> 1].x;
+                        float d = fmaf(cur.qy, Y0 + (float)r, e);
+                        d = fmaf(cur.qL, l, d);
+                        d = fmaf(cur.qa, a, d);
+                        d = fmaf(cur.qb, b, d);
+                        d = inx ? d : INF;
+                        SLIC_SELECT(r, d)
+                    }
+                }
+#undef SLIC_SELECT
+            }
+        }
+#undef RL_F
+        PHASE_MARK(2)                              // candidate loop
+        if (s.phase_prof && tid == 0) prof_slot[9] += c_end;
+        // near ties (second best inside the margin for some pixel of the row): exact fp64 loop over the
+        // candidates that were looked at
+        const float U16 = 16.f * 5.9604644775390625e-8f * 1.01f;
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r) {
+            const float m = U16 * (b1[r] + b2[r] + 4.f * xb[r]) + 1e-30f;
+            const bool near2 = best_s[r] >= 0 && b2[r] < INF && !(b2[r] - b1[r] > m);
+            if (!__any(near2)) continue;
+            const int e = exact_row(cand, c_end, wy0 + r, x, sw, pL[r], pA[r], pB[r]);
+            if (near2) best_s[r] = e;
+        }
+        PHASE_MARK(3)                              // near-tie resolution
+    }
+
+    // labels: a pixel no window covers keeps its previous assignment (nearest_segments persists in
+    // _slic.pyx).  Such pixels, and the pixels of tiles without a candidate list, are queued for
+    // k_slic_leftover, which adds them to the centroid sums with plain global atomics (rare).
+    unsigned pending = 0;
+    int win_k[ROWS];
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r) win_k[r] = __shfl(my_k, best_s[r] & 63, 64);
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r) {
+        const int y = wy0 + r;
+        if (!(xin && y < s.H)) continue;
+        const int p = y * s.W + x;
+        if (best_s[r] >= 0) {
+            labels[p] = win_k[r];
+            pending |= 1u << r;
+            continue;
+        }
+        if (best_s[r] <= -2) labels[p] = -(best_s[r] + 2);
+        if (ACCUM) s.leftover[atomicAdd(s.leftover_count, 1)] = p;
+    }
+    PHASE_MARK(4)                                  // label stores
+    if (!ACCUM) {
+        PHASE_FLUSH()
+        return;
+    }
+
+    // Segmented reduction.  The fixed-point limbs of every colour value (common.h fix_split) are
+    // integer-valued doubles below 2^43 (|Lab| < 2^12 on this path), so sums over the pixels of a wave are
+    // exact in fp64.  Each 16-lane row of the wave (a 16 x 4 pixel block) works on its own slot -- the
+    // smallest one still pending in the block -- so the number of passes is the largest number of distinct
+    // labels in one block (2 on average) rather than in the whole 64 x 4 strip.  Per pass eight values per
+    // lane (six limb sums, sum x, sum y * 512 + n) go through one transposed DPP reduction over the row and
+    // its even lanes add the totals into the workgroup's LDS slot.
+    while (__any(pending != 0)) {
+        int mine = 0x7fffffff;
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r)
+            if (pending & (1u << r)) mine = min(mine, best_s[r]);
+        mine = min(mine, __builtin_amdgcn_update_dpp(0, mine, 0x140, 0xf, 0xf, false));
+        mine = min(mine, __builtin_amdgcn_update_dpp(0, mine, 0x141, 0xf, 0xf, false));
+        mine = min(mine, __builtin_amdgcn_update_dpp(0, mine, 0x1b, 0xf, 0xf, false));
+        mine = min(mine, __builtin_amdgcn_update_dpp(0, mine, 0xb1, 0xf, 0xf, false));
+        const int slot = mine;                     // uniform over the 16-lane row; 0x7fffffff: row is done
+        double q[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+        int qn = 0, qy = 0;
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r) {
+            if ((pending & (1u << r)) && best_s[r] == slot) {
+                double t, h;
+                t = pL[r] * 1073741824.0; h = trunc(t); q[0] += h; q[1] += trunc((t - h) * 4294967296.0);
+                t = pA[r] * 1073741824.0; h = trunc(t); q[2] += h; q[3] += trunc((t - h) * 4294967296.0);
+                t = pB[r] * 1073741824.0; h = trunc(t); q[4] += h; q[5] += trunc((t - h) * 4294967296.0);
+                qn += 1;
+                qy += wy0 + r;
+                pending &= ~(1u << r);
+            }
+        }
+        q[6] = (double)(qn * x);
+        q[7] = (double)(qy * 512 + qn);
+        const double tot = row16_reduce8_f64(q, lane);
+        if ((lane & 1) == 0 && slot != 0x7fffffff) {
+            const int j = ((lane >> 3) & 1) * 4 + ((lane >> 2) & 1) * 2 + ((lane >> 1) & 1);
+            const long long tv = (long long)tot;
+            if (j < 6) atomic_add_i64(&lacc[slot][3 + j], tv);
+            else if (j == 6) atomic_add_i64(&lacc[slot][2], tv);
+            else {
+                atomic_add_i64(&lacc[slot][0], tv & 511);
+                atomic_add_i64(&lacc[slot][1], tv >> 9);
+            }
+        }
+        if (s.phase_prof && tid == 0) prof_slot[8] += 1;
+    }
+    PHASE_MARK(5)                                  // accumulation passes
+    __syncthreads();
+    PHASE_MARK(6)                                  // barrier
+    for (int i = tid; i < nc * 9; i += 256) {
+        const int c = i / 9, j = i - 9 * c;
+        const long long v = lacc[c][j];
+        if (v != 0) atomic_add_i64(s.acc + (size_t)lk[c] * 9 + j, v);
+    }
+    PHASE_MARK(7)                                  // flush
+    PHASE_FLUSH()
+}
+
 int launch_slic_iterations(SlicState s, const double *lab, const double *init_yx_dev, int32_t *labels, int max_iter,
                            int max_cand, const ProfHook &prof, hipStream_t st)
 {
@@ -785,6 +1206,22 @@ int launch_slic_iterations(SlicState s, const double *lab, const double *init_yx
                                     BIN_MAX_K_LDS * (int)sizeof(int4)));
         bin_attr = true;
     }
+    // first sweep in closed form: allowed when every pixel lies inside the search window of its nearest grid
+    // node (per axis: half a grid step in the interior, the border offsets at the ends)
+    bool grid_covers = false;
+    {
+        const int ny = s.K / s.grid_nx;
+        const int reach_y = std::max(std::max(s.grid_y0, s.H - 1 - (s.grid_y0 + (ny - 1) * s.grid_dy)), s.grid_dy / 2 + 1);
+        const int reach_x = std::max(std::max(s.grid_x0, s.W - 1 - (s.grid_x0 + (s.grid_nx - 1) * s.grid_dx)), s.grid_dx / 2 + 1);
+        grid_covers = reach_y <= 2 * s.step_y && reach_x <= 2 * s.step_x;
+    }
+    if (getenv("IMSEGM_PRINT_OCC")) {
+        int nb = 0;
+        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void *)k_slic_assign_dot<true, false>, 256, 0));
+        fprintf(stderr, "[occupancy] k_slic_assign_dot<true>: %d workgroups per CU\n", nb);
+        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void *)k_slic_assign_dot<false, false>, 256, 0));
+        fprintf(stderr, "[occupancy] k_slic_assign_dot<false>: %d workgroups per CU\n", nb);
+    }
     for (int it = 0; it < max_iter; ++it) {
         hipLaunchKernelGGL(k_slic_bin, cdiv(n_tiles, BIN_TILES_PER_BLOCK), 256,
                            (size_t)std::min(s.K, BIN_MAX_K_LDS) * sizeof(int4), st, s, (int)grid.x, n_tiles, max_cand,
@@ -793,14 +1230,24 @@ int launch_slic_iterations(SlicState s, const double *lab, const double *init_yx
         // first sweep: integer-grid centroids with zero colour -> exact integer path (needs the
         // fast-path preconditions and a spatial weight far above the fp64 resolution)
         const bool first = it == 0 && s.fast32 && s.spatial_weight > 1e-9;
+        const bool dot = !first && s.fast32 && !(s.debug & 16);
+        const bool first_grid = first && grid_covers && !(s.debug & 32);
         if (it + 1 < max_iter) {
-            if (first)
+            if (first_grid)
+                hipLaunchKernelGGL((k_slic_assign_dot<true, true>), grid, 256, 0, st, s, lab, labels);
+            else if (first)
                 hipLaunchKernelGGL((k_slic_assign<true, true>), grid, 256, 0, st, s, lab, labels, s.tile_cands, s.tile_count);
+            else if (dot)
+                hipLaunchKernelGGL((k_slic_assign_dot<true, false>), grid, 256, 0, st, s, lab, labels);
             else
                 hipLaunchKernelGGL((k_slic_assign<true, false>), grid, 256, 0, st, s, lab, labels, s.tile_cands, s.tile_count);
         } else {
-            if (first)
+            if (first_grid)
+                hipLaunchKernelGGL((k_slic_assign_dot<false, true>), grid, 256, 0, st, s, lab, labels);
+            else if (first)
                 hipLaunchKernelGGL((k_slic_assign<false, true>), grid, 256, 0, st, s, lab, labels, s.tile_cands, s.tile_count);
+            else if (dot)
+                hipLaunchKernelGGL((k_slic_assign_dot<false, false>), grid, 256, 0, st, s, lab, labels);
             else
                 hipLaunchKernelGGL((k_slic_assign<false, false>), grid, 256, 0, st, s, lab, labels, s.tile_cands, s.tile_count);
         }

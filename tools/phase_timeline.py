@@ -1,0 +1,31 @@
+"""Analyse the per-workgroup timestamps dumped by IMSEGM_PHASE_PROF=1 IMSEGM_PHASE_DUMP=<file> (profiling aid)."""
+import sys
+import numpy as np
+
+a = np.fromfile(sys.argv[1], dtype=np.int64).reshape(-1, 2, 16)
+for v, name in ((1, 'accum sweep (last launch)'), (0, 'final sweep')):
+    d = a[:, v, :]
+    d = d[d[:, 15] > 0]
+    if not len(d):
+        continue
+    st, en, hw, xcc = d[:, 10], d[:, 11], d[:, 12], d[:, 13] & 0xf
+    t0 = st.min()
+    st = (st - t0) / 100.0
+    en = (en - t0) / 100.0          # microseconds
+    print(name, 'workgroups', len(d), 'span %.1f us' % en.max(), 'WG lifetime us p5/p50/p95 %.1f %.1f %.1f'
+          % tuple(np.percentile(en - st, [5, 50, 95])))
+    cu = ((hw >> 8) & 0xf) + 16 * ((hw >> 12) & 1) + 32 * ((hw >> 13) & 7) + 256 * xcc
+    u, c = np.unique(cu, return_counts=True)
+    print('  CUs used', len(u), 'WGs per CU min/mean/max', c.min(), c.mean(), c.max())
+    ev = np.concatenate([np.stack([st, np.ones_like(st)], 1), np.stack([en, -np.ones_like(en)], 1)])
+    ev = ev[np.argsort(ev[:, 0], kind='stable')]
+    conc = np.cumsum(ev[:, 1])
+    t = ev[:, 0]
+    dt = np.diff(t)
+    edges = np.linspace(0, en.max(), 13)
+    out = []
+    for i in range(12):
+        m = (t[:-1] >= edges[i]) & (t[:-1] < edges[i + 1])
+        out.append(int((conc[:-1][m] * dt[m]).sum() / max(dt[m].sum(), 1e-9)))
+    print('  resident WGs (whole GPU) over 12 time slices:', out, ' (5 per CU = %d)' % (5 * len(u)))
+    print('  last start at %.1f us, first end at %.1f us' % (st.max(), en.min()))
