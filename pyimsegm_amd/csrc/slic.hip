@@ -895,9 +895,12 @@ __device__ __forceinline__ double row16_reduce8_f64(const double (&v)[8], int la
 // the winner is the nearest grid node per axis, ties to the lower index (= lowest centroid index, what
 // the strict '<' of _slic.pyx keeps).  The launcher only selects this variant when every pixel lies inside
 // the search window of its nearest node.
+// (6 waves per SIMD: three pixel values that only bypass the hot loop are parked in scratch to stay at 80 VGPRs)
 template <bool ACCUM, bool FIRST>
-__global__ void __launch_bounds__(256)
-k_slic_assign_dot(SlicState s, const double *__restrict__ lab, int32_t *__restrict__ labels)
+__global__ void __launch_bounds__(256, 6)
+k_slic_assign_dot(SlicState s, const double *__restrict__ lab, int32_t *__restrict__ labels,
+                  const Cand *__restrict__ tile_cands, const Rec32 *__restrict__ tile_rec,
+                  const TileInfo *__restrict__ tile_info, const int *__restrict__ tile_k)
 {
     __shared__ long long lacc[MAXC][9];
     __shared__ int lk[MAXC];
@@ -917,9 +920,10 @@ k_slic_assign_dot(SlicState s, const double *__restrict__ lab, int32_t *__restri
     const int wy0 = blockIdx.y * WG_Y + wave * ROWS;                    // first row of this wave
     const int rel0 = (blockIdx.y & 1) * WG_Y + wave * ROWS;             // ... relative to the bin tile
     const size_t plane = (size_t)s.H * s.W;
-    const Cand *__restrict__ cand = s.tile_cands + (size_t)tile * MAXC;
-    const Rec32 *__restrict__ rec = s.tile_rec + (size_t)tile * MAXC;
-    const TileInfo *__restrict__ ti = s.tile_info + tile;
+    // (the tables come in as restrict-qualified kernel arguments so that their uniform reads are scalar loads)
+    const Cand *__restrict__ cand = tile_cands + (size_t)tile * MAXC;
+    const Rec32 *__restrict__ rec = tile_rec + (size_t)tile * MAXC;
+    const TileInfo *__restrict__ ti = tile_info + tile;
 
     const int x = tx0 + lane;
     const bool xin = x < s.W;
@@ -937,7 +941,7 @@ k_slic_assign_dot(SlicState s, const double *__restrict__ lab, int32_t *__restri
         pB[r] = lab[2 * plane + p];
         best_s[r] = -1;
     }
-    const int my_k = s.tile_k[(size_t)tile * MAXC + lane];
+    const int my_k = tile_k[(size_t)tile * MAXC + lane];
     // candidate table in registers: lane c holds the record of candidate c; the loop fetches the fields
     // with v_readlane, i.e. without any memory latency between two candidates
     const float4 my_ra = reinterpret_cast<const float4 *>(rec + lane)[0];      // q0, qx, qy, qL
@@ -1025,11 +1029,13 @@ k_slic_assign_dot(SlicState s, const double *__restrict__ lab, int32_t *__restri
                 float wl = 0.f;
 #pragma unroll
                 for (int r = 0; r < ROWS; ++r) {
-                    const float l = r & 1 ? fL[r >> 1].y : fL[r >> 1].x, a = r & 1 ? fA[r >> 1].y : fA[r >> 1].x,
-                                b = r & 1 ? fB[r >> 1].y : fB[r >> 1].x;
+                    float l = r & 1 ? fL[r >> 1].y : fL[r >> 1].x, a = r & 1 ? fA[r >> 1].y : fA[r >> 1].x,
+                          b = r & 1 ? fB[r >> 1].y : fB[r >> 1].x, xbr = xb[r], Xv = X;
+                    // (keeps this rarely executed arithmetic inside the branch instead of in 9 hoisted registers)
+                    asm volatile("" : "+v"(l), "+v"(a), "+v"(b), "+v"(xbr), "+v"(Xv));
                     const float Yr = Y0 + (float)r;
-                    const float P = fmaf(sw32, fmaf(Yr, Yr, X * X), fmaf(l, l, fmaf(a, a, b * b)));
-                    const float v = fmaf(fmaxf(b1[r] + P, 0.f), 1.002f, 0.002f * (xb[r] + 1.f));
+                    const float P = fmaf(sw32, fmaf(Yr, Yr, Xv * Xv), fmaf(l, l, fmaf(a, a, b * b)));
+                    const float v = fmaf(fmaxf(b1[r] + P, 0.f), 1.002f, 0.002f * (xbr + 1.f));
                     if (xin && r < rows_valid) wl = fmaxf(wl, v);
                 }
                 int wi = __float_as_int(wl);                  // wl >= 0: integer order == float order
@@ -1234,20 +1240,20 @@ int launch_slic_iterations(SlicState s, const double *lab, const double *init_yx
         const bool first_grid = first && grid_covers && !(s.debug & 32);
         if (it + 1 < max_iter) {
             if (first_grid)
-                hipLaunchKernelGGL((k_slic_assign_dot<true, true>), grid, 256, 0, st, s, lab, labels);
+                hipLaunchKernelGGL((k_slic_assign_dot<true, true>), grid, 256, 0, st, s, lab, labels, s.tile_cands, s.tile_rec, s.tile_info, s.tile_k);
             else if (first)
                 hipLaunchKernelGGL((k_slic_assign<true, true>), grid, 256, 0, st, s, lab, labels, s.tile_cands, s.tile_count);
             else if (dot)
-                hipLaunchKernelGGL((k_slic_assign_dot<true, false>), grid, 256, 0, st, s, lab, labels);
+                hipLaunchKernelGGL((k_slic_assign_dot<true, false>), grid, 256, 0, st, s, lab, labels, s.tile_cands, s.tile_rec, s.tile_info, s.tile_k);
             else
                 hipLaunchKernelGGL((k_slic_assign<true, false>), grid, 256, 0, st, s, lab, labels, s.tile_cands, s.tile_count);
         } else {
             if (first_grid)
-                hipLaunchKernelGGL((k_slic_assign_dot<false, true>), grid, 256, 0, st, s, lab, labels);
+                hipLaunchKernelGGL((k_slic_assign_dot<false, true>), grid, 256, 0, st, s, lab, labels, s.tile_cands, s.tile_rec, s.tile_info, s.tile_k);
             else if (first)
                 hipLaunchKernelGGL((k_slic_assign<false, true>), grid, 256, 0, st, s, lab, labels, s.tile_cands, s.tile_count);
             else if (dot)
-                hipLaunchKernelGGL((k_slic_assign_dot<false, false>), grid, 256, 0, st, s, lab, labels);
+                hipLaunchKernelGGL((k_slic_assign_dot<false, false>), grid, 256, 0, st, s, lab, labels, s.tile_cands, s.tile_rec, s.tile_info, s.tile_k);
             else
                 hipLaunchKernelGGL((k_slic_assign<false, false>), grid, 256, 0, st, s, lab, labels, s.tile_cands, s.tile_count);
         }
