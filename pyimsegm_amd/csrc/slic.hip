@@ -895,9 +895,8 @@ __device__ __forceinline__ double row16_reduce8_f64(const double (&v)[8], int la
 // the winner is the nearest grid node per axis, ties to the lower index (= lowest centroid index, what
 // the strict '<' of _slic.pyx keeps).  The launcher only selects this variant when every pixel lies inside
 // the search window of its nearest node.
-// (6 waves per SIMD: three pixel values that only bypass the hot loop are parked in scratch to stay at 80 VGPRs)
 template <bool ACCUM, bool FIRST>
-__global__ void __launch_bounds__(256, 6)
+__global__ void __launch_bounds__(256, 5)
 k_slic_assign_dot(SlicState s, const double *__restrict__ lab, int32_t *__restrict__ labels,
                   const Cand *__restrict__ tile_cands, const Rec32 *__restrict__ tile_rec,
                   const TileInfo *__restrict__ tile_info, const int *__restrict__ tile_k)
@@ -1099,16 +1098,43 @@ k_slic_assign_dot(SlicState s, const double *__restrict__ lab, int32_t *__restri
 #undef RL_F
         PHASE_MARK(2)                              // candidate loop
         if (s.phase_prof && tid == 0) prof_slot[9] += c_end;
-        // near ties (second best inside the margin for some pixel of the row): exact fp64 loop over the
-        // candidates that were looked at
+        // near ties (second best inside the margin for some pixel of the row): exact fp64 evaluation, in the
+        // order of _slic.pyx, of the candidates whose fp32 value lies within the margin of the fp32 best --
+        // the exact winner is always one of them (its d32 exceeds b1 by at most half the margin).
         const float U16 = 16.f * 5.9604644775390625e-8f * 1.01f;
 #pragma unroll
         for (int r = 0; r < ROWS; ++r) {
             const float m = U16 * (b1[r] + b2[r] + 4.f * xb[r]) + 1e-30f;
             const bool near2 = best_s[r] >= 0 && b2[r] < INF && !(b2[r] - b1[r] > m);
             if (!__any(near2)) continue;
-            const int e = exact_row(cand, c_end, wy0 + r, x, sw, pL[r], pA[r], pB[r]);
-            if (near2) best_s[r] = e;
+            const float l = r & 1 ? fL[r >> 1].y : fL[r >> 1].x, a = r & 1 ? fA[r >> 1].y : fA[r >> 1].x,
+                        b = r & 1 ? fB[r >> 1].y : fB[r >> 1].x;
+            const float Yr = Y0 + (float)r;
+            const double fy = (double)(wy0 + r), fx = (double)x;
+            double bd = DBL_MAX;
+            int bs = -1, bk = 0x7fffffff;
+#define RL_F(v) __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), c))
+            for (int c = 0; c < c_end; ++c) {
+                const unsigned meta = (unsigned)__builtin_amdgcn_readlane(__float_as_int(my_rb.w), c);
+                const int rlo = meta & 0xff, rhi = (meta >> 8) & 0xff, xlo = (meta >> 16) & 0xff, xhi = meta >> 24;
+                if (rel0 + r < rlo || rel0 + r >= rhi) continue;
+                float d = fmaf(RL_F(my_ra.y), X, RL_F(my_ra.x));
+                d = fmaf(RL_F(my_ra.z), Yr, d);
+                d = fmaf(RL_F(my_ra.w), l, d);
+                d = fmaf(RL_F(my_rb.x), a, d);
+                d = fmaf(RL_F(my_rb.y), b, d);
+                const bool take = near2 && lane >= xlo && lane < xhi && d - b1[r] <= m;
+                if (!__any(take)) continue;
+                const double e = exact_dist(cand[c], fy, fx, sw, pL[r], pA[r], pB[r]);
+                const int k = cand[c].k;
+                if (take && ((bd > e) || (bd == e && k < bk))) {
+                    bd = e;
+                    bs = c;
+                    bk = k;
+                }
+            }
+#undef RL_F
+            if (near2) best_s[r] = bs;
         }
         PHASE_MARK(3)                              // near-tie resolution
     }
