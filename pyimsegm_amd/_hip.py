@@ -168,11 +168,14 @@ _default_ctx = {}
 
 
 def default_context():
-    """per-process, per-device lazily created context (re-created in forked children)"""
-    key = (os.getpid(), os.environ.get('IMSEGM_HIP_DEVICE', os.environ.get('LOCAL_RANK', '0')))
+    """per-process, per-thread, per-device lazily created context (re-created in forked children).
+
+    A context owns one HIP stream and its pinned staging buffers, so worker threads that keep several
+    images in flight on one GPU (``pipelines.NB_WORKERS``) each get their own."""
+    key = (os.getpid(), threading.get_ident(), os.environ.get('IMSEGM_HIP_DEVICE', os.environ.get('LOCAL_RANK', '0')))
     ctx = _default_ctx.get(key)
     if ctx is None:
-        device = int(key[1])
+        device = int(key[2])
         n = device_count()
         if n > 0:
             device %= n

@@ -93,21 +93,31 @@ class Group(object):
             self.dist = None
 
 
-def segment_batch_sharded(list_images, segment_fn, group):
+def segment_batch_sharded(list_images, segment_fn, group, nb_workers=1):
     """segment a batch of equally-sized images sharded over the ranks of ``group``.
 
     ``segment_fn(image) -> label map`` runs on this rank's GPU.  Every rank processes the images
     ``i = rank, rank + world, ...``; label maps travel to rank 0 with one gather per round of
     images.  Returns the full list of label maps on rank 0, ``None`` elsewhere.
+
+    ``nb_workers`` > 1 keeps that many images of this rank in flight: worker threads, each with its
+    own HIP stream (``_hip.default_context`` is per thread), so that the host stages of one image
+    (class probabilities, edge weights) overlap the kernels of another.
     """
     n = len(list_images)
     mine = group.shard(n)
     rounds = (n + group.world - 1) // group.world
     results = [None] * n if group.rank == 0 else None
     shape = np.asarray(list_images[0]).shape[:2]
+    pool = futures = None
+    if nb_workers > 1 and len(mine) > 1:
+        from concurrent.futures import ThreadPoolExecutor
+        pool = ThreadPoolExecutor(max_workers=int(nb_workers))
+        futures = [pool.submit(segment_fn, list_images[i]) for i in mine]
     for rnd in range(rounds):
         if rnd < len(mine):
-            segm = np.ascontiguousarray(segment_fn(list_images[mine[rnd]]), dtype=np.int32)
+            segm = futures[rnd].result() if futures else segment_fn(list_images[mine[rnd]])
+            segm = np.ascontiguousarray(segm, dtype=np.int32)
         else:  # ragged tail: this rank has no image in the last round, contribute a dummy
             segm = np.full(shape, -1, dtype=np.int32)
         parts = group.gather_arrays(segm, dst=0)
@@ -116,4 +126,6 @@ def segment_batch_sharded(list_images, segment_fn, group):
                 idx = rnd * group.world + r
                 if idx < n:
                     results[idx] = part
+    if pool is not None:
+        pool.shutdown()
     return results

@@ -22,9 +22,9 @@ from pyimsegm_amd.superpixels import _open_session, _open_volume, _run_slic, _ru
 FTS_SET_SIMPLE = FEATURES_SET_COLOR
 #: default modeling / clustering for unsupervised segmentation
 CLUSTER_METHOD = 'GMM'
-#: default number of workers (kept for API compatibility: images are processed one after another on
-#: the GPU of this process; see :func:`segment_batch_sharded` for the multi-GPU path)
-NB_WORKERS = 1
+#: default number of images a process keeps in flight on its GPU (worker threads with one HIP stream
+#: each; the reference's ``NB_WORKERS`` counts pool processes, ``pipelines.py:32``)
+NB_WORKERS = 2
 
 
 class _ResidentImage(object):
@@ -166,10 +166,16 @@ def estim_model_classes_group(
 
     :return tuple(model, list(ndarray)): fitted scikit-learn pipeline, features per image
     """
-    list_features = []
-    for image in list_images:
-        _, features = compute_color2d_superpixels_features(image, dict_features, sp_size=sp_size, sp_regul=sp_regul)
-        list_features.append(features)
+    def _features(image):
+        return compute_color2d_superpixels_features(image, dict_features, sp_size=sp_size, sp_regul=sp_regul)[1]
+
+    if nb_workers and nb_workers > 1 and len(list_images) > 1:
+        # several images in flight on this GPU: worker threads, one HIP stream each
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(max_workers=int(nb_workers)) as pool:
+            list_features = list(pool.map(_features, list_images))
+    else:
+        list_features = [_features(image) for image in list_images]
     features = np.nan_to_num(np.concatenate(tuple(list_features), axis=0))
     model = estim_class_model(features, nb_classes, model_type, pca_coef, use_scaler)
     return model, list_features
@@ -205,13 +211,15 @@ def segment_color2d_slic_features_model_graphcut(
 
 
 def segment_batch_color2d_slic_features_model_graphcut(list_images, model_pipeline, dict_features, sp_size=30,
-                                                       sp_regul=0.2, gc_regul=1., gc_edge_type='model', group=None):
+                                                       sp_regul=0.2, gc_regul=1., gc_edge_type='model', group=None,
+                                                       nb_workers=NB_WORKERS):
     """ segment a batch of equally-sized images with a given model, sharded over the GPUs of one node
 
     Multi-GPU counterpart of mapping :func:`segment_color2d_slic_features_model_graphcut` over a
     process pool (reference ``run_segm_slic_model_graphcut.py:505-514``): one process per GPU
     (``torchrun``), image *i* goes to rank ``i mod world``, the label maps are gathered on rank 0
-    over RCCL.  Without a process group it simply loops over the images on this GPU.
+    over RCCL.  Without a process group it processes the images on this GPU, ``nb_workers`` of them
+    in flight at a time.
 
     :return list(ndarray): label maps on rank 0 (``None`` on the other ranks)
     """
@@ -226,7 +234,7 @@ def segment_batch_color2d_slic_features_model_graphcut(list_images, model_pipeli
                                                                gc_edge_type=gc_edge_type)
         return segm
 
-    out = segment_batch_sharded(list_images, _segment, group)
+    out = segment_batch_sharded(list_images, _segment, group, nb_workers=nb_workers)
     if own:
         group.close()
     return out
