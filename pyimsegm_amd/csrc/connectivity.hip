@@ -24,7 +24,7 @@
 namespace imsegm {
 
 enum { ST_ACTIVE = 0, ST_FINAL = 1 };
-enum { CNT_OVER = 0, CNT_SMALL = 1, CNT_CURSOR = 2, CNT_KEPT = 3, CNT_FALLBACK = 4 };
+enum { CNT_OVER = 0, CNT_SMALL = 1, CNT_CURSOR = 2, CNT_KEPT = 3, CNT_FALLBACK = 4, CNT_BIG = 5, CNT_LITTLE = 6 };
 
 // neighbour of voxel p in direction d of the reference's BFS order (+x, -x, +y, -y, +z, -z); -1 outside
 __device__ __forceinline__ int neighbour(int p, int D, int H, int W, int d)
@@ -330,6 +330,24 @@ k_small_bbox(const int32_t *__restrict__ parent, const int32_t *__restrict__ csi
     atomicMax(&bbox[6 * i + 5], z);
 }
 
+// Processing order of the small components for k_small_bfs_wave: the ones with a large bounding box (long
+// BFS, the critical path of the launch) first, the many tiny ones after them.
+__global__ void __launch_bounds__(256)
+k_small_order(const int32_t *__restrict__ bbox, int32_t *counters, int D, int H, int W, int big_cells, int capacity,
+              int32_t *order)
+{
+    const int n_small = counters[CNT_SMALL];
+    if (n_small > capacity) return;
+    for (int ci = blockIdx.x * blockDim.x + threadIdx.x; ci < n_small; ci += gridDim.x * blockDim.x) {
+        const int y0 = max(bbox[6 * ci + 0] - 1, 0), y1 = min(bbox[6 * ci + 1] + 1, H - 1);
+        const int x0 = max(bbox[6 * ci + 2] - 1, 0), x1 = min(bbox[6 * ci + 3] + 1, W - 1);
+        const int z0 = max(bbox[6 * ci + 4] - 1, 0), z1 = min(bbox[6 * ci + 5] + 1, D - 1);
+        const long cells = (long)(x1 - x0 + 1) * (y1 - y0 + 1) * (z1 - z0 + 1);
+        if (cells > big_cells) order[atomicAdd(&counters[CNT_BIG], 1)] = ci;
+        else order[n_small - 1 - atomicAdd(&counters[CNT_LITTLE], 1)] = ci;
+    }
+}
+
 // Exact emulation of the reference's BFS (queue order, neighbour order +x, -x, +y, -y) by one wave:
 // level-synchronous, the frontier is kept in BFS-rank order.  Frontier element i proposes key
 // 4*i + d to each unvisited member neighbour (LDS atomicMin); the minimum key of a cell is its
@@ -340,16 +358,19 @@ k_small_bbox(const int32_t *__restrict__ parent, const int32_t *__restrict__ csi
 template <int CELLS, int FMAX>
 __global__ void __launch_bounds__(64)
 k_small_bfs_wave(const int32_t *__restrict__ list, int32_t *counters,
-                 const int32_t *__restrict__ parent, const int32_t *__restrict__ bbox, int D, int H, int W, int lo_cells,
-                 int capacity, int32_t *adjptr, int32_t *fallback_list)
+                 const int32_t *__restrict__ parent, const int32_t *__restrict__ bbox, int D, int H, int W,
+                 const int32_t *__restrict__ order, int capacity, int32_t *adjptr, int32_t *fallback_list)
 {
     __shared__ unsigned int prop[CELLS];
     __shared__ uint8_t cls[CELLS];       // 0 other, 1 member unvisited, 2 earlier foreign, 3 member visited
     __shared__ uint16_t fr[2][FMAX];
+    __shared__ int level_best;
+    static_assert(CELLS <= 8192 && 6 * FMAX <= (1 << 18), "packing of (key, cell) in level_best");
     const int lane = threadIdx.x;
     const int n_small = counters[CNT_SMALL];
     if (n_small > capacity) return;
-    for (int ci = blockIdx.x; ci < n_small; ci += gridDim.x) {
+    for (int t = blockIdx.x; t < n_small; t += gridDim.x) {
+        const int ci = order[t];
         const int root = list[ci];
         const int y0 = max(bbox[6 * ci + 0] - 1, 0), y1 = min(bbox[6 * ci + 1] + 1, H - 1);
         const int x0 = max(bbox[6 * ci + 2] - 1, 0), x1 = min(bbox[6 * ci + 3] + 1, W - 1);
@@ -357,9 +378,8 @@ k_small_bfs_wave(const int32_t *__restrict__ list, int32_t *counters,
         const int bw = x1 - x0 + 1, bh = y1 - y0 + 1, bd = z1 - z0 + 1;
         const int bwh = bw * bh;
         const long cells_l = (long)bwh * bd;
-        if (cells_l <= lo_cells) continue;         // handled by the launch with the smaller LDS tile
         if (cells_l > CELLS) {
-            if (CELLS >= 8192 && lane == 0) fallback_list[atomicAdd(&counters[CNT_FALLBACK], 1)] = root;
+            if (lane == 0) fallback_list[atomicAdd(&counters[CNT_FALLBACK], 1)] = root;
             continue;
         }
         const int cells = (int)cells_l;
@@ -373,10 +393,14 @@ k_small_bfs_wave(const int32_t *__restrict__ list, int32_t *counters,
         }
         const int rx = root % W, ry = (root / W) % H, rz = root / (W * H);
         const int seed = ((rz - z0) * bh + (ry - y0)) * bw + (rx - x0);
+        // exact division of a cell index (< 2^13) by bw / bwh through a 32-bit reciprocal
+        const unsigned int m_bw = (unsigned int)((0x100000000ull + bw - 1) / bw);
+        const unsigned int m_bwh = (unsigned int)((0x100000000ull + bwh - 1) / bwh);
         __syncthreads();
         if (lane == 0) {
             fr[0][0] = (uint16_t)seed;
             cls[seed] = 3;
+            level_best = -1;
         }
         int f = 1, cur = 0;
         int adj_cell = -1;
@@ -384,29 +408,21 @@ k_small_bfs_wave(const int32_t *__restrict__ list, int32_t *counters,
         __syncthreads();
         while (f > 0) {
             const int nkeys = 6 * f;
-            int best_key = -1, best_cell = -1;
-            // phase A: proposals + foreign neighbours
+            // phase A: proposals + foreign neighbours; the last foreign contact of this level (largest key)
+            // overrides earlier levels: one LDS atomicMax on (key << 13 | cell)
             for (int key = lane; key < nkeys; key += 64) {
-                int c = fr[cur][key / 6], d = key % 6;
-                int cz = c / bwh, rem = c - cz * bwh;
-                int cy = rem / bw, cx = rem - cy * bw;
-                int nx = cx + (d == 0) - (d == 1), ny = cy + (d == 2) - (d == 3), nz = cz + (d == 4) - (d == 5);
+                const int c = fr[cur][key / 6], d = key % 6;
+                const int cz = bd == 1 ? 0 : (int)__umulhi((unsigned int)c, m_bwh), rem = c - cz * bwh;
+                const int cy = bw == 1 ? rem : (int)__umulhi((unsigned int)rem, m_bw), cx = rem - cy * bw;
+                const int nx = cx + (d == 0) - (d == 1), ny = cy + (d == 2) - (d == 3), nz = cz + (d == 4) - (d == 5);
                 if (nx < 0 || nx >= bw || ny < 0 || ny >= bh || nz < 0 || nz >= bd) continue;
-                int nc = (nz * bh + ny) * bw + nx;
-                int t = cls[nc];
+                const int nc = (nz * bh + ny) * bw + nx;
+                const int t = cls[nc];
                 if (t == 1) atomicMin(&prop[nc], (unsigned int)key);
-                else if (t == 2) { best_key = key; best_cell = nc; }     // keys ascend per lane
-            }
-            // the last foreign contact of this level (largest key) overrides earlier levels
-            if (__any(best_key >= 0)) {
-#pragma unroll
-                for (int off = 32; off > 0; off >>= 1) {
-                    int ok = __shfl_xor(best_key, off, 64), oc = __shfl_xor(best_cell, off, 64);
-                    if (ok > best_key) { best_key = ok; best_cell = oc; }
-                }
-                adj_cell = best_cell;
+                else if (t == 2) atomicMax(&level_best, (key << 13) | nc);
             }
             __syncthreads();
+            if (level_best >= 0) adj_cell = level_best & 8191;
             // phase B: winners, compacted in key order
             int base = 0;
             for (int k0 = 0; k0 < nkeys; k0 += 64) {
@@ -414,10 +430,10 @@ k_small_bfs_wave(const int32_t *__restrict__ list, int32_t *counters,
                 bool win = false;
                 int nc = 0;
                 if (key < nkeys) {
-                    int c = fr[cur][key / 6], d = key % 6;
-                    int cz = c / bwh, rem = c - cz * bwh;
-                    int cy = rem / bw, cx = rem - cy * bw;
-                    int nx = cx + (d == 0) - (d == 1), ny = cy + (d == 2) - (d == 3), nz = cz + (d == 4) - (d == 5);
+                    const int c = fr[cur][key / 6], d = key % 6;
+                    const int cz = bd == 1 ? 0 : (int)__umulhi((unsigned int)c, m_bwh), rem = c - cz * bwh;
+                    const int cy = bw == 1 ? rem : (int)__umulhi((unsigned int)rem, m_bw), cx = rem - cy * bw;
+                    const int nx = cx + (d == 0) - (d == 1), ny = cy + (d == 2) - (d == 3), nz = cz + (d == 4) - (d == 5);
                     if (nx >= 0 && nx < bw && ny >= 0 && ny < bh && nz >= 0 && nz < bd) {
                         nc = (nz * bh + ny) * bw + nx;
                         win = (cls[nc] == 1) && (prop[nc] == (unsigned int)key);
@@ -433,6 +449,7 @@ k_small_bfs_wave(const int32_t *__restrict__ list, int32_t *counters,
             __syncthreads();
             if (base > FMAX) { failed = true; break; }
             for (int i = lane; i < base; i += 64) cls[fr[cur ^ 1][i]] = 3;
+            if (lane == 0) level_best = -1;
             __syncthreads();
             f = base;
             cur ^= 1;
@@ -530,15 +547,15 @@ static int conn_tail(const int32_t *csize_final, int32_t *adjptr, int D, int H, 
                        w.newlabel, start_label);
     HIP_TRY(hipMemsetAsync(w.visited, 0, n, st));
     HIP_TRY(hipMemsetAsync(w.counters + CNT_SMALL, 0, 2 * sizeof(int32_t), st));
-    HIP_TRY(hipMemsetAsync(w.counters + CNT_FALLBACK, 0, sizeof(int32_t), st));
+    HIP_TRY(hipMemsetAsync(w.counters + CNT_FALLBACK, 0, 3 * sizeof(int32_t), st));     // FALLBACK, BIG, LITTLE
     hipLaunchKernelGGL(k_list_small, grid, 256, 0, st, w.parent, csize_final, n, min_size, w.list, w.counters);
     hipLaunchKernelGGL(k_small_bbox_init, 64, 256, 0, st, bbox, w.list, w.counters, w.slotmap, capacity);
     hipLaunchKernelGGL(k_small_bbox, grid, 256, 0, st, w.parent, csize_final, n, H, W, min_size, w.slotmap, bbox,
                        w.counters, capacity);
-    hipLaunchKernelGGL((k_small_bfs_wave<1024, 256>), 2048, 64, 0, st, w.list, w.counters, w.parent, bbox, D, H, W, 0,
-                       capacity, adjptr, fallback_list);
-    hipLaunchKernelGGL((k_small_bfs_wave<8192, 2048>), 256, 64, 0, st, w.list, w.counters, w.parent, bbox, D, H, W, 1024,
-                       capacity, adjptr, fallback_list);
+    // one launch for all of them, long ones first (w.queue is free until the fallback kernel)
+    hipLaunchKernelGGL(k_small_order, 64, 256, 0, st, bbox, w.counters, D, H, W, 1024, capacity, w.queue);
+    hipLaunchKernelGGL((k_small_bfs_wave<8192, 2048>), 2048, 64, 0, st, w.list, w.counters, w.parent, bbox, D, H, W,
+                       w.queue, capacity, adjptr, fallback_list);
     hipLaunchKernelGGL(k_small_bfs_fallback, 64, 64, 0, st, w.list, fallback_list, w.counters, w.parent, csize_final, D, H,
                        W, capacity, w.queue, w.visited, w.counters + CNT_CURSOR, adjptr);
     hipLaunchKernelGGL(k_small_resolve, 64, 64, 0, st, w.list, w.counters, csize_final, adjptr, min_size, w.newlabel);
