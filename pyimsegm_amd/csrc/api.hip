@@ -629,8 +629,8 @@ int imsegm_image2d_graph(imsegm_image2d *im, int32_t *edges_out, int edge_capaci
     imsegm_ctx *ctx = im->ctx;
     hipStream_t st = ctx->stream;
     const int K = im->n_labels;
-    if (K > 65536) {
-        set_error("adjacency bitmap supports at most 65536 labels");
+    if ((double)K * (double)K / 8.0 > 64e9) {         // K x K bitmap: 11 GB at the 3e5 supervoxels of config 5
+        set_error("adjacency bitmap: too many labels (K*K/8 bytes must stay below 64 GB)");
         return -1;
     }
     if (edge_capacity < 0) edge_capacity = 0;
@@ -840,7 +840,7 @@ int imsegm_image2d_get_response(imsegm_image2d *im, double *planes_out)
 int imsegm_volume_create(imsegm_ctx *ctx, int depth, int height, int width, imsegm_image2d **vol_out)
 {
     if (bind(ctx)) return -1;
-    if (depth <= 0 || height <= 0 || width <= 0 || (long)depth * height * width > 0x3fffffffL) {
+    if (depth <= 0 || height <= 0 || width <= 0 || (long)depth * height * width > 0x40000000L) {
         set_error("bad volume size");
         return -1;
     }
@@ -957,6 +957,19 @@ int imsegm_volume_slic(imsegm_image2d *im, int n_segments, double compactness, c
         s.grid_d[i] = (int)ax[i].step;
         s.grid_n[i] = (int)cnt[i];
     }
+    {
+        // brick lists: capacity = 4 x the expected number of windows meeting a brick, at least 64
+        s.nbz = cdiv(D, VOL_BZ); s.nby = cdiv(H, VOL_BY); s.nbx = cdiv(W, VOL_BX);
+        const size_t n_bricks = (size_t)s.nbz * s.nby * s.nbx;
+        const double per_brick = (double)K / (double)n * (std::min(D, VOL_BZ) + 4.0 * s.step_z + 1) *
+                                 (std::min(H, VOL_BY) + 4.0 * s.step_y + 1) * (std::min(W, VOL_BX) + 4.0 * s.step_x + 1);
+        s.brick_cap = (int)std::min<double>(std::max(64.0, 4.0 * per_brick), (double)K);
+        s.brick_cap = (s.brick_cap + 63) & ~63;
+        if (getenv("IMSEGM_BRICK_CAP")) s.brick_cap = std::max(1, atoi(getenv("IMSEGM_BRICK_CAP")));   // (tests: overflow path)
+        if (im->tiles.ensure(n_bricks * ((size_t)s.brick_cap + 1) * sizeof(int) + 256)) return -1;
+        s.brick_count = im->tiles.as<int>();
+        s.brick_list = s.brick_count + ((n_bricks + 63) & ~(size_t)63);
+    }
     int sp_all = ctx->begin(PG_SLIC);
     if (launch_vol_slic(s, im->labB.as<double>(), im->nearest.as<int32_t>(), max_iter, st)) return -1;
     int n_labels = K + start_label;
@@ -1056,8 +1069,8 @@ int imsegm_volume_graph(imsegm_image2d *im, int32_t *edges_out, int edge_capacit
     imsegm_ctx *ctx = im->ctx;
     hipStream_t st = ctx->stream;
     const int K = im->n_labels;
-    if (K > 65536) {
-        set_error("adjacency bitmap supports at most 65536 labels");
+    if ((double)K * (double)K / 8.0 > 64e9) {         // K x K bitmap: 11 GB at the 3e5 supervoxels of config 5
+        set_error("adjacency bitmap: too many labels (K*K/8 bytes must stay below 64 GB)");
         return -1;
     }
     if (edge_capacity < 0) edge_capacity = 0;

@@ -87,7 +87,14 @@ struct VolState {
     int *win;                       // [K][6] = zmin, zmax, ymin, ymax, xmin, xmax
     long long *acc;                 // [K][6] = n, sum z, sum y, sum x, (hi, lo) fixed-point value sum
     int grid_0[3], grid_d[3], grid_n[3];
+    // candidate lists per brick of VOL_BZ x VOL_BY x VOL_BX voxels, filled by the centroids themselves
+    // (k_vol_scatter): a wave of the assignment kernel only looks at the list of its brick
+    int nbz, nby, nbx;              // bricks per axis
+    int brick_cap;                  // entries per brick list
+    int *brick_count;               // [n_bricks] (may exceed brick_cap: that brick scans the whole table)
+    int *brick_list;                // [n_bricks][brick_cap]
 };
+constexpr int VOL_BX = 64, VOL_BY = 16, VOL_BZ = 16;
 int launch_vol_preprocess(const void *src, int dtype, double off, double scale, int D, int H, int W, const Taps &tz, const Taps &ty,
                           const Taps &tx, double ratio, double *bufA, double *bufB, hipStream_t st);
 int launch_vol_slic(VolState s, const double *vol, int32_t *labels, int max_iter, hipStream_t st);

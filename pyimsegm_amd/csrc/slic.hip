@@ -1157,7 +1157,21 @@ k_slic_assign_dot(SlicState s, const double *__restrict__ lab, int32_t *__restri
             continue;
         }
         if (best_s[r] <= -2) labels[p] = -(best_s[r] + 2);
-        if (ACCUM) s.leftover[atomicAdd(s.leftover_count, 1)] = p;
+        if (ACCUM) {
+            // no slot in the tile's list (tile without a list, or a pixel no window covers, which keeps its
+            // previous label): straight to the global sums -- rare
+            const int k = best_s[r] <= -2 ? -(best_s[r] + 2) : labels[p];
+            if (k >= 0) {
+                long long *a = s.acc + (size_t)k * 9;
+                long long hi, lo;
+                atomic_add_i64(a + 0, 1);
+                atomic_add_i64(a + 1, y);
+                atomic_add_i64(a + 2, x);
+                fix_split(pL[r], hi, lo); atomic_add_i64(a + 3, hi); atomic_add_i64(a + 4, lo);
+                fix_split(pA[r], hi, lo); atomic_add_i64(a + 5, hi); atomic_add_i64(a + 6, lo);
+                fix_split(pB[r], hi, lo); atomic_add_i64(a + 7, hi); atomic_add_i64(a + 8, lo);
+            }
+        }
     }
     PHASE_MARK(4)                                  // label stores
     if (!ACCUM) {
@@ -1285,7 +1299,7 @@ int launch_slic_iterations(SlicState s, const double *lab, const double *init_yx
         }
         if (prof.end) prof.end(prof.user, span);
         if (it + 1 < max_iter) {
-            hipLaunchKernelGGL(k_slic_leftover, 64, 256, 0, st, s, lab, labels);
+            if (!dot && !first_grid) hipLaunchKernelGGL(k_slic_leftover, 64, 256, 0, st, s, lab, labels);
             hipLaunchKernelGGL(k_centroid_finalize, cdiv(s.K, 256), 256, 0, st, s);
         }
     }

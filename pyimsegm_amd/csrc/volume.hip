@@ -131,10 +131,31 @@ __global__ void k_vol_centroid_finalize(VolState s)
     for (int j = 0; j < 6; ++j) a[j] = 0;
 }
 
+// every centroid appends itself to the list of each brick its search window meets (order irrelevant: the
+// assignment breaks ties on the centroid index explicitly)
+__global__ void __launch_bounds__(256) k_vol_scatter(VolState s)
+{
+    int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= s.K) return;
+    const int *w = s.win + (size_t)k * 6;
+    if (w[1] <= w[0] || w[3] <= w[2] || w[5] <= w[4]) return;       // dead centroid: empty window
+    const int bz0 = w[0] / VOL_BZ, bz1 = (w[1] - 1) / VOL_BZ;
+    const int by0 = w[2] / VOL_BY, by1 = (w[3] - 1) / VOL_BY;
+    const int bx0 = w[4] / VOL_BX, bx1 = (w[5] - 1) / VOL_BX;
+    for (int bz = bz0; bz <= bz1; ++bz)
+        for (int by = by0; by <= by1; ++by)
+            for (int bx = bx0; bx <= bx1; ++bx) {
+                const int b = (bz * s.nby + by) * s.nbx + bx;
+                const int pos = atomicAdd(&s.brick_count[b], 1);
+                if (pos < s.brick_cap) s.brick_list[(size_t)b * s.brick_cap + pos] = k;
+            }
+}
+
 // ---- assignment -----------------------------------------------------------------------------------------
-// One wave = 64 consecutive x, VROWS rows of one z slice.  The wave scans the centroid table in
-// ascending k, keeps the windows that meet its voxels in an LDS list (ballot compaction keeps the
-// order), and evaluates the list in chunks: ascending k + strict '>' == lowest index wins ties.
+// One wave = 64 consecutive x, VROWS rows of one z slice.  The wave scans the candidate list of its brick
+// (or, if that list overflowed, the whole centroid table), keeps the windows that meet its voxels in an
+// LDS list (ballot compaction) and evaluates the list in chunks; equal distances go to the lower centroid
+// index, which is what the ascending scan with a strict '>' of _slic.pyx yields.
 constexpr int VROWS = 4;
 constexpr int VLIST = 256;
 
@@ -165,12 +186,20 @@ k_vol_assign(VolState s, const double *__restrict__ vol, int32_t *__restrict__ l
     }
     const double fz = (double)z, fx = (double)x;
     int count = 0;
-    const int nblk = cdiv(s.K, 64);
+    static_assert(VOL_BX == 64 && VOL_BY == 4 * VROWS, "a workgroup lies inside one brick");
+    const int brick = ((z / VOL_BZ) * s.nby + (y0 / VOL_BY)) * s.nbx + blockIdx.x;
+    const int bcount = s.brick_count[brick];
+    const bool whole = bcount > s.brick_cap;                   // list overflow: scan every centroid
+    const int *__restrict__ blist = s.brick_list + (size_t)brick * s.brick_cap;
+    const int nscan = whole ? s.K : bcount;
+    const int nblk = cdiv(nscan, 64);
     for (int b = 0; b < nblk; ++b) {
         // scan 64 windows
-        int k = b * 64 + lane;
+        const int i = b * 64 + lane;
+        int k = 0;
         bool hit = false;
-        if (k < s.K) {
+        if (i < nscan) {
+            k = whole ? i : blist[i];
             const int *w = s.win + (size_t)k * 6;
             hit = z >= w[0] && z < w[1] && w[2] < y1w && w[3] > y0 && w[4] < x1w && w[5] > x0w;
         }
@@ -199,7 +228,7 @@ k_vol_assign(VolState s, const double *__restrict__ vol, int32_t *__restrict__ l
                 double d = (dz + dy + dx2) * s.spatial_weight;
                 const double t = pv[r] - cv;
                 d = d + t * t;
-                if (inx && best_d[r] > d) {
+                if (inx && (best_d[r] > d || (best_d[r] == d && ck < best_k[r]))) {
                     best_d[r] = d;
                     best_k[r] = ck;
                 }
@@ -247,7 +276,10 @@ int launch_vol_slic(VolState s, const double *vol, int32_t *labels, int max_iter
     HIP_TRY(hipMemsetAsync(labels, 0xff, n * sizeof(int32_t), st));
     hipLaunchKernelGGL(k_vol_centroid_init, cdiv(s.K, 256), 256, 0, st, s);
     dim3 grid(cdiv(s.W, 64), cdiv(s.H, 4 * VROWS) * s.D);
+    const size_t n_bricks = (size_t)s.nbz * s.nby * s.nbx;
     for (int it = 0; it < max_iter; ++it) {
+        HIP_TRY(hipMemsetAsync(s.brick_count, 0, n_bricks * sizeof(int), st));
+        hipLaunchKernelGGL(k_vol_scatter, cdiv(s.K, 256), 256, 0, st, s);
         if (it + 1 < max_iter) {
             hipLaunchKernelGGL(k_vol_assign<true>, grid, 256, 0, st, s, vol, labels);
             hipLaunchKernelGGL(k_vol_centroid_finalize, cdiv(s.K, 256), 256, 0, st, s);

@@ -65,6 +65,17 @@ def test_volume_slic_without_connectivity(hip, oracle):
     sess.close()
 
 
+def test_volume_slic_brick_list_overflow(hip, oracle, monkeypatch):
+    """bricks whose candidate list overflows scan the whole centroid table: same result"""
+    vol = _noisy_ellipsoid((20, 48, 70), seed=7)
+    ref = oracle.slic(vol, 300, 2, sigma=1, spacing=(1, 1, 1), multichannel=False)
+    monkeypatch.setenv('IMSEGM_BRICK_CAP', '3')
+    sess = hip.Volume3D(*vol.shape).upload(vol)
+    sess.slic(300, 2, sigma=1., spacing=(1, 1, 1))
+    assert np.array_equal(sess.get_labels(), ref)
+    sess.close()
+
+
 def test_segment_slic_img3d_gray_api(oracle):
     from pyimsegm_amd import superpixels as sp
     np.random.seed(0)
