@@ -123,6 +123,7 @@ def main():
     import queue
     import threading
     inflight = max(1, args.inflight)
+    do_gather = group.dist is not None            # launched by torchrun (also exercised with a single rank)
     todo = queue.Queue()
     done = queue.Queue()
     ready = threading.Barrier(inflight + 1)
@@ -141,7 +142,7 @@ def main():
             if item is None:
                 break
             step(model, session)
-            if world > 1:
+            if do_gather:
                 gathered = threading.Event()
                 done.put((session[0], gathered))
                 gathered.wait()                   # the label buffer is reused by the next step
@@ -166,7 +167,7 @@ def main():
         if item is None:
             finished += 1
             continue
-        if world > 1:
+        if do_gather:
             item[0].ctx.synchronize()
             group.gather_arrays(_hip.segm_device_array(item[0]), dst=0, keep_on_device=True)
             item[1].set()

@@ -31,6 +31,13 @@ WORKER = textwrap.dedent('''
     else:
         assert out is None
     assert seen == g.shard(5)
+    # several images of a rank in flight (worker threads): same sharding, same result order
+    out2 = segment_batch_sharded(images, lambda img: np.full(img.shape[:2], 10 * int(img[0, 0, 0]) + g.rank, dtype=np.int32),
+                                 g, nb_workers=3)
+    if g.rank == 0:
+        assert [int(o[0, 0]) for o in out2] == [0, 11, 20, 31, 40]
+    else:
+        assert out2 is None
     g.close()
 ''') % ROOT
 

@@ -209,3 +209,22 @@ def test_texture_on_device_matches_scipy(shape, bank, dtype):
     assert names[0] == 'tLM_sigma1.4-edge-ch1_mean'
     scale = np.abs(ref).max()
     assert np.max(np.abs(fts - ref)) < 1e-5 * max(scale, 1.0), np.max(np.abs(fts - ref))
+
+
+def test_images_in_flight_match_sequential():
+    """worker threads (one HIP stream each) keep several images in flight: same results as one at a time"""
+    from pyimsegm_amd import pipelines as pipe
+    from pyimsegm_amd.utilities.synthetic import voronoi_image
+    images = [voronoi_image(200, 260, seed=40 + i) for i in range(6)]
+    feats = {'color': ('mean', 'std', 'energy')}
+    np.random.seed(0)
+    model, fts_seq = pipe.estim_model_classes_group(images, 3, feats, sp_size=15, sp_regul=0.2, nb_workers=1)
+    np.random.seed(0)
+    _, fts_par = pipe.estim_model_classes_group(images, 3, feats, sp_size=15, sp_regul=0.2, nb_workers=3)
+    assert all(np.array_equal(a, b) for a, b in zip(fts_seq, fts_par))
+    seq = [pipe.segment_color2d_slic_features_model_graphcut(im, model, feats, sp_size=15, sp_regul=0.2, gc_regul=2.)[0]
+           for im in images]
+    par = pipe.segment_batch_color2d_slic_features_model_graphcut(images, model, feats, sp_size=15, sp_regul=0.2,
+                                                                  gc_regul=2., nb_workers=3)
+    assert len(par) == len(seq)
+    assert all(np.array_equal(a, b) for a, b in zip(seq, par))

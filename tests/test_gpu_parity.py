@@ -27,6 +27,8 @@ CASES = [
     ('vor512', lambda: voronoi_image(512, 512), 23, 0.2),         # has an oversize component
     ('vor_ragged', lambda: voronoi_image(301, 517, seed=3), 15, 0.3),
     ('float_img', lambda: np.random.default_rng(0).random((125, 150, 3)), 20, 0.2),
+    # BASELINE configs[3]: drosophila_ovary_slice-sized image with the driver's defaults (slic_size=35)
+    ('ovary_size', lambda: voronoi_image(647, 1024, seed=100), 35, 0.2),
 ]
 
 
