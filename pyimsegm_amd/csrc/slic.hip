@@ -232,12 +232,139 @@ k_blur_axis(const double *__restrict__ src, double *__restrict__ dst, int H, int
     dst[(size_t)plane * H * W + (size_t)y * W + x] = v;
 }
 
+// ---------------------------------------------------------------------------------------------
+// fused pre-processing: the three passes above in one kernel (same operations in the same order, so the
+// planes are bit-identical), 27 B/px of HBM traffic instead of 96.  A workgroup produces a 64 x 16 tile:
+// Lab (+ z tap) of the tile and its blur halo goes to LDS (the halo is converted redundantly, x1.7), the y
+// pass runs LDS -> LDS one channel at a time, the x pass LDS -> HBM with the final 1/compactness.
+// ---------------------------------------------------------------------------------------------
+constexpr int PF_TX = 64, PF_TY = 16, PF_MAXR = 8, PF_THREADS = 512;
+
+template <typename T>
+__global__ void __launch_bounds__(PF_THREADS)
+k_pre_fused(const T *__restrict__ img, int H, int W, int normalize, const double *__restrict__ minmax, Taps tz, Taps ty,
+            Taps tx, double ratio, double *__restrict__ out)
+{
+    extern __shared__ double pf_sm[];
+    __shared__ double lut[256];
+    const int tid = threadIdx.x;
+    const int ry = ty.r < 0 ? 0 : ty.r, rx = tx.r < 0 ? 0 : tx.r;
+    const int tw = PF_TX + 2 * rx, th = PF_TY + 2 * ry;
+    const unsigned int tw_magic = (unsigned int)((0x100000000ull + tw - 1) / tw);     // exact i / tw for i < 2^16
+    double *L1 = pf_sm;                                   // [3][th][tw]  Lab + z tap
+    double *L2 = pf_sm + (size_t)3 * th * tw;             // [PF_TY][tw]  y-blurred, one channel at a time
+    const bool norm = normalize == 1 || (normalize == 2 && (minmax[0] != 0.0 || minmax[1] != 1.0));
+    if (sizeof(T) == 1) {
+        // uint8 input: the sRGB linearisation collapses to a 256-entry table
+        if (tid < 256) {
+            const int v = tid;
+            double x;
+            if (norm) {
+                double vmin = minmax[0], range = minmax[1] - minmax[0];
+                x = (double)(uint8_t)(v - (int)vmin) / range;
+            } else {
+                x = (double)v * (1.0 / 255);
+            }
+            lut[v] = (x > 0.04045) ? det_pow24((x + 0.055) / 1.055) : x / 12.92;
+        }
+        __syncthreads();
+    }
+    const int x0 = blockIdx.x * PF_TX, y0 = blockIdx.y * PF_TY;
+    const size_t plane = (size_t)H * W;
+    for (int i = tid; i < th * tw; i += PF_THREADS) {
+        const int ly = (int)__umulhi((unsigned int)i, tw_magic), lx = i - ly * tw;
+        const int gy = reflect_idx(y0 + ly - ry, H), gx = reflect_idx(x0 + lx - rx, W);
+        const size_t p = (size_t)gy * W + gx;
+        double L, A, B;
+        if (sizeof(T) == 1) {
+            double lin0 = lut[(int)img[3 * p + 0]], lin1 = lut[(int)img[3 * p + 1]], lin2 = lut[(int)img[3 * p + 2]];
+            double X = lin0 * 0.412453 + lin1 * 0.357580 + lin2 * 0.180423;
+            double Y = lin0 * 0.212671 + lin1 * 0.715160 + lin2 * 0.072169;
+            double Z = lin0 * 0.019334 + lin1 * 0.119193 + lin2 * 0.950227;
+            double f[3] = { X / 0.95047, Y / 1.0, Z / 1.08883 };
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                double t = f[c];
+                f[c] = (t > 0.008856) ? det_cbrt(t) : 7.787 * t + 16.0 / 116.0;
+            }
+            L = (116.0 * f[1]) - 16.0;
+            A = 500.0 * (f[0] - f[1]);
+            B = 200.0 * (f[1] - f[2]);
+        } else {
+            double rgb[3];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                double v = (double)img[3 * p + c];
+                if (norm) v = (v - minmax[0]) / (minmax[1] - minmax[0]);
+                rgb[c] = v;
+            }
+            rgb2lab_px(rgb[0], rgb[1], rgb[2], L, A, B);
+        }
+        L1[i] = zblur_point(L, tz);
+        L1[th * tw + i] = zblur_point(A, tz);
+        L1[2 * th * tw + i] = zblur_point(B, tz);
+    }
+    __syncthreads();
+    const int ox = tid & 63, oy0 = tid >> 6;
+    for (int c = 0; c < 3; ++c) {
+        const double *s1 = L1 + (size_t)c * th * tw;
+        for (int i = tid; i < PF_TY * tw; i += PF_THREADS) {
+            const int oy = (int)__umulhi((unsigned int)i, tw_magic), lx = i - oy * tw;
+            const double *col = s1 + (oy + ry) * tw + lx;
+            double v;
+            if (ty.r < 0) {
+                v = col[0];
+            } else {
+                v = col[0] * ty.w[0];
+                for (int j = ty.r; j >= 1; --j) v += (col[-j * tw] + col[j * tw]) * ty.w[j];
+            }
+            L2[i] = v;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < PF_TY / (PF_THREADS / 64); ++q) {
+            const int oy = oy0 + (PF_THREADS / 64) * q;
+            const double *row = L2 + oy * tw + ox + rx;
+            double v;
+            if (tx.r < 0) {
+                v = row[0];
+            } else {
+                v = row[0] * tx.w[0];
+                for (int j = tx.r; j >= 1; --j) v += (row[-j] + row[j]) * tx.w[j];
+            }
+            v = v * ratio;
+            const int gy = y0 + oy, gx = x0 + ox;
+            if (gy < H && gx < W) out[(size_t)c * plane + (size_t)gy * W + gx] = v;
+        }
+        __syncthreads();
+    }
+}
+
 int launch_preprocess_color2d(const void *img, int dtype, int H, int W, int normalize, const double *minmax_dev,
                               const Taps &tz, const Taps &ty, const Taps &tx, double ratio, double *bufA,
                               double *bufB, hipStream_t st)
 {
     int n = H * W;
     int grid = cdiv(n, 256);
+    if (ty.r <= PF_MAXR && tx.r <= PF_MAXR && !getenv("IMSEGM_PRE_3PASS")) {
+        const int ry = ty.r < 0 ? 0 : ty.r, rx = tx.r < 0 ? 0 : tx.r;
+        const size_t lds = ((size_t)3 * (PF_TY + 2 * ry) + PF_TY) * (PF_TX + 2 * rx) * sizeof(double);
+        const void *fn = dtype == DT_U8 ? (const void *)k_pre_fused<uint8_t>
+                       : dtype == DT_F32 ? (const void *)k_pre_fused<float> : (const void *)k_pre_fused<double>;
+        HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        dim3 gf(cdiv(W, PF_TX), cdiv(H, PF_TY));
+        if (dtype == DT_U8)
+            hipLaunchKernelGGL(k_pre_fused<uint8_t>, gf, PF_THREADS, lds, st, (const uint8_t *)img, H, W, normalize, minmax_dev, tz, ty, tx,
+                               ratio, bufA);
+        else if (dtype == DT_F32)
+            hipLaunchKernelGGL(k_pre_fused<float>, gf, PF_THREADS, lds, st, (const float *)img, H, W, normalize, minmax_dev, tz, ty, tx,
+                               ratio, bufA);
+        else
+            hipLaunchKernelGGL(k_pre_fused<double>, gf, PF_THREADS, lds, st, (const double *)img, H, W, normalize, minmax_dev, tz, ty, tx,
+                               ratio, bufA);
+        HIP_TRY(hipGetLastError());
+        return 0;   // result in bufA
+    }
     if (dtype == DT_U8)
         hipLaunchKernelGGL(k_pre_lab_u8, grid, 256, 0, st, (const uint8_t *)img, n, normalize, minmax_dev, tz, bufA);
     else if (dtype == DT_F32)
