@@ -285,6 +285,76 @@ __device__ __forceinline__ double wave_reduce16_f64(const double (&v)[16])
     return d;
 }
 
+// sum eight doubles per lane over each 16-lane row: 4 + 2 + 1 transposed exchanges + 1 plain (DPP
+// row_mirror / row_half_mirror / quad_perm; no LDS traffic).  Returns, in every lane, the row total of the
+// value with index ((lane >> 3) & 1) * 4 + ((lane >> 2) & 1) * 2 + ((lane >> 1) & 1).
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double v)
+{
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)b, CTRL, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), CTRL, 0xf, 0xf, false);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+__device__ __forceinline__ double row16_reduce8_f64(const double (&v)[8], int lane)
+{
+    double a[4], b[2];
+    bool up = lane & 8;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const double send = up ? v[j] : v[j + 4], keep = up ? v[j + 4] : v[j];
+        a[j] = keep + dpp_f64<0x140>(send);                 // row_mirror: lane i <-> 15 - i
+    }
+    up = lane & 4;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const double send = up ? a[j] : a[j + 2], keep = up ? a[j + 2] : a[j];
+        b[j] = keep + dpp_f64<0x141>(send);                 // row_half_mirror: i <-> 7 - i
+    }
+    up = lane & 2;
+    const double send = up ? b[0] : b[1], keep = up ? b[1] : b[0];
+    double c = keep + dpp_f64<0x1b>(send);                  // quad_perm [3,2,1,0]: i <-> 3 - i
+    c += dpp_f64<0xb1>(c);                                  // quad_perm [1,0,3,2]: i <-> i ^ 1
+    return c;
+}
+
+// sixteen doubles per lane -> every lane of the 16-lane row ends up with the row total of value (lane & 15)
+__device__ __forceinline__ double row16_reduce16_f64(const double (&v)[16], int lane)
+{
+    double a[8], b[4], c[2];
+    bool up = lane & 8;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const double send = up ? v[j] : v[j + 8], keep = up ? v[j + 8] : v[j];
+        a[j] = keep + dpp_f64<0x140>(send);                 // row_mirror
+    }
+    up = lane & 4;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const double send = up ? a[j] : a[j + 4], keep = up ? a[j + 4] : a[j];
+        b[j] = keep + dpp_f64<0x141>(send);                 // row_half_mirror
+    }
+    up = lane & 2;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const double send = up ? b[j] : b[j + 2], keep = up ? b[j + 2] : b[j];
+        c[j] = keep + dpp_f64<0x1b>(send);                  // quad_perm [3,2,1,0]
+    }
+    up = lane & 1;
+    const double send = up ? c[0] : c[1], keep = up ? c[1] : c[0];
+    return keep + dpp_f64<0xb1>(send);                      // quad_perm [1,0,3,2]
+}
+
+// minimum of an int over each 16-lane row (all lanes get it)
+__device__ __forceinline__ int row16_min_i32(int v)
+{
+    v = min(v, __builtin_amdgcn_update_dpp(0, v, 0x140, 0xf, 0xf, false));
+    v = min(v, __builtin_amdgcn_update_dpp(0, v, 0x141, 0xf, 0xf, false));
+    v = min(v, __builtin_amdgcn_update_dpp(0, v, 0x1b, 0xf, 0xf, false));
+    v = min(v, __builtin_amdgcn_update_dpp(0, v, 0xb1, 0xf, 0xf, false));
+    return v;
+}
+
 __device__ __forceinline__ void atomic_add_i64(long long *p, long long v)
 {
     atomicAdd(reinterpret_cast<unsigned long long *>(p), (unsigned long long)v);

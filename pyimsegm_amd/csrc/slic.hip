@@ -970,39 +970,6 @@ k_slic_assign(SlicState s, const double *__restrict__ lab, int32_t *__restrict__
 // lbt > W ends the loop: it and all later ones can neither win nor come within the margin anywhere in the wave.
 typedef float f2 __attribute__((ext_vector_type(2)));
 
-// sum eight doubles per lane over each 16-lane row: 4 + 2 + 1 transposed exchanges + 1 plain (DPP
-// row_mirror / row_half_mirror / quad_perm; no LDS traffic).  Returns, in every lane, the row total of the
-// value with index ((lane >> 3) & 1) * 4 + ((lane >> 2) & 1) * 2 + ((lane >> 1) & 1).
-template <int CTRL>
-__device__ __forceinline__ double dpp_f64(double v)
-{
-    const long long b = __double_as_longlong(v);
-    const int lo = __builtin_amdgcn_update_dpp(0, (int)b, CTRL, 0xf, 0xf, false);
-    const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), CTRL, 0xf, 0xf, false);
-    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
-}
-__device__ __forceinline__ double row16_reduce8_f64(const double (&v)[8], int lane)
-{
-    double a[4], b[2];
-    bool up = lane & 8;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const double send = up ? v[j] : v[j + 4], keep = up ? v[j + 4] : v[j];
-        a[j] = keep + dpp_f64<0x140>(send);                 // row_mirror: lane i <-> 15 - i
-    }
-    up = lane & 4;
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const double send = up ? a[j] : a[j + 2], keep = up ? a[j + 2] : a[j];
-        b[j] = keep + dpp_f64<0x141>(send);                 // row_half_mirror: i <-> 7 - i
-    }
-    up = lane & 2;
-    const double send = up ? b[0] : b[1], keep = up ? b[1] : b[0];
-    double c = keep + dpp_f64<0x1b>(send);                  // quad_perm [3,2,1,0]: i <-> 3 - i
-    c += dpp_f64<0xb1>(c);                                  // quad_perm [1,0,3,2]: i <-> i ^ 1
-    return c;
-}
-
 // (profiling aid) cycles between successive marks of every wave, summed per phase
 #define PHASE_MARK(j)                                                                              \
     if (s.phase_prof) {                                                                            \

@@ -15,8 +15,7 @@
 
 namespace imsegm {
 
-constexpr int ST_PX = 4;          // consecutive pixels per lane
-constexpr int ST_ROWS = 16;       // rows per workgroup (4 per wave)
+constexpr int ST_ROWS = 4;        // rows per lane: a wave covers 64 x 4 pixels, a workgroup 64 x 16
 constexpr int ST_SLOTS = 64;      // LDS hash slots (distinct labels per workgroup tile)
 
 // fixed point with a caller-chosen scale: v * 2^sh = hi + lo * 2^-32
@@ -40,7 +39,13 @@ struct StatParams {
     double mul, div;              //    (descriptors.py:1094 `(response * (log(1 + norm) / 0.03)) / norm`)
 };
 
-// NV = number of accumulated quantities per channel group: PASS 1 -> n + 3 x (v, v*v); PASS 2 -> 3 x (v - m)^2
+// PASS 1 -> n + 3 x (v, v*v); PASS 2 -> 3 x (v - m)^2.
+// One pixel column per lane and ST_ROWS rows; every 16-lane row of the wave (a 16 x 4 pixel block, 1.5
+// distinct labels on average) works on the smallest label still pending in it, so a wave needs about two
+// passes.  Per pass the partial sums of a lane (fixed-point limbs kept as integer-valued doubles, exact:
+// |limb| * 64 pixels < 2^53 by the choice of the scales) go through one transposed DPP reduction over the
+// 16 lanes, after which lane j of the row owns the total of quantity j and adds it to the workgroup's LDS
+// slot of the label (open addressing; a full table falls back to global atomics).
 template <typename T, int PASS>
 __global__ void __launch_bounds__(256)
 k_color_stats(const T *__restrict__ img, const int32_t *__restrict__ labels, StatParams sp,
@@ -55,98 +60,89 @@ k_color_stats(const T *__restrict__ img, const int32_t *__restrict__ labels, Sta
         for (int j = 0; j < NQ; ++j) lacc[tid][j] = 0;
     }
     __syncthreads();
-    const int x0 = (blockIdx.x * 64 + lane) * ST_PX;
-    for (int rr = 0; rr < ST_ROWS / 4; ++rr) {
-        const int y = blockIdx.y * ST_ROWS + wave * (ST_ROWS / 4) + rr;
-        int lab[ST_PX];
-        float v[ST_PX][3];
+    const int x = blockIdx.x * 64 + lane;
+    const int y0 = (blockIdx.y * 4 + wave) * ST_ROWS;
+    int lab[ST_ROWS];
+    float v[ST_ROWS][3];
 #pragma unroll
-        for (int i = 0; i < ST_PX; ++i) {
-            int x = x0 + i;
-            bool ok = (y < sp.H) && (x < sp.W);
-            size_t p = ok ? (size_t)y * sp.W + x : 0;
-            lab[i] = ok ? labels[p] : -1;
+    for (int r = 0; r < ST_ROWS; ++r) {
+        const int y = y0 + r;
+        const bool ok = (y < sp.H) && (x < sp.W);
+        const size_t p = ok ? (size_t)y * sp.W + x : 0;
+        lab[r] = ok ? labels[p] : 0x7fffffff;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const size_t idx = sp.planar ? (size_t)c * sp.plane_stride + p : 3 * p + c;
+            v[r][c] = sp.prescale ? (float)(((double)img[idx] * sp.mul) / sp.div) : load_f32(img, idx);
+        }
+    }
+    while (true) {
+        int mine = 0x7fffffff;
+#pragma unroll
+        for (int r = 0; r < ST_ROWS; ++r) mine = min(mine, lab[r]);
+        if (!__any(mine != 0x7fffffff)) break;
+        const int k = row16_min_i32(mine);              // uniform over the 16-lane row; 0x7fffffff: row is done
+        // partial sums of this lane: PASS 1 -> q[0..5] sums of v, q[6..11] sums of v*v, q[12] count
+        //                            PASS 2 -> q[0..5] sums of (v - mean32)^2
+        constexpr int NV = (PASS == 1) ? 16 : 8;
+        double q[NV];
+#pragma unroll
+        for (int j = 0; j < NV; ++j) q[j] = 0;
+#pragma unroll
+        for (int r = 0; r < ST_ROWS; ++r) {
+            if (lab[r] != k || k == 0x7fffffff) continue;
+            lab[r] = 0x7fffffff;
+            if (PASS == 1) q[12] += 1.0;
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
-                const size_t idx = sp.planar ? (size_t)c * sp.plane_stride + p : 3 * p + c;
-                v[i][c] = sp.prescale ? (float)(((double)img[idx] * sp.mul) / sp.div) : load_f32(img, idx);
+                double t, h;
+                if (PASS == 1) {
+                    float val = v[r][c];
+                    float sq = __fmul_rn(val, val);
+                    t = (double)val * sp.scale_v; h = trunc(t);
+                    q[2 * c] += h; q[2 * c + 1] += trunc((t - h) * 4294967296.0);
+                    t = (double)sq * sp.scale_e; h = trunc(t);
+                    q[6 + 2 * c] += h; q[6 + 2 * c + 1] += trunc((t - h) * 4294967296.0);
+                } else {
+                    float d = __fsub_rn(v[r][c], mean32[3 * k + c]);
+                    float sq = __fmul_rn(d, d);
+                    t = (double)sq * sp.scale_e; h = trunc(t);
+                    q[2 * c] += h; q[2 * c + 1] += trunc((t - h) * 4294967296.0);
+                }
             }
         }
-        // one pass per distinct label in the wave
-        while (true) {
-            int first = -1;
-#pragma unroll
-            for (int i = ST_PX - 1; i >= 0; --i)
-                if (lab[i] >= 0) first = lab[i];
-            unsigned long long vote = __ballot(first >= 0);
-            if (!vote) break;
-            int k = __shfl(first, __ffsll((long long)vote) - 1, 64);
-            // partial sums of this lane: PASS 1 -> q[0..5] sums of v, q[6..11] sums of v*v, q[12] count
-            //                            PASS 2 -> q[0..5] sums of (v - mean32)^2
-            // The fixed-point limbs are kept as integer-valued doubles (|limb| * pixels-per-wave < 2^53 by
-            // the choice of the scales), so the per-lane and per-wave sums are exact in fp64 and only
-            // the owner lane converts its total to int64 -- no 64-bit integer conversions per pixel.
-            constexpr int NV = (PASS == 1) ? 16 : 8;
-            double q[NV];
-#pragma unroll
-            for (int j = 0; j < NV; ++j) q[j] = 0;
-#pragma unroll
-            for (int i = 0; i < ST_PX; ++i) {
-                if (lab[i] != k) continue;
-                lab[i] = -1;
-                if (PASS == 1) q[12] += 1.0;
-#pragma unroll
-                for (int c = 0; c < 3; ++c) {
-                    double t, h;
-                    if (PASS == 1) {
-                        float val = v[i][c];
-                        float sq = __fmul_rn(val, val);
-                        t = (double)val * sp.scale_v; h = trunc(t);
-                        q[2 * c] += h; q[2 * c + 1] += trunc((t - h) * 4294967296.0);
-                        t = (double)sq * sp.scale_e; h = trunc(t);
-                        q[6 + 2 * c] += h; q[6 + 2 * c + 1] += trunc((t - h) * 4294967296.0);
-                    } else {
-                        float d = __fsub_rn(v[i][c], mean32[3 * k + c]);
-                        float sq = __fmul_rn(d, d);
-                        t = (double)sq * sp.scale_e; h = trunc(t);
-                        q[2 * c] += h; q[2 * c + 1] += trunc((t - h) * 4294967296.0);
-                    }
-                }
+        long long tot;
+        int j;
+        bool owner;
+        if (PASS == 1) {
+            tot = (long long)row16_reduce16_f64(reinterpret_cast<const double (&)[16]>(q), lane);
+            j = lane & 15;
+            owner = j < 13;
+        } else {
+            tot = (long long)row16_reduce8_f64(reinterpret_cast<const double (&)[8]>(q), lane);
+            j = ((lane >> 3) & 1) * 4 + ((lane >> 2) & 1) * 2 + ((lane >> 1) & 1);
+            owner = (lane & 1) == 0 && j < 6;
+        }
+        // LDS open-addressing slot of the row's label (found by the first lane of the row)
+        int slot = -1;
+        if ((lane & 15) == 0 && k != 0x7fffffff) {
+            int sidx = k & (ST_SLOTS - 1), probes = 0;
+            while (probes < ST_SLOTS) {
+                int old = atomicCAS(&keys[sidx], -1, k);
+                if (old == -1 || old == k) break;
+                sidx = (sidx + 1) & (ST_SLOTS - 1);
+                ++probes;
             }
-            // transposed wave reduction: lane (64 / NV) * j ends up with the total of q[j]
-            long long tot;
-            int j;
-            bool owner;
-            if (PASS == 1) {
-                tot = (long long)wave_reduce16_f64(reinterpret_cast<const double (&)[16]>(q));
-                j = lane >> 2;
-                owner = (lane & 3) == 0 && j < 13;
-            } else {
-                tot = (long long)wave_reduce8_f64(reinterpret_cast<const double (&)[8]>(q));
-                j = lane >> 3;
-                owner = (lane & 7) == 0 && j < 6;
-            }
-            // LDS open-addressing slot for label k (found by lane 0); full table -> global memory
-            int slot = -1;
-            if (lane == 0) {
-                int sidx = k & (ST_SLOTS - 1), probes = 0;
-                while (probes < ST_SLOTS) {
-                    int old = atomicCAS(&keys[sidx], -1, k);
-                    if (old == -1 || old == k) break;
-                    sidx = (sidx + 1) & (ST_SLOTS - 1);
-                    ++probes;
-                }
-                slot = probes < ST_SLOTS ? sidx : -1;
-            }
-            slot = __shfl(slot, 0, 64);
-            if (owner && tot != 0) {
-                // accumulator columns: [0] count, [1..6] value sums, [7..12] squared / variance sums
-                int col = (PASS == 1) ? (j == 12 ? 0 : 1 + j) : j;
-                if (slot >= 0)
-                    atomic_add_i64(&lacc[slot][col], tot);
-                else
-                    atomic_add_i64(acc + (size_t)k * 13 + ((PASS == 1) ? col : 7 + col), tot);
-            }
+            slot = probes < ST_SLOTS ? sidx : -1;
+        }
+        slot = __shfl(slot, lane & 48, 64);
+        if (owner && tot != 0 && k != 0x7fffffff) {
+            // accumulator columns: [0] count, [1..6] value sums, [7..12] squared / variance sums
+            int col = (PASS == 1) ? (j == 12 ? 0 : 1 + j) : j;
+            if (slot >= 0)
+                atomic_add_i64(&lacc[slot][col], tot);
+            else
+                atomic_add_i64(acc + (size_t)k * 13 + ((PASS == 1) ? col : 7 + col), tot);
         }
     }
     __syncthreads();
@@ -203,7 +199,7 @@ template <typename T>
 static void launch_pass(int pass, const T *img, const int32_t *labels, StatParams sp, const float *mean32,
                         long long *acc, hipStream_t st)
 {
-    dim3 grid(cdiv(sp.W, 64 * ST_PX), cdiv(sp.H, ST_ROWS));
+    dim3 grid(cdiv(sp.W, 64), cdiv(sp.H, 4 * ST_ROWS));
     if (pass == 1)
         hipLaunchKernelGGL((k_color_stats<T, 1>), grid, 256, 0, st, img, labels, sp, mean32, acc);
     else
