@@ -243,3 +243,34 @@ def test_slic_exact_path_matches_fast_path(hip, oracle):
     exact = im.get_labels()
     im.slic(n_seg, compact, sigma=1., normalize=2)      # data spans [0, 1] only approximately -> scaled
     assert np.array_equal(exact, ref)
+
+
+def test_slic_randomised_sweep(hip, oracle):
+    """seeded sweep over image kinds (piecewise, uint8 noise, float noise, smooth), sizes, superpixel sizes and
+    compactness from 0.09 to 400: the fp32 pre-selection with its margin, the sorted break and the exact
+    near-tie path must reproduce the oracle bit for bit everywhere"""
+    rng = np.random.default_rng(2024)
+    for case in range(16):
+        H, W = int(rng.integers(40, 300)), int(rng.integers(40, 400))
+        kind = case % 4
+        if kind == 0:
+            img = voronoi_image(H, W, seed=int(rng.integers(1 << 30)))
+        elif kind == 1:
+            img = rng.integers(0, 256, (H, W, 3), dtype=np.uint8)
+        elif kind == 2:
+            img = rng.random((H, W, 3))
+        else:
+            yy, xx = np.mgrid[:H, :W]
+            img = np.stack([np.sin(yy / 7.0) * 0.5 + 0.5, np.cos(xx / 11.0) * 0.5 + 0.5, (yy + xx) / (H + W)], axis=-1)
+        sp = int(rng.integers(5, 40))
+        regul = float(rng.choice([0.02, 0.1, 0.2, 0.5, 1.0, 3.0]))
+        n_seg, compact = _params(img, sp, regul)
+        if n_seg < 1:
+            continue
+        ref = oracle.segment_slic_img2d(img, sp, regul)
+        im = hip.Image2D(H, W).upload(img)
+        im.slic(n_seg, compact, sigma=1., normalize=2)
+        got = im.get_labels()
+        im.close()
+        assert np.array_equal(got, ref), 'case %d kind %d %dx%d sp %d regul %g: %d px differ' % (
+            case, kind, H, W, sp, regul, np.count_nonzero(got != ref))
