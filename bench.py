@@ -41,6 +41,7 @@ def parse_args():
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--size', type=int, default=HEIGHT, help='image edge (default: the BASELINE 2048)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--switch-interval', type=float, default=None, help='sys.setswitchinterval for the worker threads')
     ap.add_argument('--inflight', type=int, default=3,
                     help='images in flight per GPU (worker threads, one HIP stream each; the reference runs a '
                          'pool of nb_workers processes over the images)')
@@ -90,6 +91,11 @@ def cpu_baseline(image, model):
 
 def main():
     args = parse_args()
+    try:    # the host stages multiply 2025 x 9 matrices: one BLAS thread each, N ranks x M worker threads share the node
+        from threadpoolctl import threadpool_limits
+        threadpool_limits(limits=1)
+    except Exception:
+        pass
     from pyimsegm_amd.distributed import Group
     group = Group()                      # torch.distributed (RCCL) only when launched by torchrun
     world, rank = group.world, group.rank
@@ -123,6 +129,8 @@ def main():
     import queue
     import threading
     inflight = max(1, args.inflight)
+    if args.switch_interval:
+        sys.setswitchinterval(args.switch_interval)
     do_gather = group.dist is not None            # launched by torchrun (also exercised with a single rank)
     todo = queue.Queue()
     done = queue.Queue()
