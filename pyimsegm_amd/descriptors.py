@@ -442,7 +442,8 @@ def compute_image3d_gray_statistic(image, segm, feature_flags=NAMES_FEATURE_FLAG
     _check_gray_image_segm(image, segm)
     if not list(feature_flags):
         raise ValueError('some features has to be selected')
-    image = np.nan_to_num(image)
+    if sess is None or 'median' in feature_flags or 'meanGrad' in feature_flags:
+        image = np.nan_to_num(image)       # (a resident session already holds the caller-checked finite volume)
     features = []
     want = [f in feature_flags for f in ('mean', 'energy', 'std')]
     if any(want):

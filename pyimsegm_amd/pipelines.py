@@ -279,7 +279,7 @@ def pipe_gray3d_slic_features_model_graphcut(
     logging.info('extract segments/superpixels features.')
     slic = None
     resident = set(dict_features) == {'color'} and set(dict_features['color']) <= {'mean', 'std', 'energy'} \
-        and (image.dtype.kind != 'f' or bool(np.isfinite(image).all()))
+        and (image.dtype.kind != 'f' or bool(np.isfinite(image.sum(dtype=np.float64))))    # one pass, no temporaries
     if resident:
         features, _ = compute_selected_features_gray3d(image, _ShapeOnly(sess.shape), dict_features, sess=sess)
     else:

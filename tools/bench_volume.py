@@ -52,6 +52,34 @@ def main():
               '%.1f Mvoxel/s through SLIC' % (rep, (t1 - t0) * 1e3, k0, (t2 - t1) * 1e3, k, (t3 - t2) * 1e3,
                                               (t4 - t3) * 1e3, len(edges), n / (t1 - t0) / 1e6))
     if n <= 2**24 or '--pipeline' in sys.argv:
+        # the stages of pipe_gray3d_slic_features_model_graphcut (pipelines.py:382-431) with a clock on each
+        from pyimsegm_amd import graph_cuts as gc
+        from pyimsegm_amd.descriptors import compute_selected_features_gray3d, norm_features
+        from pyimsegm_amd.pipelines import _ShapeOnly
+        from pyimsegm_amd.superpixels import _open_volume, _run_slic3d
+        marks = [('start', time.perf_counter())]
+
+        def mark(name):
+            ctx.synchronize()
+            marks.append((name, time.perf_counter()))
+
+        np.random.seed(0)
+        sess2 = _open_volume(vol); mark('upload')
+        _run_slic3d(sess2, sp, 0.2, (1, 1, 1)); mark('slic + label')
+        feats, _ = compute_selected_features_gray3d(vol, _ShapeOnly(sess2.shape), {'color': ['mean', 'std', 'energy']}, sess=sess2)
+        feats[np.isnan(feats)] = 0
+        feats, _ = norm_features(feats); mark('features')
+        model = gc.estim_class_model(feats, 3); mark('GMM fit (host)')
+        proba = model.predict_proba(feats); mark('predict_proba (host)')
+        edges, weights = gc.compute_edge_weights(_ShapeOnly(sess2.shape), vol, feats, proba, 'model', _session=sess2); mark('graph + edge weights')
+        unary = gc.compute_unary_cost(proba)
+        pairwise = gc.compute_pairwise_cost(0.1, proba.shape)
+        labels = gc.cut_general_graph(edges, weights, unary, pairwise, n_iter=-1); mark('graph cut')
+        segm, _ = sess2.gather(labels); mark('gather + D2H')
+        print('pipeline stages: ' + ' | '.join('%s %.0f ms' % (b[0], (b[1] - a[1]) * 1e3) for a, b in zip(marks, marks[1:])) +
+              ' | total %.0f ms; K %d, E %d, classes %r' % ((marks[-1][1] - marks[0][1]) * 1e3, len(feats), len(edges), np.bincount(segm.ravel())))
+        return
+    if n <= 2**24 or '--pipeline' in sys.argv:
         t0 = time.perf_counter()
         np.random.seed(0)
         segm = pipelines.pipe_gray3d_slic_features_model_graphcut(vol, 3, {'color': ['mean', 'std', 'energy']},
