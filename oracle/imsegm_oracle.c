@@ -21,13 +21,16 @@
  *     (superpixels.py:32-40 asserts shapes only)  =>  PARITY UNPINNED for the SLIC label map.
  *     The Gaussian blur step IS pinned bit-exactly against scipy.ndimage.gaussian_filter
  *     (scipy is installed) in tests/test_oracle_slic.py.
- *     Two conscious, documented deviations from skimage's floating-point arithmetic (both at
- *     the 1e-16 relative level, needed so that a massively parallel device implementation can
- *     be bit-identical to this oracle):
+ *     Two conscious, documented deviations from skimage's floating-point arithmetic (needed so
+ *     that a massively parallel device implementation can be bit-identical to this oracle):
  *       (1) x^2.4 and cbrt are evaluated with the deterministic division-free Newton routines
- *           below (only + - * and exact bit operations) instead of libm pow/cbrt;
- *       (2) the centroid colour sums are exact fixed-point sums (order independent) instead of
- *           the raster-order running fp64 sum of _slic.pyx.
+ *           below (only + - * and exact bit operations) instead of libm pow/cbrt (<= 6 ulp);
+ *       (2) the centroid colour sums are order-independent exact sums of the values in 2^-f fixed
+ *           point (f >= 44 for |value| < 4, see orc_fix_bits) instead of the raster-order running
+ *           fp64 sum of _slic.pyx: per-pixel truncation < 2^-44 of the value range, the size of
+ *           the rounding noise of that running sum itself.
+ *     The control flow of the sweeps and of the connectivity pass is checked against a literal
+ *     pure-Python restatement of _slic.pyx in tests/test_oracle_slic.py.
  *
  * Build: see oracle/Makefile (gcc -O2 -ffp-contract=off, no -ffast-math).
  */
@@ -217,16 +220,6 @@ ORC_API void orc_slic_preprocess_gray3d(const double *img, int D, int H, int W,
     for (size_t p = 0; p < n; ++p) out[p] = out[p] * ratio;
 }
 
-/* exact order-independent fixed-point split of a double: v*2^30 = hi + lo*2^-32 (+ dropped bits) */
-static inline void fix_split(double v, int64_t *hi, int64_t *lo)
-{
-    double t = v * 1073741824.0;            /* 2^30, exact scaling */
-    int64_t h = (int64_t)t;                 /* truncation toward zero */
-    double r = t - (double)h;               /* exact, |r| < 1 */
-    *hi = h;
-    *lo = (int64_t)(r * 4294967296.0);      /* 2^32 */
-}
-
 static inline double i64_to_double(int64_t v)
 {
     /* (double)(int32 high) * 2^32 + (double)(uint32 low): one rounding, round-to-nearest-even */
@@ -235,18 +228,30 @@ static inline double i64_to_double(int64_t v)
     return (double)h * 4294967296.0 + (double)l;
 }
 
-static inline double fix_join(int64_t hi, int64_t lo)
-{
-    double s = i64_to_double(hi) + i64_to_double(lo) * (1.0 / 4294967296.0);
-    return s * (1.0 / 1073741824.0);
-}
-
 /* _slic_cython (skimage/segmentation/_slic.pyx, 0.18) for C channels planar, D x H x W.
  *   centroids : K x (3 + C) row-major [z, y, x, c0..]; colour part must be zero on entry
  *               (slic_superpixels.py concatenates zeros); updated in place
  *   nearest   : D*H*W int32 out (start_label NOT added)
  *   dead centroids (no pixel) keep a NaN position in skimage and never match again; here they
  *   are flagged by count == 0 and skipped (same observable behaviour on x86). */
+/* Fixed-point format of the centroid colour sums: value * 2^f truncated toward zero, with
+ * f = 46 - e where 2^e > max |pre-processed value| (frexp exponent; f as for 1.0 if the image is all zero).
+ * The sum of those integers is exact and order-independent (128-bit accumulator here, int64 partial sums
+ * + two int64 limbs on the GPU); it differs from the true sum by less than n * 2^-f, i.e. by less than
+ * 2^-44 relative to the value range per pixel -- the size of the rounding noise of the reference's own
+ * sequential fp64 accumulation (_slic.pyx adds pixel after pixel into a double). */
+ORC_API int orc_fix_bits(const double *img, size_t count)
+{
+    double m = 0.0;
+    for (size_t i = 0; i < count; ++i) {
+        double a = fabs(img[i]);
+        if (a > m) m = a;
+    }
+    int e = 1;
+    if (m > 0.0) (void)frexp(m, &e);            /* m = frac * 2^e, 0.5 <= frac < 1  ->  m < 2^e */
+    return 46 - e;
+}
+
 ORC_API void orc_slic_iterate(const double *img, int C, int D, int H, int W, int K,
                               double *centroids, int step_z, int step_y, int step_x, double step,
                               const double spacing[3], int max_iter, int32_t *nearest)
@@ -256,11 +261,12 @@ ORC_API void orc_slic_iterate(const double *img, int C, int D, int H, int W, int
     double *distance = (double *)malloc(n * sizeof(double));
     int64_t *cnt = (int64_t *)calloc(K, sizeof(int64_t));
     int64_t *csum = (int64_t *)calloc((size_t)K * 3, sizeof(int64_t));
-    int64_t *fhi = (int64_t *)calloc((size_t)K * C, sizeof(int64_t));
-    int64_t *flo = (int64_t *)calloc((size_t)K * C, sizeof(int64_t));
+    __int128 *fsum = (__int128 *)calloc((size_t)K * C, sizeof(__int128));
     uint8_t *dead = (uint8_t *)calloc(K, 1);
     double sz = spacing[0], sy = spacing[1], sx = spacing[2];
     double spatial_weight = 1.0 / (step * step);
+    const int fbits = orc_fix_bits(img, n * (size_t)C);
+    const double fscale = ldexp(1.0, fbits), finv = ldexp(1.0, -fbits);
     for (size_t p = 0; p < n; ++p) nearest[p] = -1;
 
     for (int it = 0; it < max_iter; ++it) {
@@ -306,8 +312,7 @@ ORC_API void orc_slic_iterate(const double *img, int C, int D, int H, int W, int
         /* recompute centres: integer coordinate sums are exact; colour sums are exact fixed point */
         memset(cnt, 0, K * sizeof(int64_t));
         memset(csum, 0, (size_t)K * 3 * sizeof(int64_t));
-        memset(fhi, 0, (size_t)K * C * sizeof(int64_t));
-        memset(flo, 0, (size_t)K * C * sizeof(int64_t));
+        memset(fsum, 0, (size_t)K * C * sizeof(__int128));
         for (int z = 0; z < D; ++z)
             for (int y = 0; y < H; ++y)
                 for (int x = 0; x < W; ++x) {
@@ -316,12 +321,8 @@ ORC_API void orc_slic_iterate(const double *img, int C, int D, int H, int W, int
                     if (k < 0) continue;
                     cnt[k] += 1;
                     csum[3 * k + 0] += z; csum[3 * k + 1] += y; csum[3 * k + 2] += x;
-                    for (int c = 0; c < C; ++c) {
-                        int64_t hi, lo;
-                        fix_split(img[(size_t)c * n + p], &hi, &lo);
-                        fhi[(size_t)k * C + c] += hi;
-                        flo[(size_t)k * C + c] += lo;
-                    }
+                    for (int c = 0; c < C; ++c)
+                        fsum[(size_t)k * C + c] += (__int128)(int64_t)trunc(img[(size_t)c * n + p] * fscale);
                 }
         for (int k = 0; k < K; ++k) {
             double *seg = centroids + (size_t)k * F;
@@ -332,11 +333,15 @@ ORC_API void orc_slic_iterate(const double *img, int C, int D, int H, int W, int
             }
             double nn = (double)cnt[k];
             for (int c = 0; c < 3; ++c) seg[c] = (double)csum[3 * k + c] / nn;
-            for (int c = 0; c < C; ++c)
-                seg[3 + c] = fix_join(fhi[(size_t)k * C + c], flo[(size_t)k * C + c]) / nn;
+            for (int c = 0; c < C; ++c) {
+                /* canonical split  sum = hi * 2^24 + lo,  0 <= lo < 2^24;  both parts are exact doubles */
+                __int128 t = fsum[(size_t)k * C + c];
+                int64_t hi = (int64_t)(t >> 24), lo = (int64_t)(t & 0xffffff);
+                seg[3 + c] = ((i64_to_double(hi) * 16777216.0 + (double)lo) * finv) / nn;
+            }
         }
     }
-    free(distance); free(cnt); free(csum); free(fhi); free(flo); free(dead);
+    free(distance); free(cnt); free(csum); free(fsum); free(dead);
 }
 
 /* _enforce_label_connectivity_cython (skimage/segmentation/_slic.pyx, 0.18), literal restatement.

@@ -419,8 +419,9 @@ int imsegm_image2d_slic(imsegm_image2d *im, int minmax_normalize, int n_segments
     int sp_all = ctx->begin(PG_SLIC);
     int sp = ctx->begin(PG_PRE);
     if (launch_minmax(im->img.p, im->dtype, n * 3, keys, minmax, st)) return -1;
+    double *premax = minmax + 2;                          // max |pre-processed value|, written on the device
     if (launch_preprocess_color2d(im->img.p, im->dtype, H, W, minmax_normalize, minmax, tz, ty, tx, 1.0 / compactness,
-                                  im->labA.as<double>(), im->labB.as<double>(), st))
+                                  im->labA.as<double>(), im->labB.as<double>(), premax, st))
         return -1;
     ctx->end(sp);
 
@@ -429,6 +430,7 @@ int imsegm_image2d_slic(imsegm_image2d *im, int minmax_normalize, int n_segments
     s.step_y = axk[1].all ? 1 : (int)axk[1].step;
     s.step_x = axk[2].all ? 1 : (int)axk[2].step;
     s.spatial_weight = 1.0 / ((double)step * (double)step);
+    s.premax = premax;
     s.debug = getenv("IMSEGM_DEBUG_ASSIGN") ? atoi(getenv("IMSEGM_DEBUG_ASSIGN")) : 0;
     s.phase_prof = nullptr;
     static long long *phase_buf = nullptr;
@@ -941,7 +943,11 @@ int imsegm_volume_slic(imsegm_image2d *im, int n_segments, double compactness, c
     if (launch_vol_preprocess(im->img.p, im->dtype, im->vol_off, im->vol_scale, D, H, W, tz, ty, tx, 1.0 / compactness, im->labA.as<double>(),
                               im->labB.as<double>(), st))
         return -1;
+    if (im->small.ensure(4096)) return -1;
+    double *premax = reinterpret_cast<double *>(im->small.as<unsigned char>() + 64);
+    if (launch_absmax_f64(im->labB.as<double>(), n, premax, st)) return -1;
     VolState s;
+    s.premax = premax;
     s.D = D; s.H = H; s.W = W; s.K = K;
     s.step_z = axk[0].all ? 1 : (int)axk[0].step;
     s.step_y = axk[1].all ? 1 : (int)axk[1].step;

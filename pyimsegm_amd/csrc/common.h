@@ -84,28 +84,31 @@ __device__ __forceinline__ void rgb2lab_px(double r, double g, double b, double 
 }
 
 // ---------------------------------------------------------------------------------------------
-// exact order-independent fixed-point accumulation:  v * 2^30 = hi + lo * 2^-32 (+ dropped bits)
+// exact order-independent fixed-point accumulation
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ void fix_split(double v, long long &hi, long long &lo)
-{
-    double t = v * 1073741824.0;
-    long long h = (long long)t;
-    double r = t - (double)h;
-    hi = h;
-    lo = (long long)(r * 4294967296.0);
-}
-
 __host__ __device__ __forceinline__ double i64_to_double(long long v)
 {
+    /* (double)(int32 high) * 2^32 + (double)(uint32 low): one rounding, round-to-nearest-even */
     int h = (int)(v >> 32);
     unsigned int l = (unsigned int)(v & 0xffffffffLL);
     return (double)h * 4294967296.0 + (double)l;
 }
 
-__host__ __device__ __forceinline__ double fix_join(long long hi, long long lo)
+// Fixed-point format of the centroid colour sums (oracle: orc_fix_bits): t = trunc(v * 2^f), f = 46 - e with
+// 2^e > max |v|.  Sums of up to 64 such integers are exact in fp64 (< 2^52), sums of a workgroup in int64; the
+// global sum lives in two int64 limbs, sum = hi * 2^24 + lo, which fix_value() brings to the canonical split
+// (0 <= lo < 2^24) before the one rounding to fp64 -- so the value is independent of how partial sums were split.
+__device__ __forceinline__ int fix_bits_of(double maxabs)
 {
-    double s = i64_to_double(hi) + i64_to_double(lo) * (1.0 / 4294967296.0);
-    return s * (1.0 / 1073741824.0);
+    int e = 1;
+    if (maxabs > 0.0) (void)frexp(maxabs, &e);
+    return 46 - e;
+}
+__host__ __device__ __forceinline__ double fix_value(long long hi, long long lo, double finv)
+{
+    hi += lo >> 24;
+    lo &= 0xffffff;
+    return (i64_to_double(hi) * 16777216.0 + (double)lo) * finv;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -358,6 +361,12 @@ __device__ __forceinline__ int row16_min_i32(int v)
 __device__ __forceinline__ void atomic_add_i64(long long *p, long long v)
 {
     atomicAdd(reinterpret_cast<unsigned long long *>(p), (unsigned long long)v);
+}
+// add the exact integer t to a two-limb global sum (hi at p[0], lo at p[1])
+__device__ __forceinline__ void fix_add_global(long long *p, long long t)
+{
+    atomic_add_i64(p, t >> 24);
+    atomic_add_i64(p + 1, t & 0xffffff);
 }
 
 }  // namespace imsegm

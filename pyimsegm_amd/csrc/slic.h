@@ -49,7 +49,8 @@ struct SlicState {
     double spatial_weight;          // 1 / step^2  (_slic.pyx "invxywt")
     double *cy, *cx, *cL, *ca, *cb; // centroid table, SoA fp64 [K]
     int4 *win;                      // integer search window {ymin, ymax, xmin, xmax} [K]
-    long long *acc;                 // [K][9] = n, sum y, sum x, (hi, lo) fixed-point sums of L, a, b
+    long long *acc;                 // [K][9] = n, sum y, sum x, (hi, lo) limbs of the fixed-point sums of L, a, b
+    const double *premax;           // [1] max |pre-processed value| (device): fixes the fixed-point format (common.h)
     Cand *tile_cands;               // [n_tiles][SLIC_MAXC] nearest-first candidate centroids per tile
     int *tile_count;                // [n_tiles] list length (negative: more than the list holds)
     Rec32 *tile_rec;                // [n_tiles][SLIC_MAXC] fp32 records, same slot order as tile_cands
@@ -65,9 +66,11 @@ struct SlicState {
 };
 
 int launch_minmax(const void *src, int dtype, size_t n, unsigned long long *keys, double *out2, hipStream_t st);
+// premax_dev[0] receives max |value| of the result planes
 int launch_preprocess_color2d(const void *img, int dtype, int H, int W, int normalize, const double *minmax_dev,
                               const Taps &tz, const Taps &ty, const Taps &tx, double ratio, double *bufA,
-                              double *bufB, hipStream_t st);
+                              double *bufB, double *premax_dev, hipStream_t st);
+int launch_absmax_f64(const double *src, size_t n, double *out_dev, hipStream_t st);
 // optional HIP-event hooks around the dominant kernel (api.hip profiler)
 struct ProfHook {
     void *user = nullptr;
@@ -85,7 +88,8 @@ struct VolState {
     double sz, sy, sx;              // voxel spacing
     double *cen;                    // [K][4] = cz, cy, cx, value
     int *win;                       // [K][6] = zmin, zmax, ymin, ymax, xmin, xmax
-    long long *acc;                 // [K][6] = n, sum z, sum y, sum x, (hi, lo) fixed-point value sum
+    long long *acc;                 // [K][6] = n, sum z, sum y, sum x, (hi, lo) limbs of the fixed-point value sum
+    const double *premax;           // [1] max |pre-processed value| (device)
     int grid_0[3], grid_d[3], grid_n[3];
     // candidate lists per brick of VOL_BZ x VOL_BY x VOL_BX voxels, filled by the centroids themselves
     // (k_vol_scatter): a wave of the assignment kernel only looks at the list of its brick

@@ -190,6 +190,42 @@ k_pre_lab_f(const T *__restrict__ img, int n, int normalize, const double *__res
     out[2 * (size_t)n + p] = zblur_point(B, tz);
 }
 
+// block maximum of a non-negative double -> one atomicMax on its bit pattern (non-negative doubles order like
+// unsigned integers); `out` must have been zeroed
+__device__ __forceinline__ void block_absmax_to(double v, double *out)
+{
+    __shared__ unsigned long long wave_max[16];
+    unsigned long long b = (unsigned long long)__double_as_longlong(v);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        unsigned long long o = __shfl_xor(b, off, 64);
+        b = o > b ? o : b;
+    }
+    const int wave = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    if ((threadIdx.x & 63) == 0) wave_max[wave] = b;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int i = 1; i < nw; ++i) b = wave_max[i] > b ? wave_max[i] : b;
+        if (b) atomicMax(reinterpret_cast<unsigned long long *>(out), b);
+    }
+}
+
+__global__ void __launch_bounds__(256) k_absmax_f64(const double *__restrict__ src, size_t n, double *out)
+{
+    double m = 0.0;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) m = fmax(m, fabs(src[i]));
+    block_absmax_to(m, out);
+}
+
+int launch_absmax_f64(const double *src, size_t n, double *out_dev, hipStream_t st)
+{
+    HIP_TRY(hipMemsetAsync(out_dev, 0, sizeof(double), st));
+    int grid = (int)std::min<size_t>(2048, (n + 256 * 8 - 1) / (256 * 8));
+    hipLaunchKernelGGL(k_absmax_f64, grid < 1 ? 1 : grid, 256, 0, st, src, n, out_dev);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
 __device__ __forceinline__ int reflect_idx(int i, int n)
 {
     if (n == 1) return 0;
@@ -243,8 +279,9 @@ constexpr int PF_TX = 64, PF_TY = 16, PF_MAXR = 8, PF_THREADS = 512;
 template <typename T>
 __global__ void __launch_bounds__(PF_THREADS)
 k_pre_fused(const T *__restrict__ img, int H, int W, int normalize, const double *__restrict__ minmax, Taps tz, Taps ty,
-            Taps tx, double ratio, double *__restrict__ out)
+            Taps tx, double ratio, double *__restrict__ out, double *premax)
 {
+    double vmax = 0.0;                                    // max |value written| by this thread
     extern __shared__ double pf_sm[];
     __shared__ double lut[256];
     const int tid = threadIdx.x;
@@ -334,15 +371,19 @@ k_pre_fused(const T *__restrict__ img, int H, int W, int normalize, const double
             }
             v = v * ratio;
             const int gy = y0 + oy, gx = x0 + ox;
-            if (gy < H && gx < W) out[(size_t)c * plane + (size_t)gy * W + gx] = v;
+            if (gy < H && gx < W) {
+                out[(size_t)c * plane + (size_t)gy * W + gx] = v;
+                vmax = fmax(vmax, fabs(v));
+            }
         }
         __syncthreads();
     }
+    block_absmax_to(vmax, premax);
 }
 
 int launch_preprocess_color2d(const void *img, int dtype, int H, int W, int normalize, const double *minmax_dev,
                               const Taps &tz, const Taps &ty, const Taps &tx, double ratio, double *bufA,
-                              double *bufB, hipStream_t st)
+                              double *bufB, double *premax_dev, hipStream_t st)
 {
     int n = H * W;
     int grid = cdiv(n, 256);
@@ -353,15 +394,16 @@ int launch_preprocess_color2d(const void *img, int dtype, int H, int W, int norm
                        : dtype == DT_F32 ? (const void *)k_pre_fused<float> : (const void *)k_pre_fused<double>;
         HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         dim3 gf(cdiv(W, PF_TX), cdiv(H, PF_TY));
+        HIP_TRY(hipMemsetAsync(premax_dev, 0, sizeof(double), st));
         if (dtype == DT_U8)
             hipLaunchKernelGGL(k_pre_fused<uint8_t>, gf, PF_THREADS, lds, st, (const uint8_t *)img, H, W, normalize, minmax_dev, tz, ty, tx,
-                               ratio, bufA);
+                               ratio, bufA, premax_dev);
         else if (dtype == DT_F32)
             hipLaunchKernelGGL(k_pre_fused<float>, gf, PF_THREADS, lds, st, (const float *)img, H, W, normalize, minmax_dev, tz, ty, tx,
-                               ratio, bufA);
+                               ratio, bufA, premax_dev);
         else
             hipLaunchKernelGGL(k_pre_fused<double>, gf, PF_THREADS, lds, st, (const double *)img, H, W, normalize, minmax_dev, tz, ty, tx,
-                               ratio, bufA);
+                               ratio, bufA, premax_dev);
         HIP_TRY(hipGetLastError());
         return 0;   // result in bufA
     }
@@ -375,7 +417,7 @@ int launch_preprocess_color2d(const void *img, int dtype, int H, int W, int norm
     hipLaunchKernelGGL(k_blur_axis<0>, g, 256, 0, st, bufA, bufB, H, W, ty, ratio, 0);
     hipLaunchKernelGGL(k_blur_axis<1>, g, 256, 0, st, bufB, bufA, H, W, tx, ratio, 1);
     HIP_TRY(hipGetLastError());
-    return 0;   // result in bufA
+    return launch_absmax_f64(bufA, (size_t)3 * n, premax_dev, st);   // result in bufA
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -434,9 +476,10 @@ __global__ void k_centroid_finalize(SlicState s)
         double cx = i64_to_double(a[2]) / nn;
         s.cy[k] = cy;
         s.cx[k] = cx;
-        s.cL[k] = fix_join(a[3], a[4]) / nn;
-        s.ca[k] = fix_join(a[5], a[6]) / nn;
-        s.cb[k] = fix_join(a[7], a[8]) / nn;
+        const double finv = ldexp(1.0, -fix_bits_of(*s.premax));
+        s.cL[k] = fix_value(a[3], a[4], finv) / nn;
+        s.ca[k] = fix_value(a[5], a[6], finv) / nn;
+        s.cb[k] = fix_value(a[7], a[8], finv) / nn;
         s.win[k] = search_window(cy, cx, s.step_y, s.step_x, s.H, s.W);
     }
 #pragma unroll
@@ -612,19 +655,13 @@ k_slic_leftover(SlicState s, const double *__restrict__ lab, const int32_t *__re
         if (k < 0) continue;            // never assigned so far: counted nowhere (as in the oracle)
         int y = p / s.W, x = p - y * s.W;
         long long *a = s.acc + (size_t)k * 9;
-        long long hi, lo;
+        const double fscale = ldexp(1.0, fix_bits_of(*s.premax));
         atomic_add_i64(a + 0, 1);
         atomic_add_i64(a + 1, y);
         atomic_add_i64(a + 2, x);
-        fix_split(lab[p], hi, lo);
-        atomic_add_i64(a + 3, hi);
-        atomic_add_i64(a + 4, lo);
-        fix_split(lab[plane + p], hi, lo);
-        atomic_add_i64(a + 5, hi);
-        atomic_add_i64(a + 6, lo);
-        fix_split(lab[2 * plane + p], hi, lo);
-        atomic_add_i64(a + 7, hi);
-        atomic_add_i64(a + 8, lo);
+        fix_add_global(a + 3, (long long)trunc(lab[p] * fscale));
+        fix_add_global(a + 5, (long long)trunc(lab[plane + p] * fscale));
+        fix_add_global(a + 7, (long long)trunc(lab[2 * plane + p] * fscale));
     }
 }
 
@@ -705,6 +742,79 @@ __device__ __forceinline__ long long wave_sum_limb_lane63(double x)
     return ((long long)hs << 24) + (long long)ls;
 }
 
+// Segmented reduction of the centroid sums, shared by both assignment kernels.  A lane owns one pixel column
+// and ROWS rows; `best_s[r]` is the slot (index into the tile's candidate list) the pixel was assigned to and
+// `pending` has one bit per row that takes part.  Each 16-lane row of the wave (a 16 x 4 pixel block) works on
+// the TWO smallest slots still pending in it, so that one pass finishes 95 % of the blocks.  Per slot four
+// values per lane -- the fixed-point colour sums trunc(v * 2^f) (common.h; integer-valued doubles, exact up to
+// the 64 pixels of a block) and one packed geometry word (n | sum of row offsets << 8 | sum of column offsets
+// << 17) -- i.e. eight values go through one transposed DPP reduction over the row, and its even lanes add
+// the totals to the int64 LDS slots of the workgroup (columns 0 n, 1 sum y, 2 sum x, 3 / 5 / 7 colour sums).
+__device__ __forceinline__ void accumulate_block_sums(int lane, int x, int wy0, const int (&best_s)[4], unsigned pending,
+                                                      const double (&pL)[4], const double (&pA)[4], const double (&pB)[4],
+                                                      double fscale, long long (*lacc)[9])
+{
+    constexpr int NONE = 0x7fffffff;
+    const int col = lane & 15;
+    while (__any(pending != 0)) {
+        int m = NONE;
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            if (pending & (1u << r)) m = min(m, best_s[r]);
+        const int sa = row16_min_i32(m);                    // smallest pending slot of the block
+        m = NONE;
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            if ((pending & (1u << r)) && best_s[r] != sa) m = min(m, best_s[r]);
+        const int sb = row16_min_i32(m);                    // second smallest (NONE: the block has one label)
+        double q[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+        int ga = 0, gb = 0;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            if (!(pending & (1u << r))) continue;
+            const int sl = best_s[r];
+            if (sl == sa) {
+                q[0] += trunc(pL[r] * fscale); q[1] += trunc(pA[r] * fscale); q[2] += trunc(pB[r] * fscale);
+                ga += 1 + (r << 8) + (col << 17);
+                pending &= ~(1u << r);
+            } else if (sl == sb) {
+                q[4] += trunc(pL[r] * fscale); q[5] += trunc(pA[r] * fscale); q[6] += trunc(pB[r] * fscale);
+                gb += 1 + (r << 8) + (col << 17);
+                pending &= ~(1u << r);
+            }
+        }
+        q[3] = (double)ga;
+        q[7] = (double)gb;
+        const double tot = row16_reduce8_f64(q, lane);      // lane pair j holds the row total of q[j]
+        const int j = ((lane >> 3) & 1) * 4 + ((lane >> 2) & 1) * 2 + ((lane >> 1) & 1);
+        const int slot = j < 4 ? sa : sb;
+        if ((lane & 1) == 0 && slot != NONE) {
+            const long long tv = (long long)tot;
+            if ((j & 3) < 3) {
+                if (tv != 0) atomic_add_i64(&lacc[slot][3 + 2 * (j & 3)], tv);
+            } else {
+                const long long n = tv & 255, sy = (tv >> 8) & 511, sx = tv >> 17;
+                atomic_add_i64(&lacc[slot][0], n);
+                atomic_add_i64(&lacc[slot][1], n * wy0 + sy);
+                atomic_add_i64(&lacc[slot][2], n * (x - col) + sx);
+            }
+        }
+    }
+}
+
+// workgroup LDS slots -> global sums (colour sums split into the two global limbs)
+__device__ __forceinline__ void flush_block_sums(const long long (*lacc)[9], int nc, const int *slot_k, long long *acc, int tid)
+{
+    for (int i = tid; i < nc * 9; i += 256) {
+        const int c = i / 9, j = i - 9 * c;
+        const long long v = lacc[c][j];
+        if (v == 0 || (j >= 3 && ((j - 3) & 1))) continue;
+        long long *dst = acc + (size_t)slot_k[c] * 9 + j;
+        if (j < 3) atomic_add_i64(dst, v);
+        else fix_add_global(dst, v);
+    }
+}
+
 // ACCUM: also accumulate the centroid sums (all sweeps but the last)
 template <bool ACCUM, bool FIRST>
 __global__ void __launch_bounds__(256)
@@ -712,6 +822,7 @@ k_slic_assign(SlicState s, const double *__restrict__ lab, int32_t *__restrict__
               const Cand *__restrict__ tile_cands, const int *__restrict__ tile_count)
 {
     __shared__ long long lacc[MAXC][9];
+    __shared__ int lk_old[MAXC];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -897,51 +1008,11 @@ k_slic_assign(SlicState s, const double *__restrict__ lab, int32_t *__restrict__
     }
     if (!ACCUM || (s.debug & 4)) return;
 
-    // wave-level segmented reduction, one pass per distinct slot present in this wave.  The two
-    // fixed-point limbs of every colour value are integer-valued doubles (|limb| < 2^45), so the
-    // per-lane sums over ROWS pixels are exact in fp64; across the wave they are summed as int32
-    // chunks through DPP and lane 63 adds the nine int64 totals into the workgroup's LDS slot.
-    while (true) {
-        int first = -1;
-#pragma unroll
-        for (int r = ROWS - 1; r >= 0; --r)
-            if (pending & (1u << r)) first = best_s[r];
-        unsigned long long vote = __ballot(first >= 0);
-        if (vote == 0) break;
-        const int slot = __shfl(first, __ffsll((long long)vote) - 1, 64);
-        double qd[6] = { 0, 0, 0, 0, 0, 0 };
-        int qn = 0, qy = 0, qx = 0;
-#pragma unroll
-        for (int r = 0; r < ROWS; ++r) {
-            if ((pending & (1u << r)) && best_s[r] == slot) {
-                double t, h;
-                t = pL[r] * 1073741824.0; h = trunc(t); qd[0] += h; qd[1] += trunc((t - h) * 4294967296.0);
-                t = pA[r] * 1073741824.0; h = trunc(t); qd[2] += h; qd[3] += trunc((t - h) * 4294967296.0);
-                t = pB[r] * 1073741824.0; h = trunc(t); qd[4] += h; qd[5] += trunc((t - h) * 4294967296.0);
-                qn += 1;
-                qy += wy0 + r;
-                qx += x;
-                pending &= ~(1u << r);
-            }
-        }
-        if (s.debug & 8) continue;           // (profiling aid) no cross-lane reduction
-        long long tot[9];
-        tot[0] = wave_sum_dpp_lane63(qn);
-        tot[1] = wave_sum_dpp_lane63(qy);
-        tot[2] = wave_sum_dpp_lane63(qx);
-#pragma unroll
-        for (int j = 0; j < 6; ++j) tot[3 + j] = wave_sum_limb_lane63(qd[j]);
-        if (lane == 63) {
-#pragma unroll
-            for (int j = 0; j < 9; ++j) atomic_add_i64(&lacc[slot][j], tot[j]);
-        }
-    }
+    accumulate_block_sums(lane, x, wy0, best_s, pending, pL, pA, pB, ldexp(1.0, fix_bits_of(*s.premax)), lacc);
     __syncthreads();
-    for (int i = tid; i < nc * 9; i += 256) {
-        int c = i / 9, j = i - 9 * c;
-        long long v = lacc[c][j];
-        if (v != 0) atomic_add_i64(s.acc + (size_t)cand[c].k * 9 + j, v);
-    }
+    if (tid < nc) lk_old[tid] = cand[tid].k;
+    __syncthreads();
+    flush_block_sums(lacc, nc, lk_old, s.acc, tid);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1257,13 +1328,13 @@ k_slic_assign_dot(SlicState s, const double *__restrict__ lab, int32_t *__restri
             const int k = best_s[r] <= -2 ? -(best_s[r] + 2) : labels[p];
             if (k >= 0) {
                 long long *a = s.acc + (size_t)k * 9;
-                long long hi, lo;
+                const double fs = ldexp(1.0, fix_bits_of(*s.premax));
                 atomic_add_i64(a + 0, 1);
                 atomic_add_i64(a + 1, y);
                 atomic_add_i64(a + 2, x);
-                fix_split(pL[r], hi, lo); atomic_add_i64(a + 3, hi); atomic_add_i64(a + 4, lo);
-                fix_split(pA[r], hi, lo); atomic_add_i64(a + 5, hi); atomic_add_i64(a + 6, lo);
-                fix_split(pB[r], hi, lo); atomic_add_i64(a + 7, hi); atomic_add_i64(a + 8, lo);
+                fix_add_global(a + 3, (long long)trunc(pL[r] * fs));
+                fix_add_global(a + 5, (long long)trunc(pA[r] * fs));
+                fix_add_global(a + 7, (long long)trunc(pB[r] * fs));
             }
         }
     }
@@ -1273,60 +1344,11 @@ k_slic_assign_dot(SlicState s, const double *__restrict__ lab, int32_t *__restri
         return;
     }
 
-    // Segmented reduction.  The fixed-point limbs of every colour value (common.h fix_split) are
-    // integer-valued doubles below 2^43 (|Lab| < 2^12 on this path), so sums over the pixels of a wave are
-    // exact in fp64.  Each 16-lane row of the wave (a 16 x 4 pixel block) works on its own slot -- the
-    // smallest one still pending in the block -- so the number of passes is the largest number of distinct
-    // labels in one block (2 on average) rather than in the whole 64 x 4 strip.  Per pass eight values per
-    // lane (six limb sums, sum x, sum y * 512 + n) go through one transposed DPP reduction over the row and
-    // its even lanes add the totals into the workgroup's LDS slot.
-    while (__any(pending != 0)) {
-        int mine = 0x7fffffff;
-#pragma unroll
-        for (int r = 0; r < ROWS; ++r)
-            if (pending & (1u << r)) mine = min(mine, best_s[r]);
-        mine = min(mine, __builtin_amdgcn_update_dpp(0, mine, 0x140, 0xf, 0xf, false));
-        mine = min(mine, __builtin_amdgcn_update_dpp(0, mine, 0x141, 0xf, 0xf, false));
-        mine = min(mine, __builtin_amdgcn_update_dpp(0, mine, 0x1b, 0xf, 0xf, false));
-        mine = min(mine, __builtin_amdgcn_update_dpp(0, mine, 0xb1, 0xf, 0xf, false));
-        const int slot = mine;                     // uniform over the 16-lane row; 0x7fffffff: row is done
-        double q[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
-        int qn = 0, qy = 0;
-#pragma unroll
-        for (int r = 0; r < ROWS; ++r) {
-            if ((pending & (1u << r)) && best_s[r] == slot) {
-                double t, h;
-                t = pL[r] * 1073741824.0; h = trunc(t); q[0] += h; q[1] += trunc((t - h) * 4294967296.0);
-                t = pA[r] * 1073741824.0; h = trunc(t); q[2] += h; q[3] += trunc((t - h) * 4294967296.0);
-                t = pB[r] * 1073741824.0; h = trunc(t); q[4] += h; q[5] += trunc((t - h) * 4294967296.0);
-                qn += 1;
-                qy += wy0 + r;
-                pending &= ~(1u << r);
-            }
-        }
-        q[6] = (double)(qn * x);
-        q[7] = (double)(qy * 512 + qn);
-        const double tot = row16_reduce8_f64(q, lane);
-        if ((lane & 1) == 0 && slot != 0x7fffffff) {
-            const int j = ((lane >> 3) & 1) * 4 + ((lane >> 2) & 1) * 2 + ((lane >> 1) & 1);
-            const long long tv = (long long)tot;
-            if (j < 6) atomic_add_i64(&lacc[slot][3 + j], tv);
-            else if (j == 6) atomic_add_i64(&lacc[slot][2], tv);
-            else {
-                atomic_add_i64(&lacc[slot][0], tv & 511);
-                atomic_add_i64(&lacc[slot][1], tv >> 9);
-            }
-        }
-        if (s.phase_prof && tid == 0) prof_slot[8] += 1;
-    }
+    accumulate_block_sums(lane, x, wy0, best_s, pending, pL, pA, pB, ldexp(1.0, fix_bits_of(*s.premax)), lacc);
     PHASE_MARK(5)                                  // accumulation passes
     __syncthreads();
     PHASE_MARK(6)                                  // barrier
-    for (int i = tid; i < nc * 9; i += 256) {
-        const int c = i / 9, j = i - 9 * c;
-        const long long v = lacc[c][j];
-        if (v != 0) atomic_add_i64(s.acc + (size_t)lk[c] * 9 + j, v);
-    }
+    flush_block_sums(lacc, nc, lk, s.acc, tid);
     PHASE_MARK(7)                                  // flush
     PHASE_FLUSH()
 }

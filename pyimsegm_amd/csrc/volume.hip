@@ -125,7 +125,7 @@ __global__ void k_vol_centroid_finalize(VolState s)
         s.cen[(size_t)k * 4 + 0] = cz;
         s.cen[(size_t)k * 4 + 1] = cy;
         s.cen[(size_t)k * 4 + 2] = cx;
-        s.cen[(size_t)k * 4 + 3] = fix_join(a[4], a[5]) / nn;
+        s.cen[(size_t)k * 4 + 3] = fix_value(a[4], a[5], ldexp(1.0, -fix_bits_of(*s.premax))) / nn;
         vol_window(s, cz, cy, cx, w);
     }
     for (int j = 0; j < 6; ++j) a[j] = 0;
@@ -247,6 +247,7 @@ k_vol_assign(VolState s, const double *__restrict__ vol, int32_t *__restrict__ l
         if (best_k[r] >= 0) pending |= 1u << r;
     }
     if (!ACCUM) return;
+    const double fscale = ldexp(1.0, fix_bits_of(*s.premax));
     while (true) {
         int first = -1;
 #pragma unroll
@@ -259,9 +260,8 @@ k_vol_assign(VolState s, const double *__restrict__ vol, int32_t *__restrict__ l
 #pragma unroll
         for (int r = 0; r < VROWS; ++r) {
             if ((pending & (1u << r)) && best_k[r] == k) {
-                long long hi, lo;
-                fix_split(pv[r], hi, lo);
-                q[0] += 1; q[1] += z; q[2] += y0 + r; q[3] += x; q[4] += hi; q[5] += lo;
+                const long long t = (long long)trunc(pv[r] * fscale);     // two limbs of the global sum: t = hi * 2^24 + lo
+                q[0] += 1; q[1] += z; q[2] += y0 + r; q[3] += x; q[4] += t >> 24; q[5] += t & 0xffffff;
                 pending &= ~(1u << r);
             }
         }

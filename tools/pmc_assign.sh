@@ -8,7 +8,7 @@ for set in "$@"; do
   i=$((i+1))
   out=$REPO/gpurun_out/pmcA$i
   rm -rf $out
-  rocprofv3 --pmc $set --kernel-trace --output-format csv -d $out -o p -- python $REPO/bench.py --steps 2 --warmup 1 --no-cpu-baseline > $out.log 2>&1
+  rocprofv3 --pmc $set --kernel-trace --output-format csv -d $out -o p -- python $REPO/bench.py --steps 2 --warmup 1 --no-cpu-baseline --inflight 1 > $out.log 2>&1
   python - "$out/p_counter_collection.csv" <<'PY'
 import csv, sys, collections
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
