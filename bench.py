@@ -103,7 +103,7 @@ def main():
     from pyimsegm_amd import _hip
     from pyimsegm_amd import pipelines as pipe
     from pyimsegm_amd.descriptors import FEATURES_SET_COLOR
-    from pyimsegm_amd.graph_cuts import estim_class_model
+    from pyimsegm_amd.graph_cuts import estim_class_model, predict_proba
     from pyimsegm_amd.superpixels import _open_session
     from pyimsegm_amd.utilities.synthetic import voronoi_image
 
@@ -114,7 +114,7 @@ def main():
 
     def step(model, session, to_host=False):
         res = pipe._ResidentImage(image, FEATURES_SET_COLOR, SP_SIZE, SP_REGUL, session=session)
-        proba = model.predict_proba(res.features)
+        proba = predict_proba(model, res.features)
         return res.segment(proba, GC_REGUL, EDGE_TYPE, to_host=to_host), res
 
     # model fit once (outside the timed region): the reference's group-model flow, run_segm...:476-514

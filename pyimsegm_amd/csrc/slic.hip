@@ -392,7 +392,11 @@ int launch_preprocess_color2d(const void *img, int dtype, int H, int W, int norm
         const size_t lds = ((size_t)3 * (PF_TY + 2 * ry) + PF_TY) * (PF_TX + 2 * rx) * sizeof(double);
         const void *fn = dtype == DT_U8 ? (const void *)k_pre_fused<uint8_t>
                        : dtype == DT_F32 ? (const void *)k_pre_fused<float> : (const void *)k_pre_fused<double>;
-        HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        static size_t lds_set[3] = { 0, 0, 0 };           // (benign race: the attribute only ever grows)
+        if (lds_set[dtype] < lds) {
+            HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            lds_set[dtype] = lds;
+        }
         dim3 gf(cdiv(W, PF_TX), cdiv(H, PF_TY));
         HIP_TRY(hipMemsetAsync(premax_dev, 0, sizeof(double), st));
         if (dtype == DT_U8)

@@ -15,7 +15,7 @@ import numpy as np
 from pyimsegm_amd import _hip
 from pyimsegm_amd.descriptors import (FEATURES_SET_COLOR, _selected_features_color2d, compute_selected_features_gray3d,
                                       compute_selected_features_img2d, norm_features)
-from pyimsegm_amd.graph_cuts import estim_class_model, segment_graph_cut_general
+from pyimsegm_amd.graph_cuts import estim_class_model, predict_proba, segment_graph_cut_general
 from pyimsegm_amd.superpixels import _open_session, _open_volume, _run_slic, _run_slic3d
 
 #: select basic features extracted from superpixels
@@ -202,7 +202,7 @@ def segment_color2d_slic_features_model_graphcut(
     if debug_visual is not None:
         debug_visual['image'] = res.image if res.image.ndim == 3 else np.repeat(res.image[:, :, None], 3, axis=2)
         debug_visual['slic'] = res.slic
-    proba = model_pipeline.predict_proba(res.features)
+    proba = predict_proba(model_pipeline, res.features)
     logging.debug('list of probabilities: %r', proba.shape)
     classes = getattr(model_pipeline, 'classes_', None)
     segm, segm_soft = res.segment(proba, gc_regul, gc_edge_type, debug_visual, classes=classes)
