@@ -7,6 +7,7 @@ importing the package before ``multiprocessing`` forks workers (the reference's 
 ``imsegm/utilities/experiments.py:392-403``) is safe.
 """
 import ctypes as C
+import functools
 import os
 import threading
 
@@ -184,9 +185,11 @@ def default_context():
     return ctx
 
 
+@functools.lru_cache(maxsize=64)
 def gaussian_taps(sigma, truncate=4.0):
     """half of the kernel of ``scipy.ndimage.gaussian_filter1d(sigma)`` (taps[0] = centre), computed
-    with the very numpy expressions of ``scipy.ndimage._filters._gaussian_kernel1d``; None: no blur"""
+    with the very numpy expressions of ``scipy.ndimage._filters._gaussian_kernel1d``; None: no blur
+    (cached: the result must be treated as read-only)"""
     sigma = float(sigma)
     if not sigma > 0:
         return None
