@@ -119,6 +119,16 @@ struct imsegm_ctx {
     {
         if (id >= 0) (void)hipEventRecord(spans[id].b, stream);
     }
+    void pair(int group, hipEvent_t *a, hipEvent_t *b)       // events filled in by a kernel launch, not recorded here
+    {
+        Span s;
+        s.group = group;
+        s.a = get_event();
+        s.b = get_event();
+        spans.push_back(s);
+        *a = s.a;
+        *b = s.b;
+    }
     void collect()
     {
         if (spans.empty()) return;
@@ -481,6 +491,7 @@ int imsegm_image2d_slic(imsegm_image2d *im, int minmax_normalize, int n_segments
         hook.user = ctx;
         hook.begin = [](void *u, int g) { return static_cast<imsegm_ctx *>(u)->begin(g); };
         hook.end = [](void *u, int id) { static_cast<imsegm_ctx *>(u)->end(id); };
+        hook.pair = [](void *u, int g, hipEvent_t *a, hipEvent_t *b) { static_cast<imsegm_ctx *>(u)->pair(g, a, b); };
     }
     if (launch_slic_iterations(s, im->labA.as<double>(), init_dev, im->nearest.as<int32_t>(), max_iter, max_candidates, hook, st))
         return -1;

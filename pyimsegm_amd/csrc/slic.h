@@ -76,6 +76,9 @@ struct ProfHook {
     void *user = nullptr;
     int (*begin)(void *, int) = nullptr;
     void (*end)(void *, int) = nullptr;
+    // event pair to attach to ONE kernel launch (hipExtLaunchKernelGGL): the pair then carries the begin / end
+    // timestamps of that dispatch itself, without the gap an hipEventRecord in front of the launch adds
+    void (*pair)(void *, int, hipEvent_t *, hipEvent_t *) = nullptr;
 };
 int launch_slic_iterations(SlicState s, const double *lab, const double *init_yx_dev, int32_t *labels, int max_iter,
                            int max_cand, const ProfHook &prof, hipStream_t st);

@@ -8,6 +8,7 @@
 // fully coalesced 512-byte wave loads); labels int32 [H][W]; centroid table SoA (cy, cx, cL, ca,
 // cb as fp64[K], integer search windows int4[K]); accumulators int64 [K][9].
 #include "slic.h"
+#include <hip/hip_ext.h>
 #include <cstdio>
 
 namespace imsegm {
@@ -1392,32 +1393,30 @@ int launch_slic_iterations(SlicState s, const double *lab, const double *init_yx
         hipLaunchKernelGGL(k_slic_bin, cdiv(n_tiles, BIN_TILES_PER_BLOCK), 256,
                            (size_t)std::min(s.K, BIN_MAX_K_LDS) * sizeof(int4), st, s, (int)grid.x, n_tiles, max_cand,
                            s.tile_cands, s.tile_count);
-        int span = prof.begin ? prof.begin(prof.user, 0) : -1;
         // first sweep: integer-grid centroids with zero colour -> exact integer path (needs the
         // fast-path preconditions and a spatial weight far above the fp64 resolution)
         const bool first = it == 0 && s.fast32 && s.spatial_weight > 1e-9;
         const bool dot = !first && s.fast32 && !(s.debug & 16);
         const bool first_grid = first && grid_covers && !(s.debug & 32);
-        if (it + 1 < max_iter) {
-            if (first_grid)
-                hipLaunchKernelGGL((k_slic_assign_dot<true, true>), grid, 256, 0, st, s, lab, labels, s.tile_cands, s.tile_rec, s.tile_info, s.tile_k);
-            else if (first)
-                hipLaunchKernelGGL((k_slic_assign<true, true>), grid, 256, 0, st, s, lab, labels, s.tile_cands, s.tile_count);
-            else if (dot)
-                hipLaunchKernelGGL((k_slic_assign_dot<true, false>), grid, 256, 0, st, s, lab, labels, s.tile_cands, s.tile_rec, s.tile_info, s.tile_k);
-            else
-                hipLaunchKernelGGL((k_slic_assign<true, false>), grid, 256, 0, st, s, lab, labels, s.tile_cands, s.tile_count);
+        const bool accum = it + 1 < max_iter;
+        // when profiling, the event pair rides on the dispatch itself (kernel begin / end timestamps)
+        hipEvent_t ev_a = nullptr, ev_b = nullptr;
+        if (prof.pair) prof.pair(prof.user, 0, &ev_a, &ev_b);
+#define LAUNCH_ASSIGN(kernel, ...) hipExtLaunchKernelGGL(kernel, grid, dim3(256), 0, st, ev_a, ev_b, 0, __VA_ARGS__)
+        if (first_grid) {
+            if (accum) LAUNCH_ASSIGN((k_slic_assign_dot<true, true>), s, lab, labels, s.tile_cands, s.tile_rec, s.tile_info, s.tile_k);
+            else LAUNCH_ASSIGN((k_slic_assign_dot<false, true>), s, lab, labels, s.tile_cands, s.tile_rec, s.tile_info, s.tile_k);
+        } else if (dot) {
+            if (accum) LAUNCH_ASSIGN((k_slic_assign_dot<true, false>), s, lab, labels, s.tile_cands, s.tile_rec, s.tile_info, s.tile_k);
+            else LAUNCH_ASSIGN((k_slic_assign_dot<false, false>), s, lab, labels, s.tile_cands, s.tile_rec, s.tile_info, s.tile_k);
+        } else if (first) {
+            if (accum) LAUNCH_ASSIGN((k_slic_assign<true, true>), s, lab, labels, s.tile_cands, s.tile_count);
+            else LAUNCH_ASSIGN((k_slic_assign<false, true>), s, lab, labels, s.tile_cands, s.tile_count);
         } else {
-            if (first_grid)
-                hipLaunchKernelGGL((k_slic_assign_dot<false, true>), grid, 256, 0, st, s, lab, labels, s.tile_cands, s.tile_rec, s.tile_info, s.tile_k);
-            else if (first)
-                hipLaunchKernelGGL((k_slic_assign<false, true>), grid, 256, 0, st, s, lab, labels, s.tile_cands, s.tile_count);
-            else if (dot)
-                hipLaunchKernelGGL((k_slic_assign_dot<false, false>), grid, 256, 0, st, s, lab, labels, s.tile_cands, s.tile_rec, s.tile_info, s.tile_k);
-            else
-                hipLaunchKernelGGL((k_slic_assign<false, false>), grid, 256, 0, st, s, lab, labels, s.tile_cands, s.tile_count);
+            if (accum) LAUNCH_ASSIGN((k_slic_assign<true, false>), s, lab, labels, s.tile_cands, s.tile_count);
+            else LAUNCH_ASSIGN((k_slic_assign<false, false>), s, lab, labels, s.tile_cands, s.tile_count);
         }
-        if (prof.end) prof.end(prof.user, span);
+#undef LAUNCH_ASSIGN
         if (it + 1 < max_iter) {
             if (!dot && !first_grid) hipLaunchKernelGGL(k_slic_leftover, 64, 256, 0, st, s, lab, labels);
             hipLaunchKernelGGL(k_centroid_finalize, cdiv(s.K, 256), 256, 0, st, s);
