@@ -176,6 +176,10 @@ def default_context():
     key = (os.getpid(), threading.get_ident(), os.environ.get('IMSEGM_HIP_DEVICE', os.environ.get('LOCAL_RANK', '0')))
     ctx = _default_ctx.get(key)
     if ctx is None:
+        # a new thread asks for its context: first give back those of threads that have ended
+        alive = {t.ident for t in threading.enumerate()}
+        for old in [k for k in _default_ctx if k[0] == key[0] and k[1] not in alive]:
+            _default_ctx.pop(old).close()
         device = int(key[2])
         n = device_count()
         if n > 0:

@@ -210,6 +210,11 @@ EDGE_CASES = [
     ('thin_strip', lambda: voronoi_image(9, 400, seed=8, nb_seeds=6), 8, 0.25),
     ('low_compactness', lambda: voronoi_image(150, 170, seed=9), 12, 0.02),         # large colour weight
     ('binary_0_1', lambda: (voronoi_image(96, 96, seed=2) > 100).astype(np.uint8), 10, 0.2),   # min 0, max 1: no scaling
+    ('one_row', lambda: voronoi_image(1, 300, seed=3, nb_seeds=5), 6, 0.3),
+    ('one_column', lambda: voronoi_image(300, 1, seed=3, nb_seeds=5), 6, 0.3),
+    ('four_by_four', lambda: voronoi_image(4, 4, seed=3, nb_seeds=5), 2, 0.3),
+    ('tile_plus_one_column', lambda: voronoi_image(32, 65, seed=3, nb_seeds=5), 9, 0.3),      # 64 x 32 tile geometry
+    ('tile_plus_one_row', lambda: voronoi_image(33, 64, seed=3, nb_seeds=5), 9, 0.3),
 ]
 
 

@@ -204,3 +204,31 @@ def test_pipe_gray3d(oracle):
     left, right = segm[:, :, :60], segm[:, :, 90:]
     assert np.mean(left == np.bincount(left.ravel()).argmax()) > 0.95
     assert np.bincount(left.ravel()).argmax() != np.bincount(right.ravel()).argmax()
+
+
+def test_volume_slic_randomised_sweep(hip, oracle):
+    """seeded sweep over volume shapes, dtypes, spacings, supervoxel sizes and compactness (colour- to
+    space-dominated): raw SLIC + connectivity and the measure.label relabelling, bit for bit"""
+    from pyimsegm_amd.superpixels import _slic3d_params
+    rng = np.random.default_rng(77)
+    for case in range(8):
+        shape = (int(rng.integers(1, 20)), int(rng.integers(20, 70)), int(rng.integers(20, 90)))
+        dtype = [np.float64, np.uint8, np.float32, np.uint16][case % 4]
+        vol = _noisy_ellipsoid(shape, seed=int(rng.integers(1000)), dtype=np.float64 if dtype == np.float32 else dtype)
+        if dtype == np.float32:
+            vol = vol.astype(np.float32)
+        space = [(1, 1, 1), (3, 1, 1), (1, 1, 2), (6, 1, 1)][int(rng.integers(4))]
+        sp = int(rng.integers(5, 14))
+        regul = float(rng.choice([0.05, 0.2, 0.6]))
+        n_seg, compact = _slic3d_params(shape, sp, regul, space)
+        if n_seg < 1 or compact < 1:
+            continue
+        ref_raw = oracle.slic(vol, n_seg, compact, sigma=1, spacing=space, multichannel=False)
+        sess = hip.Volume3D(*shape).upload(vol)
+        sess.slic(n_seg, compact, sigma=1., spacing=space)
+        raw = sess.get_labels()
+        assert np.array_equal(raw, ref_raw), 'case %d %r %s spacing %r sp %d regul %g: %d voxels differ' % (
+            case, shape, np.dtype(dtype).name, space, sp, regul, np.count_nonzero(raw != ref_raw))
+        sess.label_cc()
+        assert np.array_equal(sess.get_labels(), oracle.label_cc(ref_raw))
+        sess.close()
