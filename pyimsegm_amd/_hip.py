@@ -128,6 +128,9 @@ def _ptr(arr):
 
 
 class Context(object):
+    #: sessions alive on this context (a context with sessions is never released behind their back)
+    users = 0
+
     """one HIP device + one stream"""
 
     def __init__(self, device=0):
@@ -178,7 +181,7 @@ def default_context():
     if ctx is None:
         # a new thread asks for its context: first give back those of threads that have ended
         alive = {t.ident for t in threading.enumerate()}
-        for old in [k for k in _default_ctx if k[0] == key[0] and k[1] not in alive]:
+        for old in [k for k in _default_ctx if k[0] == key[0] and k[1] not in alive and _default_ctx[k].users == 0]:
             _default_ctx.pop(old).close()
         device = int(key[2])
         n = device_count()
@@ -217,10 +220,13 @@ class Image2D(object):
         self._h = _vp()
         self.n_labels = 0
         _check(load_library().imsegm_image2d_create(self.ctx._h, self.shape[0], self.shape[1], C.byref(self._h)))
+        self.ctx.users += 1
 
     def close(self):
-        if self._h and self.ctx is not None and self.ctx._h and self.ctx.pid == os.getpid():
-            load_library().imsegm_image2d_destroy(self._h)
+        if self._h and self.ctx is not None:
+            self.ctx.users -= 1
+            if self.ctx._h and self.ctx.pid == os.getpid():
+                load_library().imsegm_image2d_destroy(self._h)
         self._h = None
 
     def __del__(self):
@@ -389,6 +395,7 @@ class Volume3D(Image2D):
         self.n_labels = 0
         _check(load_library().imsegm_volume_create(self.ctx._h, self.shape[0], self.shape[1], self.shape[2],
                                                    C.byref(self._h)))
+        self.ctx.users += 1
 
     def upload(self, volume):
         """D x H x W volume; uint8 / float32 / float64 go up as they are, anything else as float64
