@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """bench.py -- headline benchmark of the SLIC -> descriptors -> GraphCut hot path on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--inflight M]
 
 Workload (BASELINE.json configs[1]): one synthetic 2048 x 2048 RGB uint8 image per GPU, SLIC
 (sp_size 46 -> n_segments 1982, K = 2025 grid centroids) + colour mean/std/energy descriptors +
@@ -11,9 +11,13 @@ imsegm/pipelines.py:160).  One step = one pass of that function over the residen
 input image is already in HBM when the timed region starts and the outputs (segm H x W int32,
 segm_soft H x W x 3 float64) stay in HBM; the scikit-learn `predict_proba` and the numpy edge-weight
 formulas of the reference run on the host inside the timed region, as do the K x F / E / K x C
-transfers between the stages.  N > 1: one process per GPU (torch.distributed / RCCL), every rank
-segments its own image (weak scaling, no data-path collective) and the label maps are gathered on
-rank 0 with one RCCL gather per step.
+transfers between the stages.  The K timed steps are taken by M worker threads per process (default 3), each
+with its own HIP stream and resident copy of the image, so that the host stages of one step overlap the
+kernels of another -- the reference maps a pool of worker processes over the images.  The `roofline` and
+`stage_ms_per_step` figures come from a second, un-overlapped pass on one stream (the assignment kernel is
+timed by a HIP event pair attached to its dispatch).  N > 1: one process per GPU (torch.distributed / RCCL),
+every rank segments its own image (weak scaling, no data-path collective) and every label map is gathered
+on rank 0 with one RCCL gather per step, zero copy from HBM.
 
 Prints ONE JSON line on rank 0.
 """
