@@ -354,7 +354,10 @@ k_pre_fused(const T *__restrict__ img, int H, int W, int normalize, const double
                 v = col[0];
             } else {
                 v = col[0] * ty.w[0];
-                for (int j = ty.r; j >= 1; --j) v += (col[-j * tw] + col[j * tw]) * ty.w[j];
+                // (unrolled over the largest radius: the taps become scalar registers loaded once)
+#pragma unroll
+                for (int j = PF_MAXR; j >= 1; --j)
+                    if (j <= ty.r) v += (col[-j * tw] + col[j * tw]) * ty.w[j];
             }
             L2[i] = v;
         }
@@ -368,7 +371,9 @@ k_pre_fused(const T *__restrict__ img, int H, int W, int normalize, const double
                 v = row[0];
             } else {
                 v = row[0] * tx.w[0];
-                for (int j = tx.r; j >= 1; --j) v += (row[-j] + row[j]) * tx.w[j];
+#pragma unroll
+                for (int j = PF_MAXR; j >= 1; --j)
+                    if (j <= tx.r) v += (row[-j] + row[j]) * tx.w[j];
             }
             v = v * ratio;
             const int gy = y0 + oy, gx = x0 + ox;
