@@ -203,6 +203,18 @@ def test_full_size_properties(hip):
     assert np.allclose((mean * counts[:, None]).sum(axis=0) / n, glob, rtol=1e-12)
 
 
+def _flat_dot(h, w):
+    img = np.full((h, w, 3), 128, dtype=np.uint8)
+    img[h // 3, w // 4] = 129
+    return img
+
+
+def _two_halves(h, w):
+    img = np.zeros((h, w, 3), dtype=np.uint8)
+    img[:, w // 2:] = (200, 50, 120)
+    return img
+
+
 EDGE_CASES = [
     ('ovary_slice_size', lambda: voronoi_image(647, 1024, seed=100), 35, 0.2),    # BASELINE config 4 image shape
     ('tiny_20x30', lambda: voronoi_image(20, 30, seed=5, nb_seeds=4), 6, 0.3),     # smaller than one tile
@@ -210,6 +222,8 @@ EDGE_CASES = [
     ('thin_strip', lambda: voronoi_image(9, 400, seed=8, nb_seeds=6), 8, 0.25),
     ('low_compactness', lambda: voronoi_image(150, 170, seed=9), 12, 0.02),         # large colour weight
     ('binary_0_1', lambda: (voronoi_image(96, 96, seed=2) > 100).astype(np.uint8), 10, 0.2),   # min 0, max 1: no scaling
+    ('flat_with_one_dot', lambda: _flat_dot(96, 128), 12, 0.2),      # exact ties everywhere: the near-tie path decides
+    ('two_flat_halves', lambda: _two_halves(120, 90), 15, 0.2),
     ('one_row', lambda: voronoi_image(1, 300, seed=3, nb_seeds=5), 6, 0.3),
     ('one_column', lambda: voronoi_image(300, 1, seed=3, nb_seeds=5), 6, 0.3),
     ('four_by_four', lambda: voronoi_image(4, 4, seed=3, nb_seeds=5), 2, 0.3),
