@@ -186,6 +186,8 @@ k_vol_assign(VolState s, const double *__restrict__ vol, int32_t *__restrict__ l
     }
     const double fz = (double)z, fx = (double)x;
     int count = 0;
+    double wave_worst = DBL_MAX;          // >= the current best distance of every voxel of this wave
+    int since_refresh = 0;
     static_assert(VOL_BX == 64 && VOL_BY == 4 * VROWS, "a workgroup lies inside one brick");
     const int brick = ((z / VOL_BZ) * s.nby + (y0 / VOL_BY)) * s.nbx + blockIdx.x;
     const int bcount = s.brick_count[brick];
@@ -207,16 +209,26 @@ k_vol_assign(VolState s, const double *__restrict__ vol, int32_t *__restrict__ l
         if (hit) list[wave][count + __popcll(m & ((1ULL << lane) - 1ULL))] = k;
         count += __popcll(m);
         if (count < VLIST - 64 && b + 1 < nblk) continue;
-        // evaluate the collected candidates (ascending k)
+        // evaluate the collected candidates.  Exact pruning: the spatial part of the distance to the nearest
+        // point of the strip is a lower bound of the distance of every voxel of the strip (every operation is
+        // monotone in IEEE arithmetic and the colour term is >= 0); a candidate whose bound exceeds the worst
+        // current best of the wave can neither win nor tie.
         for (int c = 0; c < count; ++c) {
             const int ck = list[wave][c];
             const int *w = s.win + (size_t)ck * 6;
             const double cz = s.cen[(size_t)ck * 4], cy = s.cen[(size_t)ck * 4 + 1], cx = s.cen[(size_t)ck * 4 + 2];
+            const double tz = s.sz * (cz - fz);
+            const double dz = tz * tz;
+            {
+                const double yn = fmin(fmax(cy, (double)y0), (double)(y1w - 1));
+                const double xn = fmin(fmax(cx, (double)x0w), (double)(x1w - 1));
+                const double tyl = s.sy * (cy - yn), txl = s.sx * (cx - xn);
+                const double lb = (dz + tyl * tyl + txl * txl) * s.spatial_weight;
+                if (lb > wave_worst) continue;                 // wave-uniform
+            }
             const double cv = s.cen[(size_t)ck * 4 + 3];
             const int wy0 = w[2], wy1 = w[3];
             const bool inx = x >= w[4] && x < w[5];
-            const double tz = s.sz * (cz - fz);
-            const double dz = tz * tz;
             const double tx = s.sx * (cx - fx);
             const double dx2 = tx * tx;
 #pragma unroll
@@ -232,6 +244,14 @@ k_vol_assign(VolState s, const double *__restrict__ vol, int32_t *__restrict__ l
                     best_d[r] = d;
                     best_k[r] = ck;
                 }
+            }
+            if (++since_refresh == 8) {                        // refresh the bound now and then
+                since_refresh = 0;
+                double m = 0.0;
+#pragma unroll
+                for (int r = 0; r < VROWS; ++r)
+                    if (xin && (y0 + r) < s.H) m = fmax(m, best_d[r]);
+                wave_worst = wave_max_f64(m);
             }
         }
         count = 0;
