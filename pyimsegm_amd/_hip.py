@@ -128,12 +128,14 @@ def _ptr(arr):
 
 
 class Context(object):
+    """one HIP device + one stream"""
+
     #: sessions alive on this context (a context with sessions is never released behind their back)
     users = 0
 
-    """one HIP device + one stream"""
-
     def __init__(self, device=0):
+        #: idle sessions kept for reuse, by image shape (superpixels._open_session / _release_session)
+        self.idle_sessions = {}
         lib = load_library()
         if device_count() < 1:
             raise HipUnavailableError('no HIP device is visible: the imsegm HIP path cannot run (no CPU fallback)')
@@ -157,6 +159,9 @@ class Context(object):
         return ms.value, n.value
 
     def close(self):
+        for sess in list(self.idle_sessions.values()):
+            sess.close()
+        self.idle_sessions.clear()
         if self._h and self.pid == os.getpid():
             load_library().imsegm_ctx_destroy(self._h)
         self._h = None
@@ -169,6 +174,7 @@ class Context(object):
 
 
 _default_ctx = {}
+_default_ctx_lock = threading.Lock()
 
 
 def default_context():
@@ -179,16 +185,20 @@ def default_context():
     key = (os.getpid(), threading.get_ident(), os.environ.get('IMSEGM_HIP_DEVICE', os.environ.get('LOCAL_RANK', '0')))
     ctx = _default_ctx.get(key)
     if ctx is None:
-        # a new thread asks for its context: first give back those of threads that have ended
-        alive = {t.ident for t in threading.enumerate()}
-        for old in [k for k in _default_ctx if k[0] == key[0] and k[1] not in alive and _default_ctx[k].users == 0]:
-            _default_ctx.pop(old).close()
-        device = int(key[2])
-        n = device_count()
-        if n > 0:
-            device %= n
-        ctx = Context(device)
-        _default_ctx[key] = ctx
+        # a new thread asks for its context: first give back those of threads that have ended (and the
+        # sessions they kept for reuse); workers start together, so one at a time
+        with _default_ctx_lock:
+            alive = {t.ident for t in threading.enumerate()}
+            dead = [k for k in _default_ctx if k[0] == key[0] and k[1] not in alive
+                    and _default_ctx[k].users == len(_default_ctx[k].idle_sessions)]
+            for old in dead:
+                _default_ctx.pop(old).close()
+            device = int(key[2])
+            n = device_count()
+            if n > 0:
+                device %= n
+            ctx = Context(device)
+            _default_ctx[key] = ctx
     return ctx
 
 

@@ -16,7 +16,7 @@ from pyimsegm_amd import _hip
 from pyimsegm_amd.descriptors import (FEATURES_SET_COLOR, _selected_features_color2d, compute_selected_features_gray3d,
                                       compute_selected_features_img2d, norm_features)
 from pyimsegm_amd.graph_cuts import estim_class_model, predict_proba, segment_graph_cut_general
-from pyimsegm_amd.superpixels import _open_session, _open_volume, _run_slic, _run_slic3d
+from pyimsegm_amd.superpixels import _open_session, _open_volume, _release_session, _run_slic, _run_slic3d
 
 #: select basic features extracted from superpixels
 FTS_SET_SIMPLE = FEATURES_SET_COLOR
@@ -30,15 +30,17 @@ NB_WORKERS = 2
 class _ResidentImage(object):
     """one image on the device: superpixels + features, graph cut, gathers"""
 
-    def __init__(self, image, dict_features, sp_size, sp_regul, session=None):
-        """``session``: (Image2D, normalize_mode) of an image that is already uploaded (bench loop)"""
+    def __init__(self, image, dict_features, sp_size, sp_regul, session=None, reuse=False):
+        """``session``: (Image2D, normalize_mode) of an image that is already uploaded (bench loop);
+        ``reuse``: recycle the device buffers of the previous image of the same size on this thread (batches)"""
         if sp_regul <= 0.:
             raise ValueError('slic. regularisation must be positive')
         image = np.asarray(image)
         self.image = image
         logging.debug('run Superpixel clustering.')
         self.own_session = session is None
-        self.sess, mode = _open_session(image) if session is None else session
+        self.reuse = reuse
+        self.sess, mode = _open_session(image, reuse=reuse) if session is None else session
         self.nb_labels = _run_slic(self.sess, mode, sp_size, sp_regul)
         logging.debug('extract slic/superpixels features.')
         self._slic = None
@@ -57,7 +59,7 @@ class _ResidentImage(object):
             self._slic = self.sess.get_labels()
         return self._slic
 
-    def segment(self, proba, gc_regul, gc_edge_type, debug_visual=None, classes=None, to_host=True):
+    def segment(self, proba, gc_regul, gc_edge_type, debug_visual=None, classes=None, to_host=True, want_soft=True):
         image = self.image
         # the graph stage only reads the label map of the session; `segments` is passed for its
         # ndim / debug output and is only materialised on the host when somebody needs it
@@ -66,14 +68,17 @@ class _ResidentImage(object):
                                                  debug_visual=debug_visual, _session=self.sess)
         if classes is not None:
             graph_labels = np.asarray(classes)[graph_labels]
-        segm, segm_soft = self.sess.gather(graph_labels, proba, to_host=to_host)
+        segm, segm_soft = self.sess.gather(graph_labels, proba if want_soft else None, to_host=to_host)
         if to_host and classes is not None and np.asarray(classes).dtype != np.int32:
             segm = segm.astype(np.asarray(classes).dtype)
         return segm, segm_soft
 
     def close(self):
         if self.own_session:
-            self.sess.close()
+            if self.reuse:
+                _release_session(self.sess)
+            else:
+                self.sess.close()
 
 
 class _ShapeOnly(object):
@@ -228,10 +233,15 @@ def segment_batch_color2d_slic_features_model_graphcut(list_images, model_pipeli
     if own:
         group = Group()
 
+    classes = getattr(model_pipeline, 'classes_', None)
+
     def _segment(image):
-        segm, _ = segment_color2d_slic_features_model_graphcut(image, model_pipeline, dict_features, sp_size=sp_size,
-                                                               sp_regul=sp_regul, gc_regul=gc_regul,
-                                                               gc_edge_type=gc_edge_type)
+        # as segment_color2d_slic_features_model_graphcut, minus what a batch does not need: the soft
+        # segmentation stays on the device and the session buffers are recycled from image to image
+        res = _ResidentImage(image, dict_features, sp_size, sp_regul, reuse=True)
+        proba = predict_proba(model_pipeline, res.features)
+        segm, _ = res.segment(proba, gc_regul, gc_edge_type, classes=classes, want_soft=False)
+        res.close()
         return segm
 
     out = segment_batch_sharded(list_images, _segment, group, nb_workers=nb_workers)

@@ -35,8 +35,11 @@ def _slic_params(shape2d, sp_size, relative_compact):
     return int(nb_pixels / (sp_size**2)), (sp_size * relative_compact)**1.5
 
 
-def _open_session(img):
-    """upload an image for the device-resident pipeline; returns (session, normalize_mode)"""
+def _open_session(img, reuse=False):
+    """upload an image for the device-resident pipeline; returns (session, normalize_mode)
+
+    ``reuse``: take the idle session of the same size that this thread's context keeps from an earlier image
+    (its device buffers are recycled, only the pixels are uploaded); give it back with :func:`_release_session`."""
     img = _as_rgb(img)
     mode = 2  # min-max scale unless min == 0 and max == 1 (superpixels.py:53-54), decided on device
     if img.dtype not in (np.uint8, np.float32, np.float64):
@@ -54,8 +57,23 @@ def _open_session(img):
         else:
             img = img.astype(np.float64)
         mode = 0
-    sess = _hip.Image2D(img.shape[0], img.shape[1]).upload(img)
+    sess = None
+    if reuse:
+        idle = _hip.default_context().idle_sessions
+        sess = idle.pop(img.shape[:2], None)
+    if sess is None:
+        sess = _hip.Image2D(img.shape[0], img.shape[1])
+    sess.upload(img)
     return sess, mode
+
+
+def _release_session(sess):
+    """keep a session for the next image of the same size on this thread (one per size), else close it"""
+    idle = sess.ctx.idle_sessions
+    if sess.shape in idle or sess.ctx is not _hip.default_context():
+        sess.close()
+    else:
+        idle[sess.shape] = sess
 
 
 def _run_slic(sess, mode, sp_size, relative_compact):

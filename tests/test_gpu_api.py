@@ -228,3 +228,14 @@ def test_images_in_flight_match_sequential():
                                                                   gc_regul=2., nb_workers=3)
     assert len(par) == len(seq)
     assert all(np.array_equal(a, b) for a, b in zip(seq, par))
+    # one worker: all six images go through ONE recycled session; a second size interleaved gets its own
+    one = pipe.segment_batch_color2d_slic_features_model_graphcut(images, model, feats, sp_size=15, sp_regul=0.2,
+                                                                  gc_regul=2., nb_workers=1)
+    assert all(np.array_equal(a, b) for a, b in zip(seq, one))
+    other = voronoi_image(120, 300, seed=77)
+    ref_other = pipe.segment_color2d_slic_features_model_graphcut(other, model, feats, sp_size=15, sp_regul=0.2, gc_regul=2.)[0]
+    mixed = [pipe.segment_batch_color2d_slic_features_model_graphcut([im], model, feats, sp_size=15, sp_regul=0.2,
+                                                                     gc_regul=2., nb_workers=1)[0]
+             for im in (images[0], other, images[1], other)]
+    assert np.array_equal(mixed[0], seq[0]) and np.array_equal(mixed[2], seq[1])
+    assert np.array_equal(mixed[1], ref_other) and np.array_equal(mixed[3], ref_other)
