@@ -59,12 +59,13 @@ IMSEGM_API int imsegm_image2d_upload(imsegm_image2d *img, const void *host_pixel
  * in (minmax_normalize: 1 = always, 0 = never, 2 = as the reference: unless min == 0 and max == 1).
  * taps_*: half kernels (taps[0] = centre, radius taps follow) of scipy.ndimage.gaussian_filter1d for
  * sigma / spacing per axis; radius < 0 disables the axis.  max_candidates: 0 = default (debug knob
- * that forces the kernel's global-memory fallback when small).  Labels stay on the device. */
+ * that forces the kernel's global-memory fallback when small).  slic_zero: skimage's slic_zero=True
+ * (SLICO, superpixels.py:63 `slic_zero=slico`).  Labels stay on the device. */
 IMSEGM_API int imsegm_image2d_slic(imsegm_image2d *img, int minmax_normalize, int n_segments, double compactness,
                         const double *taps_z, int radius_z, const double *taps_y, int radius_y,
                         const double *taps_x, int radius_x, int max_iter, int enforce_connectivity,
                         double min_size_factor, double max_size_factor, int start_label,
-                        int max_candidates, int *n_labels_out);
+                        int max_candidates, int slic_zero, int *n_labels_out);
 
 /* copy the current label map to the host as int64 (dtype leaked by skimage, superpixels.py:69) */
 IMSEGM_API int imsegm_image2d_get_labels(imsegm_image2d *img, int64_t *labels_out);

@@ -254,10 +254,14 @@ ORC_API int orc_fix_bits(const double *img, size_t count)
 
 ORC_API void orc_slic_iterate(const double *img, int C, int D, int H, int W, int K,
                               double *centroids, int step_z, int step_y, int step_x, double step,
-                              const double spacing[3], int max_iter, int32_t *nearest)
+                              const double spacing[3], int max_iter, int slic_zero, int32_t *nearest)
 {
     size_t n = (size_t)D * H * W;
     int F = 3 + C;
+    /* SLICO (slic_zero): colour distances are divided by the largest colour distance seen so far inside the
+     * segment; "the colors are scaled before ... so max_color_sq can be initialised as all ones" (_slic.pyx) */
+    double *max_dist_color = (double *)malloc((size_t)K * sizeof(double));
+    for (int k = 0; k < K; ++k) max_dist_color[k] = 1.0;
     double *distance = (double *)malloc(n * sizeof(double));
     int64_t *cnt = (int64_t *)calloc(K, sizeof(int64_t));
     int64_t *csum = (int64_t *)calloc((size_t)K * 3, sizeof(int64_t));
@@ -298,7 +302,8 @@ ORC_API void orc_slic_iterate(const double *img, int C, int D, int H, int W, int
                             double t = img[(size_t)c * n + p] - seg[3 + c];
                             dist_color += t * t;
                         }
-                        dist_center += dist_color;
+                        if (slic_zero) dist_center += dist_color / max_dist_color[k];
+                        else dist_center += dist_color;
                         if (distance[p] > dist_center) {
                             nearest[p] = k;
                             distance[p] = dist_center;
@@ -340,7 +345,22 @@ ORC_API void orc_slic_iterate(const double *img, int C, int D, int H, int W, int
                 seg[3 + c] = ((i64_to_double(hi) * 16777216.0 + (double)lo) * finv) / nn;
             }
         }
+        /* SLICO: update the colour-distance maxima with the distances to the NEW centres; only increases
+         * ("The reference implementation seems to only change the color if it increases", _slic.pyx) */
+        if (slic_zero)
+            for (size_t p = 0; p < n; ++p) {
+                int k = nearest[p];
+                if (k < 0) continue;
+                const double *seg = centroids + (size_t)k * F;
+                double dist_color = 0;
+                for (int c = 0; c < C; ++c) {
+                    double t = img[(size_t)c * n + p] - seg[3 + c];
+                    dist_color += t * t;
+                }
+                if (max_dist_color[k] < dist_color) max_dist_color[k] = dist_color;
+            }
     }
+    free(max_dist_color);
     free(distance); free(cnt); free(csum); free(fsum); free(dead);
 }
 

@@ -27,7 +27,8 @@ def lib():
     global _LIB
     if _LIB is None:
         path = os.path.join(_HERE, 'liboracle.so')
-        if not os.path.exists(path):
+        src = os.path.join(_HERE, 'imsegm_oracle.c')
+        if not os.path.exists(path) or os.path.getmtime(path) < os.path.getmtime(src):
             build()
         _LIB = C.CDLL(path)
         _LIB.orc_det_cbrt.restype = C.c_double
@@ -130,7 +131,7 @@ def img_as_float64(image):
 
 def slic(image, n_segments, compactness, sigma=0., spacing=None, multichannel=True, max_iter=10,
          enforce_connectivity=True, min_size_factor=0.5, max_size_factor=3, start_label=0,
-         normalize=None, return_internals=False):
+         normalize=None, return_internals=False, slic_zero=False):
     """CPU restatement of ``skimage.segmentation.slic`` (0.18.x) for the two call shapes of the
     reference: H x W x 3 colour (``imsegm/superpixels.py:61``) and D x H x W gray with
     ``multichannel=False`` (``:104``).
@@ -187,7 +188,8 @@ def slic(image, n_segments, compactness, sigma=0., spacing=None, multichannel=Tr
     nearest = np.empty((D, H, W), dtype=np.int32)
     L.orc_slic_iterate(_p(pre), C.c_int(nch), C.c_int(D), C.c_int(H), C.c_int(W), C.c_int(K),
                        _p(segments), C.c_int(isteps[0]), C.c_int(isteps[1]), C.c_int(isteps[2]),
-                       C.c_double(np.float32(step)), _p(spacing), C.c_int(max_iter), _p(nearest))
+                       C.c_double(np.float32(step)), _p(spacing), C.c_int(max_iter), C.c_int(int(bool(slic_zero))),
+                       _p(nearest))
     labels = nearest + start_label
     raw = labels
     if enforce_connectivity:
@@ -207,8 +209,8 @@ def slic(image, n_segments, compactness, sigma=0., spacing=None, multichannel=Tr
     return labels
 
 
-def segment_slic_img2d(img, sp_size=50, relative_compact=0.1, start_label=0, return_internals=False):
-    """imsegm/superpixels.py:22-69 on the oracle (slico not supported)"""
+def segment_slic_img2d(img, sp_size=50, relative_compact=0.1, start_label=0, return_internals=False, slico=False):
+    """imsegm/superpixels.py:22-69 on the oracle (``slico``: skimage's ``slic_zero``)"""
     img = np.asarray(img)
     nb_pixels = np.prod(img.shape[:2])
     if img.ndim == 2:
@@ -222,7 +224,7 @@ def segment_slic_img2d(img, sp_size=50, relative_compact=0.1, start_label=0, ret
     n_seg = int(nb_pixels / (sp_size**2))
     compact = (sp_size * relative_compact)**1.5
     return slic(img, n_seg, compact, sigma=1, normalize=normalize, start_label=start_label,
-                return_internals=return_internals)
+                return_internals=return_internals, slic_zero=slico)
 
 
 def label_cc(labels):

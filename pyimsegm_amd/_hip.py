@@ -57,7 +57,7 @@ _SIGNATURES = {
     'imsegm_image2d_destroy': (None, [_vp]),
     'imsegm_image2d_upload': (C.c_int, [_vp, _vp, C.c_int]),
     'imsegm_image2d_slic': (C.c_int, [_vp, C.c_int, C.c_int, C.c_double, _vp, C.c_int, _vp, C.c_int, _vp, C.c_int,
-                                      C.c_int, C.c_int, C.c_double, C.c_double, C.c_int, C.c_int, _ip]),
+                                      C.c_int, C.c_int, C.c_double, C.c_double, C.c_int, C.c_int, C.c_int, _ip]),
     'imsegm_image2d_get_labels': (C.c_int, [_vp, _vp]),
     'imsegm_image2d_set_labels': (C.c_int, [_vp, _vp, C.c_int]),
     'imsegm_image2d_get_lab': (C.c_int, [_vp, _vp]),
@@ -257,14 +257,14 @@ class Image2D(object):
         return self
 
     def slic(self, n_segments, compactness, sigma=1., normalize=2, max_iter=10, enforce_connectivity=True,
-             min_size_factor=0.5, max_size_factor=3., start_label=0, max_candidates=0):
+             min_size_factor=0.5, max_size_factor=3., start_label=0, max_candidates=0, slic_zero=False):
         taps = gaussian_taps(sigma)
         r = -1 if taps is None else len(taps) - 1
         n_out = C.c_int(0)
         _check(load_library().imsegm_image2d_slic(
             self._h, int(normalize), int(n_segments), float(compactness), _ptr(taps), r, _ptr(taps), r, _ptr(taps), r,
             int(max_iter), int(bool(enforce_connectivity)), float(min_size_factor), float(max_size_factor),
-            int(start_label), int(max_candidates), C.byref(n_out)))
+            int(start_label), int(max_candidates), int(bool(slic_zero)), C.byref(n_out)))
         self.n_labels = n_out.value
         return self.n_labels
 

@@ -371,7 +371,7 @@ int imsegm_image2d_slic(imsegm_image2d *im, int minmax_normalize, int n_segments
                         const double *taps_z, int radius_z, const double *taps_y, int radius_y,
                         const double *taps_x, int radius_x, int max_iter, int enforce_connectivity,
                         double min_size_factor, double max_size_factor, int start_label, int max_candidates,
-                        int *n_labels_out)
+                        int slic_zero, int *n_labels_out)
 {
     if (!im || bind(im->ctx)) return -1;
     if (wrong_kind(im, false)) return -1;
@@ -472,6 +472,8 @@ int imsegm_image2d_slic(imsegm_image2d *im, int minmax_normalize, int n_segments
     s.ca = reinterpret_cast<double *>(cb); cb += (size_t)K * 8;
     s.cb = reinterpret_cast<double *>(cb); cb += (size_t)K * 8;
     s.win = reinterpret_cast<int4 *>(cb); cb += (size_t)K * 16;
+    s.mdc = reinterpret_cast<double *>(cb); cb += (size_t)K * 8;
+    s.slico = slic_zero ? 1 : 0;
     s.grid_y0 = (int)ax[1].start; s.grid_dy = (int)ax[1].step;
     s.grid_x0 = (int)ax[2].start; s.grid_dx = (int)ax[2].step; s.grid_nx = (int)nx;
     double *init_dev = nullptr;                            // the grid is generated on the device

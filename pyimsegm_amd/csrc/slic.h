@@ -23,7 +23,7 @@ struct Cand {
     int k;                       // centroid index
     float ry, rx;                // fp32 position relative to the tile origin
     float fL, fa, fb;            // fp32 colour
-    int pad[2];
+    double mdc;                  // SLICO: largest colour distance seen inside the segment (1 otherwise)
 };
 
 // compact fp32 record of the same candidate for the pre-selection loop of k_slic_assign_dot (32 bytes, read
@@ -63,6 +63,8 @@ struct SlicState {
     int grid_y0, grid_dy, grid_x0, grid_dx, grid_nx;   // initial centroid grid (skimage regular_grid)
     long long *phase_prof;          // profiling aid (env IMSEGM_PHASE_PROF): per-phase cycle sums, or null
     int debug;                      // profiling aid (env IMSEGM_DEBUG_ASSIGN): ablation bits, results invalid
+    int slico;                      // skimage slic_zero: colour distance / mdc[k], mdc updated after every sweep
+    double *mdc;                    // [K] max_dist_color of _slic.pyx (starts at 1)
 };
 
 int launch_minmax(const void *src, int dtype, size_t n, unsigned long long *keys, double *out2, hipStream_t st);

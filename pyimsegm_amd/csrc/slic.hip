@@ -465,6 +465,7 @@ __global__ void k_centroid_init(SlicState s, const double *__restrict__ init_yx)
     s.ca[k] = 0.0;
     s.cb[k] = 0.0;
     s.win[k] = search_window(cy, cx, s.step_y, s.step_x, s.H, s.W);
+    s.mdc[k] = 1.0;
     for (int j = 0; j < 9; ++j) s.acc[(size_t)k * 9 + j] = 0;
     if (k == 0) *s.leftover_count = 0;
 }
@@ -600,7 +601,7 @@ k_slic_bin(SlicState s, int tiles_x, int n_tiles, int max_cand, Cand *__restrict
     cd.ry = (float)(cd.cy - (double)ty0);
     cd.rx = (float)(cd.cx - (double)tx0);
     cd.fL = (float)cd.cL; cd.fa = (float)cd.ca; cd.fb = (float)cd.cb;
-    cd.pad[0] = cd.pad[1] = 0;
+    cd.mdc = s.slico ? s.mdc[k] : 1.0;
     if (have) {
         tile_cands[(size_t)tile * MAXC + rank] = cd;
         s.tile_rec[(size_t)tile * MAXC + rank] = rc;
@@ -675,7 +676,29 @@ k_slic_leftover(SlicState s, const double *__restrict__ lab, const int32_t *__re
     }
 }
 
-__device__ __forceinline__ double exact_dist(const Cand &cd, double fy, double fx, double sw, double L, double A, double B)
+// SLICO (_slic.pyx, slic_zero): after the centres have been recomputed, max_dist_color[k] grows to the largest
+// colour distance of a pixel of segment k to its NEW centre.  A maximum is order independent, and non-negative
+// doubles order like their bit patterns: integer atomicMax, exact.  The plain read in front keeps the atomics
+// rare (the maxima settle after the first few thousand pixels).
+__global__ void __launch_bounds__(256)
+k_slico_update(SlicState s, const double *__restrict__ lab, const int32_t *__restrict__ labels)
+{
+    const size_t n = (size_t)s.H * s.W;
+    for (size_t p = (size_t)blockIdx.x * 256 + threadIdx.x; p < n; p += (size_t)gridDim.x * 256) {
+        const int k = labels[p];
+        if (k < 0) continue;
+        const double t0 = lab[p] - s.cL[k], t1 = lab[n + p] - s.ca[k], t2 = lab[2 * n + p] - s.cb[k];
+        double col = t0 * t0;
+        col = col + t1 * t1;
+        col = col + t2 * t2;
+        unsigned long long *m = reinterpret_cast<unsigned long long *>(s.mdc + k);
+        if (__hip_atomic_load(m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned long long)__double_as_longlong(col))
+            atomicMax(m, (unsigned long long)__double_as_longlong(col));
+    }
+}
+
+__device__ __forceinline__ double exact_dist(const Cand &cd, double fy, double fx, double sw, double L, double A, double B,
+                                             bool slico = false)
 {
     const double ty = cd.cy - fy, tx = cd.cx - fx;
     double d = (ty * ty + tx * tx) * sw;
@@ -683,12 +706,13 @@ __device__ __forceinline__ double exact_dist(const Cand &cd, double fy, double f
     double col = t0 * t0;
     col = col + t1 * t1;
     col = col + t2 * t2;
+    if (slico) col = col / cd.mdc;       // _slic.pyx: dist_center += dist_color / max_dist_color[k]  (IEEE division)
     return d + col;
 }
 
 // exact argmin over the whole candidate list of one pixel row (wave-uniform y)
 __device__ __forceinline__ int exact_row(const Cand *__restrict__ cand, int nc, int y, int x, double sw, double L,
-                                         double A, double B)
+                                         double A, double B, bool slico = false)
 {
     double bd = DBL_MAX;
     int bs = -1, bk = 0x7fffffff;
@@ -697,7 +721,7 @@ __device__ __forceinline__ int exact_row(const Cand *__restrict__ cand, int nc, 
         const int4 w = cand[c].win;
         if (y < w.x || y >= w.y) continue;
         const bool inx = (x >= w.z) && (x < w.w);
-        const double d = exact_dist(cand[c], fy, fx, sw, L, A, B);
+        const double d = exact_dist(cand[c], fy, fx, sw, L, A, B, slico);
         const int k = cand[c].k;
         if (inx && ((bd > d) || (bd == d && k < bk))) {
             bd = d;
@@ -720,7 +744,8 @@ __device__ __forceinline__ int exact_row_global(const SlicState &s, int y, int x
         if (y < w.x || y >= w.y || x < w.z || x >= w.w) continue;
         Cand cd;
         cd.cy = s.cy[k]; cd.cx = s.cx[k]; cd.cL = s.cL[k]; cd.ca = s.ca[k]; cd.cb = s.cb[k];
-        const double d = exact_dist(cd, fy, fx, s.spatial_weight, L, A, B);
+        cd.mdc = s.slico ? s.mdc[k] : 1.0;
+        const double d = exact_dist(cd, fy, fx, s.spatial_weight, L, A, B, s.slico != 0);
         if (bd > d) {
             bd = d;
             res = -(k + 2);
@@ -890,7 +915,7 @@ k_slic_assign(SlicState s, const double *__restrict__ lab, int32_t *__restrict__
         for (int r = 0; r < ROWS; ++r) best_s[r] = exact_row_global(s, wy0 + r, x, pL[r], pA[r], pB[r]);
     } else if (!s.fast32) {
 #pragma unroll
-        for (int r = 0; r < ROWS; ++r) best_s[r] = exact_row(cand, nc, wy0 + r, x, sw, pL[r], pA[r], pB[r]);
+        for (int r = 0; r < ROWS; ++r) best_s[r] = exact_row(cand, nc, wy0 + r, x, sw, pL[r], pA[r], pB[r], s.slico != 0);
     } else if (FIRST) {
         // integer distances (see header): centroid positions are exact integers in the first sweep
         int bn[ROWS], bk[ROWS];
@@ -1401,7 +1426,9 @@ int launch_slic_iterations(SlicState s, const double *lab, const double *init_yx
         // first sweep: integer-grid centroids with zero colour -> exact integer path (needs the
         // fast-path preconditions and a spatial weight far above the fp64 resolution)
         const bool first = it == 0 && s.fast32 && s.spatial_weight > 1e-9;
-        const bool dot = !first && s.fast32 && !(s.debug & 16);
+        // SLICO: the first sweep is the plain one (colour 0, maxima 1: the colour term is common to all
+        // candidates); every later sweep divides by a per-centroid maximum and takes the exact fp64 path
+        const bool dot = !first && s.fast32 && !s.slico && !(s.debug & 16);
         const bool first_grid = first && grid_covers && !(s.debug & 32);
         const bool accum = it + 1 < max_iter;
         // when profiling, the event pair rides on the dispatch itself (kernel begin / end timestamps)
@@ -1418,13 +1445,17 @@ int launch_slic_iterations(SlicState s, const double *lab, const double *init_yx
             if (accum) LAUNCH_ASSIGN((k_slic_assign<true, true>), s, lab, labels, s.tile_cands, s.tile_count);
             else LAUNCH_ASSIGN((k_slic_assign<false, true>), s, lab, labels, s.tile_cands, s.tile_count);
         } else {
-            if (accum) LAUNCH_ASSIGN((k_slic_assign<true, false>), s, lab, labels, s.tile_cands, s.tile_count);
-            else LAUNCH_ASSIGN((k_slic_assign<false, false>), s, lab, labels, s.tile_cands, s.tile_count);
+            SlicState se = s;
+            if (s.slico) se.fast32 = 0;
+            if (accum) LAUNCH_ASSIGN((k_slic_assign<true, false>), se, lab, labels, s.tile_cands, s.tile_count);
+            else LAUNCH_ASSIGN((k_slic_assign<false, false>), se, lab, labels, s.tile_cands, s.tile_count);
         }
 #undef LAUNCH_ASSIGN
         if (it + 1 < max_iter) {
             if (!dot && !first_grid) hipLaunchKernelGGL(k_slic_leftover, 64, 256, 0, st, s, lab, labels);
             hipLaunchKernelGGL(k_centroid_finalize, cdiv(s.K, 256), 256, 0, st, s);
+            if (s.slico)
+                hipLaunchKernelGGL(k_slico_update, (int)std::min<size_t>(cdiv(n, (size_t)256), 4096), 256, 0, st, s, lab, labels);
         }
     }
     HIP_TRY(hipGetLastError());

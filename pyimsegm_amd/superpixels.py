@@ -76,13 +76,13 @@ def _release_session(sess):
         idle[sess.shape] = sess
 
 
-def _run_slic(sess, mode, sp_size, relative_compact):
+def _run_slic(sess, mode, sp_size, relative_compact, slico=False):
     n_seg, compact = _slic_params(sess.shape, sp_size, relative_compact)
     logging.debug('Starting SLIC with params NB=%i & compat=%f for image %r', n_seg, compact, sess.shape)
     if n_seg < 1:
         raise ValueError('superpixel size %r is larger than the image %r' % (sp_size, sess.shape))
     return sess.slic(n_seg, compact, sigma=1., normalize=mode, max_iter=SLIC_MAX_ITER, enforce_connectivity=True,
-                     start_label=SLIC_START_LABEL)
+                     start_label=SLIC_START_LABEL, slic_zero=slico)
 
 
 def segment_slic_img2d(img, sp_size=50, relative_compact=0.1, slico=False):
@@ -91,7 +91,7 @@ def segment_slic_img2d(img, sp_size=50, relative_compact=0.1, slico=False):
     :param ndarray img: input image, H x W or H x W x 3
     :param int sp_size: initial superpixel size (edge length in pixels)
     :param float relative_compact: regularisation in (0, 1); 0 free-form, 1 nearly square
-    :param bool slico: parameter-free SLICO variant (not available on the HIP path)
+    :param bool slico: parameter-free SLICO variant (``slic_zero=True`` of skimage; exact fp64 sweeps on the device)
     :return ndarray: int64 label map H x W
 
     >>> np.random.seed(0)
@@ -102,10 +102,8 @@ def segment_slic_img2d(img, sp_size=50, relative_compact=0.1, slico=False):
     """
     logging.debug('Init SLIC superpixels 2d RGB clustering with params size=%i and regul=%f for image dims %r',
                   sp_size, relative_compact, np.shape(img))
-    if slico:
-        raise NotImplementedError('SLICO (slic_zero=True) is not implemented by the HIP path yet')
     sess, mode = _open_session(img)
-    _run_slic(sess, mode, sp_size, relative_compact)
+    _run_slic(sess, mode, sp_size, relative_compact, slico=slico)
     logging.debug('SLIC finished')
     labels = sess.get_labels()
     sess.close()

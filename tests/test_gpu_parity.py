@@ -49,6 +49,38 @@ def test_slic_bit_exact(hip, oracle, name, make, sp, regul):
     assert k == ref_labels.max() + 1
 
 
+SLICO_CASES = [
+    ('voronoi', lambda: voronoi_image(150, 210, seed=5), 14, 0.2),
+    ('disc', lambda: disc_image(256), 18, 0.3),
+    ('float_noise', lambda: np.random.default_rng(3).random((97, 131, 3)), 11, 0.1),
+    ('ovary_size', lambda: voronoi_image(647, 1024, seed=101), 35, 0.2),
+]
+
+
+@pytest.mark.parametrize('name,make,sp,regul', SLICO_CASES, ids=[c[0] for c in SLICO_CASES])
+def test_slico_bit_exact(hip, oracle, name, make, sp, regul):
+    """slic_zero=True (segment_slic_img2d(slico=True), superpixels.py:63): raw assignment and final map"""
+    from pyimsegm_amd import superpixels
+    img = make()
+    ref_labels, info = oracle.segment_slic_img2d(img, sp, regul, return_internals=True, slico=True)
+    plain = oracle.segment_slic_img2d(img, sp, regul)
+    assert not np.array_equal(plain, ref_labels), 'SLICO must differ from plain SLIC on this input'
+    n_seg, compact = _params(img, sp, regul)
+    im = hip.Image2D(*img.shape[:2]).upload(img)
+    k = im.slic(n_seg, compact, sigma=1., normalize=2, slic_zero=True)
+    assert np.array_equal(im.get_nearest(), info['nearest'][0]), 'k-means assignment differs'
+    assert np.array_equal(im.get_labels(), ref_labels)
+    assert k == ref_labels.max() + 1
+    # the candidate-overflow path (whole table scan) divides by the same maxima
+    im.slic(n_seg, compact, sigma=1., normalize=2, slic_zero=True, max_candidates=3)
+    assert np.array_equal(im.get_labels(), ref_labels)
+    # the same session afterwards gives plain SLIC again
+    im.slic(n_seg, compact, sigma=1., normalize=2)
+    assert np.array_equal(im.get_labels(), plain)
+    im.close()
+    assert np.array_equal(superpixels.segment_slic_img2d(img, sp, regul, slico=True), ref_labels)
+
+
 def test_slic_candidate_overflow_path(hip, oracle):
     """force the kernel's global-memory fallback (more candidates than LDS slots)"""
     img = disc_image(256)

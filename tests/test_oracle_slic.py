@@ -11,7 +11,7 @@ import numpy as np
 import pytest
 
 
-def literal_slic(pre, segments, isteps, step, spacing, max_iter):
+def literal_slic(pre, segments, isteps, step, spacing, max_iter, slic_zero=False):
     """pre: (C, D, H, W) pre-processed image; segments: (K, 3 + C) initial centroids (modified in place)"""
     nch, D, H, W = pre.shape
     K = segments.shape[0]
@@ -19,6 +19,7 @@ def literal_slic(pre, segments, isteps, step, spacing, max_iter):
     nearest = np.full((D, H, W), -1, dtype=np.int64)
     sz, sy, sx = spacing
     spatial_weight = 1.0 / (step * step)
+    max_dist_color = np.ones(K)
     for _ in range(max_iter):
         distance = np.full((D, H, W), np.finfo(np.float64).max)
         for k in range(K):
@@ -37,7 +38,10 @@ def literal_slic(pre, segments, isteps, step, spacing, max_iter):
                         dist_color = 0.0
                         for c in range(nch):
                             dist_color += (pre[c, z, y, x] - segments[k, 3 + c])**2
-                        dist_center += dist_color
+                        if slic_zero:
+                            dist_center += dist_color / max_dist_color[k]
+                        else:
+                            dist_center += dist_color
                         if distance[z, y, x] > dist_center:
                             nearest[z, y, x] = k
                             distance[z, y, x] = dist_center
@@ -57,6 +61,18 @@ def literal_slic(pre, segments, isteps, step, spacing, max_iter):
                         segments[k, 3 + c] += pre[c, z, y, x]
         with np.errstate(invalid='ignore', divide='ignore'):
             segments /= count[:, None].astype(np.float64)          # 0/0 -> nan: the centroid is dead
+        if slic_zero:
+            for z in range(D):
+                for y in range(H):
+                    for x in range(W):
+                        k = nearest[z, y, x]
+                        if k < 0:
+                            continue
+                        dist_color = 0.0
+                        for c in range(nch):
+                            dist_color += (pre[c, z, y, x] - segments[k, 3 + c])**2
+                        if max_dist_color[k] < dist_color:
+                            max_dist_color[k] = dist_color
     return nearest
 
 
@@ -101,6 +117,8 @@ CASES = [
     ('colour2d', (1, 26, 34), 3, 30, 4.0, (1., 1., 1.)),
     ('colour2d_loose', (1, 31, 23), 3, 12, 0.7, (1., 1., 1.)),
     ('gray3d_aniso', (5, 14, 17), 1, 18, 2.0, (3., 1., 1.)),
+    ('colour2d_slico', (1, 26, 34), 3, 30, 4.0, (1., 1., 1.)),
+    ('colour2d_slico_loose', (1, 29, 31), 3, 14, 0.5, (1., 1., 1.)),
 ]
 
 
@@ -109,9 +127,10 @@ def test_oracle_sweeps_and_connectivity_match_literal_restatement(oracle, name, 
                                                                   spacing):
     rng = np.random.default_rng(7)
     D, H, W = shape
+    slico = 'slico' in name
     if nch == 3:
         image = rng.random((H, W, 3))
-        labels, info = oracle.slic(image, n_segments, compactness, sigma=1., return_internals=True)
+        labels, info = oracle.slic(image, n_segments, compactness, sigma=1., return_internals=True, slic_zero=slico)
     else:
         image = rng.random((D, H, W))
         labels, info = oracle.slic(image, n_segments, compactness, sigma=1., spacing=spacing, multichannel=False,
@@ -122,7 +141,7 @@ def test_oracle_sweeps_and_connectivity_match_literal_restatement(oracle, name, 
     assert K == info['K']
     segments = np.zeros((K, 3 + nch))
     segments[:, :3] = cent
-    nearest = literal_slic(pre, segments, info['steps'], float(np.float32(info['step'])), spacing, 10)
+    nearest = literal_slic(pre, segments, info['steps'], float(np.float32(info['step'])), spacing, 10, slic_zero=slico)
     assert np.array_equal(nearest, np.asarray(info['nearest']).reshape(D, H, W)), \
         '%d voxels differ' % np.count_nonzero(nearest != np.asarray(info['nearest']).reshape(D, H, W))
     segment_size = D * H * W / K
