@@ -9,7 +9,7 @@ import pyimsegm_amd
 
 __version__ = pyimsegm_amd.__version__
 
-for _name in ('utilities', 'utilities.data_io', 'superpixels', 'descriptors', 'graph_cuts', 'pipelines'):
+for _name in ('utilities', 'utilities.data_io', 'superpixels', 'descriptors', 'graph_cuts', 'labeling', 'classification', 'pipelines'):
     _mod = importlib.import_module('pyimsegm_amd.' + _name)
     sys.modules['imsegm.' + _name] = _mod
     if '.' not in _name:

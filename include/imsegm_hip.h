@@ -72,6 +72,12 @@ IMSEGM_API int imsegm_image2d_get_labels(imsegm_image2d *img, int64_t *labels_ou
 /* install an arbitrary label map (int32, values in [0, n_labels)) -- stage-level entry for the
  * descriptor / graph functions that take a user segmentation */
 IMSEGM_API int imsegm_image2d_set_labels(imsegm_image2d *img, const int32_t *labels, int n_labels);
+/* Replaces the per-pixel Python loop of imsegm/labeling.py:208-247 histogram_regions_labels_counts(slic, segm)
+ * (called through histogram_regions_labels_norm at imsegm/pipelines.py:284 to label superpixels from an
+ * annotation): hist_out[k * nb_annot + a] = number of pixels with resident label k and annotation a.
+ * annot: host int32, one value per pixel (voxel) of the session; values outside [0, nb_annot) are not counted.
+ * hist_out: host int64 [n_labels * nb_annot].  Works on image and volume sessions. */
+IMSEGM_API int imsegm_image2d_label_hist(imsegm_image2d *img, const int32_t *annot, int nb_annot, int64_t *hist_out);
 /* inspection for the parity tests: pre-processed Lab planes [3][H][W] and raw k-means assignment */
 IMSEGM_API int imsegm_image2d_get_lab(imsegm_image2d *img, double *lab_out);
 IMSEGM_API int imsegm_image2d_get_nearest(imsegm_image2d *img, int32_t *nearest_out);

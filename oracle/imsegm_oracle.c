@@ -914,3 +914,16 @@ ORC_API int orc_label_cc(const int32_t *in, int D, int H, int W, int32_t *out)
     free(parent);
     return count;
 }
+
+/* imsegm/labeling.py:208-247 histogram_regions_labels_counts: matrix_hist[slic[i], segm[i]] += 1 over the flat
+ * arrays (:244-245).  hist: [K][nb], zeroed here; pairs outside the matrix are not counted (the Python code
+ * cannot meet them: K = max(slic) + 1, nb = max(segm) + 1, negatives rejected at :236). */
+ORC_API void orc_label_hist(const int32_t *slic, const int32_t *annot, size_t n, int K, int nb, int64_t *hist)
+{
+    memset(hist, 0, (size_t)K * nb * sizeof(int64_t));
+    for (size_t i = 0; i < n; ++i) {
+        int k = slic[i], a = annot[i];
+        if (k < 0 || k >= K || a < 0 || a >= nb) continue;
+        hist[(size_t)k * nb + a] += 1;
+    }
+}

@@ -364,3 +364,27 @@ def gather_f64(lut, idx):
     out = np.empty(idx32.shape + (lut.shape[1],), dtype=np.float64)
     lib().orc_gather_f64(_p(lut), C.c_int(lut.shape[1]), _p(idx32), C.c_size_t(idx32.size), _p(out))
     return out
+
+
+def histogram_regions_labels_counts(slic, segm):
+    """imsegm/labeling.py:208-247 on the oracle: float matrix [max(slic) + 1, max(segm) + 1] of pixel counts"""
+    slic = np.ascontiguousarray(slic, dtype=np.int32)
+    segm = np.ascontiguousarray(segm, dtype=np.int32)
+    if slic.shape != segm.shape:
+        raise TypeError('dimension does not agree')
+    if segm.size and segm.min() < 0:
+        raise ValueError('only positive labels are allowed')
+    K, nb = int(slic.max()) + 1, int(segm.max()) + 1
+    hist = np.zeros((K, nb), dtype=np.int64)
+    lib().orc_label_hist(_p(slic), _p(segm), C.c_size_t(slic.size), C.c_int(K), C.c_int(nb), _p(hist))
+    return hist.astype(np.float64)
+
+
+def histogram_regions_labels_norm(slic, segm):
+    """imsegm/labeling.py:250-280: rows divided by their sums (empty rows stay 0)"""
+    hist = histogram_regions_labels_counts(slic, segm)
+    sums = hist.sum(axis=1, keepdims=True)
+    sums[sums == 0] = -1.
+    hist = np.nan_to_num(hist / sums)
+    hist[hist == 0] = 0
+    return hist

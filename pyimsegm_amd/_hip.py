@@ -60,6 +60,7 @@ _SIGNATURES = {
                                       C.c_int, C.c_int, C.c_double, C.c_double, C.c_int, C.c_int, C.c_int, _ip]),
     'imsegm_image2d_get_labels': (C.c_int, [_vp, _vp]),
     'imsegm_image2d_set_labels': (C.c_int, [_vp, _vp, C.c_int]),
+    'imsegm_image2d_label_hist': (C.c_int, [_vp, _vp, C.c_int, _vp]),
     'imsegm_image2d_get_lab': (C.c_int, [_vp, _vp]),
     'imsegm_image2d_get_nearest': (C.c_int, [_vp, _vp]),
     'imsegm_image2d_color_stats': (C.c_int, [_vp, _vp, _vp, _vp]),
@@ -284,6 +285,17 @@ class Image2D(object):
         _check(load_library().imsegm_image2d_set_labels(self._h, _ptr(labels), int(n_labels)))
         self.n_labels = int(n_labels)
         return self
+
+    def label_hist(self, annot, nb_annot=None):
+        """counts[k, a] = pixels with resident label k and annotation a (int64 [n_labels, nb_annot])"""
+        annot = np.ascontiguousarray(annot, dtype=np.int32)
+        if annot.shape != self.shape:
+            raise ValueError('annotation %r does not match the session %r' % (annot.shape, self.shape))
+        if nb_annot is None:
+            nb_annot = int(annot.max()) + 1 if annot.size else 1
+        out = np.empty((self.n_labels, int(nb_annot)), dtype=np.int64)
+        _check(load_library().imsegm_image2d_label_hist(self._h, _ptr(annot), int(nb_annot), _ptr(out)))
+        return out
 
     def get_lab(self):
         out = np.empty((3,) + self.shape, dtype=np.float64)

@@ -157,7 +157,7 @@ struct imsegm_image2d {
     bool is_volume = false;
     double vol_off = 0.0, vol_scale = 1.0;      // intensity seen by the volume SLIC = (v + off) * scale
     DevBuf img, labA, labB, nearest, labels, conn_i32, conn_u8, small, cent, tiles, feat, graph, gather_lut, gather_out_i, gather_out_f,
-        tex_planes, tex_resp, tex_small, vol_cent;
+        tex_planes, tex_resp, tex_small, vol_cent, annot, hist;
 };
 
 // entry points are specific to colour images (D == 1) or gray volumes (created by imsegm_volume_create)
@@ -342,7 +342,7 @@ void imsegm_image2d_destroy(imsegm_image2d *im)
     (void)hipStreamSynchronize(im->ctx->stream);
     DevBuf *all[] = { &im->img, &im->labA, &im->labB, &im->nearest, &im->labels, &im->conn_i32, &im->conn_u8, &im->small,
                       &im->cent, &im->tiles, &im->feat, &im->graph, &im->gather_lut, &im->gather_out_i, &im->gather_out_f,
-                      &im->tex_planes, &im->tex_resp, &im->tex_small, &im->vol_cent };
+                      &im->tex_planes, &im->tex_resp, &im->tex_small, &im->vol_cent, &im->annot, &im->hist };
     for (auto b : all) b->release();
     delete im;
 }
@@ -576,6 +576,34 @@ int imsegm_image2d_set_labels(imsegm_image2d *im, const int32_t *labels, int n_l
     HIP_TRY(hipStreamSynchronize(im->ctx->stream));
     im->n_labels = n_labels;
     im->have_labels = true;
+    return 0;
+}
+
+// labeling.py:208-247 histogram_regions_labels_counts(slic, segm) on the resident label map (any session kind)
+int imsegm_image2d_label_hist(imsegm_image2d *im, const int32_t *annot, int nb_annot, int64_t *hist_out)
+{
+    if (!im || bind(im->ctx)) return -1;
+    if (!im->have_labels) {
+        set_error("label_hist needs a label map (run slic or set_labels first)");
+        return -1;
+    }
+    if (!annot || !hist_out || nb_annot < 1) {
+        set_error("label_hist: annotation, output and a positive number of annotation labels are required");
+        return -1;
+    }
+    const size_t bins = (size_t)im->n_labels * (size_t)nb_annot;
+    if (bins > ((size_t)1 << 31)) {
+        set_error("label_hist: histogram of more than 2^31 bins");
+        return -1;
+    }
+    hipStream_t st = im->ctx->stream;
+    if (im->annot.ensure(im->n * 4 + 32) || im->hist.ensure(bins * 8)) return -1;
+    HIP_TRY(hipMemcpyAsync(im->annot.p, annot, im->n * 4, hipMemcpyHostToDevice, st));
+    if (launch_label_hist(im->labels.as<int32_t>(), im->annot.as<int32_t>(), im->n, im->n_labels, nb_annot,
+                          im->hist.as<unsigned long long>(), st))
+        return -1;
+    HIP_TRY(hipMemcpyAsync(hist_out, im->hist.p, bins * 8, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
     return 0;
 }
 

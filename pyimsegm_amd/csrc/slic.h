@@ -133,6 +133,9 @@ int launch_enforce_connectivity(const int32_t *labels_in, int D, int H, int W, l
                                 hipStream_t st);
 
 // stats.hip ---------------------------------------------------------------------------------------
+// hist[K][nb] (zeroed here) += 1 per pixel with label k in [0, K) and annotation a in [0, nb)  (labeling.py:208-247)
+int launch_label_hist(const int32_t *labels, const int32_t *annot, size_t n, int K, int nb, unsigned long long *hist,
+                      hipStream_t st);
 // per-superpixel colour statistics (features_cython.pyx:59-141): sums of v, v*v (float32 product)
 // and (v - mean32)^2 (float32), exact fixed-point accumulation. acc: [K][13] int64 scratch.
 int launch_color_stats(const void *img, int dtype, const int32_t *labels, int H, int W, int K, double maxabs,

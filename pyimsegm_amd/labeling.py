@@ -1,0 +1,98 @@
+"""Superpixel x annotation histograms -- the part of the reference module ``imsegm/labeling.py`` that sits on
+the supervised SLIC -> features -> classifier -> GraphCut path (``histogram_regions_labels_counts`` :208,
+``histogram_regions_labels_norm`` :250, called at ``imsegm/pipelines.py:284``).
+
+The reference counts with a per-pixel Python loop (``labeling.py:244-245``); here the pairs are counted by the
+HIP kernel ``k_label_hist`` (``csrc/stats.hip``) through ``imsegm_image2d_label_hist``.  There is no CPU
+fallback: without the HIP library the calls raise.
+"""
+import numpy as np
+
+from pyimsegm_amd import _hip
+from pyimsegm_amd.utilities import ImageDimensionError
+
+
+def _flat2d(arr):
+    """any-dimensional label array as rows x columns (the histogram only sees the flat order)"""
+    arr = np.asarray(arr)
+    if arr.ndim == 0:
+        return arr.reshape(1, 1)
+    return arr.reshape(-1, arr.shape[-1]) if arr.ndim != 2 else arr
+
+
+def histogram_regions_labels_counts(slic, segm, _session=None):
+    """ histogram of overlapping regions between two segmentations,
+    the typical usage is labelling superpixels from an annotation
+
+    :param ndarray slic: input superpixel segmentation
+    :param ndarray segm: reference segmentation (annotation), non-negative labels
+    :param _session: (internal) device session that already holds ``slic`` as its label map
+    :return ndarray: float matrix, rows = superpixels ``0..max(slic)``, columns = labels ``0..max(segm)``
+
+    >>> slic = np.array([[0] * 3 + [1] * 3 + [2] * 3] * 4 +
+    ...                 [[4] * 3 + [5] * 3 + [6] * 3] * 4)
+    >>> segm = np.zeros(slic.shape, dtype=int)
+    >>> segm[4:, 5:] = 2
+    >>> histogram_regions_labels_counts(slic, segm)  # doctest: +SKIP
+    array([[12.,  0.,  0.],
+           [12.,  0.,  0.],
+           [12.,  0.,  0.],
+           [ 0.,  0.,  0.],
+           [12.,  0.,  0.],
+           [ 8.,  0.,  4.],
+           [ 0.,  0., 12.]])
+    """
+    segm = np.asarray(segm)
+    if _session is None:
+        slic = np.asarray(slic)
+        if slic.shape != segm.shape:
+            raise ImageDimensionError('dimension does not agree')
+    elif tuple(_session.shape) != segm.shape:
+        raise ImageDimensionError('dimension does not agree')
+    if segm.size and segm.min() < 0:
+        raise ValueError('only positive labels are allowed')
+    nb_annot = int(segm.max()) + 1 if segm.size else 1
+    if _session is not None:
+        counts = _session.label_hist(segm, nb_annot)
+    else:
+        slic2d = _flat2d(slic)
+        if slic2d.size and slic2d.min() < 0:
+            raise ValueError('only positive superpixel labels are allowed')
+        sess = _hip.Image2D(slic2d.shape[0], slic2d.shape[1]).set_labels(slic2d)
+        try:
+            counts = sess.label_hist(_flat2d(segm), nb_annot)
+        finally:
+            sess.close()
+    return counts.astype(np.float64)
+
+
+def histogram_regions_labels_norm(slic, segm, _session=None):
+    """ normalised histogram of overlapping regions between two segmentations: the relative overlap of every
+    superpixel with every annotation label (rows of superpixels without pixels stay zero)
+
+    :param ndarray slic: input superpixel segmentation
+    :param ndarray segm: reference segmentation
+    :return ndarray:
+
+    >>> slic = np.array([[0] * 3 + [1] * 3 + [2] * 3] * 4 +
+    ...                 [[4] * 3 + [5] * 3 + [6] * 3] * 4)
+    >>> segm = np.zeros(slic.shape, dtype=int)
+    >>> segm[4:, 5:] = 2
+    >>> histogram_regions_labels_norm(slic, segm)  # doctest: +SKIP
+    array([[1.        , 0.        , 0.        ],
+           [1.        , 0.        , 0.        ],
+           [1.        , 0.        , 0.        ],
+           [0.        , 0.        , 0.        ],
+           [1.        , 0.        , 0.        ],
+           [0.66666667, 0.        , 0.33333333],
+           [0.        , 0.        , 1.        ]])
+    """
+    shape = tuple(_session.shape) if _session is not None else np.shape(slic)
+    if shape != np.shape(segm):
+        raise ImageDimensionError('dimension of SLIC %r and segm %r should match' % (shape, np.shape(segm)))
+    matrix_hist = histogram_regions_labels_counts(slic, segm, _session=_session)
+    region_sums = matrix_hist.sum(axis=1, keepdims=True)
+    region_sums[region_sums == 0] = -1.            # no division by zero
+    matrix_hist = np.nan_to_num(matrix_hist / region_sums)
+    matrix_hist[matrix_hist == 0] = 0              # no negative zeros
+    return matrix_hist

@@ -3,7 +3,8 @@
 Host-side mirror of the unsupervised part of the reference module ``imsegm/pipelines.py``
 (``pipe_color2d_slic_features_model_graphcut`` :46, ``estim_model_classes_group`` :113,
 ``segment_color2d_slic_features_model_graphcut`` :160, ``compute_color2d_superpixels_features``
-:244).  One image is uploaded once; superpixels, descriptors, adjacency graph, graph cut and the
+:244) and of its supervised part (``wrapper_compute_color2d_slic_features_labels`` :272,
+``train_classif_color2d_slic_features`` :292).  One image is uploaded once; superpixels, descriptors, adjacency graph, graph cut and the
 final ``proba[slic]`` / ``labels[slic]`` gathers all work on the device-resident session, only
 K x F features, E edges and K x C probabilities cross the PCIe bus in between (the class model is
 scikit-learn on the host, as in the reference).
@@ -16,12 +17,17 @@ from pyimsegm_amd import _hip
 from pyimsegm_amd.descriptors import (FEATURES_SET_COLOR, _selected_features_color2d, compute_selected_features_gray3d,
                                       compute_selected_features_img2d, norm_features)
 from pyimsegm_amd.graph_cuts import estim_class_model, predict_proba, segment_graph_cut_general
+from pyimsegm_amd.labeling import histogram_regions_labels_norm
 from pyimsegm_amd.superpixels import _open_session, _open_volume, _release_session, _run_slic, _run_slic3d
 
 #: select basic features extracted from superpixels
 FTS_SET_SIMPLE = FEATURES_SET_COLOR
 #: default modeling / clustering for unsupervised segmentation
 CLUSTER_METHOD = 'GMM'
+#: default classifier for supervised segmentation
+CLASSIF_NAME = 'RandForest'
+#: number of images held out per fold of the group cross-validation (reference ``pipelines.py:38``)
+CROSS_VAL_LEAVE_OUT = 2
 #: default number of images a process keeps in flight on its GPU (worker threads with one HIP stream
 #: each; the reference's ``NB_WORKERS`` counts pool processes, ``pipelines.py:32``)
 NB_WORKERS = 2
@@ -106,6 +112,98 @@ def compute_color2d_superpixels_features(image, dict_features, sp_size=30, sp_re
     res.close()
     logging.debug('list of features RAW: %r', features.shape)
     return slic, features
+
+
+def wrapper_compute_color2d_slic_features_labels(img_annot, sp_size, sp_regul, dict_features, label_purity):
+    """ superpixels, their features and their training labels from an annotation (reference ``pipelines.py:272-289``)
+
+    The label of a superpixel is the annotation label that covers most of it; superpixels whose best label covers
+    less than ``label_purity`` of them, or whose best label is a negative ("do not care") annotation, get -1.
+    SLIC, the descriptors and the superpixel x annotation histogram all run on one device-resident session.
+
+    :param tuple(ndarray,ndarray) img_annot: image and its annotation (integer labels, negative = ignore)
+    :return tuple(ndarray,ndarray,ndarray): superpixel map, features K x F, labels K
+    """
+    from pyimsegm_amd.utilities import ImageDimensionError
+    img, annot = img_annot
+    annot = np.asarray(annot).astype(int)            # binary annotations become integer labels
+    if np.shape(img)[:2] != annot.shape[:2]:
+        raise ImageDimensionError('image %r and annot %r should match' % (np.shape(img), annot.shape))
+    res = _ResidentImage(img, dict_features, sp_size, sp_regul)
+    neg_label = np.max(annot) + 1 if np.sum(annot < 0) > 0 else None
+    if neg_label is not None:
+        annot[annot < 0] = neg_label
+    label_hist = histogram_regions_labels_norm(None, annot, _session=res.sess)
+    slic, features = res.slic, res.features
+    res.close()
+    labels = np.argmax(label_hist, axis=1)
+    purity = np.max(label_hist, axis=1)
+    if neg_label is not None:
+        labels[labels == neg_label] = -1
+    labels[purity < label_purity] = -1
+    return slic, features, labels
+
+
+def train_classif_color2d_slic_features(
+    list_images,
+    list_annots,
+    dict_features,
+    sp_size=30,
+    sp_regul=0.2,
+    clf_name=CLASSIF_NAME,
+    label_purity=0.9,
+    feature_balance='unique',
+    pca_coef=None,
+    nb_classif_search=1,
+    nb_hold_out=CROSS_VAL_LEAVE_OUT,
+    nb_workers=1,
+):
+    """ train a classifier on a list of annotated images (reference ``pipelines.py:292-379``)
+
+    :param list(ndarray) list_images: RGB images
+    :param list(ndarray) list_annots: annotations, integer labels (negative = do not care)
+    :param dict(list(str)) dict_features: features to be extracted
+    :param int sp_size: initial size of a superpixel (edge length)
+    :param float sp_regul: regularisation in (0, 1)
+    :param str clf_name: classifier, see :func:`classification.create_classifiers`
+    :param float label_purity: minimal share of a superpixel its label has to cover
+    :param str feature_balance: how to balance the training set (per image): 'unique', 'random', 'kmeans' or None
+    :param float pca_coef: PCA coefficient or None
+    :param int nb_classif_search: number of tries of the hyper-parameter search (<= 1: train once)
+    :param int nb_hold_out: images held out per cross-validation fold of that search
+    :param int nb_workers: images in flight on this GPU (worker threads) and jobs of the search
+    :return tuple(obj,list(ndarray),list(ndarray),list(ndarray)): classifier, superpixel maps, features, labels
+    """
+    from pyimsegm_amd.classification import (CrossValidateGroups, convert_set_features_labels_2_dataset,
+                                             create_classif_search_train_export)
+    logging.info('TRAIN Superpixels-Features-Classifier')
+    if len(list_images) != len(list_annots):
+        raise ValueError('size of images (%i) and annotations (%i) should match' % (len(list_images), len(list_annots)))
+
+    def _compute(img_annot):
+        return wrapper_compute_color2d_slic_features_labels(img_annot, sp_size, sp_regul, dict_features, label_purity)
+
+    pairs = list(zip(list_images, list_annots))
+    if nb_workers and nb_workers > 1 and len(pairs) > 1:
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(max_workers=int(nb_workers)) as pool:
+            results = list(pool.map(_compute, pairs))
+    else:
+        results = [_compute(pair) for pair in pairs]
+    list_slic = [r[0] for r in results]
+    list_features = [r[1] for r in results]
+    list_labels = [r[2] for r in results]
+
+    # one training set over all images; the "do not care" superpixels (-1) are dropped
+    features, labels, sizes = convert_set_features_labels_2_dataset(
+        dict(zip(range(len(list_features)), list_features)), dict(zip(range(len(list_labels)), list_labels)),
+        balance_type=feature_balance, drop_labels=[-1])
+    features = np.nan_to_num(features)
+    # hold out whole images when there are enough of them, else plain 10-fold
+    cv = CrossValidateGroups(sizes, nb_hold_out=nb_hold_out) if len(sizes) > (nb_hold_out * 5) else 10
+    classif, _ = create_classif_search_train_export(clf_name, features, labels, pca_coef=pca_coef, cross_val=cv,
+                                                    nb_search_iter=nb_classif_search, nb_workers=nb_workers)
+    return classif, list_slic, list_features, list_labels
 
 
 def pipe_color2d_slic_features_model_graphcut(

@@ -14,9 +14,10 @@ def disc_image(size=256, radius=80, seed=0):
     return img.astype(np.uint8)
 
 
-def voronoi_image(height=2048, width=2048, nb_seeds=24, seed=1, noise=12.):
+def voronoi_image(height=2048, width=2048, nb_seeds=24, seed=1, noise=12., return_classes=False):
     """configs C2-C4: 3-class piecewise-constant image (Voronoi cells of ``nb_seeds`` points,
-    class = cell id mod 3) with class colours + N(0, noise) clipped to uint8"""
+    class = cell id mod 3) with class colours + N(0, noise) clipped to uint8; ``return_classes``: also the class map
+    (the annotation of the supervised path)"""
     rng = np.random.default_rng(seed)
     pts = np.stack([rng.uniform(0, height, nb_seeds), rng.uniform(0, width, nb_seeds)], axis=1)
     yy, xx = np.mgrid[:height, :width]
@@ -29,7 +30,8 @@ def voronoi_image(height=2048, width=2048, nb_seeds=24, seed=1, noise=12.):
         cell[upd] = i
     colours = np.array([(60, 60, 180), (200, 180, 40), (40, 170, 90)], dtype=np.float64)
     img = colours[cell % 3] + rng.normal(0, noise, (height, width, 3))
-    return np.clip(np.round(img), 0, 255).astype(np.uint8)
+    img = np.clip(np.round(img), 0, 255).astype(np.uint8)
+    return (img, (cell % 3).astype(np.int64)) if return_classes else img
 
 
 def ellipsoid_volume(shape=(16, 64, 64), seed=5, noise=0.05):

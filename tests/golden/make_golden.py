@@ -118,6 +118,21 @@ def main():
     np.savez_compressed(os.path.join(HERE, 'texture.npz'), gray=gray, names=np.array(names),
                         **{'battery_%02d' % i: np.asarray(b) for i, b in enumerate(bank)},
                         **{'response_%02d' % i: r for i, r in enumerate(responses)}, smooth=smooth)
+
+    # ---- labeling.py: superpixel x annotation histograms (supervised path, pipelines.py:284) ---------
+    class ImageDimensionError(TypeError):
+        pass
+    ns = {'np': np, 'logging': logging, 'ImageDimensionError': ImageDimensionError}
+    lift(os.path.join(REF, 'labeling.py'), ['histogram_regions_labels_counts', 'histogram_regions_labels_norm'], ns)
+    rng2 = np.random.default_rng(77)                       # own stream: the sections above keep their vectors
+    yy, xx = np.mgrid[:45, :61]
+    slic = ((yy // 7) * 10 + xx // 7).astype(np.int64)
+    slic[slic == 13] = 80                                  # an unused stretch of labels
+    annot = ((yy > 20).astype(np.int64) + (xx > 33) * 2)
+    annot[rng2.random(annot.shape) < 0.15] = 5            # sparse extra label, leaves label 4 unused
+    np.savez_compressed(os.path.join(HERE, 'labeling.npz'), slic=slic, annot=annot,
+                        counts=ns['histogram_regions_labels_counts'](slic, annot),
+                        norm=ns['histogram_regions_labels_norm'](slic, annot))
     print('golden vectors written to', HERE)
 
 

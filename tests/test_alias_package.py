@@ -17,7 +17,8 @@ def test_alias_modules_are_the_same_objects():
     seg_fts.USE_CYTHON = True
     assert issubclass(ImageDimensionError, TypeError)
     for name in ('pipe_color2d_slic_features_model_graphcut', 'estim_model_classes_group',
-                 'segment_color2d_slic_features_model_graphcut', 'compute_color2d_superpixels_features'):
+                 'segment_color2d_slic_features_model_graphcut', 'compute_color2d_superpixels_features',
+                 'train_classif_color2d_slic_features', 'wrapper_compute_color2d_slic_features_labels'):
         assert callable(getattr(seg_pipe, name))
     assert imsegm.__version__
 
@@ -29,9 +30,11 @@ def test_host_side_doctests():
     import pyimsegm_amd.descriptors as d
     import pyimsegm_amd.graph_cuts as g
     import pyimsegm_amd.superpixels as s
+    import pyimsegm_amd.classification as c
+    import pyimsegm_amd.labeling as lb
     import pyimsegm_amd.utilities.data_io as io
     with warnings.catch_warnings():
         warnings.simplefilter('ignore')
-        for mod in (d, g, s, io):
+        for mod in (d, g, s, io, c, lb):
             res = doctest.testmod(mod)
             assert res.failed == 0, mod.__name__

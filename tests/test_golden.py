@@ -63,3 +63,21 @@ def test_host_texture_bank_matches_reference():
         resp = d.compute_img_filter_response2d(t['gray'], battery)
         np.testing.assert_allclose(resp, t['response_%02d' % i], rtol=1e-12, atol=1e-12)
     assert 'smooth' in t.files
+
+
+def test_oracle_label_histograms_match_reference(oracle):
+    """labeling.py:208-280 lifted from the reference and its doctest vectors (:217-230, :259-270)"""
+    g = _load('labeling.npz')
+    counts = oracle.histogram_regions_labels_counts(g['slic'], g['annot'])
+    assert counts.dtype == np.float64 and np.array_equal(counts, g['counts'])
+    assert np.array_equal(oracle.histogram_regions_labels_norm(g['slic'], g['annot']), g['norm'])
+    slic = np.array([[0] * 3 + [1] * 3 + [2] * 3] * 4 + [[4] * 3 + [5] * 3 + [6] * 3] * 4)
+    segm = np.zeros(slic.shape, dtype=int)
+    segm[4:, 5:] = 2
+    assert oracle.histogram_regions_labels_counts(slic, segm).tolist() == \
+        [[12, 0, 0], [12, 0, 0], [12, 0, 0], [0, 0, 0], [12, 0, 0], [8, 0, 4], [0, 0, 12]]
+    norm = oracle.histogram_regions_labels_norm(slic, segm)
+    np.testing.assert_allclose(norm[5], [2 / 3., 0, 1 / 3.], rtol=0, atol=1e-15)
+    assert norm[3].tolist() == [0, 0, 0] and not np.signbit(norm).any()
+    with pytest.raises(ValueError):
+        oracle.histogram_regions_labels_counts(slic, segm - 1)

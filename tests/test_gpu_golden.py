@@ -33,3 +33,36 @@ def test_descriptors_match_reference_cython():
     np.testing.assert_allclose(d.cython_img3d_gray_mean(t['vol'], t['segv']), t['meanv'], rtol=1e-6, atol=1e-7)
     np.testing.assert_allclose(d.cython_img3d_gray_energy(t['vol'], t['segv']), t['energyv'], rtol=1e-6, atol=1e-7)
     np.testing.assert_allclose(d.cython_img3d_gray_std(t['vol'], t['segv'])**2, t['varv'], rtol=1e-6, atol=1e-7)
+
+
+def test_label_histograms_match_reference(oracle):
+    """labeling.py:208-280: golden vectors of the reference's own functions, its doctest vectors, and the
+    oracle on shapes that exercise the kernel's tail / unaligned paths"""
+    from pyimsegm_amd import labeling as lb
+    from pyimsegm_amd.utilities import ImageDimensionError
+    g = _load('labeling.npz')
+    counts = lb.histogram_regions_labels_counts(g['slic'], g['annot'])
+    assert counts.dtype == np.float64 and np.array_equal(counts, g['counts'])
+    assert np.array_equal(lb.histogram_regions_labels_norm(g['slic'], g['annot']), g['norm'])
+    slic = np.array([[0] * 3 + [1] * 3 + [2] * 3] * 4 + [[4] * 3 + [5] * 3 + [6] * 3] * 4)
+    segm = np.zeros(slic.shape, dtype=int)
+    segm[4:, 5:] = 2
+    assert lb.histogram_regions_labels_counts(slic, segm).tolist() == \
+        [[12, 0, 0], [12, 0, 0], [12, 0, 0], [0, 0, 0], [12, 0, 0], [8, 0, 4], [0, 0, 12]]
+    norm = lb.histogram_regions_labels_norm(slic, segm)
+    np.testing.assert_allclose(norm[5], [2 / 3., 0, 1 / 3.], rtol=0, atol=1e-15)
+    with pytest.raises(ValueError):
+        lb.histogram_regions_labels_counts(slic, segm - 1)
+    with pytest.raises(ImageDimensionError):
+        lb.histogram_regions_labels_norm(slic, segm[:, :-1])
+    rng = np.random.default_rng(5)
+    for shape, K, nb in [((1, 1), 1, 1), ((3, 5), 4, 2), ((67, 129), 300, 7), ((5, 9, 13), 40, 3), ((1031,), 17, 2),
+                         ((640, 1024), 522, 4)]:
+        s = rng.integers(0, K, shape)
+        a = rng.integers(0, nb, shape)
+        if len(shape) == 2 and shape[0] > 60:        # realistic: blocky superpixels, smooth annotation
+            yy, xx = np.mgrid[:shape[0], :shape[1]]
+            s = ((yy // 24) * ((shape[1] + 23) // 24) + xx // 24) % K
+            a = ((yy + xx) // 97) % nb
+        assert np.array_equal(lb.histogram_regions_labels_counts(s, a), oracle.histogram_regions_labels_counts(s, a)), shape
+        assert np.array_equal(lb.histogram_regions_labels_norm(s, a), oracle.histogram_regions_labels_norm(s, a)), shape
