@@ -416,7 +416,7 @@ int imsegm_image2d_slic(imsegm_image2d *im, int minmax_normalize, int n_segments
     // buffers
     if (im->labA.ensure(3 * n * sizeof(double)) || im->labB.ensure(3 * n * sizeof(double))) return -1;
     if (im->nearest.ensure(n * 4) || im->labels.ensure(n * 4)) return -1;
-    size_t cent_bytes = (size_t)K * (5 * 8 + 16 + 9 * 8 + 16) + 256;
+    size_t cent_bytes = (size_t)K * (5 * 8 + 16 + 9 * 8 + 16) + 256 + SLIC_DRIFT_SLOTS * sizeof(int);
     if (im->cent.ensure(cent_bytes)) return -1;
     const size_t n_tiles = (size_t)cdiv(W, SLIC_TILE_X) * cdiv(H, SLIC_TILE_Y);
     if (im->tiles.ensure(n_tiles * (SLIC_MAXC * (sizeof(Cand) + sizeof(Rec32) + sizeof(int)) + sizeof(TileInfo) + sizeof(int)) + n * 4 + 1024))
@@ -474,6 +474,7 @@ int imsegm_image2d_slic(imsegm_image2d *im, int minmax_normalize, int n_segments
     s.win = reinterpret_cast<int4 *>(cb); cb += (size_t)K * 16;
     s.mdc = reinterpret_cast<double *>(cb); cb += (size_t)K * 8;
     s.slico = slic_zero ? 1 : 0;
+    s.drift = reinterpret_cast<int *>(cb); cb += SLIC_DRIFT_SLOTS * sizeof(int);
     s.grid_y0 = (int)ax[1].start; s.grid_dy = (int)ax[1].step;
     s.grid_x0 = (int)ax[2].start; s.grid_dx = (int)ax[2].step; s.grid_nx = (int)nx;
     double *init_dev = nullptr;                            // the grid is generated on the device

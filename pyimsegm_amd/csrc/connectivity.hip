@@ -71,19 +71,21 @@ __device__ __forceinline__ void uf_union(int32_t *parent, int a, int b)
 // Run-based initialisation: every active pixel points at the leftmost pixel of its horizontal run
 // inside its 64-pixel wave segment (ballot + count-leading-zeros, no memory traffic), so the
 // union-find forest starts with paths of length <= 1 and the merge pass only has to join runs.
-__device__ __forceinline__ bool run_continues(const int32_t *labels, const uint8_t *state, int p, int x)
+// ALL: every pixel is active (the first round, i.e. always on the fast path): the state bytes are not read
+template <bool ALL> __device__ __forceinline__ bool is_active(const uint8_t *state, int p)
 {
-    return x > 0 && state[p - 1] == ST_ACTIVE && labels[p - 1] == labels[p];
+    return ALL || state[p] == ST_ACTIVE;
 }
 
+template <bool ALL>
 __global__ void __launch_bounds__(256)
 k_ccl_init(const int32_t *__restrict__ labels, const uint8_t *__restrict__ state, int32_t *parent, int n, int W)
 {
     int p = blockIdx.x * blockDim.x + threadIdx.x;
     const int lane = threadIdx.x & 63;
-    bool active = p < n && state[p] == ST_ACTIVE;
+    bool active = p < n && is_active<ALL>(state, p);
     bool cont = false;
-    if (active) cont = run_continues(labels, state, p, p % W);
+    if (active) cont = (p % W) > 0 && is_active<ALL>(state, p - 1) && labels[p - 1] == labels[p];
     unsigned long long starts = __ballot(active && !cont);
     if (!active) return;
     unsigned long long below = starts & ((lane == 63) ? ~0ULL : ((2ULL << lane) - 1ULL));
@@ -91,44 +93,47 @@ k_ccl_init(const int32_t *__restrict__ labels, const uint8_t *__restrict__ state
     parent[p] = p - (lane - start_lane);
 }
 
+template <bool ALL>
 __global__ void __launch_bounds__(256)
 k_ccl_merge(const int32_t *__restrict__ labels, const uint8_t *__restrict__ state, int32_t *parent, int D, int H, int W)
 {
     int p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= D * H * W || state[p] != ST_ACTIVE) return;
+    if (p >= D * H * W || !is_active<ALL>(state, p)) return;
     int x = p % W, y = (p / W) % H, z = p / (W * H);
     int l = labels[p];
-    bool cont = x > 0 && state[p - 1] == ST_ACTIVE && labels[p - 1] == l;
+    bool cont = x > 0 && is_active<ALL>(state, p - 1) && labels[p - 1] == l;
     // horizontal: only the first lane of a wave segment still has to be tied to its left neighbour
     if (cont && (threadIdx.x & 63) == 0) uf_union(parent, p, p - 1);
     // vertical: one union per pair of overlapping runs is enough -- skip it when the left
     // neighbour pair (p-1, p-W-1) carries the same two runs (it, or a pixel further left, does it)
-    if (y > 0 && state[p - W] == ST_ACTIVE && labels[p - W] == l) {
-        bool left_pair_same = cont && state[p - W - 1] == ST_ACTIVE && labels[p - W - 1] == l;
+    if (y > 0 && is_active<ALL>(state, p - W) && labels[p - W] == l) {
+        bool left_pair_same = cont && is_active<ALL>(state, p - W - 1) && labels[p - W - 1] == l;
         if (!left_pair_same) uf_union(parent, p, p - W);
     }
     const int HW = H * W;
-    if (z > 0 && state[p - HW] == ST_ACTIVE && labels[p - HW] == l) {
-        bool left_pair_same = cont && state[p - HW - 1] == ST_ACTIVE && labels[p - HW - 1] == l;
+    if (z > 0 && is_active<ALL>(state, p - HW) && labels[p - HW] == l) {
+        bool left_pair_same = cont && is_active<ALL>(state, p - HW - 1) && labels[p - HW - 1] == l;
         if (!left_pair_same) uf_union(parent, p, p - HW);
     }
 }
 
+template <bool ALL>
 __global__ void __launch_bounds__(256) k_ccl_flatten(int32_t *parent, const uint8_t *state, int32_t *csize, int n)
 {
     int p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= n || state[p] != ST_ACTIVE) return;
+    if (p >= n || !is_active<ALL>(state, p)) return;
     int r = uf_find(parent, p);
     parent[p] = r;
     if (r == p) csize[p] = 0;
 }
 
 // component sizes: wave-aggregated atomics (runs of equal roots are the common case)
+template <bool ALL>
 __global__ void __launch_bounds__(256)
 k_comp_size(const int32_t *__restrict__ parent, const uint8_t *__restrict__ state, int32_t *csize, int n)
 {
     int p = blockIdx.x * blockDim.x + threadIdx.x;
-    int r = (p < n && state[p] == ST_ACTIVE) ? parent[p] : -1;
+    int r = (p < n && is_active<ALL>(state, p)) ? parent[p] : -1;
     while (true) {
         unsigned long long vote = __ballot(r >= 0);
         if (!vote) break;
@@ -140,12 +145,13 @@ k_comp_size(const int32_t *__restrict__ parent, const uint8_t *__restrict__ stat
     }
 }
 
+template <bool ALL>
 __global__ void __launch_bounds__(256)
 k_find_oversize(const int32_t *__restrict__ parent, const uint8_t *__restrict__ state, const int32_t *__restrict__ csize,
                 int n, int max_size, int32_t *over_list, int32_t *counters)
 {
     int p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= n || state[p] != ST_ACTIVE || parent[p] != p) return;
+    if (p >= n || !is_active<ALL>(state, p) || parent[p] != p) return;
     if (csize[p] >= max_size) {
         int i = atomicAdd(&counters[CNT_OVER], 1);
         over_list[i] = p;
@@ -222,10 +228,11 @@ __device__ __forceinline__ int block_exclusive_scan(int v, int *total)
     return base + incl - v;
 }
 
+// ASSIGN: second pass -- kept roots receive their labels, the roots of small components are appended to `list`
 template <bool ASSIGN>
 __global__ void __launch_bounds__(256)
 k_kept_scan(const int32_t *__restrict__ parent, const int32_t *__restrict__ csize, int n, int min_size,
-            int32_t *blocksum, int32_t *newlabel, int start_label)
+            int32_t *blocksum, int32_t *newlabel, int start_label, int32_t *list, int32_t *counters)
 {
     int p0 = blockIdx.x * SCAN_BLOCK + threadIdx.x * SCAN_PER_THREAD;
     int cnt = 0;
@@ -241,7 +248,10 @@ k_kept_scan(const int32_t *__restrict__ parent, const int32_t *__restrict__ csiz
         int rank = blocksum[blockIdx.x] + excl;
         for (int j = 0; j < SCAN_PER_THREAD; ++j) {
             int p = p0 + j;
-            if (p < n && parent[p] == p && csize[p] >= min_size) newlabel[p] = start_label + rank++;
+            if (p < n && parent[p] == p) {
+                if (csize[p] >= min_size) newlabel[p] = start_label + rank++;
+                else list[atomicAdd(&counters[CNT_SMALL], 1)] = p;
+            }
         }
     }
 }
@@ -266,18 +276,6 @@ __global__ void __launch_bounds__(256) k_scan_blocksums(int32_t *blocksum, int n
 }
 
 // ---- small components ------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256)
-k_list_small(const int32_t *__restrict__ parent, const int32_t *__restrict__ csize, int n, int min_size,
-             int32_t *list, int32_t *counters)
-{
-    int p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= n || parent[p] != p) return;
-    if (csize[p] < min_size) {
-        int i = atomicAdd(&counters[CNT_SMALL], 1);
-        list[i] = p;
-    }
-}
-
 __global__ void __launch_bounds__(64)
 k_small_resolve(const int32_t *__restrict__ list, const int32_t *__restrict__ counters,
                 const int32_t *__restrict__ csize, const int32_t *__restrict__ adjptr, int min_size,
@@ -311,23 +309,43 @@ k_small_bbox_init(int32_t *bbox, const int32_t *__restrict__ list, const int32_t
     }
 }
 
+// four consecutive pixels per thread (one 16-byte load of their roots): their roots nearly always agree, so a
+// thread looks up one component size, and only the few pixels of small components touch the bbox table
 __global__ void __launch_bounds__(256)
 k_small_bbox(const int32_t *__restrict__ parent, const int32_t *__restrict__ csize, int n, int H, int W, int min_size,
              const int32_t *__restrict__ slotmap, int32_t *bbox, const int32_t *__restrict__ counters, int capacity)
 {
-    int p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= n) return;
-    int r = parent[p];
-    if (csize[r] >= min_size) return;
-    if (counters[CNT_SMALL] > capacity) return;     // table too small: the thread-BFS fallback takes all
-    int i = slotmap[r];
-    int x = p % W, y = (p / W) % H, z = p / (W * H);
-    atomicMin(&bbox[6 * i + 0], y);
-    atomicMax(&bbox[6 * i + 1], y);
-    atomicMin(&bbox[6 * i + 2], x);
-    atomicMax(&bbox[6 * i + 3], x);
-    atomicMin(&bbox[6 * i + 4], z);
-    atomicMax(&bbox[6 * i + 5], z);
+    const int p0 = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (p0 >= n) return;
+    int r[4];
+    if (p0 + 4 <= n) {
+        const int4 v = *reinterpret_cast<const int4 *>(parent + p0);
+        r[0] = v.x; r[1] = v.y; r[2] = v.z; r[3] = v.w;
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) r[j] = p0 + j < n ? parent[p0 + j] : -1;
+    }
+    int last_r = -1;
+    bool last_small = false;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        if (r[j] < 0) continue;
+        if (r[j] != last_r) {
+            last_r = r[j];
+            last_small = csize[last_r] < min_size;
+        }
+        if (!last_small) continue;
+        if (counters[CNT_SMALL] > capacity) return;     // table too small: the thread-BFS fallback takes all
+        const int p = p0 + j;
+        const int i = slotmap[last_r];
+        const int x = p % W, y = (p / W) % H, z = p / (W * H);
+        atomicMin(&bbox[6 * i + 0], y);
+        atomicMax(&bbox[6 * i + 1], y);
+        atomicMin(&bbox[6 * i + 2], x);
+        atomicMax(&bbox[6 * i + 3], x);
+        atomicMin(&bbox[6 * i + 4], z);
+        atomicMax(&bbox[6 * i + 5], z);
+    }
 }
 
 // Processing order of the small components for k_small_bfs_wave: the ones with a large bounding box (long
@@ -518,39 +536,41 @@ k_write_labels(const int32_t *__restrict__ parent, const int32_t *__restrict__ n
 }
 
 // CCL + sizes + oversize detection for the currently active pixels
+template <bool ALL>
 static void conn_ccl_round(const int32_t *labels_in, int D, int H, int W, int max_size, const ConnWork &w, uint8_t *state,
                            hipStream_t st)
 {
     const int n = D * H * W, grid = cdiv(n, 256);
-    hipLaunchKernelGGL(k_ccl_init, grid, 256, 0, st, labels_in, state, w.parent, n, W);
-    hipLaunchKernelGGL(k_ccl_merge, grid, 256, 0, st, labels_in, state, w.parent, D, H, W);
-    hipLaunchKernelGGL(k_ccl_flatten, grid, 256, 0, st, w.parent, state, w.csize, n);
-    hipLaunchKernelGGL(k_comp_size, grid, 256, 0, st, w.parent, state, w.csize, n);
-    hipLaunchKernelGGL(k_find_oversize, grid, 256, 0, st, w.parent, state, w.csize, n, max_size, w.list, w.counters);
+    hipLaunchKernelGGL(k_ccl_init<ALL>, grid, 256, 0, st, labels_in, state, w.parent, n, W);
+    hipLaunchKernelGGL(k_ccl_merge<ALL>, grid, 256, 0, st, labels_in, state, w.parent, D, H, W);
+    hipLaunchKernelGGL(k_ccl_flatten<ALL>, grid, 256, 0, st, w.parent, state, w.csize, n);
+    hipLaunchKernelGGL(k_comp_size<ALL>, grid, 256, 0, st, w.parent, state, w.csize, n);
+    hipLaunchKernelGGL(k_find_oversize<ALL>, grid, 256, 0, st, w.parent, state, w.csize, n, max_size, w.list, w.counters);
 }
 
 // everything after the component structure is final: consecutive labels for kept components,
 // `adjacent` of the small ones (exact BFS emulation), pointer resolution, label write.
 // No host round trip: list lengths stay on the device, the kernels loop over them.
 static int conn_tail(const int32_t *csize_final, int32_t *adjptr, int D, int H, int W, int min_size, int start_label,
-                     const ConnWork &w, int32_t *labels_out, hipStream_t st)
+                     const ConnWork &w, int32_t *labels_out, hipStream_t st, bool counters_are_zero)
 {
     const int n = D * H * W, grid = cdiv(n, 256);
     const int nblocks = cdiv(n, SCAN_BLOCK);
     const int capacity = n / 12;                      // bbox table: 6 ints per small component
     int32_t *bbox = w.bbox;
     int32_t *fallback_list = w.bbox + (size_t)6 * capacity;
+    if (!counters_are_zero) {
+        HIP_TRY(hipMemsetAsync(w.counters + CNT_SMALL, 0, 2 * sizeof(int32_t), st));
+        HIP_TRY(hipMemsetAsync(w.counters + CNT_FALLBACK, 0, 3 * sizeof(int32_t), st));     // FALLBACK, BIG, LITTLE
+    }
     hipLaunchKernelGGL(k_kept_scan<false>, nblocks, 256, 0, st, w.parent, csize_final, n, min_size, w.blocksum,
-                       w.newlabel, start_label);
+                       w.newlabel, start_label, w.list, w.counters);
     hipLaunchKernelGGL(k_scan_blocksums, 1, 256, 0, st, w.blocksum, nblocks, w.counters);
     hipLaunchKernelGGL(k_kept_scan<true>, nblocks, 256, 0, st, w.parent, csize_final, n, min_size, w.blocksum,
-                       w.newlabel, start_label);
+                       w.newlabel, start_label, w.list, w.counters);
     HIP_TRY(hipMemsetAsync(w.visited, 0, n, st));
-    HIP_TRY(hipMemsetAsync(w.counters + CNT_SMALL, 0, 2 * sizeof(int32_t), st));
-    HIP_TRY(hipMemsetAsync(w.counters + CNT_FALLBACK, 0, 3 * sizeof(int32_t), st));     // FALLBACK, BIG, LITTLE
-    hipLaunchKernelGGL(k_list_small, grid, 256, 0, st, w.parent, csize_final, n, min_size, w.list, w.counters);
     hipLaunchKernelGGL(k_small_bbox_init, 64, 256, 0, st, bbox, w.list, w.counters, w.slotmap, capacity);
-    hipLaunchKernelGGL(k_small_bbox, grid, 256, 0, st, w.parent, csize_final, n, H, W, min_size, w.slotmap, bbox,
+    hipLaunchKernelGGL(k_small_bbox, cdiv(cdiv(n, 4), 256), 256, 0, st, w.parent, csize_final, n, H, W, min_size, w.slotmap, bbox,
                        w.counters, capacity);
     // one launch for all of them, long ones first (w.queue is free until the fallback kernel)
     hipLaunchKernelGGL(k_small_order, 64, 256, 0, st, bbox, w.counters, D, H, W, 1024, capacity, w.queue);
@@ -577,10 +597,10 @@ int launch_enforce_connectivity(const int32_t *labels_in, int D, int H, int W, l
 
     // fast path, speculating that no component reaches max_size: one CCL round, then the tail;
     // a single host synchronisation at the very end reads the counters
-    HIP_TRY(hipMemsetAsync(state, ST_ACTIVE, n, st));
+    // (every pixel is active in this round: the kernels do not look at the state bytes)
     HIP_TRY(hipMemsetAsync(w.counters, 0, 16 * sizeof(int32_t), st));
-    conn_ccl_round(labels_in, D, H, W, max_size, w, state, st);
-    if (conn_tail(w.csize, w.adjptr, D, H, W, min_size, start_label, w, labels_out, st)) return -1;
+    conn_ccl_round<true>(labels_in, D, H, W, max_size, w, state, st);
+    if (conn_tail(w.csize, w.adjptr, D, H, W, min_size, start_label, w, labels_out, st, true)) return -1;
     HIP_TRY(hipMemcpyAsync(host_counters, w.counters, 8 * sizeof(int32_t), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
 
@@ -592,7 +612,7 @@ int launch_enforce_connectivity(const int32_t *labels_in, int D, int H, int W, l
         for (int round = 0;; ++round) {
             HIP_TRY(hipMemsetAsync(w.visited, 0, n, st));
             HIP_TRY(hipMemsetAsync(w.counters, 0, 3 * sizeof(int32_t), st));
-            conn_ccl_round(labels_in, D, H, W, max_size, w, state, st);
+            conn_ccl_round<false>(labels_in, D, H, W, max_size, w, state, st);
             HIP_TRY(hipMemcpyAsync(host_counters, w.counters, 4 * sizeof(int32_t), hipMemcpyDeviceToHost, st));
             HIP_TRY(hipStreamSynchronize(st));
             int n_over = host_counters[CNT_OVER];
@@ -612,7 +632,7 @@ int launch_enforce_connectivity(const int32_t *labels_in, int D, int H, int W, l
                 return -1;
             }
         }
-        if (conn_tail(csize_final, w.csize, D, H, W, min_size, start_label, w, labels_out, st)) return -1;
+        if (conn_tail(csize_final, w.csize, D, H, W, min_size, start_label, w, labels_out, st, false)) return -1;
         HIP_TRY(hipMemcpyAsync(host_counters, w.counters, 8 * sizeof(int32_t), hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
     }

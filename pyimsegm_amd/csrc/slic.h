@@ -43,6 +43,7 @@ struct TileInfo {
 };
 
 // device-side SLIC state for one 2-D image (all pointers are device pointers)
+constexpr int SLIC_DRIFT_SLOTS = 64;
 struct SlicState {
     int H, W, K;
     int step_y, step_x;
@@ -65,6 +66,7 @@ struct SlicState {
     int debug;                      // profiling aid (env IMSEGM_DEBUG_ASSIGN): ablation bits, results invalid
     int slico;                      // skimage slic_zero: colour distance / mdc[k], mdc updated after every sweep
     double *mdc;                    // [K] max_dist_color of _slic.pyx (starts at 1)
+    int *drift;                     // [SLIC_DRIFT_SLOTS] per sweep: max displacement of a centroid from its grid node
 };
 
 int launch_minmax(const void *src, int dtype, size_t n, unsigned long long *keys, double *out2, hipStream_t st);

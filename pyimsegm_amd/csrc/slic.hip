@@ -455,6 +455,7 @@ __device__ __forceinline__ int4 search_window(double cy, double cx, int step_y, 
 __global__ void k_centroid_init(SlicState s, const double *__restrict__ init_yx)
 {
     int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < SLIC_DRIFT_SLOTS) s.drift[k] = 0;
     if (k >= s.K) return;
     (void)init_yx;
     const int iy = k / s.grid_nx, ix = k - iy * s.grid_nx;
@@ -472,7 +473,9 @@ __global__ void k_centroid_init(SlicState s, const double *__restrict__ init_yx)
 
 // divide the accumulated sums, recompute the integer search windows, clear the accumulators.
 // A centroid that received no pixel is dead from now on (NaN position in skimage): empty window.
-__global__ void k_centroid_finalize(SlicState s)
+// `drift_slot`: where the largest distance (per axis, rounded up) of a centroid from its grid node goes; the next
+// k_slic_bin only scans the grid nodes that can reach its tile (any upper bound is valid there).
+__global__ void k_centroid_finalize(SlicState s, int drift_slot)
 {
     int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k == 0) *s.leftover_count = 0;
@@ -492,6 +495,10 @@ __global__ void k_centroid_finalize(SlicState s)
         s.ca[k] = fix_value(a[5], a[6], finv) / nn;
         s.cb[k] = fix_value(a[7], a[8], finv) / nn;
         s.win[k] = search_window(cy, cx, s.step_y, s.step_x, s.H, s.W);
+        const int iy = k / s.grid_nx, ix = k - iy * s.grid_nx;
+        const double dy = fabs(cy - (double)(s.grid_y0 + iy * s.grid_dy)), dx = fabs(cx - (double)(s.grid_x0 + ix * s.grid_dx));
+        const int d = (int)ceil(fmax(dy, dx));
+        if (d > 0) atomicMax(&s.drift[drift_slot], d);
     }
 #pragma unroll
     for (int j = 0; j < 9; ++j) a[j] = 0;
@@ -507,10 +514,11 @@ constexpr int MAXC = SLIC_MAXC;
 // its list with wave-uniform (scalar) loads: no LDS staging, no barriers in front of the hot loop.
 constexpr int BIN_TILES_PER_BLOCK = 4;     // one wave per tile, four tiles share one LDS copy of the windows
 constexpr int BIN_MAX_K_LDS = 4096;        // centroids whose windows fit the LDS copy (64 KB)
+constexpr int BIN_LOCAL_MAX = 512;         // grid nodes a tile may have to look at on the local path
 
 __global__ void __launch_bounds__(256)
 k_slic_bin(SlicState s, int tiles_x, int n_tiles, int max_cand, Cand *__restrict__ tile_cands,
-           int *__restrict__ tile_count)
+           int *__restrict__ tile_count, int drift_slot)
 {
     extern __shared__ int4 lds_win[];                 // [min(K, BIN_MAX_K_LDS)]
     __shared__ int ck[BIN_TILES_PER_BLOCK][MAXC];
@@ -519,19 +527,48 @@ k_slic_bin(SlicState s, int tiles_x, int n_tiles, int max_cand, Cand *__restrict
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int klds = min(s.K, BIN_MAX_K_LDS);
-    for (int k = threadIdx.x; k < klds; k += 256) lds_win[k] = s.win[k];
-    __syncthreads();
+    // Centroids stay near their grid nodes: with `drift` = the largest displacement so far (k_centroid_finalize), only
+    // the nodes within reach of the tile have to be looked at -- one or two wave iterations instead of K / 64.  The
+    // exact test on the integer windows is the same either way; when the centroids have wandered far, scan them all.
+    const int drift = s.drift[drift_slot];
+    const int reach_y = 2 * s.step_y + 1 + drift, reach_x = 2 * s.step_x + 1 + drift;
+    const bool local = s.grid_dy > 0 && s.grid_dx > 0 && (long)(2 * reach_y + TILE_Y + 2 * s.grid_dy) * (2 * reach_x + TILE_X + 2 * s.grid_dx) <=
+                       (long)BIN_LOCAL_MAX * s.grid_dy * s.grid_dx;
+    if (!local) {
+        for (int k = threadIdx.x; k < klds; k += 256) lds_win[k] = s.win[k];
+        __syncthreads();
+    }
     const int tile = blockIdx.x * BIN_TILES_PER_BLOCK + wave;
     if (tile >= n_tiles) return;
     const int tx0 = (tile % tiles_x) * TILE_X, ty0 = (tile / tiles_x) * TILE_Y;
     const int tx1 = min(tx0 + TILE_X, s.W), ty1 = min(ty0 + TILE_Y, s.H);
     int count = 0;
-    for (int k0 = 0; k0 < s.K; k0 += 64) {
+    // grid nodes (iy, ix) in [iy0, iy1] x [ix0, ix1] (row major = ascending k, the order of the full scan)
+    int iy0 = 0, ix0 = 0, nry = 0, nrx = 1, total = s.K;
+    if (local) {
+        auto floor_div = [](int a, int b) { return a >= 0 ? a / b : -((-a + b - 1) / b); };
+        const int ny = s.K / s.grid_nx;
+        iy0 = max(0, floor_div(ty0 - reach_y - s.grid_y0 + s.grid_dy - 1, s.grid_dy));
+        const int iy1 = min(ny - 1, floor_div(ty1 + reach_y - s.grid_y0, s.grid_dy));
+        ix0 = max(0, floor_div(tx0 - reach_x - s.grid_x0 + s.grid_dx - 1, s.grid_dx));
+        const int ix1 = min(s.grid_nx - 1, floor_div(tx1 + reach_x - s.grid_x0, s.grid_dx));
+        nry = max(iy1 - iy0 + 1, 0);
+        nrx = max(ix1 - ix0 + 1, 1);
+        total = ix1 >= ix0 ? nry * nrx : 0;
+    }
+    for (int k0 = 0; k0 < total; k0 += 64) {
         int k = k0 + lane;
         bool hit = false;
         float key = 0.f;
-        if (k < s.K) {
-            int4 w = k < klds ? lds_win[k] : s.win[k];
+        if (k < total) {
+            int4 w;
+            if (local) {
+                const int jy = k / nrx;
+                k = (iy0 + jy) * s.grid_nx + ix0 + (k - jy * nrx);
+                w = s.win[k];
+            } else {
+                w = k < klds ? lds_win[k] : s.win[k];
+            }
             hit = w.x < ty1 && w.y > ty0 && w.z < tx1 && w.w > tx0;
             // heuristic sort key: squared distance of the window centre to the tile centre
             float my = 0.5f * (float)(w.x + w.y) - 0.5f * (float)(ty0 + ty1);
@@ -1422,7 +1459,7 @@ int launch_slic_iterations(SlicState s, const double *lab, const double *init_yx
     for (int it = 0; it < max_iter; ++it) {
         hipLaunchKernelGGL(k_slic_bin, cdiv(n_tiles, BIN_TILES_PER_BLOCK), 256,
                            (size_t)std::min(s.K, BIN_MAX_K_LDS) * sizeof(int4), st, s, (int)grid.x, n_tiles, max_cand,
-                           s.tile_cands, s.tile_count);
+                           s.tile_cands, s.tile_count, it % SLIC_DRIFT_SLOTS);
         // first sweep: integer-grid centroids with zero colour -> exact integer path (needs the
         // fast-path preconditions and a spatial weight far above the fp64 resolution)
         const bool first = it == 0 && s.fast32 && s.spatial_weight > 1e-9;
@@ -1453,7 +1490,7 @@ int launch_slic_iterations(SlicState s, const double *lab, const double *init_yx
 #undef LAUNCH_ASSIGN
         if (it + 1 < max_iter) {
             if (!dot && !first_grid) hipLaunchKernelGGL(k_slic_leftover, 64, 256, 0, st, s, lab, labels);
-            hipLaunchKernelGGL(k_centroid_finalize, cdiv(s.K, 256), 256, 0, st, s);
+            hipLaunchKernelGGL(k_centroid_finalize, cdiv(s.K, 256), 256, 0, st, s, (it + 1) % SLIC_DRIFT_SLOTS);
             if (s.slico)
                 hipLaunchKernelGGL(k_slico_update, (int)std::min<size_t>(cdiv(n, (size_t)256), 4096), 256, 0, st, s, lab, labels);
         }
