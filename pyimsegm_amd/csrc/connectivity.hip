@@ -309,15 +309,52 @@ k_small_bbox_init(int32_t *bbox, const int32_t *__restrict__ list, const int32_t
     }
 }
 
-// four consecutive pixels per thread (one 16-byte load of their roots): their roots nearly always agree, so a
-// thread looks up one component size, and only the few pixels of small components touch the bbox table
+// Bounding boxes of the small components.  Four consecutive pixels per lane (one 16-byte load of their roots): the
+// roots nearly always agree, so a lane looks up one component size and builds one box per run of equal small roots;
+// the boxes of a wave that belong to the same component are merged with shuffles before one lane issues the atomics
+// (all pixels of a small component used to hammer the same six words).
+struct Box6 {
+    int y0, y1, x0, x1, z0, z1;
+};
+
+__device__ __forceinline__ void box_commit_wave(int slot, Box6 b, int32_t *bbox)
+{
+    // lanes with slot < 0 have nothing; leader loop over the distinct slots of the wave
+    while (true) {
+        const unsigned long long vote = __ballot(slot >= 0);
+        if (!vote) break;
+        const int leader = __ffsll((long long)vote) - 1;
+        const int ls = __shfl(slot, leader, 64);
+        const bool mine = slot == ls;
+        Box6 m;
+        m.y0 = mine ? b.y0 : 0x7fffffff; m.y1 = mine ? b.y1 : -1;
+        m.x0 = mine ? b.x0 : 0x7fffffff; m.x1 = mine ? b.x1 : -1;
+        m.z0 = mine ? b.z0 : 0x7fffffff; m.z1 = mine ? b.z1 : -1;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            m.y0 = min(m.y0, __shfl_xor(m.y0, off, 64)); m.y1 = max(m.y1, __shfl_xor(m.y1, off, 64));
+            m.x0 = min(m.x0, __shfl_xor(m.x0, off, 64)); m.x1 = max(m.x1, __shfl_xor(m.x1, off, 64));
+            m.z0 = min(m.z0, __shfl_xor(m.z0, off, 64)); m.z1 = max(m.z1, __shfl_xor(m.z1, off, 64));
+        }
+        if ((int)(threadIdx.x & 63) == leader) {
+            atomicMin(&bbox[6 * ls + 0], m.y0);
+            atomicMax(&bbox[6 * ls + 1], m.y1);
+            atomicMin(&bbox[6 * ls + 2], m.x0);
+            atomicMax(&bbox[6 * ls + 3], m.x1);
+            atomicMin(&bbox[6 * ls + 4], m.z0);
+            atomicMax(&bbox[6 * ls + 5], m.z1);
+        }
+        if (mine) slot = -1;
+    }
+}
+
 __global__ void __launch_bounds__(256)
 k_small_bbox(const int32_t *__restrict__ parent, const int32_t *__restrict__ csize, int n, int H, int W, int min_size,
              const int32_t *__restrict__ slotmap, int32_t *bbox, const int32_t *__restrict__ counters, int capacity)
 {
+    if (counters[CNT_SMALL] > capacity) return;         // table too small: the thread-BFS fallback takes all (uniform)
     const int p0 = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
-    if (p0 >= n) return;
-    int r[4];
+    int r[4] = { -1, -1, -1, -1 };
     if (p0 + 4 <= n) {
         const int4 v = *reinterpret_cast<const int4 *>(parent + p0);
         r[0] = v.x; r[1] = v.y; r[2] = v.z; r[3] = v.w;
@@ -325,26 +362,38 @@ k_small_bbox(const int32_t *__restrict__ parent, const int32_t *__restrict__ csi
 #pragma unroll
         for (int j = 0; j < 4; ++j) r[j] = p0 + j < n ? parent[p0 + j] : -1;
     }
-    int last_r = -1;
-    bool last_small = false;
+    // runs of equal small roots inside the lane: at most four boxes, nearly always one or none
+    int slot[4];
+    Box6 box[4];
+    int last_r = -1, last_slot = -1;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
+        slot[j] = -1;
+        box[j] = { 0x7fffffff, -1, 0x7fffffff, -1, 0x7fffffff, -1 };
         if (r[j] < 0) continue;
         if (r[j] != last_r) {
             last_r = r[j];
-            last_small = csize[last_r] < min_size;
+            last_slot = csize[last_r] < min_size ? slotmap[last_r] : -1;
         }
-        if (!last_small) continue;
-        if (counters[CNT_SMALL] > capacity) return;     // table too small: the thread-BFS fallback takes all
+        if (last_slot < 0) continue;
+        slot[j] = last_slot;
         const int p = p0 + j;
-        const int i = slotmap[last_r];
         const int x = p % W, y = (p / W) % H, z = p / (W * H);
-        atomicMin(&bbox[6 * i + 0], y);
-        atomicMax(&bbox[6 * i + 1], y);
-        atomicMin(&bbox[6 * i + 2], x);
-        atomicMax(&bbox[6 * i + 3], x);
-        atomicMin(&bbox[6 * i + 4], z);
-        atomicMax(&bbox[6 * i + 5], z);
+        box[j] = { y, y, x, x, z, z };
+    }
+    // fold every run into its first pixel (static indices only: the boxes stay in registers)
+#pragma unroll
+    for (int j = 2; j >= 0; --j)
+        if (slot[j] >= 0 && slot[j + 1] == slot[j]) {
+            box[j].y0 = min(box[j].y0, box[j + 1].y0); box[j].y1 = max(box[j].y1, box[j + 1].y1);
+            box[j].x0 = min(box[j].x0, box[j + 1].x0); box[j].x1 = max(box[j].x1, box[j + 1].x1);
+            box[j].z0 = min(box[j].z0, box[j + 1].z0); box[j].z1 = max(box[j].z1, box[j + 1].z1);
+        }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int sl = (j == 0 || slot[j] != slot[j - 1]) ? slot[j] : -1;      // run start
+        if (!__any(sl >= 0)) continue;
+        box_commit_wave(sl, box[j], bbox);
     }
 }
 
