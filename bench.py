@@ -41,12 +41,15 @@ ASSIGN_BYTES_PER_PX = 28.0     # read fp64 Lab 3 x 8 B + write int3
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--steps', type=int, default=100)
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--size', type=int, default=HEIGHT, help='image edge (default: the BASELINE 2048)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--switch-interval', type=float, default=None, help='sys.setswitchinterval for the worker threads')
-    ap.add_argument('--inflight', type=int, default=3,
+    ap.add_argument('--host-pool', type=int, default=1,
+                    help='1: the numpy stages (class model, graph-cut terms) of the images in flight run in helper '
+                         'processes (pyimsegm_amd.hostpool), 0: in the worker threads themselves')
+    ap.add_argument('--inflight', type=int, default=6,
                     help='images in flight per GPU (worker threads, one HIP stream each; the reference runs a '
                          'pool of nb_workers processes over the images)')
     return ap.parse_args()
@@ -116,8 +119,12 @@ def main():
     ctx = _hip.default_context()
     sess, mode = _open_session(image)           # H2D once: the image is resident from here on
 
+    host_pool = None
+
     def step(model, session, to_host=False):
         res = pipe._ResidentImage(image, FEATURES_SET_COLOR, SP_SIZE, SP_REGUL, session=session)
+        if host_pool is not None:
+            return res.segment_with_model(model, GC_REGUL, EDGE_TYPE, host_pool, to_host=to_host), res
         proba = predict_proba(model, res.features)
         return res.segment(proba, GC_REGUL, EDGE_TYPE, to_host=to_host), res
 
@@ -133,6 +140,12 @@ def main():
     import queue
     import threading
     inflight = max(1, args.inflight)
+    if args.host_pool and inflight > 1:
+        # the numpy stages of the images in flight leave the interpreter lock of this process (same functions,
+        # same numbers: pyimsegm_amd/hostpool.py); helpers are started and given the model before the timed region
+        from pyimsegm_amd.hostpool import HostMathPool
+        host_pool = HostMathPool(inflight)
+        host_pool.set_model(model)
     if args.switch_interval:
         sys.setswitchinterval(args.switch_interval)
     do_gather = group.dist is not None            # launched by torchrun (also exercised with a single rank)
@@ -234,6 +247,8 @@ def main():
                             'pre-fitted GMM (BASELINE configs[1])' % (size, size),
                 'images_per_step_per_gpu': 1,
                 'images_in_flight_per_gpu': inflight,
+                'host_math': ('%d helper processes per GPU (scikit-learn class model + graph-cut terms)' % inflight)
+                if host_pool is not None else 'in the worker threads',
                 'parallelism': 'images sharded over %d GPU(s), %d in flight per GPU (one HIP stream each), RCCL gather '
                                'of label maps' % (world, inflight),
             },
@@ -263,6 +278,8 @@ def main():
             except Exception as ex:   # the baseline is a reported extra, never a reason to lose the line
                 out['cpu_baseline'] = {'error': repr(ex)}
         print(json.dumps(out), flush=True)
+    if host_pool is not None:
+        host_pool.close()
     group.close()
 
 

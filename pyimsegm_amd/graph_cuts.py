@@ -407,6 +407,18 @@ def compute_edge_weights(segments, image=None, features=None, proba=None, edge_t
         centre_list = superpixel_centers(segments)
     logging.debug('graph edges %r', edges.shape)
 
+    edge_weights = edge_weights_from_graph(edges, centres if centre_list is None else centre_list, features, proba,
+                                           edge_type, image=image, segments=segments)
+    return edges, edge_weights
+
+
+def edge_weights_from_graph(edges, centres, features=None, proba=None, edge_type='', image=None, segments=None):
+    """ the weights of given edges (second half of :func:`compute_edge_weights`, reference ``graph_cuts.py:616-657``)
+
+    :param ndarray edges: int32 E x 2
+    :param centres: superpixel centres, dense K x ndim table or list of tuples
+    :return ndarray: float weights E clipped to [1e-3, 1e3]
+    """
     if edge_type.startswith('model'):
         if proba is None or len(proba) == 0:
             raise ValueError('"proba" is required')
@@ -433,11 +445,11 @@ def compute_edge_weights(segments, image=None, features=None, proba=None, edge_t
     edge_weights = np.array(edge_weights, dtype=float)
     if edge_type in ['model', 'features', 'color', 'spatial']:
         # device centres already hold [-1, -1] for unused labels (superpixels.py:218 semantics)
-        edge_weights /= compute_spatial_dist(centres if centre_list is None else centre_list, edges, relative=True)
+        edge_weights /= compute_spatial_dist(centres, edges, relative=True)
 
     edge_weights[edge_weights < 1. / MIN_MAX_EDGE_WEIGHT] = 1. / MIN_MAX_EDGE_WEIGHT
     edge_weights[edge_weights > MIN_MAX_EDGE_WEIGHT] = MIN_MAX_EDGE_WEIGHT
-    return edges, edge_weights
+    return edge_weights
 
 
 def segment_graph_cut_general(

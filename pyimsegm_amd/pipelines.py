@@ -79,6 +79,28 @@ class _ResidentImage(object):
             segm = segm.astype(np.asarray(classes).dtype)
         return segm, segm_soft
 
+    def segment_with_model(self, model, gc_regul, gc_edge_type, host_pool, classes=None, to_host=True, want_soft=True):
+        """ as ``segment(predict_proba(model, features), ...)`` with the numpy stages (class probabilities, unary /
+        pairwise costs, edge weights) evaluated by a helper process of ``host_pool`` (:mod:`pyimsegm_amd.hostpool`, the
+        model was handed over by ``host_pool.set_model``): identical numbers, but this thread holds the interpreter
+        lock only for the glue, and the graph kernels follow the descriptor kernels without a host stage in between.
+        Edge types that need the image (``'color'``) take the in-process route. """
+        if gc_edge_type == 'color' or not (np.isscalar(gc_regul) and gc_regul > 0):
+            return self.segment(predict_proba(model, self.features), gc_regul, gc_edge_type, classes=classes,
+                                to_host=to_host, want_soft=want_soft)
+        from pyimsegm_amd.graph_cuts import _edges_centres, cut_general_graph
+        edges, centres, _ = _edges_centres(_ShapeOnly(self.sess.shape), self.sess)
+        edges = np.array(edges, dtype=np.int32).reshape(-1, 2)
+        proba, unary_cost, pairwise_cost, edge_weights = host_pool.terms(self.features, edges, centres, gc_regul,
+                                                                         gc_edge_type)
+        graph_labels = cut_general_graph(edges, edge_weights, unary_cost, pairwise_cost, algorithm='expansion', n_iter=-1)
+        if classes is not None:
+            graph_labels = np.asarray(classes)[graph_labels]
+        segm, segm_soft = self.sess.gather(graph_labels, proba if want_soft else None, to_host=to_host)
+        if to_host and classes is not None and np.asarray(classes).dtype != np.int32:
+            segm = segm.astype(np.asarray(classes).dtype)
+        return segm, segm_soft
+
     def close(self):
         if self.own_session:
             if self.reuse:
@@ -315,7 +337,7 @@ def segment_color2d_slic_features_model_graphcut(
 
 def segment_batch_color2d_slic_features_model_graphcut(list_images, model_pipeline, dict_features, sp_size=30,
                                                        sp_regul=0.2, gc_regul=1., gc_edge_type='model', group=None,
-                                                       nb_workers=NB_WORKERS):
+                                                       nb_workers=NB_WORKERS, host_procs=True):
     """ segment a batch of equally-sized images with a given model, sharded over the GPUs of one node
 
     Multi-GPU counterpart of mapping :func:`segment_color2d_slic_features_model_graphcut` over a
@@ -332,13 +354,28 @@ def segment_batch_color2d_slic_features_model_graphcut(list_images, model_pipeli
         group = Group()
 
     classes = getattr(model_pipeline, 'classes_', None)
+    # several images in flight: their numpy stages (class model, graph-cut terms) run in helper processes, so the
+    # worker threads do not queue for the interpreter lock (pyimsegm_amd/hostpool.py; same functions, same numbers)
+    host_pool = None
+    if host_procs and nb_workers and nb_workers > 1 and len(list_images) > 1:
+        from pyimsegm_amd.hostpool import shared_pool
+        try:
+            host_pool = shared_pool(nb_workers)      # started once per process, reused by later batches
+            host_pool.set_model(model_pipeline)
+        except Exception as ex:                      # e.g. a model that cannot be pickled: stay in process
+            logging.warning('host helper processes not available (%s): class model evaluated in the worker threads', ex)
+            host_pool = None
 
     def _segment(image):
         # as segment_color2d_slic_features_model_graphcut, minus what a batch does not need: the soft
         # segmentation stays on the device and the session buffers are recycled from image to image
         res = _ResidentImage(image, dict_features, sp_size, sp_regul, reuse=True)
-        proba = predict_proba(model_pipeline, res.features)
-        segm, _ = res.segment(proba, gc_regul, gc_edge_type, classes=classes, want_soft=False)
+        if host_pool is not None:
+            segm, _ = res.segment_with_model(model_pipeline, gc_regul, gc_edge_type, host_pool, classes=classes,
+                                             want_soft=False)
+        else:
+            proba = predict_proba(model_pipeline, res.features)
+            segm, _ = res.segment(proba, gc_regul, gc_edge_type, classes=classes, want_soft=False)
         res.close()
         return segm
 
