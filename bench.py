@@ -49,9 +49,10 @@ def parse_args():
     ap.add_argument('--host-pool', type=int, default=1,
                     help='1: the numpy stages (class model, graph-cut terms) of the images in flight run in helper '
                          'processes (pyimsegm_amd.hostpool), 0: in the worker threads themselves')
-    ap.add_argument('--inflight', type=int, default=6,
+    ap.add_argument('--inflight', type=int, default=0,
                     help='images in flight per GPU (worker threads, one HIP stream each; the reference runs a '
-                         'pool of nb_workers processes over the images)')
+                         'pool of nb_workers processes over the images); 0 = by the number of timed steps: a deep '
+                         'pipeline only pays off when its fill and drain are amortised (6 from 40 steps, else 4 or fewer)')
     return ap.parse_args()
 
 
@@ -139,7 +140,9 @@ def main():
     # label map is gathered on rank 0 by the main thread (one RCCL gather per step, zero copy from HBM).
     import queue
     import threading
-    inflight = max(1, args.inflight)
+    # measured on MI355X (total ms for K steps at 2 / 3 / 4 / 6 in flight): K=10: 21 / 19 / 18 / 24, K=20: 34 / 31 / 32 / 32,
+    # K=50: 85 / 66 / 66 / 59, K=100: - / - / 129 / 104
+    inflight = args.inflight if args.inflight > 0 else (6 if args.steps >= 40 else 4 if args.steps >= 8 else min(3, max(1, args.steps)))
     if args.host_pool and inflight > 1:
         # the numpy stages of the images in flight leave the interpreter lock of this process (same functions,
         # same numbers: pyimsegm_amd/hostpool.py); helpers are started and given the model before the timed region
