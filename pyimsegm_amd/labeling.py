@@ -96,3 +96,34 @@ def histogram_regions_labels_norm(slic, segm, _session=None):
     matrix_hist = np.nan_to_num(matrix_hist / region_sums)
     matrix_hist[matrix_hist == 0] = 0              # no negative zeros
     return matrix_hist
+
+
+def assume_bg_on_boundary(segm, bg_label=0, boundary_size=1):
+    """ swap labels such that the background label is the one that dominates the image boundary
+    (reference ``labeling.py:719-753``, called by the driver at ``run_segm_slic_model_graphcut.py:373,422``)
+
+    :param ndarray segm: segmentation
+    :param int bg_label: background label
+    :param float boundary_size: width of the border that is looked at
+    :return ndarray: segmentation with the boundary label and ``bg_label`` exchanged
+
+    >>> segm = np.zeros((6, 12), dtype=int)
+    >>> segm[1:4, 4:] = 2
+    >>> assume_bg_on_boundary(segm, boundary_size=1)[2].tolist()
+    [0, 0, 0, 0, 2, 2, 2, 2, 2, 2, 2, 2]
+    >>> segm[segm == 0] = 1
+    >>> out = assume_bg_on_boundary(segm, boundary_size=1)
+    >>> out[0].tolist(), out[2].tolist()
+    ([0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0], [0, 0, 0, 0, 2, 2, 2, 2, 2, 2, 2, 2])
+    """
+    from pyimsegm_amd.utilities.data_io import get_image2d_boundary_color
+    boundary_lb = int(get_image2d_boundary_color(segm, size=boundary_size))
+    used_lbs = np.unique(segm)
+    if boundary_lb not in used_lbs:
+        segm[segm == boundary_lb] = bg_label
+        return segm
+    # NOTE: when the background label is not in use the reference's look-up table may be too short for it
+    lut = list(range(max(int(used_lbs.max()), int(bg_label)) + 1))
+    lut[boundary_lb] = bg_label
+    lut[bg_label] = boundary_lb
+    return np.array(lut)[segm]

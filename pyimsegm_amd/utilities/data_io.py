@@ -98,3 +98,32 @@ def convert_img_color_from_rgb(image, color_space):
     if image.ndim == 3 and image.shape[-1] in (3, 4) and color_space in DICT_CONVERT_COLOR_FROM_RGB:
         image = DICT_CONVERT_COLOR_FROM_RGB[color_space](image)
     return image
+
+
+def get_image2d_boundary_color(image, size=1):
+    """ the dominant value on the image border of width ``size`` (reference ``utilities/data_io.py:1002-1036``):
+    the most frequent label of a 2D (label) image, the per-channel median of a colour image
+
+    >>> img = np.zeros((5, 15), dtype=int)
+    >>> img[:4, 3:9] = 1
+    >>> int(get_image2d_boundary_color(img))
+    0
+    >>> get_image2d_boundary_color(np.ones((5, 15, 3), dtype=int), size=2).tolist()
+    [1, 1, 1]
+    >>> int(get_image2d_boundary_color(np.ones((5, 15, 3, 1), dtype=int)))
+    0
+    """
+    import logging
+    image = np.asarray(image)
+    size = int(size)
+    strips = [image[:size, :], image[:, :size], image[-size:, :], image[:, -size:]]
+    if image.ndim == 2:
+        pixels = np.concatenate([strip.ravel() for strip in strips])
+        colour = np.argmax(np.bincount(pixels))
+    elif image.ndim == 3:
+        pixels = np.concatenate([strip.reshape(-1, image.shape[-1]) for strip in strips], axis=0)
+        colour = np.median(pixels, axis=0)
+    else:
+        logging.error('not supported image dim: %r', image.shape)
+        colour = np.array(0)
+    return np.asarray(colour).astype(image.dtype)

@@ -130,9 +130,22 @@ def main():
     slic[slic == 13] = 80                                  # an unused stretch of labels
     annot = ((yy > 20).astype(np.int64) + (xx > 33) * 2)
     annot[rng2.random(annot.shape) < 0.15] = 5            # sparse extra label, leaves label 4 unused
+    # driver touch point run_segm_slic_model_graphcut.py:373,422: background label on the image boundary
+    lift(os.path.join(REF, 'utilities', 'data_io.py'), ['get_image2d_boundary_color'], ns)
+    lift(os.path.join(REF, 'labeling.py'), ['assume_bg_on_boundary'], ns)
+    segm_a = (annot % 3).astype(np.int64)                  # boundary dominated by label 0 or 1, all labels in use
+    segm_b = segm_a + 1                                    # background label 0 not in use
+    segm_b[10:30, 10:40] = 3
+    bg = {}
+    for name, sg in (('a', segm_a), ('b', segm_b)):
+        for size in (1, 3):
+            bg['bg_%s_%d' % (name, size)] = ns['assume_bg_on_boundary'](sg.copy(), bg_label=0, boundary_size=size)
+    colour = rng2.integers(0, 255, (9, 14, 3))
     np.savez_compressed(os.path.join(HERE, 'labeling.npz'), slic=slic, annot=annot,
                         counts=ns['histogram_regions_labels_counts'](slic, annot),
-                        norm=ns['histogram_regions_labels_norm'](slic, annot))
+                        norm=ns['histogram_regions_labels_norm'](slic, annot),
+                        segm_a=segm_a, segm_b=segm_b, colour=colour,
+                        colour_bg=ns['get_image2d_boundary_color'](colour, size=2), **bg)
     print('golden vectors written to', HERE)
 
 

@@ -6,7 +6,7 @@ REPO=${GRAFT_REPO_ROOT:-/root/repo}
 cd /tmp && export TMPDIR=/tmp
 OUT=$REPO/gpurun_out/prof_$TAG
 rm -rf $OUT && mkdir -p $OUT
-python $REPO/bench.py --steps 20 --warmup 3 > $OUT/bench.json 2> $OUT/bench.err
+python $REPO/bench.py > $OUT/bench.json 2> $OUT/bench.err          # the default command: what the driver runs
 # the default command (three images in flight: kernels of different streams overlap) ...
 rocprofv3 --kernel-trace --stats -d $OUT/kt -o bench -- python $REPO/bench.py --steps 10 --warmup 2 --no-cpu-baseline > $OUT/bench_rocprof_run.json 2> $OUT/kt.err
 DB=$(find $OUT/kt -name "*.db" | head -1)
