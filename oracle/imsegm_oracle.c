@@ -16,12 +16,20 @@
  *     sources are NOT in /root/reference.  Pinned by the reference doctests
  *     graph_cuts.py:700-703 and region_growing.py:72-75.  Beyond those: PARITY UNPINNED.
  *   - SLIC: restates scikit-image 0.18.x `skimage.segmentation.slic` (slic_superpixels.py,
- *     _slic.pyx, util/_regular_grid.py, color/colorconv.py rgb2lab) -- third-party, absent from
- *     /root/reference and not installable here.  The reference holds no golden label maps
- *     (superpixels.py:32-40 asserts shapes only)  =>  PARITY UNPINNED for the SLIC label map.
- *     The Gaussian blur step IS pinned bit-exactly against scipy.ndimage.gaussian_filter
+ *     _slic.pyx, util/_regular_grid.py, color/colorconv.py rgb2lab), `measure.label` and the
+ *     regionprops centroids -- third-party, absent from /root/reference.  The reference holds no golden
+ *     label maps (superpixels.py:32-40 asserts shapes only), but the build container carries a conda
+ *     Python 3.9 with scikit-image 0.18.3: tests/golden/skimage.npz holds its outputs for the
+ *     reference's call shapes (tests/golden/make_golden_skimage.py) and this oracle reproduces every
+ *     label map BIT FOR BIT (tests/test_golden_skimage.py: colour / gray / float 2-D incl. SLICO and the
+ *     raw assignment, uint8 / uint16 / float64 volumes incl. anisotropic spacing, measure.label,
+ *     centroids)  =>  PINNED.  One exception: a float32 volume runs in float32 inside scikit-image 0.18
+ *     (sequential float32 centroid sums); here it is widened to float64, and ~30 % of the voxels of
+ *     the test volume end up in a different (equally valid) supervoxel -- documented deviation.
+ *     The Gaussian blur step is also pinned bit-exactly against scipy.ndimage.gaussian_filter
  *     (scipy is installed) in tests/test_oracle_slic.py.
- *     Two conscious, documented deviations from skimage's floating-point arithmetic (needed so
+ *     Two conscious, documented deviations from skimage's floating-point arithmetic, both below the
+ *     resolution of the label maps in every pinned case (needed so
  *     that a massively parallel device implementation can be bit-identical to this oracle):
  *       (1) x^2.4 and cbrt are evaluated with the deterministic division-free Newton routines
  *           below (only + - * and exact bit operations) instead of libm pow/cbrt (<= 6 ulp);

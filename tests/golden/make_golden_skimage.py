@@ -1,0 +1,96 @@
+#!/usr/bin/env python
+"""Golden SLIC vectors from the REAL scikit-image (the third-party code behind imsegm/superpixels.py:61-63,104-111).
+
+scikit-image is not importable by the interpreter the tests run under, but the build container carries a conda
+Python 3.9 with scikit-image 0.18.3 (the last release line the reference's 3-D call `slic(..., multichannel=False)`
+works with unchanged).  Run there:
+
+    /opt/conda/bin/python3.9 tests/golden/make_golden_skimage.py
+
+Inputs are the seeded generators of pyimsegm_amd/utilities/synthetic.py (numpy only); the file stores their CRC so
+that a drifting generator is noticed, and the outputs of the reference's two call shapes, re-stated here parameter
+for parameter (superpixels.py:41-69 and :87-112), with and without connectivity enforcement / SLICO.
+"""
+import os
+import sys
+import warnings
+import zlib
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+warnings.filterwarnings('ignore')
+
+CASES_2D = {
+    # name: (generator call, sp_size, relative_compact)
+    'voronoi': ('voronoi_image(150, 210, seed=5)', 14, 0.2),
+    'disc': ('disc_image(256)', 18, 0.2),                                  # BASELINE configs[0]
+    'float': ('np.random.default_rng(3).random((97, 131, 3))', 11, 0.1),
+    'gray': ('voronoi_image(120, 160, seed=2)[:, :, 0]', 12, 0.3),
+    'voronoi_big': ('voronoi_image(400, 520, seed=9)', 25, 0.3),
+    'ovary_size': ('voronoi_image(647, 1024, seed=100)', 35, 0.2),         # BASELINE configs[3] image size and parameters
+}
+CASES_3D = {
+    'vol_aniso_f64': ('ellipsoid_volume((8, 44, 40), seed=6).astype(np.float64)', 9, 0.3, (3, 1, 1)),
+    'vol_u8': ('(ellipsoid_volume((10, 36, 40), seed=7) * 200).clip(0, 255).astype(np.uint8)', 8, 0.2, (1, 1, 2)),
+    'vol_u16': ('(ellipsoid_volume((9, 40, 36), seed=8) * 40000).clip(0, 65535).astype(np.uint16)', 8, 0.25, (1, 1, 1)),
+    'vol_f64': ('ellipsoid_volume((12, 40, 48)).astype(np.float64)', 8, 0.2, (1, 1, 1)),
+}
+
+
+def make_input(expr):
+    from pyimsegm_amd.utilities.synthetic import disc_image, ellipsoid_volume, voronoi_image  # noqa: F401
+    return eval(expr)
+
+
+def crc(arr):
+    return zlib.crc32(np.ascontiguousarray(arr).tobytes())
+
+
+def main():
+    import skimage
+    from skimage import measure
+    from skimage.segmentation import slic
+    assert skimage.__version__.startswith('0.18'), skimage.__version__
+    out = {'skimage_version': np.array(skimage.__version__)}
+
+    def slic2d(img, sp_size, rc, slico, conn):
+        nb_pixels = np.prod(img.shape[:2])
+        if img.ndim == 2:
+            img = np.rollaxis(np.tile(img, (3, 1, 1)), 0, 3)
+        if img.min() != 0. or img.max() != 1.:
+            img = (img - img.min()) / float(img.max() - img.min())
+        n_seg = int(nb_pixels / (sp_size**2))
+        compact = (sp_size * rc)**1.5
+        return np.array(slic(img, n_segments=n_seg, compactness=compact, sigma=1, enforce_connectivity=conn,
+                             slic_zero=slico)).astype(np.int32)
+
+    for name, (expr, sp, rc) in CASES_2D.items():
+        img = make_input(expr)
+        out[name + '_crc'] = np.array(crc(img), dtype=np.uint32)
+        out[name + '_final'] = slic2d(img, sp, rc, False, True)
+        if name in ('voronoi', 'float'):
+            out[name + '_raw'] = slic2d(img, sp, rc, False, False)
+            out[name + '_slico_final'] = slic2d(img, sp, rc, True, True)
+            out[name + '_slico_raw'] = slic2d(img, sp, rc, True, False)
+        if name == 'float':
+            props = measure.regionprops(out[name + '_final'] + 1)
+            out[name + '_centroids'] = np.array([p.centroid for p in props], dtype=np.float64)
+
+    for name, (expr, sp, rc, space) in CASES_3D.items():
+        vol = make_input(expr)
+        out[name + '_crc'] = np.array(crc(vol), dtype=np.uint32)
+        nb_pixels = np.prod(vol.shape)
+        sp_vol = np.prod(sp / np.asarray(space, dtype=np.float32) * min(space))
+        n_seg = int(nb_pixels / sp_vol)
+        compact = int((sp_vol * rc)**1.5)
+        raw = slic(vol, n_segments=n_seg, compactness=compact, spacing=space, sigma=1, multichannel=False)
+        out[name + '_slic'] = np.array(raw).astype(np.int32)
+        out[name + '_label'] = measure.label(raw).astype(np.int32)
+    np.savez_compressed(os.path.join(HERE, 'skimage.npz'), **out)
+    print('scikit-image %s vectors written: %d arrays' % (skimage.__version__, len(out)))
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,51 @@
+"""The CPU oracle against outputs of the REAL scikit-image 0.18.3 (tests/golden/skimage.npz, produced by
+tests/golden/make_golden_skimage.py under the container's conda Python 3.9): the two call shapes of the reference
+(imsegm/superpixels.py:61-63 colour 2-D incl. SLICO, :104-111 gray 3-D + measure.label) -- label maps bit for bit."""
+import importlib.util
+import os
+import zlib
+
+import numpy as np
+import pytest
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+
+
+def load_cases():
+    spec = importlib.util.spec_from_file_location('make_golden_skimage', os.path.join(GOLDEN, 'make_golden_skimage.py'))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+GEN = load_cases()
+VEC = np.load(os.path.join(GOLDEN, 'skimage.npz'), allow_pickle=False)
+
+
+def make_input(name, expr):
+    arr = GEN.make_input(expr)
+    assert zlib.crc32(np.ascontiguousarray(arr).tobytes()) == int(VEC[name + '_crc']), 'input generator drifted: %s' % name
+    return arr
+
+
+@pytest.mark.parametrize('name', sorted(GEN.CASES_2D))
+def test_oracle_slic2d_equals_scikit_image(oracle, name):
+    expr, sp, rc = GEN.CASES_2D[name]
+    img = make_input(name, expr)
+    labels, info = oracle.segment_slic_img2d(img, sp, rc, return_internals=True)
+    assert np.array_equal(labels, VEC[name + '_final'])
+    if name + '_raw' in VEC.files:
+        assert np.array_equal(np.asarray(info['nearest'])[0], VEC[name + '_raw'])
+        slico, info = oracle.segment_slic_img2d(img, sp, rc, return_internals=True, slico=True)
+        assert np.array_equal(slico, VEC[name + '_slico_final'])
+        assert np.array_equal(np.asarray(info['nearest'])[0], VEC[name + '_slico_raw'])
+    if name + '_centroids' in VEC.files:            # skimage.measure.regionprops(segments + 1), superpixels.py:222
+        assert np.array_equal(np.asarray(oracle.centers(labels.astype(np.int32))), VEC[name + '_centroids'])
+
+
+@pytest.mark.parametrize('name', sorted(GEN.CASES_3D))
+def test_oracle_slic3d_equals_scikit_image(oracle, name):
+    expr, sp, rc, space = GEN.CASES_3D[name]
+    vol = make_input(name, expr)
+    assert np.array_equal(oracle.label_cc(VEC[name + '_slic']), VEC[name + '_label'])       # skimage.measure.label
+    assert np.array_equal(oracle.segment_slic_img3d_gray(vol, sp, rc, space), VEC[name + '_label'])

@@ -1,8 +1,8 @@
 """The C oracle's SLIC sweeps and connectivity enforcement against a literal, loop-for-loop pure-Python
 restatement of scikit-image 0.18's `_slic_cython` / `_enforce_label_connectivity_cython` (the third-party code
-behind /root/reference/imsegm/superpixels.py:61-63,104-106; scikit-image itself is not installable here, so
-this pins the oracle's control flow -- windows, visiting order, tie-breaking, BFS order, size caps -- but not
-scikit-image's bits: "parity unpinned" stays in the oracle header).
+behind /root/reference/imsegm/superpixels.py:61-63,104-106).  This pins the oracle's control flow -- windows,
+visiting order, tie-breaking, BFS order, size caps -- on inputs small enough for Python loops; the outputs of the real
+scikit-image 0.18.3 are pinned separately in tests/test_golden_skimage.py.
 
 The literal version adds the colour sums sequentially in fp64 exactly like `_slic.pyx`; the oracle adds them
 as exact fixed-point sums.  The two agree to ~1e-15, which only matters for a pixel whose two best centroids
