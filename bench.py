@@ -73,6 +73,49 @@ def cpu_baseline(image, model, passes=5):
     }, segm, soft
 
 
+_SKIMAGE_SCRIPT = r'''
+import sys, time, warnings
+warnings.filterwarnings("ignore")
+import numpy as np
+from skimage.segmentation import slic
+import skimage
+img = np.load(sys.argv[1])
+sp_size, rc = float(sys.argv[3]), float(sys.argv[4])
+nb_pixels = img.shape[0] * img.shape[1]
+if img.min() != 0. or img.max() != 1.:                       # imsegm/superpixels.py:53-54
+    img = (img - img.min()) / float(img.max() - img.min())
+t0 = time.perf_counter()
+labels = slic(img, n_segments=int(nb_pixels / sp_size**2), compactness=(sp_size * rc)**1.5, sigma=1,
+              enforce_connectivity=True, slic_zero=False)      # imsegm/superpixels.py:57-63
+t1 = time.perf_counter()
+np.save(sys.argv[2], np.asarray(labels).astype(np.int32))
+print("%s %.4f" % (skimage.__version__, t1 - t0))
+'''
+
+
+def real_skimage_slic(image):
+    """the REAL `skimage.segmentation.slic` behind imsegm/superpixels.py:61-63, when the box carries the image's conda
+    Python 3.9 with scikit-image (the interpreter of this script cannot import it): (version, seconds of the slic
+    call on one host core, label map), or None.  Reported next to the oracle's own time; never part of `value`."""
+    import subprocess
+    import tempfile
+    py = os.environ.get('IMSEGM_SKIMAGE_PYTHON', '/opt/conda/bin/python3.9')
+    if not os.path.exists(py):
+        return None
+    try:
+        with tempfile.TemporaryDirectory() as tmp:
+            src, dst = os.path.join(tmp, 'image.npy'), os.path.join(tmp, 'labels.npy')
+            np.save(src, image)
+            run = subprocess.run([py, '-c', _SKIMAGE_SCRIPT, src, dst, str(SP_SIZE), str(SP_REGUL)], capture_output=True,
+                                 text=True, timeout=300)
+            if run.returncode != 0:
+                return None
+            version, seconds = run.stdout.split()[-2:]
+            return version, float(seconds), np.load(dst)
+    except Exception:
+        return None
+
+
 def _cpu_baseline_pass(image, model):
     from oracle import oracle as orc
     from pyimsegm_amd import graph_cuts as gc
@@ -283,9 +326,18 @@ def main():
             try:
                 base, segm_cpu, _ = cpu_baseline(image, model)
                 out['cpu_baseline'] = base
-                (segm_gpu, _), _ = step(model, (sess, mode), to_host=True)
+                (segm_gpu, _), res_gpu = step(model, (sess, mode), to_host=True)
                 out['gpu_equals_cpu_oracle'] = bool(np.array_equal(segm_gpu, segm_cpu))
                 out['speedup_vs_cpu_baseline'] = round(value / base['value'], 2)
+                try:      # the third-party reference itself, when the box has it (an extra: never loses the line)
+                    real = real_skimage_slic(image)
+                    if real is not None:
+                        base['reference_slic'] = {'scikit_image': real[0], 'seconds': round(real[1], 3), 'cores': 1,
+                                                  'note': 'skimage.segmentation.slic as called at imsegm/superpixels.py:'
+                                                          '61-63, same image; the oracle SLIC time is in `sample`'}
+                        out['gpu_slic_equals_scikit_image'] = bool(np.array_equal(res_gpu.slic, real[2]))
+                except Exception:
+                    pass
             except Exception as ex:   # the baseline is a reported extra, never a reason to lose the line
                 out['cpu_baseline'] = {'error': repr(ex)}
         print(json.dumps(out), flush=True)
