@@ -79,9 +79,10 @@ _HED_FROM_RGB = np.linalg.inv(np.array([[0.65, 0.70, 0.29], [0.07, 0.99, 0.11], 
 
 
 def rgb2hed(rgb):
+    """ RGB -> Haematoxylin-Eosin-DAB (colour deconvolution as ``skimage.color.rgb2hed`` of scikit-image 0.18: the
+    stain values are not clipped at zero; newer releases clip them) """
     arr = np.maximum(_as_float_rgb(rgb), 1e-6)
-    stains = (np.log(arr) / np.log(1e-6)) @ _HED_FROM_RGB
-    return np.maximum(stains, 0)
+    return (np.log(arr) / np.log(1e-6)) @ _HED_FROM_RGB
 
 
 #: conversion function from RGB color space

@@ -88,6 +88,15 @@ def main():
         raw = slic(vol, n_segments=n_seg, compactness=compact, spacing=space, sigma=1, multichannel=False)
         out[name + '_slic'] = np.array(raw).astype(np.int32)
         out[name + '_label'] = measure.label(raw).astype(np.int32)
+    # skimage.color conversions reached through imsegm/utilities/data_io.py:28-34 (feature keys color_hsv / _luv / ...)
+    from skimage import color
+    rgb_f = np.random.default_rng(11).random((13, 17, 3))
+    rgb_u8 = (np.random.default_rng(12).random((11, 9, 3)) * 255).astype(np.uint8)
+    out['color_crc'] = np.array([crc(rgb_f), crc(rgb_u8)], dtype=np.uint32)
+    for space in ('hsv', 'luv', 'lab', 'hed', 'xyz'):
+        fn = getattr(color, 'rgb2' + space)
+        out['color_%s_f64' % space] = fn(rgb_f)
+        out['color_%s_u8' % space] = fn(rgb_u8)
     np.savez_compressed(os.path.join(HERE, 'skimage.npz'), **out)
     print('scikit-image %s vectors written: %d arrays' % (skimage.__version__, len(out)))
 

@@ -49,3 +49,17 @@ def test_oracle_slic3d_equals_scikit_image(oracle, name):
     vol = make_input(name, expr)
     assert np.array_equal(oracle.label_cc(VEC[name + '_slic']), VEC[name + '_label'])       # skimage.measure.label
     assert np.array_equal(oracle.segment_slic_img3d_gray(vol, sp, rc, space), VEC[name + '_label'])
+
+
+@pytest.mark.parametrize('space', ['hsv', 'luv', 'lab', 'hed', 'xyz'])
+def test_colour_conversions_equal_scikit_image(space):
+    """numpy restatements of skimage.color.rgb2* (pyimsegm_amd/utilities/data_io.py) against the real functions"""
+    from pyimsegm_amd.utilities.data_io import convert_img_color_from_rgb
+    rgb_f = np.random.default_rng(11).random((13, 17, 3))
+    rgb_u8 = (np.random.default_rng(12).random((11, 9, 3)) * 255).astype(np.uint8)
+    assert [zlib.crc32(rgb_f.tobytes()), zlib.crc32(rgb_u8.tobytes())] == VEC['color_crc'].tolist()
+    for tag, rgb in (('f64', rgb_f), ('u8', rgb_u8)):
+        ref = VEC['color_%s_%s' % (space, tag)]
+        out = convert_img_color_from_rgb(rgb, space)
+        scale = max(1.0, float(np.abs(ref).max()))
+        assert out.shape == ref.shape and np.max(np.abs(out - ref)) <= 1e-12 * scale, (space, tag, np.max(np.abs(out - ref)))
