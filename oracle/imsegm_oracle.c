@@ -5,7 +5,8 @@
  * GraphCut hot path.  Only tests/, __graft_entry__.smoke() and the
  * cpu_baseline leg of bench.py may load this library.
  *
- * PARITY STATUS (also stated in DESIGN.md):
+ * PARITY STATUS (also stated in DESIGN.md).  Besides the per-stage pins below, the whole chain is checked against a run
+ * of the reference itself (tests/golden/make_golden_reference.py, tests/test_golden_reference.py):
  *   - descriptors (orc_color2d_*, orc_gray3d_*): restate /root/reference/imsegm/features_cython.pyx:59-219
  *     line by line; pinned against the reference doctest vectors (descriptors.py:218-283, 470-537)
  *     and against the reference .pyx itself compiled into oracle/_ref (bit-exact).

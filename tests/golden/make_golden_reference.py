@@ -1,0 +1,139 @@
+#!/usr/bin/env python
+"""Golden vectors of the WHOLE hot path from the reference's OWN code, run unchanged from /root/reference
+(build container only), stage by stage and end to end:
+
+    /opt/conda/bin/python3.9 tests/golden/make_golden_reference.py
+
+The container's conda Python 3.9 carries the reference's real dependencies scikit-image 0.18.3, scikit-learn and
+Cython; what it lacks is stubbed in `sys.modules` before `import imsegm`:
+  * nibabel, planar, OleFileIO_PL -- file readers / drawing, never called on this path: empty modules;
+  * gco (gco-wrapper) -- the ONE piece of the path that is not the reference's: `cut_general_graph` is bridged to
+    this repo's CPU oracle (oracle/liboracle.so, `orc_cut_general_graph`), and its inputs are recorded.  Everything
+    up to that call (SLIC, descriptors, class model, unary / pairwise / edge terms) and after it (label gathers) is
+    the reference's code with its real dependencies.
+`imsegm/features_cython.pyx` is compiled for this interpreter into a temporary directory (flags of the reference's
+setup.py) and put on `imsegm.__path__`, so the reference runs its Cython descriptor path (USE_CYTHON = True).
+
+Nothing of the reference is copied: only numbers go to tests/golden/reference.npz.
+"""
+import ctypes as C
+import os
+import subprocess
+import sys
+import sysconfig
+import tempfile
+import types
+import warnings
+import zlib
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF = '/root/reference'
+warnings.filterwarnings('ignore')
+
+#: name: (input expression, sp_size, sp_regul, dict_features, nb_classes, gc_regul, gc_edge_type)
+CASES = {
+    'disc': ('disc_image(256)', 18, 0.2, {'color': ['mean']}, 2, 1.0, 'model'),                       # BASELINE configs[0]
+    'voronoi': ('voronoi_image(300, 400, seed=7)', 20, 0.2, {'color': ('mean', 'std', 'energy')}, 3, 2.0, 'model'),
+    'voronoi_spatial': ('voronoi_image(180, 240, seed=4)', 15, 0.3, {'color': ('mean', 'std', 'energy')}, 3, 1.5, 'spatial'),
+}
+
+
+def make_input(expr):
+    sys.path.insert(0, ROOT)
+    from pyimsegm_amd.utilities.synthetic import disc_image, ellipsoid_volume, voronoi_image  # noqa: F401
+    return eval(expr)
+
+
+def crc(arr):
+    return zlib.crc32(np.ascontiguousarray(arr).tobytes())
+
+
+def build_cython(tmp):
+    import numpy
+    pyx = os.path.join(REF, 'imsegm', 'features_cython.pyx')
+    cpp = os.path.join(tmp, 'features_cython.cpp')
+    target = os.path.join(tmp, 'features_cython' + sysconfig.get_config_var('EXT_SUFFIX'))
+    subprocess.check_call([sys.executable, '-m', 'cython', '--cplus', '-3', pyx, '-o', cpp])
+    subprocess.check_call(['g++', '-shared', '-fPIC', '-O3', '-ffast-math', '-march=x86-64-v2', '-w',
+                           '-DNPY_NO_DEPRECATED_API=NPY_1_7_API_VERSION', '-I' + numpy.get_include(),
+                           '-I' + sysconfig.get_paths()['include'], cpp, '-o', target])
+    return target
+
+
+def main():
+    recorded = {}
+    lib = C.CDLL(os.path.join(ROOT, 'oracle', 'liboracle.so'))
+    lib.orc_cut_general_graph.restype = C.c_int64
+
+    def bridge_cut_general_graph(edges, edge_weights, unary_cost, pairwise_cost, n_iter=-1, algorithm='expansion', **kw):
+        edges = np.ascontiguousarray(edges, dtype=np.int32)
+        weights = np.ascontiguousarray(edge_weights, dtype=np.float64)
+        unary = np.ascontiguousarray(unary_cost, dtype=np.float64)
+        pairwise = np.ascontiguousarray(pairwise_cost, dtype=np.float64)
+        recorded.update(edges=edges.copy(), edge_weights=weights.copy(), unary=unary.copy(), pairwise=pairwise.copy())
+        labels = np.zeros(unary.shape[0], dtype=np.int32)
+        ptr = lambda a: a.ctypes.data_as(C.c_void_p)  # noqa: E731
+        lib.orc_cut_general_graph(ptr(edges), C.c_int(len(edges)), ptr(weights), ptr(unary), C.c_int(unary.shape[0]),
+                                  C.c_int(unary.shape[1]), ptr(pairwise), C.c_int(n_iter), ptr(labels))
+        return labels
+
+    for name in ('nibabel', 'planar', 'gco', 'OleFileIO_PL'):
+        sys.modules[name] = types.ModuleType(name)
+    sys.modules['planar'].line = types.ModuleType('planar.line')
+    sys.modules['gco'].cut_general_graph = bridge_cut_general_graph
+    sys.modules['gco'].cut_grid_graph = bridge_cut_general_graph
+    sys.path.insert(0, REF)
+    import imsegm
+    with tempfile.TemporaryDirectory() as tmp:
+        build_cython(tmp)
+        imsegm.__path__.append(tmp)
+        import imsegm.descriptors as seg_fts
+        import imsegm.graph_cuts as seg_gc
+        import imsegm.pipelines as seg_pipe
+        import imsegm.superpixels as seg_spx
+        assert seg_fts.USE_CYTHON, 'the reference must run its Cython descriptor path'
+        import skimage
+        import sklearn
+        out = {'versions': np.array('scikit-image %s, scikit-learn %s, numpy %s' %
+                                    (skimage.__version__, sklearn.__version__, np.__version__))}
+        for name, (expr, sp, rc, feats, nb_classes, gc_regul, edge_type) in CASES.items():
+            image = make_input(expr)
+            out[name + '_crc'] = np.array(crc(image), dtype=np.uint32)
+            # stage by stage, in the order of pipelines.py:86-110
+            slic, features = seg_pipe.compute_color2d_superpixels_features(image, feats, sp_size=sp, sp_regul=rc)
+            np.random.seed(0)
+            model = seg_gc.estim_class_model(features, nb_classes, 'GMM', None, True)
+            proba = model.predict_proba(features)
+            vertices, edges_graph = seg_spx.make_graph_segm_connect_grid2d_conn4(slic)
+            centres = seg_spx.superpixel_centers(slic)
+            recorded.clear()
+            graph_labels = seg_gc.segment_graph_cut_general(slic, proba, image, features, gc_regul, edge_type)
+            segm = graph_labels[slic]
+            # ... and the reference's one-call pipeline with the same seed must agree
+            np.random.seed(0)
+            segm_pipe, soft_pipe = seg_pipe.pipe_color2d_slic_features_model_graphcut(
+                image, nb_classes, feats, sp_size=sp, sp_regul=rc, pca_coef=None, use_scaler=True, estim_model='GMM',
+                gc_regul=gc_regul, gc_edge_type=edge_type)
+            assert np.array_equal(segm_pipe, segm) and np.array_equal(soft_pipe, proba[slic])
+            scaler, gmm = model.steps[0][1], model.steps[-1][1]
+            out.update({
+                name + '_slic': np.asarray(slic).astype(np.int32), name + '_features': np.asarray(features, dtype=np.float64),
+                name + '_proba': proba, name + '_centres': np.array(centres, dtype=np.float64),
+                name + '_vertices': np.asarray(vertices).astype(np.int32), name + '_edges_graph': np.array(edges_graph, dtype=np.int32),
+                name + '_gc_edges': recorded['edges'], name + '_gc_edge_weights': recorded['edge_weights'],
+                name + '_gc_unary': recorded['unary'], name + '_gc_pairwise': recorded['pairwise'],
+                name + '_graph_labels': np.asarray(graph_labels).astype(np.int32), name + '_segm': segm.astype(np.int8),
+                name + '_scaler_mean': scaler.mean_, name + '_scaler_scale': scaler.scale_, name + '_gmm_weights': gmm.weights_,
+                name + '_gmm_means': gmm.means_, name + '_gmm_covariances': gmm.covariances_,
+                name + '_gmm_precisions_cholesky': gmm.precisions_cholesky_,
+            })
+            print(name, 'K =', int(slic.max()) + 1, 'E =', len(recorded['edges']), 'classes', np.bincount(segm.ravel()).tolist())
+    np.savez_compressed(os.path.join(HERE, 'reference.npz'), **out)
+    print('reference vectors written:', len(out), 'arrays;', str(out['versions']))
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,84 @@
+"""Stage-by-stage vectors of the reference's OWN pipeline (tests/golden/reference.npz: the reference run unchanged
+under the container's conda Python 3.9 with real scikit-image / scikit-learn / its Cython descriptors; only the gco
+call is bridged to the oracle -- see tests/golden/make_golden_reference.py) against the CPU oracle and the host mirror
+functions.  The GPU side lives in test_gpu_zz_reference.py."""
+import importlib.util
+import os
+import zlib
+
+import numpy as np
+import pytest
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+_spec = importlib.util.spec_from_file_location('make_golden_reference', os.path.join(GOLDEN, 'make_golden_reference.py'))
+GEN = importlib.util.module_from_spec(_spec)
+_spec.loader.exec_module(GEN)
+VEC = np.load(os.path.join(GOLDEN, 'reference.npz'), allow_pickle=False)
+NAMES = sorted(GEN.CASES)
+
+
+def make_input(name):
+    image = GEN.make_input(GEN.CASES[name][0])
+    assert zlib.crc32(np.ascontiguousarray(image).tobytes()) == int(VEC[name + '_crc']), 'input generator drifted'
+    return image
+
+
+def rebuild_model(name):
+    """the fitted Pipeline(StandardScaler, GaussianMixture) of the reference run, from its parameters"""
+    from sklearn.mixture import GaussianMixture
+    from sklearn.pipeline import Pipeline
+    from sklearn.preprocessing import StandardScaler
+    scaler = StandardScaler()
+    scaler.mean_, scaler.scale_ = VEC[name + '_scaler_mean'], VEC[name + '_scaler_scale']
+    scaler.var_ = scaler.scale_**2
+    scaler.n_features_in_ = len(scaler.mean_)
+    scaler.n_samples_seen_ = len(VEC[name + '_features'])
+    gmm = GaussianMixture(n_components=len(VEC[name + '_gmm_weights']), covariance_type='full')
+    gmm.weights_, gmm.means_ = VEC[name + '_gmm_weights'], VEC[name + '_gmm_means']
+    gmm.covariances_, gmm.precisions_cholesky_ = VEC[name + '_gmm_covariances'], VEC[name + '_gmm_precisions_cholesky']
+    gmm.precisions_ = np.array([pc @ pc.T for pc in gmm.precisions_cholesky_])
+    gmm.converged_, gmm.n_iter_, gmm.lower_bound_ = True, 1, 0.
+    gmm.n_features_in_ = scaler.n_features_in_
+    return Pipeline([('scaler', scaler), ('GMM', gmm)])
+
+
+def oracle_features(oracle, image, slic, flags):
+    img32, seg32 = np.asarray(image, dtype=np.float32), slic.astype(np.int32)
+    mean = oracle.color2d_mean(img32, seg32)
+    cols = {'mean': mean}
+    if 'std' in flags:
+        cols['std'] = np.sqrt(oracle.color2d_variance(img32, seg32, mean.astype(np.float32)))
+    if 'energy' in flags:
+        cols['energy'] = oracle.color2d_energy(img32, seg32)
+    return np.nan_to_num(np.hstack([cols[f] for f in ('mean', 'std', 'energy') if f in flags]))
+
+
+@pytest.mark.parametrize('name', NAMES)
+def test_oracle_and_host_mirror_follow_the_reference_run(oracle, name):
+    from pyimsegm_amd import graph_cuts as G
+    _, sp, rc, feats, nb_classes, gc_regul, edge_type = GEN.CASES[name]
+    image = make_input(name)
+    # superpixels: reference segment_slic_img2d (real scikit-image) == oracle
+    slic = oracle.segment_slic_img2d(image, sp, rc)
+    assert np.array_equal(slic, VEC[name + '_slic'])
+    # descriptors: reference Cython path (-ffast-math) vs the oracle's restatement
+    features = oracle_features(oracle, image, slic, feats['color'])
+    np.testing.assert_allclose(features, VEC[name + '_features'], rtol=1e-6, atol=1e-6 * np.abs(VEC[name + '_features']).max())
+    # graph and centres (regionprops in the reference)
+    vertices, edges = oracle.adjacency(slic.astype(np.int32))
+    assert vertices.tolist() == VEC[name + '_vertices'].tolist() and np.array_equal(np.array(edges), VEC[name + '_edges_graph'])
+    np.testing.assert_allclose(np.asarray(oracle.centers(slic.astype(np.int32))), VEC[name + '_centres'], rtol=0, atol=1e-9)
+    # class model: same parameters -> same probabilities (other numpy / scikit-learn builds: not bit for bit)
+    proba_ref = VEC[name + '_proba']
+    np.testing.assert_allclose(G.predict_proba(rebuild_model(name), VEC[name + '_features']), proba_ref, rtol=1e-9, atol=1e-12)
+    # graph-cut terms handed to gco by the reference vs the host mirror functions on the reference's inputs
+    assert np.array_equal(VEC[name + '_gc_edges'], np.array(edges, dtype=np.int32))
+    weights = G.edge_weights_from_graph(VEC[name + '_gc_edges'], VEC[name + '_centres'], VEC[name + '_features'], proba_ref, edge_type)
+    np.testing.assert_allclose(weights, VEC[name + '_gc_edge_weights'], rtol=1e-12, atol=0)
+    np.testing.assert_allclose(G.compute_unary_cost(proba_ref), VEC[name + '_gc_unary'], rtol=1e-13, atol=0)
+    assert np.array_equal(G.compute_pairwise_cost(gc_regul, proba_ref.shape), VEC[name + '_gc_pairwise'])
+    # (the labels of the reference run come from the oracle's alpha expansion, bridged in for the absent gco)
+    labels = oracle.cut_general_graph(VEC[name + '_gc_edges'], VEC[name + '_gc_edge_weights'], VEC[name + '_gc_unary'],
+                                      VEC[name + '_gc_pairwise'], n_iter=-1)
+    assert np.array_equal(labels, VEC[name + '_graph_labels'])
+    assert np.array_equal(labels[slic], VEC[name + '_segm'])

@@ -1,0 +1,51 @@
+"""The HIP path against the stage-by-stage vectors of the reference's OWN pipeline run (tests/golden/reference.npz,
+see tests/golden/make_golden_reference.py and tests/test_golden_reference.py for the oracle side)."""
+import numpy as np
+import pytest
+
+from test_golden_reference import GEN, NAMES, VEC, make_input, rebuild_model
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize('name', NAMES)
+def test_hip_stages_follow_the_reference_run(name):
+    from pyimsegm_amd import graph_cuts as G
+    from pyimsegm_amd import pipelines as P
+    from pyimsegm_amd import superpixels as S
+    _, sp, rc, feats, nb_classes, gc_regul, edge_type = GEN.CASES[name]
+    image = make_input(name)
+    # SLIC + descriptors (pipelines.py:244-269): label map bit for bit, descriptors within the 1e-5 of the requirement
+    slic, features = P.compute_color2d_superpixels_features(image, feats, sp_size=sp, sp_regul=rc)
+    assert slic.dtype == np.int64 and np.array_equal(slic, VEC[name + '_slic'])
+    ref_fts = VEC[name + '_features']
+    assert features.shape == ref_fts.shape
+    np.testing.assert_allclose(features, ref_fts, rtol=1e-5, atol=1e-5 * np.abs(ref_fts).max())
+    # adjacency graph and centres (superpixels.py:157-242)
+    vertices, edges = S.make_graph_segm_connect_grid2d_conn4(slic)
+    assert np.asarray(vertices).tolist() == VEC[name + '_vertices'].tolist()
+    assert np.array_equal(np.array(edges, dtype=np.int32), VEC[name + '_edges_graph'])
+    np.testing.assert_allclose(np.array(S.superpixel_centers(slic), dtype=np.float64), VEC[name + '_centres'], rtol=0, atol=1e-9)
+    # graph cut on the reference's probabilities (graph_cuts.py:660-747): labels of the superpixels, then the gather
+    labels = G.segment_graph_cut_general(slic, VEC[name + '_proba'], image, ref_fts, gc_regul, edge_type)
+    assert labels.dtype == np.int32 and np.array_equal(labels, VEC[name + '_graph_labels'])
+    assert np.array_equal(labels[slic], VEC[name + '_segm'])
+    # on the device, from the terms the reference handed to gco
+    direct = G.cut_general_graph(VEC[name + '_gc_edges'], VEC[name + '_gc_edge_weights'], VEC[name + '_gc_unary'],
+                                 VEC[name + '_gc_pairwise'], n_iter=-1, algorithm='expansion')
+    assert np.array_equal(direct, VEC[name + '_graph_labels'])
+
+
+@pytest.mark.parametrize('name', NAMES)
+def test_hip_pipeline_end_to_end_follows_the_reference_run(name):
+    """one call, with the class model of the reference run rebuilt from its parameters (pipelines.py:160-241)"""
+    from pyimsegm_amd import pipelines as P
+    _, sp, rc, feats, nb_classes, gc_regul, edge_type = GEN.CASES[name]
+    image = make_input(name)
+    segm, soft = P.segment_color2d_slic_features_model_graphcut(image, rebuild_model(name), feats, sp_size=sp, sp_regul=rc,
+                                                                gc_regul=gc_regul, gc_edge_type=edge_type)
+    ref_soft = VEC[name + '_proba'][VEC[name + '_slic']]
+    assert soft.shape == ref_soft.shape and np.max(np.abs(soft - ref_soft)) < 1e-5
+    # the descriptors differ from the reference's -ffast-math Cython sums in the last bits, the integer energies of the
+    # graph cut are therefore not guaranteed identical: demand (near) identity of the label map
+    assert segm.shape == image.shape[:2] and np.mean(segm != VEC[name + '_segm']) < 1e-3
