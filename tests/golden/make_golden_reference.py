@@ -41,6 +41,16 @@ CASES = {
 }
 
 
+#: name: (input expression, sp_size, sp_regul, spacing, dict_features, nb_classes, gc_regul)
+CASES_3D = {
+    'vol_u8': ('(ellipsoid_volume((10, 36, 40), seed=7) * 200).clip(0, 255).astype(np.uint8)', 8, 0.2, (1, 1, 2),
+               {'color': ('mean', 'std', 'energy')}, 3, 0.1),
+    'vol_f64': ('ellipsoid_volume((8, 44, 40), seed=6).astype(np.float64)', 9, 0.3, (3, 1, 1), {'color': ['mean']}, 2, 0.5),
+}
+#: (input expression, sp_size, sp_regul) of the texture case
+TEXTURE_CASE = ('voronoi_image(60, 75, seed=8)', 12, 0.2)
+
+
 def make_input(expr):
     sys.path.insert(0, ROOT)
     from pyimsegm_amd.utilities.synthetic import disc_image, ellipsoid_volume, voronoi_image  # noqa: F401
@@ -131,6 +141,52 @@ def main():
                 name + '_gmm_precisions_cholesky': gmm.precisions_cholesky_,
             })
             print(name, 'K =', int(slic.max()) + 1, 'E =', len(recorded['edges']), 'classes', np.bincount(segm.ravel()).tolist())
+        # ---- gray 3-D pipeline, stage by stage (pipelines.py:382-431) ------------------------------------------
+        for name, (expr, sp, rc, space, feats, nb_classes, gc_regul) in CASES_3D.items():
+            vol = make_input(expr)
+            out[name + '_crc'] = np.array(crc(vol), dtype=np.uint32)
+            slic = seg_spx.segment_slic_img3d_gray(vol, sp_size=sp, relative_compact=rc, space=space)
+            features, names = seg_fts.compute_selected_features_gray3d(vol, slic, feats)
+            features[np.isnan(features)] = 0
+            normed, _ = seg_fts.norm_features(features.copy())
+            np.random.seed(0)
+            model = seg_gc.estim_class_model(normed, nb_classes)
+            proba = model.predict_proba(normed)
+            vertices, edges_graph = seg_spx.make_graph_segm_connect_grid3d_conn6(slic)
+            centres = seg_spx.superpixel_centers(slic)
+            recorded.clear()
+            graph_labels = seg_gc.segment_graph_cut_general(slic, proba, vol, normed, gc_regul)
+            np.random.seed(0)
+            segm_pipe = seg_pipe.pipe_gray3d_slic_features_model_graphcut(vol, nb_classes, feats, spacing=space, sp_size=sp,
+                                                                          sp_regul=rc, gc_regul=gc_regul)
+            assert np.array_equal(segm_pipe, graph_labels[slic])
+            out.update({
+                name + '_slic': np.asarray(slic).astype(np.int32), name + '_features': np.asarray(features, dtype=np.float64),
+                name + '_normed': normed, name + '_proba': proba, name + '_edges_graph': np.array(edges_graph, dtype=np.int32),
+                name + '_centres': np.array([c if len(np.shape(c)) else [-1, -1, -1] for c in centres], dtype=np.float64),
+                name + '_gc_edge_weights': recorded['edge_weights'], name + '_gc_unary': recorded['unary'],
+                name + '_gc_pairwise': recorded['pairwise'], name + '_graph_labels': np.asarray(graph_labels).astype(np.int32),
+            })
+            print(name, 'K =', int(slic.max()) + 1, 'E =', len(recorded['edges']), 'classes', np.bincount(segm_pipe.ravel()).tolist())
+
+        # ---- Leung-Malik texture descriptors (descriptors.py:1041-1106) on the reference's SLIC -----------------
+        image = make_input(TEXTURE_CASE[0])
+        slic = seg_spx.segment_slic_img2d(image, TEXTURE_CASE[1], TEXTURE_CASE[2])
+        fts, names = seg_fts.compute_selected_features_img2d(image, slic, {'tLM_short': ('mean', 'std', 'energy')})
+        out.update(texture_crc=np.array(crc(image), dtype=np.uint32), texture_slic=np.asarray(slic).astype(np.int32),
+                   texture_features=np.asarray(fts, dtype=np.float64), texture_names=np.array(names))
+        print('texture', fts.shape)
+
+        # ---- supervised path: superpixel labels from an annotation (pipelines.py:272-289, labeling.py:208-280) --
+        from pyimsegm_amd.utilities.synthetic import voronoi_image
+        image, annot = voronoi_image(210, 280, seed=3, nb_seeds=9, return_classes=True)
+        annot = annot.copy()
+        annot[:40, :50] = -1
+        slic, features, labels = seg_pipe.wrapper_compute_color2d_slic_features_labels(
+            (image, annot.copy()), 16, 0.2, {'color': ('mean', 'std', 'energy')}, 0.9)
+        out.update(supervised_crc=np.array([crc(image), crc(annot)], dtype=np.uint32), supervised_slic=np.asarray(slic).astype(np.int32),
+                   supervised_features=np.asarray(features, dtype=np.float64), supervised_labels=np.asarray(labels).astype(np.int32))
+        print('supervised', np.bincount(labels + 1).tolist())
     np.savez_compressed(os.path.join(HERE, 'reference.npz'), **out)
     print('reference vectors written:', len(out), 'arrays;', str(out['versions']))
 

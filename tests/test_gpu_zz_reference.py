@@ -49,3 +49,49 @@ def test_hip_pipeline_end_to_end_follows_the_reference_run(name):
     # the descriptors differ from the reference's -ffast-math Cython sums in the last bits, the integer energies of the
     # graph cut are therefore not guaranteed identical: demand (near) identity of the label map
     assert segm.shape == image.shape[:2] and np.mean(segm != VEC[name + '_segm']) < 1e-3
+
+
+@pytest.mark.parametrize('name', sorted(GEN.CASES_3D))
+def test_hip_gray3d_stages_follow_the_reference_run(name):
+    """pipe_gray3d_slic_features_model_graphcut (pipelines.py:382-431): supervoxels, descriptors, graph, graph cut"""
+    from pyimsegm_amd import descriptors as D
+    from pyimsegm_amd import graph_cuts as G
+    from pyimsegm_amd import superpixels as S
+    expr, sp, rc, space, feats, nb_classes, gc_regul = GEN.CASES_3D[name]
+    vol = GEN.make_input(expr)
+    slic = S.segment_slic_img3d_gray(vol, sp_size=sp, relative_compact=rc, space=space)
+    assert np.array_equal(slic, VEC[name + '_slic'])
+    features, _ = D.compute_selected_features_gray3d(vol, slic, feats)
+    ref_fts = VEC[name + '_features']
+    np.testing.assert_allclose(features, ref_fts, rtol=1e-5, atol=1e-5 * np.abs(ref_fts).max())
+    _, edges = S.make_graph_segm_connect_grid3d_conn6(slic)
+    assert np.array_equal(np.array(edges, dtype=np.int32), VEC[name + '_edges_graph'])
+    centres = np.array([c if len(np.shape(c)) else [-1, -1, -1] for c in S.superpixel_centers(slic)], dtype=np.float64)
+    np.testing.assert_allclose(centres, VEC[name + '_centres'], rtol=0, atol=1e-9)
+    labels = G.segment_graph_cut_general(slic, VEC[name + '_proba'], vol, VEC[name + '_normed'], gc_regul)
+    assert np.array_equal(labels, VEC[name + '_graph_labels'])
+
+
+def test_hip_texture_descriptors_follow_the_reference_run():
+    """Leung-Malik bank descriptors (descriptors.py:1041-1106; scipy convolutions in the reference) on the reference's SLIC"""
+    from pyimsegm_amd import descriptors as D
+    from pyimsegm_amd import superpixels as S
+    image = GEN.make_input(GEN.TEXTURE_CASE[0])
+    slic = S.segment_slic_img2d(image, GEN.TEXTURE_CASE[1], GEN.TEXTURE_CASE[2])
+    assert np.array_equal(slic, VEC['texture_slic'])
+    fts, names = D.compute_selected_features_img2d(image, slic, {'tLM_short': ('mean', 'std', 'energy')})
+    ref = VEC['texture_features']
+    assert list(names) == VEC['texture_names'].tolist() and fts.shape == ref.shape
+    assert np.max(np.abs(fts - ref)) < 1e-5 * max(np.abs(ref).max(), 1.0), np.max(np.abs(fts - ref))
+
+
+def test_hip_superpixel_labels_follow_the_reference_run():
+    """wrapper_compute_color2d_slic_features_labels (pipelines.py:272-289): labels of the superpixels from an annotation"""
+    from pyimsegm_amd import pipelines as P
+    from test_golden_reference import supervised_input
+    image, annot = supervised_input()
+    slic, features, labels = P.wrapper_compute_color2d_slic_features_labels(
+        (image, annot), 16, 0.2, {'color': ('mean', 'std', 'energy')}, 0.9)
+    assert np.array_equal(slic, VEC['supervised_slic']) and np.array_equal(labels, VEC['supervised_labels'])
+    ref = VEC['supervised_features']
+    np.testing.assert_allclose(features, ref, rtol=1e-5, atol=1e-5 * np.abs(ref).max())
