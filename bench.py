@@ -11,7 +11,7 @@ imsegm/pipelines.py:160).  One step = one pass of that function over the residen
 input image is already in HBM when the timed region starts and the outputs (segm H x W int32,
 segm_soft H x W x 3 float64) stay in HBM; the scikit-learn `predict_proba` and the numpy edge-weight
 formulas of the reference run on the host inside the timed region, as do the K x F / E / K x C
-transfers between the stages.  The K timed steps are taken by M worker threads per process (default 3), each
+transfers between the stages.  The K timed steps are taken by M worker threads per process (default: by K, 6 from 40 steps), each
 with its own HIP stream and resident copy of the image, so that the host stages of one step overlap the
 kernels of another -- the reference maps a pool of worker processes over the images.  The `roofline` and
 `stage_ms_per_step` figures come from a second, un-overlapped pass on one stream (the assignment kernel is
