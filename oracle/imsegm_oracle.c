@@ -936,3 +936,110 @@ ORC_API void orc_label_hist(const int32_t *slic, const int32_t *annot, size_t n,
         hist[(size_t)k * nb + a] += 1;
     }
 }
+
+/* ---------------------------------------------------------------------------------------------------------
+ * float32 volumes.  scikit-image 0.18 keeps a float32 input in float32 from end to end (slic_superpixels.py:
+ * `dtype = image.dtype` ... `_slic_cython[float32]`): the Gaussian filter stores float32 after every axis pass
+ * (scipy computes each line in double), `image * ratio` is a float32 product, centroids, spacing, distances and
+ * the raster-order running sums of the centroid update are float32.  This is the restatement of that variant
+ * for the reference's 3-D call (superpixels.py:104-106, multichannel=False); it is checked against the real
+ * scikit-image 0.18.3 in tests/test_golden_skimage.py.  The HIP path does not have it yet (it widens float32
+ * volumes to float64): the sequential float32 sums need an order-preserving reduction.
+ * --------------------------------------------------------------------------------------------------------- */
+static void blur_axis_f32(float *vol, int D, int H, int W, int axis, const double *w, int r)
+{
+    size_t n = (size_t)D * H * W;
+    double *src = (double *)calloc(n, sizeof(double)), *dst = (double *)calloc(n, sizeof(double));
+    for (size_t p = 0; p < n; ++p) src[p] = (double)vol[p];
+    blur_axis(src, dst, D, H, W, axis, w, r);
+    for (size_t p = 0; p < n; ++p) vol[p] = (float)dst[p];          /* scipy casts the line to the output dtype */
+    free(src); free(dst);
+}
+
+ORC_API void orc_slic_gray3d_f32(const float *img, int D, int H, int W,
+                                 const double *wz, int rz, const double *wy, int ry, const double *wx, int rx,
+                                 double ratio, int K, const double *centroids_zyx, int step_z, int step_y, int step_x,
+                                 float step, const double spacing_in[3], int max_iter,
+                                 float *pre_out, int32_t *nearest)
+{
+    size_t n = (size_t)D * H * W;
+    float *im = pre_out;
+    memcpy(im, img, n * sizeof(float));
+    if (rz >= 0) blur_axis_f32(im, D, H, W, 0, wz, rz);
+    if (ry >= 0) blur_axis_f32(im, D, H, W, 1, wy, ry);
+    if (rx >= 0) blur_axis_f32(im, D, H, W, 2, wx, rx);
+    const float fratio = (float)ratio;                               /* numpy: float32 array * Python float */
+    for (size_t p = 0; p < n; ++p) im[p] = im[p] * fratio;
+
+    float *seg = (float *)calloc((size_t)K * 4, sizeof(float));
+    for (int k = 0; k < K; ++k)
+        for (int c = 0; c < 3; ++c) seg[4 * k + c] = (float)centroids_zyx[3 * k + c];
+    float *distance = (float *)malloc(n * sizeof(float));
+    long *cnt = (long *)calloc(K, sizeof(long));
+    uint8_t *dead = (uint8_t *)calloc(K, 1);
+    const float sz = (float)spacing_in[0], sy = (float)spacing_in[1], sx = (float)spacing_in[2];
+    const float spatial_weight = (float)(1.0 / ((double)step * (double)step));
+    for (size_t p = 0; p < n; ++p) nearest[p] = -1;
+    for (int it = 0; it < max_iter; ++it) {
+        int change = 0;
+        for (size_t p = 0; p < n; ++p) distance[p] = INFINITY;        /* DBL_MAX stored as float32 */
+        for (int k = 0; k < K; ++k) {
+            if (dead[k]) continue;
+            const float cz = seg[4 * k], cy = seg[4 * k + 1], cx = seg[4 * k + 2], cv = seg[4 * k + 3];
+            float a;
+            a = cz - 2 * step_z; long z_min = (long)(a > 0 ? a : 0);
+            a = cz + 2 * step_z + 1; long z_max = (long)(a < D ? a : D);
+            a = cy - 2 * step_y; long y_min = (long)(a > 0 ? a : 0);
+            a = cy + 2 * step_y + 1; long y_max = (long)(a < H ? a : H);
+            a = cx - 2 * step_x; long x_min = (long)(a > 0 ? a : 0);
+            a = cx + 2 * step_x + 1; long x_max = (long)(a < W ? a : W);
+            for (long z = z_min; z < z_max; ++z) {
+                const float tz = sz * (cz - (float)z);
+                const float dz = tz * tz;
+                for (long y = y_min; y < y_max; ++y) {
+                    const float ty = sy * (cy - (float)y);
+                    const float dy = ty * ty;
+                    for (long x = x_min; x < x_max; ++x) {
+                        size_t p = ((size_t)z * H + y) * W + x;
+                        const float tx = sx * (cx - (float)x);
+                        float dist_center = ((dz + dy) + tx * tx) * spatial_weight;
+                        const float t = im[p] - cv;
+                        float dist_color = 0.f;
+                        dist_color += t * t;
+                        dist_center += dist_color;
+                        if (distance[p] > dist_center) {
+                            nearest[p] = k;
+                            distance[p] = dist_center;
+                            change = 1;
+                        }
+                    }
+                }
+            }
+        }
+        if (!change) break;
+        memset(cnt, 0, K * sizeof(long));
+        for (int k = 0; k < K; ++k)
+            if (!dead[k]) seg[4 * k] = seg[4 * k + 1] = seg[4 * k + 2] = seg[4 * k + 3] = 0.f;
+        for (int z = 0; z < D; ++z)
+            for (int y = 0; y < H; ++y)
+                for (int x = 0; x < W; ++x) {
+                    size_t p = ((size_t)z * H + y) * W + x;
+                    int k = nearest[p];
+                    if (k < 0) continue;
+                    cnt[k] += 1;
+                    seg[4 * k] += (float)z;                               /* running float32 sums, raster order */
+                    seg[4 * k + 1] += (float)y;
+                    seg[4 * k + 2] += (float)x;
+                    seg[4 * k + 3] += im[p];
+                }
+        for (int k = 0; k < K; ++k) {
+            if (dead[k]) continue;
+            if (cnt[k] == 0) {
+                dead[k] = 1;
+                continue;
+            }
+            for (int c = 0; c < 4; ++c) seg[4 * k + c] = seg[4 * k + c] / (float)cnt[k];
+        }
+    }
+    free(seg); free(distance); free(cnt); free(dead);
+}

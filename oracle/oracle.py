@@ -388,3 +388,36 @@ def histogram_regions_labels_norm(slic, segm):
     hist = np.nan_to_num(hist / sums)
     hist[hist == 0] = 0
     return hist
+
+
+def slic_gray3d_float32(vol, n_segments, compactness, sigma=1., spacing=(1., 1., 1.), max_iter=10, enforce_connectivity=True,
+                        start_label=0, return_raw=False):
+    """``skimage.segmentation.slic(vol_float32, ..., multichannel=False)`` as scikit-image 0.18 evaluates it: float32
+    from end to end (see imsegm_oracle.c).  Oracle only -- the HIP path widens float32 volumes to float64."""
+    L = lib()
+    vol = np.ascontiguousarray(vol, dtype=np.float32)
+    D, H, W = vol.shape
+    spacing32 = np.asarray(spacing, dtype=np.float32)
+    sig = np.array([sigma, sigma, sigma], dtype=np.float32) / spacing32           # float32 division, then float(sigma)
+    taps = [gaussian_taps(float(s)) for s in sig]
+    tap_args = []
+    for t in taps:
+        tap_args += [None, C.c_int(-1)] if t is None else [_p(t), C.c_int(len(t) - 1)]
+    cent, steps = grid_centroids((D, H, W), n_segments)
+    K = cent.shape[0]
+    step = max(steps)
+    isteps = [int(s if s is not None else 1) for _, s in regular_grid((D, H, W), K)]
+    pre = np.empty((D, H, W), dtype=np.float32)
+    nearest = np.empty((D, H, W), dtype=np.int32)
+    L.orc_slic_gray3d_f32(_p(vol), C.c_int(D), C.c_int(H), C.c_int(W), *tap_args, C.c_double(1.0 / compactness), C.c_int(K),
+                          _p(np.ascontiguousarray(cent[:, :3], dtype=np.float64)), C.c_int(isteps[0]), C.c_int(isteps[1]),
+                          C.c_int(isteps[2]), C.c_float(step), _p(np.asarray(spacing32, dtype=np.float64)), C.c_int(max_iter),
+                          _p(pre), _p(nearest))
+    labels = nearest + start_label
+    if return_raw or not enforce_connectivity:
+        return labels.astype(np.int64)
+    segment_size = D * H * W / K
+    out = np.empty_like(labels)
+    L.orc_enforce_connectivity(_p(labels), C.c_int(D), C.c_int(H), C.c_int(W), C.c_long(int(0.5 * segment_size)),
+                               C.c_long(int(3 * segment_size)), C.c_int(start_label), _p(out))
+    return out.astype(np.int64)

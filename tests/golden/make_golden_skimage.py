@@ -39,6 +39,13 @@ CASES_3D = {
 }
 
 
+#: float32 volumes: scikit-image 0.18 runs them in float32 from end to end (the oracle has that variant, the HIP path not yet)
+CASES_3D_F32 = {
+    'vol_f32': ('ellipsoid_volume((12, 40, 48))', 8, 0.2, (1, 1, 1)),
+    'vol_f32_aniso': ('ellipsoid_volume((8, 44, 40), seed=6)', 9, 0.3, (3, 1, 1)),
+}
+
+
 def make_input(expr):
     from pyimsegm_amd.utilities.synthetic import disc_image, ellipsoid_volume, voronoi_image  # noqa: F401
     return eval(expr)
@@ -78,8 +85,9 @@ def main():
             props = measure.regionprops(out[name + '_final'] + 1)
             out[name + '_centroids'] = np.array([p.centroid for p in props], dtype=np.float64)
 
-    for name, (expr, sp, rc, space) in CASES_3D.items():
+    for name, (expr, sp, rc, space) in list(CASES_3D.items()) + list(CASES_3D_F32.items()):
         vol = make_input(expr)
+        assert (vol.dtype == np.float32) == (name in CASES_3D_F32)
         out[name + '_crc'] = np.array(crc(vol), dtype=np.uint32)
         nb_pixels = np.prod(vol.shape)
         sp_vol = np.prod(sp / np.asarray(space, dtype=np.float32) * min(space))
