@@ -116,6 +116,41 @@ def real_skimage_slic(image):
         return None
 
 
+def compare_with_reference_run(image, sess, mode, pipe, predict_proba):
+    """one extra, untimed GPU pass with the class model of the reference's own run on the benchmark image
+    (tests/golden/reference_2048.npz: real scikit-image 0.18.3 + the reference's Cython descriptors + its scikit-learn
+    GMM, gco bridged to the oracle; label maps stored as CRC32): the superpixel map and the final segmentation of the
+    GPU must have the same checksums"""
+    import zlib
+    from sklearn.mixture import GaussianMixture
+    from sklearn.pipeline import Pipeline
+    from sklearn.preprocessing import StandardScaler
+    path = os.path.join(ROOT, 'tests', 'golden', 'reference_2048.npz')
+    if not os.path.exists(path):
+        return None
+    ref = np.load(path, allow_pickle=False)
+    if zlib.crc32(np.ascontiguousarray(image).tobytes()) != int(ref['image_crc']):
+        return None
+    scaler = StandardScaler()
+    scaler.mean_, scaler.scale_ = ref['scaler_mean'], ref['scaler_scale']
+    scaler.var_, scaler.n_features_in_ = scaler.scale_**2, len(scaler.mean_)
+    gmm = GaussianMixture(n_components=len(ref['gmm_weights']), covariance_type='full')
+    gmm.weights_, gmm.means_ = ref['gmm_weights'], ref['gmm_means']
+    gmm.covariances_, gmm.precisions_cholesky_ = ref['gmm_covariances'], ref['gmm_precisions_cholesky']
+    gmm.precisions_ = np.array([pc @ pc.T for pc in gmm.precisions_cholesky_])
+    gmm.converged_, gmm.n_features_in_ = True, scaler.n_features_in_
+    model = Pipeline([('scaler', scaler), ('GMM', gmm)])
+    from pyimsegm_amd.descriptors import FEATURES_SET_COLOR
+    res = pipe._ResidentImage(image, FEATURES_SET_COLOR, SP_SIZE, SP_REGUL, session=(sess, mode))
+    segm, _ = res.segment(predict_proba(model, res.features), GC_REGUL, EDGE_TYPE, to_host=True)
+    slic_ok = zlib.crc32(np.ascontiguousarray(res.slic, dtype=np.int32).tobytes()) == int(ref['slic_crc'])
+    segm_ok = zlib.crc32(np.ascontiguousarray(segm, dtype=np.int32).tobytes()) == int(ref['segm_crc'])
+    return {'gpu_equals_reference_run': bool(slic_ok and segm_ok),
+            'reference_run': 'tests/golden/reference_2048.npz: the reference itself on this image (%s), superpixel map %s, '
+                             'segmentation %s' % (str(ref['versions']), 'equal' if slic_ok else 'DIFFERENT',
+                                                  'equal' if segm_ok else 'DIFFERENT')}
+
+
 def _cpu_baseline_pass(image, model):
     from oracle import oracle as orc
     from pyimsegm_amd import graph_cuts as gc
@@ -340,6 +375,13 @@ def main():
                     pass
             except Exception as ex:   # the baseline is a reported extra, never a reason to lose the line
                 out['cpu_baseline'] = {'error': repr(ex)}
+        if world == 1 and size == HEIGHT:
+            try:      # the reference's own run on this very image (build container, tests/golden/make_golden_reference.py)
+                verdict = compare_with_reference_run(image, sess, mode, pipe, predict_proba)
+                if verdict is not None:
+                    out.update(verdict)
+            except Exception:
+                pass
         print(json.dumps(out), flush=True)
     if host_pool is not None:
         host_pool.close()

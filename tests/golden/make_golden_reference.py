@@ -47,6 +47,8 @@ CASES_3D = {
                {'color': ('mean', 'std', 'energy')}, 3, 0.1),
     'vol_f64': ('ellipsoid_volume((8, 44, 40), seed=6).astype(np.float64)', 9, 0.3, (3, 1, 1), {'color': ['mean']}, 2, 0.5),
 }
+#: the benchmark workload of bench.py (BASELINE configs[1])
+FULL_CASE = ('voronoi_image(2048, 2048, seed=1)', 46, 0.2, {'color': ('mean', 'std', 'energy')}, 3, 2.0, 'model')
 #: (input expression, sp_size, sp_regul) of the texture case
 TEXTURE_CASE = ('voronoi_image(60, 75, seed=8)', 12, 0.2)
 
@@ -187,6 +189,31 @@ def main():
         out.update(supervised_crc=np.array([crc(image), crc(annot)], dtype=np.uint32), supervised_slic=np.asarray(slic).astype(np.int32),
                    supervised_features=np.asarray(features, dtype=np.float64), supervised_labels=np.asarray(labels).astype(np.int32))
         print('supervised', np.bincount(labels + 1).tolist())
+
+        # ---- the benchmark image itself (BASELINE configs[1]: 2048 x 2048 RGB, bench.py defaults), full size: the
+        # ---- label maps are stored as checksums, the class model with all its parameters ---------------------------
+        image = make_input(FULL_CASE[0])
+        _, sp, rc, feats, nb_classes, gc_regul, edge_type = FULL_CASE
+        np.random.seed(0)
+        model, list_features = seg_pipe.estim_model_classes_group([image], nb_classes, feats, sp_size=sp, sp_regul=rc,
+                                                                  nb_workers=1)
+        recorded.clear()
+        segm, soft = seg_pipe.segment_color2d_slic_features_model_graphcut(image, model, feats, sp_size=sp, sp_regul=rc,
+                                                                           gc_regul=gc_regul, gc_edge_type=edge_type)
+        slic = seg_spx.segment_slic_img2d(image, sp, rc)
+        scaler, gmm = model.steps[0][1], model.steps[-1][1]
+        full = {
+            'versions': out['versions'], 'image_crc': np.array(crc(image), dtype=np.uint32),
+            'slic_crc': np.array(crc(np.asarray(slic).astype(np.int32)), dtype=np.uint32),
+            'nb_superpixels': np.array(int(slic.max()) + 1),
+            'features': np.asarray(list_features[0], dtype=np.float64), 'proba': model.predict_proba(list_features[0]),
+            'segm_crc': np.array(crc(np.asarray(segm).astype(np.int32)), dtype=np.uint32),
+            'class_counts': np.bincount(np.asarray(segm).ravel()), 'nb_edges': np.array(len(recorded['edges'])),
+            'scaler_mean': scaler.mean_, 'scaler_scale': scaler.scale_, 'gmm_weights': gmm.weights_, 'gmm_means': gmm.means_,
+            'gmm_covariances': gmm.covariances_, 'gmm_precisions_cholesky': gmm.precisions_cholesky_,
+        }
+        np.savez_compressed(os.path.join(HERE, 'reference_2048.npz'), **full)
+        print('full size', 'K =', int(slic.max()) + 1, 'E =', len(recorded['edges']), 'classes', full['class_counts'].tolist())
     np.savez_compressed(os.path.join(HERE, 'reference.npz'), **out)
     print('reference vectors written:', len(out), 'arrays;', str(out['versions']))
 
