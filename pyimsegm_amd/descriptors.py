@@ -462,7 +462,9 @@ def compute_image3d_gray_statistic(image, segm, feature_flags=NAMES_FEATURE_FLAG
     if 'median' in feature_flags:
         features.append(numpy_img3d_gray_median(image, segm))
     if 'meanGrad' in feature_flags:
-        grad = np.zeros_like(image, dtype=np.float64)
+        # as the reference (descriptors.py:767-769): the gradient sums are stored in the image's own dtype -- for an
+        # integer volume they are truncated and wrap around exactly as numpy does there
+        grad = np.zeros_like(image)
         for i in range(image.shape[0]):
             grad[i] = np.sum(np.gradient(image[i]), axis=0)
         features.append(cython_img3d_gray_mean(grad, segm))
@@ -492,7 +494,8 @@ def _color_statistic_session(sess, image, segm, feature_flags, color_name):
     if 'median' in feature_flags:
         blocks.append(numpy_img2d_color_median(image, segm))
     if 'meanGrad' in feature_flags:
-        grad = np.zeros(image.shape, dtype=np.float64)
+        # as the reference (descriptors.py:842-844): stored in the image's own dtype (integer images truncate / wrap)
+        grad = np.zeros_like(image)
         for i in range(3):
             grad[:, :, i] = np.sum(np.gradient(image[:, :, i]), axis=0)
         blocks.append(hip_img2d_color_mean(grad, segm))

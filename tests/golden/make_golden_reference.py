@@ -47,6 +47,14 @@ CASES_3D = {
                {'color': ('mean', 'std', 'energy')}, 3, 0.1),
     'vol_f64': ('ellipsoid_volume((8, 44, 40), seed=6).astype(np.float64)', 9, 0.3, (3, 1, 1), {'color': ['mean']}, 2, 0.5),
 }
+#: descriptor variants: image and label map of one SLIC run, then feature dictionaries on (a view of) that image
+FEATURE_CASE = ('voronoi_image(120, 150, seed=12)', 14, 0.2)
+FEATURE_VARIANTS = {
+    'hsv_lab': ('image', {'color_hsv': ('mean', 'std', 'energy'), 'color_lab': ('mean', 'std')}),
+    'all_flags_float': ('image / 255.', {'color': ('mean', 'std', 'energy', 'median', 'meanGrad')}),
+    'all_flags_uint8': ('image', {'color': ('mean', 'std', 'energy', 'median', 'meanGrad')}),
+    'gray2d': ('image[:, :, 1] / 255.', {'color': ('mean', 'std', 'energy', 'median', 'meanGrad')}),
+}
 #: the benchmark workload of bench.py (BASELINE configs[1])
 FULL_CASE = ('voronoi_image(2048, 2048, seed=1)', 46, 0.2, {'color': ('mean', 'std', 'energy')}, 3, 2.0, 'model')
 #: (input expression, sp_size, sp_regul) of the texture case
@@ -189,6 +197,18 @@ def main():
         out.update(supervised_crc=np.array([crc(image), crc(annot)], dtype=np.uint32), supervised_slic=np.asarray(slic).astype(np.int32),
                    supervised_features=np.asarray(features, dtype=np.float64), supervised_labels=np.asarray(labels).astype(np.int32))
         print('supervised', np.bincount(labels + 1).tolist())
+
+        # ---- descriptor variants of compute_selected_features_img2d (descriptors.py:1207-1285): other colour spaces,
+        # ---- median and mean gradient, gray 2-D input -- on a fixed label map ---------------------------------------
+        image = make_input(FEATURE_CASE[0])
+        slic = seg_spx.segment_slic_img2d(image, FEATURE_CASE[1], FEATURE_CASE[2])
+        out.update(variants_crc=np.array(crc(image), dtype=np.uint32), variants_slic=np.asarray(slic).astype(np.int32))
+        for tag, (img_expr, flags) in FEATURE_VARIANTS.items():
+            img = eval(img_expr, {'image': image, 'np': np})
+            fts, names = seg_fts.compute_selected_features_img2d(img, slic, flags)
+            out['variants_%s' % tag] = np.asarray(fts, dtype=np.float64)
+            out['variants_%s_names' % tag] = np.array(names)
+            print('features', tag, fts.shape)
 
         # ---- the benchmark image itself (BASELINE configs[1]: 2048 x 2048 RGB, bench.py defaults), full size: the
         # ---- label maps are stored as checksums, the class model with all its parameters ---------------------------

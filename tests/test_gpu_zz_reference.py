@@ -95,3 +95,17 @@ def test_hip_superpixel_labels_follow_the_reference_run():
     assert np.array_equal(slic, VEC['supervised_slic']) and np.array_equal(labels, VEC['supervised_labels'])
     ref = VEC['supervised_features']
     np.testing.assert_allclose(features, ref, rtol=1e-5, atol=1e-5 * np.abs(ref).max())
+
+
+@pytest.mark.parametrize('tag', sorted(GEN.FEATURE_VARIANTS))
+def test_hip_descriptor_variants_follow_the_reference_run(tag):
+    """compute_selected_features_img2d (descriptors.py:1207-1285) with other colour spaces, median, mean gradient and a
+    gray 2-D image, on the label map of the reference's SLIC"""
+    from pyimsegm_amd import descriptors as D
+    image = GEN.make_input(GEN.FEATURE_CASE[0])
+    img_expr, flags = GEN.FEATURE_VARIANTS[tag]
+    img = eval(img_expr, {'image': image, 'np': np})
+    fts, names = D.compute_selected_features_img2d(img, VEC['variants_slic'].astype(np.int64), flags)
+    ref = VEC['variants_%s' % tag]
+    assert list(names) == VEC['variants_%s_names' % tag].tolist() and fts.shape == ref.shape
+    np.testing.assert_allclose(fts, ref, rtol=1e-5, atol=1e-5 * max(1.0, np.abs(ref).max()))
