@@ -1,6 +1,10 @@
 """Timing of the gray-volume (supervoxel) path on one GPU (BASELINE config 5 is 64 x 4096 x 4096).
 
-    python tools/bench_volume.py [D H W] [sp_size]
+    python tools/bench_volume.py [D H W] [sp_size] [--pipeline] [--uint8]
+
+The synthetic volume is float32 by default; note that scikit-image 0.18 runs a float32 volume in
+float32 while this path widens it to float64.  `--uint8` quantises the same volume to uint8, for
+which the path reproduces scikit-image bit for bit.
 """
 import sys
 import time
@@ -30,6 +34,9 @@ def main():
     shape = tuple(int(v) for v in args[0:3]) if len(args) >= 3 else (64, 512, 512)
     sp = int(args[3]) if len(args) > 3 else 15
     vol = volume(shape)
+    if '--uint8' in sys.argv:
+        np.clip(vol, 0, 1, out=vol)
+        vol = (vol * np.float32(255)).astype(np.uint8)
     n = vol.size
     n_seg, compact = _slic3d_params(shape, sp, 0.2, (1, 1, 1))
     print('volume %r, %d voxels, n_segments %d, compactness %d' % (shape, n, n_seg, compact))
