@@ -233,8 +233,14 @@ def main():
         # the numpy stages of the images in flight leave the interpreter lock of this process (same functions,
         # same numbers: pyimsegm_amd/hostpool.py); helpers are started and given the model before the timed region
         from pyimsegm_amd.hostpool import HostMathPool
-        host_pool = HostMathPool(inflight)
-        host_pool.set_model(model)
+        try:
+            host_pool = HostMathPool(inflight)
+            host_pool.set_model(model)
+        except Exception as ex:       # no helpers (cannot spawn, model not picklable ...): the threads do the numpy work
+            print('host helper processes not available (%r): numpy stages stay in the worker threads' % (ex, ), file=sys.stderr)
+            if host_pool is not None:
+                host_pool.close()
+            host_pool = None
     if args.switch_interval:
         sys.setswitchinterval(args.switch_interval)
     do_gather = group.dist is not None            # launched by torchrun (also exercised with a single rank)
@@ -243,32 +249,42 @@ def main():
     ready = threading.Barrier(inflight + 1)
     contexts = [None] * inflight
 
+    errors = []
+
     def worker(idx):
-        wctx = _hip.default_context()            # per thread
-        contexts[idx] = wctx
-        session = _open_session(image)
-        for _ in range(max(args.warmup, 1)):
-            step(model, session)
-        wctx.synchronize()
-        ready.wait()
-        while True:
-            item = todo.get()
-            if item is None:
-                break
-            step(model, session)
-            if do_gather:
-                gathered = threading.Event()
-                done.put((session[0], gathered))
-                gathered.wait()                   # the label buffer is reused by the next step
-            else:
-                done.put((session[0], None))
-        wctx.synchronize()
-        done.put(None)
+        try:
+            wctx = _hip.default_context()            # per thread
+            contexts[idx] = wctx
+            session = _open_session(image)
+            for _ in range(max(args.warmup, 1)):
+                step(model, session)
+            wctx.synchronize()
+            ready.wait()
+            while True:
+                item = todo.get()
+                if item is None:
+                    break
+                step(model, session)
+                if do_gather:
+                    gathered = threading.Event()
+                    done.put((session[0], gathered))
+                    gathered.wait()                   # the label buffer is reused by the next step
+                else:
+                    done.put((session[0], None))
+            wctx.synchronize()
+        except BaseException as ex:                   # never leave the main thread waiting for a dead worker
+            errors.append(ex)
+            ready.abort()
+        finally:
+            done.put(None)
 
     threads = [threading.Thread(target=worker, args=(i,), daemon=True) for i in range(inflight)]
     for t in threads:
         t.start()
-    ready.wait()                                  # sessions resident, warm-up done
+    try:
+        ready.wait()                              # sessions resident, warm-up done
+    except threading.BrokenBarrierError:
+        raise RuntimeError('a worker thread failed during warm-up: %r' % (errors[:1], ))
     group.barrier()
     t0 = time.perf_counter()
     for i in range(args.steps):
@@ -289,6 +305,8 @@ def main():
     elapsed = time.perf_counter() - t0
     for t in threads:
         t.join()
+    if errors:
+        raise RuntimeError('a worker thread failed: %r' % (errors[0], ))
     elapsed = group.max_over_ranks(elapsed)
 
     # Kernel-level figures (roofline of the dominant kernel, stage breakdown): a second, un-overlapped pass of
