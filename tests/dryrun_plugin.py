@@ -1,0 +1,113 @@
+"""TEST-LOGIC DRY RUN (test infrastructure, opt-in, never loaded by default and never by the product).
+
+    python -m pytest -p dryrun_plugin tests/test_gpu_zz_reference.py -m gpu        # from the tests/ directory on sys.path:
+    PYTHONPATH=tests python -m pytest -p dryrun_plugin tests -m gpu -k "zz or api"
+
+The `-m gpu` tests need an MI355X.  GPU time is scarce, and a typo in a new GPU test (a wrong tolerance, argument order,
+fixture name) would only show up there.  This pytest plugin replaces the ctypes session classes of `pyimsegm_amd._hip`
+with stand-ins that answer from the CPU oracle, so that the PYTHON side of the GPU tests, of `bench.py` and of the host
+code (pipelines, helper processes, threading) can be exercised on a machine without a GPU.  It says NOTHING about the
+kernels -- a dry run passing here proves only that the test logic is sound, given that the HIP path equals the oracle
+(which the real `-m gpu` run establishes).  The product has no CPU fallback: `pyimsegm_amd` never imports this file or
+`oracle/`, and without the HIP library its calls raise.  Texture (`lm_*`) entry points are not emulated.
+"""
+import sys
+import numpy as np
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from oracle import oracle as orc
+from pyimsegm_amd import _hip
+
+
+class FakeCtx(object):
+    users = 0
+    def __init__(self): self.idle_sessions = {}; self._h = 1
+    def synchronize(self): pass
+    def close(self): pass
+
+_CTX = FakeCtx()
+
+
+class Image2D(object):
+    def __init__(self, height, width, ctx=None):
+        self.ctx = _CTX; self.shape = (int(height), int(width)); self.n_labels = 0; self.img = None; self.labels = None
+    def close(self): pass
+    def upload(self, image):
+        image = np.asarray(image)
+        assert image.ndim == 3 and image.shape[2] == 3 and image.shape[:2] == self.shape
+        if image.dtype not in (np.uint8, np.float32, np.float64): image = image.astype(np.float64)
+        self.img = image; return self
+    def slic(self, n_segments, compactness, sigma=1., normalize=2, max_iter=10, enforce_connectivity=True,
+             min_size_factor=0.5, max_size_factor=3., start_label=0, max_candidates=0, slic_zero=False):
+        img = self.img
+        norm = None
+        if normalize == 1 or (normalize == 2 and (img.min() != 0. or img.max() != 1.)):
+            norm = (float(img.min()), float(img.max()))
+        lab = orc.slic(img, n_segments, compactness, sigma=sigma, max_iter=max_iter, enforce_connectivity=enforce_connectivity,
+                       min_size_factor=min_size_factor, max_size_factor=max_size_factor, start_label=start_label,
+                       normalize=norm, slic_zero=slic_zero)
+        self.labels = np.asarray(lab, dtype=np.int32); self.n_labels = int(self.labels.max()) + 1
+        return self.n_labels
+    def get_labels(self): return self.labels.astype(np.int64)
+    def set_labels(self, labels, n_labels=None):
+        labels = np.ascontiguousarray(labels, dtype=np.int32); assert labels.shape == self.shape
+        self.labels = labels; self.n_labels = int(labels.max()) + 1 if n_labels is None else int(n_labels); return self
+    def label_hist(self, annot, nb_annot=None):
+        annot = np.asarray(annot, dtype=np.int32)
+        nb = int(annot.max()) + 1 if nb_annot is None else int(nb_annot)
+        out = np.zeros((self.n_labels, nb), dtype=np.int64)
+        np.add.at(out, (self.labels.ravel(), annot.ravel()), 1)
+        return out
+    def color_stats(self, mean=True, energy=True, var=True):
+        img32 = np.asarray(self.img, dtype=np.float32)
+        m = orc.color2d_mean(img32, self.labels)
+        e = orc.color2d_energy(img32, self.labels) if energy else None
+        v = orc.color2d_variance(img32, self.labels, m.astype(np.float32)) if var else None
+        return (m if mean else None), e, v
+    def graph(self):
+        vertices, edges = orc.adjacency(self.labels)
+        centres = np.asarray(orc.centers(self.labels), dtype=np.float64).reshape(self.n_labels, -1)
+        present = np.zeros(self.n_labels, dtype=bool); present[np.asarray(vertices)] = True
+        return np.array(edges, dtype=np.int32).reshape(-1, 2), centres, present
+    def gather(self, graph_labels=None, proba=None, to_host=True):
+        segm = np.asarray(graph_labels, dtype=np.int32)[self.labels] if graph_labels is not None else None
+        soft = np.asarray(proba, dtype=np.float64)[self.labels] if proba is not None else None
+        return segm, soft
+
+
+class Volume3D(Image2D):
+    def __init__(self, depth, height, width, ctx=None):
+        self.ctx = _CTX; self.shape = (int(depth), int(height), int(width)); self.n_labels = 0
+    def upload(self, volume):
+        volume = np.asarray(volume); assert volume.shape == self.shape; self.img = volume; return self
+    def slic(self, n_segments, compactness, sigma=1., spacing=(1., 1., 1.), max_iter=10, enforce_connectivity=True,
+             min_size_factor=0.5, max_size_factor=3., start_label=0):
+        lab = orc.slic(self.img, n_segments, compactness, sigma=sigma, spacing=spacing, multichannel=False, max_iter=max_iter,
+                       enforce_connectivity=enforce_connectivity, start_label=start_label)
+        self.labels = np.asarray(lab, dtype=np.int32); self.n_labels = int(self.labels.max()) + 1; return self.n_labels
+    def label_cc(self):
+        self.labels = orc.label_cc(self.labels).astype(np.int32); self.n_labels = int(self.labels.max()) + 1; return self.n_labels
+    def gray_stats(self, mean=True, energy=True, var=True):
+        v32 = np.asarray(self.img, dtype=np.float32)
+        m = orc.gray3d_stat(v32, self.labels, 'mean')
+        e = orc.gray3d_stat(v32, self.labels, 'energy') if energy else None
+        v = orc.gray3d_stat(v32, self.labels, 'var', m.astype(np.float32)) if var else None
+        return (m if mean else None), e, v
+
+
+def pytest_configure(config):
+    _hip.Image2D = Image2D
+    _hip.Volume3D = Volume3D
+    _hip.default_context = lambda: _CTX
+    _hip.cut_general_graph = lambda e, w, u, p, n_iter=-1, algorithm='expansion', **k: orc.cut_general_graph(
+        np.asarray(e, dtype=np.int32).reshape(-1, 2), w, u, p, n_iter=n_iter)
+    import pyimsegm_amd.graph_cuts as G
+    G._hip = _hip
+
+
+def _ctx_extra():
+    FakeCtx.profile_enable = lambda self, enable=True: None
+    FakeCtx.profile_reset = lambda self: None
+    FakeCtx.profile_get = lambda self, group: (1.0, 10)
+
+_ctx_extra()
