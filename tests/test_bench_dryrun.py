@@ -1,0 +1,32 @@
+"""Host side of bench.py at world size 2 (torchrun + gloo, one process per "GPU") with the device calls answered by the
+oracle (tests/dryrun_bench.py): worker threads, helper processes, one gather per step on the main thread, barriers, the
+maximum over ranks and ONE JSON line from rank 0.  The kernels are not involved; this guards the N > 1 control flow
+that cannot be run on the single-GPU test box."""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def run_bench(nproc, steps, port):
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(nproc), '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.join(ROOT, 'tests', 'dryrun_bench.py'), '--gpus', str(nproc), '--size', '192',
+           '--steps', str(steps), '--warmup', '1']
+    env = dict(os.environ, OMP_NUM_THREADS='1')
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1, 'exactly one JSON line from rank 0, got %d' % len(lines)
+    return json.loads(lines[0])
+
+
+def test_bench_control_flow_two_ranks():
+    d = run_bench(2, 9, 29631)
+    assert d['n_gpus'] == 2 and d['steps'] == 9 and d['warmup'] == 1 and d['scaling'] == 'weak'
+    assert d['higher_is_better'] is True and d['vs_baseline'] is None and d['value'] > 0
+    assert abs(d['value'] - 2 * 9 * 192 * 192 / (d['ms_per_step'] * 9 / 1e3) / 1e6) / d['value'] < 1e-3      # whole-job aggregate
+    assert set(d['roofline']) >= {'bound', 'achieved', 'peak', 'unit', 'frac', 'traffic'}
+    assert d['config']['images_in_flight_per_gpu'] == 4 and 'helper processes' in d['config']['host_math']
+    assert 'cpu_baseline' not in d                     # rank 0 at N = 1 only
