@@ -85,6 +85,7 @@ class HostMathPool(object):
     """``nb_workers`` helper processes; every call borrows one of them (blocking while all are busy)"""
 
     def __init__(self, nb_workers):
+        self._pid = os.getpid()                   # a forked child inherits the handles but must not talk to our helpers
         root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
         env = dict(os.environ)
         env['PYTHONPATH'] = root + os.pathsep + env.get('PYTHONPATH', '')
@@ -120,6 +121,8 @@ class HostMathPool(object):
 
     def terms(self, features, edges, centres, gc_regul, edge_type):
         """proba, unary cost, pairwise cost and edge weights of one image, evaluated by a free helper"""
+        if self._pid != os.getpid():
+            raise RuntimeError('this pool belongs to the parent process: create a pool after the fork')
         proc = self._free.get()
         try:
             return self._call(proc, ('terms', features, edges, centres, gc_regul, edge_type))
@@ -127,6 +130,9 @@ class HostMathPool(object):
             self._free.put(proc)
 
     def close(self):
+        if getattr(self, '_pid', None) != os.getpid():
+            self._procs = []
+            return
         for proc in self._procs:
             try:
                 _send(proc.stdin, ('quit', ))
