@@ -30,6 +30,8 @@ CASES_2D = {
     'gray': ('voronoi_image(120, 160, seed=2)[:, :, 0]', 12, 0.3),
     'voronoi_big': ('voronoi_image(400, 520, seed=9)', 25, 0.3),
     'ovary_size': ('voronoi_image(647, 1024, seed=100)', 35, 0.2),         # BASELINE configs[3] image size and parameters
+    'uint16': ('(voronoi_image(140, 190, seed=21).astype(np.uint16) * 257)', 13, 0.25),       # microscopy-style 16-bit RGB
+    'float32': ('(voronoi_image(150, 210, seed=5) / 255.).astype(np.float32)', 14, 0.2),       # runs in float32 inside scikit-image
 }
 CASES_3D = {
     'vol_aniso_f64': ('ellipsoid_volume((8, 44, 40), seed=6).astype(np.float64)', 9, 0.3, (3, 1, 1)),
