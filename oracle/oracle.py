@@ -69,7 +69,10 @@ def gaussian_taps(sigma, truncate=4.0):
     """half kernel w[0..r] (w[0] = centre) of scipy.ndimage.gaussian_filter1d; None if sigma == 0"""
     if not sigma > 0:
         return None
-    from scipy.ndimage import _filters
+    try:
+        from scipy.ndimage import _filters
+    except ImportError:                       # scipy < 1.8 (the build container's conda interpreter)
+        from scipy.ndimage import filters as _filters
     r = int(truncate * float(sigma) + 0.5)
     full = _filters._gaussian_kernel1d(float(sigma), 0, r)[::-1]
     return np.ascontiguousarray(full[r:], dtype=np.float64)

@@ -361,10 +361,24 @@ def compute_pairwise_cost(gc_regul, proba_shape, max_pairwise_cost=MAX_PAIRWISE_
     return pairwise_cost
 
 
+def _reference_drawing():
+    """``imsegm.utilities.drawing`` of an installed reference (overlay mode of the ``imsegm`` package), else None"""
+    import sys
+    pkg = sys.modules.get('imsegm')
+    if pkg is None or getattr(pkg, 'REFERENCE_PATH', None) is None:
+        return None
+    try:
+        import importlib
+        return importlib.import_module('imsegm.utilities.drawing')
+    except Exception as ex:        # drawing needs matplotlib / planar: not part of the hot path
+        logging.debug('reference drawing module not importable: %s', ex)
+        return None
+
+
 def insert_gc_debug_images(debug_visual, segments, graph_labels, unary_cost, edges, edge_weights):
-    """ store intermediate variables (the rendered debug figures of the reference,
-    ``graph_cuts.py:558-571``, need its drawing module which is out of scope: only the raw
-    arrays are stored) """
+    """ store intermediate variables; when the reference's drawing module is installed (``imsegm`` overlay) also
+    the rendered debug images of ``graph_cuts.py:558-571`` (``imgs_unary_cost``, ``img_graph_edges``,
+    ``img_graph_segm``) that ``drawing.figure_segm_graphcut_debug`` expects """
     if debug_visual is None:
         return
     debug_visual['segments'] = segments
@@ -372,6 +386,15 @@ def insert_gc_debug_images(debug_visual, segments, graph_labels, unary_cost, edg
     debug_visual['edge_weights'] = edge_weights
     debug_visual['unary_cost'] = unary_cost
     debug_visual['graph_labels'] = graph_labels
+    draw = _reference_drawing()
+    if draw is None:
+        return
+    segments = np.asarray(segments)
+    debug_visual['imgs_unary_cost'] = draw.draw_graphcut_unary_cost_segments(segments, unary_cost)
+    from pyimsegm_amd.superpixels import superpixel_centers
+    debug_visual['img_graph_edges'] = draw.draw_graphcut_weighted_edges(
+        segments, superpixel_centers(segments), edges, edge_weights, img_bg=debug_visual.get('slic_mean', None))
+    debug_visual['img_graph_segm'] = draw.draw_color_labeling(segments, graph_labels)
 
 
 def _edges_centres(segments, _session=None):

@@ -101,6 +101,24 @@ class _ResidentImage(object):
             segm = segm.astype(np.asarray(classes).dtype)
         return segm, segm_soft
 
+    def mean_colour_image(self):
+        """ ``skimage.color.label2rgb(slic, image, kind='avg')`` (reference ``pipelines.py:93``, the ``slic_mean`` debug
+        image): per-superpixel mean colour gathered back to the pixels, on the device; as in scikit-image the
+        label 0 counts as background and stays black """
+        means, _, _ = self.sess.color_stats(mean=True, energy=False, var=False)
+        means = np.array(means, dtype=np.float64)
+        means[0] = 0.
+        _, out = self.sess.gather(None, means)
+        return out
+
+    def fill_debug(self, debug_visual):
+        if debug_visual is None:
+            return
+        image = self.image
+        debug_visual['image'] = image if image.ndim == 3 else np.repeat(image[:, :, None], 3, axis=2)
+        debug_visual['slic'] = self.slic
+        debug_visual['slic_mean'] = self.mean_colour_image()
+
     def close(self):
         if self.own_session:
             if self.reuse:
@@ -265,9 +283,7 @@ def pipe_color2d_slic_features_model_graphcut(
     """
     logging.info('PIPELINE Superpixels-Features-GMM-GraphCut')
     res = _ResidentImage(image, dict_features, sp_size, sp_regul)
-    if debug_visual is not None:
-        debug_visual['image'] = res.image if res.image.ndim == 3 else np.repeat(res.image[:, :, None], 3, axis=2)
-        debug_visual['slic'] = res.slic
+    res.fill_debug(debug_visual)
     model = estim_class_model(res.features, nb_classes, estim_model, pca_coef, use_scaler)
     proba = model.predict_proba(res.features)
     logging.debug('list of probabilities: %r', proba.shape)
@@ -324,9 +340,7 @@ def segment_color2d_slic_features_model_graphcut(
     """
     logging.info('PIPELINE Superpixels-Features-Model-GraphCut')
     res = _ResidentImage(image, dict_features, sp_size, sp_regul)
-    if debug_visual is not None:
-        debug_visual['image'] = res.image if res.image.ndim == 3 else np.repeat(res.image[:, :, None], 3, axis=2)
-        debug_visual['slic'] = res.slic
+    res.fill_debug(debug_visual)
     proba = predict_proba(model_pipeline, res.features)
     logging.debug('list of probabilities: %r', proba.shape)
     classes = getattr(model_pipeline, 'classes_', None)
