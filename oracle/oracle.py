@@ -247,7 +247,10 @@ def segment_slic_img3d_gray(im, sp_size=50, relative_compact=0.1, space=(1, 1, 1
     sp_vol = np.prod(sp_size / np.asarray(space, dtype=np.float32) * min(space))
     n_seg = int(nb_pixels / sp_vol)
     compact = int((sp_vol * relative_compact)**1.5)
-    seg = slic(np.array(im), n_seg, compact, sigma=1, spacing=space, multichannel=False, start_label=start_label)
+    if im.dtype == np.float32:       # scikit-image 0.18 runs a float32 volume in float32 from end to end
+        seg = slic_gray3d_float32(im, n_seg, compact, sigma=1., spacing=space, start_label=start_label)
+    else:
+        seg = slic(np.array(im), n_seg, compact, sigma=1, spacing=space, multichannel=False, start_label=start_label)
     return label_cc(seg)
 
 
@@ -396,7 +399,7 @@ def histogram_regions_labels_norm(slic, segm):
 def slic_gray3d_float32(vol, n_segments, compactness, sigma=1., spacing=(1., 1., 1.), max_iter=10, enforce_connectivity=True,
                         start_label=0, return_raw=False):
     """``skimage.segmentation.slic(vol_float32, ..., multichannel=False)`` as scikit-image 0.18 evaluates it: float32
-    from end to end (see imsegm_oracle.c).  Oracle only -- the HIP path widens float32 volumes to float64."""
+    from end to end (see imsegm_oracle.c; HIP counterpart: the float32 section of csrc/volume.hip)."""
     L = lib()
     vol = np.ascontiguousarray(vol, dtype=np.float32)
     D, H, W = vol.shape

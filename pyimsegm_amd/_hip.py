@@ -430,14 +430,19 @@ class Volume3D(Image2D):
             volume = volume.astype(np.float64)
         volume = np.ascontiguousarray(volume)
         _check(load_library().imsegm_volume_upload(self._h, _ptr(volume), _DTYPES[volume.dtype], off, scale))
+        self.dtype = volume.dtype
         return self
 
     def slic(self, n_segments, compactness, sigma=1., spacing=(1., 1., 1.), max_iter=10, enforce_connectivity=True,
              min_size_factor=0.5, max_size_factor=3., start_label=0):
-        spacing = np.ascontiguousarray(spacing, dtype=np.float64)
+        # scikit-image 0.18 keeps spacing and sigma in the dtype of the image: float32 for a float32 volume (which then
+        # runs in float32 on the device too), float64 for everything else
+        fdt = np.float32 if getattr(self, 'dtype', None) == np.float32 else np.float64
+        spacing = np.ascontiguousarray(spacing, dtype=fdt)
         if spacing.shape != (3, ):
             raise ValueError('spacing must have 3 elements (z, y, x)')
-        taps = [gaussian_taps(s) for s in np.array([sigma, sigma, sigma], dtype=np.float64) / spacing]
+        taps = [gaussian_taps(float(s)) for s in np.array([sigma, sigma, sigma], dtype=fdt) / spacing]
+        spacing = np.ascontiguousarray(spacing, dtype=np.float64)
         args = []
         for t in taps:
             args += [_ptr(t), -1 if t is None else len(t) - 1]

@@ -981,13 +981,21 @@ int imsegm_volume_slic(imsegm_image2d *im, int n_segments, double compactness, c
     float step = (float)fs;
     regular_grid3(shape, K, axk);
     if (im->labA.ensure(n * 8) || im->labB.ensure(n * 8) || im->nearest.ensure(n * 4) || im->labels.ensure(n * 4)) return -1;
-    if (im->vol_cent.ensure((size_t)K * (4 * 8 + 6 * 4 + 6 * 8) + 256)) return -1;
-    if (launch_vol_preprocess(im->img.p, im->dtype, im->vol_off, im->vol_scale, D, H, W, tz, ty, tx, 1.0 / compactness, im->labA.as<double>(),
-                              im->labB.as<double>(), st))
-        return -1;
+    // a float32 volume stays float32 from end to end, as in scikit-image 0.18 (volume.hip, float32 section)
+    const bool f32 = im->dtype == IMSEGM_F32;
+    if (im->vol_cent.ensure((size_t)K * (4 * 8 + 6 * 4 + 6 * 8 + 4 * 4 + 6 * 4) + 256)) return -1;
     if (im->small.ensure(4096)) return -1;
     double *premax = reinterpret_cast<double *>(im->small.as<unsigned char>() + 64);
-    if (launch_absmax_f64(im->labB.as<double>(), n, premax, st)) return -1;
+    if (f32) {
+        if (launch_vol_preprocess_f32(im->img.as<float>(), D, H, W, tz, ty, tx, 1.0 / compactness, im->labA.as<double>(),
+                                      im->labB.as<double>(), st))
+            return -1;
+    } else {
+        if (launch_vol_preprocess(im->img.p, im->dtype, im->vol_off, im->vol_scale, D, H, W, tz, ty, tx, 1.0 / compactness,
+                                  im->labA.as<double>(), im->labB.as<double>(), st))
+            return -1;
+        if (launch_absmax_f64(im->labB.as<double>(), n, premax, st)) return -1;
+    }
     VolState s;
     s.premax = premax;
     s.D = D; s.H = H; s.W = W; s.K = K;
@@ -999,7 +1007,9 @@ int imsegm_volume_slic(imsegm_image2d *im, int n_segments, double compactness, c
     unsigned char *cb = im->vol_cent.as<unsigned char>();
     s.cen = reinterpret_cast<double *>(cb); cb += (size_t)K * 4 * 8;
     s.acc = reinterpret_cast<long long *>(cb); cb += (size_t)K * 6 * 8;
-    s.win = reinterpret_cast<int *>(cb);
+    s.win = reinterpret_cast<int *>(cb); cb += (size_t)K * 6 * 4;
+    s.cen32 = reinterpret_cast<float *>(cb); cb += (size_t)K * 4 * 4;
+    s.bbox = reinterpret_cast<int *>(cb);
     for (int i = 0; i < 3; ++i) {
         s.grid_0[i] = (int)ax[i].start;
         s.grid_d[i] = (int)ax[i].step;
@@ -1019,7 +1029,11 @@ int imsegm_volume_slic(imsegm_image2d *im, int n_segments, double compactness, c
         s.brick_list = s.brick_count + ((n_bricks + 63) & ~(size_t)63);
     }
     int sp_all = ctx->begin(PG_SLIC);
-    if (launch_vol_slic(s, im->labB.as<double>(), im->nearest.as<int32_t>(), max_iter, st)) return -1;
+    if (f32) {
+        if (launch_vol_slic_f32(s, im->labB.as<float>(), im->nearest.as<int32_t>(), max_iter, st)) return -1;
+    } else if (launch_vol_slic(s, im->labB.as<double>(), im->nearest.as<int32_t>(), max_iter, st)) {
+        return -1;
+    }
     int n_labels = K + start_label;
     if (enforce_connectivity) {
         double segment_size = (double)n / (double)K;

@@ -104,11 +104,19 @@ struct VolState {
     int brick_cap;                  // entries per brick list
     int *brick_count;               // [n_bricks] (may exceed brick_cap: that brick scans the whole table)
     int *brick_list;                // [n_bricks][brick_cap]
+    // float32 volumes (scikit-image keeps them in float32): float32 centroid table and the bounding boxes of the
+    // segments' voxels that the order-preserving update walks
+    float *cen32;                   // [K][4] = cz, cy, cx, value
+    int *bbox;                      // [K][6] = zmin, zmax, ymin, ymax, xmin, xmax (inclusive; zmax < zmin: no voxel)
 };
 constexpr int VOL_BX = 64, VOL_BY = 16, VOL_BZ = 16;
 int launch_vol_preprocess(const void *src, int dtype, double off, double scale, int D, int H, int W, const Taps &tz, const Taps &ty,
                           const Taps &tx, double ratio, double *bufA, double *bufB, hipStream_t st);
 int launch_vol_slic(VolState s, const double *vol, int32_t *labels, int max_iter, hipStream_t st);
+// float32 volume: result of the pre-processing is a float32 plane in bufB
+int launch_vol_preprocess_f32(const float *src, int D, int H, int W, const Taps &tz, const Taps &ty, const Taps &tx, double ratio,
+                              double *bufA, double *bufB, hipStream_t st);
+int launch_vol_slic_f32(VolState s, const float *vol, int32_t *labels, int max_iter, hipStream_t st);
 int launch_label_cc(int32_t *labels_inout, int D, int H, int W, int32_t *parent, int32_t *newlabel, int32_t *blocksum,
                     int32_t *total_dev, hipStream_t st);
 int launch_vol_adjacency(const int32_t *labels, int D, int H, int W, int K, int words, uint32_t *bitmap, long long *cacc,

@@ -311,6 +311,318 @@ int launch_vol_slic(VolState s, const double *vol, int32_t *labels, int max_iter
     return 0;
 }
 
+// ---- float32 volumes: scikit-image 0.18 keeps a float32 input in float32 from end to end ---------------------
+// (slic_superpixels.py `dtype = image.dtype` -> `_slic_cython[float32]`; oracle: orc_slic_gray3d_f32).  What that
+// means for the arithmetic, all of it reproduced here:
+//   * the Gaussian filter computes every line in double and stores float32 after every axis pass;
+//   * `image * ratio` is a float32 product;
+//   * centroids, spacing, the distance  ((dz + dy) + dx) * (1/step^2) + (v - cv)^2  and the search windows are float32;
+//   * the centroid update adds the members of a segment in RASTER ORDER into float32 running sums -- not
+//     associative, so no parallel reduction reproduces it.  Here one wave owns one centroid: it walks the
+//     bounding box of the segment's voxels (tracked by the assignment kernel with integer atomics) in raster
+//     order, 64 voxels per load, and folds the member lanes one by one (ballot bits -> v_readlane) into four
+//     float32 accumulators kept in lanes 0..3 (z, y, x, value): the additions happen in exactly the order of the
+//     sequential loop of _slic.pyx.
+template <int AXIS>
+__global__ void __launch_bounds__(256)
+k_vol_blur_r32(const double *__restrict__ src, double *__restrict__ dst, float *__restrict__ dst32, int D, int H, int W, Taps t,
+               float fratio, int last)
+{
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    size_t n = (size_t)D * H * W;
+    if (i >= n) return;
+    int x = (int)(i % W), y = (int)((i / W) % H), z = (int)(i / ((size_t)W * H));
+    double v;
+    if (t.r < 0) {
+        v = src[i];                                       // axis not filtered: the float32 value passes through
+    } else {
+        v = src[i] * t.w[0];
+        for (int j = t.r; j >= 1; --j) {
+            size_t a, b;
+            if (AXIS == 0) {
+                a = ((size_t)vreflect(z - j, D) * H + y) * W + x;
+                b = ((size_t)vreflect(z + j, D) * H + y) * W + x;
+            } else if (AXIS == 1) {
+                a = ((size_t)z * H + vreflect(y - j, H)) * W + x;
+                b = ((size_t)z * H + vreflect(y + j, H)) * W + x;
+            } else {
+                a = ((size_t)z * H + y) * W + vreflect(x - j, W);
+                b = ((size_t)z * H + y) * W + vreflect(x + j, W);
+            }
+            v += (src[a] + src[b]) * t.w[j];
+        }
+    }
+    const float f = (float)v;                             // scipy stores the line in the output dtype (float32)
+    if (last) dst32[i] = f * fratio;                      // numpy: float32 array * Python float
+    else dst[i] = (double)f;
+}
+
+int launch_vol_preprocess_f32(const float *src, int D, int H, int W, const Taps &tz, const Taps &ty, const Taps &tx, double ratio,
+                              double *bufA, double *bufB, hipStream_t st)
+{
+    size_t n = (size_t)D * H * W;
+    int grid = cdiv((long)n, 256);
+    hipLaunchKernelGGL(k_vol_to_f64<float>, grid, 256, 0, st, src, n, 0.0, 1.0, bufA);
+    hipLaunchKernelGGL(k_vol_blur_r32<0>, grid, 256, 0, st, bufA, bufB, (float *)nullptr, D, H, W, tz, 0.f, 0);
+    hipLaunchKernelGGL(k_vol_blur_r32<1>, grid, 256, 0, st, bufB, bufA, (float *)nullptr, D, H, W, ty, 0.f, 0);
+    hipLaunchKernelGGL(k_vol_blur_r32<2>, grid, 256, 0, st, bufA, (double *)nullptr, reinterpret_cast<float *>(bufB), D, H, W, tx,
+                       (float)ratio, 1);
+    HIP_TRY(hipGetLastError());
+    return 0;   // float32 result in bufB
+}
+
+__device__ __forceinline__ void vol_window_f32(const VolState &s, float cz, float cy, float cx, int *w)
+{
+    // _slic.pyx with float32 centroids: <Py_ssize_t>max(cz - 2 * step_z, 0), <Py_ssize_t>min(cz + 2 * step_z + 1, depth)
+    float a;
+    a = cz - (float)(2 * s.step_z); w[0] = (int)(a > 0 ? a : 0.f);
+    a = cz + (float)(2 * s.step_z); a = a + 1.f; w[1] = (int)(a < (float)s.D ? a : (float)s.D);
+    a = cy - (float)(2 * s.step_y); w[2] = (int)(a > 0 ? a : 0.f);
+    a = cy + (float)(2 * s.step_y); a = a + 1.f; w[3] = (int)(a < (float)s.H ? a : (float)s.H);
+    a = cx - (float)(2 * s.step_x); w[4] = (int)(a > 0 ? a : 0.f);
+    a = cx + (float)(2 * s.step_x); a = a + 1.f; w[5] = (int)(a < (float)s.W ? a : (float)s.W);
+}
+
+__device__ __forceinline__ void vol_bbox_reset(int *b)
+{
+    b[0] = b[2] = b[4] = 0x7fffffff;
+    b[1] = b[3] = b[5] = -1;
+}
+
+__global__ void k_vol_centroid_init_f32(VolState s)
+{
+    int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= s.K) return;
+    int ix = k % s.grid_n[2], iy = (k / s.grid_n[2]) % s.grid_n[1], iz = k / (s.grid_n[2] * s.grid_n[1]);
+    float cz = (float)(double)(s.grid_0[0] + iz * s.grid_d[0]);
+    float cy = (float)(double)(s.grid_0[1] + iy * s.grid_d[1]);
+    float cx = (float)(double)(s.grid_0[2] + ix * s.grid_d[2]);
+    s.cen32[(size_t)k * 4 + 0] = cz;
+    s.cen32[(size_t)k * 4 + 1] = cy;
+    s.cen32[(size_t)k * 4 + 2] = cx;
+    s.cen32[(size_t)k * 4 + 3] = 0.f;
+    vol_window_f32(s, cz, cy, cx, s.win + (size_t)k * 6);
+    vol_bbox_reset(s.bbox + (size_t)k * 6);
+}
+
+template <bool TRACK>
+__global__ void __launch_bounds__(256)
+k_vol_assign_f32(VolState s, const float *__restrict__ vol, int32_t *__restrict__ labels)
+{
+    __shared__ int list[4][VLIST];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int rows_per_block = 4 * VROWS;
+    const int yb = cdiv(s.H, rows_per_block);
+    const int z = blockIdx.y / yb;
+    const int y0 = (blockIdx.y % yb) * rows_per_block + wave * VROWS;
+    const int x = blockIdx.x * 64 + lane;
+    const int x0w = blockIdx.x * 64, x1w = min(x0w + 64, s.W);
+    if (y0 >= s.H) return;
+    const int y1w = min(y0 + VROWS, s.H);
+    const bool xin = x < s.W;
+    float pv[VROWS], best_d[VROWS];
+    int best_k[VROWS];
+#pragma unroll
+    for (int r = 0; r < VROWS; ++r) {
+        bool ok = xin && (y0 + r) < s.H;
+        pv[r] = vol[ok ? ((size_t)z * s.H + y0 + r) * s.W + x : 0];
+        best_d[r] = INFINITY;
+        best_k[r] = -1;
+    }
+    const float fz = (float)z, fx = (float)x;
+    const float sz = (float)s.sz, sy = (float)s.sy, sx = (float)s.sx;
+    const float sw = (float)s.spatial_weight;              // = (float)(1 / ((double)step * (double)step))
+    int count = 0;
+    float wave_worst = INFINITY;
+    int since_refresh = 0;
+    const int brick = ((z / VOL_BZ) * s.nby + (y0 / VOL_BY)) * s.nbx + blockIdx.x;
+    const int bcount = s.brick_count[brick];
+    const bool whole = bcount > s.brick_cap;
+    const int *__restrict__ blist = s.brick_list + (size_t)brick * s.brick_cap;
+    const int nscan = whole ? s.K : bcount;
+    const int nblk = cdiv(nscan, 64);
+    for (int b = 0; b < nblk; ++b) {
+        const int i = b * 64 + lane;
+        int k = 0;
+        bool hit = false;
+        if (i < nscan) {
+            k = whole ? i : blist[i];
+            const int *w = s.win + (size_t)k * 6;
+            hit = z >= w[0] && z < w[1] && w[2] < y1w && w[3] > y0 && w[4] < x1w && w[5] > x0w;
+        }
+        unsigned long long m = __ballot(hit);
+        if (hit) list[wave][count + __popcll(m & ((1ULL << lane) - 1ULL))] = k;
+        count += __popcll(m);
+        if (count < VLIST - 64 && b + 1 < nblk) continue;
+        for (int c = 0; c < count; ++c) {
+            const int ck = list[wave][c];
+            const int *w = s.win + (size_t)ck * 6;
+            const float cz = s.cen32[(size_t)ck * 4], cy = s.cen32[(size_t)ck * 4 + 1], cx = s.cen32[(size_t)ck * 4 + 2];
+            const float tz = sz * (cz - fz);
+            const float dz = tz * tz;
+            {
+                // exact pruning as in the fp64 kernel: every float32 operation below is monotone and the colour term >= 0
+                const float yn = fminf(fmaxf(cy, (float)y0), (float)(y1w - 1));
+                const float xn = fminf(fmaxf(cx, (float)x0w), (float)(x1w - 1));
+                const float tyl = sy * (cy - yn), txl = sx * (cx - xn);
+                const float lb = ((dz + tyl * tyl) + txl * txl) * sw;
+                if (lb > wave_worst) continue;                 // wave-uniform
+            }
+            const float cv = s.cen32[(size_t)ck * 4 + 3];
+            const int wy0 = w[2], wy1 = w[3];
+            const bool inx = x >= w[4] && x < w[5];
+            const float tx = sx * (cx - fx);
+            const float dx2 = tx * tx;
+#pragma unroll
+            for (int r = 0; r < VROWS; ++r) {
+                const int y = y0 + r;
+                if (y < wy0 || y >= wy1) continue;
+                const float ty = sy * (cy - (float)y);
+                const float dy = ty * ty;
+                float d = ((dz + dy) + dx2) * sw;
+                const float t = pv[r] - cv;
+                d = d + t * t;
+                if (inx && (best_d[r] > d || (best_d[r] == d && ck < best_k[r]))) {
+                    best_d[r] = d;
+                    best_k[r] = ck;
+                }
+            }
+            if (++since_refresh == 8) {
+                since_refresh = 0;
+                float m2 = 0.f;
+#pragma unroll
+                for (int r = 0; r < VROWS; ++r)
+                    if (xin && (y0 + r) < s.H) m2 = fmaxf(m2, best_d[r]);
+                wave_worst = (float)wave_max_f64((double)m2);
+            }
+        }
+        count = 0;
+    }
+    unsigned pending = 0;
+#pragma unroll
+    for (int r = 0; r < VROWS; ++r) {
+        if (!(xin && (y0 + r) < s.H)) continue;
+        size_t p = ((size_t)z * s.H + y0 + r) * s.W + x;
+        if (best_k[r] >= 0) labels[p] = best_k[r];
+        else best_k[r] = labels[p];                           // uncovered voxel keeps its previous assignment
+        if (best_k[r] >= 0) pending |= 1u << r;
+    }
+    if (!TRACK) return;
+    // bounding box of every segment's voxels (incl. the ones that kept an old label): the region the
+    // order-preserving update of that centroid has to walk
+    while (true) {
+        int first = -1;
+#pragma unroll
+        for (int r = VROWS - 1; r >= 0; --r)
+            if (pending & (1u << r)) first = best_k[r];
+        unsigned long long vote = __ballot(first >= 0);
+        if (!vote) break;
+        const int k = __shfl(first, __ffsll((long long)vote) - 1, 64);
+        int ylo = 0x7fffffff, yhi = -1;
+        bool any = false;
+#pragma unroll
+        for (int r = 0; r < VROWS; ++r) {
+            if ((pending & (1u << r)) && best_k[r] == k) {
+                ylo = min(ylo, y0 + r);
+                yhi = max(yhi, y0 + r);
+                any = true;
+                pending &= ~(1u << r);
+            }
+        }
+        int xlo = any ? x : 0x7fffffff, xhi = any ? x : -1;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            ylo = min(ylo, __shfl_xor(ylo, off, 64));
+            yhi = max(yhi, __shfl_xor(yhi, off, 64));
+            xlo = min(xlo, __shfl_xor(xlo, off, 64));
+            xhi = max(xhi, __shfl_xor(xhi, off, 64));
+        }
+        if (lane == 0) {
+            int *b = s.bbox + (size_t)k * 6;
+            if (b[0] > z) atomicMin(&b[0], z);
+            if (b[1] < z) atomicMax(&b[1], z);
+            if (b[2] > ylo) atomicMin(&b[2], ylo);
+            if (b[3] < yhi) atomicMax(&b[3], yhi);
+            if (b[4] > xlo) atomicMin(&b[4], xlo);
+            if (b[5] < xhi) atomicMax(&b[5], xhi);
+        }
+    }
+}
+
+// one wave per centroid: raster-order float32 running sums over the segment's bounding box, then the division,
+// the new search window and the reset of the box (oracle orc_slic_gray3d_f32, the loop after `if (!change) break`)
+__global__ void __launch_bounds__(256)
+k_vol_update_f32(VolState s, const float *__restrict__ vol, const int32_t *__restrict__ labels)
+{
+    const int lane = threadIdx.x & 63;
+    const int k = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (k >= s.K) return;
+    int *bb = s.bbox + (size_t)k * 6;
+    int *w = s.win + (size_t)k * 6;
+    const int z0 = bb[0], z1 = bb[1], y0 = bb[2], y1 = bb[3], x0 = bb[4], x1 = bb[5];
+    if (z1 < z0) {                                            // no voxel carries this label: the centroid is dead
+        if (lane < 6) w[lane] = 0;
+        return;
+    }
+    float acc = 0.f;                                          // lanes 0..3: running sums of z, y, x, value
+    int cnt = 0;
+    const int nx = x1 - x0 + 1;
+    for (int z = z0; z <= z1; ++z) {
+        const float fz = (float)z;
+        for (int y = y0; y <= y1; ++y) {
+            const float fy = (float)y;
+            const size_t row = ((size_t)z * s.H + y) * s.W;
+            for (int xb = 0; xb < nx; xb += 64) {
+                const int x = x0 + xb + lane;
+                const bool in = x <= x1;
+                const bool mine = in && labels[row + x] == k;
+                unsigned long long m = __ballot(mine);
+                if (!m) continue;
+                const float v = mine ? vol[row + x] : 0.f;
+                cnt += __popcll(m);
+                const float sel_zy = lane == 0 ? fz : fy;
+                while (m) {
+                    const int b = __ffsll((long long)m) - 1;
+                    m &= m - 1;
+                    const float vb = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), b));
+                    const float fxv = (float)(x0 + xb + b);
+                    const float op = lane < 2 ? sel_zy : (lane == 2 ? fxv : vb);
+                    acc = acc + op;
+                }
+            }
+        }
+    }
+    const float q = acc / (float)cnt;                         // seg[c] / (float)cnt   (cnt > 0 here)
+    const float cz = __shfl(q, 0, 64), cy = __shfl(q, 1, 64), cx = __shfl(q, 2, 64);
+    if (lane < 4) s.cen32[(size_t)k * 4 + lane] = q;
+    if (lane == 0) {
+        vol_window_f32(s, cz, cy, cx, w);
+        vol_bbox_reset(bb);
+    }
+}
+
+int launch_vol_slic_f32(VolState s, const float *vol, int32_t *labels, int max_iter, hipStream_t st)
+{
+    size_t n = (size_t)s.D * s.H * s.W;
+    HIP_TRY(hipMemsetAsync(labels, 0xff, n * sizeof(int32_t), st));
+    hipLaunchKernelGGL(k_vol_centroid_init_f32, cdiv(s.K, 256), 256, 0, st, s);
+    dim3 grid(cdiv(s.W, 64), cdiv(s.H, 4 * VROWS) * s.D);
+    const size_t n_bricks = (size_t)s.nbz * s.nby * s.nbx;
+    for (int it = 0; it < max_iter; ++it) {
+        HIP_TRY(hipMemsetAsync(s.brick_count, 0, n_bricks * sizeof(int), st));
+        hipLaunchKernelGGL(k_vol_scatter, cdiv(s.K, 256), 256, 0, st, s);
+        if (it + 1 < max_iter) {
+            hipLaunchKernelGGL(k_vol_assign_f32<true>, grid, 256, 0, st, s, vol, labels);
+            hipLaunchKernelGGL(k_vol_update_f32, cdiv(s.K, 4), 256, 0, st, s, vol, labels);
+        } else {
+            hipLaunchKernelGGL(k_vol_assign_f32<false>, grid, 256, 0, st, s, vol, labels);
+        }
+    }
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
 // ---- skimage.measure.label: full (26-/8-) connectivity, value 0 = background ------------------------------
 __device__ __forceinline__ int cc_find(const int32_t *parent, int a)
 {

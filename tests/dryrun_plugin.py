@@ -83,8 +83,12 @@ class Volume3D(Image2D):
         volume = np.asarray(volume); assert volume.shape == self.shape; self.img = volume; return self
     def slic(self, n_segments, compactness, sigma=1., spacing=(1., 1., 1.), max_iter=10, enforce_connectivity=True,
              min_size_factor=0.5, max_size_factor=3., start_label=0):
-        lab = orc.slic(self.img, n_segments, compactness, sigma=sigma, spacing=spacing, multichannel=False, max_iter=max_iter,
-                       enforce_connectivity=enforce_connectivity, start_label=start_label)
+        if self.img.dtype == np.float32:
+            lab = orc.slic_gray3d_float32(self.img, n_segments, compactness, sigma=sigma, spacing=spacing, max_iter=max_iter,
+                                          enforce_connectivity=enforce_connectivity, start_label=start_label)
+        else:
+            lab = orc.slic(self.img, n_segments, compactness, sigma=sigma, spacing=spacing, multichannel=False, max_iter=max_iter,
+                           enforce_connectivity=enforce_connectivity, start_label=start_label)
         self.labels = np.asarray(lab, dtype=np.int32); self.n_labels = int(self.labels.max()) + 1; return self.n_labels
     def label_cc(self):
         self.labels = orc.label_cc(self.labels).astype(np.int32); self.n_labels = int(self.labels.max()) + 1; return self.n_labels

@@ -41,10 +41,12 @@ CASES_3D = {
 }
 
 
-#: float32 volumes: scikit-image 0.18 runs them in float32 from end to end (the oracle has that variant, the HIP path not yet)
+#: float32 volumes: scikit-image 0.18 runs them in float32 from end to end (oracle: slic_gray3d_float32; HIP: float32 section of csrc/volume.hip)
 CASES_3D_F32 = {
     'vol_f32': ('ellipsoid_volume((12, 40, 48))', 8, 0.2, (1, 1, 1)),
     'vol_f32_aniso': ('ellipsoid_volume((8, 44, 40), seed=6)', 9, 0.3, (3, 1, 1)),
+    # several bricks of 64 x 16 x 16 voxels per axis, x not a multiple of the wave width
+    'vol_f32_large': ('ellipsoid_volume((24, 70, 150), seed=9)', 9, 0.25, (2, 1, 1)),
 }
 
 

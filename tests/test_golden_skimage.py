@@ -68,8 +68,7 @@ def test_colour_conversions_equal_scikit_image(space):
 @pytest.mark.parametrize('name', sorted(GEN.CASES_3D_F32))
 def test_oracle_float32_volume_equals_scikit_image(oracle, name):
     """scikit-image 0.18 runs a float32 volume in float32 (filter output, products, distances, raster-order running sums):
-    the oracle's float32 variant reproduces it bit for bit.  (The HIP path widens float32 volumes to float64 -- a
-    documented deviation, DESIGN.md section 5 -- so there is no GPU counterpart of this test yet.)"""
+    the oracle's float32 variant reproduces it bit for bit (GPU counterpart: tests/test_gpu_zz_skimage.py)."""
     from pyimsegm_amd.superpixels import _slic3d_params
     expr, sp, rc, space = GEN.CASES_3D_F32[name]
     vol = make_input(name, expr)
@@ -78,5 +77,4 @@ def test_oracle_float32_volume_equals_scikit_image(oracle, name):
     raw = oracle.slic_gray3d_float32(vol, n_seg, compact, sigma=1., spacing=space)
     assert np.array_equal(raw, VEC[name + '_slic'])
     assert np.array_equal(oracle.label_cc(raw), VEC[name + '_label'])
-    widened = oracle.segment_slic_img3d_gray(vol, sp, rc, space)           # what the HIP path computes today
-    assert widened.shape == raw.shape and widened.max() > 0
+    assert np.array_equal(oracle.segment_slic_img3d_gray(vol, sp, rc, space), VEC[name + '_label'])

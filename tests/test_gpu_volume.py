@@ -28,8 +28,19 @@ def _noisy_ellipsoid(shape, seed=0, dtype=np.float64):
     return vol.astype(dtype)
 
 
+def _oracle_raw(oracle, vol, n_seg, compact, space, **kw):
+    """SLIC + connectivity as scikit-image 0.18 evaluates it for the dtype: float32 volumes run in float32"""
+    if vol.dtype == np.float32:
+        return oracle.slic_gray3d_float32(vol, n_seg, compact, sigma=1., spacing=space, **kw)
+    return oracle.slic(vol, n_seg, compact, sigma=1, spacing=space, multichannel=False, **kw)
+
+
 VOLUMES = [
     ('iso_f64', (24, 40, 48), np.float64, 7, 0.2, (1, 1, 1)),
+    ('iso_f32', (24, 40, 48), np.float32, 7, 0.2, (1, 1, 1)),
+    ('aniso_z_f32', (9, 64, 70), np.float32, 12, 0.2, (5, 1, 1)),
+    ('bricks_f32', (35, 50, 200), np.float32, 8, 0.1, (2, 1, 1)),
+    ('one_slice_f32', (1, 50, 60), np.float32, 8, 0.2, (1, 1, 1)),
     ('aniso_z_f64', (9, 64, 70), np.float64, 12, 0.2, (5, 1, 1)),
     ('aniso_x_u8', (50, 60, 11), np.uint8, 10, 0.3, (1, 1, 5)),
     ('ragged_u16', (7, 33, 129), np.uint16, 9, 0.25, (3, 1, 1)),
@@ -42,7 +53,7 @@ def test_volume_slic_bit_exact(hip, oracle, name, shape, dtype, sp, regul, space
     from pyimsegm_amd.superpixels import _slic3d_params
     vol = _noisy_ellipsoid(shape, dtype=dtype)
     n_seg, compact = _slic3d_params(shape, sp, regul, space)
-    ref_raw = oracle.slic(vol, n_seg, compact, sigma=1, spacing=space, multichannel=False)
+    ref_raw = _oracle_raw(oracle, vol, n_seg, compact, space)
     sess = hip.Volume3D(*shape).upload(vol)
     sess.slic(n_seg, compact, sigma=1., spacing=space)
     raw = sess.get_labels()
@@ -65,14 +76,29 @@ def test_volume_slic_without_connectivity(hip, oracle):
     sess.close()
 
 
-def test_volume_slic_brick_list_overflow(hip, oracle, monkeypatch):
+@pytest.mark.parametrize('dtype', [np.float64, np.float32])
+def test_volume_slic_brick_list_overflow(hip, oracle, monkeypatch, dtype):
     """bricks whose candidate list overflows scan the whole centroid table: same result"""
-    vol = _noisy_ellipsoid((20, 48, 70), seed=7)
-    ref = oracle.slic(vol, 300, 2, sigma=1, spacing=(1, 1, 1), multichannel=False)
+    vol = _noisy_ellipsoid((20, 48, 70), seed=7, dtype=dtype)
+    ref = _oracle_raw(oracle, vol, 300, 2, (1, 1, 1))
     monkeypatch.setenv('IMSEGM_BRICK_CAP', '3')
     sess = hip.Volume3D(*vol.shape).upload(vol)
     sess.slic(300, 2, sigma=1., spacing=(1, 1, 1))
     assert np.array_equal(sess.get_labels(), ref)
+    sess.close()
+
+
+def test_float32_volume_without_connectivity_and_session_reuse(hip, oracle):
+    """raw float32 k-means assignment (no connectivity pass), then a float64 volume through the same session"""
+    vol = _noisy_ellipsoid((12, 40, 44), seed=4, dtype=np.float32)
+    ref = _oracle_raw(oracle, vol, 150, 3, (2, 1, 1), enforce_connectivity=False)
+    sess = hip.Volume3D(*vol.shape).upload(vol)
+    sess.slic(150, 3, sigma=1., spacing=(2, 1, 1), enforce_connectivity=False)
+    assert np.array_equal(sess.get_labels(), ref)
+    vol64 = _noisy_ellipsoid((12, 40, 44), seed=5)
+    sess.upload(vol64)
+    sess.slic(150, 3, sigma=1., spacing=(2, 1, 1))
+    assert np.array_equal(sess.get_labels(), _oracle_raw(oracle, vol64, 150, 3, (2, 1, 1)))
     sess.close()
 
 
@@ -211,7 +237,7 @@ def test_volume_slic_randomised_sweep(hip, oracle):
     space-dominated): raw SLIC + connectivity and the measure.label relabelling, bit for bit"""
     from pyimsegm_amd.superpixels import _slic3d_params
     rng = np.random.default_rng(77)
-    for case in range(8):
+    for case in range(12):
         shape = (int(rng.integers(1, 20)), int(rng.integers(20, 70)), int(rng.integers(20, 90)))
         dtype = [np.float64, np.uint8, np.float32, np.uint16][case % 4]
         vol = _noisy_ellipsoid(shape, seed=int(rng.integers(1000)), dtype=np.float64 if dtype == np.float32 else dtype)
@@ -223,7 +249,7 @@ def test_volume_slic_randomised_sweep(hip, oracle):
         n_seg, compact = _slic3d_params(shape, sp, regul, space)
         if n_seg < 1 or compact < 1:
             continue
-        ref_raw = oracle.slic(vol, n_seg, compact, sigma=1, spacing=space, multichannel=False)
+        ref_raw = _oracle_raw(oracle, vol, n_seg, compact, space)
         sess = hip.Volume3D(*shape).upload(vol)
         sess.slic(n_seg, compact, sigma=1., spacing=space)
         raw = sess.get_labels()

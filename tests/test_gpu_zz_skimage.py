@@ -28,3 +28,22 @@ def test_hip_slic3d_equals_scikit_image(name):
     expr, sp, rc, space = GEN.CASES_3D[name]
     vol = make_input(name, expr)
     assert np.array_equal(sp_mod.segment_slic_img3d_gray(vol, sp, rc, space), VEC[name + '_label'])
+
+
+@pytest.mark.parametrize('name', sorted(GEN.CASES_3D_F32))
+def test_hip_float32_volume_equals_scikit_image(name):
+    """a float32 volume stays float32 on the device as inside scikit-image 0.18: float32 filter output, distances and the
+    raster-order float32 running sums of the centroid update (one wave per centroid, csrc/volume.hip)"""
+    from pyimsegm_amd import _hip
+    from pyimsegm_amd import superpixels as sp_mod
+    expr, sp, rc, space = GEN.CASES_3D_F32[name]
+    vol = make_input(name, expr)
+    assert vol.dtype == np.float32
+    # raw SLIC (before measure.label) and the relabelled map of superpixels.py:111
+    n_seg, compact = sp_mod._slic3d_params(vol.shape, sp, rc, space)
+    sess = _hip.Volume3D(*vol.shape).upload(vol)
+    sess.slic(n_seg, compact, sigma=1., spacing=space, start_label=0)
+    raw = sess.get_labels()
+    sess.close()
+    assert np.array_equal(raw, VEC[name + '_slic'])
+    assert np.array_equal(sp_mod.segment_slic_img3d_gray(vol, sp, rc, space), VEC[name + '_label'])
