@@ -1,23 +1,36 @@
 #!/usr/bin/env python
 """bench.py -- headline benchmark of the SLIC -> descriptors -> GraphCut hot path on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--inflight M]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config 2|3|4|5] [--inflight M]
 
-Workload (BASELINE.json configs[1]): one synthetic 2048 x 2048 RGB uint8 image per GPU, SLIC
-(sp_size 46 -> n_segments 1982, K = 2025 grid centroids) + colour mean/std/energy descriptors +
-3-class alpha-expansion GraphCut (gc_regul 2.0, edge type 'model') with a class model fitted once
-during warm-up (the reference's `segment_color2d_slic_features_model_graphcut`,
-imsegm/pipelines.py:160).  One step = one pass of that function over the resident image: the
-input image is already in HBM when the timed region starts and the outputs (segm H x W int32,
-segm_soft H x W x 3 float64) stay in HBM; the scikit-learn `predict_proba` and the numpy edge-weight
-formulas of the reference run on the host inside the timed region, as do the K x F / E / K x C
-transfers between the stages.  The K timed steps are taken by M worker threads per process (default: by K, 6 from 40 steps), each
-with its own HIP stream and resident copy of the image, so that the host stages of one step overlap the
-kernels of another -- the reference maps a pool of worker processes over the images.  The `roofline` and
-`stage_ms_per_step` figures come from a second, un-overlapped pass on one stream (the assignment kernel is
-timed by a HIP event pair attached to its dispatch).  N > 1: one process per GPU (torch.distributed / RCCL),
-every rank segments its own image (weak scaling, no data-path collective) and every label map is gathered
-on rank 0 with one RCCL gather per step, zero copy from HBM.
+What one STEP is ("image resident in host numpy" -> "`segm` resident in host numpy"):
+
+  config 2 (default, BASELINE configs[1], the configuration the metric is quoted on)
+      one synthetic 2048 x 2048 RGB uint8 image per GPU through `segment_color2d_slic_features_model_graphcut`
+      (imsegm/pipelines.py:160): H2D of the image, SLIC (sp_size 46 -> K = 2025 centroids, 10 sweeps, connectivity),
+      colour mean / std / energy, the pre-fitted 3-class mixture (evaluated on the device), unary / edge terms,
+      alpha-expansion (gc_regul 2.0, edge type 'model'), `classes_[graph_labels][slic]`, D2H of `segm` (int32).
+      The class model is fitted once during warm-up (the reference's group-model flow, run_segm...:476-514).
+  config 3  same image, `{'tLM': ('mean', 'std', 'energy')}` (Leung-Malik bank, F = 180): `--config 3`
+  config 4  a batch of 8 images of 647 x 1024 RGB uint8 per GPU (BASELINE: 64 images over 8 GPUs) through
+            `segment_batch_color2d_slic_features_model_graphcut`: `--config 4`
+  config 5  one 64 x 4096 x 4096 float32 volume through `pipe_gray3d_slic_features_model_graphcut` (model fit
+            included, as the reference function does): `--config 5`
+
+`value` = pixels (voxels) of all timed steps of all ranks / wall time, host to host.  M images are kept in flight per
+GPU (worker threads with one HIP stream and one recycled session each; a thread spends a step inside a handful of C
+calls, outside the interpreter lock) -- the reference maps a pool of worker processes over the images.  Timing is
+taken in STEADY STATE: W + K + M steps are issued back to back between two barriers + device synchronisations, and
+the clock runs from the completion of step W to the completion of step W + K, so exactly K steps are timed and the
+figure does not depend on the fill and drain of the pipeline (`ms_per_step_incl_fill_drain` is reported next to it).
+Separate keys carry the device-resident rate of the same pipeline (image already in HBM, result left in HBM:
+`device_resident`), the extra cost of fetching `segm_soft` (`soft_d2h_ms`), and a single image end to end with
+nothing else in flight (`latency_ms`).
+
+`roofline` and `stage_ms_per_step` come from a separate, un-overlapped pass on one stream (the dominant kernel is timed
+by a HIP event pair attached to its dispatch).  N > 1: one process per GPU (ranks from the launcher's environment),
+every rank segments its own image(s) (weak scaling, no data-path collective) and the label maps of every round of
+M steps are gathered in rank 0's HBM with one grouped RCCL send / recv (pyimsegm_amd.distributed, ctypes on librccl).
 
 Prints ONE JSON line on rank 0.
 """
@@ -25,6 +38,7 @@ import argparse
 import json
 import os
 import sys
+import threading
 import time
 
 import numpy as np
@@ -35,44 +49,28 @@ sys.path.insert(0, ROOT)
 SP_SIZE, SP_REGUL, NB_CLASSES, GC_REGUL, EDGE_TYPE = 46, 0.2, 3, 2.0, 'model'
 HEIGHT = WIDTH = 2048
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s
+FP64_VALU_PEAK_TFLOPS = 78.6   # MI355X_MICROARCH.md: fp64 vector (non-MFMA) peak
 ASSIGN_BYTES_PER_PX = 28.0     # read fp64 Lab 3 x 8 B + write int32 label 4 B per pixel per sweep
+VOL_ASSIGN_BYTES_PER_VOXEL = 8.0   # float32 volume: read 4 B + write int32 label 4 B per voxel per sweep
 
 
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=100)
-    ap.add_argument('--warmup', type=int, default=3)
-    ap.add_argument('--size', type=int, default=HEIGHT, help='image edge (default: the BASELINE 2048)')
+    ap.add_argument('--steps', type=int, default=None)
+    ap.add_argument('--warmup', type=int, default=None)
+    ap.add_argument('--config', type=int, default=2, choices=(2, 3, 4, 5))
+    ap.add_argument('--size', type=int, default=None, help='image edge of configs 2 / 3 (default: the BASELINE 2048)')
+    ap.add_argument('--volume', type=str, default='64,4096,4096', help='D,H,W of config 5')
+    ap.add_argument('--inflight', type=int, default=0, help='images in flight per GPU (worker threads); 0 = default of the config')
+    ap.add_argument('--pinned-input', type=int, default=0, help='1: the input images live in page-locked host memory')
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--switch-interval', type=float, default=None, help='sys.setswitchinterval for the worker threads')
-    ap.add_argument('--host-pool', type=int, default=1,
-                    help='1: the numpy stages (class model, graph-cut terms) of the images in flight run in helper '
-                         'processes (pyimsegm_amd.hostpool), 0: in the worker threads themselves')
-    ap.add_argument('--inflight', type=int, default=0,
-                    help='images in flight per GPU (worker threads, one HIP stream each; the reference runs a '
-                         'pool of nb_workers processes over the images); 0 = by the number of timed steps: a deep '
-                         'pipeline only pays off when its fill and drain are amortised (6 from 40 steps, else 4 or fewer)')
     return ap.parse_args()
 
 
-def cpu_baseline(image, model, passes=5):
-    """the CPU oracle (port of the reference path) timed on one host core: `passes` full images (about 12 s),
-    median pass reported (warm-up free C code, median of 5)"""
-    runs = [_cpu_baseline_pass(image, model) for _ in range(max(1, passes))]
-    runs.sort(key=lambda r: r[0])
-    total, parts, segm, soft = runs[len(runs) // 2]
-    return {
-        'value': round(image.shape[0] * image.shape[1] / total / 1e6, 4),
-        'unit': 'Mpixels/s',
-        'cores': 1,
-        'kind': 'port',
-        'sample': '%d passes over one full %dx%d image (%.1f s of CPU), median pass: oracle C SLIC %.2fs + descriptors '
-                  '%.2fs + graph/weights %.2fs + GC %.3fs + gathers %.2fs'
-                  % ((len(runs), image.shape[0], image.shape[1], sum(r[0] for r in runs)) + parts),
-    }, segm, soft
-
-
+# -----------------------------------------------------------------------------------------------------------------
+# CPU baseline (rank 0, N = 1): the reference's own legs where they exist on the box, the oracle port for the rest
+# -----------------------------------------------------------------------------------------------------------------
 _SKIMAGE_SCRIPT = r'''
 import sys, time, warnings
 warnings.filterwarnings("ignore")
@@ -93,10 +91,10 @@ print("%s %.4f" % (skimage.__version__, t1 - t0))
 '''
 
 
-def real_skimage_slic(image):
+def real_skimage_slic(image, sp_size, sp_regul):
     """the REAL `skimage.segmentation.slic` behind imsegm/superpixels.py:61-63, when the box carries the image's conda
     Python 3.9 with scikit-image (the interpreter of this script cannot import it): (version, seconds of the slic
-    call on one host core, label map), or None.  Reported next to the oracle's own time; never part of `value`."""
+    call on one host core, label map), or None"""
     import subprocess
     import tempfile
     py = os.environ.get('IMSEGM_SKIMAGE_PYTHON', '/opt/conda/bin/python3.9')
@@ -106,8 +104,8 @@ def real_skimage_slic(image):
         with tempfile.TemporaryDirectory() as tmp:
             src, dst = os.path.join(tmp, 'image.npy'), os.path.join(tmp, 'labels.npy')
             np.save(src, image)
-            run = subprocess.run([py, '-c', _SKIMAGE_SCRIPT, src, dst, str(SP_SIZE), str(SP_REGUL)], capture_output=True,
-                                 text=True, timeout=300)
+            run = subprocess.run([py, '-c', _SKIMAGE_SCRIPT, src, dst, str(sp_size), str(sp_regul)], capture_output=True,
+                                 text=True, timeout=600)
             if run.returncode != 0:
                 return None
             version, seconds = run.stdout.split()[-2:]
@@ -116,54 +114,35 @@ def real_skimage_slic(image):
         return None
 
 
-def compare_with_reference_run(image, sess, mode, pipe, predict_proba):
-    """one extra, untimed GPU pass with the class model of the reference's own run on the benchmark image
-    (tests/golden/reference_2048.npz: real scikit-image 0.18.3 + the reference's Cython descriptors + its scikit-learn
-    GMM, gco bridged to the oracle; label maps stored as CRC32): the superpixel map and the final segmentation of the
-    GPU must have the same checksums"""
-    import zlib
-    from sklearn.mixture import GaussianMixture
-    from sklearn.pipeline import Pipeline
-    from sklearn.preprocessing import StandardScaler
-    path = os.path.join(ROOT, 'tests', 'golden', 'reference_2048.npz')
-    if not os.path.exists(path):
-        return None
-    ref = np.load(path, allow_pickle=False)
-    if zlib.crc32(np.ascontiguousarray(image).tobytes()) != int(ref['image_crc']):
-        return None
-    scaler = StandardScaler()
-    scaler.mean_, scaler.scale_ = ref['scaler_mean'], ref['scaler_scale']
-    scaler.var_, scaler.n_features_in_ = scaler.scale_**2, len(scaler.mean_)
-    gmm = GaussianMixture(n_components=len(ref['gmm_weights']), covariance_type='full')
-    gmm.weights_, gmm.means_ = ref['gmm_weights'], ref['gmm_means']
-    gmm.covariances_, gmm.precisions_cholesky_ = ref['gmm_covariances'], ref['gmm_precisions_cholesky']
-    gmm.precisions_ = np.array([pc @ pc.T for pc in gmm.precisions_cholesky_])
-    gmm.converged_, gmm.n_features_in_ = True, scaler.n_features_in_
-    model = Pipeline([('scaler', scaler), ('GMM', gmm)])
-    from pyimsegm_amd.descriptors import FEATURES_SET_COLOR
-    res = pipe._ResidentImage(image, FEATURES_SET_COLOR, SP_SIZE, SP_REGUL, session=(sess, mode))
-    segm, _ = res.segment(predict_proba(model, res.features), GC_REGUL, EDGE_TYPE, to_host=True)
-    slic_ok = zlib.crc32(np.ascontiguousarray(res.slic, dtype=np.int32).tobytes()) == int(ref['slic_crc'])
-    segm_ok = zlib.crc32(np.ascontiguousarray(segm, dtype=np.int32).tobytes()) == int(ref['segm_crc'])
-    return {'gpu_equals_reference_run': bool(slic_ok and segm_ok),
-            'reference_run': 'tests/golden/reference_2048.npz: the reference itself on this image (%s), superpixel map %s, '
-                             'segmentation %s' % (str(ref['versions']), 'equal' if slic_ok else 'DIFFERENT',
-                                                  'equal' if segm_ok else 'DIFFERENT')}
-
-
-def _cpu_baseline_pass(image, model):
+def cpu_baseline_color2d(image, model, sp_size, sp_regul):
+    """one full image through the CPU path on ONE host core (the reference is single-threaded per image):
+    SLIC = the real scikit-image when the box has it (else the oracle's C restatement), descriptors = the reference's own
+    features_cython.pyx compiled into oracle/_ref (else the oracle's C restatement), graph / edge weights / GraphCut /
+    gathers = the oracle port (gco exists nowhere).  Returns (entry for the JSON line, segmentation of the port chain,
+    label map of the real scikit-image or None)."""
     from oracle import oracle as orc
     from pyimsegm_amd import graph_cuts as gc
     orc.lib()
+    parts = {}
     t0 = time.perf_counter()
-    slic = orc.segment_slic_img2d(image, SP_SIZE, SP_REGUL)
-    t1 = time.perf_counter()
+    slic = orc.segment_slic_img2d(image, sp_size, sp_regul)
+    parts['slic_port_s'] = time.perf_counter() - t0
+    real = real_skimage_slic(image, sp_size, sp_regul)
     img32 = np.asarray(image, dtype=np.float32)
     seg32 = slic.astype(np.int32)
+    ref = orc.ref_features_cython()
+    t1 = time.perf_counter()
+    if ref is not None:        # descriptors.py:209-296: the reference's Cython functions on float32 image / int32 labels
+        mean = np.array(ref.computeColorImage2dMean(img32, seg32))
+        std = np.sqrt(np.array(ref.computeColorImage2dVariance(img32, seg32, np.array(mean, dtype=np.float32))))
+        energy = np.array(ref.computeColorImage2dEnergy(img32, seg32))
+        parts['descriptors_reference_s'] = time.perf_counter() - t1
+    t1 = time.perf_counter()
     mean = orc.color2d_mean(img32, seg32)
     std = np.sqrt(orc.color2d_variance(img32, seg32, mean.astype(np.float32)))
     energy = orc.color2d_energy(img32, seg32)
     features = np.nan_to_num(np.hstack([mean, std, energy]))
+    parts['descriptors_port_s'] = time.perf_counter() - t1
     t2 = time.perf_counter()
     proba = model.predict_proba(features)
     _, edges = orc.adjacency(seg32)
@@ -174,236 +153,469 @@ def _cpu_baseline_pass(image, model):
     weights = np.clip(weights, 1e-3, 1e3)
     unary = gc.compute_unary_cost(proba)
     pairwise = gc.compute_pairwise_cost(GC_REGUL, proba.shape)
+    parts['graph_terms_port_s'] = time.perf_counter() - t2
     t3 = time.perf_counter()
     labels = orc.cut_general_graph(edges, weights, unary, pairwise, n_iter=-1)
+    parts['graphcut_port_s'] = time.perf_counter() - t3
     t4 = time.perf_counter()
     segm = labels[slic]
-    soft = proba[slic]
-    t5 = time.perf_counter()
-    return t5 - t0, (t1 - t0, t2 - t1, t3 - t2, t4 - t3, t5 - t4), segm, soft
+    _ = proba[slic]
+    parts['gathers_s'] = time.perf_counter() - t4
+    slic_s = real[1] if real is not None else parts['slic_port_s']
+    desc_s = parts.get('descriptors_reference_s', parts['descriptors_port_s'])
+    total = slic_s + desc_s + parts['graph_terms_port_s'] + parts['graphcut_port_s'] + parts['gathers_s']
+    kind = 'reference+port' if (real is not None or ref is not None) else 'port'
+    entry = {
+        'value': round(image.shape[0] * image.shape[1] / total / 1e6, 4),
+        'unit': 'Mpixels/s',
+        'cores': 1,
+        'kind': kind,
+        'sample': 'one full %dx%d image, %.1f s of CPU on one core: SLIC %.2f s (%s), descriptors %.3f s (%s), graph + edge '
+                  'weights %.2f s (port), GraphCut %.3f s (port; gco exists nowhere), gathers %.2f s'
+                  % (image.shape[0], image.shape[1], total, slic_s,
+                     'real scikit-image %s' % real[0] if real is not None else 'oracle C restatement', desc_s,
+                     "the reference's features_cython.pyx (oracle/_ref)" if ref is not None else 'oracle C restatement',
+                     parts['graph_terms_port_s'], parts['graphcut_port_s'], parts['gathers_s']),
+        'legs_s': {k: round(v, 4) for k, v in parts.items()},
+    }
+    if real is not None:
+        entry['reference_slic'] = {'scikit_image': real[0], 'seconds': round(real[1], 3), 'cores': 1}
+    try:     # the reference ITSELF, whole pipeline, timed in the build container (tools/time_reference.py)
+        with open(os.path.join(ROOT, 'profiles', 'reference_time_r02.json')) as fp:
+            entry['reference_whole_pipeline_build_container'] = json.load(fp)
+    except Exception:
+        pass
+    return entry, segm, (real[2] if real is not None else None)
+
+
+def load_reference_model():
+    """class model of the reference's own run on the benchmark image (tests/golden/reference_2048.npz)"""
+    from sklearn.mixture import GaussianMixture
+    from sklearn.pipeline import Pipeline
+    from sklearn.preprocessing import StandardScaler
+    path = os.path.join(ROOT, 'tests', 'golden', 'reference_2048.npz')
+    if not os.path.exists(path):
+        return None, None
+    ref = np.load(path, allow_pickle=False)
+    scaler = StandardScaler()
+    scaler.mean_, scaler.scale_ = ref['scaler_mean'], ref['scaler_scale']
+    scaler.var_, scaler.n_features_in_ = scaler.scale_**2, len(scaler.mean_)
+    gmm = GaussianMixture(n_components=len(ref['gmm_weights']), covariance_type='full')
+    gmm.weights_, gmm.means_ = ref['gmm_weights'], ref['gmm_means']
+    gmm.covariances_, gmm.precisions_cholesky_ = ref['gmm_covariances'], ref['gmm_precisions_cholesky']
+    gmm.precisions_ = np.array([pc @ pc.T for pc in gmm.precisions_cholesky_])
+    gmm.converged_, gmm.n_features_in_ = True, scaler.n_features_in_
+    return Pipeline([('scaler', scaler), ('GMM', gmm)]), ref
+
+
+def compare_with_reference_run(image, pipe):
+    """one extra, untimed GPU pass with the class model of the reference's own run on the benchmark image (real
+    scikit-image 0.18.3 + the reference's Cython descriptors + its scikit-learn GMM, gco bridged to the oracle; label maps
+    stored as CRC32): the superpixel map and the final segmentation of the GPU must have the same checksums"""
+    import zlib
+    model, ref = load_reference_model()
+    if model is None or zlib.crc32(np.ascontiguousarray(image).tobytes()) != int(ref['image_crc']):
+        return None
+    from pyimsegm_amd.descriptors import FEATURES_SET_COLOR
+    res = pipe._ResidentImage(image, FEATURES_SET_COLOR, SP_SIZE, SP_REGUL)
+    try:
+        segm, _ = res.segment(None, GC_REGUL, EDGE_TYPE, to_host=True, want_soft=False, model=model)
+        slic = res.slic
+    finally:
+        res.close()
+    slic_ok = zlib.crc32(np.ascontiguousarray(slic, dtype=np.int32).tobytes()) == int(ref['slic_crc'])
+    segm_ok = zlib.crc32(np.ascontiguousarray(segm, dtype=np.int32).tobytes()) == int(ref['segm_crc'])
+    return {'gpu_equals_reference_run': bool(slic_ok and segm_ok),
+            'reference_run': 'tests/golden/reference_2048.npz: the reference itself on this image (%s), superpixel map %s, '
+                             'segmentation %s' % (str(ref['versions']), 'equal' if slic_ok else 'DIFFERENT',
+                                                  'equal' if segm_ok else 'DIFFERENT')}
+
+
+# -----------------------------------------------------------------------------------------------------------------
+# steady-state runner: M worker threads take W + K + M steps back to back
+# -----------------------------------------------------------------------------------------------------------------
+class SteadyRun(object):
+    def __init__(self, group, inflight, make_worker_state, do_step, gather_item_bytes=0, items_per_step=1):
+        """make_worker_state() -> per-thread state (own HIP context); do_step(state, index, stage) runs one step and
+        calls stage(k, handle) for the label map of its k-th image (handle: device array of the map); with more than
+        one rank the maps of every round of `inflight` steps go to rank 0 in one grouped RCCL call"""
+        self.group, self.inflight = group, inflight
+        self.make_worker_state, self.do_step = make_worker_state, do_step
+        self.gather = None
+        self.item_bytes, self.items_per_step = gather_item_bytes, items_per_step
+        if group.distributed and gather_item_bytes:
+            from pyimsegm_amd.distributed import DeviceGather
+            self.gather = DeviceGather(group, gather_item_bytes * items_per_step, inflight)
+
+    def run(self, warmup, steps):
+        from pyimsegm_amd import _hip
+        group, M = self.group, self.inflight
+        total = warmup + steps + M                # M cool-down steps keep the pipeline full while the last timed steps finish
+        rounds = (total + M - 1) // M
+        done = [None] * total                     # completion time of every step
+        staged = [threading.Event() for _ in range(total)]
+        lock = threading.Lock()
+        cond = threading.Condition()
+        nxt = [0]
+        flushed = [0]
+        errors = []
+        ready = threading.Barrier(M + 1)
+        go = threading.Event()
+
+        def worker():
+            try:
+                state = self.make_worker_state()
+                self.do_step(state, -1, lambda k, handle: None)     # first-use allocations of this thread's session
+                ready.wait()
+                go.wait()
+                while True:
+                    with lock:
+                        i = nxt[0]
+                        nxt[0] += 1
+                    if i >= total:
+                        break
+                    rnd, item = divmod(i, M)
+                    if self.gather is not None:
+                        with cond:                                    # the send ring holds two rounds
+                            cond.wait_for(lambda: flushed[0] >= rnd - 1 or errors)
+
+                        def stage(k, handle, rnd=rnd, item=item):
+                            self.gather.stage(rnd, item, handle, state['ctx'], offset=k * self.item_bytes, nbytes=self.item_bytes)
+                    else:
+                        def stage(k, handle):
+                            return None
+                    self.do_step(state, i, stage)
+                    done[i] = time.perf_counter()
+                    staged[i].set()
+            except BaseException as ex:           # never leave the main thread waiting for a dead worker
+                errors.append(ex)
+                ready.abort()
+                for ev in staged:
+                    ev.set()
+                with cond:
+                    cond.notify_all()
+
+        threads = [threading.Thread(target=worker, daemon=True) for _ in range(M)]
+        for t in threads:
+            t.start()
+        try:
+            ready.wait()
+        except threading.BrokenBarrierError:
+            raise RuntimeError('a worker thread failed during set-up: %r' % (errors[:1], ))
+        ctx = _hip.default_context()
+        ctx.synchronize()
+        group.barrier()
+        t_start = time.perf_counter()
+        go.set()
+        gather_done = [None] * rounds
+        if self.gather is not None:
+            for rnd in range(rounds):
+                for i in range(rnd * M, min((rnd + 1) * M, total)):
+                    staged[i].wait()
+                if group.any_over_ranks(bool(errors)):
+                    break
+                self.gather.flush(rnd)
+                gather_done[rnd] = time.perf_counter()
+                with cond:
+                    flushed[0] = rnd + 1
+                    cond.notify_all()
+        for t in threads:
+            t.join()
+        ctx.synchronize()
+        group.barrier()
+        t_end = time.perf_counter()
+        if errors:
+            raise RuntimeError('a worker thread failed: %r' % (errors[0], ))
+        order = sorted(done)
+        t0 = order[warmup - 1] if warmup > 0 else t_start
+        t1 = order[warmup + steps - 1]
+        if self.gather is not None:               # the gather of the round that holds the last timed step belongs to it
+            t1 = max(t1, gather_done[(warmup + steps - 1) // M])
+        elapsed = group.max_over_ranks(t1 - t0)
+        cold = group.max_over_ranks(t_end - t_start) / total
+        return elapsed, cold
+
+    def close(self):
+        if self.gather is not None:
+            self.gather.close()
+
+
+def host_image(image, pinned):
+    if not pinned:
+        return image
+    from pyimsegm_amd import _hip
+    out = _hip.pinned_empty(image.shape, image.dtype)
+    out[...] = image
+    return out
+
+
+# -----------------------------------------------------------------------------------------------------------------
+# configs 2 / 3 / 4: colour images through segment_color2d_slic_features_model_graphcut
+# -----------------------------------------------------------------------------------------------------------------
+def bench_color2d(args, group):
+    from pyimsegm_amd import _hip
+    from pyimsegm_amd import pipelines as pipe
+    from pyimsegm_amd.descriptors import FEATURES_SET_COLOR
+    from pyimsegm_amd.graph_cuts import estim_class_model
+    from pyimsegm_amd.utilities.synthetic import voronoi_image
+
+    cfg, world, rank = args.config, group.world, group.rank
+    if cfg == 4:
+        height, width, sp_size, per_step = 647, 1024, 35, 8          # run_segm...:105-106 slic_size 35; 64 images / 8 GPUs
+        images = [voronoi_image(height, width, seed=100 + rank * per_step + i) for i in range(per_step)]
+        features = FEATURES_SET_COLOR
+    else:
+        height = width = args.size or HEIGHT
+        sp_size, per_step = SP_SIZE, 1
+        images = [voronoi_image(height, width, seed=1 + rank)]
+        features = FEATURES_SET_COLOR if cfg == 2 else {'tLM': ('mean', 'std', 'energy')}
+    images = [host_image(im, args.pinned_input) for im in images]
+    steps = args.steps if args.steps is not None else {2: 100, 3: 5, 4: 40}[cfg]
+    warmup = args.warmup if args.warmup is not None else {2: 3, 3: 1, 4: 3}[cfg]
+    inflight = args.inflight if args.inflight > 0 else {2: 4, 3: 2, 4: 4}[cfg]
+    npx_step = per_step * height * width
+
+    # model fit once, outside the timed region (the reference's group-model flow)
+    np.random.seed(0)
+    ctx = _hip.default_context()
+    res0 = pipe._ResidentImage(images[0], features, sp_size, SP_REGUL)
+    model = estim_class_model(res0.features, NB_CLASSES, 'GMM', None, True)
+    res0.close()
+    on_device = pipe._device_gmm(model) is not None
+    classes = getattr(model, 'classes_', None)
+
+    def one_image(image, to_host=True, session=None, stage=None, k=0):
+        res = pipe._ResidentImage(image, features, sp_size, SP_REGUL, session=session, reuse=session is None,
+                                  features_to_host=not on_device)
+        try:
+            segm, _ = res.segment(None, GC_REGUL, EDGE_TYPE, classes=classes, to_host=to_host, want_soft=False, model=model)
+            if stage is not None and group.distributed:
+                stage(k, _hip.segm_device_array(res.sess))           # D2D into the send ring before the session is recycled
+            return segm
+        finally:
+            res.close()
+
+    def make_state():
+        return {'ctx': _hip.default_context()}
+
+    def do_step(state, index, stage):
+        for k, image in enumerate(images):
+            one_image(image, stage=stage, k=k)
+
+    runner = SteadyRun(group, inflight, make_state, do_step, gather_item_bytes=height * width * 4, items_per_step=per_step)
+    elapsed, cold = runner.run(warmup, steps)
+    runner.close()
+
+    # ---- separate figures: device-resident rate, soft D2H, single-image latency (un-timed for `value`)
+    extras = {}
+    if rank == 0:
+        from pyimsegm_amd.superpixels import _open_session
+        t = time.perf_counter()
+        for _ in range(3):
+            one_image(images[0])
+        extras['latency_ms'] = round((time.perf_counter() - t) / 3 * 1e3, 3)
+        if cfg != 4:
+            resident = {'sessions': []}
+
+            def make_resident():
+                sess, mode = _open_session(images[0])
+                st = {'ctx': _hip.default_context(), 'session': (sess, mode)}
+                resident['sessions'].append(sess)
+                return st
+
+            def resident_step(state, index, stage):
+                one_image(images[0], to_host=False, session=state['session'])
+
+            from pyimsegm_amd.distributed import Group as _G
+            rr = SteadyRun(_G(single=True), inflight, make_resident, resident_step)     # this process only
+            r_elapsed, _ = rr.run(min(warmup, 3), min(steps, 30))
+            extras['device_resident'] = {'value': round(min(steps, 30) * npx_step / r_elapsed / 1e6, 3), 'unit': 'Mpixels/s',
+                                         'ms_per_step': round(r_elapsed / min(steps, 30) * 1e3, 4),
+                                         'note': 'same pipeline with the image already in HBM and `segm` left in HBM'}
+            for sess in resident['sessions']:
+                sess.close()
+            # segm_soft (H x W x C float64, 100 MB at 2048^2) to the host on request
+            res = pipe._ResidentImage(images[0], features, sp_size, SP_REGUL, features_to_host=not on_device)
+            res.segment(None, GC_REGUL, EDGE_TYPE, classes=classes, to_host=True, want_soft=True, model=model)   # buffers
+            t = time.perf_counter()
+            res.segment(None, GC_REGUL, EDGE_TYPE, classes=classes, to_host=True, want_soft=False, model=model)
+            t_a = time.perf_counter()
+            res.segment(None, GC_REGUL, EDGE_TYPE, classes=classes, to_host=True, want_soft=True, model=model)
+            t_b = time.perf_counter()
+            res.close()
+            extras['soft_d2h_ms'] = round(((t_b - t_a) - (t_a - t)) * 1e3, 3)
+
+    # ---- kernel-level figures: un-overlapped pass on one stream with HIP events around every stage
+    prof_steps = 3 if cfg == 3 else 5
+    ctx.profile_enable(True)
+    ctx.profile_reset()
+    for _ in range(prof_steps):
+        one_image(images[0])
+    ctx.synchronize()
+    stage_ms = {g: ctx.profile_get(g) for g in _hip.PROFILE_GROUPS}
+    ctx.profile_enable(False)
+
+    out = None
+    if rank == 0:
+        value = world * steps * npx_step / elapsed / 1e6
+        npx = height * width
+        if cfg == 3:
+            tex_ms, tex_n = stage_ms['texture']
+            flops = 2.0 * 1089 * 76 * 3 * npx                      # SURVEY 8(d): 2 * 33^2 taps * 76 kernels * 3 channels per pixel
+            achieved = flops / (tex_ms / prof_steps / 1e3) / 1e12 if tex_n else 0.0
+            roofline = {'bound': 'fp64_valu', 'kernel': 'k_conv_battery<NK> (all 20 batteries of the Leung-Malik bank per image)',
+                        'achieved': round(achieved, 3), 'peak': FP64_VALU_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                        'frac': round(achieved / FP64_VALU_PEAK_TFLOPS, 5), 'traffic': None,
+                        'algorithmic_flops_per_image': flops, 'battery_ms_per_image': round(tex_ms / prof_steps, 3)}
+        else:
+            assign_ms, assign_n = stage_ms['slic_assign']
+            avg_s = assign_ms / max(assign_n, 1) / 1e3
+            achieved = ASSIGN_BYTES_PER_PX * npx / avg_s / 1e9 if assign_n else 0.0
+            traffic = None
+            try:   # HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
+                with open(os.path.join(ROOT, 'profiles', 'pmc_traffic.json')) as fp:
+                    pmc = json.load(fp)
+                if (height, width) == (HEIGHT, WIDTH):
+                    traffic = pmc['hbm_bytes_per_launch']
+            except Exception:
+                pass
+            roofline = {'bound': 'hbm', 'kernel': 'k_slic_assign_dot (assignment + fused centroid accumulation; all sweeps)',
+                        'achieved': round(achieved, 2), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                        'frac': round(achieved / HBM_PEAK_GBS, 5), 'traffic': traffic,
+                        'traffic_source': 'profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)',
+                        'avg_kernel_us': round(avg_s * 1e6, 3), 'launches': assign_n,
+                        'algorithmic_bytes_per_launch': ASSIGN_BYTES_PER_PX * npx}
+        workload = {
+            2: 'single %dx%d RGB uint8 per GPU, SLIC(sp_size=46, K=2025, 10 sweeps) + colour mean/std/energy + 3-class '
+               'alpha-expansion GC (gc_regul=2.0, edge=model), pre-fitted GMM, host numpy in -> segm int32 in host numpy '
+               '(BASELINE configs[1])' % (height, width),
+            3: 'single %dx%d RGB uint8 per GPU, SLIC(sp_size=46) + full Leung-Malik bank (76 kernels 33x33, sigma=150 high-pass, '
+               'F=180) + 3-class GC, pre-fitted GMM (scikit-learn on the host: F > 32), host in -> host out (BASELINE '
+               'configs[2])' % (height, width),
+            4: 'batch of %d images %dx%d RGB uint8 per GPU per step (BASELINE configs[3]: 64 images over 8 GPUs), '
+               'SLIC(sp_size=35) + colour mean/std/energy + 3-class GC, pre-fitted GMM, host in -> host out'
+               % (per_step, height, width),
+        }[cfg]
+        out = {
+            'metric': 'Mpixels/s end-to-end SLIC+fts+GC, 2048x2048 RGB; % HBM roofline',
+            'value': round(value, 3), 'unit': 'Mpixels/s', 'n_gpus': world, 'steps': steps, 'warmup': warmup,
+            'ms_per_step': round(elapsed / steps * 1e3, 4), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'dtype': 'f64', 'data': 'synthetic',
+            'config': {
+                'workload': workload, 'bench_config': cfg, 'images_per_step_per_gpu': per_step,
+                'images_in_flight_per_gpu': inflight,
+                'timed_region': 'host numpy image -> H2D -> SLIC -> descriptors -> class model -> graph-cut terms -> '
+                                'alpha-expansion -> gathers -> D2H -> segm in host numpy (page-locked result array); model fit outside',
+                'input_memory': 'page-locked' if args.pinned_input else 'pageable numpy',
+                'class_model': 'device (scaler + full-covariance GMM)' if on_device else 'host scikit-learn predict_proba',
+                'timing': 'steady state: %d warm-up + %d timed + %d cool-down steps back to back, clock from completion of '
+                          'step W to completion of step W+K' % (warmup, steps, inflight),
+                'parallelism': 'images sharded over %d GPU(s), %d in flight per GPU (one HIP stream each)%s'
+                               % (world, inflight, ', label maps gathered in rank 0 HBM per round of %d steps (%s)'
+                                  % (inflight, group.backend) if group.distributed else ''),
+            },
+            'ms_per_step_incl_fill_drain': round(cold * 1e3, 4),
+            'roofline': roofline,
+            'stage_ms_per_step': {g: round(ms / prof_steps, 4) for g, (ms, n) in stage_ms.items()},
+            'stage_note': 'stage and roofline figures: separate pass of %d un-overlapped host-to-host images on one stream' % prof_steps,
+        }
+        out.update(extras)
+        if world == 1 and not args.no_cpu_baseline and cfg in (2, 4):
+            try:
+                base, segm_cpu, slic_real = cpu_baseline_color2d(np.asarray(images[0]), model, sp_size, SP_REGUL)
+                out['cpu_baseline'] = base
+                segm_gpu = one_image(images[0])
+                out['gpu_equals_cpu_oracle'] = bool(np.array_equal(segm_gpu, segm_cpu))
+                out['speedup_vs_cpu_baseline'] = round(value / base['value'], 2)
+                if slic_real is not None:
+                    res = pipe._ResidentImage(images[0], features, sp_size, SP_REGUL)
+                    out['gpu_slic_equals_scikit_image'] = bool(np.array_equal(res.slic, slic_real))
+                    res.close()
+            except Exception as ex:   # the baseline is a reported extra, never a reason to lose the line
+                out['cpu_baseline'] = {'error': repr(ex)}
+        if world == 1 and cfg == 2 and (height, width) == (HEIGHT, WIDTH):
+            try:      # the reference's own run on this very image (build container, tests/golden/make_golden_reference.py)
+                verdict = compare_with_reference_run(np.asarray(images[0]), pipe)
+                if verdict is not None:
+                    out.update(verdict)
+            except Exception as ex:
+                out['reference_run_error'] = repr(ex)
+    return out
+
+
+# -----------------------------------------------------------------------------------------------------------------
+# config 5: one gray volume through pipe_gray3d_slic_features_model_graphcut
+# -----------------------------------------------------------------------------------------------------------------
+def bench_volume(args, group):
+    from pyimsegm_amd import _hip
+    from pyimsegm_amd import pipelines as pipe
+    from pyimsegm_amd.utilities.synthetic import ellipsoid_volume
+
+    shape = tuple(int(v) for v in args.volume.split(','))
+    steps = args.steps if args.steps is not None else 2
+    warmup = args.warmup if args.warmup is not None else 1
+    rng = np.random.default_rng(5 + group.rank)
+    vol = ellipsoid_volume(shape).astype(np.float32)                      # float32: SURVEY 8(d) C5
+    vol += (0.05 * rng.standard_normal(shape, dtype=np.float32))
+    feats = {'color': ('mean', 'std', 'energy')}
+    ctx = _hip.default_context()
+
+    def step():
+        np.random.seed(0)
+        return pipe.pipe_gray3d_slic_features_model_graphcut(vol, NB_CLASSES, feats, spacing=(1, 1, 1), sp_size=15, sp_regul=0.2,
+                                                             gc_regul=0.1)
+
+    for _ in range(warmup):
+        step()
+    ctx.synchronize()
+    group.barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        segm = step()
+    ctx.synchronize()
+    group.barrier()
+    elapsed = group.max_over_ranks(time.perf_counter() - t0)
+    ctx.profile_enable(True)
+    ctx.profile_reset()
+    step()
+    stage_ms = {g: ctx.profile_get(g) for g in _hip.PROFILE_GROUPS}
+    ctx.profile_enable(False)
+    if group.rank != 0:
+        return None
+    nvox = int(np.prod(shape))
+    slic_ms = stage_ms['slic'][0]
+    achieved = 10 * VOL_ASSIGN_BYTES_PER_VOXEL * nvox / (slic_ms / 1e3) / 1e9 if slic_ms else 0.0
+    return {
+        'metric': 'Mpixels/s end-to-end SLIC+fts+GC, 2048x2048 RGB; % HBM roofline',
+        'value': round(group.world * steps * nvox / elapsed / 1e6, 3), 'unit': 'Mpixels/s', 'n_gpus': group.world, 'steps': steps,
+        'warmup': warmup, 'ms_per_step': round(elapsed / steps * 1e3, 3), 'higher_is_better': True, 'scaling': 'weak',
+        'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+        'config': {'workload': 'single %dx%dx%d float32 gray volume per GPU through pipe_gray3d_slic_features_model_graphcut '
+                               '(sp_size=15, spacing (1,1,1), gray mean/std/energy, 3-class GMM fitted inside the step on the host, '
+                               'gc_regul=0.1), host in -> host out (BASELINE configs[4]); unit = Mvoxels/s' % shape,
+                   'bench_config': 5, 'classes_found': int(len(np.unique(segm)))},
+        'roofline': {'bound': 'hbm', 'kernel': 'whole 3-D SLIC stage (pre-processing, 10 x [scatter, k_vol_assign_f32, k_vol_update_f32], connectivity)',
+                     'achieved': round(achieved, 2), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBS, 5),
+                     'traffic': None, 'algorithmic_bytes': 10 * VOL_ASSIGN_BYTES_PER_VOXEL * nvox, 'stage_ms': round(slic_ms, 2)},
+        'stage_ms_per_step': {g: round(ms, 3) for g, (ms, n) in stage_ms.items()},
+    }
 
 
 def main():
     args = parse_args()
-    try:    # the host stages multiply 2025 x 9 matrices: one BLAS thread each, N ranks x M worker threads share the node
+    try:    # host-side BLAS (model fit, non-GMM models): one thread each, N ranks x M worker threads share the node
         from threadpoolctl import threadpool_limits
         threadpool_limits(limits=1)
     except Exception:
         pass
     from pyimsegm_amd.distributed import Group
-    group = Group()                      # torch.distributed (RCCL) only when launched by torchrun
-    world, rank = group.world, group.rank
-
-    from pyimsegm_amd import _hip
-    from pyimsegm_amd import pipelines as pipe
-    from pyimsegm_amd.descriptors import FEATURES_SET_COLOR
-    from pyimsegm_amd.graph_cuts import estim_class_model, predict_proba
-    from pyimsegm_amd.superpixels import _open_session
-    from pyimsegm_amd.utilities.synthetic import voronoi_image
-
-    size = args.size
-    image = voronoi_image(size, size, seed=1 + rank)
-    ctx = _hip.default_context()
-    sess, mode = _open_session(image)           # H2D once: the image is resident from here on
-
-    host_pool = None
-
-    def step(model, session, to_host=False):
-        res = pipe._ResidentImage(image, FEATURES_SET_COLOR, SP_SIZE, SP_REGUL, session=session)
-        if host_pool is not None:
-            return res.segment_with_model(model, GC_REGUL, EDGE_TYPE, host_pool, to_host=to_host), res
-        proba = predict_proba(model, res.features)
-        return res.segment(proba, GC_REGUL, EDGE_TYPE, to_host=to_host), res
-
-    # model fit once (outside the timed region): the reference's group-model flow, run_segm...:476-514
-    np.random.seed(0)
-    res0 = pipe._ResidentImage(image, FEATURES_SET_COLOR, SP_SIZE, SP_REGUL, session=(sess, mode))
-    model = estim_class_model(res0.features, NB_CLASSES, 'GMM', None, True)
-
-    # Worker threads keep `inflight` images of this rank in flight: each has its own context (HIP stream)
-    # and its own resident copy of the image; the host stages of one step overlap the kernels of another.
-    # Step i of the K timed steps is taken by the next free worker; with more than one rank every finished
-    # label map is gathered on rank 0 by the main thread (one RCCL gather per step, zero copy from HBM).
-    import queue
-    import threading
-    # measured on MI355X (total ms for K steps at 2 / 3 / 4 / 6 in flight): K=10: 21 / 19 / 18 / 24, K=20: 34 / 31 / 32 / 32,
-    # K=50: 85 / 66 / 66 / 59, K=100: - / - / 129 / 104
-    inflight = args.inflight if args.inflight > 0 else (6 if args.steps >= 40 else 4 if args.steps >= 8 else min(3, max(1, args.steps)))
-    if args.host_pool and inflight > 1:
-        # the numpy stages of the images in flight leave the interpreter lock of this process (same functions,
-        # same numbers: pyimsegm_amd/hostpool.py); helpers are started and given the model before the timed region
-        from pyimsegm_amd.hostpool import HostMathPool
-        try:
-            host_pool = HostMathPool(inflight)
-            host_pool.set_model(model)
-        except Exception as ex:       # no helpers (cannot spawn, model not picklable ...): the threads do the numpy work
-            print('host helper processes not available (%r): numpy stages stay in the worker threads' % (ex, ), file=sys.stderr)
-            if host_pool is not None:
-                host_pool.close()
-            host_pool = None
-    if args.switch_interval:
-        sys.setswitchinterval(args.switch_interval)
-    do_gather = group.dist is not None            # launched by torchrun (also exercised with a single rank)
-    todo = queue.Queue()
-    done = queue.Queue()
-    ready = threading.Barrier(inflight + 1)
-    contexts = [None] * inflight
-
-    errors = []
-
-    def worker(idx):
-        try:
-            wctx = _hip.default_context()            # per thread
-            contexts[idx] = wctx
-            session = _open_session(image)
-            for _ in range(max(args.warmup, 1)):
-                step(model, session)
-            wctx.synchronize()
-            ready.wait()
-            while True:
-                item = todo.get()
-                if item is None:
-                    break
-                step(model, session)
-                if do_gather:
-                    gathered = threading.Event()
-                    done.put((session[0], gathered))
-                    gathered.wait()                   # the label buffer is reused by the next step
-                else:
-                    done.put((session[0], None))
-            wctx.synchronize()
-        except BaseException as ex:                   # never leave the main thread waiting for a dead worker
-            errors.append(ex)
-            ready.abort()
-        finally:
-            done.put(None)
-
-    threads = [threading.Thread(target=worker, args=(i,), daemon=True) for i in range(inflight)]
-    for t in threads:
-        t.start()
+    group = Group()
     try:
-        ready.wait()                              # sessions resident, warm-up done
-    except threading.BrokenBarrierError:
-        raise RuntimeError('a worker thread failed during warm-up: %r' % (errors[:1], ))
-    group.barrier()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        todo.put(i)
-    for _ in threads:
-        todo.put(None)
-    finished = 0
-    while finished < inflight:
-        item = done.get()
-        if item is None:
-            finished += 1
-            continue
-        if do_gather:
-            item[0].ctx.synchronize()
-            group.gather_arrays(_hip.segm_device_array(item[0]), dst=0, keep_on_device=True)
-            item[1].set()
-    group.barrier()
-    elapsed = time.perf_counter() - t0
-    for t in threads:
-        t.join()
-    if errors:
-        raise RuntimeError('a worker thread failed: %r' % (errors[0], ))
-    elapsed = group.max_over_ranks(elapsed)
-
-    # Kernel-level figures (roofline of the dominant kernel, stage breakdown): a second, un-overlapped pass of
-    # a few steps on one stream with HIP events around every stage -- with several images in flight the
-    # kernels of different streams share the GPU and their individual durations say nothing.
-    prof_steps = min(max(args.steps, 1), 5)
-    ctx.profile_enable(True)
-    ctx.profile_reset()
-    for _ in range(prof_steps):
-        step(model, (sess, mode))
-    ctx.synchronize()
-    assign_ms, assign_n = ctx.profile_get('slic_assign')
-    stage_ms = {g: ctx.profile_get(g) for g in _hip.PROFILE_GROUPS}
-    ctx.profile_enable(False)
-
-    if rank == 0:
-        npx = size * size
-        value = world * args.steps * npx / elapsed / 1e6
-        avg_assign_s = assign_ms / max(assign_n, 1) / 1e3
-        achieved = ASSIGN_BYTES_PER_PX * npx / avg_assign_s / 1e9 if assign_n else 0.0
-        traffic = None
-        try:   # HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
-            with open(os.path.join(ROOT, 'profiles', 'pmc_traffic.json')) as fp:
-                pmc = json.load(fp)
-            if size == HEIGHT:
-                traffic = pmc['hbm_bytes_per_launch']
-        except Exception:
-            pass
-        out = {
-            'metric': 'Mpixels/s end-to-end SLIC+fts+GC, 2048x2048 RGB; % HBM roofline',
-            'value': round(value, 3),
-            'unit': 'Mpixels/s',
-            'n_gpus': world,
-            'steps': args.steps,
-            'warmup': args.warmup,
-            'ms_per_step': round(elapsed / args.steps * 1e3, 4),
-            'higher_is_better': True,
-            'scaling': 'weak',
-            'vs_baseline': None,
-            'dtype': 'f64',
-            'data': 'synthetic',
-            'config': {
-                'workload': 'single %dx%d RGB uint8 per GPU, SLIC(sp_size=46, n_segments=1982, K=2025, 10 sweeps) + '
-                            'colour mean/std/energy + 3-class alpha-expansion GC (gc_regul=2.0, edge=model), '
-                            'pre-fitted GMM (BASELINE configs[1])' % (size, size),
-                'images_per_step_per_gpu': 1,
-                'images_in_flight_per_gpu': inflight,
-                'host_math': ('%d helper processes per GPU (scikit-learn class model + graph-cut terms)' % inflight)
-                if host_pool is not None else 'in the worker threads',
-                'parallelism': 'images sharded over %d GPU(s), %d in flight per GPU (one HIP stream each), RCCL gather '
-                               'of label maps' % (world, inflight),
-            },
-            'roofline': {
-                'bound': 'hbm',
-                'kernel': 'k_slic_assign_dot (assignment + fused centroid accumulation; all sweeps of the pass)',
-                'achieved': round(achieved, 2),
-                'peak': HBM_PEAK_GBS,
-                'unit': 'GB/s',
-                'frac': round(achieved / HBM_PEAK_GBS, 5),
-                'traffic': traffic,
-                'traffic_source': 'profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)',
-                'avg_kernel_us': round(avg_assign_s * 1e6, 3),
-                'launches': assign_n,
-                'algorithmic_bytes_per_launch': ASSIGN_BYTES_PER_PX * npx,
-            },
-            'stage_ms_per_step': {g: round(ms / prof_steps, 4) for g, (ms, n) in stage_ms.items()},
-            'stage_note': 'stage and roofline figures: separate pass of %d un-overlapped steps on one stream' % prof_steps,
-        }
-        if world == 1 and not args.no_cpu_baseline:
-            try:
-                base, segm_cpu, _ = cpu_baseline(image, model)
-                out['cpu_baseline'] = base
-                (segm_gpu, _), res_gpu = step(model, (sess, mode), to_host=True)
-                out['gpu_equals_cpu_oracle'] = bool(np.array_equal(segm_gpu, segm_cpu))
-                out['speedup_vs_cpu_baseline'] = round(value / base['value'], 2)
-                try:      # the third-party reference itself, when the box has it (an extra: never loses the line)
-                    real = real_skimage_slic(image)
-                    if real is not None:
-                        base['reference_slic'] = {'scikit_image': real[0], 'seconds': round(real[1], 3), 'cores': 1,
-                                                  'note': 'skimage.segmentation.slic as called at imsegm/superpixels.py:'
-                                                          '61-63, same image; the oracle SLIC time is in `sample`'}
-                        out['gpu_slic_equals_scikit_image'] = bool(np.array_equal(res_gpu.slic, real[2]))
-                except Exception:
-                    pass
-            except Exception as ex:   # the baseline is a reported extra, never a reason to lose the line
-                out['cpu_baseline'] = {'error': repr(ex)}
-        if world == 1 and size == HEIGHT:
-            try:      # the reference's own run on this very image (build container, tests/golden/make_golden_reference.py)
-                verdict = compare_with_reference_run(image, sess, mode, pipe, predict_proba)
-                if verdict is not None:
-                    out.update(verdict)
-            except Exception:
-                pass
-        print(json.dumps(out), flush=True)
-    if host_pool is not None:
-        host_pool.close()
-    group.close()
+        out = bench_volume(args, group) if args.config == 5 else bench_color2d(args, group)
+        if group.rank == 0:
+            print(json.dumps(out), flush=True)
+    finally:
+        group.close()
 
 
 if __name__ == '__main__':

@@ -14,6 +14,7 @@
 #ifndef IMSEGM_HIP_H
 #define IMSEGM_HIP_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -33,14 +34,29 @@ IMSEGM_API const char *imsegm_last_error(void);
 IMSEGM_API int imsegm_version(void);
 IMSEGM_API int imsegm_device_count(int *count_out);
 
+/* page-locked host memory: images / results living in it travel by DMA, asynchronously to the host (the Python layer
+ * hands out numpy arrays backed by it: pyimsegm_amd._hip.pinned_empty) */
+IMSEGM_API int imsegm_host_alloc(size_t bytes, void **ptr_out);
+IMSEGM_API void imsegm_host_free(void *ptr);
+
+/* plain device buffers and copies for the multi-GPU layer (pyimsegm_amd/distributed.py hands these pointers and the
+ * context's stream to RCCL): hipMalloc / hipFree, hipSetDevice for the calling thread, hipMemcpyAsync (any direction)
+ * on the context's stream */
+IMSEGM_API int imsegm_device_alloc(int device, size_t bytes, void **ptr_out);
+IMSEGM_API void imsegm_device_free(void *ptr);
+IMSEGM_API int imsegm_set_device(int device);
+
 IMSEGM_API int imsegm_ctx_create(int device, imsegm_ctx **ctx_out);
 IMSEGM_API void imsegm_ctx_destroy(imsegm_ctx *ctx);
 IMSEGM_API int imsegm_ctx_synchronize(imsegm_ctx *ctx);
+IMSEGM_API int imsegm_ctx_stream(imsegm_ctx *ctx, void **hip_stream_out);
+IMSEGM_API int imsegm_ctx_copy(imsegm_ctx *ctx, void *dst, const void *src, size_t bytes, int synchronize);
 
 /* HIP-event timing of the kernels launched on the context's stream (bench.py roofline leg).
  * group: 0 = SLIC assignment(+accumulate) kernel, 1 = whole SLIC stage, 2 = connectivity,
  *        3 = colour statistics, 4 = adjacency + centres, 5 = alpha expansion, 6 = gathers,
- *        7 = SLIC pre-processing.  Returns accumulated milliseconds and launch count since reset. */
+ *        7 = SLIC pre-processing, 8 = class model + graph-cut terms, 9 = Leung-Malik filter batteries.  Returns accumulated milliseconds and launch
+ *        count since reset. */
 IMSEGM_API int imsegm_ctx_profile_enable(imsegm_ctx *ctx, int enable);
 IMSEGM_API int imsegm_ctx_profile_reset(imsegm_ctx *ctx);
 IMSEGM_API int imsegm_ctx_profile_get(imsegm_ctx *ctx, int group, double *total_ms_out, int *count_out);
@@ -51,7 +67,8 @@ IMSEGM_API int imsegm_ctx_profile_get(imsegm_ctx *ctx, int group, double *total_
 IMSEGM_API int imsegm_image2d_create(imsegm_ctx *ctx, int height, int width, imsegm_image2d **img_out);
 IMSEGM_API void imsegm_image2d_destroy(imsegm_image2d *img);
 
-/* H2D copy of an H x W x 3 interleaved colour image (dtype IMSEGM_U8 / IMSEGM_F32 / IMSEGM_F64). */
+/* H2D copy of an H x W x 3 interleaved colour image (dtype IMSEGM_U8 / IMSEGM_F32 / IMSEGM_F64).  A page-locked source
+ * (imsegm_host_alloc) is copied asynchronously: keep it unchanged until the next synchronising call (imsegm_image2d_slic). */
 IMSEGM_API int imsegm_image2d_upload(imsegm_image2d *img, const void *host_pixels, int dtype);
 
 /* Replaces skimage.segmentation.slic(image, n_segments, compactness, sigma, enforce_connectivity=True)
@@ -145,6 +162,65 @@ IMSEGM_API int imsegm_volume_gray_stats(imsegm_image2d *vol, double *mean_out, d
  * (imsegm/superpixels.py:180-242); centres_out is n_labels x 3 (z, y, x). */
 IMSEGM_API int imsegm_volume_graph(imsegm_image2d *vol, int32_t *edges_out, int edge_capacity, int *n_edges_out,
                                    double *centres_out, uint8_t *present_out);
+
+/* ---------------------------------------------------------------------------------------------
+ * fused back half of the pipeline (no host round trip between the stages)
+ * ------------------------------------------------------------------------------------------- */
+/* Per-superpixel feature table of compute_image2d_color_statistic / compute_image3d_gray_statistic
+ * (imsegm/descriptors.py:705-863) for the flags mean (1) | std (2) | energy (4): columns ordered mean, std, energy,
+ * three columns each (colour channels; a gray volume repeats its single channel), NaN -> 0, -0 -> +0.  The table
+ * stays resident for imsegm_image2d_segment; features_out (n_labels x 3*nflags float64) may be NULL. */
+IMSEGM_API int imsegm_image2d_features_color(imsegm_image2d *img, int feature_mask, double *features_out);
+
+/* class model evaluated on the device: sklearn Pipeline([StandardScaler,] GaussianMixture(covariance_type='full')) as
+ * imsegm.graph_cuts.estim_class_model builds it (imsegm/graph_cuts.py:73-163).  The host passes what scikit-learn
+ * itself precomputes per model (not per sample). */
+typedef struct {
+    int n_features, n_classes;
+    const double *scaler_mean;    /* [F] StandardScaler.mean_ or NULL */
+    const double *scaler_scale;   /* [F] StandardScaler.scale_ or NULL */
+    const double *prec_chol;      /* [C][F][F] GaussianMixture.precisions_cholesky_ */
+    const double *mu_proj;        /* [C][F]   means_[c] @ precisions_cholesky_[c] */
+    const double *log_det;        /* [C]      _compute_log_det_cholesky */
+    const double *log_weights;    /* [C]      log(weights_) */
+    double const_term;            /* n_features * log(2 pi) */
+} imsegm_gmm;
+
+/* edge types of imsegm.graph_cuts.compute_edge_weights (imsegm/graph_cuts.py:574-657); `| IMSEGM_EDGE_SPATIAL_NORM`
+ * divides the weights by the relative distance of the superpixel centres (:647-650: 'model', 'features', 'spatial') */
+#define IMSEGM_EDGE_CONST 0
+#define IMSEGM_EDGE_SPATIAL 1
+#define IMSEGM_EDGE_MODEL_LT 2
+#define IMSEGM_EDGE_MODEL_L1 3
+#define IMSEGM_EDGE_MODEL_L2 4
+#define IMSEGM_EDGE_FEATURES 5
+#define IMSEGM_EDGE_SPATIAL_NORM 0x100
+
+/* optional inspection outputs of imsegm_image2d_segment (parity tests, debug_visual): NULL pointers are skipped */
+typedef struct {
+    int edge_capacity;            /* in: rows of edges / edge_weights / edge_weights_int */
+    int n_edges;                  /* out */
+    int32_t *edges;               /* E x 2, a < b, ordered by (b, a) */
+    double *edge_weights;         /* E, after clipping and edge_cost */
+    int32_t *edge_weights_int;    /* E, the pyGCO integers */
+    double *unary;                /* K x C */
+    int32_t *unary_int;           /* K x C */
+    double *centres;              /* K x ndim */
+    int64_t *energy;              /* final integer energy of the expansion */
+    int keep_soft_on_device;      /* in: compute proba[slic] into the session's buffer even when soft_out is NULL */
+} imsegm_terms_debug;
+
+/* Replaces, on the resident label map (and feature table): model.predict_proba (gmm != NULL; else `proba`, K x C, comes
+ * from the host), compute_unary_cost, compute_edge_weights, compute_pairwise_cost's result `pairwise` (C x C, host),
+ * gco.cut_general_graph(..., algorithm='expansion', n_iter=-1) (use_graphcut = 0: argmin of the unary cost,
+ * graph_cuts.py:729-731), classes_[graph_labels] (classes_lut, may be NULL) and the gathers graph_labels[slic],
+ * proba[slic] (imsegm/graph_cuts.py:660-747, imsegm/pipelines.py:96-109,232-240).  One stream, one synchronisation at
+ * the end.  Outputs (each may be NULL): segm_out H x W int32, soft_out H x W x C float64, graph_labels_out K int32
+ * (before classes_lut), proba_out K x C. */
+IMSEGM_API int imsegm_image2d_segment(imsegm_image2d *img, const imsegm_gmm *gmm, const double *proba, int n_classes,
+                                      const double *pairwise, int edge_type, double edge_cost, int use_graphcut,
+                                      const int32_t *classes_lut, int32_t *segm_out, double *soft_out,
+                                      int32_t *graph_labels_out, double *proba_out, imsegm_terms_debug *debug_out);
 
 /* Device address of a result buffer of the session (valid until the next call that rewrites it):
  * which = 0: label map int32 H x W; 1: gathered segmentation int32 H x W; 2: gathered soft

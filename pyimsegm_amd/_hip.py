@@ -26,6 +26,8 @@ PROFILE_GROUPS = {
     'graphcut': 5,
     'gather': 6,
     'slic_preprocess': 7,
+    'terms': 8,
+    'texture': 9,
 }
 
 
@@ -43,8 +45,35 @@ _lib_lock = threading.Lock()
 _vp = C.c_void_p
 _ip = C.POINTER(C.c_int)
 
+class GmmParams(C.Structure):
+    """``imsegm_gmm`` of include/imsegm_hip.h"""
+    _fields_ = [('n_features', C.c_int), ('n_classes', C.c_int), ('scaler_mean', _vp), ('scaler_scale', _vp),
+                ('prec_chol', _vp), ('mu_proj', _vp), ('log_det', _vp), ('log_weights', _vp), ('const_term', C.c_double)]
+
+
+class TermsDebug(C.Structure):
+    """``imsegm_terms_debug`` of include/imsegm_hip.h"""
+    _fields_ = [('edge_capacity', C.c_int), ('n_edges', C.c_int), ('edges', _vp), ('edge_weights', _vp),
+                ('edge_weights_int', _vp), ('unary', _vp), ('unary_int', _vp), ('centres', _vp), ('energy', _vp),
+                ('keep_soft_on_device', C.c_int)]
+
+
+#: edge types of ``imsegm_image2d_segment``; 0x100 = divide by the relative centre distance (graph_cuts.py:647-650)
+EDGE_TYPES = {'': 0, 'const': 0, 'spatial': 1 | 0x100, 'model': 2 | 0x100, 'model_lT': 2, 'model_l1': 3, 'model_l2': 4,
+              'features': 5 | 0x100}
+
 _SIGNATURES = {
     'imsegm_last_error': (C.c_char_p, []),
+    'imsegm_host_alloc': (C.c_int, [C.c_size_t, C.POINTER(_vp)]),
+    'imsegm_host_free': (None, [_vp]),
+    'imsegm_device_alloc': (C.c_int, [C.c_int, C.c_size_t, C.POINTER(_vp)]),
+    'imsegm_device_free': (None, [_vp]),
+    'imsegm_set_device': (C.c_int, [C.c_int]),
+    'imsegm_ctx_stream': (C.c_int, [_vp, C.POINTER(_vp)]),
+    'imsegm_ctx_copy': (C.c_int, [_vp, _vp, _vp, C.c_size_t, C.c_int]),
+    'imsegm_image2d_features_color': (C.c_int, [_vp, C.c_int, _vp]),
+    'imsegm_image2d_segment': (C.c_int, [_vp, C.POINTER(GmmParams), _vp, C.c_int, _vp, C.c_int, C.c_double, C.c_int, _vp, _vp, _vp,
+                                         _vp, _vp, C.POINTER(TermsDebug)]),
     'imsegm_version': (C.c_int, []),
     'imsegm_device_count': (C.c_int, [_ip]),
     'imsegm_ctx_create': (C.c_int, [C.c_int, C.POINTER(_vp)]),
@@ -148,6 +177,17 @@ class Context(object):
     def synchronize(self):
         _check(load_library().imsegm_ctx_synchronize(self._h))
 
+    @property
+    def stream(self):
+        """the HIP stream of this context as an integer handle (for RCCL calls on the same stream)"""
+        p = _vp()
+        _check(load_library().imsegm_ctx_stream(self._h, C.byref(p)))
+        return p.value
+
+    def copy(self, dst_ptr, src_ptr, nbytes, synchronize=True):
+        """``hipMemcpyAsync`` (any direction) on this context's stream"""
+        _check(load_library().imsegm_ctx_copy(self._h, _vp(dst_ptr), _vp(src_ptr), int(nbytes), int(bool(synchronize))))
+
     def profile_enable(self, enable=True):
         _check(load_library().imsegm_ctx_profile_enable(self._h, int(enable)))
 
@@ -203,6 +243,99 @@ def default_context():
     return ctx
 
 
+class _PinnedBlock(object):
+    """a page-locked host allocation; goes back to the free list of its size class when the last numpy view dies"""
+    __slots__ = ('ptr', 'size', 'pid', '__weakref__')
+
+    def __init__(self, ptr, size):
+        self.ptr, self.size, self.pid = ptr, size, os.getpid()
+
+    def __del__(self):
+        try:
+            if self.pid != os.getpid():
+                return
+            with _pinned_lock:
+                cache = _pinned_free.setdefault(self.size, [])
+                if len(cache) < _PINNED_KEEP:
+                    cache.append(self.ptr)
+                    return
+            load_library().imsegm_host_free(self.ptr)
+        except Exception:
+            pass
+
+
+_pinned_free = {}
+_pinned_lock = threading.Lock()
+_PINNED_KEEP = 16      # blocks kept per size class for reuse (hipHostMalloc costs far more than the copy it speeds up)
+
+
+def pinned_empty(shape, dtype):
+    """``numpy.empty(shape, dtype)`` in page-locked host memory: uploads from / downloads into such an array run as
+    asynchronous DMA (``Image2D.upload``, ``Image2D.segment``).  The memory returns to a small per-size free list when
+    the array (and every view of it) is garbage collected."""
+    dtype = np.dtype(dtype)
+    shape = tuple(int(v) for v in np.atleast_1d(shape))
+    nbytes = int(np.prod(shape, dtype=np.int64)) * dtype.itemsize
+    size = max(4096, (nbytes + 4095) & ~4095)
+    ptr = None
+    with _pinned_lock:
+        cache = _pinned_free.get(size)
+        if cache:
+            ptr = cache.pop()
+    if ptr is None:
+        if device_count() < 1:
+            raise HipUnavailableError('no HIP device is visible: page-locked memory is not available')
+        p = _vp()
+        _check(load_library().imsegm_host_alloc(size, C.byref(p)))
+        ptr = p.value
+    block = _PinnedBlock(ptr, size)
+    buf = (C.c_char * size).from_address(ptr)
+    buf._block = block                                    # the ctypes buffer (base of the array) keeps the block alive
+    return np.frombuffer(buf, dtype=dtype, count=nbytes // dtype.itemsize).reshape(shape)
+
+
+class DeviceGmm(object):
+    """the constants of a fitted ``Pipeline([StandardScaler,] GaussianMixture(covariance_type='full'))`` that the
+    device needs for ``predict_proba``: what scikit-learn computes once per model (``means_ @ precisions_cholesky_``,
+    the log-determinants, ``log(weights_)``), formed with the very numpy expressions of ``sklearn/mixture/
+    _gaussian_mixture.py`` (``_estimate_log_gaussian_prob``, ``_compute_log_det_cholesky``)"""
+
+    def __init__(self, model):
+        from sklearn.mixture import GaussianMixture
+        from sklearn.pipeline import Pipeline
+        from sklearn.preprocessing import StandardScaler
+        steps = list(model.steps) if isinstance(model, Pipeline) else [('model', model)]
+        gmm = steps[-1][1]
+        if type(gmm) is not GaussianMixture or gmm.covariance_type != 'full' or not hasattr(gmm, 'precisions_cholesky_'):
+            raise TypeError('not a fitted full-covariance GaussianMixture')
+        if len(steps) > 2 or any(type(st) is not StandardScaler for _, st in steps[:-1]):
+            raise TypeError('only an optional StandardScaler in front of the mixture is evaluated on the device')
+        n_comp, n_feat = gmm.means_.shape
+        if n_feat > 32 or n_comp > 16:
+            raise TypeError('device class model: at most 32 features and 16 classes')
+        self.n_features, self.n_classes = int(n_feat), int(n_comp)
+        self.classes = getattr(model, 'classes_', None)
+        par = GmmParams()
+        par.n_features, par.n_classes = self.n_features, self.n_classes
+        self.scaler_mean = self.scaler_scale = None
+        if len(steps) == 2:
+            scaler = steps[0][1]
+            if scaler.with_mean:
+                self.scaler_mean = np.ascontiguousarray(scaler.mean_, dtype=np.float64)
+            if scaler.with_std:
+                self.scaler_scale = np.ascontiguousarray(scaler.scale_, dtype=np.float64)
+        chol = np.ascontiguousarray(gmm.precisions_cholesky_, dtype=np.float64)
+        self.prec_chol = chol
+        self.mu_proj = np.ascontiguousarray([np.dot(mu, pc) for mu, pc in zip(gmm.means_, chol)], dtype=np.float64)
+        self.log_det = np.ascontiguousarray(np.sum(np.log(chol.reshape(n_comp, -1)[:, ::n_feat + 1]), 1), dtype=np.float64)
+        self.log_weights = np.ascontiguousarray(np.log(gmm.weights_), dtype=np.float64)
+        self.const_term = float(n_feat * np.log(2 * np.pi))
+        for name in ('scaler_mean', 'scaler_scale', 'prec_chol', 'mu_proj', 'log_det', 'log_weights'):
+            setattr(par, name, _ptr(getattr(self, name)))
+        par.const_term = self.const_term
+        self.params = par
+
+
 @functools.lru_cache(maxsize=64)
 def gaussian_taps(sigma, truncate=4.0):
     """half of the kernel of ``scipy.ndimage.gaussian_filter1d(sigma)`` (taps[0] = centre), computed
@@ -255,7 +388,80 @@ class Image2D(object):
             image = image.astype(np.float64)
         image = np.ascontiguousarray(image)
         _check(load_library().imsegm_image2d_upload(self._h, _ptr(image), _DTYPES[image.dtype]))
+        self._uploaded = image          # a page-locked source is read asynchronously: keep it alive until the next sync
         return self
+
+    def features_color(self, mean=True, std=True, energy=True, to_host=True):
+        """resident feature table (columns mean | std | energy, 3 each) of the uploaded image on the current labels;
+        returns it as K x F float64 when ``to_host``"""
+        mask = (1 if mean else 0) | (2 if std else 0) | (4 if energy else 0)
+        nflags = bool(mean) + bool(std) + bool(energy)
+        out = np.empty((self.n_labels, 3 * nflags), dtype=np.float64) if to_host else None
+        _check(load_library().imsegm_image2d_features_color(self._h, mask, _ptr(out)))
+        return out
+
+    def segment(self, pairwise, edge_type='model', edge_cost=1., gmm=None, proba=None, use_graphcut=True, classes=None,
+                want_segm=True, want_soft=False, want_graph_labels=False, want_proba=False, debug=False, pinned=True,
+                keep_soft_on_device=False):
+        """fused back half of the pipeline on the resident label map (``imsegm_image2d_segment``): class probabilities
+        (``gmm``: :class:`DeviceGmm` on the resident features, else ``proba`` K x C from the host), unary / edge terms,
+        alpha-expansion, ``classes[graph_labels][slic]`` and ``proba[slic]``; one synchronisation.
+
+        :return dict: 'segm' (H x W int32), 'soft' (H x W x C), 'graph_labels' (K), 'proba' (K x C) as requested, plus
+            with ``debug`` the graph-cut terms ('edges', 'edge_weights', 'edge_weights_int', 'unary', 'unary_int',
+            'centres', 'energy')"""
+        code = EDGE_TYPES.get(edge_type)
+        if code is None:
+            raise ValueError('edge type %r is not evaluated on the device' % (edge_type, ))
+        pairwise = np.ascontiguousarray(pairwise, dtype=np.float64)
+        nc = pairwise.shape[0]
+        if pairwise.shape != (nc, nc):
+            raise ValueError('pairwise cost must be square')
+        k = self.n_labels
+        pr = None
+        if gmm is None:
+            pr = np.ascontiguousarray(proba, dtype=np.float64)
+            if pr.ndim != 2 or pr.shape[0] < k or pr.shape[1] != nc:
+                raise ValueError('proba %r does not fit %d superpixels x %d classes' % (pr.shape, k, nc))
+            pr = np.ascontiguousarray(pr[:k])
+        elif gmm.n_classes != nc:
+            raise ValueError('class model has %d classes, pairwise cost %d' % (gmm.n_classes, nc))
+        cl = None if classes is None else np.ascontiguousarray(classes, dtype=np.int32)
+        if cl is not None and cl.shape != (nc, ):
+            raise ValueError('classes must hold one value per class')
+        alloc = pinned_empty if pinned else np.empty
+        out = {}
+        if want_segm:
+            out['segm'] = alloc(self.shape, np.int32)
+        if want_soft:
+            out['soft'] = alloc(self.shape + (nc, ), np.float64)
+        if want_graph_labels or debug:
+            out['graph_labels'] = np.empty(k, dtype=np.int32)
+        if want_proba or debug:
+            out['proba'] = np.empty((k, nc), dtype=np.float64)
+        dbg = None
+        if debug or keep_soft_on_device:
+            dbg = TermsDebug()
+            dbg.keep_soft_on_device = int(bool(keep_soft_on_device))
+        if debug:
+            cap = (16 if len(self.shape) == 3 else 3) * k + 64
+            ndim = len(self.shape)
+            out.update(edges=np.empty((cap, 2), np.int32), edge_weights=np.empty(cap), edge_weights_int=np.empty(cap, np.int32),
+                       unary=np.empty((k, nc)), unary_int=np.empty((k, nc), np.int32), centres=np.empty((k, ndim)),
+                       energy=np.zeros(1, np.int64))
+            dbg.edge_capacity = cap
+            for name in ('edges', 'edge_weights', 'edge_weights_int', 'unary', 'unary_int', 'centres', 'energy'):
+                setattr(dbg, name, _ptr(out[name]))
+        _check(load_library().imsegm_image2d_segment(
+            self._h, C.byref(gmm.params) if gmm is not None else None, _ptr(pr), nc, _ptr(pairwise), code, float(edge_cost),
+            int(bool(use_graphcut)), _ptr(cl), _ptr(out.get('segm')), _ptr(out.get('soft')), _ptr(out.get('graph_labels')),
+            _ptr(out.get('proba')), C.byref(dbg) if dbg is not None else None))
+        if debug:
+            ne = dbg.n_edges
+            for name in ('edges', 'edge_weights', 'edge_weights_int'):
+                out[name] = out[name][:ne]
+            out['energy'] = int(out['energy'][0])
+        return out
 
     def slic(self, n_segments, compactness, sigma=1., normalize=2, max_iter=10, enforce_connectivity=True,
              min_size_factor=0.5, max_size_factor=3., start_label=0, max_candidates=0, slic_zero=False):

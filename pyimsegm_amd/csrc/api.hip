@@ -46,7 +46,7 @@ struct DevBuf {
     template <typename T> T *as() { return reinterpret_cast<T *>(p); }
 };
 
-enum { PG_ASSIGN = 0, PG_SLIC = 1, PG_CONN = 2, PG_STATS = 3, PG_GRAPH = 4, PG_GC = 5, PG_GATHER = 6, PG_PRE = 7, PG_COUNT = 8 };
+enum { PG_ASSIGN = 0, PG_SLIC = 1, PG_CONN = 2, PG_STATS = 3, PG_GRAPH = 4, PG_GC = 5, PG_GATHER = 6, PG_PRE = 7, PG_TERMS = 8, PG_TEX = 9, PG_COUNT = 10 };
 
 struct Span {
     int group;
@@ -157,7 +157,8 @@ struct imsegm_image2d {
     bool is_volume = false;
     double vol_off = 0.0, vol_scale = 1.0;      // intensity seen by the volume SLIC = (v + off) * scale
     DevBuf img, labA, labB, nearest, labels, conn_i32, conn_u8, small, cent, tiles, feat, graph, gather_lut, gather_out_i, gather_out_f,
-        tex_planes, tex_resp, tex_small, vol_cent, annot, hist;
+        tex_planes, tex_resp, tex_small, vol_cent, annot, hist, featK, seg;
+    int feat_mask = 0, feat_F = 0;              // layout of the resident feature table (imsegm_image2d_features_color)
 };
 
 // entry points are specific to colour images (D == 1) or gray volumes (created by imsegm_volume_create)
@@ -234,7 +235,69 @@ static int fill_taps(Taps &t, const double *w, int r)
     return 0;
 }
 
+static bool is_pinned(const void *p)
+{
+    hipPointerAttribute_t attr;
+    if (hipPointerGetAttributes(&attr, p) != hipSuccess) {
+        (void)hipGetLastError();
+        return false;
+    }
+    return attr.type == hipMemoryTypeHost;
+}
+
 extern "C" {
+
+int imsegm_host_alloc(size_t bytes, void **ptr_out)
+{
+    if (!ptr_out) {
+        set_error("null argument");
+        return -1;
+    }
+    HIP_TRY(hipHostMalloc(ptr_out, bytes ? bytes : 1, hipHostMallocDefault));
+    return 0;
+}
+
+void imsegm_host_free(void *ptr)
+{
+    if (ptr) (void)hipHostFree(ptr);
+}
+
+int imsegm_device_alloc(int device, size_t bytes, void **ptr_out)
+{
+    if (!ptr_out) {
+        set_error("null argument");
+        return -1;
+    }
+    HIP_TRY(hipSetDevice(device));
+    HIP_TRY(hipMalloc(ptr_out, bytes ? bytes : 1));
+    return 0;
+}
+
+void imsegm_device_free(void *ptr)
+{
+    if (ptr) (void)hipFree(ptr);
+}
+
+int imsegm_set_device(int device)
+{
+    HIP_TRY(hipSetDevice(device));
+    return 0;
+}
+
+int imsegm_ctx_stream(imsegm_ctx *ctx, void **stream_out)
+{
+    if (bind(ctx)) return -1;
+    *stream_out = ctx->stream;
+    return 0;
+}
+
+int imsegm_ctx_copy(imsegm_ctx *ctx, void *dst, const void *src, size_t bytes, int synchronize)
+{
+    if (bind(ctx)) return -1;
+    HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDefault, ctx->stream));
+    if (synchronize) HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return 0;
+}
 
 const char *imsegm_last_error(void) { return g_error.c_str(); }
 int imsegm_version(void) { return 100; }
@@ -342,7 +405,7 @@ void imsegm_image2d_destroy(imsegm_image2d *im)
     (void)hipStreamSynchronize(im->ctx->stream);
     DevBuf *all[] = { &im->img, &im->labA, &im->labB, &im->nearest, &im->labels, &im->conn_i32, &im->conn_u8, &im->small,
                       &im->cent, &im->tiles, &im->feat, &im->graph, &im->gather_lut, &im->gather_out_i, &im->gather_out_f,
-                      &im->tex_planes, &im->tex_resp, &im->tex_small, &im->vol_cent, &im->annot, &im->hist };
+                      &im->tex_planes, &im->tex_resp, &im->tex_small, &im->vol_cent, &im->annot, &im->hist, &im->featK, &im->seg };
     for (auto b : all) b->release();
     delete im;
 }
@@ -360,8 +423,11 @@ int imsegm_image2d_upload(imsegm_image2d *im, const void *host_pixels, int dtype
     size_t bytes = im->n * 3 * es;
     if (im->img.ensure(bytes + 16)) return -1;
     HIP_TRY(hipMemcpyAsync(im->img.p, host_pixels, bytes, hipMemcpyHostToDevice, im->ctx->stream));
-    HIP_TRY(hipStreamSynchronize(im->ctx->stream));
+    // a page-locked source (imsegm_host_alloc) is read by the DMA engine when the stream gets there: no wait here,
+    // the caller keeps the buffer untouched until the next call that synchronises (slic does)
+    if (!is_pinned(host_pixels)) HIP_TRY(hipStreamSynchronize(im->ctx->stream));
     im->dtype = dtype;
+    im->feat_mask = 0;
     return 0;
 }
 
@@ -840,8 +906,10 @@ int imsegm_image2d_lm_battery(imsegm_image2d *im, const double *weights, int n_k
     double *d_sum = partial + 1024;
     HIP_TRY(hipMemcpyAsync(d_w, weights, wbytes, hipMemcpyHostToDevice, st));
     HIP_TRY(hipStreamSynchronize(st));
+    int spx = im->ctx->begin(PG_TEX);
     if (launch_filter_battery(im->tex_planes.as<double>(), im->H, im->W, d_w, n_kernels, radius, clip, resp, partial, d_sum, st))
         return -1;
+    im->ctx->end(spx);
     HIP_TRY(hipMemcpyAsync(sum_squares_out, d_sum, 8, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
     return 0;
@@ -1284,6 +1352,304 @@ int imsegm_cut_general_graph(imsegm_ctx *ctx, const int32_t *edges, int n_edges,
         return -1;
     }
     if (energy_out) *energy_out = energy;
+    return 0;
+}
+
+
+// ---------------------------------------------------------------------------------------------------
+// fused back half of the pipeline: statistics -> feature table -> graph -> class model -> graph-cut terms ->
+// alpha-expansion -> gathers, enqueued on the session's stream without a host round trip
+// ---------------------------------------------------------------------------------------------------
+int imsegm_image2d_features_color(imsegm_image2d *im, int feature_mask, double *features_out)
+{
+    if (!im || bind(im->ctx)) return -1;
+    if (!im->have_labels || im->dtype < 0) {
+        set_error("features_color needs an uploaded image and a label map");
+        return -1;
+    }
+    if (feature_mask < 1 || feature_mask > 7) {
+        set_error("features_color: feature_mask is a combination of 1 (mean), 2 (std), 4 (energy)");
+        return -1;
+    }
+    imsegm_ctx *ctx = im->ctx;
+    hipStream_t st = ctx->stream;
+    const int K = im->n_labels;
+    double maxabs = 255.0;
+    if (im->dtype != IMSEGM_U8) {
+        if (im->small.ensure(4096)) return -1;
+        unsigned long long *keys = im->small.as<unsigned long long>();
+        double *minmax = reinterpret_cast<double *>(keys + 2);
+        if (launch_minmax(im->img.p, im->dtype, im->is_volume ? im->n : im->n * 3, keys, minmax, st)) return -1;
+        double mm[2];
+        HIP_TRY(hipMemcpyAsync(mm, minmax, 16, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        maxabs = std::max(fabs(mm[0]), fabs(mm[1]));
+        if (!(maxabs < 1e300)) maxabs = 1e300;
+    }
+    // statistics without the D2H of stats_run
+    size_t fb = (size_t)K * (13 * 8 + 3 * 3 * 8 + 3 * 4) + 256;
+    if (im->feat.ensure(fb)) return -1;
+    unsigned char *b = im->feat.as<unsigned char>();
+    long long *acc = reinterpret_cast<long long *>(b); b += (size_t)K * 13 * 8;
+    double *d_mean = reinterpret_cast<double *>(b); b += (size_t)K * 3 * 8;
+    double *d_energy = reinterpret_cast<double *>(b); b += (size_t)K * 3 * 8;
+    double *d_var = reinterpret_cast<double *>(b); b += (size_t)K * 3 * 8;
+    float *d_mean32 = reinterpret_cast<float *>(b);
+    int sp = ctx->begin(PG_STATS);
+    int rc;
+    if (im->is_volume)      // the gray plane read as all three channels (plane stride 0), the volume as a (D*H) x W image
+        rc = launch_color_stats(im->img.p, im->dtype, im->labels.as<int32_t>(), im->D * im->H, im->W, K, maxabs, (feature_mask & 2) != 0,
+                                acc, d_mean, d_energy, d_var, d_mean32, st, 1, 0, 1.0, 1.0, 0);
+    else
+        rc = launch_color_stats(im->img.p, im->dtype, im->labels.as<int32_t>(), im->H, im->W, K, maxabs, (feature_mask & 2) != 0, acc,
+                                d_mean, d_energy, d_var, d_mean32, st, 0, 0, 1.0, 1.0, -1);
+    if (rc) return -1;
+    const int nflags = ((feature_mask & 1) != 0) + ((feature_mask & 2) != 0) + ((feature_mask & 4) != 0);
+    const int F = 3 * nflags;
+    if (im->featK.ensure((size_t)K * F * 8 + 64)) return -1;
+    if (launch_features_assemble(d_mean, d_energy, d_var, K, feature_mask, im->featK.as<double>(), st)) return -1;
+    ctx->end(sp);
+    im->feat_mask = feature_mask;
+    im->feat_F = F;
+    if (features_out) {
+        HIP_TRY(hipMemcpyAsync(features_out, im->featK.p, (size_t)K * F * 8, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+    }
+    return 0;
+}
+
+int imsegm_image2d_segment(imsegm_image2d *im, const imsegm_gmm *gmm, const double *proba, int n_classes,
+                           const double *pairwise, int edge_type, double edge_cost, int use_graphcut,
+                           const int32_t *classes_lut, int32_t *segm_out, double *soft_out, int32_t *graph_labels_out,
+                           double *proba_out, imsegm_terms_debug *debug_out)
+{
+    if (!im || bind(im->ctx)) return -1;
+    if (!im->have_labels) {
+        set_error("segment needs a label map");
+        return -1;
+    }
+    const int K = im->n_labels, C = n_classes;
+    if (C < 1 || C > 16 || !pairwise || (!gmm && !proba)) {
+        set_error("segment: 1..16 classes, a pairwise matrix and either a class model or probabilities are required");
+        return -1;
+    }
+    int edge_code = edge_type & 0xff;
+    const int spatial_norm = (edge_type & IMSEGM_EDGE_SPATIAL_NORM) ? 1 : 0;
+    if (edge_code < 0 || edge_code > 5) {
+        set_error("segment: unknown edge type");
+        return -1;
+    }
+    const bool need_features = gmm != nullptr || edge_code == 5;
+    if (need_features && im->feat_mask == 0) {
+        set_error("segment: the class model / edge type needs the resident feature table (imsegm_image2d_features_color)");
+        return -1;
+    }
+    const int F = need_features ? im->feat_F : 0;
+    if (gmm && (gmm->n_features != F || gmm->n_classes != C)) {
+        set_error("segment: class model does not match the resident features / number of classes");
+        return -1;
+    }
+    for (int a = 0; a < C; ++a)
+        for (int b = 0; b < C; ++b)
+            if (pairwise[a * C + b] != pairwise[b * C + a]) {
+                set_error("Cost matrix not square or not symmetric");
+                return -1;
+            }
+    if ((double)K * (double)K / 8.0 > 2e9) {
+        set_error("segment: too many labels for the fused path (adjacency bitmap)");
+        return -1;
+    }
+    imsegm_ctx *ctx = im->ctx;
+    hipStream_t st = ctx->stream;
+    const size_t n = im->n;
+    const int ndim = im->is_volume ? 3 : 2;
+    const int words = cdiv(K, 32);
+    const int Ecap = im->is_volume ? 16 * K + 64 : 3 * K + 64;          // planar graph: E <= 3K - 6
+    auto al = [](size_t v) { return (v + 63) & ~(size_t)63; };
+    // ---- host -> device parameter block (one pinned staging copy)
+    const size_t FF = (size_t)F * F;
+    size_t o = 0;
+    const size_t o_pw = o; o += al((size_t)C * C * 8);
+    const size_t o_sm = o; o += al((size_t)C * C * 4);
+    const size_t o_cl = o; o += al((size_t)C * 4);
+    const size_t o_sc = o; o += al((size_t)2 * F * 8);
+    const size_t o_pc = o; o += al((size_t)C * FF * 8);
+    const size_t o_mp = o; o += al((size_t)C * F * 8);
+    const size_t o_ld = o; o += al((size_t)C * 8);
+    const size_t o_lw = o; o += al((size_t)C * 8);
+    const size_t o_pr = o; o += (gmm ? 0 : al((size_t)K * C * 8));
+    const size_t up_bytes = o;
+    // ---- device layout
+    const size_t d_par = 0;
+    size_t d = al(up_bytes);
+    if (gmm) { /* proba lives behind the parameters */ }
+    const size_t d_proba = gmm ? d : d_par + o_pr; if (gmm) d += al((size_t)K * C * 8);
+    const size_t d_unary = d; d += al((size_t)K * C * 8);
+    const size_t d_unary_i = d; d += al((size_t)K * C * 4);
+    const size_t d_w = d; d += al((size_t)Ecap * 8);
+    const size_t d_wi = d; d += al((size_t)Ecap * 4);
+    const size_t d_edist = d; d += al((size_t)Ecap * 8);
+    const size_t d_elen = d; d += al((size_t)Ecap * 8);
+    const size_t d_edges = d; d += al((size_t)Ecap * 8);
+    const size_t d_as = d; d += al((size_t)(K + 1) * 4);
+    const size_t d_at = d; d += al((size_t)Ecap * 8);
+    const size_t d_ar = d; d += al((size_t)Ecap * 8);
+    const size_t d_ea = d; d += al((size_t)Ecap * 8);
+    const size_t d_deg = d; d += al((size_t)K * 4);
+    const size_t d_dlow = d; d += al((size_t)K * 4);
+    const size_t d_es = d; d += al((size_t)K * 4);
+    const size_t d_wp = d; d += al((size_t)K * words * 4);
+    const size_t d_gl = d; d += al((size_t)K * 4);
+    const size_t d_lut = d; d += al((size_t)K * 4);
+    const size_t d_misc = d; d += 256;          // K | E | status | pad | energy (8) | scalars[8] | fstd[2F]
+    const size_t d_fstd = d; d += al((size_t)2 * std::max(F, 1) * 8);
+    const size_t d_bitmap = d; d += al((size_t)K * words * 4);
+    const size_t d_cacc = d; d += al((size_t)K * 4 * 8);
+    const size_t d_cent = d; d += al((size_t)K * 3 * 8);
+    const size_t d_present = d; d += al((size_t)K);
+    const size_t d_work = d; d += al(alpha_expansion_work_bytes(K, Ecap));
+    if (im->seg.ensure(d + 256)) return -1;
+    unsigned char *dev = im->seg.as<unsigned char>();
+    unsigned char *host = static_cast<unsigned char *>(ctx->stage(up_bytes + 64));
+    if (!host) {
+        set_error("cannot allocate pinned staging memory");
+        return -1;
+    }
+    memset(host, 0, up_bytes);
+    memcpy(host + o_pw, pairwise, (size_t)C * C * 8);
+    int32_t *si = reinterpret_cast<int32_t *>(host + o_sm);
+    int smax = 0;
+    double pmax = -DBL_MAX;
+    for (int i = 0; i < C * C; ++i) {
+        si[i] = (int32_t)(pairwise[i] * 100);                 // pygco: smooth cost * 100, truncated
+        smax = std::max(smax, std::abs(si[i]));
+        pmax = std::max(pmax, pairwise[i]);
+    }
+    if (classes_lut) memcpy(host + o_cl, classes_lut, (size_t)C * 4);
+    if (gmm) {
+        if (gmm->scaler_mean) memcpy(host + o_sc, gmm->scaler_mean, (size_t)F * 8);
+        if (gmm->scaler_scale) memcpy(host + o_sc + (size_t)F * 8, gmm->scaler_scale, (size_t)F * 8);
+        memcpy(host + o_pc, gmm->prec_chol, (size_t)C * FF * 8);
+        memcpy(host + o_mp, gmm->mu_proj, (size_t)C * F * 8);
+        memcpy(host + o_ld, gmm->log_det, (size_t)C * 8);
+        memcpy(host + o_lw, gmm->log_weights, (size_t)C * 8);
+    } else {
+        memcpy(host + o_pr, proba, (size_t)K * C * 8);
+    }
+    HIP_TRY(hipMemcpyAsync(dev + d_par, host, up_bytes, hipMemcpyHostToDevice, st));
+    ctx->mark_stage_in_flight();
+    int32_t *misc = reinterpret_cast<int32_t *>(dev + d_misc);
+    int32_t *K_dev = misc, *E_dev = misc + 1, *status = misc + 2;
+    long long *energy = reinterpret_cast<long long *>(dev + d_misc + 16);
+    double *scalars = reinterpret_cast<double *>(dev + d_misc + 64);
+    HIP_TRY(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(misc), K, 1, st));      // K | E = 0 | status = 0 | gc status = 0 | energy
+    HIP_TRY(hipMemsetAsync(misc + 1, 0, 28, st));
+    // ---- graph: bitmap + centres, then the symmetric CSR
+    uint32_t *bitmap = reinterpret_cast<uint32_t *>(dev + d_bitmap);
+    double *centres = reinterpret_cast<double *>(dev + d_cent);
+    int sp = ctx->begin(PG_GRAPH);
+    if (im->is_volume) {
+        if (launch_vol_adjacency(im->labels.as<int32_t>(), im->D, im->H, im->W, K, words, bitmap, reinterpret_cast<long long *>(dev + d_cacc),
+                                 centres, dev + d_present, st))
+            return -1;
+    } else if (launch_adjacency_bitmap(im->labels.as<int32_t>(), im->H, im->W, K, bitmap, reinterpret_cast<long long *>(dev + d_cacc),
+                                       centres, dev + d_present, st)) {
+        return -1;
+    }
+    int32_t *edges = reinterpret_cast<int32_t *>(dev + d_edges);
+    if (launch_graph_csr(bitmap, K_dev, K, words, reinterpret_cast<int32_t *>(dev + d_wp), reinterpret_cast<int32_t *>(dev + d_deg),
+                         reinterpret_cast<int32_t *>(dev + d_dlow), reinterpret_cast<int32_t *>(dev + d_as),
+                         reinterpret_cast<int32_t *>(dev + d_es), E_dev, Ecap, edges, reinterpret_cast<int32_t *>(dev + d_at),
+                         reinterpret_cast<int32_t *>(dev + d_ar), reinterpret_cast<int32_t *>(dev + d_ea), st))
+        return -1;
+    ctx->end(sp);
+    // ---- class probabilities, unary / edge terms, integer energies
+    TermsArgs a;
+    memset(&a, 0, sizeof(a));
+    a.Kp = K_dev; a.Ep = E_dev; a.edge_capacity = Ecap; a.F = F; a.C = C;
+    a.features = need_features ? im->featK.as<double>() : nullptr;
+    a.gmm = gmm ? 1 : 0;
+    if (gmm) {
+        a.scaler_mean = gmm->scaler_mean ? reinterpret_cast<double *>(dev + d_par + o_sc) : nullptr;
+        a.scaler_scale = gmm->scaler_scale ? reinterpret_cast<double *>(dev + d_par + o_sc) + F : nullptr;
+        a.prec_chol = reinterpret_cast<double *>(dev + d_par + o_pc);
+        a.mu_proj = reinterpret_cast<double *>(dev + d_par + o_mp);
+        a.log_det = reinterpret_cast<double *>(dev + d_par + o_ld);
+        a.log_w = reinterpret_cast<double *>(dev + d_par + o_lw);
+        a.const_term = gmm->const_term;
+    }
+    a.proba = reinterpret_cast<double *>(dev + d_proba);
+    a.edge_type = edge_code; a.spatial_norm = spatial_norm; a.edge_cost = edge_cost;
+    a.edges = edges; a.centres = centres; a.ndim = ndim;
+    a.edge_dist = reinterpret_cast<double *>(dev + d_edist); a.edge_len = reinterpret_cast<double *>(dev + d_elen);
+    a.unary = reinterpret_cast<double *>(dev + d_unary); a.weights = reinterpret_cast<double *>(dev + d_w);
+    a.pairwise = reinterpret_cast<double *>(dev + d_par + o_pw); a.pairwise_max = pmax;
+    a.unary_i = reinterpret_cast<int32_t *>(dev + d_unary_i); a.weights_i = reinterpret_cast<int32_t *>(dev + d_wi);
+    a.smooth_max = smax; a.status = status; a.scalars = scalars; a.fstd = reinterpret_cast<double *>(dev + d_fstd);
+    int spt = ctx->begin(PG_TERMS);
+    if (launch_gc_terms(a, st)) return -1;
+    ctx->end(spt);
+    // ---- alpha-expansion (or the argmin of the unary cost for gc_regul <= 0)
+    int32_t *glab = reinterpret_cast<int32_t *>(dev + d_gl);
+    int spg = ctx->begin(PG_GC);
+    if (use_graphcut) {
+        GcProblem p;
+        p.K = K; p.C = C; p.E = Ecap; p.E_dev = E_dev;
+        p.edges = edges; p.w = a.weights_i; p.unary = a.unary_i; p.smooth = reinterpret_cast<int32_t *>(dev + d_par + o_sm);
+        if (launch_alpha_expansion(p, reinterpret_cast<int32_t *>(dev + d_as), reinterpret_cast<int32_t *>(dev + d_at),
+                                   reinterpret_cast<int32_t *>(dev + d_ar), reinterpret_cast<int32_t *>(dev + d_ea), -1, glab, energy,
+                                   status + 1, dev + d_work, st))
+            return -1;
+    } else if (launch_unary_argmin(a.unary, K_dev, K, C, glab, st)) {
+        return -1;
+    }
+    ctx->end(spg);
+    // ---- gathers: classes_[graph_labels][slic] and proba[slic]
+    int32_t *lut = reinterpret_cast<int32_t *>(dev + d_lut);
+    if (launch_label_lut(glab, K_dev, K, classes_lut ? reinterpret_cast<int32_t *>(dev + d_par + o_cl) : nullptr, lut, st)) return -1;
+    if (im->gather_out_i.ensure(n * 4)) return -1;
+    const bool want_soft = soft_out != nullptr || (debug_out && debug_out->keep_soft_on_device);
+    if (want_soft && im->gather_out_f.ensure(n * C * 8)) return -1;
+    int spq = ctx->begin(PG_GATHER);
+    if (launch_gather_labels(lut, im->labels.as<int32_t>(), n, im->gather_out_i.as<int32_t>(), st)) return -1;
+    if (want_soft && launch_gather_proba(a.proba, C, im->labels.as<int32_t>(), n, im->gather_out_f.as<double>(), st)) return -1;
+    ctx->end(spq);
+    // ---- results
+    if (segm_out) HIP_TRY(hipMemcpyAsync(segm_out, im->gather_out_i.p, n * 4, hipMemcpyDeviceToHost, st));
+    if (soft_out) HIP_TRY(hipMemcpyAsync(soft_out, im->gather_out_f.p, n * C * 8, hipMemcpyDeviceToHost, st));
+    if (graph_labels_out) HIP_TRY(hipMemcpyAsync(graph_labels_out, glab, (size_t)K * 4, hipMemcpyDeviceToHost, st));
+    if (proba_out) HIP_TRY(hipMemcpyAsync(proba_out, a.proba, (size_t)K * C * 8, hipMemcpyDeviceToHost, st));
+    int32_t hmisc[4] = { 0, 0, 0, 0 };
+    HIP_TRY(hipMemcpyAsync(hmisc, misc, sizeof(hmisc), hipMemcpyDeviceToHost, st));
+    if (debug_out) {
+        if (debug_out->unary) HIP_TRY(hipMemcpyAsync(debug_out->unary, a.unary, (size_t)K * C * 8, hipMemcpyDeviceToHost, st));
+        if (debug_out->unary_int) HIP_TRY(hipMemcpyAsync(debug_out->unary_int, a.unary_i, (size_t)K * C * 4, hipMemcpyDeviceToHost, st));
+        if (debug_out->centres) HIP_TRY(hipMemcpyAsync(debug_out->centres, centres, (size_t)K * ndim * 8, hipMemcpyDeviceToHost, st));
+        if (debug_out->energy) HIP_TRY(hipMemcpyAsync(debug_out->energy, energy, 8, hipMemcpyDeviceToHost, st));
+    }
+    HIP_TRY(hipStreamSynchronize(st));
+    const int E = hmisc[1];
+    if (debug_out) {
+        debug_out->n_edges = E;
+        const int Ec = std::min(E, debug_out->edge_capacity);
+        if (Ec > 0) {
+            if (debug_out->edges) HIP_TRY(hipMemcpy(debug_out->edges, edges, (size_t)Ec * 8, hipMemcpyDeviceToHost));
+            if (debug_out->edge_weights) HIP_TRY(hipMemcpy(debug_out->edge_weights, a.weights, (size_t)Ec * 8, hipMemcpyDeviceToHost));
+            if (debug_out->edge_weights_int) HIP_TRY(hipMemcpy(debug_out->edge_weights_int, a.weights_i, (size_t)Ec * 4, hipMemcpyDeviceToHost));
+        }
+    }
+    if (hmisc[2] & 2) {
+        set_error("segment: more graph edges than the edge table holds");
+        return -1;
+    }
+    if (use_graphcut && (hmisc[2] & 1)) {
+        set_error("cut_general_graph: smoothness term is larger than GCO_MAX_ENERGYTERM");
+        return -1;
+    }
+    if (use_graphcut && hmisc[3] != 0) {
+        set_error("alpha_expansion: max-flow did not converge");
+        return -1;
+    }
     return 0;
 }
 

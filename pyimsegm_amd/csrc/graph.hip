@@ -142,9 +142,8 @@ __global__ void k_edge_emit(const uint32_t *__restrict__ bitmap, int K, int word
     }
 }
 
-int launch_adjacency_centres(const int32_t *labels, int H, int W, int K, uint32_t *bitmap, long long *cacc,
-                             int32_t *edges_out, int edge_capacity, int32_t *n_edges_dev, double *centres_out,
-                             uint8_t *present_out, int32_t *rowcount, hipStream_t st)
+int launch_adjacency_bitmap(const int32_t *labels, int H, int W, int K, uint32_t *bitmap, long long *cacc, double *centres_out,
+                            uint8_t *present_out, hipStream_t st)
 {
     int words = cdiv(K, 32);
     HIP_TRY(hipMemsetAsync(bitmap, 0, (size_t)K * words * sizeof(uint32_t), st));
@@ -152,7 +151,16 @@ int launch_adjacency_centres(const int32_t *labels, int H, int W, int K, uint32_
     dim3 grid(cdiv(W, 64 * GR_PX), cdiv(H, 4));
     hipLaunchKernelGGL(k_adjacency_centres, grid, 256, 0, st, labels, H, W, K, words, bitmap, cacc);
     hipLaunchKernelGGL(k_centres_finalize, cdiv(K, 256), 256, 0, st, cacc, K, centres_out, present_out);
-    return launch_edge_extract(bitmap, K, words, rowcount, edges_out, edge_capacity, n_edges_dev, st);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int launch_adjacency_centres(const int32_t *labels, int H, int W, int K, uint32_t *bitmap, long long *cacc,
+                             int32_t *edges_out, int edge_capacity, int32_t *n_edges_dev, double *centres_out,
+                             uint8_t *present_out, int32_t *rowcount, hipStream_t st)
+{
+    if (launch_adjacency_bitmap(labels, H, W, K, bitmap, cacc, centres_out, present_out, st)) return -1;
+    return launch_edge_extract(bitmap, K, cdiv(K, 32), rowcount, edges_out, edge_capacity, n_edges_dev, st);
 }
 
 // read the K x K adjacency bitmap out in row-major order: edges [a, b], a < b, sorted by (b, a)

@@ -26,6 +26,7 @@ constexpr int GC_PUSH_ROUNDS = 24;        // lock-free push/relabel sweeps betwe
 
 struct GcDevice {
     int K, C, E, n_iter;
+    const int32_t *E_dev;      // when set: the real number of edges lives on the device, E is its capacity
     const int32_t *edges;      // [E][2]
     const int32_t *w;          // [E]
     const int32_t *unary;      // [K][C]
@@ -230,6 +231,7 @@ __device__ bool gc_expand(const GcDevice &g, int alpha, int *cap, int *height, l
 
 __global__ void __launch_bounds__(GC_THREADS) k_alpha_expansion(GcDevice g)
 {
+    if (g.E_dev) g.E = min(*g.E_dev, g.E);
     extern __shared__ __align__(16) unsigned char dyn[];
     __shared__ long long scratch[GC_THREADS / 64];
     __shared__ long long energy;
@@ -331,7 +333,7 @@ int launch_alpha_expansion(GcProblem p, const int32_t *arc_start, const int32_t 
         set_error("alpha_expansion: more than 64 labels are not supported by the single-workgroup kernel");
         return -1;
     }
-    if (p.E == 0) {
+    if (p.E == 0 && !p.E_dev) {
         HIP_TRY(hipMemsetAsync(energy_dev, 0, sizeof(long long), st));
         hipLaunchKernelGGL(k_unary_argmin, cdiv(p.K, 256), 256, 0, st, p.unary, p.K, p.C, labels_dev, energy_dev);
         HIP_TRY(hipGetLastError());
@@ -339,6 +341,7 @@ int launch_alpha_expansion(GcProblem p, const int32_t *arc_start, const int32_t 
     }
     GcDevice g;
     g.K = p.K; g.C = p.C; g.E = p.E; g.n_iter = n_iter;
+    g.E_dev = p.E_dev;
     g.edges = p.edges; g.w = p.w; g.unary = p.unary; g.smooth = p.smooth;
     g.arc_start = arc_start; g.arc_to = arc_to; g.arc_rev = arc_rev; g.edge_arc = edge_arc;
     g.labels = labels_dev;
@@ -352,14 +355,8 @@ int launch_alpha_expansion(GcProblem p, const int32_t *arc_start, const int32_t 
     size_t lds_need = (size_t)p.K * 8 + ((size_t)2 * p.E + p.K) * 4;
     g.use_lds = lds_need <= 150 * 1024;
     size_t dyn = g.use_lds ? lds_need : 0;
-    if (dyn > 48 * 1024) {
-        static bool attr_set = false;
-        if (!attr_set) {
-            HIP_TRY(hipFuncSetAttribute((const void *)k_alpha_expansion, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                        150 * 1024));
-            attr_set = true;
-        }
-    }
+    if (dyn > 48 * 1024)      // the opt-in is per device and cheap: set it on every launch that needs it
+        HIP_TRY(hipFuncSetAttribute((const void *)k_alpha_expansion, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
     hipLaunchKernelGGL(k_alpha_expansion, 1, GC_THREADS, dyn, st, g);
     HIP_TRY(hipGetLastError());
     return 0;

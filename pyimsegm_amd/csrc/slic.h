@@ -163,12 +163,16 @@ int launch_filter_battery(const double *planes, int H, int W, const double *wgt_
 int launch_adjacency_centres(const int32_t *labels, int H, int W, int K, uint32_t *bitmap, long long *cacc,
                              int32_t *edges_out, int edge_capacity, int32_t *n_edges_dev, double *centres_out,
                              uint8_t *present_out, int32_t *rowcount, hipStream_t st);
+// bitmap (row b, column a < b) + centre sums only; launch_adjacency_centres = this + launch_edge_extract
+int launch_adjacency_bitmap(const int32_t *labels, int H, int W, int K, uint32_t *bitmap, long long *cacc, double *centres_out,
+                            uint8_t *present_out, hipStream_t st);
 int launch_gather_labels(const int32_t *lut, const int32_t *idx, size_t n, int32_t *out, hipStream_t st);
 int launch_gather_proba(const double *lut, int C, const int32_t *idx, size_t n, double *out, hipStream_t st);
 
 // graphcut.hip ------------------------------------------------------------------------------------
 struct GcProblem {
-    int K, C, E;
+    int K, C, E;            // E: number of edges, or their capacity when E_dev is given
+    const int32_t *E_dev = nullptr;   // number of edges on the device (fused pipeline: no host round trip)
     const int32_t *edges;   // [E][2], a < b
     const int32_t *w;       // [E]
     const int32_t *unary;   // [K][C]
@@ -178,5 +182,50 @@ int launch_alpha_expansion(GcProblem p, const int32_t *arc_start, const int32_t 
                            const int32_t *edge_arc, int n_iter, int32_t *labels_dev, long long *energy_dev,
                            int32_t *status_dev, void *work, hipStream_t st);
 size_t alpha_expansion_work_bytes(int K, int E);
+
+// terms.hip ---------------------------------------------------------------------------------------
+struct TermsArgs {
+    const int *Kp;                 // number of superpixels (device)
+    const int *Ep;                 // number of edges (device)
+    int edge_capacity;
+    int F, C;
+    const double *features;        // [K][F]
+    // class model (gmm != 0): StandardScaler + full-covariance Gaussian mixture
+    int gmm;
+    const double *scaler_mean, *scaler_scale;   // [F] or null
+    const double *prec_chol;       // [C][F][F]
+    const double *mu_proj;         // [C][F] = means @ prec_chol (host, as scikit-learn forms it)
+    const double *log_det;         // [C]
+    const double *log_w;           // [C]
+    double const_term;             // F * log(2 pi)
+    double *proba;                 // [K][C] in (gmm == 0) / out
+    // edges
+    int edge_type;                 // 0 const, 1 spatial, 2 model lT, 3 model l1, 4 model l2, 5 features
+    int spatial_norm;              // divide by the relative centre distance (graph_cuts.py:647: only 'model', 'features', 'spatial')
+    double edge_cost;
+    const int32_t *edges;          // [E][2]
+    const double *centres;         // [K][ndim]
+    int ndim;
+    double *edge_dist, *edge_len;  // [E] scratch
+    // outputs
+    double *unary;                 // [K][C]
+    double *weights;               // [E]
+    const double *pairwise;        // [C][C]
+    double pairwise_max;
+    int32_t *unary_i, *weights_i;  // pyGCO integers
+    int smooth_max;                // max |int(pairwise * 100)|
+    int32_t *status;               // bit 0: smoothness term above GCO_MAX_ENERGYTERM, bit 1: edge list overflow
+    double *scalars;               // [8] debug: mean len, mean dist, std dist, umax, wmax, dwf
+    double *fstd;                  // [2][F] scratch (edge type 'features')
+};
+int launch_features_assemble(const double *mean, const double *energy, const double *var, int K, int mask, double *out,
+                             hipStream_t st);
+// symmetric bitmap -> edge list ordered by (b, a), CSR arcs in ascending neighbour order, reverse arcs, edge -> arc table
+int launch_graph_csr(uint32_t *bitmap, const int *K_dev, int K_cap, int words, int32_t *wordprefix, int32_t *deg, int32_t *deg_low,
+                     int32_t *arc_start, int32_t *edge_start, int32_t *n_edges_dev, int edge_capacity, int32_t *edges,
+                     int32_t *arc_to, int32_t *arc_rev, int32_t *edge_arc, hipStream_t st);
+int launch_gc_terms(const TermsArgs &a, hipStream_t st);
+int launch_unary_argmin(const double *unary, const int *K_dev, int K_cap, int C, int32_t *labels, hipStream_t st);
+int launch_label_lut(const int32_t *graph_labels, const int *K_dev, int K_cap, const int32_t *classes, int32_t *lut, hipStream_t st);
 
 }  // namespace imsegm

@@ -1,0 +1,423 @@
+// terms.hip -- everything between the descriptors and the graph cut, on the device: feature table, class
+// probabilities of a Gaussian mixture, unary / edge terms, their pyGCO integer form and the CSR arc structure of the
+// superpixel graph.  With these the whole chain  label map -> statistics -> graph -> terms -> alpha-expansion ->
+// gathers  is enqueued on one stream without a host round trip (api.hip imsegm_image2d_segment).
+//
+// Replaces, in /root/reference/imsegm/graph_cuts.py:
+//   model.predict_proba(features)  for sklearn Pipeline([StandardScaler,] GaussianMixture(covariance_type='full'))
+//       (:73-163 estim_class_model builds exactly this; pipelines.py:96,232 call it)
+//   compute_unary_cost :523-540, compute_edge_model :383-439, compute_spatial_dist :303-336,
+//   compute_edge_weights :616-657 (edge types '', const, spatial, model[_l1|_l2|_lT], features), edge_cost :722
+// and the float -> integer conversion of gco-wrapper's pygco.cut_general_graph (down_weight_factor, truncation).
+// Arithmetic: fp64, one rounding per operation (-ffp-contract=off), formula order of numpy / scikit-learn; sums run in
+// a fixed tree order (numpy uses pairwise summation, BLAS its own order): class probabilities agree with scikit-learn
+// to ~1e-13, edge weights to ~1e-15 relative (tests: 1e-9 / 1e-12) -- the integer energies are identical unless a
+// scaled cost lies within that distance of an integer.
+#include "slic.h"
+
+namespace imsegm {
+
+constexpr int TM_THREADS = 1024;
+
+__device__ __forceinline__ double block_reduce_f64(double v, double *scratch, bool is_max)
+{
+    // fixed order: lanes of a wave by xor butterfly, then the 16 wave results in index order
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const double o = __shfl_xor(v, off, 64);
+        v = is_max ? fmax(v, o) : v + o;
+    }
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) scratch[threadIdx.x >> 6] = v;
+    __syncthreads();
+    double t = scratch[0];
+    for (int i = 1; i < TM_THREADS / 64; ++i) t = is_max ? fmax(t, scratch[i]) : t + scratch[i];
+    __syncthreads();
+    return t;
+}
+
+// ---- feature table [K][F] from the statistics of stats.hip: columns mean | std | energy (descriptors.py:787-863 order),
+// np.nan_to_num and the -0 -> +0 of descriptors.py:1265 applied
+__global__ void __launch_bounds__(256)
+k_features_assemble(const double *__restrict__ mean, const double *__restrict__ energy, const double *__restrict__ var, int K,
+                    int mask, int F, double *__restrict__ out)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= K * 3) return;
+    const int k = i / 3, ch = i - 3 * k;
+    int col = ch;
+    auto put = [&](double v) {
+        if (v != v) v = 0.0;                                          // nan_to_num
+        else if (v > DBL_MAX) v = DBL_MAX;
+        else if (v < -DBL_MAX) v = -DBL_MAX;
+        if (v == 0.0) v = 0.0;                                        // -0 -> +0
+        out[(size_t)k * F + col] = v;
+        col += 3;
+    };
+    if (mask & 1) put(mean[i]);
+    if (mask & 2) put(sqrt(var[i]));
+    if (mask & 4) put(energy[i]);
+}
+
+// ---- symmetric adjacency: the pixel pass sets bit (row b, column a) for a < b; mirror it so that row v lists ALL
+// neighbours of v in ascending order -- the order in which the host CSR of round 1 held the arcs of v (edges sorted
+// by (b, a): first the edges whose larger end is v, then those whose smaller end is v)
+__global__ void __launch_bounds__(256)
+k_adj_symmetrize(uint32_t *bitmap, const int *__restrict__ Kp, int words)
+{
+    const int K = *Kp;
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+    for (int b = wave; b < K; b += (gridDim.x * blockDim.x) >> 6) {
+        for (int w = lane; w <= (b >> 5) && w < words; w += 64) {
+            uint32_t bits = bitmap[(size_t)b * words + w];
+            if (w == (b >> 5)) bits &= (1u << (b & 31)) - 1u;         // columns below b only
+            while (bits) {
+                const int a = w * 32 + __ffs(bits) - 1;
+                bits &= bits - 1;
+                atomicOr(bitmap + (size_t)a * words + (b >> 5), 1u << (b & 31));
+            }
+        }
+    }
+}
+
+// per row: exclusive popcount prefix per word, degree, number of lower neighbours
+__global__ void __launch_bounds__(256)
+k_adj_rowprefix(const uint32_t *__restrict__ bitmap, const int *__restrict__ Kp, int words, int32_t *__restrict__ wordprefix,
+                int32_t *__restrict__ deg, int32_t *__restrict__ deg_low)
+{
+    const int K = *Kp;
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+    for (int v = wave; v < K; v += (gridDim.x * blockDim.x) >> 6) {
+        int carry = 0, low = 0;
+        for (int w0 = 0; w0 < words; w0 += 64) {
+            const int w = w0 + lane;
+            const uint32_t bits = w < words ? bitmap[(size_t)v * words + w] : 0u;
+            const int c = __popc(bits);
+            int incl = c;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const int t = __shfl_up(incl, off, 64);
+                if (lane >= off) incl += t;
+            }
+            if (w < words) wordprefix[(size_t)v * words + w] = carry + incl - c;
+            int lowc = 0;
+            if (w < (v >> 5)) lowc = c;
+            else if (w == (v >> 5)) lowc = __popc(bits & ((1u << (v & 31)) - 1u));
+            low += wave_sum_i32(lowc);
+            carry += __shfl(incl, 63, 64);
+        }
+        if (lane == 0) {
+            deg[v] = carry;
+            deg_low[v] = low;
+        }
+    }
+}
+
+// exclusive scans of deg_low (-> first edge index of row v) and deg (-> arc_start) by one workgroup
+__global__ void __launch_bounds__(256)
+k_adj_scan(const int *__restrict__ Kp, const int32_t *__restrict__ deg, const int32_t *__restrict__ deg_low, int32_t *arc_start,
+           int32_t *edge_start, int32_t *n_edges)
+{
+    __shared__ int wsum[2][4];
+    __shared__ int carry[2];
+    const int K = *Kp;
+    if (threadIdx.x < 2) carry[threadIdx.x] = 0;
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int base = 0; base < K; base += 256) {
+        const int i = base + threadIdx.x;
+        const int v0 = i < K ? deg[i] : 0, v1 = i < K ? deg_low[i] : 0;
+        int i0 = v0, i1 = v1;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int t0 = __shfl_up(i0, off, 64), t1 = __shfl_up(i1, off, 64);
+            if (lane >= off) {
+                i0 += t0;
+                i1 += t1;
+            }
+        }
+        if (lane == 63) {
+            wsum[0][wave] = i0;
+            wsum[1][wave] = i1;
+        }
+        __syncthreads();
+        int p0 = carry[0], p1 = carry[1];
+        for (int w = 0; w < wave; ++w) {
+            p0 += wsum[0][w];
+            p1 += wsum[1][w];
+        }
+        if (i < K) {
+            arc_start[i] = p0 + i0 - v0;
+            edge_start[i] = p1 + i1 - v1;
+        }
+        __syncthreads();
+        if (threadIdx.x == 255) {
+            carry[0] = p0 + i0;
+            carry[1] = p1 + i1;
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        arc_start[K] = carry[0];
+        *n_edges = carry[1];
+    }
+}
+
+// arcs, reverse arcs, edge list (a < b, ordered by (b, a)) and the edge -> arc table
+__global__ void __launch_bounds__(256)
+k_adj_emit(const uint32_t *__restrict__ bitmap, const int *__restrict__ Kp, int words, const int32_t *__restrict__ wordprefix,
+           const int32_t *__restrict__ arc_start, const int32_t *__restrict__ edge_start, int edge_capacity,
+           int32_t *__restrict__ edges, int32_t *__restrict__ arc_to, int32_t *__restrict__ arc_rev, int32_t *__restrict__ edge_arc)
+{
+    const int K = *Kp;
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+    for (int v = wave; v < K; v += (gridDim.x * blockDim.x) >> 6) {
+        const int a0 = arc_start[v], e0 = edge_start[v];
+        for (int w = lane; w < words; w += 64) {
+            uint32_t bits = bitmap[(size_t)v * words + w];
+            int t = wordprefix[(size_t)v * words + w];
+            while (bits) {
+                const int u = w * 32 + __ffs(bits) - 1;
+                bits &= bits - 1;
+                const int pos = a0 + t;
+                const int rev = arc_start[u] + wordprefix[(size_t)u * words + (v >> 5)] +
+                                __popc(bitmap[(size_t)u * words + (v >> 5)] & ((1u << (v & 31)) - 1u));
+                if (pos < 2 * edge_capacity) {
+                    arc_to[pos] = u;
+                    arc_rev[pos] = rev;
+                }
+                if (u < v) {                                    // lower neighbours come first: t is the rank inside the row
+                    const int j = e0 + t;
+                    if (j < edge_capacity) {
+                        edges[2 * j] = u;
+                        edges[2 * j + 1] = v;
+                        edge_arc[2 * j] = rev;                  // arc u -> v
+                        edge_arc[2 * j + 1] = pos;              // arc v -> u
+                    }
+                }
+                ++t;
+            }
+        }
+    }
+}
+
+// ---- class probabilities + graph-cut terms: ONE workgroup (K ~ 2e3 rows, E ~ 6e3 edges: a few microseconds; the
+// phases need grid-wide reductions of a handful of scalars, which a single workgroup gets from __syncthreads)
+
+__global__ void __launch_bounds__(TM_THREADS) k_gc_terms(TermsArgs a)
+{
+    __shared__ double scratch[TM_THREADS / 64];
+    const int K = *a.Kp, C = a.C, F = a.F;
+    int E = *a.Ep;
+    if (E > a.edge_capacity) {
+        if (threadIdx.x == 0) atomicOr(a.status, 2);
+        E = a.edge_capacity;
+    }
+    // 1. predict_proba: StandardScaler.transform, GaussianMixture._estimate_weighted_log_prob, logsumexp, exp
+    if (a.gmm) {
+        for (int k = threadIdx.x; k < K; k += TM_THREADS) {
+            double x[32];
+            for (int f = 0; f < F; ++f) {
+                double v = a.features[(size_t)k * F + f];
+                if (a.scaler_mean) v = v - a.scaler_mean[f];
+                if (a.scaler_scale) v = v / a.scaler_scale[f];
+                x[f] = v;
+            }
+            double wl[16];
+            double amax = -INFINITY;
+            for (int c = 0; c < C; ++c) {
+                const double *P = a.prec_chol + (size_t)c * F * F;
+                double lp = 0.0;
+                for (int j = 0; j < F; ++j) {
+                    double y = 0.0;
+                    for (int f = 0; f < F; ++f) y += x[f] * P[f * F + j];
+                    y = y - a.mu_proj[c * F + j];
+                    lp += y * y;
+                }
+                const double lg = -0.5 * (a.const_term + lp) + a.log_det[c];
+                wl[c] = lg + a.log_w[c];
+                amax = fmax(amax, wl[c]);
+            }
+            if (!(fabs(amax) <= DBL_MAX)) amax = 0.0;            // scipy.special.logsumexp: non-finite maximum -> 0
+            double s = 0.0;
+            for (int c = 0; c < C; ++c) s += exp(wl[c] - amax);
+            const double lse = log(s) + amax;
+            for (int c = 0; c < C; ++c) a.proba[(size_t)k * C + c] = exp(wl[c] - lse);
+        }
+        __syncthreads();
+    }
+    // 2. unary cost |-log(clip(p, 0.01, 0.99))| and its maximum
+    double umax = 0.0;
+    for (int i = threadIdx.x; i < K * C; i += TM_THREADS) {
+        double p = a.proba[i];
+        if (p < 0.01) p = 0.01;
+        if (p > 1 - 0.01) p = 1 - 0.01;
+        const double u = fabs(-log(p));
+        a.unary[i] = u;
+        umax = fmax(umax, u);
+    }
+    umax = block_reduce_f64(umax, scratch, true);
+    // 3. edge type 'features': StandardScaler().fit_transform(features) -- per-column mean and population std
+    if (a.edge_type == 5) {
+        for (int f = 0; f < F; ++f) {
+            double s = 0.0;
+            for (int k = threadIdx.x; k < K; k += TM_THREADS) s += a.features[(size_t)k * F + f];
+            const double mean = block_reduce_f64(s, scratch, false) / (double)K;
+            double q = 0.0;
+            for (int k = threadIdx.x; k < K; k += TM_THREADS) {
+                const double d = a.features[(size_t)k * F + f] - mean;
+                q += d * d;
+            }
+            double sd = sqrt(block_reduce_f64(q, scratch, false) / (double)K);
+            if (sd == 0.0) sd = 1.0;                              // sklearn _handle_zeros_in_scale
+            if (threadIdx.x == 0) {
+                a.fstd[f] = mean;
+                a.fstd[F + f] = sd;
+            }
+        }
+        __syncthreads();
+    }
+    // 4. per edge: distance of the end points in the chosen space + Euclidean distance of the centres
+    double sum_len = 0.0, sum_dist = 0.0;
+    for (int j = threadIdx.x; j < E; j += TM_THREADS) {
+        const int p = a.edges[2 * j], q = a.edges[2 * j + 1];
+        double len = 0.0;
+        for (int d = 0; d < a.ndim; ++d) {
+            double cp = a.centres[(size_t)p * a.ndim + d], cq = a.centres[(size_t)q * a.ndim + d];
+            const double t = cp - cq;
+            len += t * t;
+        }
+        len = sqrt(len);
+        double dist = 0.0;
+        if (a.edge_type >= 2 && a.edge_type <= 4) {
+            for (int c = 0; c < C; ++c) {
+                const double t = a.proba[(size_t)p * C + c] - a.proba[(size_t)q * C + c];
+                if (a.edge_type == 2) dist = fmax(dist, t * t);           // lT: max squared difference
+                else if (a.edge_type == 3) dist += fabs(t);               // l1
+                else dist += t * t;                                       // l2 (root below)
+            }
+            if (a.edge_type == 4) dist = sqrt(dist);
+        } else if (a.edge_type == 5) {
+            for (int f = 0; f < F; ++f) {
+                const double xp = (a.features[(size_t)p * F + f] - a.fstd[f]) / a.fstd[F + f];
+                const double xq = (a.features[(size_t)q * F + f] - a.fstd[f]) / a.fstd[F + f];
+                const double t = xp - xq;
+                dist += t * t;
+            }
+            dist = sqrt(dist);
+        }
+        a.edge_len[j] = len;
+        a.edge_dist[j] = dist;
+        sum_len += len;
+        sum_dist += dist;
+    }
+    const double mean_len = block_reduce_f64(sum_len, scratch, false) / (double)E;
+    const double mean_dist = block_reduce_f64(sum_dist, scratch, false) / (double)E;
+    double q = 0.0;
+    for (int j = threadIdx.x; j < E; j += TM_THREADS) {
+        const double d = a.edge_dist[j] - mean_dist;
+        q += d * d;
+    }
+    const double std_dist = sqrt(block_reduce_f64(q, scratch, false) / (double)E);
+    // 5. weights: exp(-dist / (2 std^2)) | 1, divided by the relative centre distance, clipped, times edge_cost
+    const double denom = 2 * (std_dist * std_dist);
+    double wmax = 0.0;
+    for (int j = threadIdx.x; j < E; j += TM_THREADS) {
+        double w = 1.0;
+        if (a.edge_type >= 2) w = exp(-a.edge_dist[j] / denom);
+        if (a.spatial_norm) w = w / (a.edge_len[j] / mean_len);
+        if (w < 1. / 1e3) w = 1. / 1e3;
+        if (w > 1e3) w = 1e3;
+        w = w * a.edge_cost;
+        a.weights[j] = w;
+        wmax = fmax(wmax, fabs(w));
+    }
+    wmax = block_reduce_f64(wmax, scratch, true);
+    // 6. pygco.cut_general_graph: down_weight_factor, integer energies by truncation
+    const double dwf = ((E > 0 && wmax * a.pairwise_max > umax) ? wmax * a.pairwise_max : umax) + 1e-10;
+    for (int i = threadIdx.x; i < K * C; i += TM_THREADS) a.unary_i[i] = (int32_t)((a.unary[i] / dwf) * 100000);
+    int bad = 0;
+    for (int j = threadIdx.x; j < E; j += TM_THREADS) {
+        const int32_t wi = (int32_t)((a.weights[j] / dwf) * 1000);
+        a.weights_i[j] = wi;
+        if ((long long)abs(wi) * a.smooth_max > 10000000LL) bad = 1;     // GCO_MAX_ENERGYTERM
+    }
+    if (bad) atomicOr(a.status, 1);
+    if (threadIdx.x == 0) {
+        a.scalars[0] = mean_len; a.scalars[1] = mean_dist; a.scalars[2] = std_dist;
+        a.scalars[3] = umax; a.scalars[4] = wmax; a.scalars[5] = dwf;
+    }
+}
+
+// gc_regul <= 0: argmin of the unary cost (graph_cuts.py:729-731), first minimum wins as np.argmin
+__global__ void __launch_bounds__(256)
+k_unary_argmin_f64(const double *__restrict__ unary, const int *__restrict__ Kp, int C, int32_t *__restrict__ labels)
+{
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= *Kp) return;
+    int best = 0;
+    for (int c = 1; c < C; ++c)
+        if (unary[(size_t)k * C + c] < unary[(size_t)k * C + best]) best = c;
+    labels[k] = best;
+}
+
+// LUT of the final gather: classes_[graph_labels] (pipelines.py:238) or the graph labels themselves
+__global__ void __launch_bounds__(256)
+k_label_lut(const int32_t *__restrict__ graph_labels, const int *__restrict__ Kp, const int32_t *__restrict__ classes,
+            int32_t *__restrict__ lut)
+{
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= *Kp) return;
+    const int l = graph_labels[k];
+    lut[k] = classes ? classes[l] : l;
+}
+
+int launch_features_assemble(const double *mean, const double *energy, const double *var, int K, int mask, double *out,
+                             hipStream_t st)
+{
+    const int F = 3 * (((mask & 1) != 0) + ((mask & 2) != 0) + ((mask & 4) != 0));
+    hipLaunchKernelGGL(k_features_assemble, cdiv((long)K * 3, 256), 256, 0, st, mean, energy, var, K, mask, F, out);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int launch_graph_csr(uint32_t *bitmap, const int *K_dev, int K_cap, int words, int32_t *wordprefix, int32_t *deg, int32_t *deg_low,
+                     int32_t *arc_start, int32_t *edge_start, int32_t *n_edges_dev, int edge_capacity, int32_t *edges,
+                     int32_t *arc_to, int32_t *arc_rev, int32_t *edge_arc, hipStream_t st)
+{
+    const int grid = std::min(cdiv((long)K_cap * 64, 256), 4096);
+    hipLaunchKernelGGL(k_adj_symmetrize, grid, 256, 0, st, bitmap, K_dev, words);
+    hipLaunchKernelGGL(k_adj_rowprefix, grid, 256, 0, st, bitmap, K_dev, words, wordprefix, deg, deg_low);
+    hipLaunchKernelGGL(k_adj_scan, 1, 256, 0, st, K_dev, deg, deg_low, arc_start, edge_start, n_edges_dev);
+    hipLaunchKernelGGL(k_adj_emit, grid, 256, 0, st, bitmap, K_dev, words, wordprefix, arc_start, edge_start, edge_capacity,
+                       edges, arc_to, arc_rev, edge_arc);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int launch_gc_terms(const TermsArgs &a, hipStream_t st)
+{
+    if (a.F > 32 || a.C > 16) {
+        set_error("device class model: at most 32 features and 16 classes");
+        return -1;
+    }
+    hipLaunchKernelGGL(k_gc_terms, 1, TM_THREADS, 0, st, a);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int launch_unary_argmin(const double *unary, const int *K_dev, int K_cap, int C, int32_t *labels, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_unary_argmin_f64, cdiv(K_cap, 256), 256, 0, st, unary, K_dev, C, labels);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int launch_label_lut(const int32_t *graph_labels, const int *K_dev, int K_cap, const int32_t *classes, int32_t *lut, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_label_lut, cdiv(K_cap, 256), 256, 0, st, graph_labels, K_dev, classes, lut);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+}  // namespace imsegm

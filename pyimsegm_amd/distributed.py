@@ -1,131 +1,508 @@
-"""Multi-GPU plumbing: one process per GPU, images of a batch sharded across ranks, results
-gathered on rank 0 (RCCL over xGMI when the backend is ``nccl``; ``gloo`` on CPU for tests).
+"""Multi-GPU plumbing: one process per GPU, images of a batch sharded across ranks, label maps gathered on rank 0.
 
-The reference's only parallelism is a process pool over images
-(``imsegm/utilities/experiments.py:392-403``, used at ``pipelines.py:142-150``); this is its multi-GPU
-counterpart.  The hot path itself has no data-path collective: every image is segmented entirely on
-one GPU.  ``torch`` is used for the process group only.
+The reference's only parallelism is a process pool over images (``imsegm/utilities/experiments.py:392-403``, used at
+``pipelines.py:142-150``); this is its multi-GPU counterpart.  The hot path itself has no data-path
+collective: every image is segmented entirely on one GPU.  Two planes, neither of them PyTorch:
+
+* **data plane** -- RCCL, bound directly with ctypes (``librccl.so``: ``ncclGetUniqueId``, ``ncclCommInitRank``, grouped
+  ``ncclSend`` / ``ncclRecv``): label maps travel from every rank's HBM to rank 0's HBM over xGMI, a whole round of
+  images per call, on the stream of the calling context (:class:`DeviceGather`);
+* **control plane** -- a few small host-side exchanges (barrier, maximum of a float, the RCCL unique id, feature
+  matrices / model parameters of the group model): length-prefixed pickles over a Unix-domain socket with rank 0 as the
+  hub (one node, as the benchmark contract says; :class:`_Star`).  The same plane carries numpy arrays when no GPU is
+  present -- that is what the world-size-2 CPU tests run on.
+
+Ranks are taken from the environment a launcher such as ``python -m torch.distributed.run`` sets (``RANK``,
+``LOCAL_RANK``, ``WORLD_SIZE``, ``MASTER_PORT``); nothing of ``torch`` is imported.
 """
+import ctypes as C
 import os
+import pickle
+import socket
+import struct
+import time
 
 import numpy as np
 
 
-class Group(object):
-    """thin wrapper around ``torch.distributed`` that degrades to a single process"""
+# ---------------------------------------------------------------------------------------------------------
+# control plane
+# ---------------------------------------------------------------------------------------------------------
+def _send_msg(sock, data):
+    sock.sendall(struct.pack('<Q', len(data)))
+    sock.sendall(data)
 
-    def __init__(self, backend=None):
-        self.world = int(os.environ.get('WORLD_SIZE', '1'))
-        self.rank = int(os.environ.get('RANK', '0'))
+
+def _recv_exact(sock, size):
+    chunks = []
+    while size:
+        chunk = sock.recv(min(size, 1 << 20))
+        if not chunk:
+            raise ConnectionError('peer closed the control connection')
+        chunks.append(chunk)
+        size -= len(chunk)
+    return b''.join(chunks)
+
+
+def _recv_msg(sock):
+    size, = struct.unpack('<Q', _recv_exact(sock, 8))
+    return _recv_exact(sock, size)
+
+
+class _Star(object):
+    """host-side exchanges of one node: rank 0 listens on a Unix-domain socket, every other rank keeps one connection"""
+
+    def __init__(self, rank, world, timeout=300.):
+        self.rank, self.world = rank, world
+        tag = '%s-%s' % (os.environ.get('MASTER_PORT', '0'), os.environ.get('TORCHELASTIC_RUN_ID', 'run'))
+        tag = ''.join(ch if ch.isalnum() or ch in '-_' else '_' for ch in tag)[:60]
+        self.path = os.environ.get('IMSEGM_COMM_SOCKET', '/tmp/imsegm-%d-%s.sock' % (os.getuid(), tag))
+        self.peers = {}
+        self.sock = None
+        deadline = time.time() + timeout
+        if rank == 0:
+            try:
+                os.unlink(self.path)
+            except OSError:
+                pass
+            srv = socket.socket(socket.AF_UNIX, socket.SOCK_STREAM)
+            srv.bind(self.path)
+            srv.listen(world)
+            srv.settimeout(timeout)
+            self.server = srv
+            while len(self.peers) < world - 1:
+                conn, _ = srv.accept()
+                conn.settimeout(None)
+                peer, = struct.unpack('<i', _recv_exact(conn, 4))
+                self.peers[peer] = conn
+        else:
+            while True:
+                sock = socket.socket(socket.AF_UNIX, socket.SOCK_STREAM)
+                try:
+                    sock.connect(self.path)
+                    sock.sendall(struct.pack('<i', rank))
+                    self.sock = sock
+                    break
+                except OSError:
+                    sock.close()
+                    if time.time() > deadline:
+                        raise RuntimeError('rank %d: no control connection to rank 0 at %s' % (rank, self.path))
+                    time.sleep(0.05)
+
+    def gather(self, data):
+        """bytes of every rank on rank 0 (list indexed by rank), None elsewhere"""
+        if self.rank == 0:
+            out = [data] + [None] * (self.world - 1)
+            for peer, conn in self.peers.items():
+                out[peer] = _recv_msg(conn)
+            return out
+        _send_msg(self.sock, data)
+        return None
+
+    def bcast(self, data):
+        """bytes of rank 0 on every rank"""
+        if self.rank == 0:
+            for conn in self.peers.values():
+                _send_msg(conn, data)
+            return data
+        return _recv_msg(self.sock)
+
+    def close(self):
+        if self.rank == 0:
+            for conn in self.peers.values():
+                conn.close()
+            self.server.close()
+            try:
+                os.unlink(self.path)
+            except OSError:
+                pass
+        elif self.sock is not None:
+            self.sock.close()
+
+
+# ---------------------------------------------------------------------------------------------------------
+# data plane: RCCL through ctypes
+# ---------------------------------------------------------------------------------------------------------
+class _NcclUniqueId(C.Structure):
+    _fields_ = [('internal', C.c_char * 128)]
+
+
+NCCL_INT8, NCCL_UINT8, NCCL_INT32, NCCL_FLOAT64 = 0, 1, 2, 8
+
+
+class Rccl(object):
+    """one RCCL communicator of this process (``ncclCommInitRank`` over all ranks of the group)"""
+
+    def __init__(self, group):
+        path = os.environ.get('IMSEGM_RCCL_LIBRARY', '')
+        names = [path] if path else ['librccl.so', 'librccl.so.1', '/opt/rocm/lib/librccl.so']
+        lib = None
+        for name in names:
+            try:
+                lib = C.CDLL(name)
+                break
+            except OSError:
+                continue
+        if lib is None:
+            raise RuntimeError('librccl.so not found')
+        vp = C.c_void_p
+        lib.ncclGetErrorString.restype = C.c_char_p
+        lib.ncclGetErrorString.argtypes = [C.c_int]
+        lib.ncclGetUniqueId.argtypes = [C.POINTER(_NcclUniqueId)]
+        lib.ncclCommInitRank.argtypes = [C.POINTER(vp), C.c_int, _NcclUniqueId, C.c_int]
+        lib.ncclCommDestroy.argtypes = [vp]
+        lib.ncclSend.argtypes = [vp, C.c_size_t, C.c_int, C.c_int, vp, vp]
+        lib.ncclRecv.argtypes = [vp, C.c_size_t, C.c_int, C.c_int, vp, vp]
+        lib.ncclGroupStart.argtypes = []
+        lib.ncclGroupEnd.argtypes = []
+        for fn in ('ncclGetUniqueId', 'ncclCommInitRank', 'ncclCommDestroy', 'ncclSend', 'ncclRecv', 'ncclGroupStart', 'ncclGroupEnd'):
+            getattr(lib, fn).restype = C.c_int
+        self.lib, self.group = lib, group
+        self.comm = None
+
+    def connect(self):
+        """collective over all ranks: unique id from rank 0 over the control plane, ``ncclCommInitRank``"""
+        from pyimsegm_amd import _hip
+        lib, group = self.lib, self.group
+        _hip._check(_hip.load_library().imsegm_set_device(group.device_index))
+        uid = _NcclUniqueId()
+        status = lib.ncclGetUniqueId(C.byref(uid)) if group.rank == 0 else 0
+        raw = group._bcast_bytes(C.string_at(C.byref(uid), 128) if (group.rank == 0 and status == 0) else b'')
+        self._ok(status, 'ncclGetUniqueId')
+        if len(raw) != 128:
+            raise RuntimeError('rank 0 could not create the RCCL unique id')
+        C.memmove(C.byref(uid), raw, 128)
+        comm = C.c_void_p()
+        self._ok(lib.ncclCommInitRank(C.byref(comm), group.world, uid, group.rank), 'ncclCommInitRank')
+        self.comm = comm
+
+    def _ok(self, status, what):
+        if status != 0:
+            raise RuntimeError('%s failed: %s' % (what, self.lib.ncclGetErrorString(status).decode('utf-8', 'replace')))
+
+    def gather_to_root(self, send_ptr, recv_ptr, nbytes, stream, root=0):
+        """every rank sends ``nbytes`` from ``send_ptr``; the root receives rank r's block at ``recv_ptr + r * nbytes``
+        (device pointers; one grouped call = one launch per peer pair, all links in parallel)"""
+        lib, g = self.lib, self.group
+        vp = C.c_void_p
+        self._ok(lib.ncclGroupStart(), 'ncclGroupStart')
+        if g.rank == root:
+            for peer in range(g.world):
+                self._ok(lib.ncclRecv(vp(recv_ptr + peer * nbytes), nbytes, NCCL_UINT8, peer, self.comm, vp(stream)), 'ncclRecv')
+        self._ok(lib.ncclSend(vp(send_ptr), nbytes, NCCL_UINT8, root, self.comm, vp(stream)), 'ncclSend')
+        self._ok(lib.ncclGroupEnd(), 'ncclGroupEnd')
+
+    def close(self):
+        if self.comm:
+            self.lib.ncclCommDestroy(self.comm)
+            self.comm = None
+
+
+class Group(object):
+    """the ranks of one job on one node; degrades to a single process"""
+
+    def __init__(self, backend=None, single=False):
+        """``backend``: None = RCCL when a GPU is visible and the job has more than one rank (or was launched by a
+        distributed launcher), host sockets otherwise; ``'host'`` / ``'gloo'`` force the host plane (CPU tests);
+        ``single``: a group of this process alone whatever the environment says"""
+        self.world = 1 if single else int(os.environ.get('WORLD_SIZE', '1'))
+        self.rank = 0 if single else int(os.environ.get('RANK', '0'))
         self.local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-        self.dist = None
-        self.torch = None
-        self.device = 'cpu'
-        if self.world > 1 or 'RANK' in os.environ:
-            import torch
-            import torch.distributed as dist
-            self.torch, self.dist = torch, dist
-            if backend is None:
-                backend = 'nccl' if torch.cuda.is_available() else 'gloo'
-            if backend == 'nccl':
-                torch.cuda.set_device(self.local_rank)
-                self.device = torch.device('cuda', self.local_rank)
-                dist.init_process_group('nccl', device_id=self.device)
-            else:
-                dist.init_process_group(backend)
-            self.backend = backend
+        self.distributed = not single and (self.world > 1 or 'RANK' in os.environ)
+        self.star = _Star(self.rank, self.world) if self.world > 1 else None
         # the HIP library of this process binds to the rank's GPU
         os.environ.setdefault('IMSEGM_HIP_DEVICE', str(self.local_rank))
+        self.device_index = 0
+        self.rccl = None
+        self.backend = 'host'
+        self.rccl_error = None
+        if backend in (None, 'rccl', 'nccl') and self.distributed:
+            # stage 1 (local): a GPU and the library; stage 2 (collective, only if every rank passed stage 1): the communicator
+            rccl = None
+            try:
+                from pyimsegm_amd import _hip
+                n = _hip.device_count()
+                if n > 0:
+                    self.device_index = self.local_rank % n
+                    rccl = Rccl(self)
+            except Exception as ex:      # no GPU / no library: every rank falls back to the host plane
+                self.rccl_error = repr(ex)
+            if self.min_over_ranks(1 if rccl is not None else 0) > 0:
+                ok = 0
+                try:
+                    rccl.connect()
+                    ok = 1
+                except Exception as ex:
+                    self.rccl_error = repr(ex)
+                if self.min_over_ranks(ok) > 0:
+                    self.rccl, self.backend = rccl, 'rccl'
+                else:
+                    rccl.close()
 
     # -- work partition --------------------------------------------------------------------------
     def shard(self, n_items):
         """indices of the items this rank owns: item i -> rank i mod world"""
         return list(range(self.rank, n_items, self.world))
 
-    # -- collectives -------------------------------------------------------------------------------
+    # -- control plane ---------------------------------------------------------------------------
+    def _gather_bytes(self, data):
+        return [data] if self.star is None else self.star.gather(data)
+
+    def _bcast_bytes(self, data):
+        return data if self.star is None else self.star.bcast(data)
+
     def barrier(self):
-        if self.dist is not None:
-            self.dist.barrier()
-            if self.backend == 'nccl':
-                self.torch.cuda.synchronize()
-
-    def max_over_ranks(self, value):
-        if self.dist is None:
-            return float(value)
-        t = self.torch.tensor([float(value)], dtype=self.torch.float64, device=self.device)
-        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
-        return float(t.item())
-
-    def gather_arrays(self, array, dst=0, keep_on_device=False):
-        """gather one equally-shaped array per rank on ``dst`` (numpy, or a device array exposing
-        ``__cuda_array_interface__``); returns the list of numpy arrays there, else None"""
-        if self.dist is None:
-            return [array]
-        if hasattr(array, '__cuda_array_interface__'):
-            t = self.torch.as_tensor(array, device=self.device)      # zero copy: already in this GPU's HBM
-        else:
-            t = self.torch.from_numpy(np.ascontiguousarray(array)).to(self.device)
-        out = [self.torch.empty_like(t) for _ in range(self.world)] if self.rank == dst else None
-        self.dist.gather(t, out, dst=dst)
-        if self.rank != dst:
-            return None
-        return out if keep_on_device else [o.cpu().numpy() for o in out]
+        if self.star is not None:
+            self.star.gather(b'')
+            self.star.bcast(b'')
 
     def gather_objects(self, obj, dst=0):
-        """gather small picklable objects (feature matrices for the group model) on ``dst``"""
-        if self.dist is None:
-            return [obj]
-        out = [None] * self.world if self.rank == dst else None
-        self.dist.gather_object(obj, out, dst=dst)
-        return out
+        """gather small picklable objects (feature matrices for the group model) on rank 0"""
+        if dst != 0:
+            raise ValueError('rank 0 is the hub of the control plane')
+        parts = self._gather_bytes(pickle.dumps(obj, protocol=pickle.HIGHEST_PROTOCOL))
+        return None if parts is None else [pickle.loads(p) for p in parts]
 
     def broadcast_object(self, obj, src=0):
-        if self.dist is None:
-            return obj
-        box = [obj]
-        self.dist.broadcast_object_list(box, src=src)
-        return box[0]
+        if src != 0:
+            raise ValueError('rank 0 is the hub of the control plane')
+        return pickle.loads(self._bcast_bytes(pickle.dumps(obj, protocol=pickle.HIGHEST_PROTOCOL) if self.rank == 0 else b''))
+
+    def max_over_ranks(self, value):
+        parts = self.gather_objects(float(value))
+        return float(self.broadcast_object(max(parts) if parts is not None else None))
+
+    def min_over_ranks(self, value):
+        parts = self.gather_objects(float(value))
+        return float(self.broadcast_object(min(parts) if parts is not None else None))
+
+    def any_over_ranks(self, flag):
+        return self.max_over_ranks(1.0 if flag else 0.0) > 0
+
+    def gather_arrays(self, array, dst=0):
+        """gather one numpy array per rank on rank 0 over the host plane; list of arrays there, None elsewhere"""
+        array = np.ascontiguousarray(array)
+        parts = self.gather_objects((array.shape, array.dtype.str, array.tobytes()), dst=dst)
+        if parts is None:
+            return None
+        return [np.frombuffer(raw, dtype=np.dtype(dt)).reshape(shape).copy() for shape, dt, raw in parts]
 
     def close(self):
-        if self.dist is not None:
-            self.dist.barrier()
-            self.dist.destroy_process_group()
-            self.dist = None
+        if self.rccl is not None:
+            self.rccl.close()
+            self.rccl = None
+        if self.star is not None:
+            try:
+                self.barrier()
+            except Exception:
+                pass
+            self.star.close()
+            self.star = None
 
 
-def segment_batch_sharded(list_images, segment_fn, group, nb_workers=1):
-    """segment a batch of equally-sized images sharded over the ranks of ``group``.
+class DeviceGather(object):
+    """rounds of equally sized device buffers (label maps) from every rank's HBM to rank 0's HBM over RCCL.
 
-    ``segment_fn(image) -> label map`` runs on this rank's GPU.  Every rank processes the images
-    ``i = rank, rank + world, ...``; label maps travel to rank 0 with one gather per round of
-    images.  Returns the full list of label maps on rank 0, ``None`` elsewhere.
+    A worker stages a finished label map into a slot of the send ring (device-to-device copy on its own stream, so
+    its session can start the next image at once); when ``items_per_round`` slots are filled on every rank, ONE grouped
+    ``ncclSend`` / ``ncclRecv`` moves the whole round.  Rank 0 keeps the latest round of all ranks in ``recv``
+    (world x items_per_round x item_bytes, in HBM).  Without RCCL (CPU tests, one process) the round travels over the
+    host plane instead."""
 
-    ``nb_workers`` > 1 keeps that many images of this rank in flight: worker threads, each with its
-    own HIP stream (``_hip.default_context`` is per thread), so that the host stages of one image
-    (class probabilities, edge weights) overlap the kernels of another.
+    def __init__(self, group, item_bytes, items_per_round, ctx=None):
+        from pyimsegm_amd import _hip
+        self.group, self.item_bytes, self.per_round = group, int(item_bytes), int(items_per_round)
+        self.ctx = ctx or _hip.default_context()
+        self.hip = _hip
+        self.round_bytes = self.item_bytes * self.per_round
+        self.rounds_done = 0
+        self.send = self.recv = None
+        if group.rccl is not None:
+            lib = _hip.load_library()
+            p = C.c_void_p()
+            _hip._check(lib.imsegm_device_alloc(group.device_index, 2 * self.round_bytes, C.byref(p)))      # double buffered
+            self.send = p.value
+            if group.rank == 0:
+                q = C.c_void_p()
+                _hip._check(lib.imsegm_device_alloc(group.device_index, group.world * self.round_bytes, C.byref(q)))
+                self.recv = q.value
+        self.host_round = [None] * self.per_round          # host-plane fallback
+
+    def slot_ptr(self, round_index, item):
+        return self.send + (round_index % 2) * self.round_bytes + item * self.item_bytes
+
+    def stage(self, round_index, item, src, worker_ctx=None, offset=0, nbytes=None):
+        """put (a part of) item ``item`` of round ``round_index`` into the ring.  ``src``: a device array (anything with
+        ``__cuda_array_interface__``; copied device to device on the worker's stream) or, on the host plane, a numpy array"""
+        nbytes = self.item_bytes if nbytes is None else int(nbytes)
+        if self.group.rccl is not None:
+            ptr = src.__cuda_array_interface__['data'][0] if hasattr(src, '__cuda_array_interface__') else int(src)
+            (worker_ctx or self.ctx).copy(self.slot_ptr(round_index, item) + offset, ptr, nbytes, synchronize=True)
+        else:
+            slot = self.host_round[item]
+            if slot is None:
+                slot = self.host_round[item] = {}
+            slot[offset] = np.array(src, copy=True)
+
+    def flush(self, round_index):
+        """collective: move round ``round_index`` (all its items staged on every rank) to rank 0"""
+        g = self.group
+        if g.rccl is not None:
+            g.rccl.gather_to_root(self.slot_ptr(round_index, 0), self.recv or 0, self.round_bytes, self.ctx.stream)
+            self.ctx.synchronize()
+            out = None
+        else:
+            items = [[slot[k] for k in sorted(slot)] for slot in self.host_round if slot is not None]
+            out = g.gather_objects(items)
+            self.host_round = [None] * self.per_round
+        self.rounds_done += 1
+        return out
+
+    def close(self):
+        lib = self.hip.load_library()
+        if self.send:
+            lib.imsegm_device_free(C.c_void_p(self.send))
+        if self.recv:
+            lib.imsegm_device_free(C.c_void_p(self.recv))
+        self.send = self.recv = None
+
+
+def estim_model_classes_group_sharded(list_images, features_fn, fit_fn, group):
+    """the group model across ranks (reference ``pipelines.py:142-155``): every rank extracts the
+    K_i x F features of its images ``i = rank, rank + world, ...``, the blocks are gathered on rank 0 in image order,
+    the model is fitted there once and broadcast (its parameters are a few hundred doubles)
+
+    :param features_fn: image -> K x F features (runs on this rank's GPU)
+    :param fit_fn: concatenated features -> fitted model (runs on rank 0)
+    :return tuple(model, list(ndarray)): the model on every rank; all feature blocks on rank 0, this rank's elsewhere
     """
     n = len(list_images)
     mine = group.shard(n)
+    local = [features_fn(list_images[i]) for i in mine]
+    parts = group.gather_objects(list(zip(mine, local)))
+    model, blocks = None, local
+    if group.rank == 0:
+        by_index = dict(pair for part in parts for pair in part)
+        blocks = [by_index[i] for i in range(n)]
+        model = fit_fn(np.nan_to_num(np.concatenate(tuple(blocks), axis=0)))
+    model = group.broadcast_object(model)
+    return model, blocks
+
+
+def segment_batch_sharded(list_images, segment_fn, group, nb_workers=1, segment_device_fn=None):
+    """segment a batch of equally-sized images sharded over the ranks of ``group``.
+
+    ``segment_fn(image) -> label map`` runs on this rank's GPU.  Every rank processes the images
+    ``i = rank, rank + world, ...``; label maps travel to rank 0 one round of images at a time.  Returns the full
+    list of label maps on rank 0, ``None`` elsewhere.
+
+    With RCCL (``group.rccl``) and ``segment_device_fn(image) -> object with .device_ptr / .ctx / .close()`` the label maps
+    never visit the host of their own rank: each worker stages its finished map into the send ring in HBM, one grouped
+    ``ncclSend`` / ``ncclRecv`` per round of ``nb_workers`` images per rank moves them to rank 0's HBM over xGMI, and only
+    rank 0 copies them to its host.  Otherwise (CPU tests, one process) the maps travel over the host plane.
+
+    ``nb_workers`` > 1 keeps that many images of this rank in flight: worker threads, each with its
+    own HIP stream (``_hip.default_context`` is per thread).  A rank whose ``segment_fn`` fails still takes part in
+    every collective (with a dummy map), the error is raised on all ranks after the last round.
+    """
+    n = len(list_images)
+    if n == 0:
+        return [] if group.rank == 0 else None
+    mine = group.shard(n)
+    shape = np.asarray(list_images[0]).shape[:2]
+    nb_workers = max(1, int(nb_workers or 1))
+    if group.rccl is not None and segment_device_fn is not None:
+        return _segment_batch_rccl(list_images, segment_device_fn, group, nb_workers, mine, shape)
     rounds = (n + group.world - 1) // group.world
     results = [None] * n if group.rank == 0 else None
-    shape = np.asarray(list_images[0]).shape[:2]
     pool = futures = None
-    if nb_workers > 1 and len(mine) > 1:
-        from concurrent.futures import ThreadPoolExecutor
-        pool = ThreadPoolExecutor(max_workers=int(nb_workers))
-        futures = [pool.submit(segment_fn, list_images[i]) for i in mine]
-    for rnd in range(rounds):
-        if rnd < len(mine):
-            segm = futures[rnd].result() if futures else segment_fn(list_images[mine[rnd]])
-            segm = np.ascontiguousarray(segm, dtype=np.int32)
-        else:  # ragged tail: this rank has no image in the last round, contribute a dummy
-            segm = np.full(shape, -1, dtype=np.int32)
-        parts = group.gather_arrays(segm, dst=0)
-        if group.rank == 0:
-            for r, part in enumerate(parts):
-                idx = rnd * group.world + r
-                if idx < n:
-                    results[idx] = part
-    if pool is not None:
+    error = None
+    try:
+        if nb_workers > 1 and len(mine) > 1:
+            from concurrent.futures import ThreadPoolExecutor
+            pool = ThreadPoolExecutor(max_workers=nb_workers)
+            futures = [pool.submit(segment_fn, list_images[i]) for i in mine]
+        for rnd in range(rounds):
+            segm = None
+            if rnd < len(mine) and error is None:
+                try:
+                    segm = futures[rnd].result() if futures else segment_fn(list_images[mine[rnd]])
+                    segm = np.ascontiguousarray(segm)
+                except Exception as ex:            # keep the collective pattern alive, report after the loop
+                    error = ex
+            if segm is None:    # ragged tail (no image of this rank in the last round) or a failed image: a dummy
+                segm = np.full(shape, -1, dtype=np.int32)
+            parts = group.gather_arrays(segm, dst=0)
+            if group.rank == 0:
+                for r, part in enumerate(parts):
+                    idx = rnd * group.world + r
+                    if idx < n:
+                        results[idx] = part
+    finally:
+        if pool is not None:
+            pool.shutdown()
+    failed = group.any_over_ranks(error is not None)
+    if error is not None:
+        raise error
+    if failed:
+        raise RuntimeError('segmentation failed on another rank')
+    return results
+
+
+def _segment_batch_rccl(list_images, segment_device_fn, group, nb_workers, mine, shape):
+    import threading
+    from concurrent.futures import ThreadPoolExecutor
+    from pyimsegm_amd import _hip
+    n = len(list_images)
+    per_round = nb_workers
+    max_mine = (n + group.world - 1) // group.world                  # images of rank 0 = the most any rank has
+    rounds = (max_mine + per_round - 1) // per_round
+    item_bytes = int(shape[0]) * int(shape[1]) * 4
+    ctx = _hip.default_context()
+    gather = DeviceGather(group, item_bytes, per_round, ctx)
+    cond = threading.Condition()
+    flushed = [0]
+    errors = []
+
+    def work(pos):
+        rnd, item = divmod(pos, per_round)
+        res = None
+        try:
+            res = segment_device_fn(list_images[mine[pos]])
+            with cond:
+                cond.wait_for(lambda: flushed[0] >= rnd - 1)         # the ring holds two rounds
+            gather.stage(rnd, item, res.device_ptr, res.ctx)
+        except Exception as ex:
+            errors.append(ex)
+        finally:
+            if res is not None:
+                res.close()
+
+    results = [None] * n if group.rank == 0 else None
+    host = _hip.pinned_empty((group.world, per_round) + tuple(shape), np.int32) if group.rank == 0 else None
+    pool = ThreadPoolExecutor(max_workers=nb_workers)
+    try:
+        futures = [pool.submit(work, pos) for pos in range(len(mine))]
+        for rnd in range(rounds):
+            for fut in futures[rnd * per_round:(rnd + 1) * per_round]:
+                fut.result()
+            gather.flush(rnd)                                        # collective: every rank, every round
+            with cond:
+                flushed[0] = rnd + 1
+                cond.notify_all()
+            if group.rank == 0:
+                ctx.copy(host.ctypes.data, gather.recv, host.nbytes, synchronize=True)
+                for r in range(group.world):
+                    for item in range(per_round):
+                        idx = (rnd * per_round + item) * group.world + r
+                        if idx < n:
+                            results[idx] = host[r, item].copy()
+    finally:
         pool.shutdown()
+        gather.close()
+    failed = group.any_over_ranks(bool(errors))
+    if errors:
+        raise errors[0]
+    if failed:
+        raise RuntimeError('segmentation failed on another rank')
     return results

@@ -33,12 +33,39 @@ CROSS_VAL_LEAVE_OUT = 2
 NB_WORKERS = 2
 
 
-class _ResidentImage(object):
-    """one image on the device: superpixels + features, graph cut, gathers"""
+_device_models = None
 
-    def __init__(self, image, dict_features, sp_size, sp_regul, session=None, reuse=False):
+
+def _device_gmm(model):
+    """:class:`_hip.DeviceGmm` of a fitted ``Pipeline([StandardScaler,] GaussianMixture('full'))`` (cached per model
+    object as long as its parameters are the same arrays), or None when the model has to be evaluated by scikit-learn"""
+    global _device_models
+    import weakref
+    if _device_models is None:
+        _device_models = weakref.WeakKeyDictionary()
+    try:
+        last = model.steps[-1][1] if hasattr(model, 'steps') else model
+        chol = getattr(last, 'precisions_cholesky_', None)
+        hit = _device_models.get(model)
+        if hit is not None and hit[0] is chol:
+            return hit[1]
+        dev = _hip.DeviceGmm(model)
+        _device_models[model] = (chol, dev)
+        return dev
+    except TypeError:
+        return None
+    except Exception as ex:       # private scikit-learn layout changed ...: the host evaluates the model
+        logging.debug('class model stays on the host: %s', ex)
+        return None
+
+
+class _ResidentImage(object):
+    """one image on the device: superpixels + features, then the fused class model / graph cut / gathers"""
+
+    def __init__(self, image, dict_features, sp_size, sp_regul, session=None, reuse=False, features_to_host=True):
         """``session``: (Image2D, normalize_mode) of an image that is already uploaded (bench loop);
-        ``reuse``: recycle the device buffers of the previous image of the same size on this thread (batches)"""
+        ``reuse``: recycle the device buffers of the previous image of the same size on this thread (batches);
+        ``features_to_host``: False when nobody on the host needs the K x F table (pre-fitted mixture on the device)"""
         if sp_regul <= 0.:
             raise ValueError('slic. regularisation must be positive')
         image = np.asarray(image)
@@ -47,17 +74,35 @@ class _ResidentImage(object):
         self.own_session = session is None
         self.reuse = reuse
         self.sess, mode = _open_session(image, reuse=reuse) if session is None else session
-        self.nb_labels = _run_slic(self.sess, mode, sp_size, sp_regul)
-        logging.debug('extract slic/superpixels features.')
-        self._slic = None
-        if image.ndim == 3 and set(dict_features) == {'color'} and image.dtype in (np.uint8, np.float64) \
-                and set(dict_features['color']) <= {'mean', 'std', 'energy'}:
-            # everything stays on the device: statistics of the uploaded image on the resident labels
-            features, _ = _selected_features_color2d(image, None, dict_features, sess=self.sess)
-        else:
-            features, _ = compute_selected_features_img2d(image, self.slic, dict_features)
-        features[np.isnan(features)] = 0
-        self.features = features
+        try:
+            self.nb_labels = _run_slic(self.sess, mode, sp_size, sp_regul)
+            logging.debug('extract slic/superpixels features.')
+            self._slic = None
+            self._features = None
+            self.resident_features = False
+            flags = dict_features.get('color', ()) if set(dict_features) == {'color'} else None
+            if image.ndim == 3 and flags is not None and image.dtype in (np.uint8, np.float64) \
+                    and 0 < len(flags) and set(flags) <= {'mean', 'std', 'energy'}:
+                # everything stays on the device: statistics of the uploaded image on the resident labels, assembled
+                # into the feature table the class model and the 'features' edge type read
+                # (float images: NaN / inf would have to be replaced first, descriptors.py:818 -- checked on the host)
+                if image.dtype == np.uint8 or bool(np.isfinite(image.sum(dtype=np.float64))):
+                    self._flags = ('mean' in flags, 'std' in flags, 'energy' in flags)
+                    self._features = self.sess.features_color(*self._flags, to_host=features_to_host)
+                    self.resident_features = True
+            if not self.resident_features:
+                features, _ = compute_selected_features_img2d(image, self.slic, dict_features)
+                features[np.isnan(features)] = 0
+                self._features = features
+        except BaseException:
+            self.close()
+            raise
+
+    @property
+    def features(self):
+        if self._features is None:        # resident table that was not needed on the host so far
+            self._features = self.sess.features_color(*self._flags, to_host=True)
+        return self._features
 
     @property
     def slic(self):
@@ -65,38 +110,40 @@ class _ResidentImage(object):
             self._slic = self.sess.get_labels()
         return self._slic
 
-    def segment(self, proba, gc_regul, gc_edge_type, debug_visual=None, classes=None, to_host=True, want_soft=True):
+    def segment(self, proba, gc_regul, gc_edge_type, debug_visual=None, classes=None, to_host=True, want_soft=True,
+                model=None):
+        """ graph cut + gathers.  ``proba``: K x C from the host, or None with ``model`` = a mixture the device evaluates
+        on the resident features.  Everything runs in one fused call (:meth:`_hip.Image2D.segment`) unless the edge
+        type needs the image on the host (``'color'``). """
         image = self.image
-        # the graph stage only reads the label map of the session; `segments` is passed for its
-        # ndim / debug output and is only materialised on the host when somebody needs it
-        segments = self.slic if (debug_visual is not None or gc_edge_type == 'color') else _ShapeOnly(self.sess.shape)
-        graph_labels = segment_graph_cut_general(segments, proba, image, self.features, gc_regul, gc_edge_type,
-                                                 debug_visual=debug_visual, _session=self.sess)
-        if classes is not None:
-            graph_labels = np.asarray(classes)[graph_labels]
-        segm, segm_soft = self.sess.gather(graph_labels, proba if want_soft else None, to_host=to_host)
-        if to_host and classes is not None and np.asarray(classes).dtype != np.int32:
-            segm = segm.astype(np.asarray(classes).dtype)
-        return segm, segm_soft
-
-    def segment_with_model(self, model, gc_regul, gc_edge_type, host_pool, classes=None, to_host=True, want_soft=True):
-        """ as ``segment(predict_proba(model, features), ...)`` with the numpy stages (class probabilities, unary /
-        pairwise costs, edge weights) evaluated by a helper process of ``host_pool`` (:mod:`pyimsegm_amd.hostpool`, the
-        model was handed over by ``host_pool.set_model``): identical numbers, but this thread holds the interpreter
-        lock only for the glue, and the graph kernels follow the descriptor kernels without a host stage in between.
-        Edge types that need the image (``'color'``) take the in-process route. """
-        if gc_edge_type == 'color' or not (np.isscalar(gc_regul) and gc_regul > 0):
-            return self.segment(predict_proba(model, self.features), gc_regul, gc_edge_type, classes=classes,
-                                to_host=to_host, want_soft=want_soft)
-        from pyimsegm_amd.graph_cuts import _edges_centres, cut_general_graph
-        edges, centres, _ = _edges_centres(_ShapeOnly(self.sess.shape), self.sess)
-        edges = np.array(edges, dtype=np.int32).reshape(-1, 2)
-        proba, unary_cost, pairwise_cost, edge_weights = host_pool.terms(self.features, edges, centres, gc_regul,
-                                                                         gc_edge_type)
-        graph_labels = cut_general_graph(edges, edge_weights, unary_cost, pairwise_cost, algorithm='expansion', n_iter=-1)
-        if classes is not None:
-            graph_labels = np.asarray(classes)[graph_labels]
-        segm, segm_soft = self.sess.gather(graph_labels, proba if want_soft else None, to_host=to_host)
+        gmm = None
+        if proba is None:
+            gmm = _device_gmm(model) if self.resident_features else None
+            if gmm is None:
+                proba = predict_proba(model, self.features)
+        nb_classes = gmm.n_classes if gmm is not None else np.shape(proba)[1]
+        if gc_edge_type in _hip.EDGE_TYPES and (gc_edge_type != 'features' or self.resident_features):
+            from pyimsegm_amd.graph_cuts import compute_pairwise_cost, insert_gc_debug_images
+            pairwise = compute_pairwise_cost(gc_regul, (self.nb_labels, nb_classes))
+            use_gc = not (np.isscalar(gc_regul) and gc_regul <= 0)
+            cls = None if classes is None else np.asarray(classes)
+            res = self.sess.segment(pairwise, gc_edge_type, gmm=gmm, proba=proba, use_graphcut=use_gc,
+                                    classes=None if cls is None else cls.astype(np.int32), want_segm=to_host,
+                                    want_soft=to_host and want_soft, debug=debug_visual is not None,
+                                    keep_soft_on_device=want_soft and not to_host)
+            if debug_visual is not None:
+                insert_gc_debug_images(debug_visual, self.slic, res['graph_labels'], res['unary'], res['edges'],
+                                       res['edge_weights'])
+            segm, segm_soft = res.get('segm'), res.get('soft')
+        else:
+            # the graph stage only reads the label map of the session; `segments` is passed for its
+            # ndim / debug output and is only materialised on the host when somebody needs it
+            segments = self.slic if (debug_visual is not None or gc_edge_type == 'color') else _ShapeOnly(self.sess.shape)
+            graph_labels = segment_graph_cut_general(segments, proba, image, self.features, gc_regul, gc_edge_type,
+                                                     debug_visual=debug_visual, _session=self.sess)
+            if classes is not None:
+                graph_labels = np.asarray(classes)[graph_labels]
+            segm, segm_soft = self.sess.gather(graph_labels, proba if want_soft else None, to_host=to_host)
         if to_host and classes is not None and np.asarray(classes).dtype != np.int32:
             segm = segm.astype(np.asarray(classes).dtype)
         return segm, segm_soft
@@ -120,11 +167,12 @@ class _ResidentImage(object):
         debug_visual['slic_mean'] = self.mean_colour_image()
 
     def close(self):
-        if self.own_session:
+        if self.own_session and self.sess is not None:
             if self.reuse:
                 _release_session(self.sess)
             else:
                 self.sess.close()
+            self.sess = None
 
 
 class _ShapeOnly(object):
@@ -148,8 +196,10 @@ def compute_color2d_superpixels_features(image, dict_features, sp_size=30, sp_re
     :return tuple(ndarray,ndarray): superpixel label map, features K x F
     """
     res = _ResidentImage(image, dict_features, sp_size, sp_regul)
-    slic, features = res.slic, res.features
-    res.close()
+    try:
+        slic, features = res.slic, res.features
+    finally:
+        res.close()
     logging.debug('list of features RAW: %r', features.shape)
     return slic, features
 
@@ -170,12 +220,14 @@ def wrapper_compute_color2d_slic_features_labels(img_annot, sp_size, sp_regul, d
     if np.shape(img)[:2] != annot.shape[:2]:
         raise ImageDimensionError('image %r and annot %r should match' % (np.shape(img), annot.shape))
     res = _ResidentImage(img, dict_features, sp_size, sp_regul)
-    neg_label = np.max(annot) + 1 if np.sum(annot < 0) > 0 else None
-    if neg_label is not None:
-        annot[annot < 0] = neg_label
-    label_hist = histogram_regions_labels_norm(None, annot, _session=res.sess)
-    slic, features = res.slic, res.features
-    res.close()
+    try:
+        neg_label = np.max(annot) + 1 if np.sum(annot < 0) > 0 else None
+        if neg_label is not None:
+            annot[annot < 0] = neg_label
+        label_hist = histogram_regions_labels_norm(None, annot, _session=res.sess)
+        slic, features = res.slic, res.features
+    finally:
+        res.close()
     labels = np.argmax(label_hist, axis=1)
     purity = np.max(label_hist, axis=1)
     if neg_label is not None:
@@ -283,12 +335,14 @@ def pipe_color2d_slic_features_model_graphcut(
     """
     logging.info('PIPELINE Superpixels-Features-GMM-GraphCut')
     res = _ResidentImage(image, dict_features, sp_size, sp_regul)
-    res.fill_debug(debug_visual)
-    model = estim_class_model(res.features, nb_classes, estim_model, pca_coef, use_scaler)
-    proba = model.predict_proba(res.features)
-    logging.debug('list of probabilities: %r', proba.shape)
-    segm, segm_soft = res.segment(proba, gc_regul, gc_edge_type, debug_visual)
-    res.close()
+    try:
+        res.fill_debug(debug_visual)
+        model = estim_class_model(res.features, nb_classes, estim_model, pca_coef, use_scaler)
+        # the fitted mixture is evaluated on the device (resident features) when it is the scaler + GMM pipeline,
+        # by scikit-learn otherwise
+        segm, segm_soft = res.segment(None, gc_regul, gc_edge_type, debug_visual, model=model)
+    finally:
+        res.close()
     return segm, segm_soft
 
 
@@ -339,26 +393,26 @@ def segment_color2d_slic_features_model_graphcut(
     :return tuple(ndarray,ndarray): segmentation H x W, soft segmentation H x W x nb_classes
     """
     logging.info('PIPELINE Superpixels-Features-Model-GraphCut')
-    res = _ResidentImage(image, dict_features, sp_size, sp_regul)
-    res.fill_debug(debug_visual)
-    proba = predict_proba(model_pipeline, res.features)
-    logging.debug('list of probabilities: %r', proba.shape)
-    classes = getattr(model_pipeline, 'classes_', None)
-    segm, segm_soft = res.segment(proba, gc_regul, gc_edge_type, debug_visual, classes=classes)
-    res.close()
+    res = _ResidentImage(image, dict_features, sp_size, sp_regul, features_to_host=_device_gmm(model_pipeline) is None)
+    try:
+        res.fill_debug(debug_visual)
+        classes = getattr(model_pipeline, 'classes_', None)
+        segm, segm_soft = res.segment(None, gc_regul, gc_edge_type, debug_visual, classes=classes, model=model_pipeline)
+    finally:
+        res.close()
     return segm, segm_soft
 
 
 def segment_batch_color2d_slic_features_model_graphcut(list_images, model_pipeline, dict_features, sp_size=30,
                                                        sp_regul=0.2, gc_regul=1., gc_edge_type='model', group=None,
-                                                       nb_workers=NB_WORKERS, host_procs=True):
+                                                       nb_workers=NB_WORKERS):
     """ segment a batch of equally-sized images with a given model, sharded over the GPUs of one node
 
     Multi-GPU counterpart of mapping :func:`segment_color2d_slic_features_model_graphcut` over a
-    process pool (reference ``run_segm_slic_model_graphcut.py:505-514``): one process per GPU
-    (``torchrun``), image *i* goes to rank ``i mod world``, the label maps are gathered on rank 0
-    over RCCL.  Without a process group it processes the images on this GPU, ``nb_workers`` of them
-    in flight at a time.
+    process pool (reference ``run_segm_slic_model_graphcut.py:505-514``): one process per GPU, image *i* goes to
+    rank ``i mod world``, the label maps are gathered on rank 0 over RCCL.  Without a process group it processes the
+    images on this GPU, ``nb_workers`` of them in flight at a time (worker threads with one HIP stream each; a thread
+    spends its time inside two C calls per image, outside the interpreter lock).
 
     :return list(ndarray): label maps on rank 0 (``None`` on the other ranks)
     """
@@ -366,37 +420,41 @@ def segment_batch_color2d_slic_features_model_graphcut(list_images, model_pipeli
     own = group is None
     if own:
         group = Group()
-
     classes = getattr(model_pipeline, 'classes_', None)
-    # several images in flight: their numpy stages (class model, graph-cut terms) run in helper processes, so the
-    # worker threads do not queue for the interpreter lock (pyimsegm_amd/hostpool.py; same functions, same numbers)
-    host_pool = None
-    if host_procs and nb_workers and nb_workers > 1 and len(list_images) > 1:
-        from pyimsegm_amd.hostpool import shared_pool
-        try:
-            host_pool = shared_pool(nb_workers)      # started once per process, reused by later batches
-            host_pool.set_model(model_pipeline)
-        except Exception as ex:                      # e.g. a model that cannot be pickled: stay in process
-            logging.warning('host helper processes not available (%s): class model evaluated in the worker threads', ex)
-            host_pool = None
+    on_device = _device_gmm(model_pipeline) is not None
 
     def _segment(image):
         # as segment_color2d_slic_features_model_graphcut, minus what a batch does not need: the soft
-        # segmentation stays on the device and the session buffers are recycled from image to image
-        res = _ResidentImage(image, dict_features, sp_size, sp_regul, reuse=True)
-        if host_pool is not None:
-            segm, _ = res.segment_with_model(model_pipeline, gc_regul, gc_edge_type, host_pool, classes=classes,
-                                             want_soft=False)
-        else:
-            proba = predict_proba(model_pipeline, res.features)
-            segm, _ = res.segment(proba, gc_regul, gc_edge_type, classes=classes, want_soft=False)
-        res.close()
+        # segmentation is not computed and the session buffers are recycled from image to image
+        res = _ResidentImage(image, dict_features, sp_size, sp_regul, reuse=True, features_to_host=not on_device)
+        try:
+            segm, _ = res.segment(None, gc_regul, gc_edge_type, classes=classes, want_soft=False, model=model_pipeline)
+        finally:
+            res.close()
         return segm
 
-    out = segment_batch_sharded(list_images, _segment, group, nb_workers=nb_workers)
-    if own:
-        group.close()
-    return out
+    class _OnDevice(object):
+        """a finished image whose label map is still in its session's HBM buffer (RCCL gather, zero copy)"""
+
+        def __init__(self, image):
+            self.res = _ResidentImage(image, dict_features, sp_size, sp_regul, reuse=True, features_to_host=not on_device)
+            try:
+                self.res.segment(None, gc_regul, gc_edge_type, classes=classes, to_host=False, want_soft=False,
+                                 model=model_pipeline)
+                self.ctx = self.res.sess.ctx
+                self.device_ptr = _hip.segm_device_array(self.res.sess).__cuda_array_interface__['data'][0]
+            except BaseException:
+                self.res.close()
+                raise
+
+        def close(self):
+            self.res.close()
+
+    try:
+        return segment_batch_sharded(list_images, _segment, group, nb_workers=nb_workers, segment_device_fn=_OnDevice)
+    finally:
+        if own:
+            group.close()
 
 
 def pipe_gray3d_slic_features_model_graphcut(
@@ -455,7 +513,14 @@ def pipe_gray3d_slic_features_model_graphcut(
     proba = model.predict_proba(features)
     logging.debug('list of probabilities: %r', proba.shape)
 
-    graph_labels = segment_graph_cut_general(_ShapeOnly(sess.shape), proba, image, features, gc_regul, _session=sess)
-    segm, _ = sess.gather(graph_labels)
+    if float(sess.n_labels)**2 / 8. <= 2e9:
+        # fused: graph, unary / edge terms ('model' edges), alpha-expansion and the gather in one call
+        from pyimsegm_amd.graph_cuts import compute_pairwise_cost
+        use_gc = not (np.isscalar(gc_regul) and gc_regul <= 0)
+        segm = sess.segment(compute_pairwise_cost(gc_regul, proba.shape), 'model', proba=proba, use_graphcut=use_gc,
+                            pinned=False)['segm']
+    else:
+        graph_labels = segment_graph_cut_general(_ShapeOnly(sess.shape), proba, image, features, gc_regul, _session=sess)
+        segm, _ = sess.gather(graph_labels)
     sess.close()
     return segm

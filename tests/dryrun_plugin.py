@@ -74,6 +74,43 @@ class Image2D(object):
         self.last_segm = segm
         soft = np.asarray(proba, dtype=np.float64)[self.labels] if proba is not None else None
         return segm, soft
+    def features_color(self, mean=True, std=True, energy=True, to_host=True):
+        m, e, v = self.color_stats(True, energy, std)
+        blocks = ([m] if mean else []) + ([np.sqrt(v)] if std else []) + ([e] if energy else [])
+        fts = np.nan_to_num(np.hstack(blocks)); fts[fts == 0] = 0
+        self.features = fts
+        return fts if to_host else None
+    def segment(self, pairwise, edge_type='model', edge_cost=1., gmm=None, proba=None, use_graphcut=True, classes=None,
+                want_segm=True, want_soft=False, want_graph_labels=False, want_proba=False, debug=False, pinned=True,
+                keep_soft_on_device=False):
+        """the fused call, restated with the host mirror functions of graph_cuts + the oracle's alpha-expansion"""
+        import pyimsegm_amd.graph_cuts as G
+        from scipy.special import logsumexp
+        if gmm is not None:
+            x = np.array(self.features, dtype=np.float64)
+            if gmm.scaler_mean is not None: x = x - gmm.scaler_mean
+            if gmm.scaler_scale is not None: x = x / gmm.scaler_scale
+            lp = np.stack([np.sum((x @ pc - mp)**2, axis=1) for pc, mp in zip(gmm.prec_chol, gmm.mu_proj)], axis=1)
+            wl = -0.5 * (gmm.const_term + lp) + gmm.log_det + gmm.log_weights
+            proba = np.exp(wl - logsumexp(wl, axis=1)[:, None])
+        proba = np.asarray(proba, dtype=np.float64)[:self.n_labels]
+        edges, centres, _ = self.graph()
+        weights = G.edge_weights_from_graph(edges, centres, getattr(self, 'features', None), proba, edge_type) * edge_cost
+        unary = G.compute_unary_cost(proba)
+        pairwise = np.asarray(pairwise, dtype=np.float64)
+        if use_graphcut:
+            gl = np.asarray(orc.cut_general_graph(edges, weights, unary, pairwise, n_iter=-1), dtype=np.int32)
+        else:
+            gl = np.argmin(unary, axis=-1).astype(np.int32)
+        lut = gl if classes is None else np.asarray(classes, dtype=np.int32)[gl]
+        out = {}
+        self.last_segm = lut[self.labels]
+        if want_segm: out['segm'] = self.last_segm
+        if want_soft: out['soft'] = proba[self.labels]
+        if want_graph_labels or debug: out['graph_labels'] = gl
+        if want_proba or debug: out['proba'] = proba
+        if debug: out.update(edges=edges, edge_weights=weights, unary=unary, centres=centres)
+        return out
 
 
 class Volume3D(Image2D):
@@ -81,6 +118,11 @@ class Volume3D(Image2D):
         self.ctx = _CTX; self.shape = (int(depth), int(height), int(width)); self.n_labels = 0
     def upload(self, volume):
         volume = np.asarray(volume); assert volume.shape == self.shape; self.img = volume; return self
+    def graph(self):
+        vertices, edges = orc.adjacency(self.labels)
+        centres = np.asarray(orc.centers(self.labels), dtype=np.float64).reshape(self.n_labels, -1)
+        present = np.zeros(self.n_labels, dtype=bool); present[np.asarray(vertices)] = True
+        return np.array(edges, dtype=np.int32).reshape(-1, 2), centres, present
     def slic(self, n_segments, compactness, sigma=1., spacing=(1., 1., 1.), max_iter=10, enforce_connectivity=True,
              min_size_factor=0.5, max_size_factor=3., start_label=0):
         if self.img.dtype == np.float32:
@@ -107,6 +149,7 @@ def pytest_configure(config):
     _hip.cut_general_graph = lambda e, w, u, p, n_iter=-1, algorithm='expansion', **k: orc.cut_general_graph(
         np.asarray(e, dtype=np.int32).reshape(-1, 2), w, u, p, n_iter=n_iter)
     _hip.segm_device_array = lambda sess: sess.last_segm          # (the real one exposes the HBM buffer)
+    _hip.pinned_empty = lambda shape, dtype: np.empty(shape, dtype)
     import pyimsegm_amd.graph_cuts as G
     G._hip = _hip
 

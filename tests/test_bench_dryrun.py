@@ -1,7 +1,7 @@
-"""Host side of bench.py at world size 2 (torchrun + gloo, one process per "GPU") with the device calls answered by the
-oracle (tests/dryrun_bench.py): worker threads, helper processes, one gather per step on the main thread, barriers, the
-maximum over ranks and ONE JSON line from rank 0.  The kernels are not involved; this guards the N > 1 control flow
-that cannot be run on the single-GPU test box."""
+"""Host side of bench.py at world size 2 (the launcher of the benchmark contract, one process per "GPU") with the device
+calls answered by the oracle (tests/dryrun_bench.py): worker threads, steady-state timing, one gather per round of steps
+on the main thread, barriers, the maximum over ranks and ONE JSON line from rank 0.  The kernels are not involved; this
+guards the N > 1 control flow that cannot be run on the single-GPU test box."""
 import json
 import os
 import subprocess
@@ -10,10 +10,10 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def run_bench(nproc, steps, port):
+def run_bench(nproc, steps, port, extra=()):
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(nproc), '--master-addr', '127.0.0.1',
            '--master-port', str(port), os.path.join(ROOT, 'tests', 'dryrun_bench.py'), '--gpus', str(nproc), '--size', '192',
-           '--steps', str(steps), '--warmup', '1']
+           '--steps', str(steps), '--warmup', '1'] + list(extra)
     env = dict(os.environ, OMP_NUM_THREADS='1')
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
     assert out.returncode == 0, out.stderr[-2000:]
@@ -28,5 +28,12 @@ def test_bench_control_flow_two_ranks():
     assert d['higher_is_better'] is True and d['vs_baseline'] is None and d['value'] > 0
     assert abs(d['value'] - 2 * 9 * 192 * 192 / (d['ms_per_step'] * 9 / 1e3) / 1e6) / d['value'] < 1e-3      # whole-job aggregate
     assert set(d['roofline']) >= {'bound', 'achieved', 'peak', 'unit', 'frac', 'traffic'}
-    assert d['config']['images_in_flight_per_gpu'] == 4 and 'helper processes' in d['config']['host_math']
+    assert d['config']['images_in_flight_per_gpu'] == 4 and 'gathered in rank 0' in d['config']['parallelism']
+    assert d['ms_per_step_incl_fill_drain'] > 0 and 'steady state' in d['config']['timing']
     assert 'cpu_baseline' not in d                     # rank 0 at N = 1 only
+
+
+def test_bench_batch_config_two_ranks():
+    d = run_bench(2, 3, 29633, extra=['--config', '4'])
+    assert d['n_gpus'] == 2 and d['config']['bench_config'] == 4 and d['config']['images_per_step_per_gpu'] == 8
+    assert abs(d['value'] - 2 * 3 * 8 * 647 * 1024 / (d['ms_per_step'] * 3 / 1e3) / 1e6) / d['value'] < 1e-3

@@ -1,4 +1,6 @@
-"""N > 1 path on CPU: 2 processes, gloo backend -- sharding, per-round gather, max-over-ranks."""
+"""N > 1 path on CPU: 2 processes started by torch.distributed.run (the launcher of the benchmark contract), host control
+plane of pyimsegm_amd.distributed (the role gloo played in round 1) -- sharding, per-round gather, max-over-ranks,
+the group model across ranks, a failing rank."""
 import os
 import subprocess
 import sys
@@ -10,7 +12,7 @@ WORKER = textwrap.dedent('''
     import sys, numpy as np
     sys.path.insert(0, %r)
     from pyimsegm_amd.distributed import Group, segment_batch_sharded
-    g = Group(backend='gloo')
+    g = Group(backend='host')
     assert g.world == 2
     images = [np.full((6, 8, 3), i, dtype=np.uint8) for i in range(5)]      # ragged: 5 images, 2 ranks
     assert g.shard(5) == ([0, 2, 4] if g.rank == 0 else [1, 3])
@@ -38,6 +40,24 @@ WORKER = textwrap.dedent('''
         assert [int(o[0, 0]) for o in out2] == [0, 11, 20, 31, 40]
     else:
         assert out2 is None
+    # group model across ranks (pipelines.py:142-155): features of image i from rank i mod world, fitted on rank 0, broadcast
+    from pyimsegm_amd.distributed import estim_model_classes_group_sharded
+    model, blocks = estim_model_classes_group_sharded(
+        images, lambda img: np.full((2, 3), float(img[0, 0, 0])), lambda fts: {'mean': float(fts.mean()), 'rows': len(fts)}, g)
+    assert model == {'mean': 2.0, 'rows': 10}, model
+    if g.rank == 0:
+        assert [float(b[0, 0]) for b in blocks] == [0., 1., 2., 3., 4.]
+    # a rank that fails keeps the collective pattern alive and the error surfaces on every rank
+    def failing(img):
+        if g.rank == 1 and int(img[0, 0, 0]) == 3:
+            raise ValueError('boom')
+        return np.zeros(img.shape[:2], dtype=np.int32)
+    try:
+        segment_batch_sharded(images, failing, g)
+        raise SystemExit('no error raised')
+    except (ValueError, RuntimeError) as ex:
+        assert ('boom' in str(ex)) == (g.rank == 1)
+    assert segment_batch_sharded([], failing, g) == ([] if g.rank == 0 else None)
     g.close()
 ''') % ROOT
 

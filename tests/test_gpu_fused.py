@@ -1,0 +1,199 @@
+"""The fused back half of the pipeline (imsegm_image2d_features_color + imsegm_image2d_segment: feature table, class
+model, unary / edge terms, pyGCO integers, CSR, alpha-expansion, gathers in one enqueue) against
+  * scikit-learn's own predict_proba (1e-9) and the host mirror functions of graph_cuts (1e-12),
+  * the integer energies pygco would form from those terms (identical),
+  * the stage-by-stage path of round 1 (separate C calls with host numpy in between): same labels, same segmentation,
+  * the vectors of the reference's own run (tests/golden/reference.npz): the integers it handed to gco, its labels."""
+import numpy as np
+import pytest
+
+from pyimsegm_amd.utilities.synthetic import ellipsoid_volume, voronoi_image
+from test_golden_reference import GEN, NAMES, VEC, make_input, rebuild_model
+
+pytestmark = pytest.mark.gpu
+
+
+def pygco_integers(unary, weights, pairwise):
+    """float -> int conversion of gco-wrapper's pygco.cut_general_graph (restated in api.hip for the stand-alone call)"""
+    mu, mw, mp = np.abs(unary).max(), np.abs(weights).max() if len(weights) else 0., pairwise.max()
+    dwf = (mw * mp if (len(weights) and mw * mp > mu) else mu) + 1e-10
+    return ((unary / dwf) * 100000).astype(np.int32), ((weights / dwf) * 1000).astype(np.int32)
+
+
+@pytest.fixture(scope='module')
+def fitted():
+    from pyimsegm_amd import _hip
+    from pyimsegm_amd import graph_cuts as G
+    from pyimsegm_amd import superpixels as S
+    image = voronoi_image(300, 400, seed=3)
+    sess, mode = S._open_session(image)
+    S._run_slic(sess, mode, 20, 0.2)
+    features = sess.features_color(True, True, True, to_host=True)
+    np.random.seed(0)
+    model = G.estim_class_model(features, 3, 'GMM', None, True)
+    yield image, sess, features, model, _hip.DeviceGmm(model)
+    sess.close()
+
+
+def test_feature_table_equals_the_separate_statistics(fitted):
+    image, sess, features, _, _ = fitted
+    mean, energy, var = sess.color_stats()
+    assert np.array_equal(features, np.hstack([mean, np.sqrt(var), energy]))
+    assert np.array_equal(sess.features_color(True, False, True), np.hstack([mean, energy]))
+    assert np.array_equal(sess.features_color(False, True, False), np.sqrt(var))
+    sess.features_color(True, True, True, to_host=False)
+
+
+@pytest.mark.parametrize('edge_type', ['model', 'model_l1', 'model_l2', 'model_lT', 'spatial', 'features', '', 'const'])
+def test_fused_terms_equal_sklearn_and_the_host_mirror(fitted, edge_type):
+    from pyimsegm_amd import _hip
+    from pyimsegm_amd import graph_cuts as G
+    image, sess, features, model, gmm = fitted
+    pairwise = G.compute_pairwise_cost(1.5, (len(features), 3))
+    out = sess.segment(pairwise, edge_type, edge_cost=1.0, gmm=gmm, debug=True, want_soft=True)
+    proba = out['proba']
+    np.testing.assert_allclose(proba, model.predict_proba(features), rtol=0, atol=1e-9)
+    np.testing.assert_allclose(proba, G.predict_proba(model, features), rtol=0, atol=1e-9)
+    edges, centres, _ = sess.graph()
+    assert np.array_equal(out['edges'], edges) and np.array_equal(out['centres'], centres)
+    # terms from the DEVICE probabilities through the host functions of the reference mirror
+    np.testing.assert_allclose(out['unary'], G.compute_unary_cost(proba), rtol=1e-13, atol=1e-13)
+    ref_w = G.edge_weights_from_graph(edges, centres, features, proba, edge_type)
+    np.testing.assert_allclose(out['edge_weights'], ref_w, rtol=1e-10, atol=1e-13)
+    ui, wi = pygco_integers(out['unary'], out['edge_weights'], pairwise)
+    assert np.array_equal(out['unary_int'], ui) and np.array_equal(out['edge_weights_int'], wi)
+    # the graph cut on those very terms through the stand-alone entry point (host-built CSR) gives the same labels
+    labels, energy = _hip.cut_general_graph(edges, out['edge_weights'], out['unary'], pairwise, return_energy=True)
+    assert np.array_equal(out['graph_labels'], labels) and out['energy'] == energy
+    slic = sess.get_labels()
+    assert out['segm'].dtype == np.int32 and np.array_equal(out['segm'], labels[slic])
+    assert np.array_equal(out['soft'], proba[slic])
+
+
+def test_fused_variants(fitted):
+    """probabilities from the host, classes_ LUT, gc_regul <= 0, edge_cost, pageable outputs, soft kept on the device"""
+    from pyimsegm_amd import graph_cuts as G
+    image, sess, features, model, gmm = fitted
+    slic = sess.get_labels()
+    proba = model.predict_proba(features)
+    pairwise = G.compute_pairwise_cost(2.0, proba.shape)
+    a = sess.segment(pairwise, 'model', gmm=gmm, want_graph_labels=True)
+    b = sess.segment(pairwise, 'model', proba=proba, want_graph_labels=True, pinned=False)
+    assert np.array_equal(a['graph_labels'], b['graph_labels']) and np.array_equal(a['segm'], b['segm'])
+    classes = np.array([7, 3, 11])
+    c = sess.segment(pairwise, 'model', gmm=gmm, classes=classes)
+    assert np.array_equal(c['segm'], classes[a['graph_labels']][slic])
+    d = sess.segment(G.compute_pairwise_cost(0., proba.shape), 'model', gmm=gmm, use_graphcut=False, want_graph_labels=True, debug=True)
+    assert np.array_equal(d['graph_labels'], np.argmin(d['unary'], axis=-1))
+    e = sess.segment(pairwise, 'model', edge_cost=3.0, gmm=gmm, debug=True)
+    f = sess.segment(pairwise, 'model', edge_cost=1.0, gmm=gmm, debug=True)
+    np.testing.assert_allclose(e['edge_weights'], 3.0 * f['edge_weights'], rtol=1e-15)
+    g = sess.segment(pairwise, 'model', gmm=gmm, want_segm=False, keep_soft_on_device=True)
+    assert g == {}
+    with pytest.raises(ValueError):
+        sess.segment(pairwise, 'color', gmm=gmm)
+
+
+@pytest.mark.parametrize('name', NAMES)
+def test_fused_path_hands_gco_the_integers_of_the_reference_run(name):
+    """label map, probabilities and model of the reference's own run: the device forms the same graph, the same integer
+    energies as pygco would from the reference's float terms, and the same labels"""
+    from pyimsegm_amd import _hip
+    from pyimsegm_amd import graph_cuts as G
+    _, sp, rc, feats, nb_classes, gc_regul, edge_type = GEN.CASES[name]
+    image = make_input(name)
+    slic = VEC[name + '_slic']
+    sess = _hip.Image2D(*slic.shape).upload(image).set_labels(slic)
+    flags = feats['color']
+    sess.features_color('mean' in flags, 'std' in flags, 'energy' in flags, to_host=False)
+    pairwise = G.compute_pairwise_cost(gc_regul, VEC[name + '_proba'].shape)
+    assert np.array_equal(pairwise, VEC[name + '_gc_pairwise'])
+    # (a) the reference's probabilities handed in
+    out = sess.segment(pairwise, edge_type, proba=VEC[name + '_proba'], debug=True)
+    assert np.array_equal(out['edges'], VEC[name + '_gc_edges'])
+    np.testing.assert_allclose(out['edge_weights'], VEC[name + '_gc_edge_weights'], rtol=1e-12, atol=1e-15)
+    np.testing.assert_allclose(out['unary'], VEC[name + '_gc_unary'], rtol=1e-13, atol=1e-13)
+    ui, wi = pygco_integers(VEC[name + '_gc_unary'], VEC[name + '_gc_edge_weights'], pairwise)
+    assert np.array_equal(out['unary_int'], ui) and np.array_equal(out['edge_weights_int'], wi)
+    assert np.array_equal(out['graph_labels'], VEC[name + '_graph_labels'])
+    assert np.array_equal(out['segm'], VEC[name + '_segm'])
+    # (b) the reference's fitted model evaluated on the device (descriptors of the HIP path: last-bit differences from
+    # the reference's -ffast-math sums are allowed to move an integer energy by one unit)
+    gmm = _hip.DeviceGmm(rebuild_model(name))
+    out = sess.segment(pairwise, edge_type, gmm=gmm, debug=True)
+    np.testing.assert_allclose(out['proba'], VEC[name + '_proba'], rtol=0, atol=1e-9)
+    assert np.abs(out['unary_int'].astype(np.int64) - ui).max() <= 1
+    assert np.mean(out['segm'] != VEC[name + '_segm']) < 1e-3
+    sess.close()
+
+
+def test_fused_volume_pipeline_equals_the_staged_path():
+    """3-D session: 6-connected graph, centres with three coordinates, probabilities from the host"""
+    from pyimsegm_amd import _hip
+    from pyimsegm_amd import graph_cuts as G
+    from pyimsegm_amd import superpixels as S
+    rng = np.random.default_rng(3)
+    vol = ellipsoid_volume((12, 40, 48)).astype(np.float64) + 0.1 * rng.standard_normal((12, 40, 48))
+    sess = S._open_volume(vol)
+    S._run_slic3d(sess, 8, 0.2, (2, 1, 1))
+    k = sess.n_labels
+    proba = rng.dirichlet(np.ones(3), size=k)
+    pairwise = G.compute_pairwise_cost(0.3, proba.shape)
+    out = sess.segment(pairwise, 'model', proba=proba, debug=True, pinned=False)
+    edges, centres, _ = sess.graph()
+    assert np.array_equal(out['edges'], edges) and np.array_equal(out['centres'], centres)
+    ref_w = G.edge_weights_from_graph(edges, centres, None, proba, 'model')
+    np.testing.assert_allclose(out['edge_weights'], ref_w, rtol=1e-10, atol=1e-13)
+    labels = _hip.cut_general_graph(edges, out['edge_weights'], out['unary'], pairwise)
+    assert np.array_equal(out['graph_labels'], labels)
+    assert np.array_equal(out['segm'], labels[sess.get_labels()])
+    feats = sess.features_color(True, True, True)
+    m, e, v = sess.gray_stats()
+    assert np.array_equal(feats[:, 0], m) and np.array_equal(feats[:, 3], np.sqrt(v)) and np.array_equal(feats[:, 6], e)
+    sess.close()
+
+
+def test_pinned_arrays_are_recycled():
+    from pyimsegm_amd import _hip
+    a = _hip.pinned_empty((300, 400), np.int32)
+    a[:] = 7
+    addr = a.ctypes.data
+    del a
+    b = _hip.pinned_empty((300, 400), np.int32)
+    assert b.ctypes.data == addr and b.shape == (300, 400)
+    image = _hip.pinned_empty((64, 96, 3), np.uint8)
+    image[...] = voronoi_image(64, 96, seed=2)
+    from pyimsegm_amd import superpixels as S
+    assert np.array_equal(S.segment_slic_img2d(image, 12, 0.2), S.segment_slic_img2d(np.array(image), 12, 0.2))
+
+
+def test_rccl_single_rank_round_trip(monkeypatch):
+    """the ctypes binding of RCCL with one rank: unique id, communicator, grouped send / recv to itself on the context's
+    stream through DeviceGather (all the N > 1 gather does, minus the peers)"""
+    from pyimsegm_amd import _hip
+    from pyimsegm_amd.distributed import DeviceGather, Group
+    monkeypatch.setenv('RANK', '0')
+    monkeypatch.setenv('WORLD_SIZE', '1')
+    monkeypatch.setenv('LOCAL_RANK', '0')
+    group = Group()
+    try:
+        assert group.backend == 'rccl', group.rccl_error
+        ctx = _hip.default_context()
+        data = _hip.pinned_empty((2, 5, 1000), np.int32)
+        data[...] = np.arange(10000).reshape(2, 5, 1000)
+        back = _hip.pinned_empty((5, 1000), np.int32)
+        gather = DeviceGather(group, 4000, 5, ctx)
+        import ctypes as C
+        dev = C.c_void_p()
+        _hip._check(_hip.load_library().imsegm_device_alloc(0, data.nbytes, C.byref(dev)))
+        ctx.copy(dev.value, data.ctypes.data, data.nbytes)
+        for rnd in range(2):
+            for item in range(5):
+                gather.stage(rnd, item, dev.value + (rnd * 5 + item) * 4000, ctx)
+            gather.flush(rnd)
+            ctx.copy(back.ctypes.data, gather.recv, back.nbytes)
+            assert np.array_equal(back, data[rnd])
+        gather.close()
+        _hip.load_library().imsegm_device_free(dev)
+    finally:
+        group.close()
