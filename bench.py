@@ -372,7 +372,7 @@ def bench_color2d(args, group):
     images = [host_image(im, args.pinned_input) for im in images]
     steps = args.steps if args.steps is not None else {2: 100, 3: 5, 4: 40}[cfg]
     warmup = args.warmup if args.warmup is not None else {2: 3, 3: 1, 4: 3}[cfg]
-    inflight = args.inflight if args.inflight > 0 else {2: 4, 3: 2, 4: 4}[cfg]
+    inflight = args.inflight if args.inflight > 0 else {2: 3, 3: 2, 4: 4}[cfg]
     npx_step = per_step * height * width
 
     # model fit once, outside the timed region (the reference's group-model flow)
@@ -385,6 +385,14 @@ def bench_color2d(args, group):
     classes = getattr(model, 'classes_', None)
 
     def one_image(image, to_host=True, session=None, stage=None, k=0):
+        if to_host and session is None:
+            # the library's one-call form of segment_color2d_slic_features_model_graphcut (recycled session); with several
+            # ranks the label map is copied into the send ring (device to device) before the session is recycled
+            hook = (lambda sess: stage(k, _hip.segm_device_array(sess))) if (stage is not None and group.distributed) else None
+            fast = pipe._segment_color2d_one_call(image, model, features, sp_size, SP_REGUL, GC_REGUL, EDGE_TYPE, want_soft=False,
+                                                  reuse=True, with_session=hook)
+            if fast is not None:
+                return fast[0]
         res = pipe._ResidentImage(image, features, sp_size, SP_REGUL, session=session, reuse=session is None,
                                   features_to_host=not on_device)
         try:

@@ -222,6 +222,16 @@ IMSEGM_API int imsegm_image2d_segment(imsegm_image2d *img, const imsegm_gmm *gmm
                                       const int32_t *classes_lut, int32_t *segm_out, double *soft_out,
                                       int32_t *graph_labels_out, double *proba_out, imsegm_terms_debug *debug_out);
 
+/* segment_color2d_slic_features_model_graphcut (imsegm/pipelines.py:160-241) for a colour image, colour statistics and a
+ * mixture model the device evaluates, in ONE call: imsegm_image2d_upload + imsegm_image2d_slic (isotropic `taps`,
+ * connectivity enforced with skimage's 0.5 / 3 size factors) + imsegm_image2d_features_color + imsegm_image2d_segment. */
+IMSEGM_API int imsegm_image2d_run_color(imsegm_image2d *img, const void *host_pixels, int dtype, int minmax_normalize,
+                                        int n_segments, double compactness, const double *taps, int radius, int max_iter,
+                                        int start_label, int slic_zero, int feature_mask, const imsegm_gmm *gmm,
+                                        int n_classes, const double *pairwise, int edge_type, double edge_cost,
+                                        int use_graphcut, const int32_t *classes_lut, int32_t *segm_out, double *soft_out,
+                                        int *n_labels_out);
+
 /* Device address of a result buffer of the session (valid until the next call that rewrites it):
  * which = 0: label map int32 H x W; 1: gathered segmentation int32 H x W; 2: gathered soft
  * segmentation float64 H x W x C.  For zero-copy hand-over to a collective library (RCCL) running on

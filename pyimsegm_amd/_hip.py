@@ -72,6 +72,8 @@ _SIGNATURES = {
     'imsegm_ctx_stream': (C.c_int, [_vp, C.POINTER(_vp)]),
     'imsegm_ctx_copy': (C.c_int, [_vp, _vp, _vp, C.c_size_t, C.c_int]),
     'imsegm_image2d_features_color': (C.c_int, [_vp, C.c_int, _vp]),
+    'imsegm_image2d_run_color': (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, C.c_double, _vp, C.c_int, C.c_int, C.c_int, C.c_int,
+                                           C.c_int, C.POINTER(GmmParams), C.c_int, _vp, C.c_int, C.c_double, C.c_int, _vp, _vp, _vp, _ip]),
     'imsegm_image2d_segment': (C.c_int, [_vp, C.POINTER(GmmParams), _vp, C.c_int, _vp, C.c_int, C.c_double, C.c_int, _vp, _vp, _vp,
                                          _vp, _vp, C.POINTER(TermsDebug)]),
     'imsegm_version': (C.c_int, []),
@@ -215,7 +217,7 @@ class Context(object):
 
 
 _default_ctx = {}
-_default_ctx_lock = threading.Lock()
+_default_ctx_lock = threading.RLock()
 
 
 def default_context():
@@ -224,11 +226,13 @@ def default_context():
     A context owns one HIP stream and its pinned staging buffers, so worker threads that keep several
     images in flight on one GPU (``pipelines.NB_WORKERS``) each get their own."""
     key = (os.getpid(), threading.get_ident(), os.environ.get('IMSEGM_HIP_DEVICE', os.environ.get('LOCAL_RANK', '0')))
-    ctx = _default_ctx.get(key)
-    if ctx is None:
-        # a new thread asks for its context: first give back those of threads that have ended (and the
-        # sessions they kept for reuse); workers start together, so one at a time
-        with _default_ctx_lock:
+    # the whole lookup runs under the lock: thread identifiers are recycled, and a new thread must not pick up the
+    # context of a dead thread with the same identifier while another new thread is giving that context back
+    with _default_ctx_lock:
+        ctx = _default_ctx.get(key)
+        if ctx is None:
+            # a new thread asks for its context: first give back those of threads that have ended (and the
+            # sessions they kept for reuse)
             alive = {t.ident for t in threading.enumerate()}
             dead = [k for k in _default_ctx if k[0] == key[0] and k[1] not in alive
                     and _default_ctx[k].users == len(_default_ctx[k].idle_sessions)]
@@ -265,7 +269,7 @@ class _PinnedBlock(object):
 
 
 _pinned_free = {}
-_pinned_lock = threading.Lock()
+_pinned_lock = threading.RLock()
 _PINNED_KEEP = 16      # blocks kept per size class for reuse (hipHostMalloc costs far more than the copy it speeds up)
 
 
@@ -390,6 +394,37 @@ class Image2D(object):
         _check(load_library().imsegm_image2d_upload(self._h, _ptr(image), _DTYPES[image.dtype]))
         self._uploaded = image          # a page-locked source is read asynchronously: keep it alive until the next sync
         return self
+
+    def run_color(self, image, n_segments, compactness, gmm, pairwise, edge_type='model', feature_flags=(True, True, True),
+                  sigma=1., normalize=2, max_iter=10, start_label=0, slic_zero=False, edge_cost=1., use_graphcut=True,
+                  classes=None, want_soft=False, pinned=True):
+        """upload + SLIC + colour features + class model + graph cut + gathers of one uint8 / float64 colour image in
+        one C call (``imsegm_image2d_run_color``); returns (segm int32 H x W, soft or None)"""
+        image = np.ascontiguousarray(image)
+        if image.shape != self.shape + (3, ) or image.dtype not in _DTYPES:
+            raise ValueError('expected an image of shape %r + (3,) and dtype uint8 / float32 / float64' % (self.shape, ))
+        code = EDGE_TYPES.get(edge_type)
+        if code is None:
+            raise ValueError('edge type %r is not evaluated on the device' % (edge_type, ))
+        pairwise = np.ascontiguousarray(pairwise, dtype=np.float64)
+        nc = gmm.n_classes
+        if pairwise.shape != (nc, nc):
+            raise ValueError('pairwise cost must be %d x %d' % (nc, nc))
+        cl = None if classes is None else np.ascontiguousarray(classes, dtype=np.int32)
+        taps = gaussian_taps(sigma)
+        r = -1 if taps is None else len(taps) - 1
+        alloc = pinned_empty if pinned else np.empty
+        segm = alloc(self.shape, np.int32)
+        soft = alloc(self.shape + (nc, ), np.float64) if want_soft else None
+        mask = (1 if feature_flags[0] else 0) | (2 if feature_flags[1] else 0) | (4 if feature_flags[2] else 0)
+        n_out = C.c_int(0)
+        _check(load_library().imsegm_image2d_run_color(
+            self._h, _ptr(image), _DTYPES[image.dtype], int(normalize), int(n_segments), float(compactness), _ptr(taps), r,
+            int(max_iter), int(start_label), int(bool(slic_zero)), mask, C.byref(gmm.params), nc, _ptr(pairwise), code,
+            float(edge_cost), int(bool(use_graphcut)), _ptr(cl), _ptr(segm), _ptr(soft), C.byref(n_out)))
+        self.n_labels = n_out.value
+        self._uploaded = image
+        return segm, soft
 
     def features_color(self, mean=True, std=True, energy=True, to_host=True):
         """resident feature table (columns mean | std | energy, 3 each) of the uploaded image on the current labels;

@@ -1566,7 +1566,7 @@ int imsegm_image2d_segment(imsegm_image2d *im, const imsegm_gmm *gmm, const doub
     // ---- class probabilities, unary / edge terms, integer energies
     TermsArgs a;
     memset(&a, 0, sizeof(a));
-    a.Kp = K_dev; a.Ep = E_dev; a.edge_capacity = Ecap; a.F = F; a.C = C;
+    a.Kp = K_dev; a.K_cap = K; a.Ep = E_dev; a.edge_capacity = Ecap; a.F = F; a.C = C;
     a.features = need_features ? im->featK.as<double>() : nullptr;
     a.gmm = gmm ? 1 : 0;
     if (gmm) {
@@ -1651,6 +1651,26 @@ int imsegm_image2d_segment(imsegm_image2d *im, const imsegm_gmm *gmm, const doub
         return -1;
     }
     return 0;
+}
+
+
+// the whole colour pipeline of one image in ONE call: a worker thread of the Python layer spends a step here, outside
+// the interpreter lock (H2D, SLIC with one host synchronisation for the label count, features, fused back half, D2H)
+int imsegm_image2d_run_color(imsegm_image2d *im, const void *host_pixels, int dtype, int minmax_normalize, int n_segments,
+                             double compactness, const double *taps, int radius, int max_iter, int start_label, int slic_zero,
+                             int feature_mask, const imsegm_gmm *gmm, int n_classes, const double *pairwise, int edge_type,
+                             double edge_cost, int use_graphcut, const int32_t *classes_lut, int32_t *segm_out, double *soft_out,
+                             int *n_labels_out)
+{
+    if (imsegm_image2d_upload(im, host_pixels, dtype)) return -1;
+    int n_labels = 0;
+    if (imsegm_image2d_slic(im, minmax_normalize, n_segments, compactness, taps, radius, taps, radius, taps, radius, max_iter, 1, 0.5,
+                            3.0, start_label, 0, slic_zero, &n_labels))
+        return -1;
+    if (n_labels_out) *n_labels_out = n_labels;
+    if (imsegm_image2d_features_color(im, feature_mask, nullptr)) return -1;
+    return imsegm_image2d_segment(im, gmm, nullptr, n_classes, pairwise, edge_type, edge_cost, use_graphcut, classes_lut, segm_out,
+                                  soft_out, nullptr, nullptr, nullptr);
 }
 
 }  // extern "C"

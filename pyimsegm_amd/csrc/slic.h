@@ -186,6 +186,7 @@ size_t alpha_expansion_work_bytes(int K, int E);
 // terms.hip ---------------------------------------------------------------------------------------
 struct TermsArgs {
     const int *Kp;                 // number of superpixels (device)
+    int K_cap;                     // upper bound of it known to the host (launch geometry)
     const int *Ep;                 // number of edges (device)
     int edge_capacity;
     int F, C;

@@ -204,6 +204,47 @@ k_adj_emit(const uint32_t *__restrict__ bitmap, const int *__restrict__ Kp, int 
 // ---- class probabilities + graph-cut terms: ONE workgroup (K ~ 2e3 rows, E ~ 6e3 edges: a few microseconds; the
 // phases need grid-wide reductions of a handful of scalars, which a single workgroup gets from __syncthreads)
 
+// predict_proba of Pipeline([StandardScaler,] GaussianMixture('full')): StandardScaler.transform,
+// GaussianMixture._estimate_weighted_log_prob, scipy logsumexp, exp.  One wave per superpixel: lane j forms
+// y_j = sum_f x_f P[c][f][j] - mu_proj[c][j] (sequential in f, as a plain dot product), lane 0 adds the squares in index order.
+__global__ void __launch_bounds__(256) k_gmm_proba(TermsArgs a)
+{
+    const int K = *a.Kp, C = a.C, F = a.F;
+    const int lane = threadIdx.x & 63;
+    const int k = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if (k >= K) return;
+    double xv = 0.0;
+    if (lane < F) {
+        xv = a.features[(size_t)k * F + lane];
+        if (a.scaler_mean) xv = xv - a.scaler_mean[lane];
+        if (a.scaler_scale) xv = xv / a.scaler_scale[lane];
+    }
+    double mywl = -INFINITY;                             // lane c keeps the weighted log probability of class c
+    double amax = -INFINITY;
+    for (int c = 0; c < C; ++c) {
+        const double *P = a.prec_chol + (size_t)c * F * F;
+        double y = 0.0;
+        for (int f = 0; f < F; ++f) {
+            const double xf = __shfl(xv, f, 64);
+            if (lane < F) y += xf * P[f * F + lane];
+        }
+        if (lane < F) y = y - a.mu_proj[c * F + lane];
+        const double y2 = y * y;
+        double lp = 0.0;
+        for (int j = 0; j < F; ++j) lp += __shfl(y2, j, 64);
+        const double lg = -0.5 * (a.const_term + lp) + a.log_det[c];
+        const double w = lg + a.log_w[c];
+        if (lane == c) mywl = w;
+        amax = fmax(amax, w);
+    }
+    if (!(fabs(amax) <= DBL_MAX)) amax = 0.0;            // scipy.special.logsumexp: non-finite maximum -> 0
+    const double ex = exp(mywl - amax);                  // lanes >= C: exp(-inf) = 0
+    double s = 0.0;
+    for (int c = 0; c < C; ++c) s += __shfl(ex, c, 64);
+    const double lse = log(s) + amax;
+    if (lane < C) a.proba[(size_t)k * C + lane] = exp(mywl - lse);
+}
+
 __global__ void __launch_bounds__(TM_THREADS) k_gc_terms(TermsArgs a)
 {
     __shared__ double scratch[TM_THREADS / 64];
@@ -213,39 +254,7 @@ __global__ void __launch_bounds__(TM_THREADS) k_gc_terms(TermsArgs a)
         if (threadIdx.x == 0) atomicOr(a.status, 2);
         E = a.edge_capacity;
     }
-    // 1. predict_proba: StandardScaler.transform, GaussianMixture._estimate_weighted_log_prob, logsumexp, exp
-    if (a.gmm) {
-        for (int k = threadIdx.x; k < K; k += TM_THREADS) {
-            double x[32];
-            for (int f = 0; f < F; ++f) {
-                double v = a.features[(size_t)k * F + f];
-                if (a.scaler_mean) v = v - a.scaler_mean[f];
-                if (a.scaler_scale) v = v / a.scaler_scale[f];
-                x[f] = v;
-            }
-            double wl[16];
-            double amax = -INFINITY;
-            for (int c = 0; c < C; ++c) {
-                const double *P = a.prec_chol + (size_t)c * F * F;
-                double lp = 0.0;
-                for (int j = 0; j < F; ++j) {
-                    double y = 0.0;
-                    for (int f = 0; f < F; ++f) y += x[f] * P[f * F + j];
-                    y = y - a.mu_proj[c * F + j];
-                    lp += y * y;
-                }
-                const double lg = -0.5 * (a.const_term + lp) + a.log_det[c];
-                wl[c] = lg + a.log_w[c];
-                amax = fmax(amax, wl[c]);
-            }
-            if (!(fabs(amax) <= DBL_MAX)) amax = 0.0;            // scipy.special.logsumexp: non-finite maximum -> 0
-            double s = 0.0;
-            for (int c = 0; c < C; ++c) s += exp(wl[c] - amax);
-            const double lse = log(s) + amax;
-            for (int c = 0; c < C; ++c) a.proba[(size_t)k * C + c] = exp(wl[c] - lse);
-        }
-        __syncthreads();
-    }
+    // (1. predict_proba ran before this kernel: k_gmm_proba, one wave per superpixel)
     // 2. unary cost |-log(clip(p, 0.01, 0.99))| and its maximum
     double umax = 0.0;
     for (int i = threadIdx.x; i < K * C; i += TM_THREADS) {
@@ -401,6 +410,7 @@ int launch_gc_terms(const TermsArgs &a, hipStream_t st)
         set_error("device class model: at most 32 features and 16 classes");
         return -1;
     }
+    if (a.gmm) hipLaunchKernelGGL(k_gmm_proba, cdiv((long)a.K_cap * 64, 256), 256, 0, st, a);
     hipLaunchKernelGGL(k_gc_terms, 1, TM_THREADS, 0, st, a);
     HIP_TRY(hipGetLastError());
     return 0;

@@ -59,6 +59,53 @@ def _device_gmm(model):
         return None
 
 
+def _segment_color2d_one_call(image, model, dict_features, sp_size, sp_regul, gc_regul, gc_edge_type, want_soft=True, reuse=False,
+                              with_session=None):
+    """``segment_color2d_slic_features_model_graphcut`` as ONE call into the library (:meth:`_hip.Image2D.run_color`) when
+    everything it needs lives on the device: uint8 / float64 colour image, colour mean / std / energy features, a
+    scaler + full-covariance mixture, an edge type the device evaluates.  Returns None when the general path is needed.
+    ``with_session(sess)`` is called before the session is recycled (the label map is still in its HBM buffer then)."""
+    from pyimsegm_amd.graph_cuts import compute_pairwise_cost
+    from pyimsegm_amd.superpixels import SLIC_MAX_ITER, SLIC_START_LABEL, _slic_params
+    image = np.asarray(image)
+    flags = dict_features.get('color', ()) if set(dict_features) == {'color'} else None
+    if image.ndim != 3 or image.shape[2] != 3 or image.dtype not in (np.uint8, np.float64) or not flags \
+            or not set(flags) <= {'mean', 'std', 'energy'} or gc_edge_type not in _hip.EDGE_TYPES:
+        return None
+    if sp_regul <= 0.:
+        raise ValueError('slic. regularisation must be positive')
+    gmm = _device_gmm(model)
+    if gmm is None or gmm.n_features != 3 * len(set(flags)):
+        return None
+    if image.dtype != np.uint8 and not bool(np.isfinite(image.sum(dtype=np.float64))):
+        return None
+    n_seg, compact = _slic_params(image.shape[:2], sp_size, sp_regul)
+    if n_seg < 1:
+        raise ValueError('superpixel size %r is larger than the image %r' % (sp_size, image.shape[:2]))
+    pairwise = compute_pairwise_cost(gc_regul, (0, gmm.n_classes))
+    classes = getattr(model, 'classes_', None)
+    sess = None
+    if reuse:
+        sess = _hip.default_context().idle_sessions.pop(image.shape[:2], None)
+    if sess is None:
+        sess = _hip.Image2D(image.shape[0], image.shape[1])
+    try:
+        segm, soft = sess.run_color(image, n_seg, compact, gmm, pairwise, gc_edge_type,
+                                    ('mean' in flags, 'std' in flags, 'energy' in flags), max_iter=SLIC_MAX_ITER,
+                                    start_label=SLIC_START_LABEL, use_graphcut=not (np.isscalar(gc_regul) and gc_regul <= 0),
+                                    classes=None if classes is None else np.asarray(classes).astype(np.int32), want_soft=want_soft)
+        if with_session is not None:
+            with_session(sess)
+    finally:
+        if reuse:
+            _release_session(sess)
+        else:
+            sess.close()
+    if classes is not None and np.asarray(classes).dtype != np.int32:
+        segm = segm.astype(np.asarray(classes).dtype)
+    return segm, soft
+
+
 class _ResidentImage(object):
     """one image on the device: superpixels + features, then the fused class model / graph cut / gathers"""
 
@@ -393,6 +440,10 @@ def segment_color2d_slic_features_model_graphcut(
     :return tuple(ndarray,ndarray): segmentation H x W, soft segmentation H x W x nb_classes
     """
     logging.info('PIPELINE Superpixels-Features-Model-GraphCut')
+    if debug_visual is None:
+        fast = _segment_color2d_one_call(image, model_pipeline, dict_features, sp_size, sp_regul, gc_regul, gc_edge_type)
+        if fast is not None:
+            return fast
     res = _ResidentImage(image, dict_features, sp_size, sp_regul, features_to_host=_device_gmm(model_pipeline) is None)
     try:
         res.fill_debug(debug_visual)
@@ -426,6 +477,10 @@ def segment_batch_color2d_slic_features_model_graphcut(list_images, model_pipeli
     def _segment(image):
         # as segment_color2d_slic_features_model_graphcut, minus what a batch does not need: the soft
         # segmentation is not computed and the session buffers are recycled from image to image
+        fast = _segment_color2d_one_call(image, model_pipeline, dict_features, sp_size, sp_regul, gc_regul, gc_edge_type,
+                                         want_soft=False, reuse=True)
+        if fast is not None:
+            return fast[0]
         res = _ResidentImage(image, dict_features, sp_size, sp_regul, reuse=True, features_to_host=not on_device)
         try:
             segm, _ = res.segment(None, gc_regul, gc_edge_type, classes=classes, want_soft=False, model=model_pipeline)

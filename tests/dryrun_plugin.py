@@ -74,6 +74,14 @@ class Image2D(object):
         self.last_segm = segm
         soft = np.asarray(proba, dtype=np.float64)[self.labels] if proba is not None else None
         return segm, soft
+    def run_color(self, image, n_segments, compactness, gmm, pairwise, edge_type='model', feature_flags=(True, True, True),
+                  sigma=1., normalize=2, max_iter=10, start_label=0, slic_zero=False, edge_cost=1., use_graphcut=True,
+                  classes=None, want_soft=False, pinned=True):
+        self.upload(image)
+        self.slic(n_segments, compactness, sigma=sigma, normalize=normalize, max_iter=max_iter, start_label=start_label, slic_zero=slic_zero)
+        self.features_color(*feature_flags, to_host=False)
+        out = self.segment(pairwise, edge_type, edge_cost, gmm=gmm, use_graphcut=use_graphcut, classes=classes, want_soft=want_soft)
+        return out['segm'], out.get('soft')
     def features_color(self, mean=True, std=True, energy=True, to_host=True):
         m, e, v = self.color_stats(True, energy, std)
         blocks = ([m] if mean else []) + ([np.sqrt(v)] if std else []) + ([e] if energy else [])
