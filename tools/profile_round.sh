@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round profile: bench JSON, rocprofv3 kernel stats and the HBM-traffic PMC passes of the same command.
 # Run on the GPU box (gpurun); copies the summaries into profiles/ under the given tag.
-TAG=${1:-r01b}
+TAG=${1:-r02a}
 REPO=${GRAFT_REPO_ROOT:-/root/repo}
 cd /tmp && export TMPDIR=/tmp
 OUT=$REPO/gpurun_out/prof_$TAG
