@@ -14,7 +14,7 @@ import threading
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libimsegm_hip.so')
+LIB_PATH = os.environ.get('IMSEGM_HIP_LIBRARY') or os.path.join(_HERE, 'libimsegm_hip.so')
 
 U8, F64, F32 = 0, 1, 2
 PROFILE_GROUPS = {

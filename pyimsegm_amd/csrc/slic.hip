@@ -1132,8 +1132,11 @@ typedef float f2 __attribute__((ext_vector_type(2)));
 // the winner is the nearest grid node per axis, ties to the lower index (= lowest centroid index, what
 // the strict '<' of _slic.pyx keeps).  The launcher only selects this variant when every pixel lies inside
 // the search window of its nearest node.
+#ifndef SLIC_DOT_MIN_BLOCKS
+#define SLIC_DOT_MIN_BLOCKS 5
+#endif
 template <bool ACCUM, bool FIRST>
-__global__ void __launch_bounds__(256, 5)
+__global__ void __launch_bounds__(256, SLIC_DOT_MIN_BLOCKS)
 k_slic_assign_dot(SlicState s, const double *__restrict__ lab, int32_t *__restrict__ labels,
                   const Cand *__restrict__ tile_cands, const Rec32 *__restrict__ tile_rec,
                   const TileInfo *__restrict__ tile_info, const int *__restrict__ tile_k)
