@@ -232,6 +232,14 @@ IMSEGM_API int imsegm_image2d_run_color(imsegm_image2d *img, const void *host_pi
                                         int use_graphcut, const int32_t *classes_lut, int32_t *segm_out, double *soft_out,
                                         int *n_labels_out);
 
+/* The 'median' and 'meanGrad' statistics of compute_image2d_color_statistic / compute_image3d_gray_statistic
+ * (imsegm/descriptors.py:420-455, 671-702, 766-770, 841-845) on the resident image (K x 3) or volume (K):
+ * median of the pixel values per label and channel (NaN for labels without pixels, as np.median of an empty list);
+ * mean over the label of np.sum(np.gradient(slice), axis=0) stored in the image's dtype (float32 staging as the other
+ * means).  Both invalidate a prepared Leung-Malik state (they borrow its buffers). */
+IMSEGM_API int imsegm_image2d_median(imsegm_image2d *img, double *median_out);
+IMSEGM_API int imsegm_image2d_mean_gradient(imsegm_image2d *img, double *mean_out);
+
 /* Device address of a result buffer of the session (valid until the next call that rewrites it):
  * which = 0: label map int32 H x W; 1: gathered segmentation int32 H x W; 2: gathered soft
  * segmentation float64 H x W x C.  For zero-copy hand-over to a collective library (RCCL) running on
@@ -239,8 +247,22 @@ IMSEGM_API int imsegm_image2d_run_color(imsegm_image2d *img, const void *host_pi
 IMSEGM_API int imsegm_image2d_device_ptr(imsegm_image2d *img, int which, void **ptr_out);
 
 /* ---------------------------------------------------------------------------------------------
- * stand-alone stage
+ * stand-alone stages
  * ------------------------------------------------------------------------------------------- */
+/* Replaces imsegm.features_cython.computeLabelHistogram2d (imsegm/features_cython.pyx:222-241; called per position through
+ * descriptors.py:1411-1495 compute_label_hist_segm / cython_label_hist_seg2d) for a BATCH of windows of one label image:
+ * window p = segm[y0 : y0 + h, x0 : x0 + w] against struc_elem[sy0 : sy0 + h, sx0 : sx0 + w], windows[p] = {y0, x0, h, w, sy0,
+ * sx0}; hist_out[p][l] = pixels with label l (0 <= l < nb_labels) where the structuring element equals 1. */
+IMSEGM_API int imsegm_label_hist2d(imsegm_ctx *ctx, const int16_t *segm, int height, int width, const int32_t *windows,
+                                   int n_windows, const int16_t *struc_elem, int se_height, int se_width, int nb_labels,
+                                   uint32_t *hist_out);
+/* Replaces imsegm.features_cython.computeRayFeaturesBinary2d (features_cython.pyx:244-282; descriptors.py:1630-1660
+ * cython_ray_features_seg2d) for a BATCH of positions (row, col): directions[a] = (sin, cos) of angle a divided by the
+ * larger of their magnitudes, float32, formed by the caller as the .pyx forms them; edge 1 = 'up', -1 = 'down';
+ * ray_dist_out[p][a] = distance to the edge along ray a, -1 if none (0 for every ray when 'up' starts inside). */
+IMSEGM_API int imsegm_ray_features_binary2d(imsegm_ctx *ctx, const int8_t *seg_binary, int height, int width,
+                                            const int32_t *positions, int n_positions, const float *directions, int n_angles,
+                                            int edge, float *ray_dist_out);
 /* Replaces gco.cut_general_graph(edges, edge_weights, unary_cost, pairwise_cost, n_iter,
  * algorithm='expansion') (gco-wrapper >= 3.0.8) as called at imsegm/graph_cuts.py:735-744.
  * edges: E x 2 int32 with edges[:,0] < edges[:,1]; edge_weights: E; unary: K x C; pairwise: C x C

@@ -427,3 +427,16 @@ def slic_gray3d_float32(vol, n_segments, compactness, sigma=1., spacing=(1., 1.,
     L.orc_enforce_connectivity(_p(labels), C.c_int(D), C.c_int(H), C.c_int(W), C.c_long(int(0.5 * segment_size)),
                                C.c_long(int(3 * segment_size)), C.c_int(start_label), _p(out))
     return out.astype(np.int64)
+
+
+def cut_grid_graph(unary_cost, pairwise_cost, cost_v, cost_h, n_iter=-1, algorithm='expansion'):
+    """CPU restatement of ``gco.cut_grid_graph`` (gco-wrapper 3.0.x, pygco.py: the vertical edges followed by the horizontal
+    ones of a general graph, one down-weight factor over all of them), called at imsegm/region_growing.py:248"""
+    unary_cost = np.asarray(unary_cost, dtype=np.float64)
+    height, width, n_labels = unary_cost.shape
+    index = np.arange(height * width, dtype=np.int32).reshape(height, width)
+    edges = np.concatenate([np.stack([index[:-1].ravel(), index[1:].ravel()], axis=1),
+                            np.stack([index[:, :-1].ravel(), index[:, 1:].ravel()], axis=1)], axis=0)
+    weights = np.concatenate([np.asarray(cost_v, dtype=np.float64).ravel(), np.asarray(cost_h, dtype=np.float64).ravel()])
+    return cut_general_graph(edges, weights, unary_cost.reshape(height * width, n_labels), pairwise_cost, n_iter=n_iter,
+                             algorithm=algorithm)

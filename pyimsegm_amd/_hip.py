@@ -109,6 +109,10 @@ _SIGNATURES = {
     'imsegm_volume_label_cc': (C.c_int, [_vp, _ip]),
     'imsegm_volume_gray_stats': (C.c_int, [_vp, _vp, _vp, _vp]),
     'imsegm_volume_graph': (C.c_int, [_vp, _vp, C.c_int, _ip, _vp, _vp]),
+    'imsegm_image2d_median': (C.c_int, [_vp, _vp]),
+    'imsegm_image2d_mean_gradient': (C.c_int, [_vp, _vp]),
+    'imsegm_label_hist2d': (C.c_int, [_vp, _vp, C.c_int, C.c_int, _vp, C.c_int, _vp, C.c_int, C.c_int, C.c_int, _vp]),
+    'imsegm_ray_features_binary2d': (C.c_int, [_vp, _vp, C.c_int, C.c_int, _vp, C.c_int, _vp, C.c_int, C.c_int, _vp]),
     'imsegm_cut_general_graph': (C.c_int, [_vp, _vp, C.c_int, _vp, _vp, C.c_int, C.c_int, _vp, C.c_int, _vp,
                                            C.POINTER(C.c_int64)]),
 }
@@ -425,6 +429,18 @@ class Image2D(object):
         self.n_labels = n_out.value
         self._uploaded = image
         return segm, soft
+
+    def median(self):
+        """per-label median of the uploaded image / volume on the current labels: K x 3 (K for a volume)"""
+        out = np.empty((self.n_labels, 3) if len(self.shape) == 2 else (self.n_labels, ), dtype=np.float64)
+        _check(load_library().imsegm_image2d_median(self._h, _ptr(out)))
+        return out
+
+    def mean_gradient(self):
+        """per-label mean of ``np.sum(np.gradient(slice), axis=0)`` (stored in the image's dtype): K x 3 (K for a volume)"""
+        out = np.empty((self.n_labels, 3) if len(self.shape) == 2 else (self.n_labels, ), dtype=np.float64)
+        _check(load_library().imsegm_image2d_mean_gradient(self._h, _ptr(out)))
+        return out
 
     def features_color(self, mean=True, std=True, energy=True, to_host=True):
         """resident feature table (columns mean | std | energy, 3 each) of the uploaded image on the current labels;
@@ -771,3 +787,46 @@ def cut_general_graph(edges, edge_weights, unary_cost, pairwise_cost, n_iter=-1,
     _check(load_library().imsegm_cut_general_graph(ctx._h, _ptr(edges), len(edges), _ptr(ew), _ptr(un), un.shape[0],
                                                    un.shape[1], _ptr(pw), int(n_iter), _ptr(labels), C.byref(energy)))
     return (labels, energy.value) if return_energy else labels
+
+
+def cut_grid_graph(unary_cost, pairwise_cost, cost_v, cost_h, n_iter=-1, algorithm='expansion', ctx=None):
+    """drop-in for ``gco.cut_grid_graph`` (gco-wrapper, reference ``region_growing.py:248``): 4-connected pixel grid with
+    vertical / horizontal edge costs ``cost_v`` (H-1 x W) / ``cost_h`` (H x W-1); pygco hands GCO the vertical edges followed
+    by the horizontal ones of the general graph, which is what happens here.  Returns int32 labels of the H*W sites."""
+    unary_cost = np.asarray(unary_cost, dtype=np.float64)
+    if unary_cost.ndim != 3:
+        raise ValueError('unary_cost must be height x width x labels')
+    height, width, n_labels = unary_cost.shape
+    cost_v, cost_h = np.asarray(cost_v, dtype=np.float64), np.asarray(cost_h, dtype=np.float64)
+    if cost_v.shape != (height - 1, width) or cost_h.shape != (height, width - 1):
+        raise ValueError('cost_v / cost_h do not match the grid %d x %d' % (height, width))
+    index = np.arange(height * width, dtype=np.int32).reshape(height, width)
+    edges = np.concatenate([np.stack([index[:-1].ravel(), index[1:].ravel()], axis=1),
+                            np.stack([index[:, :-1].ravel(), index[:, 1:].ravel()], axis=1)], axis=0)
+    weights = np.concatenate([cost_v.ravel(), cost_h.ravel()])
+    return cut_general_graph(edges, weights, unary_cost.reshape(height * width, n_labels), pairwise_cost, n_iter=n_iter,
+                             algorithm=algorithm, ctx=ctx)
+
+
+def label_hist2d(segm, windows, struc_elem, nb_labels, ctx=None):
+    """``computeLabelHistogram2d`` for a batch of windows (``imsegm_label_hist2d``): uint32 [P, nb_labels]"""
+    ctx = ctx or default_context()
+    segm = np.ascontiguousarray(segm, dtype=np.int16)
+    selem = np.ascontiguousarray(struc_elem, dtype=np.int16)
+    windows = np.ascontiguousarray(windows, dtype=np.int32).reshape(-1, 6)
+    out = np.zeros((len(windows), int(nb_labels)), dtype=np.uint32)
+    _check(load_library().imsegm_label_hist2d(ctx._h, _ptr(segm), segm.shape[0], segm.shape[1], _ptr(windows), len(windows),
+                                              _ptr(selem), selem.shape[0], selem.shape[1], int(nb_labels), _ptr(out)))
+    return out
+
+
+def ray_features_binary2d(seg_binary, positions, directions, edge, ctx=None):
+    """``computeRayFeaturesBinary2d`` for a batch of positions (``imsegm_ray_features_binary2d``): float32 [P, A]"""
+    ctx = ctx or default_context()
+    seg = np.ascontiguousarray(seg_binary, dtype=np.int8)
+    positions = np.ascontiguousarray(positions, dtype=np.int32).reshape(-1, 2)
+    directions = np.ascontiguousarray(directions, dtype=np.float32).reshape(-1, 2)
+    out = np.empty((len(positions), len(directions)), dtype=np.float32)
+    _check(load_library().imsegm_ray_features_binary2d(ctx._h, _ptr(seg), seg.shape[0], seg.shape[1], _ptr(positions), len(positions),
+                                                       _ptr(directions), len(directions), int(edge), _ptr(out)))
+    return out

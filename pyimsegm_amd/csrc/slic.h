@@ -169,6 +169,18 @@ int launch_adjacency_bitmap(const int32_t *labels, int H, int W, int K, uint32_t
 int launch_gather_labels(const int32_t *lut, const int32_t *idx, size_t n, int32_t *out, hipStream_t st);
 int launch_gather_proba(const double *lut, int C, const int32_t *idx, size_t n, double *out, hipStream_t st);
 
+// median.hip -------------------------------------------------------------------------------------
+int launch_gradient_image(const void *src, void *dst, int dtype, int S, int H, int W, int C, hipStream_t st);
+size_t median_scratch_bytes(size_t n, int K);
+int launch_segment_median(const void *img, int dtype, int C, size_t n, const int32_t *labels, int K, void *scratch, size_t scratch_bytes,
+                          double *out, hipStream_t st);
+
+// natives.hip ------------------------------------------------------------------------------------
+int launch_label_hist2d(const int16_t *segm, int H, int W, const int32_t *windows, int P, const int16_t *selem, int SH, int SW,
+                        int nb_labels, unsigned int *hist, hipStream_t st);
+int launch_ray_features_binary2d(const int8_t *seg, int H, int W, const int32_t *positions, int P, const float *grad, int A, int edge,
+                                 float *out, hipStream_t st);
+
 // graphcut.hip ------------------------------------------------------------------------------------
 struct GcProblem {
     int K, C, E;            // E: number of edges, or their capacity when E_dev is given

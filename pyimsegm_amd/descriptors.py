@@ -446,28 +446,37 @@ def compute_image3d_gray_statistic(image, segm, feature_flags=NAMES_FEATURE_FLAG
         image = np.nan_to_num(image)       # (a resident session already holds the caller-checked finite volume)
     features = []
     want = [f in feature_flags for f in ('mean', 'energy', 'std')]
-    if any(want):
+    # median / meanGrad run on the device for the dtypes a session holds unchanged (the gradient volume keeps the dtype
+    # of the source, descriptors.py:767-769: integer volumes truncate / wrap); exotic dtypes take the numpy route
+    on_device = image.dtype in (np.uint8, np.float32, np.float64) and min(image.shape[1:]) >= 2
+    extra = on_device and ('median' in feature_flags or 'meanGrad' in feature_flags)
+    own = False
+    if any(want) or extra:
         own = sess is None
         if own:
             sess = _hip.Volume3D(*segm.shape).upload(image).set_labels(segm)
-        mean, energy, var = sess.gray_stats(mean=want[0], energy=want[1], var=want[2])
+    try:
+        if any(want):
+            mean, energy, var = sess.gray_stats(mean=want[0], energy=want[1], var=want[2])
+            if want[0]:
+                features.append(mean)
+            if want[2]:
+                features.append(np.sqrt(var))
+            if want[1]:
+                features.append(energy)
+        if 'median' in feature_flags:
+            features.append(sess.median() if on_device else numpy_img3d_gray_median(image, segm))
+        if 'meanGrad' in feature_flags:
+            if on_device:
+                features.append(sess.mean_gradient())
+            else:
+                grad = np.zeros_like(image)
+                for i in range(image.shape[0]):
+                    grad[i] = np.sum(np.gradient(image[i]), axis=0)
+                features.append(cython_img3d_gray_mean(grad, segm))
+    finally:
         if own:
             sess.close()
-        if want[0]:
-            features.append(mean)
-        if want[2]:
-            features.append(np.sqrt(var))
-        if want[1]:
-            features.append(energy)
-    if 'median' in feature_flags:
-        features.append(numpy_img3d_gray_median(image, segm))
-    if 'meanGrad' in feature_flags:
-        # as the reference (descriptors.py:767-769): the gradient sums are stored in the image's own dtype -- for an
-        # integer volume they are truncated and wrap around exactly as numpy does there
-        grad = np.zeros_like(image)
-        for i in range(image.shape[0]):
-            grad[i] = np.sum(np.gradient(image[i]), axis=0)
-        features.append(cython_img3d_gray_mean(grad, segm))
     names = ['%s_%s' % (ch_name, n) for n in NAMES_FEATURE_FLAGS if n in feature_flags]
     _check_unrecognised_feature_names(feature_flags)
     features = np.nan_to_num(np.array(features)).T
@@ -491,14 +500,19 @@ def _color_statistic_session(sess, image, segm, feature_flags, color_name):
         blocks.append(np.sqrt(var))
     if want[2]:
         blocks.append(energy)
+    # median / meanGrad: on the device for the dtypes a session holds unchanged (the gradient image keeps the dtype of
+    # the source, descriptors.py:842-844: integer images truncate / wrap); exotic dtypes take the numpy route
+    on_device = np.asarray(image).dtype in (np.uint8, np.float32, np.float64) and min(np.shape(image)[:2]) >= 2
     if 'median' in feature_flags:
-        blocks.append(numpy_img2d_color_median(image, segm))
+        blocks.append(sess.median() if on_device else numpy_img2d_color_median(image, segm))
     if 'meanGrad' in feature_flags:
-        # as the reference (descriptors.py:842-844): stored in the image's own dtype (integer images truncate / wrap)
-        grad = np.zeros_like(image)
-        for i in range(3):
-            grad[:, :, i] = np.sum(np.gradient(image[:, :, i]), axis=0)
-        blocks.append(hip_img2d_color_mean(grad, segm))
+        if on_device:
+            blocks.append(sess.mean_gradient())
+        else:
+            grad = np.zeros_like(image)
+            for i in range(3):
+                grad[:, :, i] = np.sum(np.gradient(image[:, :, i]), axis=0)
+            blocks.append(hip_img2d_color_mean(grad, segm))
     ch_names = ['%s-ch%i' % (color_name, i + 1) for i in range(3)]
     names = list(itertools.chain.from_iterable(['%s_%s' % (n, f) for n in ch_names] for f in NAMES_FEATURE_FLAGS
                                                if f in feature_flags))
@@ -873,3 +887,139 @@ def compute_selected_features_img2d(image, segm, features_flags=FEATURES_SET_COL
     if image.ndim == 2:
         return compute_selected_features_gray2d(image, segm, features_flags)
     logging.error('invalid image size - %r', image.shape)
+
+
+# ------------------------------------------------------------------------------------------------
+# label histograms around positions and ray features (reference descriptors.py:1371-1660); the
+# natives behind them (features_cython.pyx:222-282) run batched on the device
+# ------------------------------------------------------------------------------------------------
+
+
+def adjust_bounding_box_crop(image_size, bbox_size, position):
+    """ clip a box of ``bbox_size`` centred at ``position`` to the image (reference ``descriptors.py:1371-1409``)
+
+    :return (), (), (), (): begin / end of the crop in the image, begin / end of the matching part of the box
+
+    >>> adjust_bounding_box_crop((50, 50), (7, 7), (20, 20))
+    ((17, 17), (24, 24), (0, 0), (7, 7))
+    >>> adjust_bounding_box_crop((50, 50), (15, 15), (20, 45))
+    ((13, 38), (28, 50), (0, 0), (15, 12))
+    >>> adjust_bounding_box_crop((50, 50), (15, 15), (5, 5))
+    ((0, 0), (13, 13), (2, 2), (15, 15))
+    >>> adjust_bounding_box_crop((50, 50), (80, 80), (20, 20))
+    ((0, 0), (50, 50), (20, 20), (70, 70))
+    """
+    if len(image_size) != len(bbox_size):
+        raise ValueError('incompatible sizes %r != %r' % (image_size, bbox_size))
+    im_begin, im_end, bb_begin, bb_end = [], [], [], []
+    for size, box, pos in zip(image_size, bbox_size, position):
+        size, box, pos = int(size), int(box), int(pos)
+        half_lo, half_hi = box // 2, box - box // 2             # floor(box / 2), ceil(box / 2)
+        lo, hi = max(pos - half_lo, 0), min(pos + half_hi, size)
+        im_begin.append(lo)
+        im_end.append(hi)
+        bb_begin.append(half_lo - pos if lo == 0 else 0)
+        bb_end.append(half_lo + (size - pos) if hi == size else box)
+    if [e - b for b, e in zip(im_begin, im_end)] != [e - b for b, e in zip(bb_begin, bb_end)]:
+        raise ValueError('different sizes of image %r and bounding box %r mask'
+                         % ([e - b for b, e in zip(im_begin, im_end)], [e - b for b, e in zip(bb_begin, bb_end)]))
+    return tuple(im_begin), tuple(im_end), tuple(bb_begin), tuple(bb_end)
+
+
+def hip_label_hist_seg2d(segm_select, struc_elem, nb_labels):
+    """ histogram of the labels under a structuring element (``computeLabelHistogram2d``) on the device
+
+    >>> segm = np.zeros((10, 10), dtype=int)
+    >>> segm[1:9, 2:8] = 1
+    >>> segm[3:7, 4:6] = 2
+    >>> hip_label_hist_seg2d(segm[2:5, 4:7], np.ones((3, 3)), 3).tolist()  # doctest: +SKIP
+    [0.0, 5.0, 4.0]
+    """
+    segm_select, struc_elem = np.asarray(segm_select), np.asarray(struc_elem)
+    if segm_select.shape != struc_elem.shape:
+        raise ValueError('segm. %r and mask %r sizes do not match' % (segm_select.shape, struc_elem.shape))
+    if segm_select.dtype.kind == 'f':
+        segm_select = np.where(np.isnan(segm_select), -1, segm_select)      # NaN marks "no label" (descriptors.py:1490)
+    h, w = segm_select.shape
+    hist = _hip.label_hist2d(segm_select, [[0, 0, h, w, 0, 0]], struc_elem, nb_labels)[0]
+    return np.array(hist, dtype=float)
+
+
+cython_label_hist_seg2d = hip_label_hist_seg2d
+
+
+def compute_label_hist_segm(segm, position, struc_elem, nb_labels):
+    """ label histogram of the neighbourhood ``struc_elem`` around ``position`` and the size of that neighbourhood
+    (reference ``descriptors.py:1411-1461``)
+
+    >>> segm = np.zeros((10, 10), dtype=int)
+    >>> segm[1:9, 2:8] = 1
+    >>> segm[3:7, 4:6] = 2
+    >>> compute_label_hist_segm(segm, [6, 6], np.ones((3, 3)), 3)  # doctest: +SKIP
+    (array([ 0.,  7.,  2.]), 9.0)
+    """
+    hists, sizes = compute_label_hist_positions(segm, [position], struc_elem, nb_labels)
+    return hists[0], sizes[0]
+
+
+def compute_label_hist_positions(segm, positions, struc_elem, nb_labels):
+    """ :func:`compute_label_hist_segm` for many positions in ONE launch (a wave per position)
+
+    :return tuple(ndarray,ndarray): histograms P x nb_labels (float), sizes of the clipped neighbourhoods P
+    """
+    segm, struc_elem = np.asarray(segm), np.asarray(struc_elem)
+    windows, sizes = [], []
+    for position in positions:
+        if segm.ndim != len(position):
+            raise ValueError('dim of position %r should match the segmentation %r dim' % (position, segm.shape))
+        position = [int(p) for p in position]
+        im_begin, im_end, bb_begin, bb_end = adjust_bounding_box_crop(segm.shape, struc_elem.shape, position)
+        windows.append([im_begin[0], im_begin[1], im_end[0] - im_begin[0], im_end[1] - im_begin[1], bb_begin[0], bb_begin[1]])
+        sizes.append(np.sum(struc_elem[bb_begin[0]:bb_end[0], bb_begin[1]:bb_end[1]]))
+    hists = _hip.label_hist2d(segm, windows, struc_elem, nb_labels)
+    return np.array(hists, dtype=float), np.array(sizes, dtype=float)
+
+
+def _ray_directions(angle_step):
+    """per-angle step (d_row, d_col) of ``computeRayFeaturesBinary2d`` with the precision chain of features_cython.pyx:253-269:
+    the float32 angle goes through ``np.deg2rad`` as a Python float (float64), the result is stored in a C ``float``; its
+    sine / cosine are again formed in float64 and stored as ``float``; the division by the larger magnitude is float32"""
+    angles = np.arange(0, 360, angle_step, dtype=np.float32)
+    dirs = np.empty((len(angles), 2), dtype=np.float32)
+    for i, ang in enumerate(angles):
+        rad = np.float32(np.deg2rad(float(ang)))
+        g0, g1 = np.float32(np.sin(float(rad))), np.float32(np.cos(float(rad)))
+        gmax = max(abs(g0), abs(g1))
+        dirs[i] = g0 / gmax, g1 / gmax
+    return dirs
+
+
+def hip_ray_features_positions(seg_binary, positions, angle_step=5., edge='up'):
+    """ ray features of many positions in ONE launch (``computeRayFeaturesBinary2d`` per position): float32 P x A """
+    edge_int = {'down': -1, 'up': 1}[edge]
+    return _hip.ray_features_binary2d(np.asarray(seg_binary) != 0, positions, _ray_directions(float(angle_step)), edge_int)
+
+
+def hip_ray_features_seg2d(seg_binary, position, angle_step=5., edge='up'):
+    """ distances from ``position`` to the object boundary along rays (reference ``descriptors.py:1630-1659``)
+
+    >>> seg_empty = np.zeros((100, 150), dtype=bool)
+    >>> hip_ray_features_seg2d(seg_empty, (50, 75), 90).tolist()  # doctest: +SKIP
+    [-1.0, -1.0, -1.0, -1.0]
+    """
+    return np.array(hip_ray_features_positions(seg_binary, [position], angle_step, edge)[0])
+
+
+cython_ray_features_seg2d = hip_ray_features_seg2d
+
+
+def compute_ray_features_segm_2d(seg_binary, position, angle_step=5., smooth_coef=0, edge='up'):
+    """ ray features of one position, optionally smoothed along the angle (reference ``descriptors.py:1715-1758``:
+    the ray casting followed by ``gaussian_filter1d``) """
+    seg_binary = np.asarray(seg_binary)
+    if seg_binary.ndim != len(position):
+        raise ValueError('Segmentation dim of %r and position (%i) does not match' % (seg_binary.ndim, len(position)))
+    ray_dist = hip_ray_features_seg2d(seg_binary.astype(bool), tuple(map(int, position)), angle_step, edge)
+    if smooth_coef is not None and smooth_coef > 0:
+        ray_dist = ndimage.gaussian_filter1d(ray_dist, smooth_coef)
+    return ray_dist

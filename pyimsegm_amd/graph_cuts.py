@@ -33,6 +33,11 @@ MAX_PAIRWISE_COST = 1e5
 MIN_MAX_EDGE_WEIGHT = 1e3
 
 
+def cut_grid_graph(unary_cost, pairwise_cost, cost_v, cost_h, n_iter=-1, algorithm='expansion', **kwargs):
+    """ drop-in for ``gco.cut_grid_graph`` (reference ``region_growing.py:20,248``) on the GPU """
+    return _hip.cut_grid_graph(unary_cost, pairwise_cost, cost_v, cost_h, n_iter=n_iter, algorithm=algorithm)
+
+
 def cut_general_graph(edges, edge_weights, unary_cost, pairwise_cost, n_iter=-1, algorithm='expansion', **kwargs):
     """ drop-in for ``gco.cut_general_graph`` (reference import ``graph_cuts.py:12-15``) on the GPU """
     return _hip.cut_general_graph(edges, edge_weights, unary_cost, pairwise_cost, n_iter=n_iter, algorithm=algorithm)
