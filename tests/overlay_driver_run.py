@@ -8,7 +8,7 @@ that carries the reference's dependencies -- the build container's conda Python 
 * `sys.path` = [this repo, the reference tree]: `import imsegm` is this repo's overlay, which finds the reference package
   behind it and completes itself with the reference's own `utilities.{data_io,drawing,experiments}`, `labeling`
   fall-backs etc.; the driver module is imported by its file name, nothing of it is edited or copied.
-* nibabel / planar / OleFileIO_PL / gco (file readers, ellipse drawing, the GraphCut wheel) are absent from the
+* `gco` is this repo's shim (gco/__init__.py); nibabel / planar / OleFileIO_PL (file readers, ellipse drawing) are absent from the
   container: empty stub modules, exactly as tests/golden/make_golden_reference.py does.  They are never called here.
   The `np.float` / `np.int` / `np.bool` aliases the reference's drawing module still uses are restored (numpy >= 1.24).
 * without `--device` (no GPU in the build container) the ctypes session classes are replaced by the oracle-backed
@@ -29,7 +29,8 @@ ROOT = os.path.dirname(HERE)
 def main():
     ref, out_dir = os.path.abspath(sys.argv[1]), os.path.abspath(sys.argv[2])
     use_device = '--device' in sys.argv[3:]
-    for name in ('nibabel', 'planar', 'gco', 'OleFileIO_PL'):
+    sys.path[:0] = [ROOT, ref, os.path.join(ref, 'experiments_segmentation')]
+    for name in ('nibabel', 'planar', 'OleFileIO_PL'):
         if name not in sys.modules:
             try:
                 __import__(name)
@@ -37,7 +38,6 @@ def main():
                 sys.modules[name] = types.ModuleType(name)
     if not hasattr(sys.modules['planar'], 'line'):
         sys.modules['planar'].line = types.ModuleType('planar.line')
-    sys.path[:0] = [ROOT, ref, os.path.join(ref, 'experiments_segmentation')]
     os.chdir(ref)                                   # the driver resolves 'data-images' relative to the tree
     if not use_device:
         sys.path.insert(0, HERE)
@@ -62,7 +62,9 @@ def main():
     }
     # a name of a shadowed module that only the reference defines resolves to the reference's function
     import imsegm.descriptors as seg_fts
-    seen['fallback_attr'] = seg_fts.compute_ray_features_segm_2d.__module__
+    seen['fallback_attr'] = seg_fts.reconstruct_ray_features_2d.__module__
+    import gco                                      # this repo's shim: the reference's region_growing cuts graphs on the device
+    seen['gco'] = os.path.relpath(gco.__file__, ROOT)
     import imsegm.region_growing                    # noqa: F401  (reference module importing shadowed ones by name)
     seen['region_growing'] = os.path.relpath(sys.modules['imsegm.region_growing'].__file__, ref)
 

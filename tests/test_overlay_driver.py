@@ -32,7 +32,7 @@ def test_unchanged_reference_driver_runs_on_the_overlay(tmp_path):
     assert seen['labeling'] == 'pyimsegm_amd.labeling'
     assert seen['data_io'] == 'imsegm/utilities/data_io.py' and seen['drawing'] == 'imsegm/utilities/drawing.py'
     assert seen['experiments'] == 'imsegm/utilities/experiments.py' and seen['region_growing'] == 'imsegm/region_growing.py'
-    assert seen['fallback_attr'] == 'imsegm._reference.descriptors'
+    assert seen['fallback_attr'] == 'imsegm._reference.descriptors' and seen['gco'] == 'gco/__init__.py'
     assert seen['shape'] == [900, 1200] and len(seen['classes']) > 1          # a real segmentation, not the except branch
     assert seen['files'] == ['0000_img_12.npz', '0000_img_12.png']
     assert seen['visu'] == ['0000_img_12.png', '0000_img_12_debug.png']       # incl. figure_segm_graphcut_debug
@@ -45,7 +45,7 @@ def test_overlay_is_inert_without_a_reference():
             "import importlib\n"
             "try:\n    importlib.import_module('imsegm.region_growing'); raise SystemExit(3)\n"
             "except ImportError:\n    pass\n"
-            "try:\n    imsegm.descriptors.compute_ray_features_segm_2d; raise SystemExit(4)\n"
+            "try:\n    imsegm.descriptors.reconstruct_ray_features_2d; raise SystemExit(4)\n"
             "except AttributeError:\n    pass\n") % os.path.dirname(HERE)
     import sys
     res = subprocess.run([sys.executable, '-c', code], cwd='/', stdout=subprocess.PIPE, stderr=subprocess.PIPE,
