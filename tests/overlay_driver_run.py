@@ -68,6 +68,20 @@ def main():
     import imsegm.region_growing                    # noqa: F401  (reference module importing shadowed ones by name)
     seen['region_growing'] = os.path.relpath(sys.modules['imsegm.region_growing'].__file__, ref)
 
+    # the reference's OWN region_growing functions cutting their graphs through the shim (doctests region_growing.py:72-75,
+    # 187-200: the known answers of gco there)
+    import imsegm.region_growing as seg_rg
+    sys.path.insert(0, HERE)
+    import natives_cases as NC
+    got = seg_rg.object_segmentation_graphcut_pixels(NC.GRID_SEGM, NC.GRID_CENTRES, gc_regul=0., coef_shape=0.5)
+    got2 = seg_rg.object_segmentation_graphcut_pixels(NC.GRID_SEGM, NC.GRID_CENTRES, gc_regul=.5, seed_size=1)
+    seen['region_growing_pixels'] = bool(np.array_equal(got, NC.GRID_EXPECT_SHAPE) and np.array_equal(got2, NC.GRID_EXPECT_SEED))
+    slic = np.array([[0] * 3 + [1] * 3 + [2] * 3 + [3] * 3 + [4] * 3, [5] * 3 + [6] * 3 + [7] * 3 + [8] * 3 + [9] * 3])
+    segm = np.array([[0] * 15, [1] * 12 + [0] * 3])
+    seen['region_growing_slic'] = [
+        np.asarray(seg_rg.object_segmentation_graphcut_slic(slic, segm, [(1, 7)], gc_regul=0., edge_coef=1., coef_shape=1.)).tolist(),
+        np.asarray(seg_rg.object_segmentation_graphcut_slic(slic, segm, [(1, 7)], gc_regul=1., edge_coef=1.)).tolist()]
+
     params = dict(drv.SEGM_PARAMS)
     params['path_exp'] = out_dir
     for sub in (drv.FOLDER_IMAGE, drv.FOLDER_SEGM_GMM, drv.FOLDER_SEGM_GMM_VISU):

@@ -33,6 +33,9 @@ def test_unchanged_reference_driver_runs_on_the_overlay(tmp_path):
     assert seen['data_io'] == 'imsegm/utilities/data_io.py' and seen['drawing'] == 'imsegm/utilities/drawing.py'
     assert seen['experiments'] == 'imsegm/utilities/experiments.py' and seen['region_growing'] == 'imsegm/region_growing.py'
     assert seen['fallback_attr'] == 'imsegm._reference.descriptors' and seen['gco'] == 'gco/__init__.py'
+    # the reference's own region_growing module with its graph cuts going through the gco shim: gco's known answers
+    assert seen['region_growing_pixels'] is True
+    assert seen['region_growing_slic'] == [[0, 0, 0, 0, 0, 1, 1, 1, 1, 0]] * 2
     assert seen['shape'] == [900, 1200] and len(seen['classes']) > 1          # a real segmentation, not the except branch
     assert seen['files'] == ['0000_img_12.npz', '0000_img_12.png']
     assert seen['visu'] == ['0000_img_12.png', '0000_img_12_debug.png']       # incl. figure_segm_graphcut_debug
