@@ -744,7 +744,27 @@ class Volume3D(Image2D):
     def _unsupported(self, *args, **kwargs):
         raise HipError('not available for volumes')
 
-    get_lab = color_stats = lm_prepare = lm_battery = response_stats = get_response = _unsupported
+    get_lab = color_stats = run_color = _unsupported
+
+    # -- Leung-Malik responses of the slices (descriptors.py:969-1038: every slice is filtered as a 2-D image) --------
+    def lm_prepare(self, sigma=150.):
+        """planes = volume - gaussian_filter(slice, sigma) per slice   (image_subtract_gauss_smooth, descriptors.py:981-994)"""
+        taps = gaussian_taps(sigma)
+        _check(load_library().imsegm_image2d_lm_prepare(self._h, _ptr(taps), len(taps) - 1, None))
+        return self
+
+    def response_stats(self, mul, div, mean=True, energy=True, var=True):
+        k = self.n_labels
+        m = np.empty(k, dtype=np.float64) if mean else None
+        e = np.empty(k, dtype=np.float64) if energy else None
+        v = np.empty(k, dtype=np.float64) if var else None
+        _check(load_library().imsegm_image2d_response_stats(self._h, float(mul), float(div), _ptr(m), _ptr(e), _ptr(v)))
+        return m, e, v
+
+    def get_response(self):
+        out = np.empty(self.shape, dtype=np.float64)
+        _check(load_library().imsegm_image2d_get_response(self._h, _ptr(out)))
+        return out
 
 
 class DeviceArray(object):

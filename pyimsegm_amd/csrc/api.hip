@@ -861,27 +861,32 @@ static int stats_run(imsegm_image2d *im, const void *src, int dtype, double maxa
 int imsegm_image2d_lm_prepare(imsegm_image2d *im, const double *taps, int radius, const double *channel_mix)
 {
     if (!im || bind(im->ctx)) return -1;
-    if (wrong_kind(im, false)) return -1;
     if (im->dtype < 0) {
         set_error("no image uploaded");
         return -1;
     }
-    if (radius < 0 || !taps || !channel_mix) {
+    if (radius < 0 || !taps || (!channel_mix && !im->is_volume)) {
         set_error("lm_prepare: bad arguments");
         return -1;
     }
     hipStream_t st = im->ctx->stream;
-    const size_t n = im->n;
-    if (im->tex_planes.ensure(3 * n * 8) || im->labA.ensure(3 * n * 8) || im->labB.ensure(3 * n * 8)) return -1;
+    // colour image: three channel planes of H x W; gray volume: its D slices, filtered independently (descriptors.py:981-994)
+    const size_t np = im->is_volume ? im->n : 3 * im->n;
+    if (im->tex_planes.ensure(np * 8) || im->labA.ensure(np * 8) || im->labB.ensure(np * 8)) return -1;
     if (im->tex_small.ensure(((size_t)radius + 1 + 9) * 8 + 1024 * 8 + 4096)) return -1;
     double *d_taps = im->tex_small.as<double>();
     double *d_mix = d_taps + radius + 1;
     HIP_TRY(hipMemcpyAsync(d_taps, taps, ((size_t)radius + 1) * 8, hipMemcpyHostToDevice, st));
-    HIP_TRY(hipMemcpyAsync(d_mix, channel_mix, 9 * 8, hipMemcpyHostToDevice, st));
+    if (channel_mix) HIP_TRY(hipMemcpyAsync(d_mix, channel_mix, 9 * 8, hipMemcpyHostToDevice, st));
     HIP_TRY(hipStreamSynchronize(st));
-    if (launch_texture_prepare(im->img.p, im->dtype, im->H, im->W, d_taps, radius, d_mix, im->tex_planes.as<double>(),
-                               im->labA.as<double>(), im->labB.as<double>(), st))
+    if (im->is_volume) {
+        if (launch_texture_prepare_volume(im->img.p, im->dtype, im->D, im->H, im->W, d_taps, radius, im->tex_planes.as<double>(),
+                                          im->labA.as<double>(), im->labB.as<double>(), st))
+            return -1;
+    } else if (launch_texture_prepare(im->img.p, im->dtype, im->H, im->W, d_taps, radius, d_mix, im->tex_planes.as<double>(),
+                                      im->labA.as<double>(), im->labB.as<double>(), st)) {
         return -1;
+    }
     im->tex_ready = true;
     return 0;
 }
@@ -890,13 +895,13 @@ int imsegm_image2d_lm_battery(imsegm_image2d *im, const double *weights, int n_k
                               double *sum_squares_out)
 {
     if (!im || bind(im->ctx)) return -1;
-    if (wrong_kind(im, false)) return -1;
     if (!im->tex_ready) {
         set_error("lm_battery: call imsegm_image2d_lm_prepare first");
         return -1;
     }
     hipStream_t st = im->ctx->stream;
-    const size_t n = im->n;
+    const size_t n = im->is_volume ? (im->n + 2) / 3 : im->n;          // the buffers below hold 3 * n values
+    const int P = im->is_volume ? im->D : 3;
     const size_t S = 2 * (size_t)radius + 1;
     const size_t wbytes = S * S * n_kernels * 8;
     if (im->tex_resp.ensure(3 * n * 8 + wbytes + 1024 * 8 + 64)) return -1;
@@ -907,7 +912,7 @@ int imsegm_image2d_lm_battery(imsegm_image2d *im, const double *weights, int n_k
     HIP_TRY(hipMemcpyAsync(d_w, weights, wbytes, hipMemcpyHostToDevice, st));
     HIP_TRY(hipStreamSynchronize(st));
     int spx = im->ctx->begin(PG_TEX);
-    if (launch_filter_battery(im->tex_planes.as<double>(), im->H, im->W, d_w, n_kernels, radius, clip, resp, partial, d_sum, st))
+    if (launch_filter_battery(im->tex_planes.as<double>(), im->H, im->W, d_w, n_kernels, radius, clip, resp, partial, d_sum, st, P))
         return -1;
     im->ctx->end(spx);
     HIP_TRY(hipMemcpyAsync(sum_squares_out, d_sum, 8, hipMemcpyDeviceToHost, st));
@@ -919,29 +924,42 @@ int imsegm_image2d_response_stats(imsegm_image2d *im, double mul, double div, do
                                   double *var_out)
 {
     if (!im || bind(im->ctx)) return -1;
-    if (wrong_kind(im, false)) return -1;
-    if (!im->tex_ready || !im->have_labels || im->tex_resp.cap < 3 * im->n * 8) {
+    if (!im->tex_ready || !im->have_labels || im->tex_resp.cap < (im->is_volume ? im->n : 3 * im->n) * 8) {
         set_error("response_stats needs a filter response and a label map");
         return -1;
     }
-    double maxabs = fabs(mul / div) * 1.0;     // |response| <= its own L2 norm == div
     if (!(div != 0.0)) {
         set_error("response_stats: zero norm");
         return -1;
     }
-    maxabs = fabs(mul);                        // |r| <= norm = div  =>  |r * mul / div| <= |mul|
-    return stats_run(im, im->tex_resp.p, IMSEGM_F64, maxabs, 1, 1, mul, div, mean_out, energy_out, var_out);
+    const double maxabs = fabs(mul);           // |r| <= norm = div  =>  |r * mul / div| <= |mul|
+    if (!im->is_volume) return stats_run(im, im->tex_resp.p, IMSEGM_F64, maxabs, 1, 1, mul, div, mean_out, energy_out, var_out);
+    // volume: the response is one plane of (D * H) x W read as all three channels (plane stride 0); K values each
+    const int K = im->n_labels;
+    std::vector<double> m((size_t)K * 3), e((size_t)K * 3), v((size_t)K * 3);
+    const int keepH = im->H;
+    im->H = im->D * keepH;
+    int rc = stats_run(im, im->tex_resp.p, IMSEGM_F64, maxabs, 1, 1, mul, div, mean_out ? m.data() : nullptr,
+                       energy_out ? e.data() : nullptr, var_out ? v.data() : nullptr, 0);
+    im->H = keepH;
+    if (rc) return rc;
+    for (int k = 0; k < K; ++k) {
+        if (mean_out) mean_out[k] = m[(size_t)k * 3];
+        if (energy_out) energy_out[k] = e[(size_t)k * 3];
+        if (var_out) var_out[k] = v[(size_t)k * 3];
+    }
+    return 0;
 }
 
 int imsegm_image2d_get_response(imsegm_image2d *im, double *planes_out)
 {
     if (!im || bind(im->ctx)) return -1;
-    if (wrong_kind(im, false)) return -1;
-    if (im->tex_resp.cap < 3 * im->n * 8) {
+    const size_t nv = im->is_volume ? im->n : 3 * im->n;
+    if (im->tex_resp.cap < nv * 8) {
         set_error("no filter response");
         return -1;
     }
-    HIP_TRY(hipMemcpyAsync(planes_out, im->tex_resp.p, 3 * im->n * 8, hipMemcpyDeviceToHost, im->ctx->stream));
+    HIP_TRY(hipMemcpyAsync(planes_out, im->tex_resp.p, nv * 8, hipMemcpyDeviceToHost, im->ctx->stream));
     HIP_TRY(hipStreamSynchronize(im->ctx->stream));
     return 0;
 }

@@ -156,8 +156,11 @@ int launch_color_stats(const void *img, int dtype, const int32_t *labels, int H,
 // texture.hip -------------------------------------------------------------------------------------
 int launch_texture_prepare(const void *img, int dtype, int H, int W, const double *taps_dev, int radius,
                            const double *mix_dev, double *planes, double *tmpA, double *tmpB, hipStream_t st);
+int launch_texture_prepare_volume(const void *vol, int dtype, int P, int H, int W, const double *taps_dev, int radius, double *planes,
+                                  double *tmpA, double *tmpB, hipStream_t st);
+// P planes of H x W (3 colour channels, or the D slices of a gray volume)
 int launch_filter_battery(const double *planes, int H, int W, const double *wgt_dev, int nk, int radius, double clip,
-                          double *resp, double *partial, double *sumsq_dev, hipStream_t st);
+                          double *resp, double *partial, double *sumsq_dev, hipStream_t st, int P = 3);
 
 // graph.hip ---------------------------------------------------------------------------------------
 int launch_adjacency_centres(const int32_t *labels, int H, int W, int K, uint32_t *bitmap, long long *cacc,

@@ -62,6 +62,20 @@ k_corr1d_long(const double *__restrict__ src, double *__restrict__ dst, int H, i
     dst[(size_t)blockIdx.z * H * W + (size_t)y * W + x] = acc;
 }
 
+// gray volume: every slice is an independent plane (descriptors.py:981-994 image_subtract_gauss_smooth)
+template <typename T>
+__global__ void __launch_bounds__(256) k_vol_to_planes(const T *__restrict__ vol, size_t n, double *__restrict__ planes)
+{
+    size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p < n) planes[p] = (double)vol[p];
+}
+__global__ void __launch_bounds__(256)
+k_subtract(const double *__restrict__ orig, const double *__restrict__ blur, size_t n, double *__restrict__ out)
+{
+    size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p < n) out[p] = orig[p] - blur[p];
+}
+
 // channel-axis pass of the 3-D Gaussian (a 3 x 3 mixing matrix, folded on the host) and the
 // subtraction: out = original - blurred
 __global__ void __launch_bounds__(256)
@@ -181,8 +195,25 @@ int launch_texture_prepare(const void *img, int dtype, int H, int W, const doubl
     return 0;
 }
 
+// planes = volume - gaussian_filter(slice, sigma) per slice, P = D planes of H x W
+int launch_texture_prepare_volume(const void *vol, int dtype, int P, int H, int W, const double *taps_dev, int radius, double *planes,
+                                  double *tmpA, double *tmpB, hipStream_t st)
+{
+    const size_t n = (size_t)P * H * W;
+    const int grid = cdiv((long)n, 256);
+    if (dtype == DT_U8) hipLaunchKernelGGL(k_vol_to_planes<uint8_t>, grid, 256, 0, st, (const uint8_t *)vol, n, planes);
+    else if (dtype == DT_F32) hipLaunchKernelGGL(k_vol_to_planes<float>, grid, 256, 0, st, (const float *)vol, n, planes);
+    else hipLaunchKernelGGL(k_vol_to_planes<double>, grid, 256, 0, st, (const double *)vol, n, planes);
+    dim3 g(cdiv(W, 64), cdiv(H, 4), P);
+    hipLaunchKernelGGL(k_corr1d_long<0>, g, 256, 0, st, planes, tmpA, H, W, taps_dev, radius);
+    hipLaunchKernelGGL(k_corr1d_long<1>, g, 256, 0, st, tmpA, tmpB, H, W, taps_dev, radius);
+    hipLaunchKernelGGL(k_subtract, grid, 256, 0, st, planes, tmpB, n, planes);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
 int launch_filter_battery(const double *planes, int H, int W, const double *wgt_dev, int nk, int radius, double clip,
-                          double *resp, double *partial, double *sumsq_dev, hipStream_t st)
+                          double *resp, double *partial, double *sumsq_dev, hipStream_t st, int P)
 {
     if (nk != 1 && nk != 2 && nk != 4 && nk != 8) {
         set_error("filter battery: 1, 2, 4 or 8 kernels per battery are supported");
@@ -193,7 +224,7 @@ int launch_filter_battery(const double *planes, int H, int W, const double *wgt_
         set_error("filter battery: kernel radius too large for the LDS tile");
         return -1;
     }
-    dim3 grid(cdiv(W, CV_TX), cdiv(H, CV_TY), 3);
+    dim3 grid(cdiv(W, CV_TX), cdiv(H, CV_TY), P);
     const void *fn = nk == 8 ? (const void *)k_conv_battery<8> : nk == 4 ? (const void *)k_conv_battery<4>
                    : nk == 2 ? (const void *)k_conv_battery<2> : (const void *)k_conv_battery<1>;
     if (lds > 48 * 1024) HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -202,7 +233,7 @@ int launch_filter_battery(const double *planes, int H, int W, const double *wgt_
     else if (nk == 2) hipLaunchKernelGGL(k_conv_battery<2>, grid, 256, lds, st, planes, H, W, wgt_dev, radius, clip, resp);
     else hipLaunchKernelGGL(k_conv_battery<1>, grid, 256, lds, st, planes, H, W, wgt_dev, radius, clip, resp);
     const int nb = 1024;
-    hipLaunchKernelGGL(k_sumsq_partial, nb, 256, 0, st, resp, (size_t)3 * H * W, partial);
+    hipLaunchKernelGGL(k_sumsq_partial, nb, 256, 0, st, resp, (size_t)P * H * W, partial);
     hipLaunchKernelGGL(k_sumsq_final, 1, 256, 0, st, partial, nb, sumsq_dev);
     HIP_TRY(hipGetLastError());
     return 0;

@@ -663,8 +663,10 @@ def compute_texture_desc_lm_img3d_val(img, seg, feature_flags, bank_type='normal
     img, seg = np.asarray(img), np.asarray(seg)
     _check_gray_image_segm(img, seg)
     logging.debug('compute texture descriptors using Leung-Malik')
-    img = image_subtract_gauss_smooth(img, 150)
     filters, fl_names = _select_bank(bank_type)
+    if set(feature_flags) <= {'mean', 'std', 'energy'} and all(len(f) <= 8 for f in filters):
+        return _texture_desc_lm_device3d(img, seg, feature_flags, filters, fl_names)
+    img = image_subtract_gauss_smooth(img, 150)
     features, names = [], []
     for battery, fl_name in zip(filters, fl_names):
         response = _normalise_response(compute_img_filter_response3d(img, battery))
@@ -758,6 +760,37 @@ def _texture_desc_lm_device(img, seg, feature_flags, filters, fl_names, sess=Non
     if own:
         sess.close()
     return _finish_texture(features, names)
+
+
+def _texture_desc_lm_device3d(img, seg, feature_flags, filters, fl_names):
+    """Leung-Malik statistics of a gray volume on the GPU: per-slice high-pass and filter batteries (the slices are the
+    planes the 2-D kernels work on), one norm over the volume, per-supervoxel statistics"""
+    sess = _hip.Volume3D(*seg.shape).upload(np.nan_to_num(img)).set_labels(seg)
+    try:
+        sess.lm_prepare(150.)
+        want = [f in feature_flags for f in ('mean', 'std', 'energy')]
+        features, names = [], []
+        for battery, fl_name in zip(filters, fl_names):
+            norm = sess.lm_battery(battery, MAX_SIGNAL_RESPONSE)
+            nb = sess.n_labels
+            if norm == 0 or abs(norm) == np.inf:
+                mean = energy = var = np.zeros(nb)
+            else:
+                mean, energy, var = sess.response_stats(np.log(1 + norm) / 0.03, norm, mean=want[0], energy=want[2], var=want[1])
+            blocks = ([mean] if want[0] else []) + ([np.sqrt(var)] if want[1] else []) + ([energy] if want[2] else [])
+            fts = np.nan_to_num(np.array(blocks)).T
+            fts[fts == 0] = 0
+            features.append(fts)
+            names += ['%s_%s' % (fl_name, f) for f in NAMES_FEATURE_FLAGS if f in feature_flags]
+    finally:
+        sess.close()
+    _check_unrecognised_feature_names(feature_flags)
+    features = np.nan_to_num(np.concatenate(tuple(features), axis=1))
+    features[features == 0] = 0
+    names = ['tLM_%s' % name for name in names]
+    if features.shape[1] != len(names):
+        raise ValueError('features: %r and names %r' % (features.shape, names))
+    return features, names
 
 
 # ------------------------------------------------------------------------------------------------

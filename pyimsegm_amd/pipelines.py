@@ -403,14 +403,25 @@ def estim_model_classes_group(
     pca_coef=None,
     model_type='GMM',
     nb_workers=NB_WORKERS,
+    group=None,
 ):
-    """ estimate one class model from the superpixel features of a sequence of images
+    """ estimate one class model from the superpixel features of a sequence of images (reference ``pipelines.py:113-157``)
 
-    :return tuple(model, list(ndarray)): fitted scikit-learn pipeline, features per image
+    With a multi-rank ``group`` (:class:`pyimsegm_amd.distributed.Group`) every rank extracts the features of its images
+    ``i = rank, rank + world, ...``, the K_i x F blocks are gathered on rank 0 in image order, the model is fitted
+    there once and broadcast to all ranks.
+
+    :return tuple(model, list(ndarray)): fitted scikit-learn pipeline, features per image (all of them on rank 0)
     """
     def _features(image):
         return compute_color2d_superpixels_features(image, dict_features, sp_size=sp_size, sp_regul=sp_regul)[1]
 
+    def _fit(features):
+        return estim_class_model(features, nb_classes, model_type, pca_coef, use_scaler)
+
+    if group is not None and group.world > 1:
+        from pyimsegm_amd.distributed import estim_model_classes_group_sharded
+        return estim_model_classes_group_sharded(list_images, _features, _fit, group)
     if nb_workers and nb_workers > 1 and len(list_images) > 1:
         # several images in flight on this GPU: worker threads, one HIP stream each
         from concurrent.futures import ThreadPoolExecutor
@@ -418,9 +429,7 @@ def estim_model_classes_group(
             list_features = list(pool.map(_features, list_images))
     else:
         list_features = [_features(image) for image in list_images]
-    features = np.nan_to_num(np.concatenate(tuple(list_features), axis=0))
-    model = estim_class_model(features, nb_classes, model_type, pca_coef, use_scaler)
-    return model, list_features
+    return _fit(np.nan_to_num(np.concatenate(tuple(list_features), axis=0))), list_features
 
 
 def segment_color2d_slic_features_model_graphcut(
