@@ -508,6 +508,7 @@ int imsegm_image2d_slic(imsegm_image2d *im, int minmax_normalize, int n_segments
     s.spatial_weight = 1.0 / ((double)step * (double)step);
     s.premax = premax;
     s.debug = getenv("IMSEGM_DEBUG_ASSIGN") ? atoi(getenv("IMSEGM_DEBUG_ASSIGN")) : 0;
+    s.assign_units = getenv("IMSEGM_ASSIGN_UNITS") ? atoi(getenv("IMSEGM_ASSIGN_UNITS")) : 1;
     s.phase_prof = nullptr;
     static long long *phase_buf = nullptr;
     const size_t PHASE_SLOTS = 1 << 16;                    // workgroups of the assignment grid (profiling aid)
@@ -593,7 +594,7 @@ int imsegm_image2d_slic(imsegm_image2d *im, int minmax_normalize, int n_segments
         double segment_size = (double)n / (double)K;
         long min_size = (long)(min_size_factor * segment_size);
         long max_size = (long)(max_size_factor * segment_size);
-        if (im->conn_i32.ensure(n * 4 * 8 + ((n / 4096) + 64) * 4 + 256) || im->conn_u8.ensure(2 * n + 64)) return -1;
+        if (im->conn_i32.ensure(conn_i32_bytes(n)) || im->conn_u8.ensure(2 * n + 64)) return -1;
         ConnWork w = make_conn_work(im);
         int spc = ctx->begin(PG_CONN);
         // the raw assignment carries no start_label offset; the reference adds it before the
@@ -1018,7 +1019,8 @@ static ConnWork make_conn_work(imsegm_image2d *im)
     w.slotmap = b; b += n;
     w.bbox = b; b += n;
     w.blocksum = b; b += (n / 4096) + 32;
-    w.counters = b;
+    w.counters = b; b += 64;
+    w.dense = b;
     w.visited = im->conn_u8.as<uint8_t>();
     return w;
 }
@@ -1125,7 +1127,7 @@ int imsegm_volume_slic(imsegm_image2d *im, int n_segments, double compactness, c
         double segment_size = (double)n / (double)K;
         long min_size = (long)(min_size_factor * segment_size);
         long max_size = (long)(max_size_factor * segment_size);
-        if (im->conn_i32.ensure(n * 4 * 8 + ((n / 4096) + 64) * 4 + 256) || im->conn_u8.ensure(2 * n + 64)) return -1;
+        if (im->conn_i32.ensure(conn_i32_bytes(n)) || im->conn_u8.ensure(2 * n + 64)) return -1;
         ConnWork w = make_conn_work(im);
         if (launch_enforce_connectivity(im->nearest.as<int32_t>(), D, H, W, min_size, max_size, start_label, w,
                                         im->labels.as<int32_t>(), &n_labels, st))
@@ -1154,7 +1156,7 @@ int imsegm_volume_label_cc(imsegm_image2d *im, int *n_labels_out)
     }
     hipStream_t st = im->ctx->stream;
     const size_t n = im->n;
-    if (im->conn_i32.ensure(n * 4 * 8 + ((n / 4096) + 64) * 4 + 256) || im->conn_u8.ensure(2 * n + 64)) return -1;
+    if (im->conn_i32.ensure(conn_i32_bytes(n)) || im->conn_u8.ensure(2 * n + 64)) return -1;
     ConnWork w = make_conn_work(im);
     if (launch_label_cc(im->labels.as<int32_t>(), im->D, im->H, im->W, w.parent, w.newlabel, w.blocksum, w.counters, st)) return -1;
     int total = 0;

@@ -24,7 +24,8 @@
 namespace imsegm {
 
 enum { ST_ACTIVE = 0, ST_FINAL = 1 };
-enum { CNT_OVER = 0, CNT_SMALL = 1, CNT_CURSOR = 2, CNT_KEPT = 3, CNT_FALLBACK = 4, CNT_BIG = 5, CNT_LITTLE = 6 };
+enum { CNT_OVER = 0, CNT_SMALL = 1, CNT_CURSOR = 2, CNT_KEPT = 3, CNT_FALLBACK = 4, CNT_BIG = 5, CNT_LITTLE = 6,
+       CNT_LROOT = 8, CNT_FLAG = 9, CNT_FB = 10 };      // 8..10: the 2-D tile path
 
 // neighbour of voxel p in direction d of the reference's BFS order (+x, -x, +y, -y, +z, -z); -1 outside
 __device__ __forceinline__ int neighbour(int p, int D, int H, int W, int d)
@@ -281,7 +282,7 @@ k_small_resolve(const int32_t *__restrict__ list, const int32_t *__restrict__ co
                 const int32_t *__restrict__ csize, const int32_t *__restrict__ adjptr, int min_size,
                 int32_t *newlabel)
 {
-    const int n_small = counters[CNT_SMALL];
+    const int n_small = counters[CNT_FLAG] ? 0 : counters[CNT_SMALL];
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n_small; i += gridDim.x * blockDim.x) {
         int root = list[i];
         int r = adjptr[root];
@@ -422,9 +423,11 @@ k_small_order(const int32_t *__restrict__ bbox, int32_t *counters, int D, int H,
 // the next frontier in exactly the order the sequential queue would hold it.  `adjacent` is the
 // component of the foreign, already-labelled (smaller root) neighbour with the largest
 // (level, 4*i + d).  The bounding box (+1 ring) of the component is staged in LDS first.
-template <int CELLS, int FMAX>
+// HOP2 (2-D tile path below): parent[] holds the tile-local root of a pixel, whose own entry is the global root.
+// `order` may be null (identity); `count` points at the number of listed components.
+template <int CELLS, int FMAX, bool HOP2>
 __global__ void __launch_bounds__(64)
-k_small_bfs_wave(const int32_t *__restrict__ list, int32_t *counters,
+k_small_bfs_wave(const int32_t *__restrict__ list, int32_t *counters, const int32_t *__restrict__ count,
                  const int32_t *__restrict__ parent, const int32_t *__restrict__ bbox, int D, int H, int W,
                  const int32_t *__restrict__ order, int capacity, int32_t *adjptr, int32_t *fallback_list)
 {
@@ -434,10 +437,10 @@ k_small_bfs_wave(const int32_t *__restrict__ list, int32_t *counters,
     __shared__ int level_best;
     static_assert(CELLS <= 8192 && 6 * FMAX <= (1 << 18), "packing of (key, cell) in level_best");
     const int lane = threadIdx.x;
-    const int n_small = counters[CNT_SMALL];
-    if (n_small > capacity) return;
+    const int n_small = *count;
+    if (n_small > capacity || (HOP2 && counters[CNT_FLAG])) return;
     for (int t = blockIdx.x; t < n_small; t += gridDim.x) {
-        const int ci = order[t];
+        const int ci = order ? order[t] : t;
         const int root = list[ci];
         const int y0 = max(bbox[6 * ci + 0] - 1, 0), y1 = min(bbox[6 * ci + 1] + 1, H - 1);
         const int x0 = max(bbox[6 * ci + 2] - 1, 0), x1 = min(bbox[6 * ci + 3] + 1, W - 1);
@@ -455,6 +458,7 @@ k_small_bfs_wave(const int32_t *__restrict__ list, int32_t *counters,
             int cz = c / bwh, rem = c - cz * bwh;
             int cy = rem / bw, cx = rem - cy * bw;
             int q = parent[((size_t)(z0 + cz) * H + (y0 + cy)) * W + x0 + cx];
+            if (HOP2) q = parent[q];
             cls[c] = (q == root) ? 1 : (q < root ? 2 : 0);
             prop[c] = 0xffffffffu;
         }
@@ -531,6 +535,7 @@ k_small_bfs_wave(const int32_t *__restrict__ list, int32_t *counters,
                 int cz = adj_cell / bwh, rem = adj_cell - cz * bwh;
                 int cy = rem / bw, cx = rem - cy * bw;
                 adj = parent[((size_t)(z0 + cz) * H + (y0 + cy)) * W + x0 + cx];
+                if (HOP2) adj = parent[adj];
             }
             adjptr[root] = adj;
         }
@@ -577,10 +582,11 @@ k_small_bfs_fallback(const int32_t *__restrict__ list_all, const int32_t *__rest
 }
 
 __global__ void __launch_bounds__(256)
-k_write_labels(const int32_t *__restrict__ parent, const int32_t *__restrict__ newlabel, int n, int32_t *out)
+k_write_labels(const int32_t *__restrict__ parent, const int32_t *__restrict__ newlabel, int n, int32_t *out,
+               const int32_t *__restrict__ abort_flag)
 {
     int p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= n) return;
+    if (p >= n || (abort_flag && *abort_flag)) return;
     out[p] = newlabel[parent[p]];
 }
 
@@ -623,13 +629,478 @@ static int conn_tail(const int32_t *csize_final, int32_t *adjptr, int D, int H, 
                        w.counters, capacity);
     // one launch for all of them, long ones first (w.queue is free until the fallback kernel)
     hipLaunchKernelGGL(k_small_order, 64, 256, 0, st, bbox, w.counters, D, H, W, 1024, capacity, w.queue);
-    hipLaunchKernelGGL((k_small_bfs_wave<8192, 2048>), 2048, 64, 0, st, w.list, w.counters, w.parent, bbox, D, H, W,
-                       w.queue, capacity, adjptr, fallback_list);
+    hipLaunchKernelGGL((k_small_bfs_wave<8192, 2048, false>), 2048, 64, 0, st, w.list, w.counters, w.counters + CNT_SMALL, w.parent,
+                       bbox, D, H, W, w.queue, capacity, adjptr, fallback_list);
     hipLaunchKernelGGL(k_small_bfs_fallback, 64, 64, 0, st, w.list, fallback_list, w.counters, w.parent, csize_final, D, H,
                        W, capacity, w.queue, w.visited, w.counters + CNT_CURSOR, adjptr);
     hipLaunchKernelGGL(k_small_resolve, 64, 64, 0, st, w.list, w.counters, csize_final, adjptr, min_size, w.newlabel);
-    hipLaunchKernelGGL(k_write_labels, grid, 256, 0, st, w.parent, w.newlabel, n, labels_out);
+    hipLaunchKernelGGL(k_write_labels, grid, 256, 0, st, w.parent, w.newlabel, n, labels_out, (const int32_t *)nullptr);
     HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+
+// ====================================================================================================
+// 2-D fast path (every pixel active, no component reaches max_size -- checked on the device).
+//
+// The label map is read once and the final map written once; everything in between works on the few thousand
+// tile-local components instead of the 4 M pixels:
+//   k_ccl_tile      one workgroup per 64 x 32 tile: run-based union-find in LDS; parent[p] = tile-local root (global
+//                   pixel index of the raster-first pixel of the local component); per local root: size and bounding
+//                   box (atomics of the run leaders on <= 64 LDS slots), appended to a dense list
+//   k_ccl_border    unions across tile borders (one per pair of touching runs), on the local roots only
+//   k_lroot_merge   per local root: global root (min raster index), size and bounding box summed / merged there
+//   k_root_classify per global root: kept (>= min_size) -> list of kept roots, small -> list of small roots,
+//                   >= max_size -> flag (the general path takes over)
+//   k_kept_rank     one workgroup: raster rank of the kept roots (bucket sort in LDS) = their consecutive labels
+//   k_small_bfs_reg `adjacent` of every small component: exact emulation of the reference's BFS order by one wave
+//                   with the frontier in registers (lane = BFS rank inside the level), the component's bounding box
+//                   (+2 rings) staged in LDS as one byte per cell
+//   k_small_resolve, k_lroot_labels, k_write_labels   chains of merged components, labels of the local roots, and
+//                   out[p] = newlabel[parent[p]]
+// Anything the fast path cannot take (more than 64 local components in a tile, list capacities, a frontier of more
+// than 64 cells and a bounding box the old wave kernel cannot stage either, an oversize component) raises a flag /
+// counter that the host reads at its single synchronisation, and the general path above runs instead.
+constexpr int CT_W = 64, CT_H = 32, CT_SLOTS = 64;
+constexpr int CONN_LROOT_CAP = 1 << 16, CONN_KEPT_CAP = 1 << 16, CONN_FB_CAP = 4096;
+static_assert(3 * CONN_LROOT_CAP + 2 * CONN_KEPT_CAP + 8 * CONN_FB_CAP <= CONN_DENSE_INTS, "dense scratch of the tile path");
+
+struct ConnDense {
+    int32_t *lroots, *lsize, *lbox, *kept, *sorted, *fb_list, *fb_reject, *fb_bbox;
+};
+static ConnDense conn_dense(const ConnWork &w)
+{
+    ConnDense d;
+    int32_t *b = w.dense;
+    d.lroots = b; b += CONN_LROOT_CAP;
+    d.lsize = b; b += CONN_LROOT_CAP;
+    d.lbox = b; b += CONN_LROOT_CAP;
+    d.kept = b; b += CONN_KEPT_CAP;
+    d.sorted = b; b += CONN_KEPT_CAP;
+    d.fb_list = b; b += CONN_FB_CAP;
+    d.fb_reject = b; b += CONN_FB_CAP;
+    d.fb_bbox = b;
+    return d;
+}
+
+__device__ __forceinline__ int lds_find(volatile int *par, int a)
+{
+    int p = par[a];
+    while (p != a) {
+        a = p;
+        p = par[a];
+    }
+    return a;
+}
+
+__device__ __forceinline__ void lds_union(int *par, int a, int b)
+{
+    while (true) {
+        a = lds_find(par, a);
+        b = lds_find(par, b);
+        if (a == b) return;
+        if (a < b) {
+            const int t = a;
+            a = b;
+            b = t;
+        }
+        const int old = atomicMin(&par[a], b);
+        if (old == a) return;
+        a = old;
+    }
+}
+
+__global__ void __launch_bounds__(256)
+k_ccl_tile(const int32_t *__restrict__ labels, int H, int W, int32_t *__restrict__ parent, int32_t *__restrict__ csize,
+           int32_t *__restrict__ ymax_g, int32_t *__restrict__ xmin_g, int32_t *__restrict__ xmax_g,
+           int32_t *__restrict__ lroots, int32_t *__restrict__ lsize, int32_t *__restrict__ lbox, int32_t *counters)
+{
+    __shared__ int slab[CT_H * CT_W];      // labels; after the unions: slot of a local root
+    __shared__ int spar[CT_H * CT_W];
+    __shared__ int c_root[CT_SLOTS], c_size[CT_SLOTS], c_ymax[CT_SLOTS], c_xmin[CT_SLOTS], c_xmax[CT_SLOTS];
+    __shared__ int s_n, s_base;
+    constexpr int OUT = (int)0x80000000;   // outside the image (never a label)
+    constexpr int RPW = CT_H / 4;          // rows per wave
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tx0 = blockIdx.x * CT_W, ty0 = blockIdx.y * CT_H;
+    const int x = tx0 + lane;
+    const unsigned long long le = (lane == 63) ? ~0ULL : ((2ULL << lane) - 1ULL);      // lanes <= me
+    if (tid == 0) s_n = 0;
+
+    int l[RPW];
+    bool cont[RPW];
+    unsigned long long starts[RPW];
+#pragma unroll
+    for (int j = 0; j < RPW; ++j) {
+        const int y = ty0 + wave * RPW + j;
+        l[j] = (x < W && y < H) ? labels[(size_t)y * W + x] : OUT;
+    }
+#pragma unroll
+    for (int j = 0; j < RPW; ++j) {
+        const int idx = (wave * RPW + j) * CT_W + lane;
+        const int left = __shfl_up(l[j], 1, 64);
+        const bool active = l[j] != OUT;
+        cont[j] = lane > 0 && active && left == l[j];
+        starts[j] = __ballot(active && !cont[j]);
+        const unsigned long long below = starts[j] & le;
+        const int start_lane = below ? 63 - __clzll((long long)below) : lane;
+        spar[idx] = active ? idx - (lane - start_lane) : idx;
+        slab[idx] = l[j];
+    }
+    __syncthreads();
+    // vertical: one union per pair of overlapping runs (the pair further left does it when it joins the same two runs)
+#pragma unroll
+    for (int j = 0; j < RPW; ++j) {
+        const int row = wave * RPW + j;
+        if (row == 0) continue;                                        // wave-uniform
+        const int idx = row * CT_W + lane;
+        const int up = j > 0 ? l[j - 1] : slab[idx - CT_W];
+        const int upleft = __shfl_up(up, 1, 64);
+        if (l[j] != OUT && up == l[j] && !(cont[j] && upleft == l[j])) lds_union(spar, idx, idx - CT_W);
+    }
+    __syncthreads();
+    int rj[RPW];
+#pragma unroll
+    for (int j = 0; j < RPW; ++j) {
+        const int idx = (wave * RPW + j) * CT_W + lane;
+        rj[j] = l[j] != OUT ? lds_find(spar, idx) : -1;
+        if (rj[j] == idx) {
+            const int sl = atomicAdd(&s_n, 1);
+            if (sl < CT_SLOTS) {
+                c_root[sl] = idx;
+                c_size[sl] = 0;
+                c_ymax[sl] = 0;
+                c_xmin[sl] = CT_W - 1;
+                c_xmax[sl] = 0;
+                slab[idx] = sl;
+            }
+        }
+    }
+    __syncthreads();
+    const int ns = s_n;
+    if (ns > CT_SLOTS) {                                               // block-uniform
+        if (tid == 0) atomicOr(&counters[CNT_FLAG], 1);
+        return;
+    }
+    // size and bounding box of the local components: one set of LDS atomics per horizontal run
+#pragma unroll
+    for (int j = 0; j < RPW; ++j) {
+        const int nact = __popcll(__ballot(l[j] != OUT));
+        if (l[j] != OUT && !cont[j]) {
+            const unsigned long long above = starts[j] & ~le;
+            const int end = above ? __ffsll((long long)above) - 1 : nact;      // one past the run
+            const int sl = slab[rj[j]];
+            atomicAdd(&c_size[sl], end - lane);
+            atomicMax(&c_ymax[sl], wave * RPW + j);
+            atomicMin(&c_xmin[sl], lane);
+            atomicMax(&c_xmax[sl], end - 1);
+        }
+    }
+    if (tid == 0) s_base = atomicAdd(&counters[CNT_LROOT], ns);
+    __syncthreads();
+    if (tid < ns) {
+        const int r = c_root[tid];
+        const int g = (ty0 + (r >> 6)) * W + tx0 + (r & 63);
+        csize[g] = 0;
+        ymax_g[g] = -1;
+        xmin_g[g] = 0x7fffffff;
+        xmax_g[g] = -1;
+        const int pos = s_base + tid;
+        if (pos < CONN_LROOT_CAP) {
+            lroots[pos] = g;
+            lsize[pos] = c_size[tid];
+            lbox[pos] = (c_ymax[tid] << 16) | (c_xmin[tid] << 8) | c_xmax[tid];
+        } else {
+            atomicOr(&counters[CNT_FLAG], 2);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < RPW; ++j) {
+        const int y = ty0 + wave * RPW + j;
+        if (l[j] != OUT) parent[(size_t)y * W + x] = (ty0 + (rj[j] >> 6)) * W + tx0 + (rj[j] & 63);
+    }
+}
+
+__global__ void __launch_bounds__(256)
+k_ccl_border(const int32_t *__restrict__ labels, int H, int W, int32_t *parent, const int32_t *__restrict__ counters)
+{
+    if (counters[CNT_FLAG]) return;                  // a tile gave up: parent[] is incomplete, the general path follows
+    long t = (long)blockIdx.x * 256 + threadIdx.x;
+    const int nby = (H - 1) / CT_H, nbx = (W - 1) / CT_W;
+    if (t < (long)nby * W) {
+        const int y = (int)(t / W + 1) * CT_H, x = (int)(t % W);
+        const int p = y * W + x, l = labels[p];
+        if (labels[p - W] != l) return;
+        if ((x % CT_W) != 0 && labels[p - 1] == l && labels[p - W - 1] == l) return;
+        uf_union(parent, p, p - W);
+        return;
+    }
+    t -= (long)nby * W;
+    if (t < (long)nbx * H) {
+        const int x = (int)(t / H + 1) * CT_W, y = (int)(t % H);
+        const int p = y * W + x, l = labels[p];
+        if (labels[p - 1] != l) return;
+        if ((y % CT_H) != 0 && labels[p - W] == l && labels[p - W - 1] == l) return;
+        uf_union(parent, p, p - 1);
+    }
+}
+
+__global__ void __launch_bounds__(256)
+k_lroot_merge(const int32_t *__restrict__ lroots, const int32_t *__restrict__ lsize, const int32_t *__restrict__ lbox,
+              const int32_t *__restrict__ counters, int32_t *parent, int32_t *csize, int32_t *ymax_g, int32_t *xmin_g,
+              int32_t *xmax_g, int W)
+{
+    if (counters[CNT_FLAG]) return;
+    const int n = min(counters[CNT_LROOT], CONN_LROOT_CAP);
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int r = lroots[i];
+    const int g = uf_find(parent, r);
+    if (g != r) parent[r] = g;
+    atomicAdd(&csize[g], lsize[i]);
+    const int b = lbox[i];
+    const int ty0 = (r / W) & ~(CT_H - 1), tx0 = (r % W) & ~(CT_W - 1);
+    atomicMax(&ymax_g[g], ty0 + (b >> 16));
+    atomicMin(&xmin_g[g], tx0 + ((b >> 8) & 255));
+    atomicMax(&xmax_g[g], tx0 + (b & 255));
+}
+
+__global__ void __launch_bounds__(256)
+k_root_classify(const int32_t *__restrict__ lroots, int32_t *counters, const int32_t *__restrict__ parent,
+                const int32_t *__restrict__ csize, int min_size, int max_size, int32_t *kept, int32_t *list)
+{
+    if (counters[CNT_FLAG]) return;
+    const int n = min(counters[CNT_LROOT], CONN_LROOT_CAP);
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int r = lroots[i];
+    if (parent[r] != r) return;
+    const int sz = csize[r];
+    if (sz >= max_size) {
+        atomicAdd(&counters[CNT_OVER], 1);
+    } else if (sz >= min_size) {
+        const int k = atomicAdd(&counters[CNT_KEPT], 1);
+        if (k < CONN_KEPT_CAP) kept[k] = r;
+    } else {
+        list[atomicAdd(&counters[CNT_SMALL], 1)] = r;
+    }
+}
+
+// consecutive labels of the kept components = raster rank of their roots: bucket sort by pixel index in LDS
+constexpr int KR_BUCKETS = 4096, KR_THREADS = 1024;
+__global__ void __launch_bounds__(KR_THREADS)
+k_kept_rank(const int32_t *__restrict__ kept, const int32_t *__restrict__ counters, long n_pixels, int start_label,
+            int32_t *sorted, int32_t *newlabel)
+{
+    __shared__ int offs[KR_BUCKETS + 1];
+    __shared__ int cursor[KR_BUCKETS];
+    __shared__ int wsum[KR_THREADS / 64];
+    const int tid = threadIdx.x;
+    const int nk = counters[CNT_KEPT];
+    if (nk > CONN_KEPT_CAP || counters[CNT_FLAG]) return;                  // the host sees the count and takes the general path
+    for (int b = tid; b < KR_BUCKETS; b += KR_THREADS) cursor[b] = 0;
+    __syncthreads();
+    for (int k = tid; k < nk; k += KR_THREADS) atomicAdd(&cursor[(int)(((long)kept[k] * KR_BUCKETS) / n_pixels)], 1);
+    __syncthreads();
+    {   // exclusive scan of the bucket counts: KR_BUCKETS / KR_THREADS consecutive buckets per thread
+        constexpr int PER = KR_BUCKETS / KR_THREADS;
+        int v[PER], sum = 0;
+#pragma unroll
+        for (int j = 0; j < PER; ++j) {
+            v[j] = cursor[tid * PER + j];
+            sum += v[j];
+        }
+        const int lane = tid & 63, wave = tid >> 6;
+        int incl = sum;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int t = __shfl_up(incl, off, 64);
+            if (lane >= off) incl += t;
+        }
+        if (lane == 63) wsum[wave] = incl;
+        __syncthreads();
+        int base = 0;
+        for (int w = 0; w < wave; ++w) base += wsum[w];
+        int run = base + incl - sum;
+#pragma unroll
+        for (int j = 0; j < PER; ++j) {
+            offs[tid * PER + j] = run;
+            run += v[j];
+        }
+        if (tid == KR_THREADS - 1) offs[KR_BUCKETS] = run;
+        __syncthreads();
+        for (int b = tid; b < KR_BUCKETS; b += KR_THREADS) cursor[b] = offs[b];
+    }
+    __syncthreads();
+    for (int k = tid; k < nk; k += KR_THREADS) {
+        const int r = kept[k];
+        sorted[atomicAdd(&cursor[(int)(((long)r * KR_BUCKETS) / n_pixels)], 1)] = r;
+    }
+    __threadfence();
+    __syncthreads();
+    for (int i = tid; i < nk; i += KR_THREADS) {
+        const int r = sorted[i];
+        const int b = (int)(((long)r * KR_BUCKETS) / n_pixels);
+        int rank = offs[b];
+        for (int j = offs[b]; j < offs[b + 1]; ++j) rank += sorted[j] < r;
+        newlabel[r] = start_label + rank;
+    }
+}
+
+// `adjacent` of the small components (2-D): exact emulation of the reference's BFS (queue order, neighbour order
+// +x, -x, +y, -y) by one wave with the frontier in registers -- lane i holds the cell of BFS rank i inside the current
+// level.  The bounding box of the component plus two rings is staged in LDS by the whole workgroup as one byte per
+// cell: 0 other, 1 member not yet discovered, 2 pixel of an earlier component (smaller root: already labelled when the
+// reference gets here), 3 member done, 4 + i member of the current frontier with rank i.  A frontier cell claims the
+// undiscovered neighbour n unless one of the other three neighbours of n is a frontier cell of lower rank (that one
+// discovers it first); the claims of a level, ordered by (rank, direction), are the next frontier: positions from four
+// ballots.  `adjacent` is the earlier-component neighbour met by the highest (level, rank, direction).
+constexpr int BR_CELLS = 8192;
+__global__ void __launch_bounds__(256)
+k_small_bfs_reg(const int32_t *__restrict__ list, int32_t *counters, const int32_t *__restrict__ parent,
+                const int32_t *__restrict__ ymax_g, const int32_t *__restrict__ xmin_g, const int32_t *__restrict__ xmax_g,
+                int H, int W, int32_t *adjptr, int32_t *fb_list, int32_t *fb_bbox)
+{
+    __shared__ uint8_t cs_mem[BR_CELLS];
+    __shared__ int fr_mem[64];
+    volatile uint8_t *cs = cs_mem;
+    volatile int *fr = fr_mem;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int n_small = counters[CNT_FLAG] ? 0 : counters[CNT_SMALL];
+    for (int t = blockIdx.x; t < n_small; t += gridDim.x) {
+        const int root = list[t];
+        const int ry = root / W, rx = root - ry * W;
+        const int y1 = ymax_g[root], x0 = xmin_g[root], x1 = xmax_g[root];
+        const int by0 = ry - 2, bx0 = x0 - 2;
+        const int bw = x1 - x0 + 5, bh = y1 - ry + 5;
+        const long cells_l = (long)bw * bh;
+        bool reject = cells_l > BR_CELLS;                 // block-uniform
+        int adj_cell = -1;
+        if (!reject) {
+            const int cells = (int)cells_l;
+            const unsigned int m_bw = (unsigned int)((0x100000000ull + bw - 1) / bw);
+            __syncthreads();                              // the previous component is done with the tile
+            for (int c = tid; c < cells; c += 256) {
+                const int cy = (int)__umulhi((unsigned int)c, m_bw), cx = c - cy * bw;
+                const int y = by0 + cy, x = bx0 + cx;
+                int v = 0;
+                if (y >= 0 && y < H && x >= 0 && x < W) {
+                    const int q = parent[parent[(size_t)y * W + x]];
+                    v = q == root ? 1 : (q < root ? 2 : 0);
+                }
+                cs[c] = (uint8_t)v;
+            }
+            __syncthreads();
+            if (tid < 64) {
+                int c = 2 * bw + (rx - bx0);              // the root: row 2 of the tile
+                int f = 1;
+                if (lane == 0) cs[c] = 4;
+                const unsigned long long lt = (1ULL << lane) - 1ULL;
+                while (f > 0) {
+                    const bool act = lane < f;
+                    if (!act) c = 2 * bw + 2;             // any cell two rings inside: keeps the addresses valid
+                    const int v0 = cs[c + 1], v1 = cs[c - 1], v2 = cs[c + bw], v3 = cs[c - bw];
+                    const int e0 = cs[c + 2], e1 = cs[c - 2], e2 = cs[c + 2 * bw], e3 = cs[c - 2 * bw];
+                    const int epp = cs[c + 1 + bw], epm = cs[c + 1 - bw], emp = cs[c - 1 + bw], emm = cs[c - 1 - bw];
+                    auto lower = [lane](int v) { return (unsigned int)(v - 4) < (unsigned int)lane; };
+                    const bool w0 = act && v0 == 1 && !(lower(e0) || lower(epp) || lower(epm));
+                    const bool w1 = act && v1 == 1 && !(lower(e1) || lower(emp) || lower(emm));
+                    const bool w2 = act && v2 == 1 && !(lower(e2) || lower(epp) || lower(emp));
+                    const bool w3 = act && v3 == 1 && !(lower(e3) || lower(epm) || lower(emm));
+                    const unsigned long long con = __ballot(act && (v0 == 2 || v1 == 2 || v2 == 2 || v3 == 2));
+                    if (con) {
+                        const int cand = v3 == 2 ? c - bw : (v2 == 2 ? c + bw : (v1 == 2 ? c - 1 : c + 1));
+                        adj_cell = __shfl(cand, 63 - __clzll((long long)con), 64);
+                    }
+                    const unsigned long long b0 = __ballot(w0), b1 = __ballot(w1), b2 = __ballot(w2), b3 = __ballot(w3);
+                    const int total = __popcll(b0) + __popcll(b1) + __popcll(b2) + __popcll(b3);
+                    if (total > 64) {
+                        reject = true;
+                        break;
+                    }
+                    const int p0 = __popcll(b0 & lt) + __popcll(b1 & lt) + __popcll(b2 & lt) + __popcll(b3 & lt);
+                    const int p1 = p0 + (w0 ? 1 : 0), p2 = p1 + (w1 ? 1 : 0), p3 = p2 + (w2 ? 1 : 0);
+                    if (act) cs[c] = 3;
+                    if (w0) { fr[p0] = c + 1; cs[c + 1] = (uint8_t)(4 + p0); }
+                    if (w1) { fr[p1] = c - 1; cs[c - 1] = (uint8_t)(4 + p1); }
+                    if (w2) { fr[p2] = c + bw; cs[c + bw] = (uint8_t)(4 + p2); }
+                    if (w3) { fr[p3] = c - bw; cs[c - bw] = (uint8_t)(4 + p3); }
+                    f = total;
+                    c = fr[lane];
+                }
+            }
+        }
+        if (tid == 0) {
+            if (reject) {
+                // hand over to the LDS-frontier kernel (k_small_bfs_wave): it gets the tight bounding box
+                adjptr[root] = -1;                    // (defined even if nobody takes it: k_small_resolve walks these)
+                const int i = atomicAdd(&counters[CNT_FB], 1);
+                if (i < CONN_FB_CAP) {
+                    fb_list[i] = root;
+                    fb_bbox[6 * i + 0] = ry; fb_bbox[6 * i + 1] = y1;
+                    fb_bbox[6 * i + 2] = x0; fb_bbox[6 * i + 3] = x1;
+                    fb_bbox[6 * i + 4] = 0; fb_bbox[6 * i + 5] = 0;
+                }
+            } else {
+                int adj = -1;
+                if (adj_cell >= 0) {
+                    const int cy = adj_cell / bw, cx = adj_cell - cy * bw;
+                    adj = parent[parent[(size_t)(by0 + cy) * W + bx0 + cx]];
+                }
+                adjptr[root] = adj;
+            }
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256)
+k_lroot_labels(const int32_t *__restrict__ lroots, const int32_t *__restrict__ counters, const int32_t *__restrict__ parent,
+               int32_t *newlabel)
+{
+    if (counters[CNT_FLAG]) return;
+    const int n = min(counters[CNT_LROOT], CONN_LROOT_CAP);
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int r = lroots[i], g = parent[r];
+    if (g != r) newlabel[r] = newlabel[g];
+}
+
+// returns 0 and *ok = true when the fast path produced the result (labels_out, *n_kept)
+static int conn_fast_2d(const int32_t *labels_in, int H, int W, int min_size, int max_size, int start_label, const ConnWork &w,
+                        int32_t *labels_out, int *n_kept, bool *ok, hipStream_t st)
+{
+    const int n = H * W;
+    const ConnDense d = conn_dense(w);
+    int32_t *ymax_g = w.queue, *xmin_g = w.slotmap, *xmax_g = w.bbox;
+    int32_t host_counters[16];
+    HIP_TRY(hipMemsetAsync(w.counters, 0, 16 * sizeof(int32_t), st));
+    hipLaunchKernelGGL(k_ccl_tile, dim3(cdiv(W, CT_W), cdiv(H, CT_H)), 256, 0, st, labels_in, H, W, w.parent, w.csize, ymax_g,
+                       xmin_g, xmax_g, d.lroots, d.lsize, d.lbox, w.counters);
+    const long nborder = (long)((H - 1) / CT_H) * W + (long)((W - 1) / CT_W) * H;
+    if (nborder > 0) hipLaunchKernelGGL(k_ccl_border, cdiv(nborder, 256), 256, 0, st, labels_in, H, W, w.parent, w.counters);
+    const int lgrid = cdiv(std::min<long>(n, CONN_LROOT_CAP), 256);
+    hipLaunchKernelGGL(k_lroot_merge, lgrid, 256, 0, st, d.lroots, d.lsize, d.lbox, w.counters, w.parent, w.csize, ymax_g,
+                       xmin_g, xmax_g, W);
+    hipLaunchKernelGGL(k_root_classify, lgrid, 256, 0, st, d.lroots, w.counters, w.parent, w.csize, min_size, max_size, d.kept,
+                       w.list);
+    hipLaunchKernelGGL(k_kept_rank, 1, KR_THREADS, 0, st, d.kept, w.counters, (long)n, start_label, d.sorted, w.newlabel);
+    hipLaunchKernelGGL(k_small_bfs_reg, 2048, 256, 0, st, w.list, w.counters, w.parent, ymax_g, xmin_g, xmax_g, H, W, w.adjptr,
+                       d.fb_list, d.fb_bbox);
+    // components the register-frontier kernel handed over (frontier of more than 64 cells, large bounding box);
+    // what this one cannot take either ends up in CNT_FALLBACK and sends the image to the general path
+    hipLaunchKernelGGL((k_small_bfs_wave<8192, 2048, true>), 256, 64, 0, st, d.fb_list, w.counters, w.counters + CNT_FB, w.parent,
+                       d.fb_bbox, 1, H, W, (const int32_t *)nullptr, CONN_FB_CAP, w.adjptr, d.fb_reject);
+    hipLaunchKernelGGL(k_small_resolve, 64, 64, 0, st, w.list, w.counters, w.csize, w.adjptr, min_size, w.newlabel);
+    hipLaunchKernelGGL(k_lroot_labels, lgrid, 256, 0, st, d.lroots, w.counters, w.parent, w.newlabel);
+    hipLaunchKernelGGL(k_write_labels, cdiv(n, 256), 256, 0, st, w.parent, w.newlabel, n, labels_out,
+                       (const int32_t *)(w.counters + CNT_FLAG));
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(host_counters, w.counters, 16 * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    *ok = host_counters[CNT_FLAG] == 0 && host_counters[CNT_OVER] == 0 && host_counters[CNT_FALLBACK] == 0 &&
+          host_counters[CNT_LROOT] <= CONN_LROOT_CAP && host_counters[CNT_KEPT] <= CONN_KEPT_CAP &&
+          host_counters[CNT_FB] <= CONN_FB_CAP;
+    *n_kept = host_counters[CNT_KEPT];
     return 0;
 }
 
@@ -643,6 +1114,16 @@ int launch_enforce_connectivity(const int32_t *labels_in, int D, int H, int W, l
     const int max_size = (int)std::min<long>(max_size_l, 0x7fffffff);
     uint8_t *state = w.visited + n;       // second half of the byte scratch (2 * n bytes)
     int32_t host_counters[16];
+
+    if (D == 1 && !getenv("IMSEGM_CONN_GENERAL")) {
+        bool ok = false;
+        int n_kept = 0;
+        if (conn_fast_2d(labels_in, H, W, min_size, max_size, start_label, w, labels_out, &n_kept, &ok, st)) return -1;
+        if (ok) {
+            *n_labels_out_host = n_kept > 0 ? start_label + n_kept : 1;
+            return 0;
+        }
+    }
 
     // fast path, speculating that no component reaches max_size: one CCL round, then the tail;
     // a single host synchronisation at the very end reads the counters

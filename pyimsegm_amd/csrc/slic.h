@@ -64,6 +64,7 @@ struct SlicState {
     int grid_y0, grid_dy, grid_x0, grid_dx, grid_nx;   // initial centroid grid (skimage regular_grid)
     long long *phase_prof;          // profiling aid (env IMSEGM_PHASE_PROF): per-phase cycle sums, or null
     int debug;                      // profiling aid (env IMSEGM_DEBUG_ASSIGN): ablation bits, results invalid
+    int assign_units;               // 64 x 4 units per wave of k_slic_assign_dot: 2 (a workgroup = one bin tile) or 1
     int slico;                      // skimage slic_zero: colour distance / mdc[k], mdc updated after every sweep
     double *mdc;                    // [K] max_dist_color of _slic.pyx (starts at 1)
     int *drift;                     // [SLIC_DRIFT_SLOTS] per sweep: max displacement of a centroid from its grid node
@@ -137,7 +138,11 @@ struct ConnWork {
     int32_t *counters;    // [16] misc device counters
     int32_t *slotmap;     // [N] root -> index in the small-component list
     int32_t *bbox;        // [N] bounding boxes of small components (N/12 x 6) + fallback list (N/2)
+    int32_t *dense;       // [CONN_DENSE_INTS] dense lists of the 2-D tile path (local roots, kept roots, hand-overs)
 };
+constexpr size_t CONN_DENSE_INTS = 5 * 65536 + 8 * 4096;
+// bytes of the int32 scratch behind a ConnWork for n pixels
+static inline size_t conn_i32_bytes(size_t n) { return n * 4 * 8 + ((n / 4096) + 64) * 4 + 256 + CONN_DENSE_INTS * 4; }
 int launch_enforce_connectivity(const int32_t *labels_in, int D, int H, int W, long min_size, long max_size,
                                 int start_label, ConnWork w, int32_t *labels_out, int *n_labels_out_host,
                                 hipStream_t st);

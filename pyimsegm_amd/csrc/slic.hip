@@ -1135,8 +1135,11 @@ typedef float f2 __attribute__((ext_vector_type(2)));
 #ifndef SLIC_DOT_MIN_BLOCKS
 #define SLIC_DOT_MIN_BLOCKS 5
 #endif
-template <bool ACCUM, bool FIRST>
-__global__ void __launch_bounds__(256, SLIC_DOT_MIN_BLOCKS)
+#ifndef SLIC_DOT_MIN_BLOCKS_TILE
+#define SLIC_DOT_MIN_BLOCKS_TILE 4
+#endif
+template <bool ACCUM, bool FIRST, int U>
+__global__ void __launch_bounds__(256, U == 1 ? SLIC_DOT_MIN_BLOCKS : SLIC_DOT_MIN_BLOCKS_TILE)
 k_slic_assign_dot(SlicState s, const double *__restrict__ lab, int32_t *__restrict__ labels,
                   const Cand *__restrict__ tile_cands, const Rec32 *__restrict__ tile_rec,
                   const TileInfo *__restrict__ tile_info, const int *__restrict__ tile_k)
@@ -1154,10 +1157,12 @@ k_slic_assign_dot(SlicState s, const double *__restrict__ lab, int32_t *__restri
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int tile = (blockIdx.y >> 1) * gridDim.x + blockIdx.x;       // 64 x 32 bin tile
+    const int tile_row = (blockIdx.y * U) >> 1;
+    const int tile = tile_row * gridDim.x + blockIdx.x;                // 64 x 32 bin tile
     const int tx0 = blockIdx.x * TILE_X;
-    const int wy0 = blockIdx.y * WG_Y + wave * ROWS;                    // first row of this wave
-    const int rel0 = (blockIdx.y & 1) * WG_Y + wave * ROWS;             // ... relative to the bin tile
+    // first row of this wave's unit 0 relative to the bin tile: U == 1: half a tile per workgroup, U == 2: the whole
+    // tile, every wave works through two 64 x 4 units one after the other (pixel loads of both issued up front)
+    const int relbase = U == 1 ? (blockIdx.y & 1) * WG_Y + wave * ROWS : wave * (ROWS * U);
     const size_t plane = (size_t)s.H * s.W;
     // (the tables come in as restrict-qualified kernel arguments so that their uniform reads are scalar loads)
     const Cand *__restrict__ cand = tile_cands + (size_t)tile * MAXC;
@@ -1168,18 +1173,18 @@ k_slic_assign_dot(SlicState s, const double *__restrict__ lab, int32_t *__restri
     const bool xin = x < s.W;
     const double sw = s.spatial_weight;
 
-    double pL[ROWS], pA[ROWS], pB[ROWS];
-    int best_s[ROWS];      // slot in the candidate list; -1: nothing covers the pixel; <= -2: centroid -(k+2)
+    double pLu[U][ROWS], pAu[U][ROWS], pBu[U][ROWS];
 #pragma unroll
-    for (int r = 0; r < ROWS; ++r) {
-        const int y = wy0 + r;
-        const bool ok = xin && y < s.H;
-        const size_t p = (size_t)(ok ? y : 0) * s.W + (ok ? x : 0);
-        pL[r] = lab[p];
-        pA[r] = lab[plane + p];
-        pB[r] = lab[2 * plane + p];
-        best_s[r] = -1;
-    }
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r) {
+            const int y = tile_row * TILE_Y + relbase + u * ROWS + r;
+            const bool ok = xin && y < s.H;
+            const size_t p = (size_t)(ok ? y : 0) * s.W + (ok ? x : 0);
+            pLu[u][r] = lab[p];
+            pAu[u][r] = lab[plane + p];
+            pBu[u][r] = lab[2 * plane + p];
+        }
     const int my_k = tile_k[(size_t)tile * MAXC + lane];
     // candidate table in registers: lane c holds the record of candidate c; the loop fetches the fields
     // with v_readlane, i.e. without any memory latency between two candidates
@@ -1195,6 +1200,15 @@ k_slic_assign_dot(SlicState s, const double *__restrict__ lab, int32_t *__restri
         __syncthreads();
     }
     PHASE_MARK(1)                                  // LDS clear + barrier
+
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+    const int rel0 = relbase + u * ROWS;
+    const int wy0 = tile_row * TILE_Y + rel0;                          // first row of this unit
+    const double (&pL)[ROWS] = pLu[u], (&pA)[ROWS] = pAu[u], (&pB)[ROWS] = pBu[u];
+    int best_s[ROWS];      // slot in the candidate list; -1: nothing covers the pixel; <= -2: centroid -(k+2)
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r) best_s[r] = -1;
 
     if (overflow) {
 #pragma unroll
@@ -1414,13 +1428,15 @@ k_slic_assign_dot(SlicState s, const double *__restrict__ lab, int32_t *__restri
         }
     }
     PHASE_MARK(4)                                  // label stores
+    if (ACCUM) {
+        accumulate_block_sums(lane, x, wy0, best_s, pending, pL, pA, pB, ldexp(1.0, fix_bits_of(*s.premax)), lacc);
+        PHASE_MARK(5)                              // accumulation passes
+    }
+    }   // units
     if (!ACCUM) {
         PHASE_FLUSH()
         return;
     }
-
-    accumulate_block_sums(lane, x, wy0, best_s, pending, pL, pA, pB, ldexp(1.0, fix_bits_of(*s.premax)), lacc);
-    PHASE_MARK(5)                                  // accumulation passes
     __syncthreads();
     PHASE_MARK(6)                                  // barrier
     flush_block_sums(lacc, nc, lk, s.acc, tid);
@@ -1437,6 +1453,9 @@ int launch_slic_iterations(SlicState s, const double *lab, const double *init_yx
     hipLaunchKernelGGL(k_centroid_init, cdiv(s.K, 256), 256, 0, st, s, init_yx_dev);
     dim3 grid(cdiv(s.W, TILE_X), 2 * cdiv(s.H, TILE_Y));     // two 64 x 16 workgroups per bin tile
     const int n_tiles = grid.x * cdiv(s.H, TILE_Y);
+    // workgroups of the dot kernel: 1 = half a bin tile (64 x 16), 2 = a whole tile, two units per wave
+    const dim3 grid_tile(grid.x, cdiv(s.H, TILE_Y));
+    const int units = s.assign_units == 2 ? 2 : 1;
     static bool bin_attr = false;
     if (!bin_attr) {
         HIP_TRY(hipFuncSetAttribute((const void *)k_slic_bin, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1454,9 +1473,9 @@ int launch_slic_iterations(SlicState s, const double *lab, const double *init_yx
     }
     if (getenv("IMSEGM_PRINT_OCC")) {
         int nb = 0;
-        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void *)k_slic_assign_dot<true, false>, 256, 0));
+        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void *)k_slic_assign_dot<true, false, 2>, 256, 0));
         fprintf(stderr, "[occupancy] k_slic_assign_dot<true>: %d workgroups per CU\n", nb);
-        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void *)k_slic_assign_dot<false, false>, 256, 0));
+        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void *)k_slic_assign_dot<false, false, 2>, 256, 0));
         fprintf(stderr, "[occupancy] k_slic_assign_dot<false>: %d workgroups per CU\n", nb);
     }
     for (int it = 0; it < max_iter; ++it) {
@@ -1475,12 +1494,19 @@ int launch_slic_iterations(SlicState s, const double *lab, const double *init_yx
         hipEvent_t ev_a = nullptr, ev_b = nullptr;
         if (prof.pair) prof.pair(prof.user, 0, &ev_a, &ev_b);
 #define LAUNCH_ASSIGN(kernel, ...) hipExtLaunchKernelGGL(kernel, grid, dim3(256), 0, st, ev_a, ev_b, 0, __VA_ARGS__)
+#define LAUNCH_DOT(ACC, FST)                                                                                         \
+    {                                                                                                                \
+        if (units == 2)                                                                                              \
+            hipExtLaunchKernelGGL((k_slic_assign_dot<ACC, FST, 2>), grid_tile, dim3(256), 0, st, ev_a, ev_b, 0, s, lab,   \
+                                  labels, s.tile_cands, s.tile_rec, s.tile_info, s.tile_k);                          \
+        else                                                                                                         \
+            hipExtLaunchKernelGGL((k_slic_assign_dot<ACC, FST, 1>), grid, dim3(256), 0, st, ev_a, ev_b, 0, s, lab,   \
+                                  labels, s.tile_cands, s.tile_rec, s.tile_info, s.tile_k);                          \
+    }
         if (first_grid) {
-            if (accum) LAUNCH_ASSIGN((k_slic_assign_dot<true, true>), s, lab, labels, s.tile_cands, s.tile_rec, s.tile_info, s.tile_k);
-            else LAUNCH_ASSIGN((k_slic_assign_dot<false, true>), s, lab, labels, s.tile_cands, s.tile_rec, s.tile_info, s.tile_k);
+            if (accum) LAUNCH_DOT(true, true) else LAUNCH_DOT(false, true)
         } else if (dot) {
-            if (accum) LAUNCH_ASSIGN((k_slic_assign_dot<true, false>), s, lab, labels, s.tile_cands, s.tile_rec, s.tile_info, s.tile_k);
-            else LAUNCH_ASSIGN((k_slic_assign_dot<false, false>), s, lab, labels, s.tile_cands, s.tile_rec, s.tile_info, s.tile_k);
+            if (accum) LAUNCH_DOT(true, false) else LAUNCH_DOT(false, false)
         } else if (first) {
             if (accum) LAUNCH_ASSIGN((k_slic_assign<true, true>), s, lab, labels, s.tile_cands, s.tile_count);
             else LAUNCH_ASSIGN((k_slic_assign<false, true>), s, lab, labels, s.tile_cands, s.tile_count);
@@ -1490,6 +1516,7 @@ int launch_slic_iterations(SlicState s, const double *lab, const double *init_yx
             if (accum) LAUNCH_ASSIGN((k_slic_assign<true, false>), se, lab, labels, s.tile_cands, s.tile_count);
             else LAUNCH_ASSIGN((k_slic_assign<false, false>), se, lab, labels, s.tile_cands, s.tile_count);
         }
+#undef LAUNCH_DOT
 #undef LAUNCH_ASSIGN
         if (it + 1 < max_iter) {
             if (!dot && !first_grid) hipLaunchKernelGGL(k_slic_leftover, 64, 256, 0, st, s, lab, labels);

@@ -29,3 +29,27 @@ for v, name in ((1, 'accum sweep (last launch)'), (0, 'final sweep')):
         out.append(int((conc[:-1][m] * dt[m]).sum() / max(dt[m].sum(), 1e-9)))
     print('  resident WGs (whole GPU) over 12 time slices:', out, ' (5 per CU = %d)' % (5 * len(u)))
     print('  last start at %.1f us, first end at %.1f us' % (st.max(), en.min()))
+
+# late starters against the rest: where does the lifetime of the last workgroups go?
+print()
+for v, name in ((1, 'accum sweep'), (0, 'final sweep')):
+    d = a[:, v, :]
+    d = d[d[:, 15] > 0]
+    if not len(d):
+        continue
+    t0 = d[:, 10].min()
+    st = (d[:, 10] - t0) / 100.0
+    life = (d[:, 11] - d[:, 10]) / 100.0
+    n = d[:, 15].astype(float)
+    edges = np.percentile(st, [0, 25, 50, 75, 90, 97, 100])
+    print(name, ': start-time buckets (us) -> n, lifetime mean/p95, cycles of wave 0 per phase p0..p7 (per launch), candidates')
+    for i in range(len(edges) - 1):
+        m = (st >= edges[i]) & (st <= edges[i + 1] if i == len(edges) - 2 else st < edges[i + 1])
+        if not m.any():
+            continue
+        ph = (d[m, :8] / n[m, None]).mean(0)
+        print('  %5.1f-%5.1f  n=%5d life %.1f / %.1f   ' % (edges[i], edges[i + 1], m.sum(), life[m].mean(), np.percentile(life[m], 95)),
+              ' '.join('%5.0f' % x for x in ph), '  cand %.1f' % (d[m, 9] / n[m]).mean())
+    slow = life > np.percentile(life, 95)
+    print('  slowest 5%%: start %.1f..%.1f us, phases' % (st[slow].min(), st[slow].max()),
+          ' '.join('%5.0f' % x for x in (d[slow, :8] / n[slow, None]).mean(0)))
