@@ -594,7 +594,7 @@ int imsegm_image2d_slic(imsegm_image2d *im, int minmax_normalize, int n_segments
         double segment_size = (double)n / (double)K;
         long min_size = (long)(min_size_factor * segment_size);
         long max_size = (long)(max_size_factor * segment_size);
-        if (im->conn_i32.ensure(conn_i32_bytes(n)) || im->conn_u8.ensure(2 * n + 64)) return -1;
+        if (im->conn_i32.ensure(conn_i32_bytes(n, H, W)) || im->conn_u8.ensure(2 * n + 64)) return -1;
         ConnWork w = make_conn_work(im);
         int spc = ctx->begin(PG_CONN);
         // the raw assignment carries no start_label offset; the reference adds it before the

@@ -662,24 +662,28 @@ static int conn_tail(const int32_t *csize_final, int32_t *adjptr, int D, int H, 
 // than 64 cells and a bounding box the old wave kernel cannot stage either, an oversize component) raises a flag /
 // counter that the host reads at its single synchronisation, and the general path above runs instead.
 constexpr int CT_W = 64, CT_H = 32, CT_SLOTS = 64;
-constexpr int CONN_LROOT_CAP = 1 << 16, CONN_KEPT_CAP = 1 << 16, CONN_FB_CAP = 4096;
-static_assert(3 * CONN_LROOT_CAP + 2 * CONN_KEPT_CAP + 8 * CONN_FB_CAP <= CONN_DENSE_INTS, "dense scratch of the tile path");
+constexpr int CONN_KEPT_CAP = 1 << 16, CONN_FB_CAP = 4096;
+static_assert(2 * CONN_KEPT_CAP + 8 * CONN_FB_CAP <= CONN_DENSE_INTS, "dense scratch of the tile path");
+static_assert(CT_W * CT_H == CONN_TILE_PIXELS && CT_SLOTS == CONN_TILE_SLOTS, "sizes used by conn_i32_bytes (slic.h)");
 
 struct ConnDense {
-    int32_t *lroots, *lsize, *lbox, *kept, *sorted, *fb_list, *fb_reject, *fb_bbox;
+    int32_t *lroots, *lsize, *lbox, *ntile, *kept, *sorted, *fb_list, *fb_reject, *fb_bbox;
 };
-static ConnDense conn_dense(const ConnWork &w)
+// local roots live in fixed slots: tile t owns entries [t * CT_SLOTS, t * CT_SLOTS + ntile[t]) (no global cursor: two
+// thousand workgroups adding to one counter serialise on it)
+static ConnDense conn_dense(const ConnWork &w, int n_tiles)
 {
     ConnDense d;
     int32_t *b = w.dense;
-    d.lroots = b; b += CONN_LROOT_CAP;
-    d.lsize = b; b += CONN_LROOT_CAP;
-    d.lbox = b; b += CONN_LROOT_CAP;
     d.kept = b; b += CONN_KEPT_CAP;
     d.sorted = b; b += CONN_KEPT_CAP;
     d.fb_list = b; b += CONN_FB_CAP;
     d.fb_reject = b; b += CONN_FB_CAP;
-    d.fb_bbox = b;
+    d.fb_bbox = b; b += 6 * CONN_FB_CAP;
+    d.lroots = b; b += (size_t)n_tiles * CT_SLOTS;
+    d.lsize = b; b += (size_t)n_tiles * CT_SLOTS;
+    d.lbox = b; b += (size_t)n_tiles * CT_SLOTS;
+    d.ntile = b;
     return d;
 }
 
@@ -693,11 +697,16 @@ __device__ __forceinline__ int lds_find(volatile int *par, int a)
     return a;
 }
 
+// (the finds compress: a stack of full-width runs would otherwise grow a chain as long as the tile is high;
+// atomicMin keeps the entry a valid, only ever smaller, ancestor)
 __device__ __forceinline__ void lds_union(int *par, int a, int b)
 {
     while (true) {
+        const int a0 = a, b0 = b;
         a = lds_find(par, a);
         b = lds_find(par, b);
+        if (a != a0) atomicMin(&par[a0], a);
+        if (b != b0) atomicMin(&par[b0], b);
         if (a == b) return;
         if (a < b) {
             const int t = a;
@@ -713,12 +722,13 @@ __device__ __forceinline__ void lds_union(int *par, int a, int b)
 __global__ void __launch_bounds__(256)
 k_ccl_tile(const int32_t *__restrict__ labels, int H, int W, int32_t *__restrict__ parent, int32_t *__restrict__ csize,
            int32_t *__restrict__ ymax_g, int32_t *__restrict__ xmin_g, int32_t *__restrict__ xmax_g,
-           int32_t *__restrict__ lroots, int32_t *__restrict__ lsize, int32_t *__restrict__ lbox, int32_t *counters)
+           int32_t *__restrict__ lroots, int32_t *__restrict__ lsize, int32_t *__restrict__ lbox, int32_t *__restrict__ ntile,
+           int32_t *counters)
 {
     __shared__ int slab[CT_H * CT_W];      // labels; after the unions: slot of a local root
     __shared__ int spar[CT_H * CT_W];
     __shared__ int c_root[CT_SLOTS], c_size[CT_SLOTS], c_ymax[CT_SLOTS], c_xmin[CT_SLOTS], c_xmax[CT_SLOTS];
-    __shared__ int s_n, s_base;
+    __shared__ int s_n;
     constexpr int OUT = (int)0x80000000;   // outside the image (never a label)
     constexpr int RPW = CT_H / 4;          // rows per wave
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -759,11 +769,26 @@ k_ccl_tile(const int32_t *__restrict__ labels, int H, int W, int32_t *__restrict
         if (l[j] != OUT && up == l[j] && !(cont[j] && upleft == l[j])) lds_union(spar, idx, idx - CT_W);
     }
     __syncthreads();
+    // roots of the eight pixels of this lane by pointer jumping, all eight chains in flight at once
     int rj[RPW];
+#pragma unroll
+    for (int j = 0; j < RPW; ++j) rj[j] = spar[(wave * RPW + j) * CT_W + lane];
+    while (true) {
+        int nx[RPW];
+        bool moved = false;
+#pragma unroll
+        for (int j = 0; j < RPW; ++j) nx[j] = spar[rj[j]];
+#pragma unroll
+        for (int j = 0; j < RPW; ++j) {
+            moved |= nx[j] != rj[j];
+            rj[j] = nx[j];
+        }
+        if (!__any(moved)) break;
+    }
 #pragma unroll
     for (int j = 0; j < RPW; ++j) {
         const int idx = (wave * RPW + j) * CT_W + lane;
-        rj[j] = l[j] != OUT ? lds_find(spar, idx) : -1;
+        if (l[j] == OUT) rj[j] = -1;
         if (rj[j] == idx) {
             const int sl = atomicAdd(&s_n, 1);
             if (sl < CT_SLOTS) {
@@ -778,8 +803,12 @@ k_ccl_tile(const int32_t *__restrict__ labels, int H, int W, int32_t *__restrict
     }
     __syncthreads();
     const int ns = s_n;
+    const int tile = blockIdx.y * gridDim.x + blockIdx.x;
     if (ns > CT_SLOTS) {                                               // block-uniform
-        if (tid == 0) atomicOr(&counters[CNT_FLAG], 1);
+        if (tid == 0) {
+            atomicOr(&counters[CNT_FLAG], 1);
+            ntile[tile] = 0;
+        }
         return;
     }
     // size and bounding box of the local components: one set of LDS atomics per horizontal run
@@ -796,7 +825,7 @@ k_ccl_tile(const int32_t *__restrict__ labels, int H, int W, int32_t *__restrict
             atomicMax(&c_xmax[sl], end - 1);
         }
     }
-    if (tid == 0) s_base = atomicAdd(&counters[CNT_LROOT], ns);
+    if (tid == 0) ntile[tile] = ns;
     __syncthreads();
     if (tid < ns) {
         const int r = c_root[tid];
@@ -805,14 +834,10 @@ k_ccl_tile(const int32_t *__restrict__ labels, int H, int W, int32_t *__restrict
         ymax_g[g] = -1;
         xmin_g[g] = 0x7fffffff;
         xmax_g[g] = -1;
-        const int pos = s_base + tid;
-        if (pos < CONN_LROOT_CAP) {
-            lroots[pos] = g;
-            lsize[pos] = c_size[tid];
-            lbox[pos] = (c_ymax[tid] << 16) | (c_xmin[tid] << 8) | c_xmax[tid];
-        } else {
-            atomicOr(&counters[CNT_FLAG], 2);
-        }
+        const int pos = tile * CT_SLOTS + tid;
+        lroots[pos] = g;
+        lsize[pos] = c_size[tid];
+        lbox[pos] = (c_ymax[tid] << 16) | (c_xmin[tid] << 8) | c_xmax[tid];
     }
 #pragma unroll
     for (int j = 0; j < RPW; ++j) {
@@ -847,13 +872,12 @@ k_ccl_border(const int32_t *__restrict__ labels, int H, int W, int32_t *parent, 
 
 __global__ void __launch_bounds__(256)
 k_lroot_merge(const int32_t *__restrict__ lroots, const int32_t *__restrict__ lsize, const int32_t *__restrict__ lbox,
-              const int32_t *__restrict__ counters, int32_t *parent, int32_t *csize, int32_t *ymax_g, int32_t *xmin_g,
+              const int32_t *__restrict__ ntile, int n_slots, const int32_t *__restrict__ counters, int32_t *parent, int32_t *csize, int32_t *ymax_g, int32_t *xmin_g,
               int32_t *xmax_g, int W)
 {
     if (counters[CNT_FLAG]) return;
-    const int n = min(counters[CNT_LROOT], CONN_LROOT_CAP);
     const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
+    if (i >= n_slots || (i & (CT_SLOTS - 1)) >= ntile[i / CT_SLOTS]) return;
     const int r = lroots[i];
     const int g = uf_find(parent, r);
     if (g != r) parent[r] = g;
@@ -865,45 +889,58 @@ k_lroot_merge(const int32_t *__restrict__ lroots, const int32_t *__restrict__ ls
     atomicMax(&xmax_g[g], tx0 + (b & 255));
 }
 
-__global__ void __launch_bounds__(256)
-k_root_classify(const int32_t *__restrict__ lroots, int32_t *counters, const int32_t *__restrict__ parent,
-                const int32_t *__restrict__ csize, int min_size, int max_size, int32_t *kept, int32_t *list)
+// (positions inside the two lists: counted in LDS per workgroup of 16 tiles, one global atomic per list and workgroup --
+// a few thousand single-lane atomics on one address serialise at ~6 ns each)
+__global__ void __launch_bounds__(1024)
+k_root_classify(const int32_t *__restrict__ lroots, const int32_t *__restrict__ ntile, int n_slots, int32_t *counters,
+                const int32_t *__restrict__ parent, const int32_t *__restrict__ csize, int min_size, int max_size, int32_t *kept,
+                int32_t *list)
 {
+    __shared__ int n_k, n_s, base_k, base_s;
     if (counters[CNT_FLAG]) return;
-    const int n = min(counters[CNT_LROOT], CONN_LROOT_CAP);
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    const int r = lroots[i];
-    if (parent[r] != r) return;
-    const int sz = csize[r];
-    if (sz >= max_size) {
-        atomicAdd(&counters[CNT_OVER], 1);
-    } else if (sz >= min_size) {
-        const int k = atomicAdd(&counters[CNT_KEPT], 1);
-        if (k < CONN_KEPT_CAP) kept[k] = r;
-    } else {
-        list[atomicAdd(&counters[CNT_SMALL], 1)] = r;
+    if (threadIdx.x == 0) n_k = n_s = 0;
+    __syncthreads();
+    const int i = blockIdx.x * 1024 + threadIdx.x;
+    int r = -1, kind = 0, pos = 0;                     // kind 1 kept, 2 small
+    if (i < n_slots && (i & (CT_SLOTS - 1)) < ntile[i / CT_SLOTS]) {
+        r = lroots[i];
+        if (parent[r] == r) {
+            const int sz = csize[r];
+            if (sz >= max_size) atomicAdd(&counters[CNT_OVER], 1);
+            else if (sz >= min_size) { kind = 1; pos = atomicAdd(&n_k, 1); }
+            else { kind = 2; pos = atomicAdd(&n_s, 1); }
+        }
     }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        base_k = n_k ? atomicAdd(&counters[CNT_KEPT], n_k) : 0;
+        base_s = n_s ? atomicAdd(&counters[CNT_SMALL], n_s) : 0;
+    }
+    __syncthreads();
+    if (kind == 1 && base_k + pos < CONN_KEPT_CAP) kept[base_k + pos] = r;
+    if (kind == 2) list[base_s + pos] = r;
 }
 
-// consecutive labels of the kept components = raster rank of their roots: bucket sort by pixel index in LDS
-constexpr int KR_BUCKETS = 4096, KR_THREADS = 1024;
-__global__ void __launch_bounds__(KR_THREADS)
-k_kept_rank(const int32_t *__restrict__ kept, const int32_t *__restrict__ counters, long n_pixels, int start_label,
-            int32_t *sorted, int32_t *newlabel)
+// consecutive labels of the kept components = raster rank of their roots: bucket sort by pixel index in LDS, by one
+// workgroup of NT threads (the last workgroup of the k_small_bfs_reg launch: it needs nothing from the others and
+// hides behind them)
+constexpr int KR_BUCKETS = 1024, KR_SORTED_LDS = 2048;
+template <int NT>
+__device__ __forceinline__ void kept_rank_block(int *offs /* [KR_BUCKETS + 1] */, int *cursor /* [KR_BUCKETS] */,
+                                                int *wsum /* [NT / 64] */, int *sorted_lds /* [KR_SORTED_LDS] */,
+                                                const int32_t *__restrict__ kept, const int32_t *__restrict__ counters,
+                                                long n_pixels, int start_label, int32_t *sorted_global, int32_t *newlabel)
 {
-    __shared__ int offs[KR_BUCKETS + 1];
-    __shared__ int cursor[KR_BUCKETS];
-    __shared__ int wsum[KR_THREADS / 64];
     const int tid = threadIdx.x;
     const int nk = counters[CNT_KEPT];
     if (nk > CONN_KEPT_CAP || counters[CNT_FLAG]) return;                  // the host sees the count and takes the general path
-    for (int b = tid; b < KR_BUCKETS; b += KR_THREADS) cursor[b] = 0;
+    int *sorted = nk <= KR_SORTED_LDS ? sorted_lds : sorted_global;
+    for (int b = tid; b < KR_BUCKETS; b += NT) cursor[b] = 0;
     __syncthreads();
-    for (int k = tid; k < nk; k += KR_THREADS) atomicAdd(&cursor[(int)(((long)kept[k] * KR_BUCKETS) / n_pixels)], 1);
+    for (int k = tid; k < nk; k += NT) atomicAdd(&cursor[(int)(((long)kept[k] * KR_BUCKETS) / n_pixels)], 1);
     __syncthreads();
-    {   // exclusive scan of the bucket counts: KR_BUCKETS / KR_THREADS consecutive buckets per thread
-        constexpr int PER = KR_BUCKETS / KR_THREADS;
+    {   // exclusive scan of the bucket counts: KR_BUCKETS / NT consecutive buckets per thread
+        constexpr int PER = KR_BUCKETS / NT;
         int v[PER], sum = 0;
 #pragma unroll
         for (int j = 0; j < PER; ++j) {
@@ -927,18 +964,18 @@ k_kept_rank(const int32_t *__restrict__ kept, const int32_t *__restrict__ counte
             offs[tid * PER + j] = run;
             run += v[j];
         }
-        if (tid == KR_THREADS - 1) offs[KR_BUCKETS] = run;
+        if (tid == NT - 1) offs[KR_BUCKETS] = run;
         __syncthreads();
-        for (int b = tid; b < KR_BUCKETS; b += KR_THREADS) cursor[b] = offs[b];
+        for (int b = tid; b < KR_BUCKETS; b += NT) cursor[b] = offs[b];
     }
     __syncthreads();
-    for (int k = tid; k < nk; k += KR_THREADS) {
+    for (int k = tid; k < nk; k += NT) {
         const int r = kept[k];
         sorted[atomicAdd(&cursor[(int)(((long)r * KR_BUCKETS) / n_pixels)], 1)] = r;
     }
     __threadfence();
     __syncthreads();
-    for (int i = tid; i < nk; i += KR_THREADS) {
+    for (int i = tid; i < nk; i += NT) {
         const int r = sorted[i];
         const int b = (int)(((long)r * KR_BUCKETS) / n_pixels);
         int rank = offs[b];
@@ -955,19 +992,26 @@ k_kept_rank(const int32_t *__restrict__ kept, const int32_t *__restrict__ counte
 // undiscovered neighbour n unless one of the other three neighbours of n is a frontier cell of lower rank (that one
 // discovers it first); the claims of a level, ordered by (rank, direction), are the next frontier: positions from four
 // ballots.  `adjacent` is the earlier-component neighbour met by the highest (level, rank, direction).
-constexpr int BR_CELLS = 8192;
+constexpr int BR_CELLS = 16384;      // 16.6 KB of LDS per workgroup: every small component of an image is resident at once
 __global__ void __launch_bounds__(256)
 k_small_bfs_reg(const int32_t *__restrict__ list, int32_t *counters, const int32_t *__restrict__ parent,
                 const int32_t *__restrict__ ymax_g, const int32_t *__restrict__ xmin_g, const int32_t *__restrict__ xmax_g,
-                int H, int W, int32_t *adjptr, int32_t *fb_list, int32_t *fb_bbox)
+                int H, int W, int32_t *adjptr, int32_t *fb_list, int32_t *fb_bbox, const int32_t *__restrict__ kept,
+                int start_label, int32_t *sorted, int32_t *newlabel)
 {
-    __shared__ uint8_t cs_mem[BR_CELLS];
-    __shared__ int fr_mem[64];
-    volatile uint8_t *cs = cs_mem;
-    volatile int *fr = fr_mem;
+    static_assert(BR_CELLS + 64 * 4 >= (2 * KR_BUCKETS + 1 + 4 + KR_SORTED_LDS) * 4, "shared memory of the two roles");
+    __shared__ __align__(16) uint8_t smem[BR_CELLS + 64 * 4];
     const int tid = threadIdx.x, lane = tid & 63;
+    if (blockIdx.x == gridDim.x - 1) {
+        int *si = reinterpret_cast<int *>(smem);
+        kept_rank_block<256>(si, si + KR_BUCKETS + 1, si + 2 * KR_BUCKETS + 1, si + 2 * KR_BUCKETS + 1 + 4, kept, counters,
+                             (long)H * W, start_label, sorted, newlabel);
+        return;
+    }
+    uint8_t *cs = smem;
+    int *fr = reinterpret_cast<int *>(smem + BR_CELLS);
     const int n_small = counters[CNT_FLAG] ? 0 : counters[CNT_SMALL];
-    for (int t = blockIdx.x; t < n_small; t += gridDim.x) {
+    for (int t = blockIdx.x; t < n_small; t += gridDim.x - 1) {
         const int root = list[t];
         const int ry = root / W, rx = root - ry * W;
         const int y1 = ymax_g[root], x0 = xmin_g[root], x1 = xmax_g[root];
@@ -980,15 +1024,21 @@ k_small_bfs_reg(const int32_t *__restrict__ list, int32_t *counters, const int32
             const int cells = (int)cells_l;
             const unsigned int m_bw = (unsigned int)((0x100000000ull + bw - 1) / bw);
             __syncthreads();                              // the previous component is done with the tile
-            for (int c = tid; c < cells; c += 256) {
-                const int cy = (int)__umulhi((unsigned int)c, m_bw), cx = c - cy * bw;
-                const int y = by0 + cy, x = bx0 + cx;
-                int v = 0;
-                if (y >= 0 && y < H && x >= 0 && x < W) {
-                    const int q = parent[parent[(size_t)y * W + x]];
-                    v = q == root ? 1 : (q < root ? 2 : 0);
+            // four cells per thread and round: the two dependent loads of four cells are in flight together
+            for (int c0 = tid; c0 < cells; c0 += 4 * 256) {
+                int q[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int c = c0 + u * 256;
+                    const int cy = (int)__umulhi((unsigned int)c, m_bw), cx = c - cy * bw;
+                    const int y = by0 + cy, x = bx0 + cx;
+                    q[u] = (c < cells && y >= 0 && y < H && x >= 0 && x < W) ? parent[(size_t)y * W + x] : -1;
                 }
-                cs[c] = (uint8_t)v;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) q[u] = q[u] >= 0 ? parent[q[u]] : 0x7fffffff;
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (c0 + u * 256 < cells) cs[c0 + u * 256] = (uint8_t)(q[u] == root ? 1 : (q[u] < root ? 2 : 0));
             }
             __syncthreads();
             if (tid < 64) {
@@ -996,7 +1046,32 @@ k_small_bfs_reg(const int32_t *__restrict__ list, int32_t *counters, const int32
                 int f = 1;
                 if (lane == 0) cs[c] = 4;
                 const unsigned long long lt = (1ULL << lane) - 1ULL;
+                // (one wave: its LDS operations execute in program order; the compiler barriers keep the reads of a level
+                // behind the writes of the previous one)
                 while (f > 0) {
+                    __asm__ volatile("" ::: "memory");
+                    if (f == 1) {
+                        // one frontier cell (every level of a one-pixel-wide sliver): nothing competes, everything is
+                        // wave-uniform -- one LDS round trip, no ballots, no exchange through LDS
+                        const int cu = __builtin_amdgcn_readfirstlane(c);
+                        const int u0 = __builtin_amdgcn_readfirstlane((int)cs[cu + 1]);
+                        const int u1 = __builtin_amdgcn_readfirstlane((int)cs[cu - 1]);
+                        const int u2 = __builtin_amdgcn_readfirstlane((int)cs[cu + bw]);
+                        const int u3 = __builtin_amdgcn_readfirstlane((int)cs[cu - bw]);
+                        if (u3 == 2) adj_cell = cu - bw;
+                        else if (u2 == 2) adj_cell = cu + bw;
+                        else if (u1 == 2) adj_cell = cu - 1;
+                        else if (u0 == 2) adj_cell = cu + 1;
+                        int k = 0;
+                        __asm__ volatile("" ::: "memory");
+                        if (lane == 0) cs[cu] = 3;
+                        if (u0 == 1) { if (lane == k) { c = cu + 1; cs[c] = (uint8_t)(4 + k); } ++k; }
+                        if (u1 == 1) { if (lane == k) { c = cu - 1; cs[c] = (uint8_t)(4 + k); } ++k; }
+                        if (u2 == 1) { if (lane == k) { c = cu + bw; cs[c] = (uint8_t)(4 + k); } ++k; }
+                        if (u3 == 1) { if (lane == k) { c = cu - bw; cs[c] = (uint8_t)(4 + k); } ++k; }
+                        f = k;
+                        continue;
+                    }
                     const bool act = lane < f;
                     if (!act) c = 2 * bw + 2;             // any cell two rings inside: keeps the addresses valid
                     const int v0 = cs[c + 1], v1 = cs[c - 1], v2 = cs[c + bw], v3 = cs[c - bw];
@@ -1010,7 +1085,7 @@ k_small_bfs_reg(const int32_t *__restrict__ list, int32_t *counters, const int32
                     const unsigned long long con = __ballot(act && (v0 == 2 || v1 == 2 || v2 == 2 || v3 == 2));
                     if (con) {
                         const int cand = v3 == 2 ? c - bw : (v2 == 2 ? c + bw : (v1 == 2 ? c - 1 : c + 1));
-                        adj_cell = __shfl(cand, 63 - __clzll((long long)con), 64);
+                        adj_cell = __builtin_amdgcn_readlane(cand, 63 - __clzll((long long)con));
                     }
                     const unsigned long long b0 = __ballot(w0), b1 = __ballot(w1), b2 = __ballot(w2), b3 = __ballot(w3);
                     const int total = __popcll(b0) + __popcll(b1) + __popcll(b2) + __popcll(b3);
@@ -1020,12 +1095,14 @@ k_small_bfs_reg(const int32_t *__restrict__ list, int32_t *counters, const int32
                     }
                     const int p0 = __popcll(b0 & lt) + __popcll(b1 & lt) + __popcll(b2 & lt) + __popcll(b3 & lt);
                     const int p1 = p0 + (w0 ? 1 : 0), p2 = p1 + (w1 ? 1 : 0), p3 = p2 + (w2 ? 1 : 0);
+                    __asm__ volatile("" ::: "memory");
                     if (act) cs[c] = 3;
                     if (w0) { fr[p0] = c + 1; cs[c + 1] = (uint8_t)(4 + p0); }
                     if (w1) { fr[p1] = c - 1; cs[c - 1] = (uint8_t)(4 + p1); }
                     if (w2) { fr[p2] = c + bw; cs[c + bw] = (uint8_t)(4 + p2); }
                     if (w3) { fr[p3] = c - bw; cs[c - bw] = (uint8_t)(4 + p3); }
                     f = total;
+                    __asm__ volatile("" ::: "memory");
                     c = fr[lane];
                 }
             }
@@ -1053,16 +1130,23 @@ k_small_bfs_reg(const int32_t *__restrict__ list, int32_t *counters, const int32
     }
 }
 
+// labels of all tile-local roots (what k_write_labels looks up): kept component -> its consecutive label; small
+// component -> the label of the kept component at the end of its `adjacent` chain (roots strictly decrease), 0 when the
+// BFS met no labelled neighbour (k_small_resolve of the general path, done per local root)
 __global__ void __launch_bounds__(256)
-k_lroot_labels(const int32_t *__restrict__ lroots, const int32_t *__restrict__ counters, const int32_t *__restrict__ parent,
-               int32_t *newlabel)
+k_lroot_labels(const int32_t *__restrict__ lroots, const int32_t *__restrict__ ntile, int n_slots,
+               const int32_t *__restrict__ counters, const int32_t *__restrict__ parent,
+               const int32_t *__restrict__ csize, const int32_t *__restrict__ adjptr, int min_size, int32_t *newlabel)
 {
     if (counters[CNT_FLAG]) return;
-    const int n = min(counters[CNT_LROOT], CONN_LROOT_CAP);
     const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    const int r = lroots[i], g = parent[r];
-    if (g != r) newlabel[r] = newlabel[g];
+    if (i >= n_slots || (i & (CT_SLOTS - 1)) >= ntile[i / CT_SLOTS]) return;
+    const int r = lroots[i];
+    int g = parent[r];
+    const bool kept_root = g == r && csize[g] >= min_size;
+    if (kept_root) return;                             // (its label comes from the ranking)
+    while (g >= 0 && csize[g] < min_size) g = adjptr[g];
+    newlabel[r] = g >= 0 ? newlabel[g] : 0;
 }
 
 // returns 0 and *ok = true when the fast path produced the result (labels_out, *n_kept)
@@ -1070,35 +1154,35 @@ static int conn_fast_2d(const int32_t *labels_in, int H, int W, int min_size, in
                         int32_t *labels_out, int *n_kept, bool *ok, hipStream_t st)
 {
     const int n = H * W;
-    const ConnDense d = conn_dense(w);
+    const dim3 tiles(cdiv(W, CT_W), cdiv(H, CT_H));
+    const int n_tiles = tiles.x * tiles.y, n_slots = n_tiles * CT_SLOTS;
+    const ConnDense d = conn_dense(w, n_tiles);
     int32_t *ymax_g = w.queue, *xmin_g = w.slotmap, *xmax_g = w.bbox;
     int32_t host_counters[16];
     HIP_TRY(hipMemsetAsync(w.counters, 0, 16 * sizeof(int32_t), st));
-    hipLaunchKernelGGL(k_ccl_tile, dim3(cdiv(W, CT_W), cdiv(H, CT_H)), 256, 0, st, labels_in, H, W, w.parent, w.csize, ymax_g,
-                       xmin_g, xmax_g, d.lroots, d.lsize, d.lbox, w.counters);
+    hipLaunchKernelGGL(k_ccl_tile, tiles, 256, 0, st, labels_in, H, W, w.parent, w.csize, ymax_g, xmin_g, xmax_g, d.lroots, d.lsize,
+                       d.lbox, d.ntile, w.counters);
     const long nborder = (long)((H - 1) / CT_H) * W + (long)((W - 1) / CT_W) * H;
     if (nborder > 0) hipLaunchKernelGGL(k_ccl_border, cdiv(nborder, 256), 256, 0, st, labels_in, H, W, w.parent, w.counters);
-    const int lgrid = cdiv(std::min<long>(n, CONN_LROOT_CAP), 256);
-    hipLaunchKernelGGL(k_lroot_merge, lgrid, 256, 0, st, d.lroots, d.lsize, d.lbox, w.counters, w.parent, w.csize, ymax_g,
+    const int lgrid = cdiv(n_slots, 256);
+    hipLaunchKernelGGL(k_lroot_merge, lgrid, 256, 0, st, d.lroots, d.lsize, d.lbox, d.ntile, n_slots, w.counters, w.parent, w.csize, ymax_g,
                        xmin_g, xmax_g, W);
-    hipLaunchKernelGGL(k_root_classify, lgrid, 256, 0, st, d.lroots, w.counters, w.parent, w.csize, min_size, max_size, d.kept,
+    hipLaunchKernelGGL(k_root_classify, cdiv(n_slots, 1024), 1024, 0, st, d.lroots, d.ntile, n_slots, w.counters, w.parent, w.csize, min_size, max_size, d.kept,
                        w.list);
-    hipLaunchKernelGGL(k_kept_rank, 1, KR_THREADS, 0, st, d.kept, w.counters, (long)n, start_label, d.sorted, w.newlabel);
-    hipLaunchKernelGGL(k_small_bfs_reg, 2048, 256, 0, st, w.list, w.counters, w.parent, ymax_g, xmin_g, xmax_g, H, W, w.adjptr,
-                       d.fb_list, d.fb_bbox);
+    hipLaunchKernelGGL(k_small_bfs_reg, 2048 + 1, 256, 0, st, w.list, w.counters, w.parent, ymax_g, xmin_g, xmax_g, H, W, w.adjptr,
+                       d.fb_list, d.fb_bbox, d.kept, start_label, d.sorted, w.newlabel);
     // components the register-frontier kernel handed over (frontier of more than 64 cells, large bounding box);
     // what this one cannot take either ends up in CNT_FALLBACK and sends the image to the general path
     hipLaunchKernelGGL((k_small_bfs_wave<8192, 2048, true>), 256, 64, 0, st, d.fb_list, w.counters, w.counters + CNT_FB, w.parent,
                        d.fb_bbox, 1, H, W, (const int32_t *)nullptr, CONN_FB_CAP, w.adjptr, d.fb_reject);
-    hipLaunchKernelGGL(k_small_resolve, 64, 64, 0, st, w.list, w.counters, w.csize, w.adjptr, min_size, w.newlabel);
-    hipLaunchKernelGGL(k_lroot_labels, lgrid, 256, 0, st, d.lroots, w.counters, w.parent, w.newlabel);
+    hipLaunchKernelGGL(k_lroot_labels, lgrid, 256, 0, st, d.lroots, d.ntile, n_slots, w.counters, w.parent, w.csize, w.adjptr, min_size, w.newlabel);
     hipLaunchKernelGGL(k_write_labels, cdiv(n, 256), 256, 0, st, w.parent, w.newlabel, n, labels_out,
                        (const int32_t *)(w.counters + CNT_FLAG));
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(host_counters, w.counters, 16 * sizeof(int32_t), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
     *ok = host_counters[CNT_FLAG] == 0 && host_counters[CNT_OVER] == 0 && host_counters[CNT_FALLBACK] == 0 &&
-          host_counters[CNT_LROOT] <= CONN_LROOT_CAP && host_counters[CNT_KEPT] <= CONN_KEPT_CAP &&
+          host_counters[CNT_KEPT] <= CONN_KEPT_CAP &&
           host_counters[CNT_FB] <= CONN_FB_CAP;
     *n_kept = host_counters[CNT_KEPT];
     return 0;
