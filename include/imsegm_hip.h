@@ -89,6 +89,13 @@ IMSEGM_API int imsegm_image2d_get_labels(imsegm_image2d *img, int64_t *labels_ou
 /* install an arbitrary label map (int32, values in [0, n_labels)) -- stage-level entry for the
  * descriptor / graph functions that take a user segmentation */
 IMSEGM_API int imsegm_image2d_set_labels(imsegm_image2d *img, const int32_t *labels, int n_labels);
+/* Replaces skimage.segmentation._slic._enforce_label_connectivity_cython(segments, min_size, max_size, start_label)
+ * (scikit-image 0.18; the connectivity pass of skimage.segmentation.slic, reached from imsegm/superpixels.py:61-63 and
+ * :104-106 with enforce_connectivity=True) on a label map given by the caller: labels = host int32, one value per
+ * pixel (voxel) of the session, raster order, all values >= start_label (skimage's mask label start_label - 1 does not
+ * occur in the reference's calls and is not interpreted).  The result becomes the session's label map (imsegm_image2d_get_labels). */
+IMSEGM_API int imsegm_image2d_enforce_connectivity(imsegm_image2d *img, const int32_t *labels, long min_size, long max_size,
+                                                   int start_label, int *n_labels_out);
 /* Replaces the per-pixel Python loop of imsegm/labeling.py:208-247 histogram_regions_labels_counts(slic, segm)
  * (called through histogram_regions_labels_norm at imsegm/pipelines.py:284 to label superpixels from an
  * annotation): hist_out[k * nb_annot + a] = number of pixels with resident label k and annotation a.

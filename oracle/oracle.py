@@ -230,6 +230,17 @@ def segment_slic_img2d(img, sp_size=50, relative_compact=0.1, start_label=0, ret
                 return_internals=return_internals, slic_zero=slico)
 
 
+def enforce_connectivity(labels, min_size, max_size, start_label=0):
+    """``_enforce_label_connectivity_cython`` (scikit-image 0.18 ``_slic.pyx``) on a 2-D or 3-D int label map"""
+    L = lib()
+    lab = np.ascontiguousarray(labels, dtype=np.int32)
+    shape3 = (1, ) + lab.shape if lab.ndim == 2 else lab.shape
+    out = np.empty_like(lab)
+    L.orc_enforce_connectivity(_p(lab), C.c_int(shape3[0]), C.c_int(shape3[1]), C.c_int(shape3[2]), C.c_long(int(min_size)),
+                               C.c_long(int(max_size)), C.c_int(start_label), _p(out))
+    return out.astype(np.int64)
+
+
 def label_cc(labels):
     """skimage.measure.label(labels) restated (background 0, full connectivity, raster-order numbering)"""
     lab = np.ascontiguousarray(labels, dtype=np.int32)

@@ -91,6 +91,7 @@ _SIGNATURES = {
                                       C.c_int, C.c_int, C.c_double, C.c_double, C.c_int, C.c_int, C.c_int, _ip]),
     'imsegm_image2d_get_labels': (C.c_int, [_vp, _vp]),
     'imsegm_image2d_set_labels': (C.c_int, [_vp, _vp, C.c_int]),
+    'imsegm_image2d_enforce_connectivity': (C.c_int, [_vp, _vp, C.c_long, C.c_long, C.c_int, _vp]),
     'imsegm_image2d_label_hist': (C.c_int, [_vp, _vp, C.c_int, _vp]),
     'imsegm_image2d_get_lab': (C.c_int, [_vp, _vp]),
     'imsegm_image2d_get_nearest': (C.c_int, [_vp, _vp]),
@@ -530,6 +531,17 @@ class Image2D(object):
         out = np.empty(self.shape, dtype=np.int64)
         _check(load_library().imsegm_image2d_get_labels(self._h, _ptr(out)))
         return out
+
+    def enforce_connectivity(self, labels, min_size, max_size, start_label=0):
+        """``_enforce_label_connectivity_cython`` of scikit-image 0.18 on a given label map; returns the int64 map"""
+        labels = np.ascontiguousarray(labels, dtype=np.int32)
+        if labels.shape != self.shape:
+            raise ValueError('label map %r does not match image %r' % (labels.shape, self.shape))
+        n_out = C.c_int(0)
+        _check(load_library().imsegm_image2d_enforce_connectivity(self._h, _ptr(labels), int(min_size), int(max_size),
+                                                                  int(start_label), C.byref(n_out)))
+        self.n_labels = n_out.value
+        return self.get_labels()
 
     def set_labels(self, labels, n_labels=None):
         labels = np.ascontiguousarray(labels, dtype=np.int32)

@@ -647,6 +647,37 @@ int imsegm_image2d_set_labels(imsegm_image2d *im, const int32_t *labels, int n_l
     return 0;
 }
 
+// skimage.segmentation._slic._enforce_label_connectivity_cython(segments, min_size, max_size, start_label) -- the second
+// native call inside skimage.segmentation.slic (superpixels.py:61-63, enforce_connectivity=True) -- on a label map
+// given by the caller; the result becomes the session's label map.  2-D image sessions and volume sessions.
+int imsegm_image2d_enforce_connectivity(imsegm_image2d *im, const int32_t *labels, long min_size, long max_size, int start_label,
+                                        int *n_labels_out)
+{
+    if (!im || bind(im->ctx)) return -1;
+    if (!labels || min_size < 0 || max_size < 1) {
+        set_error("enforce_connectivity: label map, min_size >= 0 and max_size >= 1 are required");
+        return -1;
+    }
+    if (start_label != 0 && start_label != 1) {
+        set_error("start_label should be 0 or 1.");
+        return -1;
+    }
+    hipStream_t st = im->ctx->stream;
+    const size_t n = im->n;
+    if (im->nearest.ensure(n * 4) || im->labels.ensure(n * 4)) return -1;
+    if (im->conn_i32.ensure(conn_i32_bytes(n, im->D == 1 ? im->H : 0, im->D == 1 ? im->W : 0)) || im->conn_u8.ensure(2 * n + 64)) return -1;
+    HIP_TRY(hipMemcpyAsync(im->nearest.p, labels, n * 4, hipMemcpyHostToDevice, st));
+    ConnWork w = make_conn_work(im);
+    int n_labels = 0;
+    if (launch_enforce_connectivity(im->nearest.as<int32_t>(), im->D, im->H, im->W, min_size, max_size, start_label, w,
+                                    im->labels.as<int32_t>(), &n_labels, st))
+        return -1;
+    im->n_labels = n_labels;
+    im->have_labels = true;
+    if (n_labels_out) *n_labels_out = n_labels;
+    return 0;
+}
+
 // labeling.py:208-247 histogram_regions_labels_counts(slic, segm) on the resident label map (any session kind)
 int imsegm_image2d_label_hist(imsegm_image2d *im, const int32_t *annot, int nb_annot, int64_t *hist_out)
 {
