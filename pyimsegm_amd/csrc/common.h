@@ -321,6 +321,29 @@ __device__ __forceinline__ double row16_reduce8_f64(const double (&v)[8], int la
     return c;
 }
 
+// the same for eight ints per lane (lane pair j of the row holds the row total of value j; j as in row16_reduce8_f64)
+__device__ __forceinline__ int row16_reduce8_i32(const int (&v)[8], int lane)
+{
+    int a[4], b[2];
+    bool up = lane & 8;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int send = up ? v[j] : v[j + 4], keep = up ? v[j + 4] : v[j];
+        a[j] = keep + __builtin_amdgcn_update_dpp(0, send, 0x140, 0xf, 0xf, false);
+    }
+    up = lane & 4;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int send = up ? a[j] : a[j + 2], keep = up ? a[j + 2] : a[j];
+        b[j] = keep + __builtin_amdgcn_update_dpp(0, send, 0x141, 0xf, 0xf, false);
+    }
+    up = lane & 2;
+    const int send = up ? b[0] : b[1], keep = up ? b[1] : b[0];
+    int c = keep + __builtin_amdgcn_update_dpp(0, send, 0x1b, 0xf, 0xf, false);
+    c += __builtin_amdgcn_update_dpp(0, c, 0xb1, 0xf, 0xf, false);
+    return c;
+}
+
 // sixteen doubles per lane -> every lane of the 16-lane row ends up with the row total of value (lane & 15)
 __device__ __forceinline__ double row16_reduce16_f64(const double (&v)[16], int lane)
 {

@@ -14,62 +14,92 @@
 
 namespace imsegm {
 
-constexpr int GR_PX = 4;
+constexpr int GR_ROWS = 4;        // rows per wave (one pixel column per lane); a workgroup covers 64 x 16 pixels
+constexpr int GR_SLOTS = 64;      // LDS hash slots for the centre sums of a workgroup
 
+// Edges: a pixel is compared with its right neighbour (the next lane; the pixel right of the wave for lane 63) and the
+// one below (the next row of the same lane; one halo row per wave).  Centre sums: the horizontal runs of equal labels of a
+// 64-pixel row come out of one ballot; the first lane of a run knows its length, hence n, sum x and sum y of the run in
+// closed form, and adds them to the workgroup's LDS hash table (label -> n, sum y, sum x; 32-bit LDS atomics), which is
+// flushed with one set of int64 global atomics per label and workgroup.  No wave reductions, no per-label passes.  A
+// label that finds no slot (more than GR_SLOTS labels in a 64 x 16 tile) goes to the global sums directly.
 __global__ void __launch_bounds__(256)
 k_adjacency_centres(const int32_t *__restrict__ labels, int H, int W, int K, int words, uint32_t *bitmap,
                     long long *__restrict__ cacc)
 {
+    __shared__ int h_key[GR_SLOTS], h_n[GR_SLOTS], h_sy[GR_SLOTS], h_sx[GR_SLOTS];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int y = blockIdx.y * 4 + wave;
-    const int x0 = (blockIdx.x * 64 + lane) * GR_PX;
-    int lab[GR_PX];
-#pragma unroll
-    for (int i = 0; i < GR_PX; ++i) {
-        int x = x0 + i;
-        bool ok = y < H && x < W;
-        lab[i] = ok ? labels[(size_t)y * W + x] : -1;
+    if (threadIdx.x < GR_SLOTS) {
+        h_key[threadIdx.x] = -1;
+        h_n[threadIdx.x] = 0;
+        h_sy[threadIdx.x] = 0;
+        h_sx[threadIdx.x] = 0;
     }
+    __syncthreads();
+    const int x = blockIdx.x * 64 + lane;
+    const int y0 = (blockIdx.y * 4 + wave) * GR_ROWS;
+    const bool xin = x < W;
+    int lab[GR_ROWS + 1], right[GR_ROWS];
 #pragma unroll
-    for (int i = 0; i < GR_PX; ++i) {
-        int x = x0 + i;
-        if (lab[i] < 0) continue;
-        int nb[2];
-        nb[0] = (x + 1 < W) ? ((i + 1 < GR_PX) ? lab[i + 1] : labels[(size_t)y * W + x + 1]) : lab[i];
-        nb[1] = (y + 1 < H) ? labels[(size_t)(y + 1) * W + x] : lab[i];
+    for (int r = 0; r <= GR_ROWS; ++r) lab[r] = (xin && y0 + r < H) ? labels[(size_t)(y0 + r) * W + x] : -1;
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            if (nb[j] == lab[i]) continue;
-            int a = min(lab[i], nb[j]), b = max(lab[i], nb[j]);
-            uint32_t *wp = bitmap + (size_t)b * words + (a >> 5);
-            uint32_t bit = 1u << (a & 31);
-            if (!(*wp & bit)) atomicOr(wp, bit);
-        }
+    for (int r = 0; r < GR_ROWS; ++r) {
+        right[r] = __shfl_down(lab[r], 1, 64);
+        if (lane == 63) right[r] = (x + 1 < W && y0 + r < H) ? labels[(size_t)(y0 + r) * W + x + 1] : -1;
     }
-    // centre sums: one wave pass per distinct label
-    while (true) {
-        int first = -1;
+    const unsigned long long le = (lane == 63) ? ~0ULL : ((2ULL << lane) - 1ULL);
 #pragma unroll
-        for (int i = GR_PX - 1; i >= 0; --i)
-            if (lab[i] >= 0) first = lab[i];
-        unsigned long long vote = __ballot(first >= 0);
-        if (!vote) break;
-        int k = __shfl(first, __ffsll((long long)vote) - 1, 64);
-        int n = 0, sx = 0;
+    for (int r = 0; r < GR_ROWS; ++r) {
+        const int y = y0 + r;
+        const int l = lab[r];
+        const int left = __shfl_up(l, 1, 64);
+        const bool act = l >= 0;
+        // (wave-uniform from here on only through the ballots)
+        if (act) {
+            const int nb[2] = { right[r], lab[r + 1] };       // -1: no neighbour on that side
 #pragma unroll
-        for (int i = 0; i < GR_PX; ++i)
-            if (lab[i] == k) {
-                n += 1;
-                sx += x0 + i;
-                lab[i] = -1;
+            for (int j = 0; j < 2; ++j) {
+                if (nb[j] < 0 || nb[j] == l) continue;
+                const int a = min(l, nb[j]), b = max(l, nb[j]);
+                uint32_t *wp = bitmap + (size_t)b * words + (a >> 5);
+                const uint32_t bit = 1u << (a & 31);
+                if (!(*wp & bit)) atomicOr(wp, bit);
             }
-        n = wave_sum_i32(n);
-        long long sxl = wave_sum_i64((long long)sx);
-        if (lane == 0) {
-            atomic_add_i64(cacc + (size_t)k * 3 + 0, n);
-            atomic_add_i64(cacc + (size_t)k * 3 + 1, (long long)n * y);
-            atomic_add_i64(cacc + (size_t)k * 3 + 2, sxl);
         }
+        const bool start = act && (lane == 0 || left != l);
+        const unsigned long long starts = __ballot(start);
+        const int nact = __popcll(__ballot(act));
+        if (start) {
+            const unsigned long long above = starts & ~le;
+            const int len = (above ? __ffsll((long long)above) - 1 : nact) - lane;
+            const int n = len, sy = len * y, sx = len * x + (len * (len - 1)) / 2;
+            int slot = (int)(((unsigned int)l * 2654435761u) >> 26);          // 6 bits
+            bool placed = false;
+            for (int probe = 0; probe < GR_SLOTS; ++probe) {
+                const int old = atomicCAS(&h_key[slot], -1, l);
+                if (old == -1 || old == l) {
+                    placed = true;
+                    break;
+                }
+                slot = (slot + 1) & (GR_SLOTS - 1);
+            }
+            if (placed) {
+                atomicAdd(&h_n[slot], n);
+                atomicAdd(&h_sy[slot], sy);
+                atomicAdd(&h_sx[slot], sx);
+            } else {
+                atomic_add_i64(cacc + (size_t)l * 3 + 0, n);
+                atomic_add_i64(cacc + (size_t)l * 3 + 1, (long long)sy);
+                atomic_add_i64(cacc + (size_t)l * 3 + 2, (long long)sx);
+            }
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < GR_SLOTS && h_key[threadIdx.x] >= 0) {
+        const int k = h_key[threadIdx.x];
+        atomic_add_i64(cacc + (size_t)k * 3 + 0, h_n[threadIdx.x]);
+        atomic_add_i64(cacc + (size_t)k * 3 + 1, h_sy[threadIdx.x]);
+        atomic_add_i64(cacc + (size_t)k * 3 + 2, h_sx[threadIdx.x]);
     }
 }
 
@@ -148,7 +178,7 @@ int launch_adjacency_bitmap(const int32_t *labels, int H, int W, int K, uint32_t
     int words = cdiv(K, 32);
     HIP_TRY(hipMemsetAsync(bitmap, 0, (size_t)K * words * sizeof(uint32_t), st));
     HIP_TRY(hipMemsetAsync(cacc, 0, (size_t)K * 3 * sizeof(long long), st));
-    dim3 grid(cdiv(W, 64 * GR_PX), cdiv(H, 4));
+    dim3 grid(cdiv(W, 64), cdiv(H, 4 * GR_ROWS));
     hipLaunchKernelGGL(k_adjacency_centres, grid, 256, 0, st, labels, H, W, K, words, bitmap, cacc);
     hipLaunchKernelGGL(k_centres_finalize, cdiv(K, 256), 256, 0, st, cacc, K, centres_out, present_out);
     HIP_TRY(hipGetLastError());

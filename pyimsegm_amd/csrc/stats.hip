@@ -15,7 +15,8 @@
 
 namespace imsegm {
 
-constexpr int ST_ROWS = 4;        // rows per lane: a wave covers 64 x 4 pixels, a workgroup 64 x 16
+constexpr int ST_ROWS = 16;       // rows per lane: a wave covers 64 x 16 pixels, a workgroup 64 x 64 (a 16-lane row sums 256 pixels:
+                                  // the exactness bound pow2_scale is built for)
 constexpr int ST_SLOTS = 64;      // LDS hash slots (distinct labels per workgroup tile)
 
 // fixed point with a caller-chosen scale: v * 2^sh = hi + lo * 2^-32
@@ -35,18 +36,19 @@ struct StatParams {
     double scale_v, scale_e;      // 2^shift for the value / squared-value sums
     int planar;                   // 0: H x W x 3 interleaved, 1: three planes `plane_stride` elements apart
     size_t plane_stride;          //    (0: one gray plane read three times)
+    int u8_int;                   // uint8 image, power-of-two scales >= 1: integer block sums in the first pass
     int prescale;                 // 1: value = (raw * mul) / div before the float32 staging
     double mul, div;              //    (descriptors.py:1094 `(response * (log(1 + norm) / 0.03)) / norm`)
 };
 
 // PASS 1 -> n + 3 x (v, v*v); PASS 2 -> 3 x (v - m)^2.
-// One pixel column per lane and ST_ROWS rows; every 16-lane row of the wave (a 16 x 4 pixel block, 1.5
-// distinct labels on average) works on the smallest label still pending in it, so a wave needs about two
-// passes.  Per pass the partial sums of a lane (fixed-point limbs kept as integer-valued doubles, exact:
-// |limb| * 64 pixels < 2^53 by the choice of the scales) go through one transposed DPP reduction over the
+// One pixel column per lane and ST_ROWS rows; every 16-lane row of the wave (a 16 x 16 pixel block, two to
+// three distinct labels) works on the smallest label still pending in it, so a wave needs two or three
+// passes for four times the pixels of the former 16 x 4 blocks.  Per pass the partial sums of a lane (fixed-point limbs kept as integer-valued doubles, exact:
+// |limb| * 256 pixels < 2^53 by the choice of the scales) go through one transposed DPP reduction over the
 // 16 lanes, after which lane j of the row owns the total of quantity j and adds it to the workgroup's LDS
 // slot of the label (open addressing; a full table falls back to global atomics).
-template <typename T, int PASS>
+template <typename T, int PASS, bool U8INT>
 __global__ void __launch_bounds__(256)
 k_color_stats(const T *__restrict__ img, const int32_t *__restrict__ labels, StatParams sp,
               const float *__restrict__ mean32, long long *__restrict__ acc)
@@ -62,6 +64,10 @@ k_color_stats(const T *__restrict__ img, const int32_t *__restrict__ labels, Sta
     __syncthreads();
     const int x = blockIdx.x * 64 + lane;
     const int y0 = (blockIdx.y * 4 + wave) * ST_ROWS;
+    // uint8 image, first pass: the terms are small integers (v <= 255, v * v <= 65025 -- the float32 product of the
+    // reference is exact), so the block sums are plain int32 sums and the fixed-point limbs are (sum * 2^shift, 0):
+    // the same accumulator contents as the general path at a fraction of the instructions
+    static_assert(!U8INT || (PASS == 1 && sizeof(T) == 1), "integer block sums: uint8 image, first pass");
     int lab[ST_ROWS];
     float v[ST_ROWS][3];
 #pragma unroll
@@ -82,6 +88,44 @@ k_color_stats(const T *__restrict__ img, const int32_t *__restrict__ labels, Sta
         for (int r = 0; r < ST_ROWS; ++r) mine = min(mine, lab[r]);
         if (!__any(mine != 0x7fffffff)) break;
         const int k = row16_min_i32(mine);              // uniform over the 16-lane row; 0x7fffffff: row is done
+        if (U8INT) {
+            int qi[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };     // n, sums of v (3), sums of v * v (3)
+#pragma unroll
+            for (int r = 0; r < ST_ROWS; ++r) {
+                if (lab[r] != k || k == 0x7fffffff) continue;
+                lab[r] = 0x7fffffff;
+                qi[0] += 1;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    const int val = (int)v[r][c];
+                    qi[1 + c] += val;
+                    qi[4 + c] += val * val;
+                }
+            }
+            const int toti = row16_reduce8_i32(qi, lane);
+            const int j = ((lane >> 3) & 1) * 4 + ((lane >> 2) & 1) * 2 + ((lane >> 1) & 1);
+            int slot = -1;
+            if ((lane & 15) == 0 && k != 0x7fffffff) {
+                int sidx = k & (ST_SLOTS - 1), probes = 0;
+                while (probes < ST_SLOTS) {
+                    int old = atomicCAS(&keys[sidx], -1, k);
+                    if (old == -1 || old == k) break;
+                    sidx = (sidx + 1) & (ST_SLOTS - 1);
+                    ++probes;
+                }
+                slot = probes < ST_SLOTS ? sidx : -1;
+            }
+            slot = __shfl(slot, lane & 48, 64);
+            if ((lane & 1) == 0 && j < 7 && toti != 0 && k != 0x7fffffff) {
+                // accumulator columns: [0] count, [1 + 2c] high limb of the value sums, [7 + 2c] of the squared sums
+                const int col = j == 0 ? 0 : (j < 4 ? 1 + 2 * (j - 1) : 7 + 2 * (j - 4));
+                const long long tot = j == 0 ? (long long)toti
+                                             : (long long)toti * (long long)(j < 4 ? sp.scale_v : sp.scale_e);
+                if (slot >= 0) atomic_add_i64(&lacc[slot][col], tot);
+                else atomic_add_i64(acc + (size_t)k * 13 + col, tot);
+            }
+            continue;
+        }
         // partial sums of this lane: PASS 1 -> q[0..5] sums of v, q[6..11] sums of v*v, q[12] count
         //                            PASS 2 -> q[0..5] sums of (v - mean32)^2
         constexpr int NV = (PASS == 1) ? 16 : 8;
@@ -200,10 +244,12 @@ static void launch_pass(int pass, const T *img, const int32_t *labels, StatParam
                         long long *acc, hipStream_t st)
 {
     dim3 grid(cdiv(sp.W, 64), cdiv(sp.H, 4 * ST_ROWS));
-    if (pass == 1)
-        hipLaunchKernelGGL((k_color_stats<T, 1>), grid, 256, 0, st, img, labels, sp, mean32, acc);
+    if (pass == 1 && sizeof(T) == 1 && sp.u8_int)
+        hipLaunchKernelGGL((k_color_stats<T, 1, sizeof(T) == 1>), grid, 256, 0, st, img, labels, sp, mean32, acc);
+    else if (pass == 1)
+        hipLaunchKernelGGL((k_color_stats<T, 1, false>), grid, 256, 0, st, img, labels, sp, mean32, acc);
     else
-        hipLaunchKernelGGL((k_color_stats<T, 2>), grid, 256, 0, st, img, labels, sp, mean32, acc);
+        hipLaunchKernelGGL((k_color_stats<T, 2, false>), grid, 256, 0, st, img, labels, sp, mean32, acc);
 }
 
 static double pow2_scale(double n_pixels, double maxabs)
@@ -230,6 +276,7 @@ int launch_color_stats(const void *img, int dtype, const int32_t *labels, int H,
     sp.plane_stride = plane_stride >= 0 ? (size_t)plane_stride : (size_t)H * W;
     sp.scale_v = pow2_scale((double)H * W, maxabs);
     sp.scale_e = pow2_scale((double)H * W, 4.0 * maxabs * maxabs);
+    sp.u8_int = (dtype == DT_U8 && !prescale && sp.scale_v >= 1.0 && sp.scale_e >= 1.0) ? 1 : 0;
     hipLaunchKernelGGL(k_stats_clear, cdiv(K, 256), 256, 0, st, acc, K, 0, 13);
     if (dtype == DT_U8) launch_pass<uint8_t>(1, (const uint8_t *)img, labels, sp, mean32_scratch, acc, st);
     else if (dtype == DT_F32) launch_pass<float>(1, (const float *)img, labels, sp, mean32_scratch, acc, st);
