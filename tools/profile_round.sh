@@ -41,7 +41,7 @@ for c in ('FETCH_SIZE', 'WRITE_SIZE', 'SQ'):
         res.setdefault(k, {}).update({n: sum(v) / len(v) for n, v in acc[k].items()})
     lines.append('')
 open(os.path.join(out, 'pmc_counters.txt'), 'w').write('\n'.join(lines))
-name = [k for k in res if 'k_slic_assign_dot<true, false>' in k]
+name = [k for k in res if 'k_slic_assign_dot<true, false' in k]
 if name and 'FETCH_SIZE' in res[name[0]] and 'WRITE_SIZE' in res[name[0]]:
     f, w = res[name[0]]['FETCH_SIZE'], res[name[0]]['WRITE_SIZE']
     json.dump({'kernel': 'k_slic_assign_dot<true, false>', 'workload': 'bench.py default (2048x2048 RGB, K=2025)',
