@@ -828,6 +828,16 @@ __device__ __forceinline__ void accumulate_block_sums(int lane, int x, int wy0, 
 {
     constexpr int NONE = 0x7fffffff;
     const int col = lane & 15;
+    // the fixed-point terms of the four pixels of this lane (exact integers as doubles) and their geometry words
+    double tL[4], tA[4], tB[4];
+    int gw[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        tL[r] = trunc(pL[r] * fscale);
+        tA[r] = trunc(pA[r] * fscale);
+        tB[r] = trunc(pB[r] * fscale);
+        gw[r] = 1 + (r << 8) + (col << 17);
+    }
     while (__any(pending != 0)) {
         int m = NONE;
 #pragma unroll
@@ -839,21 +849,20 @@ __device__ __forceinline__ void accumulate_block_sums(int lane, int x, int wy0, 
         for (int r = 0; r < 4; ++r)
             if ((pending & (1u << r)) && best_s[r] != sa) m = min(m, best_s[r]);
         const int sb = row16_min_i32(m);                    // second smallest (NONE: the block has one label)
+        // branch free: a row contributes t * 1.0 or t * 0.0 through an fma (exact either way), so the compiler has
+        // nothing to turn into copies of the eight accumulators
         double q[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
         int ga = 0, gb = 0;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            if (!(pending & (1u << r))) continue;
-            const int sl = best_s[r];
-            if (sl == sa) {
-                q[0] += trunc(pL[r] * fscale); q[1] += trunc(pA[r] * fscale); q[2] += trunc(pB[r] * fscale);
-                ga += 1 + (r << 8) + (col << 17);
-                pending &= ~(1u << r);
-            } else if (sl == sb) {
-                q[4] += trunc(pL[r] * fscale); q[5] += trunc(pA[r] * fscale); q[6] += trunc(pB[r] * fscale);
-                gb += 1 + (r << 8) + (col << 17);
-                pending &= ~(1u << r);
-            }
+            const bool pend = (pending >> r) & 1u;
+            const bool ia = pend && best_s[r] == sa, ib = pend && best_s[r] == sb;
+            const double ma = ia ? 1.0 : 0.0, mb = ib ? 1.0 : 0.0;
+            q[0] = fma(tL[r], ma, q[0]); q[1] = fma(tA[r], ma, q[1]); q[2] = fma(tB[r], ma, q[2]);
+            q[4] = fma(tL[r], mb, q[4]); q[5] = fma(tA[r], mb, q[5]); q[6] = fma(tB[r], mb, q[6]);
+            ga += ia ? gw[r] : 0;
+            gb += ib ? gw[r] : 0;
+            pending &= ~((unsigned)(ia || ib) << r);
         }
         q[3] = (double)ga;
         q[7] = (double)gb;
@@ -1115,14 +1124,14 @@ typedef float f2 __attribute__((ext_vector_type(2)));
 
 // (profiling aid) cycles between successive marks of every wave, summed per phase
 #define PHASE_MARK(j)                                                                              \
-    if (s.phase_prof) {                                                                            \
+    if (PROF && s.phase_prof) {                                                                            \
         __builtin_amdgcn_s_waitcnt(0);                                                             \
         const long long now_ = (long long)__builtin_readcyclecounter();                            \
         if (tid == 0) prof_slot[j] += now_ - t_prev;                                               \
         t_prev = now_;                                                                             \
     }
 #define PHASE_FLUSH()                                                                              \
-    if (s.phase_prof && tid == 0) {                                                                \
+    if (PROF && s.phase_prof && tid == 0) {                                                                \
         prof_slot[15] += 1;                                                                        \
         prof_slot[11] = (long long)wall_clock64();                                                 \
     }
@@ -1138,7 +1147,9 @@ typedef float f2 __attribute__((ext_vector_type(2)));
 #ifndef SLIC_DOT_MIN_BLOCKS_TILE
 #define SLIC_DOT_MIN_BLOCKS_TILE 4
 #endif
-template <bool ACCUM, bool FIRST, int U>
+// PROF: the instantiation with the in-kernel phase timers (IMSEGM_PHASE_PROF); the production kernels carry none of it
+// (the marks end basic blocks and wait for all memory operations, which also keeps the compiler from overlapping phases)
+template <bool ACCUM, bool FIRST, int U, bool PROF>
 __global__ void __launch_bounds__(256, U == 1 ? SLIC_DOT_MIN_BLOCKS : SLIC_DOT_MIN_BLOCKS_TILE)
 k_slic_assign_dot(SlicState s, const double *__restrict__ lab, int32_t *__restrict__ labels,
                   const Cand *__restrict__ tile_cands, const Rec32 *__restrict__ tile_rec,
@@ -1146,9 +1157,9 @@ k_slic_assign_dot(SlicState s, const double *__restrict__ lab, int32_t *__restri
 {
     __shared__ long long lacc[MAXC][9];
     __shared__ int lk[MAXC];
-    long long t_prev = s.phase_prof ? (long long)__builtin_readcyclecounter() : 0;
+    long long t_prev = (PROF && s.phase_prof) ? (long long)__builtin_readcyclecounter() : 0;
     long long *prof_slot = s.phase_prof + ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 2 + (ACCUM ? 1 : 0)) * 16;
-    if (s.phase_prof && threadIdx.x == 0) {
+    if (PROF && s.phase_prof && threadIdx.x == 0) {
         prof_slot[10] = (long long)wall_clock64();                     // start, 100 MHz (overwritten by every launch)
         prof_slot[12] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));    // HW_ID
         prof_slot[13] = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11));   // XCC_ID
@@ -1351,7 +1362,7 @@ k_slic_assign_dot(SlicState s, const double *__restrict__ lab, int32_t *__restri
         }
 #undef RL_F
         PHASE_MARK(2)                              // candidate loop
-        if (s.phase_prof && tid == 0) prof_slot[9] += c_end;
+        if (PROF && s.phase_prof && tid == 0) prof_slot[9] += c_end;
         // near ties (second best inside the margin for some pixel of the row): exact fp64 evaluation, in the
         // order of _slic.pyx, of the candidates whose fp32 value lies within the margin of the fp32 best --
         // the exact winner is always one of them (its d32 exceeds b1 by at most half the margin).
@@ -1473,9 +1484,9 @@ int launch_slic_iterations(SlicState s, const double *lab, const double *init_yx
     }
     if (getenv("IMSEGM_PRINT_OCC")) {
         int nb = 0;
-        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void *)k_slic_assign_dot<true, false, 2>, 256, 0));
+        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void *)k_slic_assign_dot<true, false, 1, false>, 256, 0));
         fprintf(stderr, "[occupancy] k_slic_assign_dot<true>: %d workgroups per CU\n", nb);
-        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void *)k_slic_assign_dot<false, false, 2>, 256, 0));
+        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void *)k_slic_assign_dot<false, false, 1, false>, 256, 0));
         fprintf(stderr, "[occupancy] k_slic_assign_dot<false>: %d workgroups per CU\n", nb);
     }
     for (int it = 0; it < max_iter; ++it) {
@@ -1497,10 +1508,13 @@ int launch_slic_iterations(SlicState s, const double *lab, const double *init_yx
 #define LAUNCH_DOT(ACC, FST)                                                                                         \
     {                                                                                                                \
         if (units == 2)                                                                                              \
-            hipExtLaunchKernelGGL((k_slic_assign_dot<ACC, FST, 2>), grid_tile, dim3(256), 0, st, ev_a, ev_b, 0, s, lab,   \
+            hipExtLaunchKernelGGL((k_slic_assign_dot<ACC, FST, 2, false>), grid_tile, dim3(256), 0, st, ev_a, ev_b, 0, s, lab,   \
+                                  labels, s.tile_cands, s.tile_rec, s.tile_info, s.tile_k);                          \
+        else if (s.phase_prof)                                                                                       \
+            hipExtLaunchKernelGGL((k_slic_assign_dot<ACC, FST, 1, true>), grid, dim3(256), 0, st, ev_a, ev_b, 0, s, lab,   \
                                   labels, s.tile_cands, s.tile_rec, s.tile_info, s.tile_k);                          \
         else                                                                                                         \
-            hipExtLaunchKernelGGL((k_slic_assign_dot<ACC, FST, 1>), grid, dim3(256), 0, st, ev_a, ev_b, 0, s, lab,   \
+            hipExtLaunchKernelGGL((k_slic_assign_dot<ACC, FST, 1, false>), grid, dim3(256), 0, st, ev_a, ev_b, 0, s, lab,   \
                                   labels, s.tile_cands, s.tile_rec, s.tile_info, s.tile_k);                          \
     }
         if (first_grid) {
