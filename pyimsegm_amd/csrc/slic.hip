@@ -1256,7 +1256,13 @@ k_slic_assign_dot(SlicState s, const double *__restrict__ lab, int32_t *__restri
                 }
         }
     } else if (nc > 0) {
-        constexpr int PH1 = 4, PH2 = 8;
+#ifndef SLIC_PH1
+#define SLIC_PH1 4
+#endif
+#ifndef SLIC_PH2
+#define SLIC_PH2 8
+#endif
+        constexpr int PH1 = SLIC_PH1, PH2 = SLIC_PH2;
         const float INF = __builtin_inff();
         const float sw32 = (float)sw;
         const double ref0 = ti->ref[0], ref1 = ti->ref[1], ref2 = ti->ref[2];
