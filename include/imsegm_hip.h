@@ -75,7 +75,7 @@ IMSEGM_API int imsegm_image2d_upload(imsegm_image2d *img, const void *host_pixel
  * as called at imsegm/superpixels.py:61-63, with the min-max scaling of superpixels.py:53-54 folded
  * in (minmax_normalize: 1 = always, 0 = never, 2 = as the reference: unless min == 0 and max == 1).
  * taps_*: half kernels (taps[0] = centre, radius taps follow) of scipy.ndimage.gaussian_filter1d for
- * sigma / spacing per axis; radius < 0 disables the axis.  max_candidates: 0 = default (debug knob
+ * sigma / spacing per axis; radius < 0 disables the axis, radius > 16 (sigma / spacing > 4) is refused.  max_candidates: 0 = default (debug knob
  * that forces the kernel's global-memory fallback when small).  slic_zero: skimage's slic_zero=True
  * (SLICO, superpixels.py:63 `slic_zero=slico`).  Labels stay on the device. */
 IMSEGM_API int imsegm_image2d_slic(imsegm_image2d *img, int minmax_normalize, int n_segments, double compactness,
@@ -273,7 +273,8 @@ IMSEGM_API int imsegm_ray_features_binary2d(imsegm_ctx *ctx, const int8_t *seg_b
 /* Replaces gco.cut_general_graph(edges, edge_weights, unary_cost, pairwise_cost, n_iter,
  * algorithm='expansion') (gco-wrapper >= 3.0.8) as called at imsegm/graph_cuts.py:735-744.
  * edges: E x 2 int32 with edges[:,0] < edges[:,1]; edge_weights: E; unary: K x C; pairwise: C x C
- * symmetric.  Float costs are converted to integer energies exactly as pyGCO does. */
+ * symmetric.  Float costs are converted to integer energies exactly as pyGCO does.
+ * Limits (an error, not a fallback): C <= 64 labels; n_iter < 0 = until convergence. */
 IMSEGM_API int imsegm_cut_general_graph(imsegm_ctx *ctx, const int32_t *edges, int n_edges, const double *edge_weights,
                              const double *unary_cost, int n_sites, int n_labels, const double *pairwise_cost,
                              int n_iter, int32_t *labels_out, int64_t *energy_out);

@@ -20,6 +20,7 @@ bool hip_ok(hipError_t e, const char *what, const char *file, int line);
         if (!::imsegm::hip_ok((expr), #expr, __FILE__, __LINE__)) return -1;            \
     } while (0)
 
+constexpr int IMSEGM_MAX_DEVICES = 64;      // size of the per-device caches of function attributes
 __host__ __device__ static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
 // ---------------------------------------------------------------------------------------------

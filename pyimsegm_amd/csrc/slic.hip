@@ -398,10 +398,13 @@ int launch_preprocess_color2d(const void *img, int dtype, int H, int W, int norm
         const size_t lds = ((size_t)3 * (PF_TY + 2 * ry) + PF_TY) * (PF_TX + 2 * rx) * sizeof(double);
         const void *fn = dtype == DT_U8 ? (const void *)k_pre_fused<uint8_t>
                        : dtype == DT_F32 ? (const void *)k_pre_fused<float> : (const void *)k_pre_fused<double>;
-        static size_t lds_set[3] = { 0, 0, 0 };           // (benign race: the attribute only ever grows)
-        if (lds_set[dtype] < lds) {
+        // the opt-in above 48 KB is per device: remembered per (device, dtype); (benign race: the attribute only ever grows)
+        static size_t lds_set[IMSEGM_MAX_DEVICES][3];
+        int dev = 0;
+        HIP_TRY(hipGetDevice(&dev));
+        if (dev < 0 || dev >= IMSEGM_MAX_DEVICES || lds_set[dev][dtype] < lds) {
             HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            lds_set[dtype] = lds;
+            if (dev >= 0 && dev < IMSEGM_MAX_DEVICES) lds_set[dev][dtype] = lds;
         }
         dim3 gf(cdiv(W, PF_TX), cdiv(H, PF_TY));
         HIP_TRY(hipMemsetAsync(premax_dev, 0, sizeof(double), st));
@@ -1473,11 +1476,15 @@ int launch_slic_iterations(SlicState s, const double *lab, const double *init_yx
     // workgroups of the dot kernel: 1 = half a bin tile (64 x 16), 2 = a whole tile, two units per wave
     const dim3 grid_tile(grid.x, cdiv(s.H, TILE_Y));
     const int units = s.assign_units == 2 ? 2 : 1;
-    static bool bin_attr = false;
-    if (!bin_attr) {
-        HIP_TRY(hipFuncSetAttribute((const void *)k_slic_bin, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    BIN_MAX_K_LDS * (int)sizeof(int4)));
-        bin_attr = true;
+    {
+        static bool bin_attr[IMSEGM_MAX_DEVICES];       // per device, like every function attribute
+        int dev = 0;
+        HIP_TRY(hipGetDevice(&dev));
+        if (dev < 0 || dev >= IMSEGM_MAX_DEVICES || !bin_attr[dev]) {
+            HIP_TRY(hipFuncSetAttribute((const void *)k_slic_bin, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        BIN_MAX_K_LDS * (int)sizeof(int4)));
+            if (dev >= 0 && dev < IMSEGM_MAX_DEVICES) bin_attr[dev] = true;
+        }
     }
     // first sweep in closed form: allowed when every pixel lies inside the search window of its nearest grid
     // node (per axis: half a grid step in the interior, the border offsets at the ends)
