@@ -96,3 +96,21 @@ def test_enforce_connectivity_randomised(hip, oracle):
         finally:
             im.close()
         assert np.array_equal(got, oracle.enforce_connectivity(lab, min_size, max_size, 0)), (h, w, bh, bw)
+
+
+def test_enforce_connectivity_volume(hip, oracle):
+    """3-D label maps (6 neighbours, z first) take the general path through the same entry point"""
+    rng = np.random.RandomState(11)
+    for shape, b in (((6, 40, 50), 10), ((12, 33, 21), 7), ((1, 64, 64), 16)):
+        zz, yy, xx = np.mgrid[0:shape[0], 0:shape[1], 0:shape[2]]
+        lab = ((zz // max(1, shape[0] // 2)) * 100 + (yy // b) * 10 + xx // b).astype(np.int32)
+        m = rng.rand(*shape) < 0.03
+        lab[m] = rng.randint(0, 40, m.sum())
+        seg = lab.size / float(len(np.unique(lab)))
+        want = oracle.enforce_connectivity(lab, int(0.5 * seg), int(3 * seg), 0)
+        vol = hip.Volume3D(*shape)
+        try:
+            got = vol.enforce_connectivity(lab, int(0.5 * seg), int(3 * seg), 0)
+        finally:
+            vol.close()
+        assert np.array_equal(got, want), shape

@@ -53,3 +53,28 @@ for v, name in ((1, 'accum sweep'), (0, 'final sweep')):
     slow = life > np.percentile(life, 95)
     print('  slowest 5%%: start %.1f..%.1f us, phases' % (st[slow].min(), st[slow].max()),
           ' '.join('%5.0f' % x for x in (d[slow, :8] / n[slow, None]).mean(0)))
+
+# would a longest-first dispatch order shorten the launch?  greedy list scheduling of the measured lifetimes on the slots
+import heapq
+for v, name in ((1, 'accum sweep'),):
+    d = a[:, v, :]
+    idx = np.nonzero(d[:, 15] > 0)[0]
+    d = d[idx]
+    if not len(d):
+        continue
+    life = (d[:, 11] - d[:, 10]) / 100.0
+    cand = d[:, 9] / d[:, 15]
+    print('lifetime vs candidates of wave 0: corr %.2f; lifetime vs loop cycles corr %.2f' %
+          (np.corrcoef(life, cand)[0, 1], np.corrcoef(life, d[:, 2] / d[:, 15])[0, 1]))
+    def makespan(order, slots=1280):
+        h = [0.0] * slots
+        heapq.heapify(h)
+        end = 0.0
+        for i in order:
+            t = heapq.heappop(h) + life[i]
+            end = max(end, t)
+            heapq.heappush(h, t)
+        return end
+    n = len(life)
+    print('greedy makespan on 1280 slots: dispatch order %.1f us, longest first %.1f us, by candidates desc %.1f us, ideal %.1f us'
+          % (makespan(range(n)), makespan(np.argsort(-life)), makespan(np.argsort(-cand, kind='stable')), life.sum() / 1280))
