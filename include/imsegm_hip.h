@@ -89,6 +89,10 @@ IMSEGM_API int imsegm_image2d_get_labels(imsegm_image2d *img, int64_t *labels_ou
 /* install an arbitrary label map (int32, values in [0, n_labels)) -- stage-level entry for the
  * descriptor / graph functions that take a user segmentation */
 IMSEGM_API int imsegm_image2d_set_labels(imsegm_image2d *img, const int32_t *labels, int n_labels);
+/* Diagnostic (no reference counterpart): how many 2-D connectivity passes of this process could not be finished by the
+ * tile path of csrc/connectivity.hip and were redone by the general one (results are identical; tests use it to make sure
+ * ordinary inputs stay on the fast path). */
+IMSEGM_API long imsegm_debug_conn_general_runs(void);
 /* Replaces skimage.segmentation._slic._enforce_label_connectivity_cython(segments, min_size, max_size, start_label)
  * (scikit-image 0.18; the connectivity pass of skimage.segmentation.slic, reached from imsegm/superpixels.py:61-63 and
  * :104-106 with enforce_connectivity=True) on a label map given by the caller: labels = host int32, one value per

@@ -92,6 +92,7 @@ _SIGNATURES = {
     'imsegm_image2d_get_labels': (C.c_int, [_vp, _vp]),
     'imsegm_image2d_set_labels': (C.c_int, [_vp, _vp, C.c_int]),
     'imsegm_image2d_enforce_connectivity': (C.c_int, [_vp, _vp, C.c_long, C.c_long, C.c_int, _vp]),
+    'imsegm_debug_conn_general_runs': (C.c_long, []),
     'imsegm_image2d_label_hist': (C.c_int, [_vp, _vp, C.c_int, _vp]),
     'imsegm_image2d_get_lab': (C.c_int, [_vp, _vp]),
     'imsegm_image2d_get_nearest': (C.c_int, [_vp, _vp]),

@@ -647,6 +647,9 @@ int imsegm_image2d_set_labels(imsegm_image2d *im, const int32_t *labels, int n_l
     return 0;
 }
 
+// diagnostic: number of 2-D connectivity passes of this process that left the tile path for the general one
+long imsegm_debug_conn_general_runs(void) { return conn_general_runs(); }
+
 // skimage.segmentation._slic._enforce_label_connectivity_cython(segments, min_size, max_size, start_label) -- the second
 // native call inside skimage.segmentation.slic (superpixels.py:61-63, enforce_connectivity=True) -- on a label map
 // given by the caller; the result becomes the session's label map.  2-D image sessions and volume sessions.

@@ -21,11 +21,13 @@
 //   5. merged-into-merged chains are resolved by pointer chasing (roots strictly decrease).
 #include "slic.h"
 
+#include <atomic>
+
 namespace imsegm {
 
 enum { ST_ACTIVE = 0, ST_FINAL = 1 };
 enum { CNT_OVER = 0, CNT_SMALL = 1, CNT_CURSOR = 2, CNT_KEPT = 3, CNT_FALLBACK = 4, CNT_BIG = 5, CNT_LITTLE = 6,
-       CNT_LROOT = 8, CNT_FLAG = 9, CNT_FB = 10 };      // 8..10: the 2-D tile path
+       CNT_LROOT = 8, CNT_FLAG = 9, CNT_FB = 10, CNT_FB2 = 11 };      // 8..11: the 2-D tile path
 
 // neighbour of voxel p in direction d of the reference's BFS order (+x, -x, +y, -y, +z, -z); -1 outside
 __device__ __forceinline__ int neighbour(int p, int D, int H, int W, int d)
@@ -661,13 +663,13 @@ static int conn_tail(const int32_t *csize_final, int32_t *adjptr, int D, int H, 
 // Anything the fast path cannot take (more than 64 local components in a tile, list capacities, a frontier of more
 // than 64 cells and a bounding box the old wave kernel cannot stage either, an oversize component) raises a flag /
 // counter that the host reads at its single synchronisation, and the general path above runs instead.
-constexpr int CT_W = 64, CT_H = 32, CT_SLOTS = 64;
+constexpr int CT_W = 64, CT_H = 32, CT_SLOTS = 256;      // (config-4 images: up to 83 local components in a tile)
 constexpr int CONN_KEPT_CAP = 1 << 16, CONN_FB_CAP = 4096;
-static_assert(2 * CONN_KEPT_CAP + 8 * CONN_FB_CAP <= CONN_DENSE_INTS, "dense scratch of the tile path");
+static_assert(2 * CONN_KEPT_CAP + 16 * CONN_FB_CAP <= CONN_DENSE_INTS, "dense scratch of the tile path");
 static_assert(CT_W * CT_H == CONN_TILE_PIXELS && CT_SLOTS == CONN_TILE_SLOTS, "sizes used by conn_i32_bytes (slic.h)");
 
 struct ConnDense {
-    int32_t *lroots, *lsize, *lbox, *ntile, *kept, *sorted, *fb_list, *fb_reject, *fb_bbox;
+    int32_t *lroots, *lsize, *lbox, *ntile, *kept, *sorted, *fb_list, *fb_reject, *fb_bbox, *fb2_list, *fb2_bbox;
 };
 // local roots live in fixed slots: tile t owns entries [t * CT_SLOTS, t * CT_SLOTS + ntile[t]) (no global cursor: two
 // thousand workgroups adding to one counter serialise on it)
@@ -680,6 +682,8 @@ static ConnDense conn_dense(const ConnWork &w, int n_tiles)
     d.fb_list = b; b += CONN_FB_CAP;
     d.fb_reject = b; b += CONN_FB_CAP;
     d.fb_bbox = b; b += 6 * CONN_FB_CAP;
+    d.fb2_list = b; b += CONN_FB_CAP;
+    d.fb2_bbox = b; b += 6 * CONN_FB_CAP;
     d.lroots = b; b += (size_t)n_tiles * CT_SLOTS;
     d.lsize = b; b += (size_t)n_tiles * CT_SLOTS;
     d.lbox = b; b += (size_t)n_tiles * CT_SLOTS;
@@ -993,32 +997,42 @@ __device__ __forceinline__ void kept_rank_block(int *offs /* [KR_BUCKETS + 1] */
 // discovers it first); the claims of a level, ordered by (rank, direction), are the next frontier: positions from four
 // ballots.  `adjacent` is the earlier-component neighbour met by the highest (level, rank, direction).
 constexpr int BR_CELLS = 16384;      // 16.6 KB of LDS per workgroup: every small component of an image is resident at once
+constexpr int BR_CELLS_BIG = 131072; // second launch (a few workgroups, 128 KB of LDS each) for the bounding boxes beyond that:
+                                     // a one-pixel sliver along a 300-pixel diagonal edge has 143 pixels in 10^5 cells
+// list / count: the components to do (count capped at count_cap); rej_*: where the ones this launch cannot take go
+// (with their tight bounding box, for k_small_bfs_wave); cells_cap: cells of the LDS tile (dynamic shared memory =
+// cells_cap + 256 bytes); with_rank: the last workgroup ranks the kept roots instead
 __global__ void __launch_bounds__(256)
-k_small_bfs_reg(const int32_t *__restrict__ list, int32_t *counters, const int32_t *__restrict__ parent,
-                const int32_t *__restrict__ ymax_g, const int32_t *__restrict__ xmin_g, const int32_t *__restrict__ xmax_g,
-                int H, int W, int32_t *adjptr, int32_t *fb_list, int32_t *fb_bbox, const int32_t *__restrict__ kept,
-                int start_label, int32_t *sorted, int32_t *newlabel)
+k_small_bfs_reg(const int32_t *__restrict__ list, const int32_t *__restrict__ count, int count_cap, int32_t *counters,
+                const int32_t *__restrict__ parent, const int32_t *__restrict__ ymax_g, const int32_t *__restrict__ xmin_g,
+                const int32_t *__restrict__ xmax_g, int H, int W, int32_t *adjptr, int32_t *rej_list, int rej_counter,
+                int32_t *rej_bbox, int cells_cap, int with_rank, const int32_t *__restrict__ kept, int start_label,
+                int32_t *sorted, int32_t *newlabel)
 {
     static_assert(BR_CELLS + 64 * 4 >= (2 * KR_BUCKETS + 1 + 4 + KR_SORTED_LDS) * 4, "shared memory of the two roles");
-    __shared__ __align__(16) uint8_t smem[BR_CELLS + 64 * 4];
+    extern __shared__ __align__(16) uint8_t smem[];
     const int tid = threadIdx.x, lane = tid & 63;
-    if (blockIdx.x == gridDim.x - 1) {
-        int *si = reinterpret_cast<int *>(smem);
-        kept_rank_block<256>(si, si + KR_BUCKETS + 1, si + 2 * KR_BUCKETS + 1, si + 2 * KR_BUCKETS + 1 + 4, kept, counters,
-                             (long)H * W, start_label, sorted, newlabel);
-        return;
+    int n_workers = gridDim.x;
+    if (with_rank) {
+        n_workers -= 1;
+        if (blockIdx.x == gridDim.x - 1) {
+            int *si = reinterpret_cast<int *>(smem);
+            kept_rank_block<256>(si, si + KR_BUCKETS + 1, si + 2 * KR_BUCKETS + 1, si + 2 * KR_BUCKETS + 1 + 4, kept, counters,
+                                 (long)H * W, start_label, sorted, newlabel);
+            return;
+        }
     }
     uint8_t *cs = smem;
-    int *fr = reinterpret_cast<int *>(smem + BR_CELLS);
-    const int n_small = counters[CNT_FLAG] ? 0 : counters[CNT_SMALL];
-    for (int t = blockIdx.x; t < n_small; t += gridDim.x - 1) {
+    int *fr = reinterpret_cast<int *>(smem + cells_cap);
+    const int n_small = counters[CNT_FLAG] ? 0 : min(*count, count_cap);
+    for (int t = blockIdx.x; t < n_small; t += n_workers) {
         const int root = list[t];
         const int ry = root / W, rx = root - ry * W;
         const int y1 = ymax_g[root], x0 = xmin_g[root], x1 = xmax_g[root];
         const int by0 = ry - 2, bx0 = x0 - 2;
         const int bw = x1 - x0 + 5, bh = y1 - ry + 5;
         const long cells_l = (long)bw * bh;
-        bool reject = cells_l > BR_CELLS;                 // block-uniform
+        bool reject = cells_l > cells_cap;                // block-uniform
         int adj_cell = -1;
         if (!reject) {
             const int cells = (int)cells_l;
@@ -1030,7 +1044,8 @@ k_small_bfs_reg(const int32_t *__restrict__ list, int32_t *counters, const int32
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
                     const int c = c0 + u * 256;
-                    const int cy = (int)__umulhi((unsigned int)c, m_bw), cx = c - cy * bw;
+                    // (the reciprocal is exact while c * bw < 2^32: always for the 16 K tile)
+                    const int cy = cells_cap <= BR_CELLS ? (int)__umulhi((unsigned int)c, m_bw) : c / bw, cx = c - cy * bw;
                     const int y = by0 + cy, x = bx0 + cx;
                     q[u] = (c < cells && y >= 0 && y < H && x >= 0 && x < W) ? parent[(size_t)y * W + x] : -1;
                 }
@@ -1110,13 +1125,13 @@ k_small_bfs_reg(const int32_t *__restrict__ list, int32_t *counters, const int32
         if (tid == 0) {
             if (reject) {
                 // hand over to the LDS-frontier kernel (k_small_bfs_wave): it gets the tight bounding box
-                adjptr[root] = -1;                    // (defined even if nobody takes it: k_small_resolve walks these)
-                const int i = atomicAdd(&counters[CNT_FB], 1);
+                adjptr[root] = -1;                    // (defined even if nobody takes it: k_lroot_labels walks these)
+                const int i = atomicAdd(&counters[rej_counter], 1);
                 if (i < CONN_FB_CAP) {
-                    fb_list[i] = root;
-                    fb_bbox[6 * i + 0] = ry; fb_bbox[6 * i + 1] = y1;
-                    fb_bbox[6 * i + 2] = x0; fb_bbox[6 * i + 3] = x1;
-                    fb_bbox[6 * i + 4] = 0; fb_bbox[6 * i + 5] = 0;
+                    rej_list[i] = root;
+                    rej_bbox[6 * i + 0] = ry; rej_bbox[6 * i + 1] = y1;
+                    rej_bbox[6 * i + 2] = x0; rej_bbox[6 * i + 3] = x1;
+                    rej_bbox[6 * i + 4] = 0; rej_bbox[6 * i + 5] = 0;
                 }
             } else {
                 int adj = -1;
@@ -1169,12 +1184,26 @@ static int conn_fast_2d(const int32_t *labels_in, int H, int W, int min_size, in
                        xmin_g, xmax_g, W);
     hipLaunchKernelGGL(k_root_classify, cdiv(n_slots, 1024), 1024, 0, st, d.lroots, d.ntile, n_slots, w.counters, w.parent, w.csize, min_size, max_size, d.kept,
                        w.list);
-    hipLaunchKernelGGL(k_small_bfs_reg, 2048 + 1, 256, 0, st, w.list, w.counters, w.parent, ymax_g, xmin_g, xmax_g, H, W, w.adjptr,
-                       d.fb_list, d.fb_bbox, d.kept, start_label, d.sorted, w.newlabel);
-    // components the register-frontier kernel handed over (frontier of more than 64 cells, large bounding box);
-    // what this one cannot take either ends up in CNT_FALLBACK and sends the image to the general path
-    hipLaunchKernelGGL((k_small_bfs_wave<8192, 2048, true>), 256, 64, 0, st, d.fb_list, w.counters, w.counters + CNT_FB, w.parent,
-                       d.fb_bbox, 1, H, W, (const int32_t *)nullptr, CONN_FB_CAP, w.adjptr, d.fb_reject);
+    hipLaunchKernelGGL(k_small_bfs_reg, 2048 + 1, 256, BR_CELLS + 256, st, w.list, w.counters + CNT_SMALL, n, w.counters, w.parent,
+                       ymax_g, xmin_g, xmax_g, H, W, w.adjptr, d.fb_list, (int)CNT_FB, d.fb_bbox, BR_CELLS, 1, d.kept, start_label,
+                       d.sorted, w.newlabel);
+    // bounding boxes beyond the 16 K tile (long thin slivers): the same kernel with a 128 K tile, a few workgroups
+    {
+        static bool big_attr[IMSEGM_MAX_DEVICES];
+        int dev = 0;
+        HIP_TRY(hipGetDevice(&dev));
+        if (dev < 0 || dev >= IMSEGM_MAX_DEVICES || !big_attr[dev]) {
+            HIP_TRY(hipFuncSetAttribute((const void *)k_small_bfs_reg, hipFuncAttributeMaxDynamicSharedMemorySize, BR_CELLS_BIG + 256));
+            if (dev >= 0 && dev < IMSEGM_MAX_DEVICES) big_attr[dev] = true;
+        }
+    }
+    hipLaunchKernelGGL(k_small_bfs_reg, 128, 256, BR_CELLS_BIG + 256, st, d.fb_list, w.counters + CNT_FB, CONN_FB_CAP, w.counters,
+                       w.parent, ymax_g, xmin_g, xmax_g, H, W, w.adjptr, d.fb2_list, (int)CNT_FB2, d.fb2_bbox, BR_CELLS_BIG, 0,
+                       d.kept, start_label, d.sorted, w.newlabel);
+    // frontiers of more than 64 cells: the LDS-frontier kernel; what this one cannot take either ends up in CNT_FALLBACK and
+    // sends the image to the general path
+    hipLaunchKernelGGL((k_small_bfs_wave<8192, 2048, true>), 256, 64, 0, st, d.fb2_list, w.counters, w.counters + CNT_FB2, w.parent,
+                       d.fb2_bbox, 1, H, W, (const int32_t *)nullptr, CONN_FB_CAP, w.adjptr, d.fb_reject);
     hipLaunchKernelGGL(k_lroot_labels, lgrid, 256, 0, st, d.lroots, d.ntile, n_slots, w.counters, w.parent, w.csize, w.adjptr, min_size, w.newlabel);
     hipLaunchKernelGGL(k_write_labels, cdiv(n, 256), 256, 0, st, w.parent, w.newlabel, n, labels_out,
                        (const int32_t *)(w.counters + CNT_FLAG));
@@ -1183,10 +1212,14 @@ static int conn_fast_2d(const int32_t *labels_in, int H, int W, int min_size, in
     HIP_TRY(hipStreamSynchronize(st));
     *ok = host_counters[CNT_FLAG] == 0 && host_counters[CNT_OVER] == 0 && host_counters[CNT_FALLBACK] == 0 &&
           host_counters[CNT_KEPT] <= CONN_KEPT_CAP &&
-          host_counters[CNT_FB] <= CONN_FB_CAP;
+          host_counters[CNT_FB] <= CONN_FB_CAP && host_counters[CNT_FB2] <= CONN_FB_CAP;
     *n_kept = host_counters[CNT_KEPT];
     return 0;
 }
+
+// how often a 2-D map had to take the general path (diagnostic: tests assert that ordinary inputs stay on the tile path)
+static std::atomic<long> g_conn_general_runs{0};
+long conn_general_runs() { return g_conn_general_runs.load(); }
 
 int launch_enforce_connectivity(const int32_t *labels_in, int D, int H, int W, long min_size_l, long max_size_l,
                                 int start_label, ConnWork w, int32_t *labels_out, int *n_labels_out_host,
@@ -1207,6 +1240,7 @@ int launch_enforce_connectivity(const int32_t *labels_in, int D, int H, int W, l
             *n_labels_out_host = n_kept > 0 ? start_label + n_kept : 1;
             return 0;
         }
+        g_conn_general_runs.fetch_add(1);
     }
 
     // fast path, speculating that no component reaches max_size: one CCL round, then the tail;

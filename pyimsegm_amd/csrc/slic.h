@@ -140,14 +140,15 @@ struct ConnWork {
     int32_t *bbox;        // [N] bounding boxes of small components (N/12 x 6) + fallback list (N/2)
     int32_t *dense;       // lists of the 2-D tile path: CONN_DENSE_INTS (kept roots, hand-overs) + per-tile slots of local roots
 };
-constexpr size_t CONN_DENSE_INTS = 2 * 65536 + 8 * 4096;
-constexpr int CONN_TILE_PIXELS = 64 * 32, CONN_TILE_SLOTS = 64;
+constexpr size_t CONN_DENSE_INTS = 2 * 65536 + 16 * 4096;
+constexpr int CONN_TILE_PIXELS = 64 * 32, CONN_TILE_SLOTS = 256;
 // bytes of the int32 scratch behind a ConnWork for n pixels (2-D: H x W, tiles of 64 x 32 with 64 slots x 3 lists + a count)
 static inline size_t conn_i32_bytes(size_t n, size_t H = 0, size_t W = 0)
 {
     const size_t n_tiles = ((W + 63) / 64) * ((H + 31) / 32);
     return n * 4 * 8 + ((n / 4096) + 64) * 4 + 256 + (CONN_DENSE_INTS + n_tiles * (3 * CONN_TILE_SLOTS + 1)) * 4;
 }
+long conn_general_runs();      // diagnostic: 2-D maps that left the tile path so far
 int launch_enforce_connectivity(const int32_t *labels_in, int D, int H, int W, long min_size, long max_size,
                                 int start_label, ConnWork w, int32_t *labels_out, int *n_labels_out_host,
                                 hipStream_t st);

@@ -65,15 +65,28 @@ CASES = [
 ]
 
 
+#: which path has to finish the case: the tile path (incl. its own hand-overs to the 128 K tile and the LDS-frontier kernel), or
+#: the general one (None: either)
+PATH = {'blocks_ragged': 'tile', 'salt_1pct': 'tile', 'comb_frontier_75': 'tile', 'diagonal_100': 'tile', 'diagonal_200': 'tile',
+        'one_row': 'tile', 'one_column': 'tile', 'tiny': 'tile', 'noise': 'general', 'oversize': 'general'}
+
+
 @pytest.mark.parametrize('name,make,min_size,max_size', CASES, ids=[c[0] for c in CASES])
 @pytest.mark.parametrize('start_label', [0, 1])
 def test_enforce_connectivity_bit_exact(hip, oracle, name, make, min_size, max_size, start_label):
     lab = make() + start_label          # (as slic hands it over: no pixel carries the mask label start_label - 1)
     want = oracle.enforce_connectivity(lab, min_size, max_size, start_label)
     im = hip.Image2D(lab.shape[0], lab.shape[1])
+    general_runs = hip.load_library().imsegm_debug_conn_general_runs
     try:
+        before = general_runs()
         got = im.enforce_connectivity(lab, min_size, max_size, start_label)
+        took_general = general_runs() - before
         assert got.shape == lab.shape and np.array_equal(got, want), '%d pixels differ' % int((got != want).sum())
+        if PATH.get(name) == 'tile':
+            assert took_general == 0, 'left the tile path'
+        elif PATH.get(name) == 'general':
+            assert took_general == 1
         # session reuse: a second, different map on the same buffers
         lab2 = np.ascontiguousarray(lab[::-1])
         assert np.array_equal(im.enforce_connectivity(lab2, min_size, max_size, start_label),
@@ -114,3 +127,14 @@ def test_enforce_connectivity_volume(hip, oracle):
         finally:
             vol.close()
         assert np.array_equal(got, want), shape
+
+
+def test_slic_of_benchmark_like_images_stays_on_the_tile_path(hip):
+    """SLIC label maps of the synthetic benchmark images (configs 2 and 4) must not need the general connectivity path"""
+    from pyimsegm_amd import superpixels as S
+    from pyimsegm_amd.utilities.synthetic import voronoi_image
+    general_runs = hip.load_library().imsegm_debug_conn_general_runs
+    before = general_runs()
+    for shape, sp, seed in (((647, 1024), 35, 100), ((647, 1024), 35, 101), ((1024, 1024), 46, 1)):
+        S.segment_slic_img2d(voronoi_image(shape[0], shape[1], seed=seed), sp, 0.2)
+    assert general_runs() == before
