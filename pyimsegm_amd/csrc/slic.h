@@ -85,6 +85,7 @@ struct ProfHook {
     // timestamps of that dispatch itself, without the gap an hipEventRecord in front of the launch adds
     void (*pair)(void *, int, hipEvent_t *, hipEvent_t *) = nullptr;
 };
+int slic_prepare_device();
 int launch_slic_iterations(SlicState s, const double *lab, const double *init_yx_dev, int32_t *labels, int max_iter,
                            int max_cand, const ProfHook &prof, hipStream_t st);
 

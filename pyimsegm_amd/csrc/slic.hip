@@ -1464,6 +1464,20 @@ k_slic_assign_dot(SlicState s, const double *__restrict__ lab, int32_t *__restri
     PHASE_FLUSH()
 }
 
+// function attributes of the sweep kernels on the current device (idempotent; must not run inside a stream capture)
+int slic_prepare_device()
+{
+    static bool bin_attr[IMSEGM_MAX_DEVICES];           // per device, like every function attribute
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    if (dev < 0 || dev >= IMSEGM_MAX_DEVICES || !bin_attr[dev]) {
+        HIP_TRY(hipFuncSetAttribute((const void *)k_slic_bin, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    BIN_MAX_K_LDS * (int)sizeof(int4)));
+        if (dev >= 0 && dev < IMSEGM_MAX_DEVICES) bin_attr[dev] = true;
+    }
+    return 0;
+}
+
 int launch_slic_iterations(SlicState s, const double *lab, const double *init_yx_dev, int32_t *labels, int max_iter,
                            int max_cand, const ProfHook &prof, hipStream_t st)
 {
@@ -1476,16 +1490,7 @@ int launch_slic_iterations(SlicState s, const double *lab, const double *init_yx
     // workgroups of the dot kernel: 1 = half a bin tile (64 x 16), 2 = a whole tile, two units per wave
     const dim3 grid_tile(grid.x, cdiv(s.H, TILE_Y));
     const int units = s.assign_units == 2 ? 2 : 1;
-    {
-        static bool bin_attr[IMSEGM_MAX_DEVICES];       // per device, like every function attribute
-        int dev = 0;
-        HIP_TRY(hipGetDevice(&dev));
-        if (dev < 0 || dev >= IMSEGM_MAX_DEVICES || !bin_attr[dev]) {
-            HIP_TRY(hipFuncSetAttribute((const void *)k_slic_bin, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                        BIN_MAX_K_LDS * (int)sizeof(int4)));
-            if (dev >= 0 && dev < IMSEGM_MAX_DEVICES) bin_attr[dev] = true;
-        }
-    }
+    if (slic_prepare_device()) return -1;
     // first sweep in closed form: allowed when every pixel lies inside the search window of its nearest grid
     // node (per axis: half a grid step in the interior, the border offsets at the ends)
     bool grid_covers = false;
@@ -1517,33 +1522,37 @@ int launch_slic_iterations(SlicState s, const double *lab, const double *init_yx
         // when profiling, the event pair rides on the dispatch itself (kernel begin / end timestamps)
         hipEvent_t ev_a = nullptr, ev_b = nullptr;
         if (prof.pair) prof.pair(prof.user, 0, &ev_a, &ev_b);
-#define LAUNCH_ASSIGN(kernel, ...) hipExtLaunchKernelGGL(kernel, grid, dim3(256), 0, st, ev_a, ev_b, 0, __VA_ARGS__)
+// (with a profiler pair: the extended launch that stamps the dispatch; otherwise a plain launch, which a stream capture records)
+#define LAUNCH_ON(kernel, g, ...)                                                                                    \
+    {                                                                                                                \
+        if (ev_a) hipExtLaunchKernelGGL(kernel, g, dim3(256), 0, st, ev_a, ev_b, 0, __VA_ARGS__);                    \
+        else hipLaunchKernelGGL(kernel, g, dim3(256), 0, st, __VA_ARGS__);                                           \
+    }
+#define LAUNCH_ASSIGN(kernel, ...) LAUNCH_ON(kernel, grid, __VA_ARGS__)
 #define LAUNCH_DOT(ACC, FST)                                                                                         \
     {                                                                                                                \
         if (units == 2)                                                                                              \
-            hipExtLaunchKernelGGL((k_slic_assign_dot<ACC, FST, 2, false>), grid_tile, dim3(256), 0, st, ev_a, ev_b, 0, s, lab,   \
-                                  labels, s.tile_cands, s.tile_rec, s.tile_info, s.tile_k);                          \
+            LAUNCH_ON((k_slic_assign_dot<ACC, FST, 2, false>), grid_tile, s, lab, labels, s.tile_cands, s.tile_rec, s.tile_info, s.tile_k) \
         else if (s.phase_prof)                                                                                       \
-            hipExtLaunchKernelGGL((k_slic_assign_dot<ACC, FST, 1, true>), grid, dim3(256), 0, st, ev_a, ev_b, 0, s, lab,   \
-                                  labels, s.tile_cands, s.tile_rec, s.tile_info, s.tile_k);                          \
+            LAUNCH_ON((k_slic_assign_dot<ACC, FST, 1, true>), grid, s, lab, labels, s.tile_cands, s.tile_rec, s.tile_info, s.tile_k) \
         else                                                                                                         \
-            hipExtLaunchKernelGGL((k_slic_assign_dot<ACC, FST, 1, false>), grid, dim3(256), 0, st, ev_a, ev_b, 0, s, lab,   \
-                                  labels, s.tile_cands, s.tile_rec, s.tile_info, s.tile_k);                          \
+            LAUNCH_ON((k_slic_assign_dot<ACC, FST, 1, false>), grid, s, lab, labels, s.tile_cands, s.tile_rec, s.tile_info, s.tile_k) \
     }
         if (first_grid) {
             if (accum) LAUNCH_DOT(true, true) else LAUNCH_DOT(false, true)
         } else if (dot) {
             if (accum) LAUNCH_DOT(true, false) else LAUNCH_DOT(false, false)
         } else if (first) {
-            if (accum) LAUNCH_ASSIGN((k_slic_assign<true, true>), s, lab, labels, s.tile_cands, s.tile_count);
-            else LAUNCH_ASSIGN((k_slic_assign<false, true>), s, lab, labels, s.tile_cands, s.tile_count);
+            if (accum) LAUNCH_ASSIGN((k_slic_assign<true, true>), s, lab, labels, s.tile_cands, s.tile_count)
+            else LAUNCH_ASSIGN((k_slic_assign<false, true>), s, lab, labels, s.tile_cands, s.tile_count)
         } else {
             SlicState se = s;
             if (s.slico) se.fast32 = 0;
-            if (accum) LAUNCH_ASSIGN((k_slic_assign<true, false>), se, lab, labels, s.tile_cands, s.tile_count);
-            else LAUNCH_ASSIGN((k_slic_assign<false, false>), se, lab, labels, s.tile_cands, s.tile_count);
+            if (accum) LAUNCH_ASSIGN((k_slic_assign<true, false>), se, lab, labels, s.tile_cands, s.tile_count)
+            else LAUNCH_ASSIGN((k_slic_assign<false, false>), se, lab, labels, s.tile_cands, s.tile_count)
         }
 #undef LAUNCH_DOT
+#undef LAUNCH_ON
 #undef LAUNCH_ASSIGN
         if (it + 1 < max_iter) {
             if (!dot && !first_grid) hipLaunchKernelGGL(k_slic_leftover, 64, 256, 0, st, s, lab, labels);
