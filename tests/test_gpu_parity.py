@@ -325,3 +325,20 @@ def test_slic_randomised_sweep(hip, oracle):
         im.close()
         assert np.array_equal(got, ref), 'case %d kind %d %dx%d sp %d regul %g: %d px differ' % (
             case, kind, H, W, sp, regul, np.count_nonzero(got != ref))
+
+
+def test_slic_sweeps_replayed_from_a_hip_graph(hip, oracle, monkeypatch):
+    """IMSEGM_SLIC_GRAPH=1: capture on the first image of a session, replay on the next (same parameters), re-capture
+    when they change -- label maps as without the graph"""
+    from pyimsegm_amd.utilities.synthetic import voronoi_image
+    monkeypatch.setenv('IMSEGM_SLIC_GRAPH', '1')
+    sess = hip.Image2D(200, 264)
+    try:
+        for seed, sp in ((5, 20), (6, 20), (7, 26)):
+            img = voronoi_image(200, 264, seed=seed)
+            n_seg, compact = _params(img, sp, 0.2)
+            sess.upload(img)
+            sess.slic(n_seg, compact)
+            assert np.array_equal(sess.get_labels(), oracle.segment_slic_img2d(img, sp, 0.2))
+    finally:
+        sess.close()
