@@ -36,6 +36,7 @@ struct StatParams {
     double scale_v, scale_e;      // 2^shift for the value / squared-value sums
     int planar;                   // 0: H x W x 3 interleaved, 1: three planes `plane_stride` elements apart
     size_t plane_stride;          //    (0: one gray plane read three times)
+    size_t n_pixels;              // H * W (guards the 4-byte pixel load of interleaved uint8 images)
     int u8_int;                   // uint8 image, power-of-two scales >= 1: integer block sums in the first pass
     int prescale;                 // 1: value = (raw * mul) / div before the float32 staging
     double mul, div;              //    (descriptors.py:1094 `(response * (log(1 + norm) / 0.03)) / norm`)
@@ -76,6 +77,16 @@ k_color_stats(const T *__restrict__ img, const int32_t *__restrict__ labels, Sta
         const bool ok = (y < sp.H) && (x < sp.W);
         const size_t p = ok ? (size_t)y * sp.W + x : 0;
         lab[r] = ok ? labels[p] : 0x7fffffff;
+        if (sizeof(T) == 1 && !sp.planar && !sp.prescale && p + 1 < sp.n_pixels) {
+            // interleaved uint8: the three bytes of a pixel through one unaligned 32-bit load (the byte after them belongs
+            // to the next pixel): a third of the load instructions and of the cache-line accesses of a wave
+            uint32_t w;
+            __builtin_memcpy(&w, reinterpret_cast<const uint8_t *>(img) + 3 * p, 4);
+            v[r][0] = (float)(w & 0xffu);
+            v[r][1] = (float)((w >> 8) & 0xffu);
+            v[r][2] = (float)((w >> 16) & 0xffu);
+            continue;
+        }
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
             const size_t idx = sp.planar ? (size_t)c * sp.plane_stride + p : 3 * p + c;
@@ -272,6 +283,7 @@ int launch_color_stats(const void *img, int dtype, const int32_t *labels, int H,
 {
     StatParams sp;
     sp.H = H; sp.W = W; sp.K = K;
+    sp.n_pixels = (size_t)H * W;
     sp.planar = planar; sp.prescale = prescale; sp.mul = mul; sp.div = div;
     sp.plane_stride = plane_stride >= 0 ? (size_t)plane_stride : (size_t)H * W;
     sp.scale_v = pow2_scale((double)H * W, maxabs);
