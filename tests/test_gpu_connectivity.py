@@ -1,10 +1,14 @@
 """``_enforce_label_connectivity_cython`` (scikit-image 0.18, the second native call inside ``skimage.segmentation.slic``;
-/root/reference/imsegm/superpixels.py:61-63) on crafted label maps, HIP against the oracle, bit for bit.
+/root/reference/imsegm/superpixels.py:61-63) on crafted label maps, HIP against the oracle AND against the outputs of the real
+scikit-image 0.18.3 (``tests/golden/connectivity.npz``), bit for bit.
 
-The 2-D tile path of ``csrc/connectivity.hip`` has hand-over points (more than 64 local components in a tile, a BFS
-frontier of more than 64 cells, bounding boxes beyond the LDS tile, oversize components); every case below is built to
+The 2-D tile path of ``csrc/connectivity.hip`` has hand-over points (more than 256 local components in a tile, a BFS
+frontier of more than 64 cells, bounding boxes beyond the LDS tiles, oversize components); every case below is built to
 cross one of them.
 """
+import importlib.util
+import os
+
 import numpy as np
 import pytest
 
@@ -18,52 +22,20 @@ def hip():
     return _hip
 
 
-def _blocks(h, w, bh, bw):
-    yy, xx = np.mgrid[0:h, 0:w]
-    return ((yy // bh) * ((w + bw - 1) // bw) + xx // bw).astype(np.int32)
+HERE = os.path.dirname(os.path.abspath(__file__))
+_spec = importlib.util.spec_from_file_location('make_golden_connectivity', os.path.join(HERE, 'golden', 'make_golden_connectivity.py'))
+GEN = importlib.util.module_from_spec(_spec)
+_spec.loader.exec_module(GEN)
+_salted = GEN.salted
 
-
-def _salted(h, w, bh, bw, frac, seed):
-    rng = np.random.RandomState(seed)
-    lab = _blocks(h, w, bh, bw)
-    m = rng.rand(h, w) < frac
-    lab[m] = rng.randint(0, lab.max() + 1, m.sum())
-    return lab
-
-
-def _comb(h, w):
-    """one block label with a comb of another label inside it: small component with a wide BFS frontier"""
-    lab = np.zeros((h, w), np.int32)
-    lab[:, w // 2:] = 1
-    lab[4, 4:4 + 150] = 2                     # spine ...
-    for x in range(4, 4 + 150, 2):
-        lab[5:12, x] = 2                      # ... and 75 teeth: the frontier grows to 75 cells
-    return lab
-
-
-def _diagonal(h, w, n):
-    lab = _blocks(h, w, 64, 64)
-    for i in range(n):                        # one-pixel staircase of a foreign label: thin, bounding box n x n
-        lab[10 + i, 10 + i] = 999
-        lab[10 + i, 11 + i] = 999
-    return lab
-
-
-CASES = [
-    ('blocks_ragged', lambda: _blocks(203, 317, 23, 31), 100, 2000),
-    ('salt_1pct', lambda: _salted(256, 320, 32, 40, 0.01, 0), 300, 5000),
-    ('salt_10pct', lambda: _salted(200, 200, 25, 25, 0.10, 1), 200, 3000),
-    ('noise', lambda: np.random.RandomState(2).randint(0, 6, (150, 170)).astype(np.int32), 20, 400),
-    ('comb_frontier_75', lambda: _comb(64, 400), 1000, 100000),
-    ('diagonal_100', lambda: _diagonal(256, 256, 100), 500, 100000),
-    ('diagonal_200', lambda: _diagonal(320, 320, 200), 500, 100000),
-    ('oversize', lambda: _blocks(128, 128, 64, 64), 10, 1000),
-    ('one_row', lambda: _blocks(1, 500, 1, 37), 20, 100),
-    ('one_column', lambda: _blocks(500, 1, 41, 1), 20, 100),
-    ('tiny', lambda: _blocks(4, 4, 2, 2), 2, 100),
-    ('everything_small', lambda: _salted(96, 96, 8, 8, 0.2, 3), 100000, 1000000),
+#: the crafted maps of tests/golden/make_golden_connectivity.py (outputs of the real scikit-image 0.18.3 in connectivity.npz)
+#: plus one that only the oracle covers
+CASES = [(name, (lambda name=name: GEN.make(name)), GEN.CASES[name][1], GEN.CASES[name][2])
+         for name in GEN.CASES if name != 'volume'] + [
+    ('tiny', lambda: GEN.blocks(4, 4, 2, 2), 2, 100),
 ]
 
+GOLDEN = np.load(os.path.join(HERE, 'golden', 'connectivity.npz'))
 
 #: which path has to finish the case: the tile path (incl. its own hand-overs to the 128 K tile and the LDS-frontier kernel), or
 #: the general one (None: either)
@@ -83,6 +55,9 @@ def test_enforce_connectivity_bit_exact(hip, oracle, name, make, min_size, max_s
         got = im.enforce_connectivity(lab, min_size, max_size, start_label)
         took_general = general_runs() - before
         assert got.shape == lab.shape and np.array_equal(got, want), '%d pixels differ' % int((got != want).sum())
+        key = '%s_start%d' % (name, start_label)
+        if key in GOLDEN:                              # ... and with the real scikit-image 0.18.3
+            assert np.array_equal(got, GOLDEN[key])
         if PATH.get(name) == 'tile':
             assert took_general == 0, 'left the tile path'
         elif PATH.get(name) == 'general':
@@ -109,6 +84,19 @@ def test_enforce_connectivity_randomised(hip, oracle):
         finally:
             im.close()
         assert np.array_equal(got, oracle.enforce_connectivity(lab, min_size, max_size, 0)), (h, w, bh, bw)
+
+
+def test_enforce_connectivity_volume_golden(hip):
+    """the volume of the golden set (real scikit-image 0.18.3), both start labels"""
+    _, min_size, max_size = GEN.CASES['volume']
+    for start_label in (0, 1):
+        lab = GEN.make('volume') + start_label
+        vol = hip.Volume3D(*lab.shape)
+        try:
+            got = vol.enforce_connectivity(lab, min_size, max_size, start_label)
+        finally:
+            vol.close()
+        assert np.array_equal(got, GOLDEN['volume_start%d' % start_label])
 
 
 def test_enforce_connectivity_volume(hip, oracle):
