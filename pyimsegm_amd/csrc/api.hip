@@ -1106,6 +1106,7 @@ static ConnWork make_conn_work(imsegm_image2d *im)
     w.blocksum = b; b += (n / 4096) + 32;
     w.counters = b; b += 64;
     w.dense = b;
+    w.dense_ints = (im->conn_i32.cap - (size_t)((unsigned char *)b - im->conn_i32.as<unsigned char>())) / 4;
     w.visited = im->conn_u8.as<uint8_t>();
     return w;
 }
@@ -1212,7 +1213,8 @@ int imsegm_volume_slic(imsegm_image2d *im, int n_segments, double compactness, c
         double segment_size = (double)n / (double)K;
         long min_size = (long)(min_size_factor * segment_size);
         long max_size = (long)(max_size_factor * segment_size);
-        if (im->conn_i32.ensure(conn_i32_bytes(n)) || im->conn_u8.ensure(2 * n + 64)) return -1;
+        // (a volume of one slice takes the 2-D tile path: its per-tile lists need room like those of an image)
+        if (im->conn_i32.ensure(conn_i32_bytes(n, D == 1 ? H : 0, D == 1 ? W : 0)) || im->conn_u8.ensure(2 * n + 64)) return -1;
         ConnWork w = make_conn_work(im);
         if (launch_enforce_connectivity(im->nearest.as<int32_t>(), D, H, W, min_size, max_size, start_label, w,
                                         im->labels.as<int32_t>(), &n_labels, st))

@@ -1171,6 +1171,10 @@ static int conn_fast_2d(const int32_t *labels_in, int H, int W, int min_size, in
     const int n = H * W;
     const dim3 tiles(cdiv(W, CT_W), cdiv(H, CT_H));
     const int n_tiles = tiles.x * tiles.y, n_slots = n_tiles * CT_SLOTS;
+    if (CONN_DENSE_INTS + (size_t)n_tiles * (3 * CT_SLOTS + 1) > w.dense_ints) {
+        *ok = false;                                  // scratch sized without the per-tile lists: the general path takes it
+        return 0;
+    }
     const ConnDense d = conn_dense(w, n_tiles);
     int32_t *ymax_g = w.queue, *xmin_g = w.slotmap, *xmax_g = w.bbox;
     int32_t host_counters[16];

@@ -140,6 +140,7 @@ struct ConnWork {
     int32_t *slotmap;     // [N] root -> index in the small-component list
     int32_t *bbox;        // [N] bounding boxes of small components (N/12 x 6) + fallback list (N/2)
     int32_t *dense;       // lists of the 2-D tile path: CONN_DENSE_INTS (kept roots, hand-overs) + per-tile slots of local roots
+    size_t dense_ints;    // ints available behind `dense` (the tile path checks that its lists fit before it runs)
 };
 constexpr size_t CONN_DENSE_INTS = 2 * 65536 + 16 * 4096;
 constexpr int CONN_TILE_PIXELS = 64 * 32, CONN_TILE_SLOTS = 256;
