@@ -290,7 +290,16 @@ k_blur_axis(const double *__restrict__ src, double *__restrict__ dst, int H, int
 // Lab (+ z tap) of the tile and its blur halo goes to LDS (the halo is converted redundantly, x1.7), the y
 // pass runs LDS -> LDS one channel at a time, the x pass LDS -> HBM with the final 1/compactness.
 // ---------------------------------------------------------------------------------------------
-constexpr int PF_TX = 64, PF_TY = 16, PF_MAXR = 8, PF_THREADS = 512;
+// (tile geometry overridable at compile time for A/B builds -- tools/variants_k.sh; e.g. -DSLIC_PF_TX=32 -DSLIC_PF_TY=32 converts
+// 40 x 40 pixels per 32 x 32 outputs, x1.56 instead of x1.69, in 48 KB of LDS; not yet measured)
+#ifndef SLIC_PF_TX
+#define SLIC_PF_TX 64
+#endif
+#ifndef SLIC_PF_TY
+#define SLIC_PF_TY 16
+#endif
+constexpr int PF_TX = SLIC_PF_TX, PF_TY = SLIC_PF_TY, PF_MAXR = 8, PF_THREADS = 512;
+static_assert(PF_THREADS % PF_TX == 0 && PF_TY % (PF_THREADS / PF_TX) == 0, "x pass: whole rows per pass");
 
 template <typename T>
 __global__ void __launch_bounds__(PF_THREADS)
@@ -358,7 +367,7 @@ k_pre_fused(const T *__restrict__ img, int H, int W, int normalize, const double
         L1[2 * th * tw + i] = zblur_point(B, tz);
     }
     __syncthreads();
-    const int ox = tid & 63, oy0 = tid >> 6;
+    const int ox = tid % PF_TX, oy0 = tid / PF_TX;
     for (int c = 0; c < 3; ++c) {
         const double *s1 = L1 + (size_t)c * th * tw;
         for (int i = tid; i < PF_TY * tw; i += PF_THREADS) {
@@ -378,8 +387,8 @@ k_pre_fused(const T *__restrict__ img, int H, int W, int normalize, const double
         }
         __syncthreads();
 #pragma unroll
-        for (int q = 0; q < PF_TY / (PF_THREADS / 64); ++q) {
-            const int oy = oy0 + (PF_THREADS / 64) * q;
+        for (int q = 0; q < PF_TY / (PF_THREADS / PF_TX); ++q) {
+            const int oy = oy0 + (PF_THREADS / PF_TX) * q;
             const double *row = L2 + oy * tw + ox + rx;
             double v;
             if (tx.r < 0) {
