@@ -12,10 +12,14 @@ What one STEP is ("image resident in host numpy" -> "`segm` r
       alpha-expansion (gc_regul 2.0, edge type 'model'), `classes_[graph_labels][slic]`, D2H of `segm` (int32).
       The class model is fitted once during warm-up (the reference's group-model flow, run_segm...:476-514).
   config 3  same image, `{'tLM': ('mean', 'std', 'energy')}` (Leung-Malik bank, F = 180): `--config 3`
-  config 4  a batch of 8 images of 647 x 1024 RGB uint8 per GPU (BASELINE: 64 images over 8 GPUs) through
-            `segment_batch_color2d_slic_features_model_graphcut`: `--config 4`
+  config 4  a batch of 8 images of 647 x 1024 RGB uint8 per GPU (BASELINE: 64 images over 8 GPUs, seeds 100..163) through
+            the one-call pipeline with the GROUP model of the reference's own run over the 64 images: `--config 4`
   config 5  one 64 x 4096 x 4096 float32 volume through `pipe_gray3d_slic_features_model_graphcut` (model fit
             included, as the reference function does): `--config 5`
+
+Without `--config` the line of config 2 carries `other_configs`: configs 3, 4 and a reduced config 5 (the 32 x 512 x 512 volume
+the reference itself was run on) timed in the same invocation with a few steps each, every one with its own equality keys
+against the reference's run at that size (tests/golden/reference_c{3,4,5}.npz, tests/golden/make_golden_configs.py).
 
 `value` = pixels (voxels) of all timed steps of all ranks / wall time, host to host.  M images are kept in flight per
 GPU (worker threads with one HIP stream and one recycled session each; a thread spends a step inside a handful of C
@@ -28,9 +32,11 @@ Separate keys carry the device-resident rate of the same pipeline (image already
 nothing else in flight (`latency_ms`).
 
 `roofline` and `stage_ms_per_step` come from a separate, un-overlapped pass on one stream (the dominant kernel is timed
-by a HIP event pair attached to its dispatch).  N > 1: one process per GPU (ranks from the launcher's environment),
-every rank segments its own image(s) (weak scaling, no data-path collective) and the label maps of every round of
-M steps are gathered in rank 0's HBM with one grouped RCCL send / recv (pyimsegm_amd.distributed, ctypes on librccl).
+by a HIP event pair attached to its dispatch).  N > 1: one process per GPU -- ranks from the launcher's environment, or,
+when `--gpus N` is given without one, N ranks spawned by this script itself -- every rank segments its own image(s) (weak
+scaling, no data-path collective) and the label maps of every round of M steps are gathered in rank 0's HBM with one
+grouped RCCL send / recv (pyimsegm_amd.distributed, ctypes on librccl); rank 0 checks the CRC of EVERY gathered map of a
+verification round against the reference's run.
 
 Prints ONE JSON line on rank 0.
 """
@@ -40,36 +46,78 @@ import os
 import sys
 import threading
 import time
+import zlib
 
 import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+GOLDEN = os.path.join(ROOT, 'tests', 'golden')
 
 SP_SIZE, SP_REGUL, NB_CLASSES, GC_REGUL, EDGE_TYPE = 46, 0.2, 3, 2.0, 'model'
 HEIGHT = WIDTH = 2048
+C4_SHAPE, C4_SP_SIZE, C4_PER_STEP, C4_FIRST_SEED, C4_NB_IMAGES = (647, 1024), 35, 8, 100, 64   # run_segm...:105-106 slic_size 35
+C5_PARAMS = dict(spacing=(1, 1, 1), sp_size=15, sp_regul=0.2, gc_regul=0.1)
+C5_REDUCED = (32, 512, 512)
+FEATURES_LM = {'tLM': ('mean', 'std', 'energy')}
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s
 FP64_VALU_PEAK_TFLOPS = 78.6   # MI355X_MICROARCH.md: fp64 vector (non-MFMA) peak
 ASSIGN_BYTES_PER_PX = 28.0     # read fp64 Lab 3 x 8 B + write int32 label 4 B per pixel per sweep
 VOL_ASSIGN_BYTES_PER_VOXEL = 8.0   # float32 volume: read 4 B + write int32 label 4 B per voxel per sweep
+METRIC = 'Mpixels/s end-to-end SLIC+fts+GC, 2048x2048 RGB; % HBM roofline'
 
 
-def parse_args():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
-    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--gpus', type=int, default=None)
     ap.add_argument('--steps', type=int, default=None)
     ap.add_argument('--warmup', type=int, default=None)
-    ap.add_argument('--config', type=int, default=2, choices=(2, 3, 4, 5))
+    ap.add_argument('--config', type=int, default=None, choices=(2, 3, 4, 5),
+                    help='default: config 2 with configs 3, 4 and a reduced 5 appended as `other_configs`')
     ap.add_argument('--size', type=int, default=None, help='image edge of configs 2 / 3 (default: the BASELINE 2048)')
     ap.add_argument('--volume', type=str, default='64,4096,4096', help='D,H,W of config 5')
     ap.add_argument('--inflight', type=int, default=0, help='images in flight per GPU (worker threads); 0 = default of the config')
     ap.add_argument('--pinned-input', type=int, default=0, help='1: the input images live in page-locked host memory')
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    return ap.parse_args()
+    ap.add_argument('--no-other-configs', action='store_true')
+    return ap.parse_args(argv)
+
+
+def crc32(arr, dtype=np.int32):
+    return zlib.crc32(np.ascontiguousarray(arr, dtype=dtype).tobytes())
+
+
+def load_golden(name):
+    path = os.path.join(GOLDEN, name)
+    return np.load(path, allow_pickle=False) if os.path.exists(path) else None
+
+
+def model_from_arrays(ref):
+    """scikit-learn `Pipeline([StandardScaler, GaussianMixture('full')])` with the parameters of a run of the reference
+    (tests/golden/reference_*.npz)"""
+    from sklearn.mixture import GaussianMixture
+    from sklearn.pipeline import Pipeline
+    from sklearn.preprocessing import StandardScaler
+    scaler = StandardScaler()
+    scaler.mean_, scaler.scale_ = ref['scaler_mean'], ref['scaler_scale']
+    scaler.var_, scaler.n_features_in_ = scaler.scale_**2, len(scaler.mean_)
+    scaler.n_samples_seen_ = 1
+    gmm = GaussianMixture(n_components=len(ref['gmm_weights']), covariance_type='full')
+    gmm.weights_, gmm.means_ = ref['gmm_weights'], ref['gmm_means']
+    gmm.covariances_, gmm.precisions_cholesky_ = ref['gmm_covariances'], ref['gmm_precisions_cholesky']
+    gmm.precisions_ = np.array([pc @ pc.T for pc in gmm.precisions_cholesky_])
+    gmm.converged_, gmm.n_features_in_ = True, scaler.n_features_in_
+    return Pipeline([('scaler', scaler), ('GMM', gmm)])
+
+
+def median_min(values):
+    values = sorted(values)
+    return values[len(values) // 2], values[0]
 
 
 # -----------------------------------------------------------------------------------------------------------------
-# CPU baseline (rank 0, N = 1): the reference's own legs where they exist on the box, the oracle port for the rest
+# CPU baseline (rank 0, N = 1): the reference's own legs where they exist on the box, the oracle port for the rest.
+# BASELINE.md section 3: warm-up 1, median of 5.
 # -----------------------------------------------------------------------------------------------------------------
 _SKIMAGE_SCRIPT = r'''
 import sys, time, warnings
@@ -78,23 +126,25 @@ import numpy as np
 from skimage.segmentation import slic
 import skimage
 img = np.load(sys.argv[1])
-sp_size, rc = float(sys.argv[3]), float(sys.argv[4])
+sp_size, rc, repeats = float(sys.argv[3]), float(sys.argv[4]), int(sys.argv[5])
 nb_pixels = img.shape[0] * img.shape[1]
 if img.min() != 0. or img.max() != 1.:                       # imsegm/superpixels.py:53-54
     img = (img - img.min()) / float(img.max() - img.min())
-t0 = time.perf_counter()
-labels = slic(img, n_segments=int(nb_pixels / sp_size**2), compactness=(sp_size * rc)**1.5, sigma=1,
-              enforce_connectivity=True, slic_zero=False)      # imsegm/superpixels.py:57-63
-t1 = time.perf_counter()
+times = []
+for _ in range(repeats):
+    t0 = time.perf_counter()
+    labels = slic(img, n_segments=int(nb_pixels / sp_size**2), compactness=(sp_size * rc)**1.5, sigma=1,
+                  enforce_connectivity=True, slic_zero=False)      # imsegm/superpixels.py:57-63
+    times.append(time.perf_counter() - t0)
 np.save(sys.argv[2], np.asarray(labels).astype(np.int32))
-print("%s %.4f" % (skimage.__version__, t1 - t0))
+print("%s %s" % (skimage.__version__, ",".join("%.4f" % t for t in times)))
 '''
 
 
-def real_skimage_slic(image, sp_size, sp_regul):
+def real_skimage_slic(image, sp_size, sp_regul, repeats=1):
     """the REAL `skimage.segmentation.slic` behind imsegm/superpixels.py:61-63, when the box carries the image's conda
-    Python 3.9 with scikit-image (the interpreter of this script cannot import it): (version, seconds of the slic
-    call on one host core, label map), or None"""
+    Python 3.9 with scikit-image (the interpreter of this script cannot import it): (version, seconds of every one of
+    `repeats` slic calls on one host core, label map), or None"""
     import subprocess
     import tempfile
     py = os.environ.get('IMSEGM_SKIMAGE_PYTHON', '/opt/conda/bin/python3.9')
@@ -104,30 +154,27 @@ def real_skimage_slic(image, sp_size, sp_regul):
         with tempfile.TemporaryDirectory() as tmp:
             src, dst = os.path.join(tmp, 'image.npy'), os.path.join(tmp, 'labels.npy')
             np.save(src, image)
-            run = subprocess.run([py, '-c', _SKIMAGE_SCRIPT, src, dst, str(sp_size), str(sp_regul)], capture_output=True,
-                                 text=True, timeout=600)
+            run = subprocess.run([py, '-c', _SKIMAGE_SCRIPT, src, dst, str(sp_size), str(sp_regul), str(repeats)],
+                                 capture_output=True, text=True, timeout=900)
             if run.returncode != 0:
                 return None
             version, seconds = run.stdout.split()[-2:]
-            return version, float(seconds), np.load(dst)
+            return version, [float(s) for s in seconds.split(',')], np.load(dst)
     except Exception:
         return None
 
 
-def cpu_baseline_color2d(image, model, sp_size, sp_regul):
-    """one full image through the CPU path on ONE host core (the reference is single-threaded per image):
-    SLIC = the real scikit-image when the box has it (else the oracle's C restatement), descriptors = the reference's own
+def _cpu_chain_color2d(image, model, sp_size, sp_regul, gc_regul, slic=None):
+    """the CPU path of one image after (or including) SLIC on one core: descriptors = the reference's own
     features_cython.pyx compiled into oracle/_ref (else the oracle's C restatement), graph / edge weights / GraphCut /
-    gathers = the oracle port (gco exists nowhere).  Returns (entry for the JSON line, segmentation of the port chain,
-    label map of the real scikit-image or None)."""
+    gathers = the oracle port (gco exists nowhere); returns (legs in seconds, segmentation, label map)"""
     from oracle import oracle as orc
     from pyimsegm_amd import graph_cuts as gc
-    orc.lib()
     parts = {}
-    t0 = time.perf_counter()
-    slic = orc.segment_slic_img2d(image, sp_size, sp_regul)
-    parts['slic_port_s'] = time.perf_counter() - t0
-    real = real_skimage_slic(image, sp_size, sp_regul)
+    if slic is None:
+        t0 = time.perf_counter()
+        slic = orc.segment_slic_img2d(image, sp_size, sp_regul)
+        parts['slic_port_s'] = time.perf_counter() - t0
     img32 = np.asarray(image, dtype=np.float32)
     seg32 = slic.astype(np.int32)
     ref = orc.ref_features_cython()
@@ -152,7 +199,7 @@ def cpu_baseline_color2d(image, model, sp_size, sp_regul):
     weights = weights / gc.compute_spatial_dist([tuple(c) for c in centres], edges, relative=True)
     weights = np.clip(weights, 1e-3, 1e3)
     unary = gc.compute_unary_cost(proba)
-    pairwise = gc.compute_pairwise_cost(GC_REGUL, proba.shape)
+    pairwise = gc.compute_pairwise_cost(gc_regul, proba.shape)
     parts['graph_terms_port_s'] = time.perf_counter() - t2
     t3 = time.perf_counter()
     labels = orc.cut_general_graph(edges, weights, unary, pairwise, n_iter=-1)
@@ -161,25 +208,49 @@ def cpu_baseline_color2d(image, model, sp_size, sp_regul):
     segm = labels[slic]
     _ = proba[slic]
     parts['gathers_s'] = time.perf_counter() - t4
-    slic_s = real[1] if real is not None else parts['slic_port_s']
-    desc_s = parts.get('descriptors_reference_s', parts['descriptors_port_s'])
-    total = slic_s + desc_s + parts['graph_terms_port_s'] + parts['graphcut_port_s'] + parts['gathers_s']
-    kind = 'reference+port' if (real is not None or ref is not None) else 'port'
+    return parts, segm, slic
+
+
+def cpu_baseline_color2d(image, model, sp_size, sp_regul, repeats=5):
+    """one full image through the CPU path on ONE host core (the reference is single-threaded per image): 1 warm-up +
+    `repeats` timed passes, median (and minimum) of the per-pass totals.  SLIC = the real scikit-image when the box has it
+    (else the oracle's C restatement).  Returns (entry for the JSON line, segmentation of the port chain, label map of
+    the real scikit-image or None)."""
+    from oracle import oracle as orc
+    orc.lib()
+    real = real_skimage_slic(image, sp_size, sp_regul, repeats=repeats + 1)
+    runs = []
+    segm = None
+    for i in range(repeats + 1):
+        parts, segm, _ = _cpu_chain_color2d(image, model, sp_size, sp_regul, GC_REGUL)
+        if real is not None:
+            parts['slic_reference_s'] = real[1][i]
+        runs.append(parts)
+    runs = runs[1:]                                   # the first pass is the warm-up
+
+    def total(p):
+        return (p.get('slic_reference_s', p['slic_port_s']) + p.get('descriptors_reference_s', p['descriptors_port_s'])
+                + p['graph_terms_port_s'] + p['graphcut_port_s'] + p['gathers_s'])
+
+    med, best = median_min([total(p) for p in runs])
+    legs = {k: round(median_min([p[k] for p in runs])[0], 4) for k in runs[0]}
+    npx = image.shape[0] * image.shape[1]
+    kind = 'reference+port' if (real is not None or 'descriptors_reference_s' in legs) else 'port'
     entry = {
-        'value': round(image.shape[0] * image.shape[1] / total / 1e6, 4),
-        'unit': 'Mpixels/s',
-        'cores': 1,
-        'kind': kind,
-        'sample': 'one full %dx%d image, %.1f s of CPU on one core: SLIC %.2f s (%s), descriptors %.3f s (%s), graph + edge '
-                  'weights %.2f s (port), GraphCut %.3f s (port; gco exists nowhere), gathers %.2f s'
-                  % (image.shape[0], image.shape[1], total, slic_s,
-                     'real scikit-image %s' % real[0] if real is not None else 'oracle C restatement', desc_s,
-                     "the reference's features_cython.pyx (oracle/_ref)" if ref is not None else 'oracle C restatement',
-                     parts['graph_terms_port_s'], parts['graphcut_port_s'], parts['gathers_s']),
-        'legs_s': {k: round(v, 4) for k, v in parts.items()},
+        'value': round(npx / med / 1e6, 4), 'unit': 'Mpixels/s', 'cores': 1, 'kind': kind,
+        'value_best_of_%d' % repeats: round(npx / best / 1e6, 4),
+        'sample': 'one full %dx%d image, 1 warm-up + %d timed passes on one core, median %.2f s (min %.2f s): SLIC %.2f s (%s), '
+                  'descriptors %.3f s (%s), graph + edge weights %.2f s (port), GraphCut %.3f s (port; gco exists nowhere), '
+                  'gathers %.2f s'
+                  % (image.shape[0], image.shape[1], repeats, med, best, legs.get('slic_reference_s', legs['slic_port_s']),
+                     'real scikit-image %s' % real[0] if real is not None else 'oracle C restatement',
+                     legs.get('descriptors_reference_s', legs['descriptors_port_s']),
+                     "the reference's features_cython.pyx (oracle/_ref)" if 'descriptors_reference_s' in legs else 'oracle C restatement',
+                     legs['graph_terms_port_s'], legs['graphcut_port_s'], legs['gathers_s']),
+        'legs_s_median': legs,
     }
     if real is not None:
-        entry['reference_slic'] = {'scikit_image': real[0], 'seconds': round(real[1], 3), 'cores': 1}
+        entry['reference_slic'] = {'scikit_image': real[0], 'seconds_median': round(median_min(real[1][1:])[0], 3), 'cores': 1}
     try:     # the reference ITSELF, whole pipeline, timed in the build container (tools/time_reference.py)
         with open(os.path.join(ROOT, 'profiles', 'reference_time_r02.json')) as fp:
             entry['reference_whole_pipeline_build_container'] = json.load(fp)
@@ -188,64 +259,198 @@ def cpu_baseline_color2d(image, model, sp_size, sp_regul):
     return entry, segm, (real[2] if real is not None else None)
 
 
-def load_reference_model():
-    """class model of the reference's own run on the benchmark image (tests/golden/reference_2048.npz)"""
-    from sklearn.mixture import GaussianMixture
-    from sklearn.pipeline import Pipeline
-    from sklearn.preprocessing import StandardScaler
-    path = os.path.join(ROOT, 'tests', 'golden', 'reference_2048.npz')
-    if not os.path.exists(path):
-        return None, None
-    ref = np.load(path, allow_pickle=False)
-    scaler = StandardScaler()
-    scaler.mean_, scaler.scale_ = ref['scaler_mean'], ref['scaler_scale']
-    scaler.var_, scaler.n_features_in_ = scaler.scale_**2, len(scaler.mean_)
-    gmm = GaussianMixture(n_components=len(ref['gmm_weights']), covariance_type='full')
-    gmm.weights_, gmm.means_ = ref['gmm_weights'], ref['gmm_means']
-    gmm.covariances_, gmm.precisions_cholesky_ = ref['gmm_covariances'], ref['gmm_precisions_cholesky']
-    gmm.precisions_ = np.array([pc @ pc.T for pc in gmm.precisions_cholesky_])
-    gmm.converged_, gmm.n_features_in_ = True, scaler.n_features_in_
-    return Pipeline([('scaler', scaler), ('GMM', gmm)]), ref
+def _pool_one_image(task):
+    seed, sp_size, sp_regul, gc_regul, arrays = task
+    try:
+        from threadpoolctl import threadpool_limits
+        threadpool_limits(limits=1)
+    except Exception:
+        pass
+    from pyimsegm_amd.utilities.synthetic import voronoi_image
+    image = voronoi_image(C4_SHAPE[0], C4_SHAPE[1], seed=seed)
+    t0 = time.perf_counter()
+    _cpu_chain_color2d(image, model_from_arrays(arrays), sp_size, sp_regul, gc_regul)
+    return time.perf_counter() - t0
 
 
-def compare_with_reference_run(image, pipe):
+def cpu_baseline_batch(model_arrays, sp_size, sp_regul, nb_images=None):
+    """config 4 on the host as the reference's driver runs it: a pool of `int(0.9 * nproc)` worker processes mapped over
+    the images (run_segm_slic_model_graphcut.py:61, experiments.py:392-403), every worker one image at a time on one core;
+    bounded sample of 2 images per worker.  The per-image chain is the oracle port (its SLIC runs within 2 % of the real
+    scikit-image's time, see the config-2 baseline)."""
+    import multiprocessing as mp
+    nproc = os.cpu_count() or 1
+    workers = max(1, int(0.9 * nproc))
+    nb_images = nb_images or min(C4_NB_IMAGES, 2 * workers)
+    tasks = [(C4_FIRST_SEED + i, sp_size, sp_regul, GC_REGUL, model_arrays) for i in range(nb_images)]
+    with mp.get_context('spawn').Pool(workers) as pool:
+        pool.map(_pool_one_image, tasks[:workers])                  # warm-up: imports, library loads
+        t0 = time.perf_counter()
+        per_image = pool.map(_pool_one_image, tasks, chunksize=1)
+        wall = time.perf_counter() - t0
+    npx = C4_SHAPE[0] * C4_SHAPE[1]
+    return {'value': round(nb_images * npx / wall / 1e6, 4), 'unit': 'Mpixels/s', 'cores': workers, 'kind': 'port',
+            'sample': '%d images of %dx%d over a pool of %d worker processes (int(0.9 * %d cpus), as the reference driver), wall %.2f s; '
+                      'one image on one core: median %.2f s' % (nb_images, C4_SHAPE[0], C4_SHAPE[1], workers, nproc, wall,
+                                                                  median_min(per_image)[0]),
+            'one_core_value': round(npx / median_min(per_image)[0] / 1e6, 4)}
+
+
+def cpu_baseline_volume(shape_full, crop=(64, 256, 256)):
+    """config 5 on one host core: the oracle port (C restatement of scikit-image's float32 3-D SLIC + measure.label, the
+    reference's gray statistics, graph, GraphCut) on a crop, extrapolated linearly in the number of voxels (BASELINE.md
+    section 3: the reference's own per-voxel Python loops make the full volume infeasible)"""
+    from oracle import oracle as orc
+    from pyimsegm_amd import descriptors as d
+    from pyimsegm_amd import graph_cuts as gc
+    from pyimsegm_amd.utilities.synthetic import config5_volume
+    crop = tuple(min(c, s) for c, s in zip(crop, shape_full))
+    vol = config5_volume(crop)
+    p = C5_PARAMS
+    t0 = time.perf_counter()
+    slic = orc.segment_slic_img3d_gray(vol, p['sp_size'], p['sp_regul'], p['spacing'])
+    t_slic = time.perf_counter() - t0
+    seg32 = slic.astype(np.int32)
+    mean = orc.gray3d_stat(vol, seg32, 'mean')
+    var = orc.gray3d_stat(vol, seg32, 'var', mean.astype(np.float32))
+    energy = orc.gray3d_stat(vol, seg32, 'energy')
+    features = np.nan_to_num(np.stack([mean, np.sqrt(var), energy], axis=1))
+    features, _ = d.norm_features(features)
+    t1 = time.perf_counter()
+    np.random.seed(0)
+    model = gc.estim_class_model(features, NB_CLASSES)
+    proba = model.predict_proba(features)
+    t_fit = time.perf_counter() - t1
+    _, edges = orc.adjacency(slic)
+    edges = np.array(edges, dtype=np.int32)
+    weights = gc.compute_edge_model(edges, proba, 'lT')
+    weights = np.clip(weights / gc.compute_spatial_dist(orc.centers(slic), edges, relative=True), 1e-3, 1e3)
+    labels = orc.cut_general_graph(edges, weights, gc.compute_unary_cost(proba), gc.compute_pairwise_cost(p['gc_regul'], proba.shape),
+                                   n_iter=-1)
+    _ = np.asarray(labels)[slic]
+    total = time.perf_counter() - t0
+    nvox = int(np.prod(crop))
+    return {'value': round(nvox / total / 1e6, 4), 'unit': 'Mpixels/s', 'cores': 1, 'kind': 'port',
+            'sample': '%dx%dx%d crop of the volume on one core, %.1f s (SLIC + measure.label %.1f s, model fit %.1f s); the rate is '
+                      'EXTRAPOLATED linearly to the full volume' % (crop + (total, t_slic, t_fit)),
+            'extrapolated_seconds_full_volume': round(total * float(np.prod(shape_full)) / nvox, 1)}
+
+
+# -----------------------------------------------------------------------------------------------------------------
+# equality with the reference's own run at the size of each config (tests/golden/make_golden_*.py)
+# -----------------------------------------------------------------------------------------------------------------
+def compare_config2(image, pipe):
     """one extra, untimed GPU pass with the class model of the reference's own run on the benchmark image (real
     scikit-image 0.18.3 + the reference's Cython descriptors + its scikit-learn GMM, gco bridged to the oracle; label maps
     stored as CRC32): the superpixel map and the final segmentation of the GPU must have the same checksums"""
-    import zlib
-    model, ref = load_reference_model()
-    if model is None or zlib.crc32(np.ascontiguousarray(image).tobytes()) != int(ref['image_crc']):
+    ref = load_golden('reference_2048.npz')
+    if ref is None or crc32(image, np.uint8) != int(ref['image_crc']):
         return None
     from pyimsegm_amd.descriptors import FEATURES_SET_COLOR
+    model = model_from_arrays(ref)
     res = pipe._ResidentImage(image, FEATURES_SET_COLOR, SP_SIZE, SP_REGUL)
     try:
         segm, _ = res.segment(None, GC_REGUL, EDGE_TYPE, to_host=True, want_soft=False, model=model)
         slic = res.slic
     finally:
         res.close()
-    slic_ok = zlib.crc32(np.ascontiguousarray(slic, dtype=np.int32).tobytes()) == int(ref['slic_crc'])
-    segm_ok = zlib.crc32(np.ascontiguousarray(segm, dtype=np.int32).tobytes()) == int(ref['segm_crc'])
+    slic_ok = crc32(slic) == int(ref['slic_crc'])
+    segm_ok = crc32(segm) == int(ref['segm_crc'])
     return {'gpu_equals_reference_run': bool(slic_ok and segm_ok),
             'reference_run': 'tests/golden/reference_2048.npz: the reference itself on this image (%s), superpixel map %s, '
-                             'segmentation %s' % (str(ref['versions']), 'equal' if slic_ok else 'DIFFERENT',
-                                                  'equal' if segm_ok else 'DIFFERENT')}
+                             'segmentation %s (the cut of that run is the oracle\'s: gco exists nowhere)'
+                             % (str(ref['versions']), 'equal' if slic_ok else 'DIFFERENT', 'equal' if segm_ok else 'DIFFERENT')}
+
+
+def compare_config3(image, pipe):
+    """configs[2] at full size: superpixel map (CRC), the K x 180 Leung-Malik descriptors (1e-5) and, under the reference
+    run's class model, the segmentation (CRC) against tests/golden/reference_c3.npz"""
+    ref = load_golden('reference_c3.npz')
+    if ref is None or crc32(image, np.uint8) != int(ref['image_crc']):
+        return None
+    model = model_from_arrays(ref)
+    res = pipe._ResidentImage(image, FEATURES_LM, SP_SIZE, SP_REGUL)
+    try:
+        features = np.array(res.features)
+        segm, _ = res.segment(None, GC_REGUL, EDGE_TYPE, to_host=True, want_soft=False, model=model)
+        slic = res.slic
+    finally:
+        res.close()
+    slic_ok = crc32(slic) == int(ref['slic_crc'])
+    fts_ok = features.shape == ref['features'].shape and bool(np.allclose(features, ref['features'], rtol=1e-5, atol=1e-5))
+    err = float(np.max(np.abs(features - ref['features']))) if features.shape == ref['features'].shape else None
+    segm_ok = crc32(segm) == int(ref['segm_crc'])
+    counts = np.bincount(np.asarray(segm).ravel(), minlength=len(ref['class_counts']))
+    return {'gpu_equals_reference_run': bool(slic_ok and fts_ok and segm_ok),
+            'reference_run': 'tests/golden/reference_c3.npz (%s): superpixel map %s, %d x %d descriptors %s (max abs difference %.3g, '
+                             'tolerance 1e-5), segmentation %s (pixels per class %s vs %s)'
+                             % (str(ref['versions']), 'equal' if slic_ok else 'DIFFERENT', features.shape[0], features.shape[1],
+                                'equal within tolerance' if fts_ok else 'DIFFERENT', err if err is not None else float('nan'),
+                                'equal' if segm_ok else 'DIFFERENT', counts.tolist(), ref['class_counts'].tolist())}
+
+
+def compare_config5(shape, pipe):
+    """configs[4]: the float32 supervoxel map against the real scikit-image's (CRC), and on the reduced volume also the
+    descriptors (1e-5) and -- under the class probabilities of the reference's run -- the segmentation (CRC)"""
+    from pyimsegm_amd.descriptors import compute_selected_features_gray3d
+    from pyimsegm_amd.graph_cuts import compute_pairwise_cost
+    from pyimsegm_amd.superpixels import _open_volume, _run_slic3d
+    from pyimsegm_amd.utilities.synthetic import config5_volume
+    ref = None
+    for name in ('reference_c5.npz', 'reference_c5_full.npz'):
+        cand = load_golden(name)
+        if cand is not None and tuple(int(v) for v in cand['shape']) == tuple(shape):
+            ref = cand
+    if ref is None:
+        return None
+    vol = config5_volume(tuple(shape))
+    if crc32(vol, np.float32) != int(ref['volume_crc']):
+        return None
+    p = C5_PARAMS
+    sess = _open_volume(vol)
+    try:
+        _run_slic3d(sess, p['sp_size'], p['sp_regul'], p['spacing'])
+        labels = sess.get_labels_int32()
+        slic_ok = crc32(labels) == int(ref['slic_crc'])
+        nb_ok = sess.n_labels == int(ref['nb_supervoxels'])
+        out = {'gpu_slic_equals_scikit_image': bool(slic_ok and nb_ok)}
+        text = 'supervoxel map %s (K = %d vs %d)' % ('equal' if slic_ok else 'DIFFERENT', sess.n_labels, int(ref['nb_supervoxels']))
+        if 'features' in ref.files:
+            features, _ = compute_selected_features_gray3d(vol, pipe._ShapeOnly(sess.shape), {'color': ('mean', 'std', 'energy')}, sess=sess)
+            features[np.isnan(features)] = 0
+            fts_ok = features.shape == ref['features'].shape and bool(np.allclose(features, ref['features'], rtol=1e-5, atol=1e-5))
+            segm = sess.segment(compute_pairwise_cost(p['gc_regul'], ref['proba'].shape), 'model', proba=ref['proba'], pinned=False)['segm']
+            segm_ok = crc32(segm) == int(ref['segm_crc'])
+            out['gpu_equals_reference_run'] = bool(slic_ok and nb_ok and fts_ok and segm_ok)
+            text += ', descriptors %s, segmentation under the class probabilities of that run %s' % (
+                'equal within 1e-5' if fts_ok else 'DIFFERENT', 'equal' if segm_ok else 'DIFFERENT')
+        out['reference_run'] = '%s (%s): %s' % ('tests/golden/reference_c5.npz' if 'features' in ref.files else
+                                                'tests/golden/reference_c5_full.npz', str(ref['versions']), text)
+        return out
+    finally:
+        sess.close()
 
 
 # -----------------------------------------------------------------------------------------------------------------
 # steady-state runner: M worker threads take W + K + M steps back to back
 # -----------------------------------------------------------------------------------------------------------------
+RING_ROUNDS = 4
+
+
 class SteadyRun(object):
     def __init__(self, group, inflight, make_worker_state, do_step, gather_item_bytes=0, items_per_step=1):
         """make_worker_state() -> per-thread state (own HIP context); do_step(state, index, stage) runs one step and
         calls stage(k, handle) for the label map of its k-th image (handle: device array of the map); with more than
-        one rank the maps of every round of `inflight` steps go to rank 0 in one grouped RCCL call"""
+        one rank the maps of every round of `inflight` steps go to rank 0 in one grouped RCCL call.  No host-side exchange
+        happens inside the timed region: a rank whose worker failed keeps taking part in the rounds (with whatever its send
+        ring holds) and the error is agreed on after the last round."""
         self.group, self.inflight = group, inflight
         self.make_worker_state, self.do_step = make_worker_state, do_step
         self.gather = None
         self.item_bytes, self.items_per_step = gather_item_bytes, items_per_step
         if group.distributed and gather_item_bytes:
             from pyimsegm_amd.distributed import DeviceGather
-            self.gather = DeviceGather(group, gather_item_bytes * items_per_step, inflight)
+            self.gather = DeviceGather(group, gather_item_bytes * items_per_step, inflight, depth=RING_ROUNDS)
 
     def run(self, warmup, steps):
         from pyimsegm_amd import _hip
@@ -276,8 +481,8 @@ class SteadyRun(object):
                         break
                     rnd, item = divmod(i, M)
                     if self.gather is not None:
-                        with cond:                                    # the send ring holds two rounds
-                            cond.wait_for(lambda: flushed[0] >= rnd - 1 or errors)
+                        with cond:                                    # the send ring holds RING_ROUNDS rounds
+                            cond.wait_for(lambda: flushed[0] >= rnd - (RING_ROUNDS - 1) or errors)
 
                         def stage(k, handle, rnd=rnd, item=item):
                             self.gather.stage(rnd, item, handle, state['ctx'], offset=k * self.item_bytes, nbytes=self.item_bytes)
@@ -301,7 +506,10 @@ class SteadyRun(object):
         try:
             ready.wait()
         except threading.BrokenBarrierError:
+            group.any_over_ranks(True)
             raise RuntimeError('a worker thread failed during set-up: %r' % (errors[:1], ))
+        if group.any_over_ranks(False):
+            raise RuntimeError('set-up failed on another rank')
         ctx = _hip.default_context()
         ctx.synchronize()
         group.barrier()
@@ -312,9 +520,7 @@ class SteadyRun(object):
             for rnd in range(rounds):
                 for i in range(rnd * M, min((rnd + 1) * M, total)):
                     staged[i].wait()
-                if group.any_over_ranks(bool(errors)):
-                    break
-                self.gather.flush(rnd)
+                self.gather.flush(rnd)            # collective; a failed rank sends what its ring holds, see any_over_ranks below
                 gather_done[rnd] = time.perf_counter()
                 with cond:
                     flushed[0] = rnd + 1
@@ -324,8 +530,11 @@ class SteadyRun(object):
         ctx.synchronize()
         group.barrier()
         t_end = time.perf_counter()
+        failed = group.any_over_ranks(bool(errors))
         if errors:
             raise RuntimeError('a worker thread failed: %r' % (errors[0], ))
+        if failed:
+            raise RuntimeError('a worker thread failed on another rank')
         order = sorted(done)
         t0 = order[warmup - 1] if warmup > 0 else t_start
         t1 = order[warmup + steps - 1]
@@ -334,6 +543,28 @@ class SteadyRun(object):
         elapsed = group.max_over_ranks(t1 - t0)
         cold = group.max_over_ranks(t_end - t_start) / total
         return elapsed, cold
+
+    def verify_round(self, state, do_step):
+        """one extra, untimed round: every rank runs `do_step` once (item 0 of the round), the round is gathered, and rank 0
+        gets every rank's staged maps as host arrays: list over ranks of uint8 buffers of items_per_step * item_bytes"""
+        if self.gather is None:
+            return None
+        rnd = self.gather.rounds_done
+        g = self.gather
+
+        def stage(k, handle):
+            g.stage(rnd, 0, handle, state['ctx'], offset=k * self.item_bytes, nbytes=self.item_bytes)
+
+        do_step(state, -2, stage)
+        out = g.flush(rnd)
+        step_bytes = self.item_bytes * self.items_per_step
+        if self.group.rank != 0:
+            return None
+        if out is not None:                        # host plane: [rank][slot][part]
+            return [np.concatenate([np.ascontiguousarray(part).view(np.uint8).ravel() for part in items[0]]) for items in out]
+        host = np.empty((self.group.world, g.round_bytes), dtype=np.uint8)
+        g.ctx.copy(host.ctypes.data, g.recv, host.nbytes, synchronize=True)
+        return [host[r, :step_bytes] for r in range(self.group.world)]
 
     def close(self):
         if self.gather is not None:
@@ -352,35 +583,45 @@ def host_image(image, pinned):
 # -----------------------------------------------------------------------------------------------------------------
 # configs 2 / 3 / 4: colour images through segment_color2d_slic_features_model_graphcut
 # -----------------------------------------------------------------------------------------------------------------
-def bench_color2d(args, group):
+def bench_color2d(args, group, cfg, quick=False):
     from pyimsegm_amd import _hip
     from pyimsegm_amd import pipelines as pipe
     from pyimsegm_amd.descriptors import FEATURES_SET_COLOR
     from pyimsegm_amd.graph_cuts import estim_class_model
     from pyimsegm_amd.utilities.synthetic import voronoi_image
 
-    cfg, world, rank = args.config, group.world, group.rank
+    world, rank = group.world, group.rank
+    golden4 = load_golden('reference_c4.npz') if cfg == 4 else None
     if cfg == 4:
-        height, width, sp_size, per_step = 647, 1024, 35, 8          # run_segm...:105-106 slic_size 35; 64 images / 8 GPUs
-        images = [voronoi_image(height, width, seed=100 + rank * per_step + i) for i in range(per_step)]
+        (height, width), sp_size, per_step = C4_SHAPE, C4_SP_SIZE, C4_PER_STEP
+        seeds = [C4_FIRST_SEED + (rank * per_step + i) % C4_NB_IMAGES for i in range(per_step)]
+        images = [voronoi_image(height, width, seed=s) for s in seeds]
         features = FEATURES_SET_COLOR
     else:
         height = width = args.size or HEIGHT
         sp_size, per_step = SP_SIZE, 1
-        images = [voronoi_image(height, width, seed=1 + rank)]
-        features = FEATURES_SET_COLOR if cfg == 2 else {'tLM': ('mean', 'std', 'energy')}
+        seeds = [1 + rank]
+        images = [voronoi_image(height, width, seed=seeds[0])]
+        features = FEATURES_SET_COLOR if cfg == 2 else FEATURES_LM
     images = [host_image(im, args.pinned_input) for im in images]
-    steps = args.steps if args.steps is not None else {2: 100, 3: 5, 4: 40}[cfg]
-    warmup = args.warmup if args.warmup is not None else {2: 3, 3: 1, 4: 3}[cfg]
+    steps = args.steps if (args.steps is not None and not quick) else ({3: 3, 4: 20}[cfg] if quick else {2: 100, 3: 5, 4: 40}[cfg])
+    warmup = args.warmup if (args.warmup is not None and not quick) else {2: 3, 3: 1, 4: 3}[cfg]
     inflight = args.inflight if args.inflight > 0 else {2: 3, 3: 2, 4: 4}[cfg]
     npx_step = per_step * height * width
 
-    # model fit once, outside the timed region (the reference's group-model flow)
+    # class model: fitted once, outside the timed region (the reference's group-model flow); config 4 takes the group model
+    # of the reference's own run over the 64 images, so that every rank works with the same model and every label map
+    # can be checked against that run
     np.random.seed(0)
     ctx = _hip.default_context()
-    res0 = pipe._ResidentImage(images[0], features, sp_size, SP_REGUL)
-    model = estim_class_model(res0.features, NB_CLASSES, 'GMM', None, True)
-    res0.close()
+    if golden4 is not None:
+        model = model_from_arrays(golden4)
+        model_source = 'group model of the reference run over the 64 images (tests/golden/reference_c4.npz)'
+    else:
+        res0 = pipe._ResidentImage(images[0], features, sp_size, SP_REGUL)
+        model = estim_class_model(res0.features, NB_CLASSES, 'GMM', None, True)
+        res0.close()
+        model_source = 'fitted on the first image of the rank during warm-up'
     on_device = pipe._device_gmm(model) is not None
     classes = getattr(model, 'classes_', None)
 
@@ -412,6 +653,44 @@ def bench_color2d(args, group):
 
     runner = SteadyRun(group, inflight, make_state, do_step, gather_item_bytes=height * width * 4, items_per_step=per_step)
     elapsed, cold = runner.run(warmup, steps)
+
+    # ---- every gathered label map against the reference's run (N > 1: the first multi-GPU run validates the RCCL gather)
+    verdict = {}
+    if cfg == 4 and golden4 is not None:
+        want = {int(s): int(c) for s, c in zip(golden4['seeds'], golden4['segm_crc'])}
+        if group.distributed:
+            maps = runner.verify_round(make_state(), do_step)
+            if rank == 0:
+                bad = []
+                for r, buf in enumerate(maps):
+                    for k in range(per_step):
+                        seed = C4_FIRST_SEED + (r * per_step + k) % C4_NB_IMAGES
+                        got = zlib.crc32(np.ascontiguousarray(buf[k * height * width * 4:(k + 1) * height * width * 4]).tobytes())
+                        if got != want[seed]:
+                            bad.append((r, seed))
+                verdict['gathered_maps_equal_reference_run'] = not bad
+                verdict['gathered_maps_checked'] = world * per_step
+                if bad:
+                    verdict['gathered_maps_different'] = bad[:16]
+        if rank == 0:
+            slic_want = {int(s): int(c) for s, c in zip(golden4['seeds'], golden4['slic_crc'])}
+            check_seeds = list(range(C4_FIRST_SEED, C4_FIRST_SEED + C4_NB_IMAGES)) if (world == 1 and not quick) else seeds
+            bad_segm, bad_slic = [], []
+            for s in check_seeds:
+                img = images[seeds.index(s)] if s in seeds else voronoi_image(height, width, seed=s)
+                res = pipe._ResidentImage(img, features, sp_size, SP_REGUL, reuse=True, features_to_host=False)
+                try:
+                    segm, _ = res.segment(None, GC_REGUL, EDGE_TYPE, classes=classes, to_host=True, want_soft=False, model=model)
+                    if crc32(res.slic) != slic_want[s]:
+                        bad_slic.append(s)
+                    if crc32(segm) != want[s]:
+                        bad_segm.append(s)
+                finally:
+                    res.close()
+            verdict['gpu_equals_reference_run'] = not bad_segm and not bad_slic
+            verdict['reference_run'] = ('tests/golden/reference_c4.npz (%s): %d images checked (seeds %d..%d), superpixel maps different: %s, '
+                                        'segmentations different: %s' % (str(golden4['versions']), len(check_seeds), check_seeds[0],
+                                                                          check_seeds[-1], bad_slic or 'none', bad_segm or 'none'))
     runner.close()
 
     # ---- separate figures: device-resident rate, soft D2H, single-image latency (un-timed for `value`)
@@ -422,7 +701,7 @@ def bench_color2d(args, group):
         for _ in range(3):
             one_image(images[0])
         extras['latency_ms'] = round((time.perf_counter() - t) / 3 * 1e3, 3)
-        if cfg != 4:
+        if cfg != 4 and not quick:
             resident = {'sessions': []}
 
             def make_resident():
@@ -477,35 +756,38 @@ def bench_color2d(args, group):
                         'algorithmic_flops_per_image': flops, 'battery_ms_per_image': round(tex_ms / prof_steps, 3)}
         else:
             assign_ms, assign_n = stage_ms['slic_assign']
+            sweeps = _hip.assign_sweeps_per_launch() if hasattr(_hip, 'assign_sweeps_per_launch') else 1
             avg_s = assign_ms / max(assign_n, 1) / 1e3
-            achieved = ASSIGN_BYTES_PER_PX * npx / avg_s / 1e9 if assign_n else 0.0
+            achieved = ASSIGN_BYTES_PER_PX * npx * sweeps / avg_s / 1e9 if assign_n else 0.0
             traffic = None
             try:   # HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
                 with open(os.path.join(ROOT, 'profiles', 'pmc_traffic.json')) as fp:
                     pmc = json.load(fp)
-                if (height, width) == (HEIGHT, WIDTH):
+                if (height, width) == (HEIGHT, WIDTH) and int(pmc.get('sweeps_per_launch', 1)) == sweeps:
                     traffic = pmc['hbm_bytes_per_launch']
             except Exception:
                 pass
-            roofline = {'bound': 'hbm', 'kernel': 'k_slic_assign_dot (assignment + fused centroid accumulation; all sweeps)',
+            kernel = ('k_slic_sweeps (ONE persistent launch for all %d sweeps: per-tile candidate lists, assignment, fused centroid '
+                      'accumulation and centroid update)' % sweeps) if sweeps > 1 else \
+                'k_slic_assign_dot (assignment + fused centroid accumulation; all sweeps)'
+            roofline = {'bound': 'hbm', 'kernel': kernel,
                         'achieved': round(achieved, 2), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                         'frac': round(achieved / HBM_PEAK_GBS, 5), 'traffic': traffic,
                         'traffic_source': 'profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)',
-                        'avg_kernel_us': round(avg_s * 1e6, 3), 'launches': assign_n,
-                        'algorithmic_bytes_per_launch': ASSIGN_BYTES_PER_PX * npx}
+                        'avg_kernel_us': round(avg_s * 1e6, 3), 'launches': assign_n, 'sweeps_per_launch': sweeps,
+                        'algorithmic_bytes_per_launch': ASSIGN_BYTES_PER_PX * npx * sweeps}
         workload = {
             2: 'single %dx%d RGB uint8 per GPU, SLIC(sp_size=46, K=2025, 10 sweeps) + colour mean/std/energy + 3-class '
                'alpha-expansion GC (gc_regul=2.0, edge=model), pre-fitted GMM, host numpy in -> segm int32 in host numpy '
                '(BASELINE configs[1])' % (height, width),
             3: 'single %dx%d RGB uint8 per GPU, SLIC(sp_size=46) + full Leung-Malik bank (76 kernels 33x33, sigma=150 high-pass, '
-               'F=180) + 3-class GC, pre-fitted GMM (scikit-learn on the host: F > 32), host in -> host out (BASELINE '
-               'configs[2])' % (height, width),
-            4: 'batch of %d images %dx%d RGB uint8 per GPU per step (BASELINE configs[3]: 64 images over 8 GPUs), '
+               'F=180) + 3-class GC, pre-fitted GMM, host in -> host out (BASELINE configs[2])' % (height, width),
+            4: 'batch of %d images %dx%d RGB uint8 per GPU per step (BASELINE configs[3]: 64 images over 8 GPUs, seeds 100..163), '
                'SLIC(sp_size=35) + colour mean/std/energy + 3-class GC, pre-fitted GMM, host in -> host out'
                % (per_step, height, width),
         }[cfg]
         out = {
-            'metric': 'Mpixels/s end-to-end SLIC+fts+GC, 2048x2048 RGB; % HBM roofline',
+            'metric': METRIC,
             'value': round(value, 3), 'unit': 'Mpixels/s', 'n_gpus': world, 'steps': steps, 'warmup': warmup,
             'ms_per_step': round(elapsed / steps * 1e3, 4), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': 'f64', 'data': 'synthetic',
@@ -515,7 +797,7 @@ def bench_color2d(args, group):
                 'timed_region': 'host numpy image -> H2D -> SLIC -> descriptors -> class model -> graph-cut terms -> '
                                 'alpha-expansion -> gathers -> D2H -> segm in host numpy (page-locked result array); model fit outside',
                 'input_memory': 'page-locked' if args.pinned_input else 'pageable numpy',
-                'class_model': 'device (scaler + full-covariance GMM)' if on_device else 'host scikit-learn predict_proba',
+                'class_model': ('device (scaler + full-covariance GMM)' if on_device else 'host scikit-learn predict_proba') + '; ' + model_source,
                 'timing': 'steady state: %d warm-up + %d timed + %d cool-down steps back to back, clock from completion of '
                           'step W to completion of step W+K' % (warmup, steps, inflight),
                 'parallelism': 'images sharded over %d GPU(s), %d in flight per GPU (one HIP stream each)%s'
@@ -528,7 +810,8 @@ def bench_color2d(args, group):
             'stage_note': 'stage and roofline figures: separate pass of %d un-overlapped host-to-host images on one stream' % prof_steps,
         }
         out.update(extras)
-        if world == 1 and not args.no_cpu_baseline and cfg in (2, 4):
+        out.update(verdict)
+        if world == 1 and not args.no_cpu_baseline and cfg == 2 and not quick:
             try:
                 base, segm_cpu, slic_real = cpu_baseline_color2d(np.asarray(images[0]), model, sp_size, SP_REGUL)
                 out['cpu_baseline'] = base
@@ -541,9 +824,18 @@ def bench_color2d(args, group):
                     res.close()
             except Exception as ex:   # the baseline is a reported extra, never a reason to lose the line
                 out['cpu_baseline'] = {'error': repr(ex)}
-        if world == 1 and cfg == 2 and (height, width) == (HEIGHT, WIDTH):
-            try:      # the reference's own run on this very image (build container, tests/golden/make_golden_reference.py)
-                verdict = compare_with_reference_run(np.asarray(images[0]), pipe)
+        if world == 1 and not args.no_cpu_baseline and cfg == 4:
+            try:
+                arrays = {k: np.array(golden4[k]) for k in ('scaler_mean', 'scaler_scale', 'gmm_weights', 'gmm_means', 'gmm_covariances',
+                                                            'gmm_precisions_cholesky')} if golden4 is not None else None
+                if arrays is not None:
+                    out['cpu_baseline'] = cpu_baseline_batch(arrays, sp_size, SP_REGUL)
+                    out['speedup_vs_cpu_baseline'] = round(value / out['cpu_baseline']['value'], 2)
+            except Exception as ex:
+                out['cpu_baseline'] = {'error': repr(ex)}
+        if world == 1 and (height, width) == (HEIGHT, WIDTH) and cfg in (2, 3):
+            try:      # the reference's own run on this very image (build container, tests/golden/make_golden_*.py)
+                verdict = (compare_config2 if cfg == 2 else compare_config3)(np.asarray(images[0]), pipe)
                 if verdict is not None:
                     out.update(verdict)
             except Exception as ex:
@@ -554,24 +846,23 @@ def bench_color2d(args, group):
 # -----------------------------------------------------------------------------------------------------------------
 # config 5: one gray volume through pipe_gray3d_slic_features_model_graphcut
 # -----------------------------------------------------------------------------------------------------------------
-def bench_volume(args, group):
+def bench_volume(args, group, shape=None, quick=False):
     from pyimsegm_amd import _hip
     from pyimsegm_amd import pipelines as pipe
-    from pyimsegm_amd.utilities.synthetic import ellipsoid_volume
+    from pyimsegm_amd.utilities.synthetic import config5_volume
 
-    shape = tuple(int(v) for v in args.volume.split(','))
-    steps = args.steps if args.steps is not None else 2
-    warmup = args.warmup if args.warmup is not None else 1
-    rng = np.random.default_rng(5 + group.rank)
-    vol = ellipsoid_volume(shape).astype(np.float32)                      # float32: SURVEY 8(d) C5
-    vol += (0.05 * rng.standard_normal(shape, dtype=np.float32))
+    shape = tuple(shape) if shape is not None else tuple(int(v) for v in args.volume.split(','))
+    steps = args.steps if (args.steps is not None and not quick) else 2
+    warmup = args.warmup if (args.warmup is not None and not quick) else 1
+    vol = config5_volume(shape, seed=5 + group.rank)                      # float32: SURVEY 8(d) C5
     feats = {'color': ('mean', 'std', 'energy')}
     ctx = _hip.default_context()
+    p = C5_PARAMS
 
     def step():
         np.random.seed(0)
-        return pipe.pipe_gray3d_slic_features_model_graphcut(vol, NB_CLASSES, feats, spacing=(1, 1, 1), sp_size=15, sp_regul=0.2,
-                                                             gc_regul=0.1)
+        return pipe.pipe_gray3d_slic_features_model_graphcut(vol, NB_CLASSES, feats, spacing=p['spacing'], sp_size=p['sp_size'],
+                                                             sp_regul=p['sp_regul'], gc_regul=p['gc_regul'])
 
     for _ in range(warmup):
         step()
@@ -591,10 +882,22 @@ def bench_volume(args, group):
     if group.rank != 0:
         return None
     nvox = int(np.prod(shape))
+    assign_ms, assign_n = stage_ms['slic_assign']
     slic_ms = stage_ms['slic'][0]
-    achieved = 10 * VOL_ASSIGN_BYTES_PER_VOXEL * nvox / (slic_ms / 1e3) / 1e9 if slic_ms else 0.0
-    return {
-        'metric': 'Mpixels/s end-to-end SLIC+fts+GC, 2048x2048 RGB; % HBM roofline',
+    if assign_n:           # the assignment kernel itself (HIP events on its dispatches), 8 B/voxel/sweep
+        avg_s = assign_ms / assign_n / 1e3
+        roofline = {'bound': 'hbm', 'kernel': 'k_vol_assign_f32 (3-D assignment, all sweeps)',
+                    'achieved': round(VOL_ASSIGN_BYTES_PER_VOXEL * nvox / avg_s / 1e9, 2), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                    'frac': round(VOL_ASSIGN_BYTES_PER_VOXEL * nvox / avg_s / 1e9 / HBM_PEAK_GBS, 5), 'traffic': None,
+                    'avg_kernel_us': round(avg_s * 1e6, 1), 'launches': assign_n,
+                    'algorithmic_bytes_per_launch': VOL_ASSIGN_BYTES_PER_VOXEL * nvox}
+    else:
+        achieved = 10 * VOL_ASSIGN_BYTES_PER_VOXEL * nvox / (slic_ms / 1e3) / 1e9 if slic_ms else 0.0
+        roofline = {'bound': 'hbm', 'kernel': 'whole 3-D SLIC stage (pre-processing, 10 x [scatter, k_vol_assign_f32, k_vol_update_f32], connectivity)',
+                    'achieved': round(achieved, 2), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBS, 5),
+                    'traffic': None, 'algorithmic_bytes': 10 * VOL_ASSIGN_BYTES_PER_VOXEL * nvox, 'stage_ms': round(slic_ms, 2)}
+    out = {
+        'metric': METRIC,
         'value': round(group.world * steps * nvox / elapsed / 1e6, 3), 'unit': 'Mpixels/s', 'n_gpus': group.world, 'steps': steps,
         'warmup': warmup, 'ms_per_step': round(elapsed / steps * 1e3, 3), 'higher_is_better': True, 'scaling': 'weak',
         'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
@@ -602,15 +905,54 @@ def bench_volume(args, group):
                                '(sp_size=15, spacing (1,1,1), gray mean/std/energy, 3-class GMM fitted inside the step on the host, '
                                'gc_regul=0.1), host in -> host out (BASELINE configs[4]); unit = Mvoxels/s' % shape,
                    'bench_config': 5, 'classes_found': int(len(np.unique(segm)))},
-        'roofline': {'bound': 'hbm', 'kernel': 'whole 3-D SLIC stage (pre-processing, 10 x [scatter, k_vol_assign_f32, k_vol_update_f32], connectivity)',
-                     'achieved': round(achieved, 2), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBS, 5),
-                     'traffic': None, 'algorithmic_bytes': 10 * VOL_ASSIGN_BYTES_PER_VOXEL * nvox, 'stage_ms': round(slic_ms, 2)},
+        'roofline': roofline,
         'stage_ms_per_step': {g: round(ms, 3) for g, (ms, n) in stage_ms.items()},
     }
+    del vol, segm
+    if group.world == 1:
+        try:
+            verdict = compare_config5(shape, pipe)
+            if verdict is not None:
+                out.update(verdict)
+        except Exception as ex:
+            out['reference_run_error'] = repr(ex)
+        if not args.no_cpu_baseline:
+            try:
+                out['cpu_baseline'] = cpu_baseline_volume(shape, crop=(32, 128, 128) if quick else (64, 256, 256))
+                out['speedup_vs_cpu_baseline'] = round(out['value'] / out['cpu_baseline']['value'], 2)
+            except Exception as ex:
+                out['cpu_baseline'] = {'error': repr(ex)}
+    return out
+
+
+# -----------------------------------------------------------------------------------------------------------------
+# --gpus N without a launcher: this script starts its own ranks
+# -----------------------------------------------------------------------------------------------------------------
+def spawn_ranks(n, argv):
+    """N processes of this script, one per GPU, with the environment a distributed launcher would set (RANK, LOCAL_RANK,
+    WORLD_SIZE, MASTER_ADDR 127.0.0.1, a free MASTER_PORT); rank 0 writes to this process's stdout.  Returns the exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port),
+                   TORCHELASTIC_RUN_ID='bench%d' % os.getpid(), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(sys.argv[0])] + list(argv), env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    code = 0
+    for proc in procs:
+        code = max(code, abs(proc.wait()))
+    return code
 
 
 def main():
     args = parse_args()
+    launched = 'RANK' in os.environ or 'WORLD_SIZE' in os.environ
+    if args.gpus is not None and args.gpus > 1 and not launched:
+        sys.exit(spawn_ranks(args.gpus, sys.argv[1:]))
     try:    # host-side BLAS (model fit, non-GMM models): one thread each, N ranks x M worker threads share the node
         from threadpoolctl import threadpool_limits
         threadpool_limits(limits=1)
@@ -618,9 +960,34 @@ def main():
         pass
     from pyimsegm_amd.distributed import Group
     group = Group()
+    if args.gpus is not None and args.gpus != group.world:
+        raise SystemExit('--gpus %d but the launcher started %d rank(s)' % (args.gpus, group.world))
     try:
-        out = bench_volume(args, group) if args.config == 5 else bench_color2d(args, group)
+        cfg = args.config or 2
+        out = bench_volume(args, group) if cfg == 5 else bench_color2d(args, group, cfg)
+        if args.config is None and not args.no_other_configs and args.size is None:
+            # the other BASELINE configurations, driver-timed in the same invocation (a few seconds each): config 4 at any N (the
+            # configuration that shards over the GPUs), configs 3 and the reduced 5 on one GPU
+            others = {}
+            for name, fn in (('4', lambda: bench_color2d(args, group, 4, quick=True)),
+                             ('3', lambda: bench_color2d(args, group, 3, quick=True) if group.world == 1 else None),
+                             ('5_reduced', lambda: bench_volume(args, group, shape=C5_REDUCED, quick=True) if group.world == 1 else None)):
+                try:
+                    t0 = time.perf_counter()
+                    res = fn()
+                    if res is not None:
+                        res['wall_s'] = round(time.perf_counter() - t0, 2)
+                        for key in ('metric', 'higher_is_better', 'vs_baseline', 'data', 'scaling'):
+                            res.pop(key, None)
+                        others[name] = res
+                except Exception as ex:
+                    if group.world > 1:
+                        raise
+                    others[name] = {'error': repr(ex)}
+            if group.rank == 0:
+                out['other_configs'] = others
         if group.rank == 0:
+            assert out['n_gpus'] == (args.gpus or group.world), (out['n_gpus'], args.gpus, group.world)
             print(json.dumps(out), flush=True)
     finally:
         group.close()

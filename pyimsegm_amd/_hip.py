@@ -533,6 +533,13 @@ class Image2D(object):
         _check(load_library().imsegm_image2d_get_labels(self._h, _ptr(out)))
         return out
 
+    def get_labels_int32(self):
+        """the resident label map as it lives in HBM (int32), without the int64 widening of :meth:`get_labels`"""
+        out = np.empty(self.shape, dtype=np.int32)
+        src = _device_array(self, 0, self.shape, '<i4').__cuda_array_interface__['data'][0]
+        self.ctx.copy(out.ctypes.data, src, out.nbytes, synchronize=True)
+        return out
+
     def enforce_connectivity(self, labels, min_size, max_size, start_label=0):
         """``_enforce_label_connectivity_cython`` of scikit-image 0.18 on a given label map; returns the int64 map"""
         labels = np.ascontiguousarray(labels, dtype=np.int32)

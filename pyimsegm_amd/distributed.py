@@ -56,9 +56,19 @@ class _Star(object):
         self.rank, self.world = rank, world
         tag = '%s-%s' % (os.environ.get('MASTER_PORT', '0'), os.environ.get('TORCHELASTIC_RUN_ID', 'run'))
         tag = ''.join(ch if ch.isalnum() or ch in '-_' else '_' for ch in tag)[:60]
-        self.path = os.environ.get('IMSEGM_COMM_SOCKET', '/tmp/imsegm-%d-%s.sock' % (os.getuid(), tag))
+        # the socket lives in a directory only this user can enter (0700, ownership checked): nobody else can connect
+        # to the hub or put a socket of their own at the agreed path
+        base = os.path.join(os.environ.get('XDG_RUNTIME_DIR') or '/tmp', 'imsegm-%d' % os.getuid())
+        self.path = os.environ.get('IMSEGM_COMM_SOCKET')
+        if not self.path:
+            os.makedirs(base, mode=0o700, exist_ok=True)
+            st = os.stat(base)
+            if st.st_uid != os.getuid() or (st.st_mode & 0o077):
+                raise RuntimeError('control-plane directory %s is not private to this user' % base)
+            self.path = os.path.join(base, '%s.sock' % tag)
         self.peers = {}
         self.sock = None
+        self.server = None
         deadline = time.time() + timeout
         if rank == 0:
             try:
@@ -70,11 +80,19 @@ class _Star(object):
             srv.listen(world)
             srv.settimeout(timeout)
             self.server = srv
-            while len(self.peers) < world - 1:
-                conn, _ = srv.accept()
-                conn.settimeout(None)
-                peer, = struct.unpack('<i', _recv_exact(conn, 4))
-                self.peers[peer] = conn
+            try:
+                while len(self.peers) < world - 1:
+                    conn, _ = srv.accept()
+                    conn.settimeout(timeout)
+                    peer, = struct.unpack('<i', _recv_exact(conn, 4))
+                    if not (1 <= peer < world) or peer in self.peers:       # a stray or duplicate connection: drop it
+                        conn.close()
+                        continue
+                    conn.settimeout(None)
+                    self.peers[peer] = conn
+            except BaseException:
+                self.close()
+                raise
         else:
             while True:
                 sock = socket.socket(socket.AF_UNIX, socket.SOCK_STREAM)
@@ -111,7 +129,10 @@ class _Star(object):
         if self.rank == 0:
             for conn in self.peers.values():
                 conn.close()
-            self.server.close()
+            self.peers = {}
+            if self.server is not None:
+                self.server.close()
+                self.server = None
             try:
                 os.unlink(self.path)
             except OSError:
@@ -309,9 +330,10 @@ class DeviceGather(object):
     (world x items_per_round x item_bytes, in HBM).  Without RCCL (CPU tests, one process) the round travels over the
     host plane instead."""
 
-    def __init__(self, group, item_bytes, items_per_round, ctx=None):
+    def __init__(self, group, item_bytes, items_per_round, ctx=None, depth=2):
         from pyimsegm_amd import _hip
         self.group, self.item_bytes, self.per_round = group, int(item_bytes), int(items_per_round)
+        self.depth = max(2, int(depth))          # rounds the send ring holds: a slow rank stalls the others only beyond that
         self.ctx = ctx or _hip.default_context()
         self.hip = _hip
         self.round_bytes = self.item_bytes * self.per_round
@@ -320,7 +342,7 @@ class DeviceGather(object):
         if group.rccl is not None:
             lib = _hip.load_library()
             p = C.c_void_p()
-            _hip._check(lib.imsegm_device_alloc(group.device_index, 2 * self.round_bytes, C.byref(p)))      # double buffered
+            _hip._check(lib.imsegm_device_alloc(group.device_index, self.depth * self.round_bytes, C.byref(p)))
             self.send = p.value
             if group.rank == 0:
                 q = C.c_void_p()
@@ -329,7 +351,7 @@ class DeviceGather(object):
         self.host_round = [None] * self.per_round          # host-plane fallback
 
     def slot_ptr(self, round_index, item):
-        return self.send + (round_index % 2) * self.round_bytes + item * self.item_bytes
+        return self.send + (round_index % self.depth) * self.round_bytes + item * self.item_bytes
 
     def stage(self, round_index, item, src, worker_ctx=None, offset=0, nbytes=None):
         """put (a part of) item ``item`` of round ``round_index`` into the ring.  ``src``: a device array (anything with
@@ -459,9 +481,10 @@ def _segment_batch_rccl(list_images, segment_device_fn, group, nb_workers, mine,
     rounds = (max_mine + per_round - 1) // per_round
     item_bytes = int(shape[0]) * int(shape[1]) * 4
     ctx = _hip.default_context()
-    gather = DeviceGather(group, item_bytes, per_round, ctx)
+    gather = DeviceGather(group, item_bytes, per_round, ctx, depth=4)
     cond = threading.Condition()
     flushed = [0]
+    aborted = [False]
     errors = []
 
     def work(pos):
@@ -469,8 +492,10 @@ def _segment_batch_rccl(list_images, segment_device_fn, group, nb_workers, mine,
         res = None
         try:
             res = segment_device_fn(list_images[mine[pos]])
-            with cond:
-                cond.wait_for(lambda: flushed[0] >= rnd - 1)         # the ring holds two rounds
+            with cond:                                               # the ring holds `gather.depth` rounds
+                cond.wait_for(lambda: aborted[0] or flushed[0] >= rnd - (gather.depth - 1))
+            if aborted[0]:
+                return
             gather.stage(rnd, item, res.device_ptr, res.ctx)
         except Exception as ex:
             errors.append(ex)
@@ -498,6 +523,9 @@ def _segment_batch_rccl(list_images, segment_device_fn, group, nb_workers, mine,
                         if idx < n:
                             results[idx] = host[r, item].copy()
     finally:
+        with cond:                    # a failed flush / copy / interrupt: wake the workers that wait for a free ring slot,
+            aborted[0] = True         # else shutdown() would wait for them forever and the error never surface
+            cond.notify_all()
         pool.shutdown()
         gather.close()
     failed = group.any_over_ranks(bool(errors))

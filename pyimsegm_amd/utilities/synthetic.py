@@ -44,3 +44,26 @@ def ellipsoid_volume(shape=(16, 64, 64), seed=5, noise=0.05):
         vol[r < thr] = val
     vol += rng.normal(0, noise, shape)
     return vol.astype(np.float32)
+
+
+def config5_volume(shape=(64, 4096, 4096), seed=5, noise=0.05):
+    """config C5 at any size, float32: `ellipsoid_volume(shape, seed=5)` plus a second float32 noise field drawn from
+    `default_rng(seed)` -- the volume `bench.py --config 5` has always used -- generated slab by slab along z so that the
+    10^9-voxel volume needs no float64 temporaries of its size (the draws of a Generator are sequential in C order, so
+    the slabs reproduce the one-shot arrays bit for bit; tests/test_golden_configs.py checks that on a small shape)"""
+    depth, height, width = shape
+    rng_a = np.random.default_rng(5)              # ellipsoid_volume's own generator (its default seed)
+    rng_b = np.random.default_rng(seed)
+    zs = np.linspace(-1, 1, depth)
+    yy = (np.linspace(-1, 1, height) / 0.8)**2
+    xx = (np.linspace(-1, 1, width) / 0.7)**2
+    out = np.empty(shape, dtype=np.float32)
+    for z in range(depth):
+        r = np.sqrt(((zs[z] / 0.9)**2 + yy[:, None]) + xx[None, :])     # the summation order of ellipsoid_volume
+        vol = np.zeros((height, width))
+        for thr, val in ((0.9, 0.3), (0.6, 0.6), (0.3, 0.9)):
+            vol[r < thr] = val
+        vol += rng_a.normal(0, noise, (height, width))
+        out[z] = vol.astype(np.float32)
+        out[z] += (0.05 * rng_b.standard_normal((height, width), dtype=np.float32))
+    return out

@@ -49,6 +49,7 @@ class Image2D(object):
         self.labels = np.asarray(lab, dtype=np.int32); self.n_labels = int(self.labels.max()) + 1
         return self.n_labels
     def get_labels(self): return self.labels.astype(np.int64)
+    def get_labels_int32(self): return self.labels.astype(np.int32)
     def set_labels(self, labels, n_labels=None):
         labels = np.ascontiguousarray(labels, dtype=np.int32); assert labels.shape == self.shape
         self.labels = labels; self.n_labels = int(labels.max()) + 1 if n_labels is None else int(n_labels); return self

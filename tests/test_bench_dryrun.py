@@ -10,11 +10,17 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def run_bench(nproc, steps, port, extra=()):
-    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(nproc), '--master-addr', '127.0.0.1',
-           '--master-port', str(port), os.path.join(ROOT, 'tests', 'dryrun_bench.py'), '--gpus', str(nproc), '--size', '192',
-           '--steps', str(steps), '--warmup', '1'] + list(extra)
-    env = dict(os.environ, OMP_NUM_THREADS='1')
+def run_bench(nproc, steps, port, extra=(), launcher=False, size=('--size', '192')):
+    """`launcher`: ranks started by torch.distributed.run (what the driver does); else `--gpus N` alone, and bench.py starts
+    its own ranks"""
+    tail = [os.path.join(ROOT, 'tests', 'dryrun_bench.py'), '--gpus', str(nproc)] + list(size) + ['--steps', str(steps), '--warmup', '1'] + list(extra)
+    if launcher:
+        cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(nproc), '--master-addr', '127.0.0.1',
+               '--master-port', str(port)] + tail
+    else:
+        cmd = [sys.executable] + tail
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_PORT')}
+    env['OMP_NUM_THREADS'] = '1'
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [ln for ln in out.stdout.splitlines() if ln.startswith('{')]
@@ -22,8 +28,10 @@ def run_bench(nproc, steps, port, extra=()):
     return json.loads(lines[0])
 
 
-def test_bench_control_flow_two_ranks():
-    d = run_bench(2, 9, 29631)
+def test_bench_control_flow_two_ranks_under_the_launcher():
+    import pytest
+    pytest.importorskip('torch')
+    d = run_bench(2, 9, 29631, launcher=True)
     assert d['n_gpus'] == 2 and d['steps'] == 9 and d['warmup'] == 1 and d['scaling'] == 'weak'
     assert d['higher_is_better'] is True and d['vs_baseline'] is None and d['value'] > 0
     assert abs(d['value'] - 2 * 9 * 192 * 192 / (d['ms_per_step'] * 9 / 1e3) / 1e6) / d['value'] < 1e-3      # whole-job aggregate
@@ -33,7 +41,19 @@ def test_bench_control_flow_two_ranks():
     assert 'cpu_baseline' not in d                     # rank 0 at N = 1 only
 
 
-def test_bench_batch_config_two_ranks():
-    d = run_bench(2, 3, 29633, extra=['--config', '4'])
+def test_bench_batch_config_two_self_spawned_ranks():
+    """`--gpus 2` without a launcher: bench.py starts its own ranks; config 4 with the group model of the reference's run, and
+    rank 0 checks the CRC of EVERY gathered label map against that run (the oracle stands in for the kernels here, and it
+    reproduces the reference's maps bit for bit)"""
+    d = run_bench(2, 3, 29633, extra=['--config', '4'], size=())
     assert d['n_gpus'] == 2 and d['config']['bench_config'] == 4 and d['config']['images_per_step_per_gpu'] == 8
     assert abs(d['value'] - 2 * 3 * 8 * 647 * 1024 / (d['ms_per_step'] * 3 / 1e3) / 1e6) / d['value'] < 1e-3
+    assert d['gathered_maps_checked'] == 16 and d['gathered_maps_equal_reference_run'] is True, d
+    assert d['gpu_equals_reference_run'] is True, d['reference_run']
+
+
+def test_bench_refuses_a_rank_count_that_is_not_the_launchers():
+    cmd = [sys.executable, os.path.join(ROOT, 'tests', 'dryrun_bench.py'), '--gpus', '3', '--size', '64', '--steps', '1', '--warmup', '0']
+    env = dict(os.environ, RANK='0', LOCAL_RANK='0', WORLD_SIZE='1', MASTER_PORT='29641')
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=120, cwd=ROOT, env=env)
+    assert out.returncode != 0 and '--gpus 3' in (out.stderr + out.stdout)

@@ -1,6 +1,6 @@
-"""N > 1 path on CPU: 2 processes started by torch.distributed.run (the launcher of the benchmark contract), host control
-plane of pyimsegm_amd.distributed (the role gloo played in round 1) -- sharding, per-round gather, max-over-ranks,
-the group model across ranks, a failing rank."""
+"""N > 1 path on CPU: 2 processes with the environment a distributed launcher sets (RANK / LOCAL_RANK / WORLD_SIZE /
+MASTER_PORT -- nothing of torch is needed), host control plane of pyimsegm_amd.distributed (the role gloo played in
+round 1) -- sharding, per-round gather, max-over-ranks, the group model across ranks, a failing rank."""
 import os
 import subprocess
 import sys
@@ -62,12 +62,46 @@ WORKER = textwrap.dedent('''
 ''') % ROOT
 
 
-def test_two_rank_gloo(tmp_path):
+def test_two_rank_host_plane(tmp_path):
     script = tmp_path / 'worker.py'
     script.write_text(WORKER)
-    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=2', '--master-addr', '127.0.0.1',
-           '--master-port', '29617', str(script)]
-    env = dict(os.environ, OMP_NUM_THREADS='1')
-    res = subprocess.run(cmd, capture_output=True, text=True, timeout=240, env=env)
-    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
-    assert 'RANK0_OK' in res.stdout
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, OMP_NUM_THREADS='1', RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE='2', MASTER_ADDR='127.0.0.1',
+                   MASTER_PORT='29617', TORCHELASTIC_RUN_ID='pytest%d' % os.getpid())
+        procs.append(subprocess.Popen([sys.executable, str(script)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env))
+    outs = [p.communicate(timeout=240) for p in procs]
+    for p, (out, err) in zip(procs, outs):
+        assert p.returncode == 0, out[-2000:] + err[-2000:]
+    assert 'RANK0_OK' in outs[0][0]
+
+
+def test_control_plane_rejects_stray_connections(tmp_path):
+    """a connection that announces a rank outside 1..world-1 (or one that is taken) is dropped, the job still forms"""
+    import socket
+    import struct
+    import threading
+    import time
+    sys.path.insert(0, ROOT)
+    from pyimsegm_amd.distributed import _Star
+    path = str(tmp_path / 'hub.sock')
+    os.environ['IMSEGM_COMM_SOCKET'] = path
+    try:
+        hub = {}
+        t = threading.Thread(target=lambda: hub.setdefault('star', _Star(0, 2, timeout=30.)))
+        t.start()
+        deadline = time.time() + 10
+        while not os.path.exists(path) and time.time() < deadline:
+            time.sleep(0.02)
+        stray = socket.socket(socket.AF_UNIX, socket.SOCK_STREAM)
+        stray.connect(path)
+        stray.sendall(struct.pack('<i', 7))              # not a rank of this job
+        peer = _Star(1, 2, timeout=30.)
+        t.join(30)
+        assert sorted(hub['star'].peers) == [1]
+        peer.close()
+        hub['star'].close()
+        stray.close()
+        assert not os.path.exists(path)
+    finally:
+        del os.environ['IMSEGM_COMM_SOCKET']
