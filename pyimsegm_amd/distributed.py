@@ -364,7 +364,12 @@ class DeviceGather(object):
             slot = self.host_round[item]
             if slot is None:
                 slot = self.host_round[item] = {}
-            slot[offset] = np.array(src, copy=True)
+            if hasattr(src, '__cuda_array_interface__'):      # ranks that share one GPU (no RCCL communicator): through the host
+                host = np.empty(nbytes, dtype=np.uint8)
+                (worker_ctx or self.ctx).copy(host.ctypes.data, src.__cuda_array_interface__['data'][0], nbytes, synchronize=True)
+                slot[offset] = host
+            else:
+                slot[offset] = np.array(src, copy=True)
 
     def flush(self, round_index):
         """collective: move round ``round_index`` (all its items staged on every rank) to rank 0"""
