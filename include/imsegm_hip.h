@@ -93,6 +93,10 @@ IMSEGM_API int imsegm_image2d_set_labels(imsegm_image2d *img, const int32_t *lab
  * tile path of csrc/connectivity.hip and were redone by the general one (results are identical; tests use it to make sure
  * ordinary inputs stay on the fast path). */
 IMSEGM_API long imsegm_debug_conn_general_runs(void);
+/* Diagnostic (no reference counterpart): 2-D SLIC runs of this process whose sweeps 2..max_iter ran in the ONE persistent launch
+ * of csrc/slic.hip (k_slic_sweeps), and how many of those gave the image back to the per-sweep launches (results are identical;
+ * tests use it to make sure ordinary images stay on the persistent path, bench.py to know how many sweeps one launch covers). */
+IMSEGM_API int imsegm_debug_slic_sweep_runs(long *persistent_runs_out, long *fallback_runs_out);
 /* Replaces skimage.segmentation._slic._enforce_label_connectivity_cython(segments, min_size, max_size, start_label)
  * (scikit-image 0.18; the connectivity pass of skimage.segmentation.slic, reached from imsegm/superpixels.py:61-63 and
  * :104-106 with enforce_connectivity=True) on a label map given by the caller: labels = host int32, one value per

@@ -93,6 +93,7 @@ _SIGNATURES = {
     'imsegm_image2d_set_labels': (C.c_int, [_vp, _vp, C.c_int]),
     'imsegm_image2d_enforce_connectivity': (C.c_int, [_vp, _vp, C.c_long, C.c_long, C.c_int, _vp]),
     'imsegm_debug_conn_general_runs': (C.c_long, []),
+    'imsegm_debug_slic_sweep_runs': (C.c_int, [_vp, _vp]),
     'imsegm_image2d_label_hist': (C.c_int, [_vp, _vp, C.c_int, _vp]),
     'imsegm_image2d_get_lab': (C.c_int, [_vp, _vp]),
     'imsegm_image2d_get_nearest': (C.c_int, [_vp, _vp]),
@@ -795,6 +796,21 @@ class DeviceArray(object):
         self.owner = owner          # keeps the session alive
         self.__cuda_array_interface__ = {'shape': tuple(shape), 'typestr': typestr, 'data': (int(ptr), False),
                                          'version': 2, 'strides': None}
+
+
+def slic_sweep_runs():
+    """(2-D SLIC runs whose sweeps after the first ran in the one persistent launch, runs of those that were handed back to the
+    per-sweep launches) of this process"""
+    a, b = C.c_long(0), C.c_long(0)
+    _check(load_library().imsegm_debug_slic_sweep_runs(C.byref(a), C.byref(b)))
+    return a.value, b.value
+
+
+def assign_sweeps_per_launch(max_iter=10):
+    """sweeps one launch of the dominant SLIC kernel covered in the runs so far: max_iter - 1 when the persistent kernel took
+    them all, 1 with the per-sweep launches (bench.py: algorithmic bytes per launch)"""
+    persistent, fallback = slic_sweep_runs()
+    return max_iter - 1 if (persistent > 0 and fallback == 0) else 1
 
 
 def _device_array(sess, which, shape, typestr):

@@ -157,7 +157,8 @@ struct imsegm_image2d {
     bool is_volume = false;
     double vol_off = 0.0, vol_scale = 1.0;      // intensity seen by the volume SLIC = (v + off) * scale
     DevBuf img, labA, labB, nearest, labels, conn_i32, conn_u8, small, cent, tiles, feat, graph, gather_lut, gather_out_i, gather_out_f,
-        tex_planes, tex_resp, tex_small, vol_cent, annot, hist, featK, seg;
+        tex_planes, tex_resp, tex_small, vol_cent, annot, hist, featK, seg, sweeps;
+    int *slic_fail_host = nullptr;              // page-locked word the persistent sweep kernel raises when it cannot take the image
     int feat_mask = 0, feat_F = 0;              // layout of the resident feature table (imsegm_image2d_features_color)
     // the ten SLIC sweeps (30 kernel launches + a memset) as one captured HIP graph, re-used while every launch parameter
     // (sizes, pointers, weights: `slic_key`, the bytes of a SlicGraphKey) stays the same -- a recycled session replays it
@@ -409,8 +410,10 @@ void imsegm_image2d_destroy(imsegm_image2d *im)
     (void)hipStreamSynchronize(im->ctx->stream);
     DevBuf *all[] = { &im->img, &im->labA, &im->labB, &im->nearest, &im->labels, &im->conn_i32, &im->conn_u8, &im->small,
                       &im->cent, &im->tiles, &im->feat, &im->graph, &im->gather_lut, &im->gather_out_i, &im->gather_out_f,
-                      &im->tex_planes, &im->tex_resp, &im->tex_small, &im->vol_cent, &im->annot, &im->hist, &im->featK, &im->seg };
+                      &im->tex_planes, &im->tex_resp, &im->tex_small, &im->vol_cent, &im->annot, &im->hist, &im->featK, &im->seg,
+                      &im->sweeps };
     for (auto b : all) b->release();
+    if (im->slic_fail_host) (void)hipHostFree(im->slic_fail_host);
     if (im->slic_exec) (void)hipGraphExecDestroy(im->slic_exec);
     delete im;
 }
@@ -513,12 +516,16 @@ int imsegm_image2d_slic(imsegm_image2d *im, int minmax_normalize, int n_segments
     s.step_x = axk[2].all ? 1 : (int)axk[2].step;
     s.spatial_weight = 1.0 / ((double)step * (double)step);
     s.premax = premax;
-    s.debug = getenv("IMSEGM_DEBUG_ASSIGN") ? atoi(getenv("IMSEGM_DEBUG_ASSIGN")) : 0;
-    s.assign_units = getenv("IMSEGM_ASSIGN_UNITS") ? atoi(getenv("IMSEGM_ASSIGN_UNITS")) : 1;
+    // profiling aids: read once per process (nothing of the hot path looks at the environment per image)
+    static const int env_debug = getenv("IMSEGM_DEBUG_ASSIGN") ? atoi(getenv("IMSEGM_DEBUG_ASSIGN")) : 0;
+    static const int env_units = getenv("IMSEGM_ASSIGN_UNITS") ? atoi(getenv("IMSEGM_ASSIGN_UNITS")) : 1;
+    static const bool env_phase = getenv("IMSEGM_PHASE_PROF") != nullptr;
+    s.debug = env_debug;
+    s.assign_units = env_units;
     s.phase_prof = nullptr;
     static long long *phase_buf = nullptr;
     const size_t PHASE_SLOTS = 1 << 16;                    // workgroups of the assignment grid (profiling aid)
-    if (getenv("IMSEGM_PHASE_PROF")) {
+    if (env_phase) {
         if (!phase_buf) {
             HIP_TRY(hipMalloc(&phase_buf, PHASE_SLOTS * 32 * sizeof(long long)));
             HIP_TRY(hipMemset(phase_buf, 0, PHASE_SLOTS * 32 * sizeof(long long)));
@@ -574,6 +581,7 @@ int imsegm_image2d_slic(imsegm_image2d *im, int minmax_normalize, int n_segments
     // in flight 1.01-1.08 ms per image against 0.79-0.80 ms: the graph launches of different streams do not overlap the way
     // plain dispatches do), so it is off by default and kept for re-measuring on later runtimes.
     const bool use_graph = !ctx->profile && !s.phase_prof && getenv("IMSEGM_SLIC_GRAPH");
+    bool used_persistent = false;
     if (use_graph) {
         struct SlicGraphKey {
             SlicState s;
@@ -612,9 +620,18 @@ int imsegm_image2d_slic(imsegm_image2d *im, int minmax_normalize, int n_segments
             im->slic_key.assign(reinterpret_cast<unsigned char *>(&key), reinterpret_cast<unsigned char *>(&key) + sizeof(key));
         }
         HIP_TRY(hipGraphLaunch(im->slic_exec, st));
-    } else if (launch_slic_iterations(s, im->labA.as<double>(), init_dev, im->nearest.as<int32_t>(), max_iter, max_candidates, hook,
-                                      st)) {
-        return -1;
+    } else {
+        // scratch of the persistent sweep kernel (all sweeps after the first in one launch); its failure word is page-locked
+        // host memory that is read after the next synchronisation of this call (the connectivity stage ends with one)
+        void *sweep_scratch = nullptr;
+        if (!getenv("IMSEGM_SLIC_PER_SWEEP")) {
+            if (im->sweeps.ensure(sweep_work_bytes(K, max_iter))) return -1;
+            if (!im->slic_fail_host) HIP_TRY(hipHostMalloc((void **)&im->slic_fail_host, 64, hipHostMallocDefault));
+            sweep_scratch = im->sweeps.p;
+        }
+        if (launch_slic_iterations(s, im->labA.as<double>(), init_dev, im->nearest.as<int32_t>(), max_iter, max_candidates, hook, st,
+                                   sweep_scratch, im->slic_fail_host, &used_persistent))
+            return -1;
     }
 
     if (s.phase_prof) {
@@ -641,26 +658,38 @@ int imsegm_image2d_slic(imsegm_image2d *im, int minmax_normalize, int n_segments
         }
     }
     int n_labels = K + start_label;
-    if (enforce_connectivity) {
-        double segment_size = (double)n / (double)K;
-        long min_size = (long)(min_size_factor * segment_size);
-        long max_size = (long)(max_size_factor * segment_size);
-        if (im->conn_i32.ensure(conn_i32_bytes(n, H, W)) || im->conn_u8.ensure(2 * n + 64)) return -1;
-        ConnWork w = make_conn_work(im);
-        int spc = ctx->begin(PG_CONN);
-        // the raw assignment carries no start_label offset; the reference adds it before the
-        // connectivity pass, which only matters through mask_label = start_label - 1 (no masked
-        // pixels here), so the raw labels can be used as they are
-        if (launch_enforce_connectivity(im->nearest.as<int32_t>(), 1, H, W, min_size, max_size, start_label, w,
-                                        im->labels.as<int32_t>(), &n_labels, st))
-            return -1;
-        ctx->end(spc);
-    } else {
-        if (start_label != 0) {
-            set_error("enforce_connectivity=False is only supported with start_label=0");
-            return -1;
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        if (attempt == 1) {
+            // the persistent kernel gave the image back (more candidates in a tile than a list holds, a centroid far from its
+            // grid node, an uncovered pixel): the sweeps again, one launch each -- they take every case
+            slic_sweep_note_fallback();
+            if (launch_slic_iterations(s, im->labA.as<double>(), init_dev, im->nearest.as<int32_t>(), max_iter, max_candidates, hook, st))
+                return -1;
         }
-        HIP_TRY(hipMemcpyAsync(im->labels.p, im->nearest.p, n * 4, hipMemcpyDeviceToDevice, st));
+        if (enforce_connectivity) {
+            double segment_size = (double)n / (double)K;
+            long min_size = (long)(min_size_factor * segment_size);
+            long max_size = (long)(max_size_factor * segment_size);
+            if (im->conn_i32.ensure(conn_i32_bytes(n, H, W)) || im->conn_u8.ensure(2 * n + 64)) return -1;
+            ConnWork w = make_conn_work(im);
+            int spc = ctx->begin(PG_CONN);
+            // the raw assignment carries no start_label offset; the reference adds it before the
+            // connectivity pass, which only matters through mask_label = start_label - 1 (no masked
+            // pixels here), so the raw labels can be used as they are
+            if (launch_enforce_connectivity(im->nearest.as<int32_t>(), 1, H, W, min_size, max_size, start_label, w,
+                                            im->labels.as<int32_t>(), &n_labels, st))
+                return -1;
+            ctx->end(spc);
+        } else {
+            if (start_label != 0) {
+                set_error("enforce_connectivity=False is only supported with start_label=0");
+                return -1;
+            }
+            HIP_TRY(hipMemcpyAsync(im->labels.p, im->nearest.p, n * 4, hipMemcpyDeviceToDevice, st));
+            if (used_persistent) HIP_TRY(hipStreamSynchronize(st));     // (the failure word is read below)
+        }
+        if (!used_persistent || *im->slic_fail_host == 0) break;       // (connectivity ended with a synchronisation)
+        used_persistent = false;
     }
     ctx->end(sp_all);
     im->n_labels = n_labels;
@@ -700,6 +729,12 @@ int imsegm_image2d_set_labels(imsegm_image2d *im, const int32_t *labels, int n_l
 
 // diagnostic: number of 2-D connectivity passes of this process that left the tile path for the general one
 long imsegm_debug_conn_general_runs(void) { return conn_general_runs(); }
+
+int imsegm_debug_slic_sweep_runs(long *persistent_runs_out, long *fallback_runs_out)
+{
+    slic_sweep_counters(persistent_runs_out, fallback_runs_out);
+    return 0;
+}
 
 // skimage.segmentation._slic._enforce_label_connectivity_cython(segments, min_size, max_size, start_label) -- the second
 // native call inside skimage.segmentation.slic (superpixels.py:61-63, enforce_connectivity=True) -- on a label map

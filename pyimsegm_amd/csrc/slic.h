@@ -86,8 +86,36 @@ struct ProfHook {
     void (*pair)(void *, int, hipEvent_t *, hipEvent_t *) = nullptr;
 };
 int slic_prepare_device();
+// Scratch of the persistent sweep kernel (k_slic_sweeps: every sweep after the first in ONE launch, slic.hip).  One record per
+// centroid and sweep, 128 bytes = one cache line each, written once (write-through) and never rewritten: a tile of sweep s
+// reads table s, the centroid update of sweep s writes table s + 1.
+struct alignas(128) CenRec {
+    double cy, cx, cL, ca, cb;
+    int4 win;                       // empty window: the centroid is dead
+    double pad[9];
+};
+struct SweepWork {
+    CenRec *cen;                    // [max_iter][K]
+    long long *acc;                 // [max_iter][K][9] sums of sweep s (zeroed before the launch, touched by atomics only)
+    int *done;                      // [max_iter][K] tiles of sweep s that have added their pixels to centroid k
+    int *fin;                       // [K] highest sweep whose record of centroid k is published
+    int *ctl;                       // [0] next work item, [1] failure flag (device copy)
+    int *fail_host;                 // page-locked host word the host reads at its next synchronisation (0: result valid)
+    int n_tiles, tiles_x;
+    int sweep_begin, sweep_end;     // sweeps [sweep_begin, sweep_end) run in the launch; sweep_end = max_iter
+    int drift_max;                  // bound on |centroid - grid node| the per-tile node range is sized for
+};
+static inline size_t sweep_work_bytes(int K, int max_iter)
+{
+    return (size_t)max_iter * K * (sizeof(CenRec) + 9 * sizeof(long long) + sizeof(int)) + (size_t)K * sizeof(int) + 256 + 128;
+}
+// diagnostics: images whose sweeps ran in the persistent kernel / that had to be redone by the per-sweep launches
+void slic_sweep_counters(long *persistent_runs, long *fallback_runs);
+void slic_sweep_note_fallback();
+// `sweep_scratch` (sweep_work_bytes, 128-byte aligned) + `fail_host`: allow the persistent kernel; *used_persistent reports the choice
 int launch_slic_iterations(SlicState s, const double *lab, const double *init_yx_dev, int32_t *labels, int max_iter,
-                           int max_cand, const ProfHook &prof, hipStream_t st);
+                           int max_cand, const ProfHook &prof, hipStream_t st, void *sweep_scratch = nullptr,
+                           int *fail_host = nullptr, bool *used_persistent = nullptr);
 
 // volume.hip -------------------------------------------------------------------------------------
 struct VolState {

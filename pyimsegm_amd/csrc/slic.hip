@@ -9,6 +9,7 @@
 // cb as fp64[K], integer search windows int4[K]); accumulators int64 [K][9].
 #include "slic.h"
 #include <hip/hip_ext.h>
+#include <atomic>
 #include <cstdio>
 
 namespace imsegm {
@@ -1488,6 +1489,519 @@ k_slic_assign_dot(SlicState s, const double *__restrict__ lab, int32_t *__restri
     PHASE_FLUSH()
 }
 
+// ---------------------------------------------------------------------------------------------
+// every sweep after the first in ONE persistent launch
+// ---------------------------------------------------------------------------------------------
+// The sums of a centroid only depend on the pixels inside its own search window, so sweep s + 1 of a tile only depends on
+// the tiles of sweep s within reach of it.  Work items (sweep, 64 x 32 tile) are handed out in sweep-major raster order from
+// one atomic counter to a grid of resident workgroups; every dependency of an item has a smaller number, i.e. it was handed
+// out earlier to a workgroup that is running or done -- no deadlock, whatever the residency.  Per item:
+//   1. wave 0 waits until the centroids of the grid nodes within reach of the tile are published for this sweep
+//      (fin[k] >= sweep), builds the tile's candidate list (what k_slic_bin does) straight into LDS -- the records never
+//      touch global memory -- while the other waves already have their pixel loads in flight;
+//   2. both 64 x 16 halves are assigned (the loop of k_slic_assign_dot) and accumulated into ONE set of LDS slots;
+//   3. the slots are flushed into the sums of this sweep (returning atomics: complete when the wave has waited for them),
+//      then every candidate's arrival counter is incremented; the tile that makes a counter reach the number of tiles the
+//      centroid's window meets has seen all pixels of that centroid: its lane divides the sums (what k_centroid_finalize
+//      does), writes the record of sweep + 1 write-through (one 128-byte line per record, never rewritten), waits for the
+//      stores and publishes fin[k] = sweep + 1.
+// All cross-workgroup words are agent-scope accesses (sc1 / atomics): the per-XCD L2s are not coherent with each other.
+// What the launch cannot take raises the failure flag and the host redoes the image with the per-sweep launches: more than
+// SLIC_MAXC candidates in a tile, a centroid further than drift_max from its grid node (the node range of a tile is sized
+// for that), a pixel that no window covers, a wait that does not end.  The fixed-point sums are order independent, so the
+// label map is bit-identical to the per-sweep launches.
+#define RLX_AGENT __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
+__device__ __forceinline__ double ld_f64_agent(const double *p)
+{
+    return __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<unsigned long long *>(const_cast<double *>(p)), RLX_AGENT));
+}
+__device__ __forceinline__ void st_f64_agent(double *p, double v)
+{
+    __hip_atomic_store(reinterpret_cast<unsigned long long *>(p), (unsigned long long)__double_as_longlong(v), RLX_AGENT);
+}
+__device__ __forceinline__ int4 ld_win_agent(const CenRec *r)
+{
+    unsigned long long *q = reinterpret_cast<unsigned long long *>(const_cast<int4 *>(&r->win));
+    const unsigned long long a = __hip_atomic_load(q, RLX_AGENT), b = __hip_atomic_load(q + 1, RLX_AGENT);
+    return make_int4((int)(unsigned)(a & 0xffffffffu), (int)(unsigned)(a >> 32), (int)(unsigned)(b & 0xffffffffu), (int)(unsigned)(b >> 32));
+}
+__device__ __forceinline__ void st_win_agent(CenRec *r, int4 w)
+{
+    unsigned long long *q = reinterpret_cast<unsigned long long *>(&r->win);
+    __hip_atomic_store(q, (unsigned long long)(unsigned)w.x | ((unsigned long long)(unsigned)w.y << 32), RLX_AGENT);
+    __hip_atomic_store(q + 1, (unsigned long long)(unsigned)w.z | ((unsigned long long)(unsigned)w.w << 32), RLX_AGENT);
+}
+// a wave-uniform value held in vector registers (LDS / VALU result) moved to scalar registers
+__device__ __forceinline__ double uniform_f64(double v)
+{
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_readfirstlane((int)b), hi = __builtin_amdgcn_readfirstlane((int)(b >> 32));
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+__device__ __forceinline__ float uniform_f32(float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); }
+__device__ __forceinline__ void sweep_fail(const SweepWork &w, int code)
+{
+    __hip_atomic_store(w.ctl + 1, code, RLX_AGENT);
+    *reinterpret_cast<volatile int *>(w.fail_host) = code;
+}
+
+struct SweepLds {
+    long long lacc[MAXC][9];
+    Cand cand[MAXC];
+    Rec32 rec[MAXC];
+    int k[MAXC];
+    int ck[MAXC];
+    float ckey[MAXC], clb[MAXC];
+    TileInfo info;
+    int item;
+};
+constexpr unsigned SWEEP_SPIN_LIMIT = 1u << 21;       // polls of one wait (~1 s): a logic error must not hang the device
+
+// candidate list of one tile for sweep `sweep`, by ONE wave, into LDS (k_slic_bin's local path on the published records);
+// returns the list length, or < 0 after raising the failure flag
+__device__ __forceinline__ int sweep_bin_tile(const SlicState &s, const SweepWork &w, const CenRec *tab, int sweep, int tx0,
+                                              int ty0, SweepLds &L, int lane)
+{
+    const int tx1 = min(tx0 + TILE_X, s.W), ty1 = min(ty0 + TILE_Y, s.H);
+    const int reach_y = 2 * s.step_y + 1 + w.drift_max, reach_x = 2 * s.step_x + 1 + w.drift_max;
+    auto floor_div = [](int a, int b) { return a >= 0 ? a / b : -((-a + b - 1) / b); };
+    const int ny = s.K / s.grid_nx;
+    const int iy0 = max(0, floor_div(ty0 - reach_y - s.grid_y0 + s.grid_dy - 1, s.grid_dy));
+    const int iy1 = min(ny - 1, floor_div(ty1 + reach_y - s.grid_y0, s.grid_dy));
+    const int ix0 = max(0, floor_div(tx0 - reach_x - s.grid_x0 + s.grid_dx - 1, s.grid_dx));
+    const int ix1 = min(s.grid_nx - 1, floor_div(tx1 + reach_x - s.grid_x0, s.grid_dx));
+    const int nry = max(iy1 - iy0 + 1, 0), nrx = max(ix1 - ix0 + 1, 1);
+    const int total = ix1 >= ix0 ? nry * nrx : 0;
+    int count = 0;
+    for (int k0 = 0; k0 < total; k0 += 64) {
+        const int j = k0 + lane;
+        int k = -1;
+        if (j < total) {
+            const int jy = j / nrx;
+            k = (iy0 + jy) * s.grid_nx + ix0 + (j - jy * nrx);
+        }
+        for (unsigned spins = 0;; ++spins) {              // the records of this sweep of all these nodes are published
+            const int f = k >= 0 ? __hip_atomic_load(w.fin + k, RLX_AGENT) : 0x7fffffff;
+            if (__all(f >= sweep)) break;
+            if ((spins & 31) == 31) {
+                if (__builtin_amdgcn_readfirstlane(__hip_atomic_load(w.ctl + 1, RLX_AGENT))) return -1;
+                if (spins > SWEEP_SPIN_LIMIT) {
+                    if (lane == 0) sweep_fail(w, 4);
+                    return -1;
+                }
+            }
+            __builtin_amdgcn_s_sleep(2);
+        }
+        asm volatile("" ::: "memory");
+        bool hit = false;
+        float key = 0.f;
+        if (k >= 0) {
+            const int4 wv = ld_win_agent(tab + k);
+            hit = wv.x < ty1 && wv.y > ty0 && wv.z < tx1 && wv.w > tx0;
+            const float my = 0.5f * (float)(wv.x + wv.y) - 0.5f * (float)(ty0 + ty1);
+            const float mx = 0.5f * (float)(wv.z + wv.w) - 0.5f * (float)(tx0 + tx1);
+            key = my * my + mx * mx;
+        }
+        const unsigned long long m = __ballot(hit);
+        if (hit) {
+            const int pos = count + __popcll(m & ((1ULL << lane) - 1ULL));
+            if (pos < MAXC) {
+                L.ck[pos] = k;
+                L.ckey[pos] = key;
+            }
+        }
+        count += __popcll(m);
+    }
+    if (count > MAXC) {
+        if (lane == 0) sweep_fail(w, 1);
+        return -1;
+    }
+    if (count == 0) return 0;
+    __builtin_amdgcn_s_waitcnt(0);
+    __builtin_amdgcn_wave_barrier();
+    const bool have = lane < count;
+    // (lanes beyond the list read the first candidate's record: a record that is not published yet must never be touched,
+    // its line would sit stale in this XCD's L2 when it is needed later)
+    const int k = L.ck[have ? lane : 0];
+    const CenRec *r = tab + k;
+    Cand cd;
+    cd.cy = ld_f64_agent(&r->cy); cd.cx = ld_f64_agent(&r->cx);
+    cd.cL = ld_f64_agent(&r->cL); cd.ca = ld_f64_agent(&r->ca); cd.cb = ld_f64_agent(&r->cb);
+    cd.win = ld_win_agent(r);
+    cd.k = k;
+    const double sw = s.spatial_weight;
+    const double ryc = cd.cy - (double)(ty0 + 16), rxc = cd.cx - (double)(tx0 + 32);
+    const double dy = fmax(fmax(-16.0 - ryc, ryc - 15.0), 0.0), dx = fmax(fmax(-32.0 - rxc, rxc - 31.0), 0.0);
+    const float lbt = __double2float_rd((dy * dy + dx * dx) * sw * 0.999999);
+    const float key2 = have ? L.ckey[lane] : 0.f;
+    if (have) L.clb[lane] = lbt;
+    __builtin_amdgcn_s_waitcnt(0);
+    __builtin_amdgcn_wave_barrier();
+    int rank = 0;
+    for (int j = 0; j < count; ++j) {
+        const float kj = L.clb[j], k2j = L.ckey[j];
+        rank += (kj < lbt) || (kj == lbt && (k2j < key2 || (k2j == key2 && j < lane)));
+    }
+    const unsigned long long first = __ballot(have && rank == 0);
+    const int src = first ? __ffsll((long long)first) - 1 : 0;
+    const double ref0 = __shfl(cd.cL, src, 64), ref1 = __shfl(cd.ca, src, 64), ref2 = __shfl(cd.cb, src, 64);
+    const double c0 = cd.cL - ref0, c1 = cd.ca - ref1, c2 = cd.cb - ref2;
+    Rec32 rc;
+    rc.q0 = (float)(sw * (ryc * ryc + rxc * rxc) + (c0 * c0 + c1 * c1 + c2 * c2));
+    rc.qy = (float)(-2.0 * sw * ryc);
+    rc.qx = (float)(-2.0 * sw * rxc);
+    rc.qL = (float)(-2.0 * c0);
+    rc.qa = (float)(-2.0 * c1);
+    rc.qb = (float)(-2.0 * c2);
+    rc.lbt = lbt;
+    {
+        const int rlo = min(max(cd.win.x - ty0, 0), TILE_Y), rhi = min(max(cd.win.y - ty0, 0), TILE_Y);
+        const int xlo = min(max(cd.win.z - tx0, 0), TILE_X), xhi = min(max(cd.win.w - tx0, 0), TILE_X);
+        rc.meta = (uint32_t)rlo | ((uint32_t)rhi << 8) | ((uint32_t)xlo << 16) | ((uint32_t)xhi << 24);
+    }
+    cd.ry = (float)(cd.cy - (double)ty0);
+    cd.rx = (float)(cd.cx - (double)tx0);
+    cd.fL = (float)cd.cL; cd.fa = (float)cd.ca; cd.fb = (float)cd.cb;
+    cd.mdc = 1.0;
+    if (have) {
+        L.cand[rank] = cd;
+        L.rec[rank] = rc;
+        L.k[rank] = k;
+    }
+    float qm[5] = { have ? fabsf(rc.qy) : 0.f, have ? fabsf(rc.qx) : 0.f, have ? fabsf(rc.qL) : 0.f,
+                    have ? fabsf(rc.qa) : 0.f, have ? fabsf(rc.qb) : 0.f };
+#pragma unroll
+    for (int j = 0; j < 5; ++j)
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) qm[j] = fmaxf(qm[j], __shfl_xor(qm[j], off, 64));
+    if (lane == 0) {
+        L.info.ref[0] = ref0; L.info.ref[1] = ref1; L.info.ref[2] = ref2;
+        L.info.Qy = qm[0]; L.info.Qx = qm[1]; L.info.QL = qm[2]; L.info.Qa = qm[3]; L.info.Qb = qm[4];
+    }
+    return count;
+}
+
+// what k_centroid_finalize does, for ONE centroid whose sums of `sweep` are complete; publishes the record of sweep + 1
+__device__ __forceinline__ void sweep_finalize_centroid(const SlicState &s, const SweepWork &w, int sweep, int k)
+{
+    unsigned long long *a = reinterpret_cast<unsigned long long *>(w.acc + ((size_t)sweep * s.K + k) * 9);
+    long long v[9];
+#pragma unroll
+    for (int j = 0; j < 9; ++j) v[j] = (long long)__hip_atomic_load(a + j, RLX_AGENT);
+    if (v[0] == 0) {
+        // no pixel carries label k any more: dead in every later sweep (empty window, nothing waits for it again)
+        for (int s2 = sweep + 1; s2 < w.sweep_end; ++s2) st_win_agent(w.cen + (size_t)s2 * s.K + k, make_int4(0, 0, 0, 0));
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_store(w.fin + k, w.sweep_end, RLX_AGENT);
+        return;
+    }
+    const double nn = (double)v[0];
+    const double cy = i64_to_double(v[1]) / nn, cx = i64_to_double(v[2]) / nn;
+    const double finv = ldexp(1.0, -fix_bits_of(*s.premax));
+    CenRec *out = w.cen + (size_t)(sweep + 1) * s.K + k;
+    st_f64_agent(&out->cy, cy);
+    st_f64_agent(&out->cx, cx);
+    st_f64_agent(&out->cL, fix_value(v[3], v[4], finv) / nn);
+    st_f64_agent(&out->ca, fix_value(v[5], v[6], finv) / nn);
+    st_f64_agent(&out->cb, fix_value(v[7], v[8], finv) / nn);
+    st_win_agent(out, search_window(cy, cx, s.step_y, s.step_x, s.H, s.W));
+    const int iy = k / s.grid_nx, ix = k - iy * s.grid_nx;
+    const double dy = fabs(cy - (double)(s.grid_y0 + iy * s.grid_dy)), dx = fabs(cx - (double)(s.grid_x0 + ix * s.grid_dx));
+    if ((int)ceil(fmax(dy, dx)) > w.drift_max) sweep_fail(w, 2);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __hip_atomic_store(w.fin + k, sweep + 1, RLX_AGENT);
+}
+
+// records of sweep 1 from the SoA table k_centroid_finalize left after the first sweep; all polled words of this launch
+__global__ void k_sweeps_init(SlicState s, SweepWork w)
+{
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k == 0) {
+        w.ctl[0] = 0;
+        w.ctl[1] = 0;
+    }
+    if (k >= s.K) return;
+    const int4 win = s.win[k];
+    const bool dead = win.y <= win.x || win.w <= win.z;
+    CenRec *out = w.cen + (size_t)w.sweep_begin * s.K + k;
+    out->cy = s.cy[k]; out->cx = s.cx[k]; out->cL = s.cL[k]; out->ca = s.ca[k]; out->cb = s.cb[k];
+    out->win = win;
+    if (dead)
+        for (int s2 = w.sweep_begin + 1; s2 < w.sweep_end; ++s2) w.cen[(size_t)s2 * s.K + k].win = make_int4(0, 0, 0, 0);
+    w.fin[k] = dead ? w.sweep_end : w.sweep_begin;
+}
+
+#ifndef SLIC_SWEEPS_MIN_BLOCKS
+#define SLIC_SWEEPS_MIN_BLOCKS 5
+#endif
+__global__ void __launch_bounds__(256, SLIC_SWEEPS_MIN_BLOCKS)
+k_slic_sweeps(SlicState s, const double *__restrict__ lab, int32_t *__restrict__ labels, SweepWork w)
+{
+    __shared__ SweepLds L;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const size_t plane = (size_t)s.H * s.W;
+    const double sw = s.spatial_weight;
+    const int total_items = (w.sweep_end - w.sweep_begin) * w.n_tiles;
+    const double fscale = uniform_f64(ldexp(1.0, fix_bits_of(*s.premax)));
+
+    for (;;) {
+        __syncthreads();                                   // the LDS of the previous item is free
+        if (tid == 0) {
+            int it = __hip_atomic_fetch_add(w.ctl, 1, RLX_AGENT);
+            if (__hip_atomic_load(w.ctl + 1, RLX_AGENT)) it = 0x7fffffff;
+            L.item = it;
+        }
+        __syncthreads();
+        const int item = __builtin_amdgcn_readfirstlane(L.item);
+        if (item >= total_items) break;
+        const int sweep = w.sweep_begin + item / w.n_tiles;
+        const int tile = item - (sweep - w.sweep_begin) * w.n_tiles;
+        const int tile_row = tile / w.tiles_x;
+        const int tx0 = (tile - tile_row * w.tiles_x) * TILE_X, ty0 = tile_row * TILE_Y;
+        const bool accum = sweep + 1 < w.sweep_end;
+        const int x = tx0 + lane;
+        const bool xin = x < s.W;
+
+        // pixels of the upper half first: their latency covers the wait and the candidate list
+        double pL[ROWS], pA[ROWS], pB[ROWS];
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r) {
+            const int y = ty0 + wave * ROWS + r;
+            const bool ok = xin && y < s.H;
+            const size_t p = (size_t)(ok ? y : 0) * s.W + (ok ? x : 0);
+            pL[r] = lab[p];
+            pA[r] = lab[plane + p];
+            pB[r] = lab[2 * plane + p];
+        }
+        for (int i = tid; i < MAXC * 9; i += 256) (&L.lacc[0][0])[i] = 0;
+        if (wave == 0) {
+            const int cnt = sweep_bin_tile(s, w, w.cen + (size_t)sweep * s.K, sweep, tx0, ty0, L, lane);
+            if (lane == 0) L.info.count = cnt;
+        }
+        __syncthreads();
+        const int nc = __builtin_amdgcn_readfirstlane(L.info.count);
+        if (nc < 0) continue;                              // failure flag is up: the next fetch ends the loop
+        const int my_k = L.k[lane];
+        const float4 my_ra = reinterpret_cast<const float4 *>(&L.rec[lane])[0];      // q0, qx, qy, qL
+        const float4 my_rb = reinterpret_cast<const float4 *>(&L.rec[lane])[1];      // qa, qb, lbt, meta
+        // (tile constants: scalar registers, as the scalar loads of k_slic_assign_dot give them)
+        const double ref0 = uniform_f64(L.info.ref[0]), ref1 = uniform_f64(L.info.ref[1]), ref2 = uniform_f64(L.info.ref[2]);
+        const float xb_base = uniform_f32(16.f * L.info.Qy + 32.f * L.info.Qx), tQL = uniform_f32(L.info.QL), tQa = uniform_f32(L.info.Qa),
+                    tQb = uniform_f32(L.info.Qb);
+
+#pragma nounroll
+        for (int half = 0; half < 2; ++half) {
+            const int rel0 = half * WG_Y + wave * ROWS;
+            const int wy0 = ty0 + rel0;
+            if (half == 1) {
+#pragma unroll
+                for (int r = 0; r < ROWS; ++r) {
+                    const int y = wy0 + r;
+                    const bool ok = xin && y < s.H;
+                    const size_t p = (size_t)(ok ? y : 0) * s.W + (ok ? x : 0);
+                    pL[r] = lab[p];
+                    pA[r] = lab[plane + p];
+                    pB[r] = lab[2 * plane + p];
+                }
+            }
+            int best_s[ROWS];
+#pragma unroll
+            for (int r = 0; r < ROWS; ++r) best_s[r] = -1;
+            if (nc > 0) {
+                constexpr int PH1 = SLIC_PH1, PH2 = SLIC_PH2;
+                const float INF = __builtin_inff();
+                const float sw32 = (float)sw;
+                f2 fL[2], fA[2], fB[2];
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    fL[h] = (f2){ (float)(pL[2 * h] - ref0), (float)(pL[2 * h + 1] - ref0) };
+                    fA[h] = (f2){ (float)(pA[2 * h] - ref1), (float)(pA[2 * h + 1] - ref1) };
+                    fB[h] = (f2){ (float)(pB[2 * h] - ref2), (float)(pB[2 * h + 1] - ref2) };
+                }
+                const float X = (float)(lane - TILE_X / 2);
+                const float Y0 = (float)(rel0 - TILE_Y / 2);
+                const f2 Yp[2] = { (f2){ Y0, Y0 + 1.f }, (f2){ Y0 + 2.f, Y0 + 3.f } };
+                float xb[ROWS];
+#pragma unroll
+                for (int r = 0; r < ROWS; ++r) {
+                    const float l = r & 1 ? fL[r >> 1].y : fL[r >> 1].x, a = r & 1 ? fA[r >> 1].y : fA[r >> 1].x,
+                                b = r & 1 ? fB[r >> 1].y : fB[r >> 1].x;
+                    xb[r] = fmaf(tQL, fabsf(l), fmaf(tQa, fabsf(a), fmaf(tQb, fabsf(b), xb_base)));
+                }
+                float b1[ROWS], b2[ROWS];
+#pragma unroll
+                for (int r = 0; r < ROWS; ++r) b1[r] = b2[r] = INF;
+                const int rows_valid = min(ROWS, s.H - wy0), lanes_valid = min(TILE_X, s.W - tx0);
+                unsigned wbound = 0x7f800000u;
+                int c_end = nc;
+#define RL_F(v) __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), c))
+                for (int c = 0; c < nc; ++c) {
+                    if (c == PH1 || c == PH2) {
+                        float wl = 0.f;
+#pragma unroll
+                        for (int r = 0; r < ROWS; ++r) {
+                            float l = r & 1 ? fL[r >> 1].y : fL[r >> 1].x, a = r & 1 ? fA[r >> 1].y : fA[r >> 1].x,
+                                  b = r & 1 ? fB[r >> 1].y : fB[r >> 1].x, xbr = xb[r], Xv = X;
+                            asm volatile("" : "+v"(l), "+v"(a), "+v"(b), "+v"(xbr), "+v"(Xv));
+                            const float Yr = Y0 + (float)r;
+                            const float P = fmaf(sw32, fmaf(Yr, Yr, Xv * Xv), fmaf(l, l, fmaf(a, a, b * b)));
+                            const float v = fmaf(fmaxf(b1[r] + P, 0.f), 1.002f, 0.002f * (xbr + 1.f));
+                            if (xin && r < rows_valid) wl = fmaxf(wl, v);
+                        }
+                        int wi = __float_as_int(wl);
+                        wi = max(wi, __builtin_amdgcn_update_dpp(0, wi, 0x111, 0xf, 0xf, false));
+                        wi = max(wi, __builtin_amdgcn_update_dpp(0, wi, 0x112, 0xf, 0xf, false));
+                        wi = max(wi, __builtin_amdgcn_update_dpp(0, wi, 0x114, 0xf, 0xf, false));
+                        wi = max(wi, __builtin_amdgcn_update_dpp(0, wi, 0x118, 0xf, 0xf, false));
+                        wi = max(wi, __builtin_amdgcn_update_dpp(0, wi, 0x142, 0xa, 0xf, false));
+                        wi = max(wi, __builtin_amdgcn_update_dpp(0, wi, 0x143, 0xc, 0xf, false));
+                        wbound = (unsigned)__builtin_amdgcn_readlane(wi, 63);
+                    }
+                    if ((unsigned)__builtin_amdgcn_readlane(__float_as_int(my_rb.z), c) > wbound) {
+                        c_end = c;
+                        break;
+                    }
+                    const unsigned meta = (unsigned)__builtin_amdgcn_readlane(__float_as_int(my_rb.w), c);
+                    const int rlo = meta & 0xff, rhi = (meta >> 8) & 0xff, xlo = (meta >> 16) & 0xff, xhi = meta >> 24;
+                    if (rhi > rel0 && rlo < rel0 + ROWS) {
+                        const float q0 = RL_F(my_ra.x), qx = RL_F(my_ra.y), qy = RL_F(my_ra.z), qL = RL_F(my_ra.w);
+                        const float qa = RL_F(my_rb.x), qb = RL_F(my_rb.y);
+                        const float e = fmaf(qx, X, q0);
+#define SLIC_SELECT(r, dval)                                                                       \
+    {                                                                                              \
+        const float d_ = (dval);                                                                   \
+        const bool lt_ = d_ < b1[r];                                                               \
+        b2[r] = __builtin_amdgcn_fmed3f(b1[r], b2[r], d_);                                         \
+        b1[r] = lt_ ? d_ : b1[r];                                                                  \
+        best_s[r] = lt_ ? c : best_s[r];                                                           \
+    }
+                        if (rlo <= rel0 && rhi >= rel0 + rows_valid && xlo == 0 && xhi >= lanes_valid) {
+                            const f2 e2 = (f2){ e, e };
+                            f2 d01 = __builtin_elementwise_fma((f2){ qy, qy }, Yp[0], e2);
+                            f2 d23 = __builtin_elementwise_fma((f2){ qy, qy }, Yp[1], e2);
+                            d01 = __builtin_elementwise_fma((f2){ qL, qL }, fL[0], d01);
+                            d23 = __builtin_elementwise_fma((f2){ qL, qL }, fL[1], d23);
+                            d01 = __builtin_elementwise_fma((f2){ qa, qa }, fA[0], d01);
+                            d23 = __builtin_elementwise_fma((f2){ qa, qa }, fA[1], d23);
+                            d01 = __builtin_elementwise_fma((f2){ qb, qb }, fB[0], d01);
+                            d23 = __builtin_elementwise_fma((f2){ qb, qb }, fB[1], d23);
+                            SLIC_SELECT(0, d01.x) SLIC_SELECT(1, d01.y) SLIC_SELECT(2, d23.x) SLIC_SELECT(3, d23.y)
+                        } else {
+                            const bool inx = lane >= xlo && lane < xhi;
+#pragma unroll
+                            for (int r = 0; r < ROWS; ++r) {
+                                if (rel0 + r < rlo || rel0 + r >= rhi) continue;        // wave-uniform
+                                const float l = r & 1 ? fL[r >> 1].y : fL[r >> 1].x, a = r & 1 ? fA[r >> 1].y : fA[r >> 1].x,
+                                            b = r & 1 ? fB[r >> 1].y : fB[r >> 1].x;
+                                float d = fmaf(qy, Y0 + (float)r, e);
+                                d = fmaf(qL, l, d);
+                                d = fmaf(qa, a, d);
+                                d = fmaf(qb, b, d);
+                                d = inx ? d : INF;
+                                SLIC_SELECT(r, d)
+                            }
+                        }
+#undef SLIC_SELECT
+                    }
+                }
+                // near ties: exact fp64 evaluation over the candidates within the margin of the fp32 best (see k_slic_assign_dot)
+                const float U16 = 16.f * 5.9604644775390625e-8f * 1.01f;
+#pragma unroll
+                for (int r = 0; r < ROWS; ++r) {
+                    const float m = U16 * (b1[r] + b2[r] + 4.f * xb[r]) + 1e-30f;
+                    const bool near2 = best_s[r] >= 0 && b2[r] < INF && !(b2[r] - b1[r] > m);
+                    if (!__any(near2)) continue;
+                    const float l = r & 1 ? fL[r >> 1].y : fL[r >> 1].x, a = r & 1 ? fA[r >> 1].y : fA[r >> 1].x,
+                                b = r & 1 ? fB[r >> 1].y : fB[r >> 1].x;
+                    const float Yr = Y0 + (float)r;
+                    const double fy = (double)(wy0 + r), fx = (double)x;
+                    double bd = DBL_MAX;
+                    int bs = -1, bk = 0x7fffffff;
+                    for (int c = 0; c < c_end; ++c) {
+                        const unsigned meta = (unsigned)__builtin_amdgcn_readlane(__float_as_int(my_rb.w), c);
+                        const int rlo = meta & 0xff, rhi = (meta >> 8) & 0xff, xlo = (meta >> 16) & 0xff, xhi = meta >> 24;
+                        if (rel0 + r < rlo || rel0 + r >= rhi) continue;
+                        float d = fmaf(RL_F(my_ra.y), X, RL_F(my_ra.x));
+                        d = fmaf(RL_F(my_ra.z), Yr, d);
+                        d = fmaf(RL_F(my_ra.w), l, d);
+                        d = fmaf(RL_F(my_rb.x), a, d);
+                        d = fmaf(RL_F(my_rb.y), b, d);
+                        const bool take = near2 && lane >= xlo && lane < xhi && d - b1[r] <= m;
+                        if (!__any(take)) continue;
+                        const double e = exact_dist(L.cand[c], fy, fx, sw, pL[r], pA[r], pB[r]);
+                        const int k = L.cand[c].k;
+                        if (take && ((bd > e) || (bd == e && k < bk))) {
+                            bd = e;
+                            bs = c;
+                            bk = k;
+                        }
+                    }
+                    if (near2) best_s[r] = bs;
+                }
+#undef RL_F
+            }
+            // labels; a pixel that no window covers would keep its previous label: the per-sweep launches handle that
+            unsigned pending = 0;
+            int win_k[ROWS];
+            bool uncovered = false;
+#pragma unroll
+            for (int r = 0; r < ROWS; ++r) win_k[r] = __shfl(my_k, best_s[r] & 63, 64);
+#pragma unroll
+            for (int r = 0; r < ROWS; ++r) {
+                const int y = wy0 + r;
+                if (!(xin && y < s.H)) continue;
+                if (best_s[r] >= 0) {
+                    labels[y * s.W + x] = win_k[r];
+                    pending |= 1u << r;
+                } else {
+                    uncovered = true;
+                }
+            }
+            if (__any(uncovered)) {
+                if (lane == 0) sweep_fail(w, 3);
+            }
+            if (accum) accumulate_block_sums(lane, x, wy0, best_s, pending, pL, pA, pB, fscale, L.lacc);
+        }
+        if (!accum) continue;
+        __syncthreads();
+        // LDS slots -> sums of this sweep; the atomics return, so that the wait below covers their completion
+        {
+            long long *acc = w.acc + (size_t)sweep * s.K * 9;
+            unsigned long long sink = 0;
+            for (int i = tid; i < nc * 9; i += 256) {
+                const int c = i / 9, j = i - 9 * c;
+                const long long v = L.lacc[c][j];
+                if (v == 0 || (j >= 3 && ((j - 3) & 1))) continue;
+                unsigned long long *dst = reinterpret_cast<unsigned long long *>(acc + (size_t)L.k[c] * 9 + j);
+                if (j < 3) {
+                    sink += __hip_atomic_fetch_add(dst, (unsigned long long)v, RLX_AGENT);
+                } else {
+                    sink += __hip_atomic_fetch_add(dst, (unsigned long long)(v >> 24), RLX_AGENT);
+                    sink += __hip_atomic_fetch_add(dst + 1, (unsigned long long)(v & 0xffffff), RLX_AGENT);
+                }
+            }
+            asm volatile("s_waitcnt vmcnt(0)" : : "v"(sink) : "memory");
+        }
+        __syncthreads();
+        if (wave == 0 && lane < nc) {
+            const int4 wv = L.cand[lane].win;
+            const int expect = ((wv.y - 1) / TILE_Y - wv.x / TILE_Y + 1) * ((wv.w - 1) / TILE_X - wv.z / TILE_X + 1);
+            const int seen = __hip_atomic_fetch_add(w.done + (size_t)sweep * s.K + my_k, 1, RLX_AGENT) + 1;
+            if (seen == expect) sweep_finalize_centroid(s, w, sweep, my_k);
+        }
+    }
+}
+
+static std::atomic<long> g_sweep_persistent{0}, g_sweep_fallback{0};
+void slic_sweep_counters(long *persistent_runs, long *fallback_runs)
+{
+    if (persistent_runs) *persistent_runs = g_sweep_persistent.load();
+    if (fallback_runs) *fallback_runs = g_sweep_fallback.load();
+}
+void slic_sweep_note_fallback() { g_sweep_fallback.fetch_add(1); }
+
 // function attributes of the sweep kernels on the current device (idempotent; must not run inside a stream capture)
 int slic_prepare_device()
 {
@@ -1502,9 +2016,28 @@ int slic_prepare_device()
     return 0;
 }
 
-int launch_slic_iterations(SlicState s, const double *lab, const double *init_yx_dev, int32_t *labels, int max_iter,
-                           int max_cand, const ProfHook &prof, hipStream_t st)
+// grid of the persistent kernel: every workgroup the device holds at once (more would only queue behind the resident ones)
+static int sweeps_resident_blocks()
 {
+    static int cached[IMSEGM_MAX_DEVICES];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 1280;
+    if (dev >= 0 && dev < IMSEGM_MAX_DEVICES && cached[dev]) return cached[dev];
+    int per_cu = 0, cus = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)k_slic_sweeps, 256, 0) != hipSuccess || per_cu < 1) per_cu = 4;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 256;
+    if (const char *e = getenv("IMSEGM_SWEEPS_BLOCKS_PER_CU")) per_cu = std::max(1, atoi(e));
+    const int n = per_cu * cus;
+    if (dev >= 0 && dev < IMSEGM_MAX_DEVICES) cached[dev] = n;
+    return n;
+}
+
+int launch_slic_iterations(SlicState s, const double *lab, const double *init_yx_dev, int32_t *labels, int max_iter,
+                           int max_cand, const ProfHook &prof, hipStream_t st, void *sweep_scratch, int *fail_host,
+                           bool *used_persistent)
+{
+    if (used_persistent) *used_persistent = false;
+    const bool default_cand = max_cand <= 0 || max_cand >= MAXC;
     if (max_cand <= 0 || max_cand > MAXC) max_cand = MAXC;
     size_t n = (size_t)s.H * s.W;
     HIP_TRY(hipMemsetAsync(labels, 0xff, n * sizeof(int32_t), st));       // nearest = -1
@@ -1524,14 +2057,53 @@ int launch_slic_iterations(SlicState s, const double *lab, const double *init_yx
         const int reach_x = std::max(std::max(s.grid_x0, s.W - 1 - (s.grid_x0 + (s.grid_nx - 1) * s.grid_dx)), s.grid_dx / 2 + 1);
         grid_covers = reach_y <= 2 * s.step_y && reach_x <= 2 * s.step_x;
     }
-    if (getenv("IMSEGM_PRINT_OCC")) {
+    static const bool print_occ = getenv("IMSEGM_PRINT_OCC") != nullptr;
+    if (print_occ) {
         int nb = 0;
         HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void *)k_slic_assign_dot<true, false, 1, false>, 256, 0));
         fprintf(stderr, "[occupancy] k_slic_assign_dot<true>: %d workgroups per CU\n", nb);
         HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void *)k_slic_assign_dot<false, false, 1, false>, 256, 0));
         fprintf(stderr, "[occupancy] k_slic_assign_dot<false>: %d workgroups per CU\n", nb);
     }
+    // every sweep after the first in one persistent launch (k_slic_sweeps) when the image qualifies: the fp32 fast path, the
+    // closed-form first sweep, the default list capacity, windows that put well under SLIC_MAXC candidates into a tile
+    bool persistent = false;
+    int drift_max = 0;
+    if (sweep_scratch && fail_host && max_iter >= 3 && s.fast32 && !s.slico && s.spatial_weight > 1e-9 && grid_covers && default_cand &&
+        !s.debug && !s.phase_prof && units == 1 && s.grid_dy > 0 && s.grid_dx > 0 && !getenv("IMSEGM_SLIC_PER_SWEEP")) {
+        drift_max = std::max(s.step_y, s.step_x);
+        if (const char *e = getenv("IMSEGM_SWEEPS_DRIFT_MAX")) drift_max = std::max(0, atoi(e));     // (tests: force the hand-back)
+        const double per_tile = ((double)TILE_Y + 4.0 * s.step_y + 2.0) * ((double)TILE_X + 4.0 * s.step_x + 2.0) / ((double)s.grid_dy * s.grid_dx);
+        const long nodes = (long)((TILE_Y + 2 * (2 * s.step_y + 1 + drift_max)) / s.grid_dy + 2) * ((TILE_X + 2 * (2 * s.step_x + 1 + drift_max)) / s.grid_dx + 2);
+        persistent = per_tile <= 0.75 * MAXC && nodes <= BIN_LOCAL_MAX;
+    }
     for (int it = 0; it < max_iter; ++it) {
+        if (persistent && it == 1) {
+            SweepWork w;
+            unsigned char *p = static_cast<unsigned char *>(sweep_scratch);
+            w.cen = reinterpret_cast<CenRec *>(p); p += (size_t)max_iter * s.K * sizeof(CenRec);
+            w.acc = reinterpret_cast<long long *>(p); p += (size_t)max_iter * s.K * 9 * sizeof(long long);
+            w.done = reinterpret_cast<int *>(p); p += (size_t)max_iter * s.K * sizeof(int);
+            w.fin = reinterpret_cast<int *>(p); p += (size_t)s.K * sizeof(int);
+            w.ctl = reinterpret_cast<int *>(p);
+            w.fail_host = fail_host;
+            w.n_tiles = n_tiles; w.tiles_x = (int)grid.x;
+            w.sweep_begin = 1; w.sweep_end = max_iter;
+            w.drift_max = drift_max;
+            *fail_host = 0;
+            HIP_TRY(hipMemsetAsync(w.acc, 0, (size_t)max_iter * s.K * (9 * sizeof(long long) + sizeof(int)), st));
+            hipLaunchKernelGGL(k_sweeps_init, cdiv(s.K, 256), 256, 0, st, s, w);
+            const int total_items = (max_iter - 1) * n_tiles;
+            const int blocks = std::min(total_items, sweeps_resident_blocks());
+            hipEvent_t ev_a = nullptr, ev_b = nullptr;
+            if (prof.pair) prof.pair(prof.user, 0, &ev_a, &ev_b);
+            if (ev_a) hipExtLaunchKernelGGL(k_slic_sweeps, dim3(blocks), dim3(256), 0, st, ev_a, ev_b, 0, s, lab, labels, w);
+            else hipLaunchKernelGGL(k_slic_sweeps, dim3(blocks), dim3(256), 0, st, s, lab, labels, w);
+            HIP_TRY(hipGetLastError());
+            g_sweep_persistent.fetch_add(1);
+            if (used_persistent) *used_persistent = true;
+            return 0;
+        }
         hipLaunchKernelGGL(k_slic_bin, cdiv(n_tiles, BIN_TILES_PER_BLOCK), 256,
                            (size_t)std::min(s.K, BIN_MAX_K_LDS) * sizeof(int4), st, s, (int)grid.x, n_tiles, max_cand,
                            s.tile_cands, s.tile_count, it % SLIC_DRIFT_SLOTS);
@@ -1545,7 +2117,7 @@ int launch_slic_iterations(SlicState s, const double *lab, const double *init_yx
         const bool accum = it + 1 < max_iter;
         // when profiling, the event pair rides on the dispatch itself (kernel begin / end timestamps)
         hipEvent_t ev_a = nullptr, ev_b = nullptr;
-        if (prof.pair) prof.pair(prof.user, 0, &ev_a, &ev_b);
+        if (prof.pair && !persistent) prof.pair(prof.user, 0, &ev_a, &ev_b);     // (persistent: the pair rides on k_slic_sweeps)
 // (with a profiler pair: the extended launch that stamps the dispatch; otherwise a plain launch, which a stream capture records)
 #define LAUNCH_ON(kernel, g, ...)                                                                                    \
     {                                                                                                                \

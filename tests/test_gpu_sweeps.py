@@ -1,0 +1,77 @@
+"""The ONE persistent launch of the SLIC sweeps 2..max_iter (csrc/slic.hip k_slic_sweeps) against the per-sweep launches and the
+oracle: identical label maps (the fixed-point centroid sums are order independent), ordinary images stay on the persistent
+path, and every hand-back to the per-sweep launches gives the same result."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def hip():
+    from pyimsegm_amd import _hip
+    _hip.load_library()
+    return _hip
+
+
+def _labels(image, sp_size, regul):
+    from pyimsegm_amd.superpixels import segment_slic_img2d
+    return np.asarray(segment_slic_img2d(image, sp_size, regul))
+
+
+@pytest.mark.parametrize('shape,sp_size,regul,seed', [((512, 640), 30, 0.2, 3), ((647, 1024), 35, 0.2, 100), ((300, 1000), 24, 0.3, 4),
+                                                     ((1030, 515), 46, 0.2, 5), ((1024, 1024), 40, 0.1, 6)])
+def test_persistent_sweeps_equal_the_per_sweep_launches_and_the_oracle(hip, monkeypatch, shape, sp_size, regul, seed):
+    from oracle import oracle as orc
+    from pyimsegm_amd.utilities.synthetic import voronoi_image
+    image = voronoi_image(shape[0], shape[1], seed=seed)
+    p0, f0 = hip.slic_sweep_runs()
+    one_launch = _labels(image, sp_size, regul)
+    p1, f1 = hip.slic_sweep_runs()
+    assert (p1 - p0, f1 - f0) == (1, 0), 'the image left the persistent path'
+    monkeypatch.setenv('IMSEGM_SLIC_PER_SWEEP', '1')
+    per_sweep = _labels(image, sp_size, regul)
+    assert hip.slic_sweep_runs() == (p1, f1)
+    assert np.array_equal(one_launch, per_sweep)
+    assert np.array_equal(one_launch, orc.segment_slic_img2d(image, sp_size, regul))
+
+
+def test_handed_back_images_give_the_same_labels(hip, monkeypatch):
+    """a drift bound of one pixel: the first centroid that moves further raises the failure word, the host redoes the sweeps with
+    the per-sweep launches"""
+    from pyimsegm_amd.utilities.synthetic import voronoi_image
+    image = voronoi_image(400, 520, seed=9)
+    want = _labels(image, 25, 0.3)
+    monkeypatch.setenv('IMSEGM_SWEEPS_DRIFT_MAX', '1')
+    p0, f0 = hip.slic_sweep_runs()
+    got = _labels(image, 25, 0.3)
+    p1, f1 = hip.slic_sweep_runs()
+    assert (p1 - p0, f1 - f0) == (1, 1)
+    assert np.array_equal(got, want)
+
+
+def test_noise_image_with_wandering_centroids(hip):
+    """pure noise: the centroids move far and the windows overlap heavily -- whatever path finishes the image, the label map is
+    the oracle's"""
+    from oracle import oracle as orc
+    image = np.random.default_rng(17).integers(0, 256, (384, 448, 3)).astype(np.uint8)
+    assert np.array_equal(_labels(image, 32, 0.05), orc.segment_slic_img2d(image, 32, 0.05))
+
+
+def test_images_in_flight_on_the_persistent_path(hip):
+    """several sessions of different threads run their persistent launches concurrently (work items are pulled by whatever
+    workgroup is resident: no launch depends on having the device to itself)"""
+    from concurrent.futures import ThreadPoolExecutor
+    from pyimsegm_amd.utilities.synthetic import voronoi_image
+    images = [voronoi_image(512, 768, seed=40 + i) for i in range(6)]
+    want = [_labels(im, 32, 0.2) for im in images]
+    with ThreadPoolExecutor(max_workers=3) as pool:
+        for _ in range(3):
+            got = list(pool.map(lambda im: _labels(im, 32, 0.2), images))
+            assert all(np.array_equal(a, b) for a, b in zip(got, want))
