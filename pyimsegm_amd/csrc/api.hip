@@ -624,8 +624,8 @@ int imsegm_image2d_slic(imsegm_image2d *im, int minmax_normalize, int n_segments
         // scratch of the persistent sweep kernel (all sweeps after the first in one launch); its failure word is page-locked
         // host memory that is read after the next synchronisation of this call (the connectivity stage ends with one)
         void *sweep_scratch = nullptr;
-        if (!getenv("IMSEGM_SLIC_PER_SWEEP")) {
-            if (im->sweeps.ensure(sweep_work_bytes(K, max_iter))) return -1;
+        if (getenv("IMSEGM_SLIC_PERSISTENT")) {
+            if (im->sweeps.ensure(sweep_work_bytes(K, max_iter, (int)n_tiles, cdiv(H, SLIC_TILE_Y)))) return -1;
             if (!im->slic_fail_host) HIP_TRY(hipHostMalloc((void **)&im->slic_fail_host, 64, hipHostMallocDefault));
             sweep_scratch = im->sweeps.p;
         }
@@ -688,7 +688,20 @@ int imsegm_image2d_slic(imsegm_image2d *im, int minmax_normalize, int n_segments
             HIP_TRY(hipMemcpyAsync(im->labels.p, im->nearest.p, n * 4, hipMemcpyDeviceToDevice, st));
             if (used_persistent) HIP_TRY(hipStreamSynchronize(st));     // (the failure word is read below)
         }
+        if (used_persistent && slic_sweep_prof_buffer()) {
+            long long h[16];
+            HIP_TRY(hipMemcpy(h, slic_sweep_prof_buffer(), sizeof(h), hipMemcpyDeviceToHost));
+            HIP_TRY(hipMemset(slic_sweep_prof_buffer(), 0, sizeof(h)));
+            if (h[8] > 0) {
+                fprintf(stderr, "[slic sweeps] per item, us:");
+                for (int j = 0; j < 12; ++j)
+                    if (j != 8) fprintf(stderr, " p%d=%.2f", j, (double)h[j] / (double)h[8] / 100.0);
+                fprintf(stderr, "  (%lld items with accumulation)\n", h[8]);
+            }
+        }
         if (!used_persistent || *im->slic_fail_host == 0) break;       // (connectivity ended with a synchronisation)
+        static const bool verbose = getenv("IMSEGM_DEBUG_SWEEPS") != nullptr;
+        if (verbose) fprintf(stderr, "[slic sweeps] %d x %d, K = %d: handed back, code %d\n", H, W, K, *im->slic_fail_host);
         used_persistent = false;
     }
     ctx->end(sp_all);

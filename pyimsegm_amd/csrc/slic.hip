@@ -1493,23 +1493,32 @@ k_slic_assign_dot(SlicState s, const double *__restrict__ lab, int32_t *__restri
 // every sweep after the first in ONE persistent launch
 // ---------------------------------------------------------------------------------------------
 // The sums of a centroid only depend on the pixels inside its own search window, so sweep s + 1 of a tile only depends on
-// the tiles of sweep s within reach of it.  Work items (sweep, 64 x 32 tile) are handed out in sweep-major raster order from
-// one atomic counter to a grid of resident workgroups; every dependency of an item has a smaller number, i.e. it was handed
-// out earlier to a workgroup that is running or done -- no deadlock, whatever the residency.  Per item:
-//   1. wave 0 waits until the centroids of the grid nodes within reach of the tile are published for this sweep
-//      (fin[k] >= sweep), builds the tile's candidate list (what k_slic_bin does) straight into LDS -- the records never
-//      touch global memory -- while the other waves already have their pixel loads in flight;
+// the tiles of sweep s near it.  Work items (sweep, 64 x 32 tile) are handed out in sweep-major raster order from one atomic
+// counter to a grid of resident workgroups; every dependency of an item has a smaller number, i.e. it was handed out
+// earlier to a workgroup that is running or done -- no deadlock, whatever the residency.
+//
+// Which tiles does (s + 1, t) depend on?  A pixel that sweep s gives to centroid k lies in k's window of sweep s, i.e. within
+// R = 2 * step + 1 of c_s[k]; the new centre c_{s+1}[k] is the mean of such pixels, so it lies in that window too; and k can
+// only be a candidate of t in sweep s + 1 if t is within R of c_{s+1}[k].  Hence all pixels that decide a candidate of
+// (s + 1, t) lie within 3 R of t: the tile rows within `wait_rows` of t's row must be complete in sweep s (a counter per row
+// and sweep: rows finish in raster order anyway), and nothing is assumed about how far centroids wander from the grid.
+//
+// Per item:
+//   1. wave 0 waits for those rows, then reads the tile's candidate list of this sweep -- written by the centroids themselves,
+//      see 3 -- and builds the sorted records (what k_slic_bin does) straight into LDS: they never touch global memory;
+//      the other waves already have their pixel loads in flight;
 //   2. both 64 x 16 halves are assigned (the loop of k_slic_assign_dot) and accumulated into ONE set of LDS slots;
-//   3. the slots are flushed into the sums of this sweep (returning atomics: complete when the wave has waited for them),
+//   3. the slots are flushed into the sums of this sweep (returning atomics: complete once the wave has waited for them),
 //      then every candidate's arrival counter is incremented; the tile that makes a counter reach the number of tiles the
-//      centroid's window meets has seen all pixels of that centroid: its lane divides the sums (what k_centroid_finalize
-//      does), writes the record of sweep + 1 write-through (one 128-byte line per record, never rewritten), waits for the
-//      stores and publishes fin[k] = sweep + 1.
-// All cross-workgroup words are agent-scope accesses (sc1 / atomics): the per-XCD L2s are not coherent with each other.
+//      centroid's window meets has seen all of its pixels: that lane divides the sums (what k_centroid_finalize does), writes
+//      the record of sweep + 1 (one 128-byte line per record, written once, never rewritten) and the wave appends the centroid
+//      to the list of every tile its NEW window meets; after all that the tile counts itself into its row's counter.
+// All cross-workgroup words are agent-scope accesses (sc1 / atomics; payload stores are waited for before the counter that
+// publishes them): the per-XCD L2s are not coherent with each other, and no line is read before its final content is there.
 // What the launch cannot take raises the failure flag and the host redoes the image with the per-sweep launches: more than
-// SLIC_MAXC candidates in a tile, a centroid further than drift_max from its grid node (the node range of a tile is sized
-// for that), a pixel that no window covers, a wait that does not end.  The fixed-point sums are order independent, so the
-// label map is bit-identical to the per-sweep launches.
+// SLIC_MAXC candidates in a tile, a pixel that no window covers, a wait that does not end.  The fixed-point sums are order
+// independent and the records of a list are sorted by (lower bound, distance, centroid index), so the label map is
+// bit-identical to the per-sweep launches and does not depend on the order in which workgroups run.
 #define RLX_AGENT __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
 __device__ __forceinline__ double ld_f64_agent(const double *p)
 {
@@ -1539,9 +1548,15 @@ __device__ __forceinline__ double uniform_f64(double v)
     return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
 }
 __device__ __forceinline__ float uniform_f32(float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); }
+#ifndef SLIC_SWEEP_QUEUES
+#define SLIC_SWEEP_QUEUES 8
+#endif
+constexpr int SWEEP_QUEUES = SLIC_SWEEP_QUEUES;            // item counters, one cache line each: item i is handed out by queue i % 8
+constexpr int SWEEP_POISON = 0x40000000;                   // written over the counters by a failure: every later fetch ends its workgroup
 __device__ __forceinline__ void sweep_fail(const SweepWork &w, int code)
 {
-    __hip_atomic_store(w.ctl + 1, code, RLX_AGENT);
+    __hip_atomic_store(w.fail, code, RLX_AGENT);
+    for (int q = 0; q < SWEEP_QUEUES; ++q) __hip_atomic_store(w.ctl + q * 32, SWEEP_POISON, RLX_AGENT);
     *reinterpret_cast<volatile int *>(w.fail_host) = code;
 }
 
@@ -1550,98 +1565,112 @@ struct SweepLds {
     Cand cand[MAXC];
     Rec32 rec[MAXC];
     int k[MAXC];
-    int ck[MAXC];
     float ckey[MAXC], clb[MAXC];
     TileInfo info;
     int item;
 };
-constexpr unsigned SWEEP_SPIN_LIMIT = 1u << 21;       // polls of one wait (~1 s): a logic error must not hang the device
+constexpr unsigned SWEEP_SPIN_LIMIT = 1u << 20;       // polls of one wait (~1 s): a logic error must not hang the device
 
-// candidate list of one tile for sweep `sweep`, by ONE wave, into LDS (k_slic_bin's local path on the published records);
-// returns the list length, or < 0 after raising the failure flag
-__device__ __forceinline__ int sweep_bin_tile(const SlicState &s, const SweepWork &w, const CenRec *tab, int sweep, int tx0,
-                                              int ty0, SweepLds &L, int lane)
+// tiles a search window meets: {first tile row, first tile column, rows, columns}
+__device__ __forceinline__ int4 window_tiles(int4 w)
 {
-    const int tx1 = min(tx0 + TILE_X, s.W), ty1 = min(ty0 + TILE_Y, s.H);
-    const int reach_y = 2 * s.step_y + 1 + w.drift_max, reach_x = 2 * s.step_x + 1 + w.drift_max;
-    auto floor_div = [](int a, int b) { return a >= 0 ? a / b : -((-a + b - 1) / b); };
-    const int ny = s.K / s.grid_nx;
-    const int iy0 = max(0, floor_div(ty0 - reach_y - s.grid_y0 + s.grid_dy - 1, s.grid_dy));
-    const int iy1 = min(ny - 1, floor_div(ty1 + reach_y - s.grid_y0, s.grid_dy));
-    const int ix0 = max(0, floor_div(tx0 - reach_x - s.grid_x0 + s.grid_dx - 1, s.grid_dx));
-    const int ix1 = min(s.grid_nx - 1, floor_div(tx1 + reach_x - s.grid_x0, s.grid_dx));
-    const int nry = max(iy1 - iy0 + 1, 0), nrx = max(ix1 - ix0 + 1, 1);
-    const int total = ix1 >= ix0 ? nry * nrx : 0;
-    int count = 0;
-    for (int k0 = 0; k0 < total; k0 += 64) {
-        const int j = k0 + lane;
-        int k = -1;
-        if (j < total) {
-            const int jy = j / nrx;
-            k = (iy0 + jy) * s.grid_nx + ix0 + (j - jy * nrx);
+    const int ry0 = w.x / TILE_Y, rx0 = w.z / TILE_X;
+    return make_int4(ry0, rx0, (w.y - 1) / TILE_Y - ry0 + 1, (w.w - 1) / TILE_X - rx0 + 1);
+}
+
+// append centroid k to the candidate list of every tile its window (of sweep `sweep`) meets; by a whole wave (uniform arguments)
+__device__ __forceinline__ void sweep_scatter(const SweepWork &w, int sweep, int k, int4 win, int lane)
+{
+    const int4 tl = window_tiles(win);
+    const int nt = tl.z * tl.w;
+    for (int j0 = 0; j0 < nt; j0 += 64) {
+        const int j = j0 + lane;
+        if (j < nt) {
+            const int jy = j / tl.w;
+            const size_t t = (size_t)sweep * w.n_tiles + (size_t)(tl.x + jy) * w.tiles_x + tl.y + (j - jy * tl.w);
+            const int pos = __hip_atomic_fetch_add(w.ccount + t, 1, RLX_AGENT);
+            if (pos < MAXC) __hip_atomic_store(w.clist + t * MAXC + pos, k, RLX_AGENT);
+            else sweep_fail(w, 1);
         }
-        for (unsigned spins = 0;; ++spins) {              // the records of this sweep of all these nodes are published
-            const int f = k >= 0 ? __hip_atomic_load(w.fin + k, RLX_AGENT) : 0x7fffffff;
-            if (__all(f >= sweep)) break;
-            if ((spins & 31) == 31) {
-                if (__builtin_amdgcn_readfirstlane(__hip_atomic_load(w.ctl + 1, RLX_AGENT))) return -1;
+    }
+}
+
+// sorted candidate records of one tile for sweep `sweep`, by ONE wave, into LDS (k_slic_bin on the list the centroids have
+// written); returns the list length, or < 0 after raising the failure flag
+template <bool PROF>
+__device__ __forceinline__ int sweep_bin_tile(const SlicState &s, const SweepWork &w, int sweep, int tile, int tile_row, int tx0,
+                                              int ty0, SweepLds &L, int lane, long long &t_mark, long long (&t_sum)[12])
+{
+#define BIN_MARK(j)                                                                                \
+    if (PROF && lane == 0) {                                                                     \
+        const long long now_ = (long long)wall_clock64();                                          \
+        t_sum[j] += now_ - t_mark;                                                                 \
+        t_mark = now_;                                                                             \
+    }
+    if (sweep > w.sweep_begin) {
+        // the tile rows within reach are through with the previous sweep: ONE word, pushed by the tiles that complete a row
+        const int need = min(tile_row + w.wait_rows, w.tile_rows - 1) - max(tile_row - w.wait_rows, 0) + 1;
+        const int *word = w.rowdone + ((size_t)sweep * w.tile_rows + tile_row) * SWEEP_ROW_STRIDE + 1;
+        for (unsigned spins = 0;; ++spins) {
+            if (__builtin_amdgcn_readfirstlane(__hip_atomic_load(word, RLX_AGENT)) >= need) break;
+            if ((spins & 15) == 15) {
+                if (__builtin_amdgcn_readfirstlane(__hip_atomic_load(w.fail, RLX_AGENT))) return -1;
                 if (spins > SWEEP_SPIN_LIMIT) {
                     if (lane == 0) sweep_fail(w, 4);
                     return -1;
                 }
             }
-            __builtin_amdgcn_s_sleep(2);
+            if (spins < 8) __builtin_amdgcn_s_sleep(8);           // ~0.2 us, then ~0.9 us between polls
+            else __builtin_amdgcn_s_sleep(32);
         }
         asm volatile("" ::: "memory");
-        bool hit = false;
-        float key = 0.f;
-        if (k >= 0) {
-            const int4 wv = ld_win_agent(tab + k);
-            hit = wv.x < ty1 && wv.y > ty0 && wv.z < tx1 && wv.w > tx0;
-            const float my = 0.5f * (float)(wv.x + wv.y) - 0.5f * (float)(ty0 + ty1);
-            const float mx = 0.5f * (float)(wv.z + wv.w) - 0.5f * (float)(tx0 + tx1);
-            key = my * my + mx * mx;
-        }
-        const unsigned long long m = __ballot(hit);
-        if (hit) {
-            const int pos = count + __popcll(m & ((1ULL << lane) - 1ULL));
-            if (pos < MAXC) {
-                L.ck[pos] = k;
-                L.ckey[pos] = key;
-            }
-        }
-        count += __popcll(m);
     }
-    if (count > MAXC) {
+    BIN_MARK(9)                              // rows of the previous sweep
+    const size_t t = (size_t)sweep * w.n_tiles + tile;
+    const int count = __builtin_amdgcn_readfirstlane(__hip_atomic_load(w.ccount + t, RLX_AGENT));
+    if (count > MAXC) {                      // (the centroid that found the list full has raised the flag already)
         if (lane == 0) sweep_fail(w, 1);
         return -1;
     }
     if (count == 0) return 0;
-    __builtin_amdgcn_s_waitcnt(0);
-    __builtin_amdgcn_wave_barrier();
     const bool have = lane < count;
-    // (lanes beyond the list read the first candidate's record: a record that is not published yet must never be touched,
-    // its line would sit stale in this XCD's L2 when it is needed later)
-    const int k = L.ck[have ? lane : 0];
-    const CenRec *r = tab + k;
+    // (lanes beyond the list read the first candidate's record: a record that is not published must never be touched)
+    const int k = __hip_atomic_load(w.clist + t * MAXC + (have ? lane : 0), RLX_AGENT);
+    const CenRec *r = w.cen + (size_t)sweep * s.K + k;
     Cand cd;
     cd.cy = ld_f64_agent(&r->cy); cd.cx = ld_f64_agent(&r->cx);
     cd.cL = ld_f64_agent(&r->cL); cd.ca = ld_f64_agent(&r->ca); cd.cb = ld_f64_agent(&r->cb);
     cd.win = ld_win_agent(r);
     cd.k = k;
+    if (PROF) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    BIN_MARK(10)                             // list + records loaded
+    const int tx1 = min(tx0 + TILE_X, s.W), ty1 = min(ty0 + TILE_Y, s.H);
+    // heuristic sort key: squared distance of the window centre to the tile centre
+    const float my = 0.5f * (float)(cd.win.x + cd.win.y) - 0.5f * (float)(ty0 + ty1);
+    const float mx = 0.5f * (float)(cd.win.z + cd.win.w) - 0.5f * (float)(tx0 + tx1);
+    const float key2 = my * my + mx * mx;
     const double sw = s.spatial_weight;
     const double ryc = cd.cy - (double)(ty0 + 16), rxc = cd.cx - (double)(tx0 + 32);
     const double dy = fmax(fmax(-16.0 - ryc, ryc - 15.0), 0.0), dx = fmax(fmax(-32.0 - rxc, rxc - 31.0), 0.0);
     const float lbt = __double2float_rd((dy * dy + dx * dx) * sw * 0.999999);
-    const float key2 = have ? L.ckey[lane] : 0.f;
-    if (have) L.clb[lane] = lbt;
+    if (have) {
+        L.clb[lane] = lbt;
+        L.ckey[lane] = key2;
+        L.k[lane] = k;                       // (list order; overwritten with the sorted order below)
+    }
     __builtin_amdgcn_s_waitcnt(0);
     __builtin_amdgcn_wave_barrier();
+    // rank by (lower bound of the distance over the tile, distance of the window centre, centroid index): a total order, so
+    // the records do not depend on the order in which the centroids appended themselves
     int rank = 0;
     for (int j = 0; j < count; ++j) {
         const float kj = L.clb[j], k2j = L.ckey[j];
-        rank += (kj < lbt) || (kj == lbt && (k2j < key2 || (k2j == key2 && j < lane)));
+        const int kk = L.k[j];
+        rank += (kj < lbt) || (kj == lbt && (k2j < key2 || (k2j == key2 && kk < k)));
     }
+    __builtin_amdgcn_s_waitcnt(0);
+    __builtin_amdgcn_wave_barrier();
+    // reference colour of the tile: the colour of the first candidate (exact)
     const unsigned long long first = __ballot(have && rank == 0);
     const int src = first ? __ffsll((long long)first) - 1 : 0;
     const double ref0 = __shfl(cd.cL, src, 64), ref1 = __shfl(cd.ca, src, 64), ref2 = __shfl(cd.cb, src, 64);
@@ -1678,114 +1707,142 @@ __device__ __forceinline__ int sweep_bin_tile(const SlicState &s, const SweepWor
         L.info.ref[0] = ref0; L.info.ref[1] = ref1; L.info.ref[2] = ref2;
         L.info.Qy = qm[0]; L.info.Qx = qm[1]; L.info.QL = qm[2]; L.info.Qa = qm[3]; L.info.Qb = qm[4];
     }
+    BIN_MARK(11)                             // records sorted and written
+#undef BIN_MARK
     return count;
 }
 
-// what k_centroid_finalize does, for ONE centroid whose sums of `sweep` are complete; publishes the record of sweep + 1
-__device__ __forceinline__ void sweep_finalize_centroid(const SlicState &s, const SweepWork &w, int sweep, int k)
+// what k_centroid_finalize does, for ONE centroid whose sums of `sweep` are complete: writes the record of sweep + 1 and
+// returns its search window (empty: no pixel carries the label any more -- dead from now on, it joins no list again)
+__device__ __forceinline__ int4 sweep_finalize_centroid(const SlicState &s, const SweepWork &w, int sweep, int k)
 {
     unsigned long long *a = reinterpret_cast<unsigned long long *>(w.acc + ((size_t)sweep * s.K + k) * 9);
     long long v[9];
 #pragma unroll
     for (int j = 0; j < 9; ++j) v[j] = (long long)__hip_atomic_load(a + j, RLX_AGENT);
-    if (v[0] == 0) {
-        // no pixel carries label k any more: dead in every later sweep (empty window, nothing waits for it again)
-        for (int s2 = sweep + 1; s2 < w.sweep_end; ++s2) st_win_agent(w.cen + (size_t)s2 * s.K + k, make_int4(0, 0, 0, 0));
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __hip_atomic_store(w.fin + k, w.sweep_end, RLX_AGENT);
-        return;
-    }
+    if (v[0] == 0) return make_int4(0, 0, 0, 0);
     const double nn = (double)v[0];
     const double cy = i64_to_double(v[1]) / nn, cx = i64_to_double(v[2]) / nn;
     const double finv = ldexp(1.0, -fix_bits_of(*s.premax));
     CenRec *out = w.cen + (size_t)(sweep + 1) * s.K + k;
+    const int4 win = search_window(cy, cx, s.step_y, s.step_x, s.H, s.W);
     st_f64_agent(&out->cy, cy);
     st_f64_agent(&out->cx, cx);
     st_f64_agent(&out->cL, fix_value(v[3], v[4], finv) / nn);
     st_f64_agent(&out->ca, fix_value(v[5], v[6], finv) / nn);
     st_f64_agent(&out->cb, fix_value(v[7], v[8], finv) / nn);
-    st_win_agent(out, search_window(cy, cx, s.step_y, s.step_x, s.H, s.W));
-    const int iy = k / s.grid_nx, ix = k - iy * s.grid_nx;
-    const double dy = fabs(cy - (double)(s.grid_y0 + iy * s.grid_dy)), dx = fabs(cx - (double)(s.grid_x0 + ix * s.grid_dx));
-    if ((int)ceil(fmax(dy, dx)) > w.drift_max) sweep_fail(w, 2);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __hip_atomic_store(w.fin + k, sweep + 1, RLX_AGENT);
+    st_win_agent(out, win);
+    return win;
 }
 
-// records of sweep 1 from the SoA table k_centroid_finalize left after the first sweep; all polled words of this launch
+// records and candidate lists of the first persistent sweep from the SoA table k_centroid_finalize left after sweep 0; the
+// words the launch polls (ctl) -- the counters are zeroed by a memset in front
 __global__ void k_sweeps_init(SlicState s, SweepWork w)
 {
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k == 0) {
-        w.ctl[0] = 0;
-        w.ctl[1] = 0;
-    }
     if (k >= s.K) return;
     const int4 win = s.win[k];
-    const bool dead = win.y <= win.x || win.w <= win.z;
+    if (win.y <= win.x || win.w <= win.z) return;             // dead after the first sweep
     CenRec *out = w.cen + (size_t)w.sweep_begin * s.K + k;
     out->cy = s.cy[k]; out->cx = s.cx[k]; out->cL = s.cL[k]; out->ca = s.ca[k]; out->cb = s.cb[k];
     out->win = win;
-    if (dead)
-        for (int s2 = w.sweep_begin + 1; s2 < w.sweep_end; ++s2) w.cen[(size_t)s2 * s.K + k].win = make_int4(0, 0, 0, 0);
-    w.fin[k] = dead ? w.sweep_end : w.sweep_begin;
+    const int4 tl = window_tiles(win);
+    for (int jy = 0; jy < tl.z; ++jy)
+        for (int jx = 0; jx < tl.w; ++jx) {
+            const size_t t = (size_t)w.sweep_begin * w.n_tiles + (size_t)(tl.x + jy) * w.tiles_x + tl.y + jx;
+            const int pos = atomicAdd(w.ccount + t, 1);
+            if (pos < MAXC) w.clist[t * MAXC + pos] = k;
+        }
 }
 
 #ifndef SLIC_SWEEPS_MIN_BLOCKS
-#define SLIC_SWEEPS_MIN_BLOCKS 5
+#define SLIC_SWEEPS_MIN_BLOCKS 4
 #endif
+// PROF: the instantiation with the phase timers (IMSEGM_DEBUG_SWEEPS); the production kernel carries none of it
+template <bool PROF>
 __global__ void __launch_bounds__(256, SLIC_SWEEPS_MIN_BLOCKS)
 k_slic_sweeps(SlicState s, const double *__restrict__ lab, int32_t *__restrict__ labels, SweepWork w)
 {
     __shared__ SweepLds L;
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const size_t plane = (size_t)s.H * s.W;
     const double sw = s.spatial_weight;
     const int total_items = (w.sweep_end - w.sweep_begin) * w.n_tiles;
     const double fscale = uniform_f64(ldexp(1.0, fix_bits_of(*s.premax)));
+    if (w.force_fail && blockIdx.x == 0 && threadIdx.x == 0) sweep_fail(w, 9);
+    if (w.sweep_begin > 1 && __builtin_amdgcn_readfirstlane(__hip_atomic_load(w.fail, RLX_AGENT))) return;     // an earlier launch gave the image back
+    int queue = blockIdx.x & (SWEEP_QUEUES - 1);           // (thread 0's; workgroup b is observed on XCD b % 8)
+    // (IMSEGM_DEBUG_SWEEPS) phase times of thread 0 summed in registers, one set of atomics per workgroup at the very end
+    long long t_mark = 0, t_sum[12] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
+#define SWEEP_MARK(j)                                                                              \
+    if (PROF && tid == 0) {                                                                      \
+        const long long now_ = (long long)wall_clock64();                                          \
+        t_sum[j] += now_ - t_mark;                                                                 \
+        t_mark = now_;                                                                             \
+    }
 
     for (;;) {
+        // (the thread index is made opaque once per item: everything derived from it -- lane constants, LDS addresses -- is
+        // recomputed per item instead of being hoisted out of this loop into registers that live through the whole kernel)
+        int tid = threadIdx.x;
+        asm volatile("" : "+v"(tid));
+        const int lane = tid & 63;
+        const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
         __syncthreads();                                   // the LDS of the previous item is free
+        if (PROF && tid == 0) t_mark = (long long)wall_clock64();
         if (tid == 0) {
-            int it = __hip_atomic_fetch_add(w.ctl, 1, RLX_AGENT);
-            if (__hip_atomic_load(w.ctl + 1, RLX_AGENT)) it = 0x7fffffff;
+            // own queue first; a workgroup whose queue has run dry takes from the others (the tail of the launch)
+            int it = 0x7fffffff;
+            for (int tries = 0; tries < SWEEP_QUEUES; ++tries) {
+                const int j = __hip_atomic_fetch_add(w.ctl + queue * 32, 1, RLX_AGENT);
+                if (j >= SWEEP_POISON) break;
+                const long cand_item = (long)j * SWEEP_QUEUES + queue;
+                if (cand_item < total_items) {
+                    it = (int)cand_item;
+                    break;
+                }
+                queue = (queue + 1) & (SWEEP_QUEUES - 1);
+            }
             L.item = it;
         }
         __syncthreads();
         const int item = __builtin_amdgcn_readfirstlane(L.item);
-        if (item >= total_items) break;
+        if (item >= total_items) break;                    // (all queues dry, or a failure has poisoned them)
         const int sweep = w.sweep_begin + item / w.n_tiles;
         const int tile = item - (sweep - w.sweep_begin) * w.n_tiles;
         const int tile_row = tile / w.tiles_x;
         const int tx0 = (tile - tile_row * w.tiles_x) * TILE_X, ty0 = tile_row * TILE_Y;
-        const bool accum = sweep + 1 < w.sweep_end;
+        const bool accum = sweep + 1 < w.sweep_last;
         const int x = tx0 + lane;
         const bool xin = x < s.W;
 
         // pixels of the upper half first: their latency covers the wait and the candidate list
         double pL[ROWS], pA[ROWS], pB[ROWS];
+        auto load_rows = [&](int wy) {
 #pragma unroll
-        for (int r = 0; r < ROWS; ++r) {
-            const int y = ty0 + wave * ROWS + r;
-            const bool ok = xin && y < s.H;
-            const size_t p = (size_t)(ok ? y : 0) * s.W + (ok ? x : 0);
-            pL[r] = lab[p];
-            pA[r] = lab[plane + p];
-            pB[r] = lab[2 * plane + p];
-        }
+            for (int r = 0; r < ROWS; ++r) {
+                const int y = wy + r;
+                const bool ok = xin && y < s.H;
+                const size_t p = (size_t)(ok ? y : 0) * s.W + (ok ? x : 0);
+                pL[r] = lab[p];
+                pA[r] = lab[plane + p];
+                pB[r] = lab[2 * plane + p];
+            }
+        };
         for (int i = tid; i < MAXC * 9; i += 256) (&L.lacc[0][0])[i] = 0;
+        SWEEP_MARK(0)                                      // item fetched
         if (wave == 0) {
-            const int cnt = sweep_bin_tile(s, w, w.cen + (size_t)sweep * s.K, sweep, tx0, ty0, L, lane);
+            // (wave 0 takes its pixels after the list: nothing of them lives in its registers meanwhile)
+            const int cnt = sweep_bin_tile<PROF>(s, w, sweep, tile, tile_row, tx0, ty0, L, lane, t_mark, t_sum);
             if (lane == 0) L.info.count = cnt;
+            load_rows(ty0);
+        } else {
+            load_rows(ty0 + wave * ROWS);
         }
+        SWEEP_MARK(1)                                      // wait for the rows + candidate records
         __syncthreads();
+        SWEEP_MARK(2)
         const int nc = __builtin_amdgcn_readfirstlane(L.info.count);
-        if (nc < 0) continue;                              // failure flag is up: the next fetch ends the loop
-        const int my_k = L.k[lane];
-        const float4 my_ra = reinterpret_cast<const float4 *>(&L.rec[lane])[0];      // q0, qx, qy, qL
-        const float4 my_rb = reinterpret_cast<const float4 *>(&L.rec[lane])[1];      // qa, qb, lbt, meta
+        if (nc < 0) break;                                 // failure flag is up
         // (tile constants: scalar registers, as the scalar loads of k_slic_assign_dot give them)
         const double ref0 = uniform_f64(L.info.ref[0]), ref1 = uniform_f64(L.info.ref[1]), ref2 = uniform_f64(L.info.ref[2]);
         const float xb_base = uniform_f32(16.f * L.info.Qy + 32.f * L.info.Qx), tQL = uniform_f32(L.info.QL), tQa = uniform_f32(L.info.Qa),
@@ -1795,17 +1852,11 @@ k_slic_sweeps(SlicState s, const double *__restrict__ lab, int32_t *__restrict__
         for (int half = 0; half < 2; ++half) {
             const int rel0 = half * WG_Y + wave * ROWS;
             const int wy0 = ty0 + rel0;
-            if (half == 1) {
-#pragma unroll
-                for (int r = 0; r < ROWS; ++r) {
-                    const int y = wy0 + r;
-                    const bool ok = xin && y < s.H;
-                    const size_t p = (size_t)(ok ? y : 0) * s.W + (ok ? x : 0);
-                    pL[r] = lab[p];
-                    pA[r] = lab[plane + p];
-                    pB[r] = lab[2 * plane + p];
-                }
-            }
+            if (half == 1) load_rows(wy0);
+            // candidate table in registers: lane c holds the record of candidate c (re-read from LDS for each half, so that it
+            // does not live in registers across the accumulation of the other half)
+            const float4 my_ra = reinterpret_cast<const float4 *>(&L.rec[lane])[0];      // q0, qx, qy, qL
+            const float4 my_rb = reinterpret_cast<const float4 *>(&L.rec[lane])[1];      // qa, qb, lbt, meta
             int best_s[ROWS];
 #pragma unroll
             for (int r = 0; r < ROWS; ++r) best_s[r] = -1;
@@ -1947,13 +1998,15 @@ k_slic_sweeps(SlicState s, const double *__restrict__ lab, int32_t *__restrict__
             int win_k[ROWS];
             bool uncovered = false;
 #pragma unroll
-            for (int r = 0; r < ROWS; ++r) win_k[r] = __shfl(my_k, best_s[r] & 63, 64);
+            for (int r = 0; r < ROWS; ++r) win_k[r] = L.k[best_s[r] & 63];
 #pragma unroll
             for (int r = 0; r < ROWS; ++r) {
                 const int y = wy0 + r;
                 if (!(xin && y < s.H)) continue;
                 if (best_s[r] >= 0) {
-                    labels[y * s.W + x] = win_k[r];
+                    // only the last sweep's labels are ever read; plain stores of two sweeps to one address from different
+                    // XCDs would reach memory in no particular order (each L2 writes back when it pleases)
+                    if (!accum) labels[y * s.W + x] = win_k[r];
                     pending |= 1u << r;
                 } else {
                     uncovered = true;
@@ -1964,37 +2017,77 @@ k_slic_sweeps(SlicState s, const double *__restrict__ lab, int32_t *__restrict__
             }
             if (accum) accumulate_block_sums(lane, x, wy0, best_s, pending, pL, pA, pB, fscale, L.lacc);
         }
+        SWEEP_MARK(3)                                      // both halves assigned and accumulated (wave 0)
         if (!accum) continue;
         __syncthreads();
-        // LDS slots -> sums of this sweep; the atomics return, so that the wait below covers their completion
+        SWEEP_MARK(4)
+        // LDS slots -> sums of this sweep
         {
             long long *acc = w.acc + (size_t)sweep * s.K * 9;
-            unsigned long long sink = 0;
             for (int i = tid; i < nc * 9; i += 256) {
                 const int c = i / 9, j = i - 9 * c;
                 const long long v = L.lacc[c][j];
                 if (v == 0 || (j >= 3 && ((j - 3) & 1))) continue;
-                unsigned long long *dst = reinterpret_cast<unsigned long long *>(acc + (size_t)L.k[c] * 9 + j);
-                if (j < 3) {
-                    sink += __hip_atomic_fetch_add(dst, (unsigned long long)v, RLX_AGENT);
-                } else {
-                    sink += __hip_atomic_fetch_add(dst, (unsigned long long)(v >> 24), RLX_AGENT);
-                    sink += __hip_atomic_fetch_add(dst + 1, (unsigned long long)(v & 0xffffff), RLX_AGENT);
-                }
+                long long *dst = acc + (size_t)L.k[c] * 9 + j;
+                if (j < 3) atomic_add_i64(dst, v);
+                else fix_add_global(dst, v);
             }
-            asm volatile("s_waitcnt vmcnt(0)" : : "v"(sink) : "memory");
+            // the arrival counters below publish these sums: every wave waits until its atomics are through
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
+        SWEEP_MARK(5)                                      // flush
         __syncthreads();
-        if (wave == 0 && lane < nc) {
-            const int4 wv = L.cand[lane].win;
-            const int expect = ((wv.y - 1) / TILE_Y - wv.x / TILE_Y + 1) * ((wv.w - 1) / TILE_X - wv.z / TILE_X + 1);
-            const int seen = __hip_atomic_fetch_add(w.done + (size_t)sweep * s.K + my_k, 1, RLX_AGENT) + 1;
-            if (seen == expect) sweep_finalize_centroid(s, w, sweep, my_k);
+        SWEEP_MARK(6)
+        if (wave == 0) {
+            // arrival counters; the lane that completes a centroid divides its sums; the wave enters it into the lists of sweep + 1
+            bool last = false;
+            const int my_k = L.k[lane];
+            if (lane < nc) {
+                const int4 tl = window_tiles(L.cand[lane].win);
+                const int seen = __hip_atomic_fetch_add(w.done + (size_t)sweep * s.K + my_k, 1, RLX_AGENT) + 1;
+                last = seen == tl.z * tl.w;
+            }
+            int4 nw = make_int4(0, 0, 0, 0);
+            if (last) nw = sweep_finalize_centroid(s, w, sweep, my_k);
+            unsigned long long todo = __ballot(last && nw.y > nw.x);
+            while (todo) {
+                const int b = __ffsll((long long)todo) - 1;
+                todo &= todo - 1;
+                sweep_scatter(w, sweep + 1, __builtin_amdgcn_readlane(my_k, b),
+                              make_int4(__builtin_amdgcn_readlane(nw.x, b), __builtin_amdgcn_readlane(nw.y, b),
+                                        __builtin_amdgcn_readlane(nw.z, b), __builtin_amdgcn_readlane(nw.w, b)), lane);
+            }
+            // everything this tile publishes has arrived; then it counts itself into its row
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            int through = 0;
+            if (lane == 0) through = __hip_atomic_fetch_add(w.rowdone + ((size_t)sweep * w.tile_rows + tile_row) * SWEEP_ROW_STRIDE, 1, RLX_AGENT) + 1;
+            if (__builtin_amdgcn_readfirstlane(through) == w.tiles_x && sweep + 1 < w.sweep_end) {      // (within this launch)
+                // this tile completed its row (every other tile of the row had everything published before it counted itself):
+                // tell the rows of the next sweep that depend on it
+                const int r_lo = max(tile_row - w.wait_rows, 0), r_hi = min(tile_row + w.wait_rows, w.tile_rows - 1);
+                for (int r = r_lo + lane; r <= r_hi; r += 64)
+                    __hip_atomic_fetch_add(w.rowdone + ((size_t)(sweep + 1) * w.tile_rows + r) * SWEEP_ROW_STRIDE + 1, 1, RLX_AGENT);
+            }
         }
+        SWEEP_MARK(7)                                      // arrivals, centroid updates, list entries
+        if (PROF && tid == 0) t_sum[8] += 1;
     }
+#undef SWEEP_MARK
+    if (PROF && threadIdx.x == 0)
+        for (int j = 0; j < 12; ++j) atomic_add_i64(w.prof + j, t_sum[j]);
 }
 
 static std::atomic<long> g_sweep_persistent{0}, g_sweep_fallback{0};
+long long *slic_sweep_prof_buffer()
+{
+    static long long *buf = nullptr;
+    static const bool on = getenv("IMSEGM_DEBUG_SWEEPS") != nullptr;
+    if (on && !buf) {
+        if (hipMalloc(&buf, 16 * sizeof(long long)) != hipSuccess) return nullptr;
+        (void)hipMemset(buf, 0, 16 * sizeof(long long));
+    }
+    return buf;
+}
 void slic_sweep_counters(long *persistent_runs, long *fallback_runs)
 {
     if (persistent_runs) *persistent_runs = g_sweep_persistent.load();
@@ -2024,7 +2117,7 @@ static int sweeps_resident_blocks()
     if (hipGetDevice(&dev) != hipSuccess) return 1280;
     if (dev >= 0 && dev < IMSEGM_MAX_DEVICES && cached[dev]) return cached[dev];
     int per_cu = 0, cus = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)k_slic_sweeps, 256, 0) != hipSuccess || per_cu < 1) per_cu = 4;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)k_slic_sweeps<false>, 256, 0) != hipSuccess || per_cu < 1) per_cu = 4;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 256;
     if (const char *e = getenv("IMSEGM_SWEEPS_BLOCKS_PER_CU")) per_cu = std::max(1, atoi(e));
     const int n = per_cu * cus;
@@ -2065,40 +2158,57 @@ int launch_slic_iterations(SlicState s, const double *lab, const double *init_yx
         HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void *)k_slic_assign_dot<false, false, 1, false>, 256, 0));
         fprintf(stderr, "[occupancy] k_slic_assign_dot<false>: %d workgroups per CU\n", nb);
     }
-    // every sweep after the first in one persistent launch (k_slic_sweeps) when the image qualifies: the fp32 fast path, the
-    // closed-form first sweep, the default list capacity, windows that put well under SLIC_MAXC candidates into a tile
+    // every sweep after the first in one persistent launch (k_slic_sweeps) -- on request (IMSEGM_SLIC_PERSISTENT), and when the
+    // image qualifies: the fp32 fast path, the closed-form first sweep, the default list capacity, windows that put well under
+    // SLIC_MAXC candidates into a tile.  Measured on MI355X (round 3) it ties with the per-sweep launches for
+    // one image alone and loses when several images are in flight, so the per-sweep launches stay the default.
     bool persistent = false;
-    int drift_max = 0;
+    const int tile_rows = cdiv(s.H, TILE_Y);
     if (sweep_scratch && fail_host && max_iter >= 3 && s.fast32 && !s.slico && s.spatial_weight > 1e-9 && grid_covers && default_cand &&
-        !s.debug && !s.phase_prof && units == 1 && s.grid_dy > 0 && s.grid_dx > 0 && !getenv("IMSEGM_SLIC_PER_SWEEP")) {
-        drift_max = std::max(s.step_y, s.step_x);
-        if (const char *e = getenv("IMSEGM_SWEEPS_DRIFT_MAX")) drift_max = std::max(0, atoi(e));     // (tests: force the hand-back)
+        !s.debug && !s.phase_prof && units == 1 && s.grid_dy > 0 && s.grid_dx > 0 && getenv("IMSEGM_SLIC_PERSISTENT")) {
         const double per_tile = ((double)TILE_Y + 4.0 * s.step_y + 2.0) * ((double)TILE_X + 4.0 * s.step_x + 2.0) / ((double)s.grid_dy * s.grid_dx);
-        const long nodes = (long)((TILE_Y + 2 * (2 * s.step_y + 1 + drift_max)) / s.grid_dy + 2) * ((TILE_X + 2 * (2 * s.step_x + 1 + drift_max)) / s.grid_dx + 2);
-        persistent = per_tile <= 0.75 * MAXC && nodes <= BIN_LOCAL_MAX;
+        persistent = per_tile <= 0.75 * MAXC;
     }
     for (int it = 0; it < max_iter; ++it) {
         if (persistent && it == 1) {
             SweepWork w;
             unsigned char *p = static_cast<unsigned char *>(sweep_scratch);
             w.cen = reinterpret_cast<CenRec *>(p); p += (size_t)max_iter * s.K * sizeof(CenRec);
+            void *zeroed = p;
+            w.rowdone = reinterpret_cast<int *>(p); p += (size_t)max_iter * tile_rows * SWEEP_ROW_STRIDE * sizeof(int);     // (128-byte aligned)
+            int *ctl_all = reinterpret_cast<int *>(p); p += (size_t)max_iter * SWEEP_QUEUES * 128;                         // per launch
+            w.fail = reinterpret_cast<int *>(p); p += 128;
             w.acc = reinterpret_cast<long long *>(p); p += (size_t)max_iter * s.K * 9 * sizeof(long long);
             w.done = reinterpret_cast<int *>(p); p += (size_t)max_iter * s.K * sizeof(int);
-            w.fin = reinterpret_cast<int *>(p); p += (size_t)s.K * sizeof(int);
-            w.ctl = reinterpret_cast<int *>(p);
+            w.ccount = reinterpret_cast<int *>(p); p += (size_t)max_iter * n_tiles * sizeof(int);
+            w.clist = reinterpret_cast<int *>(p); p += (size_t)max_iter * n_tiles * MAXC * sizeof(int);
             w.fail_host = fail_host;
-            w.n_tiles = n_tiles; w.tiles_x = (int)grid.x;
-            w.sweep_begin = 1; w.sweep_end = max_iter;
-            w.drift_max = drift_max;
+            w.n_tiles = n_tiles; w.tiles_x = (int)grid.x; w.tile_rows = tile_rows;
+            w.sweep_last = max_iter;
+            // pixels that decide a candidate of a tile lie within 3 * (2 * step + 1) rows of it (see k_slic_sweeps)
+            w.wait_rows = (3 * (2 * s.step_y + 1) + TILE_Y - 1) / TILE_Y + 1;
+            w.force_fail = getenv("IMSEGM_SWEEPS_FORCE_FAIL") != nullptr;       // (tests: exercise the hand-back)
+            w.prof = slic_sweep_prof_buffer();
             *fail_host = 0;
-            HIP_TRY(hipMemsetAsync(w.acc, 0, (size_t)max_iter * s.K * (9 * sizeof(long long) + sizeof(int)), st));
+            HIP_TRY(hipMemsetAsync(zeroed, 0, sweep_zeroed_bytes(s.K, max_iter, n_tiles, tile_rows), st));
+            w.sweep_begin = 1; w.sweep_end = max_iter; w.ctl = ctl_all;
             hipLaunchKernelGGL(k_sweeps_init, cdiv(s.K, 256), 256, 0, st, s, w);
-            const int total_items = (max_iter - 1) * n_tiles;
-            const int blocks = std::min(total_items, sweeps_resident_blocks());
-            hipEvent_t ev_a = nullptr, ev_b = nullptr;
-            if (prof.pair) prof.pair(prof.user, 0, &ev_a, &ev_b);
-            if (ev_a) hipExtLaunchKernelGGL(k_slic_sweeps, dim3(blocks), dim3(256), 0, st, ev_a, ev_b, 0, s, lab, labels, w);
-            else hipLaunchKernelGGL(k_slic_sweeps, dim3(blocks), dim3(256), 0, st, s, lab, labels, w);
+            // sweeps per launch: all of them by default; fewer (IMSEGM_SWEEPS_PER_LAUNCH) trades the waits between dependent tiles of
+            // consecutive sweeps for launch boundaries
+            int per_launch = max_iter - 1;
+            if (const char *e = getenv("IMSEGM_SWEEPS_PER_LAUNCH")) per_launch = std::min(std::max(atoi(e), 1), max_iter - 1);
+            if (w.prof) fprintf(stderr, "[slic sweeps] %d x %d: %d items, %d workgroups, wait_rows %d, %d sweeps per launch\n", s.H, s.W,
+                                (max_iter - 1) * n_tiles, std::min(per_launch * n_tiles, sweeps_resident_blocks()), w.wait_rows, per_launch);
+            for (int sb = 1, g = 0; sb < max_iter; sb += per_launch, ++g) {
+                w.sweep_begin = sb; w.sweep_end = std::min(sb + per_launch, max_iter);
+                w.ctl = ctl_all + (size_t)g * SWEEP_QUEUES * 32;
+                const int blocks = std::min((w.sweep_end - w.sweep_begin) * n_tiles, sweeps_resident_blocks());
+                hipEvent_t ev_a = nullptr, ev_b = nullptr;
+                if (prof.pair) prof.pair(prof.user, 0, &ev_a, &ev_b);
+                if (w.prof) hipLaunchKernelGGL(k_slic_sweeps<true>, dim3(blocks), dim3(256), 0, st, s, lab, labels, w);
+                else if (ev_a) hipExtLaunchKernelGGL(k_slic_sweeps<false>, dim3(blocks), dim3(256), 0, st, ev_a, ev_b, 0, s, lab, labels, w);
+                else hipLaunchKernelGGL(k_slic_sweeps<false>, dim3(blocks), dim3(256), 0, st, s, lab, labels, w);
+            }
             HIP_TRY(hipGetLastError());
             g_sweep_persistent.fetch_add(1);
             if (used_persistent) *used_persistent = true;

@@ -1,6 +1,6 @@
-"""The ONE persistent launch of the SLIC sweeps 2..max_iter (csrc/slic.hip k_slic_sweeps) against the per-sweep launches and the
-oracle: identical label maps (the fixed-point centroid sums are order independent), ordinary images stay on the persistent
-path, and every hand-back to the per-sweep launches gives the same result."""
+"""The ONE persistent launch of the SLIC sweeps 2..max_iter (csrc/slic.hip k_slic_sweeps, opt-in: IMSEGM_SLIC_PERSISTENT) against
+the per-sweep launches and the oracle: identical label maps (the fixed-point centroid sums are order independent), ordinary
+images stay on the persistent path, and every hand-back to the per-sweep launches gives the same result."""
 import os
 import sys
 
@@ -20,22 +20,30 @@ def hip():
     return _hip
 
 
+@pytest.fixture(autouse=True)
+def persistent_sweeps(monkeypatch):
+    monkeypatch.setenv('IMSEGM_SLIC_PERSISTENT', '1')
+
+
 def _labels(image, sp_size, regul):
     from pyimsegm_amd.superpixels import segment_slic_img2d
     return np.asarray(segment_slic_img2d(image, sp_size, regul))
 
 
-@pytest.mark.parametrize('shape,sp_size,regul,seed', [((512, 640), 30, 0.2, 3), ((647, 1024), 35, 0.2, 100), ((300, 1000), 24, 0.3, 4),
-                                                     ((1030, 515), 46, 0.2, 5), ((1024, 1024), 40, 0.1, 6)])
-def test_persistent_sweeps_equal_the_per_sweep_launches_and_the_oracle(hip, monkeypatch, shape, sp_size, regul, seed):
+@pytest.mark.parametrize('shape,sp_size,regul,seed,per_launch', [
+    ((512, 640), 30, 0.2, 3, 9), ((647, 1024), 35, 0.2, 100, 9), ((300, 1000), 24, 0.3, 4, 9), ((1030, 515), 46, 0.2, 5, 9),
+    ((1024, 1024), 40, 0.1, 6, 9), ((647, 1024), 35, 0.2, 101, 1), ((512, 640), 30, 0.2, 7, 4)])
+def test_persistent_sweeps_equal_the_per_sweep_launches_and_the_oracle(hip, monkeypatch, shape, sp_size, regul, seed, per_launch):
+    """`per_launch` < 9: the sweeps in groups of that many per launch (the launch boundary stands in for the waits between them)"""
     from oracle import oracle as orc
     from pyimsegm_amd.utilities.synthetic import voronoi_image
     image = voronoi_image(shape[0], shape[1], seed=seed)
+    monkeypatch.setenv('IMSEGM_SWEEPS_PER_LAUNCH', str(per_launch))
     p0, f0 = hip.slic_sweep_runs()
     one_launch = _labels(image, sp_size, regul)
     p1, f1 = hip.slic_sweep_runs()
     assert (p1 - p0, f1 - f0) == (1, 0), 'the image left the persistent path'
-    monkeypatch.setenv('IMSEGM_SLIC_PER_SWEEP', '1')
+    monkeypatch.delenv('IMSEGM_SLIC_PERSISTENT')
     per_sweep = _labels(image, sp_size, regul)
     assert hip.slic_sweep_runs() == (p1, f1)
     assert np.array_equal(one_launch, per_sweep)
@@ -43,12 +51,11 @@ def test_persistent_sweeps_equal_the_per_sweep_launches_and_the_oracle(hip, monk
 
 
 def test_handed_back_images_give_the_same_labels(hip, monkeypatch):
-    """a drift bound of one pixel: the first centroid that moves further raises the failure word, the host redoes the sweeps with
-    the per-sweep launches"""
+    """the failure word raised (here: on request): the host redoes the sweeps with the per-sweep launches"""
     from pyimsegm_amd.utilities.synthetic import voronoi_image
     image = voronoi_image(400, 520, seed=9)
     want = _labels(image, 25, 0.3)
-    monkeypatch.setenv('IMSEGM_SWEEPS_DRIFT_MAX', '1')
+    monkeypatch.setenv('IMSEGM_SWEEPS_FORCE_FAIL', '1')
     p0, f0 = hip.slic_sweep_runs()
     got = _labels(image, 25, 0.3)
     p1, f1 = hip.slic_sweep_runs()
