@@ -223,6 +223,10 @@ typedef struct {
     double *centres;              /* K x ndim */
     int64_t *energy;              /* final integer energy of the expansion */
     int keep_soft_on_device;      /* in: compute proba[slic] into the session's buffer even when soft_out is NULL */
+    /* in: narrow result formats (NOT the reference's dtypes -- explicit opt-in of the caller, SURVEY section 8f row 3: the
+     * 100 MB float64 soft segmentation / the int32 class map dominate the device-to-host time once the kernels are fast) */
+    int segm_u8;                  /* segm_out points to uint8 (height x width), classes must be < 256 */
+    int soft_f32;                 /* soft_out points to float32 (height x width x n_classes) */
 } imsegm_terms_debug;
 
 /* Replaces, on the resident label map (and feature table): model.predict_proba (gmm != NULL; else `proba`, K x C, comes
@@ -264,6 +268,17 @@ IMSEGM_API int imsegm_image2d_device_ptr(imsegm_image2d *img, int which, void **
 /* ---------------------------------------------------------------------------------------------
  * stand-alone stages
  * ------------------------------------------------------------------------------------------- */
+/* Replaces imsegm.labeling.assume_bg_on_boundary(segm, bg_label, boundary_size) for 2-D label images
+ * (/root/reference/imsegm/labeling.py:719-753; called by the driver right after the pipeline,
+ * experiments_segmentation/run_segm_slic_model_graphcut.py:373,422) including the border statistics of
+ * imsegm.utilities.data_io.get_image2d_boundary_color (utilities/data_io.py:1025-1027: np.bincount over the four border
+ * strips `image[:size, :], image[:, :size].T, image[-size:, :], image[:, -size:].T`, argmax = lowest label on ties).
+ * segm_inout: host int32, height x width, non-negative on the border; strips: the four slices as {row0, row1, col0, col1}
+ * (the caller resolves numpy's slice semantics); the label that dominates the border and `bg_label` are exchanged in place.
+ * Returns < 0 with "negative label" when np.bincount would raise. */
+IMSEGM_API int imsegm_assume_bg_on_boundary(imsegm_ctx *ctx, int32_t *segm_inout, int height, int width, const int32_t strips[16],
+                                            int bg_label, int *boundary_label_out);
+
 /* Replaces imsegm.features_cython.computeLabelHistogram2d (imsegm/features_cython.pyx:222-241; called per position through
  * descriptors.py:1411-1495 compute_label_hist_segm / cython_label_hist_seg2d) for a BATCH of windows of one label image:
  * window p = segm[y0 : y0 + h, x0 : x0 + w] against struc_elem[sy0 : sy0 + h, sx0 : sx0 + w], windows[p] = {y0, x0, h, w, sy0,

@@ -55,7 +55,7 @@ class TermsDebug(C.Structure):
     """``imsegm_terms_debug`` of include/imsegm_hip.h"""
     _fields_ = [('edge_capacity', C.c_int), ('n_edges', C.c_int), ('edges', _vp), ('edge_weights', _vp),
                 ('edge_weights_int', _vp), ('unary', _vp), ('unary_int', _vp), ('centres', _vp), ('energy', _vp),
-                ('keep_soft_on_device', C.c_int)]
+                ('keep_soft_on_device', C.c_int), ('segm_u8', C.c_int), ('soft_f32', C.c_int)]
 
 
 #: edge types of ``imsegm_image2d_segment``; 0x100 = divide by the relative centre distance (graph_cuts.py:647-650)
@@ -94,6 +94,7 @@ _SIGNATURES = {
     'imsegm_image2d_enforce_connectivity': (C.c_int, [_vp, _vp, C.c_long, C.c_long, C.c_int, _vp]),
     'imsegm_debug_conn_general_runs': (C.c_long, []),
     'imsegm_debug_slic_sweep_runs': (C.c_int, [_vp, _vp]),
+    'imsegm_assume_bg_on_boundary': (C.c_int, [_vp, _vp, C.c_int, C.c_int, _vp, C.c_int, _ip]),
     'imsegm_image2d_label_hist': (C.c_int, [_vp, _vp, C.c_int, _vp]),
     'imsegm_image2d_get_lab': (C.c_int, [_vp, _vp]),
     'imsegm_image2d_get_nearest': (C.c_int, [_vp, _vp]),
@@ -456,7 +457,7 @@ class Image2D(object):
 
     def segment(self, pairwise, edge_type='model', edge_cost=1., gmm=None, proba=None, use_graphcut=True, classes=None,
                 want_segm=True, want_soft=False, want_graph_labels=False, want_proba=False, debug=False, pinned=True,
-                keep_soft_on_device=False):
+                keep_soft_on_device=False, segm_dtype=None, soft_dtype=None):
         """fused back half of the pipeline on the resident label map (``imsegm_image2d_segment``): class probabilities
         (``gmm``: :class:`DeviceGmm` on the resident features, else ``proba`` K x C from the host), unary / edge terms,
         alpha-expansion, ``classes[graph_labels][slic]`` and ``proba[slic]``; one synchronisation.
@@ -485,18 +486,28 @@ class Image2D(object):
             raise ValueError('classes must hold one value per class')
         alloc = pinned_empty if pinned else np.empty
         out = {}
+        # narrow result formats (explicit opt-in, not the reference's dtypes): uint8 class map, float32 soft segmentation
+        segm_u8 = segm_dtype is not None and np.dtype(segm_dtype) == np.uint8
+        soft_f32 = soft_dtype is not None and np.dtype(soft_dtype) == np.float32
+        if segm_dtype is not None and not segm_u8 and np.dtype(segm_dtype) != np.int32:
+            raise ValueError('the class map leaves the device as int32 (the reference) or uint8')
+        if soft_dtype is not None and not soft_f32 and np.dtype(soft_dtype) != np.float64:
+            raise ValueError('the soft segmentation leaves the device as float64 (the reference) or float32')
+        if segm_u8 and (nc > 256 or (cl is not None and (cl.min() < 0 or cl.max() > 255))):
+            raise ValueError('uint8 class map: class values must lie in 0..255')
         if want_segm:
-            out['segm'] = alloc(self.shape, np.int32)
+            out['segm'] = alloc(self.shape, np.uint8 if segm_u8 else np.int32)
         if want_soft:
-            out['soft'] = alloc(self.shape + (nc, ), np.float64)
+            out['soft'] = alloc(self.shape + (nc, ), np.float32 if soft_f32 else np.float64)
         if want_graph_labels or debug:
             out['graph_labels'] = np.empty(k, dtype=np.int32)
         if want_proba or debug:
             out['proba'] = np.empty((k, nc), dtype=np.float64)
         dbg = None
-        if debug or keep_soft_on_device:
+        if debug or keep_soft_on_device or segm_u8 or soft_f32:
             dbg = TermsDebug()
             dbg.keep_soft_on_device = int(bool(keep_soft_on_device))
+            dbg.segm_u8, dbg.soft_f32 = int(segm_u8), int(soft_f32)
         if debug:
             cap = (16 if len(self.shape) == 3 else 3) * k + 64
             ndim = len(self.shape)

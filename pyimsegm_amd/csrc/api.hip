@@ -66,6 +66,7 @@ struct imsegm_ctx {
     double acc_ms[PG_COUNT] = { 0 };
     int acc_n[PG_COUNT] = { 0 };
     DevBuf gc_buf;   // scratch of imsegm_cut_general_graph
+    DevBuf aux_buf;  // small second scratch (border histogram of imsegm_assume_bg_on_boundary)
     void *pinned = nullptr;          // page-locked staging for the small host <-> device transfers
     size_t pinned_cap = 0;
     hipEvent_t pinned_ev = nullptr;   // recorded after an H2D out of `pinned` that nobody waits for
@@ -157,7 +158,7 @@ struct imsegm_image2d {
     bool is_volume = false;
     double vol_off = 0.0, vol_scale = 1.0;      // intensity seen by the volume SLIC = (v + off) * scale
     DevBuf img, labA, labB, nearest, labels, conn_i32, conn_u8, small, cent, tiles, feat, graph, gather_lut, gather_out_i, gather_out_f,
-        tex_planes, tex_resp, tex_small, vol_cent, annot, hist, featK, seg, sweeps;
+        tex_planes, tex_resp, tex_small, vol_cent, annot, hist, featK, seg, sweeps, narrow;
     int *slic_fail_host = nullptr;              // page-locked word the persistent sweep kernel raises when it cannot take the image
     int feat_mask = 0, feat_F = 0;              // layout of the resident feature table (imsegm_image2d_features_color)
     // the ten SLIC sweeps (30 kernel launches + a memset) as one captured HIP graph, re-used while every launch parameter
@@ -342,6 +343,7 @@ void imsegm_ctx_destroy(imsegm_ctx *ctx)
     ctx->collect();
     for (auto e : ctx->pool) (void)hipEventDestroy(e);
     ctx->gc_buf.release();
+    ctx->aux_buf.release();
     if (ctx->pinned_ev) (void)hipEventDestroy(ctx->pinned_ev);
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -411,7 +413,7 @@ void imsegm_image2d_destroy(imsegm_image2d *im)
     DevBuf *all[] = { &im->img, &im->labA, &im->labB, &im->nearest, &im->labels, &im->conn_i32, &im->conn_u8, &im->small,
                       &im->cent, &im->tiles, &im->feat, &im->graph, &im->gather_lut, &im->gather_out_i, &im->gather_out_f,
                       &im->tex_planes, &im->tex_resp, &im->tex_small, &im->vol_cent, &im->annot, &im->hist, &im->featK, &im->seg,
-                      &im->sweeps };
+                      &im->sweeps, &im->narrow };
     for (auto b : all) b->release();
     if (im->slic_fail_host) (void)hipHostFree(im->slic_fail_host);
     if (im->slic_exec) (void)hipGraphExecDestroy(im->slic_exec);
@@ -1769,7 +1771,24 @@ int imsegm_image2d_segment(imsegm_image2d *im, const imsegm_gmm *gmm, const doub
     if (launch_gather_labels(lut, im->labels.as<int32_t>(), n, im->gather_out_i.as<int32_t>(), st)) return -1;
     if (want_soft && launch_gather_proba(a.proba, C, im->labels.as<int32_t>(), n, im->gather_out_f.as<double>(), st)) return -1;
     ctx->end(spq);
-    // ---- results
+    // ---- results (int32 / float64 as the reference returns them, or the narrow formats the caller asked for)
+    const bool segm_u8 = debug_out && debug_out->segm_u8, soft_f32 = debug_out && debug_out->soft_f32;
+    if ((segm_u8 && segm_out) || (soft_f32 && soft_out)) {
+        const size_t off_soft = (n + 255) & ~(size_t)255;
+        if (im->narrow.ensure(off_soft + n * C * 4 + 64)) return -1;
+        unsigned char *nb = im->narrow.as<unsigned char>();
+        if (segm_u8 && segm_out) {
+            if (launch_narrow_labels_u8(im->gather_out_i.as<int32_t>(), nb, n, st)) return -1;
+            HIP_TRY(hipMemcpyAsync(segm_out, nb, n, hipMemcpyDeviceToHost, st));
+            segm_out = nullptr;
+        }
+        if (soft_f32 && soft_out) {
+            float *f32 = reinterpret_cast<float *>(nb + off_soft);
+            if (launch_narrow_soft_f32(im->gather_out_f.as<double>(), f32, n * C, st)) return -1;
+            HIP_TRY(hipMemcpyAsync(soft_out, f32, n * C * 4, hipMemcpyDeviceToHost, st));
+            soft_out = nullptr;
+        }
+    }
     if (segm_out) HIP_TRY(hipMemcpyAsync(segm_out, im->gather_out_i.p, n * 4, hipMemcpyDeviceToHost, st));
     if (soft_out) HIP_TRY(hipMemcpyAsync(soft_out, im->gather_out_f.p, n * C * 8, hipMemcpyDeviceToHost, st));
     if (graph_labels_out) HIP_TRY(hipMemcpyAsync(graph_labels_out, glab, (size_t)K * 4, hipMemcpyDeviceToHost, st));
@@ -1836,6 +1855,61 @@ static int ctx_scratch(imsegm_ctx *ctx, size_t bytes, unsigned char **dev)
 {
     if (ctx->gc_buf.ensure(bytes + 256)) return -1;
     *dev = ctx->gc_buf.as<unsigned char>();
+    return 0;
+}
+
+int imsegm_assume_bg_on_boundary(imsegm_ctx *ctx, int32_t *segm_inout, int height, int width, const int32_t strips[16], int bg_label,
+                                 int *boundary_label_out)
+{
+    if (bind(ctx)) return -1;
+    if (!segm_inout || !strips || height <= 0 || width <= 0) {
+        set_error("assume_bg_on_boundary: bad arguments");
+        return -1;
+    }
+    for (int q = 0; q < 4; ++q)
+        if (strips[4 * q] < 0 || strips[4 * q + 1] > height || strips[4 * q + 2] < 0 || strips[4 * q + 3] > width) {
+            set_error("assume_bg_on_boundary: border strip outside the image");
+            return -1;
+        }
+    hipStream_t st = ctx->stream;
+    const size_t n = (size_t)height * width;
+    unsigned char *dev = nullptr;
+    if (ctx_scratch(ctx, n * 4 + 64, &dev)) return -1;
+    int32_t *labels = reinterpret_cast<int32_t *>(dev);
+    HIP_TRY(hipMemcpyAsync(labels, segm_inout, n * 4, hipMemcpyHostToDevice, st));
+    // label range on the border (np.bincount sizes its result by the largest value and refuses negative ones)
+    int32_t *mm_dev = nullptr;
+    DevBuf &hb = ctx->aux_buf;
+    if (hb.ensure(64)) return -1;
+    mm_dev = hb.as<int32_t>();
+    if (launch_boundary_minmax(labels, width, strips, mm_dev, st)) return -1;
+    int32_t mm[2] = { 0, 0 };
+    HIP_TRY(hipMemcpyAsync(mm, mm_dev, sizeof(mm), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    if (mm[0] > mm[1]) {
+        set_error("assume_bg_on_boundary: empty border");
+        return -1;
+    }
+    if (mm[0] < 0) {
+        set_error("assume_bg_on_boundary: negative label on the border");
+        return -1;
+    }
+    const int nb = mm[1] + 1;
+    if (hb.ensure((size_t)nb * 8 + 64)) return -1;
+    unsigned long long *hist = hb.as<unsigned long long>();
+    if (launch_boundary_hist(labels, width, strips, hist, nb, st)) return -1;
+    std::vector<unsigned long long> h(nb);
+    HIP_TRY(hipMemcpyAsync(h.data(), hist, (size_t)nb * 8, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    int best = 0;
+    for (int i = 1; i < nb; ++i)
+        if (h[i] > h[best]) best = i;                       // np.argmax: the first maximum
+    if (boundary_label_out) *boundary_label_out = best;
+    if (best != bg_label) {
+        if (launch_swap_labels(labels, n, best, bg_label, st)) return -1;
+        HIP_TRY(hipMemcpyAsync(segm_inout, labels, n * 4, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+    }
     return 0;
 }
 

@@ -230,6 +230,14 @@ int launch_adjacency_bitmap(const int32_t *labels, int H, int W, int K, uint32_t
 int launch_gather_labels(const int32_t *lut, const int32_t *idx, size_t n, int32_t *out, hipStream_t st);
 int launch_gather_proba(const double *lut, int C, const int32_t *idx, size_t n, double *out, hipStream_t st);
 
+// output.hip -------------------------------------------------------------------------------------
+// rects: four border strips {r0, r1, c0, c1} (rows [r0, r1), columns [c0, c1)); a pixel counts once per strip that holds it
+int launch_boundary_minmax(const int32_t *labels, int W, const int rects[16], int32_t *out2_dev, hipStream_t st);
+int launch_boundary_hist(const int32_t *labels, int W, const int rects[16], unsigned long long *hist_dev, int nb, hipStream_t st);
+int launch_swap_labels(int32_t *labels, size_t n, int a, int b, hipStream_t st);
+int launch_narrow_labels_u8(const int32_t *src, uint8_t *dst, size_t n, hipStream_t st);
+int launch_narrow_soft_f32(const double *src, float *dst, size_t n, hipStream_t st);
+
 // median.hip -------------------------------------------------------------------------------------
 int launch_gradient_image(const void *src, void *dst, int dtype, int S, int H, int W, int C, hipStream_t st);
 size_t median_scratch_bytes(size_t n, int K);

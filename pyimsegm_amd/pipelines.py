@@ -158,7 +158,7 @@ class _ResidentImage(object):
         return self._slic
 
     def segment(self, proba, gc_regul, gc_edge_type, debug_visual=None, classes=None, to_host=True, want_soft=True,
-                model=None):
+                model=None, segm_dtype=None, soft_dtype=None):
         """ graph cut + gathers.  ``proba``: K x C from the host, or None with ``model`` = a mixture the device evaluates
         on the resident features.  Everything runs in one fused call (:meth:`_hip.Image2D.segment`) unless the edge
         type needs the image on the host (``'color'``). """
@@ -177,7 +177,7 @@ class _ResidentImage(object):
             res = self.sess.segment(pairwise, gc_edge_type, gmm=gmm, proba=proba, use_graphcut=use_gc,
                                     classes=None if cls is None else cls.astype(np.int32), want_segm=to_host,
                                     want_soft=to_host and want_soft, debug=debug_visual is not None,
-                                    keep_soft_on_device=want_soft and not to_host)
+                                    keep_soft_on_device=want_soft and not to_host, segm_dtype=segm_dtype, soft_dtype=soft_dtype)
             if debug_visual is not None:
                 insert_gc_debug_images(debug_visual, self.slic, res['graph_labels'], res['unary'], res['edges'],
                                        res['edge_weights'])
@@ -191,18 +191,21 @@ class _ResidentImage(object):
             if classes is not None:
                 graph_labels = np.asarray(classes)[graph_labels]
             segm, segm_soft = self.sess.gather(graph_labels, proba if want_soft else None, to_host=to_host)
-        if to_host and classes is not None and np.asarray(classes).dtype != np.int32:
+            if to_host and segm_dtype is not None:
+                segm = segm.astype(segm_dtype)
+            if to_host and soft_dtype is not None and segm_soft is not None:
+                segm_soft = segm_soft.astype(soft_dtype)
+        if to_host and segm_dtype is None and classes is not None and np.asarray(classes).dtype != np.int32:
             segm = segm.astype(np.asarray(classes).dtype)
         return segm, segm_soft
 
     def mean_colour_image(self):
         """ ``skimage.color.label2rgb(slic, image, kind='avg')`` (reference ``pipelines.py:93``, the ``slic_mean`` debug
-        image): per-superpixel mean colour gathered back to the pixels, on the device; as in scikit-image the
-        label 0 counts as background and stays black """
+        image): per-superpixel mean colour gathered back to the pixels, on the device;
+        in scikit-image 0.18 -- the release line the reference's calls need -- ``bg_label`` is -1 for ``kind='avg'``, so label 0
+        gets its mean colour like every other label (tests/golden/label2rgb.npz, from the real scikit-image) """
         means, _, _ = self.sess.color_stats(mean=True, energy=False, var=False)
-        means = np.array(means, dtype=np.float64)
-        means[0] = 0.
-        _, out = self.sess.gather(None, means)
+        _, out = self.sess.gather(None, np.array(means, dtype=np.float64))
         return out
 
     def fill_debug(self, debug_visual):
@@ -441,15 +444,22 @@ def segment_color2d_slic_features_model_graphcut(
     gc_regul=1.,
     gc_edge_type='model',
     debug_visual=None,
+    segm_dtype=None,
+    soft_dtype=None,
 ):
     """ segmentation with a given (pre-trained) model: superpixels, features, predict, GraphCut
 
     :param ndarray image: input RGB image
     :param obj model_pipeline: fitted model with ``predict_proba``
+    :param segm_dtype: (not in the reference) ``np.uint8``: the class map leaves the device as bytes (classes < 256) -- a quarter
+        of the transfer; None: int32 as the reference returns it
+    :param soft_dtype: (not in the reference) ``np.float32``: the soft segmentation leaves the device as float32 (half of the
+        100 MB a 2048 x 2048 x 3 float64 array takes), ``False``: it is not produced at all; None: float64 as the reference
     :return tuple(ndarray,ndarray): segmentation H x W, soft segmentation H x W x nb_classes
     """
     logging.info('PIPELINE Superpixels-Features-Model-GraphCut')
-    if debug_visual is None:
+    narrow = segm_dtype is not None or soft_dtype is not None
+    if debug_visual is None and not narrow:
         fast = _segment_color2d_one_call(image, model_pipeline, dict_features, sp_size, sp_regul, gc_regul, gc_edge_type)
         if fast is not None:
             return fast
@@ -457,7 +467,9 @@ def segment_color2d_slic_features_model_graphcut(
     try:
         res.fill_debug(debug_visual)
         classes = getattr(model_pipeline, 'classes_', None)
-        segm, segm_soft = res.segment(None, gc_regul, gc_edge_type, debug_visual, classes=classes, model=model_pipeline)
+        segm, segm_soft = res.segment(None, gc_regul, gc_edge_type, debug_visual, classes=classes, model=model_pipeline,
+                                      want_soft=soft_dtype is not False, segm_dtype=segm_dtype,
+                                      soft_dtype=None if soft_dtype is False else soft_dtype)
     finally:
         res.close()
     return segm, segm_soft

@@ -91,7 +91,7 @@ class Image2D(object):
         return fts if to_host else None
     def segment(self, pairwise, edge_type='model', edge_cost=1., gmm=None, proba=None, use_graphcut=True, classes=None,
                 want_segm=True, want_soft=False, want_graph_labels=False, want_proba=False, debug=False, pinned=True,
-                keep_soft_on_device=False):
+                keep_soft_on_device=False, segm_dtype=None, soft_dtype=None):
         """the fused call, restated with the host mirror functions of graph_cuts + the oracle's alpha-expansion"""
         import pyimsegm_amd.graph_cuts as G
         from scipy.special import logsumexp
@@ -114,8 +114,8 @@ class Image2D(object):
         lut = gl if classes is None else np.asarray(classes, dtype=np.int32)[gl]
         out = {}
         self.last_segm = lut[self.labels]
-        if want_segm: out['segm'] = self.last_segm
-        if want_soft: out['soft'] = proba[self.labels]
+        if want_segm: out['segm'] = self.last_segm if segm_dtype is None else self.last_segm.astype(segm_dtype)
+        if want_soft: out['soft'] = proba[self.labels] if soft_dtype is None else proba[self.labels].astype(soft_dtype)
         if want_graph_labels or debug: out['graph_labels'] = gl
         if want_proba or debug: out['proba'] = proba
         if debug: out.update(edges=edges, edge_weights=weights, unary=unary, centres=centres)
