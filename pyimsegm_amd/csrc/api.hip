@@ -1575,10 +1575,33 @@ int imsegm_image2d_features_color(imsegm_image2d *im, int feature_mask, double *
     return 0;
 }
 
+// `edge_capacity` 0: sized for a planar adjacency graph (every superpixel connected); *edges_found: edges of the graph, also
+// when the table was too small for them (return value -2: the caller retries with that many)
+static int segment_impl(imsegm_image2d *im, const imsegm_gmm *gmm, const double *proba, int n_classes,
+                        const double *pairwise, int edge_type, double edge_cost, int use_graphcut,
+                        const int32_t *classes_lut, int32_t *segm_out, double *soft_out, int32_t *graph_labels_out,
+                        double *proba_out, imsegm_terms_debug *debug_out, int edge_capacity, int *edges_found);
+
 int imsegm_image2d_segment(imsegm_image2d *im, const imsegm_gmm *gmm, const double *proba, int n_classes,
                            const double *pairwise, int edge_type, double edge_cost, int use_graphcut,
                            const int32_t *classes_lut, int32_t *segm_out, double *soft_out, int32_t *graph_labels_out,
                            double *proba_out, imsegm_terms_debug *debug_out)
+{
+    int found = 0;
+    int rc = segment_impl(im, gmm, proba, n_classes, pairwise, edge_type, edge_cost, use_graphcut, classes_lut, segm_out, soft_out,
+                          graph_labels_out, proba_out, debug_out, 0, &found);
+    // a label map whose regions are not connected (installed with imsegm_image2d_set_labels) can have more neighbour pairs than
+    // a planar graph: once more with a table of the size the device has reported
+    if (rc == -2)
+        rc = segment_impl(im, gmm, proba, n_classes, pairwise, edge_type, edge_cost, use_graphcut, classes_lut, segm_out, soft_out,
+                          graph_labels_out, proba_out, debug_out, found + 64, &found);
+    return rc == -2 ? -1 : rc;
+}
+
+static int segment_impl(imsegm_image2d *im, const imsegm_gmm *gmm, const double *proba, int n_classes,
+                        const double *pairwise, int edge_type, double edge_cost, int use_graphcut,
+                        const int32_t *classes_lut, int32_t *segm_out, double *soft_out, int32_t *graph_labels_out,
+                        double *proba_out, imsegm_terms_debug *debug_out, int edge_capacity, int *edges_found)
 {
     if (!im || bind(im->ctx)) return -1;
     if (!im->have_labels) {
@@ -1621,7 +1644,7 @@ int imsegm_image2d_segment(imsegm_image2d *im, const imsegm_gmm *gmm, const doub
     const size_t n = im->n;
     const int ndim = im->is_volume ? 3 : 2;
     const int words = cdiv(K, 32);
-    const int Ecap = im->is_volume ? 16 * K + 64 : 3 * K + 64;          // planar graph: E <= 3K - 6
+    const int Ecap = edge_capacity > 0 ? edge_capacity : (im->is_volume ? 16 * K + 64 : 3 * K + 64);     // planar graph: E <= 3K - 6
     auto al = [](size_t v) { return (v + 63) & ~(size_t)63; };
     // ---- host -> device parameter block (one pinned staging copy)
     const size_t FF = (size_t)F * F;
@@ -1812,9 +1835,10 @@ int imsegm_image2d_segment(imsegm_image2d *im, const imsegm_gmm *gmm, const doub
             if (debug_out->edge_weights_int) HIP_TRY(hipMemcpy(debug_out->edge_weights_int, a.weights_i, (size_t)Ec * 4, hipMemcpyDeviceToHost));
         }
     }
+    if (edges_found) *edges_found = E;
     if (hmisc[2] & 2) {
         set_error("segment: more graph edges than the edge table holds");
-        return -1;
+        return -2;
     }
     if (use_graphcut && (hmisc[2] & 1)) {
         set_error("cut_general_graph: smoothness term is larger than GCO_MAX_ENERGYTERM");

@@ -197,3 +197,25 @@ def test_rccl_single_rank_round_trip(monkeypatch):
         _hip.load_library().imsegm_device_free(dev)
     finally:
         group.close()
+
+
+def test_fused_call_takes_label_maps_that_are_no_planar_partition():
+    """a user segmentation whose regions are scattered pixels (installed with set_labels) has far more neighbour pairs than the
+    3 K of a planar graph: the fused call sizes its edge table again from what the device reports, and equals the staged path
+    (reference: imsegm/graph_cuts.py:660-747 accepts any segmentation)"""
+    from pyimsegm_amd import _hip
+    from pyimsegm_amd.graph_cuts import compute_pairwise_cost, segment_graph_cut_general
+    rng = np.random.default_rng(23)
+    K, C = 40, 3
+    labels = rng.integers(0, K, (60, 80)).astype(np.int32)           # salt: nearly every pair of labels touches
+    proba = rng.dirichlet(np.ones(C), K)
+    sess = _hip.Image2D(60, 80).set_labels(labels, K)
+    try:
+        res = sess.segment(compute_pairwise_cost(1., proba.shape), 'model', proba=proba, want_graph_labels=True, debug=False)
+        edges, _, _ = sess.graph()
+        assert len(edges) > 3 * K + 64
+        want = segment_graph_cut_general(labels, proba, None, None, 1., 'model')
+        assert np.array_equal(res['graph_labels'], want)
+        assert np.array_equal(res['segm'], np.asarray(want)[labels])
+    finally:
+        sess.close()
