@@ -17,10 +17,12 @@
 // The mutable arrays (residual capacities, heights, excesses) live in LDS when they fit
 // (K ~ 2e3 nodes, E ~ 6e3 edges -> ~75 KB), otherwise in a global scratch buffer.
 #include "slic.h"
+#include <cstdio>
+#include <cstdlib>
 
 namespace imsegm {
 
-constexpr int GC_THREADS = 1024;
+constexpr int GC_THREADS = 1024;         // upper bound; small graphs run with fewer waves (cheaper barriers)
 constexpr int GC_MAX_LABELS = 64;
 constexpr int GC_PUSH_ROUNDS = 24;        // lock-free push/relabel sweeps between global relabels
 
@@ -42,8 +44,20 @@ struct GcDevice {
     int32_t *g_height;         // [K]
     long long *g_excess;       // [K]
     int use_lds;
+    int lds_lab;               // labels, proposal and unary costs are copied into LDS as well (written back at the end)
+    int lds_topo;              // 1: arc_start + arc_to in LDS, 2: + arc_rev
+    int e_cap;                 // edge capacity the LDS layout was sized for (E on the device may be smaller)
     int32_t *status;           // [1] 0 ok, 1 = max-flow iteration cap hit
+    long long *dbg;            // (IMSEGM_GC_DEBUG) [16] counters / 100 MHz clock sums of thread 0, or null
 };
+#define GC_DBG_ADD(j, v)                                                                           \
+    if (g.dbg && threadIdx.x == 0) g.dbg[j] += (v);
+#define GC_DBG_CLOCK(j)                                                                            \
+    if (g.dbg && threadIdx.x == 0) {                                                               \
+        const long long now_ = (long long)wall_clock64();                                          \
+        g.dbg[j] += now_ - g.dbg[15];                                                              \
+        g.dbg[15] = now_;                                                                          \
+    }
 
 // Accessors for the arrays that other threads modify with atomics.  In the LDS case the scope is
 // irrelevant; in the global-scratch case agent scope keeps the loads out of the (non-coherent for
@@ -60,15 +74,15 @@ __device__ __forceinline__ long long block_sum_i64(long long v, long long *scrat
     if ((threadIdx.x & 63) == 0) scratch[threadIdx.x >> 6] = v;
     __syncthreads();
     long long t = 0;
-    for (int i = 0; i < GC_THREADS / 64; ++i) t += scratch[i];
+    for (int i = 0; i < (int)(blockDim.x >> 6); ++i) t += scratch[i];
     return t;
 }
 
 __device__ long long gc_energy(const GcDevice &g, const int32_t *lab, long long *scratch)
 {
     long long e = 0;
-    for (int i = threadIdx.x; i < g.K; i += GC_THREADS) e += g.unary[(size_t)i * g.C + lab[i]];
-    for (int j = threadIdx.x; j < g.E; j += GC_THREADS) {
+    for (int i = threadIdx.x; i < g.K; i += blockDim.x) e += g.unary[(size_t)i * g.C + lab[i]];
+    for (int j = threadIdx.x; j < g.E; j += blockDim.x) {
         int a = g.edges[2 * j], b = g.edges[2 * j + 1];
         e += (long long)g.w[j] * g.smooth[lab[a] * g.C + lab[b]];
     }
@@ -79,14 +93,13 @@ __device__ long long gc_energy(const GcDevice &g, const int32_t *lab, long long 
 __device__ void gc_global_relabel(const GcDevice &g, int *cap, int *height, long long *excess, int alpha, int *flag)
 {
     const int HMAX = g.K + 2;
-    for (int u = threadIdx.x; u < g.K; u += GC_THREADS)
+    for (int u = threadIdx.x; u < g.K; u += blockDim.x)
         st(&height[u], (g.labels[u] != alpha && ld(&excess[u]) < 0) ? 1 : HMAX);
     __syncthreads();
     for (int level = 1; level < HMAX; ++level) {
-        if (threadIdx.x == 0) *flag = 0;
-        __syncthreads();
+        GC_DBG_ADD(2, 1)
         int changed = 0;
-        for (int u = threadIdx.x; u < g.K; u += GC_THREADS) {
+        for (int u = threadIdx.x; u < g.K; u += blockDim.x) {
             if (ld(&height[u]) != HMAX || g.labels[u] == alpha) continue;
             for (int a = g.arc_start[u]; a < g.arc_start[u + 1]; ++a) {
                 if (ld(&cap[a]) > 0 && ld(&height[g.arc_to[a]]) == level) {
@@ -96,11 +109,8 @@ __device__ void gc_global_relabel(const GcDevice &g, int *cap, int *height, long
                 }
             }
         }
-        if (changed) *flag = 1;
-        __syncthreads();
-        int any = *flag;
-        __syncthreads();
-        if (!any) break;
+        // (a node that got level + 1 in this pass is not read as `level` by anybody: one barrier with the OR is enough)
+        if (!__syncthreads_or(changed)) break;
     }
 }
 
@@ -110,20 +120,17 @@ __device__ bool gc_expand(const GcDevice &g, int alpha, int *cap, int *height, l
 {
     const int HMAX = g.K + 2;
     // any active site at all?
-    if (threadIdx.x == 0) *flag = 0;
-    __syncthreads();
     int mine = 0;
-    for (int u = threadIdx.x; u < g.K; u += GC_THREADS) {
+    for (int u = threadIdx.x; u < g.K; u += blockDim.x) {
         int l = g.labels[u];
         st(&excess[u], (l != alpha) ? (long long)g.unary[(size_t)u * g.C + l] - (long long)g.unary[(size_t)u * g.C + alpha] : 0LL);
         mine |= (l != alpha);
     }
-    if (mine) *flag = 1;
-    __syncthreads();
-    if (!*flag) return false;
-    __syncthreads();
+    GC_DBG_ADD(0, 1)
+    if (g.dbg && threadIdx.x == 0) g.dbg[15] = (long long)wall_clock64();
+    if (!__syncthreads_or(mine)) return false;
     // pairwise terms (energy.h add_term2 / add_term1)
-    for (int j = threadIdx.x; j < g.E; j += GC_THREADS) {
+    for (int j = threadIdx.x; j < g.E; j += blockDim.x) {
         int p = g.edges[2 * j], q = g.edges[2 * j + 1];
         long long w = g.w[j];
         int lp = g.labels[p], lq = g.labels[q];
@@ -163,28 +170,28 @@ __device__ bool gc_expand(const GcDevice &g, int alpha, int *cap, int *height, l
     }
     __syncthreads();
 
+    GC_DBG_CLOCK(8)            // move set-up
     // maximum preflow
     for (int outer = 0;; ++outer) {
+        GC_DBG_ADD(1, 1)
         if (outer > (1 << 20)) {
             if (threadIdx.x == 0) *g.status = 1;
             break;
         }
         gc_global_relabel(g, cap, height, excess, alpha, flag);
-        if (threadIdx.x == 0) *flag = 0;
-        __syncthreads();
         int active = 0;
-        for (int u = threadIdx.x; u < g.K; u += GC_THREADS)
+        for (int u = threadIdx.x; u < g.K; u += blockDim.x)
             if (ld(&excess[u]) > 0 && ld(&height[u]) < HMAX) active = 1;
-        if (active) *flag = 1;
-        __syncthreads();
-        int any = *flag;
-        __syncthreads();
-        if (!any) break;
+        GC_DBG_CLOCK(9)        // global relabel
+        if (!__syncthreads_or(active)) break;
         for (int round = 0; round < GC_PUSH_ROUNDS; ++round) {
-            for (int u = threadIdx.x; u < g.K; u += GC_THREADS) {
+            GC_DBG_ADD(3, 1)
+            int busy = 0;
+            for (int u = threadIdx.x; u < g.K; u += blockDim.x) {
                 long long e = ld(&excess[u]);
                 int hu = ld(&height[u]);
                 if (e <= 0 || hu >= HMAX) continue;
+                busy = 1;
                 int best_h = 0x7fffffff, best_a = -1;
                 for (int a = g.arc_start[u]; a < g.arc_start[u + 1]; ++a) {
                     if (ld(&cap[a]) > 0) {
@@ -209,20 +216,23 @@ __device__ bool gc_expand(const GcDevice &g, int alpha, int *cap, int *height, l
                     st(&height[u], best_h + 1 < HMAX ? best_h + 1 : HMAX);
                 }
             }
-            __syncthreads();
+            // (no active node in a whole round: nothing can change any more before the next global relabel)
+            if (!__syncthreads_or(busy)) break;
         }
+        GC_DBG_CLOCK(10)       // push rounds
     }
     // (the loop above always ends on a fresh global relabel: height < HMAX <=> can reach the sink)
-    for (int u = threadIdx.x; u < g.K; u += GC_THREADS) {
+    for (int u = threadIdx.x; u < g.K; u += blockDim.x) {
         int l = g.labels[u];
         g.prop[u] = (l != alpha && ld(&height[u]) >= HMAX) ? alpha : l;
     }
     __syncthreads();
     long long after = gc_energy(g, g.prop, scratch);
+    GC_DBG_CLOCK(11)           // cut + energy
     bool accept = after < *energy;
     __syncthreads();
     if (accept) {
-        for (int u = threadIdx.x; u < g.K; u += GC_THREADS) g.labels[u] = g.prop[u];
+        for (int u = threadIdx.x; u < g.K; u += blockDim.x) g.labels[u] = g.prop[u];
         if (threadIdx.x == 0) *energy = after;
     }
     __syncthreads();
@@ -231,6 +241,13 @@ __device__ bool gc_expand(const GcDevice &g, int alpha, int *cap, int *height, l
 
 __global__ void __launch_bounds__(GC_THREADS) k_alpha_expansion(GcDevice g)
 {
+    if (g.E_dev && *g.E_dev > g.E) {
+        // more edges than the tables hold (the caller sees the flag of k_gc_terms and comes back with larger ones): arcs beyond
+        // the tables must not be followed -- a defined labelling, nothing else
+        for (int u = threadIdx.x; u < g.K; u += blockDim.x) g.labels[u] = 0;
+        if (threadIdx.x == 0) *g.energy_out = 0;
+        return;
+    }
     if (g.E_dev) g.E = min(*g.E_dev, g.E);
     extern __shared__ __align__(16) unsigned char dyn[];
     __shared__ long long scratch[GC_THREADS / 64];
@@ -241,16 +258,44 @@ __global__ void __launch_bounds__(GC_THREADS) k_alpha_expansion(GcDevice g)
 
     long long *excess;
     int *cap, *height;
+    int32_t *labels_out = g.labels;
     if (g.use_lds) {
+        // LDS (through generic pointers): the arrays the moves modify, then -- as far as they fit -- what they only read.  A level
+        // of the relabelling BFS or a push round is a chain of dependent reads per node (arc range -> neighbour -> its height):
+        // ~2 us out of global memory, a fraction of that out of LDS.
         excess = reinterpret_cast<long long *>(dyn);
         cap = reinterpret_cast<int *>(dyn + (size_t)g.K * 8);
-        height = cap + 2 * (size_t)g.E;
+        height = cap + 2 * (size_t)g.e_cap;
+        int *next = height + g.K;
+        if (g.lds_lab) {
+            int *lab = next, *prop = lab + g.K, *un = prop + g.K, *sm = un + (size_t)g.K * g.C;
+            next = sm + g.C * g.C;
+            for (int i = threadIdx.x; i < g.K * g.C; i += blockDim.x) un[i] = g.unary[i];
+            for (int i = threadIdx.x; i < g.C * g.C; i += blockDim.x) sm[i] = g.smooth[i];
+            g.labels = lab;
+            g.prop = prop;
+            g.unary = un;
+            g.smooth = sm;
+        }
+        if (g.lds_topo) {
+            int *as = next, *at = as + g.K + 1;
+            next = at + 2 * (size_t)g.e_cap;
+            for (int i = threadIdx.x; i <= g.K; i += blockDim.x) as[i] = g.arc_start[i];
+            for (int i = threadIdx.x; i < 2 * g.E; i += blockDim.x) at[i] = g.arc_to[i];
+            g.arc_start = as;
+            g.arc_to = at;
+            if (g.lds_topo > 1) {
+                int *ar = next;
+                for (int i = threadIdx.x; i < 2 * g.E; i += blockDim.x) ar[i] = g.arc_rev[i];
+                g.arc_rev = ar;
+            }
+        }
     } else {
         excess = g.g_excess;
         cap = g.g_cap;
         height = g.g_height;
     }
-    for (int u = threadIdx.x; u < g.K; u += GC_THREADS) g.labels[u] = 0;
+    for (int u = threadIdx.x; u < g.K; u += blockDim.x) g.labels[u] = 0;
     if (threadIdx.x < g.C) table[threadIdx.x] = threadIdx.x;
     __syncthreads();
     long long e0 = gc_energy(g, g.labels, scratch);
@@ -304,6 +349,8 @@ __global__ void __launch_bounds__(GC_THREADS) k_alpha_expansion(GcDevice g)
         }
     }
     __syncthreads();
+    if (g.labels != labels_out)
+        for (int u = threadIdx.x; u < g.K; u += blockDim.x) labels_out[u] = g.labels[u];
     if (threadIdx.x == 0) *g.energy_out = energy;
 }
 
@@ -347,17 +394,51 @@ int launch_alpha_expansion(GcProblem p, const int32_t *arc_start, const int32_t 
     g.labels = labels_dev;
     g.energy_out = energy_dev;
     g.status = status_dev;
+    g.dbg = nullptr;
+    static const bool debug = getenv("IMSEGM_GC_DEBUG") != nullptr;
+    static long long *dbg_buf = nullptr;
+    if (debug) {
+        if (!dbg_buf) HIP_TRY(hipMalloc(&dbg_buf, 16 * sizeof(long long)));
+        HIP_TRY(hipStreamSynchronize(st));
+        long long h[16];
+        HIP_TRY(hipMemcpy(h, dbg_buf, sizeof(h), hipMemcpyDeviceToHost));
+        if (h[0] > 0 && h[0] < (1 << 20))
+            fprintf(stderr, "[alpha expansion] previous call: %lld moves, %lld relabels, %lld BFS levels, %lld push rounds; us: set-up %.1f relabel %.1f "
+                            "push %.1f cut+energy %.1f\n", h[0], h[1], h[2], h[3], h[8] / 100.0, h[9] / 100.0, h[10] / 100.0, h[11] / 100.0);
+        HIP_TRY(hipMemset(dbg_buf, 0, 16 * sizeof(long long)));
+        g.dbg = dbg_buf;
+    }
     unsigned char *wb = (unsigned char *)work;
     g.g_excess = (long long *)wb;
     g.prop = (int32_t *)(wb + (size_t)p.K * 8);
     g.g_height = g.prop + p.K;
     g.g_cap = g.g_height + p.K;
+    const size_t lds_max = 150 * 1024;
     size_t lds_need = (size_t)p.K * 8 + ((size_t)2 * p.E + p.K) * 4;
-    g.use_lds = lds_need <= 150 * 1024;
+    g.use_lds = lds_need <= lds_max;
+    g.e_cap = p.E;
+    g.lds_lab = g.lds_topo = 0;
+    if (g.use_lds) {
+        const size_t lab = ((size_t)2 * p.K + (size_t)p.K * p.C + (size_t)p.C * p.C) * 4, topo1 = ((size_t)p.K + 1 + (size_t)2 * p.E) * 4, topo2 = (size_t)2 * p.E * 4;
+        if (lds_need + lab <= lds_max) {
+            g.lds_lab = 1;
+            lds_need += lab;
+        }
+        if (lds_need + topo1 <= lds_max) {
+            g.lds_topo = 1;
+            lds_need += topo1;
+            if (lds_need + topo2 <= lds_max) {
+                g.lds_topo = 2;
+                lds_need += topo2;
+            }
+        }
+    }
     size_t dyn = g.use_lds ? lds_need : 0;
     if (dyn > 48 * 1024)      // the opt-in is per device and cheap: set it on every launch that needs it
         HIP_TRY(hipFuncSetAttribute((const void *)k_alpha_expansion, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-    hipLaunchKernelGGL(k_alpha_expansion, 1, GC_THREADS, dyn, st, g);
+    // one thread per node up to 1024; a small graph runs with fewer waves (the moves are chains of workgroup barriers)
+    const int threads = std::min(GC_THREADS, std::max(256, ((p.K + 63) / 64) * 64));
+    hipLaunchKernelGGL(k_alpha_expansion, 1, threads, dyn, st, g);
     HIP_TRY(hipGetLastError());
     return 0;
 }
