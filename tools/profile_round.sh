@@ -8,17 +8,17 @@ OUT=$REPO/gpurun_out/prof_$TAG
 rm -rf $OUT && mkdir -p $OUT
 python $REPO/bench.py > $OUT/bench.json 2> $OUT/bench.err          # the default command: what the driver runs
 # the default command (three images in flight: kernels of different streams overlap) ...
-rocprofv3 --kernel-trace --stats -d $OUT/kt -o bench -- python $REPO/bench.py --steps 10 --warmup 2 --no-cpu-baseline > $OUT/bench_rocprof_run.json 2> $OUT/kt.err
+rocprofv3 --kernel-trace --stats -d $OUT/kt -o bench -- python $REPO/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-other-configs > $OUT/bench_rocprof_run.json 2> $OUT/kt.err
 DB=$(find $OUT/kt -name "*.db" | head -1)
 python $REPO/tools/prof_summary.py $DB > $OUT/kernel_stats.txt
 # ... and one image at a time: these per-kernel durations are the ones bench.py's roofline pass measures
-rocprofv3 --kernel-trace --stats -d $OUT/kt1 -o bench -- python $REPO/bench.py --steps 10 --warmup 2 --no-cpu-baseline --inflight 1 > $OUT/bench_rocprof_run_inflight1.json 2> $OUT/kt1.err
+rocprofv3 --kernel-trace --stats -d $OUT/kt1 -o bench -- python $REPO/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-other-configs --inflight 1 > $OUT/bench_rocprof_run_inflight1.json 2> $OUT/kt1.err
 DB=$(find $OUT/kt1 -name "*.db" | head -1)
 python $REPO/tools/prof_summary.py $DB > $OUT/kernel_stats_inflight1.txt
 for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/pmc_$c -o p -- python $REPO/bench.py --steps 2 --warmup 1 --no-cpu-baseline --inflight 1 > $OUT/pmc_$c.log 2>&1
+  rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/pmc_$c -o p -- python $REPO/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-other-configs --inflight 1 > $OUT/pmc_$c.log 2>&1
 done
-rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_INSTS_LDS SQ_INSTS_SMEM SQ_WAVES --kernel-trace --output-format csv -d $OUT/pmc_SQ -o p -- python $REPO/bench.py --steps 2 --warmup 1 --no-cpu-baseline --inflight 1 > $OUT/pmc_SQ.log 2>&1
+rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_INSTS_LDS SQ_INSTS_SMEM SQ_WAVES --kernel-trace --output-format csv -d $OUT/pmc_SQ -o p -- python $REPO/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-other-configs --inflight 1 > $OUT/pmc_SQ.log 2>&1
 python - $OUT <<'PY'
 import csv, sys, collections, json, os
 out = sys.argv[1]
