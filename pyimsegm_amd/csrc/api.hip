@@ -1009,18 +1009,19 @@ int imsegm_image2d_lm_prepare(imsegm_image2d *im, const double *taps, int radius
     // colour image: three channel planes of H x W; gray volume: its D slices, filtered independently (descriptors.py:981-994)
     const size_t np = im->is_volume ? im->n : 3 * im->n;
     if (im->tex_planes.ensure(np * 8) || im->labA.ensure(np * 8) || im->labB.ensure(np * 8)) return -1;
-    if (im->tex_small.ensure(((size_t)radius + 1 + 9) * 8 + 1024 * 8 + 4096)) return -1;
+    if (im->tex_small.ensure(((size_t)radius + 1 + 9) * 8 + 1024 * 8 + 4096 + ((size_t)2 * radius + 64) * 8)) return -1;
     double *d_taps = im->tex_small.as<double>();
     double *d_mix = d_taps + radius + 1;
+    double *d_full = d_taps + radius + 1 + 9 + 1024 + 512;        // behind the partial sums of the batteries
     HIP_TRY(hipMemcpyAsync(d_taps, taps, ((size_t)radius + 1) * 8, hipMemcpyHostToDevice, st));
     if (channel_mix) HIP_TRY(hipMemcpyAsync(d_mix, channel_mix, 9 * 8, hipMemcpyHostToDevice, st));
     HIP_TRY(hipStreamSynchronize(st));
     if (im->is_volume) {
         if (launch_texture_prepare_volume(im->img.p, im->dtype, im->D, im->H, im->W, d_taps, radius, im->tex_planes.as<double>(),
-                                          im->labA.as<double>(), im->labB.as<double>(), st))
+                                          im->labA.as<double>(), im->labB.as<double>(), st, d_full))
             return -1;
     } else if (launch_texture_prepare(im->img.p, im->dtype, im->H, im->W, d_taps, radius, d_mix, im->tex_planes.as<double>(),
-                                      im->labA.as<double>(), im->labB.as<double>(), st)) {
+                                      im->labA.as<double>(), im->labB.as<double>(), st, d_full)) {
         return -1;
     }
     im->tex_ready = true;
@@ -1040,10 +1041,11 @@ int imsegm_image2d_lm_battery(imsegm_image2d *im, const double *weights, int n_k
     const int P = im->is_volume ? im->D : 3;
     const size_t S = 2 * (size_t)radius + 1;
     const size_t wbytes = S * S * n_kernels * 8;
-    if (im->tex_resp.ensure(3 * n * 8 + wbytes + 1024 * 8 + 64)) return -1;
+    const size_t wpad = S * (S + 8) * n_kernels;                     // the row-padded copy the battery kernel reads (texture.hip)
+    if (im->tex_resp.ensure(3 * n * 8 + wbytes + wpad * 8 + 1024 * 8 + 64)) return -1;
     double *resp = im->tex_resp.as<double>();
     double *d_w = resp + 3 * n;
-    double *partial = d_w + S * S * n_kernels;
+    double *partial = d_w + S * S * n_kernels + wpad;
     double *d_sum = partial + 1024;
     HIP_TRY(hipMemcpyAsync(d_w, weights, wbytes, hipMemcpyHostToDevice, st));
     HIP_TRY(hipStreamSynchronize(st));

@@ -212,10 +212,11 @@ int launch_color_stats(const void *img, int dtype, const int32_t *labels, int H,
                        double div = 1.0, long plane_stride = -1);
 
 // texture.hip -------------------------------------------------------------------------------------
+// fullpad: device scratch of 2 * radius + 1 + 16 doubles (the zero-padded full tap table the column pass reads)
 int launch_texture_prepare(const void *img, int dtype, int H, int W, const double *taps_dev, int radius,
-                           const double *mix_dev, double *planes, double *tmpA, double *tmpB, hipStream_t st);
+                           const double *mix_dev, double *planes, double *tmpA, double *tmpB, hipStream_t st, double *fullpad);
 int launch_texture_prepare_volume(const void *vol, int dtype, int P, int H, int W, const double *taps_dev, int radius, double *planes,
-                                  double *tmpA, double *tmpB, hipStream_t st);
+                                  double *tmpA, double *tmpB, hipStream_t st, double *fullpad);
 // P planes of H x W (3 colour channels, or the D slices of a gray volume)
 int launch_filter_battery(const double *planes, int H, int W, const double *wgt_dev, int nk, int radius, double clip,
                           double *resp, double *partial, double *sumsq_dev, hipStream_t st, int P = 3);

@@ -35,31 +35,89 @@ __global__ void __launch_bounds__(256) k_to_planes(const T *__restrict__ img, in
     for (int c = 0; c < 3; ++c) planes[(size_t)c * n + p] = (double)img[3 * (size_t)p + c];
 }
 
-// symmetric 1-D correlation along y (AXIS 0) or x (AXIS 1) with a long kernel (sigma = 150 ->
-// radius 600); one output per lane, lanes run along x so every tap is a coalesced row segment
-template <int AXIS>
-__global__ void __launch_bounds__(256)
-k_corr1d_long(const double *__restrict__ src, double *__restrict__ dst, int H, int W, const double *__restrict__ taps,
-              int radius)
+// ---- long symmetric 1-D correlation (sigma = 150 -> radius 600, 1201 taps) ------------------------------------------------
+// Round 2 computed one output per lane with two global loads per FMA (3.5 TFLOP/s = 4.5 % of the fp64 vector peak, 17 % of a
+// config-3 image's time).  Now a lane owns one column and CR = 8 consecutive output rows: every value it loads feeds 8 FMAs,
+// and the 15 taps a block of 8 source rows needs are a contiguous window of the (zero padded) full tap table, wave uniform ->
+// scalar loads, as the weights of the filter batteries.  The pass is always along y (coalesced row segments); the x pass runs
+// on the transposed planes (two LDS-tiled transposes, 2 x 100 MB each, instead of strided reads).
+constexpr int CR = 8;
+// fullpad[CR - 1 + d + radius] = taps[|d|] for |d| <= radius, zero elsewhere (length 2 * radius + 1 + 2 * CR)
+__global__ void k_taps_full(const double *__restrict__ taps, int radius, double *__restrict__ fullpad)
 {
-    int x = blockIdx.x * 64 + (threadIdx.x & 63);
-    int y = blockIdx.y * 4 + (threadIdx.x >> 6);
-    if (x >= W || y >= H) return;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= 2 * radius + 1 + 2 * CR) return;
+    const int d = i - (CR - 1) - radius;
+    fullpad[i] = (d >= -radius && d <= radius) ? taps[d < 0 ? -d : d] : 0.0;
+}
+
+__global__ void __launch_bounds__(256)
+k_corr1d_col(const double *__restrict__ src, double *__restrict__ dst, int H, int W, const double *__restrict__ fullpad, int radius)
+{
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int y0 = (blockIdx.y * 4 + wave) * CR;
+    if (y0 >= H) return;
+    const int x = blockIdx.x * 64 + lane;
+    const int xs = x < W ? x : W - 1;
     const double *s = src + (size_t)blockIdx.z * H * W;
-    double acc = s[(size_t)y * W + x] * taps[0];
-    if (AXIS == 0) {
-        const bool interior = y - radius >= 0 && y + radius < H;
-        for (int j = 1; j <= radius; ++j) {
-            int ya = interior ? y - j : reflect_index(y - j, H), yb = interior ? y + j : reflect_index(y + j, H);
-            acc = fma(s[(size_t)ya * W + x] + s[(size_t)yb * W + x], taps[j], acc);
-        }
-    } else {
-        for (int j = 1; j <= radius; ++j) {
-            int xa = reflect_index(x - j, W), xb = reflect_index(x + j, W);
-            acc = fma(s[(size_t)y * W + xa] + s[(size_t)y * W + xb], taps[j], acc);
-        }
+    double acc[CR];
+#pragma unroll
+    for (int i = 0; i < CR; ++i) acc[i] = 0.0;
+    // source rows q = y0 - radius + b * CR + j; for output row y0 + i the tap is d = q - (y0 + i) = -radius + b * CR + j - i, i.e.
+    // fullpad[(CR - 1) + radius + d] = fullpad[b * CR + (CR - 1) + j - i]: the window w[m], m = j - i + CR - 1, starts at b * CR
+    const int nblocks = (2 * radius + CR + CR - 1) / CR;
+    for (int b = 0; b < nblocks; ++b) {
+        const double *wp = fullpad + (size_t)b * CR;
+        double w[2 * CR - 1];
+#pragma unroll
+        for (int m = 0; m < 2 * CR - 1; ++m) w[m] = wp[m];
+        double v[CR];
+#pragma unroll
+        for (int j = 0; j < CR; ++j) v[j] = s[(size_t)reflect_index(y0 - radius + b * CR + j, H) * W + xs];
+#pragma unroll
+        for (int j = 0; j < CR; ++j)
+#pragma unroll
+            for (int i = 0; i < CR; ++i) acc[i] = fma(w[j - i + CR - 1], v[j], acc[i]);
     }
-    dst[(size_t)blockIdx.z * H * W + (size_t)y * W + x] = acc;
+    if (x < W) {
+        double *d = dst + (size_t)blockIdx.z * H * W;
+#pragma unroll
+        for (int i = 0; i < CR; ++i)
+            if (y0 + i < H) d[(size_t)(y0 + i) * W + x] = acc[i];
+    }
+}
+
+// dst[p][x][y] = src[p][y][x]: 32 x 32 tiles through LDS (33 columns: no bank conflicts), P planes
+__global__ void __launch_bounds__(256) k_transpose_planes(const double *__restrict__ src, double *__restrict__ dst, int H, int W)
+{
+    __shared__ double tile[32][33];
+    const size_t plane = (size_t)blockIdx.z * H * W;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;          // 32 x 8 threads
+    const int x0 = blockIdx.x * 32, y0 = blockIdx.y * 32;
+#pragma unroll
+    for (int r = 0; r < 32; r += 8) {
+        const int x = x0 + tx, y = y0 + ty + r;
+        if (x < W && y < H) tile[ty + r][tx] = src[plane + (size_t)y * W + x];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 32; r += 8) {
+        const int y = y0 + tx, x = x0 + ty + r;                      // transposed: the fast index runs along the old y
+        if (x < W && y < H) dst[plane + (size_t)x * H + y] = tile[tx][ty + r];
+    }
+}
+
+// blur along y then along x: src -> out, tmp: scratch of the same size (src is left untouched)
+static int launch_long_blur(const double *src, double *tmp, double *out, int P, int H, int W, const double *fullpad, int radius,
+                            hipStream_t st)
+{
+    hipLaunchKernelGGL(k_corr1d_col, dim3(cdiv(W, 64), cdiv(H, 4 * CR), P), 256, 0, st, src, tmp, H, W, fullpad, radius);      // y pass
+    hipLaunchKernelGGL(k_transpose_planes, dim3(cdiv(W, 32), cdiv(H, 32), P), 256, 0, st, tmp, out, H, W);                    // -> W x H
+    hipLaunchKernelGGL(k_corr1d_col, dim3(cdiv(H, 64), cdiv(W, 4 * CR), P), 256, 0, st, out, tmp, W, H, fullpad, radius);      // x pass
+    hipLaunchKernelGGL(k_transpose_planes, dim3(cdiv(H, 32), cdiv(W, 32), P), 256, 0, st, tmp, out, W, H);                    // -> H x W
+    HIP_TRY(hipGetLastError());
+    return 0;
 }
 
 // gray volume: every slice is an independent plane (descriptors.py:981-994 image_subtract_gauss_smooth)
@@ -99,20 +157,34 @@ k_mix_subtract(const double *__restrict__ orig, const double *__restrict__ blur,
 // one tap are one contiguous scalar load.
 constexpr int CV_TX = 64, CV_TY = 16, CV_ROWS = 4;
 
+// rows of the weight table per kernel column: S rows + the CV_ROWS - 1 zero rows the sliding window runs into, rounded up to
+// whole groups of CV_ROWS (k_conv_battery unrolls its row loop in such groups)
+__host__ __device__ static inline int conv_padded_rows(int radius) { return ((2 * radius + 1 + CV_ROWS - 1 + CV_ROWS - 1) / CV_ROWS) * CV_ROWS; }
+
+// wgt: [kx][t][k] as the caller passes it (S x S x NK) -> [kx][t < Spad][k], zero rows behind t = S - 1
+__global__ void k_pad_weights(const double *__restrict__ wgt, int S, int Spad, int nk, double *__restrict__ out)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= S * Spad * nk) return;
+    const int k = i % nk, t = (i / nk) % Spad, kx = i / (nk * Spad);
+    out[i] = t < S ? wgt[((size_t)kx * S + t) * nk + k] : 0.0;
+}
+
 template <int NK>
 __global__ void __launch_bounds__(256)
 k_conv_battery(const double *__restrict__ planes, int H, int W, const double *__restrict__ wgt, int radius,
                double clip, double *__restrict__ resp)
 {
-    extern __shared__ double tile[];                 // [(CV_TY + 2r)][(CV_TX + 2r)]
-    const int S = 2 * radius + 1;
-    const int tw = CV_TX + 2 * radius, th = CV_TY + 2 * radius;
+    extern __shared__ double tile[];                 // [(CV_TY - CV_ROWS + Spad)][(CV_TX + 2r)]
+    const int S = 2 * radius + 1, Spad = conv_padded_rows(radius);
+    const int tw = CV_TX + 2 * radius, th = CV_TY + 2 * radius, th_pad = CV_TY - CV_ROWS + Spad;
     const int ch = blockIdx.z;
     const double *src = planes + (size_t)ch * H * W;
     const int x0 = blockIdx.x * CV_TX, y0 = blockIdx.y * CV_TY;
-    for (int i = threadIdx.x; i < tw * th; i += 256) {
+    for (int i = threadIdx.x; i < tw * th_pad; i += 256) {
         int ty = i / tw, tx = i - ty * tw;
-        int gy = reflect_index(y0 + ty - radius, H), gx = reflect_index(x0 + tx - radius, W);
+        // (rows behind the halo only ever meet zero weights: any finite value will do)
+        int gy = reflect_index(y0 + min(ty, th - 1) - radius, H), gx = reflect_index(x0 + tx - radius, W);
         tile[i] = src[(size_t)gy * W + gx];
     }
     __syncthreads();
@@ -123,18 +195,28 @@ k_conv_battery(const double *__restrict__ planes, int H, int W, const double *__
     for (int k = 0; k < NK; ++k)
 #pragma unroll
         for (int i = 0; i < CV_ROWS; ++i) acc[k][i] = 0.0;
-    // correlation form: out[y][x] = sum_{t, kx} Wc[t][kx] * in[y + t - r][x + kx - r]; the host passes the
-    // flipped kernels, so this equals ndimage.convolve
+    // correlation form: out[y][x] = sum_{t, kx} Wc[t][kx] * in[y + t - r][x + kx - r]; the host passes the flipped kernels, so
+    // this equals ndimage.convolve.  The input value of tile row ly + ky meets weight row t = ky - i for output row i: a window of
+    // CV_ROWS weight rows slides down the kernel column, ONE new row of NK wave-uniform weights (a scalar load) per input value;
+    // the row loop is unrolled in groups of CV_ROWS, so the window lives in fixed scalar registers without any moves.
     for (int kx = 0; kx < S; ++kx) {
-        const double *wk = wgt + (size_t)kx * S * NK;
-        for (int ky = 0; ky < S + CV_ROWS - 1; ++ky) {
-            const double v = tile[(ly + ky) * tw + lx + kx];
+        const double *wk = wgt + (size_t)kx * Spad * NK;
+        double w[CV_ROWS][NK];
 #pragma unroll
-            for (int i = 0; i < CV_ROWS; ++i) {
-                const int t = ky - i;                   // tap row for output row i (wave-uniform)
-                if (t < 0 || t >= S) continue;
+        for (int u = 0; u < CV_ROWS; ++u)
 #pragma unroll
-                for (int k = 0; k < NK; ++k) acc[k][i] = fma(wk[t * NK + k], v, acc[k][i]);
+            for (int k = 0; k < NK; ++k) w[u][k] = 0.0;
+        for (int g = 0; g < Spad; g += CV_ROWS) {
+#pragma unroll
+            for (int u = 0; u < CV_ROWS; ++u) {
+                const int ky = g + u;
+#pragma unroll
+                for (int k = 0; k < NK; ++k) w[u][k] = wk[ky * NK + k];          // weight row t = ky into slot ky mod CV_ROWS
+                const double v = tile[(ly + ky) * tw + lx + kx];
+#pragma unroll
+                for (int i = 0; i < CV_ROWS; ++i)
+#pragma unroll
+                    for (int k = 0; k < NK; ++k) acc[k][i] = fma(w[(u - i + CV_ROWS) % CV_ROWS][k], v, acc[k][i]);
             }
         }
     }
@@ -180,16 +262,15 @@ __global__ void __launch_bounds__(256) k_sumsq_final(const double *partial, int 
 }
 
 int launch_texture_prepare(const void *img, int dtype, int H, int W, const double *taps_dev, int radius,
-                           const double *mix_dev, double *planes, double *tmpA, double *tmpB, hipStream_t st)
+                           const double *mix_dev, double *planes, double *tmpA, double *tmpB, hipStream_t st, double *fullpad)
 {
     const int n = H * W;
     const int grid = cdiv(n, 256);
     if (dtype == DT_U8) hipLaunchKernelGGL(k_to_planes<uint8_t>, grid, 256, 0, st, (const uint8_t *)img, n, planes);
     else if (dtype == DT_F32) hipLaunchKernelGGL(k_to_planes<float>, grid, 256, 0, st, (const float *)img, n, planes);
     else hipLaunchKernelGGL(k_to_planes<double>, grid, 256, 0, st, (const double *)img, n, planes);
-    dim3 g(cdiv(W, 64), cdiv(H, 4), 3);
-    hipLaunchKernelGGL(k_corr1d_long<0>, g, 256, 0, st, planes, tmpA, H, W, taps_dev, radius);
-    hipLaunchKernelGGL(k_corr1d_long<1>, g, 256, 0, st, tmpA, tmpB, H, W, taps_dev, radius);
+    hipLaunchKernelGGL(k_taps_full, cdiv(2 * radius + 1 + 2 * CR, 256), 256, 0, st, taps_dev, radius, fullpad);
+    if (launch_long_blur(planes, tmpA, tmpB, 3, H, W, fullpad, radius, st)) return -1;
     hipLaunchKernelGGL(k_mix_subtract, grid, 256, 0, st, planes, tmpB, n, mix_dev, planes);
     HIP_TRY(hipGetLastError());
     return 0;
@@ -197,16 +278,15 @@ int launch_texture_prepare(const void *img, int dtype, int H, int W, const doubl
 
 // planes = volume - gaussian_filter(slice, sigma) per slice, P = D planes of H x W
 int launch_texture_prepare_volume(const void *vol, int dtype, int P, int H, int W, const double *taps_dev, int radius, double *planes,
-                                  double *tmpA, double *tmpB, hipStream_t st)
+                                  double *tmpA, double *tmpB, hipStream_t st, double *fullpad)
 {
     const size_t n = (size_t)P * H * W;
     const int grid = cdiv((long)n, 256);
     if (dtype == DT_U8) hipLaunchKernelGGL(k_vol_to_planes<uint8_t>, grid, 256, 0, st, (const uint8_t *)vol, n, planes);
     else if (dtype == DT_F32) hipLaunchKernelGGL(k_vol_to_planes<float>, grid, 256, 0, st, (const float *)vol, n, planes);
     else hipLaunchKernelGGL(k_vol_to_planes<double>, grid, 256, 0, st, (const double *)vol, n, planes);
-    dim3 g(cdiv(W, 64), cdiv(H, 4), P);
-    hipLaunchKernelGGL(k_corr1d_long<0>, g, 256, 0, st, planes, tmpA, H, W, taps_dev, radius);
-    hipLaunchKernelGGL(k_corr1d_long<1>, g, 256, 0, st, tmpA, tmpB, H, W, taps_dev, radius);
+    hipLaunchKernelGGL(k_taps_full, cdiv(2 * radius + 1 + 2 * CR, 256), 256, 0, st, taps_dev, radius, fullpad);
+    if (launch_long_blur(planes, tmpA, tmpB, P, H, W, fullpad, radius, st)) return -1;
     hipLaunchKernelGGL(k_subtract, grid, 256, 0, st, planes, tmpB, n, planes);
     HIP_TRY(hipGetLastError());
     return 0;
@@ -219,19 +299,23 @@ int launch_filter_battery(const double *planes, int H, int W, const double *wgt_
         set_error("filter battery: 1, 2, 4 or 8 kernels per battery are supported");
         return -1;
     }
-    size_t lds = (size_t)(CV_TX + 2 * radius) * (CV_TY + 2 * radius) * sizeof(double);
+    const int S = 2 * radius + 1, Spad = conv_padded_rows(radius);
+    size_t lds = (size_t)(CV_TX + 2 * radius) * (CV_TY - CV_ROWS + Spad) * sizeof(double);
     if (lds > 150 * 1024) {
         set_error("filter battery: kernel radius too large for the LDS tile");
         return -1;
     }
+    // (the padded table lives behind the caller's weights: launch_filter_battery's caller reserves S * Spad * nk doubles there)
+    double *wpad = const_cast<double *>(wgt_dev) + (size_t)S * S * nk;
+    hipLaunchKernelGGL(k_pad_weights, cdiv((long)S * Spad * nk, 256), 256, 0, st, wgt_dev, S, Spad, nk, wpad);
     dim3 grid(cdiv(W, CV_TX), cdiv(H, CV_TY), P);
     const void *fn = nk == 8 ? (const void *)k_conv_battery<8> : nk == 4 ? (const void *)k_conv_battery<4>
                    : nk == 2 ? (const void *)k_conv_battery<2> : (const void *)k_conv_battery<1>;
     if (lds > 48 * 1024) HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    if (nk == 8) hipLaunchKernelGGL(k_conv_battery<8>, grid, 256, lds, st, planes, H, W, wgt_dev, radius, clip, resp);
-    else if (nk == 4) hipLaunchKernelGGL(k_conv_battery<4>, grid, 256, lds, st, planes, H, W, wgt_dev, radius, clip, resp);
-    else if (nk == 2) hipLaunchKernelGGL(k_conv_battery<2>, grid, 256, lds, st, planes, H, W, wgt_dev, radius, clip, resp);
-    else hipLaunchKernelGGL(k_conv_battery<1>, grid, 256, lds, st, planes, H, W, wgt_dev, radius, clip, resp);
+    if (nk == 8) hipLaunchKernelGGL(k_conv_battery<8>, grid, 256, lds, st, planes, H, W, wpad, radius, clip, resp);
+    else if (nk == 4) hipLaunchKernelGGL(k_conv_battery<4>, grid, 256, lds, st, planes, H, W, wpad, radius, clip, resp);
+    else if (nk == 2) hipLaunchKernelGGL(k_conv_battery<2>, grid, 256, lds, st, planes, H, W, wpad, radius, clip, resp);
+    else hipLaunchKernelGGL(k_conv_battery<1>, grid, 256, lds, st, planes, H, W, wpad, radius, clip, resp);
     const int nb = 1024;
     hipLaunchKernelGGL(k_sumsq_partial, nb, 256, 0, st, resp, (size_t)P * H * W, partial);
     hipLaunchKernelGGL(k_sumsq_final, 1, 256, 0, st, partial, nb, sumsq_dev);
