@@ -606,7 +606,7 @@ def bench_color2d(args, group, cfg, quick=False):
     images = [host_image(im, args.pinned_input) for im in images]
     steps = args.steps if (args.steps is not None and not quick) else ({3: 3, 4: 20}[cfg] if quick else {2: 100, 3: 5, 4: 40}[cfg])
     warmup = args.warmup if (args.warmup is not None and not quick) else {2: 3, 3: 1, 4: 3}[cfg]
-    inflight = args.inflight if args.inflight > 0 else {2: 3, 3: 2, 4: 8}[cfg]
+    inflight = args.inflight if args.inflight > 0 else {2: 3, 3: 2, 4: 12}[cfg]
     npx_step = per_step * height * width
 
     # class model: fitted once, outside the timed region (the reference's group-model flow); config 4 takes the group model

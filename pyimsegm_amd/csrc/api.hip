@@ -492,7 +492,7 @@ int imsegm_image2d_slic(imsegm_image2d *im, int minmax_normalize, int n_segments
     // buffers
     if (im->labA.ensure(3 * n * sizeof(double)) || im->labB.ensure(3 * n * sizeof(double))) return -1;
     if (im->nearest.ensure(n * 4) || im->labels.ensure(n * 4)) return -1;
-    size_t cent_bytes = (size_t)K * (5 * 8 + 16 + 9 * 8 + 16) + 256 + SLIC_DRIFT_SLOTS * sizeof(int);
+    size_t cent_bytes = (size_t)K * (5 * 8 + 16 + 9 * 8 + 16 + 4) + 256 + SLIC_DRIFT_SLOTS * sizeof(int);
     if (im->cent.ensure(cent_bytes)) return -1;
     const size_t n_tiles = (size_t)cdiv(W, SLIC_TILE_X) * cdiv(H, SLIC_TILE_Y);
     if (im->tiles.ensure(n_tiles * (SLIC_MAXC * (sizeof(Cand) + sizeof(Rec32) + sizeof(int)) + sizeof(TileInfo) + sizeof(int)) + n * 4 + 1024))
@@ -557,6 +557,10 @@ int imsegm_image2d_slic(imsegm_image2d *im, int minmax_normalize, int n_segments
     s.mdc = reinterpret_cast<double *>(cb); cb += (size_t)K * 8;
     s.slico = slic_zero ? 1 : 0;
     s.drift = reinterpret_cast<int *>(cb); cb += SLIC_DRIFT_SLOTS * sizeof(int);
+    // arrival counters + the page-locked failure word of the centroid update inside the assignment kernel
+    if (!im->slic_fail_host) HIP_TRY(hipHostMalloc((void **)&im->slic_fail_host, 64, hipHostMallocDefault));
+    s.done = reinterpret_cast<int *>(cb); cb += (size_t)K * sizeof(int);
+    s.fail_host = im->slic_fail_host;
     s.grid_y0 = (int)ax[1].start; s.grid_dy = (int)ax[1].step;
     s.grid_x0 = (int)ax[2].start; s.grid_dx = (int)ax[2].step; s.grid_nx = (int)nx;
     double *init_dev = nullptr;                            // the grid is generated on the device
@@ -604,7 +608,9 @@ int imsegm_image2d_slic(imsegm_image2d *im, int minmax_normalize, int n_segments
             if (slic_prepare_device()) return -1;          // function attributes: not inside a capture
             hipGraph_t graph = nullptr;
             HIP_TRY(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
-            const int rc = launch_slic_iterations(s, im->labA.as<double>(), init_dev, im->nearest.as<int32_t>(), max_iter,
+            SlicState captured = s;
+            captured.done = nullptr;          // (a replayed graph has nobody to read the failure word: separate finalize launches)
+            const int rc = launch_slic_iterations(captured, im->labA.as<double>(), init_dev, im->nearest.as<int32_t>(), max_iter,
                                                   max_candidates, hook, st);
             const hipError_t ec = hipStreamEndCapture(st, &graph);
             if (rc || ec != hipSuccess || !graph) {
@@ -628,7 +634,6 @@ int imsegm_image2d_slic(imsegm_image2d *im, int minmax_normalize, int n_segments
         void *sweep_scratch = nullptr;
         if (getenv("IMSEGM_SLIC_PERSISTENT")) {
             if (im->sweeps.ensure(sweep_work_bytes(K, max_iter, (int)n_tiles, cdiv(H, SLIC_TILE_Y)))) return -1;
-            if (!im->slic_fail_host) HIP_TRY(hipHostMalloc((void **)&im->slic_fail_host, 64, hipHostMallocDefault));
             sweep_scratch = im->sweeps.p;
         }
         if (launch_slic_iterations(s, im->labA.as<double>(), init_dev, im->nearest.as<int32_t>(), max_iter, max_candidates, hook, st,
@@ -665,7 +670,9 @@ int imsegm_image2d_slic(imsegm_image2d *im, int minmax_normalize, int n_segments
             // the persistent kernel gave the image back (more candidates in a tile than a list holds, a centroid far from its
             // grid node, an uncovered pixel): the sweeps again, one launch each -- they take every case
             slic_sweep_note_fallback();
-            if (launch_slic_iterations(s, im->labA.as<double>(), init_dev, im->nearest.as<int32_t>(), max_iter, max_candidates, hook, st))
+            SlicState plain = s;
+            plain.done = nullptr;                              // separate finalize launches: they take every case
+            if (launch_slic_iterations(plain, im->labA.as<double>(), init_dev, im->nearest.as<int32_t>(), max_iter, max_candidates, hook, st))
                 return -1;
         }
         if (enforce_connectivity) {

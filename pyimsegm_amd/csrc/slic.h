@@ -68,6 +68,13 @@ struct SlicState {
     int slico;                      // skimage slic_zero: colour distance / mdc[k], mdc updated after every sweep
     double *mdc;                    // [K] max_dist_color of _slic.pyx (starts at 1)
     int *drift;                     // [SLIC_DRIFT_SLOTS] per sweep: max displacement of a centroid from its grid node
+    // centroid update inside the assignment kernel (k_slic_assign_dot): the workgroup that adds the LAST contribution to a
+    // centroid -- arrivals are counted per centroid against the number of workgroups its search window meets -- divides the
+    // sums itself; no k_centroid_finalize launch between the sweeps
+    int *done;                      // [K] arrivals of the current sweep (null: separate finalize launches)
+    int *fail_host;                 // page-locked word raised when a contribution bypassed the arrival count (the host redoes the image)
+    int fuse_finalize;              // this launch updates the centroids itself
+    int drift_slot_next;            // drift slot the updated centroids report into
 };
 
 int launch_minmax(const void *src, int dtype, size_t n, unsigned long long *keys, double *out2, hipStream_t st);

@@ -496,6 +496,7 @@ __global__ void k_centroid_init(SlicState s, const double *__restrict__ init_yx)
     s.win[k] = search_window(cy, cx, s.step_y, s.step_x, s.H, s.W);
     s.mdc[k] = 1.0;
     for (int j = 0; j < 9; ++j) s.acc[(size_t)k * 9 + j] = 0;
+    if (s.done) s.done[k] = 0;
     if (k == 0) *s.leftover_count = 0;
 }
 
@@ -1461,6 +1462,9 @@ k_slic_assign_dot(SlicState s, const double *__restrict__ lab, int32_t *__restri
             // previous label): straight to the global sums -- rare
             const int k = best_s[r] <= -2 ? -(best_s[r] + 2) : labels[p];
             if (k >= 0) {
+                // (with the centroid update inside this kernel such a contribution is not covered by the arrival count of its
+                // centroid: the host is told and redoes the sweeps with separate finalize launches)
+                if (s.fuse_finalize) *reinterpret_cast<volatile int *>(s.fail_host) = 1;
                 long long *a = s.acc + (size_t)k * 9;
                 const double fs = ldexp(1.0, fix_bits_of(*s.premax));
                 atomic_add_i64(a + 0, 1);
@@ -1487,6 +1491,45 @@ k_slic_assign_dot(SlicState s, const double *__restrict__ lab, int32_t *__restri
     flush_block_sums(lacc, nc, lk, s.acc, tid);
     PHASE_MARK(7)                                  // flush
     PHASE_FLUSH()
+    if (U == 1 && s.fuse_finalize) {
+        // arrivals: every workgroup whose tile the search window of centroid k meets has k in its list (two workgroups per
+        // 64 x 32 tile) and counts itself once its sums are through; the last one has all pixels of k in the global sums and
+        // does what k_centroid_finalize does -- the table is read by the NEXT launch (k_slic_bin), so plain stores will do
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (wave == 0 && lane < nc) {
+            const int k = my_k;
+            const int4 wv = cand[lane].win;
+            const int expect = 2 * ((wv.y - 1) / TILE_Y - wv.x / TILE_Y + 1) * ((wv.w - 1) / TILE_X - wv.z / TILE_X + 1);
+            const int seen = __hip_atomic_fetch_add(s.done + k, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1;
+            if (seen == expect) {
+                unsigned long long *a = reinterpret_cast<unsigned long long *>(s.acc + (size_t)k * 9);
+                long long v[9];
+#pragma unroll
+                for (int j = 0; j < 9; ++j) v[j] = (long long)__hip_atomic_load(a + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (v[0] == 0) {
+                    s.win[k] = make_int4(0, 0, 0, 0);          // no pixel carries label k any more: dead from now on
+                } else {
+                    const double nn = (double)v[0];
+                    const double cy = i64_to_double(v[1]) / nn, cx = i64_to_double(v[2]) / nn;
+                    const double finv = ldexp(1.0, -fix_bits_of(*s.premax));
+                    s.cy[k] = cy;
+                    s.cx[k] = cx;
+                    s.cL[k] = fix_value(v[3], v[4], finv) / nn;
+                    s.ca[k] = fix_value(v[5], v[6], finv) / nn;
+                    s.cb[k] = fix_value(v[7], v[8], finv) / nn;
+                    s.win[k] = search_window(cy, cx, s.step_y, s.step_x, s.H, s.W);
+                    const int iy = k / s.grid_nx, ix = k - iy * s.grid_nx;
+                    const double dy = fabs(cy - (double)(s.grid_y0 + iy * s.grid_dy)), dx = fabs(cx - (double)(s.grid_x0 + ix * s.grid_dx));
+                    const int d = (int)ceil(fmax(dy, dx));
+                    if (d > 0) atomicMax(&s.drift[s.drift_slot_next], d);
+                }
+#pragma unroll
+                for (int j = 0; j < 9; ++j) s.acc[(size_t)k * 9 + j] = 0;
+                s.done[k] = 0;
+            }
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -2131,6 +2174,16 @@ int launch_slic_iterations(SlicState s, const double *lab, const double *init_yx
 {
     if (used_persistent) *used_persistent = false;
     const bool default_cand = max_cand <= 0 || max_cand >= MAXC;
+    // Centroid update inside the assignment kernel (the workgroup that completes a centroid divides its sums): measured on
+    // MI355X it wins where the sweep is launch bound -- the 647 x 1024 images of config 4: +8 % images/s -- and costs the
+    // assignment kernel 3 us of tail at 2048 x 2048 (42.2 against 39.1 us, the stage as a whole 6 us faster), so it is the default
+    // only when the whole assignment grid is resident at once (one generation of workgroups: nothing hides the extra launch).
+    static const bool env_separate_finalize = getenv("IMSEGM_SEPARATE_FINALIZE") != nullptr;
+    static const bool env_fuse_finalize = getenv("IMSEGM_FUSE_FINALIZE") != nullptr;
+    const long assign_workgroups = 2L * cdiv(s.W, TILE_X) * cdiv(s.H, TILE_Y);
+    const bool fail_host_fuse = s.done != nullptr && s.fail_host != nullptr && !env_separate_finalize &&
+                                (env_fuse_finalize || assign_workgroups <= 1280);
+    if (fail_host_fuse) *s.fail_host = 0;
     if (max_cand <= 0 || max_cand > MAXC) max_cand = MAXC;
     size_t n = (size_t)s.H * s.W;
     HIP_TRY(hipMemsetAsync(labels, 0xff, n * sizeof(int32_t), st));       // nearest = -1
@@ -2225,6 +2278,12 @@ int launch_slic_iterations(SlicState s, const double *lab, const double *init_yx
         const bool dot = !first && s.fast32 && !s.slico && !(s.debug & 16);
         const bool first_grid = first && grid_covers && !(s.debug & 32);
         const bool accum = it + 1 < max_iter;
+        // centroid update inside the assignment kernel of this sweep (no finalize launch behind it)
+        const bool fuse = accum && s.done && fail_host_fuse && units == 1 && !s.phase_prof && (first_grid || dot);
+        if (fuse && used_persistent) *used_persistent = true;       // (the caller reads the failure word after its next synchronisation)
+        SlicState sf = s;
+        sf.fuse_finalize = fuse ? 1 : 0;
+        sf.drift_slot_next = (it + 1) % SLIC_DRIFT_SLOTS;
         // when profiling, the event pair rides on the dispatch itself (kernel begin / end timestamps)
         hipEvent_t ev_a = nullptr, ev_b = nullptr;
         if (prof.pair && !persistent) prof.pair(prof.user, 0, &ev_a, &ev_b);     // (persistent: the pair rides on k_slic_sweeps)
@@ -2242,7 +2301,7 @@ int launch_slic_iterations(SlicState s, const double *lab, const double *init_yx
         else if (s.phase_prof)                                                                                       \
             LAUNCH_ON((k_slic_assign_dot<ACC, FST, 1, true>), grid, s, lab, labels, s.tile_cands, s.tile_rec, s.tile_info, s.tile_k) \
         else                                                                                                         \
-            LAUNCH_ON((k_slic_assign_dot<ACC, FST, 1, false>), grid, s, lab, labels, s.tile_cands, s.tile_rec, s.tile_info, s.tile_k) \
+            LAUNCH_ON((k_slic_assign_dot<ACC, FST, 1, false>), grid, sf, lab, labels, s.tile_cands, s.tile_rec, s.tile_info, s.tile_k) \
     }
         if (first_grid) {
             if (accum) LAUNCH_DOT(true, true) else LAUNCH_DOT(false, true)
@@ -2262,7 +2321,7 @@ int launch_slic_iterations(SlicState s, const double *lab, const double *init_yx
 #undef LAUNCH_ASSIGN
         if (it + 1 < max_iter) {
             if (!dot && !first_grid) hipLaunchKernelGGL(k_slic_leftover, 64, 256, 0, st, s, lab, labels);
-            hipLaunchKernelGGL(k_centroid_finalize, cdiv(s.K, 256), 256, 0, st, s, (it + 1) % SLIC_DRIFT_SLOTS);
+            if (!fuse) hipLaunchKernelGGL(k_centroid_finalize, cdiv(s.K, 256), 256, 0, st, s, (it + 1) % SLIC_DRIFT_SLOTS);
             if (s.slico)
                 hipLaunchKernelGGL(k_slico_update, (int)std::min<size_t>(cdiv(n, (size_t)256), 4096), 256, 0, st, s, lab, labels);
         }

@@ -82,3 +82,22 @@ def test_images_in_flight_on_the_persistent_path(hip):
         for _ in range(3):
             got = list(pool.map(lambda im: _labels(im, 32, 0.2), images))
             assert all(np.array_equal(a, b) for a, b in zip(got, want))
+
+
+@pytest.mark.parametrize('shape,sp_size,regul,seed', [((647, 1024), 35, 0.2, 100), ((1030, 1200), 46, 0.2, 5), ((300, 1000), 24, 0.3, 4)])
+def test_centroid_update_inside_the_assignment_kernel(hip, monkeypatch, shape, sp_size, regul, seed):
+    """per-sweep launches with the centroid update done by the workgroup that completes a centroid (default for small images,
+    IMSEGM_FUSE_FINALIZE for any) against separate finalize launches and the oracle"""
+    from oracle import oracle as orc
+    from pyimsegm_amd.utilities.synthetic import voronoi_image
+    monkeypatch.delenv('IMSEGM_SLIC_PERSISTENT')
+    image = voronoi_image(shape[0], shape[1], seed=seed)
+    monkeypatch.setenv('IMSEGM_FUSE_FINALIZE', '1')
+    p0, f0 = hip.slic_sweep_runs()
+    fused = _labels(image, sp_size, regul)
+    assert hip.slic_sweep_runs()[1] == f0, 'the image was handed back to the separate finalize launches'
+    monkeypatch.delenv('IMSEGM_FUSE_FINALIZE')
+    monkeypatch.setenv('IMSEGM_SEPARATE_FINALIZE', '1')
+    separate = _labels(image, sp_size, regul)
+    assert np.array_equal(fused, separate)
+    assert np.array_equal(fused, orc.segment_slic_img2d(image, sp_size, regul))
