@@ -2178,8 +2178,8 @@ int launch_slic_iterations(SlicState s, const double *lab, const double *init_yx
     // MI355X it wins where the sweep is launch bound -- the 647 x 1024 images of config 4: +8 % images/s -- and costs the
     // assignment kernel 3 us of tail at 2048 x 2048 (42.2 against 39.1 us, the stage as a whole 6 us faster), so it is the default
     // only when the whole assignment grid is resident at once (one generation of workgroups: nothing hides the extra launch).
-    static const bool env_separate_finalize = getenv("IMSEGM_SEPARATE_FINALIZE") != nullptr;
-    static const bool env_fuse_finalize = getenv("IMSEGM_FUSE_FINALIZE") != nullptr;
+    const bool env_separate_finalize = getenv("IMSEGM_SEPARATE_FINALIZE") != nullptr;      // (tests switch these at run time)
+    const bool env_fuse_finalize = getenv("IMSEGM_FUSE_FINALIZE") != nullptr;
     const long assign_workgroups = 2L * cdiv(s.W, TILE_X) * cdiv(s.H, TILE_Y);
     const bool fail_host_fuse = s.done != nullptr && s.fail_host != nullptr && !env_separate_finalize &&
                                 (env_fuse_finalize || assign_workgroups <= 1280);
