@@ -330,7 +330,15 @@ def cpu_baseline_volume(shape_full, crop=(64, 256, 256)):
     _ = np.asarray(labels)[slic]
     total = time.perf_counter() - t0
     nvox = int(np.prod(crop))
-    return {'value': round(nvox / total / 1e6, 4), 'unit': 'Mpixels/s', 'cores': 1, 'kind': 'port',
+    extra = {}
+    full = load_golden('reference_c5_full.npz')
+    if full is not None and tuple(int(v) for v in full['shape']) == tuple(shape_full):
+        # the reference's own third-party leg on the full volume, timed in the build container (tests/golden/make_golden_configs.py c5full)
+        sec = [float(v) for v in full['seconds_one_core']]
+        extra['reference_slic_full_volume_build_container'] = {
+            'what': 'real scikit-image %s slic (%.0f s) + measure.label (%.0f s) on the full volume, one core of the build container'
+                    % (str(full['versions']), sec[0], sec[1]), 'mvoxels_per_s': round(float(np.prod(shape_full)) / sum(sec) / 1e6, 4)}
+    return {**extra, 'value': round(nvox / total / 1e6, 4), 'unit': 'Mpixels/s', 'cores': 1, 'kind': 'port',
             'sample': '%dx%dx%d crop of the volume on one core, %.1f s (SLIC + measure.label %.1f s, model fit %.1f s); the rate is '
                       'EXTRAPOLATED linearly to the full volume' % (crop + (total, t_slic, t_fit)),
             'extrapolated_seconds_full_volume': round(total * float(np.prod(shape_full)) / nvox, 1)}
@@ -988,6 +996,15 @@ def main():
                 out['other_configs'] = others
         if group.rank == 0:
             assert out['n_gpus'] == (args.gpus or group.world), (out['n_gpus'], args.gpus, group.world)
+        # the communicator goes first, and whatever native libraries left in the C stdio buffer (RCCL prints a version banner
+        # to stdout) is flushed, so that the JSON line is the LAST line this process writes
+        group.close()
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        if group.rank == 0:
             print(json.dumps(out), flush=True)
     finally:
         group.close()
