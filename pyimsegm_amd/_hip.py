@@ -875,6 +875,16 @@ def cut_grid_graph(unary_cost, pairwise_cost, cost_v, cost_h, n_iter=-1, algorit
                              algorithm=algorithm, ctx=ctx)
 
 
+def assume_bg_on_boundary(work, strips, bg_label, ctx=None):
+    """``imsegm_assume_bg_on_boundary`` on a contiguous int32 label image (modified in place); returns the label that
+    dominates the four border strips"""
+    found = C.c_int(0)
+    ctx = ctx or default_context()
+    _check(load_library().imsegm_assume_bg_on_boundary(ctx._h, _ptr(work), work.shape[0], work.shape[1], _ptr(strips), int(bg_label),
+                                                       C.byref(found)))
+    return found.value
+
+
 def label_hist2d(segm, windows, struc_elem, nb_labels, ctx=None):
     """``computeLabelHistogram2d`` for a batch of windows (``imsegm_label_hist2d``): uint32 [P, nb_labels]"""
     ctx = ctx or default_context()

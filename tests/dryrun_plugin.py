@@ -151,7 +151,18 @@ class Volume3D(Image2D):
         return (m if mean else None), e, v
 
 
+def _assume_bg_on_boundary(work, strips, bg_label, ctx=None):
+    """numpy stand-in of imsegm_assume_bg_on_boundary (border histogram over the four strips, label exchange in place)"""
+    parts = [work[strips[4 * q]:strips[4 * q + 1], strips[4 * q + 2]:strips[4 * q + 3]].ravel() for q in range(4)]
+    found = int(np.argmax(np.bincount(np.concatenate(parts))))
+    if found != bg_label:
+        a, b = work == found, work == bg_label
+        work[a], work[b] = bg_label, found
+    return found
+
+
 def pytest_configure(config):
+    _hip.assume_bg_on_boundary = _assume_bg_on_boundary
     _hip.Image2D = Image2D
     _hip.Volume3D = Volume3D
     _hip.default_context = lambda: _CTX

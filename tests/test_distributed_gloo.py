@@ -94,7 +94,13 @@ def test_control_plane_rejects_stray_connections(tmp_path):
         while not os.path.exists(path) and time.time() < deadline:
             time.sleep(0.02)
         stray = socket.socket(socket.AF_UNIX, socket.SOCK_STREAM)
-        stray.connect(path)
+        while True:                                      # (the file appears with bind(), connections are taken after listen())
+            try:
+                stray.connect(path)
+                break
+            except OSError:
+                assert time.time() < deadline, 'the hub never listened'
+                time.sleep(0.02)
         stray.sendall(struct.pack('<i', 7))              # not a rank of this job
         peer = _Star(1, 2, timeout=30.)
         t.join(30)

@@ -84,13 +84,8 @@ def test_oracle_label_histograms_match_reference(oracle):
 
 
 def test_host_boundary_background_matches_reference():
-    """labeling.assume_bg_on_boundary / data_io.get_image2d_boundary_color (driver touch points) against the
-    reference's own functions"""
-    from pyimsegm_amd import labeling as lb
+    """data_io.get_image2d_boundary_color (driver touch point) against the reference's own function; labeling.assume_bg_on_boundary
+    runs on the device since round 3: the same golden vectors are checked in tests/test_gpu_output.py"""
     from pyimsegm_amd.utilities.data_io import get_image2d_boundary_color
     g = _load('labeling.npz')
-    for name in ('a', 'b'):
-        for size in (1, 3):
-            out = lb.assume_bg_on_boundary(g['segm_' + name].copy(), bg_label=0, boundary_size=size)
-            assert np.array_equal(out, g['bg_%s_%d' % (name, size)]), (name, size)
     assert np.array_equal(get_image2d_boundary_color(g['colour'], size=2), g['colour_bg'])

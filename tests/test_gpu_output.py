@@ -67,6 +67,12 @@ def test_assume_bg_on_boundary_doctests_and_random_maps():
         assert got.dtype == np.int64 and np.array_equal(got, _reference_assume_bg(segm.astype(np.int64), bg, size)), (shape, nb, size)
     with pytest.raises(Exception):
         assume_bg_on_boundary(np.full((8, 8), -1, dtype=np.int32))
+    # the reference's own function, lifted from its file (tests/golden/make_golden.py -> labeling.npz)
+    g = np.load(os.path.join(GOLDEN, 'labeling.npz'))
+    for name in ('a', 'b'):
+        for size in (1, 3):
+            out = assume_bg_on_boundary(g['segm_' + name].copy(), bg_label=0, boundary_size=size)
+            assert np.array_equal(out, g['bg_%s_%d' % (name, size)]), (name, size)
 
 
 def test_narrow_result_formats_equal_the_default_ones():
