@@ -187,6 +187,15 @@ static int bind(imsegm_ctx *ctx)
     return 0;
 }
 
+// the session's page of reduction words: zeroed once where it is allocated (launch_minmax leaves its words at zero, slic.hip)
+static int ensure_small(imsegm_image2d *im)
+{
+    if (im->small.cap >= 4096) return 0;
+    if (im->small.ensure(4096)) return -1;
+    HIP_TRY(hipMemsetAsync(im->small.p, 0, 4096, im->ctx->stream));
+    return 0;
+}
+
 // skimage.util.regular_grid (util/_regular_grid.py, 0.18) for a 3-D shape
 struct GridAxis {
     long start, step;
@@ -497,17 +506,17 @@ int imsegm_image2d_slic(imsegm_image2d *im, int minmax_normalize, int n_segments
     const size_t n_tiles = (size_t)cdiv(W, SLIC_TILE_X) * cdiv(H, SLIC_TILE_Y);
     if (im->tiles.ensure(n_tiles * (SLIC_MAXC * (sizeof(Cand) + sizeof(Rec32) + sizeof(int)) + sizeof(TileInfo) + sizeof(int)) + n * 4 + 1024))
         return -1;
-    if (im->small.ensure(4096)) return -1;
+    if (ensure_small(im)) return -1;
 
     unsigned long long *keys = im->small.as<unsigned long long>();
     double *minmax = reinterpret_cast<double *>(keys + 2);
 
     int sp_all = ctx->begin(PG_SLIC);
     int sp = ctx->begin(PG_PRE);
-    if (launch_minmax(im->img.p, im->dtype, n * 3, keys, minmax, st)) return -1;
     double *premax = minmax + 2;                          // max |pre-processed value|, written on the device
+    if (launch_minmax(im->img.p, im->dtype, n * 3, keys, minmax, st, premax)) return -1;      // (and premax = 0)
     if (launch_preprocess_color2d(im->img.p, im->dtype, H, W, minmax_normalize, minmax, tz, ty, tx, 1.0 / compactness,
-                                  im->labA.as<double>(), im->labB.as<double>(), premax, st))
+                                  im->labA.as<double>(), im->labB.as<double>(), premax, st, true))
         return -1;
     ctx->end(sp);
 
@@ -857,7 +866,7 @@ int imsegm_image2d_color_stats(imsegm_image2d *im, double *mean_out, double *ene
     hipStream_t st = ctx->stream;
     double maxabs = 255.0;
     if (im->dtype != IMSEGM_U8) {
-        if (im->small.ensure(4096)) return -1;
+        if (ensure_small(im)) return -1;
         unsigned long long *keys = im->small.as<unsigned long long>();
         double *minmax = reinterpret_cast<double *>(keys + 2);
         if (launch_minmax(im->img.p, im->dtype, im->n * 3, keys, minmax, st)) return -1;
@@ -1217,7 +1226,7 @@ int imsegm_volume_slic(imsegm_image2d *im, int n_segments, double compactness, c
     // a float32 volume stays float32 from end to end, as in scikit-image 0.18 (volume.hip, float32 section)
     const bool f32 = im->dtype == IMSEGM_F32;
     if (im->vol_cent.ensure((size_t)K * (4 * 8 + 6 * 4 + 6 * 8 + 4 * 4 + 6 * 4) + 256)) return -1;
-    if (im->small.ensure(4096)) return -1;
+    if (ensure_small(im)) return -1;
     double *premax = reinterpret_cast<double *>(im->small.as<unsigned char>() + 64);
     if (f32) {
         if (launch_vol_preprocess_f32(im->img.as<float>(), D, H, W, tz, ty, tx, 1.0 / compactness, im->labA.as<double>(),
@@ -1324,7 +1333,7 @@ int imsegm_volume_gray_stats(imsegm_image2d *im, double *mean_out, double *energ
     hipStream_t st = im->ctx->stream;
     double maxabs = 255.0;
     if (im->dtype != IMSEGM_U8) {
-        if (im->small.ensure(4096)) return -1;
+        if (ensure_small(im)) return -1;
         unsigned long long *keys = im->small.as<unsigned long long>();
         double *minmax = reinterpret_cast<double *>(keys + 2);
         if (launch_minmax(im->img.p, im->dtype, im->n, keys, minmax, st)) return -1;
@@ -1542,7 +1551,7 @@ int imsegm_image2d_features_color(imsegm_image2d *im, int feature_mask, double *
     const int K = im->n_labels;
     double maxabs = 255.0;
     if (im->dtype != IMSEGM_U8) {
-        if (im->small.ensure(4096)) return -1;
+        if (ensure_small(im)) return -1;
         unsigned long long *keys = im->small.as<unsigned long long>();
         double *minmax = reinterpret_cast<double *>(keys + 2);
         if (launch_minmax(im->img.p, im->dtype, im->is_volume ? im->n : im->n * 3, keys, minmax, st)) return -1;
@@ -1658,6 +1667,7 @@ static int segment_impl(imsegm_image2d *im, const imsegm_gmm *gmm, const double 
     // ---- host -> device parameter block (one pinned staging copy)
     const size_t FF = (size_t)F * F;
     size_t o = 0;
+    const size_t o_misc = o; o += 256;          // K | E | status | pad | energy (8) | scalars[8]: initialised by the same copy
     const size_t o_pw = o; o += al((size_t)C * C * 8);
     const size_t o_sm = o; o += al((size_t)C * C * 4);
     const size_t o_cl = o; o += al((size_t)C * 4);
@@ -1690,7 +1700,7 @@ static int segment_impl(imsegm_image2d *im, const imsegm_gmm *gmm, const double 
     const size_t d_wp = d; d += al((size_t)K * words * 4);
     const size_t d_gl = d; d += al((size_t)K * 4);
     const size_t d_lut = d; d += al((size_t)K * 4);
-    const size_t d_misc = d; d += 256;          // K | E | status | pad | energy (8) | scalars[8] | fstd[2F]
+    const size_t d_misc = d_par + o_misc;
     const size_t d_fstd = d; d += al((size_t)2 * std::max(F, 1) * 8);
     const size_t d_bitmap = d; d += al((size_t)K * words * 4);
     const size_t d_cacc = d; d += al((size_t)K * 4 * 8);
@@ -1705,6 +1715,7 @@ static int segment_impl(imsegm_image2d *im, const imsegm_gmm *gmm, const double 
         return -1;
     }
     memset(host, 0, up_bytes);
+    reinterpret_cast<int32_t *>(host + o_misc)[0] = K;            // E = 0 | status = 0 | gc status = 0 | energy = 0 behind it
     memcpy(host + o_pw, pairwise, (size_t)C * C * 8);
     int32_t *si = reinterpret_cast<int32_t *>(host + o_sm);
     int smax = 0;
@@ -1731,8 +1742,6 @@ static int segment_impl(imsegm_image2d *im, const imsegm_gmm *gmm, const double 
     int32_t *K_dev = misc, *E_dev = misc + 1, *status = misc + 2;
     long long *energy = reinterpret_cast<long long *>(dev + d_misc + 16);
     double *scalars = reinterpret_cast<double *>(dev + d_misc + 64);
-    HIP_TRY(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(misc), K, 1, st));      // K | E = 0 | status = 0 | gc status = 0 | energy
-    HIP_TRY(hipMemsetAsync(misc + 1, 0, 28, st));
     // ---- graph: bitmap + centres, then the symmetric CSR
     uint32_t *bitmap = reinterpret_cast<uint32_t *>(dev + d_bitmap);
     double *centres = reinterpret_cast<double *>(dev + d_cent);
@@ -2046,7 +2055,7 @@ int imsegm_image2d_mean_gradient(imsegm_image2d *im, double *mean_out)
     if (launch_gradient_image(im->img.p, im->tex_planes.p, im->dtype, im->D, im->H, im->W, C, st)) return -1;
     double maxabs = 255.0;
     if (im->dtype != IMSEGM_U8) {
-        if (im->small.ensure(4096)) return -1;
+        if (ensure_small(im)) return -1;
         unsigned long long *keys = im->small.as<unsigned long long>();
         double *minmax = reinterpret_cast<double *>(keys + 2);
         if (launch_minmax(im->tex_planes.p, im->dtype, im->n * C, keys, minmax, st)) return -1;

@@ -176,8 +176,14 @@ int launch_adjacency_bitmap(const int32_t *labels, int H, int W, int K, uint32_t
                             uint8_t *present_out, hipStream_t st)
 {
     int words = cdiv(K, 32);
-    HIP_TRY(hipMemsetAsync(bitmap, 0, (size_t)K * words * sizeof(uint32_t), st));
-    HIP_TRY(hipMemsetAsync(cacc, 0, (size_t)K * 3 * sizeof(long long), st));
+    // (one fill when the sums sit right behind the bitmap, as the fused call lays them out)
+    const size_t bm_bytes = (size_t)K * words * sizeof(uint32_t), gap = (size_t)((const char *)cacc - (const char *)bitmap);
+    if ((const char *)cacc >= (const char *)bitmap + bm_bytes && gap <= bm_bytes + 64) {
+        HIP_TRY(hipMemsetAsync(bitmap, 0, gap + (size_t)K * 3 * sizeof(long long), st));
+    } else {
+        HIP_TRY(hipMemsetAsync(bitmap, 0, bm_bytes, st));
+        HIP_TRY(hipMemsetAsync(cacc, 0, (size_t)K * 3 * sizeof(long long), st));
+    }
     dim3 grid(cdiv(W, 64), cdiv(H, 4 * GR_ROWS));
     hipLaunchKernelGGL(k_adjacency_centres, grid, 256, 0, st, labels, H, W, K, words, bitmap, cacc);
     hipLaunchKernelGGL(k_centres_finalize, cdiv(K, 256), 256, 0, st, cacc, K, centres_out, present_out);

@@ -78,7 +78,7 @@ __device__ __forceinline__ long long block_sum_i64(long long v, long long *scrat
     return t;
 }
 
-__device__ long long gc_energy(const GcDevice &g, const int32_t *lab, long long *scratch)
+__device__ __forceinline__ long long gc_energy(const GcDevice &g, const int32_t *lab, long long *scratch)
 {
     long long e = 0;
     for (int i = threadIdx.x; i < g.K; i += blockDim.x) e += g.unary[(size_t)i * g.C + lab[i]];
@@ -89,34 +89,108 @@ __device__ long long gc_energy(const GcDevice &g, const int32_t *lab, long long 
     return block_sum_i64(e, scratch);
 }
 
+#ifndef GC_ARCS
+#define GC_ARCS 8
+#endif
+
+// OR over the workgroup with ONE barrier per call: three LDS words used in turn -- call r sets and reads word r % 3, and thread 0
+// clears word (r + 2) % 3 behind the barrier: its last readers (call r - 1) have all arrived at this barrier, its next writers
+// (call r + 2) start behind the next one.  (__syncthreads_or costs three barriers; a relabelling level or a push round is little
+// more than its barriers.)
+__device__ __forceinline__ bool block_or(int pred, int *flags, unsigned &calls)
+{
+    int *f = flags + calls % 3;
+    if (pred) __hip_atomic_store(f, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    __syncthreads();
+    const int any = __hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (threadIdx.x == 0) __hip_atomic_store(flags + (calls + 2) % 3, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    ++calls;
+    return any != 0;
+}
+
+// The graph never changes during the kernel: with at most NPT nodes per thread (u = tid + s * blockDim) the arc range of a node and the
+// heads and reverse arcs of its first GC_ARCS arcs stay in registers, and a node's pass of a relabelling level or a push round is ONE
+// round of independent LDS reads (capacities and the heights of the heads) instead of a chain arc range -> head -> height.
+template <int NPT> struct GcTopo {
+    int a0[NPT > 0 ? NPT : 1], deg[NPT > 0 ? NPT : 1];
+    unsigned tr[NPT > 0 ? NPT : 1][GC_ARCS];          // head | reverse arc << 16 (the launcher checks that both fit)
+};
+
 // reverse BFS from the sink over residual arcs: height = exact distance to the sink, HMAX if none
-__device__ void gc_global_relabel(const GcDevice &g, int *cap, int *height, long long *excess, int alpha, int *flag)
+template <int NPT>
+__device__ __forceinline__ void gc_global_relabel(const GcDevice &g, const GcTopo<NPT> &t, int *cap, int *height, long long *excess,
+                                                  int alpha, int *flags, unsigned &calls)
 {
     const int HMAX = g.K + 2;
-    for (int u = threadIdx.x; u < g.K; u += blockDim.x)
-        st(&height[u], (g.labels[u] != alpha && ld(&excess[u]) < 0) ? 1 : HMAX);
+    unsigned act = 0;                          // bit s: node tid + s * blockDim takes part in the move (its label is not alpha)
+    {
+        int s = 0;
+        for (int u = threadIdx.x; u < g.K; u += blockDim.x, ++s) {
+            const bool a = g.labels[u] != alpha;
+            if (a && s < 32) act |= 1u << s;
+            st(&height[u], (a && ld(&excess[u]) < 0) ? 1 : HMAX);
+        }
+    }
     __syncthreads();
     for (int level = 1; level < HMAX; ++level) {
         GC_DBG_ADD(2, 1)
         int changed = 0;
-        for (int u = threadIdx.x; u < g.K; u += blockDim.x) {
-            if (ld(&height[u]) != HMAX || g.labels[u] == alpha) continue;
-            for (int a = g.arc_start[u]; a < g.arc_start[u + 1]; ++a) {
-                if (ld(&cap[a]) > 0 && ld(&height[g.arc_to[a]]) == level) {
+        if (NPT > 0) {
+#pragma unroll
+            for (int s = 0; s < (NPT > 0 ? NPT : 1); ++s) {
+                const int u = threadIdx.x + s * blockDim.x;
+                if (u >= g.K || !((act >> s) & 1) || t.deg[s] == 0 || ld(&height[u]) != HMAX) continue;
+                int c[GC_ARCS], h[GC_ARCS];
+#pragma unroll
+                for (int i = 0; i < GC_ARCS; ++i) {
+                    c[i] = ld(&cap[t.a0[s] + min(i, t.deg[s] - 1)]);
+                    h[i] = ld(&height[t.tr[s][i] & 0xffffu]);
+                }
+                bool hit = false;
+#pragma unroll
+                for (int i = 0; i < GC_ARCS; ++i) hit |= c[i] > 0 && h[i] == level;
+                for (int a = t.a0[s] + GC_ARCS; a < t.a0[s] + t.deg[s] && !hit; ++a)          // (more than GC_ARCS neighbours: rare)
+                    hit = ld(&cap[a]) > 0 && ld(&height[g.arc_to[a]]) == level;
+                if (hit) {
                     st(&height[u], level + 1);
                     changed = 1;
-                    break;
+                }
+            }
+        } else {
+            for (int u = threadIdx.x; u < g.K; u += blockDim.x) {
+                if (ld(&height[u]) != HMAX || g.labels[u] == alpha) continue;
+                // GC_ARCS arcs at a time, their loads issued together: a node's pass is three dependent reads (arc range -> capacity
+                // and head -> height of the head) per batch, not three per arc
+                const int a0 = g.arc_start[u], a1 = g.arc_start[u + 1];
+                bool hit = false;
+                for (int base = a0; base < a1 && !hit; base += GC_ARCS) {
+                    int c[GC_ARCS], h[GC_ARCS];
+#pragma unroll
+                    for (int i = 0; i < GC_ARCS; ++i) {
+                        const int a = min(base + i, a1 - 1);
+                        c[i] = ld(&cap[a]);
+                        h[i] = g.arc_to[a];
+                    }
+#pragma unroll
+                    for (int i = 0; i < GC_ARCS; ++i) h[i] = ld(&height[h[i]]);
+#pragma unroll
+                    for (int i = 0; i < GC_ARCS; ++i) hit |= c[i] > 0 && h[i] == level;
+                }
+                if (hit) {
+                    st(&height[u], level + 1);
+                    changed = 1;
                 }
             }
         }
         // (a node that got level + 1 in this pass is not read as `level` by anybody: one barrier with the OR is enough)
-        if (!__syncthreads_or(changed)) break;
+        if (!block_or(changed, flags, calls)) break;
     }
 }
 
 // one expansion move; returns (uniformly) whether the energy strictly decreased
-__device__ bool gc_expand(const GcDevice &g, int alpha, int *cap, int *height, long long *excess, long long *energy,
-                          int *flag, long long *scratch)
+template <int NPT>
+__device__ __forceinline__ bool gc_expand(const GcDevice &g, const GcTopo<NPT> &t, int alpha, int *cap, int *height, long long *excess,
+                                          long long *energy, int *flags, unsigned &calls, long long *scratch)
 {
     const int HMAX = g.K + 2;
     // any active site at all?
@@ -178,29 +252,88 @@ __device__ bool gc_expand(const GcDevice &g, int alpha, int *cap, int *height, l
             if (threadIdx.x == 0) *g.status = 1;
             break;
         }
-        gc_global_relabel(g, cap, height, excess, alpha, flag);
+        gc_global_relabel<NPT>(g, t, cap, height, excess, alpha, flags, calls);
         int active = 0;
         for (int u = threadIdx.x; u < g.K; u += blockDim.x)
             if (ld(&excess[u]) > 0 && ld(&height[u]) < HMAX) active = 1;
         GC_DBG_CLOCK(9)        // global relabel
-        if (!__syncthreads_or(active)) break;
+        if (!block_or(active, flags, calls)) break;
         for (int round = 0; round < GC_PUSH_ROUNDS; ++round) {
             GC_DBG_ADD(3, 1)
             int busy = 0;
+            if (NPT > 0) {
+#pragma unroll
+                for (int s = 0; s < (NPT > 0 ? NPT : 1); ++s) {
+                    const int u = threadIdx.x + s * blockDim.x;
+                    if (u >= g.K) continue;
+                    const long long e = ld(&excess[u]);
+                    const int hu = ld(&height[u]);
+                    if (e <= 0 || hu >= HMAX) continue;
+                    busy = 1;
+                    int best_h = 0x7fffffff, best_a = -1, best_v = 0, best_r = 0;
+                    if (t.deg[s] > 0) {
+                        int c[GC_ARCS], h[GC_ARCS];
+#pragma unroll
+                        for (int i = 0; i < GC_ARCS; ++i) {
+                            c[i] = ld(&cap[t.a0[s] + min(i, t.deg[s] - 1)]);
+                            h[i] = ld(&height[t.tr[s][i] & 0xffffu]);
+                        }
+#pragma unroll
+                        for (int i = 0; i < GC_ARCS; ++i)
+                            if (i < t.deg[s] && c[i] > 0 && h[i] < best_h) {       // (the first arc to the lowest neighbour)
+                                best_h = h[i];
+                                best_a = t.a0[s] + i;
+                                best_v = (int)(t.tr[s][i] & 0xffffu);
+                                best_r = (int)(t.tr[s][i] >> 16);
+                            }
+                        for (int a = t.a0[s] + GC_ARCS; a < t.a0[s] + t.deg[s]; ++a)
+                            if (ld(&cap[a]) > 0) {
+                                const int v = g.arc_to[a], h2 = ld(&height[v]);
+                                if (h2 < best_h) {
+                                    best_h = h2;
+                                    best_a = a;
+                                    best_v = v;
+                                    best_r = g.arc_rev[a];
+                                }
+                            }
+                    }
+                    if (best_a < 0) {
+                        st(&height[u], HMAX);
+                    } else if (hu > best_h) {
+                        const int c = ld(&cap[best_a]);
+                        const int d = (e < (long long)c) ? (int)e : c;
+                        atomicSub(&cap[best_a], d);
+                        atomicAdd(&cap[best_r], d);
+                        atomic_add_i64(&excess[u], -(long long)d);
+                        atomic_add_i64(&excess[best_v], (long long)d);
+                    } else {
+                        st(&height[u], best_h + 1 < HMAX ? best_h + 1 : HMAX);
+                    }
+                }
+            } else {
             for (int u = threadIdx.x; u < g.K; u += blockDim.x) {
                 long long e = ld(&excess[u]);
                 int hu = ld(&height[u]);
                 if (e <= 0 || hu >= HMAX) continue;
                 busy = 1;
                 int best_h = 0x7fffffff, best_a = -1;
-                for (int a = g.arc_start[u]; a < g.arc_start[u + 1]; ++a) {
-                    if (ld(&cap[a]) > 0) {
-                        int h = ld(&height[g.arc_to[a]]);
-                        if (h < best_h) {
-                            best_h = h;
-                            best_a = a;
-                        }
+                const int a0 = g.arc_start[u], a1 = g.arc_start[u + 1];
+                for (int base = a0; base < a1; base += GC_ARCS) {          // (batched like the relabelling pass)
+                    int c[GC_ARCS], h[GC_ARCS];
+#pragma unroll
+                    for (int i = 0; i < GC_ARCS; ++i) {
+                        const int a = min(base + i, a1 - 1);
+                        c[i] = ld(&cap[a]);
+                        h[i] = g.arc_to[a];
                     }
+#pragma unroll
+                    for (int i = 0; i < GC_ARCS; ++i) h[i] = ld(&height[h[i]]);
+#pragma unroll
+                    for (int i = 0; i < GC_ARCS; ++i)
+                        if (base + i < a1 && c[i] > 0 && h[i] < best_h) {       // (the first arc to the lowest neighbour)
+                            best_h = h[i];
+                            best_a = base + i;
+                        }
                 }
                 if (best_a < 0) {
                     st(&height[u], HMAX);
@@ -216,8 +349,9 @@ __device__ bool gc_expand(const GcDevice &g, int alpha, int *cap, int *height, l
                     st(&height[u], best_h + 1 < HMAX ? best_h + 1 : HMAX);
                 }
             }
+            }
             // (no active node in a whole round: nothing can change any more before the next global relabel)
-            if (!__syncthreads_or(busy)) break;
+            if (!block_or(busy, flags, calls)) break;
         }
         GC_DBG_CLOCK(10)       // push rounds
     }
@@ -239,6 +373,12 @@ __device__ bool gc_expand(const GcDevice &g, int alpha, int *cap, int *height, l
     return accept;
 }
 
+// LVL: what lives in LDS -- 0 nothing (scratch in global memory), 1 the arrays the moves modify, 2 + labels, proposal, unary and
+// smoothness costs, 3 + arc_start and arc_to, 4 + arc_rev.  A template parameter, not a run-time switch: with the placement known at
+// compile time the accesses are LDS instructions; through pointers that may be either they are flat loads of twice the latency,
+// and a relabelling level or a push round is nothing but a chain of such loads and a barrier.
+// NPT > 0: at most NPT nodes per thread, the first GC_ARCS arcs of each in registers (GcTopo).
+template <int LVL, int NPT>
 __global__ void __launch_bounds__(GC_THREADS) k_alpha_expansion(GcDevice g)
 {
     if (g.E_dev && *g.E_dev > g.E) {
@@ -252,22 +392,38 @@ __global__ void __launch_bounds__(GC_THREADS) k_alpha_expansion(GcDevice g)
     extern __shared__ __align__(16) unsigned char dyn[];
     __shared__ long long scratch[GC_THREADS / 64];
     __shared__ long long energy;
-    __shared__ int flag;
+    __shared__ int flags[3];
     __shared__ int table[GC_MAX_LABELS];
     __shared__ int queue_sizes[GC_MAX_LABELS + 2];
 
+    // (read from the arrays in global memory: the LDS copies below are not complete before the next barrier)
+    GcTopo<NPT> topo;
+    if (NPT > 0) {
+#pragma unroll
+        for (int s = 0; s < (NPT > 0 ? NPT : 1); ++s) {
+            const int u = threadIdx.x + s * blockDim.x;
+            const bool in = u < g.K;
+            topo.a0[s] = in ? g.arc_start[u] : 0;
+            topo.deg[s] = in ? g.arc_start[u + 1] - topo.a0[s] : 0;
+#pragma unroll
+            for (int i = 0; i < GC_ARCS; ++i) {
+                const int a = topo.a0[s] + min(i, topo.deg[s] - 1);
+                topo.tr[s][i] = topo.deg[s] > 0 ? (unsigned)g.arc_to[a] | ((unsigned)g.arc_rev[a] << 16) : 0u;
+            }
+        }
+    }
     long long *excess;
     int *cap, *height;
     int32_t *labels_out = g.labels;
-    if (g.use_lds) {
-        // LDS (through generic pointers): the arrays the moves modify, then -- as far as they fit -- what they only read.  A level
+    if (LVL >= 1) {
+        // LDS: the arrays the moves modify, then -- as far as they fit -- what they only read.  A level
         // of the relabelling BFS or a push round is a chain of dependent reads per node (arc range -> neighbour -> its height):
         // ~2 us out of global memory, a fraction of that out of LDS.
         excess = reinterpret_cast<long long *>(dyn);
         cap = reinterpret_cast<int *>(dyn + (size_t)g.K * 8);
         height = cap + 2 * (size_t)g.e_cap;
         int *next = height + g.K;
-        if (g.lds_lab) {
+        if (LVL >= 2) {
             int *lab = next, *prop = lab + g.K, *un = prop + g.K, *sm = un + (size_t)g.K * g.C;
             next = sm + g.C * g.C;
             for (int i = threadIdx.x; i < g.K * g.C; i += blockDim.x) un[i] = g.unary[i];
@@ -277,14 +433,14 @@ __global__ void __launch_bounds__(GC_THREADS) k_alpha_expansion(GcDevice g)
             g.unary = un;
             g.smooth = sm;
         }
-        if (g.lds_topo) {
+        if (LVL >= 3) {
             int *as = next, *at = as + g.K + 1;
             next = at + 2 * (size_t)g.e_cap;
             for (int i = threadIdx.x; i <= g.K; i += blockDim.x) as[i] = g.arc_start[i];
             for (int i = threadIdx.x; i < 2 * g.E; i += blockDim.x) at[i] = g.arc_to[i];
             g.arc_start = as;
             g.arc_to = at;
-            if (g.lds_topo > 1) {
+            if (LVL >= 4) {
                 int *ar = next;
                 for (int i = threadIdx.x; i < 2 * g.E; i += blockDim.x) ar[i] = g.arc_rev[i];
                 g.arc_rev = ar;
@@ -295,6 +451,8 @@ __global__ void __launch_bounds__(GC_THREADS) k_alpha_expansion(GcDevice g)
         cap = g.g_cap;
         height = g.g_height;
     }
+    unsigned calls = 0;
+    if (threadIdx.x < 3) flags[threadIdx.x] = 0;
     for (int u = threadIdx.x; u < g.K; u += blockDim.x) g.labels[u] = 0;
     if (threadIdx.x < g.C) table[threadIdx.x] = threadIdx.x;
     __syncthreads();
@@ -305,6 +463,9 @@ __global__ void __launch_bounds__(GC_THREADS) k_alpha_expansion(GcDevice g)
     if (g.n_iter == -1) {
         // GCoptimization::expansion(-1): adaptive cycles (see oracle orc_alpha_expansion_int)
         int nq = 1, next = 0;
+        // label of the last move that was accepted: expanding it again right away cannot lower the energy (the moves open to the
+        // new labelling are a subset of those the accepted move was the optimum of), so that move is answered without a max-flow
+        int last_accepted = -1;
         if (threadIdx.x == 0) queue_sizes[0] = g.C;
         __syncthreads();
         do {
@@ -312,7 +473,8 @@ __global__ void __launch_bounds__(GC_THREADS) k_alpha_expansion(GcDevice g)
             int start = next;
             do {
                 int alpha = table[next];
-                bool ok = gc_expand(g, alpha, cap, height, excess, &energy, &flag, scratch);
+                bool ok = alpha != last_accepted && gc_expand<NPT>(g, topo, alpha, cap, height, excess, &energy, flags, calls, scratch);
+                if (ok) last_accepted = alpha;
                 if (!ok) {
                     --queue_size;
                     __syncthreads();
@@ -341,10 +503,12 @@ __global__ void __launch_bounds__(GC_THREADS) k_alpha_expansion(GcDevice g)
             __syncthreads();
         } while (nq > 0);
     } else {
+        int last_accepted = -1;
         for (int cycle = 0; cycle < g.n_iter; ++cycle) {
             long long before = energy;
             __syncthreads();
-            for (int l = 0; l < g.C; ++l) gc_expand(g, table[l], cap, height, excess, &energy, &flag, scratch);
+            for (int l = 0; l < g.C; ++l)
+                if (table[l] != last_accepted && gc_expand<NPT>(g, topo, table[l], cap, height, excess, &energy, flags, calls, scratch)) last_accepted = table[l];
             if (!(energy < before)) break;
         }
     }
@@ -418,27 +582,57 @@ int launch_alpha_expansion(GcProblem p, const int32_t *arc_start, const int32_t 
     g.use_lds = lds_need <= lds_max;
     g.e_cap = p.E;
     g.lds_lab = g.lds_topo = 0;
+    int level = 0;                            // (nested: each level on top of the one before, as far as 150 KB reach)
     if (g.use_lds) {
+        level = 1;
         const size_t lab = ((size_t)2 * p.K + (size_t)p.K * p.C + (size_t)p.C * p.C) * 4, topo1 = ((size_t)p.K + 1 + (size_t)2 * p.E) * 4, topo2 = (size_t)2 * p.E * 4;
         if (lds_need + lab <= lds_max) {
+            level = 2;
             g.lds_lab = 1;
             lds_need += lab;
-        }
-        if (lds_need + topo1 <= lds_max) {
-            g.lds_topo = 1;
-            lds_need += topo1;
-            if (lds_need + topo2 <= lds_max) {
-                g.lds_topo = 2;
-                lds_need += topo2;
+            if (lds_need + topo1 <= lds_max) {
+                level = 3;
+                g.lds_topo = 1;
+                lds_need += topo1;
+                if (lds_need + topo2 <= lds_max) {
+                    level = 4;
+                    g.lds_topo = 2;
+                    lds_need += topo2;
+                }
             }
         }
     }
+    const int level_cap = getenv("IMSEGM_GC_LDS_LEVEL") ? atoi(getenv("IMSEGM_GC_LDS_LEVEL")) : 4;      // (tests: every placement)
+    if (level > level_cap) {
+        level = std::max(0, level_cap);
+        g.use_lds = level >= 1; g.lds_lab = level >= 2; g.lds_topo = level >= 4 ? 2 : level >= 3 ? 1 : 0;
+        lds_need = (size_t)p.K * 8 + ((size_t)2 * p.E + p.K) * 4;
+        if (level >= 2) lds_need += ((size_t)2 * p.K + (size_t)p.K * p.C + (size_t)p.C * p.C) * 4;
+        if (level >= 3) lds_need += ((size_t)p.K + 1 + (size_t)2 * p.E) * 4;
+    }
     size_t dyn = g.use_lds ? lds_need : 0;
-    if (dyn > 48 * 1024)      // the opt-in is per device and cheap: set it on every launch that needs it
-        HIP_TRY(hipFuncSetAttribute((const void *)k_alpha_expansion, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
     // one thread per node up to 1024; a small graph runs with fewer waves (the moves are chains of workgroup barriers)
-    const int threads = std::min(GC_THREADS, std::max(256, ((p.K + 63) / 64) * 64));
-    hipLaunchKernelGGL(k_alpha_expansion, 1, threads, dyn, st, g);
+    int threads = std::min(GC_THREADS, std::max(256, ((p.K + 63) / 64) * 64));
+    if (const char *e = getenv("IMSEGM_GC_THREADS")) threads = std::min(GC_THREADS, std::max(64, atoi(e) & ~63));      // (experiments)
+    // arcs in registers: one node per thread (two would spill at 1024 threads)
+    const bool cached = level >= 2 && p.K <= threads && 2 * (long)p.E <= 0xffff && !getenv("IMSEGM_GC_NO_TOPO_REGS");
+#define GC_LAUNCH(L, N)                                                                                                           \
+    {                                                                                                                             \
+        if (dyn > 48 * 1024) /* the opt-in is per device and cheap: set it on every launch that needs it */                       \
+            HIP_TRY(hipFuncSetAttribute((const void *)k_alpha_expansion<L, N>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024)); \
+        hipLaunchKernelGGL((k_alpha_expansion<L, N>), 1, threads, dyn, st, g);                                                    \
+    }
+    switch (level + (cached ? 10 : 0)) {
+    case 0: GC_LAUNCH(0, 0) break;
+    case 1: GC_LAUNCH(1, 0) break;
+    case 2: GC_LAUNCH(2, 0) break;
+    case 3: GC_LAUNCH(3, 0) break;
+    case 4: GC_LAUNCH(4, 0) break;
+    case 12: GC_LAUNCH(2, 1) break;
+    case 13: GC_LAUNCH(3, 1) break;
+    default: GC_LAUNCH(4, 1) break;
+    }
+#undef GC_LAUNCH
     HIP_TRY(hipGetLastError());
     return 0;
 }

@@ -77,11 +77,11 @@ struct SlicState {
     int drift_slot_next;            // drift slot the updated centroids report into
 };
 
-int launch_minmax(const void *src, int dtype, size_t n, unsigned long long *keys, double *out2, hipStream_t st);
+int launch_minmax(const void *src, int dtype, size_t n, unsigned long long *keys, double *out2, hipStream_t st, double *also_zero = nullptr);
 // premax_dev[0] receives max |value| of the result planes
 int launch_preprocess_color2d(const void *img, int dtype, int H, int W, int normalize, const double *minmax_dev,
                               const Taps &tz, const Taps &ty, const Taps &tx, double ratio, double *bufA,
-                              double *bufB, double *premax_dev, hipStream_t st);
+                              double *bufB, double *premax_dev, hipStream_t st, bool premax_zeroed = false);
 int launch_absmax_f64(const double *src, size_t n, double *out_dev, hipStream_t st);
 // optional HIP-event hooks around the dominant kernel (api.hip profiler)
 struct ProfHook {

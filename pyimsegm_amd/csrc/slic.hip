@@ -31,8 +31,11 @@ __host__ __device__ __forceinline__ double key_f64(unsigned long long k)
 }
 
 // wave reduce, block reduce through LDS, then ONE atomic pair per block (a per-wave atomic on the
-// same two words serialises at ~12 ns each)
-__device__ __forceinline__ void block_minmax_commit(double mn, double mx, unsigned long long *keys)
+// same two words serialises at ~12 ns each).  The words rest at zero between calls: keys[0] holds the complement of the
+// minimum's key (so both are running maxima and zero is the neutral element), keys[5] is an arrival counter (the call's results sit in between), and the
+// workgroup that arrives last decodes the pair into out2, clears `also_zero` (the accumulator of the NEXT kernel of the
+// stream) and puts the words back to zero -- no launch before or after the reduction.
+__device__ __forceinline__ void block_minmax_commit(double mn, double mx, unsigned long long *keys, double *out2, double *also_zero)
 {
     __shared__ double smn[4], smx[4];
     mn = wave_min_f64(mn);
@@ -45,13 +48,25 @@ __device__ __forceinline__ void block_minmax_commit(double mn, double mx, unsign
     if (threadIdx.x == 0) {
         mn = fmin(fmin(smn[0], smn[1]), fmin(smn[2], smn[3]));
         mx = fmax(fmax(smx[0], smx[1]), fmax(smx[2], smx[3]));
-        atomicMin(&keys[0], f64_key(mn));
-        atomicMax(&keys[1], f64_key(mx));
+        __hip_atomic_fetch_max(&keys[0], ~f64_key(mn), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_fetch_max(&keys[1], f64_key(mx), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        unsigned *ticket = reinterpret_cast<unsigned *>(keys + 5);
+        // (release / acquire at agent scope: the atomics above are performed before the ticket is taken, and the last
+        // arriver's loads below see every workgroup's)
+        const unsigned t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        if (t == gridDim.x - 1) {
+            const unsigned long long k0 = __hip_atomic_exchange(&keys[0], 0ULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned long long k1 = __hip_atomic_exchange(&keys[1], 0ULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            out2[0] = key_f64(~k0);
+            out2[1] = key_f64(k1);
+            if (also_zero) *also_zero = 0.0;
+        }
     }
 }
 
 template <typename T>
-__global__ void __launch_bounds__(256) k_minmax(const T *__restrict__ src, size_t n, unsigned long long *keys)
+__global__ void __launch_bounds__(256) k_minmax(const T *__restrict__ src, size_t n, unsigned long long *keys, double *out2, double *also_zero)
 {
     double mn = INFINITY, mx = -INFINITY;
     size_t stride = (size_t)gridDim.x * blockDim.x;
@@ -60,11 +75,12 @@ __global__ void __launch_bounds__(256) k_minmax(const T *__restrict__ src, size_
         mn = fmin(mn, v);
         mx = fmax(mx, v);
     }
-    block_minmax_commit(mn, mx, keys);
+    block_minmax_commit(mn, mx, keys, out2, also_zero);
 }
 
 // uint8 variant: 16 bytes per lane
-__global__ void __launch_bounds__(256) k_minmax_u8(const uint8_t *__restrict__ src, size_t n, unsigned long long *keys)
+__global__ void __launch_bounds__(256) k_minmax_u8(const uint8_t *__restrict__ src, size_t n, unsigned long long *keys, double *out2,
+                                                   double *also_zero)
 {
     unsigned mn = 255, mx = 0;
     size_t nvec = n / 16;
@@ -101,34 +117,23 @@ __global__ void __launch_bounds__(256) k_minmax_u8(const uint8_t *__restrict__ s
             mn = min(mn, v);
             mx = max(mx, v);
         }
-    block_minmax_commit((double)mn, (double)mx, keys);
+    block_minmax_commit((double)mn, (double)mx, keys, out2, also_zero);
 }
 
-__global__ void k_minmax_init(unsigned long long *keys)
+// `keys`: words 0, 1 and 5 are ZERO when the call is enqueued and zero again when it has run (the session zeroes them once, where it
+// allocates them); `also_zero`: one more double the last workgroup clears (nullptr: none)
+int launch_minmax(const void *src, int dtype, size_t n, unsigned long long *keys, double *out2, hipStream_t st, double *also_zero)
 {
-    keys[0] = ~0ULL;
-    keys[1] = 0ULL;
-}
-__global__ void k_minmax_decode(const unsigned long long *keys, double *out)
-{
-    out[0] = key_f64(keys[0]);
-    out[1] = key_f64(keys[1]);
-}
-
-int launch_minmax(const void *src, int dtype, size_t n, unsigned long long *keys, double *out2, hipStream_t st)
-{
-    hipLaunchKernelGGL(k_minmax_init, 1, 1, 0, st, keys);
     // few workgroups: each ends with two atomics on the same two words, and single-lane atomics on one address serialise at
     // ~12 ns (512 workgroups: 16 us, 2048: 50 us for a 12.6 MB image that streams in 3 us)
     int grid = (int)std::min<size_t>(128, (n + 256 * 16 - 1) / (256 * 16));
     if (grid < 1) grid = 1;
     if (dtype == DT_U8)
-        hipLaunchKernelGGL(k_minmax_u8, grid, 256, 0, st, (const uint8_t *)src, n, keys);
+        hipLaunchKernelGGL(k_minmax_u8, grid, 256, 0, st, (const uint8_t *)src, n, keys, out2, also_zero);
     else if (dtype == DT_F32)
-        hipLaunchKernelGGL(k_minmax<float>, grid, 256, 0, st, (const float *)src, n, keys);
+        hipLaunchKernelGGL(k_minmax<float>, grid, 256, 0, st, (const float *)src, n, keys, out2, also_zero);
     else
-        hipLaunchKernelGGL(k_minmax<double>, grid, 256, 0, st, (const double *)src, n, keys);
-    hipLaunchKernelGGL(k_minmax_decode, 1, 1, 0, st, keys, out2);
+        hipLaunchKernelGGL(k_minmax<double>, grid, 256, 0, st, (const double *)src, n, keys, out2, also_zero);
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -414,7 +419,7 @@ k_pre_fused(const T *__restrict__ img, int H, int W, int normalize, const double
 
 int launch_preprocess_color2d(const void *img, int dtype, int H, int W, int normalize, const double *minmax_dev,
                               const Taps &tz, const Taps &ty, const Taps &tx, double ratio, double *bufA,
-                              double *bufB, double *premax_dev, hipStream_t st)
+                              double *bufB, double *premax_dev, hipStream_t st, bool premax_zeroed)
 {
     int n = H * W;
     int grid = cdiv(n, 256);
@@ -432,7 +437,7 @@ int launch_preprocess_color2d(const void *img, int dtype, int H, int W, int norm
             if (dev >= 0 && dev < IMSEGM_MAX_DEVICES) lds_set[dev][dtype] = lds;
         }
         dim3 gf(cdiv(W, PF_TX), cdiv(H, PF_TY));
-        HIP_TRY(hipMemsetAsync(premax_dev, 0, sizeof(double), st));
+        if (!premax_zeroed) HIP_TRY(hipMemsetAsync(premax_dev, 0, sizeof(double), st));
         if (dtype == DT_U8)
             hipLaunchKernelGGL(k_pre_fused<uint8_t>, gf, PF_THREADS, lds, st, (const uint8_t *)img, H, W, normalize, minmax_dev, tz, ty, tx,
                                ratio, bufA, premax_dev);
@@ -2186,7 +2191,6 @@ int launch_slic_iterations(SlicState s, const double *lab, const double *init_yx
     if (fail_host_fuse) *s.fail_host = 0;
     if (max_cand <= 0 || max_cand > MAXC) max_cand = MAXC;
     size_t n = (size_t)s.H * s.W;
-    HIP_TRY(hipMemsetAsync(labels, 0xff, n * sizeof(int32_t), st));       // nearest = -1
     hipLaunchKernelGGL(k_centroid_init, cdiv(s.K, 256), 256, 0, st, s, init_yx_dev);
     dim3 grid(cdiv(s.W, TILE_X), 2 * cdiv(s.H, TILE_Y));     // two 64 x 16 workgroups per bin tile
     const int n_tiles = grid.x * cdiv(s.H, TILE_Y);
@@ -2203,6 +2207,9 @@ int launch_slic_iterations(SlicState s, const double *lab, const double *init_yx
         const int reach_x = std::max(std::max(s.grid_x0, s.W - 1 - (s.grid_x0 + (s.grid_nx - 1) * s.grid_dx)), s.grid_dx / 2 + 1);
         grid_covers = reach_y <= 2 * s.step_y && reach_x <= 2 * s.step_x;
     }
+    // nearest = -1, unless the first sweep is the closed-form one, which gives every pixel a label without looking at the map
+    if (!(max_iter > 0 && s.fast32 && s.spatial_weight > 1e-9 && grid_covers && !(s.debug & 32)))
+        HIP_TRY(hipMemsetAsync(labels, 0xff, n * sizeof(int32_t), st));
     static const bool print_occ = getenv("IMSEGM_PRINT_OCC") != nullptr;
     if (print_occ) {
         int nb = 0;

@@ -220,12 +220,13 @@ __global__ void k_stats_clear(long long *acc, int K, int from, int to)
 }
 
 // normColorFeatures (features_cython.pyx:59-78): divide by the pixel count where count > 0
-__global__ void k_stats_finalize1(const long long *__restrict__ acc, StatParams sp, double *mean_out, double *energy_out,
+// (and the energy columns go back to zero for the variance pass, which sums into them again)
+__global__ void k_stats_finalize1(long long *__restrict__ acc, StatParams sp, double *mean_out, double *energy_out,
                                   float *mean32)
 {
     int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= sp.K) return;
-    const long long *a = acc + (size_t)k * 13;
+    long long *a = acc + (size_t)k * 13;
     long long n = a[0];
     for (int c = 0; c < 3; ++c) {
         double sv = (i64_to_double(a[1 + 2 * c]) + i64_to_double(a[2 + 2 * c]) * (1.0 / 4294967296.0)) / sp.scale_v;
@@ -236,6 +237,7 @@ __global__ void k_stats_finalize1(const long long *__restrict__ acc, StatParams 
         if (energy_out) energy_out[3 * k + c] = e;
         mean32[3 * k + c] = (float)m;        // np.array(means, dtype=np.float32), descriptors.py:293
     }
+    for (int j = 7; j < 13; ++j) a[j] = 0;
 }
 
 __global__ void k_stats_finalize2(const long long *__restrict__ acc, StatParams sp, double *var_out)
@@ -295,7 +297,6 @@ int launch_color_stats(const void *img, int dtype, const int32_t *labels, int H,
     else launch_pass<double>(1, (const double *)img, labels, sp, mean32_scratch, acc, st);
     hipLaunchKernelGGL(k_stats_finalize1, cdiv(K, 256), 256, 0, st, acc, sp, mean_out, energy_out, mean32_scratch);
     if (want_var) {
-        hipLaunchKernelGGL(k_stats_clear, cdiv(K, 256), 256, 0, st, acc, K, 7, 13);
         if (dtype == DT_U8) launch_pass<uint8_t>(2, (const uint8_t *)img, labels, sp, mean32_scratch, acc, st);
         else if (dtype == DT_F32) launch_pass<float>(2, (const float *)img, labels, sp, mean32_scratch, acc, st);
         else launch_pass<double>(2, (const double *)img, labels, sp, mean32_scratch, acc, st);

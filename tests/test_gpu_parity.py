@@ -180,6 +180,35 @@ def test_graphcut_random_graphs(hip, oracle, seed, K, C):
     assert np.array_equal(out, ref)
 
 
+@pytest.mark.parametrize('level,regs', [(0, 0), (1, 0), (2, 0), (3, 0), (4, 0), (2, 1), (3, 1), (4, 1)])
+def test_graphcut_every_lds_placement(hip, oracle, level, regs, monkeypatch):
+    """the kernel is compiled once per placement of its arrays (graphcut.hip, template parameter LVL: scratch in global memory ...
+    everything in LDS); all of them against the oracle on a graph that takes several relabellings and push rounds per move"""
+    monkeypatch.setenv('IMSEGM_GC_LDS_LEVEL', str(level))
+    if not regs:
+        monkeypatch.setenv('IMSEGM_GC_NO_TOPO_REGS', '1')          # (regs: the arcs of a node in registers, K <= 1024)
+    rng = np.random.default_rng(11)
+    side, C = 26, 4
+    K = side * side
+    ids = np.arange(K).reshape(side, side)
+    pairs = np.vstack([np.c_[ids[:, :-1].ravel(), ids[:, 1:].ravel()], np.c_[ids[:-1, :].ravel(), ids[1:, :].ravel()],
+                       np.c_[ids[:-1, :-1].ravel(), ids[1:, 1:].ravel()]])
+    hub = np.c_[np.full(14, K // 2 + 3), rng.choice(K // 2, 14, replace=False)]         # a node with more arcs than registers hold
+    pairs = np.unique(np.sort(np.vstack([pairs, hub]), axis=1), axis=0).astype(np.int32)
+    weights = np.clip(rng.lognormal(0, 1, len(pairs)), 1e-3, 1e3)
+    blobs = (np.hypot(*(np.indices((side, side)) - side / 2.)) // 4).astype(int).ravel() % C          # rings: label changes far from seeds
+    proba = np.full((K, C), 0.15)
+    proba[np.arange(K), blobs] = 0.55
+    proba *= rng.uniform(0.5, 1.5, proba.shape)
+    proba /= proba.sum(axis=1, keepdims=True)
+    unary = np.abs(-np.log(np.clip(proba, 0.01, 0.99)))
+    pairwise = 1.5 * (1 - np.eye(C))
+    ref, e_ref = oracle.cut_general_graph(pairs, weights, unary, pairwise, return_energy=True)
+    out, e = hip.cut_general_graph(pairs, weights, unary, pairwise, return_energy=True)
+    assert e == e_ref and np.array_equal(out, ref)
+    assert len(np.unique(ref)) > 1
+
+
 def test_graphcut_no_edges_and_errors(hip):
     unary = np.array([[3., 1., 2.], [0.5, 0.5, 0.1], [1., 1., 1.]])
     out = hip.cut_general_graph(np.zeros((0, 2), dtype=np.int32), np.zeros(0), unary, 1 - np.eye(3))
