@@ -567,7 +567,17 @@ def pipe_gray3d_slic_features_model_graphcut(
     """
     logging.info('PIPELINE Superpixels-Features-GraphCut')
     image = np.asarray(image)
-    sess = _open_volume(image)
+    sess = _open_volume(image, reuse=True)
+    try:
+        segm = _gray3d_on_session(sess, image, nb_classes, dict_features, spacing, sp_size, sp_regul, gc_regul)
+    except Exception:
+        sess.close()
+        raise
+    _release_session(sess)                  # (kept for the next volume of this shape: see superpixels._open_volume)
+    return segm
+
+
+def _gray3d_on_session(sess, image, nb_classes, dict_features, spacing, sp_size, sp_regul, gc_regul):
     _run_slic3d(sess, sp_size, sp_regul, spacing)
     logging.info('extract segments/superpixels features.')
     slic = None
@@ -598,5 +608,4 @@ def pipe_gray3d_slic_features_model_graphcut(
     else:
         graph_labels = segment_graph_cut_general(_ShapeOnly(sess.shape), proba, image, features, gc_regul, _session=sess)
         segm, _ = sess.gather(graph_labels)
-    sess.close()
     return segm
