@@ -259,6 +259,12 @@ IMSEGM_API int imsegm_image2d_run_color(imsegm_image2d *img, const void *host_pi
 IMSEGM_API int imsegm_image2d_median(imsegm_image2d *img, double *median_out);
 IMSEGM_API int imsegm_image2d_mean_gradient(imsegm_image2d *img, double *mean_out);
 
+/* 1 when the uploaded image / volume holds no NaN and no inf (uint8: always).  The pipelines replace non-finite descriptor
+ * values by zero (/root/reference/imsegm/pipelines.py:410 `features[np.isnan(features)] = 0`, descriptors.py:818), which the
+ * resident statistics cannot reproduce from non-finite pixels: the host mirror asks before it takes the resident path (a
+ * float64 sum over 10^9 voxels on the host costs more than the whole supervoxel stage). */
+IMSEGM_API int imsegm_image2d_all_finite(imsegm_image2d *img, int *all_finite_out);
+
 /* Device address of a result buffer of the session (valid until the next call that rewrites it):
  * which = 0: label map int32 H x W; 1: gathered segmentation int32 H x W; 2: gathered soft
  * segmentation float64 H x W x C.  For zero-copy hand-over to a collective library (RCCL) running on

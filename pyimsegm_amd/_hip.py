@@ -95,6 +95,7 @@ _SIGNATURES = {
     'imsegm_debug_conn_general_runs': (C.c_long, []),
     'imsegm_debug_slic_sweep_runs': (C.c_int, [_vp, _vp]),
     'imsegm_assume_bg_on_boundary': (C.c_int, [_vp, _vp, C.c_int, C.c_int, _vp, C.c_int, _ip]),
+    'imsegm_image2d_all_finite': (C.c_int, [_vp, _ip]),
     'imsegm_image2d_label_hist': (C.c_int, [_vp, _vp, C.c_int, _vp]),
     'imsegm_image2d_get_lab': (C.c_int, [_vp, _vp]),
     'imsegm_image2d_get_nearest': (C.c_int, [_vp, _vp]),
@@ -662,6 +663,12 @@ class Image2D(object):
             if ne.value <= cap:
                 return edges[:ne.value], centres, present.astype(bool)
             cap = ne.value
+
+    def all_finite(self):
+        """no NaN / inf among the uploaded pixels (``imsegm_image2d_all_finite``)"""
+        ok = C.c_int(0)
+        _check(load_library().imsegm_image2d_all_finite(self._h, C.byref(ok)))
+        return bool(ok.value)
 
     def gather(self, graph_labels=None, proba=None, to_host=True):
         """``graph_labels[slic]`` (int32 H x W) and ``proba[slic]`` (float64 H x W x C)"""

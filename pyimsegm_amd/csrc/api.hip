@@ -1406,6 +1406,27 @@ int imsegm_volume_graph(imsegm_image2d *im, int32_t *edges_out, int edge_capacit
     return 0;
 }
 
+int imsegm_image2d_all_finite(imsegm_image2d *im, int *all_finite_out)
+{
+    if (!im || !all_finite_out || bind(im->ctx)) return -1;
+    if (im->dtype < 0 || !im->img.p) {
+        set_error("all_finite needs an uploaded image or volume");
+        return -1;
+    }
+    *all_finite_out = 1;
+    if (im->dtype == IMSEGM_U8) return 0;
+    hipStream_t st = im->ctx->stream;
+    if (ensure_small(im)) return -1;
+    unsigned int *count = reinterpret_cast<unsigned int *>(im->small.as<unsigned char>() + 256);
+    const size_t values = im->is_volume ? im->n : im->n * 3;
+    if (launch_count_nonfinite(im->img.p, im->dtype, values, count, st)) return -1;
+    unsigned int bad = 0;
+    HIP_TRY(hipMemcpyAsync(&bad, count, sizeof(bad), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    *all_finite_out = bad == 0;
+    return 0;
+}
+
 int imsegm_image2d_device_ptr(imsegm_image2d *im, int which, void **ptr_out)
 {
     if (!im || !ptr_out) {

@@ -132,4 +132,23 @@ int launch_narrow_soft_f32(const double *src, float *dst, size_t n, hipStream_t 
     return 0;
 }
 
+// ---- NaN / inf in the uploaded pixels? ------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void __launch_bounds__(256) k_count_nonfinite(const T *__restrict__ src, size_t n, unsigned int *count)
+{
+    unsigned int bad = 0;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) bad += !isfinite((double)src[i]);
+    if (__syncthreads_or(bad) && bad) atomicAdd(count, bad);
+}
+
+int launch_count_nonfinite(const void *src, int dtype, size_t n, unsigned int *count_dev, hipStream_t st)
+{
+    HIP_TRY(hipMemsetAsync(count_dev, 0, sizeof(unsigned int), st));
+    const int grid = (int)std::min<size_t>(std::max<size_t>(cdiv((long)n, 2048), 1), 8192);
+    if (dtype == DT_F32) hipLaunchKernelGGL(k_count_nonfinite<float>, grid, 256, 0, st, (const float *)src, n, count_dev);
+    else if (dtype == DT_F64) hipLaunchKernelGGL(k_count_nonfinite<double>, grid, 256, 0, st, (const double *)src, n, count_dev);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
 }  // namespace imsegm

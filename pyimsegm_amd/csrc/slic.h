@@ -245,6 +245,7 @@ int launch_boundary_hist(const int32_t *labels, int W, const int rects[16], unsi
 int launch_swap_labels(int32_t *labels, size_t n, int a, int b, hipStream_t st);
 int launch_narrow_labels_u8(const int32_t *src, uint8_t *dst, size_t n, hipStream_t st);
 int launch_narrow_soft_f32(const double *src, float *dst, size_t n, hipStream_t st);
+int launch_count_nonfinite(const void *src, int dtype, size_t n, unsigned int *count_dev, hipStream_t st);
 
 // median.hip -------------------------------------------------------------------------------------
 int launch_gradient_image(const void *src, void *dst, int dtype, int S, int H, int W, int C, hipStream_t st);

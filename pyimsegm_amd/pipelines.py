@@ -582,7 +582,8 @@ def _gray3d_on_session(sess, image, nb_classes, dict_features, spacing, sp_size,
     logging.info('extract segments/superpixels features.')
     slic = None
     resident = set(dict_features) == {'color'} and set(dict_features['color']) <= {'mean', 'std', 'energy'} \
-        and (image.dtype.kind != 'f' or bool(np.isfinite(image.sum(dtype=np.float64))))    # one pass, no temporaries
+        and (image.dtype.kind != 'f' or (sess.all_finite() if image.dtype == sess.dtype
+                                          else bool(np.isfinite(image.sum(dtype=np.float64)))))    # (asked on the device)
     if resident:
         features, _ = compute_selected_features_gray3d(image, _ShapeOnly(sess.shape), dict_features, sess=sess)
     else:

@@ -126,7 +126,9 @@ class Volume3D(Image2D):
     def __init__(self, depth, height, width, ctx=None):
         self.ctx = _CTX; self.shape = (int(depth), int(height), int(width)); self.n_labels = 0
     def upload(self, volume):
-        volume = np.asarray(volume); assert volume.shape == self.shape; self.img = volume; return self
+        volume = np.asarray(volume); assert volume.shape == self.shape; self.img = volume; self.dtype = volume.dtype; return self
+    def all_finite(self):
+        return bool(np.isfinite(self.img).all())
     def graph(self):
         vertices, edges = orc.adjacency(self.labels)
         centres = np.asarray(orc.centers(self.labels), dtype=np.float64).reshape(self.n_labels, -1)

@@ -232,6 +232,51 @@ def test_pipe_gray3d(oracle):
     assert np.bincount(left.ravel()).argmax() != np.bincount(right.ravel()).argmax()
 
 
+def test_all_finite_and_session_reuse(hip):
+    """imsegm_image2d_all_finite on the uploaded pixels (float32 / float64 volumes, a float64 colour image, uint8), and the
+    pipeline on a recycled volume session: the second volume of a shape gives what a fresh session gives"""
+    from pyimsegm_amd import pipelines
+    rng = np.random.default_rng(5)
+    for dtype in (np.float32, np.float64):
+        vol = rng.random((3, 40, 50)).astype(dtype)
+        sess = hip.Volume3D(*vol.shape).upload(vol)
+        assert sess.all_finite() is True
+        for bad in (np.nan, np.inf, -np.inf):
+            v2 = vol.copy()
+            v2[2, 39, 49] = bad
+            assert sess.upload(v2).all_finite() is False
+        assert sess.upload(vol).all_finite() is True
+        sess.close()
+    img = rng.random((30, 41, 3))
+    sess = hip.Image2D(30, 41)
+    sess.upload(img)
+    assert sess.all_finite() is True
+    img[29, 40, 2] = np.nan
+    sess.upload(img)
+    assert sess.all_finite() is False
+    sess.upload(np.zeros((30, 41, 3), dtype=np.uint8))
+    assert sess.all_finite() is True
+    sess.close()
+    vols = []
+    for seed in (1, 2):
+        v = np.random.default_rng(seed).random((4, 60, 70)) / 2.
+        if seed == 1:
+            v[:, :, :35] += 0.5
+        else:
+            v[:, :25, :] += 0.5
+        vols.append(v)
+    out = []
+    for v in (vols[0], vols[1], vols[0]):                 # the third call runs on the session the second one left
+        np.random.seed(0)
+        out.append(pipelines.pipe_gray3d_slic_features_model_graphcut(v, 2, {'color': ['mean', 'std']}, spacing=(2, 1, 1), sp_size=10))
+    assert (4, 60, 70) in hip.default_context().idle_sessions
+    assert np.array_equal(out[0], out[2]) and not np.array_equal(out[0], out[1])
+    v = vols[0].copy()
+    v[0, 0, 0] = np.nan                                    # non-finite voxels: the general path (descriptors on the host)
+    np.random.seed(0)
+    assert pipelines.pipe_gray3d_slic_features_model_graphcut(v, 2, {'color': ['mean']}, spacing=(2, 1, 1), sp_size=10).shape == v.shape
+
+
 def test_volume_slic_randomised_sweep(hip, oracle):
     """seeded sweep over volume shapes, dtypes, spacings, supervoxel sizes and compactness (colour- to
     space-dominated): raw SLIC + connectivity and the measure.label relabelling, bit for bit"""
