@@ -509,9 +509,8 @@ __global__ void k_centroid_init(SlicState s, const double *__restrict__ init_yx)
 // A centroid that received no pixel is dead from now on (NaN position in skimage): empty window.
 // `drift_slot`: where the largest distance (per axis, rounded up) of a centroid from its grid node goes; the next
 // k_slic_bin only scans the grid nodes that can reach its tile (any upper bound is valid there).
-__global__ void k_centroid_finalize(SlicState s, int drift_slot)
+__device__ __forceinline__ void centroid_finalize_one(const SlicState &s, int k, int drift_slot)
 {
-    int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k == 0) *s.leftover_count = 0;
     if (k >= s.K) return;
     long long *a = s.acc + (size_t)k * 9;
@@ -536,6 +535,11 @@ __global__ void k_centroid_finalize(SlicState s, int drift_slot)
     }
 #pragma unroll
     for (int j = 0; j < 9; ++j) a[j] = 0;
+}
+
+__global__ void k_centroid_finalize(SlicState s, int drift_slot)
+{
+    centroid_finalize_one(s, blockIdx.x * blockDim.x + threadIdx.x, drift_slot);
 }
 
 constexpr int TILE_X = SLIC_TILE_X;   // one pixel column per lane

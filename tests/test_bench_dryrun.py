@@ -36,7 +36,7 @@ def test_bench_control_flow_two_ranks_under_the_launcher():
     assert d['higher_is_better'] is True and d['vs_baseline'] is None and d['value'] > 0
     assert abs(d['value'] - 2 * 9 * 192 * 192 / (d['ms_per_step'] * 9 / 1e3) / 1e6) / d['value'] < 1e-3      # whole-job aggregate
     assert set(d['roofline']) >= {'bound', 'achieved', 'peak', 'unit', 'frac', 'traffic'}
-    assert d['config']['images_in_flight_per_gpu'] == 3 and 'gathered in rank 0' in d['config']['parallelism']
+    assert d['config']['images_in_flight_per_gpu'] == 4 and 'gathered in rank 0' in d['config']['parallelism']
     assert d['ms_per_step_incl_fill_drain'] > 0 and 'steady state' in d['config']['timing']
     assert 'cpu_baseline' not in d                     # rank 0 at N = 1 only
 
