@@ -405,27 +405,46 @@ __global__ void k_vol_centroid_init_f32(VolState s)
     vol_bbox_reset(s.bbox + (size_t)k * 6);
 }
 
+// Round 3.  (1) The four waves of a workgroup (64 x 16 voxels of one slice = the cross-section of a brick) scan the brick's list
+// ONCE, together, and stage the records of the centroids whose window meets the cross-section in LDS; before, every wave scanned
+// the whole list (~230 windows of 24 bytes) for itself.  (2) Each wave then walks the staged candidates in ascending order of
+// their lower bound over ITS strip (64 x 4) by repeated wave minima, and stops at the first bound above the worst best distance
+// of the strip (`wave_worst`): every candidate behind it is at least as far.  ~150 windows meet a strip at sp_size 15, ~30 have a
+// bound below the final worst distance; before, the list order decided how many were evaluated in full.  The pruning is exact as
+// before: a candidate is skipped only when its bound EXCEEDS what every voxel of the strip already has (float32 operations, all
+// monotone; ties go on being evaluated).  (3) The bounding boxes of the segments: the distinct labels of a strip are enumerated
+// with ballots (a strip is 4 rows: row masks give the x and y extent), parked one per lane, and the lanes compare with / update
+// the boxes in ONE round of loads instead of a serial load-compare-atomic chain per label.
+struct VolRec {
+    float cz, cy, cx, cv;
+    int wy0, wy1, wx0, wx1;
+};
+constexpr int VLIST32 = 512;          // staged candidates per batch (a batch is walked when fewer than 256 slots are left)
+
 template <bool TRACK>
 __global__ void __launch_bounds__(256)
 k_vol_assign_f32(VolState s, const float *__restrict__ vol, int32_t *__restrict__ labels)
 {
-    __shared__ int list[4][VLIST];
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    __shared__ int list[VLIST32];
+    __shared__ VolRec rec[VLIST32];
+    __shared__ int wave_base[4];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int rows_per_block = 4 * VROWS;
     const int yb = cdiv(s.H, rows_per_block);
     const int z = blockIdx.y / yb;
-    const int y0 = (blockIdx.y % yb) * rows_per_block + wave * VROWS;
+    const int Y0 = (blockIdx.y % yb) * rows_per_block, Y1 = min(Y0 + rows_per_block, s.H);
+    const int y0 = Y0 + wave * VROWS;
     const int x = blockIdx.x * 64 + lane;
     const int x0w = blockIdx.x * 64, x1w = min(x0w + 64, s.W);
-    if (y0 >= s.H) return;
+    const bool alive = y0 < s.H;                              // (a wave below the volume takes part in the barriers only)
     const int y1w = min(y0 + VROWS, s.H);
     const bool xin = x < s.W;
     float pv[VROWS], best_d[VROWS];
     int best_k[VROWS];
 #pragma unroll
     for (int r = 0; r < VROWS; ++r) {
-        bool ok = xin && (y0 + r) < s.H;
+        bool ok = alive && xin && (y0 + r) < s.H;
         pv[r] = vol[ok ? ((size_t)z * s.H + y0 + r) * s.W + x : 0];
         best_d[r] = INFINITY;
         best_k[r] = -1;
@@ -433,72 +452,121 @@ k_vol_assign_f32(VolState s, const float *__restrict__ vol, int32_t *__restrict_
     const float fz = (float)z, fx = (float)x;
     const float sz = (float)s.sz, sy = (float)s.sy, sx = (float)s.sx;
     const float sw = (float)s.spatial_weight;              // = (float)(1 / ((double)step * (double)step))
-    int count = 0;
+    int count = 0;                                         // (uniform over the workgroup)
     float wave_worst = INFINITY;
-    int since_refresh = 0;
-    const int brick = ((z / VOL_BZ) * s.nby + (y0 / VOL_BY)) * s.nbx + blockIdx.x;
+    const int brick = ((z / VOL_BZ) * s.nby + (Y0 / VOL_BY)) * s.nbx + blockIdx.x;
     const int bcount = s.brick_count[brick];
     const bool whole = bcount > s.brick_cap;
     const int *__restrict__ blist = s.brick_list + (size_t)brick * s.brick_cap;
     const int nscan = whole ? s.K : bcount;
-    const int nblk = cdiv(nscan, 64);
+    const int nblk = cdiv(nscan, 256);
+    constexpr int PER = VLIST32 / 64;
     for (int b = 0; b < nblk; ++b) {
-        const int i = b * 64 + lane;
+        const int i = b * 256 + tid;
         int k = 0;
         bool hit = false;
         if (i < nscan) {
             k = whole ? i : blist[i];
             const int *w = s.win + (size_t)k * 6;
-            hit = z >= w[0] && z < w[1] && w[2] < y1w && w[3] > y0 && w[4] < x1w && w[5] > x0w;
+            hit = z >= w[0] && z < w[1] && w[2] < Y1 && w[3] > Y0 && w[4] < x1w && w[5] > x0w;
         }
-        unsigned long long m = __ballot(hit);
-        if (hit) list[wave][count + __popcll(m & ((1ULL << lane) - 1ULL))] = k;
-        count += __popcll(m);
-        if (count < VLIST - 64 && b + 1 < nblk) continue;
-        for (int c = 0; c < count; ++c) {
-            const int ck = list[wave][c];
+        const unsigned long long m = __ballot(hit);
+        if (lane == 0) wave_base[wave] = __popcll(m);
+        __syncthreads();
+        int base = count;
+        for (int w2 = 0; w2 < wave; ++w2) base += wave_base[w2];
+        const int added = wave_base[0] + wave_base[1] + wave_base[2] + wave_base[3];
+        if (hit) list[base + __popcll(m & ((1ULL << lane) - 1ULL))] = k;
+        count += added;
+        __syncthreads();                                     // (the list is complete; wave_base may be rewritten)
+        if (count <= VLIST32 - 256 && b + 1 < nblk) continue;
+        // ---- records of the batch into LDS
+        for (int c = tid; c < count; c += 256) {
+            const int ck = list[c];
             const int *w = s.win + (size_t)ck * 6;
-            const float cz = s.cen32[(size_t)ck * 4], cy = s.cen32[(size_t)ck * 4 + 1], cx = s.cen32[(size_t)ck * 4 + 2];
-            const float tz = sz * (cz - fz);
-            const float dz = tz * tz;
-            {
-                // exact pruning as in the fp64 kernel: every float32 operation below is monotone and the colour term >= 0
-                const float yn = fminf(fmaxf(cy, (float)y0), (float)(y1w - 1));
-                const float xn = fminf(fmaxf(cx, (float)x0w), (float)(x1w - 1));
-                const float tyl = sy * (cy - yn), txl = sx * (cx - xn);
-                const float lb = ((dz + tyl * tyl) + txl * txl) * sw;
-                if (lb > wave_worst) continue;                 // wave-uniform
-            }
-            const float cv = s.cen32[(size_t)ck * 4 + 3];
-            const int wy0 = w[2], wy1 = w[3];
-            const bool inx = x >= w[4] && x < w[5];
-            const float tx = sx * (cx - fx);
-            const float dx2 = tx * tx;
+            const float4 cen = *reinterpret_cast<const float4 *>(s.cen32 + (size_t)ck * 4);
+            VolRec rc;
+            rc.cz = cen.x; rc.cy = cen.y; rc.cx = cen.z; rc.cv = cen.w;
+            rc.wy0 = w[2]; rc.wy1 = w[3]; rc.wx0 = w[4]; rc.wx1 = w[5];
+            rec[c] = rc;
+        }
+        __syncthreads();
+        if (alive) {
+            // bounds over this wave's strip; a window that misses the strip's rows is out
+            float lbl[PER];
 #pragma unroll
-            for (int r = 0; r < VROWS; ++r) {
-                const int y = y0 + r;
-                if (y < wy0 || y >= wy1) continue;
-                const float ty = sy * (cy - (float)y);
-                const float dy = ty * ty;
-                float d = ((dz + dy) + dx2) * sw;
-                const float t = pv[r] - cv;
-                d = d + t * t;
-                if (inx && (best_d[r] > d || (best_d[r] == d && ck < best_k[r]))) {
-                    best_d[r] = d;
-                    best_k[r] = ck;
+            for (int j = 0; j < PER; ++j) {
+                const int c = lane + 64 * j;
+                lbl[j] = INFINITY;
+                if (c < count) {
+                    const VolRec rc = rec[c];
+                    if (rc.wy0 < y1w && rc.wy1 > y0) {
+                        const float tz = sz * (rc.cz - fz);
+                        const float dz = tz * tz;
+                        const float yn = fminf(fmaxf(rc.cy, (float)y0), (float)(y1w - 1));
+                        const float xn = fminf(fmaxf(rc.cx, (float)x0w), (float)(x1w - 1));
+                        const float tyl = sy * (rc.cy - yn), txl = sx * (rc.cx - xn);
+                        lbl[j] = ((dz + tyl * tyl) + txl * txl) * sw;
+                    }
                 }
             }
-            if (++since_refresh == 8) {
-                since_refresh = 0;
-                float m2 = 0.f;
+            int since_refresh = 0;
+            while (true) {
+                float mine = lbl[0];
 #pragma unroll
-                for (int r = 0; r < VROWS; ++r)
-                    if (xin && (y0 + r) < s.H) m2 = fmaxf(m2, best_d[r]);
-                wave_worst = (float)wave_max_f64((double)m2);
+                for (int j = 1; j < PER; ++j) mine = fminf(mine, lbl[j]);
+                float wm = mine;
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) wm = fminf(wm, __shfl_xor(wm, off, 64));
+                if (!(wm <= wave_worst) || wm == INFINITY) break;  // (+inf: nothing left in the batch)
+                const unsigned long long own = __ballot(mine == wm);
+                const int src = __ffsll((long long)own) - 1;
+                int jsel = 0;
+#pragma unroll
+                for (int j = PER - 1; j >= 0; --j)
+                    if (lbl[j] == wm) jsel = j;
+                jsel = __builtin_amdgcn_readlane(jsel, src);
+#pragma unroll
+                for (int j = 0; j < PER; ++j)
+                    if (lane == src && j == jsel) lbl[j] = INFINITY;
+                const int c = src + 64 * jsel;
+                const int ck = list[c];
+                const VolRec rc = rec[c];
+                const float tz = sz * (rc.cz - fz);
+                const float dz = tz * tz;
+                const bool inx = x >= rc.wx0 && x < rc.wx1;
+                const float tx = sx * (rc.cx - fx);
+                const float dx2 = tx * tx;
+#pragma unroll
+                for (int r = 0; r < VROWS; ++r) {
+                    const int y = y0 + r;
+                    if (y < rc.wy0 || y >= rc.wy1) continue;
+                    const float ty = sy * (rc.cy - (float)y);
+                    const float dy = ty * ty;
+                    float d = ((dz + dy) + dx2) * sw;
+                    const float t = pv[r] - rc.cv;
+                    d = d + t * t;
+                    if (inx && (best_d[r] > d || (best_d[r] == d && ck < best_k[r]))) {
+                        best_d[r] = d;
+                        best_k[r] = ck;
+                    }
+                }
+                if (++since_refresh == 2) {
+                    since_refresh = 0;
+                    float m2 = 0.f;
+#pragma unroll
+                    for (int r = 0; r < VROWS; ++r)
+                        if (xin && (y0 + r) < s.H) m2 = fmaxf(m2, best_d[r]);
+#pragma unroll
+                    for (int off = 32; off > 0; off >>= 1) m2 = fmaxf(m2, __shfl_xor(m2, off, 64));
+                    wave_worst = m2;
+                }
             }
         }
         count = 0;
+        __syncthreads();                                     // (everybody is done with this batch's list and records)
     }
+    if (!alive) return;
     unsigned pending = 0;
 #pragma unroll
     for (int r = 0; r < VROWS; ++r) {
@@ -511,42 +579,56 @@ k_vol_assign_f32(VolState s, const float *__restrict__ vol, int32_t *__restrict_
     if (!TRACK) return;
     // bounding box of every segment's voxels (incl. the ones that kept an old label): the region the
     // order-preserving update of that centroid has to walk
+    int my_k = -1, my_ylo = 0, my_yhi = 0, my_xlo = 0, my_xhi = 0, n_distinct = 0;
     while (true) {
         int first = -1;
 #pragma unroll
         for (int r = VROWS - 1; r >= 0; --r)
             if (pending & (1u << r)) first = best_k[r];
-        unsigned long long vote = __ballot(first >= 0);
+        const unsigned long long vote = __ballot(first >= 0);
         if (!vote) break;
-        const int k = __shfl(first, __ffsll((long long)vote) - 1, 64);
-        int ylo = 0x7fffffff, yhi = -1;
-        bool any = false;
+        const int k = __builtin_amdgcn_readlane(first, __ffsll((long long)vote) - 1);
+        unsigned long long rows[VROWS], any = 0;
 #pragma unroll
         for (int r = 0; r < VROWS; ++r) {
-            if ((pending & (1u << r)) && best_k[r] == k) {
-                ylo = min(ylo, y0 + r);
-                yhi = max(yhi, y0 + r);
-                any = true;
-                pending &= ~(1u << r);
-            }
+            const bool mine = (pending & (1u << r)) && best_k[r] == k;
+            rows[r] = __ballot(mine);
+            any |= rows[r];
+            if (mine) pending &= ~(1u << r);
         }
-        int xlo = any ? x : 0x7fffffff, xhi = any ? x : -1;
+        int ylo = 0, yhi = 0;
 #pragma unroll
-        for (int off = 32; off > 0; off >>= 1) {
-            ylo = min(ylo, __shfl_xor(ylo, off, 64));
-            yhi = max(yhi, __shfl_xor(yhi, off, 64));
-            xlo = min(xlo, __shfl_xor(xlo, off, 64));
-            xhi = max(xhi, __shfl_xor(xhi, off, 64));
+        for (int r = VROWS - 1; r >= 0; --r)
+            if (rows[r]) ylo = y0 + r;
+#pragma unroll
+        for (int r = 0; r < VROWS; ++r)
+            if (rows[r]) yhi = y0 + r;
+        const int xlo = x0w + __ffsll((long long)any) - 1, xhi = x0w + 63 - __clzll((long long)any);
+        if (n_distinct == 64) {
+            // (more distinct labels than lanes in one 64 x 4 strip: flush what is parked -- never seen, kept for safety)
+            if (my_k >= 0) {
+                int *bb = s.bbox + (size_t)my_k * 6;
+                atomicMin(&bb[0], z); atomicMax(&bb[1], z);
+                atomicMin(&bb[2], my_ylo); atomicMax(&bb[3], my_yhi);
+                atomicMin(&bb[4], my_xlo); atomicMax(&bb[5], my_xhi);
+            }
+            my_k = -1;
+            n_distinct = 0;
         }
-        if (lane == 0) {
-            int *b = s.bbox + (size_t)k * 6;
-            if (b[0] > z) atomicMin(&b[0], z);
-            if (b[1] < z) atomicMax(&b[1], z);
-            if (b[2] > ylo) atomicMin(&b[2], ylo);
-            if (b[3] < yhi) atomicMax(&b[3], yhi);
-            if (b[4] > xlo) atomicMin(&b[4], xlo);
-            if (b[5] < xhi) atomicMax(&b[5], xhi);
+        if (lane == n_distinct) {
+            my_k = k; my_ylo = ylo; my_yhi = yhi; my_xlo = xlo; my_xhi = xhi;
         }
+        ++n_distinct;
+    }
+    if (my_k >= 0) {
+        int *bb = s.bbox + (size_t)my_k * 6;
+        const int b0 = bb[0], b1 = bb[1], b2 = bb[2], b3 = bb[3], b4 = bb[4], b5 = bb[5];
+        if (b0 > z) atomicMin(&bb[0], z);
+        if (b1 < z) atomicMax(&bb[1], z);
+        if (b2 > my_ylo) atomicMin(&bb[2], my_ylo);
+        if (b3 < my_yhi) atomicMax(&bb[3], my_yhi);
+        if (b4 > my_xlo) atomicMin(&bb[4], my_xlo);
+        if (b5 < my_xhi) atomicMax(&bb[5], my_xhi);
     }
 }
 
