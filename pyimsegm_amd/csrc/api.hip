@@ -1272,7 +1272,12 @@ int imsegm_volume_slic(imsegm_image2d *im, int n_segments, double compactness, c
     }
     int sp_all = ctx->begin(PG_SLIC);
     if (f32) {
-        if (launch_vol_slic_f32(s, im->labB.as<float>(), im->nearest.as<int32_t>(), max_iter, st)) return -1;
+        ProfHook hook;
+        if (ctx->profile) {
+            hook.user = ctx;
+            hook.pair = [](void *u, int g, hipEvent_t *a, hipEvent_t *b) { static_cast<imsegm_ctx *>(u)->pair(g, a, b); };
+        }
+        if (launch_vol_slic_f32(s, im->labB.as<float>(), im->nearest.as<int32_t>(), max_iter, st, ctx->profile ? &hook : nullptr)) return -1;
     } else if (launch_vol_slic(s, im->labB.as<double>(), im->nearest.as<int32_t>(), max_iter, st)) {
         return -1;
     }

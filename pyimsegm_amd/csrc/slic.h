@@ -170,7 +170,7 @@ int launch_vol_slic(VolState s, const double *vol, int32_t *labels, int max_iter
 // float32 volume: result of the pre-processing is a float32 plane in bufB
 int launch_vol_preprocess_f32(const float *src, int D, int H, int W, const Taps &tz, const Taps &ty, const Taps &tx, double ratio,
                               double *bufA, double *bufB, hipStream_t st);
-int launch_vol_slic_f32(VolState s, const float *vol, int32_t *labels, int max_iter, hipStream_t st);
+int launch_vol_slic_f32(VolState s, const float *vol, int32_t *labels, int max_iter, hipStream_t st, const ProfHook *prof = nullptr);
 int launch_label_cc(int32_t *labels_inout, int D, int H, int W, int32_t *parent, int32_t *newlabel, int32_t *blocksum,
                     int32_t *total_dev, hipStream_t st);
 int launch_vol_adjacency(const int32_t *labels, int D, int H, int W, int K, int words, uint32_t *bitmap, long long *cacc,

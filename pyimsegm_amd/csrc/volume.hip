@@ -8,10 +8,11 @@
 // Arithmetic contract of the assignment: identical to oracle orc_slic_iterate (fp64, operation order
 // of _slic.pyx with spacing):  d = ((sz*(cz-z))^2 + (sy*(cy-y))^2 + (sx*(cx-x))^2) * (1/step^2) + (v - cv)^2.
 //
-// First version: functional and exact, sized for volumes of a few 10^7 voxels -- every wave scans the
-// whole centroid table (O(waves * K)); the cell-list binning needed for the 10^9-voxel config is
-// listed in DESIGN.md section 7.
+// Candidate search: the centroids enter their index into the lists of the 64 x 16 x 16 bricks their search window meets
+// (k_vol_scatter); an assignment workgroup -- one brick cross-section -- reads the list of its brick only.  Sized for the
+// 10^9 voxels / 3 * 10^5 supervoxels of config 5; a float32 volume runs in float32 from end to end, as scikit-image 0.18 does.
 #include "slic.h"
+#include <hip/hip_ext.h>
 
 namespace imsegm {
 
@@ -684,7 +685,7 @@ k_vol_update_f32(VolState s, const float *__restrict__ vol, const int32_t *__res
     }
 }
 
-int launch_vol_slic_f32(VolState s, const float *vol, int32_t *labels, int max_iter, hipStream_t st)
+int launch_vol_slic_f32(VolState s, const float *vol, int32_t *labels, int max_iter, hipStream_t st, const ProfHook *prof)
 {
     size_t n = (size_t)s.D * s.H * s.W;
     HIP_TRY(hipMemsetAsync(labels, 0xff, n * sizeof(int32_t), st));
@@ -694,11 +695,16 @@ int launch_vol_slic_f32(VolState s, const float *vol, int32_t *labels, int max_i
     for (int it = 0; it < max_iter; ++it) {
         HIP_TRY(hipMemsetAsync(s.brick_count, 0, n_bricks * sizeof(int), st));
         hipLaunchKernelGGL(k_vol_scatter, cdiv(s.K, 256), 256, 0, st, s);
+        // (when profiling: the event pair rides on the dispatch of the assignment kernel, group 0 = "slic_assign")
+        hipEvent_t ev_a = nullptr, ev_b = nullptr;
+        if (prof && prof->pair) prof->pair(prof->user, 0, &ev_a, &ev_b);
         if (it + 1 < max_iter) {
-            hipLaunchKernelGGL(k_vol_assign_f32<true>, grid, 256, 0, st, s, vol, labels);
+            if (ev_a) hipExtLaunchKernelGGL(k_vol_assign_f32<true>, grid, dim3(256), 0, st, ev_a, ev_b, 0, s, vol, labels);
+            else hipLaunchKernelGGL(k_vol_assign_f32<true>, grid, 256, 0, st, s, vol, labels);
             hipLaunchKernelGGL(k_vol_update_f32, cdiv(s.K, 4), 256, 0, st, s, vol, labels);
         } else {
-            hipLaunchKernelGGL(k_vol_assign_f32<false>, grid, 256, 0, st, s, vol, labels);
+            if (ev_a) hipExtLaunchKernelGGL(k_vol_assign_f32<false>, grid, dim3(256), 0, st, ev_a, ev_b, 0, s, vol, labels);
+            else hipLaunchKernelGGL(k_vol_assign_f32<false>, grid, 256, 0, st, s, vol, labels);
         }
     }
     HIP_TRY(hipGetLastError());
