@@ -739,6 +739,28 @@ def bench_color2d(args, group, cfg, quick=False):
             t_b = time.perf_counter()
             res.close()
             extras['soft_d2h_ms'] = round(((t_b - t_a) - (t_a - t)) * 1e3, 3)
+            # what the host link allows: the bytes of one step (image up, int32 segmentation down) copied back to back on one
+            # stream -- on the boxes of this pool the two directions share ~55 GB/s (tools/xfer_concurrent.py: more threads or
+            # copying both ways at once moves no more), so this is a ceiling of the host -> host rate, whatever the kernels do
+            try:
+                import ctypes as C
+                dev = C.c_void_p()
+                nbytes_up, nbytes_down = images[0].nbytes, height * width * 4
+                _hip._check(_hip.load_library().imsegm_device_alloc(ctx.device if hasattr(ctx, 'device') else 0,
+                                                                   max(nbytes_up, nbytes_down) + 256, C.byref(dev)))
+                down = _hip.pinned_empty((height, width), np.int32)
+                for rep in range(12):
+                    if rep == 2:
+                        t = time.perf_counter()
+                    ctx.copy(dev.value, images[0].ctypes.data, nbytes_up)
+                    ctx.copy(down.ctypes.data, dev.value, nbytes_down)
+                link_s = (time.perf_counter() - t) / 10
+                _hip.load_library().imsegm_device_free(dev)
+                extras['host_link'] = {'bytes_per_step': nbytes_up + nbytes_down, 'gb_per_s': round((nbytes_up + nbytes_down) / link_s / 1e9, 1),
+                                       'ceiling_mpixels_per_s': round(npx_step / link_s / 1e6, 1),
+                                       'note': 'H2D of the image + D2H of the int32 segmentation, back to back on one stream'}
+            except Exception as ex:
+                extras['host_link'] = {'error': repr(ex)}
 
     # ---- kernel-level figures: un-overlapped pass on one stream with HIP events around every stage
     prof_steps = 3 if cfg == 3 else 5
