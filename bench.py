@@ -664,6 +664,22 @@ def bench_color2d(args, group, cfg, quick=False):
 
     # ---- every gathered label map against the reference's run (N > 1: the first multi-GPU run validates the RCCL gather)
     verdict = {}
+    if cfg != 4 and group.distributed:
+        # configs 2 / 3 at N > 1: every rank works on its own image (seed 1 + rank), so what rank 0 received is checked
+        # against the CRC of the map the SENDING rank holds in its own host memory (host control plane): the device
+        # gather is validated end to end by the first multi-GPU run
+        own = []
+
+        def step_with_crc(state, index, stage):
+            own.append(crc32(one_image(images[0], stage=stage, k=0)))
+        maps = runner.verify_round(make_state(), step_with_crc)
+        sent = group.gather_objects(own[-1] if own else None)
+        if rank == 0:
+            got = [crc32(np.ascontiguousarray(m[:height * width * 4]).view(np.int32).reshape(height, width)) for m in maps]
+            verdict['gathered_maps_checked'] = world
+            verdict['gathered_maps_equal_senders_own'] = bool(got == list(sent))
+            if got != list(sent):
+                verdict['gathered_maps_different_ranks'] = [r for r in range(world) if got[r] != sent[r]][:16]
     if cfg == 4 and golden4 is not None:
         want = {int(s): int(c) for s, c in zip(golden4['seeds'], golden4['segm_crc'])}
         if group.distributed:
@@ -835,6 +851,8 @@ def bench_color2d(args, group, cfg, quick=False):
                                   % (inflight, group.backend) if group.distributed else ''),
             },
             'ms_per_step_incl_fill_drain': round(cold * 1e3, 4),
+            'gather_backend': group.backend if group.distributed else None,
+            'rccl_error': getattr(group, 'rccl_error', None),
             'roofline': roofline,
             'stage_ms_per_step': {g: round(ms / prof_steps, 4) for g, (ms, n) in stage_ms.items()},
             'stage_note': 'stage and roofline figures: separate pass of %d un-overlapped host-to-host images on one stream' % prof_steps,

@@ -39,6 +39,7 @@ def test_bench_control_flow_two_ranks_under_the_launcher():
     assert d['config']['images_in_flight_per_gpu'] == 4 and 'gathered in rank 0' in d['config']['parallelism']
     assert d['ms_per_step_incl_fill_drain'] > 0 and 'steady state' in d['config']['timing']
     assert 'cpu_baseline' not in d                     # rank 0 at N = 1 only
+    assert d['gathered_maps_checked'] == 2 and d['gathered_maps_equal_senders_own'] is True      # what rank 0 received = what each rank holds
 
 
 def test_bench_batch_config_two_self_spawned_ranks():
