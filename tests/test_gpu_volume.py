@@ -45,6 +45,10 @@ VOLUMES = [
     ('aniso_x_u8', (50, 60, 11), np.uint8, 10, 0.3, (1, 1, 5)),
     ('ragged_u16', (7, 33, 129), np.uint16, 9, 0.25, (3, 1, 1)),
     ('one_slice', (1, 50, 60), np.float64, 8, 0.2, (1, 1, 1)),
+    # supervoxels of edge 3: ~900 search windows meet one 64 x 16 cross-section, the float32 assignment walks them in several
+    # batches of its 512-entry staging list; ragged in every axis
+    ('many_candidates_f32', (9, 45, 150), np.float32, 3, 0.3, (1, 1, 1)),
+    ('many_candidates_aniso_f32', (6, 37, 131), np.float32, 4, 0.2, (2, 1, 1)),
 ]
 
 
