@@ -1155,6 +1155,7 @@ int imsegm_volume_upload(imsegm_image2d *im, const void *host_voxels, int dtype,
     im->vol_off = slic_offset;
     im->vol_scale = slic_scale;
     im->tex_ready = false;
+    im->feat_mask = 0;            // (a recycled session: the feature table of the previous volume is not this one's)
     return 0;
 }
 

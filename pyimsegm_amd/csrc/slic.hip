@@ -250,6 +250,7 @@ int launch_absmax_f64(const double *src, size_t n, double *out_dev, hipStream_t 
 
 __device__ __forceinline__ int reflect_idx(int i, int n)
 {
+    if ((unsigned)i < (unsigned)n) return i;       // (inside: all but the pixels of the border tiles; the modulo below is ~30 instructions)
     if (n == 1) return 0;
     int p = 2 * n;
     i %= p;

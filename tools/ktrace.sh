@@ -4,7 +4,7 @@ cd /tmp && export TMPDIR=/tmp
 REPO=${GRAFT_REPO_ROOT:-/root/repo}
 out=$REPO/gpurun_out/ktrace
 rm -rf $out
-rocprofv3 --kernel-trace --output-format csv -d $out -o p -- python $REPO/bench.py --steps 4 --warmup 1 --no-cpu-baseline --inflight ${INFLIGHT:-1} > $out.log 2>&1
+rocprofv3 --kernel-trace --output-format csv -d $out -o p -- python $REPO/bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-other-configs --inflight ${INFLIGHT:-1} > $out.log 2>&1
 python - "$out/p_kernel_trace.csv" <<'PY'
 import csv, sys, collections, os
 acc = collections.defaultdict(list)
