@@ -612,7 +612,9 @@ def bench_color2d(args, group, cfg, quick=False):
         images = [voronoi_image(height, width, seed=seeds[0])]
         features = FEATURES_SET_COLOR if cfg == 2 else FEATURES_LM
     images = [host_image(im, args.pinned_input) for im in images]
-    steps = args.steps if (args.steps is not None and not quick) else ({3: 3, 4: 20}[cfg] if quick else {2: 100, 3: 5, 4: 40}[cfg])
+    # (whole multiples of the images in flight: completions come in groups of that size, and a window that cuts a group in two
+    # reads too fast -- config 3 with 3 steps and 2 in flight showed 40 ms per image where 8 steps show 58)
+    steps = args.steps if (args.steps is not None and not quick) else ({3: 8, 4: 24}[cfg] if quick else {2: 100, 3: 12, 4: 48}[cfg])
     warmup = args.warmup if (args.warmup is not None and not quick) else {2: 3, 3: 1, 4: 3}[cfg]
     inflight = args.inflight if args.inflight > 0 else {2: 4, 3: 2, 4: 12}[cfg]
     npx_step = per_step * height * width
