@@ -1,0 +1,24 @@
+"""host-side profile of one config-3 image (full LM bank) through segment_color2d_slic_features_model_graphcut (cProfile)"""
+import cProfile, pstats, sys, os, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import bench
+from pyimsegm_amd import pipelines as pipe
+from pyimsegm_amd.graph_cuts import estim_class_model
+from pyimsegm_amd.utilities.synthetic import voronoi_image
+img = voronoi_image(2048, 2048, seed=1)
+feats = bench.FEATURES_LM
+res0 = pipe._ResidentImage(img, feats, bench.SP_SIZE, bench.SP_REGUL)
+np.random.seed(0)
+model = estim_class_model(res0.features, bench.NB_CLASSES, 'GMM', None, True)
+res0.close()
+def step():
+    res = pipe._ResidentImage(img, feats, bench.SP_SIZE, bench.SP_REGUL, reuse=True, features_to_host=True)
+    try:
+        return res.segment(None, bench.GC_REGUL, bench.EDGE_TYPE, to_host=True, want_soft=False, model=model)[0]
+    finally:
+        res.close()
+for _ in range(2): step()
+t = time.perf_counter(); step(); print('one image %.1f ms' % ((time.perf_counter() - t) * 1e3))
+pr = cProfile.Profile(); pr.enable(); step(); pr.disable()
+pstats.Stats(pr).sort_stats('tottime').print_stats(22)
