@@ -153,110 +153,164 @@ __global__ void __launch_bounds__(256) k_vol_scatter(VolState s)
 }
 
 // ---- assignment -----------------------------------------------------------------------------------------
-// One wave = 64 consecutive x, VROWS rows of one z slice.  The wave scans the candidate list of its brick
-// (or, if that list overflowed, the whole centroid table), keeps the windows that meet its voxels in an
-// LDS list (ballot compaction) and evaluates the list in chunks; equal distances go to the lower centroid
-// index, which is what the ascending scan with a strict '>' of _slic.pyx yields.
+// One wave = 64 consecutive x, VROWS rows of one z slice; a workgroup = four such strips = the cross-section of a brick.
+// The workgroup scans the candidate list of its brick (or, if that list overflowed, the whole centroid table) once,
+// keeps the windows that meet the cross-section in an LDS list (ballot compaction), and every wave evaluates the
+// list for its strip; equal distances go to the lower centroid index, which is what the ascending scan with a
+// strict '>' of _slic.pyx yields (the order of evaluation is free: the comparison carries the index).
 constexpr int VROWS = 4;
-constexpr int VLIST = 256;
+
+// (round 3: like the float32 kernel below -- the four waves of a workgroup scan the brick's list once, together, stage the records of
+// the windows that meet the 64 x 16 cross-section in LDS, and each wave walks them in ascending order of their lower bound over
+// its strip, stopping at the first bound above the worst best distance of the strip)
+struct VolRec64 {
+    double cz, cy, cx, cv;
+    int wy0, wy1, wx0, wx1;
+};
+constexpr int VLIST64 = 512;
 
 template <bool ACCUM>
 __global__ void __launch_bounds__(256)
 k_vol_assign(VolState s, const double *__restrict__ vol, int32_t *__restrict__ labels)
 {
-    __shared__ int list[4][VLIST];
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    __shared__ int list[VLIST64];
+    __shared__ VolRec64 rec[VLIST64];
+    __shared__ int wave_base[4];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int rows_per_block = 4 * VROWS;
     const int yb = cdiv(s.H, rows_per_block);
     const int z = blockIdx.y / yb;
-    const int y0 = (blockIdx.y % yb) * rows_per_block + wave * VROWS;
+    const int Y0 = (blockIdx.y % yb) * rows_per_block, Y1 = min(Y0 + rows_per_block, s.H);
+    const int y0 = Y0 + wave * VROWS;
     const int x = blockIdx.x * 64 + lane;
     const int x0w = blockIdx.x * 64, x1w = min(x0w + 64, s.W);
-    if (y0 >= s.H) return;
+    const bool alive = y0 < s.H;                              // (a wave below the volume takes part in the barriers only)
     const int y1w = min(y0 + VROWS, s.H);
     const bool xin = x < s.W;
     double pv[VROWS], best_d[VROWS];
     int best_k[VROWS];
 #pragma unroll
     for (int r = 0; r < VROWS; ++r) {
-        bool ok = xin && (y0 + r) < s.H;
+        bool ok = alive && xin && (y0 + r) < s.H;
         pv[r] = vol[ok ? ((size_t)z * s.H + y0 + r) * s.W + x : 0];
         best_d[r] = DBL_MAX;
         best_k[r] = -1;
     }
     const double fz = (double)z, fx = (double)x;
-    int count = 0;
+    int count = 0;                                         // (uniform over the workgroup)
     double wave_worst = DBL_MAX;          // >= the current best distance of every voxel of this wave
-    int since_refresh = 0;
     static_assert(VOL_BX == 64 && VOL_BY == 4 * VROWS, "a workgroup lies inside one brick");
-    const int brick = ((z / VOL_BZ) * s.nby + (y0 / VOL_BY)) * s.nbx + blockIdx.x;
+    const int brick = ((z / VOL_BZ) * s.nby + (Y0 / VOL_BY)) * s.nbx + blockIdx.x;
     const int bcount = s.brick_count[brick];
     const bool whole = bcount > s.brick_cap;                   // list overflow: scan every centroid
     const int *__restrict__ blist = s.brick_list + (size_t)brick * s.brick_cap;
     const int nscan = whole ? s.K : bcount;
-    const int nblk = cdiv(nscan, 64);
+    const int nblk = cdiv(nscan, 256);
+    constexpr int PER = VLIST64 / 64;
     for (int b = 0; b < nblk; ++b) {
-        // scan 64 windows
-        const int i = b * 64 + lane;
+        const int i = b * 256 + tid;
         int k = 0;
         bool hit = false;
         if (i < nscan) {
             k = whole ? i : blist[i];
             const int *w = s.win + (size_t)k * 6;
-            hit = z >= w[0] && z < w[1] && w[2] < y1w && w[3] > y0 && w[4] < x1w && w[5] > x0w;
+            hit = z >= w[0] && z < w[1] && w[2] < Y1 && w[3] > Y0 && w[4] < x1w && w[5] > x0w;
         }
-        unsigned long long m = __ballot(hit);
-        if (hit) list[wave][count + __popcll(m & ((1ULL << lane) - 1ULL))] = k;
-        count += __popcll(m);
-        if (count < VLIST - 64 && b + 1 < nblk) continue;
-        // evaluate the collected candidates.  Exact pruning: the spatial part of the distance to the nearest
-        // point of the strip is a lower bound of the distance of every voxel of the strip (every operation is
-        // monotone in IEEE arithmetic and the colour term is >= 0); a candidate whose bound exceeds the worst
-        // current best of the wave can neither win nor tie.
-        for (int c = 0; c < count; ++c) {
-            const int ck = list[wave][c];
+        const unsigned long long m = __ballot(hit);
+        if (lane == 0) wave_base[wave] = __popcll(m);
+        __syncthreads();
+        int base = count;
+        for (int w2 = 0; w2 < wave; ++w2) base += wave_base[w2];
+        const int added = wave_base[0] + wave_base[1] + wave_base[2] + wave_base[3];
+        if (hit) list[base + __popcll(m & ((1ULL << lane) - 1ULL))] = k;
+        count += added;
+        __syncthreads();
+        if (count <= VLIST64 - 256 && b + 1 < nblk) continue;
+        for (int c = tid; c < count; c += 256) {
+            const int ck = list[c];
             const int *w = s.win + (size_t)ck * 6;
-            const double cz = s.cen[(size_t)ck * 4], cy = s.cen[(size_t)ck * 4 + 1], cx = s.cen[(size_t)ck * 4 + 2];
-            const double tz = s.sz * (cz - fz);
-            const double dz = tz * tz;
-            {
-                const double yn = fmin(fmax(cy, (double)y0), (double)(y1w - 1));
-                const double xn = fmin(fmax(cx, (double)x0w), (double)(x1w - 1));
-                const double tyl = s.sy * (cy - yn), txl = s.sx * (cx - xn);
-                const double lb = (dz + tyl * tyl + txl * txl) * s.spatial_weight;
-                if (lb > wave_worst) continue;                 // wave-uniform
-            }
-            const double cv = s.cen[(size_t)ck * 4 + 3];
-            const int wy0 = w[2], wy1 = w[3];
-            const bool inx = x >= w[4] && x < w[5];
-            const double tx = s.sx * (cx - fx);
-            const double dx2 = tx * tx;
+            VolRec64 rc;
+            rc.cz = s.cen[(size_t)ck * 4]; rc.cy = s.cen[(size_t)ck * 4 + 1]; rc.cx = s.cen[(size_t)ck * 4 + 2];
+            rc.cv = s.cen[(size_t)ck * 4 + 3];
+            rc.wy0 = w[2]; rc.wy1 = w[3]; rc.wx0 = w[4]; rc.wx1 = w[5];
+            rec[c] = rc;
+        }
+        __syncthreads();
+        if (alive) {
+            // Exact pruning: the spatial part of the distance to the nearest point of the strip is a lower bound of the
+            // distance of every voxel of the strip (every operation is monotone in IEEE arithmetic and the colour term
+            // is >= 0); a candidate whose bound exceeds the worst current best of the wave can neither win nor tie.
+            double lbl[PER];
 #pragma unroll
-            for (int r = 0; r < VROWS; ++r) {
-                const int y = y0 + r;
-                if (y < wy0 || y >= wy1) continue;
-                const double ty = s.sy * (cy - (double)y);
-                const double dy = ty * ty;
-                double d = (dz + dy + dx2) * s.spatial_weight;
-                const double t = pv[r] - cv;
-                d = d + t * t;
-                if (inx && (best_d[r] > d || (best_d[r] == d && ck < best_k[r]))) {
-                    best_d[r] = d;
-                    best_k[r] = ck;
+            for (int j = 0; j < PER; ++j) {
+                const int c = lane + 64 * j;
+                lbl[j] = DBL_MAX;
+                if (c < count) {
+                    const VolRec64 rc = rec[c];
+                    if (rc.wy0 < y1w && rc.wy1 > y0) {
+                        const double tz = s.sz * (rc.cz - fz);
+                        const double dz = tz * tz;
+                        const double yn = fmin(fmax(rc.cy, (double)y0), (double)(y1w - 1));
+                        const double xn = fmin(fmax(rc.cx, (double)x0w), (double)(x1w - 1));
+                        const double tyl = s.sy * (rc.cy - yn), txl = s.sx * (rc.cx - xn);
+                        lbl[j] = (dz + tyl * tyl + txl * txl) * s.spatial_weight;
+                    }
                 }
             }
-            if (++since_refresh == 8) {                        // refresh the bound now and then
-                since_refresh = 0;
-                double m = 0.0;
+            int since_refresh = 0;
+            while (true) {
+                double mine = lbl[0];
 #pragma unroll
-                for (int r = 0; r < VROWS; ++r)
-                    if (xin && (y0 + r) < s.H) m = fmax(m, best_d[r]);
-                wave_worst = wave_max_f64(m);
+                for (int j = 1; j < PER; ++j) mine = fmin(mine, lbl[j]);
+                const double wm = wave_min_f64(mine);
+                if (!(wm <= wave_worst) || wm == DBL_MAX) break;   // (DBL_MAX: nothing left in the batch)
+                const unsigned long long own = __ballot(mine == wm);
+                const int src = __ffsll((long long)own) - 1;
+                int jsel = 0;
+#pragma unroll
+                for (int j = PER - 1; j >= 0; --j)
+                    if (lbl[j] == wm) jsel = j;
+                jsel = __builtin_amdgcn_readlane(jsel, src);
+#pragma unroll
+                for (int j = 0; j < PER; ++j)
+                    if (lane == src && j == jsel) lbl[j] = DBL_MAX;
+                const int c = src + 64 * jsel;
+                const int ck = list[c];
+                const VolRec64 rc = rec[c];
+                const double tz = s.sz * (rc.cz - fz);
+                const double dz = tz * tz;
+                const bool inx = x >= rc.wx0 && x < rc.wx1;
+                const double tx = s.sx * (rc.cx - fx);
+                const double dx2 = tx * tx;
+#pragma unroll
+                for (int r = 0; r < VROWS; ++r) {
+                    const int y = y0 + r;
+                    if (y < rc.wy0 || y >= rc.wy1) continue;
+                    const double ty = s.sy * (rc.cy - (double)y);
+                    const double dy = ty * ty;
+                    double d = (dz + dy + dx2) * s.spatial_weight;
+                    const double t = pv[r] - rc.cv;
+                    d = d + t * t;
+                    if (inx && (best_d[r] > d || (best_d[r] == d && ck < best_k[r]))) {
+                        best_d[r] = d;
+                        best_k[r] = ck;
+                    }
+                }
+                if (++since_refresh == 2) {                    // refresh the bound
+                    since_refresh = 0;
+                    double m2 = 0.0;
+#pragma unroll
+                    for (int r = 0; r < VROWS; ++r)
+                        if (xin && (y0 + r) < s.H) m2 = fmax(m2, best_d[r]);
+                    wave_worst = wave_max_f64(m2);
+                }
             }
         }
         count = 0;
+        __syncthreads();
     }
+    if (!alive) return;
     // labels (an uncovered voxel keeps its previous assignment) + accumulation
     unsigned pending = 0;
 #pragma unroll

@@ -49,6 +49,8 @@ VOLUMES = [
     # batches of its 512-entry staging list; ragged in every axis
     ('many_candidates_f32', (9, 45, 150), np.float32, 3, 0.3, (1, 1, 1)),
     ('many_candidates_aniso_f32', (6, 37, 131), np.float32, 4, 0.2, (2, 1, 1)),
+    ('many_candidates_u8', (9, 45, 150), np.uint8, 3, 0.3, (1, 1, 1)),
+    ('many_candidates_aniso_f64', (6, 37, 131), np.float64, 4, 0.2, (2, 1, 1)),
 ]
 
 
