@@ -133,6 +133,16 @@ IMSEGM_API int imsegm_image2d_graph(imsegm_image2d *img, int32_t *edges_out, int
 IMSEGM_API int imsegm_image2d_gather(imsegm_image2d *img, const int32_t *graph_labels, const double *proba,
                           int n_classes, int32_t *segm_out, double *soft_out);
 
+/* The whole Leung-Malik statistics of /root/reference/imsegm/descriptors.py:1041-1106 (compute_texture_desc_lm_img2d_clr: per
+ * battery the filter responses, the maximum over the orientations, the clip, `response * (log(1 + norm) / 0.03) / norm` with
+ * norm = the L2 norm over the three channels, then mean / std / energy per superpixel) in ONE call: the norm of a battery stays on
+ * the device, the K x (3 * flags * n_batteries) table comes back once.  weights: the batteries one after the other, each
+ * [kx][ky][kernel] with n_kernels[b] in {1, 2, 4, 8} kernels (flipped for a true convolution, last kernel repeated as padding:
+ * what imsegm_image2d_lm_battery takes); feature_mask: 1 mean | 2 std | 4 energy, columns per battery in that order, three
+ * channels each -- the column order of descriptors.py:1098-1103.  Needs imsegm_image2d_lm_prepare and a label map. */
+IMSEGM_API int imsegm_image2d_lm_features(imsegm_image2d *img, const double *weights, const int *n_kernels, int n_batteries, int radius,
+                                          double clip, int feature_mask, double *features_out);
+
 /* Leung-Malik texture responses (imsegm/descriptors.py:951-1106, scipy.ndimage in the reference).
  * lm_prepare: planes = image - gaussian_filter(image, sigma) with `taps` = half kernel of
  *   scipy.ndimage.gaussian_filter1d(sigma) (taps[0] centre) for the two image axes and `channel_mix`

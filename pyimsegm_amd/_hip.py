@@ -96,6 +96,7 @@ _SIGNATURES = {
     'imsegm_debug_slic_sweep_runs': (C.c_int, [_vp, _vp]),
     'imsegm_assume_bg_on_boundary': (C.c_int, [_vp, _vp, C.c_int, C.c_int, _vp, C.c_int, _ip]),
     'imsegm_image2d_all_finite': (C.c_int, [_vp, _ip]),
+    'imsegm_image2d_lm_features': (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, C.c_double, C.c_int, _vp]),
     'imsegm_image2d_label_hist': (C.c_int, [_vp, _vp, C.c_int, _vp]),
     'imsegm_image2d_get_lab': (C.c_int, [_vp, _vp]),
     'imsegm_image2d_get_nearest': (C.c_int, [_vp, _vp]),
@@ -641,6 +642,35 @@ class Image2D(object):
         ssq = C.c_double(0)
         _check(load_library().imsegm_image2d_lm_battery(self._h, _ptr(weights), pad, side // 2, float(clip), C.byref(ssq)))
         return float(np.sqrt(ssq.value))
+
+    @staticmethod
+    def _battery_weights(battery):
+        """(weights [kx][ky][kernel] of the flipped kernels, kernels after padding to 1 / 2 / 4 / 8, radius)"""
+        battery = np.asarray(battery, dtype=np.float64)
+        nk, side = battery.shape[0], battery.shape[1]
+        if battery.ndim != 3 or battery.shape[2] != side or side % 2 != 1:
+            raise ValueError('wrong battery dim %r' % (battery.shape, ))
+        pad = {1: 1, 2: 2, 3: 4, 4: 4, 5: 8, 6: 8, 7: 8, 8: 8}.get(nk)
+        if pad is None:
+            raise ValueError('at most 8 kernels per battery')
+        if pad != nk:                    # repeat the last kernel: the maximum is unchanged
+            battery = np.concatenate([battery, np.repeat(battery[-1:], pad - nk, axis=0)], axis=0)
+        # true convolution == correlation with the flipped kernel; layout [kx][ky][kernel]
+        return np.ascontiguousarray(battery[:, ::-1, ::-1].transpose(2, 1, 0)), pad, side // 2
+
+    def lm_features(self, batteries, clip, mean=True, std=True, energy=True):
+        """``imsegm_image2d_lm_features``: K x (3 * flags * len(batteries)) statistics of all batteries in one call"""
+        parts = [self._battery_weights(b) for b in batteries]
+        radius = parts[0][2]
+        if any(p[2] != radius for p in parts):
+            raise ValueError('the batteries of one call have one kernel size')
+        weights = np.concatenate([p[0].ravel() for p in parts])
+        counts = np.array([p[1] for p in parts], dtype=np.int32)
+        mask = (1 if mean else 0) | (2 if std else 0) | (4 if energy else 0)
+        out = np.empty((self.n_labels, 3 * bin(mask).count('1') * len(parts)), dtype=np.float64)
+        _check(load_library().imsegm_image2d_lm_features(self._h, _ptr(weights), _ptr(counts), len(parts), radius, float(clip), mask,
+                                                         _ptr(out)))
+        return out
 
     def response_stats(self, mul, div, mean=True, energy=True, var=True):
         k = self.n_labels

@@ -1074,6 +1074,87 @@ int imsegm_image2d_lm_battery(imsegm_image2d *im, const double *weights, int n_k
     return 0;
 }
 
+int imsegm_image2d_lm_features(imsegm_image2d *im, const double *weights, const int *n_kernels, int n_batteries, int radius, double clip,
+                               int feature_mask, double *features_out)
+{
+    if (!im || bind(im->ctx)) return -1;
+    if (wrong_kind(im, false)) return -1;
+    if (!im->tex_ready || !im->have_labels) {
+        set_error("lm_features: call imsegm_image2d_lm_prepare first, with a label map installed");
+        return -1;
+    }
+    if (!weights || !n_kernels || n_batteries < 1 || !features_out || feature_mask < 1 || feature_mask > 7) {
+        set_error("lm_features: bad arguments");
+        return -1;
+    }
+    imsegm_ctx *ctx = im->ctx;
+    hipStream_t st = ctx->stream;
+    const size_t n = im->n;
+    const int K = im->n_labels;
+    const size_t S = 2 * (size_t)radius + 1;
+    // per battery: the weights as the caller lays them out, then room for the row-padded copy launch_filter_battery makes of them
+    std::vector<size_t> off((size_t)n_batteries + 1, 0);
+    for (int b = 0; b < n_batteries; ++b) {
+        const int nk = n_kernels[b];
+        if (nk != 1 && nk != 2 && nk != 4 && nk != 8) {
+            set_error("filter battery: 1, 2, 4 or 8 kernels per battery are supported");
+            return -1;
+        }
+        off[b + 1] = off[b] + S * S * nk + S * (S + 8) * nk;
+    }
+    const size_t wtotal = off[n_batteries];
+    if (im->tex_resp.ensure((3 * n + wtotal + 1024 + (size_t)n_batteries + 8) * 8 + 64)) return -1;
+    double *resp = im->tex_resp.as<double>();
+    double *d_w = resp + 3 * n;
+    double *partial = d_w + wtotal;
+    double *d_ssq = partial + 1024;
+    double *host = static_cast<double *>(ctx->stage(wtotal * 8));
+    if (!host) {
+        set_error("cannot allocate pinned staging memory");
+        return -1;
+    }
+    {
+        const double *src = weights;
+        for (int b = 0; b < n_batteries; ++b) {
+            const size_t cnt = S * S * n_kernels[b];
+            memcpy(host + off[b], src, cnt * 8);
+            src += cnt;
+        }
+    }
+    HIP_TRY(hipMemcpyAsync(d_w, host, wtotal * 8, hipMemcpyHostToDevice, st));
+    ctx->mark_stage_in_flight();
+    // statistics scratch (as stats_run) and the K x F table
+    const int nflags = ((feature_mask & 1) != 0) + ((feature_mask & 2) != 0) + ((feature_mask & 4) != 0);
+    const int Fb = 3 * nflags, F = Fb * n_batteries;
+    size_t fb = (size_t)K * (13 * 8 + 3 * 3 * 8 + 3 * 4) + 256;
+    if (im->feat.ensure(fb) || im->featK.ensure((size_t)K * F * 8 + 64)) return -1;
+    unsigned char *sb = im->feat.as<unsigned char>();
+    long long *acc = reinterpret_cast<long long *>(sb); sb += (size_t)K * 13 * 8;
+    double *d_mean = reinterpret_cast<double *>(sb); sb += (size_t)K * 3 * 8;
+    double *d_energy = reinterpret_cast<double *>(sb); sb += (size_t)K * 3 * 8;
+    double *d_var = reinterpret_cast<double *>(sb); sb += (size_t)K * 3 * 8;
+    float *d_mean32 = reinterpret_cast<float *>(sb);
+    for (int b = 0; b < n_batteries; ++b) {
+        int spx = ctx->begin(PG_TEX);
+        if (launch_filter_battery(im->tex_planes.as<double>(), im->H, im->W, d_w + off[b], n_kernels[b], radius, clip, resp, partial,
+                                  d_ssq + b, st, 3))
+            return -1;
+        ctx->end(spx);
+        // |r| <= norm  =>  |r * mul / div| <= mul = log(1 + norm) / 0.03 < 2^15 for every finite norm: the bound the fixed-point
+        // scales are chosen for, without the norm coming to the host (prescale 2: the kernels derive mul and div from *ssq)
+        int sps = ctx->begin(PG_STATS);
+        if (launch_color_stats(resp, IMSEGM_F64, im->labels.as<int32_t>(), im->H, im->W, K, 32768.0, (feature_mask & 2) != 0, acc, d_mean,
+                               d_energy, d_var, d_mean32, st, 1, 2, 1.0, 1.0, -1, d_ssq + b))
+            return -1;
+        if (launch_features_assemble(d_mean, d_energy, d_var, K, feature_mask, im->featK.as<double>(), st, F, b * Fb)) return -1;
+        ctx->end(sps);
+    }
+    im->feat_mask = 0;                         // (the resident table is the texture table, not the colour one the fused call reads)
+    HIP_TRY(hipMemcpyAsync(features_out, im->featK.p, (size_t)K * F * 8, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    return 0;
+}
+
 int imsegm_image2d_response_stats(imsegm_image2d *im, double mul, double div, double *mean_out, double *energy_out,
                                   double *var_out)
 {

@@ -216,7 +216,7 @@ int launch_label_hist(const int32_t *labels, const int32_t *annot, size_t n, int
 int launch_color_stats(const void *img, int dtype, const int32_t *labels, int H, int W, int K, double maxabs,
                        int want_var, long long *acc, double *mean_out, double *energy_out, double *var_out,
                        float *mean32_scratch, hipStream_t st, int planar = 0, int prescale = 0, double mul = 1.0,
-                       double div = 1.0, long plane_stride = -1);
+                       double div = 1.0, long plane_stride = -1, const double *ssq_dev = nullptr);
 
 // texture.hip -------------------------------------------------------------------------------------
 // fullpad: device scratch of 2 * radius + 1 + 16 doubles (the zero-padded full tap table the column pass reads)
@@ -310,7 +310,7 @@ struct TermsArgs {
     double *fstd;                  // [2][F] scratch (edge type 'features')
 };
 int launch_features_assemble(const double *mean, const double *energy, const double *var, int K, int mask, double *out,
-                             hipStream_t st);
+                             hipStream_t st, int row_stride = 0, int col0 = 0);
 // symmetric bitmap -> edge list ordered by (b, a), CSR arcs in ascending neighbour order, reverse arcs, edge -> arc table
 int launch_graph_csr(uint32_t *bitmap, const int *K_dev, int K_cap, int words, int32_t *wordprefix, int32_t *deg, int32_t *deg_low,
                      int32_t *arc_start, int32_t *edge_start, int32_t *n_edges_dev, int edge_capacity, int32_t *edges,

@@ -40,6 +40,7 @@ struct StatParams {
     int u8_int;                   // uint8 image, power-of-two scales >= 1: integer block sums in the first pass
     int prescale;                 // 1: value = (raw * mul) / div before the float32 staging
     double mul, div;              //    (descriptors.py:1094 `(response * (log(1 + norm) / 0.03)) / norm`)
+    const double *ssq_dev;        // prescale == 2: norm = sqrt(*ssq_dev) on the device, mul and div derived from it (0 / inf norm: all values 0)
 };
 
 // PASS 1 -> n + 3 x (v, v*v); PASS 2 -> 3 x (v - m)^2.
@@ -71,6 +72,14 @@ k_color_stats(const T *__restrict__ img, const int32_t *__restrict__ labels, Sta
     static_assert(!U8INT || (PASS == 1 && sizeof(T) == 1), "integer block sums: uint8 image, first pass");
     int lab[ST_ROWS];
     float v[ST_ROWS][3];
+    double mul = sp.mul, div = sp.div;
+    bool dead = false;
+    if (sp.prescale == 2) {                      // the L2 norm of the response stays on the device (imsegm_image2d_lm_features)
+        const double norm = sqrt(*sp.ssq_dev);
+        dead = !(norm > 0.0) || norm > DBL_MAX;
+        mul = log(1.0 + norm) / 0.03;
+        div = norm;
+    }
 #pragma unroll
     for (int r = 0; r < ST_ROWS; ++r) {
         const int y = y0 + r;
@@ -90,7 +99,7 @@ k_color_stats(const T *__restrict__ img, const int32_t *__restrict__ labels, Sta
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
             const size_t idx = sp.planar ? (size_t)c * sp.plane_stride + p : 3 * p + c;
-            v[r][c] = sp.prescale ? (float)(((double)img[idx] * sp.mul) / sp.div) : load_f32(img, idx);
+            v[r][c] = sp.prescale ? (dead ? 0.f : (float)(((double)img[idx] * mul) / div)) : load_f32(img, idx);
         }
     }
     while (true) {
@@ -281,12 +290,12 @@ static double pow2_scale(double n_pixels, double maxabs)
 int launch_color_stats(const void *img, int dtype, const int32_t *labels, int H, int W, int K, double maxabs,
                        int want_var, long long *acc, double *mean_out, double *energy_out, double *var_out,
                        float *mean32_scratch, hipStream_t st, int planar, int prescale, double mul, double div,
-                       long plane_stride)
+                       long plane_stride, const double *ssq_dev)
 {
     StatParams sp;
     sp.H = H; sp.W = W; sp.K = K;
     sp.n_pixels = (size_t)H * W;
-    sp.planar = planar; sp.prescale = prescale; sp.mul = mul; sp.div = div;
+    sp.planar = planar; sp.prescale = prescale; sp.mul = mul; sp.div = div; sp.ssq_dev = ssq_dev;
     sp.plane_stride = plane_stride >= 0 ? (size_t)plane_stride : (size_t)H * W;
     sp.scale_v = pow2_scale((double)H * W, maxabs);
     sp.scale_e = pow2_scale((double)H * W, 4.0 * maxabs * maxabs);

@@ -40,12 +40,12 @@ __device__ __forceinline__ double block_reduce_f64(double v, double *scratch, bo
 // np.nan_to_num and the -0 -> +0 of descriptors.py:1265 applied
 __global__ void __launch_bounds__(256)
 k_features_assemble(const double *__restrict__ mean, const double *__restrict__ energy, const double *__restrict__ var, int K,
-                    int mask, int F, double *__restrict__ out)
+                    int mask, int F, double *__restrict__ out, int col0)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= K * 3) return;
     const int k = i / 3, ch = i - 3 * k;
-    int col = ch;
+    int col = col0 + ch;
     auto put = [&](double v) {
         if (v != v) v = 0.0;                                          // nan_to_num
         else if (v > DBL_MAX) v = DBL_MAX;
@@ -382,10 +382,11 @@ k_label_lut(const int32_t *__restrict__ graph_labels, const int *__restrict__ Kp
 }
 
 int launch_features_assemble(const double *mean, const double *energy, const double *var, int K, int mask, double *out,
-                             hipStream_t st)
+                             hipStream_t st, int row_stride, int col0)
 {
-    const int F = 3 * (((mask & 1) != 0) + ((mask & 2) != 0) + ((mask & 4) != 0));
-    hipLaunchKernelGGL(k_features_assemble, cdiv((long)K * 3, 256), 256, 0, st, mean, energy, var, K, mask, F, out);
+    // (row_stride: columns of the table the block is written into -- several blocks side by side; 0: the block is the table)
+    const int F = row_stride > 0 ? row_stride : 3 * (((mask & 1) != 0) + ((mask & 2) != 0) + ((mask & 4) != 0));
+    hipLaunchKernelGGL(k_features_assemble, cdiv((long)K * 3, 256), 256, 0, st, mean, energy, var, K, mask, F, out, col0);
     HIP_TRY(hipGetLastError());
     return 0;
 }

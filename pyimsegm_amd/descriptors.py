@@ -735,24 +735,29 @@ def _texture_desc_lm_device(img, seg, feature_flags, filters, fl_names, sess=Non
     sess.lm_prepare(150.)
     want = [f in feature_flags for f in ('mean', 'std', 'energy')]
     features, names = [], []
+    one_call = getattr(sess, 'lm_features', None) if any(want) and len({np.shape(f)[1:] for f in filters}) == 1 else None
+    if one_call is not None:
+        # all batteries in one call: the norm of a battery never comes to the host (60 synchronisations per image less)
+        features.append(one_call(filters, MAX_SIGNAL_RESPONSE, mean=want[0], std=want[1], energy=want[2]))
     for battery, fl_name in zip(filters, fl_names):
-        norm = sess.lm_battery(battery, MAX_SIGNAL_RESPONSE)
-        nb = sess.n_labels
-        if norm == 0 or abs(norm) == np.inf:
-            mean = energy = var = np.zeros((nb, 3))
-        else:
-            mean, energy, var = sess.response_stats(np.log(1 + norm) / 0.03, norm, mean=want[0], energy=want[2],
-                                                    var=want[1])
-        blocks = []
-        if want[0]:
-            blocks.append(mean)
-        if want[1]:
-            blocks.append(np.sqrt(var))
-        if want[2]:
-            blocks.append(energy)
-        fts = np.nan_to_num(np.hstack(blocks))
-        fts[fts == 0] = 0
-        features.append(fts)
+        if one_call is None:
+            norm = sess.lm_battery(battery, MAX_SIGNAL_RESPONSE)
+            nb = sess.n_labels
+            if norm == 0 or abs(norm) == np.inf:
+                mean = energy = var = np.zeros((nb, 3))
+            else:
+                mean, energy, var = sess.response_stats(np.log(1 + norm) / 0.03, norm, mean=want[0], energy=want[2],
+                                                        var=want[1])
+            blocks = []
+            if want[0]:
+                blocks.append(mean)
+            if want[1]:
+                blocks.append(np.sqrt(var))
+            if want[2]:
+                blocks.append(energy)
+            fts = np.nan_to_num(np.hstack(blocks))
+            fts[fts == 0] = 0
+            features.append(fts)
         ch_names = ['%s-ch%i' % (fl_name, i + 1) for i in range(3)]
         names += list(itertools.chain.from_iterable(['%s_%s' % (n, f) for n in ch_names] for f in NAMES_FEATURE_FLAGS
                                                     if f in feature_flags))

@@ -211,6 +211,34 @@ def test_texture_on_device_matches_scipy(shape, bank, dtype):
     assert np.max(np.abs(fts - ref)) < 1e-5 * max(scale, 1.0), np.max(np.abs(fts - ref))
 
 
+@pytest.mark.parametrize('flags', [('mean', 'std', 'energy'), ('std', ), ('energy', 'mean')])
+def test_texture_one_call_equals_battery_by_battery(flags):
+    """imsegm_image2d_lm_features (all batteries in one call, the L2 norm of a battery stays on the device) against the
+    battery-by-battery calls with the norm on the host: same table up to the last bits of log()"""
+    from pyimsegm_amd import _hip, descriptors as D
+    rng = np.random.default_rng(8)
+    img = rng.integers(0, 256, (90, 141, 3)).astype(np.uint8)
+    img[:, 70:] //= 3
+    seg = ((np.arange(90)[:, None] // 18) * 6 + np.arange(141)[None, :] // 24).astype(np.int32)
+    filters, fl_names = D.create_filter_bank_lm_2d()
+    sess = _hip.Image2D(90, 141).upload(img).set_labels(seg)
+    sess.lm_prepare(150.)
+    one = sess.lm_features(filters, D.MAX_SIGNAL_RESPONSE, mean='mean' in flags, std='std' in flags, energy='energy' in flags)
+    blocks = []
+    for battery in filters:
+        norm = sess.lm_battery(battery, D.MAX_SIGNAL_RESPONSE)
+        m, e, v = sess.response_stats(np.log(1 + norm) / 0.03, norm)
+        blocks += ([m] if 'mean' in flags else []) + ([np.sqrt(v)] if 'std' in flags else []) + ([e] if 'energy' in flags else [])
+    sess.close()
+    ref = np.hstack(blocks)
+    assert one.shape == ref.shape == (seg.max() + 1, 3 * len(flags) * len(filters))
+    assert np.max(np.abs(one - ref)) <= 1e-11 * max(1.0, np.abs(ref).max()), np.max(np.abs(one - ref))
+    # ... and through the descriptor function the pipelines call
+    fts, names = D.compute_texture_desc_lm_img2d_clr(img, seg, list(flags))
+    assert fts.shape == one.shape and len(names) == one.shape[1]
+    assert np.array_equal(fts, np.nan_to_num(one) + 0.0)
+
+
 def test_images_in_flight_match_sequential():
     """worker threads (one HIP stream each) keep several images in flight: same results as one at a time"""
     from pyimsegm_amd import pipelines as pipe
