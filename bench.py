@@ -614,9 +614,9 @@ def bench_color2d(args, group, cfg, quick=False):
     images = [host_image(im, args.pinned_input) for im in images]
     # (whole multiples of the images in flight: completions come in groups of that size, and a window that cuts a group in two
     # reads too fast -- config 3 with 3 steps and 2 in flight showed 40 ms per image where 8 steps show 58)
-    steps = args.steps if (args.steps is not None and not quick) else ({3: 8, 4: 24}[cfg] if quick else {2: 100, 3: 12, 4: 48}[cfg])
+    steps = args.steps if (args.steps is not None and not quick) else ({3: 9, 4: 24}[cfg] if quick else {2: 100, 3: 12, 4: 48}[cfg])
     warmup = args.warmup if (args.warmup is not None and not quick) else {2: 3, 3: 1, 4: 3}[cfg]
-    inflight = args.inflight if args.inflight > 0 else {2: 4, 3: 2, 4: 12}[cfg]
+    inflight = args.inflight if args.inflight > 0 else {2: 4, 3: 3, 4: 12}[cfg]      # (config 3: 80 against 73 Mpixels/s with two)
     npx_step = per_step * height * width
 
     # class model: fitted once, outside the timed region (the reference's group-model flow); config 4 takes the group model
