@@ -1024,6 +1024,8 @@ def main():
         threadpool_limits(limits=1)
     except Exception:
         pass
+    from pyimsegm_amd import _hip
+    _hip.init(hardware_queues=8)        # explicit (imsegm_init): four images in flight + the default stream want more than 4 queues
     from pyimsegm_amd.distributed import Group
     group = Group()
     if args.gpus is not None and args.gpus != group.world:

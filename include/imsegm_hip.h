@@ -33,6 +33,16 @@ typedef struct imsegm_image2d imsegm_image2d;   /* device-resident state of one 
 IMSEGM_API const char *imsegm_last_error(void);
 IMSEGM_API int imsegm_version(void);
 IMSEGM_API int imsegm_device_count(int *count_out);
+/* Optional, once per process and BEFORE the first call that touches a device: the number of hardware queues the HIP runtime maps
+ * the streams of this process onto (the runtime's GPU_MAX_HW_QUEUES, default 4; with one stream per image in flight a fifth
+ * stream shares a queue with another one and its kernels wait behind that image's -- bench.py asks for 8).  The runtime reads
+ * the setting when it starts: returns 0 when the request was recorded, 1 when it can have no effect any more (this library has
+ * already started the runtime) or the user has set GPU_MAX_HW_QUEUES himself (his value wins); nothing is changed then.
+ * No reference counterpart (the reference's parallelism is a process pool, imsegm/utilities/experiments.py:392-403). */
+IMSEGM_API int imsegm_init(int hardware_queues);
+/* Debug / experiment switches (IMSEGM_* environment variables) are read once, at first use; this call reads them again
+ * (tests flip them at run time).  No reference counterpart. */
+IMSEGM_API void imsegm_debug_reload_env(void);
 
 /* page-locked host memory: images / results living in it travel by DMA, asynchronously to the host (the Python layer
  * hands out numpy arrays backed by it: pyimsegm_amd._hip.pinned_empty) */

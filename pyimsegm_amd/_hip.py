@@ -97,6 +97,8 @@ _SIGNATURES = {
     'imsegm_assume_bg_on_boundary': (C.c_int, [_vp, _vp, C.c_int, C.c_int, _vp, C.c_int, _ip]),
     'imsegm_image2d_all_finite': (C.c_int, [_vp, _ip]),
     'imsegm_image2d_lm_features': (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, C.c_double, C.c_int, _vp]),
+    'imsegm_init': (C.c_int, [C.c_int]),
+    'imsegm_debug_reload_env': (None, []),
     'imsegm_image2d_label_hist': (C.c_int, [_vp, _vp, C.c_int, _vp]),
     'imsegm_image2d_get_lab': (C.c_int, [_vp, _vp]),
     'imsegm_image2d_get_nearest': (C.c_int, [_vp, _vp]),
@@ -135,12 +137,6 @@ def load_library():
             if not os.path.exists(LIB_PATH):
                 raise HipUnavailableError(
                     'libimsegm_hip.so is not built (%s); run `python -m pyimsegm_amd.build`' % LIB_PATH)
-            # Hardware queues of the process: the HIP runtime maps its streams onto GPU_MAX_HW_QUEUES queues (default 4) -- with
-            # one stream per image in flight plus the default stream, a fourth image shares a queue with another one and its
-            # kernels wait behind that image's.  Eight queues: 6.5-6.9 instead of 5.6-5.8 Gpx/s on the 2048^2 line with four
-            # images in flight (round 3).  The runtime reads the variable when it starts; a value the user
-            # has set wins, and a runtime that is already up (torch interop) is not affected.
-            os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')
             try:
                 lib = C.CDLL(LIB_PATH)
             except OSError as ex:
@@ -151,6 +147,28 @@ def load_library():
                 fn.argtypes = args
             _lib = lib
     return _lib
+
+
+def init(hardware_queues=8):
+    """Explicit, optional, once per process before the first device call (``imsegm_init``): the number of hardware queues the HIP
+    runtime maps this process's streams onto (its ``GPU_MAX_HW_QUEUES``, default 4).  With one stream per image in flight plus
+    the default stream, a fourth image shares a queue with another one and its kernels wait behind that image's: eight queues
+    gave 6.5-6.9 instead of 5.6-5.8 Gpx/s on the 2048^2 line with four images in flight (round 3).
+    Returns True when the request was recorded; False when the runtime is already up or the user has set the variable (his
+    value wins).  Loading the library never touches the environment."""
+    status = load_library().imsegm_init(int(hardware_queues))
+    if status < 0:
+        raise HipError(load_library().imsegm_last_error().decode('utf-8', 'replace'))
+    if status == 0:
+        # (the C library's setenv does not show in os.environ, which Python copied at start-up: keep the two in step for
+        # child processes started with os.environ and for anyone who looks)
+        os.environ.setdefault('GPU_MAX_HW_QUEUES', str(int(hardware_queues)))
+    return status == 0
+
+
+def reload_env():
+    """read the IMSEGM_* debug switches again (the library reads them once): tests flip them at run time"""
+    load_library().imsegm_debug_reload_env()
 
 
 def _check(status):

@@ -2,6 +2,7 @@
 #include "../../include/imsegm_hip.h"
 #include "slic.h"
 
+#include <atomic>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -21,6 +22,42 @@ bool hip_ok(hipError_t e, const char *what, const char *file, int line)
     g_error = buf;
     return false;
 }
+
+static Knobs read_knobs()
+{
+    auto flag = [](const char *n) { return getenv(n) != nullptr; };
+    auto num = [](const char *n, int dflt) { const char *e = getenv(n); return e ? atoi(e) : dflt; };
+    Knobs k;
+    k.slic_graph = flag("IMSEGM_SLIC_GRAPH");
+    k.slic_persistent = flag("IMSEGM_SLIC_PERSISTENT");
+    k.pre_3pass = flag("IMSEGM_PRE_3PASS");
+    k.separate_finalize = flag("IMSEGM_SEPARATE_FINALIZE");
+    k.fuse_finalize = flag("IMSEGM_FUSE_FINALIZE");
+    k.sweeps_force_fail = flag("IMSEGM_SWEEPS_FORCE_FAIL");
+    k.conn_general = flag("IMSEGM_CONN_GENERAL");
+    k.gc_no_topo_regs = flag("IMSEGM_GC_NO_TOPO_REGS");
+    k.brick_cap = num("IMSEGM_BRICK_CAP", 0);
+    k.gc_lds_level = num("IMSEGM_GC_LDS_LEVEL", 4);
+    k.gc_threads = num("IMSEGM_GC_THREADS", 0);
+    k.sweeps_blocks_per_cu = num("IMSEGM_SWEEPS_BLOCKS_PER_CU", 0);
+    k.sweeps_per_launch = num("IMSEGM_SWEEPS_PER_LAUNCH", 0);
+    const char *d = getenv("IMSEGM_PHASE_DUMP");
+    k.phase_dump = d ? d : "";
+    return k;
+}
+// (a snapshot is never freed: a thread may still hold a reference to the one it started its call with)
+static std::atomic<const Knobs *> g_knobs{ nullptr };
+const Knobs &knobs()
+{
+    const Knobs *k = g_knobs.load(std::memory_order_acquire);
+    if (!k) {
+        const Knobs *fresh = new Knobs(read_knobs());
+        if (g_knobs.compare_exchange_strong(k, fresh, std::memory_order_acq_rel)) k = fresh;
+        else delete fresh;
+    }
+    return *k;
+}
+void reload_knobs() { g_knobs.store(new Knobs(read_knobs()), std::memory_order_release); }
 
 // growable device buffer
 struct DevBuf {
@@ -177,6 +214,8 @@ static int wrong_kind(const imsegm_image2d *im, bool want_volume)
     return 0;
 }
 
+static std::atomic<bool> g_runtime_started{ false };      // a HIP call has been made through this library (imsegm_init is too late)
+
 static int bind(imsegm_ctx *ctx)
 {
     if (!ctx) {
@@ -264,6 +303,7 @@ extern "C" {
 
 int imsegm_host_alloc(size_t bytes, void **ptr_out)
 {
+    g_runtime_started.store(true);
     if (!ptr_out) {
         set_error("null argument");
         return -1;
@@ -279,6 +319,7 @@ void imsegm_host_free(void *ptr)
 
 int imsegm_device_alloc(int device, size_t bytes, void **ptr_out)
 {
+    g_runtime_started.store(true);
     if (!ptr_out) {
         set_error("null argument");
         return -1;
@@ -295,6 +336,7 @@ void imsegm_device_free(void *ptr)
 
 int imsegm_set_device(int device)
 {
+    g_runtime_started.store(true);
     HIP_TRY(hipSetDevice(device));
     return 0;
 }
@@ -317,8 +359,21 @@ int imsegm_ctx_copy(imsegm_ctx *ctx, void *dst, const void *src, size_t bytes, i
 const char *imsegm_last_error(void) { return g_error.c_str(); }
 int imsegm_version(void) { return 100; }
 
+int imsegm_init(int hardware_queues)
+{
+    if (hardware_queues < 1 || hardware_queues > 64) {
+        set_error("imsegm_init: 1..64 hardware queues");
+        return -1;
+    }
+    if (g_runtime_started.load() || getenv("GPU_MAX_HW_QUEUES")) return 1;
+    char buf[16];
+    snprintf(buf, sizeof(buf), "%d", hardware_queues);
+    return setenv("GPU_MAX_HW_QUEUES", buf, 0) == 0 ? 0 : -1;
+}
+
 int imsegm_device_count(int *count_out)
 {
+    g_runtime_started.store(true);
     int c = 0;
     hipError_t e = hipGetDeviceCount(&c);
     if (e != hipSuccess) {
@@ -331,6 +386,7 @@ int imsegm_device_count(int *count_out)
 
 int imsegm_ctx_create(int device, imsegm_ctx **ctx_out)
 {
+    g_runtime_started.store(true);
     int c = 0;
     HIP_TRY(hipGetDeviceCount(&c));
     if (device < 0 || device >= c) {
@@ -595,7 +651,7 @@ int imsegm_image2d_slic(imsegm_image2d *im, int minmax_normalize, int n_segments
     // on ROCm 7.2 / MI355X it is SLOWER than the 31 plain launches (one image alone 1.97-2.03 ms against 1.86-1.87 ms; three
     // in flight 1.01-1.08 ms per image against 0.79-0.80 ms: the graph launches of different streams do not overlap the way
     // plain dispatches do), so it is off by default and kept for re-measuring on later runtimes.
-    const bool use_graph = !ctx->profile && !s.phase_prof && getenv("IMSEGM_SLIC_GRAPH");
+    const bool use_graph = !ctx->profile && !s.phase_prof && knobs().slic_graph;
     bool used_persistent = false;
     if (use_graph) {
         struct SlicGraphKey {
@@ -641,7 +697,7 @@ int imsegm_image2d_slic(imsegm_image2d *im, int minmax_normalize, int n_segments
         // scratch of the persistent sweep kernel (all sweeps after the first in one launch); its failure word is page-locked
         // host memory that is read after the next synchronisation of this call (the connectivity stage ends with one)
         void *sweep_scratch = nullptr;
-        if (getenv("IMSEGM_SLIC_PERSISTENT")) {
+        if (knobs().slic_persistent) {
             if (im->sweeps.ensure(sweep_work_bytes(K, max_iter, (int)n_tiles, cdiv(H, SLIC_TILE_Y)))) return -1;
             sweep_scratch = im->sweeps.p;
         }
@@ -656,8 +712,8 @@ int imsegm_image2d_slic(imsegm_image2d *im, int minmax_normalize, int n_segments
         HIP_TRY(hipMemset(s.phase_prof, 0, all.size() * 8));
         bool any = false;
         for (size_t i = 15; i < all.size() && !any; i += 16) any = all[i] != 0;
-        if (any && getenv("IMSEGM_PHASE_DUMP")) {
-            FILE *f = fopen(getenv("IMSEGM_PHASE_DUMP"), "wb");
+        if (any && !knobs().phase_dump.empty()) {
+            FILE *f = fopen(knobs().phase_dump.c_str(), "wb");
             if (f) {
                 fwrite(all.data(), 8, all.size(), f);
                 fclose(f);
@@ -760,6 +816,8 @@ int imsegm_image2d_set_labels(imsegm_image2d *im, const int32_t *labels, int n_l
 
 // diagnostic: number of 2-D connectivity passes of this process that left the tile path for the general one
 long imsegm_debug_conn_general_runs(void) { return conn_general_runs(); }
+
+void imsegm_debug_reload_env(void) { reload_knobs(); }
 
 int imsegm_debug_slic_sweep_runs(long *persistent_runs_out, long *fallback_runs_out)
 {
@@ -1347,7 +1405,7 @@ int imsegm_volume_slic(imsegm_image2d *im, int n_segments, double compactness, c
                                  (std::min(H, VOL_BY) + 4.0 * s.step_y + 1) * (std::min(W, VOL_BX) + 4.0 * s.step_x + 1);
         s.brick_cap = (int)std::min<double>(std::max(64.0, 4.0 * per_brick), (double)K);
         s.brick_cap = (s.brick_cap + 63) & ~63;
-        if (getenv("IMSEGM_BRICK_CAP")) s.brick_cap = std::max(1, atoi(getenv("IMSEGM_BRICK_CAP")));   // (tests: overflow path)
+        if (knobs().brick_cap) s.brick_cap = std::max(1, knobs().brick_cap);   // (tests: overflow path)
         if (im->tiles.ensure(n_bricks * ((size_t)s.brick_cap + 1) * sizeof(int) + 256)) return -1;
         s.brick_count = im->tiles.as<int>();
         s.brick_list = s.brick_count + ((n_bricks + 63) & ~(size_t)63);
@@ -1620,6 +1678,7 @@ int imsegm_cut_general_graph(imsegm_ctx *ctx, const int32_t *edges, int n_edges,
     GcProblem p;
     p.K = K; p.C = C; p.E = E;
     p.edges = (int32_t *)(io + o_e); p.w = (int32_t *)(io + o_w); p.unary = (int32_t *)(io + o_u); p.smooth = (int32_t *)(io + o_s);
+    p.metric = smooth_is_metric(si, C);
     int sp = ctx->begin(PG_GC);
     if (launch_alpha_expansion(p, (int32_t *)(io + o_as), (int32_t *)(io + o_at), (int32_t *)(io + o_ar), (int32_t *)(io + o_ea),
                                n_iter, d_lab, d_energy, d_status, work, st))
@@ -1833,6 +1892,7 @@ static int segment_impl(imsegm_image2d *im, const imsegm_gmm *gmm, const double 
         smax = std::max(smax, std::abs(si[i]));
         pmax = std::max(pmax, pairwise[i]);
     }
+    const int metric = smooth_is_metric(si, C);
     if (classes_lut) memcpy(host + o_cl, classes_lut, (size_t)C * 4);
     if (gmm) {
         if (gmm->scaler_mean) memcpy(host + o_sc, gmm->scaler_mean, (size_t)F * 8);
@@ -1902,6 +1962,7 @@ static int segment_impl(imsegm_image2d *im, const imsegm_gmm *gmm, const double 
         GcProblem p;
         p.K = K; p.C = C; p.E = Ecap; p.E_dev = E_dev;
         p.edges = edges; p.w = a.weights_i; p.unary = a.unary_i; p.smooth = reinterpret_cast<int32_t *>(dev + d_par + o_sm);
+        p.metric = metric;
         if (launch_alpha_expansion(p, reinterpret_cast<int32_t *>(dev + d_as), reinterpret_cast<int32_t *>(dev + d_at),
                                    reinterpret_cast<int32_t *>(dev + d_ar), reinterpret_cast<int32_t *>(dev + d_ea), -1, glab, energy,
                                    status + 1, dev + d_work, st))
@@ -2042,6 +2103,10 @@ int imsegm_assume_bg_on_boundary(imsegm_ctx *ctx, int32_t *segm_inout, int heigh
     }
     if (mm[0] < 0) {
         set_error("assume_bg_on_boundary: negative label on the border");
+        return -1;
+    }
+    if (mm[1] >= (1 << 28)) {                 // (a histogram of 2^28 bins is 2 GB; INT32_MAX + 1 would overflow `nb`)
+        set_error("assume_bg_on_boundary: border label too large for the border histogram");
         return -1;
     }
     const int nb = mm[1] + 1;

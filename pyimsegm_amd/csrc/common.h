@@ -20,6 +20,20 @@ bool hip_ok(hipError_t e, const char *what, const char *file, int line);
         if (!::imsegm::hip_ok((expr), #expr, __FILE__, __LINE__)) return -1;            \
     } while (0)
 
+// Debug / experiment switches of the library.  The process environment is read ONCE (first use) and again only when
+// imsegm_debug_reload_env() is called (tests flip switches at run time): nothing on the per-image path looks at the environment.
+struct Knobs {
+    bool slic_graph, slic_persistent, pre_3pass, separate_finalize, fuse_finalize, sweeps_force_fail, conn_general, gc_no_topo_regs;
+    int brick_cap;             // IMSEGM_BRICK_CAP (0: default)
+    int gc_lds_level;          // IMSEGM_GC_LDS_LEVEL (default 4)
+    int gc_threads;            // IMSEGM_GC_THREADS (0: default)
+    int sweeps_blocks_per_cu;  // IMSEGM_SWEEPS_BLOCKS_PER_CU (0: default)
+    int sweeps_per_launch;     // IMSEGM_SWEEPS_PER_LAUNCH (0: all)
+    std::string phase_dump;    // IMSEGM_PHASE_DUMP (file name, empty: none)
+};
+const Knobs &knobs();
+void reload_knobs();
+
 constexpr int IMSEGM_MAX_DEVICES = 64;      // size of the per-device caches of function attributes
 __host__ __device__ static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 

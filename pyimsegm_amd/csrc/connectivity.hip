@@ -1236,7 +1236,7 @@ int launch_enforce_connectivity(const int32_t *labels_in, int D, int H, int W, l
     uint8_t *state = w.visited + n;       // second half of the byte scratch (2 * n bytes)
     int32_t host_counters[16];
 
-    if (D == 1 && !getenv("IMSEGM_CONN_GENERAL")) {
+    if (D == 1 && !knobs().conn_general) {
         bool ok = false;
         int n_kept = 0;
         if (conn_fast_2d(labels_in, H, W, min_size, max_size, start_label, w, labels_out, &n_kept, &ok, st)) return -1;

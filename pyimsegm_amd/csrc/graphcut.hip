@@ -47,6 +47,7 @@ struct GcDevice {
     int lds_lab;               // labels, proposal and unary costs are copied into LDS as well (written back at the end)
     int lds_topo;              // 1: arc_start + arc_to in LDS, 2: + arc_rev
     int e_cap;                 // edge capacity the LDS layout was sized for (E on the device may be smaller)
+    int skip_repeat;           // the smoothness term is a metric: a move that repeats the last accepted label is skipped
     int32_t *status;           // [1] 0 ok, 1 = max-flow iteration cap hit
     long long *dbg;            // (IMSEGM_GC_DEBUG) [16] counters / 100 MHz clock sums of thread 0, or null
 };
@@ -463,8 +464,10 @@ __global__ void __launch_bounds__(GC_THREADS) k_alpha_expansion(GcDevice g)
     if (g.n_iter == -1) {
         // GCoptimization::expansion(-1): adaptive cycles (see oracle orc_alpha_expansion_int)
         int nq = 1, next = 0;
-        // label of the last move that was accepted: expanding it again right away cannot lower the energy (the moves open to the
-        // new labelling are a subset of those the accepted move was the optimum of), so that move is answered without a max-flow
+        // label of the last move that was accepted: with a metric smoothness term (every move energy submodular, the max-flow
+        // its exact optimum) expanding it again right away cannot lower the energy (the moves open to the new labelling are a
+        // subset of those the accepted move was the optimum of), so that move is answered without a max-flow; with any other
+        // matrix GCO truncates terms, a move is not exactly optimal, and every move is run (g.skip_repeat = 0)
         int last_accepted = -1;
         if (threadIdx.x == 0) queue_sizes[0] = g.C;
         __syncthreads();
@@ -473,7 +476,7 @@ __global__ void __launch_bounds__(GC_THREADS) k_alpha_expansion(GcDevice g)
             int start = next;
             do {
                 int alpha = table[next];
-                bool ok = alpha != last_accepted && gc_expand<NPT>(g, topo, alpha, cap, height, excess, &energy, flags, calls, scratch);
+                bool ok = !(g.skip_repeat && alpha == last_accepted) && gc_expand<NPT>(g, topo, alpha, cap, height, excess, &energy, flags, calls, scratch);
                 if (ok) last_accepted = alpha;
                 if (!ok) {
                     --queue_size;
@@ -558,6 +561,7 @@ int launch_alpha_expansion(GcProblem p, const int32_t *arc_start, const int32_t 
     g.labels = labels_dev;
     g.energy_out = energy_dev;
     g.status = status_dev;
+    g.skip_repeat = p.metric;
     g.dbg = nullptr;
     static const bool debug = getenv("IMSEGM_GC_DEBUG") != nullptr;
     static long long *dbg_buf = nullptr;
@@ -602,7 +606,7 @@ int launch_alpha_expansion(GcProblem p, const int32_t *arc_start, const int32_t 
             }
         }
     }
-    const int level_cap = getenv("IMSEGM_GC_LDS_LEVEL") ? atoi(getenv("IMSEGM_GC_LDS_LEVEL")) : 4;      // (tests: every placement)
+    const int level_cap = knobs().gc_lds_level;      // (tests: every placement)
     if (level > level_cap) {
         level = std::max(0, level_cap);
         g.use_lds = level >= 1; g.lds_lab = level >= 2; g.lds_topo = level >= 4 ? 2 : level >= 3 ? 1 : 0;
@@ -613,9 +617,9 @@ int launch_alpha_expansion(GcProblem p, const int32_t *arc_start, const int32_t 
     size_t dyn = g.use_lds ? lds_need : 0;
     // one thread per node up to 1024; a small graph runs with fewer waves (the moves are chains of workgroup barriers)
     int threads = std::min(GC_THREADS, std::max(256, ((p.K + 63) / 64) * 64));
-    if (const char *e = getenv("IMSEGM_GC_THREADS")) threads = std::min(GC_THREADS, std::max(64, atoi(e) & ~63));      // (experiments)
+    if (knobs().gc_threads) threads = std::min(GC_THREADS, std::max(64, knobs().gc_threads & ~63));      // (experiments)
     // arcs in registers: one node per thread (two would spill at 1024 threads)
-    const bool cached = level >= 2 && p.K <= threads && 2 * (long)p.E <= 0xffff && !getenv("IMSEGM_GC_NO_TOPO_REGS");
+    const bool cached = level >= 2 && p.K <= threads && 2 * (long)p.E <= 0xffff && !knobs().gc_no_topo_regs;
 #define GC_LAUNCH(L, N)                                                                                                           \
     {                                                                                                                             \
         if (dyn > 48 * 1024) /* the opt-in is per device and cheap: set it on every launch that needs it */                       \

@@ -267,7 +267,24 @@ struct GcProblem {
     const int32_t *w;       // [E]
     const int32_t *unary;   // [K][C]
     const int32_t *smooth;  // [C][C]
+    // the integer smoothness matrix is a metric (smooth_is_metric): every expansion move is then solved exactly, and a move that
+    // repeats the label of the last accepted move cannot lower the energy -- the kernel answers it without a max-flow
+    int metric = 0;
 };
+// V(a, a) = 0, V(a, b) = V(b, a) >= 0, V(a, b) <= V(a, c) + V(c, b) on the integers GCO works with
+static inline int smooth_is_metric(const int32_t *s, int C)
+{
+    for (int a = 0; a < C; ++a) {
+        if (s[a * C + a] != 0) return 0;
+        for (int b = 0; b < C; ++b)
+            if (s[a * C + b] < 0 || s[a * C + b] != s[b * C + a]) return 0;
+    }
+    for (int a = 0; a < C; ++a)
+        for (int b = 0; b < C; ++b)
+            for (int c = 0; c < C; ++c)
+                if ((long long)s[a * C + b] > (long long)s[a * C + c] + (long long)s[c * C + b]) return 0;
+    return 1;
+}
 int launch_alpha_expansion(GcProblem p, const int32_t *arc_start, const int32_t *arc_to, const int32_t *arc_rev,
                            const int32_t *edge_arc, int n_iter, int32_t *labels_dev, long long *energy_dev,
                            int32_t *status_dev, void *work, hipStream_t st);

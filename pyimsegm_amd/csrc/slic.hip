@@ -424,7 +424,7 @@ int launch_preprocess_color2d(const void *img, int dtype, int H, int W, int norm
 {
     int n = H * W;
     int grid = cdiv(n, 256);
-    if (ty.r <= PF_MAXR && tx.r <= PF_MAXR && !getenv("IMSEGM_PRE_3PASS")) {
+    if (ty.r <= PF_MAXR && tx.r <= PF_MAXR && !knobs().pre_3pass) {
         const int ry = ty.r < 0 ? 0 : ty.r, rx = tx.r < 0 ? 0 : tx.r;
         const size_t lds = ((size_t)3 * (PF_TY + 2 * ry) + PF_TY) * (PF_TX + 2 * rx) * sizeof(double);
         const void *fn = dtype == DT_U8 ? (const void *)k_pre_fused<uint8_t>
@@ -2172,7 +2172,7 @@ static int sweeps_resident_blocks()
     int per_cu = 0, cus = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)k_slic_sweeps<false>, 256, 0) != hipSuccess || per_cu < 1) per_cu = 4;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 256;
-    if (const char *e = getenv("IMSEGM_SWEEPS_BLOCKS_PER_CU")) per_cu = std::max(1, atoi(e));
+    if (knobs().sweeps_blocks_per_cu) per_cu = std::max(1, knobs().sweeps_blocks_per_cu);
     const int n = per_cu * cus;
     if (dev >= 0 && dev < IMSEGM_MAX_DEVICES) cached[dev] = n;
     return n;
@@ -2188,10 +2188,12 @@ int launch_slic_iterations(SlicState s, const double *lab, const double *init_yx
     // MI355X it wins where the sweep is launch bound -- the 647 x 1024 images of config 4: +8 % images/s -- and costs the
     // assignment kernel 3 us of tail at 2048 x 2048 (42.2 against 39.1 us, the stage as a whole 6 us faster), so it is the default
     // only when the whole assignment grid is resident at once (one generation of workgroups: nothing hides the extra launch).
-    const bool env_separate_finalize = getenv("IMSEGM_SEPARATE_FINALIZE") != nullptr;      // (tests switch these at run time)
-    const bool env_fuse_finalize = getenv("IMSEGM_FUSE_FINALIZE") != nullptr;
+    const bool env_separate_finalize = knobs().separate_finalize;      // (tests switch these: imsegm_debug_reload_env)
+    const bool env_fuse_finalize = knobs().fuse_finalize;
     const long assign_workgroups = 2L * cdiv(s.W, TILE_X) * cdiv(s.H, TILE_Y);
-    const bool fail_host_fuse = s.done != nullptr && s.fail_host != nullptr && !env_separate_finalize &&
+    // (a list capacity below the default leaves tiles without a list, whose pixels bypass the arrival count: every image would
+    // be handed back and run twice -- such runs keep the separate finalize launches)
+    const bool fail_host_fuse = s.done != nullptr && s.fail_host != nullptr && !env_separate_finalize && default_cand &&
                                 (env_fuse_finalize || assign_workgroups <= 1280);
     if (fail_host_fuse) *s.fail_host = 0;
     if (max_cand <= 0 || max_cand > MAXC) max_cand = MAXC;
@@ -2230,7 +2232,7 @@ int launch_slic_iterations(SlicState s, const double *lab, const double *init_yx
     bool persistent = false;
     const int tile_rows = cdiv(s.H, TILE_Y);
     if (sweep_scratch && fail_host && max_iter >= 3 && s.fast32 && !s.slico && s.spatial_weight > 1e-9 && grid_covers && default_cand &&
-        !s.debug && !s.phase_prof && units == 1 && s.grid_dy > 0 && s.grid_dx > 0 && getenv("IMSEGM_SLIC_PERSISTENT")) {
+        !s.debug && !s.phase_prof && units == 1 && s.grid_dy > 0 && s.grid_dx > 0 && knobs().slic_persistent) {
         const double per_tile = ((double)TILE_Y + 4.0 * s.step_y + 2.0) * ((double)TILE_X + 4.0 * s.step_x + 2.0) / ((double)s.grid_dy * s.grid_dx);
         persistent = per_tile <= 0.75 * MAXC;
     }
@@ -2252,7 +2254,7 @@ int launch_slic_iterations(SlicState s, const double *lab, const double *init_yx
             w.sweep_last = max_iter;
             // pixels that decide a candidate of a tile lie within 3 * (2 * step + 1) rows of it (see k_slic_sweeps)
             w.wait_rows = (3 * (2 * s.step_y + 1) + TILE_Y - 1) / TILE_Y + 1;
-            w.force_fail = getenv("IMSEGM_SWEEPS_FORCE_FAIL") != nullptr;       // (tests: exercise the hand-back)
+            w.force_fail = knobs().sweeps_force_fail;       // (tests: exercise the hand-back)
             w.prof = slic_sweep_prof_buffer();
             *fail_host = 0;
             HIP_TRY(hipMemsetAsync(zeroed, 0, sweep_zeroed_bytes(s.K, max_iter, n_tiles, tile_rows), st));
@@ -2261,7 +2263,7 @@ int launch_slic_iterations(SlicState s, const double *lab, const double *init_yx
             // sweeps per launch: all of them by default; fewer (IMSEGM_SWEEPS_PER_LAUNCH) trades the waits between dependent tiles of
             // consecutive sweeps for launch boundaries
             int per_launch = max_iter - 1;
-            if (const char *e = getenv("IMSEGM_SWEEPS_PER_LAUNCH")) per_launch = std::min(std::max(atoi(e), 1), max_iter - 1);
+            if (knobs().sweeps_per_launch) per_launch = std::min(std::max(knobs().sweeps_per_launch, 1), max_iter - 1);
             if (w.prof) fprintf(stderr, "[slic sweeps] %d x %d: %d items, %d workgroups, wait_rows %d, %d sweeps per launch\n", s.H, s.W,
                                 (max_iter - 1) * n_tiles, std::min(per_launch * n_tiles, sweeps_resident_blocks()), w.wait_rows, per_launch);
             for (int sb = 1, g = 0; sb < max_iter; sb += per_launch, ++g) {

@@ -19,6 +19,7 @@ import ctypes as C
 import os
 import pickle
 import socket
+import stat
 import struct
 import time
 
@@ -62,9 +63,9 @@ class _Star(object):
         self.path = os.environ.get('IMSEGM_COMM_SOCKET')
         if not self.path:
             os.makedirs(base, mode=0o700, exist_ok=True)
-            st = os.stat(base)
-            if st.st_uid != os.getuid() or (st.st_mode & 0o077):
-                raise RuntimeError('control-plane directory %s is not private to this user' % base)
+            st = os.lstat(base)             # (lstat: a symbolic link planted at the predictable /tmp path is refused, not followed)
+            if not stat.S_ISDIR(st.st_mode) or st.st_uid != os.getuid() or (st.st_mode & 0o077):
+                raise RuntimeError('control-plane directory %s is not a directory private to this user' % base)
             self.path = os.path.join(base, '%s.sock' % tag)
         self.peers = {}
         self.sock = None
@@ -82,9 +83,16 @@ class _Star(object):
             self.server = srv
             try:
                 while len(self.peers) < world - 1:
+                    srv.settimeout(max(deadline - time.time(), 0.05))
                     conn, _ = srv.accept()
-                    conn.settimeout(timeout)
-                    peer, = struct.unpack('<i', _recv_exact(conn, 4))
+                    # a rank sends its number right after connecting: a connection that stays silent (or closes) is a stray one
+                    # and is dropped like one with an invalid number -- it does not take the hub down
+                    conn.settimeout(min(10., timeout))
+                    try:
+                        peer, = struct.unpack('<i', _recv_exact(conn, 4))
+                    except (socket.timeout, ConnectionError, OSError):
+                        conn.close()
+                        continue
                     if not (1 <= peer < world) or peer in self.peers:       # a stray or duplicate connection: drop it
                         conn.close()
                         continue

@@ -123,7 +123,9 @@ def assume_bg_on_boundary(segm, bg_label=0, boundary_size=1):
     arr = np.asarray(segm)
     size = int(boundary_size)
     if arr.ndim == 2 and arr.size and 0 < size <= min(arr.shape) and arr.dtype.kind in 'iu' and 0 <= int(bg_label) < 2**31 \
-            and (arr.dtype.itemsize < 4 or (arr.dtype == np.int32) or int(arr.max()) < 2**31):
+            and int(arr.min()) >= 0 and int(arr.max()) < 2**28:
+        # (negative labels wrap around in the reference's ``np.array(lut)[segm]``, values of 2^28 and more do not fit the
+        # device's border histogram: both take the numpy statements below)
         height, width = arr.shape
         # the four strips of data_io.py:1026 (0 < size <= min(shape): the only sizes np.hstack accepts there)
         rows_top, cols_left = slice(None, size).indices(height), slice(None, size).indices(width)

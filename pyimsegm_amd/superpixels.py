@@ -72,8 +72,18 @@ def _release_session(sess):
     idle = sess.ctx.idle_sessions
     if sess.shape in idle or sess.ctx is not _hip.default_context():
         sess.close()
-    else:
-        idle[sess.shape] = sess
+        return
+    if len(sess.shape) == 3:
+        # a volume session owns ~70 bytes of device memory per voxel (75 GB at 64 x 4096 x 4096): at most ONE idle volume
+        # session per context, whatever its shape
+        _evict_idle_volumes(idle)
+    idle[sess.shape] = sess
+
+
+def _evict_idle_volumes(idle, keep=None):
+    """close the idle volume sessions of a context (all shapes but ``keep``)"""
+    for shape in [s for s in idle if len(s) == 3 and s != keep]:
+        idle.pop(shape).close()
 
 
 def _run_slic(sess, mode, sp_size, relative_compact, slico=False):
@@ -124,14 +134,30 @@ def _open_volume(im, reuse=False):
     im = np.asarray(im)
     if im.ndim != 3:
         raise ValueError('expected a 3D gray volume, got shape %r' % (im.shape, ))
-    sess = _hip.default_context().idle_sessions.pop(tuple(im.shape), None) if reuse else None
+    idle = _hip.default_context().idle_sessions
+    sess = idle.pop(tuple(im.shape), None) if reuse else None
     if sess is None:
+        _evict_idle_volumes(idle)          # the memory of an idle volume of another shape is needed now
         sess = _hip.Volume3D(*im.shape)
     try:
         return sess.upload(im)
-    except Exception:
+    except _hip.HipUnavailableError:
         sess.close()
         raise
+    except Exception:
+        # (device allocations happen on first use: upload, slic) out of memory with idle sessions around: give every idle
+        # session of this context back and try once more
+        sess.close()
+        if not idle:
+            raise
+        for shape in list(idle):
+            idle.pop(shape).close()
+        sess = _hip.Volume3D(*im.shape)
+        try:
+            return sess.upload(im)
+        except Exception:
+            sess.close()
+            raise
 
 
 def _run_slic3d(sess, sp_size, relative_compact, space):

@@ -6,6 +6,8 @@ import subprocess
 import sys
 import textwrap
 
+import pytest
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 WORKER = textwrap.dedent('''
@@ -102,6 +104,9 @@ def test_control_plane_rejects_stray_connections(tmp_path):
                 assert time.time() < deadline, 'the hub never listened'
                 time.sleep(0.02)
         stray.sendall(struct.pack('<i', 7))              # not a rank of this job
+        mute = socket.socket(socket.AF_UNIX, socket.SOCK_STREAM)
+        mute.connect(path)
+        mute.close()                                     # connects and never says who it is: dropped, the hub stays up
         peer = _Star(1, 2, timeout=30.)
         t.join(30)
         assert sorted(hub['star'].peers) == [1]
@@ -111,3 +116,19 @@ def test_control_plane_rejects_stray_connections(tmp_path):
         assert not os.path.exists(path)
     finally:
         del os.environ['IMSEGM_COMM_SOCKET']
+
+
+def test_control_plane_directory_must_be_a_private_directory_not_a_link(tmp_path, monkeypatch):
+    """the hub's socket lives in <runtime dir>/imsegm-<uid>: a symbolic link planted there (to a directory the user owns, mode
+    0700 -- os.stat would be satisfied) is refused"""
+    sys.path.insert(0, ROOT)
+    from pyimsegm_amd.distributed import _Star
+    target = tmp_path / 'elsewhere'
+    target.mkdir(mode=0o700)
+    runtime = tmp_path / 'run'
+    runtime.mkdir()
+    os.symlink(str(target), str(runtime / ('imsegm-%d' % os.getuid())))
+    monkeypatch.setenv('XDG_RUNTIME_DIR', str(runtime))
+    monkeypatch.delenv('IMSEGM_COMM_SOCKET', raising=False)
+    with pytest.raises(RuntimeError, match='private'):
+        _Star(0, 1, timeout=5.)

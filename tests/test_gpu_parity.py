@@ -180,6 +180,26 @@ def test_graphcut_random_graphs(hip, oracle, seed, K, C):
     assert np.array_equal(out, ref)
 
 
+@pytest.mark.parametrize('seed,K,C', [(7, 400, 3), (8, 900, 4)])
+def test_graphcut_pairwise_that_is_not_a_metric(hip, oracle, seed, K, C):
+    """cut_general_graph takes any symmetric pairwise matrix (/root/reference/imsegm/graph_cuts.py:735-744).  The kernel's
+    shortcut for a move that repeats the last accepted label is only taken when the integer matrix is a metric (ADVICE r3);
+    here V(a, a) = 1 != 0 -- not a metric, every move term still submodular, so the result is defined -- and every move is run"""
+    rng = np.random.default_rng(seed)
+    side = int(np.ceil(np.sqrt(K)))
+    ids = np.arange(side * side).reshape(side, side)
+    pairs = np.vstack([np.c_[ids[:, :-1].ravel(), ids[:, 1:].ravel()], np.c_[ids[:-1, :].ravel(), ids[1:, :].ravel()]])
+    pairs = pairs[(pairs < K).all(axis=1)].astype(np.int32)
+    weights = np.clip(rng.lognormal(0, 1, len(pairs)), 1e-3, 1e3)
+    proba = rng.dirichlet(np.ones(C) * 0.6, K)
+    unary = np.abs(-np.log(np.clip(proba, 0.01, 0.99)))
+    pairwise = 1. + 2. * (1 - np.eye(C))
+    ref, e_ref = oracle.cut_general_graph(pairs, weights, unary, pairwise, return_energy=True)
+    out, e = hip.cut_general_graph(pairs, weights, unary, pairwise, return_energy=True)
+    assert e == e_ref
+    assert np.array_equal(out, ref)
+
+
 @pytest.mark.parametrize('level,regs', [(0, 0), (1, 0), (2, 0), (3, 0), (4, 0), (2, 1), (3, 1), (4, 1)])
 def test_graphcut_every_lds_placement(hip, oracle, level, regs, monkeypatch):
     """the kernel is compiled once per placement of its arrays (graphcut.hip, template parameter LVL: scratch in global memory ...

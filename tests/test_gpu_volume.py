@@ -277,6 +277,15 @@ def test_all_finite_and_session_reuse(hip):
         out.append(pipelines.pipe_gray3d_slic_features_model_graphcut(v, 2, {'color': ['mean', 'std']}, spacing=(2, 1, 1), sp_size=10))
     assert (4, 60, 70) in hip.default_context().idle_sessions
     assert np.array_equal(out[0], out[2]) and not np.array_equal(out[0], out[1])
+    # volumes of another shape back to back: at most ONE idle volume session per context (a volume session owns
+    # ~70 bytes of device memory per voxel; one idle session per distinct shape ended in hipMalloc failures)
+    for shape in ((3, 50, 64), (5, 40, 48)):
+        np.random.seed(0)
+        w = np.random.default_rng(9).random(shape) / 2.
+        w[:, :, :shape[2] // 2] += 0.5
+        assert pipelines.pipe_gray3d_slic_features_model_graphcut(w, 2, {'color': ['mean']}, spacing=(2, 1, 1), sp_size=10).shape == shape
+        idle3 = [k for k in hip.default_context().idle_sessions if len(k) == 3]
+        assert idle3 == [shape], idle3
     v = vols[0].copy()
     v[0, 0, 0] = np.nan                                    # non-finite voxels: the general path (descriptors on the host)
     np.random.seed(0)
