@@ -59,6 +59,7 @@ HEIGHT = WIDTH = 2048
 C4_SHAPE, C4_SP_SIZE, C4_PER_STEP, C4_FIRST_SEED, C4_NB_IMAGES = (647, 1024), 35, 8, 100, 64   # run_segm...:105-106 slic_size 35
 C5_PARAMS = dict(spacing=(1, 1, 1), sp_size=15, sp_regul=0.2, gc_regul=0.1)
 C5_REDUCED = (32, 512, 512)
+C5_FULL = (64, 4096, 4096)
 FEATURES_LM = {'tLM': ('mean', 'std', 'energy')}
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s
 FP64_VALU_PEAK_TFLOPS = 78.6   # MI355X_MICROARCH.md: fp64 vector (non-MFMA) peak
@@ -80,6 +81,7 @@ def parse_args(argv=None):
     ap.add_argument('--pinned-input', type=int, default=0, help='1: the input images live in page-locked host memory')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-other-configs', action='store_true')
+    ap.add_argument('--no-full-volume', action='store_true', help='leave BASELINE configs[4] at its full 64x4096x4096 out of `other_configs`')
     return ap.parse_args(argv)
 
 
@@ -259,6 +261,60 @@ def cpu_baseline_color2d(image, model, sp_size, sp_regul, repeats=5):
     return entry, segm, (real[2] if real is not None else None)
 
 
+def cpu_baseline_texture(image, sp_size, sp_regul, budget_s=20.0):
+    """config 3 on one host core of THIS box: the reference's Leung-Malik leg is scipy.ndimage.convolve per kernel and colour
+    channel (/root/reference/imsegm/descriptors.py:951-966, compute_img_filter_response2d) -- a bounded sample of those
+    convolutions is timed here with the installed scipy (the first kernels of the bank on the benchmark image's channels, about
+    `budget_s` seconds) and multiplied up to the 76 x 3 convolutions of the bank; the sigma = 150 high-pass is timed whole; SLIC
+    as in config 2.  Beside it: the seconds the reference ITSELF took for `compute_color2d_superpixels_features` on this very
+    image in the build container (tests/golden/reference_c3.npz, 827 s on one core)."""
+    from scipy import ndimage
+    from pyimsegm_amd import descriptors as d
+    filters, _ = d.create_filter_bank_lm_2d()
+    kernels = [k for battery in filters for k in battery]
+    img = np.asarray(image)
+    t0 = time.perf_counter()
+    high = img - ndimage.gaussian_filter(img, 150)                   # descriptors.py:1078 (scalar sigma: the channel axis too)
+    t_blur = time.perf_counter() - t0
+    planes = [np.ascontiguousarray(high[:, :, c]) for c in range(3)]
+    spent, done = 0.0, 0
+    for kernel in kernels:
+        for plane in planes:
+            t = time.perf_counter()
+            ndimage.convolve(plane, kernel)                           # descriptors.py:960-963
+            spent += time.perf_counter() - t
+            done += 1
+            if spent >= budget_s:
+                break
+        if spent >= budget_s:
+            break
+    per_conv = spent / done
+    total_conv = len(kernels) * 3
+    real = real_skimage_slic(img, sp_size, sp_regul, repeats=1)
+    t_slic = float(np.median(real[1])) if real is not None else None
+    slic_how = 'real scikit-image %s' % real[0] if real is not None else 'oracle port'
+    if t_slic is None:
+        from oracle import oracle as orc
+        t = time.perf_counter()
+        orc.segment_slic_img2d(img, sp_size, sp_regul)
+        t_slic = time.perf_counter() - t
+    total = t_slic + t_blur + per_conv * total_conv
+    out = {'value': round(img.shape[0] * img.shape[1] / total / 1e6, 5), 'unit': 'Mpixels/s', 'cores': 1, 'kind': 'reference+port',
+           'sample': 'SLIC %.2f s (%s) + sigma=150 high-pass %.1f s (scipy, whole) + %d of the %d scipy.ndimage.convolve calls of the '
+                     'bank (76 kernels 33x33 x 3 channels) timed: %.2f s each, EXTRAPOLATED to %.0f s; per-superpixel statistics, '
+                     'class model and GraphCut (under 0.3 s in config 2) not included'
+                     % (t_slic, slic_how, t_blur, done, total_conv, per_conv, per_conv * total_conv),
+           'extrapolated_seconds_per_image': round(total, 1)}
+    ref = load_golden('reference_c3.npz')
+    if ref is not None and 'seconds_slic_and_descriptors_one_core' in ref.files:
+        sec = float(ref['seconds_slic_and_descriptors_one_core'])
+        out['reference_whole_stage_build_container'] = {
+            'what': 'the reference itself (unchanged, %s): compute_color2d_superpixels_features with the full Leung-Malik bank on this '
+                    'image, one core of the build container (NOT the GPU box)' % str(ref['versions']),
+            'seconds': round(sec, 1), 'mpixels_per_s': round(img.shape[0] * img.shape[1] / sec / 1e6, 5)}
+    return out
+
+
 def _pool_one_image(task):
     seed, sp_size, sp_regul, gc_regul, arrays = task
     try:
@@ -397,7 +453,7 @@ def compare_config3(image, pipe):
                                 'equal' if segm_ok else 'DIFFERENT', counts.tolist(), ref['class_counts'].tolist())}
 
 
-def compare_config5(shape, pipe):
+def compare_config5(shape, pipe, vol=None):
     """configs[4]: the float32 supervoxel map against the real scikit-image's (CRC), and on the reduced volume also the
     descriptors (1e-5) and -- under the class probabilities of the reference's run -- the segmentation (CRC)"""
     from pyimsegm_amd.descriptors import compute_selected_features_gray3d
@@ -411,11 +467,12 @@ def compare_config5(shape, pipe):
             ref = cand
     if ref is None:
         return None
-    vol = config5_volume(tuple(shape))
+    if vol is None:
+        vol = config5_volume(tuple(shape))
     if crc32(vol, np.float32) != int(ref['volume_crc']):
         return None
     p = C5_PARAMS
-    sess = _open_volume(vol)
+    sess = _open_volume(vol, reuse=True)      # (the session the timed steps left: 75 GB of allocations at full size)
     try:
         _run_slic3d(sess, p['sp_size'], p['sp_regul'], p['spacing'])
         labels = sess.get_labels_int32()
@@ -874,6 +931,12 @@ def bench_color2d(args, group, cfg, quick=False):
                     res.close()
             except Exception as ex:   # the baseline is a reported extra, never a reason to lose the line
                 out['cpu_baseline'] = {'error': repr(ex)}
+        if world == 1 and not args.no_cpu_baseline and cfg == 3 and (height, width) == (HEIGHT, WIDTH):
+            try:
+                out['cpu_baseline'] = cpu_baseline_texture(np.asarray(images[0]), sp_size, SP_REGUL, budget_s=12.0 if quick else 20.0)
+                out['speedup_vs_cpu_baseline'] = round(value / out['cpu_baseline']['value'], 1)
+            except Exception as ex:
+                out['cpu_baseline'] = {'error': repr(ex)}
         if world == 1 and not args.no_cpu_baseline and cfg == 4:
             try:
                 arrays = {k: np.array(golden4[k]) for k in ('scaler_mean', 'scaler_scale', 'gmm_weights', 'gmm_means', 'gmm_covariances',
@@ -918,6 +981,17 @@ def bench_volume(args, group, shape=None, quick=False):
     # apart, it is most of the step at full size
     fit_seconds = [0.0]
     fit = pipe.estim_class_model
+    # threads of the host-side fit: the reference does not pin them; with one rank on the box the fit (k-means + EM restarts on
+    # K x 3 features, most of the step at full size) may use the host's cores (capped: 3 * 10^5 rows do not feed 256 threads)
+    fit_threads = 1
+    limiter = None
+    if group.world == 1:
+        try:
+            from threadpoolctl import threadpool_limits
+            fit_threads = max(1, min(32, os.cpu_count() or 1))
+            limiter = threadpool_limits(limits=fit_threads)
+        except Exception:
+            fit_threads, limiter = 1, None
 
     def timed_fit(*a, **kw):
         t = time.perf_counter()
@@ -944,6 +1018,13 @@ def bench_volume(args, group, shape=None, quick=False):
     pipe.estim_class_model = fit
     stage_ms = {g: ctx.profile_get(g) for g in _hip.PROFILE_GROUPS}
     ctx.profile_enable(False)
+    if limiter is not None:
+        try:
+            limiter.restore_original_limits()
+            from threadpoolctl import threadpool_limits
+            threadpool_limits(limits=1)           # (what main() set for the image configurations)
+        except Exception:
+            pass
     if group.rank != 0:
         return None
     nvox = int(np.prod(shape))
@@ -973,11 +1054,12 @@ def bench_volume(args, group, shape=None, quick=False):
         'roofline': roofline,
         'stage_ms_per_step': {g: round(ms, 3) for g, (ms, n) in stage_ms.items()},
         'host_model_fit_ms_per_step': round(fit_ms, 1), 'ms_per_step_excluding_fit': round(elapsed / steps * 1e3 - fit_ms, 1),
+        'host_model_fit_threads': fit_threads,
     }
-    del vol, segm
+    del segm
     if group.world == 1:
         try:
-            verdict = compare_config5(shape, pipe)
+            verdict = compare_config5(shape, pipe, vol=vol if group.rank == 0 else None)
             if verdict is not None:
                 out.update(verdict)
         except Exception as ex:
@@ -988,6 +1070,8 @@ def bench_volume(args, group, shape=None, quick=False):
                 out['speedup_vs_cpu_baseline'] = round(out['value'] / out['cpu_baseline']['value'], 2)
             except Exception as ex:
                 out['cpu_baseline'] = {'error': repr(ex)}
+    del vol
+    ctx.close_idle_sessions()                  # (a volume session is ~70 bytes per voxel: nothing of it stays behind the bench)
     return out
 
 
@@ -1019,11 +1103,16 @@ def main():
     launched = 'RANK' in os.environ or 'WORLD_SIZE' in os.environ
     if args.gpus is not None and args.gpus > 1 and not launched:
         sys.exit(spawn_ranks(args.gpus, sys.argv[1:]))
-    try:    # host-side BLAS (model fit, non-GMM models): one thread each, N ranks x M worker threads share the node
-        from threadpoolctl import threadpool_limits
-        threadpool_limits(limits=1)
-    except Exception:
-        pass
+    world_env = int(os.environ.get('WORLD_SIZE', '1') or 1)
+    if world_env > 1 or (args.config or 2) != 5:
+        # host-side BLAS (model fit, non-GMM models): one thread each when N ranks x M worker threads share the node.  Not for
+        # the volume configuration on one GPU: its scikit-learn fit is most of the step and the reference does not pin threads
+        # (bench_volume lifts the limit for itself when it runs behind config 2 in the default invocation)
+        try:
+            from threadpoolctl import threadpool_limits
+            threadpool_limits(limits=1)
+        except Exception:
+            pass
     from pyimsegm_amd import _hip
     _hip.init(hardware_queues=8)        # explicit (imsegm_init): four images in flight + the default stream want more than 4 queues
     from pyimsegm_amd.distributed import Group
@@ -1039,7 +1128,10 @@ def main():
             others = {}
             for name, fn in (('4', lambda: bench_color2d(args, group, 4, quick=True)),
                              ('3', lambda: bench_color2d(args, group, 3, quick=True) if group.world == 1 else None),
-                             ('5_reduced', lambda: bench_volume(args, group, shape=C5_REDUCED, quick=True) if group.world == 1 else None)):
+                             ('5_reduced', lambda: bench_volume(args, group, shape=C5_REDUCED, quick=True) if group.world == 1 else None),
+                             # BASELINE configs[4] at its own size (64 x 4096 x 4096: about three minutes, most of it the host
+                             # generating the 10^9 voxels): the supervoxel map against the real scikit-image's on the full volume
+                             ('5', lambda: bench_volume(args, group, shape=C5_FULL, quick=True) if (group.world == 1 and not args.no_full_volume) else None)):
                 try:
                     t0 = time.perf_counter()
                     res = fn()

@@ -235,10 +235,14 @@ class Context(object):
         _check(load_library().imsegm_ctx_profile_get(self._h, PROFILE_GROUPS[group], C.byref(ms), C.byref(n)))
         return ms.value, n.value
 
-    def close(self):
+    def close_idle_sessions(self):
+        """give the device memory of the sessions kept for reuse back (a volume session owns ~70 bytes per voxel)"""
         for sess in list(self.idle_sessions.values()):
             sess.close()
         self.idle_sessions.clear()
+
+    def close(self):
+        self.close_idle_sessions()
         if self._h and self.pid == os.getpid():
             load_library().imsegm_ctx_destroy(self._h)
         self._h = None

@@ -49,6 +49,15 @@ def main():
             setattr(np, alias, typ)
     import imsegm
     assert imsegm.REFERENCE_PATH == os.path.join(ref, 'imsegm'), imsegm.REFERENCE_PATH
+    device_calls = [0]
+    if use_device:                                  # count the SLIC runs that reach libimsegm_hip.so
+        from pyimsegm_amd import _hip
+        real_slic = _hip.Image2D.slic
+
+        def counted_slic(self, *a, **kw):
+            device_calls[0] += 1
+            return real_slic(self, *a, **kw)
+        _hip.Image2D.slic = counted_slic
     import run_segm_slic_model_graphcut as drv     # the reference's driver, unchanged
     import pyimsegm_amd.pipelines
 
@@ -93,6 +102,10 @@ def main():
     seen.update(name=name, shape=list(segm.shape), classes=sorted(int(v) for v in np.unique(segm)),
                 files=sorted(os.listdir(os.path.join(out_dir, drv.FOLDER_SEGM_GMM))),
                 visu=sorted(os.listdir(os.path.join(out_dir, drv.FOLDER_SEGM_GMM_VISU))))
+    seen['device_calls'] = device_calls[0]
+    if use_device:
+        from pyimsegm_amd import _hip
+        seen['library'] = os.path.relpath(_hip.LIB_PATH, ROOT)
     print('OVERLAY ' + json.dumps(seen))
 
 

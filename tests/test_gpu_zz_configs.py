@@ -51,17 +51,44 @@ def test_config5_reduced_volume_equals_the_reference_run():
     assert verdict is not None and verdict['gpu_slic_equals_scikit_image'] and verdict['gpu_equals_reference_run'], verdict
 
 
-@pytest.mark.skipif(not (os.path.isdir('/root/reference/imsegm') and os.path.exists('/opt/conda/bin/python3.9')),
-                    reason='needs the reference tree and the conda interpreter of the build container')
+def _reference_tree():
+    """the reference tree (build container) or the driver bundle oracle/build_ref.py staged from it into oracle/_ref/reference
+    (git-ignored build output that travels with the working tree: the GPU box has no /root/reference)"""
+    for cand in ('/root/reference', os.path.join(ROOT, 'oracle', '_ref', 'reference')):
+        if os.path.isfile(os.path.join(cand, 'experiments_segmentation', 'run_segm_slic_model_graphcut.py')) \
+                and os.path.isdir(os.path.join(cand, 'imsegm', 'utilities')):
+            return cand
+    return None
+
+
+@pytest.mark.skipif(not os.path.exists('/opt/conda/bin/python3.9'),
+                    reason="needs the image's conda interpreter (scikit-image 0.18, matplotlib, pandas: the reference driver's imports)")
 def test_unchanged_reference_driver_on_the_device(tmp_path):
     """tests/overlay_driver_run.py --device: the reference's unchanged run_segm_slic_model_graphcut.py with the kernels
-    (tests/test_overlay_driver.py is the same run with the oracle standing in for them)"""
+    (tests/test_overlay_driver.py is the same run with the oracle standing in for them); the log goes to gpurun_out/"""
     import json
+    ref = _reference_tree()
+    assert ref is not None, 'no reference tree and no oracle/_ref/reference bundle: run __graft_entry__.build() where /root/reference exists'
     env = dict(os.environ, MPLBACKEND='Agg', OMP_NUM_THREADS='1')
     env.pop('PYTHONPATH', None)
-    res = subprocess.run(['/opt/conda/bin/python3.9', os.path.join(ROOT, 'tests', 'overlay_driver_run.py'), '/root/reference', str(tmp_path),
+    env.pop('IMSEGM_REFERENCE', None)
+    # the conda interpreter ships a libstdc++ older than the one libamdhip64.so.7 was linked against, and its matplotlib loads
+    # it first: the system's goes in front (INTEGRATION.md, "conda interpreters")
+    for cand in ('/usr/lib/x86_64-linux-gnu/libstdc++.so.6', '/usr/lib64/libstdc++.so.6'):
+        if os.path.exists(cand):
+            env['LD_PRELOAD'] = (cand + ' ' + env.get('LD_PRELOAD', '')).strip()
+            break
+    res = subprocess.run(['/opt/conda/bin/python3.9', os.path.join(ROOT, 'tests', 'overlay_driver_run.py'), ref, str(tmp_path),
                           '--device'], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, universal_newlines=True, timeout=900)
+    try:
+        os.makedirs(os.path.join(ROOT, 'gpurun_out'), exist_ok=True)
+        with open(os.path.join(ROOT, 'gpurun_out', 'overlay_driver_device.log'), 'w') as fp:
+            fp.write('$ /opt/conda/bin/python3.9 tests/overlay_driver_run.py %s <tmp> --device\nexit code %d\n--- stdout\n%s\n--- stderr (tail)\n%s\n'
+                     % (ref, res.returncode, res.stdout[-6000:], res.stderr[-6000:]))
+    except OSError:
+        pass
     assert res.returncode == 0, res.stderr[-3000:]
     seen = json.loads([ln for ln in res.stdout.splitlines() if ln.startswith('OVERLAY ')][-1][len('OVERLAY '):])
     assert seen['pipelines_is_hip'] and seen['shape'] == [900, 1200] and len(seen['classes']) > 1
+    assert seen['device_calls'] > 0, seen
     assert seen['region_growing_pixels'] is True
