@@ -81,6 +81,8 @@ def parse_args(argv=None):
     ap.add_argument('--pinned-input', type=int, default=0, help='1: the input images live in page-locked host memory')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-other-configs', action='store_true')
+    ap.add_argument('--batch-images', type=int, default=-1, help='config 4: 0 = one image per launch chain (round 3), default: the 8 '
+                                                                 'images of a step in ONE launch chain (imsegm_batch2d_run_color)')
     ap.add_argument('--no-full-volume', action='store_true', help='leave BASELINE configs[4] at its full 64x4096x4096 out of `other_configs`')
     return ap.parse_args(argv)
 
@@ -673,7 +675,9 @@ def bench_color2d(args, group, cfg, quick=False):
     # reads too fast -- config 3 with 3 steps and 2 in flight showed 40 ms per image where 8 steps show 58)
     steps = args.steps if (args.steps is not None and not quick) else ({3: 9, 4: 24}[cfg] if quick else {2: 100, 3: 12, 4: 48}[cfg])
     warmup = args.warmup if (args.warmup is not None and not quick) else {2: 3, 3: 1, 4: 3}[cfg]
-    inflight = args.inflight if args.inflight > 0 else {2: 4, 3: 3, 4: 12}[cfg]      # (config 3: 80 against 73 Mpixels/s with two)
+    # (config 3: 80 against 73 Mpixels/s with two; config 4: steps of 8 images in one launch chain each, three of them in flight --
+    # twelve when the images go one by one, --batch-images 0)
+    inflight = args.inflight if args.inflight > 0 else {2: 4, 3: 3, 4: 12 if args.batch_images == 0 else 3}[cfg]
     npx_step = per_step * height * width
 
     # class model: fitted once, outside the timed region (the reference's group-model flow); config 4 takes the group model
@@ -714,9 +718,21 @@ def bench_color2d(args, group, cfg, quick=False):
     def make_state():
         return {'ctx': _hip.default_context()}
 
+    # config 4: the images of a step go through the library TOGETHER (csrc/batch.hip: every kernel launched once for the
+    # batch, image = blockIdx.z) -- what the reference does with a pool map over the images
+    batched = cfg == 4 and on_device and args.batch_images != 0 and pipe.BATCH_IMAGES > 0
+
     def do_step(state, index, stage):
-        for k, image in enumerate(images):
-            one_image(image, stage=stage, k=k)
+        if batched:
+            hook = None
+            if stage is not None and group.distributed:
+                def hook(batch):
+                    for k in range(len(images)):
+                        stage(k, batch.segm_device_array(k))         # D2D into the send ring before the batch object is recycled
+            got = pipe._segment_color2d_batch_call(images, model, features, sp_size, SP_REGUL, GC_REGUL, EDGE_TYPE, with_batch=hook)
+            if got is not None:
+                return got
+        return [one_image(image, stage=stage, k=k) for k, image in enumerate(images)]
 
     runner = SteadyRun(group, inflight, make_state, do_step, gather_item_bytes=height * width * 4, items_per_step=per_step)
     elapsed, cold = runner.run(warmup, steps)
@@ -770,6 +786,16 @@ def bench_color2d(args, group, cfg, quick=False):
                         bad_segm.append(s)
                 finally:
                     res.close()
+            if batched:
+                # ... and the batched path itself: every image of this rank's step, segmentation and superpixel map
+                maps = []
+                got = pipe._segment_color2d_batch_call(images, model, features, sp_size, SP_REGUL, GC_REGUL, EDGE_TYPE,
+                                                       with_batch=lambda b: maps.extend(b.get_labels(k) for k in range(len(images))))
+                for k, s_ in enumerate(seeds):
+                    if got is None or crc32(got[k]) != want[s_]:
+                        bad_segm.append(('batch', s_))
+                    if got is None or crc32(maps[k]) != slic_want[s_]:
+                        bad_slic.append(('batch', s_))
             verdict['gpu_equals_reference_run'] = not bad_segm and not bad_slic
             verdict['reference_run'] = ('tests/golden/reference_c4.npz (%s): %d images checked (seeds %d..%d), superpixel maps different: %s, '
                                         'segmentations different: %s' % (str(golden4['versions']), len(check_seeds), check_seeds[0],
@@ -842,7 +868,10 @@ def bench_color2d(args, group, cfg, quick=False):
     ctx.profile_enable(True)
     ctx.profile_reset()
     for _ in range(prof_steps):
-        one_image(images[0])
+        if batched:
+            do_step(None, -1, None)                   # (the launch chain of the timed steps: per_step images per launch)
+        else:
+            one_image(images[0])
     ctx.synchronize()
     stage_ms = {g: ctx.profile_get(g) for g in _hip.PROFILE_GROUPS}
     ctx.profile_enable(False)
@@ -863,7 +892,8 @@ def bench_color2d(args, group, cfg, quick=False):
             assign_ms, assign_n = stage_ms['slic_assign']
             sweeps = _hip.assign_sweeps_per_launch() if hasattr(_hip, 'assign_sweeps_per_launch') else 1
             avg_s = assign_ms / max(assign_n, 1) / 1e3
-            achieved = ASSIGN_BYTES_PER_PX * npx * sweeps / avg_s / 1e9 if assign_n else 0.0
+            per_launch = per_step if batched else 1          # images one launch of the kernel works on
+            achieved = ASSIGN_BYTES_PER_PX * npx * per_launch * sweeps / avg_s / 1e9 if assign_n else 0.0
             traffic = None
             try:   # HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
                 with open(os.path.join(ROOT, 'profiles', 'pmc_traffic.json')) as fp:
@@ -880,7 +910,8 @@ def bench_color2d(args, group, cfg, quick=False):
                         'frac': round(achieved / HBM_PEAK_GBS, 5), 'traffic': traffic,
                         'traffic_source': 'profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)',
                         'avg_kernel_us': round(avg_s * 1e6, 3), 'launches': assign_n, 'sweeps_per_launch': sweeps,
-                        'algorithmic_bytes_per_launch': ASSIGN_BYTES_PER_PX * npx * sweeps}
+                        'images_per_launch': per_launch,
+                        'algorithmic_bytes_per_launch': ASSIGN_BYTES_PER_PX * npx * per_launch * sweeps}
         workload = {
             2: 'single %dx%d RGB uint8 per GPU, SLIC(sp_size=46, K=2025, 10 sweeps) + colour mean/std/energy + 3-class '
                'alpha-expansion GC (gc_regul=2.0, edge=model), pre-fitted GMM, host numpy in -> segm int32 in host numpy '
@@ -898,7 +929,8 @@ def bench_color2d(args, group, cfg, quick=False):
             'dtype': 'f64', 'data': 'synthetic',
             'config': {
                 'workload': workload, 'bench_config': cfg, 'images_per_step_per_gpu': per_step,
-                'images_in_flight_per_gpu': inflight, 'hardware_queues': os.environ.get('GPU_MAX_HW_QUEUES', 'runtime default (4)'),
+                'images_per_launch_chain': per_step if batched else 1,
+                'images_in_flight_per_gpu': inflight * (per_step if batched else 1) if cfg == 4 else inflight, 'hardware_queues': os.environ.get('GPU_MAX_HW_QUEUES', 'runtime default (4)'),
                 'timed_region': 'host numpy image -> H2D -> SLIC -> descriptors -> class model -> graph-cut terms -> '
                                 'alpha-expansion -> gathers -> D2H -> segm in host numpy (page-locked result array); model fit outside',
                 'input_memory': 'page-locked' if args.pinned_input else 'pageable numpy',
@@ -914,7 +946,8 @@ def bench_color2d(args, group, cfg, quick=False):
             'rccl_error': getattr(group, 'rccl_error', None),
             'roofline': roofline,
             'stage_ms_per_step': {g: round(ms / prof_steps, 4) for g, (ms, n) in stage_ms.items()},
-            'stage_note': 'stage and roofline figures: separate pass of %d un-overlapped host-to-host images on one stream' % prof_steps,
+            'stage_note': 'stage and roofline figures: separate pass of %d un-overlapped host-to-host %s on one stream'
+                          % (prof_steps, 'steps (batches of %d images in one launch chain)' % per_step if batched else 'images'),
         }
         out.update(extras)
         out.update(verdict)

@@ -271,6 +271,30 @@ IMSEGM_API int imsegm_image2d_run_color(imsegm_image2d *img, const void *host_pi
                                         int use_graphcut, const int32_t *classes_lut, int32_t *segm_out, double *soft_out,
                                         int *n_labels_out);
 
+/* ---------------------------------------------------------------------------------------------
+ * several images of ONE size per launch chain
+ * ------------------------------------------------------------------------------------------- */
+/* Replaces the pool map of the reference's experiment driver over the images of a batch
+ * (/root/reference/experiments_segmentation/run_segm_slic_model_graphcut.py:451-473 and :505-514 `segment_image_model` mapped through
+ * imsegm/utilities/experiments.py:392-403 WrapExecuteSequence): up to `max_images` images of height x width go through
+ * segment_color2d_slic_features_model_graphcut (imsegm/pipelines.py:160-241) TOGETHER -- every kernel of the chain is launched once
+ * for the batch (image = blockIdx.z), with two host synchronisations per batch instead of two per image.  Results are those of
+ * imsegm_image2d_run_color image by image, bit for bit. */
+typedef struct imsegm_batch2d imsegm_batch2d;
+IMSEGM_API int imsegm_batch2d_create(imsegm_ctx *ctx, int max_images, int height, int width, imsegm_batch2d **batch_out);
+IMSEGM_API void imsegm_batch2d_destroy(imsegm_batch2d *batch);
+/* host_pixels[i]: H x W x 3 interleaved image i (all of `dtype`); segm_out[i]: H x W int32 (a null entry, or segm_out == NULL:
+ * that map stays on the device, imsegm_batch2d_device_ptr); n_labels_out: n_images superpixel counts or NULL.  Arguments as
+ * imsegm_image2d_run_color; SLICO, a blur radius above 8 and host-evaluated class models take the single-image calls (an
+ * error here, not a fallback). */
+IMSEGM_API int imsegm_batch2d_run_color(imsegm_batch2d *batch, int n_images, const void *const *host_pixels, int dtype,
+                                        int minmax_normalize, int n_segments, double compactness, const double *taps, int radius,
+                                        int max_iter, int start_label, int feature_mask, const imsegm_gmm *gmm, int n_classes,
+                                        const double *pairwise, int edge_type, double edge_cost, int use_graphcut,
+                                        const int32_t *classes_lut, int32_t *const *segm_out, int *n_labels_out);
+/* device address of a result of image `image` of the last batch: which = 0 label map, 1 segmentation (int32 H x W each) */
+IMSEGM_API int imsegm_batch2d_device_ptr(imsegm_batch2d *batch, int image, int which, void **ptr_out);
+
 /* The 'median' and 'meanGrad' statistics of compute_image2d_color_statistic / compute_image3d_gray_statistic
  * (imsegm/descriptors.py:420-455, 671-702, 766-770, 841-845) on the resident image (K x 3) or volume (K):
  * median of the pixel values per label and channel (NaN for labels without pixels, as np.median of an empty list);

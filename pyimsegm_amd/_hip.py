@@ -97,6 +97,11 @@ _SIGNATURES = {
     'imsegm_assume_bg_on_boundary': (C.c_int, [_vp, _vp, C.c_int, C.c_int, _vp, C.c_int, _ip]),
     'imsegm_image2d_all_finite': (C.c_int, [_vp, _ip]),
     'imsegm_image2d_lm_features': (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, C.c_double, C.c_int, _vp]),
+    'imsegm_batch2d_create': (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.POINTER(_vp)]),
+    'imsegm_batch2d_destroy': (None, [_vp]),
+    'imsegm_batch2d_run_color': (C.c_int, [_vp, C.c_int, _vp, C.c_int, C.c_int, C.c_int, C.c_double, _vp, C.c_int, C.c_int, C.c_int,
+                                           C.c_int, _vp, C.c_int, _vp, C.c_int, C.c_double, C.c_int, _vp, _vp, _vp]),
+    'imsegm_batch2d_device_ptr': (C.c_int, [_vp, C.c_int, C.c_int, C.POINTER(_vp)]),
     'imsegm_init': (C.c_int, [C.c_int]),
     'imsegm_debug_reload_env': (None, []),
     'imsegm_image2d_label_hist': (C.c_int, [_vp, _vp, C.c_int, _vp]),
@@ -862,6 +867,100 @@ class Volume3D(Image2D):
         out = np.empty(self.shape, dtype=np.float64)
         _check(load_library().imsegm_image2d_get_response(self._h, _ptr(out)))
         return out
+
+
+class Batch2D(object):
+    """up to ``max_images`` colour images of ONE size through the whole pipeline in one chain of launches
+    (``imsegm_batch2d_*``, csrc/batch.hip: image = blockIdx.z): what the reference does by mapping ``segment_image_model``
+    over a process pool (``run_segm_slic_model_graphcut.py:505-514``)"""
+
+    def __init__(self, max_images, height, width, ctx=None):
+        self.ctx = ctx or default_context()
+        self.shape = (int(height), int(width))
+        self.max_images = int(max_images)
+        self._h = _vp()
+        self.n_labels = []
+        self.n_images = 0
+        _check(load_library().imsegm_batch2d_create(self.ctx._h, self.max_images, self.shape[0], self.shape[1], C.byref(self._h)))
+        self.ctx.users += 1
+
+    def close(self):
+        if self._h and self.ctx is not None:
+            self.ctx.users -= 1
+            if self.ctx._h and self.ctx.pid == os.getpid():
+                load_library().imsegm_batch2d_destroy(self._h)
+        self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def run_color(self, images, n_segments, compactness, gmm, pairwise, edge_type='model', feature_flags=(True, True, True),
+                  sigma=1., normalize=2, max_iter=10, start_label=0, edge_cost=1., use_graphcut=True, classes=None, to_host=True,
+                  pinned=True, out=None):
+        """``Image2D.run_color`` for a list of images of this batch's size and one dtype (uint8 / float32 / float64):
+        returns the list of segmentations (int32 H x W; ``out``: arrays to write them into) or, with ``to_host=False``,
+        leaves them on the device (:meth:`segm_device_array`)"""
+        images = [np.ascontiguousarray(im) for im in images]
+        if not 0 < len(images) <= self.max_images:
+            raise ValueError('between 1 and %d images per batch' % self.max_images)
+        dtype = images[0].dtype
+        if dtype not in _DTYPES or any(im.shape != self.shape + (3, ) or im.dtype != dtype for im in images):
+            raise ValueError('expected images of shape %r + (3,) and one dtype of uint8 / float32 / float64' % (self.shape, ))
+        code = EDGE_TYPES.get(edge_type)
+        if code is None:
+            raise ValueError('edge type %r is not evaluated on the device' % (edge_type, ))
+        pairwise = np.ascontiguousarray(pairwise, dtype=np.float64)
+        nc = gmm.n_classes
+        if pairwise.shape != (nc, nc):
+            raise ValueError('pairwise cost must be %d x %d' % (nc, nc))
+        cl = None if classes is None else np.ascontiguousarray(classes, dtype=np.int32)
+        taps = gaussian_taps(sigma)
+        r = -1 if taps is None else len(taps) - 1
+        n = len(images)
+        src = (_vp * n)(*[im.ctypes.data for im in images])
+        segm, dst = None, None
+        if to_host:
+            if out is not None:
+                segm = list(out)
+                if len(segm) != n or any(a.shape != self.shape or a.dtype != np.int32 or not a.flags['C_CONTIGUOUS'] for a in segm):
+                    raise ValueError('out: one C-contiguous int32 array of the image size per image')
+            else:
+                alloc = pinned_empty if pinned else np.empty
+                segm = [alloc(self.shape, np.int32) for _ in range(n)]
+            dst = (_vp * n)(*[a.ctypes.data for a in segm])
+        mask = (1 if feature_flags[0] else 0) | (2 if feature_flags[1] else 0) | (4 if feature_flags[2] else 0)
+        counts = (C.c_int * n)()
+        _check(load_library().imsegm_batch2d_run_color(
+            self._h, n, src, _DTYPES[dtype], int(normalize), int(n_segments), float(compactness), _ptr(taps), r, int(max_iter),
+            int(start_label), mask, C.byref(gmm.params), nc, _ptr(pairwise), code, float(edge_cost), int(bool(use_graphcut)), _ptr(cl),
+            dst, counts))
+        self.n_labels = list(counts)
+        self.n_images = n
+        self._uploaded = images         # page-locked sources are read asynchronously (the call ends with a synchronisation)
+        return segm
+
+    def _device_array(self, image, which):
+        ptr = _vp()
+        _check(load_library().imsegm_batch2d_device_ptr(self._h, int(image), which, C.byref(ptr)))
+        return DeviceArray(ptr.value, self.shape, '<i4', self)
+
+    def segm_device_array(self, image):
+        """the segmentation of image ``image`` of the last batch (int32 H x W) as a device array"""
+        return self._device_array(image, 1)
+
+    def labels_device_array(self, image):
+        """the superpixel map of image ``image`` of the last batch (int32 H x W) as a device array"""
+        return self._device_array(image, 0)
+
+    def get_labels(self, image):
+        """superpixel map of image ``image`` of the last batch on the host (int64, the dtype scikit-image leaks)"""
+        arr = self.labels_device_array(image)
+        out = np.empty(self.shape, dtype=np.int32)
+        self.ctx.copy(out.ctypes.data, arr.__cuda_array_interface__['data'][0], out.nbytes, synchronize=True)
+        return out.astype(np.int64)
 
 
 class DeviceArray(object):

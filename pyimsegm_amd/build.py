@@ -12,8 +12,8 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 LIB = os.path.join(HERE, 'libimsegm_hip.so')
-SOURCES = ['api.hip', 'slic.hip', 'connectivity.hip', 'stats.hip', 'graph.hip', 'graphcut.hip', 'texture.hip', 'volume.hip', 'terms.hip', 'natives.hip', 'median.hip', 'output.hip']
-HEADERS = ['common.h', 'slic.h', os.path.join('..', '..', 'include', 'imsegm_hip.h')]
+SOURCES = ['api.hip', 'batch.hip', 'slic.hip', 'connectivity.hip', 'stats.hip', 'graph.hip', 'graphcut.hip', 'texture.hip', 'volume.hip', 'terms.hip', 'natives.hip', 'median.hip', 'output.hip']
+HEADERS = ['common.h', 'slic.h', 'session.h', os.path.join('..', '..', 'include', 'imsegm_hip.h')]
 # -ffp-contract=off: every fp64 operation rounds on its own -- the bit-exactness contract with the
 # CPU oracle; no fast-math anywhere.
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-ffp-contract=off', '-fvisibility=hidden',

@@ -59,245 +59,90 @@ const Knobs &knobs()
 }
 void reload_knobs() { g_knobs.store(new Knobs(read_knobs()), std::memory_order_release); }
 
-// growable device buffer
-struct DevBuf {
-    void *p = nullptr;
-    size_t cap = 0;
-    int ensure(size_t bytes)
-    {
-        if (bytes <= cap) return 0;
-        if (p) HIP_TRY(hipFree(p));
-        p = nullptr;
-        cap = 0;
-        size_t want = bytes + bytes / 8 + 256;
-        HIP_TRY(hipMalloc(&p, want));
-        cap = want;
-        return 0;
-    }
-    void release()
-    {
-        if (p) (void)hipFree(p);
-        p = nullptr;
-        cap = 0;
-    }
-    template <typename T> T *as() { return reinterpret_cast<T *>(p); }
-};
-
-enum { PG_ASSIGN = 0, PG_SLIC = 1, PG_CONN = 2, PG_STATS = 3, PG_GRAPH = 4, PG_GC = 5, PG_GATHER = 6, PG_PRE = 7, PG_TERMS = 8, PG_TEX = 9, PG_COUNT = 10 };
-
-struct Span {
-    int group;
-    hipEvent_t a, b;
-};
-
 }  // namespace imsegm
 
-using namespace imsegm;
+#include "session.h"
 
-struct imsegm_ctx {
-    int device = 0;
-    hipStream_t stream = nullptr;
-    bool profile = false;
-    std::vector<Span> spans;
-    std::vector<hipEvent_t> pool;
-    double acc_ms[PG_COUNT] = { 0 };
-    int acc_n[PG_COUNT] = { 0 };
-    DevBuf gc_buf;   // scratch of imsegm_cut_general_graph
-    DevBuf aux_buf;  // small second scratch (border histogram of imsegm_assume_bg_on_boundary)
-    void *pinned = nullptr;          // page-locked staging for the small host <-> device transfers
-    size_t pinned_cap = 0;
-    hipEvent_t pinned_ev = nullptr;   // recorded after an H2D out of `pinned` that nobody waits for
-    bool pinned_busy = false;
-    void mark_stage_in_flight()
-    {
-        if (!pinned_ev) (void)hipEventCreateWithFlags(&pinned_ev, hipEventDisableTiming);
-        (void)hipEventRecord(pinned_ev, stream);
-        pinned_busy = true;
-    }
-    void *stage(size_t bytes)
-    {
-        if (pinned_busy) {
-            (void)hipEventSynchronize(pinned_ev);
-            pinned_busy = false;
-        }
-        if (bytes > pinned_cap) {
-            if (pinned) (void)hipHostFree(pinned);
-            pinned = nullptr;
-            pinned_cap = 0;
-            size_t want = bytes + bytes / 2 + 4096;
-            if (hipHostMalloc(&pinned, want, hipHostMallocDefault) != hipSuccess) return nullptr;
-            pinned_cap = want;
-        }
-        return pinned;
-    }
+std::atomic<bool> g_runtime_started{ false };
 
-    hipEvent_t get_event()
-    {
-        if (!pool.empty()) {
-            hipEvent_t e = pool.back();
-            pool.pop_back();
-            return e;
-        }
-        hipEvent_t e;
-        (void)hipEventCreate(&e);
-        return e;
-    }
-    int begin(int group)
-    {
-        if (!profile) return -1;
-        Span s;
-        s.group = group;
-        s.a = get_event();
-        s.b = get_event();
-        (void)hipEventRecord(s.a, stream);
-        spans.push_back(s);
-        return (int)spans.size() - 1;
-    }
-    void end(int id)
-    {
-        if (id >= 0) (void)hipEventRecord(spans[id].b, stream);
-    }
-    void pair(int group, hipEvent_t *a, hipEvent_t *b)       // events filled in by a kernel launch, not recorded here
-    {
-        Span s;
-        s.group = group;
-        s.a = get_event();
-        s.b = get_event();
-        spans.push_back(s);
-        *a = s.a;
-        *b = s.b;
-    }
-    void collect()
-    {
-        if (spans.empty()) return;
-        (void)hipStreamSynchronize(stream);
-        for (auto &s : spans) {
-            float ms = 0;
-            if (hipEventElapsedTime(&ms, s.a, s.b) == hipSuccess) {
-                acc_ms[s.group] += ms;
-                acc_n[s.group] += 1;
-            }
-            pool.push_back(s.a);
-            pool.push_back(s.b);
-        }
-        spans.clear();
-    }
-};
-
-struct imsegm_image2d {
-    imsegm_ctx *ctx = nullptr;
-    int D = 1, H = 0, W = 0;      // D > 1: gray volume session (imsegm_volume_*)
-    size_t n = 0;
-    int dtype = -1;
-    int n_labels = 0;
-    bool have_labels = false;
-    bool tex_ready = false;
-    bool is_volume = false;
-    double vol_off = 0.0, vol_scale = 1.0;      // intensity seen by the volume SLIC = (v + off) * scale
-    DevBuf img, labA, labB, nearest, labels, conn_i32, conn_u8, small, cent, tiles, feat, graph, gather_lut, gather_out_i, gather_out_f,
-        tex_planes, tex_resp, tex_small, vol_cent, annot, hist, featK, seg, sweeps, narrow;
-    int *slic_fail_host = nullptr;              // page-locked word the persistent sweep kernel raises when it cannot take the image
-    int feat_mask = 0, feat_F = 0;              // layout of the resident feature table (imsegm_image2d_features_color)
-    // the ten SLIC sweeps (30 kernel launches + a memset) as one captured HIP graph, re-used while every launch parameter
-    // (sizes, pointers, weights: `slic_key`, the bytes of a SlicGraphKey) stays the same -- a recycled session replays it
-    hipGraphExec_t slic_exec = nullptr;
-    std::vector<unsigned char> slic_key;
-};
-
-// entry points are specific to colour images (D == 1) or gray volumes (created by imsegm_volume_create)
-static int wrong_kind(const imsegm_image2d *im, bool want_volume)
+// ---------------------------------------------------------------------------------------------------
+// what of the 2-D SLIC state follows from the image size and the parameters (shared by api.hip and batch.hip):
+// centroid grid (slic_superpixels.py _get_grid_centroids), integer steps (_slic.pyx), fp32 margin
+// ---------------------------------------------------------------------------------------------------
+int slic_geometry(int H, int W, int n_segments, double compactness, int minmax_normalize, int max_candidates, int slic_zero,
+                  SlicState &s, SlicGeometry &geo)
 {
-    if (im && im->is_volume != want_volume) {
-        set_error(want_volume ? "this call needs a volume session" : "this call needs a 2-D colour image session");
-        return 1;
-    }
-    return 0;
-}
-
-static std::atomic<bool> g_runtime_started{ false };      // a HIP call has been made through this library (imsegm_init is too late)
-
-static int bind(imsegm_ctx *ctx)
-{
-    if (!ctx) {
-        set_error("null context");
+    long shape[3] = { 1, H, W };
+    GridAxis ax[3];
+    regular_grid3(shape, n_segments, ax);
+    long ny = 0, nx = 0;
+    for (long y = ax[1].start; y < H; y += ax[1].step) ny++;
+    for (long x = ax[2].start; x < W; x += ax[2].step) nx++;
+    // (depth axis: one z = 0 plane, z start is always 0 for a length-1 axis)
+    const int K = (int)(ny * nx);
+    if (K < 1) {
+        set_error("slic: empty centroid grid");
         return -1;
     }
-    HIP_TRY(hipSetDevice(ctx->device));
+    double fsteps[3];
+    for (int i = 0; i < 3; ++i) fsteps[i] = ax[i].all ? 1.0 : (double)ax[i].step;
+    float step = (float)std::max(fsteps[0], std::max(fsteps[1], fsteps[2]));
+    GridAxis axk[3];
+    regular_grid3(shape, K, axk);
+    memset(&s, 0, sizeof(s));                              // (padding included: the bytes are the key of the cached graph)
+    s.H = H; s.W = W; s.K = K;
+    s.step_y = axk[1].all ? 1 : (int)axk[1].step;
+    s.step_x = axk[2].all ? 1 : (int)axk[2].step;
+    s.spatial_weight = 1.0 / ((double)step * (double)step);
+    s.assign_units = 1;
+    {
+        // fp32 pre-selection margin (k_slic_assign): valid when the image entering rgb2lab lies in
+        // [0, 1] (then |L|, |a|, |b| <= 108 before and after the convex blur), i.e. whenever the
+        // min-max scaling is applied or the data already spans exactly [0, 1]
+        const double u = 5.9604644775390625e-8;                      // 2^-24
+        const double M = 108.0 * (1.0 / compactness) * 1.001;
+        const double R = 2.0 * std::max(s.step_y, s.step_x) + 1.0;
+        const double E = 3.0 * R + 64.0;
+        const double G = sqrt(2.0 * s.spatial_weight) * E + sqrt(3.0) * 4.0 * M + 16.0;
+        s.kappa = (float)(2.0 * u * (G + 1.0) * 1.0001);
+        s.fast32 = (minmax_normalize != 0 && max_candidates >= 0 && s.kappa < 1e-2f && M < 4096.0) ? 1 : 0;
+    }
+    s.slico = slic_zero ? 1 : 0;
+    s.grid_y0 = (int)ax[1].start; s.grid_dy = (int)ax[1].step;
+    s.grid_x0 = (int)ax[2].start; s.grid_dx = (int)ax[2].step; s.grid_nx = (int)nx;
+    geo.K = K;
+    geo.n_tiles = (size_t)cdiv(W, SLIC_TILE_X) * cdiv(H, SLIC_TILE_Y);
     return 0;
 }
 
-// the session's page of reduction words: zeroed once where it is allocated (launch_minmax leaves its words at zero, slic.hip)
-static int ensure_small(imsegm_image2d *im)
+// the pointers of the state into the centroid block (slic_cent_bytes) and the tile block (slic_tiles_bytes)
+void slic_place_state(SlicState &s, const SlicGeometry &geo, unsigned char *cent, unsigned char *tiles, const double *premax, int *fail_host)
 {
-    if (im->small.cap >= 4096) return 0;
-    if (im->small.ensure(4096)) return -1;
-    HIP_TRY(hipMemsetAsync(im->small.p, 0, 4096, im->ctx->stream));
-    return 0;
+    const int K = geo.K;
+    const size_t n_tiles = geo.n_tiles;
+    s.premax = premax;
+    unsigned char *cb = cent;
+    s.acc = reinterpret_cast<long long *>(cb); cb += (size_t)K * 9 * 8;
+    s.cy = reinterpret_cast<double *>(cb); cb += (size_t)K * 8;
+    s.cx = reinterpret_cast<double *>(cb); cb += (size_t)K * 8;
+    s.cL = reinterpret_cast<double *>(cb); cb += (size_t)K * 8;
+    s.ca = reinterpret_cast<double *>(cb); cb += (size_t)K * 8;
+    s.cb = reinterpret_cast<double *>(cb); cb += (size_t)K * 8;
+    s.win = reinterpret_cast<int4 *>(cb); cb += (size_t)K * 16;
+    s.mdc = reinterpret_cast<double *>(cb); cb += (size_t)K * 8;
+    s.drift = reinterpret_cast<int *>(cb); cb += SLIC_DRIFT_SLOTS * sizeof(int);
+    s.done = reinterpret_cast<int *>(cb); cb += (size_t)K * sizeof(int);
+    s.fail_host = fail_host;
+    s.tile_cands = reinterpret_cast<Cand *>(tiles);
+    unsigned char *tb = tiles + n_tiles * SLIC_MAXC * sizeof(Cand);
+    s.tile_rec = reinterpret_cast<Rec32 *>(tb); tb += n_tiles * SLIC_MAXC * sizeof(Rec32);
+    s.tile_info = reinterpret_cast<TileInfo *>(tb); tb += n_tiles * sizeof(TileInfo);
+    s.tile_k = reinterpret_cast<int *>(tb); tb += n_tiles * SLIC_MAXC * sizeof(int);
+    s.tile_count = reinterpret_cast<int *>(tb);
+    s.leftover_count = s.tile_count + n_tiles + 16;
+    s.leftover = s.leftover_count + 16;
 }
 
-// skimage.util.regular_grid (util/_regular_grid.py, 0.18) for a 3-D shape
-struct GridAxis {
-    long start, step;
-    bool all;
-};
-static void regular_grid3(const long shape[3], long n_points, GridAxis out[3])
-{
-    int order[3] = { 0, 1, 2 };
-    std::stable_sort(order, order + 3, [&](int a, int b) { return shape[a] < shape[b]; });
-    double sorted_dims[3] = { (double)shape[order[0]], (double)shape[order[1]], (double)shape[order[2]] };
-    double space = sorted_dims[0] * sorted_dims[1] * sorted_dims[2];
-    if (space <= (double)n_points) {
-        for (int i = 0; i < 3; ++i) out[i] = { 0, 1, true };
-        return;
-    }
-    double steps[3];
-    for (int i = 0; i < 3; ++i) steps[i] = pow(space / (double)n_points, 1.0 / 3);
-    bool any_small = false;
-    for (int i = 0; i < 3; ++i) any_small |= sorted_dims[i] < steps[i];
-    if (any_small) {
-        for (int dim = 0; dim < 3; ++dim) {
-            steps[dim] = sorted_dims[dim];
-            double sp = 1.0;
-            for (int j = dim + 1; j < 3; ++j) sp *= sorted_dims[j];
-            if (dim < 2) {
-                double s = pow(sp / (double)n_points, 1.0 / (3 - dim - 1));
-                for (int j = dim + 1; j < 3; ++j) steps[j] = s;
-            }
-            bool ok = true;
-            for (int j = 0; j < 3; ++j) ok &= sorted_dims[j] >= steps[j];
-            if (ok) break;
-        }
-    }
-    for (int i = 0; i < 3; ++i) {
-        long start = (long)floor(steps[i] / 2.0);
-        long step = (long)nearbyint(steps[i]);
-        out[order[i]] = { start, step, false };
-    }
-}
-
-static int fill_taps(Taps &t, const double *w, int r)
-{
-    t.r = -1;
-    for (int i = 0; i < 17; ++i) t.w[i] = 0;
-    if (r < 0 || !w) return 0;
-    if (r > 16) {
-        set_error("gaussian kernel radius > 16 is not supported");
-        return -1;
-    }
-    t.r = r;
-    for (int i = 0; i <= r; ++i) t.w[i] = w[i];
-    return 0;
-}
-
-static bool is_pinned(const void *p)
-{
-    hipPointerAttribute_t attr;
-    if (hipPointerGetAttributes(&attr, p) != hipSuccess) {
-        (void)hipGetLastError();
-        return false;
-    }
-    return attr.type == hipMemoryTypeHost;
-}
 
 extern "C" {
 
@@ -535,33 +380,18 @@ int imsegm_image2d_slic(imsegm_image2d *im, int minmax_normalize, int n_segments
     Taps tz, ty, tx;
     if (fill_taps(tz, taps_z, radius_z) || fill_taps(ty, taps_y, radius_y) || fill_taps(tx, taps_x, radius_x)) return -1;
 
-    // centroid grid (slic_superpixels.py _get_grid_centroids) and integer steps (_slic.pyx)
-    long shape[3] = { 1, H, W };
-    GridAxis ax[3];
-    regular_grid3(shape, n_segments, ax);
-    long ny = 0, nx = 0;
-    for (long y = ax[1].start; y < H; y += ax[1].step) ny++;
-    for (long x = ax[2].start; x < W; x += ax[2].step) nx++;
-    // (depth axis: one z = 0 plane, z start is always 0 for a length-1 axis)
-    const int K = (int)(ny * nx);
-    if (K < 1) {
-        set_error("slic: empty centroid grid");
-        return -1;
-    }
-    double fsteps[3];
-    for (int i = 0; i < 3; ++i) fsteps[i] = ax[i].all ? 1.0 : (double)ax[i].step;
-    float step = (float)std::max(fsteps[0], std::max(fsteps[1], fsteps[2]));
-    GridAxis axk[3];
-    regular_grid3(shape, K, axk);
+    // centroid grid, steps, fp32 margin: everything of the SLIC state that follows from the sizes
+    SlicState s;
+    SlicGeometry geo;
+    if (slic_geometry(H, W, n_segments, compactness, minmax_normalize, max_candidates, slic_zero, s, geo)) return -1;
+    const int K = geo.K;
+    const size_t n_tiles = geo.n_tiles;
 
     // buffers
     if (im->labA.ensure(3 * n * sizeof(double)) || im->labB.ensure(3 * n * sizeof(double))) return -1;
     if (im->nearest.ensure(n * 4) || im->labels.ensure(n * 4)) return -1;
-    size_t cent_bytes = (size_t)K * (5 * 8 + 16 + 9 * 8 + 16 + 4) + 256 + SLIC_DRIFT_SLOTS * sizeof(int);
-    if (im->cent.ensure(cent_bytes)) return -1;
-    const size_t n_tiles = (size_t)cdiv(W, SLIC_TILE_X) * cdiv(H, SLIC_TILE_Y);
-    if (im->tiles.ensure(n_tiles * (SLIC_MAXC * (sizeof(Cand) + sizeof(Rec32) + sizeof(int)) + sizeof(TileInfo) + sizeof(int)) + n * 4 + 1024))
-        return -1;
+    if (im->cent.ensure(slic_cent_bytes(K))) return -1;
+    if (im->tiles.ensure(slic_tiles_bytes(n_tiles, n))) return -1;
     if (ensure_small(im)) return -1;
 
     unsigned long long *keys = im->small.as<unsigned long long>();
@@ -576,13 +406,6 @@ int imsegm_image2d_slic(imsegm_image2d *im, int minmax_normalize, int n_segments
         return -1;
     ctx->end(sp);
 
-    SlicState s;
-    memset(&s, 0, sizeof(s));                              // (padding included: the bytes are the key of the cached graph)
-    s.H = H; s.W = W; s.K = K;
-    s.step_y = axk[1].all ? 1 : (int)axk[1].step;
-    s.step_x = axk[2].all ? 1 : (int)axk[2].step;
-    s.spatial_weight = 1.0 / ((double)step * (double)step);
-    s.premax = premax;
     // profiling aids: read once per process (nothing of the hot path looks at the environment per image)
     static const int env_debug = getenv("IMSEGM_DEBUG_ASSIGN") ? atoi(getenv("IMSEGM_DEBUG_ASSIGN")) : 0;
     static const int env_units = getenv("IMSEGM_ASSIGN_UNITS") ? atoi(getenv("IMSEGM_ASSIGN_UNITS")) : 1;
@@ -599,46 +422,10 @@ int imsegm_image2d_slic(imsegm_image2d *im, int minmax_normalize, int n_segments
         }
         s.phase_prof = phase_buf;
     }
-    {
-        // fp32 pre-selection margin (k_slic_assign): valid when the image entering rgb2lab lies in
-        // [0, 1] (then |L|, |a|, |b| <= 108 before and after the convex blur), i.e. whenever the
-        // min-max scaling is applied or the data already spans exactly [0, 1]
-        const double u = 5.9604644775390625e-8;                      // 2^-24
-        const double M = 108.0 * (1.0 / compactness) * 1.001;
-        const double R = 2.0 * std::max(s.step_y, s.step_x) + 1.0;
-        const double E = 3.0 * R + 64.0;
-        const double G = sqrt(2.0 * s.spatial_weight) * E + sqrt(3.0) * 4.0 * M + 16.0;
-        s.kappa = (float)(2.0 * u * (G + 1.0) * 1.0001);
-        s.fast32 = (minmax_normalize != 0 && max_candidates >= 0 && s.kappa < 1e-2f && M < 4096.0) ? 1 : 0;
-    }
-    unsigned char *cb = im->cent.as<unsigned char>();
-    s.acc = reinterpret_cast<long long *>(cb); cb += (size_t)K * 9 * 8;
-    s.cy = reinterpret_cast<double *>(cb); cb += (size_t)K * 8;
-    s.cx = reinterpret_cast<double *>(cb); cb += (size_t)K * 8;
-    s.cL = reinterpret_cast<double *>(cb); cb += (size_t)K * 8;
-    s.ca = reinterpret_cast<double *>(cb); cb += (size_t)K * 8;
-    s.cb = reinterpret_cast<double *>(cb); cb += (size_t)K * 8;
-    s.win = reinterpret_cast<int4 *>(cb); cb += (size_t)K * 16;
-    s.mdc = reinterpret_cast<double *>(cb); cb += (size_t)K * 8;
-    s.slico = slic_zero ? 1 : 0;
-    s.drift = reinterpret_cast<int *>(cb); cb += SLIC_DRIFT_SLOTS * sizeof(int);
     // arrival counters + the page-locked failure word of the centroid update inside the assignment kernel
     if (!im->slic_fail_host) HIP_TRY(hipHostMalloc((void **)&im->slic_fail_host, 64, hipHostMallocDefault));
-    s.done = reinterpret_cast<int *>(cb); cb += (size_t)K * sizeof(int);
-    s.fail_host = im->slic_fail_host;
-    s.grid_y0 = (int)ax[1].start; s.grid_dy = (int)ax[1].step;
-    s.grid_x0 = (int)ax[2].start; s.grid_dx = (int)ax[2].step; s.grid_nx = (int)nx;
+    slic_place_state(s, geo, im->cent.as<unsigned char>(), im->tiles.as<unsigned char>(), premax, im->slic_fail_host);
     double *init_dev = nullptr;                            // the grid is generated on the device
-    s.tile_cands = im->tiles.as<Cand>();
-    {
-        unsigned char *tb = im->tiles.as<unsigned char>() + n_tiles * SLIC_MAXC * sizeof(Cand);
-        s.tile_rec = reinterpret_cast<Rec32 *>(tb); tb += n_tiles * SLIC_MAXC * sizeof(Rec32);
-        s.tile_info = reinterpret_cast<TileInfo *>(tb); tb += n_tiles * sizeof(TileInfo);
-        s.tile_k = reinterpret_cast<int *>(tb); tb += n_tiles * SLIC_MAXC * sizeof(int);
-        s.tile_count = reinterpret_cast<int *>(tb);
-    }
-    s.leftover_count = s.tile_count + n_tiles + 16;
-    s.leftover = s.leftover_count + 16;
 
     ProfHook hook;
     if (ctx->profile) {
@@ -1300,23 +1087,7 @@ int imsegm_volume_upload(imsegm_image2d *im, const void *host_voxels, int dtype,
 
 static ConnWork make_conn_work(imsegm_image2d *im)
 {
-    const size_t n = im->n;
-    ConnWork w;
-    int32_t *b = im->conn_i32.as<int32_t>();
-    w.parent = b; b += n;
-    w.csize = b; b += n;
-    w.newlabel = b; b += n;
-    w.adjptr = b; b += n;
-    w.queue = b; b += n;
-    w.list = b; b += n;
-    w.slotmap = b; b += n;
-    w.bbox = b; b += n;
-    w.blocksum = b; b += (n / 4096) + 32;
-    w.counters = b; b += 64;
-    w.dense = b;
-    w.dense_ints = (im->conn_i32.cap - (size_t)((unsigned char *)b - im->conn_i32.as<unsigned char>())) / 4;
-    w.visited = im->conn_u8.as<uint8_t>();
-    return w;
+    return conn_work_from(im->conn_i32.as<int32_t>(), im->conn_i32.cap, im->conn_u8.as<uint8_t>(), im->n);
 }
 
 int imsegm_volume_slic(imsegm_image2d *im, int n_segments, double compactness, const double *taps_z, int radius_z,

@@ -431,8 +431,10 @@ template <int CELLS, int FMAX, bool HOP2>
 __global__ void __launch_bounds__(64)
 k_small_bfs_wave(const int32_t *__restrict__ list, int32_t *counters, const int32_t *__restrict__ count,
                  const int32_t *__restrict__ parent, const int32_t *__restrict__ bbox, int D, int H, int W,
-                 const int32_t *__restrict__ order, int capacity, int32_t *adjptr, int32_t *fallback_list)
+                 const int32_t *__restrict__ order, int capacity, int32_t *adjptr, int32_t *fallback_list, size_t zs)
 {
+    ZSHIFT(list, zs); ZSHIFT(counters, zs); ZSHIFT(count, zs); ZSHIFT(parent, zs); ZSHIFT(bbox, zs); ZSHIFT(order, zs); ZSHIFT(adjptr, zs);
+    ZSHIFT(fallback_list, zs);
     __shared__ unsigned int prop[CELLS];
     __shared__ uint8_t cls[CELLS];       // 0 other, 1 member unvisited, 2 earlier foreign, 3 member visited
     __shared__ uint16_t fr[2][FMAX];
@@ -585,8 +587,9 @@ k_small_bfs_fallback(const int32_t *__restrict__ list_all, const int32_t *__rest
 
 __global__ void __launch_bounds__(256)
 k_write_labels(const int32_t *__restrict__ parent, const int32_t *__restrict__ newlabel, int n, int32_t *out,
-               const int32_t *__restrict__ abort_flag)
+               const int32_t *__restrict__ abort_flag, size_t zs)
 {
+    ZSHIFT(parent, zs); ZSHIFT(newlabel, zs); ZSHIFT(out, zs); ZSHIFT(abort_flag, zs);
     int p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= n || (abort_flag && *abort_flag)) return;
     out[p] = newlabel[parent[p]];
@@ -632,11 +635,11 @@ static int conn_tail(const int32_t *csize_final, int32_t *adjptr, int D, int H, 
     // one launch for all of them, long ones first (w.queue is free until the fallback kernel)
     hipLaunchKernelGGL(k_small_order, 64, 256, 0, st, bbox, w.counters, D, H, W, 1024, capacity, w.queue);
     hipLaunchKernelGGL((k_small_bfs_wave<8192, 2048, false>), 2048, 64, 0, st, w.list, w.counters, w.counters + CNT_SMALL, w.parent,
-                       bbox, D, H, W, w.queue, capacity, adjptr, fallback_list);
+                       bbox, D, H, W, w.queue, capacity, adjptr, fallback_list, (size_t)0);
     hipLaunchKernelGGL(k_small_bfs_fallback, 64, 64, 0, st, w.list, fallback_list, w.counters, w.parent, csize_final, D, H,
                        W, capacity, w.queue, w.visited, w.counters + CNT_CURSOR, adjptr);
     hipLaunchKernelGGL(k_small_resolve, 64, 64, 0, st, w.list, w.counters, csize_final, adjptr, min_size, w.newlabel);
-    hipLaunchKernelGGL(k_write_labels, grid, 256, 0, st, w.parent, w.newlabel, n, labels_out, (const int32_t *)nullptr);
+    hipLaunchKernelGGL(k_write_labels, grid, 256, 0, st, w.parent, w.newlabel, n, labels_out, (const int32_t *)nullptr, (size_t)0);
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -727,8 +730,10 @@ __global__ void __launch_bounds__(256)
 k_ccl_tile(const int32_t *__restrict__ labels, int H, int W, int32_t *__restrict__ parent, int32_t *__restrict__ csize,
            int32_t *__restrict__ ymax_g, int32_t *__restrict__ xmin_g, int32_t *__restrict__ xmax_g,
            int32_t *__restrict__ lroots, int32_t *__restrict__ lsize, int32_t *__restrict__ lbox, int32_t *__restrict__ ntile,
-           int32_t *counters)
+           int32_t *counters, size_t zs)
 {
+    ZSHIFT(labels, zs); ZSHIFT(parent, zs); ZSHIFT(csize, zs); ZSHIFT(ymax_g, zs); ZSHIFT(xmin_g, zs); ZSHIFT(xmax_g, zs);
+    ZSHIFT(lroots, zs); ZSHIFT(lsize, zs); ZSHIFT(lbox, zs); ZSHIFT(ntile, zs); ZSHIFT(counters, zs);
     __shared__ int slab[CT_H * CT_W];      // labels; after the unions: slot of a local root
     __shared__ int spar[CT_H * CT_W];
     __shared__ int c_root[CT_SLOTS], c_size[CT_SLOTS], c_ymax[CT_SLOTS], c_xmin[CT_SLOTS], c_xmax[CT_SLOTS];
@@ -851,8 +856,9 @@ k_ccl_tile(const int32_t *__restrict__ labels, int H, int W, int32_t *__restrict
 }
 
 __global__ void __launch_bounds__(256)
-k_ccl_border(const int32_t *__restrict__ labels, int H, int W, int32_t *parent, const int32_t *__restrict__ counters)
+k_ccl_border(const int32_t *__restrict__ labels, int H, int W, int32_t *parent, const int32_t *__restrict__ counters, size_t zs)
 {
+    ZSHIFT(labels, zs); ZSHIFT(parent, zs); ZSHIFT(counters, zs);
     if (counters[CNT_FLAG]) return;                  // a tile gave up: parent[] is incomplete, the general path follows
     long t = (long)blockIdx.x * 256 + threadIdx.x;
     const int nby = (H - 1) / CT_H, nbx = (W - 1) / CT_W;
@@ -877,8 +883,10 @@ k_ccl_border(const int32_t *__restrict__ labels, int H, int W, int32_t *parent, 
 __global__ void __launch_bounds__(256)
 k_lroot_merge(const int32_t *__restrict__ lroots, const int32_t *__restrict__ lsize, const int32_t *__restrict__ lbox,
               const int32_t *__restrict__ ntile, int n_slots, const int32_t *__restrict__ counters, int32_t *parent, int32_t *csize, int32_t *ymax_g, int32_t *xmin_g,
-              int32_t *xmax_g, int W)
+              int32_t *xmax_g, int W, size_t zs)
 {
+    ZSHIFT(lroots, zs); ZSHIFT(lsize, zs); ZSHIFT(lbox, zs); ZSHIFT(ntile, zs); ZSHIFT(counters, zs); ZSHIFT(parent, zs); ZSHIFT(csize, zs);
+    ZSHIFT(ymax_g, zs); ZSHIFT(xmin_g, zs); ZSHIFT(xmax_g, zs);
     if (counters[CNT_FLAG]) return;
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n_slots || (i & (CT_SLOTS - 1)) >= ntile[i / CT_SLOTS]) return;
@@ -898,8 +906,9 @@ k_lroot_merge(const int32_t *__restrict__ lroots, const int32_t *__restrict__ ls
 __global__ void __launch_bounds__(1024)
 k_root_classify(const int32_t *__restrict__ lroots, const int32_t *__restrict__ ntile, int n_slots, int32_t *counters,
                 const int32_t *__restrict__ parent, const int32_t *__restrict__ csize, int min_size, int max_size, int32_t *kept,
-                int32_t *list)
+                int32_t *list, size_t zs)
 {
+    ZSHIFT(lroots, zs); ZSHIFT(ntile, zs); ZSHIFT(counters, zs); ZSHIFT(parent, zs); ZSHIFT(csize, zs); ZSHIFT(kept, zs); ZSHIFT(list, zs);
     __shared__ int n_k, n_s, base_k, base_s;
     if (counters[CNT_FLAG]) return;
     if (threadIdx.x == 0) n_k = n_s = 0;
@@ -1007,8 +1016,10 @@ k_small_bfs_reg(const int32_t *__restrict__ list, const int32_t *__restrict__ co
                 const int32_t *__restrict__ parent, const int32_t *__restrict__ ymax_g, const int32_t *__restrict__ xmin_g,
                 const int32_t *__restrict__ xmax_g, int H, int W, int32_t *adjptr, int32_t *rej_list, int rej_counter,
                 int32_t *rej_bbox, int cells_cap, int with_rank, const int32_t *__restrict__ kept, int start_label,
-                int32_t *sorted, int32_t *newlabel)
+                int32_t *sorted, int32_t *newlabel, size_t zs)
 {
+    ZSHIFT(list, zs); ZSHIFT(count, zs); ZSHIFT(counters, zs); ZSHIFT(parent, zs); ZSHIFT(ymax_g, zs); ZSHIFT(xmin_g, zs); ZSHIFT(xmax_g, zs);
+    ZSHIFT(adjptr, zs); ZSHIFT(rej_list, zs); ZSHIFT(rej_bbox, zs); ZSHIFT(kept, zs); ZSHIFT(sorted, zs); ZSHIFT(newlabel, zs);
     static_assert(BR_CELLS + 64 * 4 >= (2 * KR_BUCKETS + 1 + 4 + KR_SORTED_LDS) * 4, "shared memory of the two roles");
     extern __shared__ __align__(16) uint8_t smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -1151,8 +1162,9 @@ k_small_bfs_reg(const int32_t *__restrict__ list, const int32_t *__restrict__ co
 __global__ void __launch_bounds__(256)
 k_lroot_labels(const int32_t *__restrict__ lroots, const int32_t *__restrict__ ntile, int n_slots,
                const int32_t *__restrict__ counters, const int32_t *__restrict__ parent,
-               const int32_t *__restrict__ csize, const int32_t *__restrict__ adjptr, int min_size, int32_t *newlabel)
+               const int32_t *__restrict__ csize, const int32_t *__restrict__ adjptr, int min_size, int32_t *newlabel, size_t zs)
 {
+    ZSHIFT(lroots, zs); ZSHIFT(ntile, zs); ZSHIFT(counters, zs); ZSHIFT(parent, zs); ZSHIFT(csize, zs); ZSHIFT(adjptr, zs); ZSHIFT(newlabel, zs);
     if (counters[CNT_FLAG]) return;
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n_slots || (i & (CT_SLOTS - 1)) >= ntile[i / CT_SLOTS]) return;
@@ -1164,33 +1176,44 @@ k_lroot_labels(const int32_t *__restrict__ lroots, const int32_t *__restrict__ n
     newlabel[r] = g >= 0 ? newlabel[g] : 0;
 }
 
-// returns 0 and *ok = true when the fast path produced the result (labels_out, *n_kept)
+// Enqueues the tile path for zb.nz maps of one size (image b: every pointer b * zb.zs bytes further on) and ends with the ONE
+// host synchronisation of the stage; ok[b] = the fast path produced the result of image b (labels_out, n_kept[b]).
 static int conn_fast_2d(const int32_t *labels_in, int H, int W, int min_size, int max_size, int start_label, const ConnWork &w,
-                        int32_t *labels_out, int *n_kept, bool *ok, hipStream_t st)
+                        int32_t *labels_out, int *n_kept, bool *ok, hipStream_t st, ZBatch zb = ZBatch(), int32_t *batch_stage = nullptr)
 {
+    if (zb.nz > 1 && !batch_stage) {
+        set_error("connectivity: a batch needs a staging area for its counters");
+        return -1;
+    }
     const int n = H * W;
-    const dim3 tiles(cdiv(W, CT_W), cdiv(H, CT_H));
+    const unsigned nz = (unsigned)zb.nz;
+    const size_t zs = zb.zs;
+    const dim3 tiles(cdiv(W, CT_W), cdiv(H, CT_H), nz);
     const int n_tiles = tiles.x * tiles.y, n_slots = n_tiles * CT_SLOTS;
     if (CONN_DENSE_INTS + (size_t)n_tiles * (3 * CT_SLOTS + 1) > w.dense_ints) {
-        *ok = false;                                  // scratch sized without the per-tile lists: the general path takes it
+        for (unsigned b = 0; b < nz; ++b) ok[b] = false;  // scratch sized without the per-tile lists: the general path takes it
         return 0;
     }
     const ConnDense d = conn_dense(w, n_tiles);
     int32_t *ymax_g = w.queue, *xmin_g = w.slotmap, *xmax_g = w.bbox;
-    int32_t host_counters[16];
-    HIP_TRY(hipMemsetAsync(w.counters, 0, 16 * sizeof(int32_t), st));
+    std::vector<int32_t> host_counters((size_t)16 * nz);
+    if (launch_zero(w.counters, 16 * sizeof(int32_t), st, zb)) return -1;
     hipLaunchKernelGGL(k_ccl_tile, tiles, 256, 0, st, labels_in, H, W, w.parent, w.csize, ymax_g, xmin_g, xmax_g, d.lroots, d.lsize,
-                       d.lbox, d.ntile, w.counters);
+                       d.lbox, d.ntile, w.counters, zs);
     const long nborder = (long)((H - 1) / CT_H) * W + (long)((W - 1) / CT_W) * H;
-    if (nborder > 0) hipLaunchKernelGGL(k_ccl_border, cdiv(nborder, 256), 256, 0, st, labels_in, H, W, w.parent, w.counters);
-    const int lgrid = cdiv(n_slots, 256);
+    if (nborder > 0)
+        hipLaunchKernelGGL(k_ccl_border, dim3(cdiv(nborder, 256), 1, nz), 256, 0, st, labels_in, H, W, w.parent, w.counters, zs);
+    const dim3 lgrid(cdiv(n_slots, 256), 1, nz);
     hipLaunchKernelGGL(k_lroot_merge, lgrid, 256, 0, st, d.lroots, d.lsize, d.lbox, d.ntile, n_slots, w.counters, w.parent, w.csize, ymax_g,
-                       xmin_g, xmax_g, W);
-    hipLaunchKernelGGL(k_root_classify, cdiv(n_slots, 1024), 1024, 0, st, d.lroots, d.ntile, n_slots, w.counters, w.parent, w.csize, min_size, max_size, d.kept,
-                       w.list);
-    hipLaunchKernelGGL(k_small_bfs_reg, 2048 + 1, 256, BR_CELLS + 256, st, w.list, w.counters + CNT_SMALL, n, w.counters, w.parent,
+                       xmin_g, xmax_g, W, zs);
+    hipLaunchKernelGGL(k_root_classify, dim3(cdiv(n_slots, 1024), 1, nz), 1024, 0, st, d.lroots, d.ntile, n_slots, w.counters, w.parent, w.csize,
+                       min_size, max_size, d.kept, w.list, zs);
+    // (a batch: the images are much smaller than the 2048^2 the 2 048 workgroups were sized for -- a workgroup takes the small
+    // components i, i + grid, ... of its image)
+    const int bfs_blocks = nz > 1 ? std::max(64, 2048 / (int)nz) : 2048;
+    hipLaunchKernelGGL(k_small_bfs_reg, dim3(bfs_blocks + 1, 1, nz), 256, BR_CELLS + 256, st, w.list, w.counters + CNT_SMALL, n, w.counters, w.parent,
                        ymax_g, xmin_g, xmax_g, H, W, w.adjptr, d.fb_list, (int)CNT_FB, d.fb_bbox, BR_CELLS, 1, d.kept, start_label,
-                       d.sorted, w.newlabel);
+                       d.sorted, w.newlabel, zs);
     // bounding boxes beyond the 16 K tile (long thin slivers): the same kernel with a 128 K tile, a few workgroups
     {
         static bool big_attr[IMSEGM_MAX_DEVICES];
@@ -1201,23 +1224,50 @@ static int conn_fast_2d(const int32_t *labels_in, int H, int W, int min_size, in
             if (dev >= 0 && dev < IMSEGM_MAX_DEVICES) big_attr[dev] = true;
         }
     }
-    hipLaunchKernelGGL(k_small_bfs_reg, 128, 256, BR_CELLS_BIG + 256, st, d.fb_list, w.counters + CNT_FB, CONN_FB_CAP, w.counters,
-                       w.parent, ymax_g, xmin_g, xmax_g, H, W, w.adjptr, d.fb2_list, (int)CNT_FB2, d.fb2_bbox, BR_CELLS_BIG, 0,
-                       d.kept, start_label, d.sorted, w.newlabel);
+    hipLaunchKernelGGL(k_small_bfs_reg, dim3(nz > 1 ? 32 : 128, 1, nz), 256, BR_CELLS_BIG + 256, st, d.fb_list, w.counters + CNT_FB, CONN_FB_CAP,
+                       w.counters, w.parent, ymax_g, xmin_g, xmax_g, H, W, w.adjptr, d.fb2_list, (int)CNT_FB2, d.fb2_bbox, BR_CELLS_BIG, 0,
+                       d.kept, start_label, d.sorted, w.newlabel, zs);
     // frontiers of more than 64 cells: the LDS-frontier kernel; what this one cannot take either ends up in CNT_FALLBACK and
     // sends the image to the general path
-    hipLaunchKernelGGL((k_small_bfs_wave<8192, 2048, true>), 256, 64, 0, st, d.fb2_list, w.counters, w.counters + CNT_FB2, w.parent,
-                       d.fb2_bbox, 1, H, W, (const int32_t *)nullptr, CONN_FB_CAP, w.adjptr, d.fb_reject);
-    hipLaunchKernelGGL(k_lroot_labels, lgrid, 256, 0, st, d.lroots, d.ntile, n_slots, w.counters, w.parent, w.csize, w.adjptr, min_size, w.newlabel);
-    hipLaunchKernelGGL(k_write_labels, cdiv(n, 256), 256, 0, st, w.parent, w.newlabel, n, labels_out,
-                       (const int32_t *)(w.counters + CNT_FLAG));
+    hipLaunchKernelGGL((k_small_bfs_wave<8192, 2048, true>), dim3(nz > 1 ? 64 : 256, 1, nz), 64, 0, st, d.fb2_list, w.counters, w.counters + CNT_FB2,
+                       w.parent, d.fb2_bbox, 1, H, W, (const int32_t *)nullptr, CONN_FB_CAP, w.adjptr, d.fb_reject, zs);
+    hipLaunchKernelGGL(k_lroot_labels, lgrid, 256, 0, st, d.lroots, d.ntile, n_slots, w.counters, w.parent, w.csize, w.adjptr, min_size,
+                       w.newlabel, zs);
+    hipLaunchKernelGGL(k_write_labels, dim3(cdiv(n, 256), 1, nz), 256, 0, st, w.parent, w.newlabel, n, labels_out,
+                       (const int32_t *)(w.counters + CNT_FLAG), zs);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpyAsync(host_counters, w.counters, 16 * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    if (nz == 1) {
+        HIP_TRY(hipMemcpyAsync(host_counters.data(), w.counters, 16 * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    } else {
+        // the counter blocks of the images side by side behind the last image's (its `dense` lists are through), one transfer
+        int32_t *stage = batch_stage;
+        if (launch_copy_rows(stage, 16 * sizeof(int32_t), w.counters, zs, 16 * sizeof(int32_t), (int)nz, st)) return -1;
+        HIP_TRY(hipMemcpyAsync(host_counters.data(), stage, (size_t)nz * 16 * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    }
     HIP_TRY(hipStreamSynchronize(st));
-    *ok = host_counters[CNT_FLAG] == 0 && host_counters[CNT_OVER] == 0 && host_counters[CNT_FALLBACK] == 0 &&
-          host_counters[CNT_KEPT] <= CONN_KEPT_CAP &&
-          host_counters[CNT_FB] <= CONN_FB_CAP && host_counters[CNT_FB2] <= CONN_FB_CAP;
-    *n_kept = host_counters[CNT_KEPT];
+    for (unsigned b = 0; b < nz; ++b) {
+        const int32_t *hc = host_counters.data() + (size_t)16 * b;
+        ok[b] = hc[CNT_FLAG] == 0 && hc[CNT_OVER] == 0 && hc[CNT_FALLBACK] == 0 && hc[CNT_KEPT] <= CONN_KEPT_CAP &&
+                hc[CNT_FB] <= CONN_FB_CAP && hc[CNT_FB2] <= CONN_FB_CAP;
+        n_kept[b] = hc[CNT_KEPT];
+    }
+    return 0;
+}
+
+// The tile path for a batch of label maps of one size (csrc/batch.hip): image b lives b * zb.zs bytes behind every pointer of `w`,
+// labels_in and labels_out.  n_labels_out[b] < 0: image b has to go through launch_enforce_connectivity by itself (the general path).
+int launch_enforce_connectivity_batch(const int32_t *labels_in, int H, int W, long min_size_l, long max_size_l, int start_label, ConnWork w,
+                                      int32_t *labels_out, int *n_labels_out, hipStream_t st, ZBatch zb, int32_t *stage_dev)
+{
+    const int min_size = (int)std::min<long>(min_size_l, 0x7fffffff);
+    const int max_size = (int)std::min<long>(max_size_l, 0x7fffffff);
+    std::vector<int> n_kept(zb.nz);
+    std::vector<char> ok(zb.nz);
+    static_assert(sizeof(bool) == sizeof(char), "ok flags");
+    if (conn_fast_2d(labels_in, H, W, min_size, max_size, start_label, w, labels_out, n_kept.data(), reinterpret_cast<bool *>(ok.data()), st, zb,
+                     stage_dev))
+        return -1;
+    for (int b = 0; b < zb.nz; ++b) n_labels_out[b] = ok[b] ? (n_kept[b] > 0 ? start_label + n_kept[b] : 1) : -1;
     return 0;
 }
 

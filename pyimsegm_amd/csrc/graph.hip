@@ -25,8 +25,9 @@ constexpr int GR_SLOTS = 64;      // LDS hash slots for the centre sums of a wor
 // label that finds no slot (more than GR_SLOTS labels in a 64 x 16 tile) goes to the global sums directly.
 __global__ void __launch_bounds__(256)
 k_adjacency_centres(const int32_t *__restrict__ labels, int H, int W, int K, int words, uint32_t *bitmap,
-                    long long *__restrict__ cacc)
+                    long long *__restrict__ cacc, size_t zs)
 {
+    ZSHIFT(labels, zs); ZSHIFT(bitmap, zs); ZSHIFT(cacc, zs);
     __shared__ int h_key[GR_SLOTS], h_n[GR_SLOTS], h_sy[GR_SLOTS], h_sx[GR_SLOTS];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if (threadIdx.x < GR_SLOTS) {
@@ -103,8 +104,9 @@ k_adjacency_centres(const int32_t *__restrict__ labels, int H, int W, int K, int
     }
 }
 
-__global__ void k_centres_finalize(const long long *__restrict__ cacc, int K, double *centres, uint8_t *present)
+__global__ void k_centres_finalize(const long long *__restrict__ cacc, int K, double *centres, uint8_t *present, size_t zs)
 {
+    ZSHIFT(cacc, zs); ZSHIFT(centres, zs); ZSHIFT(present, zs);
     int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= K) return;
     long long n = cacc[(size_t)k * 3];
@@ -172,21 +174,59 @@ __global__ void k_edge_emit(const uint32_t *__restrict__ bitmap, int K, int word
     }
 }
 
+// zero `bytes` bytes (a multiple of 4, 4-byte aligned) of every image of a batch in one launch
+__global__ void __launch_bounds__(256) k_zero_words(uint32_t *p, size_t words, size_t zs)
+{
+    ZSHIFT(p, zs);
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < words; i += (size_t)gridDim.x * 256) p[i] = 0u;
+}
+
+int launch_zero(void *ptr, size_t bytes, hipStream_t st, ZBatch zb)
+{
+    if (zb.nz <= 1) {
+        HIP_TRY(hipMemsetAsync(ptr, 0, bytes, st));
+        return 0;
+    }
+    const size_t words = (bytes + 3) / 4;
+    const int gx = (int)std::min<size_t>(std::max<size_t>(cdiv((long)words, 256 * 8), 1), 256);
+    hipLaunchKernelGGL(k_zero_words, dim3(gx, 1, zb.nz), 256, 0, st, static_cast<uint32_t *>(ptr), words, zb.zs);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+// rows of `words` 32-bit words between a strided and a contiguous layout (the small per-image blocks of a batch: parameters in,
+// counters out -- one transfer over the host link for the batch instead of one per image)
+__global__ void __launch_bounds__(256) k_copy_rows(uint32_t *dst, size_t dst_stride, const uint32_t *src, size_t src_stride, size_t words)
+{
+    dst = zshift(dst, dst_stride);
+    src = zshift(src, src_stride);
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < words; i += (size_t)gridDim.x * 256) dst[i] = src[i];
+}
+
+int launch_copy_rows(void *dst, size_t dst_stride, const void *src, size_t src_stride, size_t bytes, int rows, hipStream_t st)
+{
+    const size_t words = (bytes + 3) / 4;
+    const int gx = (int)std::min<size_t>(std::max<size_t>(cdiv((long)words, 256 * 4), 1), 64);
+    hipLaunchKernelGGL(k_copy_rows, dim3(gx, 1, rows), 256, 0, st, static_cast<uint32_t *>(dst), dst_stride, static_cast<const uint32_t *>(src),
+                       src_stride, words);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
 int launch_adjacency_bitmap(const int32_t *labels, int H, int W, int K, uint32_t *bitmap, long long *cacc, double *centres_out,
-                            uint8_t *present_out, hipStream_t st)
+                            uint8_t *present_out, hipStream_t st, ZBatch zb)
 {
     int words = cdiv(K, 32);
     // (one fill when the sums sit right behind the bitmap, as the fused call lays them out)
     const size_t bm_bytes = (size_t)K * words * sizeof(uint32_t), gap = (size_t)((const char *)cacc - (const char *)bitmap);
     if ((const char *)cacc >= (const char *)bitmap + bm_bytes && gap <= bm_bytes + 64) {
-        HIP_TRY(hipMemsetAsync(bitmap, 0, gap + (size_t)K * 3 * sizeof(long long), st));
+        if (launch_zero(bitmap, gap + (size_t)K * 3 * sizeof(long long), st, zb)) return -1;
     } else {
-        HIP_TRY(hipMemsetAsync(bitmap, 0, bm_bytes, st));
-        HIP_TRY(hipMemsetAsync(cacc, 0, (size_t)K * 3 * sizeof(long long), st));
+        if (launch_zero(bitmap, bm_bytes, st, zb) || launch_zero(cacc, (size_t)K * 3 * sizeof(long long), st, zb)) return -1;
     }
-    dim3 grid(cdiv(W, 64), cdiv(H, 4 * GR_ROWS));
-    hipLaunchKernelGGL(k_adjacency_centres, grid, 256, 0, st, labels, H, W, K, words, bitmap, cacc);
-    hipLaunchKernelGGL(k_centres_finalize, cdiv(K, 256), 256, 0, st, cacc, K, centres_out, present_out);
+    dim3 grid(cdiv(W, 64), cdiv(H, 4 * GR_ROWS), zb.nz);
+    hipLaunchKernelGGL(k_adjacency_centres, grid, 256, 0, st, labels, H, W, K, words, bitmap, cacc, zb.zs);
+    hipLaunchKernelGGL(k_centres_finalize, dim3(cdiv(K, 256), 1, zb.nz), 256, 0, st, cacc, K, centres_out, present_out, zb.zs);
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -195,7 +235,7 @@ int launch_adjacency_centres(const int32_t *labels, int H, int W, int K, uint32_
                              int32_t *edges_out, int edge_capacity, int32_t *n_edges_dev, double *centres_out,
                              uint8_t *present_out, int32_t *rowcount, hipStream_t st)
 {
-    if (launch_adjacency_bitmap(labels, H, W, K, bitmap, cacc, centres_out, present_out, st)) return -1;
+    if (launch_adjacency_bitmap(labels, H, W, K, bitmap, cacc, centres_out, present_out, st, ZBatch())) return -1;
     return launch_edge_extract(bitmap, K, cdiv(K, 32), rowcount, edges_out, edge_capacity, n_edges_dev, st);
 }
 
@@ -212,8 +252,9 @@ int launch_edge_extract(const uint32_t *bitmap, int K, int words, int32_t *rowco
 
 // ---- LUT gathers --------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
-k_gather_i32(const int32_t *__restrict__ lut, const int32_t *__restrict__ idx, size_t n, int32_t *__restrict__ out)
+k_gather_i32(const int32_t *__restrict__ lut, const int32_t *__restrict__ idx, size_t n, int32_t *__restrict__ out, size_t zs)
 {
+    ZSHIFT(lut, zs); ZSHIFT(idx, zs); ZSHIFT(out, zs);
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) out[i] = lut[idx[i]];
 }
@@ -229,9 +270,9 @@ k_gather_f64(const double *__restrict__ lut, int C, const int32_t *__restrict__ 
     out[i] = lut[(size_t)idx[p] * C + c];
 }
 
-int launch_gather_labels(const int32_t *lut, const int32_t *idx, size_t n, int32_t *out, hipStream_t st)
+int launch_gather_labels(const int32_t *lut, const int32_t *idx, size_t n, int32_t *out, hipStream_t st, ZBatch zb)
 {
-    hipLaunchKernelGGL(k_gather_i32, cdiv((long)n, 256), 256, 0, st, lut, idx, n, out);
+    hipLaunchKernelGGL(k_gather_i32, dim3(cdiv((long)n, 256), 1, zb.nz), 256, 0, st, lut, idx, n, out, zb.zs);
     HIP_TRY(hipGetLastError());
     return 0;
 }

@@ -48,6 +48,8 @@ struct GcDevice {
     int lds_topo;              // 1: arc_start + arc_to in LDS, 2: + arc_rev
     int e_cap;                 // edge capacity the LDS layout was sized for (E on the device may be smaller)
     int skip_repeat;           // the smoothness term is a metric: a move that repeats the last accepted label is skipped
+    const int32_t *K_dev;      // when set: the real number of sites lives on the device, K is its upper bound (a batch: per image)
+    size_t zs;                 // several graphs per launch (ZBatch): graph blockIdx.z, every buffer zs bytes further on per graph
     int32_t *status;           // [1] 0 ok, 1 = max-flow iteration cap hit
     long long *dbg;            // (IMSEGM_GC_DEBUG) [16] counters / 100 MHz clock sums of thread 0, or null
 };
@@ -382,6 +384,14 @@ __device__ __forceinline__ bool gc_expand(const GcDevice &g, const GcTopo<NPT> &
 template <int LVL, int NPT>
 __global__ void __launch_bounds__(GC_THREADS) k_alpha_expansion(GcDevice g)
 {
+    {
+        const size_t zs = g.zs;
+        ZSHIFT(g.E_dev, zs); ZSHIFT(g.K_dev, zs); ZSHIFT(g.edges, zs); ZSHIFT(g.w, zs); ZSHIFT(g.unary, zs); ZSHIFT(g.smooth, zs);
+        ZSHIFT(g.arc_start, zs); ZSHIFT(g.arc_to, zs); ZSHIFT(g.arc_rev, zs); ZSHIFT(g.edge_arc, zs); ZSHIFT(g.labels, zs);
+        ZSHIFT(g.prop, zs); ZSHIFT(g.energy_out, zs); ZSHIFT(g.g_cap, zs); ZSHIFT(g.g_height, zs); ZSHIFT(g.g_excess, zs);
+        ZSHIFT(g.status, zs);
+        if (g.K_dev) g.K = min(*g.K_dev, g.K);
+    }
     if (g.E_dev && *g.E_dev > g.E) {
         // more edges than the tables hold (the caller sees the flag of k_gc_terms and comes back with larger ones): arcs beyond
         // the tables must not be followed -- a defined labelling, nothing else
@@ -541,10 +551,14 @@ size_t alpha_expansion_work_bytes(int K, int E)
 
 int launch_alpha_expansion(GcProblem p, const int32_t *arc_start, const int32_t *arc_to, const int32_t *arc_rev,
                            const int32_t *edge_arc, int n_iter, int32_t *labels_dev, long long *energy_dev,
-                           int32_t *status_dev, void *work, hipStream_t st)
+                           int32_t *status_dev, void *work, hipStream_t st, ZBatch zb)
 {
     if (p.C > GC_MAX_LABELS) {
         set_error("alpha_expansion: more than 64 labels are not supported by the single-workgroup kernel");
+        return -1;
+    }
+    if (zb.nz > 1 && (!p.E_dev || !p.K_dev)) {
+        set_error("alpha_expansion: a batch needs the site and edge counts on the device");
         return -1;
     }
     if (p.E == 0 && !p.E_dev) {
@@ -562,10 +576,12 @@ int launch_alpha_expansion(GcProblem p, const int32_t *arc_start, const int32_t 
     g.energy_out = energy_dev;
     g.status = status_dev;
     g.skip_repeat = p.metric;
+    g.K_dev = p.K_dev;
+    g.zs = zb.zs;
     g.dbg = nullptr;
     static const bool debug = getenv("IMSEGM_GC_DEBUG") != nullptr;
     static long long *dbg_buf = nullptr;
-    if (debug) {
+    if (debug && zb.nz == 1) {
         if (!dbg_buf) HIP_TRY(hipMalloc(&dbg_buf, 16 * sizeof(long long)));
         HIP_TRY(hipStreamSynchronize(st));
         long long h[16];
@@ -624,7 +640,7 @@ int launch_alpha_expansion(GcProblem p, const int32_t *arc_start, const int32_t 
     {                                                                                                                             \
         if (dyn > 48 * 1024) /* the opt-in is per device and cheap: set it on every launch that needs it */                       \
             HIP_TRY(hipFuncSetAttribute((const void *)k_alpha_expansion<L, N>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024)); \
-        hipLaunchKernelGGL((k_alpha_expansion<L, N>), 1, threads, dyn, st, g);                                                    \
+        hipLaunchKernelGGL((k_alpha_expansion<L, N>), dim3(1, 1, zb.nz), threads, dyn, st, g);                                    \
     }
     switch (level + (cached ? 10 : 0)) {
     case 0: GC_LAUNCH(0, 0) break;

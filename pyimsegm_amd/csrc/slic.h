@@ -75,13 +75,15 @@ struct SlicState {
     int *fail_host;                 // page-locked word raised when a contribution bypassed the arrival count (the host redoes the image)
     int fuse_finalize;              // this launch updates the centroids itself
     int drift_slot_next;            // drift slot the updated centroids report into
+    size_t zs;                      // several images per launch (ZBatch): bytes between the buffers of consecutive images
 };
 
-int launch_minmax(const void *src, int dtype, size_t n, unsigned long long *keys, double *out2, hipStream_t st, double *also_zero = nullptr);
+int launch_minmax(const void *src, int dtype, size_t n, unsigned long long *keys, double *out2, hipStream_t st, double *also_zero = nullptr,
+                  ZBatch zb = ZBatch());
 // premax_dev[0] receives max |value| of the result planes
 int launch_preprocess_color2d(const void *img, int dtype, int H, int W, int normalize, const double *minmax_dev,
                               const Taps &tz, const Taps &ty, const Taps &tx, double ratio, double *bufA,
-                              double *bufB, double *premax_dev, hipStream_t st, bool premax_zeroed = false);
+                              double *bufB, double *premax_dev, hipStream_t st, bool premax_zeroed = false, ZBatch zb = ZBatch());
 int launch_absmax_f64(const double *src, size_t n, double *out_dev, hipStream_t st);
 // optional HIP-event hooks around the dominant kernel (api.hip profiler)
 struct ProfHook {
@@ -139,7 +141,7 @@ void slic_sweep_note_fallback();
 // `sweep_scratch` (sweep_work_bytes, 128-byte aligned) + `fail_host`: allow the persistent kernel; *used_persistent reports the choice
 int launch_slic_iterations(SlicState s, const double *lab, const double *init_yx_dev, int32_t *labels, int max_iter,
                            int max_cand, const ProfHook &prof, hipStream_t st, void *sweep_scratch = nullptr,
-                           int *fail_host = nullptr, bool *used_persistent = nullptr);
+                           int *fail_host = nullptr, bool *used_persistent = nullptr, ZBatch zb = ZBatch());
 
 // volume.hip -------------------------------------------------------------------------------------
 struct VolState {
@@ -206,6 +208,11 @@ long conn_general_runs();      // diagnostic: 2-D maps that left the tile path s
 int launch_enforce_connectivity(const int32_t *labels_in, int D, int H, int W, long min_size, long max_size,
                                 int start_label, ConnWork w, int32_t *labels_out, int *n_labels_out_host,
                                 hipStream_t st);
+// the 2-D tile path on zb.nz maps of one size in one chain of launches and ONE host synchronisation; n_labels_out[b] < 0: image b
+// must go through launch_enforce_connectivity alone (the general path)
+int launch_enforce_connectivity_batch(const int32_t *labels_in, int H, int W, long min_size, long max_size, int start_label, ConnWork w,
+                                      int32_t *labels_out, int *n_labels_out, hipStream_t st, ZBatch zb, int32_t *stage_dev);
+                                      // (stage_dev: zb.nz * 16 ints of device memory outside the images' slices)
 
 // stats.hip ---------------------------------------------------------------------------------------
 // hist[K][nb] (zeroed here) += 1 per pixel with label k in [0, K) and annotation a in [0, nb)  (labeling.py:208-247)
@@ -216,7 +223,7 @@ int launch_label_hist(const int32_t *labels, const int32_t *annot, size_t n, int
 int launch_color_stats(const void *img, int dtype, const int32_t *labels, int H, int W, int K, double maxabs,
                        int want_var, long long *acc, double *mean_out, double *energy_out, double *var_out,
                        float *mean32_scratch, hipStream_t st, int planar = 0, int prescale = 0, double mul = 1.0,
-                       double div = 1.0, long plane_stride = -1, const double *ssq_dev = nullptr);
+                       double div = 1.0, long plane_stride = -1, const double *ssq_dev = nullptr, ZBatch zb = ZBatch());
 
 // texture.hip -------------------------------------------------------------------------------------
 // fullpad: device scratch of 2 * radius + 1 + 16 doubles (the zero-padded full tap table the column pass reads)
@@ -234,8 +241,12 @@ int launch_adjacency_centres(const int32_t *labels, int H, int W, int K, uint32_
                              uint8_t *present_out, int32_t *rowcount, hipStream_t st);
 // bitmap (row b, column a < b) + centre sums only; launch_adjacency_centres = this + launch_edge_extract
 int launch_adjacency_bitmap(const int32_t *labels, int H, int W, int K, uint32_t *bitmap, long long *cacc, double *centres_out,
-                            uint8_t *present_out, hipStream_t st);
-int launch_gather_labels(const int32_t *lut, const int32_t *idx, size_t n, int32_t *out, hipStream_t st);
+                            uint8_t *present_out, hipStream_t st, ZBatch zb = ZBatch());
+int launch_gather_labels(const int32_t *lut, const int32_t *idx, size_t n, int32_t *out, hipStream_t st, ZBatch zb = ZBatch());
+// zero `bytes` bytes of every image of a batch (one image: hipMemsetAsync)
+int launch_zero(void *ptr, size_t bytes, hipStream_t st, ZBatch zb);
+// `rows` rows of `bytes` bytes (multiples of 4) from src + r * src_stride to dst + r * dst_stride
+int launch_copy_rows(void *dst, size_t dst_stride, const void *src, size_t src_stride, size_t bytes, int rows, hipStream_t st);
 int launch_gather_proba(const double *lut, int C, const int32_t *idx, size_t n, double *out, hipStream_t st);
 
 // output.hip -------------------------------------------------------------------------------------
@@ -263,6 +274,7 @@ int launch_ray_features_binary2d(const int8_t *seg, int H, int W, const int32_t 
 struct GcProblem {
     int K, C, E;            // E: number of edges, or their capacity when E_dev is given
     const int32_t *E_dev = nullptr;   // number of edges on the device (fused pipeline: no host round trip)
+    const int32_t *K_dev = nullptr;   // number of sites on the device, K its upper bound (a batch: the graphs differ in size)
     const int32_t *edges;   // [E][2], a < b
     const int32_t *w;       // [E]
     const int32_t *unary;   // [K][C]
@@ -287,7 +299,7 @@ static inline int smooth_is_metric(const int32_t *s, int C)
 }
 int launch_alpha_expansion(GcProblem p, const int32_t *arc_start, const int32_t *arc_to, const int32_t *arc_rev,
                            const int32_t *edge_arc, int n_iter, int32_t *labels_dev, long long *energy_dev,
-                           int32_t *status_dev, void *work, hipStream_t st);
+                           int32_t *status_dev, void *work, hipStream_t st, ZBatch zb = ZBatch());
 size_t alpha_expansion_work_bytes(int K, int E);
 
 // terms.hip ---------------------------------------------------------------------------------------
@@ -325,15 +337,17 @@ struct TermsArgs {
     int32_t *status;               // bit 0: smoothness term above GCO_MAX_ENERGYTERM, bit 1: edge list overflow
     double *scalars;               // [8] debug: mean len, mean dist, std dist, umax, wmax, dwf
     double *fstd;                  // [2][F] scratch (edge type 'features')
+    size_t zs;                     // several images per launch (ZBatch): bytes between the buffers of consecutive images
 };
 int launch_features_assemble(const double *mean, const double *energy, const double *var, int K, int mask, double *out,
-                             hipStream_t st, int row_stride = 0, int col0 = 0);
+                             hipStream_t st, int row_stride = 0, int col0 = 0, ZBatch zb = ZBatch());
 // symmetric bitmap -> edge list ordered by (b, a), CSR arcs in ascending neighbour order, reverse arcs, edge -> arc table
 int launch_graph_csr(uint32_t *bitmap, const int *K_dev, int K_cap, int words, int32_t *wordprefix, int32_t *deg, int32_t *deg_low,
                      int32_t *arc_start, int32_t *edge_start, int32_t *n_edges_dev, int edge_capacity, int32_t *edges,
-                     int32_t *arc_to, int32_t *arc_rev, int32_t *edge_arc, hipStream_t st);
-int launch_gc_terms(const TermsArgs &a, hipStream_t st);
-int launch_unary_argmin(const double *unary, const int *K_dev, int K_cap, int C, int32_t *labels, hipStream_t st);
-int launch_label_lut(const int32_t *graph_labels, const int *K_dev, int K_cap, const int32_t *classes, int32_t *lut, hipStream_t st);
+                     int32_t *arc_to, int32_t *arc_rev, int32_t *edge_arc, hipStream_t st, ZBatch zb = ZBatch());
+int launch_gc_terms(const TermsArgs &a, hipStream_t st, int nz = 1);          // (a.zs: the stride of a batch)
+int launch_unary_argmin(const double *unary, const int *K_dev, int K_cap, int C, int32_t *labels, hipStream_t st, ZBatch zb = ZBatch());
+int launch_label_lut(const int32_t *graph_labels, const int *K_dev, int K_cap, const int32_t *classes, int32_t *lut, hipStream_t st,
+                     ZBatch zb = ZBatch());
 
 }  // namespace imsegm

@@ -66,8 +66,10 @@ __device__ __forceinline__ void block_minmax_commit(double mn, double mx, unsign
 }
 
 template <typename T>
-__global__ void __launch_bounds__(256) k_minmax(const T *__restrict__ src, size_t n, unsigned long long *keys, double *out2, double *also_zero)
+__global__ void __launch_bounds__(256) k_minmax(const T *__restrict__ src, size_t n, unsigned long long *keys, double *out2, double *also_zero,
+                                                size_t zs)
 {
+    ZSHIFT(src, zs); ZSHIFT(keys, zs); ZSHIFT(out2, zs); ZSHIFT(also_zero, zs);
     double mn = INFINITY, mx = -INFINITY;
     size_t stride = (size_t)gridDim.x * blockDim.x;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
@@ -80,8 +82,9 @@ __global__ void __launch_bounds__(256) k_minmax(const T *__restrict__ src, size_
 
 // uint8 variant: 16 bytes per lane
 __global__ void __launch_bounds__(256) k_minmax_u8(const uint8_t *__restrict__ src, size_t n, unsigned long long *keys, double *out2,
-                                                   double *also_zero)
+                                                   double *also_zero, size_t zs)
 {
+    ZSHIFT(src, zs); ZSHIFT(keys, zs); ZSHIFT(out2, zs); ZSHIFT(also_zero, zs);
     unsigned mn = 255, mx = 0;
     size_t nvec = n / 16;
     const uint4 *v4 = reinterpret_cast<const uint4 *>(src);
@@ -122,18 +125,19 @@ __global__ void __launch_bounds__(256) k_minmax_u8(const uint8_t *__restrict__ s
 
 // `keys`: words 0, 1 and 5 are ZERO when the call is enqueued and zero again when it has run (the session zeroes them once, where it
 // allocates them); `also_zero`: one more double the last workgroup clears (nullptr: none)
-int launch_minmax(const void *src, int dtype, size_t n, unsigned long long *keys, double *out2, hipStream_t st, double *also_zero)
+int launch_minmax(const void *src, int dtype, size_t n, unsigned long long *keys, double *out2, hipStream_t st, double *also_zero, ZBatch zb)
 {
     // few workgroups: each ends with two atomics on the same two words, and single-lane atomics on one address serialise at
     // ~12 ns (512 workgroups: 16 us, 2048: 50 us for a 12.6 MB image that streams in 3 us)
-    int grid = (int)std::min<size_t>(128, (n + 256 * 16 - 1) / (256 * 16));
-    if (grid < 1) grid = 1;
+    int gx = (int)std::min<size_t>(128, (n + 256 * 16 - 1) / (256 * 16));
+    if (gx < 1) gx = 1;
+    const dim3 grid(gx, 1, zb.nz);
     if (dtype == DT_U8)
-        hipLaunchKernelGGL(k_minmax_u8, grid, 256, 0, st, (const uint8_t *)src, n, keys, out2, also_zero);
+        hipLaunchKernelGGL(k_minmax_u8, grid, 256, 0, st, (const uint8_t *)src, n, keys, out2, also_zero, zb.zs);
     else if (dtype == DT_F32)
-        hipLaunchKernelGGL(k_minmax<float>, grid, 256, 0, st, (const float *)src, n, keys, out2, also_zero);
+        hipLaunchKernelGGL(k_minmax<float>, grid, 256, 0, st, (const float *)src, n, keys, out2, also_zero, zb.zs);
     else
-        hipLaunchKernelGGL(k_minmax<double>, grid, 256, 0, st, (const double *)src, n, keys, out2, also_zero);
+        hipLaunchKernelGGL(k_minmax<double>, grid, 256, 0, st, (const double *)src, n, keys, out2, also_zero, zb.zs);
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -311,8 +315,9 @@ static_assert(PF_THREADS % PF_TX == 0 && PF_TY % (PF_THREADS / PF_TX) == 0, "x p
 template <typename T>
 __global__ void __launch_bounds__(PF_THREADS)
 k_pre_fused(const T *__restrict__ img, int H, int W, int normalize, const double *__restrict__ minmax, Taps tz, Taps ty,
-            Taps tx, double ratio, double *__restrict__ out, double *premax)
+            Taps tx, double ratio, double *__restrict__ out, double *premax, size_t zs)
 {
+    ZSHIFT(img, zs); ZSHIFT(minmax, zs); ZSHIFT(out, zs); ZSHIFT(premax, zs);
     double vmax = 0.0;                                    // max |value written| by this thread
     extern __shared__ double pf_sm[];
     __shared__ double lut[256];
@@ -420,7 +425,7 @@ k_pre_fused(const T *__restrict__ img, int H, int W, int normalize, const double
 
 int launch_preprocess_color2d(const void *img, int dtype, int H, int W, int normalize, const double *minmax_dev,
                               const Taps &tz, const Taps &ty, const Taps &tx, double ratio, double *bufA,
-                              double *bufB, double *premax_dev, hipStream_t st, bool premax_zeroed)
+                              double *bufB, double *premax_dev, hipStream_t st, bool premax_zeroed, ZBatch zb)
 {
     int n = H * W;
     int grid = cdiv(n, 256);
@@ -437,19 +442,29 @@ int launch_preprocess_color2d(const void *img, int dtype, int H, int W, int norm
             HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             if (dev >= 0 && dev < IMSEGM_MAX_DEVICES) lds_set[dev][dtype] = lds;
         }
-        dim3 gf(cdiv(W, PF_TX), cdiv(H, PF_TY));
-        if (!premax_zeroed) HIP_TRY(hipMemsetAsync(premax_dev, 0, sizeof(double), st));
+        dim3 gf(cdiv(W, PF_TX), cdiv(H, PF_TY), zb.nz);
+        if (!premax_zeroed) {
+            if (zb.nz > 1) {
+                set_error("preprocess: a batch needs its premax words zeroed by the caller");
+                return -1;
+            }
+            HIP_TRY(hipMemsetAsync(premax_dev, 0, sizeof(double), st));
+        }
         if (dtype == DT_U8)
             hipLaunchKernelGGL(k_pre_fused<uint8_t>, gf, PF_THREADS, lds, st, (const uint8_t *)img, H, W, normalize, minmax_dev, tz, ty, tx,
-                               ratio, bufA, premax_dev);
+                               ratio, bufA, premax_dev, zb.zs);
         else if (dtype == DT_F32)
             hipLaunchKernelGGL(k_pre_fused<float>, gf, PF_THREADS, lds, st, (const float *)img, H, W, normalize, minmax_dev, tz, ty, tx,
-                               ratio, bufA, premax_dev);
+                               ratio, bufA, premax_dev, zb.zs);
         else
             hipLaunchKernelGGL(k_pre_fused<double>, gf, PF_THREADS, lds, st, (const double *)img, H, W, normalize, minmax_dev, tz, ty, tx,
-                               ratio, bufA, premax_dev);
+                               ratio, bufA, premax_dev, zb.zs);
         HIP_TRY(hipGetLastError());
         return 0;   // result in bufA
+    }
+    if (zb.nz > 1) {
+        set_error("preprocess: the three-pass path (blur radius > 8) does not take a batch");
+        return -1;
     }
     if (dtype == DT_U8)
         hipLaunchKernelGGL(k_pre_lab_u8, grid, 256, 0, st, (const uint8_t *)img, n, normalize, minmax_dev, tz, bufA);
@@ -485,9 +500,21 @@ __device__ __forceinline__ int4 search_window(double cy, double cx, int step_y, 
     return w;
 }
 
+// several images per launch (ZBatch): every device pointer of the state moves to image blockIdx.z (fail_host is a host word
+// shared by the batch; phase_prof is a profiling aid of single images)
+__device__ __forceinline__ void zshift_state(SlicState &s)
+{
+    const size_t zs = s.zs;
+    ZSHIFT(s.cy, zs); ZSHIFT(s.cx, zs); ZSHIFT(s.cL, zs); ZSHIFT(s.ca, zs); ZSHIFT(s.cb, zs);
+    ZSHIFT(s.win, zs); ZSHIFT(s.acc, zs); ZSHIFT(s.premax, zs);
+    ZSHIFT(s.tile_cands, zs); ZSHIFT(s.tile_count, zs); ZSHIFT(s.tile_rec, zs); ZSHIFT(s.tile_info, zs); ZSHIFT(s.tile_k, zs);
+    ZSHIFT(s.leftover, zs); ZSHIFT(s.leftover_count, zs); ZSHIFT(s.mdc, zs); ZSHIFT(s.drift, zs); ZSHIFT(s.done, zs);
+}
+
 // regular grid of skimage.util.regular_grid: centroid k = (iy, ix) in row-major order
 __global__ void k_centroid_init(SlicState s, const double *__restrict__ init_yx)
 {
+    zshift_state(s);
     int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k < SLIC_DRIFT_SLOTS) s.drift[k] = 0;
     if (k >= s.K) return;
@@ -540,6 +567,7 @@ __device__ __forceinline__ void centroid_finalize_one(const SlicState &s, int k,
 
 __global__ void k_centroid_finalize(SlicState s, int drift_slot)
 {
+    zshift_state(s);
     centroid_finalize_one(s, blockIdx.x * blockDim.x + threadIdx.x, drift_slot);
 }
 
@@ -559,6 +587,8 @@ __global__ void __launch_bounds__(256)
 k_slic_bin(SlicState s, int tiles_x, int n_tiles, int max_cand, Cand *__restrict__ tile_cands,
            int *__restrict__ tile_count, int drift_slot)
 {
+    zshift_state(s);
+    ZSHIFT(tile_cands, s.zs); ZSHIFT(tile_count, s.zs);
     extern __shared__ int4 lds_win[];                 // [min(K, BIN_MAX_K_LDS)]
     __shared__ int ck[BIN_TILES_PER_BLOCK][MAXC];
     __shared__ float ckey[BIN_TILES_PER_BLOCK][MAXC];
@@ -734,6 +764,8 @@ static_assert(2 * WG_Y == SLIC_TILE_Y, "tile geometry");
 __global__ void __launch_bounds__(256)
 k_slic_leftover(SlicState s, const double *__restrict__ lab, const int32_t *__restrict__ labels)
 {
+    zshift_state(s);
+    ZSHIFT(lab, s.zs); ZSHIFT(labels, s.zs);
     const int count = *s.leftover_count;
     const size_t plane = (size_t)s.H * s.W;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < count; i += gridDim.x * blockDim.x) {
@@ -941,6 +973,8 @@ __global__ void __launch_bounds__(256)
 k_slic_assign(SlicState s, const double *__restrict__ lab, int32_t *__restrict__ labels,
               const Cand *__restrict__ tile_cands, const int *__restrict__ tile_count)
 {
+    zshift_state(s);
+    ZSHIFT(lab, s.zs); ZSHIFT(labels, s.zs); ZSHIFT(tile_cands, s.zs); ZSHIFT(tile_count, s.zs);
     __shared__ long long lacc[MAXC][9];
     __shared__ int lk_old[MAXC];
 
@@ -1194,6 +1228,8 @@ k_slic_assign_dot(SlicState s, const double *__restrict__ lab, int32_t *__restri
                   const Cand *__restrict__ tile_cands, const Rec32 *__restrict__ tile_rec,
                   const TileInfo *__restrict__ tile_info, const int *__restrict__ tile_k)
 {
+    zshift_state(s);
+    ZSHIFT(lab, s.zs); ZSHIFT(labels, s.zs); ZSHIFT(tile_cands, s.zs); ZSHIFT(tile_rec, s.zs); ZSHIFT(tile_info, s.zs); ZSHIFT(tile_k, s.zs);
     __shared__ long long lacc[MAXC][9];
     __shared__ int lk[MAXC];
     long long t_prev = (PROF && s.phase_prof) ? (long long)__builtin_readcyclecounter() : 0;
@@ -2180,9 +2216,17 @@ static int sweeps_resident_blocks()
 
 int launch_slic_iterations(SlicState s, const double *lab, const double *init_yx_dev, int32_t *labels, int max_iter,
                            int max_cand, const ProfHook &prof, hipStream_t st, void *sweep_scratch, int *fail_host,
-                           bool *used_persistent)
+                           bool *used_persistent, ZBatch zb)
 {
     if (used_persistent) *used_persistent = false;
+    // several images per launch: image b = blockIdx.z, every device pointer of `s` (and lab / labels) b * zb.zs bytes further on;
+    // the failure word of the fused centroid update is ONE host word for the whole batch
+    s.zs = zb.zs;
+    const unsigned nz = (unsigned)zb.nz;
+    if (nz > 1 && (sweep_scratch || s.slico || s.phase_prof)) {
+        set_error("slic: the persistent sweep kernel, SLICO and the phase profiler do not take a batch");
+        return -1;
+    }
     const bool default_cand = max_cand <= 0 || max_cand >= MAXC;
     // Centroid update inside the assignment kernel (the workgroup that completes a centroid divides its sums): measured on
     // MI355X it wins where the sweep is launch bound -- the 647 x 1024 images of config 4: +8 % images/s -- and costs the
@@ -2198,11 +2242,11 @@ int launch_slic_iterations(SlicState s, const double *lab, const double *init_yx
     if (fail_host_fuse) *s.fail_host = 0;
     if (max_cand <= 0 || max_cand > MAXC) max_cand = MAXC;
     size_t n = (size_t)s.H * s.W;
-    hipLaunchKernelGGL(k_centroid_init, cdiv(s.K, 256), 256, 0, st, s, init_yx_dev);
-    dim3 grid(cdiv(s.W, TILE_X), 2 * cdiv(s.H, TILE_Y));     // two 64 x 16 workgroups per bin tile
+    hipLaunchKernelGGL(k_centroid_init, dim3(cdiv(s.K, 256), 1, nz), 256, 0, st, s, init_yx_dev);
+    dim3 grid(cdiv(s.W, TILE_X), 2 * cdiv(s.H, TILE_Y), nz);     // two 64 x 16 workgroups per bin tile
     const int n_tiles = grid.x * cdiv(s.H, TILE_Y);
     // workgroups of the dot kernel: 1 = half a bin tile (64 x 16), 2 = a whole tile, two units per wave
-    const dim3 grid_tile(grid.x, cdiv(s.H, TILE_Y));
+    const dim3 grid_tile(grid.x, cdiv(s.H, TILE_Y), nz);
     const int units = s.assign_units == 2 ? 2 : 1;
     if (slic_prepare_device()) return -1;
     // first sweep in closed form: allowed when every pixel lies inside the search window of its nearest grid
@@ -2216,7 +2260,8 @@ int launch_slic_iterations(SlicState s, const double *lab, const double *init_yx
     }
     // nearest = -1, unless the first sweep is the closed-form one, which gives every pixel a label without looking at the map
     if (!(max_iter > 0 && s.fast32 && s.spatial_weight > 1e-9 && grid_covers && !(s.debug & 32)))
-        HIP_TRY(hipMemsetAsync(labels, 0xff, n * sizeof(int32_t), st));
+        for (unsigned b = 0; b < nz; ++b)
+            HIP_TRY(hipMemsetAsync(reinterpret_cast<unsigned char *>(labels) + (size_t)b * zb.zs, 0xff, n * sizeof(int32_t), st));
     static const bool print_occ = getenv("IMSEGM_PRINT_OCC") != nullptr;
     if (print_occ) {
         int nb = 0;
@@ -2281,7 +2326,7 @@ int launch_slic_iterations(SlicState s, const double *lab, const double *init_yx
             if (used_persistent) *used_persistent = true;
             return 0;
         }
-        hipLaunchKernelGGL(k_slic_bin, cdiv(n_tiles, BIN_TILES_PER_BLOCK), 256,
+        hipLaunchKernelGGL(k_slic_bin, dim3(cdiv(n_tiles, BIN_TILES_PER_BLOCK), 1, nz), 256,
                            (size_t)std::min(s.K, BIN_MAX_K_LDS) * sizeof(int4), st, s, (int)grid.x, n_tiles, max_cand,
                            s.tile_cands, s.tile_count, it % SLIC_DRIFT_SLOTS);
         // first sweep: integer-grid centroids with zero colour -> exact integer path (needs the
@@ -2334,8 +2379,8 @@ int launch_slic_iterations(SlicState s, const double *lab, const double *init_yx
 #undef LAUNCH_ON
 #undef LAUNCH_ASSIGN
         if (it + 1 < max_iter) {
-            if (!dot && !first_grid) hipLaunchKernelGGL(k_slic_leftover, 64, 256, 0, st, s, lab, labels);
-            if (!fuse) hipLaunchKernelGGL(k_centroid_finalize, cdiv(s.K, 256), 256, 0, st, s, (it + 1) % SLIC_DRIFT_SLOTS);
+            if (!dot && !first_grid) hipLaunchKernelGGL(k_slic_leftover, dim3(64, 1, nz), 256, 0, st, s, lab, labels);
+            if (!fuse) hipLaunchKernelGGL(k_centroid_finalize, dim3(cdiv(s.K, 256), 1, nz), 256, 0, st, s, (it + 1) % SLIC_DRIFT_SLOTS);
             if (s.slico)
                 hipLaunchKernelGGL(k_slico_update, (int)std::min<size_t>(cdiv(n, (size_t)256), 4096), 256, 0, st, s, lab, labels);
         }

@@ -41,6 +41,7 @@ struct StatParams {
     int prescale;                 // 1: value = (raw * mul) / div before the float32 staging
     double mul, div;              //    (descriptors.py:1094 `(response * (log(1 + norm) / 0.03)) / norm`)
     const double *ssq_dev;        // prescale == 2: norm = sqrt(*ssq_dev) on the device, mul and div derived from it (0 / inf norm: all values 0)
+    size_t zs;                    // several images per launch (ZBatch): image blockIdx.z, every buffer zs bytes further on per image
 };
 
 // PASS 1 -> n + 3 x (v, v*v); PASS 2 -> 3 x (v - m)^2.
@@ -55,6 +56,7 @@ __global__ void __launch_bounds__(256)
 k_color_stats(const T *__restrict__ img, const int32_t *__restrict__ labels, StatParams sp,
               const float *__restrict__ mean32, long long *__restrict__ acc)
 {
+    ZSHIFT(img, sp.zs); ZSHIFT(labels, sp.zs); ZSHIFT(mean32, sp.zs); ZSHIFT(acc, sp.zs); ZSHIFT(sp.ssq_dev, sp.zs);
     constexpr int NQ = (PASS == 1) ? 13 : 6;
     __shared__ int keys[ST_SLOTS];
     __shared__ long long lacc[ST_SLOTS][13];
@@ -221,8 +223,9 @@ k_color_stats(const T *__restrict__ img, const int32_t *__restrict__ labels, Sta
     }
 }
 
-__global__ void k_stats_clear(long long *acc, int K, int from, int to)
+__global__ void k_stats_clear(long long *acc, int K, int from, int to, size_t zs)
 {
+    ZSHIFT(acc, zs);
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= K) return;
     for (int j = from; j < to; ++j) acc[(size_t)i * 13 + j] = 0;
@@ -233,6 +236,7 @@ __global__ void k_stats_clear(long long *acc, int K, int from, int to)
 __global__ void k_stats_finalize1(long long *__restrict__ acc, StatParams sp, double *mean_out, double *energy_out,
                                   float *mean32)
 {
+    ZSHIFT(acc, sp.zs); ZSHIFT(mean_out, sp.zs); ZSHIFT(energy_out, sp.zs); ZSHIFT(mean32, sp.zs);
     int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= sp.K) return;
     long long *a = acc + (size_t)k * 13;
@@ -251,6 +255,7 @@ __global__ void k_stats_finalize1(long long *__restrict__ acc, StatParams sp, do
 
 __global__ void k_stats_finalize2(const long long *__restrict__ acc, StatParams sp, double *var_out)
 {
+    ZSHIFT(acc, sp.zs); ZSHIFT(var_out, sp.zs);
     int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= sp.K) return;
     const long long *a = acc + (size_t)k * 13;
@@ -263,9 +268,9 @@ __global__ void k_stats_finalize2(const long long *__restrict__ acc, StatParams 
 
 template <typename T>
 static void launch_pass(int pass, const T *img, const int32_t *labels, StatParams sp, const float *mean32,
-                        long long *acc, hipStream_t st)
+                        long long *acc, hipStream_t st, int nz)
 {
-    dim3 grid(cdiv(sp.W, 64), cdiv(sp.H, 4 * ST_ROWS));
+    dim3 grid(cdiv(sp.W, 64), cdiv(sp.H, 4 * ST_ROWS), nz);
     if (pass == 1 && sizeof(T) == 1 && sp.u8_int)
         hipLaunchKernelGGL((k_color_stats<T, 1, sizeof(T) == 1>), grid, 256, 0, st, img, labels, sp, mean32, acc);
     else if (pass == 1)
@@ -290,9 +295,11 @@ static double pow2_scale(double n_pixels, double maxabs)
 int launch_color_stats(const void *img, int dtype, const int32_t *labels, int H, int W, int K, double maxabs,
                        int want_var, long long *acc, double *mean_out, double *energy_out, double *var_out,
                        float *mean32_scratch, hipStream_t st, int planar, int prescale, double mul, double div,
-                       long plane_stride, const double *ssq_dev)
+                       long plane_stride, const double *ssq_dev, ZBatch zb)
 {
     StatParams sp;
+    sp.zs = zb.zs;
+    const unsigned nz = (unsigned)zb.nz;
     sp.H = H; sp.W = W; sp.K = K;
     sp.n_pixels = (size_t)H * W;
     sp.planar = planar; sp.prescale = prescale; sp.mul = mul; sp.div = div; sp.ssq_dev = ssq_dev;
@@ -300,16 +307,17 @@ int launch_color_stats(const void *img, int dtype, const int32_t *labels, int H,
     sp.scale_v = pow2_scale((double)H * W, maxabs);
     sp.scale_e = pow2_scale((double)H * W, 4.0 * maxabs * maxabs);
     sp.u8_int = (dtype == DT_U8 && !prescale && sp.scale_v >= 1.0 && sp.scale_e >= 1.0) ? 1 : 0;
-    hipLaunchKernelGGL(k_stats_clear, cdiv(K, 256), 256, 0, st, acc, K, 0, 13);
-    if (dtype == DT_U8) launch_pass<uint8_t>(1, (const uint8_t *)img, labels, sp, mean32_scratch, acc, st);
-    else if (dtype == DT_F32) launch_pass<float>(1, (const float *)img, labels, sp, mean32_scratch, acc, st);
-    else launch_pass<double>(1, (const double *)img, labels, sp, mean32_scratch, acc, st);
-    hipLaunchKernelGGL(k_stats_finalize1, cdiv(K, 256), 256, 0, st, acc, sp, mean_out, energy_out, mean32_scratch);
+    const dim3 kgrid(cdiv(K, 256), 1, nz);
+    hipLaunchKernelGGL(k_stats_clear, kgrid, 256, 0, st, acc, K, 0, 13, zb.zs);
+    if (dtype == DT_U8) launch_pass<uint8_t>(1, (const uint8_t *)img, labels, sp, mean32_scratch, acc, st, zb.nz);
+    else if (dtype == DT_F32) launch_pass<float>(1, (const float *)img, labels, sp, mean32_scratch, acc, st, zb.nz);
+    else launch_pass<double>(1, (const double *)img, labels, sp, mean32_scratch, acc, st, zb.nz);
+    hipLaunchKernelGGL(k_stats_finalize1, kgrid, 256, 0, st, acc, sp, mean_out, energy_out, mean32_scratch);
     if (want_var) {
-        if (dtype == DT_U8) launch_pass<uint8_t>(2, (const uint8_t *)img, labels, sp, mean32_scratch, acc, st);
-        else if (dtype == DT_F32) launch_pass<float>(2, (const float *)img, labels, sp, mean32_scratch, acc, st);
-        else launch_pass<double>(2, (const double *)img, labels, sp, mean32_scratch, acc, st);
-        hipLaunchKernelGGL(k_stats_finalize2, cdiv(K, 256), 256, 0, st, acc, sp, var_out);
+        if (dtype == DT_U8) launch_pass<uint8_t>(2, (const uint8_t *)img, labels, sp, mean32_scratch, acc, st, zb.nz);
+        else if (dtype == DT_F32) launch_pass<float>(2, (const float *)img, labels, sp, mean32_scratch, acc, st, zb.nz);
+        else launch_pass<double>(2, (const double *)img, labels, sp, mean32_scratch, acc, st, zb.nz);
+        hipLaunchKernelGGL(k_stats_finalize2, kgrid, 256, 0, st, acc, sp, var_out);
     }
     HIP_TRY(hipGetLastError());
     return 0;

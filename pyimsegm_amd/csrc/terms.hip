@@ -40,8 +40,9 @@ __device__ __forceinline__ double block_reduce_f64(double v, double *scratch, bo
 // np.nan_to_num and the -0 -> +0 of descriptors.py:1265 applied
 __global__ void __launch_bounds__(256)
 k_features_assemble(const double *__restrict__ mean, const double *__restrict__ energy, const double *__restrict__ var, int K,
-                    int mask, int F, double *__restrict__ out, int col0)
+                    int mask, int F, double *__restrict__ out, int col0, size_t zs)
 {
+    ZSHIFT(mean, zs); ZSHIFT(energy, zs); ZSHIFT(var, zs); ZSHIFT(out, zs);
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= K * 3) return;
     const int k = i / 3, ch = i - 3 * k;
@@ -63,8 +64,9 @@ k_features_assemble(const double *__restrict__ mean, const double *__restrict__ 
 // neighbours of v in ascending order -- the order in which the host CSR of round 1 held the arcs of v (edges sorted
 // by (b, a): first the edges whose larger end is v, then those whose smaller end is v)
 __global__ void __launch_bounds__(256)
-k_adj_symmetrize(uint32_t *bitmap, const int *__restrict__ Kp, int words)
+k_adj_symmetrize(uint32_t *bitmap, const int *__restrict__ Kp, int words, size_t zs)
 {
+    ZSHIFT(bitmap, zs); ZSHIFT(Kp, zs);
     const int K = *Kp;
     const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
     for (int b = wave; b < K; b += (gridDim.x * blockDim.x) >> 6) {
@@ -83,8 +85,9 @@ k_adj_symmetrize(uint32_t *bitmap, const int *__restrict__ Kp, int words)
 // per row: exclusive popcount prefix per word, degree, number of lower neighbours
 __global__ void __launch_bounds__(256)
 k_adj_rowprefix(const uint32_t *__restrict__ bitmap, const int *__restrict__ Kp, int words, int32_t *__restrict__ wordprefix,
-                int32_t *__restrict__ deg, int32_t *__restrict__ deg_low)
+                int32_t *__restrict__ deg, int32_t *__restrict__ deg_low, size_t zs)
 {
+    ZSHIFT(bitmap, zs); ZSHIFT(Kp, zs); ZSHIFT(wordprefix, zs); ZSHIFT(deg, zs); ZSHIFT(deg_low, zs);
     const int K = *Kp;
     const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
     for (int v = wave; v < K; v += (gridDim.x * blockDim.x) >> 6) {
@@ -116,8 +119,9 @@ k_adj_rowprefix(const uint32_t *__restrict__ bitmap, const int *__restrict__ Kp,
 // exclusive scans of deg_low (-> first edge index of row v) and deg (-> arc_start) by one workgroup
 __global__ void __launch_bounds__(256)
 k_adj_scan(const int *__restrict__ Kp, const int32_t *__restrict__ deg, const int32_t *__restrict__ deg_low, int32_t *arc_start,
-           int32_t *edge_start, int32_t *n_edges)
+           int32_t *edge_start, int32_t *n_edges, size_t zs)
 {
+    ZSHIFT(Kp, zs); ZSHIFT(deg, zs); ZSHIFT(deg_low, zs); ZSHIFT(arc_start, zs); ZSHIFT(edge_start, zs); ZSHIFT(n_edges, zs);
     __shared__ int wsum[2][4];
     __shared__ int carry[2];
     const int K = *Kp;
@@ -167,8 +171,11 @@ k_adj_scan(const int *__restrict__ Kp, const int32_t *__restrict__ deg, const in
 __global__ void __launch_bounds__(256)
 k_adj_emit(const uint32_t *__restrict__ bitmap, const int *__restrict__ Kp, int words, const int32_t *__restrict__ wordprefix,
            const int32_t *__restrict__ arc_start, const int32_t *__restrict__ edge_start, int edge_capacity,
-           int32_t *__restrict__ edges, int32_t *__restrict__ arc_to, int32_t *__restrict__ arc_rev, int32_t *__restrict__ edge_arc)
+           int32_t *__restrict__ edges, int32_t *__restrict__ arc_to, int32_t *__restrict__ arc_rev, int32_t *__restrict__ edge_arc,
+           size_t zs)
 {
+    ZSHIFT(bitmap, zs); ZSHIFT(Kp, zs); ZSHIFT(wordprefix, zs); ZSHIFT(arc_start, zs); ZSHIFT(edge_start, zs); ZSHIFT(edges, zs);
+    ZSHIFT(arc_to, zs); ZSHIFT(arc_rev, zs); ZSHIFT(edge_arc, zs);
     const int K = *Kp;
     const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
     for (int v = wave; v < K; v += (gridDim.x * blockDim.x) >> 6) {
@@ -207,8 +214,21 @@ k_adj_emit(const uint32_t *__restrict__ bitmap, const int *__restrict__ Kp, int 
 // predict_proba of Pipeline([StandardScaler,] GaussianMixture('full')): StandardScaler.transform,
 // GaussianMixture._estimate_weighted_log_prob, scipy logsumexp, exp.  One wave per superpixel: lane j forms
 // y_j = sum_f x_f P[c][f][j] - mu_proj[c][j] (sequential in f, as a plain dot product), lane 0 adds the squares in index order.
+// several images per launch (ZBatch): every pointer of the argument block moves to image blockIdx.z (the parameter block with the
+// class model is uploaded once per image, so the model pointers move too)
+__device__ __forceinline__ void zshift_terms(TermsArgs &a)
+{
+    const size_t zs = a.zs;
+    ZSHIFT(a.Kp, zs); ZSHIFT(a.Ep, zs); ZSHIFT(a.features, zs); ZSHIFT(a.scaler_mean, zs); ZSHIFT(a.scaler_scale, zs);
+    ZSHIFT(a.prec_chol, zs); ZSHIFT(a.mu_proj, zs); ZSHIFT(a.log_det, zs); ZSHIFT(a.log_w, zs); ZSHIFT(a.proba, zs);
+    ZSHIFT(a.edges, zs); ZSHIFT(a.centres, zs); ZSHIFT(a.edge_dist, zs); ZSHIFT(a.edge_len, zs); ZSHIFT(a.unary, zs);
+    ZSHIFT(a.weights, zs); ZSHIFT(a.pairwise, zs); ZSHIFT(a.unary_i, zs); ZSHIFT(a.weights_i, zs); ZSHIFT(a.status, zs);
+    ZSHIFT(a.scalars, zs); ZSHIFT(a.fstd, zs);
+}
+
 __global__ void __launch_bounds__(256) k_gmm_proba(TermsArgs a)
 {
+    zshift_terms(a);
     const int K = *a.Kp, C = a.C, F = a.F;
     const int lane = threadIdx.x & 63;
     const int k = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
@@ -247,6 +267,7 @@ __global__ void __launch_bounds__(256) k_gmm_proba(TermsArgs a)
 
 __global__ void __launch_bounds__(TM_THREADS) k_gc_terms(TermsArgs a)
 {
+    zshift_terms(a);
     __shared__ double scratch[TM_THREADS / 64];
     const int K = *a.Kp, C = a.C, F = a.F;
     int E = *a.Ep;
@@ -360,8 +381,9 @@ __global__ void __launch_bounds__(TM_THREADS) k_gc_terms(TermsArgs a)
 
 // gc_regul <= 0: argmin of the unary cost (graph_cuts.py:729-731), first minimum wins as np.argmin
 __global__ void __launch_bounds__(256)
-k_unary_argmin_f64(const double *__restrict__ unary, const int *__restrict__ Kp, int C, int32_t *__restrict__ labels)
+k_unary_argmin_f64(const double *__restrict__ unary, const int *__restrict__ Kp, int C, int32_t *__restrict__ labels, size_t zs)
 {
+    ZSHIFT(unary, zs); ZSHIFT(Kp, zs); ZSHIFT(labels, zs);
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= *Kp) return;
     int best = 0;
@@ -373,8 +395,9 @@ k_unary_argmin_f64(const double *__restrict__ unary, const int *__restrict__ Kp,
 // LUT of the final gather: classes_[graph_labels] (pipelines.py:238) or the graph labels themselves
 __global__ void __launch_bounds__(256)
 k_label_lut(const int32_t *__restrict__ graph_labels, const int *__restrict__ Kp, const int32_t *__restrict__ classes,
-            int32_t *__restrict__ lut)
+            int32_t *__restrict__ lut, size_t zs)
 {
+    ZSHIFT(graph_labels, zs); ZSHIFT(Kp, zs); ZSHIFT(classes, zs); ZSHIFT(lut, zs);
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= *Kp) return;
     const int l = graph_labels[k];
@@ -382,51 +405,52 @@ k_label_lut(const int32_t *__restrict__ graph_labels, const int *__restrict__ Kp
 }
 
 int launch_features_assemble(const double *mean, const double *energy, const double *var, int K, int mask, double *out,
-                             hipStream_t st, int row_stride, int col0)
+                             hipStream_t st, int row_stride, int col0, ZBatch zb)
 {
     // (row_stride: columns of the table the block is written into -- several blocks side by side; 0: the block is the table)
     const int F = row_stride > 0 ? row_stride : 3 * (((mask & 1) != 0) + ((mask & 2) != 0) + ((mask & 4) != 0));
-    hipLaunchKernelGGL(k_features_assemble, cdiv((long)K * 3, 256), 256, 0, st, mean, energy, var, K, mask, F, out, col0);
+    hipLaunchKernelGGL(k_features_assemble, dim3(cdiv((long)K * 3, 256), 1, zb.nz), 256, 0, st, mean, energy, var, K, mask, F, out, col0, zb.zs);
     HIP_TRY(hipGetLastError());
     return 0;
 }
 
 int launch_graph_csr(uint32_t *bitmap, const int *K_dev, int K_cap, int words, int32_t *wordprefix, int32_t *deg, int32_t *deg_low,
                      int32_t *arc_start, int32_t *edge_start, int32_t *n_edges_dev, int edge_capacity, int32_t *edges,
-                     int32_t *arc_to, int32_t *arc_rev, int32_t *edge_arc, hipStream_t st)
+                     int32_t *arc_to, int32_t *arc_rev, int32_t *edge_arc, hipStream_t st, ZBatch zb)
 {
-    const int grid = std::min(cdiv((long)K_cap * 64, 256), 4096);
-    hipLaunchKernelGGL(k_adj_symmetrize, grid, 256, 0, st, bitmap, K_dev, words);
-    hipLaunchKernelGGL(k_adj_rowprefix, grid, 256, 0, st, bitmap, K_dev, words, wordprefix, deg, deg_low);
-    hipLaunchKernelGGL(k_adj_scan, 1, 256, 0, st, K_dev, deg, deg_low, arc_start, edge_start, n_edges_dev);
+    const dim3 grid(std::min(cdiv((long)K_cap * 64, 256), 4096), 1, zb.nz);
+    hipLaunchKernelGGL(k_adj_symmetrize, grid, 256, 0, st, bitmap, K_dev, words, zb.zs);
+    hipLaunchKernelGGL(k_adj_rowprefix, grid, 256, 0, st, bitmap, K_dev, words, wordprefix, deg, deg_low, zb.zs);
+    hipLaunchKernelGGL(k_adj_scan, dim3(1, 1, zb.nz), 256, 0, st, K_dev, deg, deg_low, arc_start, edge_start, n_edges_dev, zb.zs);
     hipLaunchKernelGGL(k_adj_emit, grid, 256, 0, st, bitmap, K_dev, words, wordprefix, arc_start, edge_start, edge_capacity,
-                       edges, arc_to, arc_rev, edge_arc);
+                       edges, arc_to, arc_rev, edge_arc, zb.zs);
     HIP_TRY(hipGetLastError());
     return 0;
 }
 
-int launch_gc_terms(const TermsArgs &a, hipStream_t st)
+int launch_gc_terms(const TermsArgs &a, hipStream_t st, int nz)
 {
     if (a.F > 32 || a.C > 16) {
         set_error("device class model: at most 32 features and 16 classes");
         return -1;
     }
-    if (a.gmm) hipLaunchKernelGGL(k_gmm_proba, cdiv((long)a.K_cap * 64, 256), 256, 0, st, a);
-    hipLaunchKernelGGL(k_gc_terms, 1, TM_THREADS, 0, st, a);
+    if (a.gmm) hipLaunchKernelGGL(k_gmm_proba, dim3(cdiv((long)a.K_cap * 64, 256), 1, nz), 256, 0, st, a);
+    hipLaunchKernelGGL(k_gc_terms, dim3(1, 1, nz), TM_THREADS, 0, st, a);
     HIP_TRY(hipGetLastError());
     return 0;
 }
 
-int launch_unary_argmin(const double *unary, const int *K_dev, int K_cap, int C, int32_t *labels, hipStream_t st)
+int launch_unary_argmin(const double *unary, const int *K_dev, int K_cap, int C, int32_t *labels, hipStream_t st, ZBatch zb)
 {
-    hipLaunchKernelGGL(k_unary_argmin_f64, cdiv(K_cap, 256), 256, 0, st, unary, K_dev, C, labels);
+    hipLaunchKernelGGL(k_unary_argmin_f64, dim3(cdiv(K_cap, 256), 1, zb.nz), 256, 0, st, unary, K_dev, C, labels, zb.zs);
     HIP_TRY(hipGetLastError());
     return 0;
 }
 
-int launch_label_lut(const int32_t *graph_labels, const int *K_dev, int K_cap, const int32_t *classes, int32_t *lut, hipStream_t st)
+int launch_label_lut(const int32_t *graph_labels, const int *K_dev, int K_cap, const int32_t *classes, int32_t *lut, hipStream_t st,
+                     ZBatch zb)
 {
-    hipLaunchKernelGGL(k_label_lut, cdiv(K_cap, 256), 256, 0, st, graph_labels, K_dev, classes, lut);
+    hipLaunchKernelGGL(k_label_lut, dim3(cdiv(K_cap, 256), 1, zb.nz), 256, 0, st, graph_labels, K_dev, classes, lut, zb.zs);
     HIP_TRY(hipGetLastError());
     return 0;
 }

@@ -106,6 +106,64 @@ def _segment_color2d_one_call(image, model, dict_features, sp_size, sp_regul, gc
     return segm, soft
 
 
+#: images per launch chain of the batch path (csrc/batch.hip); 0 switches it off (one image per call, worker threads)
+BATCH_IMAGES = 8
+
+
+def _segment_color2d_batch_call(images, model, dict_features, sp_size, sp_regul, gc_regul, gc_edge_type, to_host=True, out=None,
+                                with_batch=None):
+    """``segment_color2d_slic_features_model_graphcut`` of SEVERAL images of one size and dtype as ONE call into the library
+    (:meth:`_hip.Batch2D.run_color`: every kernel launched once for the batch, image = blockIdx.z) -- under the conditions
+    of :func:`_segment_color2d_one_call`.  Returns the list of segmentations, or None when the images have to go one by one.
+    The batch object is kept by the thread's context for the next batch of the same size; ``with_batch(batch)`` is called
+    before it is given back (the maps are still in its HBM buffers then)."""
+    from pyimsegm_amd.graph_cuts import compute_pairwise_cost
+    from pyimsegm_amd.superpixels import SLIC_MAX_ITER, SLIC_START_LABEL, _slic_params
+    images = [np.asarray(im) for im in images]
+    flags = dict_features.get('color', ()) if set(dict_features) == {'color'} else None
+    first = images[0]
+    if first.ndim != 3 or first.shape[2] != 3 or first.dtype not in (np.uint8, np.float64) or not flags \
+            or not set(flags) <= {'mean', 'std', 'energy'} or gc_edge_type not in _hip.EDGE_TYPES \
+            or any(im.shape != first.shape or im.dtype != first.dtype for im in images):
+        return None
+    if sp_regul <= 0.:
+        raise ValueError('slic. regularisation must be positive')
+    gmm = _device_gmm(model)
+    if gmm is None or gmm.n_features != 3 * len(set(flags)):
+        return None
+    if first.dtype != np.uint8 and not all(bool(np.isfinite(im.sum(dtype=np.float64))) for im in images):
+        return None
+    n_seg, compact = _slic_params(first.shape[:2], sp_size, sp_regul)
+    if n_seg < 1:
+        raise ValueError('superpixel size %r is larger than the image %r' % (sp_size, first.shape[:2]))
+    if first.shape[0] * first.shape[1] < 4 * n_seg:          # (superpixels of a few pixels: the single-image calls take them)
+        return None
+    pairwise = compute_pairwise_cost(gc_regul, (0, gmm.n_classes))
+    classes = getattr(model, 'classes_', None)
+    ctx = _hip.default_context()
+    key = ('batch', max(len(images), BATCH_IMAGES)) + first.shape[:2]
+    batch = ctx.idle_sessions.pop(key, None)
+    if batch is None:
+        batch = _hip.Batch2D(key[1], first.shape[0], first.shape[1])
+    try:
+        segm = batch.run_color(images, n_seg, compact, gmm, pairwise, gc_edge_type,
+                               ('mean' in flags, 'std' in flags, 'energy' in flags), max_iter=SLIC_MAX_ITER, start_label=SLIC_START_LABEL,
+                               use_graphcut=not (np.isscalar(gc_regul) and gc_regul <= 0),
+                               classes=None if classes is None else np.asarray(classes).astype(np.int32), to_host=to_host, out=out)
+        if with_batch is not None:
+            with_batch(batch)
+    except BaseException:
+        batch.close()
+        raise
+    if key in ctx.idle_sessions:
+        batch.close()
+    else:
+        ctx.idle_sessions[key] = batch
+    if segm is not None and classes is not None and np.asarray(classes).dtype != np.int32:
+        segm = [a.astype(np.asarray(classes).dtype) for a in segm]
+    return segm if segm is not None else []
+
+
 class _ResidentImage(object):
     """one image on the device: superpixels + features, then the fused class model / graph cut / gathers"""
 

@@ -122,6 +122,32 @@ class Image2D(object):
         return out
 
 
+class Batch2D(object):
+    """stand-in of _hip.Batch2D: the images of a batch answered one after the other by the oracle-backed Image2D above"""
+    def __init__(self, max_images, height, width, ctx=None):
+        self.ctx = _CTX; self.shape = (int(height), int(width)); self.max_images = int(max_images); self.n_labels = []; self.n_images = 0
+        self.sessions = []
+    def close(self): pass
+    def run_color(self, images, n_segments, compactness, gmm, pairwise, edge_type='model', feature_flags=(True, True, True),
+                  sigma=1., normalize=2, max_iter=10, start_label=0, edge_cost=1., use_graphcut=True, classes=None, to_host=True,
+                  pinned=True, out=None):
+        assert 0 < len(images) <= self.max_images
+        self.sessions, segm = [], []
+        for k, image in enumerate(images):
+            sess = Image2D(*self.shape)
+            got, _ = sess.run_color(image, n_segments, compactness, gmm, pairwise, edge_type, feature_flags, sigma, normalize, max_iter,
+                                    start_label, False, edge_cost, use_graphcut, classes)
+            if out is not None:
+                out[k][...] = got
+                got = out[k]
+            self.sessions.append(sess); segm.append(got)
+        self.n_labels = [s.n_labels for s in self.sessions]; self.n_images = len(images)
+        return segm if to_host else None
+    def segm_device_array(self, image): return self.sessions[image].last_segm
+    def labels_device_array(self, image): return self.sessions[image].labels
+    def get_labels(self, image): return self.sessions[image].labels.astype(np.int64)
+
+
 class Volume3D(Image2D):
     def __init__(self, depth, height, width, ctx=None):
         self.ctx = _CTX; self.shape = (int(depth), int(height), int(width)); self.n_labels = 0
@@ -166,6 +192,7 @@ def _assume_bg_on_boundary(work, strips, bg_label, ctx=None):
 def pytest_configure(config):
     _hip.assume_bg_on_boundary = _assume_bg_on_boundary
     _hip.Image2D = Image2D
+    _hip.Batch2D = Batch2D
     _hip.Volume3D = Volume3D
     _hip.default_context = lambda: _CTX
     _hip.cut_general_graph = lambda e, w, u, p, n_iter=-1, algorithm='expansion', **k: orc.cut_general_graph(
