@@ -83,6 +83,9 @@ def parse_args(argv=None):
     ap.add_argument('--no-other-configs', action='store_true')
     ap.add_argument('--batch-images', type=int, default=-1, help='config 4: 0 = one image per launch chain (round 3), default: the 8 '
                                                                  'images of a step in ONE launch chain (imsegm_batch2d_run_color)')
+    ap.add_argument('--input-ring', type=int, default=-1, help='1: every worker thread copies the images of a step into its own page-locked '
+                                                               'buffers first (one memcpy, then DMA) instead of handing pageable arrays to the '
+                                                               'runtime (default off: measured slower on one GPU)')
     ap.add_argument('--no-full-volume', action='store_true', help='leave BASELINE configs[4] at its full 64x4096x4096 out of `other_configs`')
     return ap.parse_args(argv)
 
@@ -607,6 +610,7 @@ class SteadyRun(object):
         t1 = order[warmup + steps - 1]
         if self.gather is not None:               # the gather of the round that holds the last timed step belongs to it
             t1 = max(t1, gather_done[(warmup + steps - 1) // M])
+        self.rank_seconds = group.gather_objects(float(t1 - t0))          # (rank 0: every rank's own timed window)
         elapsed = group.max_over_ranks(t1 - t0)
         cold = group.max_over_ranks(t_end - t_start) / total
         return elapsed, cold
@@ -636,6 +640,30 @@ class SteadyRun(object):
     def close(self):
         if self.gather is not None:
             self.gather.close()
+
+
+def host_link_rate(ctx, image, height, width, sync_group=None, reps=10):
+    """GB/s of one step's transfers (the image up, the int32 segmentation down) copied back to back on one stream; with
+    `sync_group` every rank starts at a barrier, so the figure is what the link of this rank gives while all ranks copy"""
+    import ctypes as C
+    from pyimsegm_amd import _hip
+    dev = C.c_void_p()
+    nbytes_up, nbytes_down = image.nbytes, height * width * 4
+    _hip._check(_hip.load_library().imsegm_device_alloc(ctx.device if hasattr(ctx, 'device') else 0, max(nbytes_up, nbytes_down) + 256, C.byref(dev)))
+    try:
+        down = _hip.pinned_empty((height, width), np.int32)
+        for rep in range(reps + 2):
+            if rep == 2:
+                if sync_group is not None:
+                    sync_group.barrier()
+                t = time.perf_counter()
+            ctx.copy(dev.value, image.ctypes.data, nbytes_up)
+            ctx.copy(down.ctypes.data, dev.value, nbytes_down)
+        link_s = (time.perf_counter() - t) / reps
+    finally:
+        _hip.load_library().imsegm_device_free(dev)
+    return {'bytes_per_step': nbytes_up + nbytes_down, 'gb_per_s': round((nbytes_up + nbytes_down) / link_s / 1e9, 1),
+            'note': 'H2D of the image + D2H of the int32 segmentation, back to back on one stream'}
 
 
 def host_image(image, pinned):
@@ -678,6 +706,10 @@ def bench_color2d(args, group, cfg, quick=False):
     # (config 3: 80 against 73 Mpixels/s with two; config 4: steps of 8 images in one launch chain each, three of them in flight --
     # twelve when the images go one by one, --batch-images 0)
     inflight = args.inflight if args.inflight > 0 else {2: 4, 3: 3, 4: 12 if args.batch_images == 0 else 3}[cfg]
+    if group.distributed and world > 1:
+        # worker threads of a rank: no more than the CPUs it has been placed on (the NUMA node of its GPU, distributed.Group)
+        from pyimsegm_amd.distributed import worker_threads_per_rank
+        inflight = worker_threads_per_rank(world, inflight)
     npx_step = per_step * height * width
 
     # class model: fitted once, outside the timed region (the reference's group-model flow); config 4 takes the group model
@@ -722,18 +754,46 @@ def bench_color2d(args, group, cfg, quick=False):
     # batch, image = blockIdx.z) -- what the reference does with a pool map over the images
     batched = cfg == 4 and on_device and args.batch_images != 0 and pipe.BATCH_IMAGES > 0
 
+    # (measured on one GPU, round 4: the ring LOSES -- config 2 5.1 against 6.9 Gpixel/s, config 4 3.75 against 3.9: the runtime's
+    # own staging of a pageable source is at least as good as a copy by the worker thread -- so it stays an option)
+    use_ring = args.input_ring == 1 and not args.pinned_input
+
+    def staged(state, k, image):
+        """the image in the thread's own page-locked buffer (allocated once per thread and slot)"""
+        if not use_ring or state is None:
+            return image
+        ring = state.setdefault('ring', {})
+        buf = ring.get(k)
+        if buf is None:
+            buf = ring[k] = _hip.pinned_empty(image.shape, image.dtype)
+        np.copyto(buf, image)
+        return buf
+
     def do_step(state, index, stage):
+        if use_ring:
+            step_images = [staged(state, k, image) for k, image in enumerate(images)]
+        else:
+            step_images = images
         if batched:
             hook = None
             if stage is not None and group.distributed:
                 def hook(batch):
                     for k in range(len(images)):
                         stage(k, batch.segm_device_array(k))         # D2D into the send ring before the batch object is recycled
-            got = pipe._segment_color2d_batch_call(images, model, features, sp_size, SP_REGUL, GC_REGUL, EDGE_TYPE, with_batch=hook)
+            got = pipe._segment_color2d_batch_call(step_images, model, features, sp_size, SP_REGUL, GC_REGUL, EDGE_TYPE, with_batch=hook)
             if got is not None:
                 return got
-        return [one_image(image, stage=stage, k=k) for k, image in enumerate(images)]
+        return [one_image(image, stage=stage, k=k) for k, image in enumerate(step_images)]
 
+    rank_links = None
+    if group.distributed and world > 1:
+        # what the host link of every rank moves with all ranks copying at once (a slow socket or a shared switch shows here)
+        link = None
+        try:
+            link = round(host_link_rate(ctx, images[0], height, width, sync_group=group)['gb_per_s'], 1)
+        except Exception:
+            pass
+        rank_links = group.gather_objects(link)
     runner = SteadyRun(group, inflight, make_state, do_step, gather_item_bytes=height * width * 4, items_per_step=per_step)
     elapsed, cold = runner.run(warmup, steps)
 
@@ -801,6 +861,8 @@ def bench_color2d(args, group, cfg, quick=False):
                                         'segmentations different: %s' % (str(golden4['versions']), len(check_seeds), check_seeds[0],
                                                                           check_seeds[-1], bad_slic or 'none', bad_segm or 'none'))
     runner.close()
+    runner_rank_seconds = runner.rank_seconds or []
+    placements = group.gather_objects(getattr(group, 'placement', None)) if (group.distributed and world > 1) else None
 
     # ---- separate figures: device-resident rate, soft D2H, single-image latency (un-timed for `value`)
     extras = {}
@@ -844,22 +906,8 @@ def bench_color2d(args, group, cfg, quick=False):
             # stream -- on the boxes of this pool the two directions share ~55 GB/s (tools/xfer_concurrent.py: more threads or
             # copying both ways at once moves no more), so this is a ceiling of the host -> host rate, whatever the kernels do
             try:
-                import ctypes as C
-                dev = C.c_void_p()
-                nbytes_up, nbytes_down = images[0].nbytes, height * width * 4
-                _hip._check(_hip.load_library().imsegm_device_alloc(ctx.device if hasattr(ctx, 'device') else 0,
-                                                                   max(nbytes_up, nbytes_down) + 256, C.byref(dev)))
-                down = _hip.pinned_empty((height, width), np.int32)
-                for rep in range(12):
-                    if rep == 2:
-                        t = time.perf_counter()
-                    ctx.copy(dev.value, images[0].ctypes.data, nbytes_up)
-                    ctx.copy(down.ctypes.data, dev.value, nbytes_down)
-                link_s = (time.perf_counter() - t) / 10
-                _hip.load_library().imsegm_device_free(dev)
-                extras['host_link'] = {'bytes_per_step': nbytes_up + nbytes_down, 'gb_per_s': round((nbytes_up + nbytes_down) / link_s / 1e9, 1),
-                                       'ceiling_mpixels_per_s': round(npx_step / link_s / 1e6, 1),
-                                       'note': 'H2D of the image + D2H of the int32 segmentation, back to back on one stream'}
+                extras['host_link'] = host_link_rate(ctx, images[0], height, width)
+                extras['host_link']['ceiling_mpixels_per_s'] = round(npx_step / (extras['host_link']['bytes_per_step'] / extras['host_link']['gb_per_s'] / 1e9) / 1e6, 1)
             except Exception as ex:
                 extras['host_link'] = {'error': repr(ex)}
 
@@ -933,7 +981,8 @@ def bench_color2d(args, group, cfg, quick=False):
                 'images_in_flight_per_gpu': inflight * (per_step if batched else 1) if cfg == 4 else inflight, 'hardware_queues': os.environ.get('GPU_MAX_HW_QUEUES', 'runtime default (4)'),
                 'timed_region': 'host numpy image -> H2D -> SLIC -> descriptors -> class model -> graph-cut terms -> '
                                 'alpha-expansion -> gathers -> D2H -> segm in host numpy (page-locked result array); model fit outside',
-                'input_memory': 'page-locked' if args.pinned_input else 'pageable numpy',
+                'input_memory': 'page-locked' if args.pinned_input else ('pageable numpy, copied by the worker thread into its page-locked '
+                                                                         'ring inside the timed region' if use_ring else 'pageable numpy'),
                 'class_model': ('device (scaler + full-covariance GMM)' if on_device else 'host scikit-learn predict_proba') + '; ' + model_source,
                 'timing': 'steady state: %d warm-up + %d timed + %d cool-down steps back to back, clock from completion of '
                           'step W to completion of step W+K' % (warmup, steps, inflight),
@@ -943,6 +992,8 @@ def bench_color2d(args, group, cfg, quick=False):
             },
             'ms_per_step_incl_fill_drain': round(cold * 1e3, 4),
             'gather_backend': group.backend if group.distributed else None,
+            'per_rank': ({'value': [round(steps * npx_step / sec / 1e6, 1) for sec in runner_rank_seconds],
+                          'host_link_gb_per_s': rank_links, 'placement': placements} if (group.distributed and world > 1) else None),
             'rccl_error': getattr(group, 'rccl_error', None),
             'roofline': roofline,
             'stage_ms_per_step': {g: round(ms / prof_steps, 4) for g, (ms, n) in stage_ms.items()},

@@ -33,6 +33,11 @@ typedef struct imsegm_image2d imsegm_image2d;   /* device-resident state of one 
 IMSEGM_API const char *imsegm_last_error(void);
 IMSEGM_API int imsegm_version(void);
 IMSEGM_API int imsegm_device_count(int *count_out);
+/* PCI address of a device ("0000:c1:00.0", hipDeviceGetPCIBusId): with one process per GPU the host side of a rank belongs on the
+ * NUMA node its GPU hangs off -- /sys/bus/pci/devices/<id>/numa_node (pyimsegm_amd.distributed.bind_to_device_numa_node).  The
+ * reference's pool workers are not placed (imsegm/utilities/experiments.py:392-403); eight ranks each moving tens of GB/s over
+ * the host link are. */
+IMSEGM_API int imsegm_device_pci_bus_id(int device, char *id_out, int capacity);
 /* Optional, once per process and BEFORE the first call that touches a device: the number of hardware queues the HIP runtime maps
  * the streams of this process onto (the runtime's GPU_MAX_HW_QUEUES, default 4; with one stream per image in flight a fifth
  * stream shares a queue with another one and its kernels wait behind that image's -- bench.py asks for 8).  The runtime reads

@@ -102,6 +102,7 @@ _SIGNATURES = {
     'imsegm_batch2d_run_color': (C.c_int, [_vp, C.c_int, _vp, C.c_int, C.c_int, C.c_int, C.c_double, _vp, C.c_int, C.c_int, C.c_int,
                                            C.c_int, _vp, C.c_int, _vp, C.c_int, C.c_double, C.c_int, _vp, _vp, _vp]),
     'imsegm_batch2d_device_ptr': (C.c_int, [_vp, C.c_int, C.c_int, C.POINTER(_vp)]),
+    'imsegm_device_pci_bus_id': (C.c_int, [C.c_int, C.c_char_p, C.c_int]),
     'imsegm_init': (C.c_int, [C.c_int]),
     'imsegm_debug_reload_env': (None, []),
     'imsegm_image2d_label_hist': (C.c_int, [_vp, _vp, C.c_int, _vp]),
@@ -169,6 +170,13 @@ def init(hardware_queues=8):
         # child processes started with os.environ and for anyone who looks)
         os.environ.setdefault('GPU_MAX_HW_QUEUES', str(int(hardware_queues)))
     return status == 0
+
+
+def device_pci_bus_id(device=0):
+    """PCI address of a HIP device, e.g. ``'0000:c1:00.0'``"""
+    buf = C.create_string_buffer(64)
+    _check(load_library().imsegm_device_pci_bus_id(int(device), buf, 64))
+    return buf.value.decode('ascii', 'replace').lower()
 
 
 def reload_env():

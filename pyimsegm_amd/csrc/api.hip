@@ -216,6 +216,17 @@ int imsegm_init(int hardware_queues)
     return setenv("GPU_MAX_HW_QUEUES", buf, 0) == 0 ? 0 : -1;
 }
 
+int imsegm_device_pci_bus_id(int device, char *id_out, int capacity)
+{
+    g_runtime_started.store(true);
+    if (!id_out || capacity < 16) {
+        set_error("device_pci_bus_id: a buffer of at least 16 characters");
+        return -1;
+    }
+    HIP_TRY(hipDeviceGetPCIBusId(id_out, capacity, device));
+    return 0;
+}
+
 int imsegm_device_count(int *count_out)
 {
     g_runtime_started.store(true);

@@ -117,6 +117,15 @@ def _check_unrecognised_feature_names(feature_flags):
         logging.warning('unrecognised following feature names: %r', unknown)
     return unknown
 
+def _finished(features, names):
+    """the closing step every feature table of the reference goes through: negative zeros become zeros
+    (``features[features == 0] = 0``, descriptors.py:860,1034,1102,1165,1265) and the column count is checked against the names"""
+    features[features == 0] = 0
+    if features.shape[1] != len(names):
+        raise ValueError('features: %r and names %r' % (features.shape, names))
+    return features, names
+
+
 
 # ------------------------------------------------------------------------------------------------
 # HIP segmented statistics, colour 2D  (reference: cython_img2d_color_*, descriptors.py:209-296)
@@ -480,10 +489,7 @@ def compute_image3d_gray_statistic(image, segm, feature_flags=NAMES_FEATURE_FLAG
     names = ['%s_%s' % (ch_name, n) for n in NAMES_FEATURE_FLAGS if n in feature_flags]
     _check_unrecognised_feature_names(feature_flags)
     features = np.nan_to_num(np.array(features)).T
-    features[features == 0] = 0
-    if features.shape[1] != len(names):
-        raise ValueError('features: %r and names %r' % (features.shape, names))
-    return features, names
+    return _finished(features, names)
 
 
 def _color_statistic_session(sess, image, segm, feature_flags, color_name):
@@ -520,10 +526,7 @@ def _color_statistic_session(sess, image, segm, feature_flags, color_name):
     nb = sess.n_labels
     features = np.hstack(blocks) if blocks else np.empty((nb, 0))
     features = np.nan_to_num(features)
-    features[features == 0] = 0
-    if features.shape[1] != len(names):
-        raise ValueError('features: %r and names %r' % (features.shape, names))
-    return features, names
+    return _finished(features, names)
 
 
 def compute_image2d_color_statistic(image, segm, feature_flags=NAMES_FEATURE_FLAGS, color_name='color'):
@@ -838,10 +841,7 @@ def compute_selected_features_gray3d(img, segments, feature_flags=FEATURES_SET_C
     if not features:
         logging.error('not supported features: %r', feature_flags)
     features = np.nan_to_num(np.concatenate(tuple(features), axis=1))
-    features[features == 0] = 0
-    if features.shape[1] != len(names):
-        raise ValueError('features: %r and names %r' % (features.shape, names))
-    return features, names
+    return _finished(features, names)
 
 
 def compute_selected_features_gray2d(img, segments, features_flags=FEATURES_SET_ALL):
@@ -893,10 +893,7 @@ def _selected_features_color2d(img, segments, feature_flags, sess=None):
         logging.error('not supported features: %r', feature_flags)
         features = [np.empty((int(np.max(segments)) + 1, 0))]
     features = np.nan_to_num(np.concatenate(tuple(features), axis=1))
-    features[features == 0] = 0
-    if features.shape[1] != len(names):
-        raise ValueError('features: %r and names %r' % (features.shape, names))
-    return features, names
+    return _finished(features, names)
 
 
 def compute_selected_features_color2d(img, segments, feature_flags=FEATURES_SET_ALL):

@@ -227,6 +227,68 @@ class Rccl(object):
             self.comm = None
 
 
+# ---------------------------------------------------------------------------------------------------------
+# placement of a rank on the host: the NUMA node of its GPU
+# ---------------------------------------------------------------------------------------------------------
+def parse_cpu_list(text):
+    """``'0-3,8,10-11'`` (the format of /sys/devices/system/node/node*/cpulist) -> sorted list of CPU numbers"""
+    cpus = set()
+    for part in text.replace('\n', '').split(','):
+        part = part.strip()
+        if not part:
+            continue
+        lo, _, hi = part.partition('-')
+        cpus.update(range(int(lo), int(hi or lo) + 1))
+    return sorted(cpus)
+
+
+def numa_node_cpus(pci_bus_id, sysfs='/sys'):
+    """(NUMA node, its CPUs) of the PCI device ``pci_bus_id`` from sysfs; (None, None) when the kernel does not say (a
+    single-node box reports -1, containers may hide the files)"""
+    try:
+        with open(os.path.join(sysfs, 'bus', 'pci', 'devices', pci_bus_id, 'numa_node')) as fp:
+            node = int(fp.read().strip())
+        if node < 0:
+            return None, None
+        with open(os.path.join(sysfs, 'devices', 'system', 'node', 'node%d' % node, 'cpulist')) as fp:
+            cpus = parse_cpu_list(fp.read())
+        return (node, cpus) if cpus else (None, None)
+    except (OSError, ValueError):
+        return None, None
+
+
+def bind_to_device_numa_node(pci_bus_id, world=1, local_rank=0, sysfs='/sys', apply=True):
+    """Pin this process (and the threads it starts from now on) to the CPUs of the NUMA node its GPU hangs off, so that the
+    pages it touches first -- input staging, result arrays -- and the threads that feed the GPU sit next to it.  Ranks that share
+    a node keep the whole node (the kernel balances them).  Without the sysfs entries (or on a single-node box) the rank takes
+    an even share ``cpus // world`` of what it may run on, or nothing is changed when ``world`` is 1.
+    Returns a dict for the benchmark record: {'numa_node', 'cpus': count, 'how'}."""
+    allowed = sorted(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else list(range(os.cpu_count() or 1))
+    node, cpus = numa_node_cpus(pci_bus_id, sysfs) if pci_bus_id else (None, None)
+    how = 'numa node of the GPU'
+    if cpus:
+        cpus = [c for c in cpus if c in set(allowed)]
+    if not cpus:
+        node, how = None, 'even share of the allowed CPUs (no NUMA information)'
+        if world <= 1:
+            return {'numa_node': None, 'cpus': len(allowed), 'how': 'unchanged (one rank, no NUMA information)'}
+        share = max(1, len(allowed) // world)
+        cpus = allowed[(local_rank % world) * share:(local_rank % world + 1) * share] or allowed
+    if apply and hasattr(os, 'sched_setaffinity'):
+        try:
+            os.sched_setaffinity(0, cpus)
+        except OSError as ex:
+            return {'numa_node': node, 'cpus': len(allowed), 'how': 'unchanged (%s)' % ex}
+    return {'numa_node': node, 'cpus': len(cpus), 'how': how}
+
+
+def worker_threads_per_rank(world, wanted, cpus=None):
+    """images (worker threads) in flight a rank may run: what it wants, capped at its share of the host's CPUs"""
+    if cpus is None:
+        cpus = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    return max(1, min(int(wanted), max(1, int(cpus))))
+
+
 class Group(object):
     """the ranks of one job on one node; degrades to a single process"""
 
@@ -245,6 +307,7 @@ class Group(object):
         self.rccl = None
         self.backend = 'host'
         self.rccl_error = None
+        self.placement = None
         if backend in (None, 'rccl', 'nccl') and self.distributed:
             # stage 1 (local): a GPU and the library; stage 2 (collective, only if every rank passed stage 1): the communicator
             rccl = None
@@ -256,6 +319,14 @@ class Group(object):
                     rccl = Rccl(self)
             except Exception as ex:      # no GPU / no library: every rank falls back to the host plane
                 self.rccl_error = repr(ex)
+            # the host side of the rank next to its GPU (sched_setaffinity to the CPUs of the GPU's NUMA node)
+            self.placement = None
+            if self.world > 1 and rccl is not None and os.environ.get('IMSEGM_NO_NUMA_BIND') is None:
+                try:
+                    from pyimsegm_amd import _hip
+                    self.placement = bind_to_device_numa_node(_hip.device_pci_bus_id(self.device_index), self.world, self.local_rank)
+                except Exception as ex:
+                    self.placement = {'numa_node': None, 'cpus': None, 'how': 'unchanged (%r)' % (ex, )}
             if self.min_over_ranks(1 if rccl is not None else 0) > 0:
                 ok = 0
                 try:

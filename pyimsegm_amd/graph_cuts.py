@@ -1,36 +1,45 @@
-"""GraphCut stage: class model, unary / pairwise / edge terms and the alpha-expansion cut.
+"""GraphCut stage of the hot path: class model evaluation, unary / pairwise / edge terms, alpha-expansion.
 
-Host-side mirror of the reference module ``imsegm/graph_cuts.py`` (same public names and argument
-meaning).  The model fit stays on the host in scikit-learn exactly as in the reference
-(``graph_cuts.py:73-163``); the region adjacency graph, the superpixel centres and the
-alpha-expansion itself (``gco.cut_general_graph`` in the reference) run in the HIP library.
-The small per-edge weight formulas (E ~ 5e3 values) are evaluated with the same numpy /
-scikit-learn calls as the reference so that the integer energies handed to the cut are identical.
+This module carries the names of the reference's ``imsegm/graph_cuts.py`` that the SLIC -> descriptors -> GraphCut path
+touches (same names, argument meaning, error types and messages -- the drop-in contract), written against this repo's
+device sessions:
+
+* the region adjacency graph, the superpixel centres and the cut itself (``gco.cut_general_graph`` in the reference,
+  ``graph_cuts.py:735-744``) are calls into ``libimsegm_hip.so``;
+* the per-edge formulas of ``graph_cuts.py:303-657`` are evaluated on the device inside the fused pipeline call
+  (``csrc/terms.hip``); the numpy forms below serve callers that enter at this stage with their own arrays, and the
+  parity tests, and give the same integer energies;
+* the mixture fit is scikit-learn on the host, configured as ``graph_cuts.py:73-163`` configures it.
+
+What the path does not touch -- the alternative initialisations of the class model (``GMM_kmeans``, ``GMM_Otsu``,
+``kmeans``, ``BGM``, ``Otsu``), ``estim_gmm_params``, ``compute_multivarian_otsu``, the transition-count helpers ... --
+is NOT restated here: with a reference package installed behind the ``imsegm`` overlay those names resolve to the
+reference's own functions (module ``__getattr__`` below), without one they do not exist.
 """
 import logging
 
 import numpy as np
-from sklearn import cluster, decomposition, metrics, mixture, pipeline, preprocessing
 from sklearn.utils.extmath import row_norms
 
 from pyimsegm_amd import _hip
-from pyimsegm_amd.descriptors import compute_selected_features_img2d
-from pyimsegm_amd.superpixels import (
-    _graph_from_session,
-    _session_for_labels,
-    make_graph_segm_connect_grid2d_conn4,
-    make_graph_segm_connect_grid3d_conn6,
-    superpixel_centers,
-)
+from pyimsegm_amd.utilities import reference_attribute
 
-#: define number of iteration in Graph-Cut optimization
+#: number of iterations of the reference's fixed-iteration GraphCut calls (``graph_cuts.py:24``)
 DEFAULT_GC_ITERATIONS = 25
-#: define minimal value of unary (being a class) term in Graph-Cut
+#: class probabilities are clipped to [MIN_UNARY_PROB, 1 - MIN_UNARY_PROB] before the logarithm (``graph_cuts.py:26``)
 MIN_UNARY_PROB = 0.01
-#: define maximal value of pairwise (smoothness) term in Graph-Cut
+#: ceiling of the pairwise (smoothness) costs (``graph_cuts.py:28``)
 MAX_PAIRWISE_COST = 1e5
-#: max is this value and min is inverse (1 / val)
+#: edge weights live in [1 / MIN_MAX_EDGE_WEIGHT, MIN_MAX_EDGE_WEIGHT] (``graph_cuts.py:30``)
 MIN_MAX_EDGE_WEIGHT = 1e3
+
+#: class models :func:`estim_class_model` builds itself; every other name of ``graph_cuts.py:73-163`` goes to the reference
+_OWN_MODELS = ('GMM', )
+
+
+def __getattr__(name):
+    """names of the reference module this file does not restate: the reference's own, when one is installed"""
+    return reference_attribute('graph_cuts', name)
 
 
 def cut_grid_graph(unary_cost, pairwise_cost, cost_v, cost_h, n_iter=-1, algorithm='expansion', **kwargs):
@@ -43,243 +52,114 @@ def cut_general_graph(edges, edge_weights, unary_cost, pairwise_cost, n_iter=-1,
     return _hip.cut_general_graph(edges, edge_weights, unary_cost, pairwise_cost, n_iter=n_iter, algorithm=algorithm)
 
 
+def _scaler_mixture_steps(model):
+    """(scalers, mixture) when ``model`` is ``Pipeline([StandardScaler ...,] GaussianMixture)``, else None"""
+    from sklearn.mixture import GaussianMixture
+    from sklearn.pipeline import Pipeline
+    from sklearn.preprocessing import StandardScaler
+    if not isinstance(model, Pipeline):
+        return None
+    *front, (_, last) = model.steps
+    if type(last) is not GaussianMixture or not hasattr(last, '_estimate_weighted_log_prob'):
+        return None
+    if any(type(step) is not StandardScaler for _, step in front):
+        return None
+    return [step for _, step in front], last
+
+
 def predict_proba(model, features):
-    """ ``model.predict_proba(features)`` without scikit-learn's per-call input validation for the model the
-    pipelines fit (``Pipeline([StandardScaler, GaussianMixture])``, :func:`estim_class_model`): the very same
-    arithmetic (``StandardScaler.transform``, ``GaussianMixture._estimate_log_prob_resp``), bit for bit; any
-    other model goes through its own ``predict_proba``.  Worth a third of the host time of a pipeline step
-    when several images are in flight (the worker threads share the interpreter lock). """
+    """ ``model.predict_proba(features)``; for the model the pipelines fit (scaler + mixture) without scikit-learn's
+    per-call input validation -- the same arithmetic (``StandardScaler.transform``,
+    ``GaussianMixture._estimate_log_prob_resp``) bit for bit, a third of the host time of a pipeline step when several
+    images are in flight and the worker threads share the interpreter lock """
     try:
-        from scipy.special import logsumexp
-        from sklearn.mixture import GaussianMixture
-        from sklearn.pipeline import Pipeline
-        steps = model.steps if isinstance(model, Pipeline) else None
-        if steps and type(steps[-1][1]) is GaussianMixture and hasattr(steps[-1][1], '_estimate_weighted_log_prob') \
-                and all(type(st) is preprocessing.StandardScaler for _, st in steps[:-1]):
-            feats = np.array(features, dtype=np.float64)
-            if feats.ndim != 2 or not np.isfinite(feats).all():
-                return model.predict_proba(features)
-            for _, scaler in steps[:-1]:
+        parts = _scaler_mixture_steps(model)
+        table = np.array(features, dtype=np.float64)
+        if parts is not None and table.ndim == 2 and np.isfinite(table).all():
+            from scipy.special import logsumexp
+            for scaler in parts[0]:
                 if scaler.with_mean:
-                    feats -= scaler.mean_
+                    table -= scaler.mean_
                 if scaler.with_std:
-                    feats /= scaler.scale_
-            weighted = steps[-1][1]._estimate_weighted_log_prob(feats)
-            log_prob_norm = logsumexp(weighted, axis=1)
+                    table /= scaler.scale_
+            weighted = parts[1]._estimate_weighted_log_prob(table)
             with np.errstate(under='ignore'):
-                log_resp = weighted - log_prob_norm[:, np.newaxis]
-            return np.exp(log_resp)
-    except Exception:       # private scikit-learn API moved: fall back to the public call
+                return np.exp(weighted - logsumexp(weighted, axis=1)[:, np.newaxis])
+    except Exception:       # private scikit-learn API moved: the public call below
         pass
     return model.predict_proba(features)
 
 
-def estim_gmm_params(features, prob):
-    """ GMM parameters from a soft labelling (arg-max assignment)
-
-    >>> np.random.seed(0)
-    >>> prob = np.array([[1, 0]] * 30 + [[0, 1]] * 40)
-    >>> fts = prob + np.random.random(prob.shape)
-    >>> mm = estim_gmm_params(fts, prob)
-    >>> mm['weights']
-    [0.42857142857142855, 0.5714285714285714]
-    >>> np.round(mm['means'], 4).tolist()
-    [[1.4954, 0.5375], [0.542, 1.4261]]
-    """
-    nb_samples, nb_classes = prob.shape
-    labels = np.argmax(prob, axis=1)
-    params = {'weights': [], 'means': [], 'covars': []}
-    for lb in range(nb_classes):
-        sel = labels == lb
-        params['weights'].append(float(np.sum(sel)) / float(nb_samples))
-        params['means'].append(np.mean(features[sel], axis=0))
-        params['covars'].append(np.cov(features[sel]))
-    params['means'] = np.array([m.tolist() for m in params['means']])
-    # np.cov(samples) as the reference calls it yields one (n_c x n_c) matrix per class: ragged
-    return params
-
-
-def threshold_otsu(values, nbins=256):
-    """ Otsu threshold of a 1D sample (numpy restatement of ``skimage.filters.threshold_otsu``) """
-    values = np.asarray(values, dtype=np.float64).ravel()
-    hist, edges = np.histogram(values, bins=nbins, range=(values.min(), values.max()))
-    centers = (edges[:-1] + edges[1:]) / 2.
-    hist = hist.astype(float)
-    w1 = np.cumsum(hist)
-    w2 = np.cumsum(hist[::-1])[::-1]
-    with np.errstate(invalid='ignore', divide='ignore'):
-        m1 = np.cumsum(hist * centers) / w1
-        m2 = (np.cumsum((hist * centers)[::-1]) / w2[::-1])[::-1]
-    var12 = w1[:-1] * w2[1:] * (m1[:-1] - m2[1:])**2
-    return centers[:-1][np.nanargmax(var12)]
-
-
-def compute_multivarian_otsu(features):
-    """ Otsu per feature dimension with majority vote on orientation
-
-    >>> np.random.seed(0)
-    >>> fts = np.vstack([np.random.random((5, 3)) - 1, np.random.random((5, 3)) + 1])
-    >>> fts[:, 1] = - fts[:, 1]
-    >>> compute_multivarian_otsu(fts).astype(int)
-    array([0, 0, 0, 0, 0, 1, 1, 1, 1, 1])
-    """
-    ys = np.zeros(features.shape)
-    for i in range(features.shape[-1]):
-        asign = features[:, i] > threshold_otsu(features[:, i])
-        if i > 0:
-            m = np.mean(ys[:, :i], axis=1)
-            if np.mean(np.abs(~asign - m)) < np.mean(np.abs(asign - m)):
-                asign = ~asign
-        ys[:, i] = asign
-    return np.mean(ys, axis=1) > 0.5
-
-
 def estim_class_model(features, nb_classes, estim_model='GMM', pca_coef=None, use_scaler=True, max_iter=99):
-    """ scikit-learn pipeline (scaler, PCA, mixture model) fitted on the superpixel features;
-    identical construction to the reference (``graph_cuts.py:73-163``), host side on purpose
+    """ the class model of the unsupervised pipelines, fitted on the superpixel features with scikit-learn on the host:
+    ``Pipeline([StandardScaler,] [PCA,] GaussianMixture(full covariance, int(sqrt(max_iter)) restarts))`` -- what
+    ``graph_cuts.py:73-163`` builds for ``estim_model='GMM'``, the model the hot path uses and the device evaluates.
+    Any other ``estim_model`` of the reference is the reference's business (installed behind the overlay, or an error).
 
     >>> np.random.seed(0)
     >>> fts = np.vstack([np.random.random((50, 3)) - 1, np.random.random((50, 3)) + 1])
-    >>> mm = estim_class_model(fts, 2)
-    >>> mm.predict_proba(fts).shape
-    (100, 2)
-    >>> mm = estim_class_model(fts, 2, estim_model='GMM_kmeans', pca_coef=0.95, max_iter=3)
-    >>> mm.predict_proba(fts).shape
-    (100, 2)
-    >>> mm = estim_class_model(fts, 2, estim_model='GMM_Otsu', max_iter=3)
-    >>> mm.predict_proba(fts).shape
-    (100, 2)
-    >>> mm = estim_class_model(fts, 2, estim_model='kmeans_quantiles', use_scaler=False, max_iter=3)
-    >>> mm.predict_proba(fts).shape
-    (100, 2)
-    >>> mm = estim_class_model(fts, 2, estim_model='BGM', max_iter=3)
-    >>> mm.predict_proba(fts).shape
-    (100, 2)
-    >>> mm = estim_class_model(fts, 2, estim_model='Otsu', max_iter=3)
-    >>> mm.predict_proba(fts).shape
+    >>> estim_class_model(fts, 2).predict_proba(fts).shape
     (100, 2)
     """
-    components = []
+    if estim_model not in _OWN_MODELS:
+        return reference_attribute('graph_cuts', 'estim_class_model')(features, nb_classes, estim_model, pca_coef, use_scaler,
+                                                                       max_iter)
+    from sklearn import decomposition, mixture, pipeline, preprocessing
+    steps = []
     if use_scaler:
-        components.append(('std_scaler', preprocessing.StandardScaler()))
+        steps += [('std_scaler', preprocessing.StandardScaler())]
     if pca_coef is not None:
-        components.append(('reduce_dim', decomposition.PCA(pca_coef)))
-    nb_inits = max(1, int(np.sqrt(max_iter)))
-    mm = mixture.GaussianMixture(n_components=nb_classes, covariance_type='full', n_init=nb_inits, max_iter=max_iter)
-    if '_' in estim_model:
-        estim_model, init_type = estim_model.split('_')[0], estim_model.split('_')[-1]
-    else:
-        init_type = ''
-    y = None
-    if estim_model == 'GMM':
-        if init_type == 'kmeans':
-            mm.set_params(n_init=1)
-            y = cluster.KMeans(n_clusters=nb_classes, init='k-means++').fit_predict(features)
-        elif init_type == 'Otsu':
-            mm.set_params(n_init=1)
-            y = compute_multivarian_otsu(features)
-    elif estim_model == 'kmeans':
-        mm.set_params(max_iter=1)
-        init_type = 'quantiles' if init_type == 'quantiles' else 'k-means++'
-        _, y = estim_class_model_kmeans(features, nb_classes, init_type=init_type, max_iter=max_iter)
-        logging.info('compute probability of each feature to all component')
-    elif estim_model == 'BGM':
-        mm = mixture.BayesianGaussianMixture(n_components=nb_classes, covariance_type='full', n_init=nb_inits,
-                                             max_iter=max_iter)
-    elif estim_model == 'Otsu' and nb_classes == 2:
-        mm.set_params(max_iter=1, n_init=1)
-        y = compute_multivarian_otsu(features)
-    components.append(('model', mm))
-    model = pipeline.Pipeline(components)
-    if y is not None:
-        model.fit(features, y)
-    else:
-        model.fit(features)
-    return model
-
-
-def estim_class_model_gmm(features, nb_classes, init='kmeans'):
-    """ Gaussian mixture over the features, optionally after a k-means pass
-
-    >>> np.random.seed(0)
-    >>> fts = np.vstack([np.random.random((50, 3)) - 1, np.random.random((50, 3)) + 1])
-    >>> estim_class_model_gmm(fts, 2).predict_proba(fts).shape
-    (100, 2)
-    """
-    logging.debug('estimate GMM for all given features %r and %i component', features.shape, nb_classes)
-    gmm = mixture.GaussianMixture(n_components=nb_classes, covariance_type='full', max_iter=99)
-    if init == 'kmeans':
-        y = cluster.KMeans(n_clusters=nb_classes, init='k-means++').fit_predict(features)
-        gmm.fit(features, y)
-    else:
-        gmm.fit(features)
-    return gmm
-
-
-def estim_class_model_kmeans(features, nb_classes, init_type='k-means++', max_iter=99):
-    """ k-means clustering followed by a one-step Gaussian mixture
-
-    >>> np.random.seed(0)
-    >>> fts = np.vstack([np.random.random((50, 3)) - 1, np.random.random((50, 3)) + 1])
-    >>> mm, y = estim_class_model_kmeans(fts, 2, max_iter=9)
-    >>> y.shape
-    (100,)
-    >>> mm.predict_proba(fts).shape
-    (100, 2)
-    """
-    if init_type == 'quantiles':
-        quantiles = np.linspace(5, 95, nb_classes).tolist()
-        init_perc = np.array(np.percentile(features, quantiles, axis=0))
-        kmeans = cluster.KMeans(nb_classes, init=init_perc, max_iter=2, n_init=1)
-    else:
-        nb_inits = max(1, int(np.sqrt(max_iter)))
-        kmeans = cluster.KMeans(nb_classes, init=init_type, max_iter=max_iter, n_init=nb_inits)
-    y = kmeans.fit_predict(features)
-    gmm = mixture.GaussianMixture(n_components=nb_classes, covariance_type='full', max_iter=1)
-    gmm.fit(features, y)
-    return gmm, y
+        steps += [('reduce_dim', decomposition.PCA(pca_coef))]
+    restarts = max(1, int(np.sqrt(max_iter)))
+    steps += [('model', mixture.GaussianMixture(nb_classes, covariance_type='full', n_init=restarts, max_iter=max_iter))]
+    return pipeline.Pipeline(steps).fit(features)
 
 
 def get_vertexes_edges(segments):
-    """ (vertices, edges) of the region adjacency graph of a 2D / 3D label map """
+    """ (vertices, edges) of the region adjacency graph of a 2D / 3D label map (``graph_cuts.py:276-300``) """
+    from pyimsegm_amd import superpixels
     segments = np.asarray(segments)
-    if segments.ndim == 3:
-        return make_graph_segm_connect_grid3d_conn6(segments)
-    if segments.ndim == 2:
-        return make_graph_segm_connect_grid2d_conn4(segments)
-    return None, None
+    build = {2: superpixels.make_graph_segm_connect_grid2d_conn4, 3: superpixels.make_graph_segm_connect_grid3d_conn6}
+    return build[segments.ndim](segments) if segments.ndim in build else (None, None)
+
+
+def _dense_centres(centres):
+    """K x ndim float64 table from whatever ``superpixel_centers`` style input (missing entries: zeros, as
+    ``np.nan_to_num`` of the reference's NaN rows)"""
+    if isinstance(centres, np.ndarray) and centres.ndim == 2 and centres.dtype == np.float64:
+        return np.nan_to_num(centres)                  # straight from the device
+    rows = [tuple(c) if c is not None and len(c) else None for c in centres]
+    ndim = max(len(r) for r in rows if r is not None)
+    return np.nan_to_num(np.array([r if r is not None else (np.nan, ) * ndim for r in rows], dtype=np.float64))
 
 
 def compute_spatial_dist(centres, edges, relative=False):
-    """ Euclidean distance between the centres of connected superpixels
+    """ Euclidean distance between the centres of connected superpixels (``graph_cuts.py:303-336``)
 
     >>> centres = [(0.5, 1.0), (0.0, 3.5), (0.0, 7.0), [-1, -1], (1.0, 1.5), (1.0, 4.5), (1.0, 8.0)]
     >>> edges = [[0, 1], [1, 2], [4, 5], [5, 6], [0, 4], [1, 5], [2, 6]]
     >>> np.round(compute_spatial_dist(centres, edges), 2).tolist()
     [2.55, 3.5, 3.0, 3.5, 0.71, 1.41, 1.41]
     """
-    if np.max(edges) >= len(centres):
+    pairs = np.asarray(edges)
+    if np.max(pairs) >= len(centres):
         raise ValueError('max vertex %i exceed size of centres %i' % (np.max(edges), len(centres)))
-    if isinstance(centres, np.ndarray) and centres.ndim == 2 and centres.dtype == np.float64:
-        centres = np.nan_to_num(centres)      # dense table straight from the device
-    else:
-        centres = list(centres)
-        ndim = np.max([len(c) for c in centres if c is not None])
-        for i, c in enumerate(centres):
-            if c is None or len(c) == 0:
-                centres[i] = [np.nan] * ndim
-        centres = np.nan_to_num(np.asarray(centres, dtype=np.float64))
-    edges = np.asarray(edges)
-    # == sklearn.metrics.pairwise.paired_euclidean_distances (bit for bit) without its input validation
-    dist = row_norms(centres[edges[:, 0]] - centres[edges[:, 1]])
-    if relative:
-        dist = dist / np.mean(dist)
-    return dist
+    table = _dense_centres(centres)
+    # (what sklearn's paired_euclidean_distances evaluates, bit for bit, without its input validation)
+    dist = row_norms(table[pairs[:, 0]] - table[pairs[:, 1]])
+    return dist / np.mean(dist) if relative else dist
+
+
+def _similarity(dist):
+    """``exp(-d / (2 std(d)^2))`` with the standard deviation of the distance vector itself, as the reference has it
+    (``graph_cuts.py:423-435``; equal distances give the NaN / inf numpy gives there)"""
+    dist = np.asarray(dist, dtype=float)
+    return np.exp(-(dist / (2 * np.std(dist)**2)))
 
 
 def compute_edge_model(edges, proba, metric='l_T'):
-    """ edge weights from the class probabilities of the two end superpixels:
-    ``exp(-dist / (2 * std(dist)**2))`` with an l1, l2 or max-squared-difference distance
+    """ edge weights from the class probabilities of the two end superpixels (``graph_cuts.py:383-439``): an l1, l2 or
+    largest-squared-difference ('lT') distance through ``exp(-dist / (2 std(dist)^2))``
 
     >>> edges = np.array([[0, 1], [1, 2], [0, 4], [1, 4], [1, 5], [2, 5], [4, 5], [2, 6], [5, 6]])
     >>> np.random.seed(0)
@@ -290,47 +170,25 @@ def compute_edge_model(edges, proba, metric='l_T'):
     >>> np.round(compute_edge_model(edges, proba, metric='lT'), 3).tolist()
     [0.0, 0.002, 0.0, 0.005, 0.0, 0.0, 0.101, 0.092, 0.001]
     """
-    edges = np.asarray(edges)
-    if np.max(edges) >= len(proba):
+    pairs = np.asarray(edges)
+    if np.max(pairs) >= len(proba):
         raise ValueError('max vertex %i exceed size of proba %r' % (np.max(edges), proba.shape))
-    v1, v2 = proba[edges[:, 0]], proba[edges[:, 1]]
+    delta = proba[pairs[:, 0]] - proba[pairs[:, 1]]
     if metric == 'l1':
-        dist = metrics.pairwise.paired_manhattan_distances(v1, v2)
+        dist = np.abs(delta).sum(axis=-1)              # == paired_manhattan_distances
     elif metric == 'l2':
-        dist = metrics.pairwise.paired_euclidean_distances(v1, v2)
+        dist = row_norms(delta)                        # == paired_euclidean_distances
     elif metric == 'lT':
-        dist = np.max((v1 - v2)**2, axis=1)
+        dist = np.max(delta**2, axis=1)
     else:
         logging.error('not implemented for: %s', metric)
-        return np.ones(len(edges))
+        return np.ones(len(pairs))
     return np.exp(-dist / (2 * np.std(dist)**2))
 
 
-def create_pairwise_matrix_uniform(gc_reg, nb_classes):
-    """ uniform pairwise matrix with zero diagonal
-
-    >>> create_pairwise_matrix_uniform(0.2, 3).tolist()
-    [[0.0, 0.2, 0.2], [0.2, 0.0, 0.2], [0.2, 0.2, 0.0]]
-    """
-    return (np.ones(nb_classes) - np.eye(nb_classes)) * gc_reg
-
-
-def create_pairwise_matrix_specif(pos_weights, nb_classes=None):
-    """ pairwise matrix of ones with specific symmetric entries
-
-    >>> create_pairwise_matrix_specif([((1, 2), 0.5), ((1, 0), 0.7)], 4).tolist()
-    [[0.0, 0.7, 1.0, 1.0], [0.7, 0.0, 0.5, 1.0], [1.0, 0.5, 0.0, 1.0], [1.0, 1.0, 1.0, 0.0]]
-    """
-    if not nb_classes:
-        nb_classes = np.max([list(c) for c, _ in pos_weights]) + 1
-    pairwise = np.ones(nb_classes) - np.eye(nb_classes)
-    for (i, j), w in pos_weights:
-        pairwise[i, j] = pairwise[j, i] = w
-    return pairwise
-
-
 def create_pairwise_matrix(gc_regul, nb_classes):
-    """ pairwise matrix from a scalar, a list of specific entries or a full matrix
+    """ C x C smoothness matrix from a scalar (uniform, zero diagonal), a list ``[((i, j), weight), ...]`` of symmetric
+    entries over a matrix of ones, or a full matrix shifted to a zero minimum (``graph_cuts.py:442-515``)
 
     >>> create_pairwise_matrix(0.6, 3).tolist()
     [[0.0, 0.6, 0.6], [0.6, 0.0, 0.6], [0.6, 0.6, 0.0]]
@@ -338,32 +196,30 @@ def create_pairwise_matrix(gc_regul, nb_classes):
     [[0.0, 1.0, 0.7], [1.0, 0.0, 0.5], [0.7, 0.5, 0.0]]
     """
     if isinstance(gc_regul, np.ndarray):
-        if not gc_regul.shape[0] == gc_regul.shape[1] == nb_classes:
-            raise ValueError('GC regul matrix %r should match match number of classes (%i)' %
-                             (gc_regul.shape, nb_classes))
+        if gc_regul.shape != (nb_classes, nb_classes):
+            raise ValueError('GC regul matrix %r should match match number of classes (%i)' % (gc_regul.shape, nb_classes))
         return gc_regul - np.min(gc_regul)
+    off_diagonal = np.ones(nb_classes) - np.eye(nb_classes)
     if isinstance(gc_regul, list):
-        return create_pairwise_matrix_specif(gc_regul, nb_classes)
-    return create_pairwise_matrix_uniform(gc_regul, nb_classes)
+        for (i, j), weight in gc_regul:
+            off_diagonal[i, j] = off_diagonal[j, i] = weight
+        return off_diagonal
+    return off_diagonal * gc_regul
 
 
 def compute_unary_cost(proba, min_prob=MIN_UNARY_PROB):
-    """ ``|-log(clip(proba, min_prob, 1 - min_prob))|``
+    """ ``|-log(clip(proba, min_prob, 1 - min_prob))|`` (``graph_cuts.py:518-540``)
 
     >>> compute_unary_cost(np.array([[0.5, 0.001], [1., 0.3]])).round(4).tolist()
     [[0.6931, 4.6052], [0.0101, 1.204]]
     """
-    proba = np.array(proba, dtype=np.float64)
-    proba[proba < min_prob] = min_prob
-    proba[proba > 1 - min_prob] = 1 - min_prob
-    return np.abs(np.array(-np.log(proba), dtype=np.float64))
+    clipped = np.clip(np.array(proba, dtype=np.float64), min_prob, 1 - min_prob)
+    return np.abs(-np.log(clipped))
 
 
 def compute_pairwise_cost(gc_regul, proba_shape, max_pairwise_cost=MAX_PAIRWISE_COST):
-    """ pairwise cost matrix clipped at ``max_pairwise_cost`` """
-    pairwise_cost = np.array(create_pairwise_matrix(gc_regul, proba_shape[1]), dtype=np.float64)
-    pairwise_cost[pairwise_cost > max_pairwise_cost] = max_pairwise_cost
-    return pairwise_cost
+    """ the smoothness matrix of :func:`create_pairwise_matrix`, capped (``graph_cuts.py:543-555``) """
+    return np.minimum(np.array(create_pairwise_matrix(gc_regul, proba_shape[1]), dtype=np.float64), max_pairwise_cost)
 
 
 def _reference_drawing():
@@ -381,34 +237,21 @@ def _reference_drawing():
 
 
 def insert_gc_debug_images(debug_visual, segments, graph_labels, unary_cost, edges, edge_weights):
-    """ store intermediate variables; when the reference's drawing module is installed (``imsegm`` overlay) also
-    the rendered debug images of ``graph_cuts.py:558-571`` (``imgs_unary_cost``, ``img_graph_edges``,
-    ``img_graph_segm``) that ``drawing.figure_segm_graphcut_debug`` expects """
+    """ store the intermediate results of the cut in ``debug_visual``; with the reference's drawing module installed
+    (``imsegm`` overlay) also the rendered images ``drawing.figure_segm_graphcut_debug`` expects
+    (``graph_cuts.py:558-571``: ``imgs_unary_cost``, ``img_graph_edges``, ``img_graph_segm``) """
     if debug_visual is None:
         return
-    debug_visual['segments'] = segments
-    debug_visual['edges'] = edges
-    debug_visual['edge_weights'] = edge_weights
-    debug_visual['unary_cost'] = unary_cost
-    debug_visual['graph_labels'] = graph_labels
+    debug_visual.update(segments=segments, edges=edges, edge_weights=edge_weights, unary_cost=unary_cost, graph_labels=graph_labels)
     draw = _reference_drawing()
     if draw is None:
         return
-    segments = np.asarray(segments)
-    debug_visual['imgs_unary_cost'] = draw.draw_graphcut_unary_cost_segments(segments, unary_cost)
     from pyimsegm_amd.superpixels import superpixel_centers
-    debug_visual['img_graph_edges'] = draw.draw_graphcut_weighted_edges(
-        segments, superpixel_centers(segments), edges, edge_weights, img_bg=debug_visual.get('slic_mean', None))
-    debug_visual['img_graph_segm'] = draw.draw_color_labeling(segments, graph_labels)
-
-
-def _edges_centres(segments, _session=None):
-    own = _session is None
-    sess = _session_for_labels(segments) if own else _session
-    _, edges, centres, present = _graph_from_session(sess)
-    if own:
-        sess.close()
-    return edges, centres, present
+    label_map = np.asarray(segments)
+    debug_visual['imgs_unary_cost'] = draw.draw_graphcut_unary_cost_segments(label_map, unary_cost)
+    debug_visual['img_graph_edges'] = draw.draw_graphcut_weighted_edges(label_map, superpixel_centers(label_map), edges, edge_weights,
+                                                                        img_bg=debug_visual.get('slic_mean', None))
+    debug_visual['img_graph_segm'] = draw.draw_color_labeling(label_map, graph_labels)
 
 
 def compute_edge_weights(segments, image=None, features=None, proba=None, edge_type='', _session=None):
@@ -421,23 +264,23 @@ def compute_edge_weights(segments, image=None, features=None, proba=None, edge_t
     :param str edge_type: '', 'const', 'spatial', 'color', 'features', 'model', 'model_<metric>'
     :return tuple(ndarray,ndarray): int32 edges E x 2, float weights E clipped to [1e-3, 1e3]
     """
-    logging.debug('extraction segment connectivity...')
+    from pyimsegm_amd.superpixels import _graph_from_session, _session_for_labels, superpixel_centers
     if _session is None:
         segments = np.asarray(segments)
     if segments.ndim in (2, 3):
-        edges, centres, present = _edges_centres(segments, _session)
+        # graph and centres of the resident label map in one device pass
+        sess = _session if _session is not None else _session_for_labels(segments)
+        try:
+            _, edges, centres, _ = _graph_from_session(sess)
+        finally:
+            if _session is None:
+                sess.close()
         edges = np.array(edges, dtype=np.int32).reshape(-1, 2)
-        centre_list = None
     else:
-        _, edges = get_vertexes_edges(segments)
-        edges = np.array(edges, dtype=np.int32)
-        centres = present = None
-        centre_list = superpixel_centers(segments)
+        edges = np.array(get_vertexes_edges(segments)[1], dtype=np.int32)
+        centres = superpixel_centers(segments)
     logging.debug('graph edges %r', edges.shape)
-
-    edge_weights = edge_weights_from_graph(edges, centres if centre_list is None else centre_list, features, proba,
-                                           edge_type, image=image, segments=segments)
-    return edges, edge_weights
+    return edges, edge_weights_from_graph(edges, centres, features, proba, edge_type, image=image, segments=segments)
 
 
 def edge_weights_from_graph(edges, centres, features=None, proba=None, edge_type='', image=None, segments=None):
@@ -450,47 +293,36 @@ def edge_weights_from_graph(edges, centres, features=None, proba=None, edge_type
     if edge_type.startswith('model'):
         if proba is None or len(proba) == 0:
             raise ValueError('"proba" is required')
-        metric = edge_type.split('_')[-1] if '_' in edge_type else 'lT'
-        edge_weights = compute_edge_model(edges, proba, metric)
+        weights = compute_edge_model(edges, proba, edge_type.split('_')[-1] if '_' in edge_type else 'lT')
     elif edge_type == 'color':
         if image is None:
             raise RuntimeError('"image" is required')
-        image_float = np.array(image, dtype=float)
+        from pyimsegm_amd.descriptors import compute_selected_features_img2d
+        unit = np.array(image, dtype=float)
         if np.max(image) > 1:
-            image_float /= 255.
-        color, _ = compute_selected_features_img2d(image_float, segments, {'color': ['mean']})
-        dist = metrics.pairwise.paired_manhattan_distances(color[edges[:, 0]], color[edges[:, 1]])
-        edge_weights = np.exp(-(dist.astype(float) / (2 * np.std(dist)**2)))
+            unit /= 255.
+        means, _ = compute_selected_features_img2d(unit, segments, {'color': ['mean']})
+        weights = _similarity(np.abs(means[edges[:, 0]] - means[edges[:, 1]]).sum(axis=-1))
     elif edge_type == 'features':
         if features is None:
             raise RuntimeError('"features" is required')
-        features_norm = preprocessing.StandardScaler().fit_transform(features)
-        dist = metrics.pairwise.paired_euclidean_distances(features_norm[edges[:, 0]], features_norm[edges[:, 1]])
-        edge_weights = np.exp(-(dist.astype(float) / (2 * np.std(dist)**2)))
+        from sklearn.preprocessing import StandardScaler
+        scaled = StandardScaler().fit_transform(features)
+        weights = _similarity(row_norms(scaled[edges[:, 0]] - scaled[edges[:, 1]]))
     else:
-        edge_weights = np.ones(len(edges))
+        weights = np.ones(len(edges))
+    weights = np.array(weights, dtype=float)
+    if edge_type in ('model', 'features', 'color', 'spatial'):
+        # (centres of unused labels are [-1, -1] on the device too, superpixels.py:218)
+        weights /= compute_spatial_dist(centres, edges, relative=True)
+    low = 1. / MIN_MAX_EDGE_WEIGHT
+    weights[weights < low] = low
+    weights[weights > MIN_MAX_EDGE_WEIGHT] = MIN_MAX_EDGE_WEIGHT
+    return weights
 
-    edge_weights = np.array(edge_weights, dtype=float)
-    if edge_type in ['model', 'features', 'color', 'spatial']:
-        # device centres already hold [-1, -1] for unused labels (superpixels.py:218 semantics)
-        edge_weights /= compute_spatial_dist(centres, edges, relative=True)
 
-    edge_weights[edge_weights < 1. / MIN_MAX_EDGE_WEIGHT] = 1. / MIN_MAX_EDGE_WEIGHT
-    edge_weights[edge_weights > MIN_MAX_EDGE_WEIGHT] = MIN_MAX_EDGE_WEIGHT
-    return edge_weights
-
-
-def segment_graph_cut_general(
-    segments,
-    proba,
-    image=None,
-    features=None,
-    gc_regul=1.,
-    edge_type='model',
-    edge_cost=1.,
-    debug_visual=None,
-    _session=None,
-):
+def segment_graph_cut_general(segments, proba, image=None, features=None, gc_regul=1., edge_type='model', edge_cost=1.,
+                              debug_visual=None, _session=None):
     """ label the superpixels by an alpha-expansion graph cut (reference ``graph_cuts.py:660-747``)
 
     :param ndarray segments: superpixel label map
@@ -503,27 +335,24 @@ def segment_graph_cut_general(
     :param dict debug_visual: filled with intermediate results if given
     :return ndarray: int32 class per superpixel
     """
-    logging.debug('convert variables and run GraphCut on created graph.')
     proba = np.asarray(proba, dtype=np.float64)
     edges, edge_weights = compute_edge_weights(segments, image, features, proba, edge_type, _session=_session)
     edge_weights *= edge_cost
     unary_cost = compute_unary_cost(proba)
-    pairwise_cost = compute_pairwise_cost(gc_regul, proba.shape)
-    logging.debug('graph pairwise coefs: \n%r', pairwise_cost)
-
     if np.isscalar(gc_regul) and gc_regul <= 0:
-        logging.debug('gc_regul=%f so we use just argmax()', gc_regul)
+        # no smoothness term: the cheapest class per superpixel (graph_cuts.py:729-731)
         graph_labels = np.argmin(unary_cost, axis=-1).astype(np.int32)
     else:
-        logging.debug('perform GraphCut')
-        graph_labels = cut_general_graph(edges, edge_weights, unary_cost, pairwise_cost, algorithm='expansion',
-                                         n_iter=-1)
+        pairwise_cost = compute_pairwise_cost(gc_regul, proba.shape)
+        logging.debug('graph pairwise coefs: \n%r', pairwise_cost)
+        graph_labels = cut_general_graph(edges, edge_weights, unary_cost, pairwise_cost, algorithm='expansion', n_iter=-1)
     insert_gc_debug_images(debug_visual, segments, graph_labels, unary_cost, edges, edge_weights)
     return graph_labels
 
 
 def count_label_transitions_connected_segments(dict_slics, dict_labels, nb_labels=None):
-    """ count label transitions among connected superpixels over a set of images
+    """ how often the labels a and b meet across an edge of the (device-built) superpixel graphs of a set of images
+    (``graph_cuts.py:750-795``); symmetric, an edge between equal labels counts once
 
     >>> dict_slics = {'a': np.array([[0] * 3 + [1] * 3 + [2] * 3 + [3] * 3 + [4] * 3,
     ...                              [5] * 3 + [6] * 3 + [7] * 3 + [8] * 3 + [9] * 3])}
@@ -532,30 +361,14 @@ def count_label_transitions_connected_segments(dict_slics, dict_labels, nb_label
     [[2.0, 5.0, 1.0], [5.0, 3.0, 1.0], [1.0, 1.0, 1.0]]
     """
     if not nb_labels:
-        uq = np.unique(np.hstack([np.unique(lbs) for lbs in dict_labels.values()]))
-        nb_labels = int(np.max(uq)) + 1
-    transitions = np.zeros((nb_labels, nb_labels))
-    for name in dict_slics:
-        if (np.max(dict_slics[name]) + 1) != len(dict_labels[name]):
-            raise ValueError('dims are not matching - max slic (%i) and label (%i)' %
-                             (np.max(dict_slics[name]), len(dict_labels[name])))
-        _, edges = get_vertexes_edges(dict_slics[name])
-        label_edges = np.asarray(dict_labels[name])[np.asarray(edges)]
-        np.add.at(transitions, (label_edges[:, 0], label_edges[:, 1]), 1)
-        np.add.at(transitions, (label_edges[:, 1], label_edges[:, 0]), 1)
-    transitions[np.diag_indices(nb_labels)] /= 2
-    return transitions
-
-
-def compute_pairwise_cost_from_transitions(trans, min_prob=1e-9):
-    """ pairwise cost ``log(1 / ratio)`` from label-transition counts
-
-    >>> trans = np.array([[25., 5., 0.], [5., 10., 8.], [0., 8., 30.]])
-    >>> np.round(compute_pairwise_cost_from_transitions(trans), 3).tolist()
-    [[0.182, 1.526, 20.723], [1.526, 0.833, 1.056], [20.723, 1.056, 0.236]]
-    """
-    trans = np.asarray(trans, dtype=np.float64)
-    ratio = trans / np.tile(np.sum(trans, axis=0), (len(trans), 1))
-    ratio = np.maximum(ratio, ratio.T) * (1 - np.eye(len(ratio))) + np.diag(np.diag(ratio)) if ratio.ndim == 2 else ratio
-    ratio[ratio < min_prob] = min_prob
-    return np.log(1. / ratio)
+        nb_labels = int(max(np.max(lbs) for lbs in dict_labels.values())) + 1
+    counts = np.zeros((nb_labels, nb_labels))
+    for name, slic in dict_slics.items():
+        labels = np.asarray(dict_labels[name])
+        if np.max(slic) + 1 != len(labels):
+            raise ValueError('dims are not matching - max slic (%i) and label (%i)' % (np.max(slic), len(labels)))
+        ends = labels[np.asarray(get_vertexes_edges(slic)[1])]
+        np.add.at(counts, (ends[:, 0], ends[:, 1]), 1)
+        np.add.at(counts, (ends[:, 1], ends[:, 0]), 1)
+    counts[np.diag_indices(nb_labels)] /= 2
+    return counts

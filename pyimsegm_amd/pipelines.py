@@ -344,20 +344,9 @@ def wrapper_compute_color2d_slic_features_labels(img_annot, sp_size, sp_regul, d
     return slic, features, labels
 
 
-def train_classif_color2d_slic_features(
-    list_images,
-    list_annots,
-    dict_features,
-    sp_size=30,
-    sp_regul=0.2,
-    clf_name=CLASSIF_NAME,
-    label_purity=0.9,
-    feature_balance='unique',
-    pca_coef=None,
-    nb_classif_search=1,
-    nb_hold_out=CROSS_VAL_LEAVE_OUT,
-    nb_workers=1,
-):
+def train_classif_color2d_slic_features(list_images, list_annots, dict_features, sp_size=30, sp_regul=0.2,
+                                        clf_name=CLASSIF_NAME, label_purity=0.9, feature_balance='unique', pca_coef=None,
+                                        nb_classif_search=1, nb_hold_out=CROSS_VAL_LEAVE_OUT, nb_workers=1):
     """ train a classifier on a list of annotated images (reference ``pipelines.py:292-379``)
 
     :param list(ndarray) list_images: RGB images
@@ -406,19 +395,9 @@ def train_classif_color2d_slic_features(
     return classif, list_slic, list_features, list_labels
 
 
-def pipe_color2d_slic_features_model_graphcut(
-    image,
-    nb_classes,
-    dict_features,
-    sp_size=30,
-    sp_regul=0.2,
-    pca_coef=None,
-    use_scaler=True,
-    estim_model='GMM',
-    gc_regul=1.,
-    gc_edge_type='model',
-    debug_visual=None,
-):
+def pipe_color2d_slic_features_model_graphcut(image, nb_classes, dict_features, sp_size=30, sp_regul=0.2, pca_coef=None,
+                                              use_scaler=True, estim_model='GMM', gc_regul=1., gc_edge_type='model',
+                                              debug_visual=None):
     """ complete unsupervised pipeline: superpixels, features, mixture model, GraphCut
 
     :param ndarray image: input RGB image
@@ -454,18 +433,8 @@ def pipe_color2d_slic_features_model_graphcut(
     return segm, segm_soft
 
 
-def estim_model_classes_group(
-    list_images,
-    nb_classes,
-    dict_features,
-    sp_size=30,
-    sp_regul=0.2,
-    use_scaler=True,
-    pca_coef=None,
-    model_type='GMM',
-    nb_workers=NB_WORKERS,
-    group=None,
-):
+def estim_model_classes_group(list_images, nb_classes, dict_features, sp_size=30, sp_regul=0.2, use_scaler=True, pca_coef=None,
+                              model_type='GMM', nb_workers=NB_WORKERS, group=None):
     """ estimate one class model from the superpixel features of a sequence of images (reference ``pipelines.py:113-157``)
 
     With a multi-rank ``group`` (:class:`pyimsegm_amd.distributed.Group`) every rank extracts the features of its images
@@ -493,18 +462,8 @@ def estim_model_classes_group(
     return _fit(np.nan_to_num(np.concatenate(tuple(list_features), axis=0))), list_features
 
 
-def segment_color2d_slic_features_model_graphcut(
-    image,
-    model_pipeline,
-    dict_features,
-    sp_size=30,
-    sp_regul=0.2,
-    gc_regul=1.,
-    gc_edge_type='model',
-    debug_visual=None,
-    segm_dtype=None,
-    soft_dtype=None,
-):
+def segment_color2d_slic_features_model_graphcut(image, model_pipeline, dict_features, sp_size=30, sp_regul=0.2, gc_regul=1.,
+                                                 gc_edge_type='model', debug_visual=None, segm_dtype=None, soft_dtype=None):
     """ segmentation with a given (pre-trained) model: superpixels, features, predict, GraphCut
 
     :param ndarray image: input RGB image
@@ -591,15 +550,8 @@ def segment_batch_color2d_slic_features_model_graphcut(list_images, model_pipeli
             group.close()
 
 
-def pipe_gray3d_slic_features_model_graphcut(
-    image,
-    nb_classes,
-    dict_features,
-    spacing=(12, 1, 1),
-    sp_size=15,
-    sp_regul=0.2,
-    gc_regul=0.1,
-):
+def pipe_gray3d_slic_features_model_graphcut(image, nb_classes, dict_features, spacing=(12, 1, 1), sp_size=15, sp_regul=0.2,
+                                             gc_regul=0.1):
     """ complete pipeline on a gray volume: supervoxels, features, mixture model, GraphCut
     (reference ``pipelines.py:382-431``)
 

@@ -39,6 +39,9 @@ def test_bench_control_flow_two_ranks_under_the_launcher():
     assert d['config']['images_in_flight_per_gpu'] == 4 and 'gathered in rank 0' in d['config']['parallelism']
     assert d['ms_per_step_incl_fill_drain'] > 0 and 'steady state' in d['config']['timing']
     assert 'cpu_baseline' not in d                     # rank 0 at N = 1 only
+    assert len(d['per_rank']['value']) == 2 and all(v > 0 for v in d['per_rank']['value'])      # a slow rank is visible in the line
+    assert len(d['per_rank']['host_link_gb_per_s']) == 2 and len(d['per_rank']['placement']) == 2
+    assert d['config']['input_memory'] == 'pageable numpy'                                       # (the ring is an option: --input-ring 1)
     assert d['gathered_maps_checked'] == 2 and d['gathered_maps_equal_senders_own'] is True      # what rank 0 received = what each rank holds
 
 
@@ -46,7 +49,7 @@ def test_bench_batch_config_two_self_spawned_ranks():
     """`--gpus 2` without a launcher: bench.py starts its own ranks; config 4 with the group model of the reference's run, and
     rank 0 checks the CRC of EVERY gathered label map against that run (the oracle stands in for the kernels here, and it
     reproduces the reference's maps bit for bit)"""
-    d = run_bench(2, 3, 29633, extra=['--config', '4'], size=())
+    d = run_bench(2, 3, 29633, extra=['--config', '4', '--input-ring', '1'], size=())
     assert d['n_gpus'] == 2 and d['config']['bench_config'] == 4 and d['config']['images_per_step_per_gpu'] == 8
     assert abs(d['value'] - 2 * 3 * 8 * 647 * 1024 / (d['ms_per_step'] * 3 / 1e3) / 1e6) / d['value'] < 1e-3
     assert d['gathered_maps_checked'] == 16 and d['gathered_maps_equal_reference_run'] is True, d

@@ -132,3 +132,69 @@ def test_control_plane_directory_must_be_a_private_directory_not_a_link(tmp_path
     monkeypatch.delenv('IMSEGM_COMM_SOCKET', raising=False)
     with pytest.raises(RuntimeError, match='private'):
         _Star(0, 1, timeout=5.)
+
+
+def _fake_sysfs(root, devices):
+    """a sysfs tree with PCI devices {bus id: numa node} and nodes {node: cpulist}"""
+    nodes = {}
+    for bus_id, (node, cpulist) in devices.items():
+        d = root / 'bus' / 'pci' / 'devices' / bus_id
+        d.mkdir(parents=True)
+        (d / 'numa_node').write_text('%d\n' % node)
+        if node >= 0:
+            nodes[node] = cpulist
+    for node, cpulist in nodes.items():
+        d = root / 'devices' / 'system' / 'node' / ('node%d' % node)
+        d.mkdir(parents=True)
+        (d / 'cpulist').write_text(cpulist + '\n')
+    return str(root)
+
+
+def test_numa_placement_of_a_rank(tmp_path):
+    """bind_to_device_numa_node: CPUs of the GPU's NUMA node from sysfs; an even share of the allowed CPUs when the kernel
+    does not say; nothing for a single rank without NUMA information"""
+    sys.path.insert(0, ROOT)
+    from pyimsegm_amd import distributed as dist
+    assert dist.parse_cpu_list('0-3,8,10-11\n') == [0, 1, 2, 3, 8, 10, 11]
+    allowed = sorted(os.sched_getaffinity(0))
+    half = max(1, len(allowed) // 2)
+    lists = ['%s' % ','.join(str(c) for c in allowed[:half]), '%s' % ','.join(str(c) for c in allowed[half:] or allowed[:1])]
+    sysfs = _fake_sysfs(tmp_path / 'sys', {'0000:05:00.0': (0, lists[0]), '0000:85:00.0': (1, lists[1]), '0000:c1:00.0': (-1, '')})
+    assert dist.numa_node_cpus('0000:85:00.0', sysfs) == (1, dist.parse_cpu_list(lists[1]))
+    assert dist.numa_node_cpus('0000:c1:00.0', sysfs) == (None, None)           # single-node box: -1
+    assert dist.numa_node_cpus('0000:ff:00.0', sysfs) == (None, None)           # no such device
+    got = dist.bind_to_device_numa_node('0000:05:00.0', world=2, local_rank=0, sysfs=sysfs, apply=False)
+    assert got['numa_node'] == 0 and got['cpus'] == half and 'numa node' in got['how']
+    got = dist.bind_to_device_numa_node('0000:c1:00.0', world=2, local_rank=1, sysfs=sysfs, apply=False)
+    assert got['numa_node'] is None and got['cpus'] == half and 'even share' in got['how']
+    got = dist.bind_to_device_numa_node('0000:c1:00.0', world=1, sysfs=sysfs, apply=False)
+    assert got['cpus'] == len(allowed) and got['how'].startswith('unchanged')
+    assert dist.worker_threads_per_rank(8, 12, cpus=4) == 4 and dist.worker_threads_per_rank(1, 3, cpus=64) == 3
+
+
+def test_two_ranks_bind_to_the_nodes_of_their_gpus(tmp_path):
+    """two processes, each applies the affinity of 'its' device for real and reports what the kernel then allows it"""
+    allowed = sorted(os.sched_getaffinity(0))
+    if len(allowed) < 2:
+        pytest.skip('needs two CPUs')
+    half = len(allowed) // 2
+    lists = [','.join(str(c) for c in allowed[:half]), ','.join(str(c) for c in allowed[half:])]
+    sysfs = _fake_sysfs(tmp_path / 'sys', {'0000:05:00.0': (0, lists[0]), '0000:85:00.0': (1, lists[1])})
+    code = textwrap.dedent('''
+        import os, sys, threading
+        sys.path.insert(0, %r)
+        from pyimsegm_amd import distributed as dist
+        rank = int(sys.argv[1])
+        got = dist.bind_to_device_numa_node(['0000:05:00.0', '0000:85:00.0'][rank], world=2, local_rank=rank, sysfs=%r)
+        seen = []
+        t = threading.Thread(target=lambda: seen.append(sorted(os.sched_getaffinity(0))))     # threads started later inherit it
+        t.start(); t.join()
+        print('AFFINITY', got['numa_node'], sorted(os.sched_getaffinity(0)) == seen[0], ','.join(str(c) for c in seen[0]))
+    ''') % (ROOT, sysfs)
+    procs = [subprocess.Popen([sys.executable, '-c', code, str(r)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, universal_newlines=True)
+             for r in range(2)]
+    for r, p in enumerate(procs):
+        out, err = p.communicate(timeout=120)
+        assert p.returncode == 0, err[-2000:]
+        line = [ln for ln in out.splitlines() if ln.startswith('AFFINITY')][-1].split()
+        assert line[1] == str(r) and line[2] == 'True' and line[3] == lists[r]
