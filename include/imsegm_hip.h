@@ -158,6 +158,17 @@ IMSEGM_API int imsegm_image2d_gather(imsegm_image2d *img, const int32_t *graph_l
 IMSEGM_API int imsegm_image2d_lm_features(imsegm_image2d *img, const double *weights, const int *n_kernels, int n_batteries, int radius,
                                           double clip, int feature_mask, double *features_out);
 
+/* The same with the separable kernels of the bank taken out of the dense sums: 28 of the 76 Leung-Malik kernels (the Gaussians, both
+ * Laplacians of a Gaussian, the edge / bar filters at 0 and 90 degrees; descriptors.py:903-948) are matrices of rank 1 or 2, i.e.
+ * sums of one or two products of a column and a row filter.  Battery b: n_kernels[b] dense kernels (0, 1, 2, 4, 6 or 8; laid out
+ * as above) plus sep_groups[b] (0..2) separable kernels of sep_rank[b] (1..4) components each; sep_taps holds, battery after
+ * battery, kernel after kernel, component after component, the 2 radius + 1 taps along x and then along y of the FLIPPED kernel
+ * (the singular value folded into the y taps: K_flipped = sum_i y_i x_i^T).  The response of a battery is the maximum over all its
+ * kernels, as before; the factorisation is the caller's (pyimsegm_amd._hip: numpy SVD, components above 1e-13 of the largest). */
+IMSEGM_API int imsegm_image2d_lm_features_sep(imsegm_image2d *img, const double *weights, const int *n_kernels, const double *sep_taps,
+                                              const int *sep_groups, const int *sep_rank, int n_batteries, int radius, double clip,
+                                              int feature_mask, double *features_out);
+
 /* Leung-Malik texture responses (imsegm/descriptors.py:951-1106, scipy.ndimage in the reference).
  * lm_prepare: planes = image - gaussian_filter(image, sigma) with `taps` = half kernel of
  *   scipy.ndimage.gaussian_filter1d(sigma) (taps[0] centre) for the two image axes and `channel_mix`

@@ -112,6 +112,7 @@ _SIGNATURES = {
     'imsegm_image2d_graph': (C.c_int, [_vp, _vp, C.c_int, _ip, _vp, _vp]),
     'imsegm_image2d_gather': (C.c_int, [_vp, _vp, _vp, C.c_int, _vp, _vp]),
     'imsegm_image2d_lm_prepare': (C.c_int, [_vp, _vp, C.c_int, _vp]),
+    'imsegm_image2d_lm_features_sep': (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_double, C.c_int, _vp]),
     'imsegm_image2d_lm_battery': (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_double, C.POINTER(C.c_double)]),
     'imsegm_image2d_response_stats': (C.c_int, [_vp, C.c_double, C.c_double, _vp, _vp, _vp]),
     'imsegm_image2d_get_response': (C.c_int, [_vp, _vp]),
@@ -693,18 +694,62 @@ class Image2D(object):
         # true convolution == correlation with the flipped kernel; layout [kx][ky][kernel]
         return np.ascontiguousarray(battery[:, ::-1, ::-1].transpose(2, 1, 0)), pad, side // 2
 
-    def lm_features(self, batteries, clip, mean=True, std=True, energy=True):
-        """``imsegm_image2d_lm_features``: K x (3 * flags * len(batteries)) statistics of all batteries in one call"""
-        parts = [self._battery_weights(b) for b in batteries]
-        radius = parts[0][2]
-        if any(p[2] != radius for p in parts):
+    #: kernels whose singular values fall below this share of the largest after RANK components are evaluated as separable passes
+    SEPARABLE_TOLERANCE, SEPARABLE_MAX_RANK = 1e-13, 2
+
+    @classmethod
+    def _split_battery(cls, battery, separable=True):
+        """one battery (k x S x S convolution kernels) as the device takes it: (dense weights [kx][ky][kernel] of the flipped
+        kernels that stay dense, their number after padding to 0 / 1 / 2 / 4 / 6 / 8, separable taps, groups, rank, radius).
+        A kernel of numerical rank <= SEPARABLE_MAX_RANK (numpy SVD of the flipped kernel) becomes `rank` pairs of (x taps, y
+        taps); at most two kernels per battery go that way (the 0 and 90 degree orientations of an edge / bar battery)."""
+        battery = np.asarray(battery, dtype=np.float64)
+        nk, side = battery.shape[0], battery.shape[1]
+        if battery.ndim != 3 or battery.shape[2] != side or side % 2 != 1:
+            raise ValueError('wrong battery dim %r' % (battery.shape, ))
+        if nk > 8:
+            raise ValueError('at most 8 kernels per battery')
+        flipped = battery[:, ::-1, ::-1]
+        dense, factors = [], []
+        for kernel in flipped:
+            parts = None
+            if separable and len(factors) < 2:
+                u, sv, vt = np.linalg.svd(kernel)
+                rank = int(np.sum(sv > cls.SEPARABLE_TOLERANCE * sv[0])) if sv[0] > 0 else 0
+                if 1 <= rank <= cls.SEPARABLE_MAX_RANK:
+                    parts = [(vt[i], sv[i] * u[:, i]) for i in range(rank)]          # (taps along x, taps along y)
+            if parts is None:
+                dense.append(kernel)
+            else:
+                factors.append(parts)
+        rank = max([len(p) for p in factors] or [0])
+        taps = np.zeros((len(factors), rank, 2, side))
+        for g, parts in enumerate(factors):
+            for i, (tx, ty) in enumerate(parts):
+                taps[g, i, 0], taps[g, i, 1] = tx, ty
+        pad = {0: 0, 1: 1, 2: 2, 3: 4, 4: 4, 5: 6, 6: 6, 7: 8, 8: 8}[len(dense)]
+        if pad != len(dense):            # repeat the last kernel: the maximum is unchanged
+            dense = dense + [dense[-1]] * (pad - len(dense))
+        weights = np.ascontiguousarray(np.asarray(dense).transpose(2, 1, 0)) if dense else np.zeros(0)
+        return weights, pad, taps, len(factors), rank, side // 2
+
+    def lm_features(self, batteries, clip, mean=True, std=True, energy=True, separable=True):
+        """``imsegm_image2d_lm_features_sep``: K x (3 * flags * len(batteries)) statistics of all batteries in one call;
+        ``separable=False``: every kernel as a dense S x S sum (``imsegm_image2d_lm_features``)"""
+        parts = [self._split_battery(b, separable) for b in batteries]
+        radius = parts[0][5]
+        if any(p[5] != radius for p in parts):
             raise ValueError('the batteries of one call have one kernel size')
         weights = np.concatenate([p[0].ravel() for p in parts])
         counts = np.array([p[1] for p in parts], dtype=np.int32)
+        taps = np.concatenate([p[2].ravel() for p in parts])
+        groups = np.array([p[3] for p in parts], dtype=np.int32)
+        ranks = np.array([p[4] for p in parts], dtype=np.int32)
         mask = (1 if mean else 0) | (2 if std else 0) | (4 if energy else 0)
         out = np.empty((self.n_labels, 3 * bin(mask).count('1') * len(parts)), dtype=np.float64)
-        _check(load_library().imsegm_image2d_lm_features(self._h, _ptr(weights), _ptr(counts), len(parts), radius, float(clip), mask,
-                                                         _ptr(out)))
+        _check(load_library().imsegm_image2d_lm_features_sep(
+            self._h, _ptr(weights) if weights.size else None, _ptr(counts), _ptr(taps) if taps.size else None, _ptr(groups), _ptr(ranks),
+            len(parts), radius, float(clip), mask, _ptr(out)))
         return out
 
     def response_stats(self, mul, div, mean=True, energy=True, var=True):

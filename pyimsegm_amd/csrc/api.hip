@@ -933,13 +933,22 @@ int imsegm_image2d_lm_battery(imsegm_image2d *im, const double *weights, int n_k
 int imsegm_image2d_lm_features(imsegm_image2d *im, const double *weights, const int *n_kernels, int n_batteries, int radius, double clip,
                                int feature_mask, double *features_out)
 {
+    return imsegm_image2d_lm_features_sep(im, weights, n_kernels, nullptr, nullptr, nullptr, n_batteries, radius, clip, feature_mask,
+                                          features_out);
+}
+
+int imsegm_image2d_lm_features_sep(imsegm_image2d *im, const double *weights, const int *n_kernels, const double *sep_taps,
+                                   const int *sep_groups, const int *sep_rank, int n_batteries, int radius, double clip, int feature_mask,
+                                   double *features_out)
+{
     if (!im || bind(im->ctx)) return -1;
     if (wrong_kind(im, false)) return -1;
     if (!im->tex_ready || !im->have_labels) {
         set_error("lm_features: call imsegm_image2d_lm_prepare first, with a label map installed");
         return -1;
     }
-    if (!weights || !n_kernels || n_batteries < 1 || !features_out || feature_mask < 1 || feature_mask > 7) {
+    if (!n_kernels || n_batteries < 1 || !features_out || feature_mask < 1 || feature_mask > 7 ||
+        (sep_taps && (!sep_groups || !sep_rank))) {
         set_error("lm_features: bad arguments");
         return -1;
     }
@@ -948,15 +957,24 @@ int imsegm_image2d_lm_features(imsegm_image2d *im, const double *weights, const 
     const size_t n = im->n;
     const int K = im->n_labels;
     const size_t S = 2 * (size_t)radius + 1;
-    // per battery: the weights as the caller lays them out, then room for the row-padded copy launch_filter_battery makes of them
-    std::vector<size_t> off((size_t)n_batteries + 1, 0);
+    // per battery: the dense weights as the caller lays them out, room for the row-padded copy launch_filter_battery makes of them,
+    // then the taps of its separable kernels (groups x rank components of 2 S doubles)
+    std::vector<size_t> off((size_t)n_batteries + 1, 0), sep_off((size_t)n_batteries, 0);
+    size_t dense_total = 0;
     for (int b = 0; b < n_batteries; ++b) {
-        const int nk = n_kernels[b];
-        if (nk != 1 && nk != 2 && nk != 4 && nk != 8) {
-            set_error("filter battery: 1, 2, 4 or 8 kernels per battery are supported");
+        const int nk = n_kernels[b], ng = sep_taps ? sep_groups[b] : 0, rk = sep_taps ? sep_rank[b] : 0;
+        if ((nk != 0 && nk != 1 && nk != 2 && nk != 4 && nk != 6 && nk != 8) || ng < 0 || ng > 2 || (ng > 0 && (rk < 1 || rk > 4)) ||
+            (nk == 0 && ng == 0)) {
+            set_error("filter battery: 0, 1, 2, 4, 6 or 8 dense kernels and up to 2 separable ones of rank 1..4 per battery");
             return -1;
         }
-        off[b + 1] = off[b] + S * S * nk + S * (S + 8) * nk;
+        sep_off[b] = off[b] + S * S * nk + S * (S + 8) * nk;
+        off[b + 1] = sep_off[b] + (size_t)ng * rk * 2 * S;
+        dense_total += S * S * nk;
+    }
+    if (dense_total > 0 && !weights) {
+        set_error("lm_features: dense kernels without weights");
+        return -1;
     }
     const size_t wtotal = off[n_batteries];
     if (im->tex_resp.ensure((3 * n + wtotal + 1024 + (size_t)n_batteries + 8) * 8 + 64)) return -1;
@@ -970,11 +988,14 @@ int imsegm_image2d_lm_features(imsegm_image2d *im, const double *weights, const 
         return -1;
     }
     {
-        const double *src = weights;
+        const double *src = weights, *ssrc = sep_taps;
         for (int b = 0; b < n_batteries; ++b) {
             const size_t cnt = S * S * n_kernels[b];
-            memcpy(host + off[b], src, cnt * 8);
+            if (cnt) memcpy(host + off[b], src, cnt * 8);
             src += cnt;
+            const size_t scnt = sep_taps ? (size_t)sep_groups[b] * sep_rank[b] * 2 * S : 0;
+            if (scnt) memcpy(host + sep_off[b], ssrc, scnt * 8);
+            ssrc += scnt;
         }
     }
     HIP_TRY(hipMemcpyAsync(d_w, host, wtotal * 8, hipMemcpyHostToDevice, st));
@@ -993,7 +1014,7 @@ int imsegm_image2d_lm_features(imsegm_image2d *im, const double *weights, const 
     for (int b = 0; b < n_batteries; ++b) {
         int spx = ctx->begin(PG_TEX);
         if (launch_filter_battery(im->tex_planes.as<double>(), im->H, im->W, d_w + off[b], n_kernels[b], radius, clip, resp, partial,
-                                  d_ssq + b, st, 3))
+                                  d_ssq + b, st, 3, d_w + sep_off[b], sep_taps ? sep_groups[b] : 0, sep_taps ? sep_rank[b] : 0))
             return -1;
         ctx->end(spx);
         // |r| <= norm  =>  |r * mul / div| <= mul = log(1 + norm) / 0.03 < 2^15 for every finite norm: the bound the fixed-point

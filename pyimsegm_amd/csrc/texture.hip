@@ -233,6 +233,95 @@ k_conv_battery(const double *__restrict__ planes, int H, int W, const double *__
     }
 }
 
+// ---- kernels of the bank that are separable -------------------------------------------------------------------------------
+// 28 of the 76 Leung-Malik kernels have rank 1 or 2 as 33 x 33 matrices: the Gaussians (rank 1), both Laplacians of a Gaussian
+// (rank 2: g''(x) g(y) + g(x) g''(y)) and the edge / bar filters at 0 and 90 degrees (rank 1: gx(3 sigma) gy'(sigma) on the
+// unrotated grid) -- 37 % of the 2 * 10^12 flops of an image spent on dense 33 x 33 sums that two 33-tap passes give as well.
+// The host factorises every kernel (SVD, pyimsegm_amd._hip); a component is a pair (x taps, y taps) of the flipped kernel, a
+// group the components that add up to ONE kernel's response, and the battery's response the maximum over its groups -- and, with
+// `merge`, over what the dense kernel has already written for the battery's other orientations.  Per 64 x 16 outputs: the input
+// tile with its halo in LDS (as the dense kernel), per component the x pass over all tile rows into a second LDS plane, then the
+// y pass from there: 4 * 33 FMAs per output and component instead of 1089 per kernel.
+// ST: the kernel side 2 * radius + 1 at compile time (33 for the Leung-Malik bank: both tap loops unroll and the taps of a
+// component become scalar registers loaded once, so that an FMA costs one LDS read), or 0: any radius, loops at run time.
+constexpr int SEP_MAX_GROUPS = 2;
+
+template <int ST>
+__global__ void __launch_bounds__(256)
+k_sep_battery(const double *__restrict__ planes, int H, int W, const double *__restrict__ taps, int radius, int n_groups, int rank,
+              double clip, int merge, double *__restrict__ resp)
+{
+    extern __shared__ double sep_sm[];
+    const int S = ST > 0 ? ST : 2 * radius + 1;
+    const int tw = CV_TX + 2 * radius, th = CV_TY + 2 * radius;
+    double *tile = sep_sm;                       // [th][tw]   input
+    double *T = sep_sm + (size_t)th * tw;        // [th][CV_TX] x pass of the current component
+    const int ch = blockIdx.z;
+    const double *src = planes + (size_t)ch * H * W;
+    const int x0 = blockIdx.x * CV_TX, y0 = blockIdx.y * CV_TY;
+    for (int i = threadIdx.x; i < tw * th; i += 256) {
+        const int ty = i / tw, tx = i - ty * tw;
+        tile[i] = src[(size_t)reflect_index(y0 + ty - radius, H) * W + reflect_index(x0 + tx - radius, W)];
+    }
+    __syncthreads();
+    const int lx = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int ly = wave * CV_ROWS;
+    double acc[SEP_MAX_GROUPS][CV_ROWS];
+#pragma unroll
+    for (int g = 0; g < SEP_MAX_GROUPS; ++g)
+#pragma unroll
+        for (int i = 0; i < CV_ROWS; ++i) acc[g][i] = 0.0;
+#pragma unroll
+    for (int g = 0; g < SEP_MAX_GROUPS; ++g) {
+        if (g >= n_groups) break;
+        for (int c = 0; c < rank; ++c) {
+            const double *vx = taps + (size_t)(g * rank + c) * 2 * S, *uy = vx + S;       // wave uniform: scalar loads
+            for (int ty = wave; ty < th; ty += 4) {
+                const double *row = tile + (size_t)ty * tw + lx;
+                double v = 0.0;
+                if (ST > 0) {
+#pragma unroll
+                    for (int k = 0; k < (ST > 0 ? ST : 1); ++k) v = fma(vx[k], row[k], v);
+                } else {
+                    for (int k = 0; k < S; ++k) v = fma(vx[k], row[k], v);
+                }
+                T[ty * CV_TX + lx] = v;
+            }
+            __syncthreads();
+            if (ST > 0) {
+                // (a value of the x pass serves the up to CV_ROWS output rows it lies in the window of: one LDS read, up to 4 FMAs)
+#pragma unroll
+                for (int q = 0; q < (ST > 0 ? ST : 1) + CV_ROWS - 1; ++q) {
+                    const double tv = T[(ly + q) * CV_TX + lx];
+#pragma unroll
+                    for (int i = 0; i < CV_ROWS; ++i)
+                        if (q - i >= 0 && q - i < ST) acc[g][i] = fma(uy[q - i], tv, acc[g][i]);
+                }
+            } else {
+                for (int t = 0; t < S; ++t) {
+                    const double w = uy[t];
+#pragma unroll
+                    for (int i = 0; i < CV_ROWS; ++i) acc[g][i] = fma(w, T[(ly + i + t) * CV_TX + lx], acc[g][i]);
+                }
+            }
+            __syncthreads();
+        }
+    }
+    const int x = x0 + lx;
+#pragma unroll
+    for (int i = 0; i < CV_ROWS; ++i) {
+        const int y = y0 + ly + i;
+        if (x >= W || y >= H) continue;
+        double r = acc[0][i];
+        if (n_groups > 1) r = fmax(r, acc[1][i]);
+        double *out = resp + (size_t)ch * H * W + (size_t)y * W + x;
+        if (merge) r = fmax(r, *out);            // (the dense kernels' maximum, already clipped: min and max commute here)
+        if (r > clip) r = clip;
+        *out = r;
+    }
+}
+
 // deterministic sum of squares: per-block partials, then one block adds them in a fixed order
 __global__ void __launch_bounds__(256) k_sumsq_partial(const double *__restrict__ v, size_t n, double *partial)
 {
@@ -293,10 +382,16 @@ int launch_texture_prepare_volume(const void *vol, int dtype, int P, int H, int 
 }
 
 int launch_filter_battery(const double *planes, int H, int W, const double *wgt_dev, int nk, int radius, double clip,
-                          double *resp, double *partial, double *sumsq_dev, hipStream_t st, int P)
+                          double *resp, double *partial, double *sumsq_dev, hipStream_t st, int P, const double *sep_dev, int sep_groups,
+                          int sep_rank)
 {
-    if (nk != 1 && nk != 2 && nk != 4 && nk != 8) {
-        set_error("filter battery: 1, 2, 4 or 8 kernels per battery are supported");
+    if (nk != 0 && nk != 1 && nk != 2 && nk != 4 && nk != 6 && nk != 8) {
+        set_error("filter battery: 1, 2, 4, 6 or 8 dense kernels per battery are supported");
+        return -1;
+    }
+    if (sep_groups < 0 || sep_groups > SEP_MAX_GROUPS || (sep_groups > 0 && (!sep_dev || sep_rank < 1 || sep_rank > 4)) ||
+        (nk == 0 && sep_groups == 0)) {
+        set_error("filter battery: up to 2 separable kernels of rank 1..4, and at least one kernel in all");
         return -1;
     }
     const int S = 2 * radius + 1, Spad = conv_padded_rows(radius);
@@ -305,17 +400,35 @@ int launch_filter_battery(const double *planes, int H, int W, const double *wgt_
         set_error("filter battery: kernel radius too large for the LDS tile");
         return -1;
     }
-    // (the padded table lives behind the caller's weights: launch_filter_battery's caller reserves S * Spad * nk doubles there)
-    double *wpad = const_cast<double *>(wgt_dev) + (size_t)S * S * nk;
-    hipLaunchKernelGGL(k_pad_weights, cdiv((long)S * Spad * nk, 256), 256, 0, st, wgt_dev, S, Spad, nk, wpad);
     dim3 grid(cdiv(W, CV_TX), cdiv(H, CV_TY), P);
-    const void *fn = nk == 8 ? (const void *)k_conv_battery<8> : nk == 4 ? (const void *)k_conv_battery<4>
-                   : nk == 2 ? (const void *)k_conv_battery<2> : (const void *)k_conv_battery<1>;
-    if (lds > 48 * 1024) HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    if (nk == 8) hipLaunchKernelGGL(k_conv_battery<8>, grid, 256, lds, st, planes, H, W, wpad, radius, clip, resp);
-    else if (nk == 4) hipLaunchKernelGGL(k_conv_battery<4>, grid, 256, lds, st, planes, H, W, wpad, radius, clip, resp);
-    else if (nk == 2) hipLaunchKernelGGL(k_conv_battery<2>, grid, 256, lds, st, planes, H, W, wpad, radius, clip, resp);
-    else hipLaunchKernelGGL(k_conv_battery<1>, grid, 256, lds, st, planes, H, W, wpad, radius, clip, resp);
+    if (nk > 0) {
+        // (the padded table lives behind the caller's weights: launch_filter_battery's caller reserves S * Spad * nk doubles there)
+        double *wpad = const_cast<double *>(wgt_dev) + (size_t)S * S * nk;
+        hipLaunchKernelGGL(k_pad_weights, cdiv((long)S * Spad * nk, 256), 256, 0, st, wgt_dev, S, Spad, nk, wpad);
+        const void *fn = nk == 8 ? (const void *)k_conv_battery<8> : nk == 6 ? (const void *)k_conv_battery<6>
+                       : nk == 4 ? (const void *)k_conv_battery<4> : nk == 2 ? (const void *)k_conv_battery<2> : (const void *)k_conv_battery<1>;
+        if (lds > 48 * 1024) HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        if (nk == 8) hipLaunchKernelGGL(k_conv_battery<8>, grid, 256, lds, st, planes, H, W, wpad, radius, clip, resp);
+        else if (nk == 6) hipLaunchKernelGGL(k_conv_battery<6>, grid, 256, lds, st, planes, H, W, wpad, radius, clip, resp);
+        else if (nk == 4) hipLaunchKernelGGL(k_conv_battery<4>, grid, 256, lds, st, planes, H, W, wpad, radius, clip, resp);
+        else if (nk == 2) hipLaunchKernelGGL(k_conv_battery<2>, grid, 256, lds, st, planes, H, W, wpad, radius, clip, resp);
+        else hipLaunchKernelGGL(k_conv_battery<1>, grid, 256, lds, st, planes, H, W, wpad, radius, clip, resp);
+    }
+    if (sep_groups > 0) {
+        const size_t sep_lds = ((size_t)(CV_TX + 2 * radius) + CV_TX) * (CV_TY + 2 * radius) * sizeof(double);
+        if (sep_lds > 150 * 1024) {
+            set_error("filter battery: kernel radius too large for the LDS tile");
+            return -1;
+        }
+        const void *sfn = radius == 16 ? (const void *)k_sep_battery<33> : (const void *)k_sep_battery<0>;
+        if (sep_lds > 48 * 1024) HIP_TRY(hipFuncSetAttribute(sfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sep_lds));
+        if (radius == 16)
+            hipLaunchKernelGGL(k_sep_battery<33>, grid, 256, sep_lds, st, planes, H, W, sep_dev, radius, sep_groups, sep_rank, clip,
+                               nk > 0 ? 1 : 0, resp);
+        else
+            hipLaunchKernelGGL(k_sep_battery<0>, grid, 256, sep_lds, st, planes, H, W, sep_dev, radius, sep_groups, sep_rank, clip,
+                               nk > 0 ? 1 : 0, resp);
+    }
     const int nb = 1024;
     hipLaunchKernelGGL(k_sumsq_partial, nb, 256, 0, st, resp, (size_t)P * H * W, partial);
     hipLaunchKernelGGL(k_sumsq_final, 1, 256, 0, st, partial, nb, sumsq_dev);

@@ -233,6 +233,13 @@ def test_texture_one_call_equals_battery_by_battery(flags):
     ref = np.hstack(blocks)
     assert one.shape == ref.shape == (seg.max() + 1, 3 * len(flags) * len(filters))
     assert np.max(np.abs(one - ref)) <= 1e-11 * max(1.0, np.abs(ref).max()), np.max(np.abs(one - ref))
+    # ... the separable kernels of the bank (28 of 76: two 33-tap passes instead of a 33 x 33 sum) against the all-dense evaluation
+    sess = _hip.Image2D(90, 141).upload(img).set_labels(seg)
+    sess.lm_prepare(150.)
+    dense = sess.lm_features(filters, D.MAX_SIGNAL_RESPONSE, mean='mean' in flags, std='std' in flags, energy='energy' in flags,
+                             separable=False)
+    sess.close()
+    assert np.max(np.abs(one - dense)) <= 1e-9 * max(1.0, np.abs(dense).max()), np.max(np.abs(one - dense))
     # ... and through the descriptor function the pipelines call
     fts, names = D.compute_texture_desc_lm_img2d_clr(img, seg, list(flags))
     assert fts.shape == one.shape and len(names) == one.shape[1]

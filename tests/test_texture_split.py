@@ -1,0 +1,34 @@
+"""Host side of the separable Leung-Malik kernels (pyimsegm_amd._hip.Image2D._split_battery): which kernels of the bank of
+/root/reference/imsegm/descriptors.py:903-948 leave the dense 33 x 33 sums, and that their factors reproduce them."""
+import numpy as np
+
+
+def test_the_separable_kernels_of_the_bank_and_their_factors():
+    from pyimsegm_amd import _hip, descriptors as D
+    filters, names = D.create_filter_bank_lm_2d()
+    assert sum(len(b) for b in filters) == 76
+    taken = 0
+    for battery, name in zip(filters, names):
+        weights, dense, taps, groups, rank, radius = _hip.Image2D._split_battery(battery)
+        assert radius == 16 and dense in (0, 6) and taps.shape == (groups, rank, 2, 33)
+        kind = name.split('-')[1]
+        # the Gaussian: rank 1; both Laplacians of a Gaussian: rank 2; edge / bar: the orientations 0 and 90 degrees, rank 1 each
+        assert (groups, rank, dense) == {'Gauss': (1, 1, 0), 'GaussLap': (1, 2, 0), 'GaussLap2': (1, 2, 0), 'edge': (2, 1, 6),
+                                        'bar': (2, 1, 6)}[kind], name
+        taken += groups
+        flipped = np.asarray(battery)[:, ::-1, ::-1]
+        which = [0, 4] if len(battery) == 8 else [0]
+        for g, k in enumerate(which):
+            rebuilt = sum(np.outer(taps[g, i, 1], taps[g, i, 0]) for i in range(rank))          # sum_i y_i x_i^T
+            assert np.max(np.abs(rebuilt - flipped[k])) <= 1e-15 * max(1.0, np.abs(flipped[k]).max() * 1e2), name
+        if dense:
+            rest = [k for k in range(len(battery)) if k not in which]
+            assert weights.shape == (33, 33, dense)
+            for j, k in enumerate(rest):
+                assert np.array_equal(weights[:, :, j], flipped[k].T)                           # layout [kx][ky][kernel]
+    assert taken == 28
+    # separable=False: everything dense, padded to 1 / 2 / 4 / 6 / 8 kernels by repeating the last one
+    weights, dense, taps, groups, rank, _ = _hip.Image2D._split_battery(filters[0], separable=False)
+    assert (dense, groups, rank) == (8, 0, 0) and taps.size == 0
+    weights, dense, _, groups, _, _ = _hip.Image2D._split_battery(np.asarray(filters[0])[1:4], separable=False)
+    assert dense == 4 and np.array_equal(weights[:, :, 3], weights[:, :, 2])
