@@ -164,10 +164,13 @@ IMSEGM_API int imsegm_image2d_lm_features(imsegm_image2d *img, const double *wei
  * as above) plus sep_groups[b] (0..2) separable kernels of sep_rank[b] (1..4) components each; sep_taps holds, battery after
  * battery, kernel after kernel, component after component, the 2 radius + 1 taps along x and then along y of the FLIPPED kernel
  * (the singular value folded into the y taps: K_flipped = sum_i y_i x_i^T).  The response of a battery is the maximum over all its
- * kernels, as before; the factorisation is the caller's (pyimsegm_amd._hip: numpy SVD, components above 1e-13 of the largest). */
-IMSEGM_API int imsegm_image2d_lm_features_sep(imsegm_image2d *img, const double *weights, const int *n_kernels, const double *sep_taps,
-                                              const int *sep_groups, const int *sep_rank, int n_batteries, int radius, double clip,
-                                              int feature_mask, double *features_out);
+ * kernels, as before; the factorisation is the caller's (pyimsegm_amd._hip: numpy SVD, components above 1e-13 of the largest).
+ * dense_parity[b] (or NULL): +1 / -1 when EVERY dense kernel of battery b is even / odd under the point reflection, K[-p] ==
+ * +/- K[p] bit for bit (all bar / edge filters of the bank are) -- the sums are then formed over half the kernel, one addition
+ * per pair of pixels serving all kernels of the battery; 0: no symmetry is assumed. */
+IMSEGM_API int imsegm_image2d_lm_features_sep(imsegm_image2d *img, const double *weights, const int *n_kernels, const int *dense_parity,
+                                              const double *sep_taps, const int *sep_groups, const int *sep_rank, int n_batteries,
+                                              int radius, double clip, int feature_mask, double *features_out);
 
 /* Leung-Malik texture responses (imsegm/descriptors.py:951-1106, scipy.ndimage in the reference).
  * lm_prepare: planes = image - gaussian_filter(image, sigma) with `taps` = half kernel of

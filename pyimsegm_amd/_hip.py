@@ -112,7 +112,7 @@ _SIGNATURES = {
     'imsegm_image2d_graph': (C.c_int, [_vp, _vp, C.c_int, _ip, _vp, _vp]),
     'imsegm_image2d_gather': (C.c_int, [_vp, _vp, _vp, C.c_int, _vp, _vp]),
     'imsegm_image2d_lm_prepare': (C.c_int, [_vp, _vp, C.c_int, _vp]),
-    'imsegm_image2d_lm_features_sep': (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_double, C.c_int, _vp]),
+    'imsegm_image2d_lm_features_sep': (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_double, C.c_int, _vp]),
     'imsegm_image2d_lm_battery': (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_double, C.POINTER(C.c_double)]),
     'imsegm_image2d_response_stats': (C.c_int, [_vp, C.c_double, C.c_double, _vp, _vp, _vp]),
     'imsegm_image2d_get_response': (C.c_int, [_vp, _vp]),
@@ -698,7 +698,7 @@ class Image2D(object):
     SEPARABLE_TOLERANCE, SEPARABLE_MAX_RANK = 1e-13, 2
 
     @classmethod
-    def _split_battery(cls, battery, separable=True):
+    def _split_battery(cls, battery, separable=True, symmetric=True):
         """one battery (k x S x S convolution kernels) as the device takes it: (dense weights [kx][ky][kernel] of the flipped
         kernels that stay dense, their number after padding to 0 / 1 / 2 / 4 / 6 / 8, separable taps, groups, rank, radius).
         A kernel of numerical rank <= SEPARABLE_MAX_RANK (numpy SVD of the flipped kernel) becomes `rank` pairs of (x taps, y
@@ -731,12 +731,19 @@ class Image2D(object):
         if pad != len(dense):            # repeat the last kernel: the maximum is unchanged
             dense = dense + [dense[-1]] * (pad - len(dense))
         weights = np.ascontiguousarray(np.asarray(dense).transpose(2, 1, 0)) if dense else np.zeros(0)
-        return weights, pad, taps, len(factors), rank, side // 2
+        # point symmetry of the kernels that stay dense: all even (K[-p] == K[p]) -> +1, all odd -> -1, bit for bit; else 0
+        parity = 0
+        if dense and symmetric:
+            if all(np.array_equal(k[::-1, ::-1], k) for k in dense):
+                parity = 1
+            elif all(np.array_equal(k[::-1, ::-1], -k) for k in dense):
+                parity = -1
+        return weights, pad, taps, len(factors), rank, side // 2, parity
 
     def lm_features(self, batteries, clip, mean=True, std=True, energy=True, separable=True):
         """``imsegm_image2d_lm_features_sep``: K x (3 * flags * len(batteries)) statistics of all batteries in one call;
         ``separable=False``: every kernel as a dense S x S sum (``imsegm_image2d_lm_features``)"""
-        parts = [self._split_battery(b, separable) for b in batteries]
+        parts = [self._split_battery(b, separable, separable) for b in batteries]
         radius = parts[0][5]
         if any(p[5] != radius for p in parts):
             raise ValueError('the batteries of one call have one kernel size')
@@ -745,10 +752,11 @@ class Image2D(object):
         taps = np.concatenate([p[2].ravel() for p in parts])
         groups = np.array([p[3] for p in parts], dtype=np.int32)
         ranks = np.array([p[4] for p in parts], dtype=np.int32)
+        parity = np.array([p[6] for p in parts], dtype=np.int32)
         mask = (1 if mean else 0) | (2 if std else 0) | (4 if energy else 0)
         out = np.empty((self.n_labels, 3 * bin(mask).count('1') * len(parts)), dtype=np.float64)
         _check(load_library().imsegm_image2d_lm_features_sep(
-            self._h, _ptr(weights) if weights.size else None, _ptr(counts), _ptr(taps) if taps.size else None, _ptr(groups), _ptr(ranks),
+            self._h, _ptr(weights) if weights.size else None, _ptr(counts), _ptr(parity), _ptr(taps) if taps.size else None, _ptr(groups), _ptr(ranks),
             len(parts), radius, float(clip), mask, _ptr(out)))
         return out
 

@@ -913,7 +913,7 @@ int imsegm_image2d_lm_battery(imsegm_image2d *im, const double *weights, int n_k
     const int P = im->is_volume ? im->D : 3;
     const size_t S = 2 * (size_t)radius + 1;
     const size_t wbytes = S * S * n_kernels * 8;
-    const size_t wpad = S * (S + 8) * n_kernels;                     // the row-padded copy the battery kernel reads (texture.hip)
+    const size_t wpad = S * (S + 16) * n_kernels;                    // the row-padded copy the battery kernel reads (texture.hip)
     if (im->tex_resp.ensure(3 * n * 8 + wbytes + wpad * 8 + 1024 * 8 + 64)) return -1;
     double *resp = im->tex_resp.as<double>();
     double *d_w = resp + 3 * n;
@@ -933,13 +933,13 @@ int imsegm_image2d_lm_battery(imsegm_image2d *im, const double *weights, int n_k
 int imsegm_image2d_lm_features(imsegm_image2d *im, const double *weights, const int *n_kernels, int n_batteries, int radius, double clip,
                                int feature_mask, double *features_out)
 {
-    return imsegm_image2d_lm_features_sep(im, weights, n_kernels, nullptr, nullptr, nullptr, n_batteries, radius, clip, feature_mask,
-                                          features_out);
+    return imsegm_image2d_lm_features_sep(im, weights, n_kernels, nullptr, nullptr, nullptr, nullptr, n_batteries, radius, clip,
+                                          feature_mask, features_out);
 }
 
-int imsegm_image2d_lm_features_sep(imsegm_image2d *im, const double *weights, const int *n_kernels, const double *sep_taps,
-                                   const int *sep_groups, const int *sep_rank, int n_batteries, int radius, double clip, int feature_mask,
-                                   double *features_out)
+int imsegm_image2d_lm_features_sep(imsegm_image2d *im, const double *weights, const int *n_kernels, const int *dense_parity,
+                                   const double *sep_taps, const int *sep_groups, const int *sep_rank, int n_batteries, int radius,
+                                   double clip, int feature_mask, double *features_out)
 {
     if (!im || bind(im->ctx)) return -1;
     if (wrong_kind(im, false)) return -1;
@@ -968,7 +968,7 @@ int imsegm_image2d_lm_features_sep(imsegm_image2d *im, const double *weights, co
             set_error("filter battery: 0, 1, 2, 4, 6 or 8 dense kernels and up to 2 separable ones of rank 1..4 per battery");
             return -1;
         }
-        sep_off[b] = off[b] + S * S * nk + S * (S + 8) * nk;
+        sep_off[b] = off[b] + S * S * nk + S * (S + 16) * nk;
         off[b + 1] = sep_off[b] + (size_t)ng * rk * 2 * S;
         dense_total += S * S * nk;
     }
@@ -1014,7 +1014,8 @@ int imsegm_image2d_lm_features_sep(imsegm_image2d *im, const double *weights, co
     for (int b = 0; b < n_batteries; ++b) {
         int spx = ctx->begin(PG_TEX);
         if (launch_filter_battery(im->tex_planes.as<double>(), im->H, im->W, d_w + off[b], n_kernels[b], radius, clip, resp, partial,
-                                  d_ssq + b, st, 3, d_w + sep_off[b], sep_taps ? sep_groups[b] : 0, sep_taps ? sep_rank[b] : 0))
+                                  d_ssq + b, st, 3, d_w + sep_off[b], sep_taps ? sep_groups[b] : 0, sep_taps ? sep_rank[b] : 0,
+                                  dense_parity ? dense_parity[b] : 0))
             return -1;
         ctx->end(spx);
         // |r| <= norm  =>  |r * mul / div| <= mul = log(1 + norm) / 0.03 < 2^15 for every finite norm: the bound the fixed-point

@@ -234,9 +234,11 @@ int launch_texture_prepare_volume(const void *vol, int dtype, int P, int H, int 
 // P planes of H x W (3 colour channels, or the D slices of a gray volume)
 int launch_filter_battery(const double *planes, int H, int W, const double *wgt_dev, int nk, int radius, double clip,
                           double *resp, double *partial, double *sumsq_dev, hipStream_t st, int P = 3, const double *sep_dev = nullptr,
-                          int sep_groups = 0, int sep_rank = 0);
+                          int sep_groups = 0, int sep_rank = 0, int parity = 0);
 // (nk dense kernels -- 0, 1, 2, 4, 6 or 8 -- plus sep_groups separable kernels of sep_rank components each: per component the x
-// taps then the y taps of the flipped kernel, 2 * (2 radius + 1) doubles; the response is the maximum over all of them)
+// taps then the y taps of the flipped kernel, 2 * (2 radius + 1) doubles; the response is the maximum over all of them;
+// parity +1 / -1: every dense kernel is even / odd under the point reflection, bit for bit -- the caller has checked)
+// the caller reserves S * S * nk + S * (S + 16) * nk doubles behind wgt_dev (the weights, then their row-padded copy)
 
 // graph.hip ---------------------------------------------------------------------------------------
 int launch_adjacency_centres(const int32_t *labels, int H, int W, int K, uint32_t *bitmap, long long *cacc,

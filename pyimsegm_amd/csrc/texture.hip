@@ -233,6 +233,118 @@ k_conv_battery(const double *__restrict__ planes, int H, int W, const double *__
     }
 }
 
+// ---- dense batteries of kernels with a point symmetry ------------------------------------------------------------------------
+// Every edge filter of the bank is odd and every bar filter even under the point reflection p -> -p, bit for bit (the rotated grid
+// of descriptors.py:924-928 is negated exactly): K(-p) = sign * K(p), so
+//     sum_p K(p) in(q + p)  =  sum_{p in half plane} K(p) * (in(q + p) + sign * in(q - p))  (+ the centre column as before),
+// and ONE addition per pair serves all NK kernels of the battery: 4 + 4 NK vector operations per step of 2 * 4 * NK multiply-adds
+// instead of 8 NK -- 1.7x fewer for NK = 6.  Layout as k_conv_battery: a lane owns one output column and CV_ROWS rows, the weight
+// rows slide through scalar registers.  Kernel column kx < r is paired with column 2r - kx: for the input row j of column A = lx + kx
+// the partner of output row i (weight row t = j - i) is row 2r - j + 2i of column B = lx + 2r - kx -- rows of one parity, so two
+// circular windows of four values (even / odd steps) hold them with ONE new LDS read per step; the step loop is unrolled by 8.
+constexpr int CVS_UNROLL = 8;
+__host__ __device__ static inline int conv_sym_padded_rows(int radius) { return ((2 * radius + 1 + CV_ROWS - 1 + CVS_UNROLL - 1) / CVS_UNROLL) * CVS_UNROLL; }
+
+template <int NK>
+__global__ void __launch_bounds__(256)
+k_conv_battery_sym(const double *__restrict__ planes, int H, int W, const double *__restrict__ wgt, int radius, double sign,
+                   double clip, double *__restrict__ resp)
+{
+    extern __shared__ double tile[];                 // [(CV_TY - CV_ROWS + Spad)][(CV_TX + 2r)]
+    const int Spad = conv_sym_padded_rows(radius);
+    const int tw = CV_TX + 2 * radius, th = CV_TY + 2 * radius, th_pad = CV_TY - CV_ROWS + Spad;
+    const int ch = blockIdx.z;
+    const double *src = planes + (size_t)ch * H * W;
+    const int x0 = blockIdx.x * CV_TX, y0 = blockIdx.y * CV_TY;
+    for (int i = threadIdx.x; i < tw * th_pad; i += 256) {
+        int ty = i / tw, tx = i - ty * tw;
+        // (rows behind the halo only ever meet zero weights: any finite value will do)
+        int gy = reflect_index(y0 + min(ty, th - 1) - radius, H), gx = reflect_index(x0 + tx - radius, W);
+        tile[i] = src[(size_t)gy * W + gx];
+    }
+    __syncthreads();
+    const int lx = threadIdx.x & 63;
+    const int ly = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) * CV_ROWS;
+    double acc[NK][CV_ROWS];
+#pragma unroll
+    for (int k = 0; k < NK; ++k)
+#pragma unroll
+        for (int i = 0; i < CV_ROWS; ++i) acc[k][i] = 0.0;
+    for (int kx = 0; kx < radius; ++kx) {
+        const double *wk = wgt + (size_t)kx * Spad * NK;
+        const double *colA = tile + lx + kx, *colB = tile + lx + 2 * radius - kx;
+        double w[CV_ROWS][NK];
+#pragma unroll
+        for (int u = 0; u < CV_ROWS; ++u)
+#pragma unroll
+            for (int k = 0; k < NK; ++k) w[u][k] = 0.0;
+        // partner rows of column B: window E serves the even steps (rows 2r - j + 2i, j even), O the odd ones; slot e mod 4
+        // takes the row read at even step number e, the output row i looks i even steps back.  Before the first step the windows
+        // hold the rows above 2r that meet non-zero weight rows (2r + 2 | 2r + 1, 2r + 3); every other start value only meets
+        // the zero rows of the padded weight table
+        double E[4] = { 0.0, 0.0, 0.0, colB[(size_t)(ly + 2 * radius + 2) * tw] };
+        double O[4] = { 0.0, 0.0, colB[(size_t)(ly + 2 * radius + 3) * tw], colB[(size_t)(ly + 2 * radius + 1) * tw] };
+        for (int g = 0; g < Spad; g += CVS_UNROLL) {
+#pragma unroll
+            for (int u = 0; u < CVS_UNROLL; ++u) {
+                const int j = g + u;
+#pragma unroll
+                for (int k = 0; k < NK; ++k) w[u % CV_ROWS][k] = wk[j * NK + k];         // weight row t = j into slot j mod CV_ROWS
+                const double a = colA[(size_t)(ly + j) * tw];
+                const double b = colB[(size_t)max(ly + 2 * radius - j, 0) * tw];
+                double sv[CV_ROWS];
+                if ((u & 1) == 0) {
+                    E[(u / 2) % 4] = b;
+#pragma unroll
+                    for (int i = 0; i < CV_ROWS; ++i) sv[i] = fma(sign, E[((u / 2) - i + 4) % 4], a);
+                } else {
+                    O[(u / 2) % 4] = b;
+#pragma unroll
+                    for (int i = 0; i < CV_ROWS; ++i) sv[i] = fma(sign, O[((u / 2) - i + 4) % 4], a);
+                }
+#pragma unroll
+                for (int i = 0; i < CV_ROWS; ++i)
+#pragma unroll
+                    for (int k = 0; k < NK; ++k) acc[k][i] = fma(w[(u - i + 2 * CV_ROWS) % CV_ROWS][k], sv[i], acc[k][i]);
+            }
+        }
+    }
+    {
+        // the centre column pairs with itself: the plain sum of k_conv_battery over its Spad rows
+        const double *wk = wgt + (size_t)radius * Spad * NK;
+        const double *col = tile + lx + radius;
+        double w[CV_ROWS][NK];
+#pragma unroll
+        for (int u = 0; u < CV_ROWS; ++u)
+#pragma unroll
+            for (int k = 0; k < NK; ++k) w[u][k] = 0.0;
+        for (int g = 0; g < Spad; g += CV_ROWS) {
+#pragma unroll
+            for (int u = 0; u < CV_ROWS; ++u) {
+                const int j = g + u;
+#pragma unroll
+                for (int k = 0; k < NK; ++k) w[u][k] = wk[j * NK + k];
+                const double v = col[(size_t)(ly + j) * tw];
+#pragma unroll
+                for (int i = 0; i < CV_ROWS; ++i)
+#pragma unroll
+                    for (int k = 0; k < NK; ++k) acc[k][i] = fma(w[(u - i + CV_ROWS) % CV_ROWS][k], v, acc[k][i]);
+            }
+        }
+    }
+    const int x = x0 + lx;
+#pragma unroll
+    for (int i = 0; i < CV_ROWS; ++i) {
+        const int y = y0 + ly + i;
+        if (x >= W || y >= H) continue;
+        double r = acc[0][i];
+#pragma unroll
+        for (int k = 1; k < NK; ++k) r = fmax(r, acc[k][i]);
+        if (r > clip) r = clip;
+        resp[(size_t)ch * H * W + (size_t)y * W + x] = r;
+    }
+}
+
 // ---- kernels of the bank that are separable -------------------------------------------------------------------------------
 // 28 of the 76 Leung-Malik kernels have rank 1 or 2 as 33 x 33 matrices: the Gaussians (rank 1), both Laplacians of a Gaussian
 // (rank 2: g''(x) g(y) + g(x) g''(y)) and the edge / bar filters at 0 and 90 degrees (rank 1: gx(3 sigma) gy'(sigma) on the
@@ -383,7 +495,7 @@ int launch_texture_prepare_volume(const void *vol, int dtype, int P, int H, int 
 
 int launch_filter_battery(const double *planes, int H, int W, const double *wgt_dev, int nk, int radius, double clip,
                           double *resp, double *partial, double *sumsq_dev, hipStream_t st, int P, const double *sep_dev, int sep_groups,
-                          int sep_rank)
+                          int sep_rank, int parity)
 {
     if (nk != 0 && nk != 1 && nk != 2 && nk != 4 && nk != 6 && nk != 8) {
         set_error("filter battery: 1, 2, 4, 6 or 8 dense kernels per battery are supported");
@@ -401,7 +513,27 @@ int launch_filter_battery(const double *planes, int H, int W, const double *wgt_
         return -1;
     }
     dim3 grid(cdiv(W, CV_TX), cdiv(H, CV_TY), P);
-    if (nk > 0) {
+    if (nk > 0 && parity != 0) {
+        // every dense kernel of the battery is even (+1) or odd (-1) under the point reflection: half the multiplications
+        const int Spad8 = conv_sym_padded_rows(radius);
+        const size_t lds8 = (size_t)(CV_TX + 2 * radius) * (CV_TY - CV_ROWS + Spad8) * sizeof(double);
+        if (lds8 > 150 * 1024) {
+            set_error("filter battery: kernel radius too large for the LDS tile");
+            return -1;
+        }
+        double *wpad = const_cast<double *>(wgt_dev) + (size_t)S * S * nk;
+        hipLaunchKernelGGL(k_pad_weights, cdiv((long)S * Spad8 * nk, 256), 256, 0, st, wgt_dev, S, Spad8, nk, wpad);
+        const void *fn = nk == 8 ? (const void *)k_conv_battery_sym<8> : nk == 6 ? (const void *)k_conv_battery_sym<6>
+                       : nk == 4 ? (const void *)k_conv_battery_sym<4> : nk == 2 ? (const void *)k_conv_battery_sym<2>
+                                                                                 : (const void *)k_conv_battery_sym<1>;
+        if (lds8 > 48 * 1024) HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds8));
+        const double sign = parity > 0 ? 1.0 : -1.0;
+        if (nk == 8) hipLaunchKernelGGL(k_conv_battery_sym<8>, grid, 256, lds8, st, planes, H, W, wpad, radius, sign, clip, resp);
+        else if (nk == 6) hipLaunchKernelGGL(k_conv_battery_sym<6>, grid, 256, lds8, st, planes, H, W, wpad, radius, sign, clip, resp);
+        else if (nk == 4) hipLaunchKernelGGL(k_conv_battery_sym<4>, grid, 256, lds8, st, planes, H, W, wpad, radius, sign, clip, resp);
+        else if (nk == 2) hipLaunchKernelGGL(k_conv_battery_sym<2>, grid, 256, lds8, st, planes, H, W, wpad, radius, sign, clip, resp);
+        else hipLaunchKernelGGL(k_conv_battery_sym<1>, grid, 256, lds8, st, planes, H, W, wpad, radius, sign, clip, resp);
+    } else if (nk > 0) {
         // (the padded table lives behind the caller's weights: launch_filter_battery's caller reserves S * Spad * nk doubles there)
         double *wpad = const_cast<double *>(wgt_dev) + (size_t)S * S * nk;
         hipLaunchKernelGGL(k_pad_weights, cdiv((long)S * Spad * nk, 256), 256, 0, st, wgt_dev, S, Spad, nk, wpad);

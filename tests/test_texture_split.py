@@ -9,9 +9,10 @@ def test_the_separable_kernels_of_the_bank_and_their_factors():
     assert sum(len(b) for b in filters) == 76
     taken = 0
     for battery, name in zip(filters, names):
-        weights, dense, taps, groups, rank, radius = _hip.Image2D._split_battery(battery)
+        weights, dense, taps, groups, rank, radius, parity = _hip.Image2D._split_battery(battery)
         assert radius == 16 and dense in (0, 6) and taps.shape == (groups, rank, 2, 33)
         kind = name.split('-')[1]
+        assert parity == {'edge': -1, 'bar': 1}.get(kind, 0), name        # (no dense kernels left: nothing to be symmetric)
         # the Gaussian: rank 1; both Laplacians of a Gaussian: rank 2; edge / bar: the orientations 0 and 90 degrees, rank 1 each
         assert (groups, rank, dense) == {'Gauss': (1, 1, 0), 'GaussLap': (1, 2, 0), 'GaussLap2': (1, 2, 0), 'edge': (2, 1, 6),
                                         'bar': (2, 1, 6)}[kind], name
@@ -28,7 +29,7 @@ def test_the_separable_kernels_of_the_bank_and_their_factors():
                 assert np.array_equal(weights[:, :, j], flipped[k].T)                           # layout [kx][ky][kernel]
     assert taken == 28
     # separable=False: everything dense, padded to 1 / 2 / 4 / 6 / 8 kernels by repeating the last one
-    weights, dense, taps, groups, rank, _ = _hip.Image2D._split_battery(filters[0], separable=False)
-    assert (dense, groups, rank) == (8, 0, 0) and taps.size == 0
-    weights, dense, _, groups, _, _ = _hip.Image2D._split_battery(np.asarray(filters[0])[1:4], separable=False)
+    weights, dense, taps, groups, rank, _, parity = _hip.Image2D._split_battery(filters[0], separable=False, symmetric=False)
+    assert (dense, groups, rank, parity) == (8, 0, 0, 0) and taps.size == 0
+    weights, dense, _, groups, _, _, _ = _hip.Image2D._split_battery(np.asarray(filters[0])[1:4], separable=False)
     assert dense == 4 and np.array_equal(weights[:, :, 3], weights[:, :, 2])
