@@ -51,11 +51,16 @@ struct StatParams {
 // |limb| * 256 pixels < 2^53 by the choice of the scales) go through one transposed DPP reduction over the
 // 16 lanes, after which lane j of the row owns the total of quantity j and adds it to the workgroup's LDS
 // slot of the label (open addressing; a full table falls back to global atomics).
+// (RW: rows per lane -- ST_ROWS, or half of that for float64 sources (the filter responses of the texture path): 16 rows of three
+// doubles in flight plus their IEEE divisions took 248 registers, two waves per SIMD)
+template <typename T> struct StatRows { static constexpr int value = sizeof(T) == 8 ? ST_ROWS / 2 : ST_ROWS; };
+
 template <typename T, int PASS, bool U8INT>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, 4)      // (four workgroups a CU = four waves a SIMD: the allocator aims at <= 128 registers)
 k_color_stats(const T *__restrict__ img, const int32_t *__restrict__ labels, StatParams sp,
               const float *__restrict__ mean32, long long *__restrict__ acc)
 {
+    constexpr int RW = StatRows<T>::value;
     ZSHIFT(img, sp.zs); ZSHIFT(labels, sp.zs); ZSHIFT(mean32, sp.zs); ZSHIFT(acc, sp.zs); ZSHIFT(sp.ssq_dev, sp.zs);
     constexpr int NQ = (PASS == 1) ? 13 : 6;
     __shared__ int keys[ST_SLOTS];
@@ -67,13 +72,13 @@ k_color_stats(const T *__restrict__ img, const int32_t *__restrict__ labels, Sta
     }
     __syncthreads();
     const int x = blockIdx.x * 64 + lane;
-    const int y0 = (blockIdx.y * 4 + wave) * ST_ROWS;
+    const int y0 = (blockIdx.y * 4 + wave) * RW;
     // uint8 image, first pass: the terms are small integers (v <= 255, v * v <= 65025 -- the float32 product of the
     // reference is exact), so the block sums are plain int32 sums and the fixed-point limbs are (sum * 2^shift, 0):
     // the same accumulator contents as the general path at a fraction of the instructions
     static_assert(!U8INT || (PASS == 1 && sizeof(T) == 1), "integer block sums: uint8 image, first pass");
-    int lab[ST_ROWS];
-    float v[ST_ROWS][3];
+    int lab[RW];
+    float v[RW][3];
     double mul = sp.mul, div = sp.div;
     bool dead = false;
     if (sp.prescale == 2) {                      // the L2 norm of the response stays on the device (imsegm_image2d_lm_features)
@@ -83,7 +88,7 @@ k_color_stats(const T *__restrict__ img, const int32_t *__restrict__ labels, Sta
         div = norm;
     }
 #pragma unroll
-    for (int r = 0; r < ST_ROWS; ++r) {
+    for (int r = 0; r < RW; ++r) {
         const int y = y0 + r;
         const bool ok = (y < sp.H) && (x < sp.W);
         const size_t p = ok ? (size_t)y * sp.W + x : 0;
@@ -107,13 +112,13 @@ k_color_stats(const T *__restrict__ img, const int32_t *__restrict__ labels, Sta
     while (true) {
         int mine = 0x7fffffff;
 #pragma unroll
-        for (int r = 0; r < ST_ROWS; ++r) mine = min(mine, lab[r]);
+        for (int r = 0; r < RW; ++r) mine = min(mine, lab[r]);
         if (!__any(mine != 0x7fffffff)) break;
         const int k = row16_min_i32(mine);              // uniform over the 16-lane row; 0x7fffffff: row is done
         if (U8INT) {
             int qi[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };     // n, sums of v (3), sums of v * v (3)
 #pragma unroll
-            for (int r = 0; r < ST_ROWS; ++r) {
+            for (int r = 0; r < RW; ++r) {
                 if (lab[r] != k || k == 0x7fffffff) continue;
                 lab[r] = 0x7fffffff;
                 qi[0] += 1;
@@ -148,47 +153,6 @@ k_color_stats(const T *__restrict__ img, const int32_t *__restrict__ labels, Sta
             }
             continue;
         }
-        // partial sums of this lane: PASS 1 -> q[0..5] sums of v, q[6..11] sums of v*v, q[12] count
-        //                            PASS 2 -> q[0..5] sums of (v - mean32)^2
-        constexpr int NV = (PASS == 1) ? 16 : 8;
-        double q[NV];
-#pragma unroll
-        for (int j = 0; j < NV; ++j) q[j] = 0;
-#pragma unroll
-        for (int r = 0; r < ST_ROWS; ++r) {
-            if (lab[r] != k || k == 0x7fffffff) continue;
-            lab[r] = 0x7fffffff;
-            if (PASS == 1) q[12] += 1.0;
-#pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                double t, h;
-                if (PASS == 1) {
-                    float val = v[r][c];
-                    float sq = __fmul_rn(val, val);
-                    t = (double)val * sp.scale_v; h = trunc(t);
-                    q[2 * c] += h; q[2 * c + 1] += trunc((t - h) * 4294967296.0);
-                    t = (double)sq * sp.scale_e; h = trunc(t);
-                    q[6 + 2 * c] += h; q[6 + 2 * c + 1] += trunc((t - h) * 4294967296.0);
-                } else {
-                    float d = __fsub_rn(v[r][c], mean32[3 * k + c]);
-                    float sq = __fmul_rn(d, d);
-                    t = (double)sq * sp.scale_e; h = trunc(t);
-                    q[2 * c] += h; q[2 * c + 1] += trunc((t - h) * 4294967296.0);
-                }
-            }
-        }
-        long long tot;
-        int j;
-        bool owner;
-        if (PASS == 1) {
-            tot = (long long)row16_reduce16_f64(reinterpret_cast<const double (&)[16]>(q), lane);
-            j = lane & 15;
-            owner = j < 13;
-        } else {
-            tot = (long long)row16_reduce8_f64(reinterpret_cast<const double (&)[8]>(q), lane);
-            j = ((lane >> 3) & 1) * 4 + ((lane >> 2) & 1) * 2 + ((lane >> 1) & 1);
-            owner = (lane & 1) == 0 && j < 6;
-        }
         // LDS open-addressing slot of the row's label (found by the first lane of the row)
         int slot = -1;
         if ((lane & 15) == 0 && k != 0x7fffffff) {
@@ -202,14 +166,53 @@ k_color_stats(const T *__restrict__ img, const int32_t *__restrict__ labels, Sta
             slot = probes < ST_SLOTS ? sidx : -1;
         }
         slot = __shfl(slot, lane & 48, 64);
-        if (owner && tot != 0 && k != 0x7fffffff) {
-            // accumulator columns: [0] count, [1..6] value sums, [7..12] squared / variance sums
-            int col = (PASS == 1) ? (j == 12 ? 0 : 1 + j) : j;
-            if (slot >= 0)
-                atomic_add_i64(&lacc[slot][col], tot);
-            else
-                atomic_add_i64(acc + (size_t)k * 13 + ((PASS == 1) ? col : 7 + col), tot);
+        // partial sums of this lane, eight at a time (one transposed reduction over the 16-lane row each: sixteen at once cost
+        // 250+ registers): PASS 1 -> round 0: the value sums (two limbs per channel) and the count, round 1: the sums of v * v;
+        // PASS 2 -> one round: the sums of (v - mean32)^2
+#pragma unroll
+        for (int round = 0; round < (PASS == 1 ? 2 : 1); ++round) {
+            double q[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) q[j] = 0;
+#pragma unroll
+            for (int r = 0; r < RW; ++r) {
+                if (lab[r] != k || k == 0x7fffffff) continue;
+                if (PASS == 1 && round == 0) q[6] += 1.0;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    float term;
+                    if (PASS == 1) {
+                        const float val = v[r][c];
+                        term = round == 0 ? val : __fmul_rn(val, val);
+                    } else {
+                        const float d = __fsub_rn(v[r][c], mean32[3 * k + c]);
+                        term = __fmul_rn(d, d);
+                    }
+                    // (the limbs are formed HERE, per label pass: hoisted out of the pass loop as loop invariants -- what the
+                    // optimiser does when it can see through -- they are 4 x 3 x RW doubles, 400+ registers, one wave per SIMD)
+                    asm volatile("" : "+v"(term));
+                    const double t = (double)term * ((PASS == 1 && round == 0) ? sp.scale_v : sp.scale_e), h = trunc(t);
+                    q[2 * c] += h;
+                    q[2 * c + 1] += trunc((t - h) * 4294967296.0);
+                }
+            }
+            const long long tot = (long long)row16_reduce8_f64(reinterpret_cast<const double (&)[8]>(q), lane);
+            const int j = ((lane >> 3) & 1) * 4 + ((lane >> 2) & 1) * 2 + ((lane >> 1) & 1);
+            const bool owner = (lane & 1) == 0 && (j < 6 || (PASS == 1 && round == 0 && j == 6));
+            if (owner && tot != 0 && k != 0x7fffffff) {
+                // accumulator columns: [0] count, [1..6] value sums, [7..12] squared / variance sums; the LDS slots of the second
+                // pass hold columns 7..12 at 0..5
+                const int col = PASS == 1 ? (round == 0 ? (j == 6 ? 0 : 1 + j) : 7 + j) : j;
+                if (slot >= 0)
+                    atomic_add_i64(&lacc[slot][col], tot);
+                else
+                    atomic_add_i64(acc + (size_t)k * 13 + ((PASS == 1) ? col : 7 + col), tot);
+            }
         }
+        // (this label of the row is through)
+#pragma unroll
+        for (int r = 0; r < RW; ++r)
+            if (lab[r] == k) lab[r] = 0x7fffffff;
     }
     __syncthreads();
     for (int i = tid; i < ST_SLOTS * NQ; i += 256) {
@@ -270,7 +273,7 @@ template <typename T>
 static void launch_pass(int pass, const T *img, const int32_t *labels, StatParams sp, const float *mean32,
                         long long *acc, hipStream_t st, int nz)
 {
-    dim3 grid(cdiv(sp.W, 64), cdiv(sp.H, 4 * ST_ROWS), nz);
+    dim3 grid(cdiv(sp.W, 64), cdiv(sp.H, 4 * StatRows<T>::value), nz);
     if (pass == 1 && sizeof(T) == 1 && sp.u8_int)
         hipLaunchKernelGGL((k_color_stats<T, 1, sizeof(T) == 1>), grid, 256, 0, st, img, labels, sp, mean32, acc);
     else if (pass == 1)
