@@ -955,10 +955,13 @@ def bench_color2d(args, group, cfg, quick=False):
             per_launch = per_step if batched else 1          # images one launch of the kernel works on
             achieved = ASSIGN_BYTES_PER_PX * npx * per_launch * sweeps / avg_s / 1e9 if assign_n else 0.0
             traffic = None
-            try:   # HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
-                with open(os.path.join(ROOT, 'profiles', 'pmc_traffic.json')) as fp:
+            # HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (tools/profile_round4.sh): one
+            # 2048^2 image per launch, or the eight 647 x 1024 images of a config-4 step in one launch
+            traffic_file = 'pmc_traffic_cfg4_batch_r04.json' if (cfg == 4 and batched and per_step == 8) else 'pmc_traffic.json'
+            try:
+                with open(os.path.join(ROOT, 'profiles', traffic_file)) as fp:
                     pmc = json.load(fp)
-                if (height, width) == (HEIGHT, WIDTH) and int(pmc.get('sweeps_per_launch', 1)) == sweeps:
+                if ((height, width) == (HEIGHT, WIDTH) or traffic_file != 'pmc_traffic.json') and int(pmc.get('sweeps_per_launch', 1)) == sweeps:
                     traffic = pmc['hbm_bytes_per_launch']
             except Exception:
                 pass
@@ -968,7 +971,7 @@ def bench_color2d(args, group, cfg, quick=False):
             roofline = {'bound': 'hbm', 'kernel': kernel,
                         'achieved': round(achieved, 2), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                         'frac': round(achieved / HBM_PEAK_GBS, 5), 'traffic': traffic,
-                        'traffic_source': 'profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)',
+                        'traffic_source': 'profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)' % traffic_file,
                         'avg_kernel_us': round(avg_s * 1e6, 3), 'launches': assign_n, 'sweeps_per_launch': sweeps,
                         'images_per_launch': per_launch,
                         'algorithmic_bytes_per_launch': ASSIGN_BYTES_PER_PX * npx * per_launch * sweeps}

@@ -1541,6 +1541,12 @@ k_slic_assign_dot(SlicState s, const double *__restrict__ lab, int32_t *__restri
         // arrivals: every workgroup whose tile the search window of centroid k meets has k in its list (two workgroups per
         // 64 x 32 tile) and counts itself once its sums are through; the last one has all pixels of k in the global sums and
         // does what k_centroid_finalize does -- the table is read by the NEXT launch (k_slic_bin), so plain stores will do
+        // Ordering, stated for gfx9 hardware rather than derived from the C++ memory model: the sums above are
+        // device-scope atomics, performed at the L2 / memory side; `vmcnt` only reaches zero when every one of them has been
+        // acknowledged from there, the barrier extends that to the whole workgroup, and the arrival below is again a device-scope
+        // atomic -- so the workgroup that sees the last arrival reads complete sums with its device-scope loads.  An
+        // acquire-release arrival would add a write-back of this CU's dirty label lines (16 MB per launch) to every workgroup's
+        // tail for nothing: the labels are not part of the hand-over.  gfx950 is the only target of this library.
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (wave == 0 && lane < nc) {

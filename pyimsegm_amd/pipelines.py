@@ -164,6 +164,33 @@ def _segment_color2d_batch_call(images, model, dict_features, sp_size, sp_regul,
     return segm if segm is not None else []
 
 
+def _segment_images_batched(images, model, dict_features, sp_size, sp_regul, gc_regul, gc_edge_type, nb_workers=1):
+    """segmentations of ``images`` with BATCH_IMAGES of them per call of :func:`_segment_color2d_batch_call`, ``nb_workers``
+    such calls in flight (worker threads, one HIP stream each); None when the images do not qualify (sizes, dtype, features,
+    class model: see there) and have to go one by one"""
+    if not images:
+        return []
+    chunks = [list(range(lo, min(lo + BATCH_IMAGES, len(images)))) for lo in range(0, len(images), BATCH_IMAGES)]
+
+    def run(chunk):
+        return _segment_color2d_batch_call([images[i] for i in chunk], model, dict_features, sp_size, sp_regul, gc_regul, gc_edge_type)
+
+    first = run(chunks[0])
+    if first is None:
+        return None
+    parts = [first]
+    if len(chunks) > 1:
+        if nb_workers and nb_workers > 1 and len(chunks) > 2:
+            from concurrent.futures import ThreadPoolExecutor
+            with ThreadPoolExecutor(max_workers=int(nb_workers)) as pool:
+                parts += list(pool.map(run, chunks[1:]))
+        else:
+            parts += [run(chunk) for chunk in chunks[1:]]
+    if any(part is None for part in parts):
+        return None
+    return [np.array(segm) for part in parts for segm in part]      # (copies: the page-locked result arrays go back to their pool)
+
+
 class _ResidentImage(object):
     """one image on the device: superpixels + features, then the fused class model / graph cut / gathers"""
 
@@ -511,6 +538,19 @@ def segment_batch_color2d_slic_features_model_graphcut(list_images, model_pipeli
         group = Group()
     classes = getattr(model_pipeline, 'classes_', None)
     on_device = _device_gmm(model_pipeline) is not None
+    if group.rccl is None and BATCH_IMAGES > 0 and on_device:
+        # the images of this rank several at a time through ONE launch chain each (csrc/batch.hip); with several ranks and no
+        # RCCL communicator (CPU tests, ranks sharing a GPU) the finished maps then travel over the host plane as before
+        mine = group.shard(len(list_images))
+        ready = _segment_images_batched([list_images[i] for i in mine], model_pipeline, dict_features, sp_size, sp_regul, gc_regul,
+                                        gc_edge_type, nb_workers)
+        if ready is not None:
+            table = {id(list_images[i]): segm for i, segm in zip(mine, ready)}
+            try:
+                return segment_batch_sharded(list_images, lambda image: table[id(image)], group, nb_workers=1)
+            finally:
+                if own:
+                    group.close()
 
     def _segment(image):
         # as segment_color2d_slic_features_model_graphcut, minus what a batch does not need: the soft

@@ -101,3 +101,24 @@ def test_centroid_update_inside_the_assignment_kernel(hip, monkeypatch, shape, s
     separate = _labels(image, sp_size, regul)
     assert np.array_equal(fused, separate)
     assert np.array_equal(fused, orc.segment_slic_img2d(image, sp_size, regul))
+
+
+def test_fused_centroid_update_hands_the_image_back(hip, monkeypatch):
+    """the hand-back of the centroid update inside the assignment kernel.  Superpixels of 5 pixels put far more than
+    SLIC_MAXC = 64 centroids within reach of a 64 x 32 tile: such a tile has no candidate list, its pixels go to the global sums
+    past the arrival counts, the kernel raises the failure word and the host redoes the sweeps with separate finalize launches --
+    the result must be the oracle's (and that of a run with separate launches from the start), and the hand-back must be counted"""
+    from oracle import oracle as orc
+    from pyimsegm_amd.utilities.synthetic import voronoi_image
+    monkeypatch.delenv('IMSEGM_SLIC_PERSISTENT', raising=False)
+    image = voronoi_image(96, 128, seed=17)
+    monkeypatch.setenv('IMSEGM_FUSE_FINALIZE', '1')
+    before = hip.slic_sweep_runs()[1]
+    fused = _labels(image, 5, 0.2)
+    assert hip.slic_sweep_runs()[1] == before + 1, 'the overflowing tiles were expected to hand the image back'
+    monkeypatch.delenv('IMSEGM_FUSE_FINALIZE')
+    monkeypatch.setenv('IMSEGM_SEPARATE_FINALIZE', '1')
+    separate = _labels(image, 5, 0.2)
+    assert hip.slic_sweep_runs()[1] == before + 1
+    assert np.array_equal(fused, separate)
+    assert np.array_equal(fused, orc.segment_slic_img2d(image, 5, 0.2))
