@@ -154,6 +154,20 @@ __device__ __forceinline__ double zblur_point(double v, const Taps &tz)
     return tmp;
 }
 
+// the same sum with the tap loop unrolled over the largest radius the fused kernel takes: the taps (kernel arguments) become scalar
+// registers loaded once, instead of one scalar load -- and one wait for it -- per tap, channel and pixel
+template <int MAXR>
+__device__ __forceinline__ double zblur_point_unrolled(double v, const Taps &tz)
+{
+    if (tz.r < 0) return v;
+    double tmp = v * tz.w[0];
+    const double vv = v + v;
+#pragma unroll
+    for (int j = MAXR; j >= 1; --j)
+        if (j <= tz.r) tmp += vv * tz.w[j];
+    return tmp;
+}
+
 // uint8 input: the sRGB linearisation collapses to a 256-entry table (built per block in LDS with
 // the same det_pow24 as the per-pixel path).  minmax = {vmin, vmax} on device.
 __global__ void __launch_bounds__(256)
@@ -374,9 +388,9 @@ k_pre_fused(const T *__restrict__ img, int H, int W, int normalize, const double
             }
             rgb2lab_px(rgb[0], rgb[1], rgb[2], L, A, B);
         }
-        L1[i] = zblur_point(L, tz);
-        L1[th * tw + i] = zblur_point(A, tz);
-        L1[2 * th * tw + i] = zblur_point(B, tz);
+        L1[i] = zblur_point_unrolled<PF_MAXR>(L, tz);
+        L1[th * tw + i] = zblur_point_unrolled<PF_MAXR>(A, tz);
+        L1[2 * th * tw + i] = zblur_point_unrolled<PF_MAXR>(B, tz);
     }
     __syncthreads();
     const int ox = tid % PF_TX, oy0 = tid / PF_TX;
@@ -429,7 +443,7 @@ int launch_preprocess_color2d(const void *img, int dtype, int H, int W, int norm
 {
     int n = H * W;
     int grid = cdiv(n, 256);
-    if (ty.r <= PF_MAXR && tx.r <= PF_MAXR && !knobs().pre_3pass) {
+    if (tz.r <= PF_MAXR && ty.r <= PF_MAXR && tx.r <= PF_MAXR && !knobs().pre_3pass) {
         const int ry = ty.r < 0 ? 0 : ty.r, rx = tx.r < 0 ? 0 : tx.r;
         const size_t lds = ((size_t)3 * (PF_TY + 2 * ry) + PF_TY) * (PF_TX + 2 * rx) * sizeof(double);
         const void *fn = dtype == DT_U8 ? (const void *)k_pre_fused<uint8_t>
