@@ -977,9 +977,12 @@ int imsegm_image2d_lm_features_sep(imsegm_image2d *im, const double *weights, co
         return -1;
     }
     const size_t wtotal = off[n_batteries];
-    if (im->tex_resp.ensure((3 * n + wtotal + 1024 + (size_t)n_batteries + 8) * 8 + 64)) return -1;
+    // responses of up to ROUND consecutive batteries side by side: the separable kernels of a round share ONE launch (one load of
+    // the input tile for all of them -- the five batteries of one sigma of the bank)
+    const int ROUND = std::min(n_batteries, (int)SEP_MAX_JOBS);
+    if (im->tex_resp.ensure((3 * n * ROUND + wtotal + 1024 + (size_t)n_batteries + 8) * 8 + 64)) return -1;
     double *resp = im->tex_resp.as<double>();
-    double *d_w = resp + 3 * n;
+    double *d_w = resp + 3 * n * ROUND;
     double *partial = d_w + wtotal;
     double *d_ssq = partial + 1024;
     double *host = static_cast<double *>(ctx->stage(wtotal * 8));
@@ -1011,20 +1014,36 @@ int imsegm_image2d_lm_features_sep(imsegm_image2d *im, const double *weights, co
     double *d_energy = reinterpret_cast<double *>(sb); sb += (size_t)K * 3 * 8;
     double *d_var = reinterpret_cast<double *>(sb); sb += (size_t)K * 3 * 8;
     float *d_mean32 = reinterpret_cast<float *>(sb);
-    for (int b = 0; b < n_batteries; ++b) {
+    for (int b0 = 0; b0 < n_batteries; b0 += ROUND) {
+        const int cnt = std::min(ROUND, n_batteries - b0);
         int spx = ctx->begin(PG_TEX);
-        if (launch_filter_battery(im->tex_planes.as<double>(), im->H, im->W, d_w + off[b], n_kernels[b], radius, clip, resp, partial,
-                                  d_ssq + b, st, 3, d_w + sep_off[b], sep_taps ? sep_groups[b] : 0, sep_taps ? sep_rank[b] : 0,
-                                  dense_parity ? dense_parity[b] : 0))
-            return -1;
+        SepJobs jobs;
+        memset(&jobs, 0, sizeof(jobs));
+        for (int j = 0; j < cnt; ++j) {
+            const int b = b0 + j;
+            double *rj = resp + (size_t)j * 3 * n;
+            if (launch_battery_dense(im->tex_planes.as<double>(), im->H, im->W, d_w + off[b], n_kernels[b], radius, clip, rj, st, 3,
+                                     dense_parity ? dense_parity[b] : 0))
+                return -1;
+            if (sep_taps && sep_groups[b] > 0) {
+                SepJob &q = jobs.job[jobs.n++];
+                q.resp = rj; q.taps = d_w + sep_off[b]; q.groups = sep_groups[b]; q.rank = sep_rank[b]; q.merge = n_kernels[b] > 0 ? 1 : 0;
+            }
+        }
+        if (launch_battery_sep(im->tex_planes.as<double>(), im->H, im->W, radius, clip, jobs, st, 3)) return -1;
+        for (int j = 0; j < cnt; ++j)
+            if (launch_response_sumsq(resp + (size_t)j * 3 * n, 3 * n, partial, d_ssq + b0 + j, st)) return -1;
         ctx->end(spx);
         // |r| <= norm  =>  |r * mul / div| <= mul = log(1 + norm) / 0.03 < 2^15 for every finite norm: the bound the fixed-point
         // scales are chosen for, without the norm coming to the host (prescale 2: the kernels derive mul and div from *ssq)
         int sps = ctx->begin(PG_STATS);
-        if (launch_color_stats(resp, IMSEGM_F64, im->labels.as<int32_t>(), im->H, im->W, K, 32768.0, (feature_mask & 2) != 0, acc, d_mean,
-                               d_energy, d_var, d_mean32, st, 1, 2, 1.0, 1.0, -1, d_ssq + b))
-            return -1;
-        if (launch_features_assemble(d_mean, d_energy, d_var, K, feature_mask, im->featK.as<double>(), st, F, b * Fb)) return -1;
+        for (int j = 0; j < cnt; ++j) {
+            const int b = b0 + j;
+            if (launch_color_stats(resp + (size_t)j * 3 * n, IMSEGM_F64, im->labels.as<int32_t>(), im->H, im->W, K, 32768.0,
+                                   (feature_mask & 2) != 0, acc, d_mean, d_energy, d_var, d_mean32, st, 1, 2, 1.0, 1.0, -1, d_ssq + b))
+                return -1;
+            if (launch_features_assemble(d_mean, d_energy, d_var, K, feature_mask, im->featK.as<double>(), st, F, b * Fb)) return -1;
+        }
         ctx->end(sps);
     }
     im->feat_mask = 0;                         // (the resident table is the texture table, not the colour one the fused call reads)

@@ -226,6 +226,22 @@ int launch_color_stats(const void *img, int dtype, const int32_t *labels, int H,
                        double div = 1.0, long plane_stride = -1, const double *ssq_dev = nullptr, ZBatch zb = ZBatch());
 
 // texture.hip -------------------------------------------------------------------------------------
+// the separable kernels of one battery: `groups` kernels of `rank` components (per component the x taps then the y taps of the
+// flipped kernel); merge: the maximum with what the battery's dense kernels have already written to resp
+struct SepJob {
+    double *resp;
+    const double *taps;
+    int groups, rank, merge;
+};
+constexpr int SEP_MAX_JOBS = 5;
+struct SepJobs {
+    int n;
+    SepJob job[SEP_MAX_JOBS];
+};
+int launch_battery_dense(const double *planes, int H, int W, const double *wgt_dev, int nk, int radius, double clip, double *resp,
+                         hipStream_t st, int P, int parity);
+int launch_battery_sep(const double *planes, int H, int W, int radius, double clip, const SepJobs &jobs, hipStream_t st, int P);
+int launch_response_sumsq(const double *resp, size_t count, double *partial, double *sumsq_dev, hipStream_t st);
 // fullpad: device scratch of 2 * radius + 1 + 16 doubles (the zero-padded full tap table the column pass reads)
 int launch_texture_prepare(const void *img, int dtype, int H, int W, const double *taps_dev, int radius,
                            const double *mix_dev, double *planes, double *tmpA, double *tmpB, hipStream_t st, double *fullpad);

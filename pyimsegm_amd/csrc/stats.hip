@@ -169,8 +169,8 @@ k_color_stats(const T *__restrict__ img, const int32_t *__restrict__ labels, Sta
         // partial sums of this lane, eight at a time (one transposed reduction over the 16-lane row each: sixteen at once cost
         // 250+ registers): PASS 1 -> round 0: the value sums (two limbs per channel) and the count, round 1: the sums of v * v;
         // PASS 2 -> one round: the sums of (v - mean32)^2
-#pragma unroll
-        for (int round = 0; round < (PASS == 1 ? 2 : 1); ++round) {
+        auto one_round = [&](auto round_tag) {
+            constexpr int round = decltype(round_tag)::value;
             double q[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) q[j] = 0;
@@ -208,7 +208,9 @@ k_color_stats(const T *__restrict__ img, const int32_t *__restrict__ labels, Sta
                 else
                     atomic_add_i64(acc + (size_t)k * 13 + ((PASS == 1) ? col : 7 + col), tot);
             }
-        }
+        };
+        one_round(std::integral_constant<int, 0>());
+        if (PASS == 1) one_round(std::integral_constant<int, 1>());
         // (this label of the row is through)
 #pragma unroll
         for (int r = 0; r < RW; ++r)

@@ -358,16 +358,20 @@ k_conv_battery_sym(const double *__restrict__ planes, int H, int W, const double
 // component become scalar registers loaded once, so that an FMA costs one LDS read), or 0: any radius, loops at run time.
 constexpr int SEP_MAX_GROUPS = 2;
 
+// One launch serves the separable kernels of up to SEP_MAX_JOBS batteries (the five batteries of one sigma of the bank): the input
+// tile -- 4.5 x the plane per launch, the larger part of a launch that only does a rank-1 kernel -- is loaded once for all of them.
 template <int ST>
 __global__ void __launch_bounds__(256)
-k_sep_battery(const double *__restrict__ planes, int H, int W, const double *__restrict__ taps, int radius, int n_groups, int rank,
-              double clip, int merge, double *__restrict__ resp)
+k_sep_battery(const double *__restrict__ planes, int H, int W, int radius, double clip, SepJobs jobs)
 {
     extern __shared__ double sep_sm[];
     const int S = ST > 0 ? ST : 2 * radius + 1;
-    const int tw = CV_TX + 2 * radius, th = CV_TY + 2 * radius;
+    // (row strides of an odd number of doubles: in the x pass a lane owns a tile ROW, and rows an even number of doubles apart
+    // would all start in the same LDS bank)
+    const int tw = (CV_TX + 2 * radius) | 1, th = CV_TY + 2 * radius;
+    constexpr int TS = CV_TX + 1;
     double *tile = sep_sm;                       // [th][tw]   input
-    double *T = sep_sm + (size_t)th * tw;        // [th][CV_TX] x pass of the current component
+    double *T = sep_sm + (size_t)th * tw;        // [th][TS]   x pass of the current component
     const int ch = blockIdx.z;
     const double *src = planes + (size_t)ch * H * W;
     const int x0 = blockIdx.x * CV_TX, y0 = blockIdx.y * CV_TY;
@@ -379,6 +383,11 @@ k_sep_battery(const double *__restrict__ planes, int H, int W, const double *__r
     const int lx = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int ly = wave * CV_ROWS;
+    const int x = x0 + lx;
+    for (int jb = 0; jb < jobs.n; ++jb) {
+    const double *__restrict__ taps = jobs.job[jb].taps;
+    double *__restrict__ resp = jobs.job[jb].resp;
+    const int n_groups = jobs.job[jb].groups, rank = jobs.job[jb].rank, merge = jobs.job[jb].merge;
     double acc[SEP_MAX_GROUPS][CV_ROWS];
 #pragma unroll
     for (int g = 0; g < SEP_MAX_GROUPS; ++g)
@@ -389,23 +398,48 @@ k_sep_battery(const double *__restrict__ planes, int H, int W, const double *__r
         if (g >= n_groups) break;
         for (int c = 0; c < rank; ++c) {
             const double *vx = taps + (size_t)(g * rank + c) * 2 * S, *uy = vx + S;       // wave uniform: scalar loads
-            for (int ty = wave; ty < th; ty += 4) {
-                const double *row = tile + (size_t)ty * tw + lx;
-                double v = 0.0;
-                if (ST > 0) {
+            if (ST > 0) {
+                // x pass with the lane on a tile ROW and a sliding window along it: four adjacent outputs from 36 LDS reads (the
+                // lane-per-column form needs 33 reads per output and is bound by the LDS pipe: 230 us per component and launch at
+                // 2048^2, measured); wave w takes the output columns 16 w .. 16 w + 15
+                if (lx < th) {
+                    const double *rp = tile + (size_t)lx * tw + 16 * wave;
+                    double *tp = T + (size_t)lx * TS + 16 * wave;
+                    for (int c0 = 0; c0 < 16; c0 += 4) {
+                        double o0 = 0.0, o1 = 0.0, o2 = 0.0, o3 = 0.0;
+                        // (all reads of the window first, then the arithmetic: with two waves per SIMD nobody hides a read that
+                        // is waited for right where it is issued -- 204 000 cycles per wave for 7 600 vector instructions, measured)
+                        double win[(ST > 0 ? ST : 1) + 3];
 #pragma unroll
-                    for (int k = 0; k < (ST > 0 ? ST : 1); ++k) v = fma(vx[k], row[k], v);
-                } else {
-                    for (int k = 0; k < S; ++k) v = fma(vx[k], row[k], v);
+                        for (int q = 0; q < (ST > 0 ? ST : 1) + 3; ++q) win[q] = rp[c0 + q];
+#pragma unroll
+                        for (int q = 0; q < (ST > 0 ? ST : 1) + 3; ++q) {
+                            const double v = win[q];
+                            if (q < ST) o0 = fma(vx[q < ST ? q : 0], v, o0);
+                            if (q >= 1 && q - 1 < ST) o1 = fma(vx[q >= 1 && q - 1 < ST ? q - 1 : 0], v, o1);
+                            if (q >= 2 && q - 2 < ST) o2 = fma(vx[q >= 2 && q - 2 < ST ? q - 2 : 0], v, o2);
+                            if (q >= 3 && q - 3 < ST) o3 = fma(vx[q >= 3 && q - 3 < ST ? q - 3 : 0], v, o3);
+                        }
+                        tp[c0] = o0; tp[c0 + 1] = o1; tp[c0 + 2] = o2; tp[c0 + 3] = o3;
+                    }
                 }
-                T[ty * CV_TX + lx] = v;
+            } else {
+                for (int ty = wave; ty < th; ty += 4) {
+                    const double *row = tile + (size_t)ty * tw + lx;
+                    double v = 0.0;
+                    for (int k = 0; k < S; ++k) v = fma(vx[k], row[k], v);
+                    T[ty * TS + lx] = v;
+                }
             }
             __syncthreads();
             if (ST > 0) {
                 // (a value of the x pass serves the up to CV_ROWS output rows it lies in the window of: one LDS read, up to 4 FMAs)
+                double col[(ST > 0 ? ST : 1) + CV_ROWS - 1];
+#pragma unroll
+                for (int q = 0; q < (ST > 0 ? ST : 1) + CV_ROWS - 1; ++q) col[q] = T[(ly + q) * TS + lx];
 #pragma unroll
                 for (int q = 0; q < (ST > 0 ? ST : 1) + CV_ROWS - 1; ++q) {
-                    const double tv = T[(ly + q) * CV_TX + lx];
+                    const double tv = col[q];
 #pragma unroll
                     for (int i = 0; i < CV_ROWS; ++i)
                         if (q - i >= 0 && q - i < ST) acc[g][i] = fma(uy[q - i], tv, acc[g][i]);
@@ -414,13 +448,12 @@ k_sep_battery(const double *__restrict__ planes, int H, int W, const double *__r
                 for (int t = 0; t < S; ++t) {
                     const double w = uy[t];
 #pragma unroll
-                    for (int i = 0; i < CV_ROWS; ++i) acc[g][i] = fma(w, T[(ly + i + t) * CV_TX + lx], acc[g][i]);
+                    for (int i = 0; i < CV_ROWS; ++i) acc[g][i] = fma(w, T[(ly + i + t) * TS + lx], acc[g][i]);
                 }
             }
             __syncthreads();
         }
     }
-    const int x = x0 + lx;
 #pragma unroll
     for (int i = 0; i < CV_ROWS; ++i) {
         const int y = y0 + ly + i;
@@ -432,6 +465,7 @@ k_sep_battery(const double *__restrict__ planes, int H, int W, const double *__r
         if (r > clip) r = clip;
         *out = r;
     }
+    }   // jobs
 }
 
 // deterministic sum of squares: per-block partials, then one block adds them in a fixed order
@@ -493,19 +527,15 @@ int launch_texture_prepare_volume(const void *vol, int dtype, int P, int H, int 
     return 0;
 }
 
-int launch_filter_battery(const double *planes, int H, int W, const double *wgt_dev, int nk, int radius, double clip,
-                          double *resp, double *partial, double *sumsq_dev, hipStream_t st, int P, const double *sep_dev, int sep_groups,
-                          int sep_rank, int parity)
+// the dense kernels of a battery -> resp (clipped maximum over them); nk = 0: nothing to do
+int launch_battery_dense(const double *planes, int H, int W, const double *wgt_dev, int nk, int radius, double clip, double *resp,
+                         hipStream_t st, int P, int parity)
 {
     if (nk != 0 && nk != 1 && nk != 2 && nk != 4 && nk != 6 && nk != 8) {
         set_error("filter battery: 1, 2, 4, 6 or 8 dense kernels per battery are supported");
         return -1;
     }
-    if (sep_groups < 0 || sep_groups > SEP_MAX_GROUPS || (sep_groups > 0 && (!sep_dev || sep_rank < 1 || sep_rank > 4)) ||
-        (nk == 0 && sep_groups == 0)) {
-        set_error("filter battery: up to 2 separable kernels of rank 1..4, and at least one kernel in all");
-        return -1;
-    }
+    if (nk == 0) return 0;
     const int S = 2 * radius + 1, Spad = conv_padded_rows(radius);
     size_t lds = (size_t)(CV_TX + 2 * radius) * (CV_TY - CV_ROWS + Spad) * sizeof(double);
     if (lds > 150 * 1024) {
@@ -513,7 +543,7 @@ int launch_filter_battery(const double *planes, int H, int W, const double *wgt_
         return -1;
     }
     dim3 grid(cdiv(W, CV_TX), cdiv(H, CV_TY), P);
-    if (nk > 0 && parity != 0) {
+    if (parity != 0) {
         // every dense kernel of the battery is even (+1) or odd (-1) under the point reflection: half the multiplications
         const int Spad8 = conv_sym_padded_rows(radius);
         const size_t lds8 = (size_t)(CV_TX + 2 * radius) * (CV_TY - CV_ROWS + Spad8) * sizeof(double);
@@ -533,8 +563,8 @@ int launch_filter_battery(const double *planes, int H, int W, const double *wgt_
         else if (nk == 4) hipLaunchKernelGGL(k_conv_battery_sym<4>, grid, 256, lds8, st, planes, H, W, wpad, radius, sign, clip, resp);
         else if (nk == 2) hipLaunchKernelGGL(k_conv_battery_sym<2>, grid, 256, lds8, st, planes, H, W, wpad, radius, sign, clip, resp);
         else hipLaunchKernelGGL(k_conv_battery_sym<1>, grid, 256, lds8, st, planes, H, W, wpad, radius, sign, clip, resp);
-    } else if (nk > 0) {
-        // (the padded table lives behind the caller's weights: launch_filter_battery's caller reserves S * Spad * nk doubles there)
+    } else {
+        // (the padded table lives behind the caller's weights: the caller reserves S * (S + 16) * nk doubles there)
         double *wpad = const_cast<double *>(wgt_dev) + (size_t)S * S * nk;
         hipLaunchKernelGGL(k_pad_weights, cdiv((long)S * Spad * nk, 256), 256, 0, st, wgt_dev, S, Spad, nk, wpad);
         const void *fn = nk == 8 ? (const void *)k_conv_battery<8> : nk == 6 ? (const void *)k_conv_battery<6>
@@ -546,26 +576,62 @@ int launch_filter_battery(const double *planes, int H, int W, const double *wgt_
         else if (nk == 2) hipLaunchKernelGGL(k_conv_battery<2>, grid, 256, lds, st, planes, H, W, wpad, radius, clip, resp);
         else hipLaunchKernelGGL(k_conv_battery<1>, grid, 256, lds, st, planes, H, W, wpad, radius, clip, resp);
     }
-    if (sep_groups > 0) {
-        const size_t sep_lds = ((size_t)(CV_TX + 2 * radius) + CV_TX) * (CV_TY + 2 * radius) * sizeof(double);
-        if (sep_lds > 150 * 1024) {
-            set_error("filter battery: kernel radius too large for the LDS tile");
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+// the separable kernels of up to SEP_MAX_JOBS batteries in one launch (one load of the input tile for all of them)
+int launch_battery_sep(const double *planes, int H, int W, int radius, double clip, const SepJobs &jobs, hipStream_t st, int P)
+{
+    if (jobs.n < 1) return 0;
+    for (int j = 0; j < jobs.n; ++j) {
+        const SepJob &q = jobs.job[j];
+        if (jobs.n > SEP_MAX_JOBS || q.groups < 1 || q.groups > SEP_MAX_GROUPS || !q.taps || !q.resp || q.rank < 1 || q.rank > 4) {
+            set_error("filter battery: up to 2 separable kernels of rank 1..4 per battery, up to 5 batteries per launch");
             return -1;
         }
-        const void *sfn = radius == 16 ? (const void *)k_sep_battery<33> : (const void *)k_sep_battery<0>;
-        if (sep_lds > 48 * 1024) HIP_TRY(hipFuncSetAttribute(sfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sep_lds));
-        if (radius == 16)
-            hipLaunchKernelGGL(k_sep_battery<33>, grid, 256, sep_lds, st, planes, H, W, sep_dev, radius, sep_groups, sep_rank, clip,
-                               nk > 0 ? 1 : 0, resp);
-        else
-            hipLaunchKernelGGL(k_sep_battery<0>, grid, 256, sep_lds, st, planes, H, W, sep_dev, radius, sep_groups, sep_rank, clip,
-                               nk > 0 ? 1 : 0, resp);
     }
+    const size_t sep_lds = ((size_t)((CV_TX + 2 * radius) | 1) + CV_TX + 1) * (CV_TY + 2 * radius) * sizeof(double);
+    if (sep_lds > 150 * 1024) {
+        set_error("filter battery: kernel radius too large for the LDS tile");
+        return -1;
+    }
+    dim3 grid(cdiv(W, CV_TX), cdiv(H, CV_TY), P);
+    const void *sfn = radius == 16 ? (const void *)k_sep_battery<33> : (const void *)k_sep_battery<0>;
+    if (sep_lds > 48 * 1024) HIP_TRY(hipFuncSetAttribute(sfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sep_lds));
+    if (radius == 16) hipLaunchKernelGGL(k_sep_battery<33>, grid, 256, sep_lds, st, planes, H, W, radius, clip, jobs);
+    else hipLaunchKernelGGL(k_sep_battery<0>, grid, 256, sep_lds, st, planes, H, W, radius, clip, jobs);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+// sum of squares of a response (P planes) -> sumsq_dev[0], deterministic
+int launch_response_sumsq(const double *resp, size_t count, double *partial, double *sumsq_dev, hipStream_t st)
+{
     const int nb = 1024;
-    hipLaunchKernelGGL(k_sumsq_partial, nb, 256, 0, st, resp, (size_t)P * H * W, partial);
+    hipLaunchKernelGGL(k_sumsq_partial, nb, 256, 0, st, resp, count, partial);
     hipLaunchKernelGGL(k_sumsq_final, 1, 256, 0, st, partial, nb, sumsq_dev);
     HIP_TRY(hipGetLastError());
     return 0;
+}
+
+int launch_filter_battery(const double *planes, int H, int W, const double *wgt_dev, int nk, int radius, double clip,
+                          double *resp, double *partial, double *sumsq_dev, hipStream_t st, int P, const double *sep_dev, int sep_groups,
+                          int sep_rank, int parity)
+{
+    if (nk == 0 && sep_groups == 0) {
+        set_error("filter battery: at least one kernel");
+        return -1;
+    }
+    if (launch_battery_dense(planes, H, W, wgt_dev, nk, radius, clip, resp, st, P, parity)) return -1;
+    if (sep_groups > 0) {
+        SepJobs jobs;
+        jobs.n = 1;
+        jobs.job[0].resp = resp; jobs.job[0].taps = sep_dev; jobs.job[0].groups = sep_groups; jobs.job[0].rank = sep_rank;
+        jobs.job[0].merge = nk > 0 ? 1 : 0;
+        if (launch_battery_sep(planes, H, W, radius, clip, jobs, st, P)) return -1;
+    }
+    return launch_response_sumsq(resp, (size_t)P * H * W, partial, sumsq_dev, st);
 }
 
 }  // namespace imsegm
