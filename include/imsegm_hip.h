@@ -171,6 +171,8 @@ IMSEGM_API int imsegm_image2d_lm_features(imsegm_image2d *img, const double *wei
 IMSEGM_API int imsegm_image2d_lm_features_sep(imsegm_image2d *img, const double *weights, const int *n_kernels, const int *dense_parity,
                                               const double *sep_taps, const int *sep_groups, const int *sep_rank, int n_batteries,
                                               int radius, double clip, int feature_mask, double *features_out);
+/* (features_out NULL, here only: the table stays on the device for imsegm_image2d_segment / imsegm_image2d_get_features and the call
+ * returns without waiting for the kernels) */
 
 /* Leung-Malik texture responses (imsegm/descriptors.py:951-1106, scipy.ndimage in the reference).
  * lm_prepare: planes = image - gaussian_filter(image, sigma) with `taps` = half kernel of
@@ -225,6 +227,14 @@ IMSEGM_API int imsegm_volume_graph(imsegm_image2d *vol, int32_t *edges_out, int 
  * three columns each (colour channels; a gray volume repeats its single channel), NaN -> 0, -0 -> +0.  The table
  * stays resident for imsegm_image2d_segment; features_out (n_labels x 3*nflags float64) may be NULL. */
 IMSEGM_API int imsegm_image2d_features_color(imsegm_image2d *img, int feature_mask, double *features_out);
+
+/* The feature table of SEVERAL descriptor groups side by side, as compute_selected_features_color2d concatenates them
+ * (imsegm/descriptors.py:1207-1270: the 'color' statistics, then the 'tLM' ones): the NEXT call of
+ * imsegm_image2d_features_color / imsegm_image2d_lm_features_sep (with features_out NULL) writes its columns at `column` of a
+ * resident table `total_columns` wide instead of a table of its own.  imsegm_image2d_segment evaluates the class model on that
+ * table (F <= 256); the host reads it with imsegm_image2d_get_features (capacity_columns = its width, as a check). */
+IMSEGM_API int imsegm_image2d_features_place(imsegm_image2d *img, int total_columns, int column);
+IMSEGM_API int imsegm_image2d_get_features(imsegm_image2d *img, double *features_out, int capacity_columns);
 
 /* class model evaluated on the device: sklearn Pipeline([StandardScaler,] GaussianMixture(covariance_type='full')) as
  * imsegm.graph_cuts.estim_class_model builds it (imsegm/graph_cuts.py:73-163).  The host passes what scikit-learn

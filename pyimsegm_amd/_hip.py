@@ -72,6 +72,8 @@ _SIGNATURES = {
     'imsegm_ctx_stream': (C.c_int, [_vp, C.POINTER(_vp)]),
     'imsegm_ctx_copy': (C.c_int, [_vp, _vp, _vp, C.c_size_t, C.c_int]),
     'imsegm_image2d_features_color': (C.c_int, [_vp, C.c_int, _vp]),
+    'imsegm_image2d_features_place': (C.c_int, [_vp, C.c_int, C.c_int]),
+    'imsegm_image2d_get_features': (C.c_int, [_vp, _vp, C.c_int]),
     'imsegm_image2d_run_color': (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, C.c_double, _vp, C.c_int, C.c_int, C.c_int, C.c_int,
                                            C.c_int, C.POINTER(GmmParams), C.c_int, _vp, C.c_int, C.c_double, C.c_int, _vp, _vp, _vp, _ip]),
     'imsegm_image2d_segment': (C.c_int, [_vp, C.POINTER(GmmParams), _vp, C.c_int, _vp, C.c_int, C.c_double, C.c_int, _vp, _vp, _vp,
@@ -367,8 +369,8 @@ class DeviceGmm(object):
         if len(steps) > 2 or any(type(st) is not StandardScaler for _, st in steps[:-1]):
             raise TypeError('only an optional StandardScaler in front of the mixture is evaluated on the device')
         n_comp, n_feat = gmm.means_.shape
-        if n_feat > 32 or n_comp > 16:
-            raise TypeError('device class model: at most 32 features and 16 classes')
+        if n_feat > 256 or n_comp > 16:
+            raise TypeError('device class model: at most 256 features and 16 classes')
         self.n_features, self.n_classes = int(n_feat), int(n_comp)
         self.classes = getattr(model, 'classes_', None)
         par = GmmParams()
@@ -740,24 +742,53 @@ class Image2D(object):
                 parity = -1
         return weights, pad, taps, len(factors), rank, side // 2, parity
 
-    def lm_features(self, batteries, clip, mean=True, std=True, energy=True, separable=True):
-        """``imsegm_image2d_lm_features_sep``: K x (3 * flags * len(batteries)) statistics of all batteries in one call;
-        ``separable=False``: every kernel as a dense S x S sum (``imsegm_image2d_lm_features``)"""
-        parts = [self._split_battery(b, separable, separable) for b in batteries]
+    #: the last banks handed to :meth:`lm_features`, split and packed (the factorisation is 60 SVDs per bank)
+    _packed_banks = []
+
+    @classmethod
+    def _pack_bank(cls, batteries, separable):
+        """the arguments of ``imsegm_image2d_lm_features_sep`` for a list of batteries; remembered per list of battery ARRAYS (the
+        bank of the descriptors is built once per process) with their sums as a guard against arrays changed in place"""
+        batteries = [np.asarray(b, dtype=np.float64) for b in batteries]
+        sums = [float(b.sum()) for b in batteries]
+        for held, flag, held_sums, packed in cls._packed_banks:
+            if flag == separable and len(held) == len(batteries) and all(a is b for a, b in zip(held, batteries)) and held_sums == sums:
+                return packed
+        parts = [cls._split_battery(b, separable, separable) for b in batteries]
         radius = parts[0][5]
         if any(p[5] != radius for p in parts):
             raise ValueError('the batteries of one call have one kernel size')
         weights = np.concatenate([p[0].ravel() for p in parts])
-        counts = np.array([p[1] for p in parts], dtype=np.int32)
         taps = np.concatenate([p[2].ravel() for p in parts])
-        groups = np.array([p[3] for p in parts], dtype=np.int32)
-        ranks = np.array([p[4] for p in parts], dtype=np.int32)
-        parity = np.array([p[6] for p in parts], dtype=np.int32)
+        packed = dict(weights=weights if weights.size else None, taps=taps if taps.size else None, radius=radius, count=len(parts),
+                      kernels=np.array([p[1] for p in parts], dtype=np.int32), groups=np.array([p[3] for p in parts], dtype=np.int32),
+                      ranks=np.array([p[4] for p in parts], dtype=np.int32), parity=np.array([p[6] for p in parts], dtype=np.int32))
+        cls._packed_banks.insert(0, (batteries, separable, sums, packed))
+        del cls._packed_banks[4:]
+        return packed
+
+    def lm_features(self, batteries, clip, mean=True, std=True, energy=True, separable=True, to_host=True):
+        """``imsegm_image2d_lm_features_sep``: K x (3 * flags * len(batteries)) statistics of all batteries in one call;
+        ``separable=False``: every kernel as a dense S x S sum (``imsegm_image2d_lm_features``); ``to_host=False``: the table
+        stays on the device (for :meth:`segment` with a device class model, :meth:`get_features`) and nothing is waited for"""
+        bank = self._pack_bank(batteries, bool(separable))
         mask = (1 if mean else 0) | (2 if std else 0) | (4 if energy else 0)
-        out = np.empty((self.n_labels, 3 * bin(mask).count('1') * len(parts)), dtype=np.float64)
+        out = np.empty((self.n_labels, 3 * bin(mask).count('1') * bank['count']), dtype=np.float64) if to_host else None
         _check(load_library().imsegm_image2d_lm_features_sep(
-            self._h, _ptr(weights) if weights.size else None, _ptr(counts), _ptr(parity), _ptr(taps) if taps.size else None, _ptr(groups), _ptr(ranks),
-            len(parts), radius, float(clip), mask, _ptr(out)))
+            self._h, _ptr(bank['weights']), _ptr(bank['kernels']), _ptr(bank['parity']), _ptr(bank['taps']), _ptr(bank['groups']),
+            _ptr(bank['ranks']), bank['count'], bank['radius'], float(clip), mask, _ptr(out)))
+        return out
+
+    def features_place(self, total_columns, column):
+        """``imsegm_image2d_features_place``: the next :meth:`features_color` / :meth:`lm_features` (``to_host=False``) writes its
+        columns at ``column`` of a resident table ``total_columns`` wide"""
+        _check(load_library().imsegm_image2d_features_place(self._h, int(total_columns), int(column)))
+        return self
+
+    def get_features(self, columns):
+        """the resident K x ``columns`` feature table (``imsegm_image2d_get_features``)"""
+        out = np.empty((self.n_labels, int(columns)), dtype=np.float64)
+        _check(load_library().imsegm_image2d_get_features(self._h, _ptr(out), int(columns)))
         return out
 
     def response_stats(self, mul, div, mean=True, energy=True, var=True):

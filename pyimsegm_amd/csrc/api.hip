@@ -359,6 +359,7 @@ int imsegm_image2d_upload(imsegm_image2d *im, const void *host_pixels, int dtype
     if (!is_pinned(host_pixels)) HIP_TRY(hipStreamSynchronize(im->ctx->stream));
     im->dtype = dtype;
     im->feat_mask = 0;
+    im->place_F = 0;
     return 0;
 }
 
@@ -930,6 +931,8 @@ int imsegm_image2d_lm_battery(imsegm_image2d *im, const double *weights, int n_k
     return 0;
 }
 
+static int take_placement(imsegm_image2d *im, int own_F, bool to_host, int *table_F, int *col0);
+
 int imsegm_image2d_lm_features(imsegm_image2d *im, const double *weights, const int *n_kernels, int n_batteries, int radius, double clip,
                                int feature_mask, double *features_out)
 {
@@ -947,7 +950,7 @@ int imsegm_image2d_lm_features_sep(imsegm_image2d *im, const double *weights, co
         set_error("lm_features: call imsegm_image2d_lm_prepare first, with a label map installed");
         return -1;
     }
-    if (!n_kernels || n_batteries < 1 || !features_out || feature_mask < 1 || feature_mask > 7 ||
+    if (!n_kernels || n_batteries < 1 || feature_mask < 1 || feature_mask > 7 ||
         (sep_taps && (!sep_groups || !sep_rank))) {
         set_error("lm_features: bad arguments");
         return -1;
@@ -1006,8 +1009,10 @@ int imsegm_image2d_lm_features_sep(imsegm_image2d *im, const double *weights, co
     // statistics scratch (as stats_run) and the K x F table
     const int nflags = ((feature_mask & 1) != 0) + ((feature_mask & 2) != 0) + ((feature_mask & 4) != 0);
     const int Fb = 3 * nflags, F = Fb * n_batteries;
+    int table_F = F, col0 = 0;
+    if (take_placement(im, F, features_out != nullptr, &table_F, &col0)) return -1;
     size_t fb = (size_t)K * (13 * 8 + 3 * 3 * 8 + 3 * 4) + 256;
-    if (im->feat.ensure(fb) || im->featK.ensure((size_t)K * F * 8 + 64)) return -1;
+    if (im->feat.ensure(fb) || im->featK.ensure((size_t)K * table_F * 8 + 64)) return -1;
     unsigned char *sb = im->feat.as<unsigned char>();
     long long *acc = reinterpret_cast<long long *>(sb); sb += (size_t)K * 13 * 8;
     double *d_mean = reinterpret_cast<double *>(sb); sb += (size_t)K * 3 * 8;
@@ -1042,13 +1047,19 @@ int imsegm_image2d_lm_features_sep(imsegm_image2d *im, const double *weights, co
             if (launch_color_stats(resp + (size_t)j * 3 * n, IMSEGM_F64, im->labels.as<int32_t>(), im->H, im->W, K, 32768.0,
                                    (feature_mask & 2) != 0, acc, d_mean, d_energy, d_var, d_mean32, st, 1, 2, 1.0, 1.0, -1, d_ssq + b))
                 return -1;
-            if (launch_features_assemble(d_mean, d_energy, d_var, K, feature_mask, im->featK.as<double>(), st, F, b * Fb)) return -1;
+            if (launch_features_assemble(d_mean, d_energy, d_var, K, feature_mask, im->featK.as<double>(), st, table_F, col0 + b * Fb))
+                return -1;
         }
         ctx->end(sps);
     }
-    im->feat_mask = 0;                         // (the resident table is the texture table, not the colour one the fused call reads)
-    HIP_TRY(hipMemcpyAsync(features_out, im->featK.p, (size_t)K * F * 8, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipStreamSynchronize(st));
+    // called for the resident table (no host copy asked for): imsegm_image2d_segment reads it by feat_F; with a host copy the
+    // table counts as consumed, as before
+    im->feat_mask = features_out ? 0 : 8;
+    im->feat_F = table_F;
+    if (features_out) {
+        HIP_TRY(hipMemcpyAsync(features_out, im->featK.p, (size_t)K * F * 8, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+    }
     return 0;
 }
 
@@ -1525,6 +1536,28 @@ int imsegm_cut_general_graph(imsegm_ctx *ctx, const int32_t *edges, int n_edges,
 // fused back half of the pipeline: statistics -> feature table -> graph -> class model -> graph-cut terms ->
 // alpha-expansion -> gathers, enqueued on the session's stream without a host round trip
 // ---------------------------------------------------------------------------------------------------
+// the placement of imsegm_image2d_features_place, consumed by the descriptor call that follows it: `own_F` columns at *col0 of a
+// table *table_F wide (without a placement: the block is the table)
+static int take_placement(imsegm_image2d *im, int own_F, bool to_host, int *table_F, int *col0)
+{
+    *table_F = own_F;
+    *col0 = 0;
+    if (im->place_F <= 0) return 0;
+    const int total = im->place_F, column = im->place_col;
+    im->place_F = 0;
+    if (column + own_F > total) {
+        set_error("features_place: the columns of this descriptor group do not fit the table");
+        return -1;
+    }
+    if (to_host && own_F != total) {
+        set_error("features_place: a group placed into a wider table stays on the device (imsegm_image2d_get_features reads the table)");
+        return -1;
+    }
+    *table_F = total;
+    *col0 = column;
+    return 0;
+}
+
 int imsegm_image2d_features_color(imsegm_image2d *im, int feature_mask, double *features_out)
 {
     if (!im || bind(im->ctx)) return -1;
@@ -1571,15 +1604,46 @@ int imsegm_image2d_features_color(imsegm_image2d *im, int feature_mask, double *
     if (rc) return -1;
     const int nflags = ((feature_mask & 1) != 0) + ((feature_mask & 2) != 0) + ((feature_mask & 4) != 0);
     const int F = 3 * nflags;
-    if (im->featK.ensure((size_t)K * F * 8 + 64)) return -1;
-    if (launch_features_assemble(d_mean, d_energy, d_var, K, feature_mask, im->featK.as<double>(), st)) return -1;
+    int table_F = F, col0 = 0;
+    if (take_placement(im, F, features_out != nullptr, &table_F, &col0)) return -1;
+    if (im->featK.ensure((size_t)K * table_F * 8 + 64)) return -1;
+    if (launch_features_assemble(d_mean, d_energy, d_var, K, feature_mask, im->featK.as<double>(), st, table_F, col0)) return -1;
     ctx->end(sp);
-    im->feat_mask = feature_mask;
-    im->feat_F = F;
+    im->feat_mask = table_F == F ? feature_mask : 8;          // (8: a table of several descriptor groups)
+    im->feat_F = table_F;
     if (features_out) {
         HIP_TRY(hipMemcpyAsync(features_out, im->featK.p, (size_t)K * F * 8, hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
     }
+    return 0;
+}
+
+int imsegm_image2d_features_place(imsegm_image2d *im, int total_columns, int column)
+{
+    if (!im || bind(im->ctx)) return -1;
+    if (total_columns < 1 || column < 0 || column >= total_columns) {
+        set_error("features_place: 0 <= column < total_columns is required");
+        return -1;
+    }
+    im->place_F = total_columns;
+    im->place_col = column;
+    return 0;
+}
+
+int imsegm_image2d_get_features(imsegm_image2d *im, double *features_out, int capacity_columns)
+{
+    if (!im || bind(im->ctx)) return -1;
+    if (!im->have_labels || im->feat_mask == 0 || im->feat_F < 1) {
+        set_error("get_features: no resident feature table");
+        return -1;
+    }
+    if (!features_out || capacity_columns != im->feat_F) {
+        set_error("get_features: the table has a different number of columns");
+        return -1;
+    }
+    hipStream_t st = im->ctx->stream;
+    HIP_TRY(hipMemcpyAsync(features_out, im->featK.p, (size_t)im->n_labels * im->feat_F * 8, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
     return 0;
 }
 

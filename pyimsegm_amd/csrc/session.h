@@ -151,6 +151,7 @@ struct imsegm_image2d {
         tex_planes, tex_resp, tex_small, vol_cent, annot, hist, featK, seg, sweeps, narrow;
     int *slic_fail_host = nullptr;              // page-locked word the persistent sweep kernel raises when it cannot take the image
     int feat_mask = 0, feat_F = 0;              // layout of the resident feature table (imsegm_image2d_features_color)
+    int place_F = 0, place_col = 0;             // imsegm_image2d_features_place: where the next descriptor call puts its columns
     // the ten SLIC sweeps (30 kernel launches + a memset) as one captured HIP graph, re-used while every launch parameter
     // (sizes, pointers, weights: `slic_key`, the bytes of a SlicGraphKey) stays the same -- a recycled session replays it
     hipGraphExec_t slic_exec = nullptr;

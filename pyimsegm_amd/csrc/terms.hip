@@ -226,6 +226,9 @@ __device__ __forceinline__ void zshift_terms(TermsArgs &a)
     ZSHIFT(a.scalars, zs); ZSHIFT(a.fstd, zs);
 }
 
+// predict_proba of the mixture, one wave per superpixel; lane l keeps the features (and the projected coordinates) l, l + 64, ...
+// (NF of them: F <= 64 NF).  Sums run in ascending feature order, as the F <= 64 kernel of the earlier rounds formed them.
+template <int NF>
 __global__ void __launch_bounds__(256) k_gmm_proba(TermsArgs a)
 {
     zshift_terms(a);
@@ -233,25 +236,45 @@ __global__ void __launch_bounds__(256) k_gmm_proba(TermsArgs a)
     const int lane = threadIdx.x & 63;
     const int k = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     if (k >= K) return;
-    double xv = 0.0;
-    if (lane < F) {
-        xv = a.features[(size_t)k * F + lane];
-        if (a.scaler_mean) xv = xv - a.scaler_mean[lane];
-        if (a.scaler_scale) xv = xv / a.scaler_scale[lane];
+    double xv[NF];
+#pragma unroll
+    for (int i = 0; i < NF; ++i) {
+        const int f = lane + 64 * i;
+        double v = 0.0;
+        if (f < F) {
+            v = a.features[(size_t)k * F + f];
+            if (a.scaler_mean) v = v - a.scaler_mean[f];
+            if (a.scaler_scale) v = v / a.scaler_scale[f];
+        }
+        xv[i] = v;
     }
     double mywl = -INFINITY;                             // lane c keeps the weighted log probability of class c
     double amax = -INFINITY;
     for (int c = 0; c < C; ++c) {
         const double *P = a.prec_chol + (size_t)c * F * F;
-        double y = 0.0;
-        for (int f = 0; f < F; ++f) {
-            const double xf = __shfl(xv, f, 64);
-            if (lane < F) y += xf * P[f * F + lane];
+        double y[NF];
+#pragma unroll
+        for (int j = 0; j < NF; ++j) y[j] = 0.0;
+#pragma unroll
+        for (int i = 0; i < NF; ++i) {
+            const int count = min(64, F - 64 * i);       // (uniform)
+            for (int l = 0; l < count; ++l) {
+                const double xf = __shfl(xv[i], l, 64);
+                const double *row = P + (size_t)(64 * i + l) * F;
+#pragma unroll
+                for (int j = 0; j < NF; ++j)
+                    if (lane + 64 * j < F) y[j] += xf * row[lane + 64 * j];
+            }
         }
-        if (lane < F) y = y - a.mu_proj[c * F + lane];
-        const double y2 = y * y;
         double lp = 0.0;
-        for (int j = 0; j < F; ++j) lp += __shfl(y2, j, 64);
+#pragma unroll
+        for (int j = 0; j < NF; ++j) {
+            double d = 0.0;
+            if (lane + 64 * j < F) d = y[j] - a.mu_proj[c * F + lane + 64 * j];
+            const double y2 = d * d;
+            const int count = min(64, F - 64 * j);
+            for (int l = 0; l < count; ++l) lp += __shfl(y2, l, 64);
+        }
         const double lg = -0.5 * (a.const_term + lp) + a.log_det[c];
         const double w = lg + a.log_w[c];
         if (lane == c) mywl = w;
@@ -430,11 +453,17 @@ int launch_graph_csr(uint32_t *bitmap, const int *K_dev, int K_cap, int words, i
 
 int launch_gc_terms(const TermsArgs &a, hipStream_t st, int nz)
 {
-    if (a.F > 32 || a.C > 16) {
-        set_error("device class model: at most 32 features and 16 classes");
+    if (a.F > 256 || a.C > 16) {
+        set_error("device class model: at most 256 features and 16 classes");
         return -1;
     }
-    if (a.gmm) hipLaunchKernelGGL(k_gmm_proba, dim3(cdiv((long)a.K_cap * 64, 256), 1, nz), 256, 0, st, a);
+    if (a.gmm) {
+        const dim3 grid(cdiv((long)a.K_cap * 64, 256), 1, nz);
+        if (a.F <= 64) hipLaunchKernelGGL(k_gmm_proba<1>, grid, 256, 0, st, a);
+        else if (a.F <= 128) hipLaunchKernelGGL(k_gmm_proba<2>, grid, 256, 0, st, a);
+        else if (a.F <= 192) hipLaunchKernelGGL(k_gmm_proba<3>, grid, 256, 0, st, a);
+        else hipLaunchKernelGGL(k_gmm_proba<4>, grid, 256, 0, st, a);
+    }
     hipLaunchKernelGGL(k_gc_terms, dim3(1, 1, nz), TM_THREADS, 0, st, a);
     HIP_TRY(hipGetLastError());
     return 0;

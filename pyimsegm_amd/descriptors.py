@@ -11,6 +11,7 @@ alternatives, the median / mean-gradient statistics and the Leung-Malik filter r
 (``scipy.ndimage`` convolutions, exactly as ``descriptors.py:903-1106``) -- those are not yet on the
 HIP path ("what runs where").
 """
+import functools
 import itertools
 import logging
 
@@ -646,10 +647,17 @@ def image_subtract_gauss_smooth(img, sigma):
     return img - smooth
 
 
+@functools.lru_cache(maxsize=4)
 def _select_bank(bank_type):
+    """the bank of a ``tLM`` / ``tLM_short`` group, built once per process (the arrays are shared: read-only for every caller;
+    their identity is what :meth:`_hip.Image2D.lm_features` keys its factorisation on)"""
     if bank_type == 'short':
-        return create_filter_bank_lm_2d(sigmas=SHORT_FILTERS_SIGMAS, nb_orient=4)
-    return create_filter_bank_lm_2d()
+        filters, names = create_filter_bank_lm_2d(sigmas=SHORT_FILTERS_SIGMAS, nb_orient=4)
+    else:
+        filters, names = create_filter_bank_lm_2d()
+    for battery in filters:
+        battery.setflags(write=False)
+    return filters, names
 
 
 def _normalise_response(response):
@@ -700,8 +708,7 @@ def compute_texture_desc_lm_img2d_clr(img, seg, feature_flags, bank_type='normal
     _check_color_image(img)
     logging.debug('compute texture descriptors using Leung-Malik')
     filters, fl_names = _select_bank(bank_type)
-    on_device = set(feature_flags) <= {'mean', 'std', 'energy'} and all(len(f) <= 8 for f in filters)
-    if on_device:
+    if _texture_on_device(feature_flags, filters):
         return _texture_desc_lm_device(img, seg, feature_flags, filters, fl_names)
     # host path (median / meanGrad need the response on the host): scipy as the reference
     # scalar sigma on all three axes, channel axis included (descriptors.py:1078)
@@ -718,6 +725,55 @@ def compute_texture_desc_lm_img2d_clr(img, seg, feature_flags, bank_type='normal
         names += ns
     sess.close()
     return _finish_texture(features, names)
+
+
+def _texture_on_device(feature_flags, filters):
+    """the statistics the device forms of a filter response, and batteries it takes (at most 8 kernels)"""
+    return set(feature_flags) <= {'mean', 'std', 'energy'} and all(len(f) <= 8 for f in filters)
+
+
+def resident_feature_groups(feature_flags):
+    """the descriptor groups of ``feature_flags`` in the column order of :func:`compute_selected_features_color2d` (the colour
+    statistics, then the Leung-Malik ones) as ``[(kind, flags, batteries, columns)]`` when ALL of them can be formed and kept on
+    the device -- 'color' in RGB and 'tLM' / 'tLM_<bank>' with mean / std / energy; otherwise None (converted colour spaces,
+    median, meanGrad: the general path)"""
+    order = [k for k in feature_flags if k.startswith('color')] + [k for k in feature_flags if k.startswith('tLM')]
+    if not order or len(order) != len(feature_flags):
+        return None
+    groups = []
+    for key in order:
+        flags = set(feature_flags[key])
+        if not flags or not flags <= {'mean', 'std', 'energy'}:
+            return None
+        if key == 'color':
+            groups.append(('color', flags, None, 3 * len(flags)))
+        elif key == 'tLM' or key.startswith('tLM_'):
+            filters, _ = _select_bank(key.split('_')[-1] if '_' in key else 'normal')
+            if not _texture_on_device(flags, filters) or len({np.shape(f)[1:] for f in filters}) != 1:
+                return None
+            groups.append(('tLM', flags, filters, 3 * len(flags) * len(filters)))
+        else:
+            return None
+    return groups
+
+
+def resident_feature_table(sess, groups):
+    """forms the K x F table of ``groups`` (:func:`resident_feature_groups`) on the device session that holds the image and its
+    label map -- nothing comes to the host, nothing is waited for; returns F"""
+    total = sum(g[3] for g in groups)
+    column, prepared = 0, False
+    for kind, flags, filters, width in groups:
+        sess.features_place(total, column)
+        want = dict(mean='mean' in flags, std='std' in flags, energy='energy' in flags)
+        if kind == 'color':
+            sess.features_color(to_host=False, **want)
+        else:
+            if not prepared:
+                sess.lm_prepare(150.)
+                prepared = True
+            sess.lm_features(filters, MAX_SIGNAL_RESPONSE, to_host=False, **want)
+        column += width
+    return total
 
 
 def _finish_texture(features, names):
@@ -883,7 +939,15 @@ def _selected_features_color2d(img, segments, feature_flags, sess=None):
         names += ns
     for k in [k for k in feature_flags if k.startswith('tLM')]:
         bank_type = k.split('_')[-1] if '_' in k else 'normal'
-        fts, ns = compute_texture_desc_lm_img2d_clr(img, segments, feature_flags[k], bank_type)
+        filters, fl_names = _select_bank(bank_type)
+        if _texture_on_device(feature_flags[k], filters):
+            # on the session that holds the image and the labels already (one upload for all groups)
+            _check_color_image(img)
+            if sess is None:
+                sess = _hip.Image2D(segments.shape[0], segments.shape[1]).upload(np.nan_to_num(img)).set_labels(segments)
+            fts, ns = _texture_desc_lm_device(img, segments, feature_flags[k], filters, fl_names, sess=sess)
+        else:
+            fts, ns = compute_texture_desc_lm_img2d_clr(img, segments, feature_flags[k], bank_type)
         features.append(fts)
         names += ns
     if own and sess is not None:

@@ -15,7 +15,8 @@ import numpy as np
 
 from pyimsegm_amd import _hip
 from pyimsegm_amd.descriptors import (FEATURES_SET_COLOR, _selected_features_color2d, compute_selected_features_gray3d,
-                                      compute_selected_features_img2d, norm_features)
+                                      compute_selected_features_img2d, norm_features, resident_feature_groups,
+                                      resident_feature_table)
 from pyimsegm_amd.graph_cuts import estim_class_model, predict_proba, segment_graph_cut_general
 from pyimsegm_amd.labeling import histogram_regions_labels_norm
 from pyimsegm_amd.superpixels import _open_session, _open_volume, _release_session, _run_slic, _run_slic3d
@@ -212,16 +213,16 @@ class _ResidentImage(object):
             self._slic = None
             self._features = None
             self.resident_features = False
-            flags = dict_features.get('color', ()) if set(dict_features) == {'color'} else None
-            if image.ndim == 3 and flags is not None and image.dtype in (np.uint8, np.float64) \
-                    and 0 < len(flags) and set(flags) <= {'mean', 'std', 'energy'}:
-                # everything stays on the device: statistics of the uploaded image on the resident labels, assembled
-                # into the feature table the class model and the 'features' edge type read
-                # (float images: NaN / inf would have to be replaced first, descriptors.py:818 -- checked on the host)
-                if image.dtype == np.uint8 or bool(np.isfinite(image.sum(dtype=np.float64))):
-                    self._flags = ('mean' in flags, 'std' in flags, 'energy' in flags)
-                    self._features = self.sess.features_color(*self._flags, to_host=features_to_host)
-                    self.resident_features = True
+            self._table_columns = 0
+            groups = resident_feature_groups(dict_features) if image.ndim == 3 and image.dtype in (np.uint8, np.float64) else None
+            # everything stays on the device: colour statistics of the uploaded image / Leung-Malik statistics of its filter
+            # responses on the resident labels, side by side in the feature table the class model and the 'features' edge type read
+            # (float images: NaN / inf would have to be replaced first, descriptors.py:818 -- checked on the host)
+            if groups is not None and (image.dtype == np.uint8 or bool(np.isfinite(image.sum(dtype=np.float64)))):
+                self._table_columns = resident_feature_table(self.sess, groups)
+                self.resident_features = True
+                if features_to_host:
+                    self._features = self.sess.get_features(self._table_columns)
             if not self.resident_features:
                 features, _ = compute_selected_features_img2d(image, self.slic, dict_features)
                 features[np.isnan(features)] = 0
@@ -233,7 +234,7 @@ class _ResidentImage(object):
     @property
     def features(self):
         if self._features is None:        # resident table that was not needed on the host so far
-            self._features = self.sess.features_color(*self._flags, to_host=True)
+            self._features = self.sess.get_features(self._table_columns)
         return self._features
 
     @property

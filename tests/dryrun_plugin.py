@@ -87,8 +87,21 @@ class Image2D(object):
         m, e, v = self.color_stats(True, energy, std)
         blocks = ([m] if mean else []) + ([np.sqrt(v)] if std else []) + ([e] if energy else [])
         fts = np.nan_to_num(np.hstack(blocks)); fts[fts == 0] = 0
+        place = getattr(self, '_place', None)
+        self._place = None
+        if place is not None and place[0] != fts.shape[1]:       # a group of a wider table
+            if getattr(self, 'features', None) is None or self.features.shape[1] != place[0]:
+                self.features = np.zeros((fts.shape[0], place[0]))
+            self.features[:, place[1]:place[1] + fts.shape[1]] = fts
+            return None
         self.features = fts
         return fts if to_host else None
+    def features_place(self, total_columns, column):
+        self._place = (int(total_columns), int(column))
+        return self
+    def get_features(self, columns):
+        assert self.features.shape[1] == columns
+        return np.array(self.features)
     def segment(self, pairwise, edge_type='model', edge_cost=1., gmm=None, proba=None, use_graphcut=True, classes=None,
                 want_segm=True, want_soft=False, want_graph_labels=False, want_proba=False, debug=False, pinned=True,
                 keep_soft_on_device=False, segm_dtype=None, soft_dtype=None):
