@@ -167,7 +167,12 @@ IMSEGM_API int imsegm_image2d_lm_features(imsegm_image2d *img, const double *wei
  * kernels, as before; the factorisation is the caller's (pyimsegm_amd._hip: numpy SVD, components above 1e-13 of the largest).
  * dense_parity[b] (or NULL): +1 / -1 when EVERY dense kernel of battery b is even / odd under the point reflection, K[-p] ==
  * +/- K[p] bit for bit (all bar / edge filters of the bank are) -- the sums are then formed over half the kernel, one addition
- * per pair of pixels serving all kernels of the battery; 0: no symmetry is assumed. */
+ * per pair of pixels serving all kernels of the battery; 0: no symmetry is assumed.  +2 / -2: the n_kernels[b] (2, 4, 6, 8) even /
+ * odd kernels of side 33 are, in addition, mirror images of each other in pairs, Kb(dy, dx) = m Ka(dy, -dx) -- the orientations
+ * theta and pi - theta of descriptors.py:924-928 -- and the weights block of the battery (still 33 * 33 * n_kernels[b] doubles)
+ * holds, from its start, the table [x = 0..16][t = 0..16][WS of the pairs | WD of the pairs] with WS / WD = (Ka[t][16 + x] +/-
+ * Ka[t][16 - x]) / 2 of the flipped kernel Ka, row t = 16 halved once more, followed by the signs m of the pairs: two additions and
+ * two multiply-adds per four pixels and pair of kernels (csrc/texture.hip k_conv_battery_quad). */
 IMSEGM_API int imsegm_image2d_lm_features_sep(imsegm_image2d *img, const double *weights, const int *n_kernels, const int *dense_parity,
                                               const double *sep_taps, const int *sep_groups, const int *sep_rank, int n_batteries,
                                               int radius, double clip, int feature_mask, double *features_out);

@@ -699,12 +699,52 @@ class Image2D(object):
     #: kernels whose singular values fall below this share of the largest after RANK components are evaluated as separable passes
     SEPARABLE_TOLERANCE, SEPARABLE_MAX_RANK = 1e-13, 2
 
+    #: two dense kernels count as mirror images of each other when they differ by less than this share of their maximum
+    MIRROR_TOLERANCE = 1e-12
+
     @classmethod
-    def _split_battery(cls, battery, separable=True, symmetric=True):
+    def _mirror_pairs(cls, dense):
+        """the dense (flipped) kernels as pairs (a, b, m) with ``dense[b] == m * dense[a][:, ::-1]`` (m = +-1) to MIRROR_TOLERANCE,
+        or None when they do not all pair up -- the orientations theta and pi - theta of a Leung-Malik battery do"""
+        left = list(range(len(dense)))
+        pairs = []
+        while left:
+            a = left.pop(0)
+            mirrored = dense[a][:, ::-1]
+            bound = cls.MIRROR_TOLERANCE * np.abs(dense[a]).max()
+            for b in left:
+                hit = [m for m in (1., -1.) if np.abs(dense[b] - m * mirrored).max() <= bound]
+                if hit:
+                    pairs.append((a, b, hit[0]))
+                    left.remove(b)
+                    break
+            else:
+                return None
+        return pairs
+
+    @classmethod
+    def _quad_table(cls, dense, pairs, radius):
+        """the table of ``k_conv_battery_quad`` (csrc/texture.hip): [x = 0..r][t = 0..r][WS of the pairs | WD of the pairs], WS / WD =
+        half the sum / difference of the first kernel of a pair at (row t, column r + x) and (row t, column r - x), the row of
+        the kernel centre halved once more; then the mirror signs"""
+        r = radius
+        table = np.zeros((r + 1, r + 1, 2 * len(pairs)))
+        for k, (a, _, _) in enumerate(pairs):
+            right, left = dense[a][:r + 1, r:], dense[a][:r + 1, r::-1]           # [t][x]: columns r + x | r - x
+            table[:, :, k] = ((right + left) / 2).T
+            table[:, :, len(pairs) + k] = ((right - left) / 2).T
+        table[:, r, :] /= 2
+        return np.concatenate([table.ravel(), [m for _, _, m in pairs]])
+
+    @classmethod
+    def _split_battery(cls, battery, separable=True, symmetric=True, mirror=True):
         """one battery (k x S x S convolution kernels) as the device takes it: (dense weights [kx][ky][kernel] of the flipped
-        kernels that stay dense, their number after padding to 0 / 1 / 2 / 4 / 6 / 8, separable taps, groups, rank, radius).
+        kernels that stay dense, their number after padding to 0 / 1 / 2 / 4 / 6 / 8, separable taps, groups, rank, radius, parity).
         A kernel of numerical rank <= SEPARABLE_MAX_RANK (numpy SVD of the flipped kernel) becomes `rank` pairs of (x taps, y
-        taps); at most two kernels per battery go that way (the 0 and 90 degree orientations of an edge / bar battery)."""
+        taps); at most two kernels per battery go that way (the 0 and 90 degree orientations of an edge / bar battery).
+        parity: +-1 the dense kernels are all even / odd under the point reflection; +-2 (``mirror``, side 33) they are mirror
+        images of each other in pairs as well -- the dense weights are then the quad table (:meth:`_quad_table`) in a block of
+        the usual size."""
         battery = np.asarray(battery, dtype=np.float64)
         nk, side = battery.shape[0], battery.shape[1]
         if battery.ndim != 3 or battery.shape[2] != side or side % 2 != 1:
@@ -729,10 +769,6 @@ class Image2D(object):
         for g, parts in enumerate(factors):
             for i, (tx, ty) in enumerate(parts):
                 taps[g, i, 0], taps[g, i, 1] = tx, ty
-        pad = {0: 0, 1: 1, 2: 2, 3: 4, 4: 4, 5: 6, 6: 6, 7: 8, 8: 8}[len(dense)]
-        if pad != len(dense):            # repeat the last kernel: the maximum is unchanged
-            dense = dense + [dense[-1]] * (pad - len(dense))
-        weights = np.ascontiguousarray(np.asarray(dense).transpose(2, 1, 0)) if dense else np.zeros(0)
         # point symmetry of the kernels that stay dense: all even (K[-p] == K[p]) -> +1, all odd -> -1, bit for bit; else 0
         parity = 0
         if dense and symmetric:
@@ -740,21 +776,33 @@ class Image2D(object):
                 parity = 1
             elif all(np.array_equal(k[::-1, ::-1], -k) for k in dense):
                 parity = -1
+        if parity and mirror and side == 33 and len(dense) in (2, 4, 6, 8):
+            pairs = cls._mirror_pairs(dense)
+            if pairs is not None:
+                weights = np.zeros(side * side * len(dense))
+                table = cls._quad_table(dense, pairs, side // 2)
+                weights[:table.size] = table
+                return weights, len(dense), taps, len(factors), rank, side // 2, 2 * parity
+        pad = {0: 0, 1: 1, 2: 2, 3: 4, 4: 4, 5: 6, 6: 6, 7: 8, 8: 8}[len(dense)]
+        if pad != len(dense):            # repeat the last kernel: the maximum is unchanged
+            dense = dense + [dense[-1]] * (pad - len(dense))
+        weights = np.ascontiguousarray(np.asarray(dense).transpose(2, 1, 0)) if dense else np.zeros(0)
         return weights, pad, taps, len(factors), rank, side // 2, parity
 
     #: the last banks handed to :meth:`lm_features`, split and packed (the factorisation is 60 SVDs per bank)
     _packed_banks = []
 
     @classmethod
-    def _pack_bank(cls, batteries, separable):
+    def _pack_bank(cls, batteries, separable, mirror=True):
         """the arguments of ``imsegm_image2d_lm_features_sep`` for a list of batteries; remembered per list of battery ARRAYS (the
         bank of the descriptors is built once per process) with their sums as a guard against arrays changed in place"""
         batteries = [np.asarray(b, dtype=np.float64) for b in batteries]
         sums = [float(b.sum()) for b in batteries]
+        flag_now = (separable, mirror)
         for held, flag, held_sums, packed in cls._packed_banks:
-            if flag == separable and len(held) == len(batteries) and all(a is b for a, b in zip(held, batteries)) and held_sums == sums:
+            if flag == flag_now and len(held) == len(batteries) and all(a is b for a, b in zip(held, batteries)) and held_sums == sums:
                 return packed
-        parts = [cls._split_battery(b, separable, separable) for b in batteries]
+        parts = [cls._split_battery(b, separable, separable, mirror and separable) for b in batteries]
         radius = parts[0][5]
         if any(p[5] != radius for p in parts):
             raise ValueError('the batteries of one call have one kernel size')
@@ -763,15 +811,16 @@ class Image2D(object):
         packed = dict(weights=weights if weights.size else None, taps=taps if taps.size else None, radius=radius, count=len(parts),
                       kernels=np.array([p[1] for p in parts], dtype=np.int32), groups=np.array([p[3] for p in parts], dtype=np.int32),
                       ranks=np.array([p[4] for p in parts], dtype=np.int32), parity=np.array([p[6] for p in parts], dtype=np.int32))
-        cls._packed_banks.insert(0, (batteries, separable, sums, packed))
+        cls._packed_banks.insert(0, (batteries, flag_now, sums, packed))
         del cls._packed_banks[4:]
         return packed
 
-    def lm_features(self, batteries, clip, mean=True, std=True, energy=True, separable=True, to_host=True):
+    def lm_features(self, batteries, clip, mean=True, std=True, energy=True, separable=True, to_host=True, mirror=True):
         """``imsegm_image2d_lm_features_sep``: K x (3 * flags * len(batteries)) statistics of all batteries in one call;
         ``separable=False``: every kernel as a dense S x S sum (``imsegm_image2d_lm_features``); ``to_host=False``: the table
-        stays on the device (for :meth:`segment` with a device class model, :meth:`get_features`) and nothing is waited for"""
-        bank = self._pack_bank(batteries, bool(separable))
+        stays on the device (for :meth:`segment` with a device class model, :meth:`get_features`) and nothing is waited for;
+        ``mirror=False``: the dense kernels of a battery one by one (point symmetry only), not as mirror pairs"""
+        bank = self._pack_bank(batteries, bool(separable), bool(mirror))
         mask = (1 if mean else 0) | (2 if std else 0) | (4 if energy else 0)
         out = np.empty((self.n_labels, 3 * bin(mask).count('1') * bank['count']), dtype=np.float64) if to_host else None
         _check(load_library().imsegm_image2d_lm_features_sep(

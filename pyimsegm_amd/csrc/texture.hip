@@ -345,6 +345,123 @@ k_conv_battery_sym(const double *__restrict__ planes, int H, int W, const double
     }
 }
 
+// ---- dense batteries whose kernels are mirror images of each other in pairs ------------------------------------------------------
+// The orientations theta and pi - theta of an edge / bar battery are mirror images: Kb(dy, dx) = m * Ka(dy, -dx) (m = +-1; to the
+// last bits of the rotated grid -- the host checks it to 1e-12 of the kernel's maximum and takes Ka's values for both).  Together
+// with the point symmetry K(-p) = sign * K(p), the four inputs of a quad (+-dy, +-dx) around the output,
+//     top = row c - y, bot = row c + y, A = column cx - x, B = column cx + x,
+// enter the two responses only through  U = (A + B)[top] + sign * (A + B)[bot]  and  V = (B - A)[top] - sign * (B - A)[bot]:
+//     Ra = WS * U + WD * V,    Rb = m * (WS * U - WD * V),    WS = (Ka(-y, x) + Ka(-y, -x)) / 2,  WD = (Ka(-y, x) - Ka(-y, -x)) / 2,
+// i.e. 2 additions + 2 multiply-adds per quad and PAIR of kernels where the point symmetry alone needs 2 + 4 (and the plain sum 8):
+// 624 vector operations per column pair, lane and 4 output rows for the three pairs of a Leung-Malik battery instead of 1120.
+// (The sums differ from the reference's order of additions in the last bits -- as every dense sum here does; the descriptors
+// stay 10^-9 from the reference run's, tolerance 10^-5.)  Table wq: [x = 0..R][t = 0..R][WS of the NP pairs | WD of the NP
+// pairs], t = R + dy the kernel row (the row of the output itself, t = R, halved by the host: its top and bottom coincide),
+// then the NP mirror signs m.  Layout as k_conv_battery: a lane owns one output column and CV_ROWS rows; everything is unrolled
+// over the rows (R is a compile-time constant), so the (row, output) combinations that would meet weight rows outside the
+// kernel are not computed at all and the weights need no padding.
+template <int NP, int R, bool CENTRE>
+__device__ __forceinline__ void quad_column(const double *colA, const double *colB, const double *__restrict__ w, double sign, double nsign,
+                                            double (&accS)[NP][CV_ROWS], double (&accD)[NP][CV_ROWS])
+{
+    constexpr int TW = CV_TX + 2 * R;
+    double sb[2 * R + CV_ROWS], db[2 * R + CV_ROWS];              // (A + B), (B - A) of the rows below: compile-time indices only
+#pragma unroll
+    for (int k = 1; k < CV_ROWS; ++k) {
+        const double a = colA[(2 * R + k) * TW];
+        if (CENTRE) {
+            sb[2 * R + k] = a;
+        } else {
+            const double b = colB[(2 * R + k) * TW];
+            sb[2 * R + k] = a + b;
+            db[2 * R + k] = b - a;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < R + CV_ROWS; ++j) {
+        double st, dt = 0.0;
+        {
+            const double a = colA[j * TW];
+            if (CENTRE) {
+                st = a;
+            } else {
+                const double b = colB[j * TW];
+                st = a + b;
+                dt = b - a;
+            }
+        }
+        if (j <= R) {
+            const double a = colA[(2 * R - j) * TW];
+            if (CENTRE) {
+                sb[2 * R - j] = a;
+            } else {
+                const double b = colB[(2 * R - j) * TW];
+                sb[2 * R - j] = a + b;
+                db[2 * R - j] = b - a;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < CV_ROWS; ++i) {
+            const int t = j - i;
+            if (t < 0 || t > R) continue;
+            const int rho = 2 * R - j + 2 * i;
+            const double U = fma(sign, sb[rho], st);
+#pragma unroll
+            for (int k = 0; k < NP; ++k) accS[k][i] = fma(w[t * 2 * NP + k], U, accS[k][i]);
+            if (!CENTRE) {
+                const double V = fma(nsign, db[rho], dt);
+#pragma unroll
+                for (int k = 0; k < NP; ++k) accD[k][i] = fma(w[t * 2 * NP + NP + k], V, accD[k][i]);
+            }
+        }
+    }
+}
+
+template <int NP, int R>
+__global__ void __launch_bounds__(256)
+k_conv_battery_quad(const double *__restrict__ planes, int H, int W, const double *__restrict__ wq, double sign, double clip,
+                    double *__restrict__ resp)
+{
+    extern __shared__ double tile[];                 // [CV_TY + 2R][CV_TX + 2R]
+    constexpr int TW = CV_TX + 2 * R, TH = CV_TY + 2 * R;
+    const int ch = blockIdx.z;
+    const double *src = planes + (size_t)ch * H * W;
+    const int x0 = blockIdx.x * CV_TX, y0 = blockIdx.y * CV_TY;
+    for (int i = threadIdx.x; i < TW * TH; i += 256) {
+        const int ty = i / TW, tx = i - ty * TW;
+        const int gy = reflect_index(y0 + ty - R, H), gx = reflect_index(x0 + tx - R, W);
+        tile[i] = src[(size_t)gy * W + gx];
+    }
+    __syncthreads();
+    const int lx = threadIdx.x & 63;
+    const int ly = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) * CV_ROWS;
+    double accS[NP][CV_ROWS], accD[NP][CV_ROWS];
+#pragma unroll
+    for (int k = 0; k < NP; ++k)
+#pragma unroll
+        for (int i = 0; i < CV_ROWS; ++i) accS[k][i] = accD[k][i] = 0.0;
+    const double nsign = -sign;
+    const double *centre = tile + (size_t)ly * TW + lx + R;
+    quad_column<NP, R, true>(centre, centre, wq, sign, nsign, accS, accD);
+    for (int x = 1; x <= R; ++x)
+        quad_column<NP, R, false>(centre - x, centre + x, wq + (size_t)x * (R + 1) * 2 * NP, sign, nsign, accS, accD);
+    const double *mirror = wq + (size_t)(R + 1) * (R + 1) * 2 * NP;
+    const int x = x0 + lx;
+#pragma unroll
+    for (int i = 0; i < CV_ROWS; ++i) {
+        const int y = y0 + ly + i;
+        if (x >= W || y >= H) continue;
+        double r = -INFINITY;
+#pragma unroll
+        for (int k = 0; k < NP; ++k) {
+            r = fmax(r, accS[k][i] + accD[k][i]);
+            r = fmax(r, mirror[k] * (accS[k][i] - accD[k][i]));
+        }
+        if (r > clip) r = clip;
+        resp[(size_t)ch * H * W + (size_t)y * W + x] = r;
+    }
+}
+
 // ---- kernels of the bank that are separable -------------------------------------------------------------------------------
 // 28 of the 76 Leung-Malik kernels have rank 1 or 2 as 33 x 33 matrices: the Gaussians (rank 1), both Laplacians of a Gaussian
 // (rank 2: g''(x) g(y) + g(x) g''(y)) and the edge / bar filters at 0 and 90 degrees (rank 1: gx(3 sigma) gy'(sigma) on the
@@ -543,7 +660,23 @@ int launch_battery_dense(const double *planes, int H, int W, const double *wgt_d
         return -1;
     }
     dim3 grid(cdiv(W, CV_TX), cdiv(H, CV_TY), P);
-    if (parity != 0) {
+    if (parity == 2 || parity == -2) {
+        // point symmetry AND mirror pairs: wgt_dev holds the quad table of k_conv_battery_quad (nk / 2 pairs)
+        constexpr int R = 16;
+        if (radius != R || (nk & 1)) {
+            set_error("filter battery: the mirror-pair form takes kernels of side 33 in pairs");
+            return -1;
+        }
+        const size_t ldsq = (size_t)(CV_TX + 2 * R) * (CV_TY + 2 * R) * sizeof(double);
+        const double sign = parity > 0 ? 1.0 : -1.0;
+#define LAUNCH_QUAD(NP)                                                                                                          \
+    {                                                                                                                            \
+        HIP_TRY(hipFuncSetAttribute((const void *)k_conv_battery_quad<NP, R>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsq)); \
+        hipLaunchKernelGGL((k_conv_battery_quad<NP, R>), grid, 256, ldsq, st, planes, H, W, wgt_dev, sign, clip, resp);          \
+    }
+        if (nk == 2) LAUNCH_QUAD(1) else if (nk == 4) LAUNCH_QUAD(2) else if (nk == 6) LAUNCH_QUAD(3) else LAUNCH_QUAD(4)
+#undef LAUNCH_QUAD
+    } else if (parity != 0) {
         // every dense kernel of the battery is even (+1) or odd (-1) under the point reflection: half the multiplications
         const int Spad8 = conv_sym_padded_rows(radius);
         const size_t lds8 = (size_t)(CV_TX + 2 * radius) * (CV_TY - CV_ROWS + Spad8) * sizeof(double);

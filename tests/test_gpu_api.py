@@ -238,8 +238,15 @@ def test_texture_one_call_equals_battery_by_battery(flags):
     sess.lm_prepare(150.)
     dense = sess.lm_features(filters, D.MAX_SIGNAL_RESPONSE, mean='mean' in flags, std='std' in flags, energy='energy' in flags,
                              separable=False)
+    # ... and the mirror pairs of an edge / bar battery (two multiply-adds per four pixels and pair) against the kernels one by one
+    single = sess.lm_features(filters, D.MAX_SIGNAL_RESPONSE, mean='mean' in flags, std='std' in flags, energy='energy' in flags,
+                              mirror=False)
     sess.close()
     assert np.max(np.abs(one - dense)) <= 1e-9 * max(1.0, np.abs(dense).max()), np.max(np.abs(one - dense))
+    assert np.max(np.abs(one - single)) <= 1e-9 * max(1.0, np.abs(single).max()), np.max(np.abs(one - single))
+    # (the two calls did take different kernels; the fixed-point statistics absorb most of the last-bit differences of the sums)
+    assert sorted(set(_hip.Image2D._pack_bank(filters, True, True)['parity'].tolist())) == [-2, 0, 2]
+    assert sorted(set(_hip.Image2D._pack_bank(filters, True, False)['parity'].tolist())) == [-1, 0, 1]
     # ... and through the descriptor function the pipelines call
     fts, names = D.compute_texture_desc_lm_img2d_clr(img, seg, list(flags))
     assert fts.shape == one.shape and len(names) == one.shape[1]

@@ -9,7 +9,7 @@ def test_the_separable_kernels_of_the_bank_and_their_factors():
     assert sum(len(b) for b in filters) == 76
     taken = 0
     for battery, name in zip(filters, names):
-        weights, dense, taps, groups, rank, radius, parity = _hip.Image2D._split_battery(battery)
+        weights, dense, taps, groups, rank, radius, parity = _hip.Image2D._split_battery(battery, mirror=False)
         assert radius == 16 and dense in (0, 6) and taps.shape == (groups, rank, 2, 33)
         kind = name.split('-')[1]
         assert parity == {'edge': -1, 'bar': 1}.get(kind, 0), name        # (no dense kernels left: nothing to be symmetric)
@@ -33,3 +33,46 @@ def test_the_separable_kernels_of_the_bank_and_their_factors():
     assert (dense, groups, rank, parity) == (8, 0, 0, 0) and taps.size == 0
     weights, dense, _, groups, _, _, _ = _hip.Image2D._split_battery(np.asarray(filters[0])[1:4], separable=False)
     assert dense == 4 and np.array_equal(weights[:, :, 3], weights[:, :, 2])
+
+
+def test_mirror_pairs_of_the_bank_and_the_quad_table():
+    """the orientations theta and pi - theta of every edge / bar battery are mirror images (Image2D._mirror_pairs), and the table
+    the device sums over quads of pixels (Image2D._quad_table, csrc/texture.hip k_conv_battery_quad) gives the responses of
+    scipy.ndimage.convolve -- the sums restated in numpy"""
+    from scipy import ndimage
+    from pyimsegm_amd import _hip, descriptors as D
+    rng = np.random.default_rng(3)
+    img = rng.random((60, 71))
+    r = 16
+    for bank in (D.create_filter_bank_lm_2d(), D.create_filter_bank_lm_2d(sigmas=D.SHORT_FILTERS_SIGMAS, nb_orient=4)):
+        for battery, name in zip(*bank):
+            weights, dense, taps, groups, rank, radius, parity = _hip.Image2D._split_battery(battery)
+            kind = name.split('-')[1]
+            assert parity == {'edge': -2, 'bar': 2}.get(kind, 0), name
+            if not parity:
+                continue
+            pairs = dense // 2
+            assert dense == len(battery) - 2 and weights.size == 33 * 33 * dense
+            table = weights[:(r + 1) * (r + 1) * 2 * pairs].reshape(r + 1, r + 1, 2 * pairs)
+            signs = weights[table.size:table.size + pairs]
+            assert set(np.abs(signs)) == {1.0} and not weights[table.size + pairs:].any()
+            s = 1.0 if parity > 0 else -1.0
+            padded = np.pad(img, r, mode='symmetric')               # (scipy's 'reflect')
+            h, w = img.shape
+            acc_s, acc_d = np.zeros((pairs, h, w)), np.zeros((pairs, h, w))
+            for x in range(r + 1):
+                a, b = padded[:, r - x:r - x + w], padded[:, r + x:r + x + w]
+                total, diff = (a if x == 0 else a + b), b - a
+                for t in range(r + 1):
+                    u = total[t:t + h] + s * total[2 * r - t:2 * r - t + h]
+                    v = diff[t:t + h] - s * diff[2 * r - t:2 * r - t + h]
+                    for k in range(pairs):
+                        acc_s[k] += table[x, t, k] * u
+                        acc_d[k] += table[x, t, pairs + k] * v
+            got = np.max([acc_s + acc_d, signs[:, None, None] * (acc_s - acc_d)], axis=(0, 1))
+            rest = [k for k in range(len(battery)) if k not in (0, len(battery) // 2)]
+            ref = np.max([ndimage.convolve(img, battery[k]) for k in rest], axis=0)
+            assert np.max(np.abs(got - ref)) <= 1e-13 * max(1.0, np.abs(ref).max()), name
+    # kernels that do not pair up keep the point-symmetric form
+    filters, _ = D.create_filter_bank_lm_2d()
+    assert _hip.Image2D._split_battery(np.asarray(filters[0])[[1, 2, 3, 5]])[6] == -1
