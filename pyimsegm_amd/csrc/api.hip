@@ -36,6 +36,7 @@ static Knobs read_knobs()
     k.sweeps_force_fail = flag("IMSEGM_SWEEPS_FORCE_FAIL");
     k.conn_general = flag("IMSEGM_CONN_GENERAL");
     k.gc_no_topo_regs = flag("IMSEGM_GC_NO_TOPO_REGS");
+    k.sep_wide_tile = flag("IMSEGM_SEP_WIDE_TILE");
     k.brick_cap = num("IMSEGM_BRICK_CAP", 0);
     k.gc_lds_level = num("IMSEGM_GC_LDS_LEVEL", 4);
     k.gc_threads = num("IMSEGM_GC_THREADS", 0);

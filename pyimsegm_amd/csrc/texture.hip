@@ -475,11 +475,24 @@ k_conv_battery_quad(const double *__restrict__ planes, int H, int W, const doubl
 // component become scalar registers loaded once, so that an FMA costs one LDS read), or 0: any radius, loops at run time.
 constexpr int SEP_MAX_GROUPS = 2;
 
+// what the kernels get of a SepJobs: the taps as offsets from ONE pointer the kernel takes as `const double *__restrict__` -- a
+// pointer out of the job table could alias the responses the kernel writes, and the taps would then be fetched by vector loads
+// into vector registers instead of scalar loads
+struct SepJobDev {
+    double *resp;
+    long taps_off;
+    int groups, rank, merge;
+};
+struct SepJobsDev {
+    int n;
+    SepJobDev job[SEP_MAX_JOBS];
+};
+
 // One launch serves the separable kernels of up to SEP_MAX_JOBS batteries (the five batteries of one sigma of the bank): the input
 // tile -- 4.5 x the plane per launch, the larger part of a launch that only does a rank-1 kernel -- is loaded once for all of them.
 template <int ST>
 __global__ void __launch_bounds__(256)
-k_sep_battery(const double *__restrict__ planes, int H, int W, int radius, double clip, SepJobs jobs)
+k_sep_battery(const double *__restrict__ planes, const double *__restrict__ taps_base, int H, int W, int radius, double clip, SepJobsDev jobs)
 {
     extern __shared__ double sep_sm[];
     const int S = ST > 0 ? ST : 2 * radius + 1;
@@ -502,8 +515,8 @@ k_sep_battery(const double *__restrict__ planes, int H, int W, int radius, doubl
     const int ly = wave * CV_ROWS;
     const int x = x0 + lx;
     for (int jb = 0; jb < jobs.n; ++jb) {
-    const double *__restrict__ taps = jobs.job[jb].taps;
-    double *__restrict__ resp = jobs.job[jb].resp;
+    const double *__restrict__ taps = taps_base + jobs.job[jb].taps_off;
+    double *resp = jobs.job[jb].resp;
     const int n_groups = jobs.job[jb].groups, rank = jobs.job[jb].rank, merge = jobs.job[jb].merge;
     double acc[SEP_MAX_GROUPS][CV_ROWS];
 #pragma unroll
@@ -644,6 +657,100 @@ int launch_texture_prepare_volume(const void *vol, int dtype, int P, int H, int 
     return 0;
 }
 
+// ---- the separable kernels of side 33 on a TALL tile ----------------------------------------------------------------------------
+// k_sep_battery<33> spends three quarters of its multiply-adds on the x pass over the halo rows of its 64 x 16 tile (48 rows for
+// 16 rows of output).  Here a workgroup takes 16 columns x 96 rows: the x pass runs over 128 rows of 16 outputs, the y pass over
+// 96 x 16 -- 77 multiply-adds per output and component instead of 165 -- and both passes keep every lane busy:
+//   x pass: thread = (tile row, half of its 16 columns): 8 adjacent outputs from a window of 40 values (one LDS read per 6.6 FMAs);
+//   y pass: thread = (column, 6 adjacent rows): a window of 38 values of the x pass; 16 lanes write 128 contiguous bytes.
+// Sums in the order of k_sep_battery (taps ascending, components in turn): the responses are the same bit for bit.
+constexpr int SPT_X = 16, SPT_Y = 96, SPT_R = 16, SPT_S = 2 * SPT_R + 1, SPT_XO = 8, SPT_YO = 6;
+constexpr int SPT_TW = (SPT_X + 2 * SPT_R) | 1, SPT_TH = SPT_Y + 2 * SPT_R, SPT_TS = SPT_X + 1;
+static_assert(SPT_TH * (SPT_X / SPT_XO) == 256 && SPT_X * (SPT_Y / SPT_YO) == 256, "one item per thread in both passes");
+
+__global__ void __launch_bounds__(256)
+k_sep_battery_tall(const double *__restrict__ planes, const double *__restrict__ taps_base, int H, int W, double clip, SepJobsDev jobs)
+{
+    extern __shared__ double sep_sm[];
+    double *tile = sep_sm;                                   // [SPT_TH][SPT_TW]  input (odd row stride: a lane owns a row in the x pass)
+    double *T = sep_sm + (size_t)SPT_TH * SPT_TW;            // [SPT_TH][SPT_TS]  x pass of the current component
+    const int ch = blockIdx.z;
+    const double *src = planes + (size_t)ch * H * W;
+    const int x0 = blockIdx.x * SPT_X, y0 = blockIdx.y * SPT_Y;
+    constexpr int IN_W = SPT_X + 2 * SPT_R;
+    for (int i = threadIdx.x; i < IN_W * SPT_TH; i += 256) {
+        const int ty = i / IN_W, tx = i - ty * IN_W;
+        tile[ty * SPT_TW + tx] = src[(size_t)reflect_index(y0 + ty - SPT_R, H) * W + reflect_index(x0 + tx - SPT_R, W)];
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    // x pass: row of the tile, first of its 8 output columns
+    const int xrow = (wave & 1) * 64 + lane, xseg = (wave >> 1) * SPT_XO;
+    const double *rp = tile + (size_t)xrow * SPT_TW + xseg;
+    double *tp = T + (size_t)xrow * SPT_TS + xseg;
+    // y pass: column, first of its 6 output rows
+    const int ycol = lane & 15, yrow = ((lane >> 4) + 4 * wave) * SPT_YO;
+    const double *cp = T + (size_t)yrow * SPT_TS + ycol;
+    const int x = x0 + ycol;
+    for (int jb = 0; jb < jobs.n; ++jb) {
+        const double *__restrict__ taps = taps_base + jobs.job[jb].taps_off;
+        double *resp = jobs.job[jb].resp;
+        const int n_groups = jobs.job[jb].groups, rank = jobs.job[jb].rank, merge = jobs.job[jb].merge;
+        double acc[SEP_MAX_GROUPS][SPT_YO];
+#pragma unroll
+        for (int g = 0; g < SEP_MAX_GROUPS; ++g)
+#pragma unroll
+            for (int i = 0; i < SPT_YO; ++i) acc[g][i] = 0.0;
+#pragma unroll
+        for (int g = 0; g < SEP_MAX_GROUPS; ++g) {
+            if (g >= n_groups) break;
+            for (int c = 0; c < rank; ++c) {
+                const double *vx = taps + (size_t)(g * rank + c) * 2 * SPT_S, *uy = vx + SPT_S;       // wave uniform: scalar loads
+                {
+                    // (all reads of the window first, then the arithmetic: two waves per SIMD do not hide a read that is waited for
+                    // right where it is issued)
+                    double win[SPT_S + SPT_XO - 1], o[SPT_XO];
+#pragma unroll
+                    for (int q = 0; q < SPT_S + SPT_XO - 1; ++q) win[q] = rp[q];
+#pragma unroll
+                    for (int k = 0; k < SPT_XO; ++k) o[k] = 0.0;
+#pragma unroll
+                    for (int q = 0; q < SPT_S + SPT_XO - 1; ++q)
+#pragma unroll
+                        for (int k = 0; k < SPT_XO; ++k)
+                            if (q - k >= 0 && q - k < SPT_S) o[k] = fma(vx[q - k], win[q], o[k]);
+#pragma unroll
+                    for (int k = 0; k < SPT_XO; ++k) tp[k] = o[k];
+                }
+                __syncthreads();
+                {
+                    double col[SPT_S + SPT_YO - 1];
+#pragma unroll
+                    for (int q = 0; q < SPT_S + SPT_YO - 1; ++q) col[q] = cp[q * SPT_TS];
+#pragma unroll
+                    for (int q = 0; q < SPT_S + SPT_YO - 1; ++q)
+#pragma unroll
+                        for (int i = 0; i < SPT_YO; ++i)
+                            if (q - i >= 0 && q - i < SPT_S) acc[g][i] = fma(uy[q - i], col[q], acc[g][i]);
+                }
+                __syncthreads();
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < SPT_YO; ++i) {
+            const int y = y0 + yrow + i;
+            if (x >= W || y >= H) continue;
+            double r = acc[0][i];
+            if (n_groups > 1) r = fmax(r, acc[1][i]);
+            double *out = resp + (size_t)ch * H * W + (size_t)y * W + x;
+            if (merge) r = fmax(r, *out);            // (the dense kernels' maximum, already clipped: min and max commute here)
+            if (r > clip) r = clip;
+            *out = r;
+        }
+    }
+}
+
 // the dense kernels of a battery -> resp (clipped maximum over them); nk = 0: nothing to do
 int launch_battery_dense(const double *planes, int H, int W, const double *wgt_dev, int nk, int radius, double clip, double *resp,
                          hipStream_t st, int P, int parity)
@@ -729,11 +836,26 @@ int launch_battery_sep(const double *planes, int H, int W, int radius, double cl
         set_error("filter battery: kernel radius too large for the LDS tile");
         return -1;
     }
+    SepJobsDev dev = {};
+    dev.n = jobs.n;
+    const double *taps_base = jobs.job[0].taps;
+    for (int j = 0; j < jobs.n; ++j) {
+        const SepJob &q = jobs.job[j];
+        dev.job[j].resp = q.resp; dev.job[j].taps_off = (long)(q.taps - taps_base);          // (the taps of a call lie in one buffer)
+        dev.job[j].groups = q.groups; dev.job[j].rank = q.rank; dev.job[j].merge = q.merge;
+    }
+    if (radius == SPT_R && !knobs().sep_wide_tile) {
+        const size_t lds = (size_t)SPT_TH * (SPT_TW + SPT_TS) * sizeof(double);
+        HIP_TRY(hipFuncSetAttribute((const void *)k_sep_battery_tall, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(k_sep_battery_tall, dim3(cdiv(W, SPT_X), cdiv(H, SPT_Y), P), 256, lds, st, planes, taps_base, H, W, clip, dev);
+        HIP_TRY(hipGetLastError());
+        return 0;
+    }
     dim3 grid(cdiv(W, CV_TX), cdiv(H, CV_TY), P);
     const void *sfn = radius == 16 ? (const void *)k_sep_battery<33> : (const void *)k_sep_battery<0>;
     if (sep_lds > 48 * 1024) HIP_TRY(hipFuncSetAttribute(sfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sep_lds));
-    if (radius == 16) hipLaunchKernelGGL(k_sep_battery<33>, grid, 256, sep_lds, st, planes, H, W, radius, clip, jobs);
-    else hipLaunchKernelGGL(k_sep_battery<0>, grid, 256, sep_lds, st, planes, H, W, radius, clip, jobs);
+    if (radius == 16) hipLaunchKernelGGL(k_sep_battery<33>, grid, 256, sep_lds, st, planes, taps_base, H, W, radius, clip, dev);
+    else hipLaunchKernelGGL(k_sep_battery<0>, grid, 256, sep_lds, st, planes, taps_base, H, W, radius, clip, dev);
     HIP_TRY(hipGetLastError());
     return 0;
 }

@@ -212,7 +212,7 @@ def test_texture_on_device_matches_scipy(shape, bank, dtype):
 
 
 @pytest.mark.parametrize('flags', [('mean', 'std', 'energy'), ('std', ), ('energy', 'mean')])
-def test_texture_one_call_equals_battery_by_battery(flags):
+def test_texture_one_call_equals_battery_by_battery(flags, monkeypatch):
     """imsegm_image2d_lm_features (all batteries in one call, the L2 norm of a battery stays on the device) against the
     battery-by-battery calls with the norm on the host: same table up to the last bits of log()"""
     from pyimsegm_amd import _hip, descriptors as D
@@ -241,12 +241,20 @@ def test_texture_one_call_equals_battery_by_battery(flags):
     # ... and the mirror pairs of an edge / bar battery (two multiply-adds per four pixels and pair) against the kernels one by one
     single = sess.lm_features(filters, D.MAX_SIGNAL_RESPONSE, mean='mean' in flags, std='std' in flags, energy='energy' in flags,
                               mirror=False)
-    sess.close()
     assert np.max(np.abs(one - dense)) <= 1e-9 * max(1.0, np.abs(dense).max()), np.max(np.abs(one - dense))
     assert np.max(np.abs(one - single)) <= 1e-9 * max(1.0, np.abs(single).max()), np.max(np.abs(one - single))
+    # ... the separable kernels on the tall 16 x 96 tile (default) and on the 64 x 16 one: the same sums in the same order
+    monkeypatch.setenv('IMSEGM_SEP_WIDE_TILE', '1')
+    wide = sess.lm_features(filters, D.MAX_SIGNAL_RESPONSE, mean='mean' in flags, std='std' in flags, energy='energy' in flags)
+    planes_wide = [(sess.lm_battery(filters[b], D.MAX_SIGNAL_RESPONSE), sess.get_response()) for b in (1, 3, 4)]
+    monkeypatch.delenv('IMSEGM_SEP_WIDE_TILE')
+    assert np.array_equal(one, wide)
+    for b, (norm, planes) in zip((1, 3, 4), planes_wide):              # (bar battery, Gaussian, Laplacian of a Gaussian)
+        assert sess.lm_battery(filters[b], D.MAX_SIGNAL_RESPONSE) == norm and np.array_equal(sess.get_response(), planes)
     # (the two calls did take different kernels; the fixed-point statistics absorb most of the last-bit differences of the sums)
     assert sorted(set(_hip.Image2D._pack_bank(filters, True, True)['parity'].tolist())) == [-2, 0, 2]
     assert sorted(set(_hip.Image2D._pack_bank(filters, True, False)['parity'].tolist())) == [-1, 0, 1]
+    sess.close()
     # ... and through the descriptor function the pipelines call
     fts, names = D.compute_texture_desc_lm_img2d_clr(img, seg, list(flags))
     assert fts.shape == one.shape and len(names) == one.shape[1]
