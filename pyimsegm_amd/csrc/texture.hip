@@ -37,11 +37,11 @@ __global__ void __launch_bounds__(256) k_to_planes(const T *__restrict__ img, in
 
 // ---- long symmetric 1-D correlation (sigma = 150 -> radius 600, 1201 taps) ------------------------------------------------
 // Round 2 computed one output per lane with two global loads per FMA (3.5 TFLOP/s = 4.5 % of the fp64 vector peak, 17 % of a
-// config-3 image's time).  Now a lane owns one column and CR = 8 consecutive output rows: every value it loads feeds 8 FMAs,
-// and the 15 taps a block of 8 source rows needs are a contiguous window of the (zero padded) full tap table, wave uniform ->
+// config-3 image's time).  Now a lane owns one column and CR = 16 consecutive output rows: every value it loads feeds 16 FMAs,
+// and the 31 taps a block of 16 source rows needs are a contiguous window of the (zero padded) full tap table, wave uniform ->
 // scalar loads, as the weights of the filter batteries.  The pass is always along y (coalesced row segments); the x pass runs
 // on the transposed planes (two LDS-tiled transposes, 2 x 100 MB each, instead of strided reads).
-constexpr int CR = 8;
+constexpr int CR = 16;
 // fullpad[CR - 1 + d + radius] = taps[|d|] for |d| <= radius, zero elsewhere (length 2 * radius + 1 + 2 * CR)
 __global__ void k_taps_full(const double *__restrict__ taps, int radius, double *__restrict__ fullpad)
 {
@@ -73,8 +73,18 @@ k_corr1d_col(const double *__restrict__ src, double *__restrict__ dst, int H, in
 #pragma unroll
         for (int m = 0; m < 2 * CR - 1; ++m) w[m] = wp[m];
         double v[CR];
+        const int q0 = y0 - radius + b * CR;            // (wave uniform)
+        if (q0 >= 0 && q0 + CR <= H) {
+            // all CR source rows inside the plane -- nearly every block: CR loads off one row pointer.  (The reflected row index
+            // costs ~20 scalar instructions per row, and the scalar unit serves the four SIMDs of a CU: with it in every block the
+            // pass ran at a quarter of the vector rate, 1.47 ms per pass at 2048^2.)
+            const double *p = s + (size_t)q0 * W + xs;
 #pragma unroll
-        for (int j = 0; j < CR; ++j) v[j] = s[(size_t)reflect_index(y0 - radius + b * CR + j, H) * W + xs];
+            for (int j = 0; j < CR; ++j) v[j] = p[(size_t)j * W];
+        } else {
+#pragma unroll
+            for (int j = 0; j < CR; ++j) v[j] = s[(size_t)reflect_index(q0 + j, H) * W + xs];
+        }
 #pragma unroll
         for (int j = 0; j < CR; ++j)
 #pragma unroll
