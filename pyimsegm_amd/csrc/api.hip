@@ -984,11 +984,14 @@ int imsegm_image2d_lm_features_sep(imsegm_image2d *im, const double *weights, co
     // responses of up to ROUND consecutive batteries side by side: the separable kernels of a round share ONE launch (one load of
     // the input tile for all of them -- the five batteries of one sigma of the bank)
     const int ROUND = std::min(n_batteries, (int)SEP_MAX_JOBS);
-    if (im->tex_resp.ensure((3 * n * ROUND + wtotal + 1024 + (size_t)n_batteries + 8) * 8 + 64)) return -1;
+    // (scratch of the sums of squares: 1024 partial sums of launch_response_sumsq, or one per workgroup and battery of the round when
+    // the separable kernels -- the last writers of a response -- form them on the way)
+    const size_t n_partial = std::max<size_t>(1024, sep_taps ? sep_sumsq_scratch(im->H, im->W, 3, radius, ROUND) : 0);
+    if (im->tex_resp.ensure((3 * n * ROUND + wtotal + n_partial + (size_t)n_batteries + 8) * 8 + 64)) return -1;
     double *resp = im->tex_resp.as<double>();
     double *d_w = resp + 3 * n * ROUND;
     double *partial = d_w + wtotal;
-    double *d_ssq = partial + 1024;
+    double *d_ssq = partial + n_partial;
     double *host = static_cast<double *>(ctx->stage(wtotal * 8));
     if (!host) {
         set_error("cannot allocate pinned staging memory");
@@ -1025,20 +1028,27 @@ int imsegm_image2d_lm_features_sep(imsegm_image2d *im, const double *weights, co
         int spx = ctx->begin(PG_TEX);
         SepJobs jobs;
         memset(&jobs, 0, sizeof(jobs));
+        double *ssq_of_job[SEP_MAX_JOBS] = { nullptr };
+        bool has_sep[SEP_MAX_JOBS] = { false };
         for (int j = 0; j < cnt; ++j) {
             const int b = b0 + j;
             double *rj = resp + (size_t)j * 3 * n;
             if (launch_battery_dense(im->tex_planes.as<double>(), im->H, im->W, d_w + off[b], n_kernels[b], radius, clip, rj, st, 3,
                                      dense_parity ? dense_parity[b] : 0))
                 return -1;
-            if (sep_taps && sep_groups[b] > 0) {
+            has_sep[j] = sep_taps && sep_groups[b] > 0;
+            if (has_sep[j]) {
+                ssq_of_job[jobs.n] = d_ssq + b;
                 SepJob &q = jobs.job[jobs.n++];
                 q.resp = rj; q.taps = d_w + sep_off[b]; q.groups = sep_groups[b]; q.rank = sep_rank[b]; q.merge = n_kernels[b] > 0 ? 1 : 0;
             }
         }
-        if (launch_battery_sep(im->tex_planes.as<double>(), im->H, im->W, radius, clip, jobs, st, 3)) return -1;
+        const bool fused_ssq = jobs.n > 0 && sep_sumsq_scratch(im->H, im->W, 3, radius, jobs.n) > 0;
+        if (launch_battery_sep(im->tex_planes.as<double>(), im->H, im->W, radius, clip, jobs, st, 3, fused_ssq ? partial : nullptr,
+                               fused_ssq ? ssq_of_job : nullptr))
+            return -1;
         for (int j = 0; j < cnt; ++j)
-            if (launch_response_sumsq(resp + (size_t)j * 3 * n, 3 * n, partial, d_ssq + b0 + j, st)) return -1;
+            if (!(fused_ssq && has_sep[j]) && launch_response_sumsq(resp + (size_t)j * 3 * n, 3 * n, partial, d_ssq + b0 + j, st)) return -1;
         ctx->end(spx);
         // |r| <= norm  =>  |r * mul / div| <= mul = log(1 + norm) / 0.03 < 2^15 for every finite norm: the bound the fixed-point
         // scales are chosen for, without the norm coming to the host (prescale 2: the kernels derive mul and div from *ssq)

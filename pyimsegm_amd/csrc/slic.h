@@ -240,7 +240,9 @@ struct SepJobs {
 };
 int launch_battery_dense(const double *planes, int H, int W, const double *wgt_dev, int nk, int radius, double clip, double *resp,
                          hipStream_t st, int P, int parity);
-int launch_battery_sep(const double *planes, int H, int W, int radius, double clip, const SepJobs &jobs, hipStream_t st, int P);
+size_t sep_sumsq_scratch(int H, int W, int P, int radius, int jobs);
+int launch_battery_sep(const double *planes, int H, int W, int radius, double clip, const SepJobs &jobs, hipStream_t st, int P,
+                       double *ssq_scratch, double *const *ssq_out);
 int launch_response_sumsq(const double *resp, size_t count, double *partial, double *sumsq_dev, hipStream_t st);
 // fullpad: device scratch of 2 * radius + 1 + 16 doubles (the zero-padded full tap table the column pass reads)
 int launch_texture_prepare(const void *img, int dtype, int H, int W, const double *taps_dev, int radius,

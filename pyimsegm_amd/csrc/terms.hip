@@ -226,66 +226,89 @@ __device__ __forceinline__ void zshift_terms(TermsArgs &a)
     ZSHIFT(a.scalars, zs); ZSHIFT(a.fstd, zs);
 }
 
-// predict_proba of the mixture, one wave per superpixel; lane l keeps the features (and the projected coordinates) l, l + 64, ...
-// (NF of them: F <= 64 NF).  Sums run in ascending feature order, as the F <= 64 kernel of the earlier rounds formed them.
+// predict_proba of the mixture; lane l keeps the features (and the projected coordinates) l, l + 64, ... (NF of them: F <= 64 NF)
+// of the GMM_SPW superpixels its wave works on -- a row of the precision factor is read once for all of them (with one superpixel
+// per wave the 2 000 waves of a 2048^2 image read the 778 KB of a 180-feature model 2 000 times: 0.62 ms, bound by the L2).
+// Sums run in ascending feature order, per superpixel exactly as the one-superpixel kernel of the earlier rounds formed them.
+constexpr int GMM_SPW = 4;
 template <int NF>
 __global__ void __launch_bounds__(256) k_gmm_proba(TermsArgs a)
 {
     zshift_terms(a);
     const int K = *a.Kp, C = a.C, F = a.F;
     const int lane = threadIdx.x & 63;
-    const int k = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    if (k >= K) return;
-    double xv[NF];
+    const int k0 = ((blockIdx.x * blockDim.x + threadIdx.x) >> 6) * GMM_SPW;
+    if (k0 >= K) return;
+    double xv[GMM_SPW][NF];
 #pragma unroll
-    for (int i = 0; i < NF; ++i) {
-        const int f = lane + 64 * i;
-        double v = 0.0;
-        if (f < F) {
-            v = a.features[(size_t)k * F + f];
-            if (a.scaler_mean) v = v - a.scaler_mean[f];
-            if (a.scaler_scale) v = v / a.scaler_scale[f];
+    for (int s = 0; s < GMM_SPW; ++s) {
+        const int k = min(k0 + s, K - 1);                // (the last wave repeats the last superpixel; only k < K is written)
+#pragma unroll
+        for (int i = 0; i < NF; ++i) {
+            const int f = lane + 64 * i;
+            double v = 0.0;
+            if (f < F) {
+                v = a.features[(size_t)k * F + f];
+                if (a.scaler_mean) v = v - a.scaler_mean[f];
+                if (a.scaler_scale) v = v / a.scaler_scale[f];
+            }
+            xv[s][i] = v;
         }
-        xv[i] = v;
     }
-    double mywl = -INFINITY;                             // lane c keeps the weighted log probability of class c
-    double amax = -INFINITY;
+    double mywl[GMM_SPW], amax[GMM_SPW];                 // lane c keeps the weighted log probability of class c
+#pragma unroll
+    for (int s = 0; s < GMM_SPW; ++s) mywl[s] = amax[s] = -INFINITY;
     for (int c = 0; c < C; ++c) {
         const double *P = a.prec_chol + (size_t)c * F * F;
-        double y[NF];
+        double y[GMM_SPW][NF];
 #pragma unroll
-        for (int j = 0; j < NF; ++j) y[j] = 0.0;
+        for (int s = 0; s < GMM_SPW; ++s)
+#pragma unroll
+            for (int j = 0; j < NF; ++j) y[s][j] = 0.0;
 #pragma unroll
         for (int i = 0; i < NF; ++i) {
             const int count = min(64, F - 64 * i);       // (uniform)
             for (int l = 0; l < count; ++l) {
-                const double xf = __shfl(xv[i], l, 64);
                 const double *row = P + (size_t)(64 * i + l) * F;
+                double pr[NF];
 #pragma unroll
-                for (int j = 0; j < NF; ++j)
-                    if (lane + 64 * j < F) y[j] += xf * row[lane + 64 * j];
+                for (int j = 0; j < NF; ++j) pr[j] = lane + 64 * j < F ? row[lane + 64 * j] : 0.0;
+#pragma unroll
+                for (int s = 0; s < GMM_SPW; ++s) {
+                    const double xf = __shfl(xv[s][i], l, 64);
+#pragma unroll
+                    for (int j = 0; j < NF; ++j)
+                        if (lane + 64 * j < F) y[s][j] += xf * pr[j];
+                }
             }
         }
-        double lp = 0.0;
 #pragma unroll
-        for (int j = 0; j < NF; ++j) {
-            double d = 0.0;
-            if (lane + 64 * j < F) d = y[j] - a.mu_proj[c * F + lane + 64 * j];
-            const double y2 = d * d;
-            const int count = min(64, F - 64 * j);
-            for (int l = 0; l < count; ++l) lp += __shfl(y2, l, 64);
+        for (int s = 0; s < GMM_SPW; ++s) {
+            double lp = 0.0;
+#pragma unroll
+            for (int j = 0; j < NF; ++j) {
+                double d = 0.0;
+                if (lane + 64 * j < F) d = y[s][j] - a.mu_proj[c * F + lane + 64 * j];
+                const double y2 = d * d;
+                const int count = min(64, F - 64 * j);
+                for (int l = 0; l < count; ++l) lp += __shfl(y2, l, 64);
+            }
+            const double lg = -0.5 * (a.const_term + lp) + a.log_det[c];
+            const double w = lg + a.log_w[c];
+            if (lane == c) mywl[s] = w;
+            amax[s] = fmax(amax[s], w);
         }
-        const double lg = -0.5 * (a.const_term + lp) + a.log_det[c];
-        const double w = lg + a.log_w[c];
-        if (lane == c) mywl = w;
-        amax = fmax(amax, w);
     }
-    if (!(fabs(amax) <= DBL_MAX)) amax = 0.0;            // scipy.special.logsumexp: non-finite maximum -> 0
-    const double ex = exp(mywl - amax);                  // lanes >= C: exp(-inf) = 0
-    double s = 0.0;
-    for (int c = 0; c < C; ++c) s += __shfl(ex, c, 64);
-    const double lse = log(s) + amax;
-    if (lane < C) a.proba[(size_t)k * C + lane] = exp(mywl - lse);
+#pragma unroll
+    for (int s = 0; s < GMM_SPW; ++s) {
+        double top = amax[s];
+        if (!(fabs(top) <= DBL_MAX)) top = 0.0;          // scipy.special.logsumexp: non-finite maximum -> 0
+        const double ex = exp(mywl[s] - top);            // lanes >= C: exp(-inf) = 0
+        double sum = 0.0;
+        for (int c = 0; c < C; ++c) sum += __shfl(ex, c, 64);
+        const double lse = log(sum) + top;
+        if (lane < C && k0 + s < K) a.proba[(size_t)(k0 + s) * C + lane] = exp(mywl[s] - lse);
+    }
 }
 
 __global__ void __launch_bounds__(TM_THREADS) k_gc_terms(TermsArgs a)
@@ -458,7 +481,7 @@ int launch_gc_terms(const TermsArgs &a, hipStream_t st, int nz)
         return -1;
     }
     if (a.gmm) {
-        const dim3 grid(cdiv((long)a.K_cap * 64, 256), 1, nz);
+        const dim3 grid(cdiv((long)cdiv(a.K_cap, GMM_SPW) * 64, 256), 1, nz);
         if (a.F <= 64) hipLaunchKernelGGL(k_gmm_proba<1>, grid, 256, 0, st, a);
         else if (a.F <= 128) hipLaunchKernelGGL(k_gmm_proba<2>, grid, 256, 0, st, a);
         else if (a.F <= 192) hipLaunchKernelGGL(k_gmm_proba<3>, grid, 256, 0, st, a);

@@ -495,6 +495,7 @@ struct SepJobDev {
 };
 struct SepJobsDev {
     int n;
+    double *ssq_partial;       // or null; [job][workgroup]: the sum of the squared final responses a workgroup has written
     SepJobDev job[SEP_MAX_JOBS];
 };
 
@@ -682,6 +683,7 @@ __global__ void __launch_bounds__(256)
 k_sep_battery_tall(const double *__restrict__ planes, const double *__restrict__ taps_base, int H, int W, double clip, SepJobsDev jobs)
 {
     extern __shared__ double sep_sm[];
+    __shared__ double wave_sum[4];
     double *tile = sep_sm;                                   // [SPT_TH][SPT_TW]  input (odd row stride: a lane owns a row in the x pass)
     double *T = sep_sm + (size_t)SPT_TH * SPT_TW;            // [SPT_TH][SPT_TS]  x pass of the current component
     const int ch = blockIdx.z;
@@ -747,6 +749,7 @@ k_sep_battery_tall(const double *__restrict__ planes, const double *__restrict__
                 __syncthreads();
             }
         }
+        double sq = 0.0;
 #pragma unroll
         for (int i = 0; i < SPT_YO; ++i) {
             const int y = y0 + yrow + i;
@@ -757,8 +760,40 @@ k_sep_battery_tall(const double *__restrict__ planes, const double *__restrict__
             if (merge) r = fmax(r, *out);            // (the dense kernels' maximum, already clipped: min and max commute here)
             if (r > clip) r = clip;
             *out = r;
+            sq = fma(r, r, sq);
+        }
+        if (jobs.ssq_partial) {
+            // the battery's response is final here: its sum of squares (the L2 norm of descriptors.py:1090) per workgroup, in a
+            // fixed order -- the 100 MB of a battery are not read again for it
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) sq += __shfl_down(sq, off, 64);
+            if (lane == 0) wave_sum[wave] = sq;
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                const size_t wg = ((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+                jobs.ssq_partial[(size_t)jb * gridDim.x * gridDim.y * gridDim.z + wg] = ((wave_sum[0] + wave_sum[1]) + wave_sum[2]) + wave_sum[3];
+            }
         }
     }
+}
+
+// sums of the per-workgroup partial sums of k_sep_battery_tall: block j adds the `count` values of job j in a fixed order
+struct SsqTargets {
+    double *out[SEP_MAX_JOBS];
+};
+__global__ void __launch_bounds__(256) k_sumsq_jobs(const double *__restrict__ partial, int count, SsqTargets targets)
+{
+    __shared__ double sm[256];
+    const double *p = partial + (size_t)blockIdx.x * count;
+    double a = 0.0;
+    for (int i = threadIdx.x; i < count; i += 256) a += p[i];
+    sm[threadIdx.x] = a;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (threadIdx.x < s) sm[threadIdx.x] += sm[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) targets.out[blockIdx.x][0] = sm[0];
 }
 
 // the dense kernels of a battery -> resp (clipped maximum over them); nk = 0: nothing to do
@@ -831,7 +866,18 @@ int launch_battery_dense(const double *planes, int H, int W, const double *wgt_d
 }
 
 // the separable kernels of up to SEP_MAX_JOBS batteries in one launch (one load of the input tile for all of them)
-int launch_battery_sep(const double *planes, int H, int W, int radius, double clip, const SepJobs &jobs, hipStream_t st, int P)
+// doubles of scratch launch_battery_sep needs to form the sums of squares of `jobs` batteries itself (0: it does not, for this
+// kernel size: launch_response_sumsq does it)
+size_t sep_sumsq_scratch(int H, int W, int P, int radius, int jobs)
+{
+    if (radius != SPT_R || knobs().sep_wide_tile) return 0;
+    return (size_t)jobs * cdiv(W, SPT_X) * cdiv(H, SPT_Y) * P;
+}
+
+// `ssq_scratch` (sep_sumsq_scratch doubles) with `ssq_out[j]` per job: the sum of the squared responses of job j is formed on the
+// way (every job is then the LAST writer of its response); null: not
+int launch_battery_sep(const double *planes, int H, int W, int radius, double clip, const SepJobs &jobs, hipStream_t st, int P,
+                       double *ssq_scratch, double *const *ssq_out)
 {
     if (jobs.n < 1) return 0;
     for (int j = 0; j < jobs.n; ++j) {
@@ -857,9 +903,20 @@ int launch_battery_sep(const double *planes, int H, int W, int radius, double cl
     if (radius == SPT_R && !knobs().sep_wide_tile) {
         const size_t lds = (size_t)SPT_TH * (SPT_TW + SPT_TS) * sizeof(double);
         HIP_TRY(hipFuncSetAttribute((const void *)k_sep_battery_tall, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(k_sep_battery_tall, dim3(cdiv(W, SPT_X), cdiv(H, SPT_Y), P), 256, lds, st, planes, taps_base, H, W, clip, dev);
+        dev.ssq_partial = ssq_out ? ssq_scratch : nullptr;
+        const dim3 grid(cdiv(W, SPT_X), cdiv(H, SPT_Y), P);
+        hipLaunchKernelGGL(k_sep_battery_tall, grid, 256, lds, st, planes, taps_base, H, W, clip, dev);
+        if (ssq_out) {
+            SsqTargets targets = {};
+            for (int j = 0; j < jobs.n; ++j) targets.out[j] = ssq_out[j];
+            hipLaunchKernelGGL(k_sumsq_jobs, jobs.n, 256, 0, st, ssq_scratch, (int)(grid.x * grid.y * grid.z), targets);
+        }
         HIP_TRY(hipGetLastError());
         return 0;
+    }
+    if (ssq_out) {
+        set_error("filter battery: sums of squares with the separable kernels only for kernels of side 33");
+        return -1;
     }
     dim3 grid(cdiv(W, CV_TX), cdiv(H, CV_TY), P);
     const void *sfn = radius == 16 ? (const void *)k_sep_battery<33> : (const void *)k_sep_battery<0>;
@@ -894,7 +951,7 @@ int launch_filter_battery(const double *planes, int H, int W, const double *wgt_
         jobs.n = 1;
         jobs.job[0].resp = resp; jobs.job[0].taps = sep_dev; jobs.job[0].groups = sep_groups; jobs.job[0].rank = sep_rank;
         jobs.job[0].merge = nk > 0 ? 1 : 0;
-        if (launch_battery_sep(planes, H, W, radius, clip, jobs, st, P)) return -1;
+        if (launch_battery_sep(planes, H, W, radius, clip, jobs, st, P, nullptr, nullptr)) return -1;
     }
     return launch_response_sumsq(resp, (size_t)P * H * W, partial, sumsq_dev, st);
 }
