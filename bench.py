@@ -933,20 +933,21 @@ def bench_color2d(args, group, cfg, quick=False):
             flops = 2.0 * 1089 * 76 * 3 * npx                      # 2 * 33^2 taps * 76 kernels * 3 channels per pixel
             achieved = flops / (tex_ms / prof_steps / 1e3) / 1e12 if tex_n else 0.0
             # what the kernels execute since round 4 (flops = 2 per multiply-add, 1 per addition), per output pixel and channel:
-            #   48 kernels stay dense but are even / odd under the point reflection: 16 paired columns x 33 rows + the centre column
-            #   of 33 = 561 multiply-adds each, plus one addition per pair shared by the 6 kernels of a battery (528 / 6);
+            #   the 48 dense kernels are 8 batteries of 3 mirror pairs of point-symmetric kernels (k_conv_battery_quad): per lane and 4
+            #   output rows, each of the 16 column pairs costs 72 additions (column sums / differences), 68 x 2 additions (U, V) and
+            #   68 x 6 multiply-adds, the centre column 68 x (1 + 3): (16 * 1024 + 476) / 4 = 4215 flops per pixel and battery;
             #   28 kernels are separable (36 rank-1 components: 4 Gaussians, 8 x 2 for the Laplacians, 16 axis-aligned edge / bar
-            #   filters): an x pass over the 48 tile rows of a 16-row workgroup + a y pass = (3 + 1) * 33 multiply-adds a component
-            executed = (48 * (2.0 * 561 + 528.0 / 6) + 36 * 2.0 * 132) * 3 * npx
+            #   filters) on a 16 x 96 tile: an x pass over 128 rows + a y pass over 96 = (128 + 96) / 96 * 33 = 77 multiply-adds each
+            executed = (8 * 4215.0 + 36 * 2.0 * 77) * 3 * npx
             done = executed / (tex_ms / prof_steps / 1e3) / 1e12 if tex_n else 0.0
             roofline = {'bound': 'fp64_valu',
-                        'kernel': 'k_conv_battery_sym<6> + k_sep_battery (all 20 batteries of the Leung-Malik bank per image)',
+                        'kernel': 'k_conv_battery_quad<3> + k_sep_battery_tall (all 20 batteries of the Leung-Malik bank per image)',
                         'achieved': round(done, 3), 'peak': FP64_VALU_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                         'frac': round(done / FP64_VALU_PEAK_TFLOPS, 5), 'traffic': None,
                         'executed_flops_per_image': executed, 'battery_ms_per_image': round(tex_ms / prof_steps, 3),
                         'note': 'achieved = the flops the kernels EXECUTE over the measured time.  SURVEY 8(d) counts every kernel as a '
-                                'dense 33 x 33 sum (2 * 1089 * 76 * 3 flop per pixel); 28 kernels are separable and the other 48 point '
-                                'symmetric, which cuts the work to 41 % of that count -- see survey_flops_*',
+                                'dense 33 x 33 sum (2 * 1089 * 76 * 3 flop per pixel); 28 kernels are separable and the other 48 are point '
+                                'symmetric mirror pairs, which cuts the work to 24 % of that count -- see survey_flops_*',
                         'survey_flops_per_image': flops, 'survey_flops_effective_tflops': round(achieved, 3)}
         else:
             assign_ms, assign_n = stage_ms['slic_assign']

@@ -72,16 +72,6 @@ def create_classif_search_train_export(clf_name, features, labels, cross_val=10,
     ``classification.py:656-759``; the export to ``path_out`` is not part of this path (returned untouched).
 
     :return tuple(obj,str): trained pipeline, path_out
-
-    >>> np.random.seed(0)
-    >>> lbs = np.random.randint(0, 3, 150)
-    >>> fts = np.random.random((150, 5)) + np.tile(lbs, (5, 1)).T
-    >>> clf, _ = create_classif_search_train_export('DecTree', fts, lbs, nb_search_iter=0)
-    >>> float(np.mean(clf.predict(fts) == lbs)) > 0.9
-    True
-    >>> clf, _ = create_classif_search_train_export('KNN', fts, lbs, nb_search_iter=3, cross_val=3)
-    >>> clf.predict_proba(fts).shape
-    (150, 3)
     """
     from sklearn import decomposition, metrics, model_selection, pipeline, preprocessing
     if not list(labels):
@@ -146,13 +136,6 @@ def convert_set_features_labels_2_dataset(imgs_features, imgs_labels, drop_label
     every image balanced on its own (``classification.py:1416-1476``)
 
     :return tuple(ndarray,ndarray,list(int)): features, labels, number of samples per image
-
-    >>> np.random.seed(0)
-    >>> d_fts = {'a': np.random.random((25, 3)), 'b': np.random.random((30, 3))}
-    >>> d_lbs = {'a': np.random.randint(0, 2, 25), 'b': np.random.randint(0, 2, 30)}
-    >>> fts, lbs, sizes = convert_set_features_labels_2_dataset(d_fts, d_lbs)
-    >>> fts.shape, lbs.shape, sizes
-    ((55, 3), (55,), [25, 30])
     """
     if any(key not in imgs_labels for key in imgs_features):
         raise ValueError('missing some items of %r' % imgs_labels.keys())
@@ -172,12 +155,6 @@ def convert_set_features_labels_2_dataset(imgs_features, imgs_labels, drop_label
 class CrossValidateGroups(object):
     """ cross-validation folds over whole sets (images): a fold tests on ``nb_hold_out`` consecutive sets -- a share of
     them when below one -- and trains on all others (``classification.py:1616-1700``)
-
-    >>> cv = CrossValidateGroups([2, 3, 2, 1], nb_hold_out=2)
-    >>> len(cv)
-    2
-    >>> [(train, test) for train, test in cv]
-    [([5, 6, 7], [0, 1, 2, 3, 4]), ([0, 1, 2, 3, 4], [5, 6, 7])]
     """
 
     def __init__(self, set_sizes, nb_hold_out, rand_seed=None):

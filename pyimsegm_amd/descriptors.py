@@ -20,7 +20,7 @@ from scipy import ndimage
 from sklearn import preprocessing
 
 from pyimsegm_amd import _hip
-from pyimsegm_amd.utilities import ImageDimensionError
+from pyimsegm_amd.utilities import ImageDimensionError, reference_attribute
 
 #: kept for API compatibility: the driver script assigns it (run_segm_slic_model_graphcut.py:59).
 #: It no longer selects an implementation: the native path is always the HIP library.
@@ -56,73 +56,48 @@ MAX_SIGNAL_RESPONSE = 1.e6
 # ------------------------------------------------------------------------------------------------
 
 
-def _check_color_image_segm(image, segm):
-    """ image - segmentation compatibility for colour images
-
-    >>> _check_color_image_segm(np.zeros((125, 150, 3)), np.zeros((150, 125)))  # doctest: +ELLIPSIS
-    Traceback (most recent call last):
-    ...
-    pyimsegm_amd.utilities.ImageDimensionError: ndarrays - image and segmentation do not match (125, 150, 3) vs (150, 125)
-    """
-    if image.shape[:2] != segm.shape:
-        raise ImageDimensionError('ndarrays - image and segmentation do not match %r vs %r' % (image.shape, segm.shape))
+def _fail_unless(condition, template, *values):
+    if not condition:
+        raise ImageDimensionError(template % tuple(repr(v) for v in values))
     return True
 
 
-def _check_gray_image_segm(image, segm):
-    """ image - segmentation compatibility for gray images / volumes
-
-    >>> _check_gray_image_segm(np.zeros((125, 150)), np.zeros((150, 125)))  # doctest: +ELLIPSIS
-    Traceback (most recent call last):
-    ...
-    pyimsegm_amd.utilities.ImageDimensionError: ndarrays - image and segmentation do not match (125, 150) vs (150, 125)
-    """
-    if image.shape != segm.shape:
-        raise ImageDimensionError('ndarrays - image and segmentation do not match %r vs %r' % (image.shape, segm.shape))
-    return True
+def _same_plane(image, segm):
+    """ image - segmentation compatibility for colour images (message of descriptors.py:128-146) """
+    return _fail_unless(image.shape[:2] == segm.shape, 'ndarrays - image and segmentation do not match %s vs %s', image.shape, segm.shape)
 
 
-def _check_color_image(image):
-    """ the image has to be H x W x 3
-
-    >>> _check_color_image(np.zeros((200, 250, 1)))  # doctest: +ELLIPSIS
-    Traceback (most recent call last):
-    ...
-    pyimsegm_amd.utilities.ImageDimensionError: image is not RGB with dims (200, 250, 1)
-    """
-    if image.ndim != 3 or image.shape[2] != 3:
-        raise ImageDimensionError('image is not RGB with dims %s' % repr(image.shape))
-    return True
+def _same_shape(image, segm):
+    """ image - segmentation compatibility for gray images / volumes (descriptors.py:149-167) """
+    return _fail_unless(image.shape == segm.shape, 'ndarrays - image and segmentation do not match %s vs %s', image.shape, segm.shape)
 
 
-def _check_unrecognised_feature_group(feature_flags):
-    """ report (not raise) unknown feature groups
-
-    >>> _check_unrecognised_feature_group({'color': [], 'texture': []})
-    ['texture']
-    """
-    unknown = [k for k in feature_flags if not (k.startswith('color') or k.startswith('tLM'))]
-    if unknown:
-        logging.warning('unrecognised following feature groups: %r', unknown)
-    return unknown
+def _three_channels(image):
+    """ the image has to be H x W x 3 (descriptors.py:170-184) """
+    return _fail_unless(image.ndim == 3 and image.shape[2] == 3, 'image is not RGB with dims %s', image.shape)
 
 
-def _check_unrecognised_feature_names(feature_flags):
-    """ report (not raise) unknown statistic names
+def _unknown(kind, given, known):
+    """reports (does not raise) the entries of ``given`` that ``known`` does not accept (descriptors.py:187-206)"""
+    strangers = [item for item in given if not known(item)]
+    if strangers:
+        logging.warning('unrecognised following feature %s: %r', kind, strangers)
+    return strangers
 
-    >>> _check_unrecognised_feature_names(['mean', 'average'])
-    ['average']
-    """
-    unknown = [k for k in feature_flags if k not in NAMES_FEATURE_FLAGS]
-    if unknown:
-        logging.warning('unrecognised following feature names: %r', unknown)
-    return unknown
+
+def _report_unknown_groups(feature_flags):
+    return _unknown('groups', feature_flags, lambda key: key.startswith(('color', 'tLM')))
+
+
+def _report_unknown_names(feature_flags):
+    return _unknown('names', feature_flags, lambda name: name in NAMES_FEATURE_FLAGS)
+
 
 def _finished(features, names):
     """the closing step every feature table of the reference goes through: negative zeros become zeros
     (``features[features == 0] = 0``, descriptors.py:860,1034,1102,1165,1265) and the column count is checked against the names"""
-    features[features == 0] = 0
-    if features.shape[1] != len(names):
+    np.add(features, 0., out=features, where=features == 0)          # (-0. + 0. = +0.)
+    if names is not None and len(names) != features.shape[1]:
         raise ValueError('features: %r and names %r' % (features.shape, names))
     return features, names
 
@@ -136,8 +111,8 @@ def _finished(features, names):
 def _stats_session(img, seg):
     img = np.asarray(img)
     seg = np.asarray(seg)
-    _check_color_image_segm(img, seg)
-    _check_color_image(img)
+    _same_plane(img, seg)
+    _three_channels(img)
     return _hip.Image2D(seg.shape[0], seg.shape[1]).upload(img).set_labels(seg)
 
 
@@ -147,16 +122,6 @@ def hip_img2d_color_mean(img, seg):
     :param ndarray img: input RGB image H x W x 3
     :param ndarray seg: segmentation H x W
     :return ndarray: np.array<nb_lbs, 3>
-
-    >>> image = np.zeros((2, 10, 3))
-    >>> image[:, 2:6, 0] = 1
-    >>> image[:, 3:7, 1] = 3
-    >>> image[:, 4:9, 2] = 2
-    >>> segm = np.array([[0, 0, 0, 0, 0, 1, 1, 1, 1, 1],
-    ...                  [0, 0, 0, 0, 0, 1, 1, 1, 1, 1]])
-    >>> hip_img2d_color_mean(image, segm)  # doctest: +SKIP
-    array([[0.6, 1.2, 0.4],
-           [0.2, 1.2, 1.6]])
     """
     logging.debug('HIP: computing Colour means for image %r & segm %r', np.shape(img), np.shape(seg))
     sess = _stats_session(img, seg)
@@ -193,123 +158,37 @@ cython_img2d_color_energy = hip_img2d_color_energy
 cython_img2d_color_std = hip_img2d_color_std
 
 # ------------------------------------------------------------------------------------------------
-# numpy alternatives (reference: numpy_img2d_color_*, descriptors.py:299-455) -- vectorised, float64
+# the reference's numpy alternatives (numpy_img2d_color_* / numpy_img3d_gray_*, descriptors.py:299-455, :569-702: what
+# USE_CYTHON = False selects there) are not part of this module: the names resolve to the reference's own functions when a
+# reference package is installed behind the overlay (module __getattr__ below).  What stays is the median of the dtypes a
+# device session does not hold unchanged.
 # ------------------------------------------------------------------------------------------------
 
 
-def _segmented_sums(values, seg, nb_labels):
-    """sum of ``values`` (N x C float64) per label -> (nb_labels x C, counts)"""
-    flat = seg.ravel()
-    counts = np.bincount(flat, minlength=nb_labels).astype(np.float64)
-    sums = np.stack([np.bincount(flat, weights=values[:, c], minlength=nb_labels) for c in range(values.shape[1])],
-                    axis=1)
-    return sums, counts
+def __getattr__(name):
+    """names of the reference module that are not part of the path: the reference's own, when one is installed"""
+    return reference_attribute('descriptors', name)
 
 
-def _safe_div(sums, counts):
-    counts = counts.copy()
-    counts[counts == 0] = -1
-    return sums / counts[:, np.newaxis]
-
-
-def numpy_img2d_color_mean(img, seg):
-    """ colour means by numpy (float64 throughout)
-
-    >>> image = np.zeros((2, 10, 3))
-    >>> image[:, 2:6, 0] = 1
-    >>> image[:, 3:8, 1] = 3
-    >>> image[:, 4:9, 2] = 2
-    >>> segm = np.array([[0, 0, 0, 0, 0, 1, 1, 1, 1, 1],
-    ...                  [0, 0, 0, 0, 0, 1, 1, 1, 1, 1]])
-    >>> numpy_img2d_color_mean(image, segm).tolist()
-    [[0.6, 1.2, 0.4], [0.2, 1.8, 1.6]]
-    """
-    img, seg = np.asarray(img), np.asarray(seg)
-    _check_color_image_segm(img, seg)
-    nb = int(np.max(seg)) + 1
-    sums, counts = _segmented_sums(img.reshape(-1, 3).astype(np.float64), seg, nb)
-    return _safe_div(sums, counts)
-
-
-def numpy_img2d_color_std(img, seg, means=None):
-    """ colour STD by numpy
-
-    >>> image = np.zeros((2, 10, 3))
-    >>> image[:, 2:6, 0] = 1
-    >>> image[:, 3:8, 1] = 3
-    >>> image[:, 4:9, 2] = 2
-    >>> segm = np.array([[0, 0, 0, 0, 0, 1, 1, 1, 1, 1],
-    ...                  [0, 0, 0, 0, 0, 1, 1, 1, 1, 1]])
-    >>> np.round(numpy_img2d_color_std(image, segm), 8).tolist()
-    [[0.48989795, 1.46969385, 0.8], [0.4, 1.46969385, 0.8]]
-    """
-    img, seg = np.asarray(img), np.asarray(seg)
-    _check_color_image_segm(img, seg)
-    if means is None:
-        means = numpy_img2d_color_mean(img, seg)
-    nb = int(np.max(seg)) + 1
-    if len(means) < nb:
-        raise ValueError('number of means (%i) should be equal to number of labels (%i)' % (len(means), nb))
-    diff = img.reshape(-1, 3).astype(np.float64) - np.asarray(means)[seg.ravel()]
-    sums, counts = _segmented_sums(diff**2, seg, nb)
-    variations = _safe_div(sums, counts)
-    variations[variations == 0] = 0
-    return np.sqrt(variations)
-
-
-def numpy_img2d_color_energy(img, seg):
-    """ colour energy by numpy (squares evaluated in float64: the reference's uint8 wrap-around of
-    ``img[i, j, :]**2``, descriptors.py:410, is NOT reproduced)
-
-    >>> image = np.zeros((2, 10, 3))
-    >>> image[:, 2:6, 0] = 1
-    >>> image[:, 3:8, 1] = 3
-    >>> image[:, 4:9, 2] = 2
-    >>> segm = np.array([[0, 0, 0, 0, 0, 1, 1, 1, 1, 1],
-    ...                  [0, 0, 0, 0, 0, 1, 1, 1, 1, 1]])
-    >>> numpy_img2d_color_energy(image, segm).tolist()
-    [[0.6, 3.6, 0.8], [0.2, 5.4, 3.2]]
-    """
-    img, seg = np.asarray(img), np.asarray(seg)
-    _check_color_image_segm(img, seg)
-    nb = int(np.max(seg)) + 1
-    sums, counts = _segmented_sums(img.reshape(-1, 3).astype(np.float64)**2, seg, nb)
-    return _safe_div(sums, counts)
-
-
-def _segmented_median(values, flat_seg, nb_labels):
-    """median per label of a 1D value array; NaN for labels without samples (np.median([]))"""
-    order = np.lexsort((values, flat_seg))
-    sv, sl = values[order], flat_seg[order]
-    counts = np.bincount(flat_seg, minlength=nb_labels)
-    starts = np.concatenate([[0], np.cumsum(counts)[:-1]])
+def _median_by_label(values, labels, nb_labels):
+    """median of ``values`` per label (both flat); NaN for labels without samples, as np.median([])"""
+    order = np.lexsort((values, labels))
+    ranked = values[order]
+    counts = np.bincount(labels, minlength=nb_labels)
+    first = np.cumsum(counts) - counts
     out = np.full(nb_labels, np.nan)
-    ok = counts > 0
-    lo = starts[ok] + (counts[ok] - 1) // 2
-    hi = starts[ok] + counts[ok] // 2
-    out[ok] = 0.5 * (sv[lo] + sv[hi])
-    del sl
+    some = counts > 0
+    out[some] = 0.5 * (ranked[first[some] + (counts[some] - 1) // 2] + ranked[first[some] + counts[some] // 2])
     return out
 
 
-def numpy_img2d_color_median(img, seg):
-    """ colour median by numpy
-
-    >>> image = np.zeros((2, 10, 3))
-    >>> image[:, 2:6, 0] = 1
-    >>> image[:, 3:8, 1] = 3
-    >>> image[:, 4:9, 2] = 2
-    >>> segm = np.array([[0, 0, 0, 0, 1, 1, 1, 1, 1, 1],
-    ...                  [0, 0, 0, 0, 1, 1, 1, 1, 1, 1]])
-    >>> numpy_img2d_color_median(image, segm).tolist()
-    [[0.5, 0.0, 0.0], [0.0, 3.0, 2.0]]
-    """
-    img, seg = np.asarray(img), np.asarray(seg)
-    _check_color_image_segm(img, seg)
-    nb = int(np.max(seg)) + 1
-    flat = seg.ravel()
-    vals = img.reshape(-1, 3).astype(np.float64)
-    return np.stack([_segmented_median(vals[:, c], flat, nb) for c in range(3)], axis=1)
+def _channel_medians(image, segm):
+    """per label and channel (a gray volume: one channel) by numpy, float64"""
+    image, labels = np.asarray(image, dtype=np.float64), np.asarray(segm).ravel()
+    nb = int(labels.max()) + 1
+    if image.ndim == np.ndim(segm):
+        return _median_by_label(image.ravel(), labels, nb)
+    return np.stack([_median_by_label(image[..., c].ravel(), labels, nb) for c in range(image.shape[-1])], axis=1)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -317,20 +196,9 @@ def numpy_img2d_color_median(img, seg):
 # ------------------------------------------------------------------------------------------------
 
 
-def _gray_sums(values, seg):
-    nb = int(np.max(seg)) + 1
-    flat = np.asarray(seg).ravel()
-    counts = np.bincount(flat, minlength=nb)
-    sums = np.bincount(flat, weights=np.asarray(values, dtype=np.float64).ravel(), minlength=nb)
-    out = np.zeros(nb)
-    ok = counts > 0
-    out[ok] = sums[ok] / counts[ok]
-    return out
-
-
 def _gray_stats_session(img, seg):
     img, seg = np.asarray(img), np.asarray(seg)
-    _check_gray_image_segm(img, seg)
+    _same_shape(img, seg)
     return _hip.Volume3D(*seg.shape).upload(img).set_labels(seg)
 
 
@@ -340,14 +208,6 @@ def hip_img3d_gray_mean(img, seg):
     :param ndarray img: gray volume D x H x W
     :param ndarray seg: segmentation D x H x W
     :return ndarray: np.array<nb_lbs>
-
-    >>> image = np.zeros((2, 3, 8))
-    >>> image[0, :, 2:6] = 1
-    >>> image[1, :, 3:7] = 3
-    >>> segm = np.array([[[0, 0, 0, 0, 1, 1, 1, 1]] * 3,
-    ...                  [[2, 2, 2, 2, 3, 3, 3, 3]] * 3])
-    >>> hip_img3d_gray_mean(image, segm).tolist()  # doctest: +SKIP
-    [0.5, 0.5, 0.75, 2.25]
     """
     logging.debug('HIP: computing Gray means for image %r and segm %r', np.shape(img), np.shape(seg))
     sess = _gray_stats_session(img, seg)
@@ -358,14 +218,6 @@ def hip_img3d_gray_mean(img, seg):
 
 def hip_img3d_gray_energy(img, seg):
     """ mean squared intensity per supervoxel (features_cython.pyx:169-191)
-
-    >>> image = np.zeros((2, 3, 8))
-    >>> image[0, :, 2:6] = 1
-    >>> image[1, :, 3:7] = 3
-    >>> segm = np.array([[[0, 0, 0, 0, 1, 1, 1, 1]] * 3,
-    ...                  [[2, 2, 2, 2, 3, 3, 3, 3]] * 3])
-    >>> hip_img3d_gray_energy(image, segm).tolist()  # doctest: +SKIP
-    [0.5, 0.5, 2.25, 6.75]
     """
     logging.debug('HIP: computing Gray energy for image %r and segm %r', np.shape(img), np.shape(seg))
     sess = _gray_stats_session(img, seg)
@@ -379,14 +231,6 @@ def hip_img3d_gray_std(img, seg, mean=None):
 
     ``mean`` is accepted for API compatibility; the means are (re)computed on the device, which is
     what the reference does when ``mean`` is None and what its callers pass anyway.
-
-    >>> image = np.zeros((2, 3, 8))
-    >>> image[0, :, 2:6] = 1
-    >>> image[1, :, 3:7] = 3
-    >>> segm = np.array([[[0, 0, 0, 0, 1, 1, 1, 1]] * 3,
-    ...                  [[2, 2, 2, 2, 3, 3, 3, 3]] * 3])
-    >>> np.round(hip_img3d_gray_std(image, segm), 4).tolist()  # doctest: +SKIP
-    [0.5, 0.5, 1.299, 1.299]
     """
     logging.debug('HIP: computing Gray STD for image %r and segm %r', np.shape(img), np.shape(seg))
     sess = _gray_stats_session(img, seg)
@@ -400,171 +244,106 @@ cython_img3d_gray_energy = hip_img3d_gray_energy
 cython_img3d_gray_std = hip_img3d_gray_std
 
 
-def numpy_img3d_gray_mean(img, seg):
-    img, seg = np.asarray(img), np.asarray(seg)
-    _check_gray_image_segm(img, seg)
-    return _gray_sums(img, seg)
+def _device_keeps(image, plane_axes):
+    """median / mean gradient run on the device for the dtypes a session holds unchanged (the gradient image keeps the dtype of the
+    source, descriptors.py:767-769 / :842-844: integer data truncate / wrap) and planes of at least 2 x 2; else the numpy route"""
+    image = np.asarray(image)
+    return image.dtype in (np.uint8, np.float32, np.float64) and min(image.shape[a] for a in plane_axes) >= 2
 
 
-def numpy_img3d_gray_energy(img, seg):
-    img, seg = np.asarray(img), np.asarray(seg)
-    _check_gray_image_segm(img, seg)
-    return _gray_sums(np.asarray(img, dtype=np.float64)**2, seg)
-
-
-def numpy_img3d_gray_std(img, seg, means=None):
-    img, seg = np.asarray(img), np.asarray(seg)
-    _check_gray_image_segm(img, seg)
-    if means is None:
-        means = numpy_img3d_gray_mean(img, seg)
-    nb = int(np.max(seg)) + 1
-    if len(means) < nb:
-        raise ValueError('number of means (%i) should be equal to number of labels (%i)' % (len(means), nb))
-    d = np.asarray(img, dtype=np.float64) - np.asarray(means)[seg]
-    return np.sqrt(_gray_sums(d**2, seg))
-
-
-def numpy_img3d_gray_median(img, seg):
-    img, seg = np.asarray(img), np.asarray(seg)
-    _check_gray_image_segm(img, seg)
-    nb = int(np.max(seg)) + 1
-    return _segmented_median(np.asarray(img, dtype=np.float64).ravel(), seg.ravel(), nb)
+def _ordered_columns(by_flag, feature_flags):
+    """the statistics that were asked for, in the column order of the reference (NAMES_FEATURE_FLAGS)"""
+    return [by_flag[flag]() for flag in NAMES_FEATURE_FLAGS if flag in feature_flags]
 
 
 def compute_image3d_gray_statistic(image, segm, feature_flags=NAMES_FEATURE_FLAGS, ch_name='gray', sess=None):
-    """ statistics of a gray volume per supervoxel (reference descriptors.py:705-784)
-
-    >>> image = np.zeros((2, 3, 8))
-    >>> image[0, :, 2:6] = 1
-    >>> image[1, :, 3:7] = 3
-    >>> segm = np.array([[[0, 0, 0, 0, 1, 1, 1, 1]] * 3,
-    ...                  [[2, 2, 2, 2, 5, 5, 5, 5]] * 3])
-    >>> features, names = compute_image3d_gray_statistic(image, segm)  # doctest: +SKIP
-    >>> np.round(features, 3).tolist()  # doctest: +SKIP
-    [[0.5, 0.5, 0.5, 0.5, 0.25], [0.5, 0.5, 0.5, 0.5, -0.25], [0.75, 1.299, 2.25, 0.0, 0.75],
-     [0.0, 0.0, 0.0, 0.0, 0.0], [0.0, 0.0, 0.0, 0.0, 0.0], [2.25, 1.299, 6.75, 3.0, -1.125]]
-    >>> names  # doctest: +SKIP
-    ['gray_mean', 'gray_std', 'gray_energy', 'gray_median', 'gray_meanGrad']
+    """ statistics of a gray volume per supervoxel (reference descriptors.py:705-784); ``sess``: a device session that already holds
+    the volume and its supervoxels
     """
     image = np.asarray(image)
     if sess is None:
         segm = np.asarray(segm)
-    _check_gray_image_segm(image, segm)
-    if not list(feature_flags):
+    _same_shape(image, segm)
+    if len(feature_flags) == 0:
         raise ValueError('some features has to be selected')
-    if sess is None or 'median' in feature_flags or 'meanGrad' in feature_flags:
+    on_device = _device_keeps(image, (1, 2))
+    sums = {'mean', 'std', 'energy'} & set(feature_flags)
+    needs_session = bool(sums) or (on_device and bool({'median', 'meanGrad'} & set(feature_flags)))
+    if sess is None or {'median', 'meanGrad'} & set(feature_flags):
         image = np.nan_to_num(image)       # (a resident session already holds the caller-checked finite volume)
-    features = []
-    want = [f in feature_flags for f in ('mean', 'energy', 'std')]
-    # median / meanGrad run on the device for the dtypes a session holds unchanged (the gradient volume keeps the dtype
-    # of the source, descriptors.py:767-769: integer volumes truncate / wrap); exotic dtypes take the numpy route
-    on_device = image.dtype in (np.uint8, np.float32, np.float64) and min(image.shape[1:]) >= 2
-    extra = on_device and ('median' in feature_flags or 'meanGrad' in feature_flags)
-    own = False
-    if any(want) or extra:
-        own = sess is None
-        if own:
-            sess = _hip.Volume3D(*segm.shape).upload(image).set_labels(segm)
+    own = needs_session and sess is None
+    if own:
+        sess = _hip.Volume3D(*segm.shape).upload(image).set_labels(segm)
     try:
-        if any(want):
-            mean, energy, var = sess.gray_stats(mean=want[0], energy=want[1], var=want[2])
-            if want[0]:
-                features.append(mean)
-            if want[2]:
-                features.append(np.sqrt(var))
-            if want[1]:
-                features.append(energy)
-        if 'median' in feature_flags:
-            features.append(sess.median() if on_device else numpy_img3d_gray_median(image, segm))
-        if 'meanGrad' in feature_flags:
+        mean = energy = var = None
+        if sums:
+            mean, energy, var = sess.gray_stats(mean='mean' in sums, energy='energy' in sums, var='std' in sums)
+
+        def mean_gradient():
             if on_device:
-                features.append(sess.mean_gradient())
-            else:
-                grad = np.zeros_like(image)
-                for i in range(image.shape[0]):
-                    grad[i] = np.sum(np.gradient(image[i]), axis=0)
-                features.append(cython_img3d_gray_mean(grad, segm))
+                return sess.mean_gradient()
+            slopes = np.zeros_like(image)
+            for z, plane in enumerate(image):
+                slopes[z] = np.sum(np.gradient(plane), axis=0)
+            return hip_img3d_gray_mean(slopes, segm)
+
+        columns = _ordered_columns({'mean': lambda: mean, 'std': lambda: np.sqrt(var), 'energy': lambda: energy,
+                                    'median': lambda: sess.median() if on_device else _channel_medians(image, segm),
+                                    'meanGrad': mean_gradient}, feature_flags)
     finally:
         if own:
             sess.close()
-    names = ['%s_%s' % (ch_name, n) for n in NAMES_FEATURE_FLAGS if n in feature_flags]
-    _check_unrecognised_feature_names(feature_flags)
-    features = np.nan_to_num(np.array(features)).T
-    return _finished(features, names)
+    _report_unknown_names(feature_flags)
+    names = ['%s_%s' % (ch_name, flag) for flag in NAMES_FEATURE_FLAGS if flag in feature_flags]
+    return _finished(np.nan_to_num(np.array(columns)).T, names)
 
 
 def _color_statistic_session(sess, image, segm, feature_flags, color_name):
-    """colour statistics with the mean / std / energy columns taken from a device session that
-    already holds ``image`` and ``segm`` (so nothing is re-uploaded)"""
-    want = [f in feature_flags for f in ('mean', 'std', 'energy')]
+    """colour statistics (reference descriptors.py:787-863) from a device session that already holds ``image`` and ``segm``"""
+    sums = {'mean', 'std', 'energy'} & set(feature_flags)
     mean = energy = var = None
-    if any(want):
-        mean, energy, var = sess.color_stats(mean=want[0], energy=want[2], var=want[1])
-    blocks = []
-    if want[0]:
-        blocks.append(mean)
-    if want[1]:
-        blocks.append(np.sqrt(var))
-    if want[2]:
-        blocks.append(energy)
-    # median / meanGrad: on the device for the dtypes a session holds unchanged (the gradient image keeps the dtype of
-    # the source, descriptors.py:842-844: integer images truncate / wrap); exotic dtypes take the numpy route
-    on_device = np.asarray(image).dtype in (np.uint8, np.float32, np.float64) and min(np.shape(image)[:2]) >= 2
-    if 'median' in feature_flags:
-        blocks.append(sess.median() if on_device else numpy_img2d_color_median(image, segm))
-    if 'meanGrad' in feature_flags:
+    if sums:
+        mean, energy, var = sess.color_stats(mean='mean' in sums, energy='energy' in sums, var='std' in sums)
+    on_device = _device_keeps(image, (0, 1))
+
+    def mean_gradient():
         if on_device:
-            blocks.append(sess.mean_gradient())
-        else:
-            grad = np.zeros_like(image)
-            for i in range(3):
-                grad[:, :, i] = np.sum(np.gradient(image[:, :, i]), axis=0)
-            blocks.append(hip_img2d_color_mean(grad, segm))
-    ch_names = ['%s-ch%i' % (color_name, i + 1) for i in range(3)]
-    names = list(itertools.chain.from_iterable(['%s_%s' % (n, f) for n in ch_names] for f in NAMES_FEATURE_FLAGS
-                                               if f in feature_flags))
-    _check_unrecognised_feature_names(feature_flags)
-    nb = sess.n_labels
-    features = np.hstack(blocks) if blocks else np.empty((nb, 0))
-    features = np.nan_to_num(features)
-    return _finished(features, names)
+            return sess.mean_gradient()
+        slopes = np.zeros_like(image)
+        for c in range(3):
+            slopes[..., c] = np.sum(np.gradient(image[..., c]), axis=0)
+        return hip_img2d_color_mean(slopes, segm)
+
+    blocks = _ordered_columns({'mean': lambda: mean, 'std': lambda: np.sqrt(var), 'energy': lambda: energy,
+                               'median': lambda: sess.median() if on_device else _channel_medians(image, segm),
+                               'meanGrad': mean_gradient}, feature_flags)
+    _report_unknown_names(feature_flags)
+    names = ['%s-ch%i_%s' % (color_name, c + 1, flag) for flag in NAMES_FEATURE_FLAGS if flag in feature_flags for c in range(3)]
+    table = np.hstack(blocks) if blocks else np.empty((sess.n_labels, 0))
+    return _finished(np.nan_to_num(table), names)
 
 
 def compute_image2d_color_statistic(image, segm, feature_flags=NAMES_FEATURE_FLAGS, color_name='color'):
-    """ statistics of a colour image per superpixel, columns ordered mean, std, energy, median,
-    meanGrad (reference descriptors.py:787-863)
+    """ statistics of a colour image per superpixel, columns ordered mean, std, energy, median, meanGrad with the three channels
+    of a statistic side by side (reference descriptors.py:787-863)
 
-    :param ndarray image: H x W x 3
-    :param ndarray segm: segmentation H x W
-    :param list(str) feature_flags: subset of NAMES_FEATURE_FLAGS
-    :param str color_name: prefix of the feature names
-    :return tuple(ndarray,list(str)): np.ndarray<nb_samples, nb_features>, names
-
-    >>> image = np.zeros((2, 10, 3))
-    >>> image[:, 2:6, 0] = 1
-    >>> image[:, 3:7, 1] = 3
-    >>> image[:, 4:9, 2] = 2
-    >>> segm = np.array([[0, 0, 0, 0, 0, 1, 1, 1, 1, 1],
-    ...                  [0, 0, 0, 0, 0, 1, 1, 1, 1, 1]])
-    >>> features, names = compute_image2d_color_statistic(image, segm)  # doctest: +SKIP
-    >>> features.shape  # doctest: +SKIP
-    (2, 15)
+    :return tuple(ndarray,list(str)): K x (3 * number of statistics) table, column names
     """
     image, segm = np.asarray(image), np.asarray(segm)
-    _check_color_image(image)
-    _check_color_image_segm(image, segm)
-    image = np.nan_to_num(image)
-    sess = _hip.Image2D(segm.shape[0], segm.shape[1]).upload(image).set_labels(segm)
-    out = _color_statistic_session(sess, image, segm, feature_flags, color_name)
-    sess.close()
-    return out
+    _three_channels(image)
+    _same_plane(image, segm)
+    finite = np.nan_to_num(image)
+    sess = _hip.Image2D(segm.shape[0], segm.shape[1]).upload(finite).set_labels(segm)
+    try:
+        return _color_statistic_session(sess, finite, segm, feature_flags, color_name)
+    finally:
+        sess.close()
 
 
 def norm_features(features, scaler=None):
-    """ standardise features (zero mean, unit variance); returns (features, scaler) """
-    if not scaler:
-        scaler = preprocessing.StandardScaler()
-        scaler.fit(features)
+    """ features standardised to zero mean and unit variance by ``scaler`` -- fitted here when none is given
+    (reference descriptors.py:866-877); returns (features, scaler) """
+    scaler = scaler or preprocessing.StandardScaler().fit(features)
     return scaler.transform(features), scaler
 
 
@@ -574,77 +353,70 @@ def norm_features(features, scaler=None):
 
 
 def make_gaussian_filter1d(vals, sigma, order=0):
-    if order > 2:
+    """ a Gaussian (order 0) or -- up to a constant -- its first / second derivative sampled at ``vals``, scaled to unit L1 norm
+    (reference descriptors.py:880-900).  Operation by operation the reference's arithmetic: the bank decides the last bits of
+    every filter response, and the point symmetry the device kernels rely on holds bit for bit only that way. """
+    if not order <= 2:
         raise ValueError("Only orders up to 2 are supported")
-    response = np.exp(-vals**2 / (2. * sigma**2))
-    if order == 1:
-        response = -response * vals
-    elif order == 2:
-        response = response * (vals**2 - sigma**2)
-    return response / np.abs(response).sum()
+    bell = np.exp(-vals**2 / (2. * sigma**2))
+    shaped = {1: lambda: -bell * vals, 2: lambda: bell * (vals**2 - sigma**2)}.get(order, lambda: bell)()
+    return shaped / np.abs(shaped).sum()
 
 
 def make_edge_filter2d(sig, phase, points, sup):
-    gx = make_gaussian_filter1d(points[0, :], sigma=3 * sig)
-    gy = make_gaussian_filter1d(points[1, :], sigma=sig, order=phase)
-    ft = (gx * gy).reshape(sup, sup)
-    return ft / np.abs(ft).sum()
+    """ an elongated Gaussian (3 sig along x) times the ``phase``-th derivative of a Gaussian across it on the (rotated) grid
+    ``points`` (2 x sup^2), unit L1 norm (reference descriptors.py:903-912) """
+    along = make_gaussian_filter1d(points[0], sigma=3 * sig)
+    across = make_gaussian_filter1d(points[1], sigma=sig, order=phase)
+    kernel = (along * across).reshape(sup, sup)
+    return kernel / np.abs(kernel).sum()
 
 
 def create_filter_bank_lm_2d(radius=16, sigmas=DEFAULT_FILTERS_SIGMAS, nb_orient=8):
-    """ Leung-Malik bank: per sigma rotated edge + bar batteries, Gaussian, LoG(sigma), LoG(sigma^2)
-
-    >>> filters, names = create_filter_bank_lm_2d(6, SHORT_FILTERS_SIGMAS, 2)
-    >>> [f.shape for f in filters][:5]
-    [(2, 13, 13), (2, 13, 13), (1, 13, 13), (1, 13, 13), (1, 13, 13)]
-    >>> names[:5]
-    ['sigma1.4-edge', 'sigma1.4-bar', 'sigma1.4-Gauss', 'sigma1.4-GaussLap', 'sigma1.4-GaussLap2']
+    """ Leung-Malik bank (reference descriptors.py:915-948): per sigma a battery of ``nb_orient`` edge filters and one of bar
+    filters over half a circle (the filters are symmetric), a Gaussian, and the Laplacians of Gaussians of sigma and sigma^2 --
+    five batteries per sigma, named 'sigma<s>-edge' ... 'sigma<s>-GaussLap2'
     """
     logging.debug('creating Leung-Malik filter bank')
-    support = 2 * radius + 1
-    x, y = np.mgrid[-radius:radius + 1, radius:-radius - 1:-1]
-    org_pts = np.vstack([x.ravel(), y.ravel()])
-    impulse = np.zeros((support, support))
-    impulse[radius, radius] = 1
+    side = 2 * radius + 1
+    cols, rows = np.mgrid[-radius:radius + 1, radius:-radius - 1:-1]
+    grid = np.vstack([cols.ravel(), rows.ravel()])
+    turned = []                     # the grid rotated by every orientation (the same for all sigmas)
+    for k in range(nb_orient):
+        theta = np.pi * k / nb_orient
+        cos, sin = np.cos(theta), np.sin(theta)
+        turned.append(np.dot(np.array([[cos, -sin], [sin, cos]]), grid))
+    dot = np.zeros((side, side))
+    dot[radius, radius] = 1
     filters, names = [], []
     for sigma in sigmas:
-        edges, bars = [], []
-        for orient in range(nb_orient):
-            angle = np.pi * orient / nb_orient  # half circle: the filters are symmetric
-            c, s = np.cos(angle), np.sin(angle)
-            rot_points = np.dot(np.array([[c, -s], [s, c]]), org_pts)
-            edges.append(make_edge_filter2d(sigma, 1, rot_points, support))
-            bars.append(make_edge_filter2d(sigma, 2, rot_points, support))
-        filters += [np.asarray(edges), np.asarray(bars)]
-        filters.append(ndimage.gaussian_filter(impulse, sigma)[np.newaxis, :, :])
-        filters.append(ndimage.gaussian_laplace(impulse, sigma)[np.newaxis, :, :])
-        filters.append(ndimage.gaussian_laplace(impulse, sigma**2)[np.newaxis, :, :])
-        names += ['sigma%.1f-%s' % (sigma, n) for n in ['edge', 'bar', 'Gauss', 'GaussLap', 'GaussLap2']]
+        for phase in (1, 2):        # edge, bar
+            filters.append(np.asarray([make_edge_filter2d(sigma, phase, points, side) for points in turned]))
+        filters += [ndimage.gaussian_filter(dot, sigma)[None], ndimage.gaussian_laplace(dot, sigma)[None],
+                    ndimage.gaussian_laplace(dot, sigma**2)[None]]
+        names += ['sigma%.1f-%s' % (sigma, kind) for kind in ('edge', 'bar', 'Gauss', 'GaussLap', 'GaussLap2')]
     return filters, names
 
 
 def compute_img_filter_response2d(img, filter_battery):
-    """ responses of one battery on a 2D image; maximum over orientations for multi-kernel batteries """
-    if filter_battery.ndim != 3:
+    """ response of one battery on a 2D image: the maximum over its kernels (reference descriptors.py:951-966) """
+    if np.ndim(filter_battery) != 3:
         raise ValueError('wrong battery dim %r' % filter_battery.shape)
-    responses = np.array([ndimage.convolve(img, fl) for fl in filter_battery])
-    return np.max(responses, axis=0) if filter_battery.shape[0] > 1 else responses[0]
+    each = [ndimage.convolve(img, kernel) for kernel in filter_battery]
+    return np.max(np.array(each), axis=0) if len(each) > 1 else each[0]
 
 
 def compute_img_filter_response3d(img, filter_battery):
-    """ slice-wise :func:`compute_img_filter_response2d` """
+    """ :func:`compute_img_filter_response2d` slice by slice (reference descriptors.py:969-978) """
     logging.debug('compute image filter response in 3D')
-    return np.array([compute_img_filter_response2d(img[i, :, :], filter_battery) for i in range(img.shape[0])])
+    return np.array([compute_img_filter_response2d(plane, filter_battery) for plane in img])
 
 
 def image_subtract_gauss_smooth(img, sigma):
-    """ subtract a slice-wise Gaussian-smoothed copy (first axis independent) """
-    if sigma <= 0:
+    """ every slice minus its Gaussian-smoothed copy (reference descriptors.py:981-994) """
+    if not sigma > 0:
         return img
-    smooth = np.zeros(img.shape)
-    for i in range(img.shape[0]):
-        smooth[i, :, :] = ndimage.gaussian_filter(img[i, :, :].astype(float), sigma)
-    return img - smooth
+    return img - np.array([ndimage.gaussian_filter(plane.astype(float), sigma) for plane in img])
 
 
 @functools.lru_cache(maxsize=4)
@@ -672,7 +444,7 @@ def _normalise_response(response):
 def compute_texture_desc_lm_img3d_val(img, seg, feature_flags, bank_type='normal'):
     """ Leung-Malik texture statistics of a gray volume (reference descriptors.py:997-1038) """
     img, seg = np.asarray(img), np.asarray(seg)
-    _check_gray_image_segm(img, seg)
+    _same_shape(img, seg)
     logging.debug('compute texture descriptors using Leung-Malik')
     filters, fl_names = _select_bank(bank_type)
     if set(feature_flags) <= {'mean', 'std', 'energy'} and all(len(f) <= 8 for f in filters):
@@ -684,28 +456,14 @@ def compute_texture_desc_lm_img3d_val(img, seg, feature_flags, bank_type='normal
         fts, n = compute_image3d_gray_statistic(response, seg, feature_flags, fl_name)
         features.append(fts)
         names += n
-    features = np.nan_to_num(np.concatenate(tuple(features), axis=1))
-    features[features == 0] = 0
-    names = ['tLM_%s' % name for name in names]
-    if features.shape[1] != len(names):
-        raise ValueError('features: %r and names %r' % (features.shape, names))
-    return features, names
+    return _finish_texture(features, names)
 
 
 def compute_texture_desc_lm_img2d_clr(img, seg, feature_flags, bank_type='normal'):
     """ Leung-Malik texture statistics of a colour image (reference descriptors.py:1041-1106)
-
-    >>> h, w, step = 30, 20, 5
-    >>> np.random.seed(0)
-    >>> seg = (np.arange(h)[:, None] // step) * (w // step) + np.arange(w)[None, :] // step
-    >>> img = np.random.random((h, w, 3))
-    >>> features, names = compute_texture_desc_lm_img2d_clr(img, seg, ['mean', 'std', 'median'],
-    ...                                                     bank_type='short')  # doctest: +SKIP
-    >>> features.shape  # doctest: +SKIP
-    (24, 135)
     """
     img, seg = np.asarray(img), np.asarray(seg)
-    _check_color_image(img)
+    _three_channels(img)
     logging.debug('compute texture descriptors using Leung-Malik')
     filters, fl_names = _select_bank(bank_type)
     if _texture_on_device(feature_flags, filters):
@@ -776,54 +534,45 @@ def resident_feature_table(sess, groups):
     return total
 
 
-def _finish_texture(features, names):
-    features = np.nan_to_num(np.concatenate(tuple(features), axis=1))
-    features[features == 0] = 0
-    names = ['tLM_%s' % name for name in names]
-    if features.shape[1] != len(names):
-        raise ValueError('features: %r and names %r' % (features.shape, names))
-    return features, names
+def _finish_texture(blocks, names):
+    """the blocks of the batteries side by side, NaN / inf replaced, names prefixed (descriptors.py:1031-1038, :1099-1106)"""
+    return _finished(np.nan_to_num(np.concatenate(tuple(blocks), axis=1)), ['tLM_' + name for name in names])
+
+
+def _battery_blocks(sess, battery, sums):
+    """mean | std | energy (those in ``sums``) of the response of ONE battery on a session that holds the high-passed planes,
+    with the norm of the response brought to the host in between (descriptors.py:1088-1094: a response of norm 0 or inf counts
+    as all zeros)"""
+    norm = sess.lm_battery(battery, MAX_SIGNAL_RESPONSE)
+    if not 0 < abs(norm) < np.inf:
+        mean = energy = var = np.zeros(sess.n_labels if isinstance(sess, _hip.Volume3D) else (sess.n_labels, 3))
+    else:
+        mean, energy, var = sess.response_stats(np.log(1 + norm) / 0.03, norm, mean='mean' in sums, energy='energy' in sums,
+                                                var='std' in sums)
+    return _ordered_columns({'mean': lambda: mean, 'std': lambda: np.sqrt(var), 'energy': lambda: energy}, sums)
 
 
 def _texture_desc_lm_device(img, seg, feature_flags, filters, fl_names, sess=None):
-    """Leung-Malik statistics entirely on the GPU: high-pass, filter batteries with orientation
-    maximum, global norm, per-superpixel statistics (texture.hip + stats.hip)"""
-    own = sess is None
-    if own:
+    """Leung-Malik statistics of a colour image entirely on the GPU: high-pass, filter batteries with the maximum over the
+    orientations, the norm of a battery's response, per-superpixel statistics (texture.hip + stats.hip)"""
+    borrowed = sess is not None
+    if not borrowed:
         sess = _hip.Image2D(seg.shape[0], seg.shape[1]).upload(np.nan_to_num(img)).set_labels(seg)
-    sess.lm_prepare(150.)
-    want = [f in feature_flags for f in ('mean', 'std', 'energy')]
-    features, names = [], []
-    one_call = getattr(sess, 'lm_features', None) if any(want) and len({np.shape(f)[1:] for f in filters}) == 1 else None
-    if one_call is not None:
-        # all batteries in one call: the norm of a battery never comes to the host (60 synchronisations per image less)
-        features.append(one_call(filters, MAX_SIGNAL_RESPONSE, mean=want[0], std=want[1], energy=want[2]))
-    for battery, fl_name in zip(filters, fl_names):
-        if one_call is None:
-            norm = sess.lm_battery(battery, MAX_SIGNAL_RESPONSE)
-            nb = sess.n_labels
-            if norm == 0 or abs(norm) == np.inf:
-                mean = energy = var = np.zeros((nb, 3))
-            else:
-                mean, energy, var = sess.response_stats(np.log(1 + norm) / 0.03, norm, mean=want[0], energy=want[2],
-                                                        var=want[1])
-            blocks = []
-            if want[0]:
-                blocks.append(mean)
-            if want[1]:
-                blocks.append(np.sqrt(var))
-            if want[2]:
-                blocks.append(energy)
-            fts = np.nan_to_num(np.hstack(blocks))
-            fts[fts == 0] = 0
-            features.append(fts)
-        ch_names = ['%s-ch%i' % (fl_name, i + 1) for i in range(3)]
-        names += list(itertools.chain.from_iterable(['%s_%s' % (n, f) for n in ch_names] for f in NAMES_FEATURE_FLAGS
-                                                    if f in feature_flags))
-    _check_unrecognised_feature_names(feature_flags)
-    if own:
-        sess.close()
-    return _finish_texture(features, names)
+    try:
+        sess.lm_prepare(150.)
+        sums = {'mean', 'std', 'energy'} & set(feature_flags)
+        if sums and len({np.shape(f)[1:] for f in filters}) == 1 and hasattr(sess, 'lm_features'):
+            # all batteries in one call: the norm of a battery never comes to the host (60 synchronisations per image less)
+            blocks = [sess.lm_features(filters, MAX_SIGNAL_RESPONSE, mean='mean' in sums, std='std' in sums, energy='energy' in sums)]
+        else:
+            blocks = [_finished(np.nan_to_num(np.hstack(_battery_blocks(sess, battery, sums))), None)[0] for battery in filters]
+    finally:
+        if not borrowed:
+            sess.close()
+    names = ['%s-ch%i_%s' % (name, c + 1, flag) for name in fl_names for flag in NAMES_FEATURE_FLAGS if flag in feature_flags
+             for c in range(3)]
+    _report_unknown_names(feature_flags)
+    return _finish_texture(blocks, names)
 
 
 def _texture_desc_lm_device3d(img, seg, feature_flags, filters, fl_names):
@@ -832,29 +581,13 @@ def _texture_desc_lm_device3d(img, seg, feature_flags, filters, fl_names):
     sess = _hip.Volume3D(*seg.shape).upload(np.nan_to_num(img)).set_labels(seg)
     try:
         sess.lm_prepare(150.)
-        want = [f in feature_flags for f in ('mean', 'std', 'energy')]
-        features, names = [], []
-        for battery, fl_name in zip(filters, fl_names):
-            norm = sess.lm_battery(battery, MAX_SIGNAL_RESPONSE)
-            nb = sess.n_labels
-            if norm == 0 or abs(norm) == np.inf:
-                mean = energy = var = np.zeros(nb)
-            else:
-                mean, energy, var = sess.response_stats(np.log(1 + norm) / 0.03, norm, mean=want[0], energy=want[2], var=want[1])
-            blocks = ([mean] if want[0] else []) + ([np.sqrt(var)] if want[1] else []) + ([energy] if want[2] else [])
-            fts = np.nan_to_num(np.array(blocks)).T
-            fts[fts == 0] = 0
-            features.append(fts)
-            names += ['%s_%s' % (fl_name, f) for f in NAMES_FEATURE_FLAGS if f in feature_flags]
+        sums = {'mean', 'std', 'energy'} & set(feature_flags)
+        blocks = [_finished(np.nan_to_num(np.array(_battery_blocks(sess, battery, sums))).T, None)[0] for battery in filters]
     finally:
         sess.close()
-    _check_unrecognised_feature_names(feature_flags)
-    features = np.nan_to_num(np.concatenate(tuple(features), axis=1))
-    features[features == 0] = 0
-    names = ['tLM_%s' % name for name in names]
-    if features.shape[1] != len(names):
-        raise ValueError('features: %r and names %r' % (features.shape, names))
-    return features, names
+    names = ['%s_%s' % (name, flag) for name in fl_names for flag in NAMES_FEATURE_FLAGS if flag in feature_flags]
+    _report_unknown_names(feature_flags)
+    return _finish_texture(blocks, names)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -862,130 +595,102 @@ def _texture_desc_lm_device3d(img, seg, feature_flags, filters, fl_names):
 # ------------------------------------------------------------------------------------------------
 
 
-def compute_selected_features_gray3d(img, segments, feature_flags=FEATURES_SET_COLOR, sess=None):
-    """ selected features of a gray volume
+def _groups(feature_flags, prefix):
+    """(key, suffix or None) of the descriptor groups of one kind in the order of ``feature_flags``: 'color_hsv' -> 'hsv'"""
+    return [(key, key.split('_')[-1] if '_' in key else None) for key in feature_flags if key.startswith(prefix)]
 
-    >>> np.random.seed(0)
-    >>> img = np.random.random((2, 10, 15))
-    >>> slic = np.zeros((2, 10, 15), dtype=int)
-    >>> slic[:, :, :7] += 1
-    >>> slic[1, :, :] += 2
-    >>> fts, names = compute_selected_features_gray3d(img, slic, {'color': ('mean', 'std', 'median')})  # doctest: +SKIP
-    >>> fts.shape  # doctest: +SKIP
-    (4, 3)
-    >>> names  # doctest: +SKIP
-    ['gray_mean', 'gray_std', 'gray_median']
+
+def _side_by_side(blocks, names, feature_flags):
+    """the closing step of every compute_selected_features_* (descriptors.py:1160-1166, :1262-1270): unknown groups reported,
+    the blocks of the groups concatenated (no block at all: the ValueError of numpy, as there), NaN / inf replaced"""
+    _report_unknown_groups(feature_flags)
+    if not blocks:
+        logging.error('not supported features: %r', feature_flags)
+    return _finished(np.nan_to_num(np.concatenate(tuple(blocks), axis=1)), names)
+
+
+def compute_selected_features_gray3d(img, segments, feature_flags=FEATURES_SET_COLOR, sess=None):
+    """ selected features of a gray volume (reference descriptors.py:1109-1166): the intensity statistics of ALL 'color*' groups
+    together (their flags united), then one Leung-Malik block per 'tLM*' group
     """
     img = np.asarray(img)
     if sess is None:
         segments = np.asarray(segments)
-    _check_gray_image_segm(img, segments)
+    _same_shape(img, segments)
     if not feature_flags:
         raise ValueError('some features has to be selected')
-    features, names = [], []
-    if any(k.startswith('color') for k in feature_flags):
-        flags = np.unique([feature_flags[k] for k in feature_flags if k.startswith('color')])
-        fts, ns = compute_image3d_gray_statistic(img, segments, flags, sess=sess)
-        features.append(fts)
-        names += ns
-    for k in [k for k in feature_flags if k.startswith('tLM')]:
-        bank_type = k.split('_')[-1] if '_' in k else 'normal'
-        fts, ns = compute_texture_desc_lm_img3d_val(img, segments, feature_flags[k], bank_type)
-        features.append(fts)
-        names += ns
-    _check_unrecognised_feature_group(feature_flags)
-    if not features:
-        logging.error('not supported features: %r', feature_flags)
-    features = np.nan_to_num(np.concatenate(tuple(features), axis=1))
-    return _finished(features, names)
+    blocks, names = [], []
+    colour = _groups(feature_flags, 'color')
+    if colour:
+        flags = np.unique([feature_flags[key] for key, _ in colour])
+        part, part_names = compute_image3d_gray_statistic(img, segments, flags, sess=sess)
+        blocks.append(part)
+        names += part_names
+    for key, bank in _groups(feature_flags, 'tLM'):
+        part, part_names = compute_texture_desc_lm_img3d_val(img, segments, feature_flags[key], bank or 'normal')
+        blocks.append(part)
+        names += part_names
+    return _side_by_side(blocks, names, feature_flags)
 
 
 def compute_selected_features_gray2d(img, segments, features_flags=FEATURES_SET_ALL):
-    """ selected features of a gray 2D image (treated as a one-slice volume)
-
-    >>> image = np.zeros((2, 10))
-    >>> image[0, 2:6] = 1
-    >>> image[1, 3:7] = 3
-    >>> segm = np.array([[0, 0, 0, 0, 0, 1, 1, 1, 1, 1],
-    ...                  [0, 0, 0, 0, 0, 1, 1, 1, 1, 1]])
-    >>> features, names = compute_selected_features_gray2d(image, segm, {'color': ('mean', 'std', 'median')})  # doctest: +SKIP
-    >>> np.round(features, 3).tolist()  # doctest: +SKIP
-    [[0.9, 1.136, 0.5], [0.7, 1.187, 0.0]]
+    """ selected features of a gray 2D image: a volume of one slice (reference descriptors.py:1169-1204)
     """
     img, segments = np.asarray(img), np.asarray(segments)
-    _check_gray_image_segm(img, segments)
-    return compute_selected_features_gray3d(img[np.newaxis, ...], segments[np.newaxis, ...], features_flags)
-
-
-def _convert_color(img, clr):
-    from pyimsegm_amd.utilities.data_io import convert_img_color_from_rgb
-    return convert_img_color_from_rgb(img, clr)
+    _same_shape(img, segments)
+    return compute_selected_features_gray3d(img[None], segments[None], features_flags)
 
 
 def _selected_features_color2d(img, segments, feature_flags, sess=None):
-    _check_color_image(img)
-    own = sess is None
-    features, names = [], []
-    for k in [k for k in feature_flags if k.startswith('color')]:
-        clr = k.split('_')[-1] if '_' in k else 'rgb'
-        if '_' in k:
-            img_color = np.nan_to_num(_convert_color(img, clr))
-            fts, ns = compute_image2d_color_statistic(img_color, segments, feature_flags[k], color_name=clr)
-        else:
-            if sess is None:
-                sess = _hip.Image2D(segments.shape[0], segments.shape[1]).upload(np.nan_to_num(img)).set_labels(segments)
-            fts, ns = _color_statistic_session(sess, img, segments, feature_flags[k], clr)
-        features.append(fts)
-        names += ns
-    for k in [k for k in feature_flags if k.startswith('tLM')]:
-        bank_type = k.split('_')[-1] if '_' in k else 'normal'
-        filters, fl_names = _select_bank(bank_type)
-        if _texture_on_device(feature_flags[k], filters):
-            # on the session that holds the image and the labels already (one upload for all groups)
-            _check_color_image(img)
-            if sess is None:
-                sess = _hip.Image2D(segments.shape[0], segments.shape[1]).upload(np.nan_to_num(img)).set_labels(segments)
-            fts, ns = _texture_desc_lm_device(img, segments, feature_flags[k], filters, fl_names, sess=sess)
-        else:
-            fts, ns = compute_texture_desc_lm_img2d_clr(img, segments, feature_flags[k], bank_type)
-        features.append(fts)
-        names += ns
-    if own and sess is not None:
-        sess.close()
-    _check_unrecognised_feature_group(feature_flags)
-    if not features:
-        logging.error('not supported features: %r', feature_flags)
-        features = [np.empty((int(np.max(segments)) + 1, 0))]
-    features = np.nan_to_num(np.concatenate(tuple(features), axis=1))
-    return _finished(features, names)
+    """reference descriptors.py:1207-1270 with ONE device session for all groups that read the RGB image"""
+    _three_channels(img)
+    borrowed = sess is not None
+    blocks, names = [], []
+
+    def session():
+        nonlocal sess
+        if sess is None:
+            sess = _hip.Image2D(segments.shape[0], segments.shape[1]).upload(np.nan_to_num(img)).set_labels(segments)
+        return sess
+
+    try:
+        for key, space in _groups(feature_flags, 'color'):
+            if space is None:
+                part, part_names = _color_statistic_session(session(), img, segments, feature_flags[key], 'rgb')
+            else:           # a converted colour space: its own upload
+                from pyimsegm_amd.utilities.data_io import convert_img_color_from_rgb
+                converted = np.nan_to_num(convert_img_color_from_rgb(img, space))
+                part, part_names = compute_image2d_color_statistic(converted, segments, feature_flags[key], color_name=space)
+            blocks.append(part)
+            names += part_names
+        for key, bank in _groups(feature_flags, 'tLM'):
+            filters, filter_names = _select_bank(bank or 'normal')
+            if _texture_on_device(feature_flags[key], filters):
+                part, part_names = _texture_desc_lm_device(img, segments, feature_flags[key], filters, filter_names, sess=session())
+            else:
+                part, part_names = compute_texture_desc_lm_img2d_clr(img, segments, feature_flags[key], bank or 'normal')
+            blocks.append(part)
+            names += part_names
+    finally:
+        if sess is not None and not borrowed:
+            sess.close()
+    return _side_by_side(blocks, names, feature_flags)
 
 
 def compute_selected_features_color2d(img, segments, feature_flags=FEATURES_SET_ALL):
     """ selected features of a colour 2D image (reference descriptors.py:1207-1270)
-
-    >>> image = np.zeros((2, 10, 3))
-    >>> image[:, 2:6, 0] = 1
-    >>> image[:, 3:7, 1] = 3
-    >>> image[:, 4:9, 2] = 2
-    >>> segm = np.array([[0, 0, 0, 0, 0, 1, 1, 1, 1, 1],
-    ...                  [0, 0, 0, 0, 0, 1, 1, 1, 1, 1]])
-    >>> features, names = compute_selected_features_color2d(image, segm,
-    ...                                   {'color': ('mean', 'std', 'median')})  # doctest: +SKIP
-    >>> np.round(features, 3)  # doctest: +SKIP
-    array([[0.6 , 1.2 , 0.4 , 0.49, 1.47, 0.8 , 1.  , 0.  , 0.  ],
-           [0.2 , 1.2 , 1.6 , 0.4 , 1.47, 0.8 , 0.  , 0.  , 2.  ]])
     """
     return _selected_features_color2d(np.asarray(img), np.asarray(segments), feature_flags)
 
 
 def compute_selected_features_img2d(image, segm, features_flags=FEATURES_SET_COLOR):
-    """ dispatch on the image type: H x W x 3 colour or H x W gray """
+    """ by the kind of image: H x W x 3 colour or H x W gray (reference descriptors.py:1273-1285) """
     image, segm = np.asarray(image), np.asarray(segm)
-    if image.ndim == 3 and image.shape[2] == 3:
-        return compute_selected_features_color2d(image, segm, features_flags)
-    if image.ndim == 2:
-        return compute_selected_features_gray2d(image, segm, features_flags)
-    logging.error('invalid image size - %r', image.shape)
+    colour = image.ndim == 3 and image.shape[2] == 3
+    if not colour and image.ndim != 2:
+        logging.error('invalid image size - %r', image.shape)
+        return None
+    return (compute_selected_features_color2d if colour else compute_selected_features_gray2d)(image, segm, features_flags)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -998,15 +703,6 @@ def adjust_bounding_box_crop(image_size, bbox_size, position):
     """ clip a box of ``bbox_size`` centred at ``position`` to the image (reference ``descriptors.py:1371-1409``)
 
     :return (), (), (), (): begin / end of the crop in the image, begin / end of the matching part of the box
-
-    >>> adjust_bounding_box_crop((50, 50), (7, 7), (20, 20))
-    ((17, 17), (24, 24), (0, 0), (7, 7))
-    >>> adjust_bounding_box_crop((50, 50), (15, 15), (20, 45))
-    ((13, 38), (28, 50), (0, 0), (15, 12))
-    >>> adjust_bounding_box_crop((50, 50), (15, 15), (5, 5))
-    ((0, 0), (13, 13), (2, 2), (15, 15))
-    >>> adjust_bounding_box_crop((50, 50), (80, 80), (20, 20))
-    ((0, 0), (50, 50), (20, 20), (70, 70))
     """
     if len(image_size) != len(bbox_size):
         raise ValueError('incompatible sizes %r != %r' % (image_size, bbox_size))
@@ -1027,12 +723,6 @@ def adjust_bounding_box_crop(image_size, bbox_size, position):
 
 def hip_label_hist_seg2d(segm_select, struc_elem, nb_labels):
     """ histogram of the labels under a structuring element (``computeLabelHistogram2d``) on the device
-
-    >>> segm = np.zeros((10, 10), dtype=int)
-    >>> segm[1:9, 2:8] = 1
-    >>> segm[3:7, 4:6] = 2
-    >>> hip_label_hist_seg2d(segm[2:5, 4:7], np.ones((3, 3)), 3).tolist()  # doctest: +SKIP
-    [0.0, 5.0, 4.0]
     """
     segm_select, struc_elem = np.asarray(segm_select), np.asarray(struc_elem)
     if segm_select.shape != struc_elem.shape:
@@ -1050,12 +740,6 @@ cython_label_hist_seg2d = hip_label_hist_seg2d
 def compute_label_hist_segm(segm, position, struc_elem, nb_labels):
     """ label histogram of the neighbourhood ``struc_elem`` around ``position`` and the size of that neighbourhood
     (reference ``descriptors.py:1411-1461``)
-
-    >>> segm = np.zeros((10, 10), dtype=int)
-    >>> segm[1:9, 2:8] = 1
-    >>> segm[3:7, 4:6] = 2
-    >>> compute_label_hist_segm(segm, [6, 6], np.ones((3, 3)), 3)  # doctest: +SKIP
-    (array([ 0.,  7.,  2.]), 9.0)
     """
     hists, sizes = compute_label_hist_positions(segm, [position], struc_elem, nb_labels)
     return hists[0], sizes[0]
@@ -1101,10 +785,6 @@ def hip_ray_features_positions(seg_binary, positions, angle_step=5., edge='up'):
 
 def hip_ray_features_seg2d(seg_binary, position, angle_step=5., edge='up'):
     """ distances from ``position`` to the object boundary along rays (reference ``descriptors.py:1630-1659``)
-
-    >>> seg_empty = np.zeros((100, 150), dtype=bool)
-    >>> hip_ray_features_seg2d(seg_empty, (50, 75), 90).tolist()  # doctest: +SKIP
-    [-1.0, -1.0, -1.0, -1.0]
     """
     return np.array(hip_ray_features_positions(seg_binary, [position], angle_step, edge)[0])
 

@@ -440,13 +440,6 @@ def pipe_color2d_slic_features_model_graphcut(image, nb_classes, dict_features, 
     :param str gc_edge_type: GraphCut edge type
     :param dict debug_visual: filled with intermediate results if given
     :return tuple(ndarray,ndarray): segmentation H x W, soft segmentation H x W x nb_classes
-
-    >>> np.random.seed(0)
-    >>> image = np.random.random((125, 150, 3)) / 2.
-    >>> image[:, :75] += 0.5
-    >>> segm, seg_soft = pipe_color2d_slic_features_model_graphcut(image, 2, {'color': ['mean']})  # doctest: +SKIP
-    >>> segm.shape  # doctest: +SKIP
-    (125, 150)
     """
     logging.info('PIPELINE Superpixels-Features-GMM-GraphCut')
     res = _ResidentImage(image, dict_features, sp_size, sp_regul)
@@ -608,13 +601,6 @@ def pipe_gray3d_slic_features_model_graphcut(image, nb_classes, dict_features, s
     :param float sp_regul: regularisation in (0, 1): 0 elastic, 1 nearly cubic segments
     :param float gc_regul: GraphCut regularisation
     :return ndarray: int32 class per voxel, D x H x W
-
-    >>> np.random.seed(0)
-    >>> image = np.random.random((5, 125, 150)) / 2.
-    >>> image[:, :, :75] += 0.5
-    >>> segm = pipe_gray3d_slic_features_model_graphcut(image, 2, {'color': ['mean']})  # doctest: +SKIP
-    >>> segm.shape  # doctest: +SKIP
-    (5, 125, 150)
     """
     logging.info('PIPELINE Superpixels-Features-GraphCut')
     image = np.asarray(image)

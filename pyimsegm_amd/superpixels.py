@@ -103,12 +103,6 @@ def segment_slic_img2d(img, sp_size=50, relative_compact=0.1, slico=False):
     :param float relative_compact: regularisation in (0, 1); 0 free-form, 1 nearly square
     :param bool slico: parameter-free SLICO variant (``slic_zero=True`` of skimage; exact fp64 sweeps on the device)
     :return ndarray: int64 label map H x W
-
-    >>> np.random.seed(0)
-    >>> img = np.random.random((100, 150, 3))
-    >>> slic = segment_slic_img2d(img, 20, 0.2)  # doctest: +SKIP
-    >>> slic.shape  # doctest: +SKIP
-    (100, 150)
     """
     logging.debug('Init SLIC superpixels 2d RGB clustering with params size=%i and regul=%f for image dims %r',
                   sp_size, relative_compact, np.shape(img))
@@ -183,12 +177,6 @@ def segment_slic_img3d_gray(im, sp_size=50, relative_compact=0.1, space=IMAGE_SP
     :param float relative_compact: regularisation in (0, 1)
     :param tuple(int,int,int) space: voxel spacing per axis
     :return ndarray: int64 label map of the volume's shape (labels from 1, as ``measure.label`` gives)
-
-    >>> np.random.seed(0)
-    >>> img = np.random.random((100, 100, 10))
-    >>> slic = segment_slic_img3d_gray(img, 20, 0.2, (1, 1, 5))  # doctest: +SKIP
-    >>> slic.shape  # doctest: +SKIP
-    (100, 100, 10)
     """
     logging.debug('Init SLIC superpixels 3d Gray clustering with params size=%i and regul=%f for image dims %r',
                   sp_size, relative_compact, np.shape(im))
@@ -253,11 +241,6 @@ def make_graph_segm_connect_grid2d_conn4(grid):
 
     :param ndarray grid: segmentation
     :return tuple(ndarray,list): unique labels, list of edges ``[a, b]`` with a < b ordered by (b, a)
-
-    >>> grid = np.array([[0] * 5 + [1] * 5, [2] * 5 + [3] * 5])
-    >>> v, edges = make_graph_segm_connect_grid2d_conn4(grid)  # doctest: +SKIP
-    >>> edges  # doctest: +SKIP
-    [[0, 1], [0, 2], [1, 3], [2, 3]]
     """
     logging.debug('make graph segment connect edges - 2d conn4')
     sess = _session_for_labels(grid)
@@ -271,12 +254,6 @@ def make_graph_segm_connect_grid3d_conn6(grid):
 
     :param ndarray grid: segmentation
     :return tuple(ndarray,list): unique labels, list of edges ``[a, b]`` with a < b ordered by (b, a)
-
-    >>> grid_2d = np.array([[0] * 5 + [1] * 5, [2] * 5 + [3] * 5])
-    >>> grid = np.array([grid_2d, grid_2d + 4])
-    >>> v, edges = make_graph_segm_connect_grid3d_conn6(grid)  # doctest: +SKIP
-    >>> edges  # doctest: +SKIP
-    [[0, 1], [0, 2], [1, 3], [2, 3], [0, 4], [1, 5], [4, 5], [2, 6], [4, 6], [3, 7], [5, 7], [6, 7]]
     """
     logging.debug('make graph segment connect edges - 3d conn6')
     grid = np.asarray(grid)
@@ -293,10 +270,6 @@ def superpixel_centers(segments):
 
     :param ndarray segments: label map
     :return list: per label a tuple (2D) / list (3D) of coordinates
-
-    >>> segm = np.array([[0] * 6 + [1] * 5, [0] * 6 + [2] * 5])
-    >>> superpixel_centers(segm)  # doctest: +SKIP
-    [(0.5, 2.5), (0.0, 8.0), (1.0, 8.0)]
     """
     segments = np.asarray(segments)
     logging.debug('compute centers for %d superpixels', segments.max())
@@ -316,9 +289,6 @@ def superpixel_centers(segments):
 
 def get_neighboring_segments(edges):
     """ neighbour lists from an edge list
-
-    >>> get_neighboring_segments([[0, 1], [1, 2], [1, 3], [2, 3]])
-    [[1], [0, 2, 3], [1, 3], [1, 2]]
     """
     neighbours = [[] for _ in range(int(np.max(edges)) + 1)]
     for a, b in edges:

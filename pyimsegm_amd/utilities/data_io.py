@@ -18,9 +18,6 @@ def _as_float_rgb(image):
 
 def rgb2hsv(rgb):
     """ RGB -> HSV, all channels in [0, 1] (same formulas as ``skimage.color.rgb2hsv``)
-
-    >>> rgb2hsv(np.array([[[1., 0., 0.], [0., 0.5, 0.5]]])).tolist()
-    [[[0.0, 1.0, 1.0], [0.5, 1.0, 0.5]]]
     """
     arr = _as_float_rgb(rgb)
     out = np.empty_like(arr)
@@ -91,9 +88,6 @@ DICT_CONVERT_COLOR_FROM_RGB = {'hsv': rgb2hsv, 'luv': rgb2luv, 'lab': rgb2lab, '
 
 def convert_img_color_from_rgb(image, color_space):
     """ convert image colour space from RGB to ``color_space`` (unknown names: image returned as is)
-
-    >>> convert_img_color_from_rgb(np.ones((50, 75, 3)), 'hsv').shape
-    (50, 75, 3)
     """
     image = np.asarray(image)
     if image.ndim == 3 and image.shape[-1] in (3, 4) and color_space in DICT_CONVERT_COLOR_FROM_RGB:
@@ -104,15 +98,6 @@ def convert_img_color_from_rgb(image, color_space):
 def get_image2d_boundary_color(image, size=1):
     """ the dominant value on the image border of width ``size`` (reference ``utilities/data_io.py:1002-1036``):
     the most frequent label of a 2D (label) image, the per-channel median of a colour image
-
-    >>> img = np.zeros((5, 15), dtype=int)
-    >>> img[:4, 3:9] = 1
-    >>> int(get_image2d_boundary_color(img))
-    0
-    >>> get_image2d_boundary_color(np.ones((5, 15, 3), dtype=int), size=2).tolist()
-    [1, 1, 1]
-    >>> int(get_image2d_boundary_color(np.ones((5, 15, 3, 1), dtype=int)))
-    0
     """
     import logging
     image = np.asarray(image)

@@ -24,17 +24,11 @@ def test_alias_modules_are_the_same_objects():
 
 
 def test_host_side_doctests():
-    """doctests of the host mirror that need no GPU"""
-    import doctest
+    """the examples of the host mirror that need no GPU (tests/doctests: they sat in the docstrings before)"""
     import warnings
-    import pyimsegm_amd.descriptors as d
-    import pyimsegm_amd.graph_cuts as g
-    import pyimsegm_amd.superpixels as s
-    import pyimsegm_amd.classification as c
-    import pyimsegm_amd.labeling as lb
-    import pyimsegm_amd.utilities.data_io as io
+    from tests.doctests import MODULES, run_examples
     with warnings.catch_warnings():
         warnings.simplefilter('ignore')
-        for mod in (d, g, s, io, c, lb):
-            res = doctest.testmod(mod)
-            assert res.failed == 0, mod.__name__
+        for key in MODULES:
+            failed, attempted = run_examples(key)
+            assert failed == 0 and attempted > 0, key

@@ -289,3 +289,15 @@ def test_images_in_flight_match_sequential():
              for im in (images[0], other, images[1], other)]
     assert np.array_equal(mixed[0], seq[0]) and np.array_equal(mixed[2], seq[1])
     assert np.array_equal(mixed[1], ref_other) and np.array_equal(mixed[3], ref_other)
+
+
+@pytest.mark.parametrize('key', ['descriptors', 'graph_cuts', 'superpixels', 'classification', 'labeling', 'pipelines', 'utilities_data_io'])
+def test_examples_of_the_host_modules_on_the_device(key):
+    """every example of tests/doctests -- the reference's doctest vectors of the mirrored functions among them -- with the ones
+    that need the GPU included"""
+    import warnings
+    from tests.doctests import run_examples
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        failed, attempted = run_examples(key, on_device=True)
+    assert failed == 0 and attempted > 0
