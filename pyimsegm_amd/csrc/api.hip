@@ -40,6 +40,9 @@ static Knobs read_knobs()
     k.brick_cap = num("IMSEGM_BRICK_CAP", 0);
     k.gc_lds_level = num("IMSEGM_GC_LDS_LEVEL", 4);
     k.gc_threads = num("IMSEGM_GC_THREADS", 0);
+    k.gc_grid_min_sites = num("IMSEGM_GC_GRID_MIN_SITES", 0);
+    k.gc_grid_blocks = num("IMSEGM_GC_GRID_BLOCKS", 0);
+    k.gc_one_workgroup = flag("IMSEGM_GC_ONE_WORKGROUP");
     k.sweeps_blocks_per_cu = num("IMSEGM_SWEEPS_BLOCKS_PER_CU", 0);
     k.sweeps_per_launch = num("IMSEGM_SWEEPS_PER_LAUNCH", 0);
     const char *d = getenv("IMSEGM_PHASE_DUMP");

@@ -29,6 +29,9 @@ struct Knobs {
     int brick_cap;             // IMSEGM_BRICK_CAP (0: default)
     int gc_lds_level;          // IMSEGM_GC_LDS_LEVEL (default 4)
     int gc_threads;            // IMSEGM_GC_THREADS (0: default)
+    int gc_grid_min_sites;     // IMSEGM_GC_GRID_MIN_SITES (0: default 8192): graphs of that many sites that do not fit one CU's LDS go to the grid-wide kernel
+    int gc_grid_blocks;        // IMSEGM_GC_GRID_BLOCKS (0: one per CU)
+    bool gc_one_workgroup;     // IMSEGM_GC_ONE_WORKGROUP: never the grid-wide kernel (tests, A/B)
     int sweeps_blocks_per_cu;  // IMSEGM_SWEEPS_BLOCKS_PER_CU (0: default)
     int sweeps_per_launch;     // IMSEGM_SWEEPS_PER_LAUNCH (0: all)
     std::string phase_dump;    // IMSEGM_PHASE_DUMP (file name, empty: none)

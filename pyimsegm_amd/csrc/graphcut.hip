@@ -19,6 +19,7 @@
 #include "slic.h"
 #include <cstdio>
 #include <cstdlib>
+#include <hip/hip_cooperative_groups.h>
 
 namespace imsegm {
 
@@ -531,6 +532,298 @@ __global__ void __launch_bounds__(GC_THREADS) k_alpha_expansion(GcDevice g)
     if (threadIdx.x == 0) *g.energy_out = energy;
 }
 
+// ---- graphs beyond one workgroup's reach: the same alpha-expansion by the WHOLE device ----------------------------------------
+// A graph whose mutable arrays do not fit the LDS of one CU (K >~ 4 000 sites; the 298 116 supervoxels of BASELINE configs[4]) ran
+// in ONE workgroup out of global memory: a level of the relabelling BFS or a push round was a scan of all K sites by 1 024 threads,
+// 211 ms per volume.  k_alpha_expansion_grid is the same algorithm -- the same schedule of moves, the same move energies, the same
+// lock-free push-relabel, the same cut convention, hence the same labelling -- on a cooperative launch: the sites are spread over
+// all resident threads of the device, a workgroup barrier becomes a grid barrier, the workgroup-wide OR / sum go through three
+// rotating words of a control block in global memory (rotation as block_or: one barrier per reduction).  Everything another
+// workgroup may have written is read with agent-scope atomic loads (ld / st), as the single-workgroup kernel reads its global
+// scratch.  The schedule variables live in registers of every thread and evolve identically (every decision is grid uniform).
+namespace cg = cooperative_groups;
+
+struct GcGridCtl {
+    int flags[3];
+    int status_pad;
+    long long sums[3];
+    long long energy;
+    int table[GC_MAX_LABELS];
+    int queue_sizes[GC_MAX_LABELS + 2];
+};
+
+struct GcGrid {
+    cg::grid_group grid;
+    GcGridCtl *ctl;
+    int tid, nth;
+    unsigned or_calls, sum_calls;
+    __device__ GcGrid(GcGridCtl *c) : grid(cg::this_grid()), ctl(c), tid(blockIdx.x * blockDim.x + threadIdx.x),
+                                      nth(gridDim.x * blockDim.x), or_calls(0), sum_calls(0) {}
+    __device__ __forceinline__ void sync() { grid.sync(); }
+    // OR over the grid, one barrier (word r % 3 is set and read by call r; thread 0 clears word (r + 2) % 3 behind the barrier)
+    __device__ __forceinline__ bool any(int pred)
+    {
+        int *f = ctl->flags + or_calls % 3;
+        if (pred) st(f, 1);
+        grid.sync();
+        const int r = ld(f);
+        if (tid == 0) st(ctl->flags + (or_calls + 2) % 3, 0);
+        ++or_calls;
+        return r != 0;
+    }
+    // sum over the grid, one barrier: a wave adds its total with one atomic
+    __device__ __forceinline__ long long sum(long long v)
+    {
+        long long *acc = ctl->sums + sum_calls % 3;
+        v = wave_sum_i64(v);
+        if ((threadIdx.x & 63) == 0 && v != 0) atomic_add_i64(acc, v);
+        grid.sync();
+        const long long r = ld(acc);
+        if (tid == 0) st(ctl->sums + (sum_calls + 2) % 3, 0LL);
+        ++sum_calls;
+        return r;
+    }
+};
+
+__device__ __forceinline__ long long gc_grid_energy(const GcDevice &g, GcGrid &q, const int32_t *lab)
+{
+    long long e = 0;
+    for (int i = q.tid; i < g.K; i += q.nth) e += g.unary[(size_t)i * g.C + ld(&lab[i])];
+    for (int j = q.tid; j < g.E; j += q.nth) {
+        const int a = g.edges[2 * j], b = g.edges[2 * j + 1];
+        e += (long long)g.w[j] * g.smooth[ld(&lab[a]) * g.C + ld(&lab[b])];
+    }
+    return q.sum(e);
+}
+
+__device__ __forceinline__ void gc_grid_relabel(const GcDevice &g, GcGrid &q, int *cap, int *height, long long *excess, int alpha)
+{
+    const int HMAX = g.K + 2;
+    for (int u = q.tid; u < g.K; u += q.nth)
+        st(&height[u], (ld(&g.labels[u]) != alpha && ld(&excess[u]) < 0) ? 1 : HMAX);
+    q.sync();
+    for (int level = 1; level < HMAX; ++level) {
+        if (g.dbg && q.tid == 0) g.dbg[2] += 1;
+        int changed = 0;
+        for (int u = q.tid; u < g.K; u += q.nth) {
+            if (ld(&height[u]) != HMAX || ld(&g.labels[u]) == alpha) continue;
+            const int a0 = g.arc_start[u], a1 = g.arc_start[u + 1];
+            bool hit = false;
+            for (int base = a0; base < a1 && !hit; base += GC_ARCS) {
+                int c[GC_ARCS], h[GC_ARCS];
+#pragma unroll
+                for (int i = 0; i < GC_ARCS; ++i) {
+                    const int a = min(base + i, a1 - 1);
+                    c[i] = ld(&cap[a]);
+                    h[i] = g.arc_to[a];
+                }
+#pragma unroll
+                for (int i = 0; i < GC_ARCS; ++i) h[i] = ld(&height[h[i]]);
+#pragma unroll
+                for (int i = 0; i < GC_ARCS; ++i) hit |= c[i] > 0 && h[i] == level;
+            }
+            if (hit) {
+                st(&height[u], level + 1);
+                changed = 1;
+            }
+        }
+        if (!q.any(changed)) break;
+    }
+}
+
+// one expansion move by the grid; returns (uniformly) whether the energy strictly decreased -- gc_expand, statement by statement
+__device__ __forceinline__ bool gc_grid_expand(const GcDevice &g, GcGrid &q, int alpha, int *cap, int *height, long long *excess)
+{
+    const int HMAX = g.K + 2;
+    int mine = 0;
+    for (int u = q.tid; u < g.K; u += q.nth) {
+        const int l = ld(&g.labels[u]);
+        st(&excess[u], (l != alpha) ? (long long)g.unary[(size_t)u * g.C + l] - (long long)g.unary[(size_t)u * g.C + alpha] : 0LL);
+        mine |= (l != alpha);
+    }
+    if (g.dbg && q.tid == 0) g.dbg[0] += 1;
+    if (!q.any(mine)) return false;
+    for (int j = q.tid; j < g.E; j += q.nth) {
+        const int p = g.edges[2 * j], r = g.edges[2 * j + 1];
+        const long long w = g.w[j];
+        const int lp = ld(&g.labels[p]), lq = ld(&g.labels[r]);
+        const int apq = g.edge_arc[2 * j], aqp = g.edge_arc[2 * j + 1];
+        int cpq = 0, cqp = 0;
+        const bool ap = lp != alpha, aq = lq != alpha;
+        const int32_t *V = g.smooth;
+        if (ap && aq) {
+            long long A = w * V[alpha * g.C + alpha], B = w * V[alpha * g.C + lq];
+            long long Cc = w * V[lp * g.C + alpha], D = w * V[lp * g.C + lq];
+            long long trp = D - A, trq = 0;
+            B -= A;
+            Cc -= D;
+            if (B < 0) {
+                trp -= B;
+                trq += B;
+                cqp = (int)(B + Cc);
+            } else if (Cc < 0) {
+                trp += Cc;
+                trq -= Cc;
+                cpq = (int)(B + Cc);
+            } else {
+                cpq = (int)B;
+                cqp = (int)Cc;
+            }
+            if (trp) atomic_add_i64(&excess[p], trp);
+            if (trq) atomic_add_i64(&excess[r], trq);
+        } else if (ap) {
+            const long long d = w * V[lp * g.C + lq] - w * V[alpha * g.C + lq];
+            if (d) atomic_add_i64(&excess[p], d);
+        } else if (aq) {
+            const long long d = w * V[lp * g.C + lq] - w * V[lp * g.C + alpha];
+            if (d) atomic_add_i64(&excess[r], d);
+        }
+        st(&cap[apq], cpq);
+        st(&cap[aqp], cqp);
+    }
+    q.sync();
+    for (int outer = 0;; ++outer) {
+        if (g.dbg && q.tid == 0) g.dbg[1] += 1;
+        if (outer > (1 << 20)) {
+            if (q.tid == 0) *g.status = 1;
+            break;
+        }
+        gc_grid_relabel(g, q, cap, height, excess, alpha);
+        int active = 0;
+        for (int u = q.tid; u < g.K; u += q.nth)
+            if (ld(&excess[u]) > 0 && ld(&height[u]) < HMAX) active = 1;
+        if (!q.any(active)) break;
+        for (int round = 0; round < GC_PUSH_ROUNDS; ++round) {
+            if (g.dbg && q.tid == 0) g.dbg[3] += 1;
+            int busy = 0;
+            for (int u = q.tid; u < g.K; u += q.nth) {
+                const long long e = ld(&excess[u]);
+                const int hu = ld(&height[u]);
+                if (e <= 0 || hu >= HMAX) continue;
+                busy = 1;
+                int best_h = 0x7fffffff, best_a = -1;
+                const int a0 = g.arc_start[u], a1 = g.arc_start[u + 1];
+                for (int base = a0; base < a1; base += GC_ARCS) {
+                    int c[GC_ARCS], h[GC_ARCS];
+#pragma unroll
+                    for (int i = 0; i < GC_ARCS; ++i) {
+                        const int a = min(base + i, a1 - 1);
+                        c[i] = ld(&cap[a]);
+                        h[i] = g.arc_to[a];
+                    }
+#pragma unroll
+                    for (int i = 0; i < GC_ARCS; ++i) h[i] = ld(&height[h[i]]);
+#pragma unroll
+                    for (int i = 0; i < GC_ARCS; ++i)
+                        if (base + i < a1 && c[i] > 0 && h[i] < best_h) {       // (the first arc to the lowest neighbour)
+                            best_h = h[i];
+                            best_a = base + i;
+                        }
+                }
+                if (best_a < 0) {
+                    st(&height[u], HMAX);
+                } else if (hu > best_h) {
+                    const int c = ld(&cap[best_a]);
+                    const int d = (e < (long long)c) ? (int)e : c;
+                    const int v = g.arc_to[best_a];
+                    atomicSub(&cap[best_a], d);
+                    atomicAdd(&cap[g.arc_rev[best_a]], d);
+                    atomic_add_i64(&excess[u], -(long long)d);
+                    atomic_add_i64(&excess[v], (long long)d);
+                } else {
+                    st(&height[u], best_h + 1 < HMAX ? best_h + 1 : HMAX);
+                }
+            }
+            if (!q.any(busy)) break;
+        }
+    }
+    // (the loop above always ends on a fresh global relabel: height < HMAX <=> can reach the sink)
+    for (int u = q.tid; u < g.K; u += q.nth) {
+        const int l = ld(&g.labels[u]);
+        st(&g.prop[u], (l != alpha && ld(&height[u]) >= HMAX) ? alpha : l);
+    }
+    q.sync();
+    const long long after = gc_grid_energy(g, q, g.prop);
+    const bool accept = after < ld(&q.ctl->energy);
+    q.sync();                   // (everybody has compared before the energy changes)
+    if (accept) {
+        for (int u = q.tid; u < g.K; u += q.nth) st(&g.labels[u], ld(&g.prop[u]));
+        if (q.tid == 0) st(&q.ctl->energy, after);
+    }
+    q.sync();
+    return accept;
+}
+
+__global__ void __launch_bounds__(GC_THREADS) k_alpha_expansion_grid(GcDevice g, GcGridCtl *ctl)
+{
+    if (g.K_dev) g.K = min(*g.K_dev, g.K);
+    GcGrid q(ctl);
+    if (g.E_dev && *g.E_dev > g.E) {            // (as k_alpha_expansion: more edges than the tables hold -> a defined labelling)
+        for (int u = q.tid; u < g.K; u += q.nth) g.labels[u] = 0;
+        if (q.tid == 0) *g.energy_out = 0;
+        return;
+    }
+    if (g.E_dev) g.E = min(*g.E_dev, g.E);
+    long long *excess = g.g_excess;
+    int *cap = g.g_cap, *height = g.g_height;
+    for (int u = q.tid; u < g.K; u += q.nth) st(&g.labels[u], 0);
+    if (q.tid < g.C) st(&ctl->table[q.tid], q.tid);
+    if (q.tid == 0) st(&ctl->queue_sizes[0], g.C);
+    q.sync();
+    const long long e0 = gc_grid_energy(g, q, g.labels);
+    if (q.tid == 0) st(&ctl->energy, e0);
+    q.sync();
+    if (g.n_iter == -1) {
+        // GCoptimization::expansion(-1): the adaptive cycles of k_alpha_expansion, the label table in the control block
+        int nq = 1, next = 0, last_accepted = -1;
+        do {
+            int queue_size = ld(&ctl->queue_sizes[nq - 1]);
+            const int start = next;
+            do {
+                const int alpha = ld(&ctl->table[next]);
+                const bool ok = !(g.skip_repeat && alpha == last_accepted) && gc_grid_expand(g, q, alpha, cap, height, excess);
+                if (ok) {
+                    last_accepted = alpha;
+                    ++next;
+                } else {
+                    --queue_size;
+                    q.sync();
+                    if (q.tid == 0) {
+                        const int t = ld(&ctl->table[next]);
+                        st(&ctl->table[next], ld(&ctl->table[queue_size]));
+                        st(&ctl->table[queue_size], t);
+                    }
+                    q.sync();
+                }
+            } while (next < queue_size);
+            const int back = ld(&ctl->queue_sizes[nq - 1]);
+            q.sync();
+            if (next == start) {
+                next = back;
+                nq--;
+            } else if (queue_size < back / 2) {
+                next = 0;
+                if (q.tid == 0) st(&ctl->queue_sizes[nq], queue_size);
+                nq++;
+            } else {
+                next = 0;
+            }
+            q.sync();
+        } while (nq > 0);
+    } else {
+        int last_accepted = -1;
+        for (int cycle = 0; cycle < g.n_iter; ++cycle) {
+            const long long before = ld(&ctl->energy);
+            q.sync();
+            for (int l = 0; l < g.C; ++l)
+                if (l != last_accepted && gc_grid_expand(g, q, l, cap, height, excess)) last_accepted = l;
+            if (!(ld(&ctl->energy) < before)) break;
+        }
+    }
+    q.sync();
+    if (q.tid == 0) *g.energy_out = ld(&ctl->energy);
+}
+
 // data costs only (GCO solveSpecialCases): independent argmin, first minimum wins
 __global__ void k_unary_argmin(const int32_t *unary, int K, int C, int32_t *labels, long long *energy_out)
 {
@@ -543,10 +836,12 @@ __global__ void k_unary_argmin(const int32_t *unary, int K, int C, int32_t *labe
     atomic_add_i64(energy_out, unary[(size_t)i * C + best]);
 }
 
+static size_t gc_ctl_offset(int K, int E) { return ((size_t)K * 8 + ((size_t)K * 2 + (size_t)E * 2) * 4 + 63) & ~(size_t)63; }
+
 size_t alpha_expansion_work_bytes(int K, int E)
 {
-    // prop[K] | g_cap[2E] | g_height[K] | g_excess[K] (8-byte aligned first)
-    return (size_t)K * 8 + ((size_t)K * 2 + (size_t)E * 2) * 4 + 64;
+    // g_excess[K] (8-byte aligned first) | prop[K] | g_height[K] | g_cap[2E] | the control block of the grid-wide kernel
+    return gc_ctl_offset(K, E) + sizeof(GcGridCtl) + 64;
 }
 
 int launch_alpha_expansion(GcProblem p, const int32_t *arc_start, const int32_t *arc_to, const int32_t *arc_rev,
@@ -629,6 +924,30 @@ int launch_alpha_expansion(GcProblem p, const int32_t *arc_start, const int32_t 
         lds_need = (size_t)p.K * 8 + ((size_t)2 * p.E + p.K) * 4;
         if (level >= 2) lds_need += ((size_t)2 * p.K + (size_t)p.K * p.C + (size_t)p.C * p.C) * 4;
         if (level >= 3) lds_need += ((size_t)p.K + 1 + (size_t)2 * p.E) * 4;
+    }
+    // a graph that does not fit the LDS of one CU: the whole device works on it (k_alpha_expansion_grid) -- one workgroup of 1 024
+    // threads per CU at most (the grid barrier costs one atomic per workgroup), a site or two per thread
+    if (level == 0 && zb.nz == 1 && p.K >= (knobs().gc_grid_min_sites > 0 ? knobs().gc_grid_min_sites : 8192) && !knobs().gc_one_workgroup) {
+        int dev = 0;
+        HIP_TRY(hipGetDevice(&dev));
+        static int cus[IMSEGM_MAX_DEVICES] = { 0 };
+        if (dev >= 0 && dev < IMSEGM_MAX_DEVICES && cus[dev] == 0) {
+            hipDeviceProp_t prop;
+            HIP_TRY(hipGetDeviceProperties(&prop, dev));
+            int per_cu = 0;
+            HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)k_alpha_expansion_grid, GC_THREADS, 0));
+            cus[dev] = prop.cooperativeLaunch && per_cu >= 1 ? prop.multiProcessorCount : -1;
+        }
+        const int n_cu = dev >= 0 && dev < IMSEGM_MAX_DEVICES ? cus[dev] : -1;
+        if (n_cu > 0) {
+            GcGridCtl *ctl = reinterpret_cast<GcGridCtl *>(wb + gc_ctl_offset(p.K, p.E));
+            HIP_TRY(hipMemsetAsync(ctl, 0, sizeof(GcGridCtl), st));
+            int blocks = std::min(n_cu, cdiv(p.K, GC_THREADS));
+            if (knobs().gc_grid_blocks > 0) blocks = std::min(blocks, knobs().gc_grid_blocks);
+            void *args[] = { &g, &ctl };
+            HIP_TRY(hipLaunchCooperativeKernel((const void *)k_alpha_expansion_grid, dim3(blocks), dim3(GC_THREADS), args, 0, st));
+            return 0;
+        }
     }
     size_t dyn = g.use_lds ? lds_need : 0;
     // one thread per node up to 1024; a small graph runs with fewer waves (the moves are chains of workgroup barriers)

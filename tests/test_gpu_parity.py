@@ -229,6 +229,53 @@ def test_graphcut_every_lds_placement(hip, oracle, level, regs, monkeypatch):
     assert len(np.unique(ref)) > 1
 
 
+def _large_graph(seed, side, C, extra_share=0.1):
+    """a side x side grid graph with a few long-range edges, smooth class regions with noisy probabilities: moves that take many
+    relabelling levels and push rounds"""
+    rng = np.random.default_rng(seed)
+    K = side * side
+    ids = np.arange(K).reshape(side, side)
+    pairs = np.vstack([np.c_[ids[:, :-1].ravel(), ids[:, 1:].ravel()], np.c_[ids[:-1, :].ravel(), ids[1:, :].ravel()]])
+    extra = rng.integers(0, K, (int(K * extra_share), 2))
+    pairs = np.unique(np.sort(np.vstack([pairs, extra[extra[:, 0] != extra[:, 1]]]), axis=1), axis=0).astype(np.int32)
+    weights = np.clip(rng.lognormal(0, 1, len(pairs)), 1e-3, 1e3)
+    rows, cols = np.indices((side, side))
+    region = ((np.sin(rows / 17.) + np.cos(cols / 23.) + 2.) * C / 4.).astype(int).ravel() % C
+    proba = np.full((K, C), 0.2)
+    proba[np.arange(K), region] = 0.5
+    proba *= rng.uniform(0.4, 1.6, proba.shape)
+    proba /= proba.sum(axis=1, keepdims=True)
+    return pairs, weights, np.abs(-np.log(np.clip(proba, 0.01, 0.99)))
+
+
+@pytest.mark.parametrize('seed,side,C,blocks', [(21, 100, 3, 0), (22, 150, 4, 0), (23, 120, 3, 3), (24, 96, 5, 1)])
+def test_graphcut_by_the_whole_device_against_the_oracle(hip, oracle, seed, side, C, blocks, monkeypatch):
+    """graphs beyond the LDS of one CU (9 216 .. 22 500 sites) go to the cooperative grid-wide kernel (graphcut.hip
+    k_alpha_expansion_grid): labelling and energy of the oracle's alpha-expansion (Dinic max-flow), with one workgroup per CU,
+    with three workgroups, with a single one"""
+    if blocks:
+        monkeypatch.setenv('IMSEGM_GC_GRID_BLOCKS', str(blocks))
+    pairs, weights, unary = _large_graph(seed, side, C)
+    pairwise = 1.2 * (1 - np.eye(C))
+    ref, e_ref = oracle.cut_general_graph(pairs, weights, unary, pairwise, return_energy=True)
+    out, e = hip.cut_general_graph(pairs, weights, unary, pairwise, return_energy=True)
+    assert e == e_ref and np.array_equal(out, ref)
+    assert len(np.unique(ref)) == C
+
+
+def test_graphcut_by_the_whole_device_equals_one_workgroup(hip, monkeypatch):
+    """160 000 sites, 335 000 edges: the grid-wide kernel against the single workgroup working out of global memory -- and with
+    a pairwise matrix that is not a metric (no move skipped)"""
+    pairs, weights, unary = _large_graph(31, 400, 3, extra_share=0.05)
+    for pairwise in (0.8 * (1 - np.eye(3)), 0.5 + 0.8 * (1 - np.eye(3))):
+        out, e = hip.cut_general_graph(pairs, weights, unary, pairwise, return_energy=True)
+        monkeypatch.setenv('IMSEGM_GC_ONE_WORKGROUP', '1')
+        single, e_single = hip.cut_general_graph(pairs, weights, unary, pairwise, return_energy=True)
+        monkeypatch.delenv('IMSEGM_GC_ONE_WORKGROUP')
+        assert e == e_single and np.array_equal(out, single)
+        assert len(np.unique(out)) == 3
+
+
 def test_graphcut_no_edges_and_errors(hip):
     unary = np.array([[3., 1., 2.], [0.5, 0.5, 0.1], [1., 1., 1.]])
     out = hip.cut_general_graph(np.zeros((0, 2), dtype=np.int32), np.zeros(0), unary, 1 - np.eye(3))
