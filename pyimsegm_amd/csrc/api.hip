@@ -37,6 +37,7 @@ static Knobs read_knobs()
     k.conn_general = flag("IMSEGM_CONN_GENERAL");
     k.gc_no_topo_regs = flag("IMSEGM_GC_NO_TOPO_REGS");
     k.sep_wide_tile = flag("IMSEGM_SEP_WIDE_TILE");
+    k.adjacency_table = flag("IMSEGM_ADJACENCY_TABLE");
     k.brick_cap = num("IMSEGM_BRICK_CAP", 0);
     k.gc_lds_level = num("IMSEGM_GC_LDS_LEVEL", 4);
     k.gc_threads = num("IMSEGM_GC_THREADS", 0);
@@ -1367,25 +1368,41 @@ int imsegm_volume_graph(imsegm_image2d *im, int32_t *edges_out, int edge_capacit
     imsegm_ctx *ctx = im->ctx;
     hipStream_t st = ctx->stream;
     const int K = im->n_labels;
-    if ((double)K * (double)K / 8.0 > 64e9) {         // K x K bitmap: 11 GB at the 3e5 supervoxels of config 5
-        set_error("adjacency bitmap: too many labels (K*K/8 bytes must stay below 64 GB)");
-        return -1;
-    }
     if (edge_capacity < 0) edge_capacity = 0;
     size_t words = (size_t)cdiv(K, 32);
-    size_t bytes = (size_t)K * words * 4 + (size_t)K * 4 * 8 + (size_t)edge_capacity * 8 + (size_t)K * 3 * 8 + (size_t)K * 4 + K + 512;
+    // neighbours as bits of a K x K bitmap while that is small (one pass, no retry); beyond 256 MB -- K > 46 000; 11 GB at the 3 * 10^5
+    // supervoxels of BASELINE configs[4] -- as a table of neighbour slots per label, widened until every row fits
+    const bool as_table = (double)K * (double)words * 4.0 > 256e6 || knobs().adjacency_table;
+    for (int cap = as_table ? 32 : 0;; cap *= 2) {
+    const size_t store = as_table ? (size_t)K * cap * 4 : (size_t)K * words * 4;
+    if (as_table && (cap > 65536 || store > 64e9)) {
+        set_error("adjacency: a label with more than 65 536 neighbours of smaller number");
+        return -1;
+    }
+    size_t bytes = store + (size_t)K * 4 * 8 + (size_t)edge_capacity * 8 + (size_t)K * 3 * 8 + (size_t)K * 4 + K + 512;
     if (im->graph.ensure(bytes)) return -1;
     unsigned char *b = im->graph.as<unsigned char>();
     long long *cacc = reinterpret_cast<long long *>(b); b += (size_t)K * 4 * 8;
     double *centres = reinterpret_cast<double *>(b); b += (size_t)K * 3 * 8;
-    uint32_t *bitmap = reinterpret_cast<uint32_t *>(b); b += (size_t)K * words * 4;
+    uint32_t *bitmap = reinterpret_cast<uint32_t *>(b); b += store;
     int32_t *edges = reinterpret_cast<int32_t *>(b); b += (size_t)edge_capacity * 8;
     int32_t *rowcount = reinterpret_cast<int32_t *>(b); b += (size_t)K * 4;
-    int32_t *n_edges_dev = reinterpret_cast<int32_t *>(b); b += 16;
+    int32_t *n_edges_dev = reinterpret_cast<int32_t *>(b); b += 16;             // [0] edges, [1] a row of the table was too narrow
     uint8_t *present = b;
-    if (launch_vol_adjacency(im->labels.as<int32_t>(), im->D, im->H, im->W, K, (int)words, bitmap, cacc, centres, present, st))
-        return -1;
-    if (launch_edge_extract(bitmap, K, (int)words, rowcount, edges, edge_capacity, n_edges_dev, st)) return -1;
+    if (as_table) {
+        int32_t *table = reinterpret_cast<int32_t *>(bitmap);
+        if (launch_vol_adjacency_table(im->labels.as<int32_t>(), im->D, im->H, im->W, K, table, cap, n_edges_dev + 1, cacc, centres, present, st))
+            return -1;
+        int narrow = 0;
+        HIP_TRY(hipMemcpyAsync(&narrow, n_edges_dev + 1, 4, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        if (narrow) continue;
+        if (launch_edge_extract_table(table, K, cap, rowcount, edges, edge_capacity, n_edges_dev, st)) return -1;
+    } else {
+        if (launch_vol_adjacency(im->labels.as<int32_t>(), im->D, im->H, im->W, K, (int)words, bitmap, cacc, centres, present, st))
+            return -1;
+        if (launch_edge_extract(bitmap, K, (int)words, rowcount, edges, edge_capacity, n_edges_dev, st)) return -1;
+    }
     int ne = 0;
     HIP_TRY(hipMemcpyAsync(&ne, n_edges_dev, 4, hipMemcpyDeviceToHost, st));
     if (centres_out) HIP_TRY(hipMemcpyAsync(centres_out, centres, (size_t)K * 24, hipMemcpyDeviceToHost, st));
@@ -1397,6 +1414,7 @@ int imsegm_volume_graph(imsegm_image2d *im, int32_t *edges_out, int edge_capacit
     }
     *n_edges_out = ne;
     return 0;
+    }
 }
 
 int imsegm_image2d_all_finite(imsegm_image2d *im, int *all_finite_out)

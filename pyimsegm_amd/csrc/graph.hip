@@ -174,6 +174,54 @@ __global__ void k_edge_emit(const uint32_t *__restrict__ bitmap, int K, int word
     }
 }
 
+// ---- edges out of the neighbour table (volume.hip k_vol_adjacency_centres<true>): row b holds the smaller neighbours of b in
+// any order with free slots (-1) in between; one wave per row counts them / writes them in ascending order (the rank of an entry
+// is the number of smaller ones), which gives the edge order of the bitmap: sorted by (b, a)
+__global__ void __launch_bounds__(256) k_table_rowcount(const int32_t *__restrict__ table, int K, int cap, int32_t *rowcount)
+{
+    const int lane = threadIdx.x & 63;
+    const int b = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if (b >= K) return;
+    int c = 0;
+    for (int i = lane; i < cap; i += 64) c += table[(size_t)b * cap + i] >= 0;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) c += __shfl_xor(c, off, 64);
+    if (lane == 0) rowcount[b] = c;
+}
+
+__global__ void __launch_bounds__(256) k_table_emit(const int32_t *__restrict__ table, int K, int cap, const int32_t *__restrict__ offsets,
+                                                    int32_t *edges, int capacity)
+{
+    const int lane = threadIdx.x & 63;
+    const int b = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if (b >= K) return;
+    const int32_t *row = table + (size_t)b * cap;
+    const int o = offsets[b];
+    for (int i = lane; i < cap; i += 64) {
+        const int a = row[i];
+        if (a < 0) continue;
+        int rank = 0;
+        for (int j = 0; j < cap; ++j) {
+            const int other = row[j];
+            rank += other >= 0 && other < a;
+        }
+        if (o + rank < capacity) {
+            edges[2 * (o + rank) + 0] = a;
+            edges[2 * (o + rank) + 1] = b;
+        }
+    }
+}
+
+int launch_edge_extract_table(const int32_t *table, int K, int cap, int32_t *rowcount, int32_t *edges_out, int edge_capacity,
+                              int32_t *n_edges_dev, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_table_rowcount, cdiv((long)K * 64, 256), 256, 0, st, table, K, cap, rowcount);
+    hipLaunchKernelGGL(k_edge_scan, 1, 256, 0, st, rowcount, K, n_edges_dev);
+    hipLaunchKernelGGL(k_table_emit, cdiv((long)K * 64, 256), 256, 0, st, table, K, cap, rowcount, edges_out, edge_capacity);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
 // zero `bytes` bytes (a multiple of 4, 4-byte aligned) of every image of a batch in one launch
 __global__ void __launch_bounds__(256) k_zero_words(uint32_t *p, size_t words, size_t zs)
 {

@@ -177,6 +177,10 @@ int launch_label_cc(int32_t *labels_inout, int D, int H, int W, int32_t *parent,
                     int32_t *total_dev, hipStream_t st);
 int launch_vol_adjacency(const int32_t *labels, int D, int H, int W, int K, int words, uint32_t *bitmap, long long *cacc,
                          double *centres, uint8_t *present, hipStream_t st);
+int launch_vol_adjacency_table(const int32_t *labels, int D, int H, int W, int K, int32_t *table, int cap, int *overflow, long long *cacc,
+                               double *centres, uint8_t *present, hipStream_t st);
+int launch_edge_extract_table(const int32_t *table, int K, int cap, int32_t *rowcount, int32_t *edges_out, int edge_capacity,
+                              int32_t *n_edges_dev, hipStream_t st);
 int launch_edge_extract(const uint32_t *bitmap, int K, int words, int32_t *rowcount, int32_t *edges_out, int edge_capacity,
                         int32_t *n_edges_dev, hipStream_t st);
 

@@ -705,6 +705,41 @@ k_vol_update_f32(VolState s, const float *__restrict__ vol, const int32_t *__res
     float acc = 0.f;                                          // lanes 0..3: running sums of z, y, x, value
     int cnt = 0;
     const int nx = x1 - x0 + 1;
+    if (nx <= 64) {
+        // the box is at most one wave wide (always, for the windows of a regular grid): the labels of VU_ROWS rows are requested
+        // together, then the values of the voxels that carry the label, then the rows are summed in raster order -- one round trip to
+        // memory per VU_ROWS rows instead of two per row (the kernel was a chain of such round trips: 625 rows x ~0.5 us per box)
+        constexpr int VU_ROWS = 8;
+        const int x = x0 + lane;
+        const bool in = x <= x1;
+        for (int z = z0; z <= z1; ++z) {
+            const float fz = (float)z;
+            for (int yb = y0; yb <= y1; yb += VU_ROWS) {
+                int lab[VU_ROWS];
+                float val[VU_ROWS];
+#pragma unroll
+                for (int r = 0; r < VU_ROWS; ++r)
+                    lab[r] = (in && yb + r <= y1) ? labels[((size_t)z * s.H + yb + r) * s.W + x] : -1;
+#pragma unroll
+                for (int r = 0; r < VU_ROWS; ++r) val[r] = lab[r] == k ? vol[((size_t)z * s.H + yb + r) * s.W + x] : 0.f;
+#pragma unroll
+                for (int r = 0; r < VU_ROWS; ++r) {
+                    unsigned long long m = __ballot(lab[r] == k);
+                    if (!m) continue;
+                    cnt += __popcll(m);
+                    const float sel_zy = lane == 0 ? fz : (float)(yb + r);
+                    while (m) {
+                        const int b = __ffsll((long long)m) - 1;
+                        m &= m - 1;
+                        const float vb = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(val[r]), b));
+                        const float fxv = (float)(x0 + b);
+                        const float op = lane < 2 ? sel_zy : (lane == 2 ? fxv : vb);
+                        acc = acc + op;
+                    }
+                }
+            }
+        }
+    } else
     for (int z = z0; z <= z1; ++z) {
         const float fz = (float)z;
         for (int y = y0; y <= y1; ++y) {
@@ -912,9 +947,29 @@ int launch_label_cc(int32_t *labels_inout, int D, int H, int W, int32_t *parent,
 }
 
 // ---- 6-connected adjacency bitmap + centre sums of a label volume -----------------------------------------
+// (TABLE: instead of bit (row b, column a) of a K x K bitmap, the smaller label a goes into row b of a K x cap table of neighbour
+// slots -- open addressing inside the row, -1 = free; a row that is full raises *overflow and the caller comes back with wider
+// rows.  The bitmap is 11 GB for the 3 * 10^5 supervoxels of BASELINE configs[4] and caps K; the table is K * cap * 4 bytes.)
+__device__ __forceinline__ void neighbour_insert(int32_t *table, int cap, int b, int a, int *overflow)
+{
+    int32_t *row = table + (size_t)b * cap;
+    unsigned slot = ((unsigned)a * 2654435761u) >> 7;
+    for (int probe = 0; probe < cap; ++probe, ++slot) {
+        int32_t *cell = row + (slot & (unsigned)(cap - 1));
+        int seen = __hip_atomic_load(cell, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (seen == a) return;
+        if (seen == -1) {
+            seen = atomicCAS(cell, -1, a);
+            if (seen == -1 || seen == a) return;
+        }
+    }
+    *overflow = 1;
+}
+
+template <bool TABLE>
 __global__ void __launch_bounds__(256)
 k_vol_adjacency_centres(const int32_t *__restrict__ labels, int D, int H, int W, int words, uint32_t *bitmap,
-                        long long *__restrict__ cacc)
+                        long long *__restrict__ cacc, int32_t *table, int cap, int *overflow)
 {
     int p = blockIdx.x * blockDim.x + threadIdx.x;
     const int n = D * H * W;
@@ -928,9 +983,13 @@ k_vol_adjacency_centres(const int32_t *__restrict__ labels, int D, int H, int W,
         for (int j = 0; j < 3; ++j) {
             if (nb[j] == l) continue;
             int a = min(l, nb[j]), b = max(l, nb[j]);
-            uint32_t *wp = bitmap + (size_t)b * words + (a >> 5);
-            uint32_t bit = 1u << (a & 31);
-            if (!(*wp & bit)) atomicOr(wp, bit);
+            if (TABLE) {
+                neighbour_insert(table, cap, b, a, overflow);
+            } else {
+                uint32_t *wp = bitmap + (size_t)b * words + (a >> 5);
+                uint32_t bit = 1u << (a & 31);
+                if (!(*wp & bit)) atomicOr(wp, bit);
+            }
         }
     }
     int cur = l;
@@ -962,7 +1021,22 @@ int launch_vol_adjacency(const int32_t *labels, int D, int H, int W, int K, int 
     const int n = D * H * W;
     HIP_TRY(hipMemsetAsync(bitmap, 0, (size_t)K * words * sizeof(uint32_t), st));
     HIP_TRY(hipMemsetAsync(cacc, 0, (size_t)K * 4 * sizeof(long long), st));
-    hipLaunchKernelGGL(k_vol_adjacency_centres, cdiv(n, 256), 256, 0, st, labels, D, H, W, words, bitmap, cacc);
+    hipLaunchKernelGGL(k_vol_adjacency_centres<false>, cdiv(n, 256), 256, 0, st, labels, D, H, W, words, bitmap, cacc, nullptr, 0, nullptr);
+    hipLaunchKernelGGL(k_vol_centres_finalize, cdiv(K, 256), 256, 0, st, cacc, K, centres, present);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+// the same with the neighbour table (K x cap slots, cap a power of two) instead of the bitmap; *overflow (device) is raised when a
+// row was too narrow
+int launch_vol_adjacency_table(const int32_t *labels, int D, int H, int W, int K, int32_t *table, int cap, int *overflow, long long *cacc,
+                               double *centres, uint8_t *present, hipStream_t st)
+{
+    const int n = D * H * W;
+    HIP_TRY(hipMemsetAsync(table, 0xff, (size_t)K * cap * sizeof(int32_t), st));
+    HIP_TRY(hipMemsetAsync(overflow, 0, sizeof(int), st));
+    HIP_TRY(hipMemsetAsync(cacc, 0, (size_t)K * 4 * sizeof(long long), st));
+    hipLaunchKernelGGL(k_vol_adjacency_centres<true>, cdiv(n, 256), 256, 0, st, labels, D, H, W, 0, nullptr, cacc, table, cap, overflow);
     hipLaunchKernelGGL(k_vol_centres_finalize, cdiv(K, 256), 256, 0, st, cacc, K, centres, present);
     HIP_TRY(hipGetLastError());
     return 0;

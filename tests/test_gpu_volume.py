@@ -207,6 +207,26 @@ def test_volume_graph_vs_oracle(hip, oracle):
     sess.close()
 
 
+def test_volume_graph_from_the_neighbour_table(hip, oracle, monkeypatch):
+    """the graph of a label volume with the neighbours of a label kept in a table of slots per label instead of a K x K bitmap
+    (what volumes of more than 46 000 labels take: the 298 116 supervoxels of BASELINE configs[4]; here forced): the edges of the
+    oracle in the oracle's order -- also with one label that touches 150 labels of smaller number (rows widened 32 -> 256)"""
+    monkeypatch.setenv('IMSEGM_ADJACENCY_TABLE', '1')
+    vol = _noisy_ellipsoid((14, 45, 52), seed=5)
+    seg = oracle.segment_slic_img3d_gray(vol, 8, 0.2, (3, 1, 1))
+    wide = (np.arange(6 * 30 * 40).reshape(6, 30, 40) // 8) % 150           # 150 labels in runs of 8 voxels ...
+    wide[3] = 150                                                           # ... and a slab between them that touches them all
+    for labels in (seg, wide.astype(np.int64)):
+        sess = hip.Volume3D(*labels.shape).set_labels(labels)
+        edges, centres, present = sess.graph()
+        ref_v, ref_e = oracle.adjacency(labels)
+        assert np.flatnonzero(present).tolist() == ref_v.tolist()
+        assert edges.tolist() == ref_e
+        assert np.array_equal(centres[present], oracle.centers(labels)[present])
+        sess.close()
+    assert sum(1 for a, b in ref_e if b == 150) == 150
+
+
 def test_pipe_gray3d(oracle):
     """reference doctest pipelines.py:402-407 + stage-by-stage equality with the oracle"""
     from pyimsegm_amd import pipelines, descriptors as d, graph_cuts as gc
