@@ -16,7 +16,7 @@ acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(sys.argv[1] + '/**/*counter_collection.csv', recursive=True):
     for row in csv.DictReader(open(f)):
         n = row['Kernel_Name']
-        if 'battery' not in n: continue
+        if 'battery' not in n and 'color_stats' not in n: continue
         acc[n.split('(')[0]][row['Counter_Name']].append(float(row['Counter_Value']))
 for k in sorted(acc):
     print(k[:50], ' '.join('%s=%.3g' % (c, sum(v) / len(v)) for c, v in sorted(acc[k].items())), 'n=%d' % len(next(iter(acc[k].values()))))
