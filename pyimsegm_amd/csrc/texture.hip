@@ -363,7 +363,9 @@ k_conv_battery_sym(const double *__restrict__ planes, int H, int W, const double
 // enter the two responses only through  U = (A + B)[top] + sign * (A + B)[bot]  and  V = (B - A)[top] - sign * (B - A)[bot]:
 //     Ra = WS * U + WD * V,    Rb = m * (WS * U - WD * V),    WS = (Ka(-y, x) + Ka(-y, -x)) / 2,  WD = (Ka(-y, x) - Ka(-y, -x)) / 2,
 // i.e. 2 additions + 2 multiply-adds per quad and PAIR of kernels where the point symmetry alone needs 2 + 4 (and the plain sum 8):
-// 624 vector operations per column pair, lane and 4 output rows for the three pairs of a Leung-Malik battery instead of 1120.
+// 652 vector operations per column pair, lane and 4 output rows for the three pairs of a Leung-Malik battery (544 multiply-adds
+// and U / V additions, 72 column sums / differences, 36 address steps) instead of 1120: 5.84 * 10^8 against 1.07 * 10^9 vector
+// instructions per launch at 2048^2 (profiles/rocprof_r04_cfg3_sq_counters.txt), 1.18 against 2.05 ms.
 // (The sums differ from the reference's order of additions in the last bits -- as every dense sum here does; the descriptors
 // stay 10^-9 from the reference run's, tolerance 10^-5.)  Table wq: [x = 0..R][t = 0..R][WS of the NP pairs | WD of the NP
 // pairs], t = R + dy the kernel row (the row of the output itself, t = R, halved by the host: its top and bottom coincide),
