@@ -1739,7 +1739,10 @@ static int segment_impl(imsegm_image2d *im, const imsegm_gmm *gmm, const double 
                 set_error("Cost matrix not square or not symmetric");
                 return -1;
             }
-    if ((double)K * (double)K / 8.0 > 2e9) {
+    // (the K x K adjacency bitmap and its word prefixes: 2 x 11 GB at the 298 116 supervoxels of BASELINE configs[4], on a device
+    // of 288 GB; beyond 24 GB each the caller builds the graph with imsegm_volume_graph -- neighbour slots per label -- and cuts it
+    // with imsegm_cut_general_graph)
+    if ((double)K * (double)K / 8.0 > 24e9) {
         set_error("segment: too many labels for the fused path (adjacency bitmap)");
         return -1;
     }

@@ -637,7 +637,7 @@ def _gray3d_on_session(sess, image, nb_classes, dict_features, spacing, sp_size,
     proba = model.predict_proba(features)
     logging.debug('list of probabilities: %r', proba.shape)
 
-    if float(sess.n_labels)**2 / 8. <= 2e9:
+    if float(sess.n_labels)**2 / 8. <= 24e9:           # (the bound of imsegm_image2d_segment: K x K bits in HBM)
         # fused: graph, unary / edge terms ('model' edges), alpha-expansion and the gather in one call
         from pyimsegm_amd.graph_cuts import compute_pairwise_cost
         use_gc = not (np.isscalar(gc_regul) and gc_regul <= 0)
