@@ -76,3 +76,18 @@ def test_mirror_pairs_of_the_bank_and_the_quad_table():
     # kernels that do not pair up keep the point-symmetric form
     filters, _ = D.create_filter_bank_lm_2d()
     assert _hip.Image2D._split_battery(np.asarray(filters[0])[[1, 2, 3, 5]])[6] == -1
+
+
+def test_descriptor_groups_that_stay_on_the_device():
+    """which feature sets pipelines._ResidentImage keeps in one resident table (descriptors.resident_feature_groups): 'color' in RGB
+    and 'tLM*' with mean / std / energy, in the column order of compute_selected_features_color2d
+    (/root/reference/imsegm/descriptors.py:1207-1270: the colour groups first, then the Leung-Malik ones)"""
+    from pyimsegm_amd.descriptors import resident_feature_groups
+    assert resident_feature_groups({'color': ('mean', 'median')}) is None
+    assert resident_feature_groups({'color_hsv': ('mean', )}) is None
+    assert resident_feature_groups({'tLM': ('mean', ), 'unknown': ('mean', )}) is None
+    assert resident_feature_groups({'tLM': ()}) is None and resident_feature_groups({}) is None
+    groups = resident_feature_groups({'tLM_short': ('energy', 'mean'), 'tLM': ('mean', 'std', 'energy'), 'color': ('std', )})
+    assert [(g[0], sorted(g[1]), g[3]) for g in groups] == [('color', ['std'], 3), ('tLM', ['energy', 'mean'], 90),
+                                                           ('tLM', ['energy', 'mean', 'std'], 180)]
+    assert len(groups[1][2]) == 15 and len(groups[2][2]) == 20 and groups[0][2] is None
