@@ -153,6 +153,38 @@ def test_fused_volume_pipeline_equals_the_staged_path():
     sess.close()
 
 
+def test_fused_call_on_131_072_supervoxels():
+    """a label volume of 32 x 64 x 64 blocks (K^2 / 8 = 2.1 GB per bit array: beyond the 2 GB the fused call stopped at until round 4;
+    BASELINE configs[4] has 298 116): graph, terms and the cut by the whole device in ONE call equal the graph call + the
+    terms of the host mirror + imsegm_cut_general_graph"""
+    from pyimsegm_amd import _hip
+    from pyimsegm_amd import graph_cuts as G
+    rng = np.random.default_rng(17)
+    blocks = np.arange(32 * 64 * 64, dtype=np.int64).reshape(32, 64, 64)
+    labels = np.repeat(np.repeat(np.repeat(blocks, 2, axis=0), 3, axis=1), 3, axis=2)        # 64 x 192 x 192 voxels
+    k = int(labels.max()) + 1
+    assert float(k)**2 / 8 > 2e9
+    region = (np.arange(k) // (64 * 64 * 8)) % 3                                              # slabs of classes along z
+    proba = np.full((k, 3), 0.2)
+    proba[np.arange(k), region] = 0.6
+    proba *= rng.uniform(0.5, 1.5, proba.shape)
+    proba /= proba.sum(axis=1, keepdims=True)
+    pairwise = G.compute_pairwise_cost(0.5, proba.shape)
+    sess = _hip.Volume3D(*labels.shape).set_labels(labels)
+    try:
+        out = sess.segment(pairwise, 'model', proba=proba, debug=True, pinned=False)
+        edges, centres, _ = sess.graph()
+        assert np.array_equal(out['edges'], edges) and np.array_equal(out['centres'], centres)
+        assert len(edges) == 31 * 64 * 64 + 32 * 63 * 64 * 2
+        ref_w = G.edge_weights_from_graph(edges, centres, None, proba, 'model')
+        np.testing.assert_allclose(out['edge_weights'], ref_w, rtol=1e-10, atol=1e-13)
+        cut = _hip.cut_general_graph(edges, out['edge_weights'], out['unary'], pairwise)
+        assert np.array_equal(out['graph_labels'], cut) and len(np.unique(cut)) == 3
+        assert np.array_equal(out['segm'][::2, ::3, ::3], cut[blocks])
+    finally:
+        sess.close()
+
+
 def test_pinned_arrays_are_recycled():
     from pyimsegm_amd import _hip
     a = _hip.pinned_empty((300, 400), np.int32)
