@@ -263,6 +263,17 @@ def test_graphcut_by_the_whole_device_against_the_oracle(hip, oracle, seed, side
     assert len(np.unique(ref)) == C
 
 
+@pytest.mark.parametrize('n_iter,C', [(1, 3), (3, 4), (-1, 8), (2, 8)])
+def test_graphcut_by_the_whole_device_with_a_fixed_number_of_cycles(hip, oracle, n_iter, C):
+    """gco's n_iter > 0 (that many cycles over the labels, stopping early when a cycle changes nothing) and eight classes on
+    10 000 sites: the grid-wide kernel follows the oracle through both schedules"""
+    pairs, weights, unary = _large_graph(40 + C, 100, C)
+    pairwise = 0.9 * (1 - np.eye(C))
+    ref, e_ref = oracle.cut_general_graph(pairs, weights, unary, pairwise, n_iter=n_iter, return_energy=True)
+    out, e = hip.cut_general_graph(pairs, weights, unary, pairwise, n_iter=n_iter, return_energy=True)
+    assert e == e_ref and np.array_equal(out, ref)
+
+
 def test_graphcut_by_the_whole_device_equals_one_workgroup(hip, monkeypatch):
     """160 000 sites, 335 000 edges: the grid-wide kernel against the single workgroup working out of global memory -- and with
     a pairwise matrix that is not a metric (no move skipped)"""
