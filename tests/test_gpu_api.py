@@ -191,7 +191,9 @@ def _lm_host_reference(img, seg, flags, bank_type):
     return np.concatenate(out, axis=1)
 
 
-@pytest.mark.parametrize('shape,bank,dtype', [((60, 75), 'short', 'f64'), ((97, 130), 'normal', 'u8')])
+@pytest.mark.parametrize('shape,bank,dtype', [((60, 75), 'short', 'f64'), ((97, 130), 'normal', 'u8'),
+                                              # narrower / lower than a kernel (33): the reflected border is crossed more than once
+                                              ((12, 200), 'normal', 'u8'), ((130, 17), 'short', 'f64'), ((101, 16), 'normal', 'f64')])
 def test_texture_on_device_matches_scipy(shape, bank, dtype):
     """Leung-Malik features computed by the HIP kernels vs the scipy formulation of the reference"""
     from pyimsegm_amd import descriptors as D
