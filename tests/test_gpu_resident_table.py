@@ -111,3 +111,21 @@ def test_placement_is_checked():
             sess.get_features(9)                         # the table is the 3-column one now
     finally:
         sess.close()
+
+
+def test_texture_feature_sets_with_images_in_flight():
+    """the resident table (colour + Leung-Malik groups) built by worker threads -- one context, one HIP stream and one recycled
+    session each, the factorised bank shared between them -- gives the features and segmentations of one image at a time"""
+    from pyimsegm_amd import pipelines as pipe
+    images = [_image(150, 190, seed=60 + i) for i in range(5)]
+    feats = {'color': ('mean', ), 'tLM_short': ('mean', 'std')}
+    np.random.seed(0)
+    model, fts_seq = pipe.estim_model_classes_group(images, 3, feats, sp_size=14, sp_regul=0.2, nb_workers=1)
+    np.random.seed(0)
+    _, fts_par = pipe.estim_model_classes_group(images, 3, feats, sp_size=14, sp_regul=0.2, nb_workers=3)
+    assert fts_seq[0].shape[1] == 3 + 90
+    assert all(np.array_equal(a, b) for a, b in zip(fts_seq, fts_par))
+    seq = [pipe.segment_color2d_slic_features_model_graphcut(im, model, feats, sp_size=14, sp_regul=0.2, gc_regul=1.5)[0] for im in images]
+    par = pipe.segment_batch_color2d_slic_features_model_graphcut(images, model, feats, sp_size=14, sp_regul=0.2, gc_regul=1.5, nb_workers=3)
+    assert len(par) == len(seq) and all(np.array_equal(a, b) for a, b in zip(seq, par))
+    assert any(len(np.unique(s)) > 1 for s in seq)
