@@ -20,6 +20,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <hip/hip_cooperative_groups.h>
+#include <mutex>
 
 namespace imsegm {
 
@@ -945,7 +946,13 @@ int launch_alpha_expansion(GcProblem p, const int32_t *arc_start, const int32_t 
             int blocks = std::min(n_cu, cdiv(p.K, GC_THREADS));
             if (knobs().gc_grid_blocks > 0) blocks = std::min(blocks, knobs().gc_grid_blocks);
             void *args[] = { &g, &ctl };
+            // One grid-wide cut at a time per process: two cooperative grids dispatched from two streams at once could each get a
+            // part of the CUs and wait at their first barrier for the rest for ever.  The launch is followed to its end here (the
+            // callers synchronise a few launches later anyway; a cut of this size takes milliseconds).
+            static std::mutex one_at_a_time;
+            std::lock_guard<std::mutex> guard(one_at_a_time);
             HIP_TRY(hipLaunchCooperativeKernel((const void *)k_alpha_expansion_grid, dim3(blocks), dim3(GC_THREADS), args, 0, st));
+            HIP_TRY(hipStreamSynchronize(st));
             return 0;
         }
     }

@@ -274,6 +274,21 @@ def test_graphcut_by_the_whole_device_with_a_fixed_number_of_cycles(hip, oracle,
     assert e == e_ref and np.array_equal(out, ref)
 
 
+@pytest.mark.timeout(300)
+def test_graphcut_by_the_whole_device_from_several_threads(hip):
+    """three worker threads (a context and a HIP stream each) cut graphs of 14 400 sites at the same time: cooperative launches are
+    taken one at a time (two grids that each hold a part of the CUs would wait for each other for ever); every result equals the
+    one of its graph cut alone"""
+    from concurrent.futures import ThreadPoolExecutor
+    graphs = [_large_graph(50 + i, 120, 3) for i in range(6)]
+    pairwise = 1.1 * (1 - np.eye(3))
+    alone = [hip.cut_general_graph(p, w, u, pairwise, return_energy=True) for p, w, u in graphs]
+    with ThreadPoolExecutor(max_workers=3) as pool:
+        together = list(pool.map(lambda g: hip.cut_general_graph(g[0], g[1], g[2], pairwise, return_energy=True), graphs * 2))
+    for i, (labels, energy) in enumerate(together):
+        assert energy == alone[i % 6][1] and np.array_equal(labels, alone[i % 6][0])
+
+
 def test_graphcut_by_the_whole_device_equals_one_workgroup(hip, monkeypatch):
     """160 000 sites, 335 000 edges: the grid-wide kernel against the single workgroup working out of global memory -- and with
     a pairwise matrix that is not a metric (no move skipped)"""
