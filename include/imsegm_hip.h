@@ -112,6 +112,10 @@ IMSEGM_API long imsegm_debug_conn_general_runs(void);
  * of csrc/slic.hip (k_slic_sweeps), and how many of those gave the image back to the per-sweep launches (results are identical;
  * tests use it to make sure ordinary images stay on the persistent path, bench.py to know how many sweeps one launch covers). */
 IMSEGM_API int imsegm_debug_slic_sweep_runs(long *persistent_runs_out, long *fallback_runs_out);
+/* Diagnostic (no reference counterpart): graph cuts of this process that the grid-wide kernel (csrc/graphcut.hip
+ * k_alpha_expansion_grid) gave up -- a workgroup of its grid was not resident within the bounded wait of its barrier, e.g. on a GPU
+ * shared with another process -- and the single workgroup cut again from scratch (results are identical). */
+IMSEGM_API long imsegm_debug_gc_grid_fallbacks(void);
 /* Replaces skimage.segmentation._slic._enforce_label_connectivity_cython(segments, min_size, max_size, start_label)
  * (scikit-image 0.18; the connectivity pass of skimage.segmentation.slic, reached from imsegm/superpixels.py:61-63 and
  * :104-106 with enforce_connectivity=True) on a label map given by the caller: labels = host int32, one value per

@@ -96,6 +96,7 @@ _SIGNATURES = {
     'imsegm_image2d_enforce_connectivity': (C.c_int, [_vp, _vp, C.c_long, C.c_long, C.c_int, _vp]),
     'imsegm_debug_conn_general_runs': (C.c_long, []),
     'imsegm_debug_slic_sweep_runs': (C.c_int, [_vp, _vp]),
+    'imsegm_debug_gc_grid_fallbacks': (C.c_long, []),
     'imsegm_assume_bg_on_boundary': (C.c_int, [_vp, _vp, C.c_int, C.c_int, _vp, C.c_int, _ip]),
     'imsegm_image2d_all_finite': (C.c_int, [_vp, _ip]),
     'imsegm_image2d_lm_features': (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, C.c_double, C.c_int, _vp]),
@@ -1112,6 +1113,11 @@ class DeviceArray(object):
         self.owner = owner          # keeps the session alive
         self.__cuda_array_interface__ = {'shape': tuple(shape), 'typestr': typestr, 'data': (int(ptr), False),
                                          'version': 2, 'strides': None}
+
+
+def gc_grid_fallbacks():
+    """grid-wide graph cuts of this process that gave up waiting for a workgroup and were redone by the single workgroup"""
+    return int(load_library().imsegm_debug_gc_grid_fallbacks())
 
 
 def slic_sweep_runs():

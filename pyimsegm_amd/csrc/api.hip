@@ -44,6 +44,8 @@ static Knobs read_knobs()
     k.gc_grid_min_sites = num("IMSEGM_GC_GRID_MIN_SITES", 0);
     k.gc_grid_blocks = num("IMSEGM_GC_GRID_BLOCKS", 0);
     k.gc_one_workgroup = flag("IMSEGM_GC_ONE_WORKGROUP");
+    k.gc_grid_test_absent = flag("IMSEGM_GC_GRID_TEST_ABSENT");
+    k.fused_bitmap_mb = num("IMSEGM_FUSED_BITMAP_MB", 0);
     k.sweeps_blocks_per_cu = num("IMSEGM_SWEEPS_BLOCKS_PER_CU", 0);
     k.sweeps_per_launch = num("IMSEGM_SWEEPS_PER_LAUNCH", 0);
     const char *d = getenv("IMSEGM_PHASE_DUMP");
@@ -143,6 +145,7 @@ void slic_place_state(SlicState &s, const SlicGeometry &geo, unsigned char *cent
     s.tile_rec = reinterpret_cast<Rec32 *>(tb); tb += n_tiles * SLIC_MAXC * sizeof(Rec32);
     s.tile_info = reinterpret_cast<TileInfo *>(tb); tb += n_tiles * sizeof(TileInfo);
     s.tile_k = reinterpret_cast<int *>(tb); tb += n_tiles * SLIC_MAXC * sizeof(int);
+    s.tile_rows = reinterpret_cast<uint32_t *>(tb); tb += n_tiles * SLIC_MAXC * sizeof(uint32_t);
     s.tile_count = reinterpret_cast<int *>(tb);
     s.leftover_count = s.tile_count + n_tiles + 16;
     s.leftover = s.leftover_count + 16;
@@ -622,6 +625,8 @@ int imsegm_image2d_set_labels(imsegm_image2d *im, const int32_t *labels, int n_l
 long imsegm_debug_conn_general_runs(void) { return conn_general_runs(); }
 
 void imsegm_debug_reload_env(void) { reload_knobs(); }
+
+long imsegm_debug_gc_grid_fallbacks(void) { return gc_grid_fallbacks(); }
 
 int imsegm_debug_slic_sweep_runs(long *persistent_runs_out, long *fallback_runs_out)
 {
@@ -1739,12 +1744,27 @@ static int segment_impl(imsegm_image2d *im, const imsegm_gmm *gmm, const double 
                 set_error("Cost matrix not square or not symmetric");
                 return -1;
             }
-    // (the K x K adjacency bitmap and its word prefixes: 2 x 11 GB at the 298 116 supervoxels of BASELINE configs[4], on a device
-    // of 288 GB; beyond 24 GB each the caller builds the graph with imsegm_volume_graph -- neighbour slots per label -- and cuts it
-    // with imsegm_cut_general_graph)
-    if ((double)K * (double)K / 8.0 > 24e9) {
-        set_error("segment: too many labels for the fused path (adjacency bitmap)");
-        return -1;
+    // (the K x K adjacency bitmap and its word prefixes: 2 x 11 GB at the 298 116 supervoxels of BASELINE configs[4] on a device
+    // of 288 GB.  What fits is asked of the device, not assumed: the two arrays must fit the memory that is free NOW -- plus
+    // what this session's own buffer already holds -- with a tenth of the device left over; beyond that the caller builds the graph
+    // with imsegm_volume_graph -- neighbour slots per label -- and cuts it with imsegm_cut_general_graph.  The message below is
+    // what pipelines.py recognises for that fall-back (a smaller or shared GPU must not fail in hipMalloc here).)
+    {
+        const double pair_bytes = 2.0 * (double)K * (double)cdiv(K, 32) * 4.0;
+        const int cap_mb = knobs().fused_bitmap_mb;
+        if (cap_mb > 0 && pair_bytes > 1048576.0 * cap_mb) {
+            set_error("segment: too many labels for the fused path (adjacency bitmap: IMSEGM_FUSED_BITMAP_MB)");
+            return -1;
+        }
+        if (pair_bytes > 16e6) {                  // (a 2-D image's graph: never in question, no query per image)
+            size_t free_b = 0, total_b = 0;
+            HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+            const double usable = (double)free_b + (double)im->seg.cap - 0.1 * (double)total_b;
+            if (pair_bytes > usable || pair_bytes > 48e9) {
+                set_error("segment: too many labels for the fused path (adjacency bitmap: the device has no room for it)");
+                return -1;
+            }
+        }
     }
     imsegm_ctx *ctx = im->ctx;
     hipStream_t st = ctx->stream;

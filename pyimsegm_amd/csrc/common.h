@@ -33,6 +33,8 @@ struct Knobs {
     int gc_grid_min_sites;     // IMSEGM_GC_GRID_MIN_SITES (0: default 8192): graphs of that many sites that do not fit one CU's LDS go to the grid-wide kernel
     int gc_grid_blocks;        // IMSEGM_GC_GRID_BLOCKS (0: one per CU)
     bool gc_one_workgroup;     // IMSEGM_GC_ONE_WORKGROUP: never the grid-wide kernel (tests, A/B)
+    bool gc_grid_test_absent;  // IMSEGM_GC_GRID_TEST_ABSENT: one workgroup of the grid-wide kernel never arrives (test of the bounded wait + fall-back)
+    int fused_bitmap_mb;       // IMSEGM_FUSED_BITMAP_MB (0: what the device has free): ceiling of the fused call's two K x K bit arrays (tests of the fall-back)
     int sweeps_blocks_per_cu;  // IMSEGM_SWEEPS_BLOCKS_PER_CU (0: default)
     int sweeps_per_launch;     // IMSEGM_SWEEPS_PER_LAUNCH (0: all)
     std::string phase_dump;    // IMSEGM_PHASE_DUMP (file name, empty: none)
@@ -56,12 +58,24 @@ template <typename T> __device__ __forceinline__ T *zshift(T *p, size_t zs)
 {
     // Byte arithmetic ON THE POINTER (never through an integer): the compiler knows a kernel argument to point to global memory
     // only as long as it can follow the pointer -- one uintptr_t round trip and every access behind it is a FLAT instruction
-    // (measured: the 2048^2 line fell from 6.7 to 4.5 Gpixel/s, 43 -> 1 797 flat instructions in slic.hip).  A null pointer
-    // ("output not wanted") plus zero stays null; no launch passes one together with a stride.
+    // (measured: the 2048^2 line fell from 6.7 to 4.5 Gpixel/s, 43 -> 1 797 flat instructions in slic.hip).
+    // Null stays null for EVERY image of a batch: optional arguments ("output not wanted", `order` of k_small_bfs_wave, `classes`
+    // of k_label_lut, the scaler vectors of TermsArgs) do arrive together with a stride, and the kernels test them AFTER the
+    // shift -- the select below is a scalar instruction per pointer and keeps both the provenance and the address space
+    // (relying on the compiler to fold `p + b * zs == nullptr` back onto `p` was undefined behaviour).
+    typedef typename std::conditional<std::is_const<T>::value, const char, char>::type byte_t;
+    T *const shifted = reinterpret_cast<T *>(reinterpret_cast<byte_t *>(p) + (size_t)blockIdx.z * zs);
+    return p ? shifted : nullptr;
+}
+// the same for a pointer that is NEVER null by construction (carved from a session arena): no select -- the hot SLIC kernels shift
+// two dozen of them per wave on a scalar unit that four SIMDs share
+template <typename T> __device__ __forceinline__ T *zshift_nn(T *p, size_t zs)
+{
     typedef typename std::conditional<std::is_const<T>::value, const char, char>::type byte_t;
     return reinterpret_cast<T *>(reinterpret_cast<byte_t *>(p) + (size_t)blockIdx.z * zs);
 }
 #define ZSHIFT(p, zs) (p) = ::imsegm::zshift((p), (zs))
+#define ZSHIFT_NN(p, zs) (p) = ::imsegm::zshift_nn((p), (zs))
 
 // ---------------------------------------------------------------------------------------------
 // deterministic elementary functions (mirror of oracle det_rcbrt / orc_det_cbrt / orc_det_pow24)

@@ -19,7 +19,7 @@
 #include "slic.h"
 #include <cstdio>
 #include <cstdlib>
-#include <hip/hip_cooperative_groups.h>
+#include <atomic>
 #include <mutex>
 
 namespace imsegm {
@@ -53,6 +53,7 @@ struct GcDevice {
     const int32_t *K_dev;      // when set: the real number of sites lives on the device, K is its upper bound (a batch: per image)
     size_t zs;                 // several graphs per launch (ZBatch): graph blockIdx.z, every buffer zs bytes further on per graph
     int32_t *status;           // [1] 0 ok, 1 = max-flow iteration cap hit
+    int test_absent;           // (IMSEGM_GC_GRID_TEST_ABSENT) the last workgroup of the grid-wide kernel leaves at once: a block that is not resident
     long long *dbg;            // (IMSEGM_GC_DEBUG) [16] counters / 100 MHz clock sums of thread 0, or null
 };
 #define GC_DBG_ADD(j, v)                                                                           \
@@ -523,7 +524,7 @@ __global__ void __launch_bounds__(GC_THREADS) k_alpha_expansion(GcDevice g)
             long long before = energy;
             __syncthreads();
             for (int l = 0; l < g.C; ++l)
-                if (table[l] != last_accepted && gc_expand<NPT>(g, topo, table[l], cap, height, excess, &energy, flags, calls, scratch)) last_accepted = table[l];
+                if (!(g.skip_repeat && table[l] == last_accepted) && gc_expand<NPT>(g, topo, table[l], cap, height, excess, &energy, flags, calls, scratch)) last_accepted = table[l];
             if (!(energy < before)) break;
         }
     }
@@ -542,45 +543,101 @@ __global__ void __launch_bounds__(GC_THREADS) k_alpha_expansion(GcDevice g)
 // rotating words of a control block in global memory (rotation as block_or: one barrier per reduction).  Everything another
 // workgroup may have written is read with agent-scope atomic loads (ld / st), as the single-workgroup kernel reads its global
 // scratch.  The schedule variables live in registers of every thread and evolve identically (every decision is grid uniform).
-namespace cg = cooperative_groups;
-
+//
+// The grid barrier is the library's own (round 5; cooperative_groups' grid.sync() is a software barrier of ~26 us at 256
+// workgroups on this runtime -- MI355X_MICROARCH.md price list, row barrier-cg -- and a move is a chain of hundreds of them): every
+// word another workgroup reads is an agent-scope access (write-through stores, loads that bypass L1, atomics at the memory side), so
+// the barrier needs no cache maintenance -- every wave waits for its own stores (vmcnt(0)), the workgroup meets, ONE lane arrives:
+// a counter per group of workgroups (blockIdx.x % 8 = the XCD a block is observed to run on; a matter of speed only), the last
+// arrival of a group counts on the top word, the last group writes the epoch into every group's release word, which one lane per
+// workgroup polls with relaxed loads.  Counters are monotonic (arrivals of epoch e end at e x members), nothing is reset inside the
+// launch.  Every wait is BOUNDED (2 s of the 100 MHz clock): a workgroup that gives up -- a block of the grid is not resident: the
+// device is shared with another process, ADVICE r4 -- poisons the release words, every workgroup runs the schedule down without
+// waiting or changing anything, and the host cuts the graph again with the single workgroup.
 struct GcGridCtl {
     int flags[3];
-    int status_pad;
+    int poisoned;                       // a barrier gave up: the result of this launch is void
     long long sums[3];
     long long energy;
     int table[GC_MAX_LABELS];
     int queue_sizes[GC_MAX_LABELS + 2];
+    unsigned arrive[8][32];             // one 128-byte line per word
+    unsigned top[32];
+    unsigned release[8][32];
 };
+constexpr unsigned GC_GRID_POISON = 0xffffffffu;
+constexpr long long GC_GRID_WAIT_TICKS = 200000000LL;         // 2 s at 100 MHz
 
 struct GcGrid {
-    cg::grid_group grid;
     GcGridCtl *ctl;
     int tid, nth;
-    unsigned or_calls, sum_calls;
-    __device__ GcGrid(GcGridCtl *c) : grid(cg::this_grid()), ctl(c), tid(blockIdx.x * blockDim.x + threadIdx.x),
-                                      nth(gridDim.x * blockDim.x), or_calls(0), sum_calls(0) {}
-    __device__ __forceinline__ void sync() { grid.sync(); }
+    unsigned or_calls, sum_calls, epoch;
+    int group, members, groups;
+    bool dead;
+    int *meet;                          // one LDS word of the workgroup: the outcome of the wait
+    __device__ GcGrid(GcGridCtl *c, int *lds_word)
+        : ctl(c), tid(blockIdx.x * blockDim.x + threadIdx.x), nth(gridDim.x * blockDim.x), or_calls(0), sum_calls(0), epoch(0),
+          group(blockIdx.x & 7), members(((int)gridDim.x - (int)(blockIdx.x & 7) + 7) >> 3), groups(min(8, (int)gridDim.x)), dead(false),
+          meet(lds_word) {}
+    __device__ __forceinline__ void sync()
+    {
+        if (dead) return;
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");        // every store / atomic of this wave has been performed
+        __syncthreads();
+        ++epoch;
+        if (threadIdx.x == 0) {
+            const unsigned a = __hip_atomic_fetch_add(&ctl->arrive[group][0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
+            if (a == epoch * (unsigned)members) {
+                const unsigned t = __hip_atomic_fetch_add(&ctl->top[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
+                if (t == epoch * (unsigned)groups)
+                    for (int x = 0; x < groups; ++x)
+                        __hip_atomic_fetch_max(&ctl->release[x][0], epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // (max: never below a poison)
+            }
+            int ok = 1;
+            long long t0 = 0;
+            for (unsigned spins = 1;; ++spins) {
+                const unsigned r = __hip_atomic_load(&ctl->release[group][0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (r >= epoch) {
+                    ok = r != GC_GRID_POISON;
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(1);
+                if ((spins & 255u) == 0) {
+                    const long long now = (long long)wall_clock64();
+                    if (t0 == 0) t0 = now;
+                    else if (now - t0 > GC_GRID_WAIT_TICKS) {
+                        for (int x = 0; x < 8; ++x) __hip_atomic_store(&ctl->release[x][0], GC_GRID_POISON, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        __hip_atomic_store(&ctl->poisoned, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        ok = 0;
+                        break;
+                    }
+                }
+            }
+            *meet = ok;
+        }
+        __syncthreads();
+        if (*meet == 0) dead = true;     // (the word is rewritten behind the first __syncthreads of the next barrier)
+    }
     // OR over the grid, one barrier (word r % 3 is set and read by call r; thread 0 clears word (r + 2) % 3 behind the barrier)
     __device__ __forceinline__ bool any(int pred)
     {
         int *f = ctl->flags + or_calls % 3;
-        if (pred) st(f, 1);
-        grid.sync();
+        if (pred && !dead) st(f, 1);
+        sync();
         const int r = ld(f);
-        if (tid == 0) st(ctl->flags + (or_calls + 2) % 3, 0);
+        if (tid == 0 && !dead) st(ctl->flags + (or_calls + 2) % 3, 0);
         ++or_calls;
-        return r != 0;
+        return r != 0 && !dead;
     }
     // sum over the grid, one barrier: a wave adds its total with one atomic
     __device__ __forceinline__ long long sum(long long v)
     {
         long long *acc = ctl->sums + sum_calls % 3;
         v = wave_sum_i64(v);
-        if ((threadIdx.x & 63) == 0 && v != 0) atomic_add_i64(acc, v);
-        grid.sync();
+        if ((threadIdx.x & 63) == 0 && v != 0 && !dead) atomic_add_i64(acc, v);
+        sync();
         const long long r = ld(acc);
-        if (tid == 0) st(ctl->sums + (sum_calls + 2) % 3, 0LL);
+        if (tid == 0 && !dead) st(ctl->sums + (sum_calls + 2) % 3, 0LL);
         ++sum_calls;
         return r;
     }
@@ -745,7 +802,7 @@ __device__ __forceinline__ bool gc_grid_expand(const GcDevice &g, GcGrid &q, int
     }
     q.sync();
     const long long after = gc_grid_energy(g, q, g.prop);
-    const bool accept = after < ld(&q.ctl->energy);
+    const bool accept = !q.dead && after < ld(&q.ctl->energy);
     q.sync();                   // (everybody has compared before the energy changes)
     if (accept) {
         for (int u = q.tid; u < g.K; u += q.nth) st(&g.labels[u], ld(&g.prop[u]));
@@ -758,7 +815,9 @@ __device__ __forceinline__ bool gc_grid_expand(const GcDevice &g, GcGrid &q, int
 __global__ void __launch_bounds__(GC_THREADS) k_alpha_expansion_grid(GcDevice g, GcGridCtl *ctl)
 {
     if (g.K_dev) g.K = min(*g.K_dev, g.K);
-    GcGrid q(ctl);
+    __shared__ int meet_word;
+    if (g.test_absent && blockIdx.x == gridDim.x - 1 && gridDim.x > 1) return;
+    GcGrid q(ctl, &meet_word);
     if (g.E_dev && *g.E_dev > g.E) {            // (as k_alpha_expansion: more edges than the tables hold -> a defined labelling)
         for (int u = q.tid; u < g.K; u += q.nth) g.labels[u] = 0;
         if (q.tid == 0) *g.energy_out = 0;
@@ -817,12 +876,12 @@ __global__ void __launch_bounds__(GC_THREADS) k_alpha_expansion_grid(GcDevice g,
             const long long before = ld(&ctl->energy);
             q.sync();
             for (int l = 0; l < g.C; ++l)
-                if (l != last_accepted && gc_grid_expand(g, q, l, cap, height, excess)) last_accepted = l;
+                if (!(g.skip_repeat && l == last_accepted) && gc_grid_expand(g, q, l, cap, height, excess)) last_accepted = l;
             if (!(ld(&ctl->energy) < before)) break;
         }
     }
     q.sync();
-    if (q.tid == 0) *g.energy_out = ld(&ctl->energy);
+    if (q.tid == 0 && !q.dead) *g.energy_out = ld(&ctl->energy);
 }
 
 // data costs only (GCO solveSpecialCases): independent argmin, first minimum wins
@@ -844,6 +903,9 @@ size_t alpha_expansion_work_bytes(int K, int E)
     // g_excess[K] (8-byte aligned first) | prop[K] | g_height[K] | g_cap[2E] | the control block of the grid-wide kernel
     return gc_ctl_offset(K, E) + sizeof(GcGridCtl) + 64;
 }
+
+static std::atomic<long> g_grid_fallbacks{0};
+long gc_grid_fallbacks() { return g_grid_fallbacks.load(); }
 
 int launch_alpha_expansion(GcProblem p, const int32_t *arc_start, const int32_t *arc_to, const int32_t *arc_rev,
                            const int32_t *edge_arc, int n_iter, int32_t *labels_dev, long long *energy_dev,
@@ -874,6 +936,7 @@ int launch_alpha_expansion(GcProblem p, const int32_t *arc_start, const int32_t 
     g.skip_repeat = p.metric;
     g.K_dev = p.K_dev;
     g.zs = zb.zs;
+    g.test_absent = 0;
     g.dbg = nullptr;
     static const bool debug = getenv("IMSEGM_GC_DEBUG") != nullptr;
     static long long *dbg_buf = nullptr;
@@ -931,30 +994,43 @@ int launch_alpha_expansion(GcProblem p, const int32_t *arc_start, const int32_t 
     if (level == 0 && zb.nz == 1 && p.K >= (knobs().gc_grid_min_sites > 0 ? knobs().gc_grid_min_sites : 8192) && !knobs().gc_one_workgroup) {
         int dev = 0;
         HIP_TRY(hipGetDevice(&dev));
+        // One grid-wide cut at a time PER DEVICE of this process (two cooperative grids dispatched from two streams of one device
+        // at once could each get a part of its CUs and wait at their first barrier for the rest; cuts on different devices
+        // cannot starve each other and are not serialised).  The lock also covers the first-use query of the device below.  Another
+        // PROCESS on the same GPU is not covered by any lock: there a workgroup that never becomes resident makes the barrier give
+        // up after two seconds (GcGridCtl::poisoned) and the graph is cut by the single workgroup below -- ranks should not share
+        // a GPU, IMSEGM_GC_ONE_WORKGROUP=1 avoids the wait where they must.
+        static std::mutex one_at_a_time[IMSEGM_MAX_DEVICES];
         static int cus[IMSEGM_MAX_DEVICES] = { 0 };
-        if (dev >= 0 && dev < IMSEGM_MAX_DEVICES && cus[dev] == 0) {
+        const bool known = dev >= 0 && dev < IMSEGM_MAX_DEVICES;
+        std::unique_lock<std::mutex> guard;
+        if (known) guard = std::unique_lock<std::mutex>(one_at_a_time[dev]);
+        if (known && cus[dev] == 0) {
             hipDeviceProp_t prop;
             HIP_TRY(hipGetDeviceProperties(&prop, dev));
             int per_cu = 0;
             HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)k_alpha_expansion_grid, GC_THREADS, 0));
             cus[dev] = prop.cooperativeLaunch && per_cu >= 1 ? prop.multiProcessorCount : -1;
         }
-        const int n_cu = dev >= 0 && dev < IMSEGM_MAX_DEVICES ? cus[dev] : -1;
+        const int n_cu = known ? cus[dev] : -1;
         if (n_cu > 0) {
             GcGridCtl *ctl = reinterpret_cast<GcGridCtl *>(wb + gc_ctl_offset(p.K, p.E));
             HIP_TRY(hipMemsetAsync(ctl, 0, sizeof(GcGridCtl), st));
             int blocks = std::min(n_cu, cdiv(p.K, GC_THREADS));
             if (knobs().gc_grid_blocks > 0) blocks = std::min(blocks, knobs().gc_grid_blocks);
+            g.test_absent = knobs().gc_grid_test_absent ? 1 : 0;
             void *args[] = { &g, &ctl };
-            // One grid-wide cut at a time per process: two cooperative grids dispatched from two streams at once could each get a
-            // part of the CUs and wait at their first barrier for the rest for ever.  The launch is followed to its end here (the
-            // callers synchronise a few launches later anyway; a cut of this size takes milliseconds).
-            static std::mutex one_at_a_time;
-            std::lock_guard<std::mutex> guard(one_at_a_time);
+            // The launch is followed to its end here (the callers synchronise a few launches later anyway; a cut of this size takes
+            // milliseconds).  A cooperative launch: the runtime checks the grid against what the device can hold at once.
             HIP_TRY(hipLaunchCooperativeKernel((const void *)k_alpha_expansion_grid, dim3(blocks), dim3(GC_THREADS), args, 0, st));
+            int poisoned = 0;
+            HIP_TRY(hipMemcpyAsync(&poisoned, &ctl->poisoned, sizeof(int), hipMemcpyDeviceToHost, st));
             HIP_TRY(hipStreamSynchronize(st));
-            return 0;
+            if (!poisoned) return 0;
+            g_grid_fallbacks.fetch_add(1);
+            // (not all workgroups of the grid were resident: the single workgroup below starts from scratch)
         }
+        if (guard.owns_lock()) guard.unlock();
     }
     size_t dyn = g.use_lds ? lds_need : 0;
     // one thread per node up to 1024; a small graph runs with fewer waves (the moves are chains of workgroup barriers)

@@ -266,7 +266,7 @@ void slic_place_state(imsegm::SlicState &s, const SlicGeometry &geo, unsigned ch
 inline size_t slic_cent_bytes(int K) { return (size_t)K * (5 * 8 + 16 + 9 * 8 + 16 + 4) + 256 + imsegm::SLIC_DRIFT_SLOTS * sizeof(int); }
 inline size_t slic_tiles_bytes(size_t n_tiles, size_t n)
 {
-    return n_tiles * (imsegm::SLIC_MAXC * (sizeof(imsegm::Cand) + sizeof(imsegm::Rec32) + sizeof(int)) + sizeof(imsegm::TileInfo) + sizeof(int)) +
+    return n_tiles * (imsegm::SLIC_MAXC * (sizeof(imsegm::Cand) + sizeof(imsegm::Rec32) + 2 * sizeof(int)) + sizeof(imsegm::TileInfo) + sizeof(int)) +
            n * 4 + 1024;
 }
 // the pieces of the connectivity scratch (conn_i32_bytes(n, H, W) bytes of int32 + 2 n + 64 bytes) as the kernels see them

@@ -57,6 +57,7 @@ struct SlicState {
     Rec32 *tile_rec;                // [n_tiles][SLIC_MAXC] fp32 records, same slot order as tile_cands
     TileInfo *tile_info;            // [n_tiles]
     int *tile_k;                    // [n_tiles][SLIC_MAXC] centroid index per slot (coalesced copy of Cand::k)
+    uint32_t *tile_rows;            // [n_tiles][SLIC_MAXC] bit y = row y of the 64 x 32 tile lies inside the slot's search window
     int *leftover;                  // [N] pixels to be accumulated by k_slic_leftover
     int *leftover_count;            // [1]
     int fast32;                     // 1: fp32 pre-selection allowed (Lab bounded by lab_bound)
@@ -209,6 +210,7 @@ static inline size_t conn_i32_bytes(size_t n, size_t H = 0, size_t W = 0)
     return n * 4 * 8 + ((n / 4096) + 64) * 4 + 256 + (CONN_DENSE_INTS + n_tiles * (3 * CONN_TILE_SLOTS + 1)) * 4;
 }
 long conn_general_runs();      // diagnostic: 2-D maps that left the tile path so far
+long gc_grid_fallbacks();      // diagnostic: grid-wide cuts given up (a workgroup not resident) and redone by the single workgroup
 int launch_enforce_connectivity(const int32_t *labels_in, int D, int H, int W, long min_size, long max_size,
                                 int start_label, ConnWork w, int32_t *labels_out, int *n_labels_out_host,
                                 hipStream_t st);

@@ -518,11 +518,13 @@ __device__ __forceinline__ int4 search_window(double cy, double cx, int step_y, 
 // shared by the batch; phase_prof is a profiling aid of single images)
 __device__ __forceinline__ void zshift_state(SlicState &s)
 {
+    // every table of the state is carved from the session's arenas (api.hip slic_place_state): never null -- but for `done`, which
+    // the launcher clears when the centroid update runs as separate finalize launches
     const size_t zs = s.zs;
-    ZSHIFT(s.cy, zs); ZSHIFT(s.cx, zs); ZSHIFT(s.cL, zs); ZSHIFT(s.ca, zs); ZSHIFT(s.cb, zs);
-    ZSHIFT(s.win, zs); ZSHIFT(s.acc, zs); ZSHIFT(s.premax, zs);
-    ZSHIFT(s.tile_cands, zs); ZSHIFT(s.tile_count, zs); ZSHIFT(s.tile_rec, zs); ZSHIFT(s.tile_info, zs); ZSHIFT(s.tile_k, zs);
-    ZSHIFT(s.leftover, zs); ZSHIFT(s.leftover_count, zs); ZSHIFT(s.mdc, zs); ZSHIFT(s.drift, zs); ZSHIFT(s.done, zs);
+    ZSHIFT_NN(s.cy, zs); ZSHIFT_NN(s.cx, zs); ZSHIFT_NN(s.cL, zs); ZSHIFT_NN(s.ca, zs); ZSHIFT_NN(s.cb, zs);
+    ZSHIFT_NN(s.win, zs); ZSHIFT_NN(s.acc, zs); ZSHIFT_NN(s.premax, zs);
+    ZSHIFT_NN(s.tile_cands, zs); ZSHIFT_NN(s.tile_count, zs); ZSHIFT_NN(s.tile_rec, zs); ZSHIFT_NN(s.tile_info, zs); ZSHIFT_NN(s.tile_k, zs); ZSHIFT_NN(s.tile_rows, zs);
+    ZSHIFT_NN(s.leftover, zs); ZSHIFT_NN(s.leftover_count, zs); ZSHIFT_NN(s.mdc, zs); ZSHIFT_NN(s.drift, zs); ZSHIFT(s.done, zs);
 }
 
 // regular grid of skimage.util.regular_grid: centroid k = (iy, ix) in row-major order
@@ -705,6 +707,7 @@ k_slic_bin(SlicState s, int tiles_x, int n_tiles, int max_cand, Cand *__restrict
     const double ref0 = __shfl(cd.cL, src, 64), ref1 = __shfl(cd.ca, src, 64), ref2 = __shfl(cd.cb, src, 64);
     const double c0 = cd.cL - ref0, c1 = cd.ca - ref1, c2 = cd.cb - ref2;
     Rec32 rc;
+    uint32_t rows_mask;
     rc.q0 = (float)(sw * (ryc * ryc + rxc * rxc) + (c0 * c0 + c1 * c1 + c2 * c2));
     rc.qy = (float)(-2.0 * sw * ryc);
     rc.qx = (float)(-2.0 * sw * rxc);
@@ -715,7 +718,11 @@ k_slic_bin(SlicState s, int tiles_x, int n_tiles, int max_cand, Cand *__restrict
     {
         const int rlo = min(max(cd.win.x - ty0, 0), TILE_Y), rhi = min(max(cd.win.y - ty0, 0), TILE_Y);
         const int xlo = min(max(cd.win.z - tx0, 0), TILE_X), xhi = min(max(cd.win.w - tx0, 0), TILE_X);
-        rc.meta = (uint32_t)rlo | ((uint32_t)rhi << 8) | ((uint32_t)xlo << 16) | ((uint32_t)xhi << 24);
+        // bit 23 (xlo <= 64 leaves it free): the window spans the tile's columns inside the image -- with the row mask below the
+        // whole window test of k_slic_assign_dot's common case is two scalar compares
+        const uint32_t spans_x = (xlo == 0 && xhi >= tx1 - tx0) ? (1u << 23) : 0u;
+        rc.meta = (uint32_t)rlo | ((uint32_t)rhi << 8) | ((uint32_t)xlo << 16) | ((uint32_t)xhi << 24) | spans_x;
+        rows_mask = (rhi >= 32 ? 0xffffffffu : (1u << rhi) - 1u) & ~((1u << rlo) - 1u);          // (rlo <= rhi <= 32)
     }
     // fp32 copies of the older record layout (exact / first-sweep paths)
     cd.ry = (float)(cd.cy - (double)ty0);
@@ -726,6 +733,7 @@ k_slic_bin(SlicState s, int tiles_x, int n_tiles, int max_cand, Cand *__restrict
         tile_cands[(size_t)tile * MAXC + rank] = cd;
         s.tile_rec[(size_t)tile * MAXC + rank] = rc;
         s.tile_k[(size_t)tile * MAXC + rank] = k;
+        s.tile_rows[(size_t)tile * MAXC + rank] = rows_mask;
     }
     float qm[5] = { have ? fabsf(rc.qy) : 0.f, have ? fabsf(rc.qx) : 0.f, have ? fabsf(rc.qL) : 0.f,
                     have ? fabsf(rc.qa) : 0.f, have ? fabsf(rc.qb) : 0.f };
@@ -988,7 +996,7 @@ k_slic_assign(SlicState s, const double *__restrict__ lab, int32_t *__restrict__
               const Cand *__restrict__ tile_cands, const int *__restrict__ tile_count)
 {
     zshift_state(s);
-    ZSHIFT(lab, s.zs); ZSHIFT(labels, s.zs); ZSHIFT(tile_cands, s.zs); ZSHIFT(tile_count, s.zs);
+    ZSHIFT_NN(lab, s.zs); ZSHIFT_NN(labels, s.zs); ZSHIFT_NN(tile_cands, s.zs); ZSHIFT_NN(tile_count, s.zs);
     __shared__ long long lacc[MAXC][9];
     __shared__ int lk_old[MAXC];
 
@@ -1243,7 +1251,7 @@ k_slic_assign_dot(SlicState s, const double *__restrict__ lab, int32_t *__restri
                   const TileInfo *__restrict__ tile_info, const int *__restrict__ tile_k)
 {
     zshift_state(s);
-    ZSHIFT(lab, s.zs); ZSHIFT(labels, s.zs); ZSHIFT(tile_cands, s.zs); ZSHIFT(tile_rec, s.zs); ZSHIFT(tile_info, s.zs); ZSHIFT(tile_k, s.zs);
+    ZSHIFT_NN(lab, s.zs); ZSHIFT_NN(labels, s.zs); ZSHIFT_NN(tile_cands, s.zs); ZSHIFT_NN(tile_rec, s.zs); ZSHIFT_NN(tile_info, s.zs); ZSHIFT_NN(tile_k, s.zs);
     __shared__ long long lacc[MAXC][9];
     __shared__ int lk[MAXC];
     long long t_prev = (PROF && s.phase_prof) ? (long long)__builtin_readcyclecounter() : 0;
@@ -1273,7 +1281,26 @@ k_slic_assign_dot(SlicState s, const double *__restrict__ lab, int32_t *__restri
     const bool xin = x < s.W;
     const double sw = s.spatial_weight;
 
+#ifndef SLIC_SADDR
+#define SLIC_SADDR 1
+#endif
     double pLu[U][ROWS], pAu[U][ROWS], pBu[U][ROWS];
+#if SLIC_SADDR
+    // one scalar base per (row, plane) and ONE 32-bit byte offset per lane (global_load ... v_off, s[base]): the row index of a
+    // unit is wave-uniform, so the 64-bit address arithmetic is scalar -- three vector instructions instead of fifty-five per wave.
+    // A lane right of the image reads column 0 of its row, a row below the image reads row 0 (in bounds; never used).
+    const unsigned xoff8 = (unsigned)(xin ? x : 0) * 8u;
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r) {
+            const int y = tile_row * TILE_Y + relbase + u * ROWS + r;
+            const char *row = reinterpret_cast<const char *>(lab + (size_t)(y < s.H ? y : 0) * s.W);
+            pLu[u][r] = *reinterpret_cast<const double *>(row + xoff8);
+            pAu[u][r] = *reinterpret_cast<const double *>(row + plane * sizeof(double) + xoff8);
+            pBu[u][r] = *reinterpret_cast<const double *>(row + 2 * plane * sizeof(double) + xoff8);
+        }
+#else
 #pragma unroll
     for (int u = 0; u < U; ++u)
 #pragma unroll
@@ -1285,7 +1312,9 @@ k_slic_assign_dot(SlicState s, const double *__restrict__ lab, int32_t *__restri
             pAu[u][r] = lab[plane + p];
             pBu[u][r] = lab[2 * plane + p];
         }
+#endif
     const int my_k = tile_k[(size_t)tile * MAXC + lane];
+    const unsigned my_rows = s.tile_rows[(size_t)tile * MAXC + lane];      // rows of the tile inside the slot's window (bit mask)
     // candidate table in registers: lane c holds the record of candidate c; the loop fetches the fields
     // with v_readlane, i.e. without any memory latency between two candidates
     const float4 my_ra = reinterpret_cast<const float4 *>(rec + lane)[0];      // q0, qx, qy, qL
@@ -1351,6 +1380,186 @@ k_slic_assign_dot(SlicState s, const double *__restrict__ lab, int32_t *__restri
 #ifndef SLIC_PH2
 #define SLIC_PH2 8
 #endif
+#ifndef SLIC_LOOP_R5
+#define SLIC_LOOP_R5 1
+#endif
+#if SLIC_LOOP_R5
+        // Round 5: the same arithmetic per candidate and the same margins, with the instruction count of everything AROUND the
+        // five multiply-adds cut down (the kernel is bound by vector instruction issue: 823 per wave before this, counted in the
+        // ISA): the running best / second best live in register PAIRS (f2) so that the break bound and the near-tie test are
+        // packed operations (the bound: 31 instead of 83 instructions per evaluation); ONE path through the candidate
+        // body -- a candidate whose window does not cover the whole unit masks its distances with four selects behind a uniform
+        // branch instead of taking a second copy of the body (the two copies met in ten register moves per candidate); the
+        // near-tie test of the four rows ends in ONE wave vote.
+        constexpr int PH1 = SLIC_PH1, PH2 = SLIC_PH2;
+        const float INF = __builtin_inff();
+        const float sw32 = (float)sw;
+        const double ref0 = ti->ref[0], ref1 = ti->ref[1], ref2 = ti->ref[2];
+        f2 fL[2], fA[2], fB[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            fL[h] = (f2){ (float)(pL[2 * h] - ref0), (float)(pL[2 * h + 1] - ref0) };
+            fA[h] = (f2){ (float)(pA[2 * h] - ref1), (float)(pA[2 * h + 1] - ref1) };
+            fB[h] = (f2){ (float)(pB[2 * h] - ref2), (float)(pB[2 * h + 1] - ref2) };
+        }
+        const float X = (float)(lane - TILE_X / 2);
+        const float Y0 = (float)(rel0 - TILE_Y / 2);
+        const f2 Yp[2] = { (f2){ Y0, Y0 + 1.f }, (f2){ Y0 + 2.f, Y0 + 3.f } };
+        // bound of the cross terms of this pixel over all candidates of the tile (row pairs)
+        f2 xbp[2];
+        {
+            const float base = 16.f * ti->Qy + 32.f * ti->Qx, QL = ti->QL, Qa = ti->Qa, Qb = ti->Qb;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                xbp[h].x = fmaf(QL, fabsf(fL[h].x), fmaf(Qa, fabsf(fA[h].x), fmaf(Qb, fabsf(fB[h].x), base)));
+                xbp[h].y = fmaf(QL, fabsf(fL[h].y), fmaf(Qa, fabsf(fA[h].y), fmaf(Qb, fabsf(fB[h].y), base)));
+            }
+        }
+        f2 b1p[2] = { (f2){ INF, INF }, (f2){ INF, INF } }, b2p[2] = { (f2){ INF, INF }, (f2){ INF, INF } };
+        const int rows_valid = min(ROWS, s.H - wy0);
+        const unsigned rows_all = (1u << rows_valid) - 1u;      // the rows of this unit inside the image
+        unsigned wbound = 0x7f800000u;           // float bits of the break threshold (uniform)
+        int c_end = nc;
+#define RL_F(v) __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), c))
+#define F2S(v) ((f2){ (v), (v) })
+        for (int c = 0; c < nc; ++c) {
+            if (c == PH1 || c == PH2) {
+                // W >= max over the pixels of this wave of (best D + margin), D = d + P with the pixel's own term
+                // P = sw * (Y^2 + X^2) + |f|^2; the factors 1.002 / 0.002 * (xb + 1) cover the fp32 evaluation error and the
+                // near-tie margin many times over, so neither the order of the additions nor a pixel outside the image that
+                // is counted in (a looser bound: the loop ends later, never earlier than it may) matters for the result
+                float wl = 0.f;
+                if (rows_valid == ROWS) {
+                    // (everything below is loop invariant but for b1: the two opaque copies keep the compiler from hoisting it out
+                    // of the loop into eight registers of every wave -- the registers decide between five and six waves per SIMD)
+                    float Xv = X, c002 = 0.002f;
+                    asm volatile("" : "+v"(Xv), "+v"(c002));
+                    const float X2 = Xv * Xv;
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const f2 sp = __builtin_elementwise_fma(Yp[h], Yp[h], F2S(X2));
+                        f2 P = F2S(sw32) * sp;
+                        P = __builtin_elementwise_fma(fB[h], fB[h], P);
+                        P = __builtin_elementwise_fma(fA[h], fA[h], P);
+                        P = __builtin_elementwise_fma(fL[h], fL[h], P);
+                        f2 t = b1p[h] + P;
+                        t.x = fmaxf(t.x, 0.f);
+                        t.y = fmaxf(t.y, 0.f);
+                        const f2 v = __builtin_elementwise_fma(t, F2S(1.002f), __builtin_elementwise_fma(F2S(c002), xbp[h], F2S(c002)));
+                        wl = fmaxf(fmaxf(v.x, v.y), wl);
+                    }
+                    wl = xin ? wl : 0.f;
+                } else {
+                    // the unit hangs over the lower edge of the image (H not a multiple of 4: one row of waves): no early end --
+                    // a second form of the bound here is hoisted out of the loop by the compiler into every wave's preamble
+                    wl = INF;
+                }
+                int wi = __float_as_int(wl);                  // wl >= 0: integer order == float order
+                wi = max(wi, __builtin_amdgcn_update_dpp(0, wi, 0x111, 0xf, 0xf, false));
+                wi = max(wi, __builtin_amdgcn_update_dpp(0, wi, 0x112, 0xf, 0xf, false));
+                wi = max(wi, __builtin_amdgcn_update_dpp(0, wi, 0x114, 0xf, 0xf, false));
+                wi = max(wi, __builtin_amdgcn_update_dpp(0, wi, 0x118, 0xf, 0xf, false));
+                wi = max(wi, __builtin_amdgcn_update_dpp(0, wi, 0x142, 0xa, 0xf, false));
+                wi = max(wi, __builtin_amdgcn_update_dpp(0, wi, 0x143, 0xc, 0xf, false));
+                wbound = (unsigned)__builtin_amdgcn_readlane(wi, 63);
+            }
+            if ((unsigned)__builtin_amdgcn_readlane(__float_as_int(my_rb.z), c) > wbound) {
+                c_end = c;
+                break;
+            }
+            // the rows of this unit inside the candidate's window: four bits of the tile's row mask (k_slic_bin)
+            const unsigned rows4 = ((unsigned)__builtin_amdgcn_readlane((int)my_rows, c) >> rel0) & 15u;
+            if (rows4 != 0) {
+                const float q0 = RL_F(my_ra.x), qx = RL_F(my_ra.y), qy = RL_F(my_ra.z), qL = RL_F(my_ra.w), qa = RL_F(my_rb.x),
+                            qb = RL_F(my_rb.y);
+                const unsigned meta = (unsigned)__builtin_amdgcn_readlane(__float_as_int(my_rb.w), c);
+                const f2 e2 = F2S(fmaf(qx, X, q0));
+                f2 d01 = __builtin_elementwise_fma(F2S(qy), Yp[0], e2);
+                f2 d23 = __builtin_elementwise_fma(F2S(qy), Yp[1], e2);
+                d01 = __builtin_elementwise_fma(F2S(qL), fL[0], d01);
+                d23 = __builtin_elementwise_fma(F2S(qL), fL[1], d23);
+                d01 = __builtin_elementwise_fma(F2S(qa), fA[0], d01);
+                d23 = __builtin_elementwise_fma(F2S(qa), fA[1], d23);
+                d01 = __builtin_elementwise_fma(F2S(qb), fB[0], d01);
+                d23 = __builtin_elementwise_fma(F2S(qb), fB[1], d23);
+                if (!(rows4 == rows_all && (meta & (1u << 23)))) {
+                    // the window does not cover every pixel of this unit: the pixels outside it do not see this candidate
+                    const int xlo = (meta >> 16) & 0x7f, xhi = meta >> 24;
+                    const bool inx = lane >= xlo && lane < xhi;
+                    d01.x = (inx && (rows4 & 1u)) ? d01.x : INF;
+                    d01.y = (inx && (rows4 & 2u)) ? d01.y : INF;
+                    d23.x = (inx && (rows4 & 4u)) ? d23.x : INF;
+                    d23.y = (inx && (rows4 & 8u)) ? d23.y : INF;
+                }
+#define SLIC_SELECT(r, b1v, b2v, dval)                                                             \
+    {                                                                                              \
+        const float d_ = (dval);                                                                   \
+        const bool lt_ = d_ < (b1v);                                                               \
+        (b2v) = __builtin_amdgcn_fmed3f((b1v), (b2v), d_);                                         \
+        (b1v) = lt_ ? d_ : (b1v);                                                                  \
+        best_s[r] = lt_ ? c : best_s[r];                                                           \
+    }
+                SLIC_SELECT(0, b1p[0].x, b2p[0].x, d01.x) SLIC_SELECT(1, b1p[0].y, b2p[0].y, d01.y)
+                SLIC_SELECT(2, b1p[1].x, b2p[1].x, d23.x) SLIC_SELECT(3, b1p[1].y, b2p[1].y, d23.y)
+#undef SLIC_SELECT
+            }
+        }
+#undef RL_F
+        PHASE_MARK(2)                              // candidate loop
+        if (PROF && s.phase_prof && tid == 0) prof_slot[9] += c_end;
+        // near ties (second best inside the margin for some pixel of the row): exact fp64 evaluation, in the
+        // order of _slic.pyx, of the candidates whose fp32 value lies within the margin of the fp32 best --
+        // the exact winner is always one of them (its d32 exceeds b1 by at most half the margin).
+        // (b2 finite implies b1 finite implies a slot in best_s; b2 infinite: gap and margin are both infinite, hence the test)
+        const float U16 = 16.f * 5.9604644775390625e-8f * 1.01f;
+        f2 mg[2];
+        bool near_r[ROWS];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            mg[h] = __builtin_elementwise_fma(F2S(U16), __builtin_elementwise_fma(F2S(4.f), xbp[h], b1p[h] + b2p[h]), F2S(1e-30f));
+            const f2 gap = b2p[h] - b1p[h];
+            near_r[2 * h] = b2p[h].x < INF && !(gap.x > mg[h].x);
+            near_r[2 * h + 1] = b2p[h].y < INF && !(gap.y > mg[h].y);
+        }
+        if (__any(near_r[0] || near_r[1] || near_r[2] || near_r[3])) {
+#pragma unroll
+            for (int r = 0; r < ROWS; ++r) {
+                const bool near2 = near_r[r];
+                if (!__any(near2)) continue;
+                const float m = r & 1 ? mg[r >> 1].y : mg[r >> 1].x, b1r = r & 1 ? b1p[r >> 1].y : b1p[r >> 1].x;
+                const float l = r & 1 ? fL[r >> 1].y : fL[r >> 1].x, a = r & 1 ? fA[r >> 1].y : fA[r >> 1].x,
+                            b = r & 1 ? fB[r >> 1].y : fB[r >> 1].x;
+                const float Yr = Y0 + (float)r;
+                const double fy = (double)(wy0 + r), fx = (double)x;
+                double bd = DBL_MAX;
+                int bs = -1, bk = 0x7fffffff;
+#define RL_F(v) __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), c))
+                for (int c = 0; c < c_end; ++c) {
+                    const unsigned meta = (unsigned)__builtin_amdgcn_readlane(__float_as_int(my_rb.w), c);
+                    const int rlo = meta & 0xff, rhi = (meta >> 8) & 0xff, xlo = (meta >> 16) & 0x7f, xhi = meta >> 24;
+                    if (rel0 + r < rlo || rel0 + r >= rhi) continue;
+                    float d = fmaf(RL_F(my_ra.y), X, RL_F(my_ra.x));
+                    d = fmaf(RL_F(my_ra.z), Yr, d);
+                    d = fmaf(RL_F(my_ra.w), l, d);
+                    d = fmaf(RL_F(my_rb.x), a, d);
+                    d = fmaf(RL_F(my_rb.y), b, d);
+                    const bool take = near2 && lane >= xlo && lane < xhi && d - b1r <= m;
+                    if (!__any(take)) continue;
+                    const double e = exact_dist(cand[c], fy, fx, sw, pL[r], pA[r], pB[r]);
+                    const int k = cand[c].k;
+                    if (take && ((bd > e) || (bd == e && k < bk))) {
+                        bd = e;
+                        bs = c;
+                        bk = k;
+                    }
+                }
+#undef RL_F
+                if (near2) best_s[r] = bs;
+            }
+        }
+#undef F2S
+        PHASE_MARK(3)                              // near-tie resolution
+#else   // SLIC_LOOP_R5 == 0: the loop as it stood at the end of round 4 (kept for A/B runs on one GPU box: tools/build_variant.sh)
         constexpr int PH1 = SLIC_PH1, PH2 = SLIC_PH2;
         const float INF = __builtin_inff();
         const float sw32 = (float)sw;
@@ -1411,7 +1620,7 @@ k_slic_assign_dot(SlicState s, const double *__restrict__ lab, int32_t *__restri
                 break;
             }
             const unsigned meta = (unsigned)__builtin_amdgcn_readlane(__float_as_int(my_rb.w), c);
-            const int rlo = meta & 0xff, rhi = (meta >> 8) & 0xff, xlo = (meta >> 16) & 0xff, xhi = meta >> 24;
+            const int rlo = meta & 0xff, rhi = (meta >> 8) & 0xff, xlo = (meta >> 16) & 0x7f, xhi = meta >> 24;
             if (rhi > rel0 && rlo < rel0 + ROWS) {
                 Rec32 cur;
                 cur.q0 = RL_F(my_ra.x); cur.qx = RL_F(my_ra.y); cur.qy = RL_F(my_ra.z); cur.qL = RL_F(my_ra.w);
@@ -1476,7 +1685,7 @@ k_slic_assign_dot(SlicState s, const double *__restrict__ lab, int32_t *__restri
 #define RL_F(v) __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), c))
             for (int c = 0; c < c_end; ++c) {
                 const unsigned meta = (unsigned)__builtin_amdgcn_readlane(__float_as_int(my_rb.w), c);
-                const int rlo = meta & 0xff, rhi = (meta >> 8) & 0xff, xlo = (meta >> 16) & 0xff, xhi = meta >> 24;
+                const int rlo = meta & 0xff, rhi = (meta >> 8) & 0xff, xlo = (meta >> 16) & 0x7f, xhi = meta >> 24;
                 if (rel0 + r < rlo || rel0 + r >= rhi) continue;
                 float d = fmaf(RL_F(my_ra.y), X, RL_F(my_ra.x));
                 d = fmaf(RL_F(my_ra.z), Yr, d);
@@ -1497,6 +1706,7 @@ k_slic_assign_dot(SlicState s, const double *__restrict__ lab, int32_t *__restri
             if (near2) best_s[r] = bs;
         }
         PHASE_MARK(3)                              // near-tie resolution
+#endif  // SLIC_LOOP_R5
     }
 
     // labels: a pixel no window covers keeps its previous assignment (nearest_segments persists in
@@ -1510,17 +1720,21 @@ k_slic_assign_dot(SlicState s, const double *__restrict__ lab, int32_t *__restri
     for (int r = 0; r < ROWS; ++r) {
         const int y = wy0 + r;
         if (!(xin && y < s.H)) continue;
-        const int p = y * s.W + x;
+#if SLIC_SADDR
+        int32_t &label_here = *reinterpret_cast<int32_t *>(reinterpret_cast<char *>(labels + (size_t)y * s.W) + (unsigned)x * 4u);
+#else
+        int32_t &label_here = labels[y * s.W + x];
+#endif
         if (best_s[r] >= 0) {
-            labels[p] = win_k[r];
+            label_here = win_k[r];
             pending |= 1u << r;
             continue;
         }
-        if (best_s[r] <= -2) labels[p] = -(best_s[r] + 2);
+        if (best_s[r] <= -2) label_here = -(best_s[r] + 2);
         if (ACCUM) {
             // no slot in the tile's list (tile without a list, or a pixel no window covers, which keeps its
             // previous label): straight to the global sums -- rare
-            const int k = best_s[r] <= -2 ? -(best_s[r] + 2) : labels[p];
+            const int k = best_s[r] <= -2 ? -(best_s[r] + 2) : label_here;
             if (k >= 0) {
                 // (with the centroid update inside this kernel such a contribution is not covered by the arrival count of its
                 // centroid: the host is told and redoes the sweeps with separate finalize launches)
@@ -2024,7 +2238,7 @@ k_slic_sweeps(SlicState s, const double *__restrict__ lab, int32_t *__restrict__
                         break;
                     }
                     const unsigned meta = (unsigned)__builtin_amdgcn_readlane(__float_as_int(my_rb.w), c);
-                    const int rlo = meta & 0xff, rhi = (meta >> 8) & 0xff, xlo = (meta >> 16) & 0xff, xhi = meta >> 24;
+                    const int rlo = meta & 0xff, rhi = (meta >> 8) & 0xff, xlo = (meta >> 16) & 0x7f, xhi = meta >> 24;
                     if (rhi > rel0 && rlo < rel0 + ROWS) {
                         const float q0 = RL_F(my_ra.x), qx = RL_F(my_ra.y), qy = RL_F(my_ra.z), qL = RL_F(my_ra.w);
                         const float qa = RL_F(my_rb.x), qb = RL_F(my_rb.y);
@@ -2081,7 +2295,7 @@ k_slic_sweeps(SlicState s, const double *__restrict__ lab, int32_t *__restrict__
                     int bs = -1, bk = 0x7fffffff;
                     for (int c = 0; c < c_end; ++c) {
                         const unsigned meta = (unsigned)__builtin_amdgcn_readlane(__float_as_int(my_rb.w), c);
-                        const int rlo = meta & 0xff, rhi = (meta >> 8) & 0xff, xlo = (meta >> 16) & 0xff, xhi = meta >> 24;
+                        const int rlo = meta & 0xff, rhi = (meta >> 8) & 0xff, xlo = (meta >> 16) & 0x7f, xhi = meta >> 24;
                         if (rel0 + r < rlo || rel0 + r >= rhi) continue;
                         float d = fmaf(RL_F(my_ra.y), X, RL_F(my_ra.x));
                         d = fmaf(RL_F(my_ra.z), Yr, d);

@@ -11,10 +11,12 @@ device sessions:
   parity tests, and give the same integer energies;
 * the mixture fit is scikit-learn on the host, configured as ``graph_cuts.py:73-163`` configures it.
 
-What the path does not touch -- the alternative initialisations of the class model (``GMM_kmeans``, ``GMM_Otsu``,
-``kmeans``, ``BGM``, ``Otsu``), ``estim_gmm_params``, ``compute_multivarian_otsu``, the transition-count helpers ... --
-is NOT restated here: with a reference package installed behind the ``imsegm`` overlay those names resolve to the
-reference's own functions (module ``__getattr__`` below), without one they do not exist.
+The alternative class models of ``graph_cuts.py:73-163`` (``GMM_kmeans``, ``GMM_Otsu``, ``kmeans``, ``kmeans_quantiles``,
+``BGM``, ``Otsu``) are configured here too (:func:`estim_class_model`, one table row each): they are public parameters of the
+pipelines and must work on a standalone install.  What the path never touches -- ``estim_gmm_params``, the transition-count
+helpers, the pairwise-matrix estimators ... -- is NOT restated: with a reference package installed behind the ``imsegm``
+overlay those names resolve to the reference's own functions (module ``__getattr__`` below), without one they raise an
+``AttributeError`` that says so.
 """
 import logging
 
@@ -32,10 +34,6 @@ MIN_UNARY_PROB = 0.01
 MAX_PAIRWISE_COST = 1e5
 #: edge weights live in [1 / MIN_MAX_EDGE_WEIGHT, MIN_MAX_EDGE_WEIGHT] (``graph_cuts.py:30``)
 MIN_MAX_EDGE_WEIGHT = 1e3
-
-#: class models :func:`estim_class_model` builds itself; every other name of ``graph_cuts.py:73-163`` goes to the reference
-_OWN_MODELS = ('GMM', )
-
 
 def __getattr__(name):
     """names of the reference module this file does not restate: the reference's own, when one is installed"""
@@ -90,24 +88,99 @@ def predict_proba(model, features):
     return model.predict_proba(features)
 
 
+def compute_multivarian_otsu(features):
+    """ a two-class labelling of feature vectors from one Otsu threshold per feature (``graph_cuts.py:166-193``): every
+    column votes ``value > its threshold``; a column after the first votes the other way round when that agrees better
+    with the mean vote of the columns before it; a sample is True when more than half of its columns say so
+    """
+    table = np.asarray(features)
+    votes = np.zeros(table.shape)
+    for col in range(table.shape[-1]):
+        vote = table[:, col] > _threshold_otsu(table[:, col])
+        if col:
+            consensus = votes[:, :col].mean(axis=1)
+            if np.abs(~vote - consensus).mean() < np.abs(vote - consensus).mean():
+                vote = ~vote
+        votes[:, col] = vote
+    return votes.mean(axis=1) > 0.5
+
+
+def _threshold_otsu(values, nbins=256):
+    """Otsu's threshold of a sample over a 256-bin histogram -- ``skimage.filters.threshold_otsu`` when scikit-image is
+    installed, otherwise the same published rule (the bin centre that maximises the between-class variance
+    w0 w1 (m0 - m1)^2 of the split behind it)"""
+    try:
+        from skimage.filters import threshold_otsu
+        return threshold_otsu(values, nbins)
+    except ImportError:
+        pass
+    counts, rims = np.histogram(np.ravel(values), nbins)
+    mids = (rims[:-1] + rims[1:]) / 2.
+    counts = counts.astype(float)
+    below, above = np.cumsum(counts), np.cumsum(counts[::-1])[::-1]
+    with np.errstate(divide='ignore', invalid='ignore'):
+        mean_below = np.cumsum(counts * mids) / below
+        mean_above = (np.cumsum((counts * mids)[::-1]) / above[::-1])[::-1]
+    between = below[:-1] * above[1:] * (mean_below[:-1] - mean_above[1:])**2
+    return mids[:-1][np.argmax(between)]
+
+
+def estim_class_model_kmeans(features, nb_classes, init_type='k-means++', max_iter=99):
+    """ k-means labels and a one-step mixture on the same features (``graph_cuts.py:255-285``): ``'quantiles'`` starts two
+    Lloyd iterations from the 5 .. 95 % percentiles of every feature, anything else is scikit-learn's initialisation of
+    that name with int(sqrt(max_iter)) restarts.  Returns (mixture, labels).
+    """
+    from sklearn import cluster, mixture
+    if init_type == 'quantiles':
+        start = np.percentile(features, np.linspace(5, 95, nb_classes).tolist(), axis=0)
+        kmeans = cluster.KMeans(nb_classes, init=np.array(start), max_iter=2)
+    else:
+        kmeans = cluster.KMeans(nb_classes, init=init_type, max_iter=max_iter, n_init=max(1, int(np.sqrt(max_iter))))
+    labels = kmeans.fit_predict(features)
+    return mixture.GaussianMixture(nb_classes, covariance_type='full', max_iter=1).fit(features, labels), labels
+
+
+def _class_model_plan(estim_model, nb_classes):
+    """(mixture class name, parameter overrides, labelling run before the fit) for an ``estim_model`` of
+    ``graph_cuts.py:73-163``.  The labelling does not steer the fit (scikit-learn's mixtures ignore ``y``); it runs because
+    the reference runs it: the k-means variants draw from numpy's global random stream, which the mixture's own
+    initialisation continues."""
+    parts = estim_model.split('_')
+    family, start = parts[0], (parts[-1] if len(parts) > 1 else '')
+    from sklearn import cluster
+    if family == 'GMM' and start == 'kmeans':
+        return 'GaussianMixture', dict(n_init=1), lambda fts, it: cluster.KMeans(nb_classes, init='k-means++').fit_predict(fts)
+    if family == 'GMM' and start == 'Otsu':
+        return 'GaussianMixture', dict(n_init=1), lambda fts, it: compute_multivarian_otsu(fts)
+    if family == 'kmeans':
+        how = 'quantiles' if start == 'quantiles' else 'k-means++'
+        return 'GaussianMixture', dict(max_iter=1), lambda fts, it: estim_class_model_kmeans(fts, nb_classes, how, it)[1]
+    if family == 'BGM':
+        return 'BayesianGaussianMixture', {}, None
+    if family == 'Otsu' and nb_classes == 2:
+        return 'GaussianMixture', dict(max_iter=1, n_init=1), lambda fts, it: compute_multivarian_otsu(fts)
+    return 'GaussianMixture', {}, None           # 'GMM', and -- as in the reference -- any name it does not know
+
+
 def estim_class_model(features, nb_classes, estim_model='GMM', pca_coef=None, use_scaler=True, max_iter=99):
     """ the class model of the unsupervised pipelines, fitted on the superpixel features with scikit-learn on the host:
-    ``Pipeline([StandardScaler,] [PCA,] GaussianMixture(full covariance, int(sqrt(max_iter)) restarts))`` -- what
-    ``graph_cuts.py:73-163`` builds for ``estim_model='GMM'``, the model the hot path uses and the device evaluates.
-    Any other ``estim_model`` of the reference is the reference's business (installed behind the overlay, or an error).
+    ``Pipeline([StandardScaler,] [PCA,] mixture(full covariance, int(sqrt(max_iter)) restarts))`` -- what
+    ``graph_cuts.py:73-163`` builds.  ``estim_model='GMM'`` is the model the hot path uses and the device evaluates; the
+    other names of the reference ('GMM_kmeans', 'GMM_Otsu', 'kmeans', 'kmeans_quantiles', 'BGM', 'Otsu') change the
+    mixture's parameters as :func:`_class_model_plan` lists them.
     """
-    if estim_model not in _OWN_MODELS:
-        return reference_attribute('graph_cuts', 'estim_class_model')(features, nb_classes, estim_model, pca_coef, use_scaler,
-                                                                       max_iter)
     from sklearn import decomposition, mixture, pipeline, preprocessing
+    kind, overrides, labelling = _class_model_plan(estim_model, nb_classes)
+    params = dict(n_components=nb_classes, covariance_type='full', n_init=max(1, int(np.sqrt(max_iter))), max_iter=max_iter)
+    params.update(overrides)
     steps = []
     if use_scaler:
         steps += [('std_scaler', preprocessing.StandardScaler())]
     if pca_coef is not None:
         steps += [('reduce_dim', decomposition.PCA(pca_coef))]
-    restarts = max(1, int(np.sqrt(max_iter)))
-    steps += [('model', mixture.GaussianMixture(nb_classes, covariance_type='full', n_init=restarts, max_iter=max_iter))]
-    return pipeline.Pipeline(steps).fit(features)
+    steps += [('model', getattr(mixture, kind)(**params))]
+    labels = labelling(features, max_iter) if labelling is not None else None
+    return pipeline.Pipeline(steps).fit(features, labels) if labels is not None else pipeline.Pipeline(steps).fit(features)
 
 
 def get_vertexes_edges(segments):

@@ -637,13 +637,19 @@ def _gray3d_on_session(sess, image, nb_classes, dict_features, spacing, sp_size,
     proba = model.predict_proba(features)
     logging.debug('list of probabilities: %r', proba.shape)
 
-    if float(sess.n_labels)**2 / 8. <= 24e9:           # (the bound of imsegm_image2d_segment: K x K bits in HBM)
-        # fused: graph, unary / edge terms ('model' edges), alpha-expansion and the gather in one call
+    segm = None
+    try:
+        # fused: graph, unary / edge terms ('model' edges), alpha-expansion and the gather in one call -- when the K x K bit
+        # arrays of imsegm_image2d_segment fit the memory the device has free (the library asks hipMemGetInfo)
         from pyimsegm_amd.graph_cuts import compute_pairwise_cost
         use_gc = not (np.isscalar(gc_regul) and gc_regul <= 0)
         segm = sess.segment(compute_pairwise_cost(gc_regul, proba.shape), 'model', proba=proba, use_graphcut=use_gc,
                             pinned=False)['segm']
-    else:
+    except _hip.HipError as ex:
+        if 'fused path' not in str(ex) and 'out of memory' not in str(ex).lower():
+            raise
+        logging.info('volume graph by neighbour tables (%s)', ex)
+    if segm is None:
         graph_labels = segment_graph_cut_general(_ShapeOnly(sess.shape), proba, image, features, gc_regul, _session=sess)
         segm, _ = sess.gather(graph_labels)
     return segm

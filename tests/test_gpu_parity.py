@@ -274,6 +274,35 @@ def test_graphcut_by_the_whole_device_with_a_fixed_number_of_cycles(hip, oracle,
     assert e == e_ref and np.array_equal(out, ref)
 
 
+@pytest.mark.parametrize('side,n_iter,C', [(24, 1, 3), (30, 4, 4), (100, 2, 3), (100, 5, 4)])
+def test_graphcut_fixed_cycles_with_a_pairwise_matrix_that_is_not_a_metric(hip, oracle, side, n_iter, C):
+    """with V(a, a) != 0 (not a metric: GCO's moves are not exact optima) the move that repeats the last accepted
+    label must be run in the fixed-cycle schedule too (n_iter > 0) -- by the single workgroup (576 / 900 sites) and by the
+    grid-wide kernel (10 000 sites); the oracle runs every move"""
+    pairs, weights, unary = _large_graph(60 + side + C, side, C)
+    pairwise = 0.7 + 1.1 * (1 - np.eye(C))
+    ref, e_ref = oracle.cut_general_graph(pairs, weights, unary, pairwise, n_iter=n_iter, return_energy=True)
+    out, e = hip.cut_general_graph(pairs, weights, unary, pairwise, n_iter=n_iter, return_energy=True)
+    assert e == e_ref and np.array_equal(out, ref)
+
+
+@pytest.mark.timeout(120)
+def test_graphcut_by_the_whole_device_when_a_workgroup_never_arrives(hip, oracle, monkeypatch):
+    """on a GPU shared with another process a workgroup of the grid-wide kernel may not become resident; every wait of
+    its barrier is bounded (2 s), the launch is given up as a whole and the single workgroup cuts the graph from scratch -- here
+    one workgroup leaves at once (IMSEGM_GC_GRID_TEST_ABSENT): same labelling and energy as the oracle, one fall-back counted"""
+    pairs, weights, unary = _large_graph(71, 100, 3)
+    pairwise = 1.2 * (1 - np.eye(3))
+    ref, e_ref = oracle.cut_general_graph(pairs, weights, unary, pairwise, return_energy=True)
+    before = hip.gc_grid_fallbacks()
+    out, e = hip.cut_general_graph(pairs, weights, unary, pairwise, return_energy=True)
+    assert hip.gc_grid_fallbacks() == before and e == e_ref and np.array_equal(out, ref)
+    monkeypatch.setenv('IMSEGM_GC_GRID_TEST_ABSENT', '1')
+    out, e = hip.cut_general_graph(pairs, weights, unary, pairwise, return_energy=True)
+    assert hip.gc_grid_fallbacks() == before + 1
+    assert e == e_ref and np.array_equal(out, ref)
+
+
 @pytest.mark.timeout(300)
 def test_graphcut_by_the_whole_device_from_several_threads(hip):
     """three worker threads (a context and a HIP stream each) cut graphs of 14 400 sites at the same time: cooperative launches are

@@ -258,6 +258,26 @@ def test_pipe_gray3d(oracle):
     assert np.bincount(left.ravel()).argmax() != np.bincount(right.ravel()).argmax()
 
 
+def test_pipe_gray3d_when_the_device_has_no_room_for_the_bit_arrays(hip, monkeypatch):
+    """the fused graph / terms / cut call needs two K x K bit arrays; the library asks the device what is free and
+    refuses when they do not fit (here forced by IMSEGM_FUSED_BITMAP_MB = 1 MB against 2 x 3.4 MB at 5 270 supervoxels), and the
+    pipeline falls back to the neighbour-table graph + imsegm_cut_general_graph -- same segmentation"""
+    from pyimsegm_amd import pipelines
+    rng = np.random.default_rng(3)
+    image = rng.random((12, 200, 220)) / 2.
+    image[:, :, :110] += 0.5
+    np.random.seed(0)
+    fused = pipelines.pipe_gray3d_slic_features_model_graphcut(image, 2, {'color': ['mean', 'std']}, sp_size=10, spacing=(1, 1, 1))
+    monkeypatch.setenv('IMSEGM_FUSED_BITMAP_MB', '1')
+    sess = hip.Volume3D(*image.shape).set_labels((np.arange(image.size).reshape(image.shape) // 7 % 6000).astype(np.int64))
+    with pytest.raises(hip.HipError, match='fused path'):
+        sess.segment(np.zeros((2, 2)), 'model', proba=np.full((6000, 2), 0.5), pinned=False)
+    sess.close()
+    np.random.seed(0)
+    by_tables = pipelines.pipe_gray3d_slic_features_model_graphcut(image, 2, {'color': ['mean', 'std']}, sp_size=10, spacing=(1, 1, 1))
+    assert np.array_equal(fused, by_tables) and len(np.unique(fused)) == 2
+
+
 def test_all_finite_and_session_reuse(hip):
     """imsegm_image2d_all_finite on the uploaded pixels (float32 / float64 volumes, a float64 colour image, uint8), and the
     pipeline on a recycled volume session: the second volume of a shape gives what a fresh session gives"""

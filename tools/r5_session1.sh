@@ -1,0 +1,17 @@
+#!/bin/bash
+# round 5, first GPU session: the parity suite, the A/B of the assignment loop (round-4 loop vs round-5 loop) and the default line
+REPO=${GRAFT_REPO_ROOT:-/root/repo}
+OUT=$REPO/gpurun_out/r5s1
+rm -rf $OUT && mkdir -p $OUT
+cd $REPO
+timeout 900 python -m pytest tests -m gpu -x -q > $OUT/pytest.log 2>&1; echo "pytest rc=$?" | tee -a $OUT/pytest.log
+tail -5 $OUT/pytest.log
+timeout 500 bash tools/variants_k.sh "slic_assign|k_slic_bin|centroid_fin" base new > $OUT/variants.txt 2>&1
+cat $OUT/variants.txt
+timeout 600 python bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err; echo "bench rc=$?"
+python - <<'P'
+import json
+d=json.loads(open('/root/repo/gpurun_out/r5s1/bench_default.json').read().strip().splitlines()[-1])
+print(d['value'], d['ms_per_step'], d['roofline']['frac'], d['roofline']['avg_kernel_us'], d.get('gpu_equals_reference_run'))
+for k,v in d['other_configs'].items(): print(k, v.get('value'), v.get('ms_per_step'), (v.get('roofline') or {}).get('frac'), v.get('gpu_equals_reference_run'))
+P
