@@ -369,7 +369,8 @@ k_pre_fused(const T *__restrict__ img, int H, int W, int normalize, const double
             double X = lin0 * 0.412453 + lin1 * 0.357580 + lin2 * 0.180423;
             double Y = lin0 * 0.212671 + lin1 * 0.715160 + lin2 * 0.072169;
             double Z = lin0 * 0.019334 + lin1 * 0.119193 + lin2 * 0.950227;
-            double f[3] = { X / 0.95047, Y / 1.0, Z / 1.08883 };
+            // (uint8 pixels: X, Z are 0 or >= 5e-5 -- the exact three-instruction quotient; Y / 1.0 = Y)
+            double f[3] = { DIV_CONST_IN_RANGE(X, 0.95047), Y, DIV_CONST_IN_RANGE(Z, 1.08883) };
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
                 double t = f[c];
@@ -1422,7 +1423,62 @@ k_slic_assign_dot(SlicState s, const double *__restrict__ lab, int32_t *__restri
         int c_end = nc;
 #define RL_F(v) __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), c))
 #define F2S(v) ((f2){ (v), (v) })
-        for (int c = 0; c < nc; ++c) {
+#ifndef SLIC_REC_SGPR
+#define SLIC_REC_SGPR 1
+#endif
+        // one candidate against the four rows of this unit; `rows4` = which of them lie inside its window (from k_slic_bin's row mask)
+        auto evaluate = [&](const int c, const float q0, const float qx, const float qy, const float qL, const float qa, const float qb,
+                            const unsigned meta, const unsigned rows4) __attribute__((always_inline)) {
+            {
+                const f2 e2 = F2S(fmaf(qx, X, q0));
+                f2 d01 = __builtin_elementwise_fma(F2S(qy), Yp[0], e2);
+                f2 d23 = __builtin_elementwise_fma(F2S(qy), Yp[1], e2);
+                d01 = __builtin_elementwise_fma(F2S(qL), fL[0], d01);
+                d23 = __builtin_elementwise_fma(F2S(qL), fL[1], d23);
+                d01 = __builtin_elementwise_fma(F2S(qa), fA[0], d01);
+                d23 = __builtin_elementwise_fma(F2S(qa), fA[1], d23);
+                d01 = __builtin_elementwise_fma(F2S(qb), fB[0], d01);
+                d23 = __builtin_elementwise_fma(F2S(qb), fB[1], d23);
+                if (!(rows4 == rows_all && (meta & (1u << 23)))) {
+                    // the window does not cover every pixel of this unit: the pixels outside it do not see this candidate
+                    const int xlo = (meta >> 16) & 0x7f, xhi = meta >> 24;
+                    const bool inx = lane >= xlo && lane < xhi;
+                    d01.x = (inx && (rows4 & 1u)) ? d01.x : INF;
+                    d01.y = (inx && (rows4 & 2u)) ? d01.y : INF;
+                    d23.x = (inx && (rows4 & 4u)) ? d23.x : INF;
+                    d23.y = (inx && (rows4 & 8u)) ? d23.y : INF;
+                }
+#define SLIC_SELECT(r, b1v, b2v, dval)                                                             \
+    {                                                                                              \
+        const float d_ = (dval);                                                                   \
+        const bool lt_ = d_ < (b1v);                                                               \
+        (b2v) = __builtin_amdgcn_fmed3f((b1v), (b2v), d_);                                         \
+        (b1v) = lt_ ? d_ : (b1v);                                                                  \
+        best_s[r] = lt_ ? c : best_s[r];                                                           \
+    }
+                SLIC_SELECT(0, b1p[0].x, b2p[0].x, d01.x) SLIC_SELECT(1, b1p[0].y, b2p[0].y, d01.y)
+                SLIC_SELECT(2, b1p[1].x, b2p[1].x, d23.x) SLIC_SELECT(3, b1p[1].y, b2p[1].y, d23.y)
+#undef SLIC_SELECT
+            }
+        };
+        int c_first = 0;
+#if SLIC_REC_SGPR
+        // the first PH1 candidates are evaluated by every wave (no bound exists before them): their records come through the
+        // scalar cache (uniform address: s_load_dwordx8) instead of seven v_readlane each -- the vector unit is the bottleneck
+        {
+            const unsigned *__restrict__ rows_tab = s.tile_rows + (size_t)tile * MAXC;
+#pragma unroll
+            for (int c = 0; c < PH1; ++c) {
+                if (c >= nc) break;
+                const unsigned rows4 = (rows_tab[c] >> rel0) & 15u;
+                if (rows4 == 0) continue;
+                const Rec32 r = rec[c];
+                evaluate(c, r.q0, r.qx, r.qy, r.qL, r.qa, r.qb, r.meta, rows4);
+            }
+            c_first = min(nc, PH1);
+        }
+#endif
+        for (int c = c_first; c < nc; ++c) {
             if (c == PH1 || c == PH2) {
                 // W >= max over the pixels of this wave of (best D + margin), D = d + P with the pixel's own term
                 // P = sw * (Y^2 + X^2) + |f|^2; the factors 1.002 / 0.002 * (xb + 1) cover the fp32 evaluation error and the
@@ -1467,42 +1523,10 @@ k_slic_assign_dot(SlicState s, const double *__restrict__ lab, int32_t *__restri
                 c_end = c;
                 break;
             }
-            // the rows of this unit inside the candidate's window: four bits of the tile's row mask (k_slic_bin)
             const unsigned rows4 = ((unsigned)__builtin_amdgcn_readlane((int)my_rows, c) >> rel0) & 15u;
-            if (rows4 != 0) {
-                const float q0 = RL_F(my_ra.x), qx = RL_F(my_ra.y), qy = RL_F(my_ra.z), qL = RL_F(my_ra.w), qa = RL_F(my_rb.x),
-                            qb = RL_F(my_rb.y);
-                const unsigned meta = (unsigned)__builtin_amdgcn_readlane(__float_as_int(my_rb.w), c);
-                const f2 e2 = F2S(fmaf(qx, X, q0));
-                f2 d01 = __builtin_elementwise_fma(F2S(qy), Yp[0], e2);
-                f2 d23 = __builtin_elementwise_fma(F2S(qy), Yp[1], e2);
-                d01 = __builtin_elementwise_fma(F2S(qL), fL[0], d01);
-                d23 = __builtin_elementwise_fma(F2S(qL), fL[1], d23);
-                d01 = __builtin_elementwise_fma(F2S(qa), fA[0], d01);
-                d23 = __builtin_elementwise_fma(F2S(qa), fA[1], d23);
-                d01 = __builtin_elementwise_fma(F2S(qb), fB[0], d01);
-                d23 = __builtin_elementwise_fma(F2S(qb), fB[1], d23);
-                if (!(rows4 == rows_all && (meta & (1u << 23)))) {
-                    // the window does not cover every pixel of this unit: the pixels outside it do not see this candidate
-                    const int xlo = (meta >> 16) & 0x7f, xhi = meta >> 24;
-                    const bool inx = lane >= xlo && lane < xhi;
-                    d01.x = (inx && (rows4 & 1u)) ? d01.x : INF;
-                    d01.y = (inx && (rows4 & 2u)) ? d01.y : INF;
-                    d23.x = (inx && (rows4 & 4u)) ? d23.x : INF;
-                    d23.y = (inx && (rows4 & 8u)) ? d23.y : INF;
-                }
-#define SLIC_SELECT(r, b1v, b2v, dval)                                                             \
-    {                                                                                              \
-        const float d_ = (dval);                                                                   \
-        const bool lt_ = d_ < (b1v);                                                               \
-        (b2v) = __builtin_amdgcn_fmed3f((b1v), (b2v), d_);                                         \
-        (b1v) = lt_ ? d_ : (b1v);                                                                  \
-        best_s[r] = lt_ ? c : best_s[r];                                                           \
-    }
-                SLIC_SELECT(0, b1p[0].x, b2p[0].x, d01.x) SLIC_SELECT(1, b1p[0].y, b2p[0].y, d01.y)
-                SLIC_SELECT(2, b1p[1].x, b2p[1].x, d23.x) SLIC_SELECT(3, b1p[1].y, b2p[1].y, d23.y)
-#undef SLIC_SELECT
-            }
+            if (rows4 == 0) continue;
+            evaluate(c, RL_F(my_ra.x), RL_F(my_ra.y), RL_F(my_ra.z), RL_F(my_ra.w), RL_F(my_rb.x), RL_F(my_rb.y),
+                     (unsigned)__builtin_amdgcn_readlane(__float_as_int(my_rb.w), c), rows4);
         }
 #undef RL_F
         PHASE_MARK(2)                              // candidate loop

@@ -292,10 +292,9 @@ k_vol_assign(VolState s, const double *__restrict__ vol, int32_t *__restrict__ l
                     double d = (dz + dy + dx2) * s.spatial_weight;
                     const double t = pv[r] - rc.cv;
                     d = d + t * t;
-                    if (inx && (best_d[r] > d || (best_d[r] == d && ck < best_k[r]))) {
-                        best_d[r] = d;
-                        best_k[r] = ck;
-                    }
+                    const bool take = inx && (best_d[r] > d || (best_d[r] == d && ck < best_k[r]));
+                    best_d[r] = take ? d : best_d[r];               // (selects, no change of the exec mask)
+                    best_k[r] = take ? ck : best_k[r];
                 }
                 if (++since_refresh == 2) {                    // refresh the bound
                     since_refresh = 0;
@@ -570,9 +569,7 @@ k_vol_assign_f32(VolState s, const float *__restrict__ vol, int32_t *__restrict_
                 float mine = lbl[0];
 #pragma unroll
                 for (int j = 1; j < PER; ++j) mine = fminf(mine, lbl[j]);
-                float wm = mine;
-#pragma unroll
-                for (int off = 32; off > 0; off >>= 1) wm = fminf(wm, __shfl_xor(wm, off, 64));
+                const float wm = wave_min_nonneg_f32(mine);          // (bounds are sums of squares times a positive weight, or +inf)
                 if (!(wm <= wave_worst) || wm == INFINITY) break;  // (+inf: nothing left in the batch)
                 const unsigned long long own = __ballot(mine == wm);
                 const int src = __ffsll((long long)own) - 1;
@@ -601,10 +598,9 @@ k_vol_assign_f32(VolState s, const float *__restrict__ vol, int32_t *__restrict_
                     float d = ((dz + dy) + dx2) * sw;
                     const float t = pv[r] - rc.cv;
                     d = d + t * t;
-                    if (inx && (best_d[r] > d || (best_d[r] == d && ck < best_k[r]))) {
-                        best_d[r] = d;
-                        best_k[r] = ck;
-                    }
+                    const bool take = inx && (best_d[r] > d || (best_d[r] == d && ck < best_k[r]));
+                    best_d[r] = take ? d : best_d[r];               // (selects, no change of the exec mask)
+                    best_k[r] = take ? ck : best_k[r];
                 }
                 if (++since_refresh == 2) {
                     since_refresh = 0;
@@ -612,9 +608,7 @@ k_vol_assign_f32(VolState s, const float *__restrict__ vol, int32_t *__restrict_
 #pragma unroll
                     for (int r = 0; r < VROWS; ++r)
                         if (xin && (y0 + r) < s.H) m2 = fmaxf(m2, best_d[r]);
-#pragma unroll
-                    for (int off = 32; off > 0; off >>= 1) m2 = fmaxf(m2, __shfl_xor(m2, off, 64));
-                    wave_worst = m2;
+                    wave_worst = wave_max_nonneg_f32(m2);           // (distances: never negative; +inf while a voxel has no candidate)
                 }
             }
         }
