@@ -1381,17 +1381,20 @@ k_slic_assign_dot(SlicState s, const double *__restrict__ lab, int32_t *__restri
 #ifndef SLIC_PH2
 #define SLIC_PH2 8
 #endif
-#ifndef SLIC_LOOP_R5
-#define SLIC_LOOP_R5 1
-#endif
-#if SLIC_LOOP_R5
         // Round 5: the same arithmetic per candidate and the same margins, with the instruction count of everything AROUND the
-        // five multiply-adds cut down (the kernel is bound by vector instruction issue: 823 per wave before this, counted in the
-        // ISA): the running best / second best live in register PAIRS (f2) so that the break bound and the near-tie test are
-        // packed operations (the bound: 31 instead of 83 instructions per evaluation); ONE path through the candidate
-        // body -- a candidate whose window does not cover the whole unit masks its distances with four selects behind a uniform
-        // branch instead of taking a second copy of the body (the two copies met in ten register moves per candidate); the
-        // near-tie test of the four rows ends in ONE wave vote.
+        // five multiply-adds cut down -- the kernel is bound by instruction issue (823 vector + 443 scalar instructions per wave
+        // before, counted in the ISA and by SQ_INSTS_*):
+        //  * the running best / second best live in register PAIRS (f2): the break bound and the near-tie test are packed
+        //    operations (the bound: 26 instead of 83 instructions per evaluation), the near-tie test of the four rows ends in ONE
+        //    wave vote;
+        //  * ONE path through the candidate body -- a candidate whose window does not cover the whole unit masks its distances with
+        //    four selects behind a uniform branch instead of taking a second copy of the body (the two copies met in ten register
+        //    moves per candidate);
+        //  * which rows of the unit a window covers comes from a 32-bit row mask of the tile per candidate (k_slic_bin: tile_rows)
+        //    and "spans the tile's columns" from bit 23 of the record's meta word: two scalar compares where the window was decoded
+        //    and compared field by field (30 scalar instructions per candidate);
+        //  * the first PH1 candidates, which every wave evaluates, come through the scalar cache (s_load_dwordx8) instead of seven
+        //    v_readlane each.
         constexpr int PH1 = SLIC_PH1, PH2 = SLIC_PH2;
         const float INF = __builtin_inff();
         const float sw32 = (float)sw;
@@ -1417,7 +1420,7 @@ k_slic_assign_dot(SlicState s, const double *__restrict__ lab, int32_t *__restri
             }
         }
         f2 b1p[2] = { (f2){ INF, INF }, (f2){ INF, INF } }, b2p[2] = { (f2){ INF, INF }, (f2){ INF, INF } };
-        const int rows_valid = min(ROWS, s.H - wy0);
+        const int rows_valid = max(0, min(ROWS, s.H - wy0));    // (0: a wave of the last workgroup below the image)
         const unsigned rows_all = (1u << rows_valid) - 1u;      // the rows of this unit inside the image
         unsigned wbound = 0x7f800000u;           // float bits of the break threshold (uniform)
         int c_end = nc;
@@ -1583,154 +1586,6 @@ k_slic_assign_dot(SlicState s, const double *__restrict__ lab, int32_t *__restri
         }
 #undef F2S
         PHASE_MARK(3)                              // near-tie resolution
-#else   // SLIC_LOOP_R5 == 0: the loop as it stood at the end of round 4 (kept for A/B runs on one GPU box: tools/build_variant.sh)
-        constexpr int PH1 = SLIC_PH1, PH2 = SLIC_PH2;
-        const float INF = __builtin_inff();
-        const float sw32 = (float)sw;
-        const double ref0 = ti->ref[0], ref1 = ti->ref[1], ref2 = ti->ref[2];
-        f2 fL[2], fA[2], fB[2];
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            fL[h] = (f2){ (float)(pL[2 * h] - ref0), (float)(pL[2 * h + 1] - ref0) };
-            fA[h] = (f2){ (float)(pA[2 * h] - ref1), (float)(pA[2 * h + 1] - ref1) };
-            fB[h] = (f2){ (float)(pB[2 * h] - ref2), (float)(pB[2 * h + 1] - ref2) };
-        }
-        const float X = (float)(lane - TILE_X / 2);
-        const float Y0 = (float)(rel0 - TILE_Y / 2);
-        const f2 Yp[2] = { (f2){ Y0, Y0 + 1.f }, (f2){ Y0 + 2.f, Y0 + 3.f } };
-        // bound of the cross terms of this pixel over all candidates of the tile
-        float xb[ROWS];
-        {
-            const float base = 16.f * ti->Qy + 32.f * ti->Qx, QL = ti->QL, Qa = ti->Qa, Qb = ti->Qb;
-#pragma unroll
-            for (int r = 0; r < ROWS; ++r) {
-                const float l = r & 1 ? fL[r >> 1].y : fL[r >> 1].x, a = r & 1 ? fA[r >> 1].y : fA[r >> 1].x,
-                            b = r & 1 ? fB[r >> 1].y : fB[r >> 1].x;
-                xb[r] = fmaf(QL, fabsf(l), fmaf(Qa, fabsf(a), fmaf(Qb, fabsf(b), base)));
-            }
-        }
-        float b1[ROWS], b2[ROWS];
-#pragma unroll
-        for (int r = 0; r < ROWS; ++r) b1[r] = b2[r] = INF;
-        const int rows_valid = min(ROWS, s.H - wy0), lanes_valid = min(TILE_X, s.W - tx0);
-        unsigned wbound = 0x7f800000u;           // float bits of the break threshold (uniform)
-        int c_end = nc;
-#define RL_F(v) __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), c))
-        for (int c = 0; c < nc; ++c) {
-            if (c == PH1 || c == PH2) {
-                float wl = 0.f;
-#pragma unroll
-                for (int r = 0; r < ROWS; ++r) {
-                    float l = r & 1 ? fL[r >> 1].y : fL[r >> 1].x, a = r & 1 ? fA[r >> 1].y : fA[r >> 1].x,
-                          b = r & 1 ? fB[r >> 1].y : fB[r >> 1].x, xbr = xb[r], Xv = X;
-                    // (keeps this rarely executed arithmetic inside the branch instead of in 9 hoisted registers)
-                    asm volatile("" : "+v"(l), "+v"(a), "+v"(b), "+v"(xbr), "+v"(Xv));
-                    const float Yr = Y0 + (float)r;
-                    const float P = fmaf(sw32, fmaf(Yr, Yr, Xv * Xv), fmaf(l, l, fmaf(a, a, b * b)));
-                    const float v = fmaf(fmaxf(b1[r] + P, 0.f), 1.002f, 0.002f * (xbr + 1.f));
-                    if (xin && r < rows_valid) wl = fmaxf(wl, v);
-                }
-                int wi = __float_as_int(wl);                  // wl >= 0: integer order == float order
-                wi = max(wi, __builtin_amdgcn_update_dpp(0, wi, 0x111, 0xf, 0xf, false));
-                wi = max(wi, __builtin_amdgcn_update_dpp(0, wi, 0x112, 0xf, 0xf, false));
-                wi = max(wi, __builtin_amdgcn_update_dpp(0, wi, 0x114, 0xf, 0xf, false));
-                wi = max(wi, __builtin_amdgcn_update_dpp(0, wi, 0x118, 0xf, 0xf, false));
-                wi = max(wi, __builtin_amdgcn_update_dpp(0, wi, 0x142, 0xa, 0xf, false));
-                wi = max(wi, __builtin_amdgcn_update_dpp(0, wi, 0x143, 0xc, 0xf, false));
-                wbound = (unsigned)__builtin_amdgcn_readlane(wi, 63);
-            }
-            if ((unsigned)__builtin_amdgcn_readlane(__float_as_int(my_rb.z), c) > wbound) {
-                c_end = c;
-                break;
-            }
-            const unsigned meta = (unsigned)__builtin_amdgcn_readlane(__float_as_int(my_rb.w), c);
-            const int rlo = meta & 0xff, rhi = (meta >> 8) & 0xff, xlo = (meta >> 16) & 0x7f, xhi = meta >> 24;
-            if (rhi > rel0 && rlo < rel0 + ROWS) {
-                Rec32 cur;
-                cur.q0 = RL_F(my_ra.x); cur.qx = RL_F(my_ra.y); cur.qy = RL_F(my_ra.z); cur.qL = RL_F(my_ra.w);
-                cur.qa = RL_F(my_rb.x); cur.qb = RL_F(my_rb.y);
-                const float e = fmaf(cur.qx, X, cur.q0);
-#define SLIC_SELECT(r, dval)                                                                       \
-    {                                                                                              \
-        const float d_ = (dval);                                                                   \
-        const bool lt_ = d_ < b1[r];                                                               \
-        b2[r] = __builtin_amdgcn_fmed3f(b1[r], b2[r], d_);                                         \
-        b1[r] = lt_ ? d_ : b1[r];                                                                  \
-        best_s[r] = lt_ ? c : best_s[r];                                                           \
-    }
-                if (rlo <= rel0 && rhi >= rel0 + rows_valid && xlo == 0 && xhi >= lanes_valid) {
-                    // the window covers every pixel of this wave (the common case): packed, branch free
-                    const f2 e2 = (f2){ e, e };
-                    f2 d01 = __builtin_elementwise_fma((f2){ cur.qy, cur.qy }, Yp[0], e2);
-                    f2 d23 = __builtin_elementwise_fma((f2){ cur.qy, cur.qy }, Yp[1], e2);
-                    d01 = __builtin_elementwise_fma((f2){ cur.qL, cur.qL }, fL[0], d01);
-                    d23 = __builtin_elementwise_fma((f2){ cur.qL, cur.qL }, fL[1], d23);
-                    d01 = __builtin_elementwise_fma((f2){ cur.qa, cur.qa }, fA[0], d01);
-                    d23 = __builtin_elementwise_fma((f2){ cur.qa, cur.qa }, fA[1], d23);
-                    d01 = __builtin_elementwise_fma((f2){ cur.qb, cur.qb }, fB[0], d01);
-                    d23 = __builtin_elementwise_fma((f2){ cur.qb, cur.qb }, fB[1], d23);
-                    SLIC_SELECT(0, d01.x) SLIC_SELECT(1, d01.y) SLIC_SELECT(2, d23.x) SLIC_SELECT(3, d23.y)
-                } else {
-                    const bool inx = lane >= xlo && lane < xhi;
-#pragma unroll
-                    for (int r = 0; r < ROWS; ++r) {
-                        if (rel0 + r < rlo || rel0 + r >= rhi) continue;        // wave-uniform
-                        const float l = r & 1 ? fL[r >> 1].y : fL[r >> 1].x, a = r & 1 ? fA[r >> 1].y : fA[r >> 1].x,
-                                    b = r & 1 ? fB[r >> 1].y : fB[r >> 1].x;
-                        float d = fmaf(cur.qy, Y0 + (float)r, e);
-                        d = fmaf(cur.qL, l, d);
-                        d = fmaf(cur.qa, a, d);
-                        d = fmaf(cur.qb, b, d);
-                        d = inx ? d : INF;
-                        SLIC_SELECT(r, d)
-                    }
-                }
-#undef SLIC_SELECT
-            }
-        }
-#undef RL_F
-        PHASE_MARK(2)                              // candidate loop
-        if (PROF && s.phase_prof && tid == 0) prof_slot[9] += c_end;
-        // near ties (second best inside the margin for some pixel of the row): exact fp64 evaluation, in the
-        // order of _slic.pyx, of the candidates whose fp32 value lies within the margin of the fp32 best --
-        // the exact winner is always one of them (its d32 exceeds b1 by at most half the margin).
-        const float U16 = 16.f * 5.9604644775390625e-8f * 1.01f;
-#pragma unroll
-        for (int r = 0; r < ROWS; ++r) {
-            const float m = U16 * (b1[r] + b2[r] + 4.f * xb[r]) + 1e-30f;
-            const bool near2 = best_s[r] >= 0 && b2[r] < INF && !(b2[r] - b1[r] > m);
-            if (!__any(near2)) continue;
-            const float l = r & 1 ? fL[r >> 1].y : fL[r >> 1].x, a = r & 1 ? fA[r >> 1].y : fA[r >> 1].x,
-                        b = r & 1 ? fB[r >> 1].y : fB[r >> 1].x;
-            const float Yr = Y0 + (float)r;
-            const double fy = (double)(wy0 + r), fx = (double)x;
-            double bd = DBL_MAX;
-            int bs = -1, bk = 0x7fffffff;
-#define RL_F(v) __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), c))
-            for (int c = 0; c < c_end; ++c) {
-                const unsigned meta = (unsigned)__builtin_amdgcn_readlane(__float_as_int(my_rb.w), c);
-                const int rlo = meta & 0xff, rhi = (meta >> 8) & 0xff, xlo = (meta >> 16) & 0x7f, xhi = meta >> 24;
-                if (rel0 + r < rlo || rel0 + r >= rhi) continue;
-                float d = fmaf(RL_F(my_ra.y), X, RL_F(my_ra.x));
-                d = fmaf(RL_F(my_ra.z), Yr, d);
-                d = fmaf(RL_F(my_ra.w), l, d);
-                d = fmaf(RL_F(my_rb.x), a, d);
-                d = fmaf(RL_F(my_rb.y), b, d);
-                const bool take = near2 && lane >= xlo && lane < xhi && d - b1[r] <= m;
-                if (!__any(take)) continue;
-                const double e = exact_dist(cand[c], fy, fx, sw, pL[r], pA[r], pB[r]);
-                const int k = cand[c].k;
-                if (take && ((bd > e) || (bd == e && k < bk))) {
-                    bd = e;
-                    bs = c;
-                    bk = k;
-                }
-            }
-#undef RL_F
-            if (near2) best_s[r] = bs;
-        }
-        PHASE_MARK(3)                              // near-tie resolution
-#endif  // SLIC_LOOP_R5
     }
 
     // labels: a pixel no window covers keeps its previous assignment (nearest_segments persists in
