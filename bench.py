@@ -1155,6 +1155,9 @@ def bench_volume(args, group, shape=None, quick=False):
         'stage_ms_per_step': {g: round(ms, 3) for g, (ms, n) in stage_ms.items()},
         'host_model_fit_ms_per_step': round(fit_ms, 1), 'ms_per_step_excluding_fit': round(elapsed / steps * 1e3 - fit_ms, 1),
         'host_model_fit_threads': fit_threads,
+        'host_model_fit': 'scikit-learn GaussianMixture(full, n_init=9) as graph_cuts.py:73-163 configures it; the restarts of its EM loop '
+                          'run side by side (graph_cuts.fit_mixture_restarts: same random stream, same calls, parameters bit for bit '
+                          'those of mixture.fit -- tests/test_class_models.py), %d worker threads' % __import__('pyimsegm_amd.graph_cuts', fromlist=['x'])._fit_workers(),
     }
     del segm
     if group.world == 1:

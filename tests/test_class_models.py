@@ -61,3 +61,51 @@ def test_kmeans_model_and_labels():
     assert len(set(labels[:50])) == 1 and len(set(labels[50:])) == 1 and labels[0] != labels[-1]
     model, labels = graph_cuts.estim_class_model_kmeans(fts, 2, init_type='quantiles')
     assert len(set(labels[:50])) == 1 and labels[0] != labels[-1]
+
+
+@pytest.mark.parametrize('kind,n_init', [('GaussianMixture', 5), ('BayesianGaussianMixture', 3)])
+def test_restarts_side_by_side_give_the_parameters_of_fit(kind, n_init):
+    """graph_cuts.fit_mixture_restarts: the restarts of scikit-learn's EM loop in worker threads -- fitted parameters, lower bound,
+    iteration count and the state of the random stream afterwards bit for bit those of `mixture.fit` (120 000 x 3: above the size
+    where a multi-threaded BLAS splits its reductions, the case that needs the one-thread pools inside)"""
+    from sklearn import mixture
+    rng = np.random.default_rng(7)
+    n = 120000
+    table = np.vstack([rng.normal([0, 0, 0], [1, .5, .8], (n // 3, 3)), rng.normal([3, 1, 2], [.7, .6, .5], (n // 3, 3)),
+                       rng.normal([-2, 2, 1], [.5, .9, .6], (n - 2 * (n // 3), 3))]) + rng.normal(0, 2., (n, 3))
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        np.random.seed(5)
+        plain = getattr(mixture, kind)(n_components=3, covariance_type='full', n_init=n_init, max_iter=30).fit(table)
+        after_plain = np.random.random()
+        np.random.seed(5)
+        ours = graph_cuts.fit_mixture_restarts(getattr(mixture, kind)(n_components=3, covariance_type='full', n_init=n_init, max_iter=30),
+                                               table, workers=4)
+        after_ours = np.random.random()
+    for name in ('weights_', 'means_', 'covariances_', 'precisions_cholesky_', 'precisions_'):
+        assert np.array_equal(getattr(plain, name), getattr(ours, name)), name
+    assert (plain.n_iter_, plain.lower_bound_, plain.converged_) == (ours.n_iter_, ours.lower_bound_, ours.converged_)
+    assert after_plain == after_ours
+    assert np.array_equal(plain.predict_proba(table[:2000]), ours.predict_proba(table[:2000]))
+
+
+def test_restarts_fall_back_to_fit(monkeypatch):
+    """one worker, or something unexpected inside the side-by-side path (here: the thread-pool limiter refuses): scikit-learn's own
+    loop from where the random stream stood -- same result as `fit`"""
+    import threadpoolctl
+    from sklearn import mixture
+    rng = np.random.default_rng(1)
+    table = np.vstack([rng.normal(0, 1, (300, 2)), rng.normal(4, 1, (300, 2))])
+    np.random.seed(2)
+    want = mixture.GaussianMixture(2, n_init=3).fit(table).means_
+
+    def refuse(*a, **k):
+        raise RuntimeError('no limiter')
+
+    for workers, broken in ((1, False), (4, True)):
+        if broken:
+            monkeypatch.setattr(threadpoolctl, 'threadpool_limits', refuse)
+        np.random.seed(2)
+        got = graph_cuts.fit_mixture_restarts(mixture.GaussianMixture(2, n_init=3), table, workers=workers).means_
+        monkeypatch.undo()
+        assert np.array_equal(got, want)
