@@ -215,10 +215,6 @@ def fit_mixture_restarts(mixture, table, workers=None):
                 mixture._validate_params()
             mixture._check_parameters(table)
         mixture.n_features_in_ = table.shape[1]
-        starts = []
-        for _ in range(mixture.n_init):
-            mixture._initialize_parameters(table, stream)
-            starts.append(mixture._get_parameters())
 
         def expectation_maximisation(start):
             own = copy.copy(mixture)
@@ -235,9 +231,15 @@ def fit_mixture_restarts(mixture, table, workers=None):
                     break
             return bound, own._get_parameters(), n_iter, bounds, converged
 
-        with threadpool_limits(limits=1):
-            with ThreadPoolExecutor(max_workers=min(workers, len(starts))) as pool:
-                runs = list(pool.map(expectation_maximisation, starts))
+        # (the BLAS pools only: k-means of the next initialisation keeps its OpenMP threads while the EM loops of the restarts
+        # already initialised run beside it)
+        with threadpool_limits(limits=1, user_api='blas'):
+            with ThreadPoolExecutor(max_workers=min(workers, mixture.n_init)) as pool:
+                pending = []
+                for _ in range(mixture.n_init):
+                    mixture._initialize_parameters(table, stream)
+                    pending.append(pool.submit(expectation_maximisation, mixture._get_parameters()))
+                runs = [job.result() for job in pending]
     except Exception as ex:     # private scikit-learn API moved: its own loop, from where the stream stood
         logging.debug('mixture restarts side by side not available (%r): scikit-learn\'s own loop', ex)
         stream.set_state(stream_state)
