@@ -958,7 +958,7 @@ def bench_color2d(args, group, cfg, quick=False):
             traffic = None
             # HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (tools/profile_round4.sh): one
             # 2048^2 image per launch, or the eight 647 x 1024 images of a config-4 step in one launch
-            traffic_file = 'pmc_traffic_cfg4_batch_r04.json' if (cfg == 4 and batched and per_step == 8) else 'pmc_traffic.json'
+            traffic_file = 'pmc_traffic_cfg4_batch_r05.json' if (cfg == 4 and batched and per_step == 8) else 'pmc_traffic.json'
             try:
                 with open(os.path.join(ROOT, 'profiles', traffic_file)) as fp:
                     pmc = json.load(fp)

@@ -1,5 +1,5 @@
 #!/bin/bash
-# Round-4 profile set: the driver's command, rocprofv3 kernel statistics of configs 2 / 3 / 4 (8 images per launch chain), the
+# Round-4 / round-5 profile set (TAG = first argument): the driver's command, rocprofv3 kernel statistics of configs 2 / 3 / 4 (8 images per launch chain), the
 # HBM-traffic PMC passes of the assignment kernel for one 2048^2 image and for a batch of eight 647 x 1024 images, two ranks on
 # the one GPU of the box.  Run on the GPU box (gpurun); summaries land in gpurun_out/prof_<tag>/ and are copied into profiles/.
 TAG=${1:-r04}
@@ -33,9 +33,10 @@ pmc c2_WRITE WRITE_SIZE --steps 2 --warmup 1 --no-other-configs
 pmc c2_SQ "SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_INSTS_LDS SQ_INSTS_SMEM SQ_WAVES" --steps 2 --warmup 1 --no-other-configs
 pmc c4_FETCH FETCH_SIZE --config 4 --steps 3 --warmup 1
 pmc c4_WRITE WRITE_SIZE --config 4 --steps 3 --warmup 1
-python - $OUT <<'PY'
+python - $OUT $TAG <<'PY'
 import csv, sys, collections, json, os
 out = sys.argv[1]
+tag_name = sys.argv[2] if len(sys.argv) > 2 else 'r04'
 def table(path, zmin=None):
     # (zmin: keep the launches of a whole batch only -- per kernel the dispatches with the largest grid)
     rows = list(csv.DictReader(open(path)))
@@ -80,7 +81,7 @@ for tag, fname, workload in (('c2', 'pmc_traffic.json', 'bench.py default (2048x
         f, w = res[tag][name[0]]['FETCH_SIZE'], res[tag][name[0]]['WRITE_SIZE']
         json.dump({'kernel': 'k_slic_assign_dot<true, false>', 'workload': workload, 'sweeps_per_launch': 1,
                    'fetch_size_kb': f, 'write_size_kb': w, 'hbm_bytes_per_launch': int((2 * f + w) * 1024),
-                   'how': 'rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes (profiles/rocprof_r04_pmc_counters.txt); '
+                   'how': 'rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes (profiles/rocprof_%s_pmc_counters.txt); ' % tag_name +
                           'FETCH_SIZE doubled per the gfx950 wide-coalesced-read correction of MI355X_MICROARCH.md; (2*fetch + write) KB'},
                   open(os.path.join(out, fname), 'w'), indent=2)
 PY
