@@ -504,10 +504,13 @@ class Image2D(object):
 
     def segment(self, pairwise, edge_type='model', edge_cost=1., gmm=None, proba=None, use_graphcut=True, classes=None,
                 want_segm=True, want_soft=False, want_graph_labels=False, want_proba=False, debug=False, pinned=True,
-                keep_soft_on_device=False, segm_dtype=None, soft_dtype=None):
+                keep_soft_on_device=False, segm_dtype=None, soft_dtype=None, segm_out=None):
         """fused back half of the pipeline on the resident label map (``imsegm_image2d_segment``): class probabilities
         (``gmm``: :class:`DeviceGmm` on the resident features, else ``proba`` K x C from the host), unary / edge terms,
         alpha-expansion, ``classes[graph_labels][slic]`` and ``proba[slic]``; one synchronisation.
+
+        ``segm_out``: the caller's own C-contiguous array for the class map (shape and dtype of 'segm'), e.g. one whose pages have been
+        touched while the device worked -- a download into untouched pageable memory runs at half the rate of the link.
 
         :return dict: 'segm' (H x W int32), 'soft' (H x W x C), 'graph_labels' (K), 'proba' (K x C) as requested, plus
             with ``debug`` the graph-cut terms ('edges', 'edge_weights', 'edge_weights_int', 'unary', 'unary_int',
@@ -543,7 +546,14 @@ class Image2D(object):
         if segm_u8 and (nc > 256 or (cl is not None and (cl.min() < 0 or cl.max() > 255))):
             raise ValueError('uint8 class map: class values must lie in 0..255')
         if want_segm:
-            out['segm'] = alloc(self.shape, np.uint8 if segm_u8 else np.int32)
+            want_dtype = np.dtype(np.uint8 if segm_u8 else np.int32)
+            if segm_out is not None:
+                if not isinstance(segm_out, np.ndarray) or segm_out.shape != tuple(self.shape) or segm_out.dtype != want_dtype \
+                        or not segm_out.flags.c_contiguous or not segm_out.flags.writeable:
+                    raise ValueError('segm_out must be a writeable C-contiguous %s array of shape %r' % (want_dtype, tuple(self.shape)))
+                out['segm'] = segm_out
+            else:
+                out['segm'] = alloc(self.shape, want_dtype)
         if want_soft:
             out['soft'] = alloc(self.shape + (nc, ), np.float32 if soft_f32 else np.float64)
         if want_graph_labels or debug:

@@ -614,7 +614,30 @@ def pipe_gray3d_slic_features_model_graphcut(image, nb_classes, dict_features, s
     return segm
 
 
+def _touched_result(shape, dtype=np.int32, threads=4):
+    """(array, join): a fresh pageable result array whose pages worker threads touch while the caller goes on -- a download into
+    untouched pages runs at 25 GB/s, into touched ones at the 55 GB/s of the link (tools/micro/pageable_copy.py): for the 4.3 GB
+    label map of a 64 x 4096 x 4096 volume 170 against 80 ms, hidden behind the SLIC sweeps and the model fit.  Small arrays are
+    returned as they are."""
+    import threading
+    out = np.empty(shape, dtype=dtype)
+    if out.nbytes < (64 << 20):
+        return out, (lambda: None)
+    flat = out.reshape(-1).view(np.uint8)
+    edges = np.linspace(0, flat.size, threads + 1).astype(np.int64) // 4096 * 4096
+    edges[-1] = flat.size
+
+    def touch(a, b):
+        flat[a:b:4096] = 0                 # one byte per page (the array's content is overwritten by the download)
+
+    workers = [threading.Thread(target=touch, args=(int(edges[i]), int(edges[i + 1])), daemon=True) for i in range(threads)]
+    for w in workers:
+        w.start()
+    return out, (lambda: [w.join() for w in workers])
+
+
 def _gray3d_on_session(sess, image, nb_classes, dict_features, spacing, sp_size, sp_regul, gc_regul):
+    segm_buf, segm_ready = _touched_result(sess.shape)
     _run_slic3d(sess, sp_size, sp_regul, spacing)
     logging.info('extract segments/superpixels features.')
     slic = None
@@ -643,8 +666,9 @@ def _gray3d_on_session(sess, image, nb_classes, dict_features, spacing, sp_size,
         # arrays of imsegm_image2d_segment fit the memory the device has free (the library asks hipMemGetInfo)
         from pyimsegm_amd.graph_cuts import compute_pairwise_cost
         use_gc = not (np.isscalar(gc_regul) and gc_regul <= 0)
+        segm_ready()
         segm = sess.segment(compute_pairwise_cost(gc_regul, proba.shape), 'model', proba=proba, use_graphcut=use_gc,
-                            pinned=False)['segm']
+                            pinned=False, segm_out=segm_buf)['segm']
     except _hip.HipError as ex:
         if 'fused path' not in str(ex) and 'out of memory' not in str(ex).lower():
             raise
