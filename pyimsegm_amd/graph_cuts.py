@@ -178,12 +178,13 @@ def _fit_workers():
 def fit_mixture_restarts(mixture, table, workers=None):
     """ ``mixture.fit(table)`` with the ``n_init`` restarts of scikit-learn's EM loop (``BaseMixture.fit_predict``) run side by side.
 
-    What ``fit`` does, in its order: every restart draws its k-means initialisation from ONE random stream -- that part stays
-    sequential here, on the very same stream, so every restart starts from the parameters it would have started from --; the EM
-    iterations of a restart that follow use no random numbers and nothing of the other restarts: they run in worker threads (numpy
-    releases the interpreter lock), each on its own shallow copy of the estimator, with the BLAS / OpenMP pools held at one
-    thread (several threads calling a multi-threaded BLAS at once split its long reductions differently from run to run); the
-    best restart is then picked by ``fit``'s rule (first largest lower bound).  Same scikit-learn arithmetic call by call: the
+    What ``fit`` does, in its order: every restart draws its initialisation from ONE random stream, one restart after the other;
+    the EM iterations that follow use no random numbers and nothing of the other restarts.  Here the restarts run in worker
+    threads (numpy releases the interpreter lock), each on its own shallow copy of the estimator and from the state the stream of
+    ``fit`` has when that restart begins -- for the default k-means initialisation the states are found by advancing the stream
+    with one-iteration k-means fits (only the seeding of ``KMeans.fit`` draws), for the cheap initialisations by running them in
+    order --, with the BLAS pools held at one thread (several threads calling a multi-threaded BLAS at once split its long
+    reductions differently from run to run); the best restart is then picked by ``fit``'s rule (first largest lower bound).  Same scikit-learn arithmetic call by call: the
     fitted parameters are bit for bit those of ``mixture.fit(table)`` (tests/test_class_models.py), in a third of the time at the
     298 116 x 3 table of a 64 x 4096 x 4096 volume, where the fit was 80 % of the pipeline.  Anything unexpected -- a
     scikit-learn whose private methods have moved, warm starts, a single restart -- falls back to ``mixture.fit`` on the restored
@@ -231,14 +232,35 @@ def fit_mixture_restarts(mixture, table, workers=None):
                     break
             return bound, own._get_parameters(), n_iter, bounds, converged
 
-        # (the BLAS pools only: k-means of the next initialisation keeps its OpenMP threads while the EM loops of the restarts
-        # already initialised run beside it)
+        def restart_from(state):
+            # a restart whose k-means initialisation draws from its own copy of the stream, set to where the stream of `fit`
+            # stands when that restart begins
+            own = copy.copy(mixture)
+            private = np.random.RandomState()
+            private.set_state(state)
+            own._initialize_parameters(table, private)
+            return expectation_maximisation(own._get_parameters())
+
+        # (the BLAS pools only: k-means keeps its OpenMP threads)
         with threadpool_limits(limits=1, user_api='blas'):
             with ThreadPoolExecutor(max_workers=min(workers, mixture.n_init)) as pool:
                 pending = []
-                for _ in range(mixture.n_init):
-                    mixture._initialize_parameters(table, stream)
-                    pending.append(pool.submit(expectation_maximisation, mixture._get_parameters()))
+                if getattr(mixture, 'init_params', None) == 'kmeans':
+                    # scikit-learn's default initialisation is most of what is left of the fit (k-means on all rows per
+                    # restart), and only its SEEDING draws from the stream (`KMeans.fit`: `_init_centroids`; the Lloyd iterations
+                    # use no random numbers).  A k-means of ONE iteration on the same rows advances the stream exactly as the
+                    # full one does -- whatever this scikit-learn's `KMeans.fit` draws, in its order --, so the states in
+                    # front of the restarts are known after nine cheap fits and the restarts run side by side from their start.
+                    from sklearn import cluster
+                    for _ in range(mixture.n_init):
+                        pending.append(pool.submit(restart_from, stream.get_state()))
+                        with warnings.catch_warnings():
+                            warnings.simplefilter('ignore')
+                            cluster.KMeans(n_clusters=mixture.n_components, n_init=1, max_iter=1, random_state=stream).fit(table)
+                else:
+                    for _ in range(mixture.n_init):
+                        mixture._initialize_parameters(table, stream)
+                        pending.append(pool.submit(expectation_maximisation, mixture._get_parameters()))
                 runs = [job.result() for job in pending]
     except Exception as ex:     # private scikit-learn API moved: its own loop, from where the stream stood
         logging.debug('mixture restarts side by side not available (%r): scikit-learn\'s own loop', ex)
