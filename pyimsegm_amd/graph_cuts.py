@@ -175,6 +175,51 @@ def _fit_workers():
         return os.cpu_count() or 1
 
 
+def _advance_like_kmeans(stream, table, n_clusters):
+    """draw from ``stream`` what ``KMeans(n_clusters, n_init=1, random_state=stream).fit`` draws: a fit of one iteration"""
+    import warnings
+    from sklearn import cluster
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        cluster.KMeans(n_clusters=n_clusters, n_init=1, max_iter=1, random_state=stream).fit(table)
+
+
+_SEEDING_ON_FEW_ROWS = {}
+
+
+def _seeding_rows(table, n_clusters):
+    """rows of ``table`` on which a one-iteration k-means advances a random stream exactly as on the whole table.
+
+    What ``KMeans.fit`` draws per initialisation does not depend on the rows in the scikit-learn versions this package meets
+    (0.24: one integer seed per initialisation; 1.3 and later: one uniform for the first centre and n_local_trials uniforms per
+    further centre) -- then 256 rows do, and the nine fits that only exist to advance the stream cost a millisecond each instead
+    of fifty.  Releases 1.0 - 1.2 drew the first centre with ``randint(n_samples)`` (rejection sampling: the number of raw draws
+    depends on n_samples): there, and wherever a two-trial check on a private stream disagrees, all rows are used."""
+    import sklearn
+    n = len(table)
+    few = slice(0, n, max(1, n // 256))
+    if n <= 4096:
+        return slice(None)
+    key = (sklearn.__version__, n, n_clusters)
+    if key not in _SEEDING_ON_FEW_ROWS:
+        try:
+            major, minor = (int(v) for v in sklearn.__version__.split('.')[:2])
+            trusted = (major, minor) < (1, 0) or (major, minor) >= (1, 3)
+            private = np.random.RandomState(20260926)
+            for _ in range(2 if trusted else 0):
+                before = private.get_state()
+                _advance_like_kmeans(private, table, n_clusters)
+                whole = private.get_state()
+                private.set_state(before)
+                _advance_like_kmeans(private, table[few], n_clusters)
+                part = private.get_state()
+                trusted = trusted and whole[2:] == part[2:] and np.array_equal(whole[1], part[1])
+        except Exception:
+            trusted = False
+        _SEEDING_ON_FEW_ROWS[key] = trusted
+    return few if _SEEDING_ON_FEW_ROWS[key] else slice(None)
+
+
 def fit_mixture_restarts(mixture, table, workers=None):
     """ ``mixture.fit(table)`` with the ``n_init`` restarts of scikit-learn's EM loop (``BaseMixture.fit_predict``) run side by side.
 
@@ -251,12 +296,10 @@ def fit_mixture_restarts(mixture, table, workers=None):
                     # use no random numbers).  A k-means of ONE iteration on the same rows advances the stream exactly as the
                     # full one does -- whatever this scikit-learn's `KMeans.fit` draws, in its order --, so the states in
                     # front of the restarts are known after nine cheap fits and the restarts run side by side from their start.
-                    from sklearn import cluster
+                    seeding_table = table[_seeding_rows(table, mixture.n_components)]
                     for _ in range(mixture.n_init):
                         pending.append(pool.submit(restart_from, stream.get_state()))
-                        with warnings.catch_warnings():
-                            warnings.simplefilter('ignore')
-                            cluster.KMeans(n_clusters=mixture.n_components, n_init=1, max_iter=1, random_state=stream).fit(table)
+                        _advance_like_kmeans(stream, seeding_table, mixture.n_components)
                 else:
                     for _ in range(mixture.n_init):
                         mixture._initialize_parameters(table, stream)

@@ -109,3 +109,18 @@ def test_restarts_fall_back_to_fit(monkeypatch):
         got = graph_cuts.fit_mixture_restarts(mixture.GaussianMixture(2, n_init=3), table, workers=workers).means_
         monkeypatch.undo()
         assert np.array_equal(got, want)
+
+
+def test_stream_advance_on_few_rows_only_where_it_is_known_to_be_the_same(monkeypatch):
+    """the one-iteration k-means fits that advance the random stream run on 256 rows only for scikit-learn releases whose seeding
+    draws the same whatever the number of rows (and after a check on a private stream); for 1.0 - 1.2 (randint(n_samples)) on all"""
+    import sklearn
+    rng = np.random.default_rng(3)
+    table = rng.normal(0, 1, (20000, 3))
+    graph_cuts._SEEDING_ON_FEW_ROWS.clear()
+    rows = graph_cuts._seeding_rows(table, 3)
+    major, minor = (int(v) for v in sklearn.__version__.split('.')[:2])
+    assert (rows != slice(None)) == ((major, minor) < (1, 0) or (major, minor) >= (1, 3))
+    monkeypatch.setattr(sklearn, '__version__', '1.1.3')
+    assert graph_cuts._seeding_rows(table, 3) == slice(None)
+    assert graph_cuts._seeding_rows(table[:1000], 3) == slice(None)          # (small tables: nothing to save)
