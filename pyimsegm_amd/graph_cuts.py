@@ -286,11 +286,25 @@ def fit_mixture_restarts(mixture, table, workers=None):
             own._initialize_parameters(table, private)
             return expectation_maximisation(own._get_parameters())
 
-        # (the BLAS pools only: k-means keeps its OpenMP threads)
-        with threadpool_limits(limits=1, user_api='blas'):
-            with ThreadPoolExecutor(max_workers=min(workers, mixture.n_init)) as pool:
+        # Thread budget.  k-means (the initialisation of a restart) runs its Lloyd iterations on OpenMP threads, and EVERY one of
+        # them calls into a BLAS: with nine restarts side by side on a 256-core host that were 9 x 32 callers at once -- more
+        # than the 64 an OpenBLAS build keeps per-thread buffers for, and the process died in it (measured on the GPU box, round
+        # 5).  The rule here: never more callers at once than ONE k-means of plain scikit-learn would bring in this process (its
+        # OpenMP team as it is set right now), and never more than 48; the teams of the restarts are cut accordingly, and when
+        # that leaves less than one thread per restart the initialisations run one after the other.
+        n_workers = max(1, min(workers, mixture.n_init))
+        side_by_side_init = getattr(mixture, 'init_params', None) == 'kmeans'
+        team = None
+        if side_by_side_init:
+            from threadpoolctl import threadpool_info
+            omp_now = max([int(p.get('num_threads', 1)) for p in threadpool_info() if p.get('user_api') == 'openmp'] or [1])
+            team = max(8, min(omp_now, 48)) // n_workers - 1
+            if team < 1:
+                side_by_side_init, team = False, None
+        with threadpool_limits(limits=1, user_api='blas'), threadpool_limits(limits=team, user_api='openmp'):
+            with ThreadPoolExecutor(max_workers=n_workers) as pool:
                 pending = []
-                if getattr(mixture, 'init_params', None) == 'kmeans':
+                if side_by_side_init:
                     # scikit-learn's default initialisation is most of what is left of the fit (k-means on all rows per
                     # restart), and only its SEEDING draws from the stream (`KMeans.fit`: `_init_centroids`; the Lloyd iterations
                     # use no random numbers).  A k-means of ONE iteration on the same rows advances the stream exactly as the
