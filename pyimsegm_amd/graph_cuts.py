@@ -283,13 +283,16 @@ def fit_mixture_restarts(mixture, table, workers=None):
             own = copy.copy(mixture)
             private = np.random.RandomState()
             private.set_state(state)
-            own._initialize_parameters(table, private)
+            # (the size of an OpenMP team is a per-thread setting: a limit set in the caller's thread does not reach this one,
+            # which would start a team of every core of the host -- nine of them at once is what crashed the process)
+            with threadpool_limits(limits=team, user_api='openmp'):
+                own._initialize_parameters(table, private)
             return expectation_maximisation(own._get_parameters())
 
         # Thread budget.  k-means (the initialisation of a restart) runs its Lloyd iterations on OpenMP threads, and EVERY one of
-        # them calls into a BLAS: with nine restarts side by side on a 256-core host that were 9 x 32 callers at once -- more
-        # than the 64 an OpenBLAS build keeps per-thread buffers for, and the process died in it (measured on the GPU box, round
-        # 5).  The rule here: never more callers at once than ONE k-means of plain scikit-learn would bring in this process (its
+        # them calls into a BLAS: nine restarts side by side on a 256-core host were 9 x 256 callers at once (a worker thread does
+        # not inherit the caller's OpenMP limit) -- far more than the 64 an OpenBLAS build keeps per-thread buffers for, and the
+        # process died in it (measured on the GPU box, round 5).  The rule here: never more callers at once than ONE k-means of plain scikit-learn would bring in this process (its
         # OpenMP team as it is set right now), and never more than 48; the teams of the restarts are cut accordingly, and when
         # that leaves less than one thread per restart the initialisations run one after the other.
         n_workers = max(1, min(workers, mixture.n_init))
@@ -301,7 +304,7 @@ def fit_mixture_restarts(mixture, table, workers=None):
             team = max(8, min(omp_now, 48)) // n_workers - 1
             if team < 1:
                 side_by_side_init, team = False, None
-        with threadpool_limits(limits=1, user_api='blas'), threadpool_limits(limits=team, user_api='openmp'):
+        with threadpool_limits(limits=1, user_api='blas'):
             with ThreadPoolExecutor(max_workers=n_workers) as pool:
                 pending = []
                 if side_by_side_init:
