@@ -681,6 +681,66 @@ k_vol_assign_f32(VolState s, const float *__restrict__ vol, int32_t *__restrict_
     }
 }
 
+// Round 5: one LANE per centroid.  The float32 sums of a segment must be formed in raster order (see above), which makes the sum of
+// ONE segment a serial chain -- but the chains of different segments have nothing to do with each other.  k_vol_update_f32 below
+// gives a whole wave to one chain: per member voxel a find-first-bit, a bit clear, two v_readlane and two packed additions, i.e.
+// eight issue slots of which the wave uses one lane's worth (13 ms per sweep at 298 116 supervoxels).  Here a lane walks the
+// bounding box of ITS segment voxel by voxel -- labels[p] == k ? add : skip -- and the sixty-four chains of a wave advance together;
+// lanes of one wave hold neighbouring centroids of a grid row, whose boxes lie side by side, so the lines a wave touches are shared
+// by its lanes and reused by the next steps of the walk (L1 / L2), and the additions of a chain happen in exactly the order of the
+// serial loop: z, then y, then x ascending.  Same results bit for bit (the parity tests of the float32 volumes; the full-size
+// label map against scikit-image's).
+__global__ void __launch_bounds__(256)
+k_vol_update_f32_lane(VolState s, const float *__restrict__ vol, const int32_t *__restrict__ labels)
+{
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= s.K) return;
+    int *bb = s.bbox + (size_t)k * 6;
+    int *w = s.win + (size_t)k * 6;
+    const int z0 = bb[0], z1 = bb[1], y0 = bb[2], y1 = bb[3], x0 = bb[4], x1 = bb[5];
+    if (z1 < z0) {                                            // no voxel carries this label: the centroid is dead
+#pragma unroll
+        for (int j = 0; j < 6; ++j) w[j] = 0;
+        return;
+    }
+    float sz = 0.f, sy = 0.f, sx = 0.f, sv = 0.f;
+    int cnt = 0;
+    for (int z = z0; z <= z1; ++z) {
+        const float fz = (float)z;
+        for (int y = y0; y <= y1; ++y) {
+            const float fy = (float)y;
+            const size_t row = ((size_t)z * s.H + y) * s.W;
+            // four voxels per round: their labels and values are requested together (eight loads in flight instead of a chain
+            // of two per voxel), then added in order.  A voxel of another segment adds +0.0f, which leaves a sum that started at
+            // +0.0f bit for bit as it is (a sum of this kind is never -0.0f: (+0) + (-0) = +0).
+            for (int x = x0; x <= x1; x += 4) {
+                int lab[4];
+                float val[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const size_t p = row + min(x + j, x1);
+                    lab[j] = labels[p];
+                    val[j] = vol[p];
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const bool mine = lab[j] == k && x + j <= x1;
+                    sz = sz + (mine ? fz : 0.f);
+                    sy = sy + (mine ? fy : 0.f);
+                    sx = sx + (mine ? (float)(x + j) : 0.f);
+                    sv = sv + (mine ? val[j] : 0.f);
+                    cnt += mine ? 1 : 0;
+                }
+            }
+        }
+    }
+    const float fc = (float)cnt;                              // seg[c] / (float)cnt   (cnt > 0: the box is not empty)
+    const float cz = sz / fc, cy = sy / fc, cx = sx / fc;
+    *reinterpret_cast<float4 *>(s.cen32 + (size_t)k * 4) = make_float4(cz, cy, cx, sv / fc);
+    vol_window_f32(s, cz, cy, cx, w);
+    vol_bbox_reset(bb);
+}
+
 // one wave per centroid: raster-order float32 running sums over the segment's bounding box, then the division,
 // the new search window and the reset of the box (oracle orc_slic_gray3d_f32, the loop after `if (!change) break`)
 __global__ void __launch_bounds__(256)
@@ -795,7 +855,8 @@ int launch_vol_slic_f32(VolState s, const float *vol, int32_t *labels, int max_i
         if (it + 1 < max_iter) {
             if (ev_a) hipExtLaunchKernelGGL(k_vol_assign_f32<true>, grid, dim3(256), 0, st, ev_a, ev_b, 0, s, vol, labels);
             else hipLaunchKernelGGL(k_vol_assign_f32<true>, grid, 256, 0, st, s, vol, labels);
-            hipLaunchKernelGGL(k_vol_update_f32, cdiv(s.K, 4), 256, 0, st, s, vol, labels);
+            if (knobs().vol_update_wave) hipLaunchKernelGGL(k_vol_update_f32, cdiv(s.K, 4), 256, 0, st, s, vol, labels);
+            else hipLaunchKernelGGL(k_vol_update_f32_lane, cdiv(s.K, 256), 256, 0, st, s, vol, labels);
         } else {
             if (ev_a) hipExtLaunchKernelGGL(k_vol_assign_f32<false>, grid, dim3(256), 0, st, ev_a, ev_b, 0, s, vol, labels);
             else hipLaunchKernelGGL(k_vol_assign_f32<false>, grid, 256, 0, st, s, vol, labels);

@@ -108,6 +108,23 @@ def test_float32_volume_without_connectivity_and_session_reuse(hip, oracle):
     sess.close()
 
 
+@pytest.mark.parametrize('shape,n_seg,spacing', [((12, 40, 44), 150, (2, 1, 1)), ((9, 70, 130), 420, (1, 1, 1)), ((5, 33, 257), 90, (3, 1, 1))])
+def test_float32_centroid_update_one_lane_or_one_wave_per_centroid(hip, oracle, monkeypatch, shape, n_seg, spacing):
+    """round 5: the raster-order float32 sums of a segment by ONE LANE (sixty-four segments advance per wave; the default) and by
+    one wave per segment (rounds 3 / 4, IMSEGM_VOL_UPDATE_WAVE): the same supervoxel map, the oracle's"""
+    vol = _noisy_ellipsoid(shape, seed=9 + shape[0], dtype=np.float32)
+    ref = _oracle_raw(oracle, vol, n_seg, 3, spacing, enforce_connectivity=False)
+    maps = []
+    for wave in (False, True):
+        if wave:
+            monkeypatch.setenv('IMSEGM_VOL_UPDATE_WAVE', '1')
+        sess = hip.Volume3D(*vol.shape).upload(vol)
+        sess.slic(n_seg, 3, sigma=1., spacing=spacing, enforce_connectivity=False)
+        maps.append(sess.get_labels())
+        sess.close()
+    assert np.array_equal(maps[0], ref) and np.array_equal(maps[1], ref)
+
+
 def test_segment_slic_img3d_gray_api(oracle):
     from pyimsegm_amd import superpixels as sp
     np.random.seed(0)
