@@ -148,6 +148,26 @@ def test_label_cc_background_and_diagonals(hip, oracle):
     sess.close()
 
 
+@pytest.mark.parametrize('full', [False, True])
+def test_label_cc_by_runs_and_by_every_neighbour(hip, oracle, monkeypatch, full):
+    """round 5: measure.label's merge pass ties runs (a few unions where a run starts or the row above changes); the pass with
+    thirteen unions per voxel stays behind IMSEGM_CC_MERGE_FULL -- both against the oracle: random labels (contacts through edges
+    and corners only), blocky labels (long runs), thin volumes, a single row"""
+    if full:
+        monkeypatch.setenv('IMSEGM_CC_MERGE_FULL', '1')
+    rng = np.random.default_rng(12)
+    blocks = np.kron(rng.integers(0, 4, (3, 5, 9)), np.ones((4, 6, 13), dtype=np.int64))
+    blocks[rng.random(blocks.shape) < 0.08] = 0
+    cases = [rng.integers(0, 3, (9, 17, 70)), rng.integers(0, 2, (1, 40, 131)), rng.integers(0, 4, (6, 1, 300)), blocks,
+             rng.integers(1, 3, (3, 3, 257)), (rng.random((7, 33, 65)) < 0.3).astype(np.int64) * 5]
+    for lab in cases:
+        sess = hip.Volume3D(*lab.shape).set_labels(lab)
+        k = sess.label_cc()
+        ref = oracle.label_cc(lab)
+        assert np.array_equal(sess.get_labels(), ref) and k == ref.max() + 1
+        sess.close()
+
+
 def test_gray_statistics(hip, oracle):
     from pyimsegm_amd import descriptors as d
     for dtype in (np.float64, np.uint8):
