@@ -71,9 +71,16 @@ __global__ void __launch_bounds__(256) k_minmax(const T *__restrict__ src, size_
 {
     ZSHIFT(src, zs); ZSHIFT(keys, zs); ZSHIFT(out2, zs); ZSHIFT(also_zero, zs);
     double mn = INFINITY, mx = -INFINITY;
-    size_t stride = (size_t)gridDim.x * blockDim.x;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-        double v = (double)src[i];
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    // four independent loads in flight per lane (a 4.3 GB volume read one 4-byte load at a time ran at 0.33 TB/s)
+    for (; i + 3 * stride < n; i += 4 * stride) {
+        const double v0 = (double)src[i], v1 = (double)src[i + stride], v2 = (double)src[i + 2 * stride], v3 = (double)src[i + 3 * stride];
+        mn = fmin(fmin(mn, v0), fmin(fmin(v1, v2), v3));
+        mx = fmax(fmax(mx, v0), fmax(fmax(v1, v2), v3));
+    }
+    for (; i < n; i += stride) {
+        const double v = (double)src[i];
         mn = fmin(mn, v);
         mx = fmax(mx, v);
     }
@@ -131,6 +138,8 @@ int launch_minmax(const void *src, int dtype, size_t n, unsigned long long *keys
     // ~12 ns (512 workgroups: 16 us, 2048: 50 us for a 12.6 MB image that streams in 3 us)
     int gx = (int)std::min<size_t>(128, (n + 256 * 16 - 1) / (256 * 16));
     if (gx < 1) gx = 1;
+    // (a volume: the commit of 2 048 workgroups is 50 us beside milliseconds of streaming -- eight workgroups per CU)
+    if (n >= ((size_t)1 << 26)) gx = 2048;
     const dim3 grid(gx, 1, zb.nz);
     if (dtype == DT_U8)
         hipLaunchKernelGGL(k_minmax_u8, grid, 256, 0, st, (const uint8_t *)src, n, keys, out2, also_zero, zb.zs);

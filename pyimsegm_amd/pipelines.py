@@ -657,7 +657,7 @@ def _gray3d_on_session(sess, image, nb_classes, dict_features, spacing, sp_size,
     logging.debug('list of features NORM: %r', features.shape)
 
     model = estim_class_model(features, nb_classes)
-    proba = model.predict_proba(features)
+    proba = predict_proba(model, features)          # (scikit-learn's arithmetic without its per-call validation: same bits)
     logging.debug('list of probabilities: %r', proba.shape)
 
     segm = None
