@@ -564,8 +564,24 @@ k_vol_assign_f32(VolState s, const float *__restrict__ vol, int32_t *__restrict_
                     }
                 }
             }
-            // one candidate against the four rows of the strip
-            auto evaluate = [&](const int c) __attribute__((always_inline)) {
+            int since_refresh = 0;
+            while (true) {
+                float mine = lbl[0];
+#pragma unroll
+                for (int j = 1; j < PER; ++j) mine = fminf(mine, lbl[j]);
+                const float wm = wave_min_nonneg_f32(mine);          // (bounds are sums of squares times a positive weight, or +inf)
+                if (!(wm <= wave_worst) || wm == INFINITY) break;  // (+inf: nothing left in the batch)
+                const unsigned long long own = __ballot(mine == wm);
+                const int src = __ffsll((long long)own) - 1;
+                int jsel = 0;
+#pragma unroll
+                for (int j = PER - 1; j >= 0; --j)
+                    if (lbl[j] == wm) jsel = j;
+                jsel = __builtin_amdgcn_readlane(jsel, src);
+#pragma unroll
+                for (int j = 0; j < PER; ++j)
+                    if (lane == src && j == jsel) lbl[j] = INFINITY;
+                const int c = src + 64 * jsel;
                 const int ck = list[c];
                 const VolRec rc = rec[c];
                 const float tz = sz * (rc.cz - fz);
@@ -586,61 +602,13 @@ k_vol_assign_f32(VolState s, const float *__restrict__ vol, int32_t *__restrict_
                     best_d[r] = take ? d : best_d[r];               // (selects, no change of the exec mask)
                     best_k[r] = take ? ck : best_k[r];
                 }
-            };
-            auto refresh_worst = [&]() __attribute__((always_inline)) {
-                float m2 = 0.f;
+                if (++since_refresh == 2) {
+                    since_refresh = 0;
+                    float m2 = 0.f;
 #pragma unroll
-                for (int r = 0; r < VROWS; ++r)
-                    if (xin && (y0 + r) < s.H) m2 = fmaxf(m2, best_d[r]);
-                wave_worst = wave_max_nonneg_f32(m2);               // (distances: never negative; +inf while a voxel has no candidate)
-            };
-            // Round 5.  (a) The VOL_NEAREST candidates with the smallest bounds, one wave minimum each (they settle `wave_worst`
-            // close to its final value); (b) every other candidate whose bound does not exceed `wave_worst` -- found by ONE vote
-            // per register of bounds and walked bit by bit (two scalar instructions per candidate where the minimum search costs
-            // about fifty vector ones), the votes narrowed again whenever `wave_worst` has been refreshed.  A candidate is skipped
-            // on the same condition as before -- its bound EXCEEDS what every voxel of the strip already has --, only the order in
-            // which the others are evaluated differs, and the result does not depend on it (a tie goes to the lower index).
-            constexpr int VOL_NEAREST = 6;
-            bool drained = false;
-            for (int it = 0; it < VOL_NEAREST; ++it) {
-                float mine = lbl[0];
-#pragma unroll
-                for (int j = 1; j < PER; ++j) mine = fminf(mine, lbl[j]);
-                const float wm = wave_min_nonneg_f32(mine);          // (bounds are sums of squares times a positive weight, or +inf)
-                if (!(wm <= wave_worst) || wm == INFINITY) {         // (+inf: nothing left in the batch)
-                    drained = true;
-                    break;
-                }
-                const unsigned long long own = __ballot(mine == wm);
-                const int src = __ffsll((long long)own) - 1;
-                int jsel = 0;
-#pragma unroll
-                for (int j = PER - 1; j >= 0; --j)
-                    if (lbl[j] == wm) jsel = j;
-                jsel = __builtin_amdgcn_readlane(jsel, src);
-#pragma unroll
-                for (int j = 0; j < PER; ++j)
-                    if (lane == src && j == jsel) lbl[j] = INFINITY;
-                evaluate(src + 64 * jsel);
-                if (it & 1) refresh_worst();
-            }
-            if (!drained) {
-                refresh_worst();
-                int since_refresh = 0;
-#pragma unroll
-                for (int j = 0; j < PER; ++j) {
-                    unsigned long long todo = __ballot(lbl[j] <= wave_worst);    // (an evaluated candidate's bound is +inf ...
-                    if (wave_worst == INFINITY) todo = __ballot(lbl[j] < INFINITY);  // ... which only this comparison would let in)
-                    while (todo) {
-                        const int b = __ffsll((long long)todo) - 1;
-                        todo &= todo - 1;
-                        evaluate(b + 64 * j);
-                        if (++since_refresh == 4) {
-                            since_refresh = 0;
-                            refresh_worst();
-                            todo &= __ballot(lbl[j] <= wave_worst);
-                        }
-                    }
+                    for (int r = 0; r < VROWS; ++r)
+                        if (xin && (y0 + r) < s.H) m2 = fmaxf(m2, best_d[r]);
+                    wave_worst = wave_max_nonneg_f32(m2);           // (distances: never negative; +inf while a voxel has no candidate)
                 }
             }
         }
