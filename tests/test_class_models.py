@@ -96,6 +96,7 @@ def test_restarts_fall_back_to_fit(monkeypatch):
     from sklearn import mixture
     rng = np.random.default_rng(1)
     table = np.vstack([rng.normal(0, 1, (300, 2)), rng.normal(4, 1, (300, 2))])
+    monkeypatch.setattr(graph_cuts, '_RESTARTS_SIDE_BY_SIDE_FROM', 2)            # (small tables take plain `fit` anyway)
     np.random.seed(2)
     want = mixture.GaussianMixture(2, n_init=3).fit(table).means_
 
@@ -103,6 +104,7 @@ def test_restarts_fall_back_to_fit(monkeypatch):
         raise RuntimeError('no limiter')
 
     for workers, broken in ((1, False), (4, True)):
+        monkeypatch.setattr(graph_cuts, '_RESTARTS_SIDE_BY_SIDE_FROM', 2)
         if broken:
             monkeypatch.setattr(threadpoolctl, 'threadpool_limits', refuse)
         np.random.seed(2)
