@@ -234,11 +234,11 @@ def fit_mixture_restarts(mixture, table, workers=None):
     ``fit`` has when that restart begins -- for the default k-means initialisation the states are found by advancing the stream
     with one-iteration k-means fits (only the seeding of ``KMeans.fit`` draws), for the cheap initialisations by running them in
     order --, with the BLAS pools held at one thread (several threads calling a multi-threaded BLAS at once split its long
-    reductions differently from run to run); the best restart is then picked by ``fit``'s rule (first largest lower bound).  Same scikit-learn arithmetic call by call: the
-    fitted parameters are bit for bit those of ``mixture.fit(table)`` (tests/test_class_models.py), in a third of the time at the
-    298 116 x 3 table of a 64 x 4096 x 4096 volume, where the fit was 80 % of the pipeline.  Anything unexpected -- a
-    scikit-learn whose private methods have moved, warm starts, a single restart -- falls back to ``mixture.fit`` on the restored
-    random stream.
+    reductions differently from run to run); the best restart is then picked by ``fit``'s rule (first largest lower bound).
+    Same scikit-learn arithmetic call by call: the fitted parameters are bit for bit those of ``mixture.fit(table)``
+    (tests/test_class_models.py), in a fifth of the time at the 298 116 x 3 table of a 64 x 4096 x 4096 volume, where the fit was
+    80 % of the pipeline.  Anything unexpected -- a scikit-learn whose private methods have moved, warm starts, a single restart,
+    a small table -- falls back to ``mixture.fit`` on the restored random stream.
     """
     import copy
     import warnings
@@ -297,9 +297,10 @@ def fit_mixture_restarts(mixture, table, workers=None):
         # Thread budget.  k-means (the initialisation of a restart) runs its Lloyd iterations on OpenMP threads, and EVERY one of
         # them calls into a BLAS: nine restarts side by side on a 256-core host were 9 x 256 callers at once (a worker thread does
         # not inherit the caller's OpenMP limit) -- far more than the 64 an OpenBLAS build keeps per-thread buffers for, and the
-        # process died in it (measured on the GPU box, round 5).  The rule here: never more callers at once than ONE k-means of plain scikit-learn would bring in this process (its
-        # OpenMP team as it is set right now), and never more than 48; the teams of the restarts are cut accordingly, and when
-        # that leaves less than one thread per restart the initialisations run one after the other.
+        # process died in it (measured on the GPU box, round 5).  The rule here: never more callers at once than ONE k-means of
+        # plain scikit-learn would bring in this process (its OpenMP team as it is set right now), and never more than 48; the
+        # teams of the restarts are cut accordingly, and when that leaves less than one thread per restart the initialisations
+        # run one after the other.
         n_workers = max(1, min(workers, mixture.n_init))
         side_by_side_init = getattr(mixture, 'init_params', None) == 'kmeans'
         team = None
