@@ -379,18 +379,19 @@ int launch_vol_slic(VolState s, const double *vol, int32_t *labels, int max_iter
 //     sequential loop of _slic.pyx.
 template <int AXIS>
 __global__ void __launch_bounds__(256)
-k_vol_blur_r32(const double *__restrict__ src, double *__restrict__ dst, float *__restrict__ dst32, int D, int H, int W, Taps t,
-               float fratio, int last)
+k_vol_blur_r32(const float *__restrict__ src, float *__restrict__ dst32, int D, int H, int W, Taps t, float fratio, int last)
 {
+    // (round 5: the values between two axis passes ARE float32 -- scipy stores every line in the output dtype -- so they are kept
+    // as float32, not as doubles that hold float32 values: half the bytes per pass, and the float32 input is read as it is)
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     size_t n = (size_t)D * H * W;
     if (i >= n) return;
     int x = (int)(i % W), y = (int)((i / W) % H), z = (int)(i / ((size_t)W * H));
     double v;
     if (t.r < 0) {
-        v = src[i];                                       // axis not filtered: the float32 value passes through
+        v = (double)src[i];                               // axis not filtered: the float32 value passes through
     } else {
-        v = src[i] * t.w[0];
+        v = (double)src[i] * t.w[0];
         for (int j = t.r; j >= 1; --j) {
             size_t a, b;
             if (AXIS == 0) {
@@ -403,12 +404,11 @@ k_vol_blur_r32(const double *__restrict__ src, double *__restrict__ dst, float *
                 a = ((size_t)z * H + y) * W + vreflect(x - j, W);
                 b = ((size_t)z * H + y) * W + vreflect(x + j, W);
             }
-            v += (src[a] + src[b]) * t.w[j];
+            v += ((double)src[a] + (double)src[b]) * t.w[j];
         }
     }
     const float f = (float)v;                             // scipy stores the line in the output dtype (float32)
-    if (last) dst32[i] = f * fratio;                      // numpy: float32 array * Python float
-    else dst[i] = (double)f;
+    dst32[i] = last ? f * fratio : f;                     // numpy: float32 array * Python float
 }
 
 int launch_vol_preprocess_f32(const float *src, int D, int H, int W, const Taps &tz, const Taps &ty, const Taps &tx, double ratio,
@@ -416,11 +416,10 @@ int launch_vol_preprocess_f32(const float *src, int D, int H, int W, const Taps 
 {
     size_t n = (size_t)D * H * W;
     int grid = cdiv((long)n, 256);
-    hipLaunchKernelGGL(k_vol_to_f64<float>, grid, 256, 0, st, src, n, 0.0, 1.0, bufA);
-    hipLaunchKernelGGL(k_vol_blur_r32<0>, grid, 256, 0, st, bufA, bufB, (float *)nullptr, D, H, W, tz, 0.f, 0);
-    hipLaunchKernelGGL(k_vol_blur_r32<1>, grid, 256, 0, st, bufB, bufA, (float *)nullptr, D, H, W, ty, 0.f, 0);
-    hipLaunchKernelGGL(k_vol_blur_r32<2>, grid, 256, 0, st, bufA, (double *)nullptr, reinterpret_cast<float *>(bufB), D, H, W, tx,
-                       (float)ratio, 1);
+    float *a32 = reinterpret_cast<float *>(bufA), *b32 = reinterpret_cast<float *>(bufB);
+    hipLaunchKernelGGL(k_vol_blur_r32<0>, grid, 256, 0, st, src, b32, D, H, W, tz, 0.f, 0);
+    hipLaunchKernelGGL(k_vol_blur_r32<1>, grid, 256, 0, st, (const float *)b32, a32, D, H, W, ty, 0.f, 0);
+    hipLaunchKernelGGL(k_vol_blur_r32<2>, grid, 256, 0, st, (const float *)a32, b32, D, H, W, tx, (float)ratio, 1);
     HIP_TRY(hipGetLastError());
     return 0;   // float32 result in bufB
 }
