@@ -383,15 +383,22 @@ k_vol_blur_r32(const float *__restrict__ src, float *__restrict__ dst32, int D, 
 {
     // (round 5: the values between two axis passes ARE float32 -- scipy stores every line in the output dtype -- so they are kept
     // as float32, not as doubles that hold float32 values: half the bytes per pass, and the float32 input is read as it is)
-    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    size_t n = (size_t)D * H * W;
-    if (i >= n) return;
-    int x = (int)(i % W), y = (int)((i / W) % H), z = (int)(i / ((size_t)W * H));
+    // (grid: x blocks of a row, y, z -- no 64-bit division to find the voxel)
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y, z = blockIdx.z;
+    if (x >= W) return;
+    const size_t i = ((size_t)z * H + y) * W + x;
     double v;
     if (t.r < 0) {
         v = (double)src[i];                               // axis not filtered: the float32 value passes through
     } else {
         v = (double)src[i] * t.w[0];
+        const int pos = AXIS == 0 ? z : AXIS == 1 ? y : x, len = AXIS == 0 ? D : AXIS == 1 ? H : W;
+        if (pos - t.r >= 0 && pos + t.r < len) {
+            // inside the volume along this axis (all but 2 r positions per line): the taps are i -/+ j * stride, no reflected
+            // index, no 64-bit multiply per tap -- the same additions in the same order
+            const size_t stride = AXIS == 0 ? (size_t)H * W : AXIS == 1 ? (size_t)W : 1;
+            for (int j = t.r; j >= 1; --j) v += ((double)src[i - j * stride] + (double)src[i + j * stride]) * t.w[j];
+        } else
         for (int j = t.r; j >= 1; --j) {
             size_t a, b;
             if (AXIS == 0) {
@@ -414,12 +421,15 @@ k_vol_blur_r32(const float *__restrict__ src, float *__restrict__ dst32, int D, 
 int launch_vol_preprocess_f32(const float *src, int D, int H, int W, const Taps &tz, const Taps &ty, const Taps &tx, double ratio,
                               double *bufA, double *bufB, hipStream_t st)
 {
-    size_t n = (size_t)D * H * W;
-    int grid = cdiv((long)n, 256);
     float *a32 = reinterpret_cast<float *>(bufA), *b32 = reinterpret_cast<float *>(bufB);
-    hipLaunchKernelGGL(k_vol_blur_r32<0>, grid, 256, 0, st, src, b32, D, H, W, tz, 0.f, 0);
-    hipLaunchKernelGGL(k_vol_blur_r32<1>, grid, 256, 0, st, (const float *)b32, a32, D, H, W, ty, 0.f, 0);
-    hipLaunchKernelGGL(k_vol_blur_r32<2>, grid, 256, 0, st, (const float *)a32, b32, D, H, W, tx, (float)ratio, 1);
+    if (H > 65535 || D > 65535) {
+        set_error("volume pre-processing: more than 65 535 rows or slices");
+        return -1;
+    }
+    const dim3 rows(cdiv(W, 256), H, D);
+    hipLaunchKernelGGL(k_vol_blur_r32<0>, rows, 256, 0, st, src, b32, D, H, W, tz, 0.f, 0);
+    hipLaunchKernelGGL(k_vol_blur_r32<1>, rows, 256, 0, st, (const float *)b32, a32, D, H, W, ty, 0.f, 0);
+    hipLaunchKernelGGL(k_vol_blur_r32<2>, rows, 256, 0, st, (const float *)a32, b32, D, H, W, tx, (float)ratio, 1);
     HIP_TRY(hipGetLastError());
     return 0;   // float32 result in bufB
 }
