@@ -635,6 +635,36 @@ k_vol_assign_f32(VolState s, const float *__restrict__ vol, int32_t *__restrict_
         if (best_k[r] >= 0) pending |= 1u << r;
     }
     if (!TRACK) return;
+#ifndef VOL_TRACK_RUNS
+#define VOL_TRACK_RUNS 1
+#endif
+#if VOL_TRACK_RUNS
+    // bounding box of every segment's voxels (incl. the ones that kept an old label): the region the order-preserving update of
+    // that centroid has to walk.  Round 5: by RUNS -- in every row of the strip the first lane of a run of equal labels finds the
+    // end of its run in the vote of the run starts and compares / updates the box of its label; the runs of a wave do so side by
+    // side (rounds 3 / 4 enumerated the distinct labels of the strip one after the other: ~45 instructions each, a quarter of the
+    // kernel).  Minima and maxima: the boxes are the same whatever the order and however often a label is met.
+#pragma unroll
+    for (int r = 0; r < VROWS; ++r) {
+        const int k = (pending >> r) & 1u ? best_k[r] : -1;
+        const int kp = __shfl_up(k, 1, 64);
+        const bool start = k >= 0 && (lane == 0 || kp != k);
+        const unsigned long long starts = __ballot(start), valid = __ballot(k >= 0);
+        if (start) {
+            const unsigned long long stop = (starts | ~valid) & ~((2ULL << lane) - 1ULL);     // the lanes above this one
+            const int end = stop ? __ffsll((long long)stop) - 1 : 64;
+            const int y = y0 + r, xlo = x0w + lane, xhi = x0w + end - 1;
+            int *bb = s.bbox + (size_t)k * 6;
+            const int b0 = bb[0], b1 = bb[1], b2 = bb[2], b3 = bb[3], b4 = bb[4], b5 = bb[5];
+            if (b0 > z) atomicMin(&bb[0], z);
+            if (b1 < z) atomicMax(&bb[1], z);
+            if (b2 > y) atomicMin(&bb[2], y);
+            if (b3 < y) atomicMax(&bb[3], y);
+            if (b4 > xlo) atomicMin(&bb[4], xlo);
+            if (b5 < xhi) atomicMax(&bb[5], xhi);
+        }
+    }
+#else
     // bounding box of every segment's voxels (incl. the ones that kept an old label): the region the
     // order-preserving update of that centroid has to walk
     int my_k = -1, my_ylo = 0, my_yhi = 0, my_xlo = 0, my_xhi = 0, n_distinct = 0;
@@ -688,6 +718,7 @@ k_vol_assign_f32(VolState s, const float *__restrict__ vol, int32_t *__restrict_
         if (b4 > my_xlo) atomicMin(&bb[4], my_xlo);
         if (b5 < my_xhi) atomicMax(&bb[5], my_xhi);
     }
+#endif
 }
 
 // Round 5: one LANE per centroid.  The float32 sums of a segment must be formed in raster order (see above), which makes the sum of
