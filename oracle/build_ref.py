@@ -18,9 +18,13 @@ import numpy
 #: reference tree (the GPU box): the driver script, the reference package behind the overlay (utilities, region growing, ...: the
 #: modules the overlay does not shadow) and the one sample image the test segments
 DRIVER_BUNDLE = (
-    ('experiments_segmentation', ('run_segm_slic_model_graphcut.py', )),
+    ('experiments_segmentation', ('run_segm_slic_model_graphcut.py', 'run_segm_slic_classif_graphcut.py', 'run_eval_superpixels.py')),
     ('imsegm', None),                       # the whole package directory (*.py, *.pyx)
     (os.path.join('data-images', 'drosophila_disc', 'image'), ('img_12.jpg', )),
+    # tests/overlay_consumers_run.py: two ovary slices with their annotations (the reference's own sample data)
+    (os.path.join('data-images', 'drosophila_ovary_slice', 'image'), ('insitu4174.jpg', 'insitu7545.jpg')),
+    (os.path.join('data-images', 'drosophila_ovary_slice', 'annot_struct'), ('insitu4174.png', 'insitu7545.png')),
+    (os.path.join('data-images', 'drosophila_ovary_slice', 'annot_eggs'), ('insitu7545.png', )),
 )
 
 
