@@ -171,7 +171,7 @@ def real_skimage_slic(image, sp_size, sp_regul, repeats=1):
         return None
 
 
-def _cpu_chain_color2d(image, model, sp_size, sp_regul, gc_regul, slic=None):
+def _cpu_chain_color2d(image, model, sp_size, sp_regul, gc_regul, slic=None, keep=None):
     """the CPU path of one image after (or including) SLIC on one core: descriptors = the reference's own
     features_cython.pyx compiled into oracle/_ref (else the oracle's C restatement), graph / edge weights / GraphCut /
     gathers = the oracle port (gco exists nowhere); returns (legs in seconds, segmentation, label map)"""
@@ -197,6 +197,8 @@ def _cpu_chain_color2d(image, model, sp_size, sp_regul, gc_regul, slic=None):
     energy = orc.color2d_energy(img32, seg32)
     features = np.nan_to_num(np.hstack([mean, std, energy]))
     parts['descriptors_port_s'] = time.perf_counter() - t1
+    if keep is not None:
+        keep['features'] = features
     t2 = time.perf_counter()
     proba = model.predict_proba(features)
     _, edges = orc.adjacency(seg32)
@@ -228,8 +230,9 @@ def cpu_baseline_color2d(image, model, sp_size, sp_regul, repeats=5):
     real = real_skimage_slic(image, sp_size, sp_regul, repeats=repeats + 1)
     runs = []
     segm = None
+    keep = {}
     for i in range(repeats + 1):
-        parts, segm, _ = _cpu_chain_color2d(image, model, sp_size, sp_regul, GC_REGUL)
+        parts, segm, _ = _cpu_chain_color2d(image, model, sp_size, sp_regul, GC_REGUL, keep=keep)
         if real is not None:
             parts['slic_reference_s'] = real[1][i]
         runs.append(parts)
@@ -258,6 +261,21 @@ def cpu_baseline_color2d(image, model, sp_size, sp_regul, repeats=5):
     }
     if real is not None:
         entry['reference_slic'] = {'scikit_image': real[0], 'seconds_median': round(median_min(real[1][1:])[0], 3), 'cores': 1}
+    try:
+        # the fit-inclusive form (the reference's per-image mode fits the mixture inside the call, pipelines.py:95): the SAME
+        # scikit-learn call as on the GPU side, on the same core
+        from pyimsegm_amd.graph_cuts import estim_class_model
+        fits = []
+        for _ in range(3):
+            np.random.seed(0)
+            t0 = time.perf_counter()
+            estim_class_model(keep['features'], NB_CLASSES, 'GMM', None, True)
+            fits.append(time.perf_counter() - t0)
+        fit_s = median_min(fits)[0]
+        entry['model_fit_s'] = round(fit_s, 4)
+        entry['value_including_fit'] = round(npx / (med + fit_s) / 1e6, 4)
+    except Exception as ex:
+        entry['model_fit_error'] = repr(ex)
     try:     # the reference ITSELF, whole pipeline, timed in the build container (tools/time_reference.py)
         with open(os.path.join(ROOT, 'profiles', 'reference_time_r02.json')) as fp:
             entry['reference_whole_pipeline_build_container'] = json.load(fp)
@@ -400,8 +418,12 @@ def cpu_baseline_volume(shape_full, crop=(64, 256, 256)):
             'what': 'real scikit-image %s slic (%.0f s) + measure.label (%.0f s) on the full volume, one core of the build container'
                     % (str(full['versions']), sec[0], sec[1]), 'mvoxels_per_s': round(float(np.prod(shape_full)) / sum(sec) / 1e6, 4)}
     return {**extra, 'value': round(nvox / total / 1e6, 4), 'unit': 'Mpixels/s', 'cores': 1, 'kind': 'port',
-            'sample': '%dx%dx%d crop of the volume on one core, %.1f s (SLIC + measure.label %.1f s, model fit %.1f s); the rate is '
-                      'EXTRAPOLATED linearly to the full volume' % (crop + (total, t_slic, t_fit)),
+            'sample': '%dx%dx%d %s on one core, %.1f s (SLIC + measure.label %.1f s, mixture fit + predict_proba %.2f s -- the same '
+                      'scikit-learn call as inside the GPU step --, statistics / graph / GraphCut / gather %.2f s)%s'
+                      % (crop + ('crop of the volume' if crop != tuple(shape_full) else 'volume (whole)', total, t_slic, t_fit,
+                                 total - t_slic - t_fit,
+                                 '; the rate is EXTRAPOLATED linearly to the full volume' if crop != tuple(shape_full) else '')),
+            'seconds': {'total': round(total, 3), 'slic_and_label': round(t_slic, 3), 'model_fit': round(t_fit, 3)},
             'extrapolated_seconds_full_volume': round(total * float(np.prod(shape_full)) / nvox, 1)}
 
 
@@ -678,6 +700,48 @@ def host_image(image, pinned):
 # -----------------------------------------------------------------------------------------------------------------
 # configs 2 / 3 / 4: colour images through segment_color2d_slic_features_model_graphcut
 # -----------------------------------------------------------------------------------------------------------------
+def fit_inclusive_line(pipe, images, features, sp_size, repeats):
+    """SURVEY 8(d) / BASELINE.md section 3: "GMM (host) reported as its own line AND included in end-to-end".  The reference's
+    default per-image mode fits the mixture INSIDE the call (`pipe_color2d_slic_features_model_graphcut`,
+    /root/reference/imsegm/pipelines.py:46-110, driver :354); `value` of the line times the pre-fitted form
+    (`segment_color2d_...`, pipelines.py:160, driver :405).  Here: the fit-inclusive call, one image after the other (the fit is
+    scikit-learn on the host -- GaussianMixture(n_init=9) as graph_cuts.py:98-163 configures it -- identical on the CPU side),
+    1 warm-up + `repeats` passes over `images`, median per image."""
+    fit_seconds = [0.0]
+    fit = pipe.estim_class_model
+
+    def timed_fit(*a, **kw):
+        t = time.perf_counter()
+        try:
+            return fit(*a, **kw)
+        finally:
+            fit_seconds[0] += time.perf_counter() - t
+    pipe.estim_class_model = timed_fit
+    try:
+        totals, fits = [], []
+        for rep in range(repeats + 1):
+            for image in images:
+                np.random.seed(0)
+                fit_seconds[0] = 0.0
+                t = time.perf_counter()
+                pipe.pipe_color2d_slic_features_model_graphcut(image, NB_CLASSES, features, sp_size=sp_size, sp_regul=SP_REGUL,
+                                                               pca_coef=None, use_scaler=True, estim_model='GMM', gc_regul=GC_REGUL,
+                                                               gc_edge_type=EDGE_TYPE)
+                if rep > 0:
+                    totals.append(time.perf_counter() - t)
+                    fits.append(fit_seconds[0])
+    finally:
+        pipe.estim_class_model = fit
+    total, fit_s = median_min(totals)[0], median_min(fits)[0]
+    npx = images[0].shape[0] * images[0].shape[1]
+    return {'what': 'pipe_color2d_slic_features_model_graphcut (reference pipelines.py:46-110): SLIC -> descriptors -> '
+                    'GaussianMixture fit on the host (scikit-learn, n_init=9, graph_cuts.py:98-163) -> GraphCut, one image at a time, '
+                    'host in -> segm AND segm_soft in host numpy; median of %d calls' % len(totals),
+            'ms_per_image_including_fit': round(total * 1e3, 3), 'host_model_fit_ms_per_image': round(fit_s * 1e3, 3),
+            'ms_per_image_excluding_fit': round((total - fit_s) * 1e3, 3),
+            'value_including_fit': round(npx / total / 1e6, 3), 'unit': 'Mpixels/s'}
+
+
 def bench_color2d(args, group, cfg, quick=False):
     from pyimsegm_amd import _hip
     from pyimsegm_amd import pipelines as pipe
@@ -1018,6 +1082,15 @@ def bench_color2d(args, group, cfg, quick=False):
         }
         out.update(extras)
         out.update(verdict)
+        if world == 1:
+            try:      # the fit-inclusive form of the same step (its own line item; `value` stays the pre-fitted form)
+                n_fit = {2: 3, 3: 1, 4: 1}[cfg] if quick else {2: 5, 3: 2, 4: 1}[cfg]
+                inc = fit_inclusive_line(pipe, [np.asarray(im) for im in images], features, sp_size, n_fit)
+                out['fit_inclusive'] = inc
+                out['host_model_fit_ms_per_step'] = round(inc['host_model_fit_ms_per_image'] * per_step, 3)
+                out['ms_per_step_including_fit'] = round(inc['ms_per_image_including_fit'] * per_step, 3)
+            except Exception as ex:
+                out['fit_inclusive'] = {'error': repr(ex)}
         if world == 1 and not args.no_cpu_baseline and cfg == 2 and not quick:
             try:
                 base, segm_cpu, slic_real = cpu_baseline_color2d(np.asarray(images[0]), model, sp_size, SP_REGUL)
@@ -1169,7 +1242,9 @@ def bench_volume(args, group, shape=None, quick=False):
             out['reference_run_error'] = repr(ex)
         if not args.no_cpu_baseline:
             try:
-                out['cpu_baseline'] = cpu_baseline_volume(shape, crop=(32, 128, 128) if quick else (64, 256, 256))
+                # a 64 x 256 x 256 crop (about ten seconds of one core), the fit included; the reduced
+                # volume of `other_configs` is smaller than that crop and is timed whole
+                out['cpu_baseline'] = cpu_baseline_volume(shape, crop=(64, 256, 256) if int(np.prod(shape)) > 64 * 256 * 256 else shape)
                 out['speedup_vs_cpu_baseline'] = round(out['value'] / out['cpu_baseline']['value'], 2)
             except Exception as ex:
                 out['cpu_baseline'] = {'error': repr(ex)}

@@ -27,6 +27,12 @@ extern "C" {
 #define IMSEGM_F64 1
 #define IMSEGM_F32 2
 
+/* status of imsegm_image2d_segment / imsegm_image2d_graph_prepare when the FUSED form of the back half does not apply to this
+ * label map on this device (its adjacency store does not fit the free memory, a label has more neighbours than a row of the
+ * neighbour table): nothing is wrong with the session -- the caller builds the graph with imsegm_volume_graph /
+ * imsegm_image2d_graph and cuts it with imsegm_cut_general_graph, the staged calls of imsegm/graph_cuts.py:660-747 */
+#define IMSEGM_E_FUSED_PATH (-3)
+
 typedef struct imsegm_ctx imsegm_ctx;           /* one device + one stream */
 typedef struct imsegm_image2d imsegm_image2d;   /* device-resident state of one H x W image */
 
@@ -298,6 +304,13 @@ IMSEGM_API int imsegm_image2d_segment(imsegm_image2d *img, const imsegm_gmm *gmm
                                       const double *pairwise, int edge_type, double edge_cost, int use_graphcut,
                                       const int32_t *classes_lut, int32_t *segm_out, double *soft_out,
                                       int32_t *graph_labels_out, double *proba_out, imsegm_terms_debug *debug_out);
+
+/* The part of imsegm_image2d_segment that depends on the label map alone -- make_graph_segm_connect_grid2d_conn4 / 3d_conn6 and
+ * superpixel_centers (imsegm/superpixels.py:115-242) as edges, centres and the arcs the cut walks -- enqueued AHEAD of it and
+ * without a synchronisation: the next imsegm_image2d_segment on the same label map finds the graph ready.  The gray-volume
+ * pipeline fits its class model on the host between the descriptors and the cut (imsegm/pipelines.py:412-421); the graph is
+ * built under that fit.  Any call that changes the label map drops the prepared graph.  May return IMSEGM_E_FUSED_PATH. */
+IMSEGM_API int imsegm_image2d_graph_prepare(imsegm_image2d *img);
 
 /* segment_color2d_slic_features_model_graphcut (imsegm/pipelines.py:160-241) for a colour image, colour statistics and a
  * mixture model the device evaluates, in ONE call: imsegm_image2d_upload + imsegm_image2d_slic (isotropic `taps`,

@@ -39,6 +39,15 @@ class HipError(RuntimeError):
     """a C-ABI call returned an error status"""
 
 
+class HipFusedPathError(HipError):
+    """``IMSEGM_E_FUSED_PATH`` of include/imsegm_hip.h: the fused back half (``imsegm_image2d_segment`` /
+    ``imsegm_image2d_graph_prepare``) does not apply to this label map on this device -- nothing is wrong with the session, the
+    caller takes the staged calls (graph, terms, ``cut_general_graph``, gather) instead"""
+
+
+IMSEGM_E_FUSED_PATH = -3
+
+
 _lib = None
 _lib_lock = threading.Lock()
 
@@ -76,6 +85,7 @@ _SIGNATURES = {
     'imsegm_image2d_get_features': (C.c_int, [_vp, _vp, C.c_int]),
     'imsegm_image2d_run_color': (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, C.c_double, _vp, C.c_int, C.c_int, C.c_int, C.c_int,
                                            C.c_int, C.POINTER(GmmParams), C.c_int, _vp, C.c_int, C.c_double, C.c_int, _vp, _vp, _vp, _ip]),
+    'imsegm_image2d_graph_prepare': (C.c_int, [_vp]),
     'imsegm_image2d_segment': (C.c_int, [_vp, C.POINTER(GmmParams), _vp, C.c_int, _vp, C.c_int, C.c_double, C.c_int, _vp, _vp, _vp,
                                          _vp, _vp, C.POINTER(TermsDebug)]),
     'imsegm_version': (C.c_int, []),
@@ -190,7 +200,8 @@ def reload_env():
 
 def _check(status):
     if status != 0:
-        raise HipError(load_library().imsegm_last_error().decode('utf-8', 'replace'))
+        message = load_library().imsegm_last_error().decode('utf-8', 'replace')
+        raise (HipFusedPathError if status == IMSEGM_E_FUSED_PATH else HipError)(message)
 
 
 _device_count = {}
@@ -501,6 +512,12 @@ class Image2D(object):
         out = np.empty((self.n_labels, 3 * nflags), dtype=np.float64) if to_host else None
         _check(load_library().imsegm_image2d_features_color(self._h, mask, _ptr(out)))
         return out
+
+    def graph_prepare(self):
+        """enqueue the graph of the resident label map (neighbour pairs, centres, edges, arcs) ahead of :meth:`segment`, without
+        a synchronisation (``imsegm_image2d_graph_prepare``): it depends on the label map alone, so it can run while the host fits
+        the class model.  Raises :class:`HipFusedPathError` when the fused back half does not apply."""
+        _check(load_library().imsegm_image2d_graph_prepare(self._h))
 
     def segment(self, pairwise, edge_type='model', edge_cost=1., gmm=None, proba=None, use_graphcut=True, classes=None,
                 want_segm=True, want_soft=False, want_graph_labels=False, want_proba=False, debug=False, pinned=True,
@@ -885,8 +902,9 @@ class Image2D(object):
         _check(load_library().imsegm_image2d_all_finite(self._h, C.byref(ok)))
         return bool(ok.value)
 
-    def gather(self, graph_labels=None, proba=None, to_host=True):
-        """``graph_labels[slic]`` (int32 H x W) and ``proba[slic]`` (float64 H x W x C)"""
+    def gather(self, graph_labels=None, proba=None, to_host=True, segm_out=None):
+        """``graph_labels[slic]`` (int32 H x W) and ``proba[slic]`` (float64 H x W x C); ``segm_out``: the caller's own
+        C-contiguous int32 array of the session's shape for the first"""
         segm = soft = None
         gl = pr = None
         nc = 0
@@ -895,6 +913,11 @@ class Image2D(object):
             if gl.shape[0] < self.n_labels:
                 raise ValueError('label LUT shorter than the number of superpixels')
             segm = np.empty(self.shape, dtype=np.int32) if to_host else None
+            if to_host and segm_out is not None:
+                if not isinstance(segm_out, np.ndarray) or segm_out.shape != tuple(self.shape) or segm_out.dtype != np.int32 \
+                        or not segm_out.flags.c_contiguous or not segm_out.flags.writeable:
+                    raise ValueError('segm_out must be a writeable C-contiguous int32 array of shape %r' % (tuple(self.shape), ))
+                segm = segm_out
         if proba is not None:
             pr = np.ascontiguousarray(proba, dtype=np.float64)
             if pr.ndim != 2 or pr.shape[0] < self.n_labels:

@@ -344,7 +344,7 @@ void imsegm_image2d_destroy(imsegm_image2d *im)
     DevBuf *all[] = { &im->img, &im->labA, &im->labB, &im->nearest, &im->labels, &im->conn_i32, &im->conn_u8, &im->small,
                       &im->cent, &im->tiles, &im->feat, &im->graph, &im->gather_lut, &im->gather_out_i, &im->gather_out_f,
                       &im->tex_planes, &im->tex_resp, &im->tex_small, &im->vol_cent, &im->annot, &im->hist, &im->featK, &im->seg,
-                      &im->sweeps, &im->narrow };
+                      &im->gseg, &im->sweeps, &im->narrow };
     for (auto b : all) b->release();
     if (im->slic_fail_host) (void)hipHostFree(im->slic_fail_host);
     if (im->slic_exec) (void)hipGraphExecDestroy(im->slic_exec);
@@ -590,6 +590,7 @@ int imsegm_image2d_slic(imsegm_image2d *im, int minmax_normalize, int n_segments
     ctx->end(sp_all);
     im->n_labels = n_labels;
     im->have_labels = true;
+    im->graph_ready = false;
     if (n_labels_out) *n_labels_out = n_labels;
     return 0;
 }
@@ -620,6 +621,7 @@ int imsegm_image2d_set_labels(imsegm_image2d *im, const int32_t *labels, int n_l
     HIP_TRY(hipStreamSynchronize(im->ctx->stream));
     im->n_labels = n_labels;
     im->have_labels = true;
+    im->graph_ready = false;
     return 0;
 }
 
@@ -663,6 +665,7 @@ int imsegm_image2d_enforce_connectivity(imsegm_image2d *im, const int32_t *label
         return -1;
     im->n_labels = n_labels;
     im->have_labels = true;
+    im->graph_ready = false;
     if (n_labels_out) *n_labels_out = n_labels;
     return 0;
 }
@@ -1298,6 +1301,7 @@ int imsegm_volume_slic(imsegm_image2d *im, int n_segments, double compactness, c
     ctx->end(sp_all);
     im->n_labels = n_labels;
     im->have_labels = true;
+    im->graph_ready = false;
     if (n_labels_out) *n_labels_out = n_labels;
     return 0;
 }
@@ -1319,6 +1323,7 @@ int imsegm_volume_label_cc(imsegm_image2d *im, int *n_labels_out)
     HIP_TRY(hipMemcpyAsync(&total, w.counters, 4, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
     im->n_labels = total + 1;          // 0 = background, components 1 .. total
+    im->graph_ready = false;
     if (n_labels_out) *n_labels_out = im->n_labels;
     return 0;
 }
@@ -1709,6 +1714,132 @@ int imsegm_image2d_segment(imsegm_image2d *im, const imsegm_gmm *gmm, const doub
     return rc == -2 ? -1 : rc;
 }
 
+// ---- the graph of the resident label map: neighbour pairs + centre sums, then edges (a < b, ordered by (b, a)), CSR arcs in
+// ascending neighbour order, reverse arcs, the edge -> arc table.  It depends on the label map only -- not on the class model --,
+// so imsegm_image2d_graph_prepare may enqueue it ahead of the call that needs it (the volume pipeline: under the host's mixture fit).
+static int default_edge_capacity(const imsegm_image2d *im, int K) { return im->is_volume ? 16 * K + 64 : 3 * K + 64; }   // planar: E <= 3K - 6
+
+static GraphPlan graph_plan(const imsegm_image2d *im, int K, int edge_capacity)
+{
+    auto al = [](size_t v) { return (v + 63) & ~(size_t)63; };
+    GraphPlan g;
+    g.K = K;
+    g.Ecap = edge_capacity > 0 ? edge_capacity : default_edge_capacity(im, K);
+    g.words = cdiv(K, 32);
+    // neighbours as bits of a K x K bitmap while that is small; a label volume beyond 256 MB of bitmap (K > 46 000; 11 GB at the
+    // 3 * 10^5 supervoxels of BASELINE configs[4]) keeps them as 64 slots per label
+    g.table = im->is_volume && ((double)K * (double)g.words * 4.0 > 256e6 || knobs().adjacency_table);
+    g.cap = g.table ? 64 : 0;
+    size_t d = 0;
+    g.o_head = d; d += 64;                        // K | E | a row of the table was too narrow
+    g.o_edges = d; d += al((size_t)g.Ecap * 8);
+    g.o_as = d; d += al((size_t)(K + 1) * 4);
+    g.o_at = d; d += al((size_t)g.Ecap * 8);
+    g.o_ar = d; d += al((size_t)g.Ecap * 8);
+    g.o_ea = d; d += al((size_t)g.Ecap * 8);
+    g.o_deg = d; d += al((size_t)K * 4);
+    g.o_dlow = d; d += al((size_t)K * 4);
+    g.o_es = d; d += al((size_t)K * 4);
+    g.o_cent = d; d += al((size_t)K * 3 * 8);
+    g.o_present = d; d += al((size_t)K);
+    g.o_store = d; d += al(g.table ? (size_t)K * g.cap * 4 : (size_t)K * g.words * 4);
+    g.o_cacc = d; d += al((size_t)K * 4 * 8);     // (right behind the bitmap: one fill for both, graph.hip launch_adjacency_bitmap)
+    g.o_wp = d; d += g.table ? 0 : al((size_t)K * g.words * 4);
+    g.bytes = d + 256;
+    return g;
+}
+
+__global__ void k_graph_head(int32_t *head, int K)
+{
+    head[0] = K;
+    head[1] = 0;
+    head[2] = 0;
+}
+
+// K_dev / E_dev: the words of the caller's parameter block, or null -> the head of the graph buffer itself (written by a kernel)
+static int graph_enqueue(imsegm_image2d *im, const GraphPlan &g, int32_t *K_dev, int32_t *E_dev)
+{
+    imsegm_ctx *ctx = im->ctx;
+    hipStream_t st = ctx->stream;
+    if (im->gseg.ensure(g.bytes)) return -1;
+    unsigned char *gb = im->gseg.as<unsigned char>();
+    int32_t *head = reinterpret_cast<int32_t *>(gb + g.o_head);
+    if (!K_dev || g.table) hipLaunchKernelGGL(k_graph_head, 1, 1, 0, st, head, g.K);
+    if (!K_dev) {
+        K_dev = head;
+        E_dev = head + 1;
+    }
+    int32_t *store = reinterpret_cast<int32_t *>(gb + g.o_store);
+    long long *cacc = reinterpret_cast<long long *>(gb + g.o_cacc);
+    double *centres = reinterpret_cast<double *>(gb + g.o_cent);
+    int sp = ctx->begin(PG_GRAPH);
+    if (g.table) {
+        if (launch_vol_adjacency_table(im->labels.as<int32_t>(), im->D, im->H, im->W, g.K, store, g.cap, head + 2, cacc, centres, gb + g.o_present, st))
+            return -1;
+        if (launch_graph_csr_table(store, K_dev, g.K, g.cap, head + 2, reinterpret_cast<int32_t *>(gb + g.o_deg), reinterpret_cast<int32_t *>(gb + g.o_dlow),
+                                   reinterpret_cast<int32_t *>(gb + g.o_as), reinterpret_cast<int32_t *>(gb + g.o_es), E_dev, g.Ecap,
+                                   reinterpret_cast<int32_t *>(gb + g.o_edges), reinterpret_cast<int32_t *>(gb + g.o_at),
+                                   reinterpret_cast<int32_t *>(gb + g.o_ar), reinterpret_cast<int32_t *>(gb + g.o_ea), st))
+            return -1;
+    } else {
+        uint32_t *bitmap = reinterpret_cast<uint32_t *>(store);
+        if (im->is_volume) {
+            if (launch_vol_adjacency(im->labels.as<int32_t>(), im->D, im->H, im->W, g.K, g.words, bitmap, cacc, centres, gb + g.o_present, st)) return -1;
+        } else if (launch_adjacency_bitmap(im->labels.as<int32_t>(), im->H, im->W, g.K, bitmap, cacc, centres, gb + g.o_present, st)) {
+            return -1;
+        }
+        if (launch_graph_csr(bitmap, K_dev, g.K, g.words, reinterpret_cast<int32_t *>(gb + g.o_wp), reinterpret_cast<int32_t *>(gb + g.o_deg),
+                             reinterpret_cast<int32_t *>(gb + g.o_dlow), reinterpret_cast<int32_t *>(gb + g.o_as),
+                             reinterpret_cast<int32_t *>(gb + g.o_es), E_dev, g.Ecap, reinterpret_cast<int32_t *>(gb + g.o_edges),
+                             reinterpret_cast<int32_t *>(gb + g.o_at), reinterpret_cast<int32_t *>(gb + g.o_ar),
+                             reinterpret_cast<int32_t *>(gb + g.o_ea), st))
+            return -1;
+    }
+    ctx->end(sp);
+    return 0;
+}
+
+// does the adjacency store of the fused path fit?  (the K x K bitmap and its word prefixes: what fits is asked of the device, not
+// assumed -- the two arrays must fit the memory that is free NOW, plus what the session's own buffer already holds, with a tenth of
+// the device left over; beyond that the caller builds the graph with imsegm_volume_graph and cuts it with
+// imsegm_cut_general_graph.  Status IMSEGM_E_FUSED_PATH is what the host layer turns into that fall-back: ADVICE r4 / r5.)
+static int graph_store_fits(imsegm_image2d *im, const GraphPlan &g)
+{
+    if (g.table) return 0;
+    const double pair_bytes = 2.0 * (double)g.K * (double)g.words * 4.0;
+    const int cap_mb = knobs().fused_bitmap_mb;
+    if (cap_mb > 0 && pair_bytes > 1048576.0 * cap_mb) {
+        set_error("segment: too many labels for the fused path (adjacency bitmap: IMSEGM_FUSED_BITMAP_MB)");
+        return IMSEGM_E_FUSED_PATH;
+    }
+    if (pair_bytes > 16e6) {                  // (a 2-D image's graph: never in question, no query per image)
+        size_t free_b = 0, total_b = 0;
+        HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+        const double usable = (double)free_b + (double)im->gseg.cap - 0.1 * (double)total_b;
+        if (pair_bytes > usable || pair_bytes > 48e9) {
+            set_error("segment: too many labels for the fused path (adjacency bitmap: the device has no room for it)");
+            return IMSEGM_E_FUSED_PATH;
+        }
+    }
+    return 0;
+}
+
+int imsegm_image2d_graph_prepare(imsegm_image2d *im)
+{
+    if (!im || bind(im->ctx)) return -1;
+    if (!im->have_labels) {
+        set_error("graph_prepare needs a label map");
+        return -1;
+    }
+    im->graph_ready = false;
+    const GraphPlan g = graph_plan(im, im->n_labels, 0);
+    if (int rc = graph_store_fits(im, g)) return rc;
+    if (graph_enqueue(im, g, nullptr, nullptr)) return -1;
+    im->gplan = g;
+    im->graph_ready = true;
+    return 0;
+}
+
 static int segment_impl(imsegm_image2d *im, const imsegm_gmm *gmm, const double *proba, int n_classes,
                         const double *pairwise, int edge_type, double edge_cost, int use_graphcut,
                         const int32_t *classes_lut, int32_t *segm_out, double *soft_out, int32_t *graph_labels_out,
@@ -1746,34 +1877,17 @@ static int segment_impl(imsegm_image2d *im, const imsegm_gmm *gmm, const double 
                 set_error("Cost matrix not square or not symmetric");
                 return -1;
             }
-    // (the K x K adjacency bitmap and its word prefixes: 2 x 11 GB at the 298 116 supervoxels of BASELINE configs[4] on a device
-    // of 288 GB.  What fits is asked of the device, not assumed: the two arrays must fit the memory that is free NOW -- plus
-    // what this session's own buffer already holds -- with a tenth of the device left over; beyond that the caller builds the graph
-    // with imsegm_volume_graph -- neighbour slots per label -- and cuts it with imsegm_cut_general_graph.  The message below is
-    // what pipelines.py recognises for that fall-back (a smaller or shared GPU must not fail in hipMalloc here).)
-    {
-        const double pair_bytes = 2.0 * (double)K * (double)cdiv(K, 32) * 4.0;
-        const int cap_mb = knobs().fused_bitmap_mb;
-        if (cap_mb > 0 && pair_bytes > 1048576.0 * cap_mb) {
-            set_error("segment: too many labels for the fused path (adjacency bitmap: IMSEGM_FUSED_BITMAP_MB)");
-            return -1;
-        }
-        if (pair_bytes > 16e6) {                  // (a 2-D image's graph: never in question, no query per image)
-            size_t free_b = 0, total_b = 0;
-            HIP_TRY(hipMemGetInfo(&free_b, &total_b));
-            const double usable = (double)free_b + (double)im->seg.cap - 0.1 * (double)total_b;
-            if (pair_bytes > usable || pair_bytes > 48e9) {
-                set_error("segment: too many labels for the fused path (adjacency bitmap: the device has no room for it)");
-                return -1;
-            }
-        }
-    }
+    // the graph: prepared ahead (imsegm_image2d_graph_prepare, same label map, room for the edges asked for) or built here
+    const bool prepared = im->graph_ready && im->gplan.K == K && (edge_capacity <= 0 || im->gplan.Ecap >= edge_capacity);
+    const GraphPlan g = prepared ? im->gplan : graph_plan(im, K, edge_capacity);
+    im->graph_ready = false;                   // (one segmentation per prepared graph: the cut works on the arcs' buffers)
+    if (!prepared)
+        if (int rc = graph_store_fits(im, g)) return rc;
     imsegm_ctx *ctx = im->ctx;
     hipStream_t st = ctx->stream;
     const size_t n = im->n;
     const int ndim = im->is_volume ? 3 : 2;
-    const int words = cdiv(K, 32);
-    const int Ecap = edge_capacity > 0 ? edge_capacity : (im->is_volume ? 16 * K + 64 : 3 * K + 64);     // planar graph: E <= 3K - 6
+    const int Ecap = g.Ecap;
     auto al = [](size_t v) { return (v + 63) & ~(size_t)63; };
     // ---- host -> device parameter block (one pinned staging copy)
     const size_t FF = (size_t)F * F;
@@ -1800,23 +1914,10 @@ static int segment_impl(imsegm_image2d *im, const imsegm_gmm *gmm, const double 
     const size_t d_wi = d; d += al((size_t)Ecap * 4);
     const size_t d_edist = d; d += al((size_t)Ecap * 8);
     const size_t d_elen = d; d += al((size_t)Ecap * 8);
-    const size_t d_edges = d; d += al((size_t)Ecap * 8);
-    const size_t d_as = d; d += al((size_t)(K + 1) * 4);
-    const size_t d_at = d; d += al((size_t)Ecap * 8);
-    const size_t d_ar = d; d += al((size_t)Ecap * 8);
-    const size_t d_ea = d; d += al((size_t)Ecap * 8);
-    const size_t d_deg = d; d += al((size_t)K * 4);
-    const size_t d_dlow = d; d += al((size_t)K * 4);
-    const size_t d_es = d; d += al((size_t)K * 4);
-    const size_t d_wp = d; d += al((size_t)K * words * 4);
     const size_t d_gl = d; d += al((size_t)K * 4);
     const size_t d_lut = d; d += al((size_t)K * 4);
     const size_t d_misc = d_par + o_misc;
     const size_t d_fstd = d; d += al((size_t)2 * std::max(F, 1) * 8);
-    const size_t d_bitmap = d; d += al((size_t)K * words * 4);
-    const size_t d_cacc = d; d += al((size_t)K * 4 * 8);
-    const size_t d_cent = d; d += al((size_t)K * 3 * 8);
-    const size_t d_present = d; d += al((size_t)K);
     const size_t d_work = d; d += al(alpha_expansion_work_bytes(K, Ecap));
     if (im->seg.ensure(d + 256)) return -1;
     unsigned char *dev = im->seg.as<unsigned char>();
@@ -1854,25 +1955,16 @@ static int segment_impl(imsegm_image2d *im, const imsegm_gmm *gmm, const double 
     int32_t *K_dev = misc, *E_dev = misc + 1, *status = misc + 2;
     long long *energy = reinterpret_cast<long long *>(dev + d_misc + 16);
     double *scalars = reinterpret_cast<double *>(dev + d_misc + 64);
-    // ---- graph: bitmap + centres, then the symmetric CSR
-    uint32_t *bitmap = reinterpret_cast<uint32_t *>(dev + d_bitmap);
-    double *centres = reinterpret_cast<double *>(dev + d_cent);
-    int sp = ctx->begin(PG_GRAPH);
-    if (im->is_volume) {
-        if (launch_vol_adjacency(im->labels.as<int32_t>(), im->D, im->H, im->W, K, words, bitmap, reinterpret_cast<long long *>(dev + d_cacc),
-                                 centres, dev + d_present, st))
-            return -1;
-    } else if (launch_adjacency_bitmap(im->labels.as<int32_t>(), im->H, im->W, K, bitmap, reinterpret_cast<long long *>(dev + d_cacc),
-                                       centres, dev + d_present, st)) {
-        return -1;
-    }
-    int32_t *edges = reinterpret_cast<int32_t *>(dev + d_edges);
-    if (launch_graph_csr(bitmap, K_dev, K, words, reinterpret_cast<int32_t *>(dev + d_wp), reinterpret_cast<int32_t *>(dev + d_deg),
-                         reinterpret_cast<int32_t *>(dev + d_dlow), reinterpret_cast<int32_t *>(dev + d_as),
-                         reinterpret_cast<int32_t *>(dev + d_es), E_dev, Ecap, edges, reinterpret_cast<int32_t *>(dev + d_at),
-                         reinterpret_cast<int32_t *>(dev + d_ar), reinterpret_cast<int32_t *>(dev + d_ea), st))
-        return -1;
-    ctx->end(sp);
+    // ---- graph: neighbour pairs + centres, then the symmetric CSR (im->gseg)
+    if (prepared) E_dev = nullptr;                           // (the prepared graph counted its edges in its own head)
+    else if (graph_enqueue(im, g, K_dev, E_dev)) return -1;
+    unsigned char *gb = im->gseg.as<unsigned char>();
+    int32_t *ghead = reinterpret_cast<int32_t *>(gb + g.o_head);
+    if (!E_dev) E_dev = ghead + 1;
+    int32_t *edges = reinterpret_cast<int32_t *>(gb + g.o_edges);
+    double *centres = reinterpret_cast<double *>(gb + g.o_cent);
+    int32_t *arc_start = reinterpret_cast<int32_t *>(gb + g.o_as), *arc_to = reinterpret_cast<int32_t *>(gb + g.o_at);
+    int32_t *arc_rev = reinterpret_cast<int32_t *>(gb + g.o_ar), *edge_arc = reinterpret_cast<int32_t *>(gb + g.o_ea);
     // ---- class probabilities, unary / edge terms, integer energies
     TermsArgs a;
     memset(&a, 0, sizeof(a));
@@ -1907,9 +1999,7 @@ static int segment_impl(imsegm_image2d *im, const imsegm_gmm *gmm, const double 
         p.K = K; p.C = C; p.E = Ecap; p.E_dev = E_dev;
         p.edges = edges; p.w = a.weights_i; p.unary = a.unary_i; p.smooth = reinterpret_cast<int32_t *>(dev + d_par + o_sm);
         p.metric = metric;
-        if (launch_alpha_expansion(p, reinterpret_cast<int32_t *>(dev + d_as), reinterpret_cast<int32_t *>(dev + d_at),
-                                   reinterpret_cast<int32_t *>(dev + d_ar), reinterpret_cast<int32_t *>(dev + d_ea), -1, glab, energy,
-                                   status + 1, dev + d_work, st))
+        if (launch_alpha_expansion(p, arc_start, arc_to, arc_rev, edge_arc, -1, glab, energy, status + 1, dev + d_work, st))
             return -1;
     } else if (launch_unary_argmin(a.unary, K_dev, K, C, glab, st)) {
         return -1;
@@ -1947,8 +2037,9 @@ static int segment_impl(imsegm_image2d *im, const imsegm_gmm *gmm, const double 
     if (soft_out) HIP_TRY(hipMemcpyAsync(soft_out, im->gather_out_f.p, n * C * 8, hipMemcpyDeviceToHost, st));
     if (graph_labels_out) HIP_TRY(hipMemcpyAsync(graph_labels_out, glab, (size_t)K * 4, hipMemcpyDeviceToHost, st));
     if (proba_out) HIP_TRY(hipMemcpyAsync(proba_out, a.proba, (size_t)K * C * 8, hipMemcpyDeviceToHost, st));
-    int32_t hmisc[4] = { 0, 0, 0, 0 };
+    int32_t hmisc[4] = { 0, 0, 0, 0 }, hgraph[4] = { 0, 0, 0, 0 };
     HIP_TRY(hipMemcpyAsync(hmisc, misc, sizeof(hmisc), hipMemcpyDeviceToHost, st));
+    if (prepared || g.table) HIP_TRY(hipMemcpyAsync(hgraph, ghead, sizeof(hgraph), hipMemcpyDeviceToHost, st));
     if (debug_out) {
         if (debug_out->unary) HIP_TRY(hipMemcpyAsync(debug_out->unary, a.unary, (size_t)K * C * 8, hipMemcpyDeviceToHost, st));
         if (debug_out->unary_int) HIP_TRY(hipMemcpyAsync(debug_out->unary_int, a.unary_i, (size_t)K * C * 4, hipMemcpyDeviceToHost, st));
@@ -1956,7 +2047,11 @@ static int segment_impl(imsegm_image2d *im, const imsegm_gmm *gmm, const double 
         if (debug_out->energy) HIP_TRY(hipMemcpyAsync(debug_out->energy, energy, 8, hipMemcpyDeviceToHost, st));
     }
     HIP_TRY(hipStreamSynchronize(st));
-    const int E = hmisc[1];
+    const int E = prepared ? hgraph[1] : hmisc[1];
+    if (g.table && hgraph[2]) {
+        set_error("segment: too many labels for the fused path (a label with more than 64 neighbours in the neighbour table)");
+        return IMSEGM_E_FUSED_PATH;
+    }
     if (debug_out) {
         debug_out->n_edges = E;
         const int Ec = std::min(E, debug_out->edge_capacity);

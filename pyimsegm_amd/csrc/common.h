@@ -184,6 +184,11 @@ __host__ __device__ __forceinline__ double fix_value(long long hi, long long lo,
 // ---------------------------------------------------------------------------------------------
 // wave64 helpers
 // ---------------------------------------------------------------------------------------------
+// lane i receives the value of lane i - 1 (lane 0 keeps `first`) / of lane i + 1 (lane 63 keeps `last`): ONE DPP move across the
+// whole wave (wave_shr:1 / wave_shl:1), no LDS round trip as __shfl_up / __shfl_down take
+__device__ __forceinline__ int lane_prev(int v, int first) { return __builtin_amdgcn_update_dpp(first, v, 0x138, 0xf, 0xf, false); }
+__device__ __forceinline__ int lane_next(int v, int last) { return __builtin_amdgcn_update_dpp(last, v, 0x130, 0xf, 0xf, false); }
+
 __device__ __forceinline__ long long wave_sum_i64(long long v)
 {
 #pragma unroll

@@ -174,16 +174,19 @@ __global__ void k_edge_emit(const uint32_t *__restrict__ bitmap, int K, int word
     }
 }
 
-// ---- edges out of the neighbour table (volume.hip k_vol_adjacency_centres<true>): row b holds the smaller neighbours of b in
-// any order with free slots (-1) in between; one wave per row counts them / writes them in ascending order (the rank of an entry
-// is the number of smaller ones), which gives the edge order of the bitmap: sorted by (b, a)
+// ---- edges out of the neighbour table (volume.hip k_vol_adjacency_runs<1>): row b holds ALL neighbours of b in any order with free
+// slots (-1) in between; one wave per row counts the smaller ones / writes them in ascending order (the rank of an entry is the
+// number of smaller ones), which gives the edge order of the bitmap: sorted by (b, a)
 __global__ void __launch_bounds__(256) k_table_rowcount(const int32_t *__restrict__ table, int K, int cap, int32_t *rowcount)
 {
     const int lane = threadIdx.x & 63;
     const int b = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     if (b >= K) return;
     int c = 0;
-    for (int i = lane; i < cap; i += 64) c += table[(size_t)b * cap + i] >= 0;
+    for (int i = lane; i < cap; i += 64) {
+        const int a = table[(size_t)b * cap + i];
+        c += a >= 0 && a < b;
+    }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) c += __shfl_xor(c, off, 64);
     if (lane == 0) rowcount[b] = c;
@@ -199,7 +202,7 @@ __global__ void __launch_bounds__(256) k_table_emit(const int32_t *__restrict__ 
     const int o = offsets[b];
     for (int i = lane; i < cap; i += 64) {
         const int a = row[i];
-        if (a < 0) continue;
+        if (a < 0 || a >= b) continue;                   // (the larger neighbours of b are the edges of THEIR rows)
         int rank = 0;
         for (int j = 0; j < cap; ++j) {
             const int other = row[j];

@@ -137,6 +137,16 @@ struct imsegm_ctx {
     }
 };
 
+// where the graph of a session's label map lives inside its `gseg` buffer (api.hip graph_plan: the layout follows from the number
+// of labels, the edge capacity and the form of the adjacency store -- K x K bitmap, or 64 neighbour slots per label for the label
+// volumes whose bitmap would not be small)
+struct GraphPlan {
+    int K = 0, Ecap = 0, cap = 0, words = 0;
+    bool table = false;
+    size_t o_head = 0, o_edges = 0, o_as = 0, o_at = 0, o_ar = 0, o_ea = 0, o_deg = 0, o_dlow = 0, o_es = 0, o_cent = 0, o_present = 0,
+           o_store = 0, o_cacc = 0, o_wp = 0, bytes = 0;
+};
+
 struct imsegm_image2d {
     imsegm_ctx *ctx = nullptr;
     int D = 1, H = 0, W = 0;      // D > 1: gray volume session (imsegm_volume_*)
@@ -148,7 +158,9 @@ struct imsegm_image2d {
     bool is_volume = false;
     double vol_off = 0.0, vol_scale = 1.0;      // intensity seen by the volume SLIC = (v + off) * scale
     DevBuf img, labA, labB, nearest, labels, conn_i32, conn_u8, small, cent, tiles, feat, graph, gather_lut, gather_out_i, gather_out_f,
-        tex_planes, tex_resp, tex_small, vol_cent, annot, hist, featK, seg, sweeps, narrow;
+        tex_planes, tex_resp, tex_small, vol_cent, annot, hist, featK, seg, gseg, sweeps, narrow;
+    GraphPlan gplan;                            // the graph imsegm_image2d_graph_prepare has enqueued into `gseg` ...
+    bool graph_ready = false;                   // ... for the current label map (any call that changes the labels clears this)
     int *slic_fail_host = nullptr;              // page-locked word the persistent sweep kernel raises when it cannot take the image
     int feat_mask = 0, feat_F = 0;              // layout of the resident feature table (imsegm_image2d_features_color)
     int place_F = 0, place_col = 0;             // imsegm_image2d_features_place: where the next descriptor call puts its columns

@@ -374,6 +374,11 @@ int launch_features_assemble(const double *mean, const double *energy, const dou
 int launch_graph_csr(uint32_t *bitmap, const int *K_dev, int K_cap, int words, int32_t *wordprefix, int32_t *deg, int32_t *deg_low,
                      int32_t *arc_start, int32_t *edge_start, int32_t *n_edges_dev, int edge_capacity, int32_t *edges,
                      int32_t *arc_to, int32_t *arc_rev, int32_t *edge_arc, hipStream_t st, ZBatch zb = ZBatch());
+// the same out of the symmetric neighbour table of a label volume (rows of cap <= 64 slots; the rows come back sorted)
+// (*overflow: a row was too narrow -- raised by the adjacency kernel; the graph then comes out without edges)
+int launch_graph_csr_table(int32_t *table, const int *K_dev, int K_cap, int cap, const int *overflow, int32_t *deg, int32_t *deg_low,
+                           int32_t *arc_start, int32_t *edge_start, int32_t *n_edges_dev, int edge_capacity, int32_t *edges,
+                           int32_t *arc_to, int32_t *arc_rev, int32_t *edge_arc, hipStream_t st);
 int launch_gc_terms(const TermsArgs &a, hipStream_t st, int nz = 1);          // (a.zs: the stride of a batch)
 int launch_unary_argmin(const double *unary, const int *K_dev, int K_cap, int C, int32_t *labels, hipStream_t st, ZBatch zb = ZBatch());
 int launch_label_lut(const int32_t *graph_labels, const int *K_dev, int K_cap, const int32_t *classes, int32_t *lut, hipStream_t st,

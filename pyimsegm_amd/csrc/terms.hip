@@ -208,6 +208,104 @@ k_adj_emit(const uint32_t *__restrict__ bitmap, const int *__restrict__ Kp, int 
     }
 }
 
+// ---- the same arcs out of the symmetric neighbour table of a label volume (volume.hip k_vol_adjacency_runs<1>; round 6: the
+// 3 * 10^5 supervoxels of BASELINE configs[4] made the bitmap 11 GB, its word prefixes another 11 GB, and the three kernels above
+// scan them -- the table is K x 64 slots = 76 MB).  One wave per row, one slot per lane (cap <= 64):
+//   k_tab_sort_rows  ranks the entries of a row among themselves and writes them back in ascending order (free slots behind);
+//                    degree and number of smaller neighbours fall out of two votes;
+//   k_adj_scan       (above) turns them into arc_start / edge_start / the edge count;
+//   k_tab_emit       lane i of row v holds arc v -> u_i: its reverse arc is the position of v in the (sorted) row of u -- a binary
+//                    search over at most 64 slots --, and u_i < v makes it edge (u_i, v) number edge_start[v] + i.
+// Same arcs in the same order as the bitmap path gives (rows ascending, neighbours ascending).
+__global__ void __launch_bounds__(256)
+k_tab_sort_rows(int32_t *table, const int *__restrict__ Kp, int cap, int32_t *__restrict__ deg, int32_t *__restrict__ deg_low,
+                const int *__restrict__ overflow)
+{
+    const int K = *Kp;
+    const int v = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+    if (v >= K) return;
+    if (*overflow) {
+        // a row was too narrow for its label's neighbours: the table is not the graph.  The caller reports it after its
+        // synchronisation (IMSEGM_E_FUSED_PATH); until then everything downstream works on a graph without edges.
+        if (lane == 0) {
+            deg[v] = 0;
+            deg_low[v] = 0;
+        }
+        return;
+    }
+    int32_t *row = table + (size_t)v * cap;
+    const int e = lane < cap ? row[lane] : -1;
+    const bool valid = e >= 0;
+    int rank = 0;
+    for (int j = 0; j < cap; ++j) {
+        const int o = __builtin_amdgcn_readlane(e, j);
+        rank += (o >= 0 && o < e) ? 1 : 0;
+    }
+    const int cnt = __popcll(__ballot(valid)), low = __popcll(__ballot(valid && e < v));
+    // (every lane has read its slot before any lane writes: the rank loop consumed the loads)
+    if (valid) row[rank] = e;
+    else if (lane < cap) {
+        // the free slots move behind the entries: lane = position among the invalid lanes
+        const unsigned long long inv = __ballot(!valid && lane < cap);
+        row[cnt + __popcll(inv & ((1ULL << lane) - 1ULL))] = -1;
+    }
+    if (lane == 0) {
+        deg[v] = cnt;
+        deg_low[v] = low;
+    }
+}
+
+__global__ void __launch_bounds__(256)
+k_tab_emit(const int32_t *__restrict__ table, const int *__restrict__ Kp, int cap, const int32_t *__restrict__ arc_start,
+           const int32_t *__restrict__ edge_start, int edge_capacity, int32_t *__restrict__ edges, int32_t *__restrict__ arc_to,
+           int32_t *__restrict__ arc_rev, int32_t *__restrict__ edge_arc)
+{
+    const int K = *Kp;
+    const int v = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+    if (v >= K) return;
+    if (lane >= arc_start[v + 1] - arc_start[v]) return;          // (the sorted row holds its deg entries in front)
+    const int u = table[(size_t)v * cap + lane];
+    const int pos = arc_start[v] + lane;
+    const int32_t *ru = table + (size_t)u * cap;
+    int lo = 0, hi = arc_start[u + 1] - arc_start[u];              // position of v in the sorted row of u
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (ru[mid] < v) lo = mid + 1;
+        else hi = mid;
+    }
+    const int rev = arc_start[u] + lo;
+    if (pos < 2 * edge_capacity) {
+        arc_to[pos] = u;
+        arc_rev[pos] = rev;
+    }
+    if (u < v) {                                                  // the smaller neighbours come first: lane = rank inside the row
+        const int j = edge_start[v] + lane;
+        if (j < edge_capacity) {
+            edges[2 * j] = u;
+            edges[2 * j + 1] = v;
+            edge_arc[2 * j] = rev;                               // arc u -> v
+            edge_arc[2 * j + 1] = pos;                           // arc v -> u
+        }
+    }
+}
+
+int launch_graph_csr_table(int32_t *table, const int *K_dev, int K_cap, int cap, const int *overflow, int32_t *deg, int32_t *deg_low,
+                           int32_t *arc_start, int32_t *edge_start, int32_t *n_edges_dev, int edge_capacity, int32_t *edges,
+                           int32_t *arc_to, int32_t *arc_rev, int32_t *edge_arc, hipStream_t st)
+{
+    if (cap < 1 || cap > 64) {
+        set_error("graph from the neighbour table: rows of 1 .. 64 slots");
+        return -1;
+    }
+    const dim3 grid(cdiv((long)K_cap * 64, 256));
+    hipLaunchKernelGGL(k_tab_sort_rows, grid, 256, 0, st, table, K_dev, cap, deg, deg_low, overflow);
+    hipLaunchKernelGGL(k_adj_scan, dim3(1, 1, 1), 256, 0, st, K_dev, deg, deg_low, arc_start, edge_start, n_edges_dev, (size_t)0);
+    hipLaunchKernelGGL(k_tab_emit, grid, 256, 0, st, table, K_dev, cap, arc_start, edge_start, edge_capacity, edges, arc_to, arc_rev,
+                       edge_arc);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
 // ---- class probabilities + graph-cut terms: ONE workgroup (K ~ 2e3 rows, E ~ 6e3 edges: a few microseconds; the
 // phases need grid-wide reductions of a handful of scalars, which a single workgroup gets from __syncthreads)
 

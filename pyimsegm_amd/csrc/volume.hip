@@ -418,6 +418,88 @@ k_vol_blur_r32(const float *__restrict__ src, float *__restrict__ dst32, int D, 
     dst32[i] = last ? f * fratio : f;                     // numpy: float32 array * Python float
 }
 
+// Round 6: the same three passes with a third of the traffic.  The axis passes above each read and write the whole volume (and the
+// z pass fetches every plane nine times from beyond the L2: a plane of config 5 is 64 MB) -- 20.7 ms for 2^30 voxels.
+//   * z pass (k_vol_blur_z32): a thread owns a column (four neighbouring columns: one 16-byte load per plane) and walks it along z
+//     with the 2 R + 1 planes of its window in registers -- every voxel is read once;
+//   * y and x pass together (k_vol_blur_yx32): a 64 x 32 tile of one slice with its halo goes through LDS, the y pass writes the
+//     float32 lines scipy would store into a second LDS tile, the x pass reads them from there.
+// Same operations in the same order on the same float32 intermediate values as the three passes (tests: both forms, bit for bit).
+constexpr int VBLUR_R = 4;                         // largest radius the two kernels take (sigma = 1: radius 4)
+
+template <int R, int VEC>
+__global__ void __launch_bounds__(256)
+k_vol_blur_z32(const float *__restrict__ src, float *__restrict__ dst, int D, int H, int W, Taps t, int zchunk)
+{
+    typedef float vec_t __attribute__((ext_vector_type(VEC)));
+    const int x = (blockIdx.x * 256 + threadIdx.x) * VEC, y = blockIdx.y;
+    const int z0 = blockIdx.z * zchunk, z1 = min(z0 + zchunk, D);
+    if (x >= W) return;
+    const size_t plane = (size_t)H * W, col = (size_t)y * W + x;
+    auto load = [&](int z) { return *reinterpret_cast<const vec_t *>(src + (size_t)vreflect(z, D) * plane + col); };
+    vec_t win[2 * R + 1];
+#pragma unroll
+    for (int j = 0; j <= 2 * R; ++j) win[j] = load(z0 - R + j);
+    vec_t ahead = load(z0 + R + 1);                   // the plane the NEXT step needs, requested a step early
+    for (int z = z0; z < z1; ++z) {
+        vec_t out;
+#pragma unroll
+        for (int c = 0; c < VEC; ++c) {
+            double v = (double)win[R][c] * t.w[0];
+#pragma unroll
+            for (int j = R; j >= 1; --j) v += ((double)win[R - j][c] + (double)win[R + j][c]) * t.w[j];
+            out[c] = (float)v;                       // scipy stores the line in the output dtype (float32)
+        }
+        *reinterpret_cast<vec_t *>(dst + (size_t)z * plane + col) = out;
+#pragma unroll
+        for (int j = 0; j < 2 * R; ++j) win[j] = win[j + 1];
+        win[2 * R] = ahead;
+        if (z + 2 < z1) ahead = load(z + R + 2);
+    }
+}
+
+__global__ void __launch_bounds__(256)
+k_vol_blur_yx32(const float *__restrict__ src, float *__restrict__ dst, int H, int W, Taps ty, Taps tx, float fratio)
+{
+    constexpr int TW = 64 + 2 * VBLUR_R, TH = 32 + 2 * VBLUR_R;
+    __shared__ float A[TH][TW];
+    __shared__ float B[32][TW];
+    const int X0 = blockIdx.x * 64, Y0 = blockIdx.y * 32;
+    const float *__restrict__ sl = src + (size_t)blockIdx.z * H * W;
+    for (int i = threadIdx.x; i < TH * TW; i += 256) {
+        const int r = i / TW, c = i - r * TW;
+        A[r][c] = sl[(size_t)vreflect(Y0 - VBLUR_R + r, H) * W + vreflect(X0 - VBLUR_R + c, W)];
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 32 * TW; i += 256) {
+        const int yy = i / TW, c = i - yy * TW;
+        double v = (double)A[yy + VBLUR_R][c] * ty.w[0];
+        for (int j = ty.r; j >= 1; --j) v += ((double)A[yy + VBLUR_R - j][c] + (double)A[yy + VBLUR_R + j][c]) * ty.w[j];
+        B[yy][c] = (float)v;
+    }
+    __syncthreads();
+    float *__restrict__ out = dst + (size_t)blockIdx.z * H * W;
+    for (int i = threadIdx.x; i < 32 * 64; i += 256) {
+        const int yy = i >> 6, xo = i & 63;
+        if (Y0 + yy >= H || X0 + xo >= W) continue;
+        double v = (double)B[yy][xo + VBLUR_R] * tx.w[0];
+        for (int j = tx.r; j >= 1; --j) v += ((double)B[yy][xo + VBLUR_R - j] + (double)B[yy][xo + VBLUR_R + j]) * tx.w[j];
+        out[(size_t)(Y0 + yy) * W + X0 + xo] = (float)v * fratio;      // numpy: float32 array * Python float
+    }
+}
+
+template <int VEC>
+static void launch_blur_z32(int R, dim3 grid, hipStream_t st, const float *src, float *dst, int D, int H, int W, const Taps &t, int zchunk)
+{
+    switch (R) {
+    case 0: hipLaunchKernelGGL((k_vol_blur_z32<0, VEC>), grid, 256, 0, st, src, dst, D, H, W, t, zchunk); break;
+    case 1: hipLaunchKernelGGL((k_vol_blur_z32<1, VEC>), grid, 256, 0, st, src, dst, D, H, W, t, zchunk); break;
+    case 2: hipLaunchKernelGGL((k_vol_blur_z32<2, VEC>), grid, 256, 0, st, src, dst, D, H, W, t, zchunk); break;
+    case 3: hipLaunchKernelGGL((k_vol_blur_z32<3, VEC>), grid, 256, 0, st, src, dst, D, H, W, t, zchunk); break;
+    default: hipLaunchKernelGGL((k_vol_blur_z32<4, VEC>), grid, 256, 0, st, src, dst, D, H, W, t, zchunk); break;
+    }
+}
+
 int launch_vol_preprocess_f32(const float *src, int D, int H, int W, const Taps &tz, const Taps &ty, const Taps &tx, double ratio,
                               double *bufA, double *bufB, hipStream_t st)
 {
@@ -425,6 +507,32 @@ int launch_vol_preprocess_f32(const float *src, int D, int H, int W, const Taps 
     if (H > 65535 || D > 65535) {
         set_error("volume pre-processing: more than 65 535 rows or slices");
         return -1;
+    }
+    if (tz.r <= VBLUR_R && ty.r <= VBLUR_R && tx.r <= VBLUR_R && !knobs().pre_3pass) {
+        // an axis that is not filtered (radius < 0) passes its values through: the single tap 1.0 (x * 1.0 == x, (float)(double)x == x)
+        auto eff = [](const Taps &t) {
+            Taps e = t;
+            if (e.r < 0) {
+                e.r = 0;
+                e.w[0] = 1.0;
+            }
+            return e;
+        };
+        const float *mid = src;
+        if (tz.r >= 0) {
+            const int vec = (W % 4 == 0 && (reinterpret_cast<uintptr_t>(src) & 15) == 0) ? 4 : 1;
+            // enough columns to fill the device, else the z range in chunks (each re-reads the 2 R planes around it)
+            const long columns = (long)cdiv(W, vec) * H;
+            int chunks = (int)std::min<long>(std::max<long>(1, (long)(16384L * 64 / std::max<long>(columns, 1))), std::max(1, D / 16));
+            const int zchunk = cdiv(D, chunks);
+            const dim3 grid(cdiv(cdiv(W, vec), 256), H, cdiv(D, zchunk));
+            if (vec == 4) launch_blur_z32<4>(tz.r, grid, st, src, a32, D, H, W, tz, zchunk);
+            else launch_blur_z32<1>(tz.r, grid, st, src, a32, D, H, W, tz, zchunk);
+            mid = a32;
+        }
+        hipLaunchKernelGGL(k_vol_blur_yx32, dim3(cdiv(W, 64), cdiv(H, 32), D), 256, 0, st, mid, b32, H, W, eff(ty), eff(tx), (float)ratio);
+        HIP_TRY(hipGetLastError());
+        return 0;   // float32 result in bufB
     }
     const dim3 rows(cdiv(W, 256), H, D);
     hipLaunchKernelGGL(k_vol_blur_r32<0>, rows, 256, 0, st, src, b32, D, H, W, tz, 0.f, 0);
@@ -1094,9 +1202,11 @@ int launch_label_cc(int32_t *labels_inout, int D, int H, int W, int32_t *parent,
 }
 
 // ---- 6-connected adjacency bitmap + centre sums of a label volume -----------------------------------------
-// (TABLE: instead of bit (row b, column a) of a K x K bitmap, the smaller label a goes into row b of a K x cap table of neighbour
-// slots -- open addressing inside the row, -1 = free; a row that is full raises *overflow and the caller comes back with wider
-// rows.  The bitmap is 11 GB for the 3 * 10^5 supervoxels of BASELINE configs[4] and caps K; the table is K * cap * 4 bytes.)
+// (table: instead of bit (row b, column a) of a K x K bitmap, every label goes into the row of each of its neighbours in a K x cap
+// table of neighbour slots -- open addressing inside the row, -1 = free; a row that is full raises *overflow and the caller comes
+// back with wider rows.  The bitmap is 11 GB for the 3 * 10^5 supervoxels of BASELINE configs[4] and caps K; the table is
+// K * cap * 4 bytes.  Round 6: the table is SYMMETRIC (rounds 4 / 5 kept the smaller neighbours only), so that the fused call can
+// build its arcs from it -- terms.hip k_tab_sort_rows / k_tab_emit -- as it does from the mirrored bitmap.)
 __device__ __forceinline__ void neighbour_insert(int32_t *table, int cap, int b, int a, int *overflow)
 {
     int32_t *row = table + (size_t)b * cap;
@@ -1113,42 +1223,113 @@ __device__ __forceinline__ void neighbour_insert(int32_t *table, int cap, int b,
     *overflow = 1;
 }
 
-template <bool TABLE>
-__global__ void __launch_bounds__(256)
-k_vol_adjacency_centres(const int32_t *__restrict__ labels, int D, int H, int W, int words, uint32_t *bitmap,
-                        long long *__restrict__ cacc, int32_t *table, int cap, int *overflow)
+// Round 6: by rows and runs, like the 2-D kernel (graph.hip).  A wave owns 64 x VA_ROWS voxels of one slice -- VA_ROWS + 1 rows of it
+// and VA_ROWS rows of the next slice in registers, the left / right neighbour through one DPP move each.
+//   * neighbour pairs: across x a pair exists exactly where a run ends; across y and z the pair (label, label below / behind) of a
+//     voxel is the pair of its left neighbour along the whole contact of two segments, so only the lane where EITHER label changes
+//     reports it -- a handful of inserts per run instead of one per surface voxel;
+//   * centre sums: the first lane of a run knows its length from the vote of the run starts, hence n, sum y, sum x of the run in
+//     closed form (z is the workgroup's); they meet in an LDS hash table of the workgroup (a 64 x 16 cross-section sees a dozen
+//     labels), flushed with one set of int64 global atomics per label and workgroup.
+// Rounds 2 - 5 went voxel by voxel: two 32-bit divisions per voxel for its coordinates, a serial loop over the distinct labels of
+// a wave with eight int64 wave reductions and four global atomics each (19.8 ms for the 2^30 voxels of BASELINE configs[4]).
+// MODE 0: bit (row b, column a), a < b, of the K x K bitmap; MODE 1: a into row b AND b into row a of the neighbour table.
+constexpr int VA_ROWS = 4;
+constexpr int VA_SLOTS = 64;
+
+template <int MODE>
+__device__ __forceinline__ void adjacency_report(int l, int nb, int words, uint32_t *bitmap, int32_t *table, int cap, int *overflow)
 {
-    int p = blockIdx.x * blockDim.x + threadIdx.x;
-    const int n = D * H * W;
-    const int lane = threadIdx.x & 63;
-    int l = p < n ? labels[p] : -1;
-    int x = 0, y = 0, z = 0;
-    if (l >= 0) {
-        x = p % W; y = (p / W) % H; z = p / (W * H);
-        int nb[3] = { x + 1 < W ? labels[p + 1] : l, y + 1 < H ? labels[p + W] : l, z + 1 < D ? labels[p + W * H] : l };
+    if (MODE == 1) {
+        neighbour_insert(table, cap, l, nb, overflow);
+        neighbour_insert(table, cap, nb, l, overflow);
+    } else {
+        const int a = min(l, nb), b = max(l, nb);
+        uint32_t *wp = bitmap + (size_t)b * words + (a >> 5);
+        const uint32_t bit = 1u << (a & 31);
+        if (!(*wp & bit)) atomicOr(wp, bit);
+    }
+}
+
+template <int MODE>
+__global__ void __launch_bounds__(256)
+k_vol_adjacency_runs(const int32_t *__restrict__ labels, int D, int H, int W, int words, uint32_t *bitmap,
+                     long long *__restrict__ cacc, int32_t *table, int cap, int *overflow)
+{
+    __shared__ int h_key[VA_SLOTS], h_n[VA_SLOTS], h_sy[VA_SLOTS], h_sx[VA_SLOTS];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if (threadIdx.x < VA_SLOTS) {
+        h_key[threadIdx.x] = -1;
+        h_n[threadIdx.x] = 0;
+        h_sy[threadIdx.x] = 0;
+        h_sx[threadIdx.x] = 0;
+    }
+    __syncthreads();
+    const int z = blockIdx.z;
+    const int y0 = (blockIdx.y * 4 + wave) * VA_ROWS;
+    const int x = blockIdx.x * 64 + lane;
+    const bool xin = x < W;
+    const int32_t *__restrict__ base = labels + ((size_t)z * H + y0) * W;          // (wave uniform)
+    const size_t plane = (size_t)H * W;
+    int lab[VA_ROWS + 1], behind[VA_ROWS];
 #pragma unroll
-        for (int j = 0; j < 3; ++j) {
-            if (nb[j] == l) continue;
-            int a = min(l, nb[j]), b = max(l, nb[j]);
-            if (TABLE) {
-                neighbour_insert(table, cap, b, a, overflow);
-            } else {
-                uint32_t *wp = bitmap + (size_t)b * words + (a >> 5);
-                uint32_t bit = 1u << (a & 31);
-                if (!(*wp & bit)) atomicOr(wp, bit);
+    for (int r = 0; r <= VA_ROWS; ++r) lab[r] = (xin && y0 + r < H) ? base[(size_t)r * W + x] : -1;
+#pragma unroll
+    for (int r = 0; r < VA_ROWS; ++r) behind[r] = (xin && y0 + r < H && z + 1 < D) ? base[plane + (size_t)r * W + x] : -1;
+    const unsigned long long le = (lane == 63) ? ~0ULL : ((2ULL << lane) - 1ULL);
+#pragma unroll
+    for (int r = 0; r < VA_ROWS; ++r) {
+        const int y = y0 + r;
+        const int l = lab[r];
+        const bool act = l >= 0;                                   // (the active lanes of a row are lanes 0 .. nact - 1)
+        int right = lane_next(l, -1);
+        if (lane == 63) right = (x + 1 < W && y < H) ? base[(size_t)r * W + x + 1] : -1;
+        const int left = lane_prev(l, -2);
+        const int below = lab[r + 1], back = behind[r];
+        const int below_left = lane_prev(below, -2), back_left = lane_prev(back, -2);
+        if (act) {
+            if (right >= 0 && right != l) adjacency_report<MODE>(l, right, words, bitmap, table, cap, overflow);
+            if (below >= 0 && below != l && !(left == l && below_left == below))
+                adjacency_report<MODE>(l, below, words, bitmap, table, cap, overflow);
+            if (back >= 0 && back != l && !(left == l && back_left == back))
+                adjacency_report<MODE>(l, back, words, bitmap, table, cap, overflow);
+        }
+        const bool start = act && left != l;                       // (lane 0: left = -2)
+        const unsigned long long starts = __ballot(start);
+        const int nact = __popcll(__ballot(act));
+        if (start) {
+            const unsigned long long above = starts & ~le;
+            const int len = (above ? __ffsll((long long)above) - 1 : nact) - lane;
+            const int sy = len * y, sx = len * x + (len * (len - 1)) / 2;
+            int slot = (int)(((unsigned int)l * 2654435761u) >> 26);          // 6 bits
+            bool placed = false;
+            for (int probe = 0; probe < VA_SLOTS; ++probe) {
+                const int old = atomicCAS(&h_key[slot], -1, l);
+                if (old == -1 || old == l) {
+                    placed = true;
+                    break;
+                }
+                slot = (slot + 1) & (VA_SLOTS - 1);
+            }
+            if (placed) {
+                atomicAdd(&h_n[slot], len);
+                atomicAdd(&h_sy[slot], sy);
+                atomicAdd(&h_sx[slot], sx);
+            } else {                                               // (more than VA_SLOTS labels in a 64 x 16 cross-section)
+                atomic_add_i64(cacc + (size_t)l * 4 + 0, len);
+                atomic_add_i64(cacc + (size_t)l * 4 + 1, (long long)len * z);
+                atomic_add_i64(cacc + (size_t)l * 4 + 2, (long long)sy);
+                atomic_add_i64(cacc + (size_t)l * 4 + 3, (long long)sx);
             }
         }
     }
-    int cur = l;
-    while (true) {
-        unsigned long long vote = __ballot(cur >= 0);
-        if (!vote) break;
-        int k = __shfl(cur, __ffsll((long long)vote) - 1, 64);
-        bool mine = cur == k;
-        long long q[8] = { mine ? 1 : 0, mine ? z : 0, mine ? y : 0, mine ? x : 0, 0, 0, 0, 0 };
-        long long tot = wave_reduce8_i64(q);
-        if ((lane & 7) == 0 && (lane >> 3) < 4) atomic_add_i64(cacc + (size_t)k * 4 + (lane >> 3), tot);
-        if (mine) cur = -1;
+    __syncthreads();
+    if (threadIdx.x < VA_SLOTS && h_key[threadIdx.x] >= 0) {
+        const int k = h_key[threadIdx.x], n = h_n[threadIdx.x];
+        atomic_add_i64(cacc + (size_t)k * 4 + 0, n);
+        atomic_add_i64(cacc + (size_t)k * 4 + 1, (long long)n * z);
+        atomic_add_i64(cacc + (size_t)k * 4 + 2, h_sy[threadIdx.x]);
+        atomic_add_i64(cacc + (size_t)k * 4 + 3, h_sx[threadIdx.x]);
     }
 }
 
@@ -1162,13 +1343,18 @@ __global__ void k_vol_centres_finalize(const long long *__restrict__ cacc, int K
         centres[3 * k + c] = n > 0 ? i64_to_double(cacc[(size_t)k * 4 + 1 + c]) / (double)n : -1.0;
 }
 
+static inline dim3 vol_adjacency_grid(int D, int H, int W) { return dim3(cdiv(W, 64), cdiv(H, 4 * VA_ROWS), D); }
+
 int launch_vol_adjacency(const int32_t *labels, int D, int H, int W, int K, int words, uint32_t *bitmap, long long *cacc,
                          double *centres, uint8_t *present, hipStream_t st)
 {
-    const int n = D * H * W;
+    if (D > 65535 || cdiv(H, 4 * VA_ROWS) > 65535) {
+        set_error("adjacency: more than 65 535 slices or 1 048 560 rows");
+        return -1;
+    }
     HIP_TRY(hipMemsetAsync(bitmap, 0, (size_t)K * words * sizeof(uint32_t), st));
     HIP_TRY(hipMemsetAsync(cacc, 0, (size_t)K * 4 * sizeof(long long), st));
-    hipLaunchKernelGGL(k_vol_adjacency_centres<false>, cdiv(n, 256), 256, 0, st, labels, D, H, W, words, bitmap, cacc, nullptr, 0, nullptr);
+    hipLaunchKernelGGL(k_vol_adjacency_runs<0>, vol_adjacency_grid(D, H, W), 256, 0, st, labels, D, H, W, words, bitmap, cacc, nullptr, 0, nullptr);
     hipLaunchKernelGGL(k_vol_centres_finalize, cdiv(K, 256), 256, 0, st, cacc, K, centres, present);
     HIP_TRY(hipGetLastError());
     return 0;
@@ -1179,11 +1365,14 @@ int launch_vol_adjacency(const int32_t *labels, int D, int H, int W, int K, int 
 int launch_vol_adjacency_table(const int32_t *labels, int D, int H, int W, int K, int32_t *table, int cap, int *overflow, long long *cacc,
                                double *centres, uint8_t *present, hipStream_t st)
 {
-    const int n = D * H * W;
+    if (D > 65535 || cdiv(H, 4 * VA_ROWS) > 65535) {
+        set_error("adjacency: more than 65 535 slices or 1 048 560 rows");
+        return -1;
+    }
     HIP_TRY(hipMemsetAsync(table, 0xff, (size_t)K * cap * sizeof(int32_t), st));
     HIP_TRY(hipMemsetAsync(overflow, 0, sizeof(int), st));
     HIP_TRY(hipMemsetAsync(cacc, 0, (size_t)K * 4 * sizeof(long long), st));
-    hipLaunchKernelGGL(k_vol_adjacency_centres<true>, cdiv(n, 256), 256, 0, st, labels, D, H, W, 0, nullptr, cacc, table, cap, overflow);
+    hipLaunchKernelGGL(k_vol_adjacency_runs<1>, vol_adjacency_grid(D, H, W), 256, 0, st, labels, D, H, W, 0, nullptr, cacc, table, cap, overflow);
     hipLaunchKernelGGL(k_vol_centres_finalize, cdiv(K, 256), 256, 0, st, cacc, K, centres, present);
     HIP_TRY(hipGetLastError());
     return 0;

@@ -656,24 +656,32 @@ def _gray3d_on_session(sess, image, nb_classes, dict_features, spacing, sp_size,
     features, _ = norm_features(features)
     logging.debug('list of features NORM: %r', features.shape)
 
+    # the graph of the supervoxels (neighbour pairs, centres, edges, arcs) depends on the label map alone: it is enqueued HERE and
+    # built by the device while the host fits the mixture -- the fused call below finds it ready
+    fused = True
+    try:
+        sess.graph_prepare()
+    except _hip.HipFusedPathError as ex:
+        fused = False
+        logging.info('volume graph by neighbour tables (%s)', ex)
+
     model = estim_class_model(features, nb_classes)
     proba = predict_proba(model, features)          # (scikit-learn's arithmetic without its per-call validation: same bits)
     logging.debug('list of probabilities: %r', proba.shape)
 
     segm = None
-    try:
-        # fused: graph, unary / edge terms ('model' edges), alpha-expansion and the gather in one call -- when the K x K bit
-        # arrays of imsegm_image2d_segment fit the memory the device has free (the library asks hipMemGetInfo)
-        from pyimsegm_amd.graph_cuts import compute_pairwise_cost
-        use_gc = not (np.isscalar(gc_regul) and gc_regul <= 0)
-        segm_ready()
-        segm = sess.segment(compute_pairwise_cost(gc_regul, proba.shape), 'model', proba=proba, use_graphcut=use_gc,
-                            pinned=False, segm_out=segm_buf)['segm']
-    except _hip.HipError as ex:
-        if 'fused path' not in str(ex) and 'out of memory' not in str(ex).lower():
-            raise
-        logging.info('volume graph by neighbour tables (%s)', ex)
+    if fused:
+        try:
+            # fused: unary / edge terms ('model' edges), alpha-expansion and the gather in one call on the prepared graph
+            from pyimsegm_amd.graph_cuts import compute_pairwise_cost
+            use_gc = not (np.isscalar(gc_regul) and gc_regul <= 0)
+            segm_ready()
+            segm = sess.segment(compute_pairwise_cost(gc_regul, proba.shape), 'model', proba=proba, use_graphcut=use_gc,
+                                pinned=False, segm_out=segm_buf)['segm']
+        except _hip.HipFusedPathError as ex:            # (IMSEGM_E_FUSED_PATH only: any other error of the call is an error)
+            logging.info('volume graph by neighbour tables (%s)', ex)
     if segm is None:
         graph_labels = segment_graph_cut_general(_ShapeOnly(sess.shape), proba, image, features, gc_regul, _session=sess)
-        segm, _ = sess.gather(graph_labels)
+        segm_ready()
+        segm, _ = sess.gather(graph_labels, segm_out=segm_buf)     # (into the array touched above: no second result array)
     return segm

@@ -70,8 +70,10 @@ class Image2D(object):
         centres = np.asarray(orc.centers(self.labels), dtype=np.float64).reshape(self.n_labels, -1)
         present = np.zeros(self.n_labels, dtype=bool); present[np.asarray(vertices)] = True
         return np.array(edges, dtype=np.int32).reshape(-1, 2), centres, present
-    def gather(self, graph_labels=None, proba=None, to_host=True):
+    def graph_prepare(self): pass
+    def gather(self, graph_labels=None, proba=None, to_host=True, segm_out=None):
         segm = np.asarray(graph_labels, dtype=np.int32)[self.labels] if graph_labels is not None else None
+        if segm is not None and segm_out is not None: segm_out[...] = segm; segm = segm_out
         self.last_segm = segm
         soft = np.asarray(proba, dtype=np.float64)[self.labels] if proba is not None else None
         return segm, soft

@@ -251,3 +251,112 @@ def test_fused_call_takes_label_maps_that_are_no_planar_partition():
         assert np.array_equal(res['segm'], np.asarray(want)[labels])
     finally:
         sess.close()
+
+
+def _volume_session(seed=3, shape=(12, 40, 48), sp=8):
+    from pyimsegm_amd import superpixels as S
+    rng = np.random.default_rng(seed)
+    vol = ellipsoid_volume(shape).astype(np.float64) + 0.1 * rng.standard_normal(shape)
+    sess = S._open_volume(vol)
+    S._run_slic3d(sess, sp, 0.2, (2, 1, 1))
+    return sess, rng
+
+
+_GRAPH_KEYS = ('edges', 'centres', 'edge_weights', 'edge_weights_int', 'unary_int', 'graph_labels', 'segm', 'energy')
+
+
+def test_fused_volume_call_from_the_neighbour_table(monkeypatch):
+    """round 6: beyond 46 000 labels (BASELINE configs[4]: 298 116) the fused call builds its arcs from the symmetric neighbour table
+    -- 64 slots per label, rows sorted on the device, reverse arcs by binary search (terms.hip k_tab_sort_rows / k_tab_emit) --
+    instead of the mirrored K x K bitmap.  Forced here on a small volume: edges in (b, a) order, centres, integer terms, the cut and
+    the class map equal the bitmap path's, and the graph call's (superpixels.py:180-242)."""
+    from pyimsegm_amd import graph_cuts as G
+    sess, rng = _volume_session()
+    try:
+        proba = rng.dirichlet(np.ones(3), size=sess.n_labels)
+        pairwise = G.compute_pairwise_cost(0.3, proba.shape)
+        by_bitmap = sess.segment(pairwise, 'model', proba=proba, debug=True, pinned=False)
+        monkeypatch.setenv('IMSEGM_ADJACENCY_TABLE', '1')
+        by_table = sess.segment(pairwise, 'model', proba=proba, debug=True, pinned=False)
+        for key in _GRAPH_KEYS:
+            assert np.array_equal(by_bitmap[key], by_table[key]), key
+        edges, centres, _ = sess.graph()                          # (imsegm_volume_graph: its own read-out of the table)
+        assert np.array_equal(by_table['edges'], edges) and np.array_equal(by_table['centres'], centres)
+        assert len(edges) > 3 * sess.n_labels                      # a 6-connected supervoxel graph, not a planar one
+    finally:
+        sess.close()
+
+
+def test_fused_volume_call_when_a_label_has_more_neighbours_than_a_table_row(monkeypatch):
+    """a slab that touches 150 labels does not fit the 64 slots of a row: status IMSEGM_E_FUSED_PATH (HipFusedPathError), and
+    the staged calls -- imsegm_volume_graph widens its rows -- give the segmentation"""
+    from pyimsegm_amd import _hip
+    from pyimsegm_amd.graph_cuts import compute_pairwise_cost, segment_graph_cut_general
+    monkeypatch.setenv('IMSEGM_ADJACENCY_TABLE', '1')
+    wide = (np.arange(6 * 30 * 40).reshape(6, 30, 40) // 8) % 150
+    wide[3] = 150
+    rng = np.random.default_rng(5)
+    proba = rng.dirichlet(np.ones(2), size=151)
+    sess = _hip.Volume3D(*wide.shape).set_labels(wide.astype(np.int64))
+    try:
+        with pytest.raises(_hip.HipFusedPathError, match='64 neighbours'):
+            sess.segment(compute_pairwise_cost(0.5, proba.shape), 'model', proba=proba, pinned=False)
+        with pytest.raises(_hip.HipFusedPathError):                # the prepared graph reports it at the call that reads its head
+            sess.graph_prepare()
+            sess.segment(compute_pairwise_cost(0.5, proba.shape), 'model', proba=proba, pinned=False)
+        labels = segment_graph_cut_general(wide, proba, None, None, 0.5, 'model', _session=sess)
+        monkeypatch.delenv('IMSEGM_ADJACENCY_TABLE')
+        by_bitmap = sess.segment(compute_pairwise_cost(0.5, proba.shape), 'model', proba=proba, want_graph_labels=True, pinned=False)
+        assert np.array_equal(by_bitmap['graph_labels'], labels)
+    finally:
+        sess.close()
+
+
+@pytest.mark.parametrize('table', [False, True], ids=['bitmap', 'table'])
+def test_graph_prepared_ahead_of_the_fused_call(monkeypatch, table):
+    """imsegm_image2d_graph_prepare: the graph of the label map enqueued ahead (the volume pipeline builds it under the host's
+    mixture fit) -- the fused call on it returns what the fused call alone returns; a prepared graph does not survive a new
+    label map"""
+    from pyimsegm_amd import graph_cuts as G
+    from pyimsegm_amd import superpixels as S
+    if table:
+        monkeypatch.setenv('IMSEGM_ADJACENCY_TABLE', '1')
+    sess, rng = _volume_session(seed=11)
+    try:
+        proba = rng.dirichlet(np.ones(3), size=sess.n_labels)
+        pairwise = G.compute_pairwise_cost(0.3, proba.shape)
+        alone = sess.segment(pairwise, 'model', proba=proba, debug=True, pinned=False)
+        sess.graph_prepare()
+        ahead = sess.segment(pairwise, 'model', proba=proba, debug=True, pinned=False)
+        for key in _GRAPH_KEYS:
+            assert np.array_equal(alone[key], ahead[key]), key
+        # a new label map between the preparation and the call: the call builds the graph of the NEW map
+        sess.graph_prepare()
+        S._run_slic3d(sess, 6, 0.2, (2, 1, 1))
+        proba2 = rng.dirichlet(np.ones(3), size=sess.n_labels)
+        fresh = sess.segment(pairwise, 'model', proba=proba2, debug=True, pinned=False)
+        edges, centres, _ = sess.graph()
+        assert np.array_equal(fresh['edges'], edges) and np.array_equal(fresh['centres'], centres)
+    finally:
+        sess.close()
+
+
+def test_graph_prepared_ahead_for_a_colour_image():
+    """the same on a 2-D session (bitmap store, centres with two coordinates)"""
+    from pyimsegm_amd import _hip
+    from pyimsegm_amd import graph_cuts as G
+    from pyimsegm_amd.utilities.synthetic import voronoi_image
+    image = voronoi_image(120, 160, seed=4)
+    sess = _hip.Image2D(120, 160).upload(image)
+    try:
+        sess.slic(60, 10.)
+        rng = np.random.default_rng(2)
+        proba = rng.dirichlet(np.ones(3), size=sess.n_labels)
+        pairwise = G.compute_pairwise_cost(1., proba.shape)
+        alone = sess.segment(pairwise, 'model', proba=proba, debug=True)
+        sess.graph_prepare()
+        ahead = sess.segment(pairwise, 'model', proba=proba, debug=True)
+        for key in _GRAPH_KEYS:
+            assert np.array_equal(alone[key], ahead[key]), key
+    finally:
+        sess.close()

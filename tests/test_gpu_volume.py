@@ -218,6 +218,30 @@ def test_reference_doctest_vectors_gray3d():
                                atol=1e-7)
 
 
+@pytest.mark.parametrize('shape,space', [((24, 40, 48), (1, 1, 1)), ((9, 64, 70), (5, 1, 1)), ((35, 50, 200), (2, 1, 1)),
+                                         ((1, 50, 60), (1, 1, 1)), ((3, 5, 7), (1, 1, 1)), ((20, 33, 130), (1, 2, 3))])
+def test_float32_blur_by_columns_and_tiles_equals_the_three_axis_passes(hip, monkeypatch, shape, space):
+    """round 6: the Gaussian of a float32 volume as a z pass over register windows + a fused y / x pass through LDS
+    (volume.hip k_vol_blur_z32 / k_vol_blur_yx32) against the three axis passes of rounds 2 - 5 (IMSEGM_PRE_3PASS): the k-means
+    assignment and the supervoxel map after it do not move by a voxel -- ragged sizes, a volume smaller than the filter, one
+    slice, a different radius per axis (sigma / spacing), W not a multiple of four (scalar loads)"""
+    from pyimsegm_amd.superpixels import _slic3d_params
+    vol = _noisy_ellipsoid(shape, seed=9, dtype=np.float32)
+    n_seg, compact = _slic3d_params(vol.shape, 6, 0.2, space)
+    n_seg, compact, spacing = max(n_seg, 2), max(compact, 1), space
+    maps = []
+    for three_pass in (False, True):
+        if three_pass:
+            monkeypatch.setenv('IMSEGM_PRE_3PASS', '1')
+        sess = hip.Volume3D(*vol.shape).upload(vol)
+        sess.slic(n_seg, compact, sigma=1., spacing=spacing, enforce_connectivity=False)
+        raw = sess.get_labels()
+        sess.slic(n_seg, compact, sigma=1., spacing=spacing)
+        maps.append((raw, sess.get_labels()))
+        sess.close()
+    assert np.array_equal(maps[0][0], maps[1][0]) and np.array_equal(maps[0][1], maps[1][1])
+
+
 def test_reference_doctest_vectors_graph3d():
     """superpixels.py:185-192 and :214-215 of the reference"""
     from pyimsegm_amd import superpixels as sp
@@ -307,7 +331,7 @@ def test_pipe_gray3d_when_the_device_has_no_room_for_the_bit_arrays(hip, monkeyp
     fused = pipelines.pipe_gray3d_slic_features_model_graphcut(image, 2, {'color': ['mean', 'std']}, sp_size=10, spacing=(1, 1, 1))
     monkeypatch.setenv('IMSEGM_FUSED_BITMAP_MB', '1')
     sess = hip.Volume3D(*image.shape).set_labels((np.arange(image.size).reshape(image.shape) // 7 % 6000).astype(np.int64))
-    with pytest.raises(hip.HipError, match='fused path'):
+    with pytest.raises(hip.HipFusedPathError, match='fused path'):          # (status IMSEGM_E_FUSED_PATH, not a message match)
         sess.segment(np.zeros((2, 2)), 'model', proba=np.full((6000, 2), 0.5), pinned=False)
     sess.close()
     np.random.seed(0)
