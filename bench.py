@@ -86,6 +86,7 @@ def parse_args(argv=None):
     ap.add_argument('--input-ring', type=int, default=-1, help='1: every worker thread copies the images of a step into its own page-locked '
                                                                'buffers first (one memcpy, then DMA) instead of handing pageable arrays to the '
                                                                'runtime (default off: measured slower on one GPU)')
+    ap.add_argument('--probe-seconds', type=float, default=1.0, help='N > 1, --input-ring -1: length of each of the two input-staging probes')
     ap.add_argument('--no-full-volume', action='store_true', help='leave BASELINE configs[4] at its full 64x4096x4096 out of `other_configs`')
     return ap.parse_args(argv)
 
@@ -167,6 +168,50 @@ def real_skimage_slic(image, sp_size, sp_regul, repeats=1):
                 return None
             version, seconds = run.stdout.split()[-2:]
             return version, [float(s) for s in seconds.split(',')], np.load(dst)
+    except Exception:
+        return None
+
+
+_SKIMAGE3D_SCRIPT = r'''
+import sys, time, warnings
+warnings.filterwarnings("ignore")
+import numpy as np
+from skimage import measure
+from skimage.segmentation import slic
+import skimage
+im = np.load(sys.argv[1])
+sp_size, rc = float(sys.argv[3]), float(sys.argv[4])
+space = tuple(float(v) for v in sys.argv[5].split(","))
+nb_pixels = np.prod(im.shape)                                          # imsegm/superpixels.py:93-97
+sp = np.prod(sp_size / np.asarray(space, dtype=np.float32) * min(space))
+t0 = time.perf_counter()
+seg = slic(np.array(im), n_segments=int(nb_pixels / sp), compactness=int((sp * rc)**1.5), multichannel=False, spacing=space, sigma=1)
+t1 = time.perf_counter()
+seg = measure.label(seg)                                               # imsegm/superpixels.py:104-111
+t2 = time.perf_counter()
+np.save(sys.argv[2], np.asarray(seg).astype(np.int32))
+print("%s %.4f,%.4f" % (skimage.__version__, t1 - t0, t2 - t1))
+'''
+
+
+def real_skimage_slic3d(vol, sp_size, sp_regul, spacing):
+    """the REAL `skimage.segmentation.slic` + `skimage.measure.label` behind imsegm/superpixels.py:104-111 on a gray volume, one host
+    core, under the image's conda Python 3.9 (as real_skimage_slic): (version, [slic seconds, label seconds], label map) or None"""
+    import subprocess
+    import tempfile
+    py = os.environ.get('IMSEGM_SKIMAGE_PYTHON', '/opt/conda/bin/python3.9')
+    if not os.path.exists(py):
+        return None
+    try:
+        with tempfile.TemporaryDirectory() as tmp:
+            src, dst = os.path.join(tmp, 'volume.npy'), os.path.join(tmp, 'labels.npy')
+            np.save(src, vol)
+            run = subprocess.run([py, '-c', _SKIMAGE3D_SCRIPT, src, dst, str(sp_size), str(sp_regul), ','.join(str(v) for v in spacing)],
+                                 capture_output=True, text=True, timeout=900, env=dict(os.environ, OMP_NUM_THREADS='1'))
+            if run.returncode != 0:
+                return None
+            version, seconds = run.stdout.split()[-2:]
+            return version, [float(v) for v in seconds.split(',')], np.load(dst)
     except Exception:
         return None
 
@@ -386,9 +431,13 @@ def cpu_baseline_volume(shape_full, crop=(64, 256, 256)):
     crop = tuple(min(c, s) for c, s in zip(crop, shape_full))
     vol = config5_volume(crop)
     p = C5_PARAMS
+    # supervoxels: the REAL scikit-image where the box carries it (the reference's own third-party leg), else the oracle port
+    real = real_skimage_slic3d(vol, p['sp_size'], p['sp_regul'], p['spacing'])
     t0 = time.perf_counter()
     slic = orc.segment_slic_img3d_gray(vol, p['sp_size'], p['sp_regul'], p['spacing'])
-    t_slic = time.perf_counter() - t0
+    t_port = time.perf_counter() - t0
+    t_slic = sum(real[1]) if real is not None else t_port
+    t0 = time.perf_counter() - t_slic                      # (the clock of the legs below continues behind the leg that counts)
     seg32 = slic.astype(np.int32)
     mean = orc.gray3d_stat(vol, seg32, 'mean')
     var = orc.gray3d_stat(vol, seg32, 'var', mean.astype(np.float32))
@@ -417,10 +466,14 @@ def cpu_baseline_volume(shape_full, crop=(64, 256, 256)):
         extra['reference_slic_full_volume_build_container'] = {
             'what': 'real scikit-image %s slic (%.0f s) + measure.label (%.0f s) on the full volume, one core of the build container'
                     % (str(full['versions']), sec[0], sec[1]), 'mvoxels_per_s': round(float(np.prod(shape_full)) / sum(sec) / 1e6, 4)}
-    return {**extra, 'value': round(nvox / total / 1e6, 4), 'unit': 'Mpixels/s', 'cores': 1, 'kind': 'port',
-            'sample': '%dx%dx%d %s on one core, %.1f s (SLIC + measure.label %.1f s, mixture fit + predict_proba %.2f s -- the same '
+    if real is not None:
+        extra['reference_slic'] = {'scikit_image': real[0], 'slic_seconds': round(real[1][0], 3), 'label_seconds': round(real[1][1], 3),
+                                   'port_seconds': round(t_port, 3), 'port_equals_scikit_image': bool(np.array_equal(real[2], seg32))}
+    return {**extra, 'value': round(nvox / total / 1e6, 4), 'unit': 'Mpixels/s', 'cores': 1, 'kind': 'reference+port' if real is not None else 'port',
+            'sample': '%dx%dx%d %s on one core, %.1f s (SLIC + measure.label %.1f s [%s], mixture fit + predict_proba %.2f s -- the same '
                       'scikit-learn call as inside the GPU step --, statistics / graph / GraphCut / gather %.2f s)%s'
-                      % (crop + ('crop of the volume' if crop != tuple(shape_full) else 'volume (whole)', total, t_slic, t_fit,
+                      % (crop + ('crop of the volume' if crop != tuple(shape_full) else 'volume (whole)', total, t_slic,
+                                 'real scikit-image ' + real[0] if real is not None else 'oracle C restatement', t_fit,
                                  total - t_slic - t_fit,
                                  '; the rate is EXTRAPOLATED linearly to the full volume' if crop != tuple(shape_full) else '')),
             'seconds': {'total': round(total, 3), 'slic_and_label': round(t_slic, 3), 'model_fit': round(t_fit, 3)},
@@ -819,12 +872,14 @@ def bench_color2d(args, group, cfg, quick=False):
     batched = cfg == 4 and on_device and args.batch_images != 0 and pipe.BATCH_IMAGES > 0
 
     # (measured on one GPU, round 4: the ring LOSES -- config 2 5.1 against 6.9 Gpixel/s, config 4 3.75 against 3.9: the runtime's
-    # own staging of a pageable source is at least as good as a copy by the worker thread -- so it stays an option)
-    use_ring = args.input_ring == 1 and not args.pinned_input
+    # own staging of a pageable source is at least as good as a copy by the worker thread.  That was ONE rank; with N ranks the
+    # runtime's staging threads of all ranks share the host's memory system, so with `--input-ring -1` (the default) and more than
+    # one rank the choice is MEASURED below -- about a second per form, all ranks at once -- instead of carried over.)
+    staging = {'on': args.input_ring == 1 and not args.pinned_input, 'chosen_by': 'flag' if args.input_ring in (0, 1) else 'default (one rank: measured in round 4)'}
 
     def staged(state, k, image):
         """the image in the thread's own page-locked buffer (allocated once per thread and slot)"""
-        if not use_ring or state is None:
+        if not staging['on'] or state is None:
             return image
         ring = state.setdefault('ring', {})
         buf = ring.get(k)
@@ -834,7 +889,7 @@ def bench_color2d(args, group, cfg, quick=False):
         return buf
 
     def do_step(state, index, stage):
-        if use_ring:
+        if staging['on']:
             step_images = [staged(state, k, image) for k, image in enumerate(images)]
         else:
             step_images = images
@@ -858,8 +913,26 @@ def bench_color2d(args, group, cfg, quick=False):
         except Exception:
             pass
         rank_links = group.gather_objects(link)
+    if group.distributed and world > 1 and args.input_ring == -1 and not args.pinned_input:
+        # which input staging is faster HERE, with every rank of the node moving its images at the same time: this rank's own
+        # steady-state rate without a gather, first as the timed run would start (pageable source), then through the ring
+        from pyimsegm_amd.distributed import Group as _G
+        probe = {}
+        for mode in (False, True):
+            staging['on'] = mode
+            local = SteadyRun(_G(single=True), inflight, make_state, do_step)
+            t_cal, _ = local.run(1, 2 * inflight)
+            n_probe = max(inflight, int(min(max(2 * inflight, args.probe_seconds / max(t_cal / (2 * inflight), 1e-6)), 4096)) // inflight * inflight)
+            group.barrier()
+            t_run, _ = local.run(inflight, n_probe)
+            local.close()
+            probe['ring' if mode else 'pageable'] = round(n_probe * npx_step / t_run / 1e6, 1)
+        staging['on'] = probe['ring'] > 1.03 * probe['pageable']
+        staging['chosen_by'] = 'probe on this rank with all %d ranks running (Mpixels/s: %r)' % (world, probe)
+        staging['probe'] = probe
     runner = SteadyRun(group, inflight, make_state, do_step, gather_item_bytes=height * width * 4, items_per_step=per_step)
     elapsed, cold = runner.run(warmup, steps)
+    rank_rings = group.gather_objects({'input_ring': bool(staging['on']), 'chosen_by': staging['chosen_by']}) if (group.distributed and world > 1) else None
 
     # ---- every gathered label map against the reference's run (N > 1: the first multi-GPU run validates the RCCL gather)
     verdict = {}
@@ -1062,7 +1135,8 @@ def bench_color2d(args, group, cfg, quick=False):
                 'timed_region': 'host numpy image -> H2D -> SLIC -> descriptors -> class model -> graph-cut terms -> '
                                 'alpha-expansion -> gathers -> D2H -> segm in host numpy (page-locked result array); model fit outside',
                 'input_memory': 'page-locked' if args.pinned_input else ('pageable numpy, copied by the worker thread into its page-locked '
-                                                                         'ring inside the timed region' if use_ring else 'pageable numpy'),
+                                                                         'ring inside the timed region' if staging['on'] else 'pageable numpy'),
+                'input_ring': staging['chosen_by'],
                 'class_model': ('device (scaler + full-covariance GMM)' if on_device else 'host scikit-learn predict_proba') + '; ' + model_source,
                 'timing': 'steady state: %d warm-up + %d timed + %d cool-down steps back to back, clock from completion of '
                           'step W to completion of step W+K' % (warmup, steps, inflight),
@@ -1073,7 +1147,13 @@ def bench_color2d(args, group, cfg, quick=False):
             'ms_per_step_incl_fill_drain': round(cold * 1e3, 4),
             'gather_backend': group.backend if group.distributed else None,
             'per_rank': ({'value': [round(steps * npx_step / sec / 1e6, 1) for sec in runner_rank_seconds],
-                          'host_link_gb_per_s': rank_links, 'placement': placements} if (group.distributed and world > 1) else None),
+                          'host_link_gb_per_s': rank_links, 'placement': placements, 'input_staging': rank_rings,
+                          # what a rank asks of the HOST's memory system at its measured rate: the image read (twice more when it
+                          # goes through the ring: the copy's read and write) and the int32 map written, per second
+                          'host_memory_traffic_gb_per_s': [
+                              round((per_step * (images[0].nbytes * (3 if (rr or {}).get('input_ring') else 1) + height * width * 4))
+                                    * steps / sec / 1e9, 4) for sec, rr in zip(runner_rank_seconds, rank_rings or [None] * world)]}
+                         if (group.distributed and world > 1) else None),
             'rccl_error': getattr(group, 'rccl_error', None),
             'roofline': roofline,
             'stage_ms_per_step': {g: round(ms / prof_steps, 4) for g, (ms, n) in stage_ms.items()},

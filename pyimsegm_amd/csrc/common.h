@@ -26,7 +26,8 @@ bool hip_ok(hipError_t e, const char *what, const char *file, int line);
 struct Knobs {
     bool slic_graph, slic_persistent, pre_3pass, separate_finalize, fuse_finalize, sweeps_force_fail, conn_general, gc_no_topo_regs,
         adjacency_table,       // IMSEGM_ADJACENCY_TABLE: the neighbour table of a label volume's graph for every K (default: beyond 46 000 labels)
-        cc_merge_full,         // IMSEGM_CC_MERGE_FULL: measure.label's merge pass with thirteen unions per voxel (rounds 2 - 4; tests, A/B)
+        cc_merge_full,         // IMSEGM_CC_MERGE_FULL: the voxel-by-voxel merge passes of rounds 2 - 4 -- measure.label with thirteen unions per voxel, connectivity with
+                               // its per-voxel loads -- instead of the row-segment kernels (tests, A/B)
         vol_update_wave,       // IMSEGM_VOL_UPDATE_WAVE: the float32 centroid update of a volume with one WAVE per centroid (round 3 / 4; tests, A/B)
         sep_wide_tile;         // IMSEGM_SEP_WIDE_TILE: the separable kernels of side 33 on the 64 x 16 tile of round 4's first half (tests, A/B)
     int brick_cap;             // IMSEGM_BRICK_CAP (0: default)

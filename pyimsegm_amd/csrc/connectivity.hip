@@ -53,11 +53,29 @@ __device__ __forceinline__ int uf_find(const int32_t *parent, int a)
     return a;
 }
 
+// find with path halving, for the merge passes (Jayanti / Tarjan; ECL-CC's "intermediate pointer jumping"): every step of the walk
+// re-points the voxel it leaves at its grandparent.  Safe next to the atomicMin of the unions: a parent pointer only ever moves to a
+// smaller index of the same set -- a root is never written here (the walk stops at it), a stale read yields an older ancestor,
+// and a store that overwrites a concurrent hook of the SAME voxel loses nothing, because the union that placed the hook goes on with
+// the value it displaced.  The chains of a supervoxel (one link per row and slice it spans) shrink while they are walked; the
+// flatten pass behind finds them short.
+__device__ __forceinline__ int uf_find_halving(int32_t *parent, int a)
+{
+    int p = parent[a];
+    while (p != a) {
+        const int g = parent[p];
+        if (g != p) parent[a] = g;
+        a = p;
+        p = g;
+    }
+    return a;
+}
+
 __device__ __forceinline__ void uf_union(int32_t *parent, int a, int b)
 {
     while (true) {
-        a = uf_find(parent, a);
-        b = uf_find(parent, b);
+        a = uf_find_halving(parent, a);
+        b = uf_find_halving(parent, b);
         if (a == b) return;
         if (a < b) {
             int t = a;
@@ -118,6 +136,51 @@ k_ccl_merge(const int32_t *__restrict__ labels, const uint8_t *__restrict__ stat
         bool left_pair_same = cont && is_active<ALL>(state, p - HW - 1) && labels[p - HW - 1] == l;
         if (!left_pair_same) uf_union(parent, p, p - HW);
     }
+}
+
+// Round 6, first round of a volume (every voxel active): initialisation and merge pass by row segments.  A wave covers CR_SPAN = 62
+// voxels of a row with lane 0 / lane 63 carrying the voxels left / right of them; the three rows the rule looks at -- (z, y),
+// (z, y - 1), (z - 1, y) -- are loaded once per wave, the x - 1 neighbours come from the neighbouring lane (one DPP move), and the
+// coordinates from the grid (no division).  Same rule as k_ccl_init / k_ccl_merge above (runs inside a segment start as one set; one
+// union per pair of overlapping runs), hence the same components with the same roots (the smallest index of a set).
+constexpr int CR_SPAN = 62;
+
+__global__ void __launch_bounds__(256)
+k_ccl_init_rows(const int32_t *__restrict__ labels, int32_t *__restrict__ parent, int H, int W)
+{
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int x = (blockIdx.x * 4 + wave) * CR_SPAN + lane - 1;
+    const size_t row = ((size_t)blockIdx.z * H + blockIdx.y) * W;
+    const bool inx = x >= 0 && x < W;
+    const int l = inx ? labels[row + x] : -5;            // (a voxel no window covered carries -1: the fillers differ from it)
+    const bool mine = inx && lane >= 1 && lane <= CR_SPAN;
+    const bool cont = lane_prev(l, -8) == l && lane > 1;
+    const unsigned long long starts = __ballot(mine && !cont);
+    if (!mine) return;
+    const unsigned long long below = starts & ((2ULL << lane) - 1ULL);     // (lane <= 62)
+    const int start_lane = 63 - __clzll((long long)below);
+    parent[row + x] = (int)(row + x) - (lane - start_lane);
+}
+
+__global__ void __launch_bounds__(256)
+k_ccl_merge_rows(const int32_t *__restrict__ labels, int32_t *parent, int D, int H, int W)
+{
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int x = (blockIdx.x * 4 + wave) * CR_SPAN + lane - 1;
+    const int y = blockIdx.y, z = blockIdx.z;
+    const bool inx = x >= 0 && x < W;
+    const size_t plane = (size_t)H * W, row = (size_t)z * plane + (size_t)y * W;
+    const int l = inx ? labels[row + x] : -5;
+    const int up = (inx && y > 0) ? labels[row - W + x] : -6;
+    const int back = (inx && z > 0) ? labels[row - plane + x] : -7;
+    const bool cont = lane_prev(l, -8) == l;                                // the left neighbour carries the same label
+    const bool up_left = lane_prev(up, -8) == l, back_left = lane_prev(back, -8) == l;
+    if (!(inx && lane >= 1 && lane <= CR_SPAN)) return;
+    const int p = (int)(row + x);
+    if (cont && lane == 1) uf_union(parent, p, p - 1);                        // a run that crosses into the segment
+    // one union per pair of overlapping runs: skipped when the pair to the left (p - 1, q - 1) carries the same two runs
+    if (up == l && !(cont && up_left)) uf_union(parent, p, p - W);
+    if (back == l && !(cont && back_left)) uf_union(parent, p, (int)(row - plane + x));
 }
 
 template <bool ALL>
@@ -601,8 +664,14 @@ static void conn_ccl_round(const int32_t *labels_in, int D, int H, int W, int ma
                            hipStream_t st)
 {
     const int n = D * H * W, grid = cdiv(n, 256);
-    hipLaunchKernelGGL(k_ccl_init<ALL>, grid, 256, 0, st, labels_in, state, w.parent, n, W);
-    hipLaunchKernelGGL(k_ccl_merge<ALL>, grid, 256, 0, st, labels_in, state, w.parent, D, H, W);
+    if (ALL && H <= 65535 && D <= 65535 && !knobs().cc_merge_full) {
+        const dim3 rows(cdiv(W, 4 * CR_SPAN), H, D);
+        hipLaunchKernelGGL(k_ccl_init_rows, rows, 256, 0, st, labels_in, w.parent, H, W);
+        hipLaunchKernelGGL(k_ccl_merge_rows, rows, 256, 0, st, labels_in, w.parent, D, H, W);
+    } else {
+        hipLaunchKernelGGL(k_ccl_init<ALL>, grid, 256, 0, st, labels_in, state, w.parent, n, W);
+        hipLaunchKernelGGL(k_ccl_merge<ALL>, grid, 256, 0, st, labels_in, state, w.parent, D, H, W);
+    }
     hipLaunchKernelGGL(k_ccl_flatten<ALL>, grid, 256, 0, st, w.parent, state, w.csize, n);
     hipLaunchKernelGGL(k_comp_size<ALL>, grid, 256, 0, st, w.parent, state, w.csize, n);
     hipLaunchKernelGGL(k_find_oversize<ALL>, grid, 256, 0, st, w.parent, state, w.csize, n, max_size, w.list, w.counters);

@@ -41,7 +41,9 @@ def test_bench_control_flow_two_ranks_under_the_launcher():
     assert 'cpu_baseline' not in d                     # rank 0 at N = 1 only
     assert len(d['per_rank']['value']) == 2 and all(v > 0 for v in d['per_rank']['value'])      # a slow rank is visible in the line
     assert len(d['per_rank']['host_link_gb_per_s']) == 2 and len(d['per_rank']['placement']) == 2
-    assert d['config']['input_memory'] == 'pageable numpy'                                       # (the ring is an option: --input-ring 1)
+    # input staging at N > 1: measured on every rank, all ranks at once (either form may win here; --input-ring 0 / 1 fixes it)
+    assert d['config']['input_memory'].startswith('pageable numpy') and 'probe on this rank with all 2 ranks' in d['config']['input_ring']
+    assert len(d['per_rank']['input_staging']) == 2 and len(d['per_rank']['host_memory_traffic_gb_per_s']) == 2
     assert d['gathered_maps_checked'] == 2 and d['gathered_maps_equal_senders_own'] is True      # what rank 0 received = what each rank holds
 
 
@@ -61,3 +63,19 @@ def test_bench_refuses_a_rank_count_that_is_not_the_launchers():
     env = dict(os.environ, RANK='0', LOCAL_RANK='0', WORLD_SIZE='1', MASTER_PORT='29641')
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=120, cwd=ROOT, env=env)
     assert out.returncode != 0 and '--gpus 3' in (out.stderr + out.stdout)
+
+
+def test_bench_eight_self_spawned_ranks_on_a_host_with_as_many_cpus():
+    """`bench.py --gpus 8` as the driver's scaling run starts it, on the 8 CPUs of the build container (one per rank: the worker
+    threads of a rank are cut to the CPUs it has, the hub serves eight connections, the input-staging probe runs on every rank at
+    once): ONE JSON line, whole-job aggregate, every rank's own rate, staging choice and host-memory traffic in it, every gathered
+    map checked against the map its sender holds"""
+    d = run_bench(8, 4, 29651, size=('--size', '128'), extra=['--probe-seconds', '0.2'])
+    assert d['n_gpus'] == 8 and d['steps'] == 4 and d['scaling'] == 'weak' and d['value'] > 0
+    assert abs(d['value'] - 8 * 4 * 128 * 128 / (d['ms_per_step'] * 4 / 1e3) / 1e6) / d['value'] < 1e-3
+    per_rank = d['per_rank']
+    assert len(per_rank['value']) == 8 and all(v > 0 for v in per_rank['value'])
+    assert len(per_rank['input_staging']) == 8 and all('probe' in r['chosen_by'] for r in per_rank['input_staging'])
+    assert len(per_rank['host_memory_traffic_gb_per_s']) == 8 and all(v > 0 for v in per_rank['host_memory_traffic_gb_per_s'])
+    assert d['gathered_maps_checked'] == 8 and d['gathered_maps_equal_senders_own'] is True
+    assert 'cpu_baseline' not in d and 'other_configs' not in d or d.get('other_configs') is not None

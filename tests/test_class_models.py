@@ -141,3 +141,33 @@ def test_touched_result_array():
     flat = big.reshape(-1).view(np.uint8)
     assert big.shape == (17, 1024, 1024) and big.flags.c_contiguous
     assert not flat[::4096].any() and flat[4096 * 5 + 1] == 7
+
+
+def test_float32_features_stay_float32_as_in_pipeline_fit():
+    """`Pipeline.fit` keeps a float32 table float32 through StandardScaler and the mixture; estim_class_model used to
+    cast to float64 first (parameters then differ in the last bits).  Same class, same parameters, same probabilities as the plain
+    scikit-learn pipeline on the float32 table -- and a second side-by-side fit while one is running takes scikit-learn's own loop
+    (one holder of the process-wide BLAS limit at a time)"""
+    from sklearn import mixture, pipeline, preprocessing
+    rng = np.random.default_rng(3)
+    fts = np.vstack([rng.normal(0, 1, (300, 3)), rng.normal(3, 1, (300, 3))]).astype(np.float32)
+    np.random.seed(4)
+    want = pipeline.Pipeline([('std_scaler', preprocessing.StandardScaler()),
+                              ('model', mixture.GaussianMixture(n_components=2, covariance_type='full', n_init=9, max_iter=99))]).fit(fts)
+    np.random.seed(4)
+    got = graph_cuts.estim_class_model(fts, 2)
+    assert got.steps[-1][1].means_.dtype == want.steps[-1][1].means_.dtype
+    for name in ('weights_', 'means_', 'covariances_', 'precisions_cholesky_'):
+        assert np.array_equal(getattr(want.steps[-1][1], name), getattr(got.steps[-1][1], name)), name
+    assert np.array_equal(want.predict_proba(fts), got.predict_proba(fts))
+    # the lock: a fit that finds another side-by-side fit running does not touch the process-wide limits
+    table = np.vstack([rng.normal(0, 1, (20000, 2)), rng.normal(4, 1, (20000, 2))])
+    assert graph_cuts._SIDE_BY_SIDE.acquire(blocking=False)
+    try:
+        np.random.seed(6)
+        busy = graph_cuts.fit_mixture_restarts(mixture.GaussianMixture(2, n_init=3), table[:40000], workers=4)
+    finally:
+        graph_cuts._SIDE_BY_SIDE.release()
+    np.random.seed(6)
+    plain = mixture.GaussianMixture(2, n_init=3).fit(table)
+    assert np.array_equal(busy.means_, plain.means_)

@@ -78,6 +78,66 @@ def test_two_rank_host_plane(tmp_path):
     assert 'RANK0_OK' in outs[0][0]
 
 
+WORKER_EIGHT = textwrap.dedent('''
+    import sys, numpy as np
+    sys.path.insert(0, %r)
+    from pyimsegm_amd.distributed import Group, segment_batch_sharded, estim_model_classes_group_sharded, worker_threads_per_rank
+    g = Group(backend='host')
+    assert g.world == 8
+    # BASELINE configs[3]: 64 images over 8 ranks, image i on rank i mod 8 (SURVEY 8e) -- and a ragged count
+    assert g.shard(64) == list(range(g.rank, 64, 8)) and g.shard(19) == list(range(g.rank, 19, 8))
+    assert g.shard(3) == ([g.rank] if g.rank < 3 else [])
+    images = [np.full((5, 7, 3), i, dtype=np.uint8) for i in range(19)]
+    out = segment_batch_sharded(images, lambda img: np.full(img.shape[:2], 100 * int(img[0, 0, 0]) + g.rank, dtype=np.int32), g,
+                                nb_workers=3)
+    if g.rank == 0:
+        assert [int(o[0, 0]) for o in out] == [100 * i + i %% 8 for i in range(19)]
+        print('RANK0_OK')
+    else:
+        assert out is None
+    assert g.max_over_ranks(float(g.rank)) == 7.0 and g.min_over_ranks(float(g.rank)) == 0.0
+    assert g.any_over_ranks(g.rank == 5) is True and g.any_over_ranks(False) is False
+    blocks = g.gather_objects({'rank': g.rank, 'payload': np.arange(1000 * (g.rank + 1))})
+    if g.rank == 0:
+        assert [b['rank'] for b in blocks] == list(range(8)) and [len(b['payload']) for b in blocks] == [1000 * (r + 1) for r in range(8)]
+    assert g.broadcast_object({'k': 11} if g.rank == 0 else None) == {'k': 11}
+    model, _ = estim_model_classes_group_sharded(images, lambda img: np.full((2, 3), float(img[0, 0, 0])),
+                                                 lambda fts: {'mean': float(fts.mean()), 'rows': len(fts)}, g)
+    assert model == {'mean': 9.0, 'rows': 38}, model
+    # worker threads per rank: never more than the CPUs a rank has (eight ranks on a small host: at least one each)
+    assert worker_threads_per_rank(8, 4, cpus=3) == 3 and worker_threads_per_rank(8, 4, cpus=1) == 1
+    # a rank that dies inside a step: every rank sees an error, nobody hangs in the gather
+    def failing(img):
+        if g.rank == 6:
+            raise ValueError('boom')
+        return np.zeros(img.shape[:2], dtype=np.int32)
+    try:
+        segment_batch_sharded(images, failing, g)
+        raise SystemExit('no error raised')
+    except (ValueError, RuntimeError) as ex:
+        assert ('boom' in str(ex)) == (g.rank == 6)
+    g.barrier()
+    g.close()
+''') % ROOT
+
+
+def test_eight_rank_host_plane(tmp_path):
+    """the world size of the driver's scaling run, which cannot be rehearsed on the one-GPU test box: eight processes on the host
+    control plane (hub accept loop, gathers of ragged payloads, broadcast, the group model, sharding of 64 / 19 / 3 images, a rank
+    that fails inside a step) -- reference: the pool map of imsegm/utilities/experiments.py:386-411"""
+    script = tmp_path / 'worker8.py'
+    script.write_text(WORKER_EIGHT)
+    procs = []
+    for rank in range(8):
+        env = dict(os.environ, OMP_NUM_THREADS='1', RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE='8', MASTER_ADDR='127.0.0.1',
+                   MASTER_PORT='29619', TORCHELASTIC_RUN_ID='pytest8_%d' % os.getpid())
+        procs.append(subprocess.Popen([sys.executable, str(script)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env))
+    outs = [p.communicate(timeout=300) for p in procs]
+    for p, (out, err) in zip(procs, outs):
+        assert p.returncode == 0, out[-2000:] + err[-2000:]
+    assert 'RANK0_OK' in outs[0][0]
+
+
 def test_control_plane_rejects_stray_connections(tmp_path):
     """a connection that announces a rank outside 1..world-1 (or one that is taken) is dropped, the job still forms"""
     import socket
