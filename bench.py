@@ -1042,11 +1042,19 @@ def bench_color2d(args, group, cfg, quick=False):
             # what the host link allows: the bytes of one step (image up, int32 segmentation down) copied back to back on one
             # stream -- on the boxes of this pool the two directions share ~55 GB/s (tools/xfer_concurrent.py: more threads or
             # copying both ways at once moves no more), so this is a ceiling of the host -> host rate, whatever the kernels do
-            try:
-                extras['host_link'] = host_link_rate(ctx, images[0], height, width)
-                extras['host_link']['ceiling_mpixels_per_s'] = round(npx_step / (extras['host_link']['bytes_per_step'] / extras['host_link']['gb_per_s'] / 1e9) / 1e6, 1)
-            except Exception as ex:
-                extras['host_link'] = {'error': repr(ex)}
+
+    if rank == 0:
+        # what the host link allows: the bytes of one image (pixels up, int32 segmentation down) copied back to back on one
+        # stream -- on the boxes of this pool the two directions share ~55 GB/s (tools/xfer_concurrent.py: more threads or
+        # copying both ways at once moves no more), so this is a ceiling of the host -> host rate, whatever the kernels do.
+        # For every configuration (round 6: config 4 too -- the driver's line of round 5 read 3.6 Gpixel/s where the builder's
+        # boxes gave 4.6 - 4.9; the link of the box is the first thing to look at)
+        try:
+            extras['host_link'] = host_link_rate(ctx, np.asarray(images[0]), height, width)
+            extras['host_link']['ceiling_mpixels_per_s'] = round(height * width / (extras['host_link']['bytes_per_step'] / extras['host_link']['gb_per_s'] / 1e9) / 1e6, 1)
+            extras['host_link']['fraction_of_ceiling'] = None       # (filled in below, once `value` is known)
+        except Exception as ex:
+            extras['host_link'] = {'error': repr(ex)}
 
     # ---- kernel-level figures: un-overlapped pass on one stream with HIP events around every stage
     prof_steps = 3 if cfg == 3 else 5
@@ -1162,6 +1170,8 @@ def bench_color2d(args, group, cfg, quick=False):
         }
         out.update(extras)
         out.update(verdict)
+        if isinstance(out.get('host_link'), dict) and out['host_link'].get('ceiling_mpixels_per_s'):
+            out['host_link']['fraction_of_ceiling'] = round(value / world / out['host_link']['ceiling_mpixels_per_s'], 3)
         if world == 1:
             try:      # the fit-inclusive form of the same step (its own line item; `value` stays the pre-fitted form)
                 n_fit = {2: 3, 3: 1, 4: 1}[cfg] if quick else {2: 5, 3: 2, 4: 1}[cfg]
@@ -1246,24 +1256,57 @@ def bench_volume(args, group, shape=None, quick=False):
         except Exception:
             fit_threads, limiter = 1, None
 
+    fit_lock = threading.Lock()
+
     def timed_fit(*a, **kw):
         t = time.perf_counter()
         try:
             return fit(*a, **kw)
         finally:
-            fit_seconds[0] += time.perf_counter() - t
+            with fit_lock:
+                fit_seconds[0] += time.perf_counter() - t
     pipe.estim_class_model = timed_fit
-    for _ in range(warmup):
-        step()
-    fit_seconds[0] = 0.0
+    # Volumes in flight (round 6).  A step is device work (upload, supervoxels, labelling, statistics: ~0.35 s at full size), then
+    # the mixture fit on the HOST (~0.6 s, the device idle), then terms / cut / gather / download (~0.15 s).  With three volumes in
+    # flight -- three worker threads, one HIP stream and one resident session (~75 GB) each, what the 2-D configurations have done
+    # since round 2 with four images -- the fits (two at a time, graph_cuts._SideBySideGate) run under the device work of the other
+    # volumes: measured 1.10 s per volume alone, 0.77 - 0.81 s with two and 0.52 - 0.55 s with three in flight (one box, s16 / s18 of
+    # tools/).  `latency_ms` below is one volume alone.
+    inflight = args.inflight if args.inflight > 0 else (3 if int(np.prod(shape)) >= (1 << 28) else 1)
+    if inflight > 1:
+        try:                                    # (a device without room for two resident volumes: one at a time)
+            free_b, total_b = _hip.mem_info()
+            while inflight > 1 and free_b < inflight * 85.0 * float(np.prod(shape)):
+                inflight -= 1
+        except Exception:
+            inflight = 1
+    # one volume alone first (warm-up + one timed call on this thread): the latency of the call and the share of the fit in it
+    step()
     ctx.synchronize()
-    group.barrier()
-    t0 = time.perf_counter()
-    for _ in range(steps):
+    latency_ms, latency_fit_ms = float('inf'), 0.0
+    segm = None
+    for _ in range(2):                          # (the faster of two)
+        fit_seconds[0] = 0.0
+        t_lat = time.perf_counter()
         segm = step()
-    ctx.synchronize()
-    group.barrier()
-    elapsed = group.max_over_ranks(time.perf_counter() - t0)
+        if (time.perf_counter() - t_lat) * 1e3 < latency_ms:
+            latency_ms, latency_fit_ms = (time.perf_counter() - t_lat) * 1e3, fit_seconds[0] * 1e3
+    classes_found = int(len(np.unique(segm[::4, ::16, ::16])))
+    del segm
+    if inflight > 1:
+        ctx.close_idle_sessions()               # (the worker threads bring their own resident volumes)
+    def do_step(state, index, stage):
+        step()                                  # (the class map goes back to the pool of page-locked result arrays at once)
+    if inflight > 1 and (args.steps is None or quick):
+        steps, warmup = max(steps, 2 * inflight), max(warmup, inflight)
+    runner = SteadyRun(group, inflight, lambda: {'ctx': _hip.default_context()}, do_step)
+    fit_seconds[0] = 0.0
+    elapsed, cold = runner.run(warmup, steps)
+    runner.close()
+    if inflight > 1:
+        _hip.reap_contexts()                    # (the resident volumes of the worker threads that have just ended)
+    # (the clock of the fit: its share of the timed steps only -- SteadyRun runs first-use, warm-up, timed and cool-down steps)
+    fit_seconds[0] = fit_seconds[0] * steps / (warmup + steps + 2 * inflight)
     fit_ms = fit_seconds[0] / steps * 1e3
     ctx.profile_enable(True)
     ctx.profile_reset()
@@ -1303,16 +1346,23 @@ def bench_volume(args, group, shape=None, quick=False):
         'config': {'workload': 'single %dx%dx%d float32 gray volume per GPU through pipe_gray3d_slic_features_model_graphcut '
                                '(sp_size=15, spacing (1,1,1), gray mean/std/energy, 3-class GMM fitted inside the step on the host, '
                                'gc_regul=0.1), host in -> host out (BASELINE configs[4]); unit = Mvoxels/s' % shape,
-                   'bench_config': 5, 'classes_found': int(len(np.unique(segm)))},
+                   'volumes_in_flight_per_gpu': inflight,
+                   'timing': 'steady state: %d warm-up + %d timed + %d cool-down volumes back to back on %d worker thread(s), clock from the '
+                             'completion of step W to the completion of step W+K; latency_ms = one volume alone' % (warmup, steps, inflight, inflight),
+                   'bench_config': 5, 'classes_found': classes_found},
         'roofline': roofline,
         'stage_ms_per_step': {g: round(ms, 3) for g, (ms, n) in stage_ms.items()},
-        'host_model_fit_ms_per_step': round(fit_ms, 1), 'ms_per_step_excluding_fit': round(elapsed / steps * 1e3 - fit_ms, 1),
+        # (one volume alone: the whole call, its host-side fit, and the rest -- with volumes in flight the fit of one runs under the
+        # device work of the next, so `ms_per_step` is NOT their sum)
+        'host_model_fit_ms_per_step': round(latency_fit_ms, 1), 'ms_per_step_excluding_fit': round(latency_ms - latency_fit_ms, 1),
+        'host_model_fit_ms_in_flight': round(fit_ms, 1),      # (per step of the timed run, waiting for the other volume's fit included)
+        'volumes_in_flight': inflight, 'latency_ms': round(latency_ms, 1), 'latency_host_model_fit_ms': round(latency_fit_ms, 1),
+        'ms_per_step_incl_fill_drain': round(cold * 1e3, 1),
         'host_model_fit_threads': fit_threads,
         'host_model_fit': 'scikit-learn GaussianMixture(full, n_init=9) as graph_cuts.py:73-163 configures it; the restarts of its EM loop '
                           'run side by side (graph_cuts.fit_mixture_restarts: same random stream, same calls, parameters bit for bit '
                           'those of mixture.fit -- tests/test_class_models.py), %d worker threads' % __import__('pyimsegm_amd.graph_cuts', fromlist=['x'])._fit_workers(),
     }
-    del segm
     if group.world == 1:
         try:
             verdict = compare_config5(shape, pipe, vol=vol if group.rank == 0 else None)

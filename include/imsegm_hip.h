@@ -44,6 +44,9 @@ IMSEGM_API int imsegm_device_count(int *count_out);
  * reference's pool workers are not placed (imsegm/utilities/experiments.py:392-403); eight ranks each moving tens of GB/s over
  * the host link are. */
 IMSEGM_API int imsegm_device_pci_bus_id(int device, char *id_out, int capacity);
+/* free and total bytes of a device's memory right now (hipMemGetInfo): a gray-volume session keeps ~75 bytes per voxel resident
+ * (imsegm_volume_*), so how many volumes of BASELINE configs[4] a device holds in flight is asked, not assumed */
+IMSEGM_API int imsegm_device_mem_info(int device, size_t *free_bytes_out, size_t *total_bytes_out);
 /* Optional, once per process and BEFORE the first call that touches a device: the number of hardware queues the HIP runtime maps
  * the streams of this process onto (the runtime's GPU_MAX_HW_QUEUES, default 4; with one stream per image in flight a fifth
  * stream shares a queue with another one and its kernels wait behind that image's -- bench.py asks for 8).  The runtime reads

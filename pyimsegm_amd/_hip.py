@@ -85,6 +85,7 @@ _SIGNATURES = {
     'imsegm_image2d_get_features': (C.c_int, [_vp, _vp, C.c_int]),
     'imsegm_image2d_run_color': (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, C.c_double, _vp, C.c_int, C.c_int, C.c_int, C.c_int,
                                            C.c_int, C.POINTER(GmmParams), C.c_int, _vp, C.c_int, C.c_double, C.c_int, _vp, _vp, _vp, _ip]),
+    'imsegm_device_mem_info': (C.c_int, [C.c_int, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
     'imsegm_image2d_graph_prepare': (C.c_int, [_vp]),
     'imsegm_image2d_segment': (C.c_int, [_vp, C.POINTER(GmmParams), _vp, C.c_int, _vp, C.c_int, C.c_double, C.c_int, _vp, _vp, _vp,
                                          _vp, _vp, C.POINTER(TermsDebug)]),
@@ -193,6 +194,13 @@ def device_pci_bus_id(device=0):
     return buf.value.decode('ascii', 'replace').lower()
 
 
+def mem_info(device=0):
+    """(free, total) bytes of a device's memory right now"""
+    free_b, total_b = C.c_size_t(0), C.c_size_t(0)
+    _check(load_library().imsegm_device_mem_info(int(device), C.byref(free_b), C.byref(total_b)))
+    return int(free_b.value), int(total_b.value)
+
+
 def reload_env():
     """read the IMSEGM_* debug switches again (the library reads them once): tests flip them at run time"""
     load_library().imsegm_debug_reload_env()
@@ -286,6 +294,23 @@ _default_ctx = {}
 _default_ctx_lock = threading.RLock()
 
 
+def _reap_contexts_locked(pid):
+    alive = {t.ident for t in threading.enumerate()}
+    dead = [k for k in _default_ctx if k[0] == pid and k[1] not in alive
+            and _default_ctx[k].users == len(_default_ctx[k].idle_sessions)]
+    for old in dead:
+        _default_ctx.pop(old).close()
+    return len(dead)
+
+
+def reap_contexts():
+    """close the contexts of this process's threads that have ended, with the sessions they kept for reuse (a gray-volume session
+    holds ~75 bytes of device memory per voxel): done whenever a new thread asks for its context, and here on request -- after a
+    pool of worker threads has gone and before the calling thread needs the memory itself.  Returns the number closed."""
+    with _default_ctx_lock:
+        return _reap_contexts_locked(os.getpid())
+
+
 def default_context():
     """per-process, per-thread, per-device lazily created context (re-created in forked children).
 
@@ -299,11 +324,7 @@ def default_context():
         if ctx is None:
             # a new thread asks for its context: first give back those of threads that have ended (and the
             # sessions they kept for reuse)
-            alive = {t.ident for t in threading.enumerate()}
-            dead = [k for k in _default_ctx if k[0] == key[0] and k[1] not in alive
-                    and _default_ctx[k].users == len(_default_ctx[k].idle_sessions)]
-            for old in dead:
-                _default_ctx.pop(old).close()
+            _reap_contexts_locked(key[0])
             device = int(key[2])
             n = device_count()
             if n > 0:
@@ -326,7 +347,7 @@ class _PinnedBlock(object):
                 return
             with _pinned_lock:
                 cache = _pinned_free.setdefault(self.size, [])
-                if len(cache) < _PINNED_KEEP:
+                if len(cache) < (_PINNED_KEEP if self.size < _PINNED_BIG else _PINNED_KEEP_BIG):
                     cache.append(self.ptr)
                     return
             load_library().imsegm_host_free(self.ptr)
@@ -337,6 +358,7 @@ class _PinnedBlock(object):
 _pinned_free = {}
 _pinned_lock = threading.RLock()
 _PINNED_KEEP = 16      # blocks kept per size class for reuse (hipHostMalloc costs far more than the copy it speeds up)
+_PINNED_BIG, _PINNED_KEEP_BIG = 256 << 20, 3      # ... of 256 MB and more (the 4.3 GB class map of a 64 x 4096 x 4096 volume): three
 
 
 def pinned_empty(shape, dtype):

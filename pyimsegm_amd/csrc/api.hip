@@ -237,6 +237,18 @@ int imsegm_device_pci_bus_id(int device, char *id_out, int capacity)
     return 0;
 }
 
+int imsegm_device_mem_info(int device, size_t *free_bytes_out, size_t *total_bytes_out)
+{
+    if (!free_bytes_out || !total_bytes_out) {
+        set_error("mem_info: null output");
+        return -1;
+    }
+    g_runtime_started.store(true);
+    HIP_TRY(hipSetDevice(device));
+    HIP_TRY(hipMemGetInfo(free_bytes_out, total_bytes_out));
+    return 0;
+}
+
 int imsegm_device_count(int *count_out)
 {
     g_runtime_started.store(true);
@@ -1265,9 +1277,13 @@ int imsegm_volume_slic(imsegm_image2d *im, int n_segments, double compactness, c
         s.brick_cap = (int)std::min<double>(std::max(64.0, 4.0 * per_brick), (double)K);
         s.brick_cap = (s.brick_cap + 63) & ~63;
         if (knobs().brick_cap) s.brick_cap = std::max(1, knobs().brick_cap);   // (tests: overflow path)
-        if (im->tiles.ensure(n_bricks * ((size_t)s.brick_cap + 1) * sizeof(int) + 256)) return -1;
+        // (a float32 volume's lists hold whole entries -- 12 words: position, value, window, index -- so that the assignment kernel
+        // reads what it needs of a candidate in one trip; 2.6 GB at the 65 536 bricks x 832 slots of BASELINE configs[4])
+        const size_t words_per_slot = f32 ? 12 : 1;
+        if (im->tiles.ensure((n_bricks + 64 + n_bricks * (size_t)s.brick_cap * words_per_slot) * sizeof(int) + 256)) return -1;
         s.brick_count = im->tiles.as<int>();
         s.brick_list = s.brick_count + ((n_bricks + 63) & ~(size_t)63);
+        s.brick_entries = s.brick_list;                       // (16-byte aligned: n_bricks rounded to 64 words behind a hipMalloc)
     }
     int sp_all = ctx->begin(PG_SLIC);
     if (f32) {

@@ -53,29 +53,11 @@ __device__ __forceinline__ int uf_find(const int32_t *parent, int a)
     return a;
 }
 
-// find with path halving, for the merge passes (Jayanti / Tarjan; ECL-CC's "intermediate pointer jumping"): every step of the walk
-// re-points the voxel it leaves at its grandparent.  Safe next to the atomicMin of the unions: a parent pointer only ever moves to a
-// smaller index of the same set -- a root is never written here (the walk stops at it), a stale read yields an older ancestor,
-// and a store that overwrites a concurrent hook of the SAME voxel loses nothing, because the union that placed the hook goes on with
-// the value it displaced.  The chains of a supervoxel (one link per row and slice it spans) shrink while they are walked; the
-// flatten pass behind finds them short.
-__device__ __forceinline__ int uf_find_halving(int32_t *parent, int a)
-{
-    int p = parent[a];
-    while (p != a) {
-        const int g = parent[p];
-        if (g != p) parent[a] = g;
-        a = p;
-        p = g;
-    }
-    return a;
-}
-
 __device__ __forceinline__ void uf_union(int32_t *parent, int a, int b)
 {
     while (true) {
-        a = uf_find_halving(parent, a);
-        b = uf_find_halving(parent, b);
+        a = uf_find(parent, a);
+        b = uf_find(parent, b);
         if (a == b) return;
         if (a < b) {
             int t = a;

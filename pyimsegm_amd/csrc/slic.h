@@ -161,6 +161,7 @@ struct VolState {
     int brick_cap;                  // entries per brick list
     int *brick_count;               // [n_bricks] (may exceed brick_cap: that brick scans the whole table)
     int *brick_list;                // [n_bricks][brick_cap]
+    int *brick_entries;             // float32 volumes: [n_bricks][brick_cap][12] -- a VolEntry per list entry (volume.hip), brick_list unused
     // float32 volumes (scikit-image keeps them in float32): float32 centroid table and the bounding boxes of the
     // segments' voxels that the order-preserving update walks
     float *cen32;                   // [K][4] = cz, cy, cx, value

@@ -592,15 +592,173 @@ struct VolRec {
 };
 constexpr int VLIST32 = 512;          // staged candidates per batch (a batch is walked when fewer than 256 slots are left)
 
+// -DIMSEGM_VOL_PHASE_PROF (tools/build_variant.sh; never in the shipped library): shader-clock ticks per section of the assignment
+// kernel, summed over the lane 0 of every wave, + waves and evaluated candidates -> imsegm_debug_vol_phases
+#ifdef IMSEGM_VOL_PHASE_PROF
+__device__ unsigned long long g_vol_phase[16];
+#define VOL_PH_BEGIN unsigned long long ph_t0 = clock64(), ph_t1; int ph_evaluated = 0;
+#define VOL_PH(i) do { if (lane == 0) { ph_t1 = clock64(); atomicAdd(&g_vol_phase[i], ph_t1 - ph_t0); ph_t0 = ph_t1; } } while (0)
+#define VOL_PH_COUNT(i, v) do { if (lane == 0) atomicAdd(&g_vol_phase[i], (unsigned long long)(v)); } while (0)
+#else
+#define VOL_PH_BEGIN
+#define VOL_PH(i)
+#define VOL_PH_COUNT(i, v)
+#endif
+
+// Round 6: the walk over one batch of staged candidates, instantiated for the number of list slots a lane really holds (NS =
+// ceil(count / 64): ~150 windows meet a cross-section at sp_size 15, i.e. 3 slots, where rounds 3 - 5 always carried the 8 of a full
+// list through every minimum, search and clear), and on integer KEYS: the bits of the (non-negative) float32 bound with the slot
+// number in their three lowest bits.  The wave minimum of the keys is the next candidate's bound -- rounded down by at most seven
+// units in the last place, still a lower bound -- AND its slot: no search for the slot, no second exchange.  Which candidates are
+// evaluated can only grow by the rounding; the result does not depend on it (the comparison carries the centroid index).
+constexpr int VOL_KEY_INF = 0x7f800000;
+
+__device__ __forceinline__ int wave_min_key(int key)
+{
+    // keys of real candidates lie in [0, VOL_KEY_INF): as a maximum of VOL_KEY_INF - key, a lane without a source contributes 0
+    int x = VOL_KEY_INF - key;
+    x = max(x, __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, false));
+    x = max(x, __builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, false));
+    x = max(x, __builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xf, false));
+    x = max(x, __builtin_amdgcn_update_dpp(0, x, 0x118, 0xf, 0xf, false));
+    x = max(x, __builtin_amdgcn_update_dpp(0, x, 0x142, 0xa, 0xf, false));
+    x = max(x, __builtin_amdgcn_update_dpp(0, x, 0x143, 0xc, 0xf, false));
+    return VOL_KEY_INF - __builtin_amdgcn_readlane(x, 63);
+}
+
+template <int NS>
+__device__ __forceinline__ void vol_walk_f32(const VolRec *rec, const int *list, int count, int lane, int y0, int y1w, int x0w, int x1w,
+                                             int x, bool xin, int H, float fz, float fx, float sz, float sy, float sx, float sw,
+                                             const float (&pv)[VROWS], float (&best_d)[VROWS], int (&best_k)[VROWS], float &wave_worst)
+{
+    static_assert(NS >= 1 && NS <= 8, "three bits of a key hold the slot");
+    // bounds over this wave's strip; a window that misses the strip's rows is out
+    int key[NS];
+#pragma unroll
+    for (int j = 0; j < NS; ++j) {
+        const int c = lane + 64 * j;
+        key[j] = VOL_KEY_INF;
+        if (c < count) {
+            const VolRec rc = rec[c];
+            if (rc.wy0 < y1w && rc.wy1 > y0) {
+                const float tz = sz * (rc.cz - fz);
+                const float dz = tz * tz;
+                const float yn = fminf(fmaxf(rc.cy, (float)y0), (float)(y1w - 1));
+                const float xn = fminf(fmaxf(rc.cx, (float)x0w), (float)(x1w - 1));
+                const float tyl = sy * (rc.cy - yn), txl = sx * (rc.cx - xn);
+                const float lb = ((dz + tyl * tyl) + txl * txl) * sw;       // >= 0, or +inf / NaN (then: not a candidate)
+                const int bits = __float_as_int(lb);
+                key[j] = (bits >= 0 && bits < VOL_KEY_INF) ? ((bits & ~7) | j) : VOL_KEY_INF;
+            }
+        }
+    }
+    int since_refresh = 0;
+    while (true) {
+        int mine = key[0];
+#pragma unroll
+        for (int j = 1; j < NS; ++j) mine = min(mine, key[j]);
+        const int wk = wave_min_key(mine);
+        if (wk >= VOL_KEY_INF) break;                              // nothing left in the batch
+        if (!(__int_as_float(wk & ~7) <= wave_worst)) break;       // every candidate left is farther than what the strip has
+        const unsigned long long own = __ballot(mine == wk);
+        const int src = __ffsll((long long)own) - 1;
+        const int jsel = wk & 7;
+#pragma unroll
+        for (int j = 0; j < NS; ++j)
+            if (lane == src && j == jsel) key[j] = VOL_KEY_INF;
+        const int c = src + 64 * jsel;
+        const int ck = list[c];
+        const VolRec rc = rec[c];
+        VOL_PH_COUNT(11, 1);
+        const float tz = sz * (rc.cz - fz);
+        const float dz = tz * tz;
+        const bool inx = x >= rc.wx0 && x < rc.wx1;
+        const float tx = sx * (rc.cx - fx);
+        const float dx2 = tx * tx;
+#pragma unroll
+        for (int r = 0; r < VROWS; ++r) {
+            const int y = y0 + r;
+            if (y < rc.wy0 || y >= rc.wy1) continue;
+            const float ty = sy * (rc.cy - (float)y);
+            const float dy = ty * ty;
+            float d = ((dz + dy) + dx2) * sw;
+            const float t = pv[r] - rc.cv;
+            d = d + t * t;
+            const bool take = inx && (best_d[r] > d || (best_d[r] == d && ck < best_k[r]));
+            best_d[r] = take ? d : best_d[r];               // (selects, no change of the exec mask)
+            best_k[r] = take ? ck : best_k[r];
+        }
+        if (++since_refresh == 2) {
+            since_refresh = 0;
+            float m2 = 0.f;
+#pragma unroll
+            for (int r = 0; r < VROWS; ++r)
+                if (xin && (y0 + r) < H) m2 = fmaxf(m2, best_d[r]);
+            wave_worst = wave_max_nonneg_f32(m2);           // (distances: never negative; +inf while a voxel has no candidate)
+        }
+    }
+}
+
+
+// Round 6.  A phase profile of the kernel (shader-clock ticks per section, tools/vol_phase_probe.py) showed where a workgroup's
+// 25 us go: 27 % into the scan of the brick list (list entry -> search window of that centroid -> test: two dependent trips to
+// global memory), 8 % into fetching the records of the hits (a third), 31 % into the bounding boxes (per strip row, every run
+// start loads its label's box and compares: four more dependent trips per wave) and 17 % into the walk itself -- the kernel waits,
+// all four waves of a workgroup together, far more than it computes.  So the trips are taken out:
+//   * k_vol_scatter_f32 writes everything the assignment needs of a centroid -- position, value, search window, index: one
+//     VolEntry of 48 bytes -- into the brick lists; the scan loads an entry with three 16-byte loads, tests it and drops it
+//     straight into the LDS records: ONE trip instead of three, and one barrier less;
+//   * the bounding boxes of a workgroup's labels meet in an LDS hash table first (a 64 x 16 cross-section sees a dozen labels):
+//     run starts update it with LDS atomics, and one thread per label compares with / updates the global box at the end --
+//     a dozen box updates per workgroup instead of one per run, row and wave (~100).
+// Same candidates, same arithmetic, same order-free comparison: the label maps do not move.
+struct VolEntry {
+    float cz, cy, cx, cv;
+    int wy0, wy1, wx0, wx1;
+    int wz0, wz1, k, pad;
+};
+static_assert(sizeof(VolEntry) == 48, "three 16-byte loads per entry");
+constexpr int VT_SLOTS = 64;          // labels of a workgroup's cross-section whose boxes meet in LDS (more: straight to global memory)
+
+// every centroid writes its entry into the list of each brick its search window meets (float32 volumes)
+__global__ void __launch_bounds__(256) k_vol_scatter_f32(VolState s)
+{
+    int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= s.K) return;
+    const int *w = s.win + (size_t)k * 6;
+    if (w[1] <= w[0] || w[3] <= w[2] || w[5] <= w[4]) return;       // dead centroid: empty window
+    const float4 cen = *reinterpret_cast<const float4 *>(s.cen32 + (size_t)k * 4);
+    const int4 e0 = make_int4(__float_as_int(cen.x), __float_as_int(cen.y), __float_as_int(cen.z), __float_as_int(cen.w));
+    const int4 e1 = make_int4(w[2], w[3], w[4], w[5]);
+    const int4 e2 = make_int4(w[0], w[1], k, 0);
+    const int bz0 = w[0] / VOL_BZ, bz1 = (w[1] - 1) / VOL_BZ;
+    const int by0 = w[2] / VOL_BY, by1 = (w[3] - 1) / VOL_BY;
+    const int bx0 = w[4] / VOL_BX, bx1 = (w[5] - 1) / VOL_BX;
+    for (int bz = bz0; bz <= bz1; ++bz)
+        for (int by = by0; by <= by1; ++by)
+            for (int bx = bx0; bx <= bx1; ++bx) {
+                const int b = (bz * s.nby + by) * s.nbx + bx;
+                const int pos = atomicAdd(&s.brick_count[b], 1);
+                if (pos < s.brick_cap) {
+                    int4 *dst = reinterpret_cast<int4 *>(s.brick_entries + ((size_t)b * s.brick_cap + pos) * 12);
+                    dst[0] = e0;
+                    dst[1] = e1;
+                    dst[2] = e2;
+                }
+            }
+}
+
 template <bool TRACK>
 __global__ void __launch_bounds__(256)
 k_vol_assign_f32(VolState s, const float *__restrict__ vol, int32_t *__restrict__ labels)
 {
     __shared__ int list[VLIST32];
-    __shared__ VolRec rec[VLIST32];
+    __shared__ __attribute__((aligned(16))) VolRec rec[VLIST32];      // (filled with 16-byte stores)
     __shared__ int wave_base[4];
+    __shared__ int hb_key[TRACK ? VT_SLOTS : 1], hb_box[TRACK ? VT_SLOTS : 1][4];      // label -> ymin, ymax, xmin, xmax
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    VOL_PH_BEGIN
     const int rows_per_block = 4 * VROWS;
     const int yb = cdiv(s.H, rows_per_block);
     const int z = blockIdx.y / yb;
@@ -611,6 +769,10 @@ k_vol_assign_f32(VolState s, const float *__restrict__ vol, int32_t *__restrict_
     const bool alive = y0 < s.H;                              // (a wave below the volume takes part in the barriers only)
     const int y1w = min(y0 + VROWS, s.H);
     const bool xin = x < s.W;
+    if (TRACK && tid < VT_SLOTS) {                            // (visible to all after the first barrier of the scan below)
+        hb_key[tid] = -1;
+        hb_box[tid][0] = 0x7fffffff; hb_box[tid][1] = -1; hb_box[tid][2] = 0x7fffffff; hb_box[tid][3] = -1;
+    }
     float pv[VROWS], best_d[VROWS];
     int best_k[VROWS];
 #pragma unroll
@@ -627,19 +789,35 @@ k_vol_assign_f32(VolState s, const float *__restrict__ vol, int32_t *__restrict_
     float wave_worst = INFINITY;
     const int brick = ((z / VOL_BZ) * s.nby + (Y0 / VOL_BY)) * s.nbx + blockIdx.x;
     const int bcount = s.brick_count[brick];
-    const bool whole = bcount > s.brick_cap;
-    const int *__restrict__ blist = s.brick_list + (size_t)brick * s.brick_cap;
+    const bool whole = bcount > s.brick_cap;                   // list overflow: scan every centroid
+    const int4 *__restrict__ entries = reinterpret_cast<const int4 *>(s.brick_entries + (size_t)brick * s.brick_cap * 12);
+    // (requesting the first 256 entries before the length of the list is known -- one trip to memory instead of two -- was built and
+    // measured: 3.30 against 2.67 ms per sweep of a 64 x 2048 x 2048 volume on one box, alternating.  Twelve more registers per
+    // thread and half the speculative loads wasted cost more than the trip.)
     const int nscan = whole ? s.K : bcount;
     const int nblk = cdiv(nscan, 256);
-    constexpr int PER = VLIST32 / 64;
+    static_assert(VLIST32 == 512, "eight list slots per lane: three bits of a key");
+    VOL_PH(0);
+    VOL_PH_COUNT(8, 1);
+    VOL_PH_COUNT(9, nscan);
+    if (nblk == 0) __syncthreads();                            // (the table of the boxes is initialised for everybody)
     for (int b = 0; b < nblk; ++b) {
         const int i = b * 256 + tid;
-        int k = 0;
+        int4 e0 = make_int4(0, 0, 0, 0), e1 = e0, e2 = e0;
         bool hit = false;
         if (i < nscan) {
-            k = whole ? i : blist[i];
-            const int *w = s.win + (size_t)k * 6;
-            hit = z >= w[0] && z < w[1] && w[2] < Y1 && w[3] > Y0 && w[4] < x1w && w[5] > x0w;
+            if (whole) {
+                const int *w = s.win + (size_t)i * 6;
+                const float4 cen = *reinterpret_cast<const float4 *>(s.cen32 + (size_t)i * 4);
+                e0 = make_int4(__float_as_int(cen.x), __float_as_int(cen.y), __float_as_int(cen.z), __float_as_int(cen.w));
+                e1 = make_int4(w[2], w[3], w[4], w[5]);
+                e2 = make_int4(w[0], w[1], i, 0);
+            } else {
+                e0 = entries[3 * i];
+                e1 = entries[3 * i + 1];
+                e2 = entries[3 * i + 2];
+            }
+            hit = z >= e2.x && z < e2.y && e1.x < Y1 && e1.y > Y0 && e1.z < x1w && e1.w > x0w;
         }
         const unsigned long long m = __ballot(hit);
         if (lane == 0) wave_base[wave] = __popcll(m);
@@ -647,186 +825,106 @@ k_vol_assign_f32(VolState s, const float *__restrict__ vol, int32_t *__restrict_
         int base = count;
         for (int w2 = 0; w2 < wave; ++w2) base += wave_base[w2];
         const int added = wave_base[0] + wave_base[1] + wave_base[2] + wave_base[3];
-        if (hit) list[base + __popcll(m & ((1ULL << lane) - 1ULL))] = k;
+        if (hit) {
+            const int pos = base + __popcll(m & ((1ULL << lane) - 1ULL));
+            list[pos] = e2.z;
+            int4 *dst = reinterpret_cast<int4 *>(&rec[pos]);
+            dst[0] = e0;
+            dst[1] = e1;
+        }
         count += added;
-        __syncthreads();                                     // (the list is complete; wave_base may be rewritten)
+        __syncthreads();                                     // (list and records are complete; wave_base may be rewritten)
+        VOL_PH(1);
         if (count <= VLIST32 - 256 && b + 1 < nblk) continue;
-        // ---- records of the batch into LDS
-        for (int c = tid; c < count; c += 256) {
-            const int ck = list[c];
-            const int *w = s.win + (size_t)ck * 6;
-            const float4 cen = *reinterpret_cast<const float4 *>(s.cen32 + (size_t)ck * 4);
-            VolRec rc;
-            rc.cz = cen.x; rc.cy = cen.y; rc.cx = cen.z; rc.cv = cen.w;
-            rc.wy0 = w[2]; rc.wy1 = w[3]; rc.wx0 = w[4]; rc.wx1 = w[5];
-            rec[c] = rc;
-        }
-        __syncthreads();
+        VOL_PH_COUNT(10, count);
+        VOL_PH(2);
         if (alive) {
-            // bounds over this wave's strip; a window that misses the strip's rows is out
-            float lbl[PER];
-#pragma unroll
-            for (int j = 0; j < PER; ++j) {
-                const int c = lane + 64 * j;
-                lbl[j] = INFINITY;
-                if (c < count) {
-                    const VolRec rc = rec[c];
-                    if (rc.wy0 < y1w && rc.wy1 > y0) {
-                        const float tz = sz * (rc.cz - fz);
-                        const float dz = tz * tz;
-                        const float yn = fminf(fmaxf(rc.cy, (float)y0), (float)(y1w - 1));
-                        const float xn = fminf(fmaxf(rc.cx, (float)x0w), (float)(x1w - 1));
-                        const float tyl = sy * (rc.cy - yn), txl = sx * (rc.cx - xn);
-                        lbl[j] = ((dz + tyl * tyl) + txl * txl) * sw;
-                    }
-                }
+#define VOL_WALK(NS) vol_walk_f32<NS>(rec, list, count, lane, y0, y1w, x0w, x1w, x, xin, s.H, fz, fx, sz, sy, sx, sw, pv, best_d, best_k, wave_worst)
+            switch ((count + 63) >> 6) {
+            case 0: break;
+            case 1: VOL_WALK(1); break;
+            case 2: VOL_WALK(2); break;
+            case 3: VOL_WALK(3); break;
+            case 4: VOL_WALK(4); break;
+            case 5: VOL_WALK(5); break;
+            case 6: VOL_WALK(6); break;
+            case 7: VOL_WALK(7); break;
+            default: VOL_WALK(8); break;
             }
-            int since_refresh = 0;
-            while (true) {
-                float mine = lbl[0];
-#pragma unroll
-                for (int j = 1; j < PER; ++j) mine = fminf(mine, lbl[j]);
-                const float wm = wave_min_nonneg_f32(mine);          // (bounds are sums of squares times a positive weight, or +inf)
-                if (!(wm <= wave_worst) || wm == INFINITY) break;  // (+inf: nothing left in the batch)
-                const unsigned long long own = __ballot(mine == wm);
-                const int src = __ffsll((long long)own) - 1;
-                int jsel = 0;
-#pragma unroll
-                for (int j = PER - 1; j >= 0; --j)
-                    if (lbl[j] == wm) jsel = j;
-                jsel = __builtin_amdgcn_readlane(jsel, src);
-#pragma unroll
-                for (int j = 0; j < PER; ++j)
-                    if (lane == src && j == jsel) lbl[j] = INFINITY;
-                const int c = src + 64 * jsel;
-                const int ck = list[c];
-                const VolRec rc = rec[c];
-                const float tz = sz * (rc.cz - fz);
-                const float dz = tz * tz;
-                const bool inx = x >= rc.wx0 && x < rc.wx1;
-                const float tx = sx * (rc.cx - fx);
-                const float dx2 = tx * tx;
-#pragma unroll
-                for (int r = 0; r < VROWS; ++r) {
-                    const int y = y0 + r;
-                    if (y < rc.wy0 || y >= rc.wy1) continue;
-                    const float ty = sy * (rc.cy - (float)y);
-                    const float dy = ty * ty;
-                    float d = ((dz + dy) + dx2) * sw;
-                    const float t = pv[r] - rc.cv;
-                    d = d + t * t;
-                    const bool take = inx && (best_d[r] > d || (best_d[r] == d && ck < best_k[r]));
-                    best_d[r] = take ? d : best_d[r];               // (selects, no change of the exec mask)
-                    best_k[r] = take ? ck : best_k[r];
-                }
-                if (++since_refresh == 2) {
-                    since_refresh = 0;
-                    float m2 = 0.f;
-#pragma unroll
-                    for (int r = 0; r < VROWS; ++r)
-                        if (xin && (y0 + r) < s.H) m2 = fmaxf(m2, best_d[r]);
-                    wave_worst = wave_max_nonneg_f32(m2);           // (distances: never negative; +inf while a voxel has no candidate)
-                }
-            }
+#undef VOL_WALK
         }
+        VOL_PH(3);
         count = 0;
-        __syncthreads();                                     // (everybody is done with this batch's list and records)
+        if (b + 1 < nblk) __syncthreads();                   // (everybody is done with this batch's list and records)
+        VOL_PH(4);
     }
-    if (!alive) return;
     unsigned pending = 0;
-#pragma unroll
-    for (int r = 0; r < VROWS; ++r) {
-        if (!(xin && (y0 + r) < s.H)) continue;
-        size_t p = ((size_t)z * s.H + y0 + r) * s.W + x;
-        if (best_k[r] >= 0) labels[p] = best_k[r];
-        else best_k[r] = labels[p];                           // uncovered voxel keeps its previous assignment
-        if (best_k[r] >= 0) pending |= 1u << r;
-    }
-    if (!TRACK) return;
-#ifndef VOL_TRACK_RUNS
-#define VOL_TRACK_RUNS 1
-#endif
-#if VOL_TRACK_RUNS
-    // bounding box of every segment's voxels (incl. the ones that kept an old label): the region the order-preserving update of
-    // that centroid has to walk.  Round 5: by RUNS -- in every row of the strip the first lane of a run of equal labels finds the
-    // end of its run in the vote of the run starts and compares / updates the box of its label; the runs of a wave do so side by
-    // side (rounds 3 / 4 enumerated the distinct labels of the strip one after the other: ~45 instructions each, a quarter of the
-    // kernel).  Minima and maxima: the boxes are the same whatever the order and however often a label is met.
-#pragma unroll
-    for (int r = 0; r < VROWS; ++r) {
-        const int k = (pending >> r) & 1u ? best_k[r] : -1;
-        const int kp = __shfl_up(k, 1, 64);
-        const bool start = k >= 0 && (lane == 0 || kp != k);
-        const unsigned long long starts = __ballot(start), valid = __ballot(k >= 0);
-        if (start) {
-            const unsigned long long stop = (starts | ~valid) & ~((2ULL << lane) - 1ULL);     // the lanes above this one
-            const int end = stop ? __ffsll((long long)stop) - 1 : 64;
-            const int y = y0 + r, xlo = x0w + lane, xhi = x0w + end - 1;
-            int *bb = s.bbox + (size_t)k * 6;
-            const int b0 = bb[0], b1 = bb[1], b2 = bb[2], b3 = bb[3], b4 = bb[4], b5 = bb[5];
-            if (b0 > z) atomicMin(&bb[0], z);
-            if (b1 < z) atomicMax(&bb[1], z);
-            if (b2 > y) atomicMin(&bb[2], y);
-            if (b3 < y) atomicMax(&bb[3], y);
-            if (b4 > xlo) atomicMin(&bb[4], xlo);
-            if (b5 < xhi) atomicMax(&bb[5], xhi);
-        }
-    }
-#else
-    // bounding box of every segment's voxels (incl. the ones that kept an old label): the region the
-    // order-preserving update of that centroid has to walk
-    int my_k = -1, my_ylo = 0, my_yhi = 0, my_xlo = 0, my_xhi = 0, n_distinct = 0;
-    while (true) {
-        int first = -1;
-#pragma unroll
-        for (int r = VROWS - 1; r >= 0; --r)
-            if (pending & (1u << r)) first = best_k[r];
-        const unsigned long long vote = __ballot(first >= 0);
-        if (!vote) break;
-        const int k = __builtin_amdgcn_readlane(first, __ffsll((long long)vote) - 1);
-        unsigned long long rows[VROWS], any = 0;
+    if (alive) {
 #pragma unroll
         for (int r = 0; r < VROWS; ++r) {
-            const bool mine = (pending & (1u << r)) && best_k[r] == k;
-            rows[r] = __ballot(mine);
-            any |= rows[r];
-            if (mine) pending &= ~(1u << r);
+            if (!(xin && (y0 + r) < s.H)) continue;
+            size_t p = ((size_t)z * s.H + y0 + r) * s.W + x;
+            if (best_k[r] >= 0) labels[p] = best_k[r];
+            else best_k[r] = labels[p];                           // uncovered voxel keeps its previous assignment
+            if (best_k[r] >= 0) pending |= 1u << r;
         }
-        int ylo = 0, yhi = 0;
+    }
+    VOL_PH(5);
+    if (!TRACK) return;
+    // bounding box of every segment's voxels (incl. the ones that kept an old label): the region the order-preserving update of
+    // that centroid has to walk.  By RUNS (round 5): in every row of the strip the first lane of a run of equal labels finds the
+    // end of its run in the vote of the run starts.  Round 6: it updates the box of its label in the workgroup's LDS table (z is
+    // the workgroup's); the table goes to the global boxes once, below.  Minima and maxima: the boxes are the same whatever the
+    // order and however often a label is met.
+    if (alive) {
 #pragma unroll
-        for (int r = VROWS - 1; r >= 0; --r)
-            if (rows[r]) ylo = y0 + r;
-#pragma unroll
-        for (int r = 0; r < VROWS; ++r)
-            if (rows[r]) yhi = y0 + r;
-        const int xlo = x0w + __ffsll((long long)any) - 1, xhi = x0w + 63 - __clzll((long long)any);
-        if (n_distinct == 64) {
-            // (more distinct labels than lanes in one 64 x 4 strip: flush what is parked -- never seen, kept for safety)
-            if (my_k >= 0) {
-                int *bb = s.bbox + (size_t)my_k * 6;
-                atomicMin(&bb[0], z); atomicMax(&bb[1], z);
-                atomicMin(&bb[2], my_ylo); atomicMax(&bb[3], my_yhi);
-                atomicMin(&bb[4], my_xlo); atomicMax(&bb[5], my_xhi);
+        for (int r = 0; r < VROWS; ++r) {
+            const int k = (pending >> r) & 1u ? best_k[r] : -1;
+            const int kp = lane_prev(k, -2);
+            const bool start = k >= 0 && kp != k;
+            const unsigned long long starts = __ballot(start), valid = __ballot(k >= 0);
+            if (start) {
+                const unsigned long long stop = (starts | ~valid) & ~((2ULL << lane) - 1ULL);     // the lanes above this one
+                const int end = stop ? __ffsll((long long)stop) - 1 : 64;
+                const int y = y0 + r, xlo = x0w + lane, xhi = x0w + end - 1;
+                int slot = (int)(((unsigned int)k * 2654435761u) >> 26);          // 6 bits
+                bool placed = false;
+                for (int probe = 0; probe < VT_SLOTS; ++probe) {
+                    const int old = atomicCAS(&hb_key[slot], -1, k);
+                    if (old == -1 || old == k) {
+                        placed = true;
+                        break;
+                    }
+                    slot = (slot + 1) & (VT_SLOTS - 1);
+                }
+                if (placed) {
+                    atomicMin(&hb_box[slot][0], y);
+                    atomicMax(&hb_box[slot][1], y);
+                    atomicMin(&hb_box[slot][2], xlo);
+                    atomicMax(&hb_box[slot][3], xhi);
+                } else {                                          // (more than VT_SLOTS labels in a 64 x 16 cross-section)
+                    int *bb = s.bbox + (size_t)k * 6;
+                    atomicMin(&bb[0], z); atomicMax(&bb[1], z);
+                    atomicMin(&bb[2], y); atomicMax(&bb[3], y);
+                    atomicMin(&bb[4], xlo); atomicMax(&bb[5], xhi);
+                }
             }
-            my_k = -1;
-            n_distinct = 0;
         }
-        if (lane == n_distinct) {
-            my_k = k; my_ylo = ylo; my_yhi = yhi; my_xlo = xlo; my_xhi = xhi;
-        }
-        ++n_distinct;
     }
-    if (my_k >= 0) {
-        int *bb = s.bbox + (size_t)my_k * 6;
-        const int b0 = bb[0], b1 = bb[1], b2 = bb[2], b3 = bb[3], b4 = bb[4], b5 = bb[5];
-        if (b0 > z) atomicMin(&bb[0], z);
-        if (b1 < z) atomicMax(&bb[1], z);
-        if (b2 > my_ylo) atomicMin(&bb[2], my_ylo);
-        if (b3 < my_yhi) atomicMax(&bb[3], my_yhi);
-        if (b4 > my_xlo) atomicMin(&bb[4], my_xlo);
-        if (b5 < my_xhi) atomicMax(&bb[5], my_xhi);
+    __syncthreads();
+    if (tid < VT_SLOTS && hb_key[tid] >= 0) {
+        int *bb = s.bbox + (size_t)hb_key[tid] * 6;
+        const int2 bz = *reinterpret_cast<const int2 *>(bb), by = *reinterpret_cast<const int2 *>(bb + 2),
+                   bx = *reinterpret_cast<const int2 *>(bb + 4);
+        const int ylo = hb_box[tid][0], yhi = hb_box[tid][1], xlo = hb_box[tid][2], xhi = hb_box[tid][3];
+        if (bz.x > z) atomicMin(&bb[0], z);
+        if (bz.y < z) atomicMax(&bb[1], z);
+        if (by.x > ylo) atomicMin(&bb[2], ylo);
+        if (by.y < yhi) atomicMax(&bb[3], yhi);
+        if (bx.x > xlo) atomicMin(&bb[4], xlo);
+        if (bx.y < xhi) atomicMax(&bb[5], xhi);
     }
-#endif
+    VOL_PH(6);
 }
 
 // Round 5: one LANE per centroid.  The float32 sums of a segment must be formed in raster order (see above), which makes the sum of
@@ -996,7 +1094,7 @@ int launch_vol_slic_f32(VolState s, const float *vol, int32_t *labels, int max_i
     const size_t n_bricks = (size_t)s.nbz * s.nby * s.nbx;
     for (int it = 0; it < max_iter; ++it) {
         HIP_TRY(hipMemsetAsync(s.brick_count, 0, n_bricks * sizeof(int), st));
-        hipLaunchKernelGGL(k_vol_scatter, cdiv(s.K, 256), 256, 0, st, s);
+        hipLaunchKernelGGL(k_vol_scatter_f32, cdiv(s.K, 256), 256, 0, st, s);
         // (when profiling: the event pair rides on the dispatch of the assignment kernel, group 0 = "slic_assign")
         hipEvent_t ev_a = nullptr, ev_b = nullptr;
         if (prof && prof->pair) prof->pair(prof->user, 0, &ev_a, &ev_b);
@@ -1024,29 +1122,11 @@ __device__ __forceinline__ int cc_find(const int32_t *parent, int a)
     }
     return a;
 }
-// find with path halving, for the merge passes (Jayanti / Tarjan; ECL-CC's "intermediate pointer jumping"): every step of the walk
-// re-points the voxel it leaves at its grandparent.  Safe next to the atomicMin of the unions: a parent pointer only ever moves to a
-// smaller index of the same set -- a root is never written here (the walk stops at it), a stale read yields an older ancestor,
-// and a store that overwrites a concurrent hook of the SAME voxel loses nothing, because the union that placed the hook goes on with
-// the value it displaced.  The chains of a supervoxel (one link per row and slice it spans) shrink while they are walked; the
-// flatten pass behind finds them short.
-__device__ __forceinline__ int cc_find_halving(int32_t *parent, int a)
-{
-    int p = parent[a];
-    while (p != a) {
-        const int g = parent[p];
-        if (g != p) parent[a] = g;
-        a = p;
-        p = g;
-    }
-    return a;
-}
-
 __device__ __forceinline__ void cc_union(int32_t *parent, int a, int b)
 {
     while (true) {
-        a = cc_find_halving(parent, a);
-        b = cc_find_halving(parent, b);
+        a = cc_find(parent, a);
+        b = cc_find(parent, b);
         if (a == b) return;
         if (a < b) {
             int t = a;
@@ -1439,4 +1519,24 @@ int launch_vol_adjacency_table(const int32_t *labels, int D, int H, int W, int K
     return 0;
 }
 
+#ifdef IMSEGM_VOL_PHASE_PROF
+int vol_phase_read(unsigned long long *out16, int reset)
+{
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_vol_phase), 16 * sizeof(unsigned long long)));
+    if (reset) {
+        unsigned long long zero[16] = { 0 };
+        HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_vol_phase), zero, sizeof(zero)));
+    }
+    return 0;
+}
+#endif
+
 }  // namespace imsegm
+
+#ifdef IMSEGM_VOL_PHASE_PROF
+extern "C" __attribute__((visibility("default"))) int imsegm_debug_vol_phases(unsigned long long *out16, int reset)
+{
+    return imsegm::vol_phase_read(out16, reset);
+}
+#endif

@@ -220,32 +220,51 @@ def _seeding_rows(table, n_clusters):
     return few if _SEEDING_ON_FEW_ROWS[key] else slice(None)
 
 
-_HEAP_TUNED = [False]
-#: the side-by-side fit holds the process's BLAS pools at one thread (threadpool_limits is process-wide): ONE such fit at a time --
-#: a second caller (volumes in flight from several worker threads) takes scikit-learn's own loop, same parameters either way
-_SIDE_BY_SIDE = __import__('threading').Lock()
+class _SideBySideGate(object):
+    """Who may run a side-by-side fit right now.  The fits hold the process's BLAS pools at ONE thread -- ``threadpool_limits`` is
+    process-wide, so the limit is taken by the first fit that enters and given back by the last one that leaves -- and every
+    OpenMP thread of a restart's k-means calls into that BLAS, which keeps per-thread buffers for 64 callers and dies beyond
+    (round 5, on the GPU box).  Hence: at most ``slots`` fits at once (volumes in flight from several worker threads; a third
+    waits its turn), each with a budget of ``callers`` BLAS callers -- 2 x 27 stays below the 64.  Concurrent callers that leave
+    ``random_state`` at None share numpy's global stream, as concurrent callers of scikit-learn itself do: their fits are not
+    reproducible run to run."""
+
+    def __init__(self, slots=2, callers=28):
+        import threading
+        self.slots, self.callers = slots, callers
+        self._gate = threading.BoundedSemaphore(slots)
+        self._lock = threading.Lock()
+        self._active, self._limiter = 0, None
+
+    def __enter__(self):
+        self._gate.acquire()
+        try:
+            with self._lock:
+                if self._active == 0:
+                    from threadpoolctl import threadpool_limits
+                    self._limiter = threadpool_limits(limits=1, user_api='blas')
+                self._active += 1
+        except BaseException:
+            self._gate.release()
+            raise
+        return self
+
+    def __exit__(self, *exc):
+        with self._lock:
+            self._active -= 1
+            if self._active == 0 and self._limiter is not None:
+                try:
+                    self._limiter.restore_original_limits()
+                finally:
+                    self._limiter = None
+        self._gate.release()
+        return False
+
+    def busy(self):
+        return self._active
 
 
-def _keep_large_temporaries_on_the_heap():
-    """glibc hands every block above its mmap threshold (128 KB by default, growing to at most 32 MB) to ``mmap`` and returns it with
-    ``munmap``: each numpy temporary of the EM loop on a table of 3 * 10^5 rows (2.4 - 7 MB) is mapped, page-faulted in and
-    unmapped again, nine restarts at once.  With the threshold raised the blocks come from the heap and are recycled -- the same
-    arithmetic on the same values, 0.81 -> 0.72 s for the fit of a 64 x 4096 x 4096 volume's table on the GPU box
-    (tools/fit_malloc_probe.py).  Process-wide, once, only when a side-by-side fit runs; ``IMSEGM_FIT_KEEP_MALLOC=1`` leaves the
-    allocator alone."""
-    import os
-    if _HEAP_TUNED[0] or os.environ.get('IMSEGM_FIT_KEEP_MALLOC'):
-        return
-    _HEAP_TUNED[0] = True
-    try:
-        import ctypes
-        libc = ctypes.CDLL('libc.so.6')
-        m_trim_threshold, m_top_pad, m_mmap_threshold = -1, -2, -3          # <malloc.h>
-        libc.mallopt(m_mmap_threshold, 1 << 30)
-        libc.mallopt(m_trim_threshold, (1 << 31) - 1)
-        libc.mallopt(m_top_pad, 64 << 20)
-    except Exception:           # (not glibc: nothing to tune)
-        pass
+_SIDE_BY_SIDE = _SideBySideGate()
 
 
 #: rows from which the restarts of a mixture fit run side by side (below, the thread pools, the stream bookkeeping and the one-thread
@@ -282,11 +301,9 @@ def fit_mixture_restarts(mixture, table, workers=None):
             or table.ndim != 2 or table.dtype != np.float64 or len(table) < max(_RESTARTS_SIDE_BY_SIDE_FROM, mixture.n_components) \
             or not np.isfinite(table).all():
         return mixture.fit(table)
-    if not _SIDE_BY_SIDE.acquire(blocking=False):
-        return mixture.fit(table)
     stream = check_random_state(mixture.random_state)
     stream_state = stream.get_state()
-    _keep_large_temporaries_on_the_heap()
+    gate = _SIDE_BY_SIDE
     try:
         from threadpoolctl import threadpool_limits
         table = np.ascontiguousarray(table)
@@ -329,7 +346,7 @@ def fit_mixture_restarts(mixture, table, workers=None):
         # them calls into a BLAS: nine restarts side by side on a 256-core host were 9 x 256 callers at once (a worker thread does
         # not inherit the caller's OpenMP limit) -- far more than the 64 an OpenBLAS build keeps per-thread buffers for, and the
         # process died in it (measured on the GPU box, round 5).  The rule here: never more callers at once than ONE k-means of
-        # plain scikit-learn would bring in this process (its OpenMP team as it is set right now), and never more than 48; the
+        # plain scikit-learn would bring in this process (its OpenMP team as it is set right now), and never more than the gate's budget (28: two fits may run at once); the
         # teams of the restarts are cut accordingly, and when that leaves less than one thread per restart the initialisations
         # run one after the other.
         n_workers = max(1, min(workers, mixture.n_init))
@@ -338,10 +355,10 @@ def fit_mixture_restarts(mixture, table, workers=None):
         if side_by_side_init:
             from threadpoolctl import threadpool_info
             omp_now = max([int(p.get('num_threads', 1)) for p in threadpool_info() if p.get('user_api') == 'openmp'] or [1])
-            team = max(8, min(omp_now, 48)) // n_workers - 1
+            team = max(8, min(omp_now, gate.callers)) // n_workers - 1
             if team < 1:
                 side_by_side_init, team = False, None
-        with threadpool_limits(limits=1, user_api='blas'):
+        with gate:
             with ThreadPoolExecutor(max_workers=n_workers) as pool:
                 pending = []
                 if side_by_side_init:
@@ -363,8 +380,6 @@ def fit_mixture_restarts(mixture, table, workers=None):
         logging.debug('mixture restarts side by side not available (%r): scikit-learn\'s own loop', ex)
         stream.set_state(stream_state)
         return mixture.fit(table)
-    finally:
-        _SIDE_BY_SIDE.release()
     best, best_bound = None, -np.inf
     for run in runs:
         if run[0] > best_bound or best_bound == -np.inf:

@@ -636,8 +636,23 @@ def _touched_result(shape, dtype=np.int32, threads=4):
     return out, (lambda: [w.join() for w in workers])
 
 
+def _result_array(shape, dtype=np.int32):
+    """(array, wait): where the class map of a volume goes.  64 MB and more: a PAGE-LOCKED array out of the recycling pool of
+    ``_hip.pinned_empty`` (round 6) -- a fresh pageable array of 4.3 GB costs its page faults on the way in (hidden behind the
+    sweeps by :func:`_touched_result`) and 0.25 s of ``munmap`` when the caller lets go of it, every call; the page-locked block
+    returns to the pool instead and serves the next call, and the download runs as plain DMA.  When the host refuses that much
+    page-locked memory: the touched pageable array."""
+    nbytes = int(np.prod(shape, dtype=np.int64)) * np.dtype(dtype).itemsize
+    if nbytes >= (64 << 20):
+        try:
+            return _hip.pinned_empty(shape, dtype), (lambda: None)
+        except (_hip.HipError, _hip.HipUnavailableError):
+            pass
+    return _touched_result(shape, dtype)
+
+
 def _gray3d_on_session(sess, image, nb_classes, dict_features, spacing, sp_size, sp_regul, gc_regul):
-    segm_buf, segm_ready = _touched_result(sess.shape)
+    segm_buf, segm_ready = _result_array(sess.shape)
     _run_slic3d(sess, sp_size, sp_regul, spacing)
     logging.info('extract segments/superpixels features.')
     slic = None
