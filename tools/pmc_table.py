@@ -1,4 +1,4 @@
-"""kernel x counter table from the counter_collection CSVs of several rocprofv3 --pmc passes (tools/r6_c5_pmc.sh).
+"""kernel x counter table from the counter_collection CSVs of several rocprofv3 --pmc passes (tools/c5_pmc.sh).
 
     python tools/pmc_table.py <dir with counters_*.csv> <label>  ->  <dir>/summary.txt, <dir>/summary.json
 
