@@ -384,6 +384,9 @@ def cpu_baseline_texture(image, sp_size, sp_regul, budget_s=20.0):
 
 
 def _pool_one_image(task):
+    """one config-4 image through the CPU chain on one core; SLIC = the REAL scikit-image when this interpreter carries it (the
+    pool then runs under the image's conda Python, see cpu_baseline_batch), else the oracle port.  Returns (seconds, skimage
+    version or None)."""
     seed, sp_size, sp_regul, gc_regul, arrays = task
     try:
         from threadpoolctl import threadpool_limits
@@ -392,16 +395,28 @@ def _pool_one_image(task):
         pass
     from pyimsegm_amd.utilities.synthetic import voronoi_image
     image = voronoi_image(C4_SHAPE[0], C4_SHAPE[1], seed=seed)
+    version = None
     t0 = time.perf_counter()
-    _cpu_chain_color2d(image, model_from_arrays(arrays), sp_size, sp_regul, gc_regul)
-    return time.perf_counter() - t0
+    slic = None
+    try:
+        import warnings
+        import skimage
+        from skimage.segmentation import slic as sk_slic
+        img = np.asarray(image, dtype=np.float64)
+        if img.min() != 0. or img.max() != 1.:                       # imsegm/superpixels.py:53-54
+            img = (img - img.min()) / float(img.max() - img.min())
+        with warnings.catch_warnings():
+            warnings.simplefilter('ignore')
+            slic = np.asarray(sk_slic(img, n_segments=int(img.shape[0] * img.shape[1] / float(sp_size)**2),
+                                      compactness=(sp_size * sp_regul)**1.5, sigma=1, enforce_connectivity=True, slic_zero=False))
+        version = skimage.__version__
+    except ImportError:
+        pass
+    _cpu_chain_color2d(image, model_from_arrays(arrays), sp_size, sp_regul, gc_regul, slic=slic)
+    return time.perf_counter() - t0, version
 
 
-def cpu_baseline_batch(model_arrays, sp_size, sp_regul, nb_images=None):
-    """config 4 on the host as the reference's driver runs it: a pool of `int(0.9 * nproc)` worker processes mapped over
-    the images (run_segm_slic_model_graphcut.py:61, experiments.py:392-403), every worker one image at a time on one core;
-    bounded sample of 2 images per worker.  The per-image chain is the oracle port (its SLIC runs within 2 % of the real
-    scikit-image's time, see the config-2 baseline)."""
+def _pool_batch(model_arrays, sp_size, sp_regul, nb_images=None):
     import multiprocessing as mp
     nproc = os.cpu_count() or 1
     workers = max(1, int(0.9 * nproc))
@@ -410,14 +425,50 @@ def cpu_baseline_batch(model_arrays, sp_size, sp_regul, nb_images=None):
     with mp.get_context('spawn').Pool(workers) as pool:
         pool.map(_pool_one_image, tasks[:workers])                  # warm-up: imports, library loads
         t0 = time.perf_counter()
-        per_image = pool.map(_pool_one_image, tasks, chunksize=1)
+        got = pool.map(_pool_one_image, tasks, chunksize=1)
         wall = time.perf_counter() - t0
+    per_image, versions = [g[0] for g in got], sorted({g[1] for g in got if g[1]})
     npx = C4_SHAPE[0] * C4_SHAPE[1]
-    return {'value': round(nb_images * npx / wall / 1e6, 4), 'unit': 'Mpixels/s', 'cores': workers, 'kind': 'port',
+    real = versions[0] if (versions and all(g[1] for g in got)) else None
+    return {'value': round(nb_images * npx / wall / 1e6, 4), 'unit': 'Mpixels/s', 'cores': workers,
+            'kind': 'reference+port' if real else 'port',
             'sample': '%d images of %dx%d over a pool of %d worker processes (int(0.9 * %d cpus), as the reference driver), wall %.2f s; '
-                      'one image on one core: median %.2f s' % (nb_images, C4_SHAPE[0], C4_SHAPE[1], workers, nproc, wall,
-                                                                  median_min(per_image)[0]),
+                      'one image on one core: median %.2f s; SLIC = %s, the other legs = the oracle port'
+                      % (nb_images, C4_SHAPE[0], C4_SHAPE[1], workers, nproc, wall, median_min(per_image)[0],
+                         'the real scikit-image %s' % real if real else 'the oracle C restatement'),
             'one_core_value': round(npx / median_min(per_image)[0] / 1e6, 4)}
+
+
+def cpu_baseline_batch(model_arrays, sp_size, sp_regul, nb_images=None):
+    """config 4 on the host as the reference's driver runs it: a pool of `int(0.9 * nproc)` worker processes mapped over
+    the images (run_segm_slic_model_graphcut.py:61, experiments.py:392-403), every worker one image at a time on one core;
+    bounded sample of 2 images per worker.  SLIC -- 97 % of the chain -- is the REAL scikit-image: the pool runs under the
+    image's conda Python 3.9 when the box carries it (this interpreter cannot import scikit-image); otherwise the oracle port,
+    labelled so."""
+    try:
+        import skimage  # noqa: F401
+        return _pool_batch(model_arrays, sp_size, sp_regul, nb_images)
+    except ImportError:
+        pass
+    py = os.environ.get('IMSEGM_SKIMAGE_PYTHON', '/opt/conda/bin/python3.9')
+    if os.path.exists(py):
+        import subprocess
+        import tempfile
+        try:
+            with tempfile.TemporaryDirectory() as tmp:
+                path = os.path.join(tmp, 'model.npz')
+                np.savez(path, **model_arrays)
+                code = ('import sys, json, warnings; warnings.filterwarnings("ignore"); sys.path.insert(0, %r); import numpy as np; import bench; '
+                        'arrays = dict(np.load(sys.argv[1])); '
+                        'print("POOL " + json.dumps(bench._pool_batch(arrays, float(sys.argv[2]), float(sys.argv[3]), int(sys.argv[4]) or None)))' % ROOT)
+                run = subprocess.run([py, '-c', code, path, str(sp_size), str(sp_regul), str(nb_images or 0)], capture_output=True, text=True,
+                                     timeout=900, env=dict(os.environ, OMP_NUM_THREADS='1'))
+                lines = [ln for ln in run.stdout.splitlines() if ln.startswith('POOL ')]
+                if run.returncode == 0 and lines:
+                    return json.loads(lines[-1][5:])
+        except Exception:
+            pass
+    return _pool_batch(model_arrays, sp_size, sp_regul, nb_images)
 
 
 def cpu_baseline_volume(shape_full, crop=(64, 256, 256)):
@@ -1333,6 +1384,22 @@ def bench_volume(args, group, shape=None, quick=False):
                     'frac': round(VOL_ASSIGN_BYTES_PER_VOXEL * nvox / avg_s / 1e9 / HBM_PEAK_GBS, 5), 'traffic': None,
                     'avg_kernel_us': round(avg_s * 1e6, 1), 'launches': assign_n,
                     'algorithmic_bytes_per_launch': VOL_ASSIGN_BYTES_PER_VOXEL * nvox}
+        try:
+            # HBM bytes and instruction counts of the kernel from the committed rocprofv3 PMC passes (tools/c5_pmc.sh, a quarter
+            # volume with the same bricks and windows: per voxel, scaled to this volume).  HBM is not what bounds this kernel:
+            # ~60 search windows cover a voxel, a wave of 256 voxels issues ~1 350 vector + ~1 180 scalar instructions -- the floor
+            # of the vector unit (4 cycles per wave64 instruction at 2.4 GHz, 1 024 SIMDs) is quoted beside the HBM one.
+            with open(os.path.join(ROOT, 'profiles', 'pmc_traffic_cfg5_r06.json')) as fp:
+                pmc = json.load(fp)
+            roofline['traffic'] = int(pmc['hbm_bytes_per_voxel'] * nvox)
+            roofline['traffic_source'] = 'profiles/pmc_traffic_cfg5_r06.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, per voxel x voxels)'
+            issue_s = (nvox / 256.0 / 1024.0) * pmc['valu_per_wave'] * 4.0 / 2.4e9
+            roofline['valu_issue_floor'] = {'valu_per_wave': round(pmc['valu_per_wave'], 1), 'salu_per_wave': round(pmc['salu_per_wave'], 1),
+                                            'floor_us': round(issue_s * 1e6, 1), 'frac_of_floor': round(issue_s / avg_s, 3),
+                                            'note': 'waves per SIMD x vector instructions per wave x 4 cycles / 2.4 GHz: what the vector unit '
+                                                    'alone needs for the instructions this kernel issues'}
+        except Exception:
+            pass
     else:
         achieved = 10 * VOL_ASSIGN_BYTES_PER_VOXEL * nvox / (slic_ms / 1e3) / 1e9 if slic_ms else 0.0
         roofline = {'bound': 'hbm', 'kernel': 'whole 3-D SLIC stage (pre-processing, 10 x [scatter, k_vol_assign_f32, k_vol_update_f32], connectivity)',

@@ -12,7 +12,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 LIB = os.path.join(HERE, 'libimsegm_hip.so')
-SOURCES = ['api.hip', 'batch.hip', 'slic.hip', 'connectivity.hip', 'stats.hip', 'graph.hip', 'graphcut.hip', 'texture.hip', 'volume.hip', 'terms.hip', 'natives.hip', 'median.hip', 'output.hip']
+SOURCES = ['api.hip', 'api_image2d.hip', 'api_texture.hip', 'api_volume.hip', 'api_fused.hip', 'api_natives.hip', 'batch.hip', 'slic_pre.hip', 'slic.hip', 'connectivity.hip', 'stats.hip', 'graph.hip', 'graphcut.hip', 'texture.hip', 'volume.hip', 'terms.hip', 'natives.hip', 'median.hip', 'output.hip']
 HEADERS = ['common.h', 'slic.h', 'session.h', os.path.join('..', '..', 'include', 'imsegm_hip.h')]
 # -ffp-contract=off: every fp64 operation rounds on its own -- the bit-exactness contract with the
 # CPU oracle; no fast-math anywhere.

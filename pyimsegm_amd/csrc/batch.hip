@@ -294,7 +294,7 @@ int imsegm_batch2d_run_color(imsegm_batch2d *bt, int n_images, const void *const
         hook.pair = [](void *u, int g, hipEvent_t *a, hipEvent_t *b) { static_cast<imsegm_ctx *>(u)->pair(g, a, b); };
     }
     bool fused_update = false;
-    if (launch_slic_iterations(s, lab, nullptr, nearest, max_iter, 0, hook, st, nullptr, bt->fail_host, &fused_update, zb)) return -1;
+    if (launch_slic_iterations(s, lab, nullptr, nearest, max_iter, 0, hook, st, &fused_update, zb)) return -1;
 
     // ---- connectivity: the tile path on all maps, ONE synchronisation for the label counts of the batch
     ConnWork w = conn_work_from(reinterpret_cast<int32_t *>(base + L.conn_i32), L.conn_i32_bytes, base + L.conn_u8, n);
@@ -306,7 +306,7 @@ int imsegm_batch2d_run_color(imsegm_batch2d *bt, int n_images, const void *const
             slic_sweep_note_fallback();
             SlicState plain = s;
             plain.done = nullptr;
-            if (launch_slic_iterations(plain, lab, nullptr, nearest, max_iter, 0, hook, st, nullptr, nullptr, nullptr, zb)) return -1;
+            if (launch_slic_iterations(plain, lab, nullptr, nearest, max_iter, 0, hook, st, nullptr, zb)) return -1;
         }
         const int spc = ctx->begin(PG_CONN);
         if (launch_enforce_connectivity_batch(nearest, H, W, min_size, max_size, start_label, w, labels, nl.data(), st, zb,

@@ -24,11 +24,10 @@ bool hip_ok(hipError_t e, const char *what, const char *file, int line);
 // Debug / experiment switches of the library.  The process environment is read ONCE (first use) and again only when
 // imsegm_debug_reload_env() is called (tests flip switches at run time): nothing on the per-image path looks at the environment.
 struct Knobs {
-    bool slic_graph, slic_persistent, pre_3pass, separate_finalize, fuse_finalize, sweeps_force_fail, conn_general, gc_no_topo_regs,
+    bool slic_graph, pre_3pass, separate_finalize, fuse_finalize, conn_general, gc_no_topo_regs,
         adjacency_table,       // IMSEGM_ADJACENCY_TABLE: the neighbour table of a label volume's graph for every K (default: beyond 46 000 labels)
         cc_merge_full,         // IMSEGM_CC_MERGE_FULL: the voxel-by-voxel merge passes of rounds 2 - 4 -- measure.label with thirteen unions per voxel, connectivity with
                                // its per-voxel loads -- instead of the row-segment kernels (tests, A/B)
-        vol_update_wave,       // IMSEGM_VOL_UPDATE_WAVE: the float32 centroid update of a volume with one WAVE per centroid (round 3 / 4; tests, A/B)
         sep_wide_tile;         // IMSEGM_SEP_WIDE_TILE: the separable kernels of side 33 on the 64 x 16 tile of round 4's first half (tests, A/B)
     int brick_cap;             // IMSEGM_BRICK_CAP (0: default)
     int gc_lds_level;          // IMSEGM_GC_LDS_LEVEL (default 4)
@@ -38,8 +37,6 @@ struct Knobs {
     bool gc_one_workgroup;     // IMSEGM_GC_ONE_WORKGROUP: never the grid-wide kernel (tests, A/B)
     bool gc_grid_test_absent;  // IMSEGM_GC_GRID_TEST_ABSENT: one workgroup of the grid-wide kernel never arrives (test of the bounded wait + fall-back)
     int fused_bitmap_mb;       // IMSEGM_FUSED_BITMAP_MB (0: what the device has free): ceiling of the fused call's two K x K bit arrays (tests of the fall-back)
-    int sweeps_blocks_per_cu;  // IMSEGM_SWEEPS_BLOCKS_PER_CU (0: default)
-    int sweeps_per_launch;     // IMSEGM_SWEEPS_PER_LAUNCH (0: all)
     std::string phase_dump;    // IMSEGM_PHASE_DUMP (file name, empty: none)
 };
 const Knobs &knobs();

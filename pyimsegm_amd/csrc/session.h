@@ -158,10 +158,10 @@ struct imsegm_image2d {
     bool is_volume = false;
     double vol_off = 0.0, vol_scale = 1.0;      // intensity seen by the volume SLIC = (v + off) * scale
     DevBuf img, labA, labB, nearest, labels, conn_i32, conn_u8, small, cent, tiles, feat, graph, gather_lut, gather_out_i, gather_out_f,
-        tex_planes, tex_resp, tex_small, vol_cent, annot, hist, featK, seg, gseg, sweeps, narrow;
+        tex_planes, tex_resp, tex_small, vol_cent, annot, hist, featK, seg, gseg, narrow;
     GraphPlan gplan;                            // the graph imsegm_image2d_graph_prepare has enqueued into `gseg` ...
     bool graph_ready = false;                   // ... for the current label map (any call that changes the labels clears this)
-    int *slic_fail_host = nullptr;              // page-locked word the persistent sweep kernel raises when it cannot take the image
+    int *slic_fail_host = nullptr;              // page-locked word the centroid update inside the assignment kernel raises when it hands the image back
     int feat_mask = 0, feat_F = 0;              // layout of the resident feature table (imsegm_image2d_features_color)
     int place_F = 0, place_col = 0;             // imsegm_image2d_features_place: where the next descriptor call puts its columns
     // the ten SLIC sweeps (30 kernel launches + a memset) as one captured HIP graph, re-used while every launch parameter
@@ -266,7 +266,17 @@ inline bool is_pinned(const void *p)
 }
 
 
-// what of the 2-D SLIC state follows from the sizes (api.hip)
+// helpers shared by the files of the C ABI (api.hip was split by stage in round 6): defined in api_volume.hip, api_image2d.hip,
+// api_fused.hip
+extern "C" {
+// segmented statistics of `src` on the session's label map (mean, energy, variance: any may be null); planar: [C][H][W] planes
+int stats_run(imsegm_image2d *im, const void *src, int dtype, double maxabs, int planar, int prescale, double mul, double div,
+              double *mean_out, double *energy_out, double *var_out, long plane_stride = -1);
+// where a descriptor call puts its columns of the resident feature table (imsegm_image2d_features_place)
+int take_placement(imsegm_image2d *im, int own_F, bool to_host, int *table_F, int *col0);
+}
+
+// what of the 2-D SLIC state follows from the sizes (api_image2d.hip)
 struct SlicGeometry {
     int K;             // centroids of the regular grid
     size_t n_tiles;    // 64 x 32 candidate tiles
@@ -300,4 +310,10 @@ inline imsegm::ConnWork conn_work_from(int32_t *base_i32, size_t cap_bytes, uint
     w.dense_ints = (cap_bytes - (size_t)((unsigned char *)b - (unsigned char *)base_i32)) / 4;
     w.visited = base_u8;
     return w;
+}
+
+// the pieces of a session's connectivity scratch as the kernels see them
+inline imsegm::ConnWork make_conn_work(imsegm_image2d *im)
+{
+    return conn_work_from(im->conn_i32.as<int32_t>(), im->conn_i32.cap, im->conn_u8.as<uint8_t>(), im->n);
 }

@@ -96,53 +96,13 @@ struct ProfHook {
     void (*pair)(void *, int, hipEvent_t *, hipEvent_t *) = nullptr;
 };
 int slic_prepare_device();
-// Scratch of the persistent sweep kernel (k_slic_sweeps: every sweep after the first in ONE launch, slic.hip).  One record per
-// centroid and sweep, 128 bytes = one cache line each, written once (write-through) and never rewritten: a tile of sweep s
-// reads table s, the centroid update of sweep s writes table s + 1.
-struct alignas(128) CenRec {
-    double cy, cx, cL, ca, cb;
-    int4 win;                       // empty window: the centroid is dead
-    double pad[9];
-};
-struct SweepWork {
-    CenRec *cen;                    // [max_iter][K]
-    long long *acc;                 // [max_iter][K][9] sums of sweep s (zeroed before the launch, touched by atomics only)
-    int *done;                      // [max_iter][K] tiles of sweep s that have added their pixels to centroid k
-    int *ccount;                    // [max_iter][n_tiles] length of the candidate list of (sweep, tile)
-    int *rowdone;                   // [max_iter][tile_rows][SWEEP_ROW_STRIDE] (a 128-byte line per row: polled words do not share lines)
-                                    // word 0: tiles of that tile row that are through with sweep s (incl. what they publish);
-                                    // word 1: complete tile rows of sweep s - 1 within wait_rows of this row -- the ONE word a
-                                    //         tile of (s, row) polls (pushed by the tile that completes a row)
-    int *clist;                     // [max_iter][n_tiles][SLIC_MAXC] candidate lists, filled by the centroids themselves
-    int *ctl;                       // of THIS launch: [q * 32], q < 8: item counters (a failure poisons them) -- a cache line each
-    int *fail;                      // failure flag (device copy; its own cache line), shared by the launches of one image
-    int *fail_host;                 // page-locked host word the host reads at its next synchronisation (0: result valid)
-    int n_tiles, tiles_x, tile_rows;
-    int sweep_begin, sweep_end;     // sweeps [sweep_begin, sweep_end) run in this launch
-    int sweep_last;                 // max_iter: the sweep before it is the last one (no accumulation, writes the labels)
-    int wait_rows;                  // a tile of sweep s + 1 needs the tile rows within this distance complete in sweep s
-    int force_fail;                 // (tests) raise the failure flag at once
-    long long *prof;                // (IMSEGM_DEBUG_SWEEPS) per-phase sums of the 100 MHz clock over all work items, or null
-};
-long long *slic_sweep_prof_buffer();   // device buffer of 16 counters (allocated on first use), or null
-constexpr int SWEEP_ROW_STRIDE = 32;     // ints
-static inline size_t sweep_zeroed_bytes(int K, int max_iter, int n_tiles, int tile_rows)
-{
-    return (size_t)max_iter * ((size_t)K * (9 * sizeof(long long) + sizeof(int)) + (size_t)(n_tiles + tile_rows * SWEEP_ROW_STRIDE) * sizeof(int) +
-                               8 * 128) + 128;      // (+ the item counters of up to max_iter launches and the failure flag)
-}
-static inline size_t sweep_work_bytes(int K, int max_iter, int n_tiles, int tile_rows)
-{
-    return (size_t)max_iter * K * sizeof(CenRec) + sweep_zeroed_bytes(K, max_iter, n_tiles, tile_rows) +
-           (size_t)max_iter * n_tiles * SLIC_MAXC * sizeof(int) + (size_t)(max_iter * 8 + 1) * 128 + 256;
-}
-// diagnostics: images whose sweeps ran in the persistent kernel / that had to be redone by the per-sweep launches
+// diagnostics: images whose sweeps were redone with separate finalize launches (the centroid update inside the assignment kernel
+// handed them back); persistent_runs: always 0 since round 6
 void slic_sweep_counters(long *persistent_runs, long *fallback_runs);
 void slic_sweep_note_fallback();
-// `sweep_scratch` (sweep_work_bytes, 128-byte aligned) + `fail_host`: allow the persistent kernel; *used_persistent reports the choice
+// *fused_update: the centroid update ran inside the assignment kernel -- the caller reads s.fail_host after its next synchronisation
 int launch_slic_iterations(SlicState s, const double *lab, const double *init_yx_dev, int32_t *labels, int max_iter,
-                           int max_cand, const ProfHook &prof, hipStream_t st, void *sweep_scratch = nullptr,
-                           int *fail_host = nullptr, bool *used_persistent = nullptr, ZBatch zb = ZBatch());
+                           int max_cand, const ProfHook &prof, hipStream_t st, bool *fused_update = nullptr, ZBatch zb = ZBatch());
 
 // volume.hip -------------------------------------------------------------------------------------
 struct VolState {

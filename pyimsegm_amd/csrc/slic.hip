@@ -15,495 +15,6 @@
 namespace imsegm {
 
 // ---------------------------------------------------------------------------------------------
-// min / max of the input (superpixels.py:53-54), order-preserving uint64 keys + atomics
-// ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ unsigned long long f64_key(double x)
-{
-    long long b = __double_as_longlong(x);
-    return b < 0 ? ~(unsigned long long)b : ((unsigned long long)b | 0x8000000000000000ULL);
-}
-__host__ __device__ __forceinline__ double key_f64(unsigned long long k)
-{
-    unsigned long long b = (k & 0x8000000000000000ULL) ? (k & 0x7fffffffffffffffULL) : ~k;
-    union { unsigned long long u; double d; } cv;
-    cv.u = b;
-    return cv.d;
-}
-
-// wave reduce, block reduce through LDS, then ONE atomic pair per block (a per-wave atomic on the
-// same two words serialises at ~12 ns each).  The words rest at zero between calls: keys[0] holds the complement of the
-// minimum's key (so both are running maxima and zero is the neutral element), keys[5] is an arrival counter (the call's results sit in between), and the
-// workgroup that arrives last decodes the pair into out2, clears `also_zero` (the accumulator of the NEXT kernel of the
-// stream) and puts the words back to zero -- no launch before or after the reduction.
-__device__ __forceinline__ void block_minmax_commit(double mn, double mx, unsigned long long *keys, double *out2, double *also_zero)
-{
-    __shared__ double smn[4], smx[4];
-    mn = wave_min_f64(mn);
-    mx = wave_max_f64(mx);
-    if ((threadIdx.x & 63) == 0) {
-        smn[threadIdx.x >> 6] = mn;
-        smx[threadIdx.x >> 6] = mx;
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        mn = fmin(fmin(smn[0], smn[1]), fmin(smn[2], smn[3]));
-        mx = fmax(fmax(smx[0], smx[1]), fmax(smx[2], smx[3]));
-        __hip_atomic_fetch_max(&keys[0], ~f64_key(mn), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_fetch_max(&keys[1], f64_key(mx), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        unsigned *ticket = reinterpret_cast<unsigned *>(keys + 5);
-        // (release / acquire at agent scope: the atomics above are performed before the ticket is taken, and the last
-        // arriver's loads below see every workgroup's)
-        const unsigned t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-        if (t == gridDim.x - 1) {
-            const unsigned long long k0 = __hip_atomic_exchange(&keys[0], 0ULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const unsigned long long k1 = __hip_atomic_exchange(&keys[1], 0ULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            out2[0] = key_f64(~k0);
-            out2[1] = key_f64(k1);
-            if (also_zero) *also_zero = 0.0;
-        }
-    }
-}
-
-template <typename T>
-__global__ void __launch_bounds__(256) k_minmax(const T *__restrict__ src, size_t n, unsigned long long *keys, double *out2, double *also_zero,
-                                                size_t zs)
-{
-    ZSHIFT(src, zs); ZSHIFT(keys, zs); ZSHIFT(out2, zs); ZSHIFT(also_zero, zs);
-    double mn = INFINITY, mx = -INFINITY;
-    const size_t stride = (size_t)gridDim.x * blockDim.x;
-    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    // four independent loads in flight per lane (a 4.3 GB volume read one 4-byte load at a time ran at 0.33 TB/s)
-    for (; i + 3 * stride < n; i += 4 * stride) {
-        const double v0 = (double)src[i], v1 = (double)src[i + stride], v2 = (double)src[i + 2 * stride], v3 = (double)src[i + 3 * stride];
-        mn = fmin(fmin(mn, v0), fmin(fmin(v1, v2), v3));
-        mx = fmax(fmax(mx, v0), fmax(fmax(v1, v2), v3));
-    }
-    for (; i < n; i += stride) {
-        const double v = (double)src[i];
-        mn = fmin(mn, v);
-        mx = fmax(mx, v);
-    }
-    block_minmax_commit(mn, mx, keys, out2, also_zero);
-}
-
-// uint8 variant: 16 bytes per lane
-__global__ void __launch_bounds__(256) k_minmax_u8(const uint8_t *__restrict__ src, size_t n, unsigned long long *keys, double *out2,
-                                                   double *also_zero, size_t zs)
-{
-    ZSHIFT(src, zs); ZSHIFT(keys, zs); ZSHIFT(out2, zs); ZSHIFT(also_zero, zs);
-    unsigned mn = 255, mx = 0;
-    size_t nvec = n / 16;
-    const uint4 *v4 = reinterpret_cast<const uint4 *>(src);
-    size_t stride = (size_t)gridDim.x * blockDim.x;
-    // bytes 0 / 2 and 1 / 3 of a word as two 16-bit lanes each: packed 16-bit min / max, four bytes per instruction pair
-    typedef unsigned short us2 __attribute__((ext_vector_type(2)));
-    us2 pmn = { 255, 255 }, pmx = { 0, 0 };
-    // four independent 16-byte loads per thread and round (few workgroups: the loads of a thread must overlap)
-    for (size_t i0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i0 < nvec; i0 += 4 * stride) {
-        uint4 q[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const size_t i = i0 + u * stride;
-            q[u] = i < nvec ? v4[i] : v4[i0];
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const unsigned w[4] = { q[u].x, q[u].y, q[u].z, q[u].w };
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const unsigned e = w[j] & 0x00ff00ffu, o = (w[j] >> 8) & 0x00ff00ffu;
-                const us2 ev = __builtin_bit_cast(us2, e), ov = __builtin_bit_cast(us2, o);
-                pmn = __builtin_elementwise_min(pmn, __builtin_elementwise_min(ev, ov));
-                pmx = __builtin_elementwise_max(pmx, __builtin_elementwise_max(ev, ov));
-            }
-        }
-    }
-    mn = min((unsigned)pmn.x, (unsigned)pmn.y);
-    mx = max((unsigned)pmx.x, (unsigned)pmx.y);
-    if (blockIdx.x == 0)
-        for (size_t i = nvec * 16 + threadIdx.x; i < n; i += blockDim.x) {
-            unsigned v = src[i];
-            mn = min(mn, v);
-            mx = max(mx, v);
-        }
-    block_minmax_commit((double)mn, (double)mx, keys, out2, also_zero);
-}
-
-// `keys`: words 0, 1 and 5 are ZERO when the call is enqueued and zero again when it has run (the session zeroes them once, where it
-// allocates them); `also_zero`: one more double the last workgroup clears (nullptr: none)
-int launch_minmax(const void *src, int dtype, size_t n, unsigned long long *keys, double *out2, hipStream_t st, double *also_zero, ZBatch zb)
-{
-    // few workgroups: each ends with two atomics on the same two words, and single-lane atomics on one address serialise at
-    // ~12 ns (512 workgroups: 16 us, 2048: 50 us for a 12.6 MB image that streams in 3 us)
-    int gx = (int)std::min<size_t>(128, (n + 256 * 16 - 1) / (256 * 16));
-    if (gx < 1) gx = 1;
-    // (a volume: the commit of 2 048 workgroups is 50 us beside milliseconds of streaming -- eight workgroups per CU)
-    if (n >= ((size_t)1 << 26)) gx = 2048;
-    const dim3 grid(gx, 1, zb.nz);
-    if (dtype == DT_U8)
-        hipLaunchKernelGGL(k_minmax_u8, grid, 256, 0, st, (const uint8_t *)src, n, keys, out2, also_zero, zb.zs);
-    else if (dtype == DT_F32)
-        hipLaunchKernelGGL(k_minmax<float>, grid, 256, 0, st, (const float *)src, n, keys, out2, also_zero, zb.zs);
-    else
-        hipLaunchKernelGGL(k_minmax<double>, grid, 256, 0, st, (const double *)src, n, keys, out2, also_zero, zb.zs);
-    HIP_TRY(hipGetLastError());
-    return 0;
-}
-
-// ---------------------------------------------------------------------------------------------
-// pre-processing pass 1: normalise -> rgb2lab -> z-axis blur tap (depth 1) -> planar fp64
-// ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ double zblur_point(double v, const Taps &tz)
-{
-    // scipy correlate1d on a length-1 axis with 'reflect': every neighbour equals v
-    if (tz.r < 0) return v;
-    double tmp = v * tz.w[0];
-    for (int j = tz.r; j >= 1; --j) tmp += (v + v) * tz.w[j];
-    return tmp;
-}
-
-// the same sum with the tap loop unrolled over the largest radius the fused kernel takes: the taps (kernel arguments) become scalar
-// registers loaded once, instead of one scalar load -- and one wait for it -- per tap, channel and pixel
-template <int MAXR>
-__device__ __forceinline__ double zblur_point_unrolled(double v, const Taps &tz)
-{
-    if (tz.r < 0) return v;
-    double tmp = v * tz.w[0];
-    const double vv = v + v;
-#pragma unroll
-    for (int j = MAXR; j >= 1; --j)
-        if (j <= tz.r) tmp += vv * tz.w[j];
-    return tmp;
-}
-
-// uint8 input: the sRGB linearisation collapses to a 256-entry table (built per block in LDS with
-// the same det_pow24 as the per-pixel path).  minmax = {vmin, vmax} on device.
-__global__ void __launch_bounds__(256)
-k_pre_lab_u8(const uint8_t *__restrict__ img, int n, int normalize, const double *__restrict__ minmax,
-             Taps tz, double *__restrict__ out)
-{
-    __shared__ double lut[256];
-    {
-        int v = threadIdx.x;
-        double x;
-        const bool norm = normalize == 1 || (normalize == 2 && (minmax[0] != 0.0 || minmax[1] != 1.0));
-        if (norm) {
-            double vmin = minmax[0], range = minmax[1] - minmax[0];
-            x = (double)(uint8_t)(v - (int)vmin) / range;
-        } else {
-            x = (double)v * (1.0 / 255);
-        }
-        lut[v] = (x > 0.04045) ? det_pow24((x + 0.055) / 1.055) : x / 12.92;
-    }
-    __syncthreads();
-    int p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= n) return;
-    double lin0 = lut[img[3 * (size_t)p + 0]], lin1 = lut[img[3 * (size_t)p + 1]], lin2 = lut[img[3 * (size_t)p + 2]];
-    double X = lin0 * 0.412453 + lin1 * 0.357580 + lin2 * 0.180423;
-    double Y = lin0 * 0.212671 + lin1 * 0.715160 + lin2 * 0.072169;
-    double Z = lin0 * 0.019334 + lin1 * 0.119193 + lin2 * 0.950227;
-    double f[3] = { X / 0.95047, Y / 1.0, Z / 1.08883 };
-#pragma unroll
-    for (int c = 0; c < 3; ++c) {
-        double t = f[c];
-        f[c] = (t > 0.008856) ? det_cbrt(t) : 7.787 * t + 16.0 / 116.0;
-    }
-    double L = (116.0 * f[1]) - 16.0;
-    double A = 500.0 * (f[0] - f[1]);
-    double B = 200.0 * (f[1] - f[2]);
-    out[p] = zblur_point(L, tz);
-    out[(size_t)n + p] = zblur_point(A, tz);
-    out[2 * (size_t)n + p] = zblur_point(B, tz);
-}
-
-template <typename T>
-__global__ void __launch_bounds__(256)
-k_pre_lab_f(const T *__restrict__ img, int n, int normalize, const double *__restrict__ minmax, Taps tz,
-            double *__restrict__ out)
-{
-    int p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= n) return;
-    double rgb[3];
-    const bool norm = normalize == 1 || (normalize == 2 && (minmax[0] != 0.0 || minmax[1] != 1.0));
-#pragma unroll
-    for (int c = 0; c < 3; ++c) {
-        double v = (double)img[3 * (size_t)p + c];
-        if (norm) v = (v - minmax[0]) / (minmax[1] - minmax[0]);
-        rgb[c] = v;
-    }
-    double L, A, B;
-    rgb2lab_px(rgb[0], rgb[1], rgb[2], L, A, B);
-    out[p] = zblur_point(L, tz);
-    out[(size_t)n + p] = zblur_point(A, tz);
-    out[2 * (size_t)n + p] = zblur_point(B, tz);
-}
-
-// block maximum of a non-negative double -> one atomicMax on its bit pattern (non-negative doubles order like
-// unsigned integers); `out` must have been zeroed
-__device__ __forceinline__ void block_absmax_to(double v, double *out)
-{
-    __shared__ unsigned long long wave_max[16];
-    unsigned long long b = (unsigned long long)__double_as_longlong(v);
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        unsigned long long o = __shfl_xor(b, off, 64);
-        b = o > b ? o : b;
-    }
-    const int wave = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
-    if ((threadIdx.x & 63) == 0) wave_max[wave] = b;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        for (int i = 1; i < nw; ++i) b = wave_max[i] > b ? wave_max[i] : b;
-        if (b) atomicMax(reinterpret_cast<unsigned long long *>(out), b);
-    }
-}
-
-__global__ void __launch_bounds__(256) k_absmax_f64(const double *__restrict__ src, size_t n, double *out)
-{
-    double m = 0.0;
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) m = fmax(m, fabs(src[i]));
-    block_absmax_to(m, out);
-}
-
-int launch_absmax_f64(const double *src, size_t n, double *out_dev, hipStream_t st)
-{
-    HIP_TRY(hipMemsetAsync(out_dev, 0, sizeof(double), st));
-    int grid = (int)std::min<size_t>(2048, (n + 256 * 8 - 1) / (256 * 8));
-    hipLaunchKernelGGL(k_absmax_f64, grid < 1 ? 1 : grid, 256, 0, st, src, n, out_dev);
-    HIP_TRY(hipGetLastError());
-    return 0;
-}
-
-__device__ __forceinline__ int reflect_idx(int i, int n)
-{
-    if ((unsigned)i < (unsigned)n) return i;       // (inside: all but the pixels of the border tiles; the modulo below is ~30 instructions)
-    if (n == 1) return 0;
-    int p = 2 * n;
-    i %= p;
-    if (i < 0) i += p;
-    if (i >= n) i = p - 1 - i;
-    return i;
-}
-
-// pass 2 / 3: one scipy correlate1d pass along y (axis = 0) or x (axis = 1) of each [H][W] plane;
-// the x pass also applies the final `image * (1 / compactness)`.
-template <int AXIS>
-__global__ void __launch_bounds__(256)
-k_blur_axis(const double *__restrict__ src, double *__restrict__ dst, int H, int W, Taps t, double ratio, int scale)
-{
-    int x = blockIdx.x * 64 + (threadIdx.x & 63);
-    int y = blockIdx.y * 4 + (threadIdx.x >> 6);
-    int plane = blockIdx.z;
-    if (x >= W || y >= H) return;
-    const double *s = src + (size_t)plane * H * W;
-    double v;
-    if (t.r < 0) {
-        v = s[(size_t)y * W + x];
-    } else {
-        v = s[(size_t)y * W + x] * t.w[0];
-        for (int j = t.r; j >= 1; --j) {
-            double a, b;
-            if (AXIS == 0) {
-                a = s[(size_t)reflect_idx(y - j, H) * W + x];
-                b = s[(size_t)reflect_idx(y + j, H) * W + x];
-            } else {
-                a = s[(size_t)y * W + reflect_idx(x - j, W)];
-                b = s[(size_t)y * W + reflect_idx(x + j, W)];
-            }
-            v += (a + b) * t.w[j];
-        }
-    }
-    if (scale) v = v * ratio;
-    dst[(size_t)plane * H * W + (size_t)y * W + x] = v;
-}
-
-// ---------------------------------------------------------------------------------------------
-// fused pre-processing: the three passes above in one kernel (same operations in the same order, so the
-// planes are bit-identical), 27 B/px of HBM traffic instead of 96.  A workgroup produces a 64 x 16 tile:
-// Lab (+ z tap) of the tile and its blur halo goes to LDS (the halo is converted redundantly, x1.7), the y
-// pass runs LDS -> LDS one channel at a time, the x pass LDS -> HBM with the final 1/compactness.
-// ---------------------------------------------------------------------------------------------
-// (tile geometry overridable at compile time for A/B builds -- tools/variants_k.sh; e.g. -DSLIC_PF_TX=32 -DSLIC_PF_TY=32 converts
-// 40 x 40 pixels per 32 x 32 outputs, x1.56 instead of x1.69, in 48 KB of LDS: 125.8 against 129.0 us)
-#ifndef SLIC_PF_TX
-#define SLIC_PF_TX 64
-#endif
-#ifndef SLIC_PF_TY
-#define SLIC_PF_TY 16
-#endif
-constexpr int PF_TX = SLIC_PF_TX, PF_TY = SLIC_PF_TY, PF_MAXR = 8, PF_THREADS = 512;
-static_assert(PF_THREADS % PF_TX == 0 && PF_TY % (PF_THREADS / PF_TX) == 0, "x pass: whole rows per pass");
-
-template <typename T>
-__global__ void __launch_bounds__(PF_THREADS)
-k_pre_fused(const T *__restrict__ img, int H, int W, int normalize, const double *__restrict__ minmax, Taps tz, Taps ty,
-            Taps tx, double ratio, double *__restrict__ out, double *premax, size_t zs)
-{
-    ZSHIFT(img, zs); ZSHIFT(minmax, zs); ZSHIFT(out, zs); ZSHIFT(premax, zs);
-    double vmax = 0.0;                                    // max |value written| by this thread
-    extern __shared__ double pf_sm[];
-    __shared__ double lut[256];
-    const int tid = threadIdx.x;
-    const int ry = ty.r < 0 ? 0 : ty.r, rx = tx.r < 0 ? 0 : tx.r;
-    const int tw = PF_TX + 2 * rx, th = PF_TY + 2 * ry;
-    const unsigned int tw_magic = (unsigned int)((0x100000000ull + tw - 1) / tw);     // exact i / tw for i < 2^16
-    double *L1 = pf_sm;                                   // [3][th][tw]  Lab + z tap
-    double *L2 = pf_sm + (size_t)3 * th * tw;             // [PF_TY][tw]  y-blurred, one channel at a time
-    const bool norm = normalize == 1 || (normalize == 2 && (minmax[0] != 0.0 || minmax[1] != 1.0));
-    if (sizeof(T) == 1) {
-        // uint8 input: the sRGB linearisation collapses to a 256-entry table
-        if (tid < 256) {
-            const int v = tid;
-            double x;
-            if (norm) {
-                double vmin = minmax[0], range = minmax[1] - minmax[0];
-                x = (double)(uint8_t)(v - (int)vmin) / range;
-            } else {
-                x = (double)v * (1.0 / 255);
-            }
-            lut[v] = (x > 0.04045) ? det_pow24((x + 0.055) / 1.055) : x / 12.92;
-        }
-        __syncthreads();
-    }
-    const int x0 = blockIdx.x * PF_TX, y0 = blockIdx.y * PF_TY;
-    const size_t plane = (size_t)H * W;
-    for (int i = tid; i < th * tw; i += PF_THREADS) {
-        const int ly = (int)__umulhi((unsigned int)i, tw_magic), lx = i - ly * tw;
-        const int gy = reflect_idx(y0 + ly - ry, H), gx = reflect_idx(x0 + lx - rx, W);
-        const size_t p = (size_t)gy * W + gx;
-        double L, A, B;
-        if (sizeof(T) == 1) {
-            double lin0 = lut[(int)img[3 * p + 0]], lin1 = lut[(int)img[3 * p + 1]], lin2 = lut[(int)img[3 * p + 2]];
-            double X = lin0 * 0.412453 + lin1 * 0.357580 + lin2 * 0.180423;
-            double Y = lin0 * 0.212671 + lin1 * 0.715160 + lin2 * 0.072169;
-            double Z = lin0 * 0.019334 + lin1 * 0.119193 + lin2 * 0.950227;
-            // (uint8 pixels: X, Z are 0 or >= 5e-5 -- the exact three-instruction quotient; Y / 1.0 = Y)
-            double f[3] = { DIV_CONST_IN_RANGE(X, 0.95047), Y, DIV_CONST_IN_RANGE(Z, 1.08883) };
-#pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                double t = f[c];
-                f[c] = (t > 0.008856) ? det_cbrt(t) : 7.787 * t + 16.0 / 116.0;
-            }
-            L = (116.0 * f[1]) - 16.0;
-            A = 500.0 * (f[0] - f[1]);
-            B = 200.0 * (f[1] - f[2]);
-        } else {
-            double rgb[3];
-#pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                double v = (double)img[3 * p + c];
-                if (norm) v = (v - minmax[0]) / (minmax[1] - minmax[0]);
-                rgb[c] = v;
-            }
-            rgb2lab_px(rgb[0], rgb[1], rgb[2], L, A, B);
-        }
-        L1[i] = zblur_point_unrolled<PF_MAXR>(L, tz);
-        L1[th * tw + i] = zblur_point_unrolled<PF_MAXR>(A, tz);
-        L1[2 * th * tw + i] = zblur_point_unrolled<PF_MAXR>(B, tz);
-    }
-    __syncthreads();
-    const int ox = tid % PF_TX, oy0 = tid / PF_TX;
-    for (int c = 0; c < 3; ++c) {
-        const double *s1 = L1 + (size_t)c * th * tw;
-        for (int i = tid; i < PF_TY * tw; i += PF_THREADS) {
-            const int oy = (int)__umulhi((unsigned int)i, tw_magic), lx = i - oy * tw;
-            const double *col = s1 + (oy + ry) * tw + lx;
-            double v;
-            if (ty.r < 0) {
-                v = col[0];
-            } else {
-                v = col[0] * ty.w[0];
-                // (unrolled over the largest radius: the taps become scalar registers loaded once)
-#pragma unroll
-                for (int j = PF_MAXR; j >= 1; --j)
-                    if (j <= ty.r) v += (col[-j * tw] + col[j * tw]) * ty.w[j];
-            }
-            L2[i] = v;
-        }
-        __syncthreads();
-#pragma unroll
-        for (int q = 0; q < PF_TY / (PF_THREADS / PF_TX); ++q) {
-            const int oy = oy0 + (PF_THREADS / PF_TX) * q;
-            const double *row = L2 + oy * tw + ox + rx;
-            double v;
-            if (tx.r < 0) {
-                v = row[0];
-            } else {
-                v = row[0] * tx.w[0];
-#pragma unroll
-                for (int j = PF_MAXR; j >= 1; --j)
-                    if (j <= tx.r) v += (row[-j] + row[j]) * tx.w[j];
-            }
-            v = v * ratio;
-            const int gy = y0 + oy, gx = x0 + ox;
-            if (gy < H && gx < W) {
-                out[(size_t)c * plane + (size_t)gy * W + gx] = v;
-                vmax = fmax(vmax, fabs(v));
-            }
-        }
-        __syncthreads();
-    }
-    block_absmax_to(vmax, premax);
-}
-
-int launch_preprocess_color2d(const void *img, int dtype, int H, int W, int normalize, const double *minmax_dev,
-                              const Taps &tz, const Taps &ty, const Taps &tx, double ratio, double *bufA,
-                              double *bufB, double *premax_dev, hipStream_t st, bool premax_zeroed, ZBatch zb)
-{
-    int n = H * W;
-    int grid = cdiv(n, 256);
-    if (tz.r <= PF_MAXR && ty.r <= PF_MAXR && tx.r <= PF_MAXR && !knobs().pre_3pass) {
-        const int ry = ty.r < 0 ? 0 : ty.r, rx = tx.r < 0 ? 0 : tx.r;
-        const size_t lds = ((size_t)3 * (PF_TY + 2 * ry) + PF_TY) * (PF_TX + 2 * rx) * sizeof(double);
-        const void *fn = dtype == DT_U8 ? (const void *)k_pre_fused<uint8_t>
-                       : dtype == DT_F32 ? (const void *)k_pre_fused<float> : (const void *)k_pre_fused<double>;
-        // the opt-in above 48 KB is per device: remembered per (device, dtype); (benign race: the attribute only ever grows)
-        static size_t lds_set[IMSEGM_MAX_DEVICES][3];
-        int dev = 0;
-        HIP_TRY(hipGetDevice(&dev));
-        if (dev < 0 || dev >= IMSEGM_MAX_DEVICES || lds_set[dev][dtype] < lds) {
-            HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            if (dev >= 0 && dev < IMSEGM_MAX_DEVICES) lds_set[dev][dtype] = lds;
-        }
-        dim3 gf(cdiv(W, PF_TX), cdiv(H, PF_TY), zb.nz);
-        if (!premax_zeroed) {
-            if (zb.nz > 1) {
-                set_error("preprocess: a batch needs its premax words zeroed by the caller");
-                return -1;
-            }
-            HIP_TRY(hipMemsetAsync(premax_dev, 0, sizeof(double), st));
-        }
-        if (dtype == DT_U8)
-            hipLaunchKernelGGL(k_pre_fused<uint8_t>, gf, PF_THREADS, lds, st, (const uint8_t *)img, H, W, normalize, minmax_dev, tz, ty, tx,
-                               ratio, bufA, premax_dev, zb.zs);
-        else if (dtype == DT_F32)
-            hipLaunchKernelGGL(k_pre_fused<float>, gf, PF_THREADS, lds, st, (const float *)img, H, W, normalize, minmax_dev, tz, ty, tx,
-                               ratio, bufA, premax_dev, zb.zs);
-        else
-            hipLaunchKernelGGL(k_pre_fused<double>, gf, PF_THREADS, lds, st, (const double *)img, H, W, normalize, minmax_dev, tz, ty, tx,
-                               ratio, bufA, premax_dev, zb.zs);
-        HIP_TRY(hipGetLastError());
-        return 0;   // result in bufA
-    }
-    if (zb.nz > 1) {
-        set_error("preprocess: the three-pass path (blur radius > 8) does not take a batch");
-        return -1;
-    }
-    if (dtype == DT_U8)
-        hipLaunchKernelGGL(k_pre_lab_u8, grid, 256, 0, st, (const uint8_t *)img, n, normalize, minmax_dev, tz, bufA);
-    else if (dtype == DT_F32)
-        hipLaunchKernelGGL(k_pre_lab_f<float>, grid, 256, 0, st, (const float *)img, n, normalize, minmax_dev, tz, bufA);
-    else
-        hipLaunchKernelGGL(k_pre_lab_f<double>, grid, 256, 0, st, (const double *)img, n, normalize, minmax_dev, tz, bufA);
-    dim3 g(cdiv(W, 64), cdiv(H, 4), 3);
-    hipLaunchKernelGGL(k_blur_axis<0>, g, 256, 0, st, bufA, bufB, H, W, ty, ratio, 0);
-    hipLaunchKernelGGL(k_blur_axis<1>, g, 256, 0, st, bufB, bufA, H, W, tx, ratio, 1);
-    HIP_TRY(hipGetLastError());
-    return launch_absmax_f64(bufA, (size_t)3 * n, premax_dev, st);   // result in bufA
-}
-
-// ---------------------------------------------------------------------------------------------
 // centroid table
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ int4 search_window(double cy, double cx, int step_y, int step_x, int H, int W)
@@ -1701,607 +1212,16 @@ k_slic_assign_dot(SlicState s, const double *__restrict__ lab, int32_t *__restri
 }
 
 // ---------------------------------------------------------------------------------------------
-// every sweep after the first in ONE persistent launch
+// the launches of the sweeps
 // ---------------------------------------------------------------------------------------------
-// The sums of a centroid only depend on the pixels inside its own search window, so sweep s + 1 of a tile only depends on
-// the tiles of sweep s near it.  Work items (sweep, 64 x 32 tile) are handed out in sweep-major raster order from one atomic
-// counter to a grid of resident workgroups; every dependency of an item has a smaller number, i.e. it was handed out
-// earlier to a workgroup that is running or done -- no deadlock, whatever the residency.
-//
-// Which tiles does (s + 1, t) depend on?  A pixel that sweep s gives to centroid k lies in k's window of sweep s, i.e. within
-// R = 2 * step + 1 of c_s[k]; the new centre c_{s+1}[k] is the mean of such pixels, so it lies in that window too; and k can
-// only be a candidate of t in sweep s + 1 if t is within R of c_{s+1}[k].  Hence all pixels that decide a candidate of
-// (s + 1, t) lie within 3 R of t: the tile rows within `wait_rows` of t's row must be complete in sweep s (a counter per row
-// and sweep: rows finish in raster order anyway), and nothing is assumed about how far centroids wander from the grid.
-//
-// Per item:
-//   1. wave 0 waits for those rows, then reads the tile's candidate list of this sweep -- written by the centroids themselves,
-//      see 3 -- and builds the sorted records (what k_slic_bin does) straight into LDS: they never touch global memory;
-//      the other waves already have their pixel loads in flight;
-//   2. both 64 x 16 halves are assigned (the loop of k_slic_assign_dot) and accumulated into ONE set of LDS slots;
-//   3. the slots are flushed into the sums of this sweep (returning atomics: complete once the wave has waited for them),
-//      then every candidate's arrival counter is incremented; the tile that makes a counter reach the number of tiles the
-//      centroid's window meets has seen all of its pixels: that lane divides the sums (what k_centroid_finalize does), writes
-//      the record of sweep + 1 (one 128-byte line per record, written once, never rewritten) and the wave appends the centroid
-//      to the list of every tile its NEW window meets; after all that the tile counts itself into its row's counter.
-// All cross-workgroup words are agent-scope accesses (sc1 / atomics; payload stores are waited for before the counter that
-// publishes them): the per-XCD L2s are not coherent with each other, and no line is read before its final content is there.
-// What the launch cannot take raises the failure flag and the host redoes the image with the per-sweep launches: more than
-// SLIC_MAXC candidates in a tile, a pixel that no window covers, a wait that does not end.  The fixed-point sums are order
-// independent and the records of a list are sorted by (lower bound, distance, centroid index), so the label map is
-// bit-identical to the per-sweep launches and does not depend on the order in which workgroups run.
-#define RLX_AGENT __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
-__device__ __forceinline__ double ld_f64_agent(const double *p)
-{
-    return __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<unsigned long long *>(const_cast<double *>(p)), RLX_AGENT));
-}
-__device__ __forceinline__ void st_f64_agent(double *p, double v)
-{
-    __hip_atomic_store(reinterpret_cast<unsigned long long *>(p), (unsigned long long)__double_as_longlong(v), RLX_AGENT);
-}
-__device__ __forceinline__ int4 ld_win_agent(const CenRec *r)
-{
-    unsigned long long *q = reinterpret_cast<unsigned long long *>(const_cast<int4 *>(&r->win));
-    const unsigned long long a = __hip_atomic_load(q, RLX_AGENT), b = __hip_atomic_load(q + 1, RLX_AGENT);
-    return make_int4((int)(unsigned)(a & 0xffffffffu), (int)(unsigned)(a >> 32), (int)(unsigned)(b & 0xffffffffu), (int)(unsigned)(b >> 32));
-}
-__device__ __forceinline__ void st_win_agent(CenRec *r, int4 w)
-{
-    unsigned long long *q = reinterpret_cast<unsigned long long *>(&r->win);
-    __hip_atomic_store(q, (unsigned long long)(unsigned)w.x | ((unsigned long long)(unsigned)w.y << 32), RLX_AGENT);
-    __hip_atomic_store(q + 1, (unsigned long long)(unsigned)w.z | ((unsigned long long)(unsigned)w.w << 32), RLX_AGENT);
-}
-// a wave-uniform value held in vector registers (LDS / VALU result) moved to scalar registers
-__device__ __forceinline__ double uniform_f64(double v)
-{
-    const long long b = __double_as_longlong(v);
-    const int lo = __builtin_amdgcn_readfirstlane((int)b), hi = __builtin_amdgcn_readfirstlane((int)(b >> 32));
-    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
-}
-__device__ __forceinline__ float uniform_f32(float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); }
-#ifndef SLIC_SWEEP_QUEUES
-#define SLIC_SWEEP_QUEUES 8
-#endif
-constexpr int SWEEP_QUEUES = SLIC_SWEEP_QUEUES;            // item counters, one cache line each: item i is handed out by queue i % 8
-constexpr int SWEEP_POISON = 0x40000000;                   // written over the counters by a failure: every later fetch ends its workgroup
-__device__ __forceinline__ void sweep_fail(const SweepWork &w, int code)
-{
-    __hip_atomic_store(w.fail, code, RLX_AGENT);
-    for (int q = 0; q < SWEEP_QUEUES; ++q) __hip_atomic_store(w.ctl + q * 32, SWEEP_POISON, RLX_AGENT);
-    *reinterpret_cast<volatile int *>(w.fail_host) = code;
-}
-
-struct SweepLds {
-    long long lacc[MAXC][9];
-    Cand cand[MAXC];
-    Rec32 rec[MAXC];
-    int k[MAXC];
-    float ckey[MAXC], clb[MAXC];
-    TileInfo info;
-    int item;
-};
-constexpr unsigned SWEEP_SPIN_LIMIT = 1u << 20;       // polls of one wait (~1 s): a logic error must not hang the device
-
-// tiles a search window meets: {first tile row, first tile column, rows, columns}
-__device__ __forceinline__ int4 window_tiles(int4 w)
-{
-    const int ry0 = w.x / TILE_Y, rx0 = w.z / TILE_X;
-    return make_int4(ry0, rx0, (w.y - 1) / TILE_Y - ry0 + 1, (w.w - 1) / TILE_X - rx0 + 1);
-}
-
-// append centroid k to the candidate list of every tile its window (of sweep `sweep`) meets; by a whole wave (uniform arguments)
-__device__ __forceinline__ void sweep_scatter(const SweepWork &w, int sweep, int k, int4 win, int lane)
-{
-    const int4 tl = window_tiles(win);
-    const int nt = tl.z * tl.w;
-    for (int j0 = 0; j0 < nt; j0 += 64) {
-        const int j = j0 + lane;
-        if (j < nt) {
-            const int jy = j / tl.w;
-            const size_t t = (size_t)sweep * w.n_tiles + (size_t)(tl.x + jy) * w.tiles_x + tl.y + (j - jy * tl.w);
-            const int pos = __hip_atomic_fetch_add(w.ccount + t, 1, RLX_AGENT);
-            if (pos < MAXC) __hip_atomic_store(w.clist + t * MAXC + pos, k, RLX_AGENT);
-            else sweep_fail(w, 1);
-        }
-    }
-}
-
-// sorted candidate records of one tile for sweep `sweep`, by ONE wave, into LDS (k_slic_bin on the list the centroids have
-// written); returns the list length, or < 0 after raising the failure flag
-template <bool PROF>
-__device__ __forceinline__ int sweep_bin_tile(const SlicState &s, const SweepWork &w, int sweep, int tile, int tile_row, int tx0,
-                                              int ty0, SweepLds &L, int lane, long long &t_mark, long long (&t_sum)[12])
-{
-#define BIN_MARK(j)                                                                                \
-    if (PROF && lane == 0) {                                                                     \
-        const long long now_ = (long long)wall_clock64();                                          \
-        t_sum[j] += now_ - t_mark;                                                                 \
-        t_mark = now_;                                                                             \
-    }
-    if (sweep > w.sweep_begin) {
-        // the tile rows within reach are through with the previous sweep: ONE word, pushed by the tiles that complete a row
-        const int need = min(tile_row + w.wait_rows, w.tile_rows - 1) - max(tile_row - w.wait_rows, 0) + 1;
-        const int *word = w.rowdone + ((size_t)sweep * w.tile_rows + tile_row) * SWEEP_ROW_STRIDE + 1;
-        for (unsigned spins = 0;; ++spins) {
-            if (__builtin_amdgcn_readfirstlane(__hip_atomic_load(word, RLX_AGENT)) >= need) break;
-            if ((spins & 15) == 15) {
-                if (__builtin_amdgcn_readfirstlane(__hip_atomic_load(w.fail, RLX_AGENT))) return -1;
-                if (spins > SWEEP_SPIN_LIMIT) {
-                    if (lane == 0) sweep_fail(w, 4);
-                    return -1;
-                }
-            }
-            if (spins < 8) __builtin_amdgcn_s_sleep(8);           // ~0.2 us, then ~0.9 us between polls
-            else __builtin_amdgcn_s_sleep(32);
-        }
-        asm volatile("" ::: "memory");
-    }
-    BIN_MARK(9)                              // rows of the previous sweep
-    const size_t t = (size_t)sweep * w.n_tiles + tile;
-    const int count = __builtin_amdgcn_readfirstlane(__hip_atomic_load(w.ccount + t, RLX_AGENT));
-    if (count > MAXC) {                      // (the centroid that found the list full has raised the flag already)
-        if (lane == 0) sweep_fail(w, 1);
-        return -1;
-    }
-    if (count == 0) return 0;
-    const bool have = lane < count;
-    // (lanes beyond the list read the first candidate's record: a record that is not published must never be touched)
-    const int k = __hip_atomic_load(w.clist + t * MAXC + (have ? lane : 0), RLX_AGENT);
-    const CenRec *r = w.cen + (size_t)sweep * s.K + k;
-    Cand cd;
-    cd.cy = ld_f64_agent(&r->cy); cd.cx = ld_f64_agent(&r->cx);
-    cd.cL = ld_f64_agent(&r->cL); cd.ca = ld_f64_agent(&r->ca); cd.cb = ld_f64_agent(&r->cb);
-    cd.win = ld_win_agent(r);
-    cd.k = k;
-    if (PROF) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    BIN_MARK(10)                             // list + records loaded
-    const int tx1 = min(tx0 + TILE_X, s.W), ty1 = min(ty0 + TILE_Y, s.H);
-    // heuristic sort key: squared distance of the window centre to the tile centre
-    const float my = 0.5f * (float)(cd.win.x + cd.win.y) - 0.5f * (float)(ty0 + ty1);
-    const float mx = 0.5f * (float)(cd.win.z + cd.win.w) - 0.5f * (float)(tx0 + tx1);
-    const float key2 = my * my + mx * mx;
-    const double sw = s.spatial_weight;
-    const double ryc = cd.cy - (double)(ty0 + 16), rxc = cd.cx - (double)(tx0 + 32);
-    const double dy = fmax(fmax(-16.0 - ryc, ryc - 15.0), 0.0), dx = fmax(fmax(-32.0 - rxc, rxc - 31.0), 0.0);
-    const float lbt = __double2float_rd((dy * dy + dx * dx) * sw * 0.999999);
-    if (have) {
-        L.clb[lane] = lbt;
-        L.ckey[lane] = key2;
-        L.k[lane] = k;                       // (list order; overwritten with the sorted order below)
-    }
-    __builtin_amdgcn_s_waitcnt(0);
-    __builtin_amdgcn_wave_barrier();
-    // rank by (lower bound of the distance over the tile, distance of the window centre, centroid index): a total order, so
-    // the records do not depend on the order in which the centroids appended themselves
-    int rank = 0;
-    for (int j = 0; j < count; ++j) {
-        const float kj = L.clb[j], k2j = L.ckey[j];
-        const int kk = L.k[j];
-        rank += (kj < lbt) || (kj == lbt && (k2j < key2 || (k2j == key2 && kk < k)));
-    }
-    __builtin_amdgcn_s_waitcnt(0);
-    __builtin_amdgcn_wave_barrier();
-    // reference colour of the tile: the colour of the first candidate (exact)
-    const unsigned long long first = __ballot(have && rank == 0);
-    const int src = first ? __ffsll((long long)first) - 1 : 0;
-    const double ref0 = __shfl(cd.cL, src, 64), ref1 = __shfl(cd.ca, src, 64), ref2 = __shfl(cd.cb, src, 64);
-    const double c0 = cd.cL - ref0, c1 = cd.ca - ref1, c2 = cd.cb - ref2;
-    Rec32 rc;
-    rc.q0 = (float)(sw * (ryc * ryc + rxc * rxc) + (c0 * c0 + c1 * c1 + c2 * c2));
-    rc.qy = (float)(-2.0 * sw * ryc);
-    rc.qx = (float)(-2.0 * sw * rxc);
-    rc.qL = (float)(-2.0 * c0);
-    rc.qa = (float)(-2.0 * c1);
-    rc.qb = (float)(-2.0 * c2);
-    rc.lbt = lbt;
-    {
-        const int rlo = min(max(cd.win.x - ty0, 0), TILE_Y), rhi = min(max(cd.win.y - ty0, 0), TILE_Y);
-        const int xlo = min(max(cd.win.z - tx0, 0), TILE_X), xhi = min(max(cd.win.w - tx0, 0), TILE_X);
-        rc.meta = (uint32_t)rlo | ((uint32_t)rhi << 8) | ((uint32_t)xlo << 16) | ((uint32_t)xhi << 24);
-    }
-    cd.ry = (float)(cd.cy - (double)ty0);
-    cd.rx = (float)(cd.cx - (double)tx0);
-    cd.fL = (float)cd.cL; cd.fa = (float)cd.ca; cd.fb = (float)cd.cb;
-    cd.mdc = 1.0;
-    if (have) {
-        L.cand[rank] = cd;
-        L.rec[rank] = rc;
-        L.k[rank] = k;
-    }
-    float qm[5] = { have ? fabsf(rc.qy) : 0.f, have ? fabsf(rc.qx) : 0.f, have ? fabsf(rc.qL) : 0.f,
-                    have ? fabsf(rc.qa) : 0.f, have ? fabsf(rc.qb) : 0.f };
-#pragma unroll
-    for (int j = 0; j < 5; ++j)
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) qm[j] = fmaxf(qm[j], __shfl_xor(qm[j], off, 64));
-    if (lane == 0) {
-        L.info.ref[0] = ref0; L.info.ref[1] = ref1; L.info.ref[2] = ref2;
-        L.info.Qy = qm[0]; L.info.Qx = qm[1]; L.info.QL = qm[2]; L.info.Qa = qm[3]; L.info.Qb = qm[4];
-    }
-    BIN_MARK(11)                             // records sorted and written
-#undef BIN_MARK
-    return count;
-}
-
-// what k_centroid_finalize does, for ONE centroid whose sums of `sweep` are complete: writes the record of sweep + 1 and
-// returns its search window (empty: no pixel carries the label any more -- dead from now on, it joins no list again)
-__device__ __forceinline__ int4 sweep_finalize_centroid(const SlicState &s, const SweepWork &w, int sweep, int k)
-{
-    unsigned long long *a = reinterpret_cast<unsigned long long *>(w.acc + ((size_t)sweep * s.K + k) * 9);
-    long long v[9];
-#pragma unroll
-    for (int j = 0; j < 9; ++j) v[j] = (long long)__hip_atomic_load(a + j, RLX_AGENT);
-    if (v[0] == 0) return make_int4(0, 0, 0, 0);
-    const double nn = (double)v[0];
-    const double cy = i64_to_double(v[1]) / nn, cx = i64_to_double(v[2]) / nn;
-    const double finv = ldexp(1.0, -fix_bits_of(*s.premax));
-    CenRec *out = w.cen + (size_t)(sweep + 1) * s.K + k;
-    const int4 win = search_window(cy, cx, s.step_y, s.step_x, s.H, s.W);
-    st_f64_agent(&out->cy, cy);
-    st_f64_agent(&out->cx, cx);
-    st_f64_agent(&out->cL, fix_value(v[3], v[4], finv) / nn);
-    st_f64_agent(&out->ca, fix_value(v[5], v[6], finv) / nn);
-    st_f64_agent(&out->cb, fix_value(v[7], v[8], finv) / nn);
-    st_win_agent(out, win);
-    return win;
-}
-
-// records and candidate lists of the first persistent sweep from the SoA table k_centroid_finalize left after sweep 0; the
-// words the launch polls (ctl) -- the counters are zeroed by a memset in front
-__global__ void k_sweeps_init(SlicState s, SweepWork w)
-{
-    const int k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= s.K) return;
-    const int4 win = s.win[k];
-    if (win.y <= win.x || win.w <= win.z) return;             // dead after the first sweep
-    CenRec *out = w.cen + (size_t)w.sweep_begin * s.K + k;
-    out->cy = s.cy[k]; out->cx = s.cx[k]; out->cL = s.cL[k]; out->ca = s.ca[k]; out->cb = s.cb[k];
-    out->win = win;
-    const int4 tl = window_tiles(win);
-    for (int jy = 0; jy < tl.z; ++jy)
-        for (int jx = 0; jx < tl.w; ++jx) {
-            const size_t t = (size_t)w.sweep_begin * w.n_tiles + (size_t)(tl.x + jy) * w.tiles_x + tl.y + jx;
-            const int pos = atomicAdd(w.ccount + t, 1);
-            if (pos < MAXC) w.clist[t * MAXC + pos] = k;
-        }
-}
-
-#ifndef SLIC_SWEEPS_MIN_BLOCKS
-#define SLIC_SWEEPS_MIN_BLOCKS 4
-#endif
-// PROF: the instantiation with the phase timers (IMSEGM_DEBUG_SWEEPS); the production kernel carries none of it
-template <bool PROF>
-__global__ void __launch_bounds__(256, SLIC_SWEEPS_MIN_BLOCKS)
-k_slic_sweeps(SlicState s, const double *__restrict__ lab, int32_t *__restrict__ labels, SweepWork w)
-{
-    __shared__ SweepLds L;
-    const size_t plane = (size_t)s.H * s.W;
-    const double sw = s.spatial_weight;
-    const int total_items = (w.sweep_end - w.sweep_begin) * w.n_tiles;
-    const double fscale = uniform_f64(ldexp(1.0, fix_bits_of(*s.premax)));
-    if (w.force_fail && blockIdx.x == 0 && threadIdx.x == 0) sweep_fail(w, 9);
-    if (w.sweep_begin > 1 && __builtin_amdgcn_readfirstlane(__hip_atomic_load(w.fail, RLX_AGENT))) return;     // an earlier launch gave the image back
-    int queue = blockIdx.x & (SWEEP_QUEUES - 1);           // (thread 0's; workgroup b is observed on XCD b % 8)
-    // (IMSEGM_DEBUG_SWEEPS) phase times of thread 0 summed in registers, one set of atomics per workgroup at the very end
-    long long t_mark = 0, t_sum[12] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
-#define SWEEP_MARK(j)                                                                              \
-    if (PROF && tid == 0) {                                                                      \
-        const long long now_ = (long long)wall_clock64();                                          \
-        t_sum[j] += now_ - t_mark;                                                                 \
-        t_mark = now_;                                                                             \
-    }
-
-    for (;;) {
-        // (the thread index is made opaque once per item: everything derived from it -- lane constants, LDS addresses -- is
-        // recomputed per item instead of being hoisted out of this loop into registers that live through the whole kernel)
-        int tid = threadIdx.x;
-        asm volatile("" : "+v"(tid));
-        const int lane = tid & 63;
-        const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-        __syncthreads();                                   // the LDS of the previous item is free
-        if (PROF && tid == 0) t_mark = (long long)wall_clock64();
-        if (tid == 0) {
-            // own queue first; a workgroup whose queue has run dry takes from the others (the tail of the launch)
-            int it = 0x7fffffff;
-            for (int tries = 0; tries < SWEEP_QUEUES; ++tries) {
-                const int j = __hip_atomic_fetch_add(w.ctl + queue * 32, 1, RLX_AGENT);
-                if (j >= SWEEP_POISON) break;
-                const long cand_item = (long)j * SWEEP_QUEUES + queue;
-                if (cand_item < total_items) {
-                    it = (int)cand_item;
-                    break;
-                }
-                queue = (queue + 1) & (SWEEP_QUEUES - 1);
-            }
-            L.item = it;
-        }
-        __syncthreads();
-        const int item = __builtin_amdgcn_readfirstlane(L.item);
-        if (item >= total_items) break;                    // (all queues dry, or a failure has poisoned them)
-        const int sweep = w.sweep_begin + item / w.n_tiles;
-        const int tile = item - (sweep - w.sweep_begin) * w.n_tiles;
-        const int tile_row = tile / w.tiles_x;
-        const int tx0 = (tile - tile_row * w.tiles_x) * TILE_X, ty0 = tile_row * TILE_Y;
-        const bool accum = sweep + 1 < w.sweep_last;
-        const int x = tx0 + lane;
-        const bool xin = x < s.W;
-
-        // pixels of the upper half first: their latency covers the wait and the candidate list
-        double pL[ROWS], pA[ROWS], pB[ROWS];
-        auto load_rows = [&](int wy) {
-#pragma unroll
-            for (int r = 0; r < ROWS; ++r) {
-                const int y = wy + r;
-                const bool ok = xin && y < s.H;
-                const size_t p = (size_t)(ok ? y : 0) * s.W + (ok ? x : 0);
-                pL[r] = lab[p];
-                pA[r] = lab[plane + p];
-                pB[r] = lab[2 * plane + p];
-            }
-        };
-        for (int i = tid; i < MAXC * 9; i += 256) (&L.lacc[0][0])[i] = 0;
-        SWEEP_MARK(0)                                      // item fetched
-        if (wave == 0) {
-            // (wave 0 takes its pixels after the list: nothing of them lives in its registers meanwhile)
-            const int cnt = sweep_bin_tile<PROF>(s, w, sweep, tile, tile_row, tx0, ty0, L, lane, t_mark, t_sum);
-            if (lane == 0) L.info.count = cnt;
-            load_rows(ty0);
-        } else {
-            load_rows(ty0 + wave * ROWS);
-        }
-        SWEEP_MARK(1)                                      // wait for the rows + candidate records
-        __syncthreads();
-        SWEEP_MARK(2)
-        const int nc = __builtin_amdgcn_readfirstlane(L.info.count);
-        if (nc < 0) break;                                 // failure flag is up
-        // (tile constants: scalar registers, as the scalar loads of k_slic_assign_dot give them)
-        const double ref0 = uniform_f64(L.info.ref[0]), ref1 = uniform_f64(L.info.ref[1]), ref2 = uniform_f64(L.info.ref[2]);
-        const float xb_base = uniform_f32(16.f * L.info.Qy + 32.f * L.info.Qx), tQL = uniform_f32(L.info.QL), tQa = uniform_f32(L.info.Qa),
-                    tQb = uniform_f32(L.info.Qb);
-
-#pragma nounroll
-        for (int half = 0; half < 2; ++half) {
-            const int rel0 = half * WG_Y + wave * ROWS;
-            const int wy0 = ty0 + rel0;
-            if (half == 1) load_rows(wy0);
-            // candidate table in registers: lane c holds the record of candidate c (re-read from LDS for each half, so that it
-            // does not live in registers across the accumulation of the other half)
-            const float4 my_ra = reinterpret_cast<const float4 *>(&L.rec[lane])[0];      // q0, qx, qy, qL
-            const float4 my_rb = reinterpret_cast<const float4 *>(&L.rec[lane])[1];      // qa, qb, lbt, meta
-            int best_s[ROWS];
-#pragma unroll
-            for (int r = 0; r < ROWS; ++r) best_s[r] = -1;
-            if (nc > 0) {
-                constexpr int PH1 = SLIC_PH1, PH2 = SLIC_PH2;
-                const float INF = __builtin_inff();
-                const float sw32 = (float)sw;
-                f2 fL[2], fA[2], fB[2];
-#pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    fL[h] = (f2){ (float)(pL[2 * h] - ref0), (float)(pL[2 * h + 1] - ref0) };
-                    fA[h] = (f2){ (float)(pA[2 * h] - ref1), (float)(pA[2 * h + 1] - ref1) };
-                    fB[h] = (f2){ (float)(pB[2 * h] - ref2), (float)(pB[2 * h + 1] - ref2) };
-                }
-                const float X = (float)(lane - TILE_X / 2);
-                const float Y0 = (float)(rel0 - TILE_Y / 2);
-                const f2 Yp[2] = { (f2){ Y0, Y0 + 1.f }, (f2){ Y0 + 2.f, Y0 + 3.f } };
-                float xb[ROWS];
-#pragma unroll
-                for (int r = 0; r < ROWS; ++r) {
-                    const float l = r & 1 ? fL[r >> 1].y : fL[r >> 1].x, a = r & 1 ? fA[r >> 1].y : fA[r >> 1].x,
-                                b = r & 1 ? fB[r >> 1].y : fB[r >> 1].x;
-                    xb[r] = fmaf(tQL, fabsf(l), fmaf(tQa, fabsf(a), fmaf(tQb, fabsf(b), xb_base)));
-                }
-                float b1[ROWS], b2[ROWS];
-#pragma unroll
-                for (int r = 0; r < ROWS; ++r) b1[r] = b2[r] = INF;
-                const int rows_valid = min(ROWS, s.H - wy0), lanes_valid = min(TILE_X, s.W - tx0);
-                unsigned wbound = 0x7f800000u;
-                int c_end = nc;
-#define RL_F(v) __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), c))
-                for (int c = 0; c < nc; ++c) {
-                    if (c == PH1 || c == PH2) {
-                        float wl = 0.f;
-#pragma unroll
-                        for (int r = 0; r < ROWS; ++r) {
-                            float l = r & 1 ? fL[r >> 1].y : fL[r >> 1].x, a = r & 1 ? fA[r >> 1].y : fA[r >> 1].x,
-                                  b = r & 1 ? fB[r >> 1].y : fB[r >> 1].x, xbr = xb[r], Xv = X;
-                            asm volatile("" : "+v"(l), "+v"(a), "+v"(b), "+v"(xbr), "+v"(Xv));
-                            const float Yr = Y0 + (float)r;
-                            const float P = fmaf(sw32, fmaf(Yr, Yr, Xv * Xv), fmaf(l, l, fmaf(a, a, b * b)));
-                            const float v = fmaf(fmaxf(b1[r] + P, 0.f), 1.002f, 0.002f * (xbr + 1.f));
-                            if (xin && r < rows_valid) wl = fmaxf(wl, v);
-                        }
-                        int wi = __float_as_int(wl);
-                        wi = max(wi, __builtin_amdgcn_update_dpp(0, wi, 0x111, 0xf, 0xf, false));
-                        wi = max(wi, __builtin_amdgcn_update_dpp(0, wi, 0x112, 0xf, 0xf, false));
-                        wi = max(wi, __builtin_amdgcn_update_dpp(0, wi, 0x114, 0xf, 0xf, false));
-                        wi = max(wi, __builtin_amdgcn_update_dpp(0, wi, 0x118, 0xf, 0xf, false));
-                        wi = max(wi, __builtin_amdgcn_update_dpp(0, wi, 0x142, 0xa, 0xf, false));
-                        wi = max(wi, __builtin_amdgcn_update_dpp(0, wi, 0x143, 0xc, 0xf, false));
-                        wbound = (unsigned)__builtin_amdgcn_readlane(wi, 63);
-                    }
-                    if ((unsigned)__builtin_amdgcn_readlane(__float_as_int(my_rb.z), c) > wbound) {
-                        c_end = c;
-                        break;
-                    }
-                    const unsigned meta = (unsigned)__builtin_amdgcn_readlane(__float_as_int(my_rb.w), c);
-                    const int rlo = meta & 0xff, rhi = (meta >> 8) & 0xff, xlo = (meta >> 16) & 0x7f, xhi = meta >> 24;
-                    if (rhi > rel0 && rlo < rel0 + ROWS) {
-                        const float q0 = RL_F(my_ra.x), qx = RL_F(my_ra.y), qy = RL_F(my_ra.z), qL = RL_F(my_ra.w);
-                        const float qa = RL_F(my_rb.x), qb = RL_F(my_rb.y);
-                        const float e = fmaf(qx, X, q0);
-#define SLIC_SELECT(r, dval)                                                                       \
-    {                                                                                              \
-        const float d_ = (dval);                                                                   \
-        const bool lt_ = d_ < b1[r];                                                               \
-        b2[r] = __builtin_amdgcn_fmed3f(b1[r], b2[r], d_);                                         \
-        b1[r] = lt_ ? d_ : b1[r];                                                                  \
-        best_s[r] = lt_ ? c : best_s[r];                                                           \
-    }
-                        if (rlo <= rel0 && rhi >= rel0 + rows_valid && xlo == 0 && xhi >= lanes_valid) {
-                            const f2 e2 = (f2){ e, e };
-                            f2 d01 = __builtin_elementwise_fma((f2){ qy, qy }, Yp[0], e2);
-                            f2 d23 = __builtin_elementwise_fma((f2){ qy, qy }, Yp[1], e2);
-                            d01 = __builtin_elementwise_fma((f2){ qL, qL }, fL[0], d01);
-                            d23 = __builtin_elementwise_fma((f2){ qL, qL }, fL[1], d23);
-                            d01 = __builtin_elementwise_fma((f2){ qa, qa }, fA[0], d01);
-                            d23 = __builtin_elementwise_fma((f2){ qa, qa }, fA[1], d23);
-                            d01 = __builtin_elementwise_fma((f2){ qb, qb }, fB[0], d01);
-                            d23 = __builtin_elementwise_fma((f2){ qb, qb }, fB[1], d23);
-                            SLIC_SELECT(0, d01.x) SLIC_SELECT(1, d01.y) SLIC_SELECT(2, d23.x) SLIC_SELECT(3, d23.y)
-                        } else {
-                            const bool inx = lane >= xlo && lane < xhi;
-#pragma unroll
-                            for (int r = 0; r < ROWS; ++r) {
-                                if (rel0 + r < rlo || rel0 + r >= rhi) continue;        // wave-uniform
-                                const float l = r & 1 ? fL[r >> 1].y : fL[r >> 1].x, a = r & 1 ? fA[r >> 1].y : fA[r >> 1].x,
-                                            b = r & 1 ? fB[r >> 1].y : fB[r >> 1].x;
-                                float d = fmaf(qy, Y0 + (float)r, e);
-                                d = fmaf(qL, l, d);
-                                d = fmaf(qa, a, d);
-                                d = fmaf(qb, b, d);
-                                d = inx ? d : INF;
-                                SLIC_SELECT(r, d)
-                            }
-                        }
-#undef SLIC_SELECT
-                    }
-                }
-                // near ties: exact fp64 evaluation over the candidates within the margin of the fp32 best (see k_slic_assign_dot)
-                const float U16 = 16.f * 5.9604644775390625e-8f * 1.01f;
-#pragma unroll
-                for (int r = 0; r < ROWS; ++r) {
-                    const float m = U16 * (b1[r] + b2[r] + 4.f * xb[r]) + 1e-30f;
-                    const bool near2 = best_s[r] >= 0 && b2[r] < INF && !(b2[r] - b1[r] > m);
-                    if (!__any(near2)) continue;
-                    const float l = r & 1 ? fL[r >> 1].y : fL[r >> 1].x, a = r & 1 ? fA[r >> 1].y : fA[r >> 1].x,
-                                b = r & 1 ? fB[r >> 1].y : fB[r >> 1].x;
-                    const float Yr = Y0 + (float)r;
-                    const double fy = (double)(wy0 + r), fx = (double)x;
-                    double bd = DBL_MAX;
-                    int bs = -1, bk = 0x7fffffff;
-                    for (int c = 0; c < c_end; ++c) {
-                        const unsigned meta = (unsigned)__builtin_amdgcn_readlane(__float_as_int(my_rb.w), c);
-                        const int rlo = meta & 0xff, rhi = (meta >> 8) & 0xff, xlo = (meta >> 16) & 0x7f, xhi = meta >> 24;
-                        if (rel0 + r < rlo || rel0 + r >= rhi) continue;
-                        float d = fmaf(RL_F(my_ra.y), X, RL_F(my_ra.x));
-                        d = fmaf(RL_F(my_ra.z), Yr, d);
-                        d = fmaf(RL_F(my_ra.w), l, d);
-                        d = fmaf(RL_F(my_rb.x), a, d);
-                        d = fmaf(RL_F(my_rb.y), b, d);
-                        const bool take = near2 && lane >= xlo && lane < xhi && d - b1[r] <= m;
-                        if (!__any(take)) continue;
-                        const double e = exact_dist(L.cand[c], fy, fx, sw, pL[r], pA[r], pB[r]);
-                        const int k = L.cand[c].k;
-                        if (take && ((bd > e) || (bd == e && k < bk))) {
-                            bd = e;
-                            bs = c;
-                            bk = k;
-                        }
-                    }
-                    if (near2) best_s[r] = bs;
-                }
-#undef RL_F
-            }
-            // labels; a pixel that no window covers would keep its previous label: the per-sweep launches handle that
-            unsigned pending = 0;
-            int win_k[ROWS];
-            bool uncovered = false;
-#pragma unroll
-            for (int r = 0; r < ROWS; ++r) win_k[r] = L.k[best_s[r] & 63];
-#pragma unroll
-            for (int r = 0; r < ROWS; ++r) {
-                const int y = wy0 + r;
-                if (!(xin && y < s.H)) continue;
-                if (best_s[r] >= 0) {
-                    // only the last sweep's labels are ever read; plain stores of two sweeps to one address from different
-                    // XCDs would reach memory in no particular order (each L2 writes back when it pleases)
-                    if (!accum) labels[y * s.W + x] = win_k[r];
-                    pending |= 1u << r;
-                } else {
-                    uncovered = true;
-                }
-            }
-            if (__any(uncovered)) {
-                if (lane == 0) sweep_fail(w, 3);
-            }
-            if (accum) accumulate_block_sums(lane, x, wy0, best_s, pending, pL, pA, pB, fscale, L.lacc);
-        }
-        SWEEP_MARK(3)                                      // both halves assigned and accumulated (wave 0)
-        if (!accum) continue;
-        __syncthreads();
-        SWEEP_MARK(4)
-        // LDS slots -> sums of this sweep
-        {
-            long long *acc = w.acc + (size_t)sweep * s.K * 9;
-            for (int i = tid; i < nc * 9; i += 256) {
-                const int c = i / 9, j = i - 9 * c;
-                const long long v = L.lacc[c][j];
-                if (v == 0 || (j >= 3 && ((j - 3) & 1))) continue;
-                long long *dst = acc + (size_t)L.k[c] * 9 + j;
-                if (j < 3) atomic_add_i64(dst, v);
-                else fix_add_global(dst, v);
-            }
-            // the arrival counters below publish these sums: every wave waits until its atomics are through
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
-        SWEEP_MARK(5)                                      // flush
-        __syncthreads();
-        SWEEP_MARK(6)
-        if (wave == 0) {
-            // arrival counters; the lane that completes a centroid divides its sums; the wave enters it into the lists of sweep + 1
-            bool last = false;
-            const int my_k = L.k[lane];
-            if (lane < nc) {
-                const int4 tl = window_tiles(L.cand[lane].win);
-                const int seen = __hip_atomic_fetch_add(w.done + (size_t)sweep * s.K + my_k, 1, RLX_AGENT) + 1;
-                last = seen == tl.z * tl.w;
-            }
-            int4 nw = make_int4(0, 0, 0, 0);
-            if (last) nw = sweep_finalize_centroid(s, w, sweep, my_k);
-            unsigned long long todo = __ballot(last && nw.y > nw.x);
-            while (todo) {
-                const int b = __ffsll((long long)todo) - 1;
-                todo &= todo - 1;
-                sweep_scatter(w, sweep + 1, __builtin_amdgcn_readlane(my_k, b),
-                              make_int4(__builtin_amdgcn_readlane(nw.x, b), __builtin_amdgcn_readlane(nw.y, b),
-                                        __builtin_amdgcn_readlane(nw.z, b), __builtin_amdgcn_readlane(nw.w, b)), lane);
-            }
-            // everything this tile publishes has arrived; then it counts itself into its row
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            int through = 0;
-            if (lane == 0) through = __hip_atomic_fetch_add(w.rowdone + ((size_t)sweep * w.tile_rows + tile_row) * SWEEP_ROW_STRIDE, 1, RLX_AGENT) + 1;
-            if (__builtin_amdgcn_readfirstlane(through) == w.tiles_x && sweep + 1 < w.sweep_end) {      // (within this launch)
-                // this tile completed its row (every other tile of the row had everything published before it counted itself):
-                // tell the rows of the next sweep that depend on it
-                const int r_lo = max(tile_row - w.wait_rows, 0), r_hi = min(tile_row + w.wait_rows, w.tile_rows - 1);
-                for (int r = r_lo + lane; r <= r_hi; r += 64)
-                    __hip_atomic_fetch_add(w.rowdone + ((size_t)(sweep + 1) * w.tile_rows + r) * SWEEP_ROW_STRIDE + 1, 1, RLX_AGENT);
-            }
-        }
-        SWEEP_MARK(7)                                      // arrivals, centroid updates, list entries
-        if (PROF && tid == 0) t_sum[8] += 1;
-    }
-#undef SWEEP_MARK
-    if (PROF && threadIdx.x == 0)
-        for (int j = 0; j < 12; ++j) atomic_add_i64(w.prof + j, t_sum[j]);
-}
-
-static std::atomic<long> g_sweep_persistent{0}, g_sweep_fallback{0};
-long long *slic_sweep_prof_buffer()
-{
-    static long long *buf = nullptr;
-    static const bool on = getenv("IMSEGM_DEBUG_SWEEPS") != nullptr;
-    if (on && !buf) {
-        if (hipMalloc(&buf, 16 * sizeof(long long)) != hipSuccess) return nullptr;
-        (void)hipMemset(buf, 0, 16 * sizeof(long long));
-    }
-    return buf;
-}
+// (Round 3 built every sweep after the first as ONE persistent launch -- k_slic_sweeps: work items (sweep, tile) pulled from queues
+// by resident workgroups, per-row completion counters, records handed from sweep to sweep through agent-scope loads -- bit-exact
+// and not faster: 514 us against ~480 us + launch boundaries for one image, 1.23 against 0.76 ms per image with three in flight
+// (profiles/bench_r03_persistent_*.json, profiles/HISTORY.md "Round 3").  It stayed opt-in for three rounds and went in round 6.)
+static std::atomic<long> g_sweep_fallback{0};
 void slic_sweep_counters(long *persistent_runs, long *fallback_runs)
 {
-    if (persistent_runs) *persistent_runs = g_sweep_persistent.load();
+    if (persistent_runs) *persistent_runs = 0;         // (the one-launch sweeps of round 3 are gone)
     if (fallback_runs) *fallback_runs = g_sweep_fallback.load();
 }
 void slic_sweep_note_fallback() { g_sweep_fallback.fetch_add(1); }
@@ -2320,33 +1240,16 @@ int slic_prepare_device()
     return 0;
 }
 
-// grid of the persistent kernel: every workgroup the device holds at once (more would only queue behind the resident ones)
-static int sweeps_resident_blocks()
-{
-    static int cached[IMSEGM_MAX_DEVICES];
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess) return 1280;
-    if (dev >= 0 && dev < IMSEGM_MAX_DEVICES && cached[dev]) return cached[dev];
-    int per_cu = 0, cus = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)k_slic_sweeps<false>, 256, 0) != hipSuccess || per_cu < 1) per_cu = 4;
-    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 256;
-    if (knobs().sweeps_blocks_per_cu) per_cu = std::max(1, knobs().sweeps_blocks_per_cu);
-    const int n = per_cu * cus;
-    if (dev >= 0 && dev < IMSEGM_MAX_DEVICES) cached[dev] = n;
-    return n;
-}
-
 int launch_slic_iterations(SlicState s, const double *lab, const double *init_yx_dev, int32_t *labels, int max_iter,
-                           int max_cand, const ProfHook &prof, hipStream_t st, void *sweep_scratch, int *fail_host,
-                           bool *used_persistent, ZBatch zb)
+                           int max_cand, const ProfHook &prof, hipStream_t st, bool *fused_update, ZBatch zb)
 {
-    if (used_persistent) *used_persistent = false;
+    if (fused_update) *fused_update = false;
     // several images per launch: image b = blockIdx.z, every device pointer of `s` (and lab / labels) b * zb.zs bytes further on;
     // the failure word of the fused centroid update is ONE host word for the whole batch
     s.zs = zb.zs;
     const unsigned nz = (unsigned)zb.nz;
-    if (nz > 1 && (sweep_scratch || s.slico || s.phase_prof)) {
-        set_error("slic: the persistent sweep kernel, SLICO and the phase profiler do not take a batch");
+    if (nz > 1 && (s.slico || s.phase_prof)) {
+        set_error("slic: SLICO and the phase profiler do not take a batch");
         return -1;
     }
     const bool default_cand = max_cand <= 0 || max_cand >= MAXC;
@@ -2392,62 +1295,7 @@ int launch_slic_iterations(SlicState s, const double *lab, const double *init_yx
         HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void *)k_slic_assign_dot<false, false, 1, false>, 256, 0));
         fprintf(stderr, "[occupancy] k_slic_assign_dot<false>: %d workgroups per CU\n", nb);
     }
-    // every sweep after the first in one persistent launch (k_slic_sweeps) -- on request (IMSEGM_SLIC_PERSISTENT), and when the
-    // image qualifies: the fp32 fast path, the closed-form first sweep, the default list capacity, windows that put well under
-    // SLIC_MAXC candidates into a tile.  Measured on MI355X (round 3) it ties with the per-sweep launches for
-    // one image alone and loses when several images are in flight, so the per-sweep launches stay the default.
-    bool persistent = false;
-    const int tile_rows = cdiv(s.H, TILE_Y);
-    if (sweep_scratch && fail_host && max_iter >= 3 && s.fast32 && !s.slico && s.spatial_weight > 1e-9 && grid_covers && default_cand &&
-        !s.debug && !s.phase_prof && units == 1 && s.grid_dy > 0 && s.grid_dx > 0 && knobs().slic_persistent) {
-        const double per_tile = ((double)TILE_Y + 4.0 * s.step_y + 2.0) * ((double)TILE_X + 4.0 * s.step_x + 2.0) / ((double)s.grid_dy * s.grid_dx);
-        persistent = per_tile <= 0.75 * MAXC;
-    }
     for (int it = 0; it < max_iter; ++it) {
-        if (persistent && it == 1) {
-            SweepWork w;
-            unsigned char *p = static_cast<unsigned char *>(sweep_scratch);
-            w.cen = reinterpret_cast<CenRec *>(p); p += (size_t)max_iter * s.K * sizeof(CenRec);
-            void *zeroed = p;
-            w.rowdone = reinterpret_cast<int *>(p); p += (size_t)max_iter * tile_rows * SWEEP_ROW_STRIDE * sizeof(int);     // (128-byte aligned)
-            int *ctl_all = reinterpret_cast<int *>(p); p += (size_t)max_iter * SWEEP_QUEUES * 128;                         // per launch
-            w.fail = reinterpret_cast<int *>(p); p += 128;
-            w.acc = reinterpret_cast<long long *>(p); p += (size_t)max_iter * s.K * 9 * sizeof(long long);
-            w.done = reinterpret_cast<int *>(p); p += (size_t)max_iter * s.K * sizeof(int);
-            w.ccount = reinterpret_cast<int *>(p); p += (size_t)max_iter * n_tiles * sizeof(int);
-            w.clist = reinterpret_cast<int *>(p); p += (size_t)max_iter * n_tiles * MAXC * sizeof(int);
-            w.fail_host = fail_host;
-            w.n_tiles = n_tiles; w.tiles_x = (int)grid.x; w.tile_rows = tile_rows;
-            w.sweep_last = max_iter;
-            // pixels that decide a candidate of a tile lie within 3 * (2 * step + 1) rows of it (see k_slic_sweeps)
-            w.wait_rows = (3 * (2 * s.step_y + 1) + TILE_Y - 1) / TILE_Y + 1;
-            w.force_fail = knobs().sweeps_force_fail;       // (tests: exercise the hand-back)
-            w.prof = slic_sweep_prof_buffer();
-            *fail_host = 0;
-            HIP_TRY(hipMemsetAsync(zeroed, 0, sweep_zeroed_bytes(s.K, max_iter, n_tiles, tile_rows), st));
-            w.sweep_begin = 1; w.sweep_end = max_iter; w.ctl = ctl_all;
-            hipLaunchKernelGGL(k_sweeps_init, cdiv(s.K, 256), 256, 0, st, s, w);
-            // sweeps per launch: all of them by default; fewer (IMSEGM_SWEEPS_PER_LAUNCH) trades the waits between dependent tiles of
-            // consecutive sweeps for launch boundaries
-            int per_launch = max_iter - 1;
-            if (knobs().sweeps_per_launch) per_launch = std::min(std::max(knobs().sweeps_per_launch, 1), max_iter - 1);
-            if (w.prof) fprintf(stderr, "[slic sweeps] %d x %d: %d items, %d workgroups, wait_rows %d, %d sweeps per launch\n", s.H, s.W,
-                                (max_iter - 1) * n_tiles, std::min(per_launch * n_tiles, sweeps_resident_blocks()), w.wait_rows, per_launch);
-            for (int sb = 1, g = 0; sb < max_iter; sb += per_launch, ++g) {
-                w.sweep_begin = sb; w.sweep_end = std::min(sb + per_launch, max_iter);
-                w.ctl = ctl_all + (size_t)g * SWEEP_QUEUES * 32;
-                const int blocks = std::min((w.sweep_end - w.sweep_begin) * n_tiles, sweeps_resident_blocks());
-                hipEvent_t ev_a = nullptr, ev_b = nullptr;
-                if (prof.pair) prof.pair(prof.user, 0, &ev_a, &ev_b);
-                if (w.prof) hipLaunchKernelGGL(k_slic_sweeps<true>, dim3(blocks), dim3(256), 0, st, s, lab, labels, w);
-                else if (ev_a) hipExtLaunchKernelGGL(k_slic_sweeps<false>, dim3(blocks), dim3(256), 0, st, ev_a, ev_b, 0, s, lab, labels, w);
-                else hipLaunchKernelGGL(k_slic_sweeps<false>, dim3(blocks), dim3(256), 0, st, s, lab, labels, w);
-            }
-            HIP_TRY(hipGetLastError());
-            g_sweep_persistent.fetch_add(1);
-            if (used_persistent) *used_persistent = true;
-            return 0;
-        }
         hipLaunchKernelGGL(k_slic_bin, dim3(cdiv(n_tiles, BIN_TILES_PER_BLOCK), 1, nz), 256,
                            (size_t)std::min(s.K, BIN_MAX_K_LDS) * sizeof(int4), st, s, (int)grid.x, n_tiles, max_cand,
                            s.tile_cands, s.tile_count, it % SLIC_DRIFT_SLOTS);
@@ -2461,13 +1309,13 @@ int launch_slic_iterations(SlicState s, const double *lab, const double *init_yx
         const bool accum = it + 1 < max_iter;
         // centroid update inside the assignment kernel of this sweep (no finalize launch behind it)
         const bool fuse = accum && s.done && fail_host_fuse && units == 1 && !s.phase_prof && (first_grid || dot);
-        if (fuse && used_persistent) *used_persistent = true;       // (the caller reads the failure word after its next synchronisation)
+        if (fuse && fused_update) *fused_update = true;             // (the caller reads the failure word after its next synchronisation)
         SlicState sf = s;
         sf.fuse_finalize = fuse ? 1 : 0;
         sf.drift_slot_next = (it + 1) % SLIC_DRIFT_SLOTS;
         // when profiling, the event pair rides on the dispatch itself (kernel begin / end timestamps)
         hipEvent_t ev_a = nullptr, ev_b = nullptr;
-        if (prof.pair && !persistent) prof.pair(prof.user, 0, &ev_a, &ev_b);     // (persistent: the pair rides on k_slic_sweeps)
+        if (prof.pair) prof.pair(prof.user, 0, &ev_a, &ev_b);
 // (with a profiler pair: the extended launch that stamps the dispatch; otherwise a plain launch, which a stream capture records)
 #define LAUNCH_ON(kernel, g, ...)                                                                                    \
     {                                                                                                                \

@@ -928,9 +928,10 @@ k_vol_assign_f32(VolState s, const float *__restrict__ vol, int32_t *__restrict_
 }
 
 // Round 5: one LANE per centroid.  The float32 sums of a segment must be formed in raster order (see above), which makes the sum of
-// ONE segment a serial chain -- but the chains of different segments have nothing to do with each other.  k_vol_update_f32 below
-// gives a whole wave to one chain: per member voxel a find-first-bit, a bit clear, two v_readlane and two packed additions, i.e.
-// eight issue slots of which the wave uses one lane's worth (13 ms per sweep at 298 116 supervoxels).  Here a lane walks the
+// ONE segment a serial chain -- but the chains of different segments have nothing to do with each other.  Rounds 3 / 4 gave a
+// whole wave to one chain: per member voxel a find-first-bit, a bit clear, two v_readlane and two packed additions, i.e. eight
+// issue slots of which the wave used one lane's worth (13.2 ms per sweep at 298 116 supervoxels against 3.5 here; A/B in
+// profiles/rocprof_r05_cfg5_kernel_stats.txt against rocprof_r04_cfg5_kernel_stats.txt; removed in round 6).  Here a lane walks the
 // bounding box of ITS segment voxel by voxel -- labels[p] == k ? add : skip -- and the sixty-four chains of a wave advance together;
 // lanes of one wave hold neighbouring centroids of a grid row, whose boxes lie side by side, so the lines a wave touches are shared
 // by its lanes and reused by the next steps of the walk (L1 / L2), and the additions of a chain happen in exactly the order of the
@@ -987,104 +988,6 @@ k_vol_update_f32_lane(VolState s, const float *__restrict__ vol, const int32_t *
     vol_bbox_reset(bb);
 }
 
-// one wave per centroid: raster-order float32 running sums over the segment's bounding box, then the division,
-// the new search window and the reset of the box (oracle orc_slic_gray3d_f32, the loop after `if (!change) break`)
-__global__ void __launch_bounds__(256)
-k_vol_update_f32(VolState s, const float *__restrict__ vol, const int32_t *__restrict__ labels)
-{
-    const int lane = threadIdx.x & 63;
-    const int k = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (k >= s.K) return;
-    int *bb = s.bbox + (size_t)k * 6;
-    int *w = s.win + (size_t)k * 6;
-    const int z0 = bb[0], z1 = bb[1], y0 = bb[2], y1 = bb[3], x0 = bb[4], x1 = bb[5];
-    if (z1 < z0) {                                            // no voxel carries this label: the centroid is dead
-        if (lane < 6) w[lane] = 0;
-        return;
-    }
-    float acc = 0.f;                                          // lanes 0..3: running sums of z, y, x, value
-    int cnt = 0;
-    const int nx = x1 - x0 + 1;
-    if (nx <= 64) {
-        // the box is at most one wave wide (always, for the windows of a regular grid): the labels of VU_ROWS rows are requested
-        // together, then the values of the voxels that carry the label, then the rows are summed in raster order -- one round trip to
-        // memory per VU_ROWS rows instead of two per row (the kernel was a chain of such round trips: 625 rows x ~0.5 us per box)
-        // The four running sums as two packed pairs in EVERY lane (the wave computes one result): (z, y) grows by the same pair for
-        // every voxel of a row, (x, value) by the pair two v_readlane fetch from the lane of the voxel -- 2 + 2 vector instructions
-        // per voxel (v_pk_add_f32 rounds each half as v_add_f32 does) where the selects of the one-sum-per-lane form needed 7
-        // (SQ_INSTS_VALU per voxel 8.6 -> 5.5).  The launch takes as long as before: what bounds it is the SCALAR side of the bit
-        // loop -- find the next lane, clear its bit, compare, branch: 4.5 scalar instructions per voxel, serial per supervoxel by
-        // the order of the additions -- and requesting the rows of the next group ahead of time changes nothing either (measured).
-        constexpr int VU_ROWS = 8;
-        typedef float pair_t __attribute__((ext_vector_type(2)));
-        const int x = x0 + lane;
-        const bool in = x <= x1;
-        const float xf = (float)x;
-        pair_t zy = { 0.f, 0.f }, xv = { 0.f, 0.f };
-        for (int z = z0; z <= z1; ++z) {
-            const float fz = (float)z;
-            for (int yb = y0; yb <= y1; yb += VU_ROWS) {
-                int lab[VU_ROWS];
-                float val[VU_ROWS];
-#pragma unroll
-                for (int r = 0; r < VU_ROWS; ++r)
-                    lab[r] = (in && yb + r <= y1) ? labels[((size_t)z * s.H + yb + r) * s.W + x] : -1;
-#pragma unroll
-                for (int r = 0; r < VU_ROWS; ++r) val[r] = lab[r] == k ? vol[((size_t)z * s.H + yb + r) * s.W + x] : 0.f;
-#pragma unroll
-                for (int r = 0; r < VU_ROWS; ++r) {
-                    unsigned long long m = __ballot(lab[r] == k);
-                    if (!m) continue;
-                    cnt += __popcll(m);
-                    const pair_t step_zy = { fz, (float)(yb + r) };
-                    while (m) {
-                        const int b = __ffsll((long long)m) - 1;
-                        m &= ~(1ULL << b);
-                        pair_t step_xv;
-                        step_xv.x = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(xf), b));
-                        step_xv.y = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(val[r]), b));
-                        zy = zy + step_zy;
-                        xv = xv + step_xv;
-                    }
-                }
-            }
-        }
-        acc = lane == 0 ? zy.x : lane == 1 ? zy.y : lane == 2 ? xv.x : xv.y;
-    } else
-    for (int z = z0; z <= z1; ++z) {
-        const float fz = (float)z;
-        for (int y = y0; y <= y1; ++y) {
-            const float fy = (float)y;
-            const size_t row = ((size_t)z * s.H + y) * s.W;
-            for (int xb = 0; xb < nx; xb += 64) {
-                const int x = x0 + xb + lane;
-                const bool in = x <= x1;
-                const bool mine = in && labels[row + x] == k;
-                unsigned long long m = __ballot(mine);
-                if (!m) continue;
-                const float v = mine ? vol[row + x] : 0.f;
-                cnt += __popcll(m);
-                const float sel_zy = lane == 0 ? fz : fy;
-                while (m) {
-                    const int b = __ffsll((long long)m) - 1;
-                    m &= m - 1;
-                    const float vb = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), b));
-                    const float fxv = (float)(x0 + xb + b);
-                    const float op = lane < 2 ? sel_zy : (lane == 2 ? fxv : vb);
-                    acc = acc + op;
-                }
-            }
-        }
-    }
-    const float q = acc / (float)cnt;                         // seg[c] / (float)cnt   (cnt > 0 here)
-    const float cz = __shfl(q, 0, 64), cy = __shfl(q, 1, 64), cx = __shfl(q, 2, 64);
-    if (lane < 4) s.cen32[(size_t)k * 4 + lane] = q;
-    if (lane == 0) {
-        vol_window_f32(s, cz, cy, cx, w);
-        vol_bbox_reset(bb);
-    }
-}
-
 int launch_vol_slic_f32(VolState s, const float *vol, int32_t *labels, int max_iter, hipStream_t st, const ProfHook *prof)
 {
     size_t n = (size_t)s.D * s.H * s.W;
@@ -1101,8 +1004,7 @@ int launch_vol_slic_f32(VolState s, const float *vol, int32_t *labels, int max_i
         if (it + 1 < max_iter) {
             if (ev_a) hipExtLaunchKernelGGL(k_vol_assign_f32<true>, grid, dim3(256), 0, st, ev_a, ev_b, 0, s, vol, labels);
             else hipLaunchKernelGGL(k_vol_assign_f32<true>, grid, 256, 0, st, s, vol, labels);
-            if (knobs().vol_update_wave) hipLaunchKernelGGL(k_vol_update_f32, cdiv(s.K, 4), 256, 0, st, s, vol, labels);
-            else hipLaunchKernelGGL(k_vol_update_f32_lane, cdiv(s.K, 256), 256, 0, st, s, vol, labels);
+            hipLaunchKernelGGL(k_vol_update_f32_lane, cdiv(s.K, 256), 256, 0, st, s, vol, labels);
         } else {
             if (ev_a) hipExtLaunchKernelGGL(k_vol_assign_f32<false>, grid, dim3(256), 0, st, ev_a, ev_b, 0, s, vol, labels);
             else hipLaunchKernelGGL(k_vol_assign_f32<false>, grid, 256, 0, st, s, vol, labels);

@@ -1,6 +1,7 @@
-"""The ONE persistent launch of the SLIC sweeps 2..max_iter (csrc/slic.hip k_slic_sweeps, opt-in: IMSEGM_SLIC_PERSISTENT) against
-the per-sweep launches and the oracle: identical label maps (the fixed-point centroid sums are order independent), ordinary
-images stay on the persistent path, and every hand-back to the per-sweep launches gives the same result."""
+"""The centroid update INSIDE the assignment kernel (the workgroup that completes a centroid divides its sums; default where the
+whole assignment grid is resident at once, IMSEGM_FUSE_FINALIZE for any image) against separate finalize launches and the oracle,
+and its hand-back: a tile without a candidate list raises the failure word and the host redoes the sweeps with separate launches.
+(Until round 6 this file also held the tests of the one-launch persistent sweeps of round 3, which were removed.)"""
 import os
 import sys
 
@@ -20,47 +21,9 @@ def hip():
     return _hip
 
 
-@pytest.fixture(autouse=True)
-def persistent_sweeps(monkeypatch):
-    monkeypatch.setenv('IMSEGM_SLIC_PERSISTENT', '1')
-
-
 def _labels(image, sp_size, regul):
     from pyimsegm_amd.superpixels import segment_slic_img2d
     return np.asarray(segment_slic_img2d(image, sp_size, regul))
-
-
-@pytest.mark.parametrize('shape,sp_size,regul,seed,per_launch', [
-    ((512, 640), 30, 0.2, 3, 9), ((647, 1024), 35, 0.2, 100, 9), ((300, 1000), 24, 0.3, 4, 9), ((1030, 515), 46, 0.2, 5, 9),
-    ((1024, 1024), 40, 0.1, 6, 9), ((647, 1024), 35, 0.2, 101, 1), ((512, 640), 30, 0.2, 7, 4)])
-def test_persistent_sweeps_equal_the_per_sweep_launches_and_the_oracle(hip, monkeypatch, shape, sp_size, regul, seed, per_launch):
-    """`per_launch` < 9: the sweeps in groups of that many per launch (the launch boundary stands in for the waits between them)"""
-    from oracle import oracle as orc
-    from pyimsegm_amd.utilities.synthetic import voronoi_image
-    image = voronoi_image(shape[0], shape[1], seed=seed)
-    monkeypatch.setenv('IMSEGM_SWEEPS_PER_LAUNCH', str(per_launch))
-    p0, f0 = hip.slic_sweep_runs()
-    one_launch = _labels(image, sp_size, regul)
-    p1, f1 = hip.slic_sweep_runs()
-    assert (p1 - p0, f1 - f0) == (1, 0), 'the image left the persistent path'
-    monkeypatch.delenv('IMSEGM_SLIC_PERSISTENT')
-    per_sweep = _labels(image, sp_size, regul)
-    assert hip.slic_sweep_runs() == (p1, f1)
-    assert np.array_equal(one_launch, per_sweep)
-    assert np.array_equal(one_launch, orc.segment_slic_img2d(image, sp_size, regul))
-
-
-def test_handed_back_images_give_the_same_labels(hip, monkeypatch):
-    """the failure word raised (here: on request): the host redoes the sweeps with the per-sweep launches"""
-    from pyimsegm_amd.utilities.synthetic import voronoi_image
-    image = voronoi_image(400, 520, seed=9)
-    want = _labels(image, 25, 0.3)
-    monkeypatch.setenv('IMSEGM_SWEEPS_FORCE_FAIL', '1')
-    p0, f0 = hip.slic_sweep_runs()
-    got = _labels(image, 25, 0.3)
-    p1, f1 = hip.slic_sweep_runs()
-    assert (p1 - p0, f1 - f0) == (1, 1)
-    assert np.array_equal(got, want)
 
 
 def test_noise_image_with_wandering_centroids(hip):
@@ -71,26 +34,12 @@ def test_noise_image_with_wandering_centroids(hip):
     assert np.array_equal(_labels(image, 32, 0.05), orc.segment_slic_img2d(image, 32, 0.05))
 
 
-def test_images_in_flight_on_the_persistent_path(hip):
-    """several sessions of different threads run their persistent launches concurrently (work items are pulled by whatever
-    workgroup is resident: no launch depends on having the device to itself)"""
-    from concurrent.futures import ThreadPoolExecutor
-    from pyimsegm_amd.utilities.synthetic import voronoi_image
-    images = [voronoi_image(512, 768, seed=40 + i) for i in range(6)]
-    want = [_labels(im, 32, 0.2) for im in images]
-    with ThreadPoolExecutor(max_workers=3) as pool:
-        for _ in range(3):
-            got = list(pool.map(lambda im: _labels(im, 32, 0.2), images))
-            assert all(np.array_equal(a, b) for a, b in zip(got, want))
-
-
 @pytest.mark.parametrize('shape,sp_size,regul,seed', [((647, 1024), 35, 0.2, 100), ((1030, 1200), 46, 0.2, 5), ((300, 1000), 24, 0.3, 4)])
 def test_centroid_update_inside_the_assignment_kernel(hip, monkeypatch, shape, sp_size, regul, seed):
     """per-sweep launches with the centroid update done by the workgroup that completes a centroid (default for small images,
     IMSEGM_FUSE_FINALIZE for any) against separate finalize launches and the oracle"""
     from oracle import oracle as orc
     from pyimsegm_amd.utilities.synthetic import voronoi_image
-    monkeypatch.delenv('IMSEGM_SLIC_PERSISTENT')
     image = voronoi_image(shape[0], shape[1], seed=seed)
     monkeypatch.setenv('IMSEGM_FUSE_FINALIZE', '1')
     p0, f0 = hip.slic_sweep_runs()
@@ -110,7 +59,6 @@ def test_fused_centroid_update_hands_the_image_back(hip, monkeypatch):
     the result must be the oracle's (and that of a run with separate launches from the start), and the hand-back must be counted"""
     from oracle import oracle as orc
     from pyimsegm_amd.utilities.synthetic import voronoi_image
-    monkeypatch.delenv('IMSEGM_SLIC_PERSISTENT', raising=False)
     image = voronoi_image(96, 128, seed=17)
     monkeypatch.setenv('IMSEGM_FUSE_FINALIZE', '1')
     before = hip.slic_sweep_runs()[1]

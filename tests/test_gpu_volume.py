@@ -109,20 +109,15 @@ def test_float32_volume_without_connectivity_and_session_reuse(hip, oracle):
 
 
 @pytest.mark.parametrize('shape,n_seg,spacing', [((12, 40, 44), 150, (2, 1, 1)), ((9, 70, 130), 420, (1, 1, 1)), ((5, 33, 257), 90, (3, 1, 1))])
-def test_float32_centroid_update_one_lane_or_one_wave_per_centroid(hip, oracle, monkeypatch, shape, n_seg, spacing):
-    """round 5: the raster-order float32 sums of a segment by ONE LANE (sixty-four segments advance per wave; the default) and by
-    one wave per segment (rounds 3 / 4, IMSEGM_VOL_UPDATE_WAVE): the same supervoxel map, the oracle's"""
+def test_float32_centroid_update_in_raster_order(hip, oracle, shape, n_seg, spacing):
+    """the raster-order float32 sums of a segment by ONE LANE per supervoxel (sixty-four segments advance per wave; the form with one
+    wave per segment of rounds 3 / 4 went in round 6): the k-means assignment of the oracle, i.e. of `_slic_cython[float32]`"""
     vol = _noisy_ellipsoid(shape, seed=9 + shape[0], dtype=np.float32)
     ref = _oracle_raw(oracle, vol, n_seg, 3, spacing, enforce_connectivity=False)
-    maps = []
-    for wave in (False, True):
-        if wave:
-            monkeypatch.setenv('IMSEGM_VOL_UPDATE_WAVE', '1')
-        sess = hip.Volume3D(*vol.shape).upload(vol)
-        sess.slic(n_seg, 3, sigma=1., spacing=spacing, enforce_connectivity=False)
-        maps.append(sess.get_labels())
-        sess.close()
-    assert np.array_equal(maps[0], ref) and np.array_equal(maps[1], ref)
+    sess = hip.Volume3D(*vol.shape).upload(vol)
+    sess.slic(n_seg, 3, sigma=1., spacing=spacing, enforce_connectivity=False)
+    assert np.array_equal(sess.get_labels(), ref)
+    sess.close()
 
 
 def test_segment_slic_img3d_gray_api(oracle):
