@@ -626,13 +626,26 @@ __device__ __forceinline__ int wave_min_key(int key)
     return VOL_KEY_INF - __builtin_amdgcn_readlane(x, 63);
 }
 
+// VZ slices of one workgroup (see k_vol_assign_f32): a lane holds VZ x VROWS voxels -- one column of 4 rows in VZ consecutive
+// slices.  `cov[c]`: bit zi set when slice z0 + zi lies inside candidate c's search window.
+// Measured (round 6, 64 x 4096 x 4096, one box each): VZ = 1 11.4 ms per accumulating sweep; VZ = 2 -- the scan of the brick's list,
+// its barriers and the flush of the boxes serving twice the voxels, a candidate selected once for eight rows of a lane -- 12.1 ms:
+// 102 registers per lane leave four waves per SIMD where 56 leave eight, and the kernel lives on the waves that compute while
+// others wait.  The code takes either; the label maps are the same (tests with both).
+#ifndef VOL_ASSIGN_SLICES
+#define VOL_ASSIGN_SLICES 1
+#endif
+constexpr int VZ = VOL_ASSIGN_SLICES;
+
 template <int NS>
-__device__ __forceinline__ void vol_walk_f32(const VolRec *rec, const int *list, int count, int lane, int y0, int y1w, int x0w, int x1w,
-                                             int x, bool xin, int H, float fz, float fx, float sz, float sy, float sx, float sw,
-                                             const float (&pv)[VROWS], float (&best_d)[VROWS], int (&best_k)[VROWS], float &wave_worst)
+__device__ __forceinline__ void vol_walk_f32(const VolRec *rec, const int *list, const unsigned char *cov, int count, int lane, int y0,
+                                             int y1w, int x0w, int x1w, int x, bool xin, int H, int nzv, float fz0, float fx, float sz,
+                                             float sy, float sx, float sw, const float (&pv)[VZ][VROWS], float (&best_d)[VZ][VROWS],
+                                             int (&best_k)[VZ][VROWS], float &wave_worst)
 {
     static_assert(NS >= 1 && NS <= 8, "three bits of a key hold the slot");
-    // bounds over this wave's strip; a window that misses the strip's rows is out
+    // bounds over this wave's strips (one per slice); a window that misses the strips' rows is out.  The bound of a candidate is
+    // its smallest bound over the slices its window covers: below every distance it can give a voxel of this wave.
     int key[NS];
 #pragma unroll
     for (int j = 0; j < NS; ++j) {
@@ -640,13 +653,20 @@ __device__ __forceinline__ void vol_walk_f32(const VolRec *rec, const int *list,
         key[j] = VOL_KEY_INF;
         if (c < count) {
             const VolRec rc = rec[c];
+            const int cv = VZ > 1 ? cov[c] : 1;            // (one slice: the scan has kept the windows that cover it)
             if (rc.wy0 < y1w && rc.wy1 > y0) {
-                const float tz = sz * (rc.cz - fz);
-                const float dz = tz * tz;
                 const float yn = fminf(fmaxf(rc.cy, (float)y0), (float)(y1w - 1));
                 const float xn = fminf(fmaxf(rc.cx, (float)x0w), (float)(x1w - 1));
                 const float tyl = sy * (rc.cy - yn), txl = sx * (rc.cx - xn);
-                const float lb = ((dz + tyl * tyl) + txl * txl) * sw;       // >= 0, or +inf / NaN (then: not a candidate)
+                const float dy2 = tyl * tyl, dx2 = txl * txl;
+                float lb = INFINITY;
+#pragma unroll
+                for (int zi = 0; zi < VZ; ++zi) {
+                    const float tz = sz * (rc.cz - (fz0 + (float)zi));
+                    const float dz = tz * tz;
+                    const float one = ((dz + dy2) + dx2) * sw;          // >= 0, or +inf / NaN (then: not a candidate)
+                    lb = ((cv >> zi) & 1) ? fminf(lb, one) : lb;
+                }
                 const int bits = __float_as_int(lb);
                 key[j] = (bits >= 0 && bits < VOL_KEY_INF) ? ((bits & ~7) | j) : VOL_KEY_INF;
             }
@@ -659,7 +679,7 @@ __device__ __forceinline__ void vol_walk_f32(const VolRec *rec, const int *list,
         for (int j = 1; j < NS; ++j) mine = min(mine, key[j]);
         const int wk = wave_min_key(mine);
         if (wk >= VOL_KEY_INF) break;                              // nothing left in the batch
-        if (!(__int_as_float(wk & ~7) <= wave_worst)) break;       // every candidate left is farther than what the strip has
+        if (!(__int_as_float(wk & ~7) <= wave_worst)) break;       // every candidate left is farther than what the strips have
         const unsigned long long own = __ballot(mine == wk);
         const int src = __ffsll((long long)own) - 1;
         const int jsel = wk & 7;
@@ -669,31 +689,42 @@ __device__ __forceinline__ void vol_walk_f32(const VolRec *rec, const int *list,
         const int c = src + 64 * jsel;
         const int ck = list[c];
         const VolRec rc = rec[c];
+        const int cv = VZ > 1 ? cov[c] : 1;
         VOL_PH_COUNT(11, 1);
-        const float tz = sz * (rc.cz - fz);
-        const float dz = tz * tz;
         const bool inx = x >= rc.wx0 && x < rc.wx1;
         const float tx = sx * (rc.cx - fx);
         const float dx2 = tx * tx;
+        float dy[VROWS];
 #pragma unroll
         for (int r = 0; r < VROWS; ++r) {
-            const int y = y0 + r;
-            if (y < rc.wy0 || y >= rc.wy1) continue;
-            const float ty = sy * (rc.cy - (float)y);
-            const float dy = ty * ty;
-            float d = ((dz + dy) + dx2) * sw;
-            const float t = pv[r] - rc.cv;
-            d = d + t * t;
-            const bool take = inx && (best_d[r] > d || (best_d[r] == d && ck < best_k[r]));
-            best_d[r] = take ? d : best_d[r];               // (selects, no change of the exec mask)
-            best_k[r] = take ? ck : best_k[r];
+            const float ty = sy * (rc.cy - (float)(y0 + r));
+            dy[r] = ty * ty;
+        }
+#pragma unroll
+        for (int zi = 0; zi < VZ; ++zi) {
+            if (!((cv >> zi) & 1)) continue;                       // (wave uniform: the slice is outside the window)
+            const float tz = sz * (rc.cz - (fz0 + (float)zi));
+            const float dz = tz * tz;
+#pragma unroll
+            for (int r = 0; r < VROWS; ++r) {
+                const int y = y0 + r;
+                if (y < rc.wy0 || y >= rc.wy1) continue;
+                float d = ((dz + dy[r]) + dx2) * sw;
+                const float t = pv[zi][r] - rc.cv;
+                d = d + t * t;
+                const bool take = inx && (best_d[zi][r] > d || (best_d[zi][r] == d && ck < best_k[zi][r]));
+                best_d[zi][r] = take ? d : best_d[zi][r];           // (selects, no change of the exec mask)
+                best_k[zi][r] = take ? ck : best_k[zi][r];
+            }
         }
         if (++since_refresh == 2) {
             since_refresh = 0;
             float m2 = 0.f;
 #pragma unroll
-            for (int r = 0; r < VROWS; ++r)
-                if (xin && (y0 + r) < H) m2 = fmaxf(m2, best_d[r]);
+            for (int zi = 0; zi < VZ; ++zi)
+#pragma unroll
+                for (int r = 0; r < VROWS; ++r)
+                    if (xin && (y0 + r) < H && zi < nzv) m2 = fmaxf(m2, best_d[zi][r]);
             wave_worst = wave_max_nonneg_f32(m2);           // (distances: never negative; +inf while a voxel has no candidate)
         }
     }
@@ -720,48 +751,63 @@ struct VolEntry {
 static_assert(sizeof(VolEntry) == 48, "three 16-byte loads per entry");
 constexpr int VT_SLOTS = 64;          // labels of a workgroup's cross-section whose boxes meet in LDS (more: straight to global memory)
 
-// every centroid writes its entry into the list of each brick its search window meets (float32 volumes)
+// every centroid writes its entry into the list of each brick its search window meets (float32 volumes).  One WAVE per centroid:
+// lane j takes the bricks j, j + 64, ... of the window's brick range (~50 at sp_size 15: a thread per centroid walked them one
+// after the other, an atomic and three 16-byte stores each -- 0.98 ms per sweep at 298 116 supervoxels)
 __global__ void __launch_bounds__(256) k_vol_scatter_f32(VolState s)
 {
-    int k = blockIdx.x * blockDim.x + threadIdx.x;
+    const int k = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
     if (k >= s.K) return;
     const int *w = s.win + (size_t)k * 6;
-    if (w[1] <= w[0] || w[3] <= w[2] || w[5] <= w[4]) return;       // dead centroid: empty window
+    const int w0 = w[0], w1 = w[1], w2 = w[2], w3 = w[3], w4 = w[4], w5 = w[5];
+    if (w1 <= w0 || w3 <= w2 || w5 <= w4) return;       // dead centroid: empty window
     const float4 cen = *reinterpret_cast<const float4 *>(s.cen32 + (size_t)k * 4);
     const int4 e0 = make_int4(__float_as_int(cen.x), __float_as_int(cen.y), __float_as_int(cen.z), __float_as_int(cen.w));
-    const int4 e1 = make_int4(w[2], w[3], w[4], w[5]);
-    const int4 e2 = make_int4(w[0], w[1], k, 0);
-    const int bz0 = w[0] / VOL_BZ, bz1 = (w[1] - 1) / VOL_BZ;
-    const int by0 = w[2] / VOL_BY, by1 = (w[3] - 1) / VOL_BY;
-    const int bx0 = w[4] / VOL_BX, bx1 = (w[5] - 1) / VOL_BX;
-    for (int bz = bz0; bz <= bz1; ++bz)
-        for (int by = by0; by <= by1; ++by)
-            for (int bx = bx0; bx <= bx1; ++bx) {
-                const int b = (bz * s.nby + by) * s.nbx + bx;
-                const int pos = atomicAdd(&s.brick_count[b], 1);
-                if (pos < s.brick_cap) {
-                    int4 *dst = reinterpret_cast<int4 *>(s.brick_entries + ((size_t)b * s.brick_cap + pos) * 12);
-                    dst[0] = e0;
-                    dst[1] = e1;
-                    dst[2] = e2;
-                }
-            }
+    const int4 e1 = make_int4(w2, w3, w4, w5);
+    const int4 e2 = make_int4(w0, w1, k, 0);
+    const int bz0 = w0 / VOL_BZ, by0 = w2 / VOL_BY, bx0 = w4 / VOL_BX;
+    const int nz = (w1 - 1) / VOL_BZ - bz0 + 1, ny = (w3 - 1) / VOL_BY - by0 + 1, nx = (w5 - 1) / VOL_BX - bx0 + 1;
+    const int total = nz * ny * nx;
+    for (int j = lane; j < total; j += 64) {
+        const int bx = bx0 + j % nx, by = by0 + (j / nx) % ny, bz = bz0 + j / (nx * ny);
+        const int b = (bz * s.nby + by) * s.nbx + bx;
+        const int pos = atomicAdd(&s.brick_count[b], 1);
+        if (pos < s.brick_cap) {
+            int4 *dst = reinterpret_cast<int4 *>(s.brick_entries + ((size_t)b * s.brick_cap + pos) * 12);
+            dst[0] = e0;
+            dst[1] = e1;
+            dst[2] = e2;
+        }
+    }
 }
 
+// waves per SIMD the register allocation aims at: the kernel takes 80 registers when left alone (six waves), 72 at seven -- 2.53
+// against 2.68 ms per sweep of a quarter volume, alternating on one box --, and spills at eight (64 registers: 3.47 ms)
+#ifndef VOL_ASSIGN_WAVES
+#define VOL_ASSIGN_WAVES 7
+#endif
+#define VOL_ASSIGN_ATTR __attribute__((amdgpu_waves_per_eu(VOL_ASSIGN_WAVES, VOL_ASSIGN_WAVES)))
 template <bool TRACK>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256) VOL_ASSIGN_ATTR
 k_vol_assign_f32(VolState s, const float *__restrict__ vol, int32_t *__restrict__ labels)
 {
+    // A workgroup = the 64 x 16 cross-section of a brick in VZ consecutive slices (VZ = 1; 2 was measured, see VZ above);
+    // a wave = 64 columns x 4 rows x VZ slices.
     __shared__ int list[VLIST32];
     __shared__ __attribute__((aligned(16))) VolRec rec[VLIST32];      // (filled with 16-byte stores)
+    // (one slice: no coverage bytes and no z columns in the table of the boxes -- 19.7 KB per workgroup, eight of them per CU; with
+    // them it is 20.8 KB and seven)
+    __shared__ unsigned char cov[VZ > 1 ? VLIST32 : 1];
     __shared__ int wave_base[4];
-    __shared__ int hb_key[TRACK ? VT_SLOTS : 1], hb_box[TRACK ? VT_SLOTS : 1][4];      // label -> ymin, ymax, xmin, xmax
+    constexpr int HB = VZ > 1 ? 6 : 4, HB_Y = VZ > 1 ? 2 : 0;                        // label -> [zmin, zmax,] ymin, ymax, xmin, xmax
+    __shared__ int hb_key[TRACK ? VT_SLOTS : 1], hb_box[TRACK ? VT_SLOTS : 1][HB];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     VOL_PH_BEGIN
     const int rows_per_block = 4 * VROWS;
     const int yb = cdiv(s.H, rows_per_block);
-    const int z = blockIdx.y / yb;
+    const int z0 = (blockIdx.y / yb) * VZ;
+    const int nzv = min(VZ, s.D - z0);                        // slices of this workgroup inside the volume
     const int Y0 = (blockIdx.y % yb) * rows_per_block, Y1 = min(Y0 + rows_per_block, s.H);
     const int y0 = Y0 + wave * VROWS;
     const int x = blockIdx.x * 64 + lane;
@@ -771,23 +817,27 @@ k_vol_assign_f32(VolState s, const float *__restrict__ vol, int32_t *__restrict_
     const bool xin = x < s.W;
     if (TRACK && tid < VT_SLOTS) {                            // (visible to all after the first barrier of the scan below)
         hb_key[tid] = -1;
-        hb_box[tid][0] = 0x7fffffff; hb_box[tid][1] = -1; hb_box[tid][2] = 0x7fffffff; hb_box[tid][3] = -1;
-    }
-    float pv[VROWS], best_d[VROWS];
-    int best_k[VROWS];
 #pragma unroll
-    for (int r = 0; r < VROWS; ++r) {
-        bool ok = alive && xin && (y0 + r) < s.H;
-        pv[r] = vol[ok ? ((size_t)z * s.H + y0 + r) * s.W + x : 0];
-        best_d[r] = INFINITY;
-        best_k[r] = -1;
+        for (int j = 0; j < HB; ++j) hb_box[tid][j] = (j & 1) ? -1 : 0x7fffffff;
     }
-    const float fz = (float)z, fx = (float)x;
+    float pv[VZ][VROWS], best_d[VZ][VROWS];
+    int best_k[VZ][VROWS];
+#pragma unroll
+    for (int zi = 0; zi < VZ; ++zi)
+#pragma unroll
+        for (int r = 0; r < VROWS; ++r) {
+            const bool ok = alive && xin && (y0 + r) < s.H && zi < nzv;
+            pv[zi][r] = vol[ok ? ((size_t)(z0 + zi) * s.H + y0 + r) * s.W + x : 0];
+            best_d[zi][r] = INFINITY;
+            best_k[zi][r] = -1;
+        }
+    const float fz0 = (float)z0, fx = (float)x;
     const float sz = (float)s.sz, sy = (float)s.sy, sx = (float)s.sx;
     const float sw = (float)s.spatial_weight;              // = (float)(1 / ((double)step * (double)step))
     int count = 0;                                         // (uniform over the workgroup)
     float wave_worst = INFINITY;
-    const int brick = ((z / VOL_BZ) * s.nby + (Y0 / VOL_BY)) * s.nbx + blockIdx.x;
+    static_assert(VOL_BZ % VZ == 0, "the slices of a workgroup lie in one brick");
+    const int brick = ((z0 / VOL_BZ) * s.nby + (Y0 / VOL_BY)) * s.nbx + blockIdx.x;
     const int bcount = s.brick_count[brick];
     const bool whole = bcount > s.brick_cap;                   // list overflow: scan every centroid
     const int4 *__restrict__ entries = reinterpret_cast<const int4 *>(s.brick_entries + (size_t)brick * s.brick_cap * 12);
@@ -817,7 +867,7 @@ k_vol_assign_f32(VolState s, const float *__restrict__ vol, int32_t *__restrict_
                 e1 = entries[3 * i + 1];
                 e2 = entries[3 * i + 2];
             }
-            hit = z >= e2.x && z < e2.y && e1.x < Y1 && e1.y > Y0 && e1.z < x1w && e1.w > x0w;
+            hit = e2.x < z0 + nzv && e2.y > z0 && e1.x < Y1 && e1.y > Y0 && e1.z < x1w && e1.w > x0w;
         }
         const unsigned long long m = __ballot(hit);
         if (lane == 0) wave_base[wave] = __popcll(m);
@@ -831,6 +881,10 @@ k_vol_assign_f32(VolState s, const float *__restrict__ vol, int32_t *__restrict_
             int4 *dst = reinterpret_cast<int4 *>(&rec[pos]);
             dst[0] = e0;
             dst[1] = e1;
+            int inside = 0;
+#pragma unroll
+            for (int zi = 0; zi < VZ; ++zi) inside |= (zi < nzv && z0 + zi >= e2.x && z0 + zi < e2.y) ? (1 << zi) : 0;
+            if (VZ > 1) cov[pos] = (unsigned char)inside;
         }
         count += added;
         __syncthreads();                                     // (list and records are complete; wave_base may be rewritten)
@@ -839,7 +893,7 @@ k_vol_assign_f32(VolState s, const float *__restrict__ vol, int32_t *__restrict_
         VOL_PH_COUNT(10, count);
         VOL_PH(2);
         if (alive) {
-#define VOL_WALK(NS) vol_walk_f32<NS>(rec, list, count, lane, y0, y1w, x0w, x1w, x, xin, s.H, fz, fx, sz, sy, sx, sw, pv, best_d, best_k, wave_worst)
+#define VOL_WALK(NS) vol_walk_f32<NS>(rec, list, cov, count, lane, y0, y1w, x0w, x1w, x, xin, s.H, nzv, fz0, fx, sz, sy, sx, sw, pv, best_d, best_k, wave_worst)
             switch ((count + 63) >> 6) {
             case 0: break;
             case 1: VOL_WALK(1); break;
@@ -858,67 +912,76 @@ k_vol_assign_f32(VolState s, const float *__restrict__ vol, int32_t *__restrict_
         if (b + 1 < nblk) __syncthreads();                   // (everybody is done with this batch's list and records)
         VOL_PH(4);
     }
-    unsigned pending = 0;
+    unsigned pending = 0;                                    // bit zi * VROWS + r: the voxel carries a label
     if (alive) {
 #pragma unroll
-        for (int r = 0; r < VROWS; ++r) {
-            if (!(xin && (y0 + r) < s.H)) continue;
-            size_t p = ((size_t)z * s.H + y0 + r) * s.W + x;
-            if (best_k[r] >= 0) labels[p] = best_k[r];
-            else best_k[r] = labels[p];                           // uncovered voxel keeps its previous assignment
-            if (best_k[r] >= 0) pending |= 1u << r;
-        }
+        for (int zi = 0; zi < VZ; ++zi)
+#pragma unroll
+            for (int r = 0; r < VROWS; ++r) {
+                if (!(xin && (y0 + r) < s.H && zi < nzv)) continue;
+                const size_t p = ((size_t)(z0 + zi) * s.H + y0 + r) * s.W + x;
+                if (best_k[zi][r] >= 0) labels[p] = best_k[zi][r];
+                else best_k[zi][r] = labels[p];                   // uncovered voxel keeps its previous assignment
+                if (best_k[zi][r] >= 0) pending |= 1u << (zi * VROWS + r);
+            }
     }
     VOL_PH(5);
     if (!TRACK) return;
     // bounding box of every segment's voxels (incl. the ones that kept an old label): the region the order-preserving update of
     // that centroid has to walk.  By RUNS (round 5): in every row of the strip the first lane of a run of equal labels finds the
-    // end of its run in the vote of the run starts.  Round 6: it updates the box of its label in the workgroup's LDS table (z is
-    // the workgroup's); the table goes to the global boxes once, below.  Minima and maxima: the boxes are the same whatever the
-    // order and however often a label is met.
+    // end of its run in the vote of the run starts.  Round 6: it updates the box of its label in the workgroup's LDS table; the
+    // table goes to the global boxes once, below.  Minima and maxima: the boxes are the same whatever the order and however often
+    // a label is met.
     if (alive) {
 #pragma unroll
-        for (int r = 0; r < VROWS; ++r) {
-            const int k = (pending >> r) & 1u ? best_k[r] : -1;
-            const int kp = lane_prev(k, -2);
-            const bool start = k >= 0 && kp != k;
-            const unsigned long long starts = __ballot(start), valid = __ballot(k >= 0);
-            if (start) {
-                const unsigned long long stop = (starts | ~valid) & ~((2ULL << lane) - 1ULL);     // the lanes above this one
-                const int end = stop ? __ffsll((long long)stop) - 1 : 64;
-                const int y = y0 + r, xlo = x0w + lane, xhi = x0w + end - 1;
-                int slot = (int)(((unsigned int)k * 2654435761u) >> 26);          // 6 bits
-                bool placed = false;
-                for (int probe = 0; probe < VT_SLOTS; ++probe) {
-                    const int old = atomicCAS(&hb_key[slot], -1, k);
-                    if (old == -1 || old == k) {
-                        placed = true;
-                        break;
+        for (int zi = 0; zi < VZ; ++zi)
+#pragma unroll
+            for (int r = 0; r < VROWS; ++r) {
+                const int k = (pending >> (zi * VROWS + r)) & 1u ? best_k[zi][r] : -1;
+                const int kp = lane_prev(k, -2);
+                const bool start = k >= 0 && kp != k;
+                const unsigned long long starts = __ballot(start), valid = __ballot(k >= 0);
+                if (start) {
+                    const unsigned long long stop = (starts | ~valid) & ~((2ULL << lane) - 1ULL);     // the lanes above this one
+                    const int end = stop ? __ffsll((long long)stop) - 1 : 64;
+                    const int z = z0 + zi, y = y0 + r, xlo = x0w + lane, xhi = x0w + end - 1;
+                    int slot = (int)(((unsigned int)k * 2654435761u) >> 26);          // 6 bits
+                    bool placed = false;
+                    for (int probe = 0; probe < VT_SLOTS; ++probe) {
+                        const int old = atomicCAS(&hb_key[slot], -1, k);
+                        if (old == -1 || old == k) {
+                            placed = true;
+                            break;
+                        }
+                        slot = (slot + 1) & (VT_SLOTS - 1);
                     }
-                    slot = (slot + 1) & (VT_SLOTS - 1);
-                }
-                if (placed) {
-                    atomicMin(&hb_box[slot][0], y);
-                    atomicMax(&hb_box[slot][1], y);
-                    atomicMin(&hb_box[slot][2], xlo);
-                    atomicMax(&hb_box[slot][3], xhi);
-                } else {                                          // (more than VT_SLOTS labels in a 64 x 16 cross-section)
-                    int *bb = s.bbox + (size_t)k * 6;
-                    atomicMin(&bb[0], z); atomicMax(&bb[1], z);
-                    atomicMin(&bb[2], y); atomicMax(&bb[3], y);
-                    atomicMin(&bb[4], xlo); atomicMax(&bb[5], xhi);
+                    if (placed) {
+                        if (VZ > 1) {
+                            atomicMin(&hb_box[slot][0], z);
+                            atomicMax(&hb_box[slot][1], z);
+                        }
+                        atomicMin(&hb_box[slot][HB_Y], y);
+                        atomicMax(&hb_box[slot][HB_Y + 1], y);
+                        atomicMin(&hb_box[slot][HB_Y + 2], xlo);
+                        atomicMax(&hb_box[slot][HB_Y + 3], xhi);
+                    } else {                                          // (more than VT_SLOTS labels in a cross-section)
+                        int *bb = s.bbox + (size_t)k * 6;
+                        atomicMin(&bb[0], z); atomicMax(&bb[1], z);
+                        atomicMin(&bb[2], y); atomicMax(&bb[3], y);
+                        atomicMin(&bb[4], xlo); atomicMax(&bb[5], xhi);
+                    }
                 }
             }
-        }
     }
     __syncthreads();
     if (tid < VT_SLOTS && hb_key[tid] >= 0) {
         int *bb = s.bbox + (size_t)hb_key[tid] * 6;
         const int2 bz = *reinterpret_cast<const int2 *>(bb), by = *reinterpret_cast<const int2 *>(bb + 2),
                    bx = *reinterpret_cast<const int2 *>(bb + 4);
-        const int ylo = hb_box[tid][0], yhi = hb_box[tid][1], xlo = hb_box[tid][2], xhi = hb_box[tid][3];
-        if (bz.x > z) atomicMin(&bb[0], z);
-        if (bz.y < z) atomicMax(&bb[1], z);
+        const int zlo = VZ > 1 ? hb_box[tid][0] : z0, zhi = VZ > 1 ? hb_box[tid][1] : z0;
+        const int ylo = hb_box[tid][HB_Y], yhi = hb_box[tid][HB_Y + 1], xlo = hb_box[tid][HB_Y + 2], xhi = hb_box[tid][HB_Y + 3];
+        if (bz.x > zlo) atomicMin(&bb[0], zlo);
+        if (bz.y < zhi) atomicMax(&bb[1], zhi);
         if (by.x > ylo) atomicMin(&bb[2], ylo);
         if (by.y < yhi) atomicMax(&bb[3], yhi);
         if (bx.x > xlo) atomicMin(&bb[4], xlo);
@@ -937,6 +1000,8 @@ k_vol_assign_f32(VolState s, const float *__restrict__ vol, int32_t *__restrict_
 // by its lanes and reused by the next steps of the walk (L1 / L2), and the additions of a chain happen in exactly the order of the
 // serial loop: z, then y, then x ascending.  Same results bit for bit (the parity tests of the float32 volumes; the full-size
 // label map against scikit-image's).
+constexpr int VU_STEP = 4;          // (8 -- sixteen loads in flight per lane -- measured slower: 3.81 against 3.42 ms per sweep at config 5)
+
 __global__ void __launch_bounds__(256)
 k_vol_update_f32_lane(VolState s, const float *__restrict__ vol, const int32_t *__restrict__ labels)
 {
@@ -957,20 +1022,20 @@ k_vol_update_f32_lane(VolState s, const float *__restrict__ vol, const int32_t *
         for (int y = y0; y <= y1; ++y) {
             const float fy = (float)y;
             const size_t row = ((size_t)z * s.H + y) * s.W;
-            // four voxels per round: their labels and values are requested together (eight loads in flight instead of a chain
+            // VU_STEP voxels per round: their labels and values are requested together (eight loads in flight instead of a chain
             // of two per voxel), then added in order.  A voxel of another segment adds +0.0f, which leaves a sum that started at
             // +0.0f bit for bit as it is (a sum of this kind is never -0.0f: (+0) + (-0) = +0).
-            for (int x = x0; x <= x1; x += 4) {
-                int lab[4];
-                float val[4];
+            for (int x = x0; x <= x1; x += VU_STEP) {
+                int lab[VU_STEP];
+                float val[VU_STEP];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
+                for (int j = 0; j < VU_STEP; ++j) {
                     const size_t p = row + min(x + j, x1);
                     lab[j] = labels[p];
                     val[j] = vol[p];
                 }
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
+                for (int j = 0; j < VU_STEP; ++j) {
                     const bool mine = lab[j] == k && x + j <= x1;
                     sz = sz + (mine ? fz : 0.f);
                     sy = sy + (mine ? fy : 0.f);
@@ -993,11 +1058,11 @@ int launch_vol_slic_f32(VolState s, const float *vol, int32_t *labels, int max_i
     size_t n = (size_t)s.D * s.H * s.W;
     HIP_TRY(hipMemsetAsync(labels, 0xff, n * sizeof(int32_t), st));
     hipLaunchKernelGGL(k_vol_centroid_init_f32, cdiv(s.K, 256), 256, 0, st, s);
-    dim3 grid(cdiv(s.W, 64), cdiv(s.H, 4 * VROWS) * s.D);
+    dim3 grid(cdiv(s.W, 64), cdiv(s.H, 4 * VROWS) * cdiv(s.D, VZ));      // a workgroup: 64 x 16 voxels of VZ slices
     const size_t n_bricks = (size_t)s.nbz * s.nby * s.nbx;
     for (int it = 0; it < max_iter; ++it) {
         HIP_TRY(hipMemsetAsync(s.brick_count, 0, n_bricks * sizeof(int), st));
-        hipLaunchKernelGGL(k_vol_scatter_f32, cdiv(s.K, 256), 256, 0, st, s);
+        hipLaunchKernelGGL(k_vol_scatter_f32, cdiv((long)s.K * 64, 256), 256, 0, st, s);
         // (when profiling: the event pair rides on the dispatch of the assignment kernel, group 0 = "slic_assign")
         hipEvent_t ev_a = nullptr, ev_b = nullptr;
         if (prof && prof->pair) prof->pair(prof->user, 0, &ev_a, &ev_b);
