@@ -71,6 +71,28 @@ __device__ __forceinline__ void uf_union(int32_t *parent, int a, int b)
     }
 }
 
+// union with the two finds walked together (both loads of a step in flight at once: half the dependent trips of uf_union)
+__device__ __forceinline__ void uf_union_pair(int32_t *parent, int a, int b)
+{
+    while (true) {
+        while (true) {
+            const int pa = parent[a], pb = parent[b];
+            if (pa == a && pb == b) break;
+            a = pa;
+            b = pb;
+        }
+        if (a == b) return;
+        if (a < b) {
+            const int t = a;
+            a = b;
+            b = t;
+        }
+        const int old = atomicMin(&parent[a], b);
+        if (old == a) return;
+        a = old;
+    }
+}
+
 // Run-based initialisation: every active pixel points at the leftmost pixel of its horizontal run
 // inside its 64-pixel wave segment (ballot + count-leading-zeros, no memory traffic), so the
 // union-find forest starts with paths of length <= 1 and the merge pass only has to join runs.
@@ -157,12 +179,25 @@ k_ccl_merge_rows(const int32_t *__restrict__ labels, int32_t *parent, int D, int
     const int back = (inx && z > 0) ? labels[row - plane + x] : -7;
     const bool cont = lane_prev(l, -8) == l;                                // the left neighbour carries the same label
     const bool up_left = lane_prev(up, -8) == l, back_left = lane_prev(back, -8) == l;
-    if (!(inx && lane >= 1 && lane <= CR_SPAN)) return;
+    // the (at most three) unions of a voxel in rounds: every lane that still has one does its next, side by side
+    const bool mine = inx && lane >= 1 && lane <= CR_SPAN;
     const int p = (int)(row + x);
-    if (cont && lane == 1) uf_union(parent, p, p - 1);                        // a run that crosses into the segment
+    int t[3];
+    t[0] = (mine && cont && lane == 1) ? p - 1 : -1;                          // a run that crosses into the segment
     // one union per pair of overlapping runs: skipped when the pair to the left (p - 1, q - 1) carries the same two runs
-    if (up == l && !(cont && up_left)) uf_union(parent, p, p - W);
-    if (back == l && !(cont && back_left)) uf_union(parent, p, (int)(row - plane + x));
+    t[1] = (mine && up == l && !(cont && up_left)) ? p - W : -1;
+    t[2] = (mine && back == l && !(cont && back_left)) ? (int)(row - plane + x) : -1;
+    while (true) {
+        int q = -1;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const bool take = q < 0 && t[j] >= 0;
+            q = take ? t[j] : q;
+            t[j] = take ? -1 : t[j];
+        }
+        if (!__any(q >= 0)) break;
+        if (q >= 0) uf_union_pair(parent, p, q);
+    }
 }
 
 template <bool ALL>

@@ -1001,6 +1001,11 @@ k_vol_assign_f32(VolState s, const float *__restrict__ vol, int32_t *__restrict_
 // serial loop: z, then y, then x ascending.  Same results bit for bit (the parity tests of the float32 volumes; the full-size
 // label map against scikit-image's).
 constexpr int VU_STEP = 4;          // (8 -- sixteen loads in flight per lane -- measured slower: 3.81 against 3.42 ms per sweep at config 5)
+// four consecutive 4-byte elements at a 4-byte aligned address: one global_load_dwordx4
+template <typename T> struct __attribute__((packed, aligned(4))) Quad {
+    T v[4];
+};
+static_assert(VU_STEP == 4, "a round of the update is one Quad");
 
 __global__ void __launch_bounds__(256)
 k_vol_update_f32_lane(VolState s, const float *__restrict__ vol, const int32_t *__restrict__ labels)
@@ -1025,22 +1030,19 @@ k_vol_update_f32_lane(VolState s, const float *__restrict__ vol, const int32_t *
             // VU_STEP voxels per round: their labels and values are requested together (eight loads in flight instead of a chain
             // of two per voxel), then added in order.  A voxel of another segment adds +0.0f, which leaves a sum that started at
             // +0.0f bit for bit as it is (a sum of this kind is never -0.0f: (+0) + (-0) = +0).
+            // (round 6: the four voxels of a round come in ONE 16-byte load of labels and one of values -- the lanes of a wave walk
+            // different boxes, so every load instruction touches 64 cache lines whatever its width; a quarter of the instructions.
+            // Voxels past x1 are loaded -- the buffers end in padding -- and masked.)
             for (int x = x0; x <= x1; x += VU_STEP) {
-                int lab[VU_STEP];
-                float val[VU_STEP];
+                const Quad<int> lab = *reinterpret_cast<const Quad<int> *>(labels + row + x);
+                const Quad<float> val = *reinterpret_cast<const Quad<float> *>(vol + row + x);
 #pragma unroll
                 for (int j = 0; j < VU_STEP; ++j) {
-                    const size_t p = row + min(x + j, x1);
-                    lab[j] = labels[p];
-                    val[j] = vol[p];
-                }
-#pragma unroll
-                for (int j = 0; j < VU_STEP; ++j) {
-                    const bool mine = lab[j] == k && x + j <= x1;
+                    const bool mine = lab.v[j] == k && x + j <= x1;
                     sz = sz + (mine ? fz : 0.f);
                     sy = sy + (mine ? fy : 0.f);
                     sx = sx + (mine ? (float)(x + j) : 0.f);
-                    sv = sv + (mine ? val[j] : 0.f);
+                    sv = sv + (mine ? val.v[j] : 0.f);
                     cnt += mine ? 1 : 0;
                 }
             }
@@ -1101,6 +1103,28 @@ __device__ __forceinline__ void cc_union(int32_t *parent, int a, int b)
             b = t;
         }
         int old = atomicMin(&parent[a], b);
+        if (old == a) return;
+        a = old;
+    }
+}
+
+// union with the two finds walked together (both loads of a step in flight at once: half the dependent trips of cc_union)
+__device__ __forceinline__ void cc_union_pair(int32_t *parent, int a, int b)
+{
+    while (true) {
+        while (true) {
+            const int pa = parent[a], pb = parent[b];
+            if (pa == a && pb == b) break;
+            a = pa;
+            b = pb;
+        }
+        if (a == b) return;
+        if (a < b) {
+            const int t = a;
+            a = b;
+            b = t;
+        }
+        const int old = atomicMin(&parent[a], b);
         if (old == a) return;
         a = old;
     }
@@ -1192,21 +1216,30 @@ k_cc_merge_rows(const int32_t *__restrict__ labels, int32_t *parent, int D, int 
         b[r] = rl[r] == l;
         c[r] = lane_next(rl[r], -1) == l;
     }
-    if (!(inx && lane >= 1 && lane <= MR_SPAN) || l == 0) return;           // background is never joined
+    // the unions a voxel asks for -- at most nine, mostly none to two -- are collected and done in ROUNDS: in a round every lane
+    // that still has one does its next union, all of them side by side.  (Written as nine call sites, each was executed by the
+    // wave as soon as ONE lane needed it: six to nine dependent chains of loads per wave instead of two or three.)
+    const bool mine = inx && lane >= 1 && lane <= MR_SPAN && l != 0;          // background is never joined
     const int p = (int)(row + x);
-    if (left && lane == 1) cc_union(parent, p, p - 1);                        // a run that crosses into the segment
+    int t[9];
+    t[0] = (mine && left && lane == 1) ? p - 1 : -1;                           // a run that crosses into the segment
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-        if (!have[r]) continue;
         const int q = (int)(rows[r] + x);
-        if (left) {
-            if (c[r] && !b[r]) cc_union(parent, p, q + 1);
-        } else if (b[r]) {
-            cc_union(parent, p, q);
-        } else {
-            if (a[r]) cc_union(parent, p, q - 1);
-            if (c[r]) cc_union(parent, p, q + 1);
+        const bool on = mine && have[r];
+        t[1 + 2 * r] = !on ? -1 : left ? ((c[r] && !b[r]) ? q + 1 : -1) : b[r] ? q : a[r] ? q - 1 : -1;
+        t[2 + 2 * r] = (on && !left && !b[r] && c[r]) ? q + 1 : -1;
+    }
+    while (true) {
+        int q = -1;
+#pragma unroll
+        for (int j = 0; j < 9; ++j) {
+            const bool take = q < 0 && t[j] >= 0;
+            q = take ? t[j] : q;
+            t[j] = take ? -1 : t[j];
         }
+        if (!__any(q >= 0)) break;
+        if (q >= 0) cc_union_pair(parent, p, q);
     }
 }
 
