@@ -812,6 +812,10 @@ __device__ __forceinline__ bool gc_grid_expand(const GcDevice &g, GcGrid &q, int
     return accept;
 }
 
+// INVARIANT of this kernel: its grid barrier (GcGrid::sync) orders NOTHING but agent-scope accesses -- relaxed atomics
+// plus s_waitcnt, no release / acquire fences, no cache maintenance.  Every word one workgroup writes and another reads between two
+// barriers therefore MUST go through ld() / st() / the atomics of this file (agent scope: they bypass the non-coherent per-CU L1 and
+// per-XCD L2 paths).  A plain load or store of shared data added here would be a silent race across XCDs.
 __global__ void __launch_bounds__(GC_THREADS) k_alpha_expansion_grid(GcDevice g, GcGridCtl *ctl)
 {
     if (g.K_dev) g.K = min(*g.K_dev, g.K);
@@ -1002,6 +1006,9 @@ int launch_alpha_expansion(GcProblem p, const int32_t *arc_start, const int32_t 
         // a GPU, IMSEGM_GC_ONE_WORKGROUP=1 avoids the wait where they must.
         static std::mutex one_at_a_time[IMSEGM_MAX_DEVICES];
         static int cus[IMSEGM_MAX_DEVICES] = { 0 };
+        // a launch that gave up (the device is shared: two seconds lost) is remembered per device: the next cuts go straight to
+        // the single workgroup and the grid is tried again after a while, instead of paying the wait on every cut
+        static int sit_out[IMSEGM_MAX_DEVICES] = { 0 };
         const bool known = dev >= 0 && dev < IMSEGM_MAX_DEVICES;
         std::unique_lock<std::mutex> guard;
         if (known) guard = std::unique_lock<std::mutex>(one_at_a_time[dev]);
@@ -1012,7 +1019,11 @@ int launch_alpha_expansion(GcProblem p, const int32_t *arc_start, const int32_t 
             HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)k_alpha_expansion_grid, GC_THREADS, 0));
             cus[dev] = prop.cooperativeLaunch && per_cu >= 1 ? prop.multiProcessorCount : -1;
         }
-        const int n_cu = known ? cus[dev] : -1;
+        int n_cu = known ? cus[dev] : -1;
+        if (known && sit_out[dev] > 0) {
+            --sit_out[dev];
+            n_cu = -1;
+        }
         if (n_cu > 0) {
             GcGridCtl *ctl = reinterpret_cast<GcGridCtl *>(wb + gc_ctl_offset(p.K, p.E));
             HIP_TRY(hipMemsetAsync(ctl, 0, sizeof(GcGridCtl), st));
@@ -1028,6 +1039,7 @@ int launch_alpha_expansion(GcProblem p, const int32_t *arc_start, const int32_t 
             HIP_TRY(hipStreamSynchronize(st));
             if (!poisoned) return 0;
             g_grid_fallbacks.fetch_add(1);
+            if (known && !knobs().gc_grid_test_absent) sit_out[dev] = 16;
             // (not all workgroups of the grid were resident: the single workgroup below starts from scratch)
         }
         if (guard.owns_lock()) guard.unlock();
