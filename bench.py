@@ -869,8 +869,9 @@ def bench_color2d(args, group, cfg, quick=False):
     images = [host_image(im, args.pinned_input) for im in images]
     # (whole multiples of the images in flight: completions come in groups of that size, and a window that cuts a group in two
     # reads too fast -- config 3 with 3 steps and 2 in flight showed 40 ms per image where 8 steps show 58)
-    steps = args.steps if (args.steps is not None and not quick) else ({3: 9, 4: 24}[cfg] if quick else {2: 100, 3: 12, 4: 48}[cfg])
-    warmup = args.warmup if (args.warmup is not None and not quick) else {2: 3, 3: 1, 4: 3}[cfg]
+    # (config 4 inside `other_configs`: 96 steps -- a window of 24 steps is 27 ms long and read 3.97 as well as 4.75 Gpixel/s on one box)
+    steps = args.steps if (args.steps is not None and not quick) else ({3: 9, 4: 96}[cfg] if quick else {2: 100, 3: 12, 4: 96}[cfg])
+    warmup = args.warmup if (args.warmup is not None and not quick) else {2: 3, 3: 1, 4: 6}[cfg]
     # (config 3: 80 against 73 Mpixels/s with two; config 4: steps of 8 images in one launch chain each, three of them in flight --
     # twelve when the images go one by one, --batch-images 0)
     inflight = args.inflight if args.inflight > 0 else {2: 4, 3: 3, 4: 12 if args.batch_images == 0 else 3}[cfg]
