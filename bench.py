@@ -874,7 +874,8 @@ def bench_color2d(args, group, cfg, quick=False):
     warmup = args.warmup if (args.warmup is not None and not quick) else {2: 3, 3: 1, 4: 6}[cfg]
     # (config 3: 80 against 73 Mpixels/s with two; config 4: steps of 8 images in one launch chain each, three of them in flight --
     # twelve when the images go one by one, --batch-images 0)
-    inflight = args.inflight if args.inflight > 0 else {2: 4, 3: 3, 4: 12 if args.batch_images == 0 else 3}[cfg]
+    # (config 4, round 6: FOUR batches in flight -- 4.34 - 6.08 against 4.24 - 4.76 Gpixel/s with three, alternating on one box, twelve runs)
+    inflight = args.inflight if args.inflight > 0 else {2: 4, 3: 3, 4: 12 if args.batch_images == 0 else 4}[cfg]
     if group.distributed and world > 1:
         # worker threads of a rank: no more than the CPUs it has been placed on (the NUMA node of its GPU, distributed.Group)
         from pyimsegm_amd.distributed import worker_threads_per_rank
