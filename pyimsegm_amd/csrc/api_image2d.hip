@@ -284,6 +284,7 @@ int imsegm_image2d_slic(imsegm_image2d *im, int minmax_normalize, int n_segments
     ctx->end(sp_all);
     im->n_labels = n_labels;
     im->have_labels = true;
+    im->labels_connected = false;
     im->graph_ready = false;
     if (n_labels_out) *n_labels_out = n_labels;
     return 0;
@@ -315,6 +316,7 @@ int imsegm_image2d_set_labels(imsegm_image2d *im, const int32_t *labels, int n_l
     HIP_TRY(hipStreamSynchronize(im->ctx->stream));
     im->n_labels = n_labels;
     im->have_labels = true;
+    im->labels_connected = false;
     im->graph_ready = false;
     return 0;
 }
@@ -344,6 +346,7 @@ int imsegm_image2d_enforce_connectivity(imsegm_image2d *im, const int32_t *label
         return -1;
     im->n_labels = n_labels;
     im->have_labels = true;
+    im->labels_connected = false;
     im->graph_ready = false;
     if (n_labels_out) *n_labels_out = n_labels;
     return 0;

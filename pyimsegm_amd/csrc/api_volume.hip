@@ -174,6 +174,7 @@ int imsegm_volume_slic(imsegm_image2d *im, int n_segments, double compactness, c
     ctx->end(sp_all);
     im->n_labels = n_labels;
     im->have_labels = true;
+    im->labels_connected = enforce_connectivity != 0;
     im->graph_ready = false;
     if (n_labels_out) *n_labels_out = n_labels;
     return 0;
@@ -191,7 +192,14 @@ int imsegm_volume_label_cc(imsegm_image2d *im, int *n_labels_out)
     const size_t n = im->n;
     if (im->conn_i32.ensure(conn_i32_bytes(n)) || im->conn_u8.ensure(2 * n + 64)) return -1;
     ConnWork w = make_conn_work(im);
-    if (launch_label_cc(im->labels.as<int32_t>(), im->D, im->H, im->W, w.parent, w.newlabel, w.blocksum, w.counters, st)) return -1;
+    if (im->labels_connected && !knobs().label_general && (size_t)im->n_labels <= n) {
+        // the map the connectivity pass wrote: nothing to join, the labels are numbered by their first voxels (connectivity.hip)
+        if (launch_label_connected(im->labels.as<int32_t>(), n, im->n_labels, w.newlabel, reinterpret_cast<uint32_t *>(w.visited), w.blocksum,
+                                   w.counters + 16, w.counters, st))
+            return -1;
+    } else if (launch_label_cc(im->labels.as<int32_t>(), im->D, im->H, im->W, w.parent, w.newlabel, w.blocksum, w.counters, st)) {
+        return -1;
+    }
     int total = 0;
     HIP_TRY(hipMemcpyAsync(&total, w.counters, 4, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));

@@ -28,6 +28,8 @@ struct Knobs {
         adjacency_table,       // IMSEGM_ADJACENCY_TABLE: the neighbour table of a label volume's graph for every K (default: beyond 46 000 labels)
         cc_merge_full,         // IMSEGM_CC_MERGE_FULL: the voxel-by-voxel merge passes of rounds 2 - 4 -- measure.label with thirteen unions per voxel, connectivity with
                                // its per-voxel loads -- instead of the row-segment kernels (tests, A/B)
+        label_general,         // IMSEGM_LABEL_GENERAL: measure.label of a volume always by union-find, also where the label map is known to come from
+                               // the connectivity pass (tests, A/B: connectivity.hip launch_label_connected)
         sep_wide_tile;         // IMSEGM_SEP_WIDE_TILE: the separable kernels of side 33 on the 64 x 16 tile of round 4's first half (tests, A/B)
     int brick_cap;             // IMSEGM_BRICK_CAP (0: default)
     int gc_lds_level;          // IMSEGM_GC_LDS_LEVEL (default 4)
@@ -186,6 +188,43 @@ __host__ __device__ __forceinline__ double fix_value(long long hi, long long lo,
 // whole wave (wave_shr:1 / wave_shl:1), no LDS round trip as __shfl_up / __shfl_down take
 __device__ __forceinline__ int lane_prev(int v, int first) { return __builtin_amdgcn_update_dpp(first, v, 0x138, 0xf, 0xf, false); }
 __device__ __forceinline__ int lane_next(int v, int last) { return __builtin_amdgcn_update_dpp(last, v, 0x130, 0xf, 0xf, false); }
+
+// Union-find with the smaller index as the root (atomicMin on the parent of the larger root), TWO unions of a lane side by side:
+// (a0, b0) and, where a1 >= 0, (a1, b1).  The four walks to the roots advance together -- four loads in flight per step instead
+// of the one of a find after the other -- and a union whose atomicMin lost a race goes on from what it saw.  Unions of one lane
+// may touch the same sets: atomicMin keeps every interleaving a forest whose roots are the smallest indices.
+__device__ __forceinline__ void union2_min_root(int32_t *parent, int a0, int b0, int a1, int b1)
+{
+    bool on0 = a0 >= 0, on1 = a1 >= 0;
+    while (on0 || on1) {
+        const int pa0 = on0 ? parent[a0] : 0, pb0 = on0 ? parent[b0] : 0;
+        const int pa1 = on1 ? parent[a1] : 0, pb1 = on1 ? parent[b1] : 0;
+        if (on0) {
+            if (pa0 == a0 && pb0 == b0) {
+                const int hi = max(a0, b0), lo = min(a0, b0);
+                const int old = hi == lo ? hi : atomicMin(&parent[hi], lo);
+                on0 = old != hi;
+                a0 = old;
+                b0 = lo;
+            } else {
+                a0 = pa0;
+                b0 = pb0;
+            }
+        }
+        if (on1) {
+            if (pa1 == a1 && pb1 == b1) {
+                const int hi = max(a1, b1), lo = min(a1, b1);
+                const int old = hi == lo ? hi : atomicMin(&parent[hi], lo);
+                on1 = old != hi;
+                a1 = old;
+                b1 = lo;
+            } else {
+                a1 = pa1;
+                b1 = pb1;
+            }
+        }
+    }
+}
 
 __device__ __forceinline__ long long wave_sum_i64(long long v)
 {

@@ -150,7 +150,7 @@ k_ccl_merge(const int32_t *__restrict__ labels, const uint8_t *__restrict__ stat
 constexpr int CR_SPAN = 62;
 
 __global__ void __launch_bounds__(256)
-k_ccl_init_rows(const int32_t *__restrict__ labels, int32_t *__restrict__ parent, int H, int W)
+k_ccl_init_rows(const int32_t *__restrict__ labels, int32_t *__restrict__ parent, int32_t *__restrict__ csize, int H, int W)
 {
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int x = (blockIdx.x * 4 + wave) * CR_SPAN + lane - 1;
@@ -164,39 +164,61 @@ k_ccl_init_rows(const int32_t *__restrict__ labels, int32_t *__restrict__ parent
     const unsigned long long below = starts & ((2ULL << lane) - 1ULL);     // (lane <= 62)
     const int start_lane = 63 - __clzll((long long)below);
     parent[row + x] = (int)(row + x) - (lane - start_lane);
+    if (start_lane == lane) csize[row + x] = 0;          // (a root is the first voxel of a run: the sizes k_ccl_flatten_sizes adds up)
 }
+
+// CR_ROWS rows of the slice per wave: the row above the first and the rows behind are loaded once for all of them, and the unions
+// of a lane over its rows -- a bit each in `todo`: 3 r + 0 left (a run that crosses into the segment), + 1 up, + 2 behind -- are
+// done two at a time (union2_min_root), every lane that still has some side by side.  (One row per wave, one union per lane and
+// round: 10.4 ms at 2^30 voxels, the latency of one chain of dependent loads after the other.)
+constexpr int CR_ROWS = 4;
 
 __global__ void __launch_bounds__(256)
 k_ccl_merge_rows(const int32_t *__restrict__ labels, int32_t *parent, int D, int H, int W)
 {
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int x = (blockIdx.x * 4 + wave) * CR_SPAN + lane - 1;
-    const int y = blockIdx.y, z = blockIdx.z;
+    const int y0 = blockIdx.y * CR_ROWS, z = blockIdx.z;
     const bool inx = x >= 0 && x < W;
-    const size_t plane = (size_t)H * W, row = (size_t)z * plane + (size_t)y * W;
-    const int l = inx ? labels[row + x] : -5;
-    const int up = (inx && y > 0) ? labels[row - W + x] : -6;
-    const int back = (inx && z > 0) ? labels[row - plane + x] : -7;
-    const bool cont = lane_prev(l, -8) == l;                                // the left neighbour carries the same label
-    const bool up_left = lane_prev(up, -8) == l, back_left = lane_prev(back, -8) == l;
-    // the (at most three) unions of a voxel in rounds: every lane that still has one does its next, side by side
-    const bool mine = inx && lane >= 1 && lane <= CR_SPAN;
-    const int p = (int)(row + x);
-    int t[3];
-    t[0] = (mine && cont && lane == 1) ? p - 1 : -1;                          // a run that crosses into the segment
-    // one union per pair of overlapping runs: skipped when the pair to the left (p - 1, q - 1) carries the same two runs
-    t[1] = (mine && up == l && !(cont && up_left)) ? p - W : -1;
-    t[2] = (mine && back == l && !(cont && back_left)) ? (int)(row - plane + x) : -1;
-    while (true) {
-        int q = -1;
+    const int plane = H * W;
+    const size_t row0 = (size_t)z * plane + (size_t)y0 * W;
+    int l[CR_ROWS + 1], bk[CR_ROWS];                          // l[0]: the row above the first; fillers differ from every label (>= -1)
+    l[0] = (inx && y0 > 0) ? labels[row0 - W + x] : -6;
 #pragma unroll
-        for (int j = 0; j < 3; ++j) {
-            const bool take = q < 0 && t[j] >= 0;
-            q = take ? t[j] : q;
-            t[j] = take ? -1 : t[j];
+    for (int r = 0; r < CR_ROWS; ++r) {
+        const bool rowok = y0 + r < H;
+        l[1 + r] = (inx && rowok) ? labels[row0 + (size_t)r * W + x] : -5;
+        bk[r] = (inx && rowok && z > 0) ? labels[row0 - plane + (size_t)r * W + x] : -7;
+    }
+    int lp[CR_ROWS + 1];
+#pragma unroll
+    for (int r = 0; r <= CR_ROWS; ++r) lp[r] = lane_prev(l[r], -8);
+    const bool seg = inx && lane >= 1 && lane <= CR_SPAN;
+    unsigned todo = 0;
+#pragma unroll
+    for (int r = 0; r < CR_ROWS; ++r) {
+        const int cur = l[1 + r];
+        const bool mine = seg && y0 + r < H;
+        const bool cont = lp[1 + r] == cur;                    // the left neighbour carries the same label
+        const bool up_left = lp[r] == cur, back_left = lane_prev(bk[r], -8) == cur;
+        // one union per pair of overlapping runs: skipped when the pair to the left (p - 1, q - 1) carries the same two runs
+        if (mine && cont && lane == 1) todo |= 1u << (3 * r);
+        if (mine && l[r] == cur && !(cont && up_left)) todo |= 2u << (3 * r);
+        if (mine && bk[r] == cur && !(cont && back_left)) todo |= 4u << (3 * r);
+    }
+    const int p0 = (int)(row0 + x);
+    while (__any(todo != 0)) {
+        int a[2] = { -1, -1 }, b[2] = { -1, -1 };
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            if (!todo) continue;
+            const int bit = __ffs(todo) - 1;
+            todo &= todo - 1;
+            const int r = bit / 3, k = bit - 3 * r;
+            a[j] = p0 + r * W;
+            b[j] = a[j] - (k == 0 ? 1 : k == 1 ? W : plane);
         }
-        if (!__any(q >= 0)) break;
-        if (q >= 0) uf_union_pair(parent, p, q);
+        union2_min_root(parent, a[0], b[0], a[1], b[1]);
     }
 }
 
@@ -208,6 +230,63 @@ __global__ void __launch_bounds__(256) k_ccl_flatten(int32_t *parent, const uint
     int r = uf_find(parent, p);
     parent[p] = r;
     if (r == p) csize[p] = 0;
+}
+
+// Round 6, first round of a volume: flatten and component sizes in one pass (csize zeroed at the run starts by k_ccl_init_rows).
+// Four voxels per lane (16-byte load / store), their walks to the root side by side; the sizes by RUNS of equal roots along the
+// 256 voxels of a wave -- a lane whose four voxels agree joins the run of its left neighbour, the first lane of a run adds the
+// run's length with one atomic; a lane with a root change inside adds its pieces itself.
+__global__ void __launch_bounds__(256) k_ccl_flatten_sizes(int32_t *parent, int32_t *csize, int n)
+{
+    const int lane = threadIdx.x & 63;
+    const int p = (blockIdx.x * 256 + threadIdx.x) * 4;
+    const bool in = p < n, full = p + 4 <= n;
+    int r[4];
+    if (full) {
+        const int4 q = *reinterpret_cast<const int4 *>(parent + p);
+        r[0] = q.x; r[1] = q.y; r[2] = q.z; r[3] = q.w;
+    } else {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) r[c] = p + c < n ? parent[p + c] : 0;
+    }
+    while (true) {
+        int q[4];
+        bool moved = false;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) q[c] = parent[r[c]];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            moved |= q[c] != r[c];
+            r[c] = q[c];
+        }
+        if (!moved) break;
+    }
+    if (full) {
+        *reinterpret_cast<int4 *>(parent + p) = make_int4(r[0], r[1], r[2], r[3]);
+    } else {
+        for (int c = 0; p + c < n; ++c) parent[p + c] = r[c];
+    }
+    const bool uniform = full && r[0] == r[1] && r[1] == r[2] && r[2] == r[3];
+    const int key = uniform ? r[0] : -1 - lane;                       // (a mixed lane is a run of its own)
+    const bool start = lane == 0 || lane_prev(key, -100) != key;
+    const unsigned long long starts = __ballot(start);
+    if (uniform && start) {
+        const unsigned long long above = lane == 63 ? 0ULL : starts >> (lane + 1);
+        const int lanes = above ? __ffsll((long long)above) : 64 - lane;
+        atomicAdd(&csize[r[0]], 4 * lanes);
+    }
+    if (in && !uniform) {
+        int run = 0;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            if (p + c >= n) break;
+            run++;
+            if (c == 3 || p + c + 1 >= n || r[c + 1] != r[c]) {
+                atomicAdd(&csize[r[c]], run);
+                run = 0;
+            }
+        }
+    }
 }
 
 // component sizes: wave-aggregated atomics (runs of equal roots are the common case)
@@ -289,12 +368,15 @@ k_oversize_commit(int32_t *parent, uint8_t *state, int32_t *csize_next, const in
 }
 
 // ---- consecutive labels for kept components: rank of kept roots in raster order -----------------
-constexpr int SCAN_PER_THREAD = 16;
-constexpr int SCAN_BLOCK = 256 * SCAN_PER_THREAD;
+// A workgroup takes SCAN_BLOCK voxels as SCAN_TILES tiles of 1 024: four consecutive voxels per lane through one 16-byte load, a
+// wave reads 1 KB contiguous (until round 6 a lane took 16 consecutive voxels one by one -- every load instruction of a wave touched
+// 64 cache lines, and the assigning pass read them twice: 2.3 + 4.2 ms at 2^30 voxels).
+constexpr int SCAN_TILES = 4;
+constexpr int SCAN_BLOCK = SCAN_TILES * 1024;
 
-__device__ __forceinline__ int block_exclusive_scan(int v, int *total)
+template <int NW> __device__ __forceinline__ int block_exclusive_scan(int v, int *total)
 {
-    __shared__ int wsum[4];
+    __shared__ int wsum[NW];
     int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     int incl = v;
 #pragma unroll
@@ -304,52 +386,101 @@ __device__ __forceinline__ int block_exclusive_scan(int v, int *total)
     }
     if (lane == 63) wsum[wave] = incl;
     __syncthreads();
-    int base = 0;
-    for (int w = 0; w < wave; ++w) base += wsum[w];
-    *total = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    int base = 0, all = 0;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) {
+        base += w < wave ? wsum[w] : 0;
+        all += wsum[w];
+    }
+    *total = all;
     __syncthreads();
     return base + incl - v;
 }
 
-// ASSIGN: second pass -- kept roots receive their labels, the roots of small components are appended to `list`
+// !ASSIGN: first pass -- kept roots counted per workgroup; components that reach `max_size` raise counters[CNT_OVER] (the fast
+//          path's check that no component has to be truncated -- k_find_oversize in the rounds of the general path);
+// ASSIGN:  second pass -- kept roots receive their labels, the roots of small components are appended to `list` (one atomic per
+//          wave that has any; the order of the list is free -- k_small_order sorts it by size class)
 template <bool ASSIGN>
 __global__ void __launch_bounds__(256)
-k_kept_scan(const int32_t *__restrict__ parent, const int32_t *__restrict__ csize, int n, int min_size,
+k_kept_scan(const int32_t *__restrict__ parent, const int32_t *__restrict__ csize, int n, int min_size, int max_size,
             int32_t *blocksum, int32_t *newlabel, int start_label, int32_t *list, int32_t *counters)
 {
-    int p0 = blockIdx.x * SCAN_BLOCK + threadIdx.x * SCAN_PER_THREAD;
-    int cnt = 0;
-    for (int j = 0; j < SCAN_PER_THREAD; ++j) {
-        int p = p0 + j;
-        if (p < n && parent[p] == p && csize[p] >= min_size) cnt++;
+    const int base = blockIdx.x * SCAN_BLOCK + threadIdx.x * 4;
+    unsigned kept = 0, small = 0;                   // bit 4 * tile + c
+    int cnt[SCAN_TILES], n_small = 0, n_over = 0;
+#pragma unroll
+    for (int i = 0; i < SCAN_TILES; ++i) {
+        const int p = base + i * 1024;
+        int v[4];
+        if (p + 4 <= n) {
+            const int4 q = *reinterpret_cast<const int4 *>(parent + p);
+            v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
+        } else {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) v[c] = p + c < n ? parent[p + c] : -1;
+        }
+        cnt[i] = 0;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            if (v[c] != p + c) continue;
+            const int size = csize[p + c];
+            if (size >= min_size) {
+                kept |= 1u << (4 * i + c);
+                cnt[i]++;
+            } else {
+                small |= 1u << (4 * i + c);
+                n_small++;
+            }
+            n_over += size >= max_size;
+        }
     }
-    int total;
-    int excl = block_exclusive_scan(cnt, &total);
     if (!ASSIGN) {
+        int total;
+        block_exclusive_scan<4>(cnt[0] + cnt[1] + cnt[2] + cnt[3], &total);
         if (threadIdx.x == 0) blocksum[blockIdx.x] = total;
+        if (n_over) atomicAdd(&counters[CNT_OVER], n_over);
     } else {
-        int rank = blocksum[blockIdx.x] + excl;
-        for (int j = 0; j < SCAN_PER_THREAD; ++j) {
-            int p = p0 + j;
-            if (p < n && parent[p] == p) {
-                if (csize[p] >= min_size) newlabel[p] = start_label + rank++;
-                else list[atomicAdd(&counters[CNT_SMALL], 1)] = p;
+        // the small roots of the wave behind one another in the list
+        int incl = n_small;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int t = __shfl_up(incl, off, 64);
+            if ((int)(threadIdx.x & 63) >= off) incl += t;
+        }
+        const int wave_total = __shfl(incl, 63, 64);
+        int at = 0;
+        if (wave_total) {
+            if ((threadIdx.x & 63) == 63) at = atomicAdd(&counters[CNT_SMALL], wave_total);
+            at = __shfl(at, 63, 64) + incl - n_small;
+        }
+        int rank0 = blocksum[blockIdx.x];
+#pragma unroll
+        for (int i = 0; i < SCAN_TILES; ++i) {
+            int total;
+            int rank = rank0 + block_exclusive_scan<4>(cnt[i], &total);
+            rank0 += total;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const int p = base + i * 1024 + c;
+                if (kept >> (4 * i + c) & 1u) newlabel[p] = start_label + rank++;
+                if (small >> (4 * i + c) & 1u) list[at++] = p;
             }
         }
     }
 }
 
 // exclusive scan of the per-block counts by one workgroup; total -> counters[CNT_KEPT]
-__global__ void __launch_bounds__(256) k_scan_blocksums(int32_t *blocksum, int nblocks, int32_t *counters)
+__global__ void __launch_bounds__(1024) k_scan_blocksums(int32_t *blocksum, int nblocks, int32_t *counters)
 {
     __shared__ int carry;
     if (threadIdx.x == 0) carry = 0;
     __syncthreads();
-    for (int base = 0; base < nblocks; base += 256) {
+    for (int base = 0; base < nblocks; base += 1024) {
         int i = base + threadIdx.x;
         int v = i < nblocks ? blocksum[i] : 0;
         int total;
-        int excl = block_exclusive_scan(v, &total);
+        int excl = block_exclusive_scan<16>(v, &total);
         if (i < nblocks) blocksum[i] = carry + excl;
         __syncthreads();
         if (threadIdx.x == 0) carry += total;
@@ -675,6 +806,117 @@ k_write_labels(const int32_t *__restrict__ parent, const int32_t *__restrict__ n
     out[p] = newlabel[parent[p]];
 }
 
+// ---- skimage.measure.label of the map this file wrote (superpixels.py:104-111: slic, then measure.label) -------------------------
+// After the connectivity pass every label > 0 is ONE 6-connected set: a kept component, plus the small components that were merged
+// into it through a 6-neighbour (label 0 besides -- start_label 0's first segment and the small components that met no labelled
+// neighbour -- is measure.label's background whatever its shape).  A 6-connected set is one component of the full neighbourhood, so
+// measure.label has nothing to join: it numbers the labels 1, 2, ... in the raster order of their FIRST voxels and writes 0 for
+// label 0.  That is all this does -- first voxel per label, the rank of the first voxels (a bit per voxel, counted per 4 096 and
+// scanned), one pass that rewrites the map -- instead of a union-find over 2^30 voxels with thirteen neighbours each (volume.hip
+// launch_label_cc, the path of every other label map; tests/test_gpu_volume.py holds the two against each other).
+__global__ void __launch_bounds__(256) k_first_fill(int32_t *first, int n_labels)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n_labels) first[i] = 0x7fffffff;
+}
+
+// four voxels per lane; only where a run of equal labels starts (in flat order: a later voxel of a run cannot be the first) the
+// label's entry is looked at, and only an earlier voxel than the one it holds goes to the atomic -- workgroups start in raster
+// order, so next to none do
+__global__ void __launch_bounds__(256) k_first_voxel(const int32_t *__restrict__ labels, int n, int n_labels, int32_t *first)
+{
+    const int p = (blockIdx.x * 256 + threadIdx.x) * 4;
+    int v[4];
+    if (p + 4 <= n) {
+        const int4 q = *reinterpret_cast<const int4 *>(labels + p);
+        v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
+    } else {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) v[c] = p + c < n ? labels[p + c] : -1;
+    }
+    int before = lane_prev(v[3], -2);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const int l = v[c];
+        if (l > 0 && l < n_labels && l != before &&
+            p + c < __hip_atomic_load(first + l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+            atomicMin(first + l, p + c);
+        before = l;
+    }
+}
+
+__global__ void __launch_bounds__(256) k_first_mark(const int32_t *__restrict__ first, int n_labels, uint32_t *bitmap)
+{
+    const int l = blockIdx.x * 256 + threadIdx.x;
+    if (l < 1 || l >= n_labels) return;
+    const int f = first[l];
+    if (f != 0x7fffffff) atomicOr(bitmap + (f >> 5), 1u << (f & 31));
+}
+
+// set bits per 4 096 voxels (128 words): one wave per block of the scan
+__global__ void __launch_bounds__(256) k_first_block_counts(const uint32_t *__restrict__ bitmap, int nblocks, int32_t *blocksum)
+{
+    const int blk = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (blk >= nblocks) return;
+    const uint2 w = *reinterpret_cast<const uint2 *>(bitmap + (size_t)blk * 128 + 2 * lane);
+    const int c = wave_sum_i32(__popc(w.x) + __popc(w.y));
+    if (lane == 0) blocksum[blk] = c;
+}
+
+// first[l] -> the new number of label l (in place): 1 + the first voxels before its own
+__global__ void __launch_bounds__(256)
+k_first_rank(int32_t *first, int n_labels, const uint32_t *__restrict__ bitmap, const int32_t *__restrict__ blocksum)
+{
+    const int l = blockIdx.x * 256 + threadIdx.x;
+    if (l >= n_labels) return;
+    const int f = first[l];
+    if (l == 0 || f == 0x7fffffff) {
+        first[l] = 0;
+        return;
+    }
+    const int blk = f >> 12, word = f >> 5;
+    int rank = blocksum[blk];
+    for (int w = blk * 128; w < word; ++w) rank += __popc(bitmap[w]);
+    rank += __popc(bitmap[word] & ((1u << (f & 31)) - 1u));
+    first[l] = 1 + rank;
+}
+
+__global__ void __launch_bounds__(256) k_relabel(int32_t *labels, int n, int n_labels, const int32_t *__restrict__ remap)
+{
+    const int p = (blockIdx.x * 256 + threadIdx.x) * 4;
+    if (p >= n) return;
+    if (p + 4 <= n) {
+        int4 q = *reinterpret_cast<const int4 *>(labels + p);
+        q.x = (q.x > 0 && q.x < n_labels) ? remap[q.x] : 0;
+        q.y = (q.y > 0 && q.y < n_labels) ? remap[q.y] : 0;
+        q.z = (q.z > 0 && q.z < n_labels) ? remap[q.z] : 0;
+        q.w = (q.w > 0 && q.w < n_labels) ? remap[q.w] : 0;
+        *reinterpret_cast<int4 *>(labels + p) = q;
+    } else {
+        for (int c = 0; p + c < n; ++c) {
+            const int l = labels[p + c];
+            labels[p + c] = (l > 0 && l < n_labels) ? remap[l] : 0;
+        }
+    }
+}
+
+int launch_label_connected(int32_t *labels_inout, size_t n_voxels, int n_labels, int32_t *first, uint32_t *bitmap, int32_t *blocksum,
+                           int32_t *counters, int32_t *total_dev, hipStream_t st)
+{
+    const int n = (int)n_voxels, nblocks = cdiv(n, 4096), quads = cdiv(cdiv(n, 4), 256);
+    HIP_TRY(hipMemsetAsync(bitmap, 0, (size_t)nblocks * 512, st));
+    hipLaunchKernelGGL(k_first_fill, cdiv(n_labels, 256), 256, 0, st, first, n_labels);
+    hipLaunchKernelGGL(k_first_voxel, quads, 256, 0, st, labels_inout, n, n_labels, first);
+    hipLaunchKernelGGL(k_first_mark, cdiv(n_labels, 256), 256, 0, st, first, n_labels, bitmap);
+    hipLaunchKernelGGL(k_first_block_counts, cdiv(nblocks, 4), 256, 0, st, bitmap, nblocks, blocksum);
+    hipLaunchKernelGGL(k_scan_blocksums, 1, 1024, 0, st, blocksum, nblocks, counters);
+    hipLaunchKernelGGL(k_first_rank, cdiv(n_labels, 256), 256, 0, st, first, n_labels, bitmap, blocksum);
+    hipLaunchKernelGGL(k_relabel, quads, 256, 0, st, labels_inout, n, n_labels, first);
+    HIP_TRY(hipMemcpyAsync(total_dev, counters + CNT_KEPT, sizeof(int32_t), hipMemcpyDeviceToDevice, st));
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
 // CCL + sizes + oversize detection for the currently active pixels
 template <bool ALL>
 static void conn_ccl_round(const int32_t *labels_in, int D, int H, int W, int max_size, const ConnWork &w, uint8_t *state,
@@ -682,23 +924,26 @@ static void conn_ccl_round(const int32_t *labels_in, int D, int H, int W, int ma
 {
     const int n = D * H * W, grid = cdiv(n, 256);
     if (ALL && H <= 65535 && D <= 65535 && !knobs().cc_merge_full) {
-        const dim3 rows(cdiv(W, 4 * CR_SPAN), H, D);
-        hipLaunchKernelGGL(k_ccl_init_rows, rows, 256, 0, st, labels_in, w.parent, H, W);
-        hipLaunchKernelGGL(k_ccl_merge_rows, rows, 256, 0, st, labels_in, w.parent, D, H, W);
+        const dim3 rows(cdiv(W, 4 * CR_SPAN), H, D), row_groups(cdiv(W, 4 * CR_SPAN), cdiv(H, CR_ROWS), D);
+        hipLaunchKernelGGL(k_ccl_init_rows, rows, 256, 0, st, labels_in, w.parent, w.csize, H, W);
+        hipLaunchKernelGGL(k_ccl_merge_rows, row_groups, 256, 0, st, labels_in, w.parent, D, H, W);
+        hipLaunchKernelGGL(k_ccl_flatten_sizes, cdiv(cdiv(n, 4), 256), 256, 0, st, w.parent, w.csize, n);
+        return;
     } else {
         hipLaunchKernelGGL(k_ccl_init<ALL>, grid, 256, 0, st, labels_in, state, w.parent, n, W);
         hipLaunchKernelGGL(k_ccl_merge<ALL>, grid, 256, 0, st, labels_in, state, w.parent, D, H, W);
     }
     hipLaunchKernelGGL(k_ccl_flatten<ALL>, grid, 256, 0, st, w.parent, state, w.csize, n);
     hipLaunchKernelGGL(k_comp_size<ALL>, grid, 256, 0, st, w.parent, state, w.csize, n);
-    hipLaunchKernelGGL(k_find_oversize<ALL>, grid, 256, 0, st, w.parent, state, w.csize, n, max_size, w.list, w.counters);
+    // (every voxel active = the speculative first round: the first pass of k_kept_scan counts the oversize components)
+    if (!ALL) hipLaunchKernelGGL(k_find_oversize<ALL>, grid, 256, 0, st, w.parent, state, w.csize, n, max_size, w.list, w.counters);
 }
 
 // everything after the component structure is final: consecutive labels for kept components,
 // `adjacent` of the small ones (exact BFS emulation), pointer resolution, label write.
 // No host round trip: list lengths stay on the device, the kernels loop over them.
 static int conn_tail(const int32_t *csize_final, int32_t *adjptr, int D, int H, int W, int min_size, int start_label,
-                     const ConnWork &w, int32_t *labels_out, hipStream_t st, bool counters_are_zero)
+                     const ConnWork &w, int32_t *labels_out, hipStream_t st, bool counters_are_zero, int oversize_from = 0x7fffffff)
 {
     const int n = D * H * W, grid = cdiv(n, 256);
     const int nblocks = cdiv(n, SCAN_BLOCK);
@@ -709,10 +954,10 @@ static int conn_tail(const int32_t *csize_final, int32_t *adjptr, int D, int H, 
         HIP_TRY(hipMemsetAsync(w.counters + CNT_SMALL, 0, 2 * sizeof(int32_t), st));
         HIP_TRY(hipMemsetAsync(w.counters + CNT_FALLBACK, 0, 3 * sizeof(int32_t), st));     // FALLBACK, BIG, LITTLE
     }
-    hipLaunchKernelGGL(k_kept_scan<false>, nblocks, 256, 0, st, w.parent, csize_final, n, min_size, w.blocksum,
+    hipLaunchKernelGGL(k_kept_scan<false>, nblocks, 256, 0, st, w.parent, csize_final, n, min_size, oversize_from, w.blocksum,
                        w.newlabel, start_label, w.list, w.counters);
-    hipLaunchKernelGGL(k_scan_blocksums, 1, 256, 0, st, w.blocksum, nblocks, w.counters);
-    hipLaunchKernelGGL(k_kept_scan<true>, nblocks, 256, 0, st, w.parent, csize_final, n, min_size, w.blocksum,
+    hipLaunchKernelGGL(k_scan_blocksums, 1, 1024, 0, st, w.blocksum, nblocks, w.counters);
+    hipLaunchKernelGGL(k_kept_scan<true>, nblocks, 256, 0, st, w.parent, csize_final, n, min_size, 0x7fffffff, w.blocksum,
                        w.newlabel, start_label, w.list, w.counters);
     HIP_TRY(hipMemsetAsync(w.visited, 0, n, st));
     hipLaunchKernelGGL(k_small_bbox_init, 64, 256, 0, st, bbox, w.list, w.counters, w.slotmap, capacity);
@@ -1388,7 +1633,7 @@ int launch_enforce_connectivity(const int32_t *labels_in, int D, int H, int W, l
     // (every pixel is active in this round: the kernels do not look at the state bytes)
     HIP_TRY(hipMemsetAsync(w.counters, 0, 16 * sizeof(int32_t), st));
     conn_ccl_round<true>(labels_in, D, H, W, max_size, w, state, st);
-    if (conn_tail(w.csize, w.adjptr, D, H, W, min_size, start_label, w, labels_out, st, true)) return -1;
+    if (conn_tail(w.csize, w.adjptr, D, H, W, min_size, start_label, w, labels_out, st, true, max_size)) return -1;
     HIP_TRY(hipMemcpyAsync(host_counters, w.counters, 8 * sizeof(int32_t), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
 

@@ -154,6 +154,7 @@ struct imsegm_image2d {
     int dtype = -1;
     int n_labels = 0;
     bool have_labels = false;
+    bool labels_connected = false;              // the label map is what the connectivity pass wrote: every label > 0 is ONE 6-connected set
     bool tex_ready = false;
     bool is_volume = false;
     double vol_off = 0.0, vol_scale = 1.0;      // intensity seen by the volume SLIC = (v + off) * scale

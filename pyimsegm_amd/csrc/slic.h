@@ -170,6 +170,10 @@ static inline size_t conn_i32_bytes(size_t n, size_t H = 0, size_t W = 0)
     const size_t n_tiles = ((W + 63) / 64) * ((H + 31) / 32);
     return n * 4 * 8 + ((n / 4096) + 64) * 4 + 256 + (CONN_DENSE_INTS + n_tiles * (3 * CONN_TILE_SLOTS + 1)) * 4;
 }
+// measure.label of a map whose labels > 0 are connected sets each (what launch_enforce_connectivity writes): renumbering by first
+// voxel; *total_dev = the number of labels > 0
+int launch_label_connected(int32_t *labels_inout, size_t n, int n_labels, int32_t *first, uint32_t *bitmap, int32_t *blocksum,
+                           int32_t *counters, int32_t *total_dev, hipStream_t st);
 long conn_general_runs();      // diagnostic: 2-D maps that left the tile path so far
 long gc_grid_fallbacks();      // diagnostic: grid-wide cuts given up (a workgroup not resident) and redone by the single workgroup
 int launch_enforce_connectivity(const int32_t *labels_in, int D, int H, int W, long min_size, long max_size,

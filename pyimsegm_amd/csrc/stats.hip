@@ -35,7 +35,7 @@ struct StatParams {
     int H, W, K;
     double scale_v, scale_e;      // 2^shift for the value / squared-value sums
     int planar;                   // 0: H x W x 3 interleaved, 1: three planes `plane_stride` elements apart
-    size_t plane_stride;          //    (0: one gray plane read three times)
+    size_t plane_stride;          //    (0: one gray plane -- the single-channel kernel, NC = 1)
     size_t n_pixels;              // H * W (guards the 4-byte pixel load of interleaved uint8 images)
     int u8_int;                   // uint8 image, power-of-two scales >= 1: integer block sums in the first pass
     int prescale;                 // 1: value = (raw * mul) / div before the float32 staging
@@ -55,7 +55,9 @@ struct StatParams {
 // doubles in flight plus their IEEE divisions took 248 registers, two waves per SIMD)
 template <typename T> struct StatRows { static constexpr int value = sizeof(T) == 8 ? ST_ROWS / 2 : ST_ROWS; };
 
-template <typename T, int PASS, bool U8INT>
+// NC = 1: one gray plane (the volumes, features_cython.pyx:144-219) -- one channel loaded and summed into the columns of channel 0,
+// the five quantities of the first pass (count, two limbs of the value sum, two of the squared sum) through ONE transposed reduction
+template <typename T, int PASS, bool U8INT, int NC = 3>
 __global__ void __launch_bounds__(256, 4)      // (four workgroups a CU = four waves a SIMD: the allocator aims at <= 128 registers)
 k_color_stats(const T *__restrict__ img, const int32_t *__restrict__ labels, StatParams sp,
               const float *__restrict__ mean32, long long *__restrict__ acc)
@@ -76,9 +78,9 @@ k_color_stats(const T *__restrict__ img, const int32_t *__restrict__ labels, Sta
     // uint8 image, first pass: the terms are small integers (v <= 255, v * v <= 65025 -- the float32 product of the
     // reference is exact), so the block sums are plain int32 sums and the fixed-point limbs are (sum * 2^shift, 0):
     // the same accumulator contents as the general path at a fraction of the instructions
-    static_assert(!U8INT || (PASS == 1 && sizeof(T) == 1), "integer block sums: uint8 image, first pass");
+    static_assert(!U8INT || (PASS == 1 && sizeof(T) == 1 && NC == 3), "integer block sums: uint8 colour image, first pass");
     int lab[RW];
-    float v[RW][3];
+    float v[RW][NC];
     double mul = sp.mul, div = sp.div;
     bool dead = false;
     if (sp.prescale == 2) {                      // the L2 norm of the response stays on the device (imsegm_image2d_lm_features)
@@ -93,19 +95,19 @@ k_color_stats(const T *__restrict__ img, const int32_t *__restrict__ labels, Sta
         const bool ok = (y < sp.H) && (x < sp.W);
         const size_t p = ok ? (size_t)y * sp.W + x : 0;
         lab[r] = ok ? labels[p] : 0x7fffffff;
-        if (sizeof(T) == 1 && !sp.planar && !sp.prescale && p + 1 < sp.n_pixels) {
+        if (NC == 3 && sizeof(T) == 1 && !sp.planar && !sp.prescale && p + 1 < sp.n_pixels) {
             // interleaved uint8: the three bytes of a pixel through one unaligned 32-bit load (the byte after them belongs
             // to the next pixel): a third of the load instructions and of the cache-line accesses of a wave
             uint32_t w;
             __builtin_memcpy(&w, reinterpret_cast<const uint8_t *>(img) + 3 * p, 4);
             v[r][0] = (float)(w & 0xffu);
-            v[r][1] = (float)((w >> 8) & 0xffu);
-            v[r][2] = (float)((w >> 16) & 0xffu);
+            v[r][NC > 1 ? 1 : 0] = (float)((w >> 8) & 0xffu);
+            v[r][NC > 1 ? 2 : 0] = (float)((w >> 16) & 0xffu);
             continue;
         }
 #pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            const size_t idx = sp.planar ? (size_t)c * sp.plane_stride + p : 3 * p + c;
+        for (int c = 0; c < NC; ++c) {
+            const size_t idx = NC == 1 ? p : (sp.planar ? (size_t)c * sp.plane_stride + p : 3 * p + c);
             v[r][c] = sp.prescale ? (dead ? 0.f : (float)(((double)img[idx] * mul) / div)) : load_f32(img, idx);
         }
     }
@@ -115,7 +117,7 @@ k_color_stats(const T *__restrict__ img, const int32_t *__restrict__ labels, Sta
         for (int r = 0; r < RW; ++r) mine = min(mine, lab[r]);
         if (!__any(mine != 0x7fffffff)) break;
         const int k = row16_min_i32(mine);              // uniform over the 16-lane row; 0x7fffffff: row is done
-        if (U8INT) {
+        if constexpr (U8INT) {
             int qi[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };     // n, sums of v (3), sums of v * v (3)
 #pragma unroll
             for (int r = 0; r < RW; ++r) {
@@ -166,6 +168,47 @@ k_color_stats(const T *__restrict__ img, const int32_t *__restrict__ labels, Sta
             slot = probes < ST_SLOTS ? sidx : -1;
         }
         slot = __shfl(slot, lane & 48, 64);
+        if constexpr (NC == 1) {
+            const bool live = k != 0x7fffffff;
+            const float m32 = (PASS == 2 && live) ? mean32[3 * k] : 0.f;
+            double q[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) q[j] = 0;
+#pragma unroll
+            for (int r = 0; r < RW; ++r) {
+                if (lab[r] != k || !live) continue;
+                lab[r] = 0x7fffffff;
+                const float val = v[r][0];
+                float term = PASS == 1 ? __fmul_rn(val, val) : __fsub_rn(val, m32);
+                if (PASS == 2) term = __fmul_rn(term, term);
+                asm volatile("" : "+v"(term));
+                const double t = (double)term * sp.scale_e, h = trunc(t);
+                if (PASS == 1) {
+                    const double tv = (double)val * sp.scale_v, hv = trunc(tv);
+                    q[0] += hv;
+                    q[1] += trunc((tv - hv) * 4294967296.0);
+                    q[2] += h;
+                    q[3] += trunc((t - h) * 4294967296.0);
+                    q[6] += 1.0;
+                } else {
+                    q[0] += h;
+                    q[1] += trunc((t - h) * 4294967296.0);
+                }
+            }
+            const long long tot = (long long)row16_reduce8_f64(reinterpret_cast<const double (&)[8]>(q), lane);
+            const int j = ((lane >> 3) & 1) * 4 + ((lane >> 2) & 1) * 2 + ((lane >> 1) & 1);
+            const bool owner = (lane & 1) == 0 && (PASS == 1 ? (j < 4 || j == 6) : j < 2);
+            if (owner && tot != 0 && live) {
+                // columns of channel 0: [0] count, [1..2] value sum, [7..8] squared / variance sum (LDS of the second pass: 0..1)
+                const int col = PASS == 1 ? (j == 6 ? 0 : (j < 2 ? 1 + j : 5 + j)) : j;
+                if (slot >= 0)
+                    atomic_add_i64(&lacc[slot][col], tot);
+                else
+                    atomic_add_i64(acc + (size_t)k * 13 + ((PASS == 1) ? col : 7 + col), tot);
+            }
+            continue;
+        }
+        if constexpr (NC == 3) {
         // partial sums of this lane, eight at a time (one transposed reduction over the 16-lane row each: sixteen at once cost
         // 250+ registers): PASS 1 -> round 0: the value sums (two limbs per channel) and the count, round 1: the sums of v * v;
         // PASS 2 -> one round: the sums of (v - mean32)^2
@@ -215,6 +258,7 @@ k_color_stats(const T *__restrict__ img, const int32_t *__restrict__ labels, Sta
 #pragma unroll
         for (int r = 0; r < RW; ++r)
             if (lab[r] == k) lab[r] = 0x7fffffff;
+        }
     }
     __syncthreads();
     for (int i = tid; i < ST_SLOTS * NQ; i += 256) {
@@ -276,6 +320,11 @@ static void launch_pass(int pass, const T *img, const int32_t *labels, StatParam
                         long long *acc, hipStream_t st, int nz)
 {
     dim3 grid(cdiv(sp.W, 64), cdiv(sp.H, 4 * StatRows<T>::value), nz);
+    if (sp.planar && sp.plane_stride == 0 && !sp.prescale) {         // one gray plane: channel 0 only (the others stay 0)
+        if (pass == 1) hipLaunchKernelGGL((k_color_stats<T, 1, false, 1>), grid, 256, 0, st, img, labels, sp, mean32, acc);
+        else hipLaunchKernelGGL((k_color_stats<T, 2, false, 1>), grid, 256, 0, st, img, labels, sp, mean32, acc);
+        return;
+    }
     if (pass == 1 && sizeof(T) == 1 && sp.u8_int)
         hipLaunchKernelGGL((k_color_stats<T, 1, sizeof(T) == 1>), grid, 256, 0, st, img, labels, sp, mean32, acc);
     else if (pass == 1)

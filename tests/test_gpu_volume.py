@@ -163,6 +163,43 @@ def test_label_cc_by_runs_and_by_every_neighbour(hip, oracle, monkeypatch, full)
         sess.close()
 
 
+@pytest.mark.parametrize('general', [False, True])
+def test_label_cc_of_the_connectivity_pass_by_first_voxels(hip, oracle, monkeypatch, general):
+    """round 6: every label > 0 the connectivity pass writes is one 6-connected set, so measure.label of ITS map only renumbers the
+    labels by their first voxels (connectivity.hip launch_label_connected); the union-find of every other map stays behind
+    IMSEGM_LABEL_GENERAL -- both against the oracle: tiny supervoxels in noise (most components small and merged), truncated
+    components (max_size_factor 1.1), start_label 1, one slice; and a map set by the caller afterwards (a label in two pieces) must
+    take the union-find again"""
+    if general:
+        monkeypatch.setenv('IMSEGM_LABEL_GENERAL', '1')
+    rng = np.random.default_rng(31)
+    cases = [((8, 40, 130), np.float32, 900, 0.05, (1, 1, 1), {}),
+             ((9, 45, 67), np.float64, 500, 0.02, (2, 1, 1), {}),
+             ((6, 50, 70), np.float64, 40, 5.0, (3, 1, 1), {'max_size_factor': 1.1, 'min_size_factor': 0.2}),
+             ((5, 33, 129), np.uint8, 120, 0.5, (1, 1, 1), {'start_label': 1}),
+             ((1, 64, 90), np.float32, 60, 1.0, (1, 1, 1), {})]
+    for shape, dtype, n_seg, compact, spacing, kw in cases:
+        vol = rng.random(shape)
+        vol = (vol * 255).astype(np.uint8) if dtype == np.uint8 else vol.astype(dtype)
+        ref_raw = _oracle_raw(oracle, vol, n_seg, compact, spacing, **kw)
+        sess = hip.Volume3D(*shape).upload(vol)
+        sess.slic(n_seg, compact, sigma=1., spacing=spacing, **kw)
+        assert np.array_equal(sess.get_labels(), ref_raw)
+        k = sess.label_cc()
+        ref = oracle.label_cc(ref_raw)
+        assert np.array_equal(sess.get_labels(), ref) and k == ref.max() + 1, (shape, kw)
+        k2 = sess.label_cc()                          # (the relabelled map is of the same kind: numbering it again changes nothing)
+        assert np.array_equal(sess.get_labels(), ref) and k2 == k
+        # the caller's own map through the same session: label 2 in two pieces
+        lab = np.ones(shape, dtype=np.int64)
+        lab[..., :3] = 2
+        lab[..., -3:] = 2
+        sess.set_labels(lab)
+        sess.label_cc()
+        assert np.array_equal(sess.get_labels(), oracle.label_cc(lab))
+        sess.close()
+
+
 def test_gray_statistics(hip, oracle):
     from pyimsegm_amd import descriptors as d
     for dtype in (np.float64, np.uint8):
