@@ -545,90 +545,85 @@ __global__ void __launch_bounds__(GC_THREADS) k_alpha_expansion(GcDevice g)
 // scratch.  The schedule variables live in registers of every thread and evolve identically (every decision is grid uniform).
 //
 // The grid barrier is the library's own (round 5; cooperative_groups' grid.sync() is a software barrier of ~26 us at 256
-// workgroups on this runtime -- MI355X_MICROARCH.md price list, row barrier-cg -- and a move is a chain of hundreds of them): every
+// workgroups on this runtime -- MI355X_MICROARCH.md price list, row barrier-cg -- and a move is a chain of hundreds of them).  Every
 // word another workgroup reads is an agent-scope access (write-through stores, loads that bypass L1, atomics at the memory side), so
-// the barrier needs no cache maintenance -- every wave waits for its own stores (vmcnt(0)), the workgroup meets, ONE lane arrives:
-// a counter per group of workgroups (blockIdx.x % 8 = the XCD a block is observed to run on; a matter of speed only), the last
-// arrival of a group counts on the top word, the last group writes the epoch into every group's release word, which one lane per
-// workgroup polls with relaxed loads.  Counters are monotonic (arrivals of epoch e end at e x members), nothing is reset inside the
-// launch.  Every wait is BOUNDED (2 s of the 100 MHz clock): a workgroup that gives up -- a block of the grid is not resident: the
-// device is shared with another process, ADVICE r4 -- poisons the release words, every workgroup runs the schedule down without
-// waiting or changing anything, and the host cuts the graph again with the single workgroup.
+// the barrier needs no cache maintenance: every wave waits for its own stores (vmcnt(0)), the workgroup meets, ONE lane arrives.
+// Round 6: ONE 64-bit word per barrier, and the OR of `any` rides on it -- a workgroup adds 1 + (its OR << 32) to the word of the
+// epoch's parity with an atomic that returns nothing and polls the SAME word until its low half shows everybody (counts are
+// monotonic; the word of the other parity is untouched until everybody has left this barrier, so all read the same final value); the
+// high half -- how many workgroups have raised their OR so far -- against its value two epochs ago is the OR of this epoch.  One
+// trip to memory after the last arrival, where round 5's barrier (a counter per group of workgroups, a top counter, release words,
+// then the flag read back) took four or five: config 5's cut 24 -> see profiles/README_r06.md.
+// Every wait is BOUNDED (2 s of the 100 MHz clock): a workgroup that gives up -- a block of the grid is not resident: the device is
+// shared with another process, ADVICE r4 -- raises `poisoned`, which every waiting workgroup looks at between polls; all of them
+// run the schedule down without waiting or changing anything, and the host cuts the graph again with the single workgroup.
 struct GcGridCtl {
-    int flags[3];
     int poisoned;                       // a barrier gave up: the result of this launch is void
+    int pad0[31];
+    unsigned long long word[2][16];     // one 128-byte line per barrier word
     long long sums[3];
     long long energy;
     int table[GC_MAX_LABELS];
     int queue_sizes[GC_MAX_LABELS + 2];
-    unsigned arrive[8][32];             // one 128-byte line per word
-    unsigned top[32];
-    unsigned release[8][32];
 };
-constexpr unsigned GC_GRID_POISON = 0xffffffffu;
 constexpr long long GC_GRID_WAIT_TICKS = 200000000LL;         // 2 s at 100 MHz
 
 struct GcGrid {
     GcGridCtl *ctl;
     int tid, nth;
-    unsigned or_calls, sum_calls, epoch;
-    int group, members, groups;
+    unsigned sum_calls, epoch;
+    unsigned raised[2];                 // (thread 0) the high half of each word when its last barrier completed
     bool dead;
-    int *meet;                          // one LDS word of the workgroup: the outcome of the wait
-    __device__ GcGrid(GcGridCtl *c, int *lds_word)
-        : ctl(c), tid(blockIdx.x * blockDim.x + threadIdx.x), nth(gridDim.x * blockDim.x), or_calls(0), sum_calls(0), epoch(0),
-          group(blockIdx.x & 7), members(((int)gridDim.x - (int)(blockIdx.x & 7) + 7) >> 3), groups(min(8, (int)gridDim.x)), dead(false),
-          meet(lds_word) {}
-    __device__ __forceinline__ void sync()
+    int *lds;                           // four LDS words of the workgroup: [0..2] its OR in turn, [3] the outcome of the wait
+    __device__ GcGrid(GcGridCtl *c, int *lds_words)
+        : ctl(c), tid(blockIdx.x * blockDim.x + threadIdx.x), nth(gridDim.x * blockDim.x), sum_calls(0), epoch(0), dead(false), lds(lds_words)
     {
-        if (dead) return;
+        raised[0] = raised[1] = 0;
+        if (threadIdx.x < 4) lds[threadIdx.x] = 0;
+        __syncthreads();
+    }
+    // barrier + OR over the grid
+    __device__ __forceinline__ bool any(int pred)
+    {
+        if (dead) return false;
+        const unsigned e = epoch++;
+        int *mine = lds + e % 3;                                           // (set and read by call e; cleared by thread 0 behind call e + 1's barrier)
+        if (pred) *mine = 1;
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");        // every store / atomic of this wave has been performed
         __syncthreads();
-        ++epoch;
         if (threadIdx.x == 0) {
-            const unsigned a = __hip_atomic_fetch_add(&ctl->arrive[group][0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
-            if (a == epoch * (unsigned)members) {
-                const unsigned t = __hip_atomic_fetch_add(&ctl->top[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
-                if (t == epoch * (unsigned)groups)
-                    for (int x = 0; x < groups; ++x)
-                        __hip_atomic_fetch_max(&ctl->release[x][0], epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // (max: never below a poison)
-            }
-            int ok = 1;
+            lds[(e + 2) % 3] = 0;
+            unsigned long long *w = &ctl->word[e & 1][0];
+            const unsigned target = (e / 2 + 1) * gridDim.x;          // (2^32 arrivals: beyond any cut)
+            __hip_atomic_fetch_add(w, 1ULL + ((unsigned long long)(*mine != 0) << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            int outcome = -1;
             long long t0 = 0;
             for (unsigned spins = 1;; ++spins) {
-                const unsigned r = __hip_atomic_load(&ctl->release[group][0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (r >= epoch) {
-                    ok = r != GC_GRID_POISON;
+                const unsigned long long v = __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if ((unsigned)v == target) {
+                    outcome = (unsigned)(v >> 32) != raised[e & 1] ? 1 : 0;
+                    raised[e & 1] = (unsigned)(v >> 32);
                     break;
                 }
                 __builtin_amdgcn_s_sleep(1);
                 if ((spins & 255u) == 0) {
+                    if (__hip_atomic_load(&ctl->poisoned, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
                     const long long now = (long long)wall_clock64();
                     if (t0 == 0) t0 = now;
                     else if (now - t0 > GC_GRID_WAIT_TICKS) {
-                        for (int x = 0; x < 8; ++x) __hip_atomic_store(&ctl->release[x][0], GC_GRID_POISON, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         __hip_atomic_store(&ctl->poisoned, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        ok = 0;
                         break;
                     }
                 }
             }
-            *meet = ok;
+            lds[3] = outcome;
         }
         __syncthreads();
-        if (*meet == 0) dead = true;     // (the word is rewritten behind the first __syncthreads of the next barrier)
+        const int outcome = lds[3];          // (rewritten behind the first __syncthreads of the next barrier)
+        if (outcome < 0) dead = true;
+        return outcome > 0;
     }
-    // OR over the grid, one barrier (word r % 3 is set and read by call r; thread 0 clears word (r + 2) % 3 behind the barrier)
-    __device__ __forceinline__ bool any(int pred)
-    {
-        int *f = ctl->flags + or_calls % 3;
-        if (pred && !dead) st(f, 1);
-        sync();
-        const int r = ld(f);
-        if (tid == 0 && !dead) st(ctl->flags + (or_calls + 2) % 3, 0);
-        ++or_calls;
-        return r != 0 && !dead;
-    }
+    __device__ __forceinline__ void sync() { any(0); }
     // sum over the grid, one barrier: a wave adds its total with one atomic
     __device__ __forceinline__ long long sum(long long v)
     {
@@ -654,6 +649,12 @@ __device__ __forceinline__ long long gc_grid_energy(const GcDevice &g, GcGrid &q
     return q.sum(e);
 }
 
+// Global relabelling = breadth-first distances to the sink in the residual graph.  Round 6: by the FRONTIER -- a node at `level` walks
+// its arcs once and lifts the unreached neighbours that can push to it (residual capacity on the reverse arc) to level + 1 -- where
+// rounds 4 / 5 had every unreached node walk all its arcs at every level, looking for a neighbour at `level`: at config 5 (298 116
+// sites, ~14 arcs each, 67 levels per relabelling) that was ~30 walks per node instead of one, every word of them an agent-scope load
+// that no cache on the way may serve -- 43 us per level, 20 of the cut's 24 ms.  Same levels, same heights (several frontier nodes may
+// lift the same neighbour: to the same value), same end: a level that lifts nothing.
 __device__ __forceinline__ void gc_grid_relabel(const GcDevice &g, GcGrid &q, int *cap, int *height, long long *excess, int alpha)
 {
     const int HMAX = g.K + 2;
@@ -663,26 +664,36 @@ __device__ __forceinline__ void gc_grid_relabel(const GcDevice &g, GcGrid &q, in
     for (int level = 1; level < HMAX; ++level) {
         if (g.dbg && q.tid == 0) g.dbg[2] += 1;
         int changed = 0;
-        for (int u = q.tid; u < g.K; u += q.nth) {
-            if (ld(&height[u]) != HMAX || ld(&g.labels[u]) == alpha) continue;
-            const int a0 = g.arc_start[u], a1 = g.arc_start[u + 1];
-            bool hit = false;
-            for (int base = a0; base < a1 && !hit; base += GC_ARCS) {
-                int c[GC_ARCS], h[GC_ARCS];
+        // (two nodes of a thread per turn: their heights are requested together -- a thread has one or two nodes at 256 workgroups)
+        for (int v0 = q.tid; v0 < g.K; v0 += 2 * q.nth) {
+            const int v1 = v0 + q.nth;
+            const int h0 = ld(&height[v0]), h1 = v1 < g.K ? ld(&height[v1]) : -1;
 #pragma unroll
-                for (int i = 0; i < GC_ARCS; ++i) {
-                    const int a = min(base + i, a1 - 1);
-                    c[i] = ld(&cap[a]);
-                    h[i] = g.arc_to[a];
+            for (int t = 0; t < 2; ++t) {
+                const int v = t ? v1 : v0;
+                if ((t ? h1 : h0) != level) continue;
+                const int a0 = g.arc_start[v], a1 = g.arc_start[v + 1];
+                for (int base = a0; base < a1; base += GC_ARCS) {
+                    int to[GC_ARCS], c[GC_ARCS], h[GC_ARCS];
+    #pragma unroll
+                    for (int i = 0; i < GC_ARCS; ++i) {
+                        const int a = min(base + i, a1 - 1);
+                        to[i] = g.arc_to[a];
+                        c[i] = g.arc_rev[a];
+                    }
+    #pragma unroll
+                    for (int i = 0; i < GC_ARCS; ++i) {
+                        c[i] = ld(&cap[c[i]]);                       // what the neighbour may still push along its arc to v
+                        h[i] = ld(&height[to[i]]);
+                    }
+                    // (a neighbour that carries alpha has no capacity on any arc -- gc_grid_expand -- so it is never lifted)
+    #pragma unroll
+                    for (int i = 0; i < GC_ARCS; ++i)
+                        if (base + i < a1 && c[i] > 0 && h[i] == HMAX) {
+                            st(&height[to[i]], level + 1);
+                            changed = 1;
+                        }
                 }
-#pragma unroll
-                for (int i = 0; i < GC_ARCS; ++i) h[i] = ld(&height[h[i]]);
-#pragma unroll
-                for (int i = 0; i < GC_ARCS; ++i) hit |= c[i] > 0 && h[i] == level;
-            }
-            if (hit) {
-                st(&height[u], level + 1);
-                changed = 1;
             }
         }
         if (!q.any(changed)) break;
@@ -819,9 +830,9 @@ __device__ __forceinline__ bool gc_grid_expand(const GcDevice &g, GcGrid &q, int
 __global__ void __launch_bounds__(GC_THREADS) k_alpha_expansion_grid(GcDevice g, GcGridCtl *ctl)
 {
     if (g.K_dev) g.K = min(*g.K_dev, g.K);
-    __shared__ int meet_word;
+    __shared__ int grid_words[4];
     if (g.test_absent && blockIdx.x == gridDim.x - 1 && gridDim.x > 1) return;
-    GcGrid q(ctl, &meet_word);
+    GcGrid q(ctl, grid_words);
     if (g.E_dev && *g.E_dev > g.E) {            // (as k_alpha_expansion: more edges than the tables hold -> a defined labelling)
         for (int u = q.tid; u < g.K; u += q.nth) g.labels[u] = 0;
         if (q.tid == 0) *g.energy_out = 0;
@@ -994,7 +1005,7 @@ int launch_alpha_expansion(GcProblem p, const int32_t *arc_start, const int32_t 
         if (level >= 3) lds_need += ((size_t)p.K + 1 + (size_t)2 * p.E) * 4;
     }
     // a graph that does not fit the LDS of one CU: the whole device works on it (k_alpha_expansion_grid) -- one workgroup of 1 024
-    // threads per CU at most (the grid barrier costs one atomic per workgroup), a site or two per thread
+    // threads per CU at most (a grid barrier is one atomic per workgroup on one word), a site or two per thread
     if (level == 0 && zb.nz == 1 && p.K >= (knobs().gc_grid_min_sites > 0 ? knobs().gc_grid_min_sites : 8192) && !knobs().gc_one_workgroup) {
         int dev = 0;
         HIP_TRY(hipGetDevice(&dev));

@@ -637,15 +637,33 @@ __device__ __forceinline__ int wave_min_key(int key)
 #endif
 constexpr int VZ = VOL_ASSIGN_SLICES;
 
+// The voxels of a wave inside the workgroup's 64 x 16 cross-section.  VOL_ASSIGN_TILE 16 (round 6): a 16 x 16 TILE -- lane = (lane & 15)
+// in x, rows 4 (lane >> 4) .. + 3 in y; 64: a 64 x 4 strip (rounds 3 - 6) -- lane in x, four rows.  The walk evaluates a candidate for
+// all 256 voxels of the wave; at config 5 a supervoxel is ~35 x 35 voxels of a slice, a strip met the windows of ~9 centroids whose
+// bound lay below its worst distance, a tile meets ~half of that.  Same candidates per VOXEL, same arithmetic, same comparison: the
+// label maps do not move (tests with both).
+#ifndef VOL_ASSIGN_TILE
+#define VOL_ASSIGN_TILE 16
+#endif
+constexpr bool VT16 = VOL_ASSIGN_TILE == 16;
+static_assert(VOL_ASSIGN_TILE == 16 || VOL_ASSIGN_TILE == 64, "tile of a wave: 16 x 16 or 64 x 4");
+constexpr int VT_W = VT16 ? 16 : 64, VT_H = VT16 ? 16 : VROWS;
+// the neighbour to the left inside the wave's row of voxels (a tile's rows are 16 lanes: row_shr:1 keeps `first` in their first lanes)
+__device__ __forceinline__ int tile_prev(int v, int first)
+{
+    return VT16 ? __builtin_amdgcn_update_dpp(first, v, 0x111, 0xf, 0xf, false) : lane_prev(v, first);
+}
+
 template <int NS>
 __device__ __forceinline__ void vol_walk_f32(const VolRec *rec, const int *list, const unsigned char *cov, int count, int lane, int y0,
-                                             int y1w, int x0w, int x1w, int x, bool xin, int H, int nzv, float fz0, float fx, float sz,
+                                             int y1w, int x0w, int x1w, int yl, int x, bool xin, int H, int nzv, float fz0, float fx, float sz,
                                              float sy, float sx, float sw, const float (&pv)[VZ][VROWS], float (&best_d)[VZ][VROWS],
                                              int (&best_k)[VZ][VROWS], float &wave_worst)
 {
     static_assert(NS >= 1 && NS <= 8, "three bits of a key hold the slot");
-    // bounds over this wave's strips (one per slice); a window that misses the strips' rows is out.  The bound of a candidate is
-    // its smallest bound over the slices its window covers: below every distance it can give a voxel of this wave.
+    // bounds over this wave's voxels [y0, y1w) x [x0w, x1w) (per slice); a window that misses them is out.  The bound of a candidate
+    // is its smallest bound over the slices its window covers: below every distance it can give a voxel of this wave.
+    // (yl: the first of the lane's own VROWS rows)
     int key[NS];
 #pragma unroll
     for (int j = 0; j < NS; ++j) {
@@ -654,7 +672,7 @@ __device__ __forceinline__ void vol_walk_f32(const VolRec *rec, const int *list,
         if (c < count) {
             const VolRec rc = rec[c];
             const int cv = VZ > 1 ? cov[c] : 1;            // (one slice: the scan has kept the windows that cover it)
-            if (rc.wy0 < y1w && rc.wy1 > y0) {
+            if (rc.wy0 < y1w && rc.wy1 > y0 && rc.wx0 < x1w && rc.wx1 > x0w) {
                 const float yn = fminf(fmaxf(rc.cy, (float)y0), (float)(y1w - 1));
                 const float xn = fminf(fmaxf(rc.cx, (float)x0w), (float)(x1w - 1));
                 const float tyl = sy * (rc.cy - yn), txl = sx * (rc.cx - xn);
@@ -697,7 +715,7 @@ __device__ __forceinline__ void vol_walk_f32(const VolRec *rec, const int *list,
         float dy[VROWS];
 #pragma unroll
         for (int r = 0; r < VROWS; ++r) {
-            const float ty = sy * (rc.cy - (float)(y0 + r));
+            const float ty = sy * (rc.cy - (float)(yl + r));
             dy[r] = ty * ty;
         }
 #pragma unroll
@@ -707,12 +725,13 @@ __device__ __forceinline__ void vol_walk_f32(const VolRec *rec, const int *list,
             const float dz = tz * tz;
 #pragma unroll
             for (int r = 0; r < VROWS; ++r) {
-                const int y = y0 + r;
-                if (y < rc.wy0 || y >= rc.wy1) continue;
+                const int y = yl + r;
+                const bool iny = y >= rc.wy0 && y < rc.wy1;
+                if (!VT16 && !iny) continue;                         // (a strip's row: wave uniform)
                 float d = ((dz + dy[r]) + dx2) * sw;
                 const float t = pv[zi][r] - rc.cv;
                 d = d + t * t;
-                const bool take = inx && (best_d[zi][r] > d || (best_d[zi][r] == d && ck < best_k[zi][r]));
+                const bool take = inx && iny && (best_d[zi][r] > d || (best_d[zi][r] == d && ck < best_k[zi][r]));
                 best_d[zi][r] = take ? d : best_d[zi][r];           // (selects, no change of the exec mask)
                 best_k[zi][r] = take ? ck : best_k[zi][r];
             }
@@ -724,7 +743,7 @@ __device__ __forceinline__ void vol_walk_f32(const VolRec *rec, const int *list,
             for (int zi = 0; zi < VZ; ++zi)
 #pragma unroll
                 for (int r = 0; r < VROWS; ++r)
-                    if (xin && (y0 + r) < H && zi < nzv) m2 = fmaxf(m2, best_d[zi][r]);
+                    if (xin && (yl + r) < H && zi < nzv) m2 = fmaxf(m2, best_d[zi][r]);
             wave_worst = wave_max_nonneg_f32(m2);           // (distances: never negative; +inf while a voxel has no candidate)
         }
     }
@@ -800,7 +819,11 @@ k_vol_assign_f32(VolState s, const float *__restrict__ vol, int32_t *__restrict_
     __shared__ unsigned char cov[VZ > 1 ? VLIST32 : 1];
     __shared__ int wave_base[4];
     constexpr int HB = VZ > 1 ? 6 : 4, HB_Y = VZ > 1 ? 2 : 0;                        // label -> [zmin, zmax,] ymin, ymax, xmin, xmax
-    __shared__ int hb_key[TRACK ? VT_SLOTS : 1], hb_box[TRACK ? VT_SLOTS : 1][HB];
+    // (tiles of one slice: the box of a label inside the cross-section as the SET of its columns -- 64 bits, hb_box[][0..1] -- and of
+    // its rows -- 16 bits, hb_box[][2] --, joined with OR)
+    constexpr bool HB_SETS = VT16 && VZ == 1;
+    __shared__ int hb_key[TRACK ? VT_SLOTS : 1];
+    __shared__ __attribute__((aligned(8))) int hb_box[TRACK ? VT_SLOTS : 1][HB];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     VOL_PH_BEGIN
@@ -809,16 +832,19 @@ k_vol_assign_f32(VolState s, const float *__restrict__ vol, int32_t *__restrict_
     const int z0 = (blockIdx.y / yb) * VZ;
     const int nzv = min(VZ, s.D - z0);                        // slices of this workgroup inside the volume
     const int Y0 = (blockIdx.y % yb) * rows_per_block, Y1 = min(Y0 + rows_per_block, s.H);
-    const int y0 = Y0 + wave * VROWS;
-    const int x = blockIdx.x * 64 + lane;
-    const int x0w = blockIdx.x * 64, x1w = min(x0w + 64, s.W);
-    const bool alive = y0 < s.H;                              // (a wave below the volume takes part in the barriers only)
-    const int y1w = min(y0 + VROWS, s.H);
+    // the wave's voxels: [y0, y1w) x [xt0, xt1); the lane's: column x, rows yl .. yl + VROWS - 1
+    const int y0 = VT16 ? Y0 : Y0 + wave * VROWS;
+    const int yl = VT16 ? Y0 + (lane >> 4) * VROWS : y0;
+    const int x0w = blockIdx.x * 64, x1w = min(x0w + 64, s.W);                    // the cross-section (the scan of the brick's list)
+    const int xt0 = VT16 ? x0w + wave * 16 : x0w, xt1 = min(xt0 + VT_W, s.W);
+    const int x = VT16 ? xt0 + (lane & 15) : x0w + lane;
+    const bool alive = VT16 ? xt0 < s.W : y0 < s.H;           // (a wave outside the volume takes part in the barriers only)
+    const int y1w = min(y0 + VT_H, s.H);
     const bool xin = x < s.W;
     if (TRACK && tid < VT_SLOTS) {                            // (visible to all after the first barrier of the scan below)
         hb_key[tid] = -1;
 #pragma unroll
-        for (int j = 0; j < HB; ++j) hb_box[tid][j] = (j & 1) ? -1 : 0x7fffffff;
+        for (int j = 0; j < HB; ++j) hb_box[tid][j] = HB_SETS ? 0 : (j & 1) ? -1 : 0x7fffffff;
     }
     float pv[VZ][VROWS], best_d[VZ][VROWS];
     int best_k[VZ][VROWS];
@@ -826,8 +852,8 @@ k_vol_assign_f32(VolState s, const float *__restrict__ vol, int32_t *__restrict_
     for (int zi = 0; zi < VZ; ++zi)
 #pragma unroll
         for (int r = 0; r < VROWS; ++r) {
-            const bool ok = alive && xin && (y0 + r) < s.H && zi < nzv;
-            pv[zi][r] = vol[ok ? ((size_t)(z0 + zi) * s.H + y0 + r) * s.W + x : 0];
+            const bool ok = alive && xin && (yl + r) < s.H && zi < nzv;
+            pv[zi][r] = vol[ok ? ((size_t)(z0 + zi) * s.H + yl + r) * s.W + x : 0];
             best_d[zi][r] = INFINITY;
             best_k[zi][r] = -1;
         }
@@ -893,7 +919,7 @@ k_vol_assign_f32(VolState s, const float *__restrict__ vol, int32_t *__restrict_
         VOL_PH_COUNT(10, count);
         VOL_PH(2);
         if (alive) {
-#define VOL_WALK(NS) vol_walk_f32<NS>(rec, list, cov, count, lane, y0, y1w, x0w, x1w, x, xin, s.H, nzv, fz0, fx, sz, sy, sx, sw, pv, best_d, best_k, wave_worst)
+#define VOL_WALK(NS) vol_walk_f32<NS>(rec, list, cov, count, lane, y0, y1w, xt0, xt1, yl, x, xin, s.H, nzv, fz0, fx, sz, sy, sx, sw, pv, best_d, best_k, wave_worst)
             switch ((count + 63) >> 6) {
             case 0: break;
             case 1: VOL_WALK(1); break;
@@ -918,8 +944,8 @@ k_vol_assign_f32(VolState s, const float *__restrict__ vol, int32_t *__restrict_
         for (int zi = 0; zi < VZ; ++zi)
 #pragma unroll
             for (int r = 0; r < VROWS; ++r) {
-                if (!(xin && (y0 + r) < s.H && zi < nzv)) continue;
-                const size_t p = ((size_t)(z0 + zi) * s.H + y0 + r) * s.W + x;
+                if (!(xin && (yl + r) < s.H && zi < nzv)) continue;
+                const size_t p = ((size_t)(z0 + zi) * s.H + yl + r) * s.W + x;
                 if (best_k[zi][r] >= 0) labels[p] = best_k[zi][r];
                 else best_k[zi][r] = labels[p];                   // uncovered voxel keeps its previous assignment
                 if (best_k[zi][r] >= 0) pending |= 1u << (zi * VROWS + r);
@@ -932,19 +958,61 @@ k_vol_assign_f32(VolState s, const float *__restrict__ vol, int32_t *__restrict_
     // end of its run in the vote of the run starts.  Round 6: it updates the box of its label in the workgroup's LDS table; the
     // table goes to the global boxes once, below.  Minima and maxima: the boxes are the same whatever the order and however often
     // a label is met.
-    if (alive) {
+    // Tiles (one slice): by runs as the strips below, but a run joins the label's SETS of columns and rows with two ORs that return
+    // nothing, and a lane that has found the slot of a label keeps it for the rows below (a label change costs the search again).
+    // (Measured at config 5, one box: runs with minima / maxima as below 9.49 ms per sweep; label by label -- the first waiting lane
+    // names a label, four votes give its columns and rows, one lane joins them -- 11.05 ms: a serial chain per label and wave.)
+    if (HB_SETS && alive) {
+        int slot_of = -2, slot = -1;
+#pragma unroll
+        for (int r = 0; r < VROWS; ++r) {
+            const int k = (pending >> r) & 1u ? best_k[0][r] : -1;
+            const int kp = tile_prev(k, -2);                        // (the first lane of a row of the tile: a start)
+            const bool start = k >= 0 && kp != k;
+            const unsigned long long starts = __ballot(start), valid = __ballot(k >= 0);
+            if (start) {
+                const unsigned long long stop = (starts | ~valid) & ~((2ULL << lane) - 1ULL);     // the lanes above this one
+                const int len = (stop ? __ffsll((long long)stop) - 1 : 64) - lane;                 // (<= 16: the next row starts)
+                if (k != slot_of) {
+                    slot_of = k;
+                    slot = (int)(((unsigned int)k * 2654435761u) >> 26);          // 6 bits
+                    bool placed = false;
+                    for (int probe = 0; probe < VT_SLOTS; ++probe) {
+                        const int old = atomicCAS(&hb_key[slot], -1, k);
+                        if (old == -1 || old == k) {
+                            placed = true;
+                            break;
+                        }
+                        slot = (slot + 1) & (VT_SLOTS - 1);
+                    }
+                    slot = placed ? slot : -1;
+                }
+                const int y = yl + r;
+                if (slot >= 0) {
+                    atomicOr(reinterpret_cast<unsigned long long *>(&hb_box[slot][0]), ((1ULL << len) - 1ULL) << (x - x0w));
+                    atomicOr(reinterpret_cast<unsigned int *>(&hb_box[slot][2]), 1u << (y - Y0));
+                } else {                                              // (more than VT_SLOTS labels in a cross-section)
+                    int *bb = s.bbox + (size_t)k * 6;
+                    atomicMin(&bb[0], z0); atomicMax(&bb[1], z0);
+                    atomicMin(&bb[2], y); atomicMax(&bb[3], y);
+                    atomicMin(&bb[4], x); atomicMax(&bb[5], x + len - 1);
+                }
+            }
+        }
+    }
+    if (!HB_SETS && alive) {
 #pragma unroll
         for (int zi = 0; zi < VZ; ++zi)
 #pragma unroll
             for (int r = 0; r < VROWS; ++r) {
                 const int k = (pending >> (zi * VROWS + r)) & 1u ? best_k[zi][r] : -1;
-                const int kp = lane_prev(k, -2);
+                const int kp = tile_prev(k, -2);                    // (the first lane of a row of the tile: a start)
                 const bool start = k >= 0 && kp != k;
                 const unsigned long long starts = __ballot(start), valid = __ballot(k >= 0);
                 if (start) {
                     const unsigned long long stop = (starts | ~valid) & ~((2ULL << lane) - 1ULL);     // the lanes above this one
                     const int end = stop ? __ffsll((long long)stop) - 1 : 64;
-                    const int z = z0 + zi, y = y0 + r, xlo = x0w + lane, xhi = x0w + end - 1;
+                    const int z = z0 + zi, y = yl + r, xlo = x, xhi = x + (end - lane) - 1;
                     int slot = (int)(((unsigned int)k * 2654435761u) >> 26);          // 6 bits
                     bool placed = false;
                     for (int probe = 0; probe < VT_SLOTS; ++probe) {
@@ -979,7 +1047,15 @@ k_vol_assign_f32(VolState s, const float *__restrict__ vol, int32_t *__restrict_
         const int2 bz = *reinterpret_cast<const int2 *>(bb), by = *reinterpret_cast<const int2 *>(bb + 2),
                    bx = *reinterpret_cast<const int2 *>(bb + 4);
         const int zlo = VZ > 1 ? hb_box[tid][0] : z0, zhi = VZ > 1 ? hb_box[tid][1] : z0;
-        const int ylo = hb_box[tid][HB_Y], yhi = hb_box[tid][HB_Y + 1], xlo = hb_box[tid][HB_Y + 2], xhi = hb_box[tid][HB_Y + 3];
+        int ylo = hb_box[tid][HB_Y], yhi = hb_box[tid][HB_Y + 1], xlo = hb_box[tid][HB_Y + 2], xhi = hb_box[tid][HB_Y + 3];
+        if (HB_SETS) {
+            const unsigned long long colset = *reinterpret_cast<const unsigned long long *>(&hb_box[tid][0]);
+            const unsigned rows = (unsigned)hb_box[tid][2];
+            ylo = Y0 + __ffs(rows) - 1;
+            yhi = Y0 + 31 - __clz(rows);
+            xlo = x0w + __ffsll((long long)colset) - 1;
+            xhi = x0w + 63 - __clzll((long long)colset);
+        }
         if (bz.x > zlo) atomicMin(&bb[0], zlo);
         if (bz.y < zhi) atomicMax(&bb[1], zhi);
         if (by.x > ylo) atomicMin(&bb[2], ylo);
