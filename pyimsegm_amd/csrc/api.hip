@@ -37,6 +37,7 @@ static Knobs read_knobs()
     k.sep_wide_tile = flag("IMSEGM_SEP_WIDE_TILE");
     k.cc_merge_full = flag("IMSEGM_CC_MERGE_FULL");
     k.label_general = flag("IMSEGM_LABEL_GENERAL");
+    k.terms_one_workgroup = flag("IMSEGM_TERMS_ONE_WORKGROUP");
     k.adjacency_table = flag("IMSEGM_ADJACENCY_TABLE");
     k.brick_cap = num("IMSEGM_BRICK_CAP", 0);
     k.gc_lds_level = num("IMSEGM_GC_LDS_LEVEL", 4);

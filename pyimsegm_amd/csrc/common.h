@@ -28,6 +28,7 @@ struct Knobs {
         adjacency_table,       // IMSEGM_ADJACENCY_TABLE: the neighbour table of a label volume's graph for every K (default: beyond 46 000 labels)
         cc_merge_full,         // IMSEGM_CC_MERGE_FULL: the voxel-by-voxel merge passes of rounds 2 - 4 -- measure.label with thirteen unions per voxel, connectivity with
                                // its per-voxel loads -- instead of the row-segment kernels (tests, A/B)
+        terms_one_workgroup,   // IMSEGM_TERMS_ONE_WORKGROUP: the graph-cut terms of a volume by the one workgroup that computes an image's (tests, A/B)
         label_general,         // IMSEGM_LABEL_GENERAL: measure.label of a volume always by union-find, also where the label map is known to come from
                                // the connectivity pass (tests, A/B: connectivity.hip launch_label_connected)
         sep_wide_tile;         // IMSEGM_SEP_WIDE_TILE: the separable kernels of side 33 on the 64 x 16 tile of round 4's first half (tests, A/B)

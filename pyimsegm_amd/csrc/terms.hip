@@ -18,6 +18,7 @@
 namespace imsegm {
 
 constexpr int TM_THREADS = 1024;
+constexpr int TERMS_WIDE_FROM = 16384;     // supervoxels from which the terms are computed by the whole device (launch_gc_terms)
 
 __device__ __forceinline__ double block_reduce_f64(double v, double *scratch, bool is_max)
 {
@@ -523,6 +524,146 @@ __global__ void __launch_bounds__(TM_THREADS) k_gc_terms(TermsArgs a)
     }
 }
 
+// ---- the same terms for the graph of a volume (round 6) ----------------------------------------------------------------------
+// k_gc_terms is ONE workgroup: right for the 2 000 superpixels of an image, 4.8 ms for the 298 116 supervoxels and 2 * 10^6 edges of
+// config 5 -- 2 000 turns of a loop whose every turn waits for its gathers.  Here the element-wise steps (2, 4, 5, 6) run on the whole
+// device, and the sums keep THE ORDER of k_gc_terms: "thread" t of its 1 024 adds the elements t, t + 1 024, ... in ascending order
+// (k_terms_partial: sixteen waves, each streaming its lanes' elements), and the 1 024 partial sums meet in block_reduce_f64 as they
+// do there (k_terms_reduce) -- the same additions in the same order, hence the same bits in the means, the deviation, the weights
+// and the integers (tests hold the two paths against each other).  Maxima do not depend on an order: atomics on the bit patterns of
+// the non-negative values.
+__device__ __forceinline__ int terms_edges(const TermsArgs &a) { return min(*a.Ep, a.edge_capacity); }
+
+__device__ __forceinline__ void atomic_max_nonneg_f64(unsigned long long *bits, double v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = fmax(v, __shfl_xor(v, off, 64));
+    if ((threadIdx.x & 63) == 0 && v > 0.0) atomicMax(bits, (unsigned long long)__double_as_longlong(v));
+}
+
+__global__ void __launch_bounds__(256) k_terms_elem(TermsArgs a, unsigned long long *maxbits)
+{
+    const int K = *a.Kp, C = a.C;
+    const int E = terms_edges(a);
+    const int tid = blockIdx.x * 256 + threadIdx.x, nth = gridDim.x * 256;
+    if (tid == 0 && *a.Ep > a.edge_capacity) atomicOr(a.status, 2);
+    double umax = 0.0;
+    for (int i = tid; i < K * C; i += nth) {
+        double p = a.proba[i];
+        if (p < 0.01) p = 0.01;
+        if (p > 1 - 0.01) p = 1 - 0.01;
+        const double u = fabs(-log(p));
+        a.unary[i] = u;
+        umax = fmax(umax, u);
+    }
+    atomic_max_nonneg_f64(maxbits, umax);
+    for (int j = tid; j < E; j += nth) {
+        const int p = a.edges[2 * j], q = a.edges[2 * j + 1];
+        double len = 0.0;
+        for (int d = 0; d < a.ndim; ++d) {
+            double cp = a.centres[(size_t)p * a.ndim + d], cq = a.centres[(size_t)q * a.ndim + d];
+            const double t = cp - cq;
+            len += t * t;
+        }
+        len = sqrt(len);
+        double dist = 0.0;
+        if (a.edge_type >= 2 && a.edge_type <= 4) {
+            for (int c = 0; c < C; ++c) {
+                const double t = a.proba[(size_t)p * C + c] - a.proba[(size_t)q * C + c];
+                if (a.edge_type == 2) dist = fmax(dist, t * t);           // lT: max squared difference
+                else if (a.edge_type == 3) dist += fabs(t);               // l1
+                else dist += t * t;                                       // l2 (root below)
+            }
+            if (a.edge_type == 4) dist = sqrt(dist);
+        }
+        a.edge_len[j] = len;
+        a.edge_dist[j] = dist;
+    }
+}
+
+// MODE 0: the sums of the edge lengths and distances; MODE 1: of the squared deviations of the distances from their mean
+template <int MODE> __global__ void __launch_bounds__(64) k_terms_partial(TermsArgs a, double *partials)
+{
+    const int E = terms_edges(a);
+    const int t = blockIdx.x * 64 + threadIdx.x;              // the thread of k_gc_terms whose share this lane adds up
+    if (MODE == 0) {
+        double sum_len = 0.0, sum_dist = 0.0;
+#pragma unroll 8
+        for (int j = t; j < E; j += TM_THREADS) {
+            sum_len += a.edge_len[j];
+            sum_dist += a.edge_dist[j];
+        }
+        partials[t] = sum_len;
+        partials[TM_THREADS + t] = sum_dist;
+    } else {
+        const double mean_dist = a.scalars[1];
+        double q = 0.0;
+#pragma unroll 8
+        for (int j = t; j < E; j += TM_THREADS) {
+            const double d = a.edge_dist[j] - mean_dist;
+            q += d * d;
+        }
+        partials[t] = q;
+    }
+}
+
+template <int MODE> __global__ void __launch_bounds__(TM_THREADS) k_terms_reduce(TermsArgs a, const double *partials)
+{
+    __shared__ double scratch[TM_THREADS / 64];
+    const int E = terms_edges(a);
+    if (MODE == 0) {
+        const double mean_len = block_reduce_f64(partials[threadIdx.x], scratch, false) / (double)E;
+        const double mean_dist = block_reduce_f64(partials[TM_THREADS + threadIdx.x], scratch, false) / (double)E;
+        if (threadIdx.x == 0) {
+            a.scalars[0] = mean_len;
+            a.scalars[1] = mean_dist;
+        }
+    } else {
+        const double std_dist = sqrt(block_reduce_f64(partials[threadIdx.x], scratch, false) / (double)E);
+        if (threadIdx.x == 0) a.scalars[2] = std_dist;
+    }
+}
+
+__global__ void __launch_bounds__(256) k_terms_weights(TermsArgs a, unsigned long long *maxbits)
+{
+    const int E = terms_edges(a);
+    const int tid = blockIdx.x * 256 + threadIdx.x, nth = gridDim.x * 256;
+    const double mean_len = a.scalars[0], std_dist = a.scalars[2];
+    const double denom = 2 * (std_dist * std_dist);
+    double wmax = 0.0;
+    for (int j = tid; j < E; j += nth) {
+        double w = 1.0;
+        if (a.edge_type >= 2) w = exp(-a.edge_dist[j] / denom);
+        if (a.spatial_norm) w = w / (a.edge_len[j] / mean_len);
+        if (w < 1. / 1e3) w = 1. / 1e3;
+        if (w > 1e3) w = 1e3;
+        w = w * a.edge_cost;
+        a.weights[j] = w;
+        wmax = fmax(wmax, fabs(w));
+    }
+    atomic_max_nonneg_f64(maxbits + 1, wmax);
+}
+
+__global__ void __launch_bounds__(256) k_terms_integers(TermsArgs a, const unsigned long long *maxbits)
+{
+    const int K = *a.Kp, C = a.C;
+    const int E = terms_edges(a);
+    const int tid = blockIdx.x * 256 + threadIdx.x, nth = gridDim.x * 256;
+    const double umax = __longlong_as_double((long long)maxbits[0]), wmax = __longlong_as_double((long long)maxbits[1]);
+    const double dwf = ((E > 0 && wmax * a.pairwise_max > umax) ? wmax * a.pairwise_max : umax) + 1e-10;
+    for (int i = tid; i < K * C; i += nth) a.unary_i[i] = (int32_t)((a.unary[i] / dwf) * 100000);
+    int bad = 0;
+    for (int j = tid; j < E; j += nth) {
+        const int32_t wi = (int32_t)((a.weights[j] / dwf) * 1000);
+        a.weights_i[j] = wi;
+        if ((long long)abs(wi) * a.smooth_max > 10000000LL) bad = 1;     // GCO_MAX_ENERGYTERM
+    }
+    if (bad) atomicOr(a.status, 1);
+    if (tid == 0) {
+        a.scalars[3] = umax; a.scalars[4] = wmax; a.scalars[5] = dwf;
+    }
+}
+
 // gc_regul <= 0: argmin of the unary cost (graph_cuts.py:729-731), first minimum wins as np.argmin
 __global__ void __launch_bounds__(256)
 k_unary_argmin_f64(const double *__restrict__ unary, const int *__restrict__ Kp, int C, int32_t *__restrict__ labels, size_t zs)
@@ -587,6 +728,22 @@ int launch_gc_terms(const TermsArgs &a, hipStream_t st, int nz)
         else if (a.F <= 128) hipLaunchKernelGGL((k_gmm_proba<2, 4>), grid, 256, 0, st, a);
         else if (a.F <= 192) hipLaunchKernelGGL((k_gmm_proba<3, 4>), grid, 256, 0, st, a);
         else hipLaunchKernelGGL((k_gmm_proba<4, 4>), grid, 256, 0, st, a);
+    }
+    if (nz == 1 && a.zs == 0 && a.edge_type != 5 && a.K_cap >= TERMS_WIDE_FROM && a.edge_capacity >= 2 * TM_THREADS && !knobs().terms_one_workgroup) {
+        // the graph of a volume: the element-wise steps on the whole device, the sums in k_gc_terms' order (see k_terms_elem)
+        unsigned long long *maxbits = reinterpret_cast<unsigned long long *>(a.scalars + 6);
+        double *partials = a.weights;                     // (2 x 1 024 words of an array nobody reads before k_terms_weights fills it)
+        const int wide = std::min(4096, cdiv(std::max(a.K_cap * a.C, a.edge_capacity), 256));
+        HIP_TRY(hipMemsetAsync(maxbits, 0, 2 * sizeof(unsigned long long), st));
+        hipLaunchKernelGGL(k_terms_elem, wide, 256, 0, st, a, maxbits);
+        hipLaunchKernelGGL(k_terms_partial<0>, TM_THREADS / 64, 64, 0, st, a, partials);
+        hipLaunchKernelGGL(k_terms_reduce<0>, 1, TM_THREADS, 0, st, a, (const double *)partials);
+        hipLaunchKernelGGL(k_terms_partial<1>, TM_THREADS / 64, 64, 0, st, a, partials);
+        hipLaunchKernelGGL(k_terms_reduce<1>, 1, TM_THREADS, 0, st, a, (const double *)partials);
+        hipLaunchKernelGGL(k_terms_weights, wide, 256, 0, st, a, maxbits);
+        hipLaunchKernelGGL(k_terms_integers, wide, 256, 0, st, a, (const unsigned long long *)maxbits);
+        HIP_TRY(hipGetLastError());
+        return 0;
     }
     hipLaunchKernelGGL(k_gc_terms, dim3(1, 1, nz), TM_THREADS, 0, st, a);
     HIP_TRY(hipGetLastError());

@@ -458,33 +458,66 @@ k_vol_blur_z32(const float *__restrict__ src, float *__restrict__ dst, int D, in
     }
 }
 
+// (radii known when compiled, a wave = eight rows of the tile: the y pass slides a window of 8 + 2 RY values down a column -- two LDS
+// reads per value written where the loop over runtime radii took 2 RY + 1 --, no division for the coordinates: 6.2 -> see
+// profiles/README_r06.md at 2^30 voxels.  Same sums in the same order.)
+template <int RY, int RX>
 __global__ void __launch_bounds__(256)
 k_vol_blur_yx32(const float *__restrict__ src, float *__restrict__ dst, int H, int W, Taps ty, Taps tx, float fratio)
 {
-    constexpr int TW = 64 + 2 * VBLUR_R, TH = 32 + 2 * VBLUR_R;
+    constexpr int TW = 64 + 2 * RX, TH = 32 + 2 * RY;
     __shared__ float A[TH][TW];
     __shared__ float B[32][TW];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int X0 = blockIdx.x * 64, Y0 = blockIdx.y * 32;
     const float *__restrict__ sl = src + (size_t)blockIdx.z * H * W;
-    for (int i = threadIdx.x; i < TH * TW; i += 256) {
-        const int r = i / TW, c = i - r * TW;
-        A[r][c] = sl[(size_t)vreflect(Y0 - VBLUR_R + r, H) * W + vreflect(X0 - VBLUR_R + c, W)];
+    const bool extra = lane < 2 * RX;                          // the lanes that also serve the columns 64 .. TW - 1
+    const int xa = vreflect(X0 - RX + lane, W), xb = extra ? vreflect(X0 - RX + 64 + lane, W) : 0;
+    for (int r = wave; r < TH; r += 4) {
+        const float *__restrict__ row = sl + (size_t)vreflect(Y0 - RY + r, H) * W;
+        A[r][lane] = row[xa];
+        if (extra) A[r][64 + lane] = row[xb];
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < 32 * TW; i += 256) {
-        const int yy = i / TW, c = i - yy * TW;
-        double v = (double)A[yy + VBLUR_R][c] * ty.w[0];
-        for (int j = ty.r; j >= 1; --j) v += ((double)A[yy + VBLUR_R - j][c] + (double)A[yy + VBLUR_R + j][c]) * ty.w[j];
-        B[yy][c] = (float)v;
+#pragma unroll
+    for (int part = 0; part < 2; ++part) {
+        if (part == 1 && !extra) break;
+        const int c = part ? 64 + lane : lane;
+        float win[8 + 2 * RY];
+#pragma unroll
+        for (int i = 0; i < 8 + 2 * RY; ++i) win[i] = A[8 * wave + i][c];
+#pragma unroll
+        for (int o = 0; o < 8; ++o) {
+            double v = (double)win[o + RY] * ty.w[0];
+#pragma unroll
+            for (int j = RY; j >= 1; --j) v += ((double)win[o + RY - j] + (double)win[o + RY + j]) * ty.w[j];
+            B[8 * wave + o][c] = (float)v;                     // scipy stores the line in the output dtype (float32)
+        }
     }
     __syncthreads();
     float *__restrict__ out = dst + (size_t)blockIdx.z * H * W;
-    for (int i = threadIdx.x; i < 32 * 64; i += 256) {
-        const int yy = i >> 6, xo = i & 63;
-        if (Y0 + yy >= H || X0 + xo >= W) continue;
-        double v = (double)B[yy][xo + VBLUR_R] * tx.w[0];
-        for (int j = tx.r; j >= 1; --j) v += ((double)B[yy][xo + VBLUR_R - j] + (double)B[yy][xo + VBLUR_R + j]) * tx.w[j];
-        out[(size_t)(Y0 + yy) * W + X0 + xo] = (float)v * fratio;      // numpy: float32 array * Python float
+    if (X0 + lane >= W) return;
+#pragma unroll
+    for (int o = 0; o < 8; ++o) {
+        const int yy = 8 * wave + o;
+        if (Y0 + yy >= H) break;
+        double v = (double)B[yy][lane + RX] * tx.w[0];
+#pragma unroll
+        for (int j = RX; j >= 1; --j) v += ((double)B[yy][lane + RX - j] + (double)B[yy][lane + RX + j]) * tx.w[j];
+        out[(size_t)(Y0 + yy) * W + X0 + lane] = (float)v * fratio;      // numpy: float32 array * Python float
+    }
+}
+
+template <int RY>
+static void launch_blur_yx32(int rx, dim3 grid, hipStream_t st, const float *src, float *dst, int H, int W, const Taps &ty, const Taps &tx,
+                             float fratio)
+{
+    switch (rx) {
+    case 0: hipLaunchKernelGGL((k_vol_blur_yx32<RY, 0>), grid, 256, 0, st, src, dst, H, W, ty, tx, fratio); break;
+    case 1: hipLaunchKernelGGL((k_vol_blur_yx32<RY, 1>), grid, 256, 0, st, src, dst, H, W, ty, tx, fratio); break;
+    case 2: hipLaunchKernelGGL((k_vol_blur_yx32<RY, 2>), grid, 256, 0, st, src, dst, H, W, ty, tx, fratio); break;
+    case 3: hipLaunchKernelGGL((k_vol_blur_yx32<RY, 3>), grid, 256, 0, st, src, dst, H, W, ty, tx, fratio); break;
+    default: hipLaunchKernelGGL((k_vol_blur_yx32<RY, 4>), grid, 256, 0, st, src, dst, H, W, ty, tx, fratio); break;
     }
 }
 
@@ -530,7 +563,15 @@ int launch_vol_preprocess_f32(const float *src, int D, int H, int W, const Taps 
             else launch_blur_z32<1>(tz.r, grid, st, src, a32, D, H, W, tz, zchunk);
             mid = a32;
         }
-        hipLaunchKernelGGL(k_vol_blur_yx32, dim3(cdiv(W, 64), cdiv(H, 32), D), 256, 0, st, mid, b32, H, W, eff(ty), eff(tx), (float)ratio);
+        const dim3 tiles(cdiv(W, 64), cdiv(H, 32), D);
+        const Taps ey = eff(ty), ex = eff(tx);
+        switch (ey.r) {
+        case 0: launch_blur_yx32<0>(ex.r, tiles, st, mid, b32, H, W, ey, ex, (float)ratio); break;
+        case 1: launch_blur_yx32<1>(ex.r, tiles, st, mid, b32, H, W, ey, ex, (float)ratio); break;
+        case 2: launch_blur_yx32<2>(ex.r, tiles, st, mid, b32, H, W, ey, ex, (float)ratio); break;
+        case 3: launch_blur_yx32<3>(ex.r, tiles, st, mid, b32, H, W, ey, ex, (float)ratio); break;
+        default: launch_blur_yx32<4>(ex.r, tiles, st, mid, b32, H, W, ey, ex, (float)ratio); break;
+        }
         HIP_TRY(hipGetLastError());
         return 0;   // float32 result in bufB
     }
@@ -1108,10 +1149,16 @@ k_vol_update_f32_lane(VolState s, const float *__restrict__ vol, const int32_t *
             // +0.0f bit for bit as it is (a sum of this kind is never -0.0f: (+0) + (-0) = +0).
             // (round 6: the four voxels of a round come in ONE 16-byte load of labels and one of values -- the lanes of a wave walk
             // different boxes, so every load instruction touches 64 cache lines whatever its width; a quarter of the instructions.
-            // Voxels past x1 are loaded -- the buffers end in padding -- and masked.)
+            // Voxels past x1 are loaded -- the buffers end in padding -- and masked.  The values of a quad are requested only where
+            // one of its labels is the lane's -- under half of a box's voxels: 3.01 against 3.25 ms per sweep at config 5, one box.)
             for (int x = x0; x <= x1; x += VU_STEP) {
                 const Quad<int> lab = *reinterpret_cast<const Quad<int> *>(labels + row + x);
+#ifndef VOL_UPDATE_EAGER_VALUES
+                Quad<float> val = { { 0.f, 0.f, 0.f, 0.f } };
+                if (lab.v[0] == k || lab.v[1] == k || lab.v[2] == k || lab.v[3] == k) val = *reinterpret_cast<const Quad<float> *>(vol + row + x);
+#else
                 const Quad<float> val = *reinterpret_cast<const Quad<float> *>(vol + row + x);
+#endif
 #pragma unroll
                 for (int j = 0; j < VU_STEP; ++j) {
                     const bool mine = lab.v[j] == k && x + j <= x1;

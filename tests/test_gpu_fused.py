@@ -185,6 +185,36 @@ def test_fused_call_on_131_072_supervoxels():
         sess.close()
 
 
+@pytest.mark.parametrize('edge_type', ['model', 'model_l1', 'model_l2', 'spatial', 'const'])
+def test_terms_of_a_volume_by_the_whole_device_keep_the_bits_of_the_one_workgroup(monkeypatch, edge_type):
+    """round 6: from 16 384 supervoxels on the graph-cut terms are computed by the whole device (terms.hip k_terms_elem ...); the sums
+    keep the order of the one workgroup that serves images (k_gc_terms, behind IMSEGM_TERMS_ONE_WORKGROUP for volumes): weights,
+    unary costs and their integers bit for bit, and the same labelling"""
+    from pyimsegm_amd import _hip
+    from pyimsegm_amd import graph_cuts as G
+    rng = np.random.default_rng(23)
+    blocks = np.arange(20 * 32 * 32, dtype=np.int64).reshape(20, 32, 32)
+    labels = np.repeat(np.repeat(np.repeat(blocks, 2, axis=0), 3, axis=1), 2, axis=2)
+    k = int(labels.max()) + 1
+    assert k >= 16384
+    proba = rng.dirichlet(np.ones(3) * 0.7, size=k)
+    pairwise = G.compute_pairwise_cost(0.4, proba.shape)
+    outs = []
+    for one in (False, True):
+        if one:
+            monkeypatch.setenv('IMSEGM_TERMS_ONE_WORKGROUP', '1')
+        sess = _hip.Volume3D(*labels.shape).set_labels(labels)
+        try:
+            outs.append(sess.segment(pairwise, edge_type, proba=proba, debug=True, pinned=False))
+        finally:
+            sess.close()
+    wide, one = outs
+    for key in ('edge_weights', 'edge_weights_int', 'unary', 'unary_int', 'graph_labels', 'segm'):
+        assert np.array_equal(wide[key], one[key]), key
+    ref_w = G.edge_weights_from_graph(wide['edges'], wide['centres'], None, proba, edge_type)
+    np.testing.assert_allclose(wide['edge_weights'], ref_w, rtol=1e-10, atol=1e-13)
+
+
 def test_pinned_arrays_are_recycled():
     from pyimsegm_amd import _hip
     a = _hip.pinned_empty((300, 400), np.int32)
