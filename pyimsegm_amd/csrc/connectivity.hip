@@ -171,14 +171,20 @@ k_ccl_init_rows(const int32_t *__restrict__ labels, int32_t *__restrict__ parent
 // of a lane over its rows -- a bit each in `todo`: 3 r + 0 left (a run that crosses into the segment), + 1 up, + 2 behind -- are
 // done two at a time (union2_min_root), every lane that still has some side by side.  (One row per wave, one union per lane and
 // round: 10.4 ms at 2^30 voxels, the latency of one chain of dependent loads after the other.)
-constexpr int CR_ROWS = 4;
+#ifndef CCL_MERGE_ROWS
+#define CCL_MERGE_ROWS 4
+#endif
+constexpr int CR_ROWS = CCL_MERGE_ROWS;          // (<= 10: three bits of `todo` per row)
 
 __global__ void __launch_bounds__(256)
 k_ccl_merge_rows(const int32_t *__restrict__ labels, int32_t *parent, int D, int H, int W)
 {
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int x = (blockIdx.x * 4 + wave) * CR_SPAN + lane - 1;
-    const int y0 = blockIdx.y * CR_ROWS, z = blockIdx.z;
+    // (an eighth of every slice's row groups per XCD -- linear block index modulo 8 -> a fixed range of rows, so that a component's
+    // forest is walked out of ONE L2 -- was measured: 9.2 against 8.7 ms at config 5, one box; the blocks stay in launch order)
+    const int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+    const int x = (bx * 4 + wave) * CR_SPAN + lane - 1;
+    const int y0 = by * CR_ROWS, z = bz;
     const bool inx = x >= 0 && x < W;
     const int plane = H * W;
     const size_t row0 = (size_t)z * plane + (size_t)y0 * W;
@@ -287,6 +293,90 @@ __global__ void __launch_bounds__(256) k_ccl_flatten_sizes(int32_t *parent, int3
             }
         }
     }
+}
+
+// The same pass by tiles of 256 x 16 voxels of a slice (W a multiple of four: the rows stay 16-byte aligned): a wave takes four rows,
+// the sixteen walks of a lane side by side, and the runs add their lengths to the tile's roots in an LDS table first -- a tile meets a
+// dozen components, its rows a hundred runs --; one global atomic per root and tile at the end.  (Every run its own global atomic:
+// 70 * 10^6 of them at config 5, half of the 7.3 ms of the pass.)
+constexpr int FS_SLOTS = 64;
+
+__device__ __forceinline__ void fs_add(int *keys, int *vals, int32_t *csize, int root, int count)
+{
+    int slot = (int)(((unsigned int)root * 2654435761u) >> 26);          // 6 bits
+    for (int probe = 0; probe < FS_SLOTS; ++probe) {
+        const int old = atomicCAS(&keys[slot], -1, root);
+        if (old == -1 || old == root) {
+            atomicAdd(&vals[slot], count);
+            return;
+        }
+        slot = (slot + 1) & (FS_SLOTS - 1);
+    }
+    atomicAdd(&csize[root], count);                                        // (more components than slots in one tile)
+}
+
+__global__ void __launch_bounds__(256) k_ccl_flatten_sizes_rows(int32_t *parent, int32_t *csize, int H, int W)
+{
+    __shared__ int keys[FS_SLOTS], vals[FS_SLOTS];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if (threadIdx.x < FS_SLOTS) {
+        keys[threadIdx.x] = -1;
+        vals[threadIdx.x] = 0;
+    }
+    __syncthreads();
+    const int x = (blockIdx.x * 64 + lane) * 4;
+    const int y0 = blockIdx.y * 16 + wave * 4;
+    const size_t slice = (size_t)blockIdx.z * H * W;
+    const bool inx = x < W;                                                // (W % 4 == 0: the four voxels of a lane are in or out together)
+    int r[4][4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const bool ok = inx && y0 + j < H;
+        const int4 q = ok ? *reinterpret_cast<const int4 *>(parent + slice + (size_t)(y0 + j) * W + x) : make_int4(0, 0, 0, 0);
+        r[j][0] = q.x; r[j][1] = q.y; r[j][2] = q.z; r[j][3] = q.w;
+    }
+    while (true) {
+        bool moved = false;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            int q[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) q[c] = parent[r[j][c]];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                moved |= q[c] != r[j][c];
+                r[j][c] = q[c];
+            }
+        }
+        if (!moved) break;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const bool ok = inx && y0 + j < H;                                   // (wave uniform in y)
+        if (ok) *reinterpret_cast<int4 *>(parent + slice + (size_t)(y0 + j) * W + x) = make_int4(r[j][0], r[j][1], r[j][2], r[j][3]);
+        const bool uniform = ok && r[j][0] == r[j][1] && r[j][1] == r[j][2] && r[j][2] == r[j][3];
+        const int key = uniform ? r[j][0] : -1 - lane;                      // (a mixed lane is a run of its own)
+        const bool start = lane == 0 || lane_prev(key, -100) != key;
+        const unsigned long long starts = __ballot(start);
+        if (uniform && start) {
+            const unsigned long long above = lane == 63 ? 0ULL : starts >> (lane + 1);
+            const int lanes = above ? __ffsll((long long)above) : 64 - lane;
+            fs_add(keys, vals, csize, r[j][0], 4 * lanes);
+        }
+        if (ok && !uniform) {
+            int run = 0;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                run++;
+                if (c == 3 || r[j][c + 1] != r[j][c]) {
+                    fs_add(keys, vals, csize, r[j][c], run);
+                    run = 0;
+                }
+            }
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < FS_SLOTS && keys[threadIdx.x] >= 0) atomicAdd(&csize[keys[threadIdx.x]], vals[threadIdx.x]);
 }
 
 // component sizes: wave-aggregated atomics (runs of equal roots are the common case)
@@ -927,7 +1017,8 @@ static void conn_ccl_round(const int32_t *labels_in, int D, int H, int W, int ma
         const dim3 rows(cdiv(W, 4 * CR_SPAN), H, D), row_groups(cdiv(W, 4 * CR_SPAN), cdiv(H, CR_ROWS), D);
         hipLaunchKernelGGL(k_ccl_init_rows, rows, 256, 0, st, labels_in, w.parent, w.csize, H, W);
         hipLaunchKernelGGL(k_ccl_merge_rows, row_groups, 256, 0, st, labels_in, w.parent, D, H, W);
-        hipLaunchKernelGGL(k_ccl_flatten_sizes, cdiv(cdiv(n, 4), 256), 256, 0, st, w.parent, w.csize, n);
+        if (W % 4 == 0) hipLaunchKernelGGL(k_ccl_flatten_sizes_rows, dim3(cdiv(W, 256), cdiv(H, 16), D), 256, 0, st, w.parent, w.csize, H, W);
+        else hipLaunchKernelGGL(k_ccl_flatten_sizes, cdiv(cdiv(n, 4), 256), 256, 0, st, w.parent, w.csize, n);
         return;
     } else {
         hipLaunchKernelGGL(k_ccl_init<ALL>, grid, 256, 0, st, labels_in, state, w.parent, n, W);
