@@ -686,13 +686,18 @@ constexpr int VZ = VOL_ASSIGN_SLICES;
 #ifndef VOL_ASSIGN_TILE
 #define VOL_ASSIGN_TILE 16
 #endif
-constexpr bool VT16 = VOL_ASSIGN_TILE == 16;
-static_assert(VOL_ASSIGN_TILE == 16 || VOL_ASSIGN_TILE == 64, "tile of a wave: 16 x 16 or 64 x 4");
-constexpr int VT_W = VT16 ? 16 : 64, VT_H = VT16 ? 16 : VROWS;
-// the neighbour to the left inside the wave's row of voxels (a tile's rows are 16 lanes: row_shr:1 keeps `first` in their first lanes)
+// (32: a 32 x 8 tile -- lane & 31 in x, rows 4 (lane >> 5) .. + 3 -- whose rows are whole 128-byte lines of the label map: the 16 x 16
+// tile writes half lines, 2.2 bytes to memory for every byte of the map by the counters.)
+constexpr bool VT16 = VOL_ASSIGN_TILE != 64;              // (a tile, not a strip)
+static_assert(VOL_ASSIGN_TILE == 16 || VOL_ASSIGN_TILE == 32 || VOL_ASSIGN_TILE == 64, "tile of a wave: 16 x 16, 32 x 8 or 64 x 4");
+constexpr int VT_W = VOL_ASSIGN_TILE, VT_H = (64 / VOL_ASSIGN_TILE) * VROWS;
+constexpr int VT_SHIFT = VOL_ASSIGN_TILE == 16 ? 4 : VOL_ASSIGN_TILE == 32 ? 5 : 6;
+// the neighbour to the left inside the wave's row of voxels (the first lane of a tile's row keeps `first`)
 __device__ __forceinline__ int tile_prev(int v, int first)
 {
-    return VT16 ? __builtin_amdgcn_update_dpp(first, v, 0x111, 0xf, 0xf, false) : lane_prev(v, first);
+    if (VOL_ASSIGN_TILE == 16) return __builtin_amdgcn_update_dpp(first, v, 0x111, 0xf, 0xf, false);      // row_shr:1
+    const int p = lane_prev(v, first);
+    return (VOL_ASSIGN_TILE == 32 && (threadIdx.x & 31) == 0) ? first : p;
 }
 
 template <int NS>
@@ -874,12 +879,13 @@ k_vol_assign_f32(VolState s, const float *__restrict__ vol, int32_t *__restrict_
     const int nzv = min(VZ, s.D - z0);                        // slices of this workgroup inside the volume
     const int Y0 = (blockIdx.y % yb) * rows_per_block, Y1 = min(Y0 + rows_per_block, s.H);
     // the wave's voxels: [y0, y1w) x [xt0, xt1); the lane's: column x, rows yl .. yl + VROWS - 1
-    const int y0 = VT16 ? Y0 : Y0 + wave * VROWS;
-    const int yl = VT16 ? Y0 + (lane >> 4) * VROWS : y0;
+    constexpr int TILES_X = 64 / VT_W;                        // tiles of a workgroup side by side (4, 2 or 1), 4 / TILES_X below each other
+    const int y0 = Y0 + (wave / TILES_X) * VT_H;
+    const int yl = y0 + (lane >> VT_SHIFT) * VROWS;
     const int x0w = blockIdx.x * 64, x1w = min(x0w + 64, s.W);                    // the cross-section (the scan of the brick's list)
-    const int xt0 = VT16 ? x0w + wave * 16 : x0w, xt1 = min(xt0 + VT_W, s.W);
-    const int x = VT16 ? xt0 + (lane & 15) : x0w + lane;
-    const bool alive = VT16 ? xt0 < s.W : y0 < s.H;           // (a wave outside the volume takes part in the barriers only)
+    const int xt0 = x0w + (wave % TILES_X) * VT_W, xt1 = min(xt0 + VT_W, s.W);
+    const int x = xt0 + (lane & (VT_W - 1));
+    const bool alive = xt0 < s.W && y0 < s.H;                 // (a wave outside the volume takes part in the barriers only)
     const int y1w = min(y0 + VT_H, s.H);
     const bool xin = x < s.W;
     if (TRACK && tid < VT_SLOTS) {                            // (visible to all after the first barrier of the scan below)
