@@ -986,6 +986,28 @@ k_vol_assign_f32(VolState s, const float *__restrict__ vol, int32_t *__restrict_
         VOL_PH(4);
     }
     unsigned pending = 0;                                    // bit zi * VROWS + r: the voxel carries a label
+    // Tiles narrower than a line of the label map (16 voxels = 64 of its 128 bytes) hand their new labels to the LDS the records
+    // have left, and every wave stores four whole rows of the cross-section: written half line by half line the map cost 2.3 bytes
+    // to memory per byte (WRITE_SIZE, profiles/pmc_r06_cfg5_kernels.txt).
+#ifndef VOL_ASSIGN_DIRECT_STORES
+    constexpr bool STAGED = VOL_ASSIGN_TILE == 16 && VZ == 1;
+#else
+    constexpr bool STAGED = false;
+#endif
+    if (STAGED) {
+        int *stage = reinterpret_cast<int *>(rec);           // [16][64]
+        static_assert(sizeof(rec) >= 16 * 64 * sizeof(int), "the records' LDS holds a cross-section of labels");
+        __syncthreads();                                     // (everybody is done with the last batch's records)
+#pragma unroll
+        for (int r = 0; r < VROWS; ++r) stage[(yl - Y0 + r) * 64 + (x - x0w)] = best_k[0][r];
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < VROWS; ++r) {
+            const int ys = Y0 + wave * VROWS + r, xs = x0w + lane;
+            const int k = stage[(wave * VROWS + r) * 64 + lane];
+            if (k >= 0 && xs < s.W && ys < s.H) labels[((size_t)z0 * s.H + ys) * s.W + xs] = k;
+        }
+    }
     if (alive) {
 #pragma unroll
         for (int zi = 0; zi < VZ; ++zi)
@@ -993,8 +1015,11 @@ k_vol_assign_f32(VolState s, const float *__restrict__ vol, int32_t *__restrict_
             for (int r = 0; r < VROWS; ++r) {
                 if (!(xin && (yl + r) < s.H && zi < nzv)) continue;
                 const size_t p = ((size_t)(z0 + zi) * s.H + yl + r) * s.W + x;
-                if (best_k[zi][r] >= 0) labels[p] = best_k[zi][r];
-                else best_k[zi][r] = labels[p];                   // uncovered voxel keeps its previous assignment
+                if (best_k[zi][r] >= 0) {
+                    if (!STAGED) labels[p] = best_k[zi][r];
+                } else {
+                    best_k[zi][r] = labels[p];                    // uncovered voxel keeps its previous assignment
+                }
                 if (best_k[zi][r] >= 0) pending |= 1u << (zi * VROWS + r);
             }
     }
@@ -1597,6 +1622,7 @@ __device__ __forceinline__ void neighbour_insert(int32_t *table, int cap, int b,
 // MODE 0: bit (row b, column a), a < b, of the K x K bitmap; MODE 1: a into row b AND b into row a of the neighbour table.
 constexpr int VA_ROWS = 4;
 constexpr int VA_SLOTS = 64;
+constexpr int VA_DEPTH = 8;           // slices a workgroup walks (sums of a table slot stay far below 2^31: 8 192 voxels x 65 535)
 
 template <int MODE>
 __device__ __forceinline__ void adjacency_report(int l, int nb, int words, uint32_t *bitmap, int32_t *table, int cap, int *overflow)
@@ -1617,78 +1643,89 @@ __global__ void __launch_bounds__(256)
 k_vol_adjacency_runs(const int32_t *__restrict__ labels, int D, int H, int W, int words, uint32_t *bitmap,
                      long long *__restrict__ cacc, int32_t *table, int cap, int *overflow)
 {
-    __shared__ int h_key[VA_SLOTS], h_n[VA_SLOTS], h_sy[VA_SLOTS], h_sx[VA_SLOTS];
+    // (round 6, later: a workgroup walks VA_DEPTH slices -- the rows of the slice behind are the next turn's own rows, so a voxel is
+    // loaded once instead of twice, and the centre sums of all the slices meet in one LDS table: 4.85 -> see profiles/README_r06.md)
+    __shared__ int h_key[VA_SLOTS], h_n[VA_SLOTS], h_sz[VA_SLOTS], h_sy[VA_SLOTS], h_sx[VA_SLOTS];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     if (threadIdx.x < VA_SLOTS) {
         h_key[threadIdx.x] = -1;
         h_n[threadIdx.x] = 0;
+        h_sz[threadIdx.x] = 0;
         h_sy[threadIdx.x] = 0;
         h_sx[threadIdx.x] = 0;
     }
     __syncthreads();
-    const int z = blockIdx.z;
+    const int z_first = blockIdx.z * VA_DEPTH, z_end = min(z_first + VA_DEPTH, D);
     const int y0 = (blockIdx.y * 4 + wave) * VA_ROWS;
     const int x = blockIdx.x * 64 + lane;
     const bool xin = x < W;
-    const int32_t *__restrict__ base = labels + ((size_t)z * H + y0) * W;          // (wave uniform)
     const size_t plane = (size_t)H * W;
-    int lab[VA_ROWS + 1], behind[VA_ROWS];
-#pragma unroll
-    for (int r = 0; r <= VA_ROWS; ++r) lab[r] = (xin && y0 + r < H) ? base[(size_t)r * W + x] : -1;
-#pragma unroll
-    for (int r = 0; r < VA_ROWS; ++r) behind[r] = (xin && y0 + r < H && z + 1 < D) ? base[plane + (size_t)r * W + x] : -1;
     const unsigned long long le = (lane == 63) ? ~0ULL : ((2ULL << lane) - 1ULL);
+    int lab[VA_ROWS + 1], behind[VA_ROWS + 1];
+    {
+        const int32_t *__restrict__ first = labels + ((size_t)z_first * H + y0) * W;
 #pragma unroll
-    for (int r = 0; r < VA_ROWS; ++r) {
-        const int y = y0 + r;
-        const int l = lab[r];
-        const bool act = l >= 0;                                   // (the active lanes of a row are lanes 0 .. nact - 1)
-        int right = lane_next(l, -1);
-        if (lane == 63) right = (x + 1 < W && y < H) ? base[(size_t)r * W + x + 1] : -1;
-        const int left = lane_prev(l, -2);
-        const int below = lab[r + 1], back = behind[r];
-        const int below_left = lane_prev(below, -2), back_left = lane_prev(back, -2);
-        if (act) {
-            if (right >= 0 && right != l) adjacency_report<MODE>(l, right, words, bitmap, table, cap, overflow);
-            if (below >= 0 && below != l && !(left == l && below_left == below))
-                adjacency_report<MODE>(l, below, words, bitmap, table, cap, overflow);
-            if (back >= 0 && back != l && !(left == l && back_left == back))
-                adjacency_report<MODE>(l, back, words, bitmap, table, cap, overflow);
-        }
-        const bool start = act && left != l;                       // (lane 0: left = -2)
-        const unsigned long long starts = __ballot(start);
-        const int nact = __popcll(__ballot(act));
-        if (start) {
-            const unsigned long long above = starts & ~le;
-            const int len = (above ? __ffsll((long long)above) - 1 : nact) - lane;
-            const int sy = len * y, sx = len * x + (len * (len - 1)) / 2;
-            int slot = (int)(((unsigned int)l * 2654435761u) >> 26);          // 6 bits
-            bool placed = false;
-            for (int probe = 0; probe < VA_SLOTS; ++probe) {
-                const int old = atomicCAS(&h_key[slot], -1, l);
-                if (old == -1 || old == l) {
-                    placed = true;
-                    break;
+        for (int r = 0; r <= VA_ROWS; ++r) lab[r] = (xin && y0 + r < H) ? first[(size_t)r * W + x] : -1;
+    }
+    for (int z = z_first; z < z_end; ++z) {
+        const int32_t *__restrict__ base = labels + ((size_t)z * H + y0) * W;          // (wave uniform)
+#pragma unroll
+        for (int r = 0; r <= VA_ROWS; ++r) behind[r] = (xin && y0 + r < H && z + 1 < D) ? base[plane + (size_t)r * W + x] : -1;
+#pragma unroll
+        for (int r = 0; r < VA_ROWS; ++r) {
+            const int y = y0 + r;
+            const int l = lab[r];
+            const bool act = l >= 0;                                   // (the active lanes of a row are lanes 0 .. nact - 1)
+            int right = lane_next(l, -1);
+            if (lane == 63) right = (x + 1 < W && y < H) ? base[(size_t)r * W + x + 1] : -1;
+            const int left = lane_prev(l, -2);
+            const int below = lab[r + 1], back = behind[r];
+            const int below_left = lane_prev(below, -2), back_left = lane_prev(back, -2);
+            if (act) {
+                if (right >= 0 && right != l) adjacency_report<MODE>(l, right, words, bitmap, table, cap, overflow);
+                if (below >= 0 && below != l && !(left == l && below_left == below))
+                    adjacency_report<MODE>(l, below, words, bitmap, table, cap, overflow);
+                if (back >= 0 && back != l && !(left == l && back_left == back))
+                    adjacency_report<MODE>(l, back, words, bitmap, table, cap, overflow);
+            }
+            const bool start = act && left != l;                       // (lane 0: left = -2)
+            const unsigned long long starts = __ballot(start);
+            const int nact = __popcll(__ballot(act));
+            if (start) {
+                const unsigned long long above = starts & ~le;
+                const int len = (above ? __ffsll((long long)above) - 1 : nact) - lane;
+                const int sy = len * y, sx = len * x + (len * (len - 1)) / 2;
+                int slot = (int)(((unsigned int)l * 2654435761u) >> 26);          // 6 bits
+                bool placed = false;
+                for (int probe = 0; probe < VA_SLOTS; ++probe) {
+                    const int old = atomicCAS(&h_key[slot], -1, l);
+                    if (old == -1 || old == l) {
+                        placed = true;
+                        break;
+                    }
+                    slot = (slot + 1) & (VA_SLOTS - 1);
                 }
-                slot = (slot + 1) & (VA_SLOTS - 1);
-            }
-            if (placed) {
-                atomicAdd(&h_n[slot], len);
-                atomicAdd(&h_sy[slot], sy);
-                atomicAdd(&h_sx[slot], sx);
-            } else {                                               // (more than VA_SLOTS labels in a 64 x 16 cross-section)
-                atomic_add_i64(cacc + (size_t)l * 4 + 0, len);
-                atomic_add_i64(cacc + (size_t)l * 4 + 1, (long long)len * z);
-                atomic_add_i64(cacc + (size_t)l * 4 + 2, (long long)sy);
-                atomic_add_i64(cacc + (size_t)l * 4 + 3, (long long)sx);
+                if (placed) {
+                    atomicAdd(&h_n[slot], len);
+                    atomicAdd(&h_sz[slot], len * z);
+                    atomicAdd(&h_sy[slot], sy);
+                    atomicAdd(&h_sx[slot], sx);
+                } else {                                               // (more than VA_SLOTS labels in the slices of a 64 x 16 cross-section)
+                    atomic_add_i64(cacc + (size_t)l * 4 + 0, len);
+                    atomic_add_i64(cacc + (size_t)l * 4 + 1, (long long)len * z);
+                    atomic_add_i64(cacc + (size_t)l * 4 + 2, (long long)sy);
+                    atomic_add_i64(cacc + (size_t)l * 4 + 3, (long long)sx);
+                }
             }
         }
+#pragma unroll
+        for (int r = 0; r <= VA_ROWS; ++r) lab[r] = behind[r];
     }
     __syncthreads();
     if (threadIdx.x < VA_SLOTS && h_key[threadIdx.x] >= 0) {
         const int k = h_key[threadIdx.x], n = h_n[threadIdx.x];
         atomic_add_i64(cacc + (size_t)k * 4 + 0, n);
-        atomic_add_i64(cacc + (size_t)k * 4 + 1, (long long)n * z);
+        atomic_add_i64(cacc + (size_t)k * 4 + 1, h_sz[threadIdx.x]);
         atomic_add_i64(cacc + (size_t)k * 4 + 2, h_sy[threadIdx.x]);
         atomic_add_i64(cacc + (size_t)k * 4 + 3, h_sx[threadIdx.x]);
     }
@@ -1704,7 +1741,7 @@ __global__ void k_vol_centres_finalize(const long long *__restrict__ cacc, int K
         centres[3 * k + c] = n > 0 ? i64_to_double(cacc[(size_t)k * 4 + 1 + c]) / (double)n : -1.0;
 }
 
-static inline dim3 vol_adjacency_grid(int D, int H, int W) { return dim3(cdiv(W, 64), cdiv(H, 4 * VA_ROWS), D); }
+static inline dim3 vol_adjacency_grid(int D, int H, int W) { return dim3(cdiv(W, 64), cdiv(H, 4 * VA_ROWS), cdiv(D, VA_DEPTH)); }
 
 int launch_vol_adjacency(const int32_t *labels, int D, int H, int W, int K, int words, uint32_t *bitmap, long long *cacc,
                          double *centres, uint8_t *present, hipStream_t st)
