@@ -778,7 +778,10 @@ __device__ __forceinline__ void vol_walk_f32(const VolRec *rec, const int *list,
                 const float t = pv[zi][r] - rc.cv;
                 d = d + t * t;
                 const bool take = inx && iny && (best_d[zi][r] > d || (best_d[zi][r] == d && ck < best_k[zi][r]));
-                best_d[zi][r] = take ? d : best_d[zi][r];           // (selects, no change of the exec mask)
+                // (the compiler guards the arithmetic of a row with the window test -- branches; written with & and | instead, as
+                // compares into masks and two selects, every row is computed for every candidate and the kernel spills: 14.7
+                // against 8.7 ms per sweep at config 5)
+                best_d[zi][r] = take ? d : best_d[zi][r];
                 best_k[zi][r] = take ? ck : best_k[zi][r];
             }
         }
