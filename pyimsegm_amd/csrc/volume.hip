@@ -849,10 +849,12 @@ __global__ void __launch_bounds__(256) k_vol_scatter_f32(VolState s)
     }
 }
 
-// waves per SIMD the register allocation aims at: the kernel takes 80 registers when left alone (six waves), 72 at seven -- 2.53
-// against 2.68 ms per sweep of a quarter volume, alternating on one box --, and spills at eight (64 registers: 3.47 ms)
+// waves per SIMD the register allocation aims at.  On 64 x 4 strips: 80 registers when left alone (six waves), 72 at seven -- 2.53
+// against 2.68 ms per sweep of a quarter volume, alternating on one box --, spills at eight (64 registers: 3.47 ms).  On 16 x 16
+// tiles with the labels staged through LDS (more per-lane state: own rows, tile geometry) seven waves spill into scratch inside the
+// walk: 6 -> 7.48, 7 -> 8.72, 5 -> 8.37, 8 -> 11.97 ms per sweep at config 5, one box each pair.
 #ifndef VOL_ASSIGN_WAVES
-#define VOL_ASSIGN_WAVES 7
+#define VOL_ASSIGN_WAVES 6
 #endif
 #define VOL_ASSIGN_ATTR __attribute__((amdgpu_waves_per_eu(VOL_ASSIGN_WAVES, VOL_ASSIGN_WAVES)))
 template <bool TRACK>
