@@ -1160,10 +1160,15 @@ template <typename T> struct __attribute__((packed, aligned(4))) Quad {
 };
 static_assert(VU_STEP == 4, "a round of the update is one Quad");
 
-__global__ void __launch_bounds__(256)
+// (lanes per workgroup, config 5, one box: 64 -> 3.26, 256 -> 2.93, 512 -> 3.13, 1 024 -> 3.89 ms per sweep; an eighth of the centroids
+// per XCD -- block index modulo 8 -> a fixed range -- 3.06 against 2.99: not kept)
+#ifndef VOL_UPDATE_BLOCK
+#define VOL_UPDATE_BLOCK 256
+#endif
+__global__ void __launch_bounds__(VOL_UPDATE_BLOCK)
 k_vol_update_f32_lane(VolState s, const float *__restrict__ vol, const int32_t *__restrict__ labels)
 {
-    const int k = blockIdx.x * 256 + threadIdx.x;
+    const int k = blockIdx.x * VOL_UPDATE_BLOCK + threadIdx.x;
     if (k >= s.K) return;
     int *bb = s.bbox + (size_t)k * 6;
     int *w = s.win + (size_t)k * 6;
@@ -1230,7 +1235,7 @@ int launch_vol_slic_f32(VolState s, const float *vol, int32_t *labels, int max_i
         if (it + 1 < max_iter) {
             if (ev_a) hipExtLaunchKernelGGL(k_vol_assign_f32<true>, grid, dim3(256), 0, st, ev_a, ev_b, 0, s, vol, labels);
             else hipLaunchKernelGGL(k_vol_assign_f32<true>, grid, 256, 0, st, s, vol, labels);
-            hipLaunchKernelGGL(k_vol_update_f32_lane, cdiv(s.K, 256), 256, 0, st, s, vol, labels);
+            hipLaunchKernelGGL(k_vol_update_f32_lane, cdiv(s.K, VOL_UPDATE_BLOCK), VOL_UPDATE_BLOCK, 0, st, s, vol, labels);
         } else {
             if (ev_a) hipExtLaunchKernelGGL(k_vol_assign_f32<false>, grid, dim3(256), 0, st, ev_a, ev_b, 0, s, vol, labels);
             else hipLaunchKernelGGL(k_vol_assign_f32<false>, grid, 256, 0, st, s, vol, labels);
