@@ -227,7 +227,9 @@ IMSEGM_API int imsegm_volume_slic(imsegm_image2d *vol, int n_segments, double co
                                   const double *spacing, int max_iter, int enforce_connectivity, double min_size_factor,
                                   double max_size_factor, int start_label, int *n_labels_out);
 /* Replaces skimage.measure.label(segments) (imsegm/superpixels.py:111): components of equal non-zero
- * value under full connectivity, numbered 1.. in raster order of their first voxel; 0 stays background. */
+ * value under full connectivity, numbered 1.. in raster order of their first voxel; 0 stays background.
+ * (On the map imsegm_volume_slic has just written with enforce_connectivity -- every value > 0 one connected set -- this is a
+ * renumbering by first voxels and is computed as one; any other map goes through the union-find.  Same result either way.) */
 IMSEGM_API int imsegm_volume_label_cc(imsegm_image2d *vol, int *n_labels_out);
 /* Replaces imsegm.features_cython.computeGrayImage3dMean / Energy / Variance (features_cython.pyx:144-219);
  * outputs n_labels float64 each (NULL = not wanted). */
