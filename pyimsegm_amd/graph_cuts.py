@@ -264,7 +264,19 @@ class _SideBySideGate(object):
         return self._active
 
 
-_SIDE_BY_SIDE = _SideBySideGate()
+def _gate_from_env():
+    """``IMSEGM_FIT_GATE=slots,callers`` (experiments; slots x callers must stay below the 64 BLAS buffers)"""
+    import os
+    try:
+        slots, callers = (int(v) for v in os.environ.get('IMSEGM_FIT_GATE', '').split(','))
+        if slots >= 1 and callers >= 10 and slots * callers < 64:
+            return _SideBySideGate(slots, callers)
+    except ValueError:
+        pass
+    return _SideBySideGate()
+
+
+_SIDE_BY_SIDE = _gate_from_env()
 
 
 #: rows from which the restarts of a mixture fit run side by side (below, the thread pools, the stream bookkeeping and the one-thread
