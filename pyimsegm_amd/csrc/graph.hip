@@ -302,12 +302,21 @@ int launch_edge_extract(const uint32_t *bitmap, int K, int words, int32_t *rowco
 }
 
 // ---- LUT gathers --------------------------------------------------------------------------------------
+// (four indices per lane where the arrays are 16-byte aligned: one 16-byte load and store instead of four of each -- 2.67 -> see
+// profiles/README_r06.md for the 2^30 voxels of config 5)
 __global__ void __launch_bounds__(256)
 k_gather_i32(const int32_t *__restrict__ lut, const int32_t *__restrict__ idx, size_t n, int32_t *__restrict__ out, size_t zs)
 {
     ZSHIFT(lut, zs); ZSHIFT(idx, zs); ZSHIFT(out, zs);
-    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) out[i] = lut[idx[i]];
+    const size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (i >= n) return;
+    const bool aligned = ((reinterpret_cast<uintptr_t>(idx) | reinterpret_cast<uintptr_t>(out)) & 15) == 0;
+    if (aligned && i + 4 <= n) {
+        const int4 q = *reinterpret_cast<const int4 *>(idx + i);
+        *reinterpret_cast<int4 *>(out + i) = make_int4(lut[q.x], lut[q.y], lut[q.z], lut[q.w]);
+    } else {
+        for (size_t j = i; j < n && j < i + 4; ++j) out[j] = lut[idx[j]];
+    }
 }
 
 __global__ void __launch_bounds__(256)
@@ -323,7 +332,7 @@ k_gather_f64(const double *__restrict__ lut, int C, const int32_t *__restrict__ 
 
 int launch_gather_labels(const int32_t *lut, const int32_t *idx, size_t n, int32_t *out, hipStream_t st, ZBatch zb)
 {
-    hipLaunchKernelGGL(k_gather_i32, dim3(cdiv((long)n, 256), 1, zb.nz), 256, 0, st, lut, idx, n, out, zb.zs);
+    hipLaunchKernelGGL(k_gather_i32, dim3(cdiv(cdiv((long)n, 4), 256), 1, zb.nz), 256, 0, st, lut, idx, n, out, zb.zs);
     HIP_TRY(hipGetLastError());
     return 0;
 }
