@@ -53,7 +53,8 @@ struct StatParams {
 // slot of the label (open addressing; a full table falls back to global atomics).
 // (RW: rows per lane -- ST_ROWS, or half of that for float64 sources (the filter responses of the texture path): 16 rows of three
 // doubles in flight plus their IEEE divisions took 248 registers, two waves per SIMD)
-template <typename T> struct StatRows { static constexpr int value = sizeof(T) == 8 ? ST_ROWS / 2 : ST_ROWS; };
+// (one channel: the first pass keeps four limbs per row in registers -- eight rows; the second two -- sixteen)
+template <typename T, int NC = 3, int PASS = 1> struct StatRows { static constexpr int value = (sizeof(T) == 8 || (NC == 1 && PASS == 1)) ? ST_ROWS / 2 : ST_ROWS; };
 
 // NC = 1: one gray plane (the volumes, features_cython.pyx:144-219) -- one channel loaded and summed into the columns of channel 0,
 // the five quantities of the first pass (count, two limbs of the value sum, two of the squared sum) through ONE transposed reduction
@@ -62,7 +63,7 @@ __global__ void __launch_bounds__(256, 4)      // (four workgroups a CU = four w
 k_color_stats(const T *__restrict__ img, const int32_t *__restrict__ labels, StatParams sp,
               const float *__restrict__ mean32, long long *__restrict__ acc)
 {
-    constexpr int RW = StatRows<T>::value;
+    constexpr int RW = StatRows<T, NC, PASS>::value;
     ZSHIFT(img, sp.zs); ZSHIFT(labels, sp.zs); ZSHIFT(mean32, sp.zs); ZSHIFT(acc, sp.zs); ZSHIFT(sp.ssq_dev, sp.zs);
     constexpr int NQ = (PASS == 1) ? 13 : 6;
     __shared__ int keys[ST_SLOTS];
@@ -109,6 +110,20 @@ k_color_stats(const T *__restrict__ img, const int32_t *__restrict__ labels, Sta
         for (int c = 0; c < NC; ++c) {
             const size_t idx = NC == 1 ? p : (sp.planar ? (size_t)c * sp.plane_stride + p : 3 * p + c);
             v[r][c] = sp.prescale ? (dead ? 0.f : (float)(((double)img[idx] * mul) / div)) : load_f32(img, idx);
+        }
+    }
+    double limb[(NC == 1 && PASS == 1) ? RW : 1][(NC == 1 && PASS == 1) ? 4 : 1];
+    if constexpr (NC == 1 && PASS == 1) {
+#pragma unroll
+        for (int r = 0; r < RW; ++r) {
+            const float val = v[r][0];
+            const float term = __fmul_rn(val, val);
+            const double t = (double)term * sp.scale_e, h = trunc(t);
+            const double tv = (double)val * sp.scale_v, hv = trunc(tv);
+            limb[r][0] = hv;
+            limb[r][1] = trunc((tv - hv) * 4294967296.0);
+            limb[r][2] = h;
+            limb[r][3] = trunc((t - h) * 4294967296.0);
         }
     }
     while (true) {
@@ -169,6 +184,9 @@ k_color_stats(const T *__restrict__ img, const int32_t *__restrict__ labels, Sta
         }
         slot = __shfl(slot, lane & 48, 64);
         if constexpr (NC == 1) {
+            // (one channel, eight rows per lane: the limbs of a voxel are formed ONCE, in front of the loop over the labels of the row
+            // -- 4 x 8 doubles per lane --, and a pass over a label only adds the limbs of its voxels: 16 rows and the limbs formed
+            // again for every label of a 16 x 16 block were 4.5 + 2.1 ms for the 2^30 voxels of config 5)
             const bool live = k != 0x7fffffff;
             const float m32 = (PASS == 2 && live) ? mean32[3 * k] : 0.f;
             double q[8];
@@ -176,21 +194,21 @@ k_color_stats(const T *__restrict__ img, const int32_t *__restrict__ labels, Sta
             for (int j = 0; j < 8; ++j) q[j] = 0;
 #pragma unroll
             for (int r = 0; r < RW; ++r) {
-                if (lab[r] != k || !live) continue;
-                lab[r] = 0x7fffffff;
-                const float val = v[r][0];
-                float term = PASS == 1 ? __fmul_rn(val, val) : __fsub_rn(val, m32);
-                if (PASS == 2) term = __fmul_rn(term, term);
-                asm volatile("" : "+v"(term));
-                const double t = (double)term * sp.scale_e, h = trunc(t);
+                const bool on = lab[r] == k && live;
+                lab[r] = on ? 0x7fffffff : lab[r];
                 if (PASS == 1) {
-                    const double tv = (double)val * sp.scale_v, hv = trunc(tv);
-                    q[0] += hv;
-                    q[1] += trunc((tv - hv) * 4294967296.0);
-                    q[2] += h;
-                    q[3] += trunc((t - h) * 4294967296.0);
-                    q[6] += 1.0;
-                } else {
+                    q[0] += on ? limb[r][0] : 0.0;
+                    q[1] += on ? limb[r][1] : 0.0;
+                    q[2] += on ? limb[r][2] : 0.0;
+                    q[3] += on ? limb[r][3] : 0.0;
+                    q[6] += on ? 1.0 : 0.0;
+                } else if (on) {
+                    // (second pass: the mean is the label's -- one load per pass over a label, not one gather per voxel: forming
+                    // these two limbs in front of the loop like the first pass's four measured 2.44 against 2.12 ms)
+                    const float d = __fsub_rn(v[r][0], m32);
+                    float term = __fmul_rn(d, d);
+                    asm volatile("" : "+v"(term));
+                    const double t = (double)term * sp.scale_e, h = trunc(t);
                     q[0] += h;
                     q[1] += trunc((t - h) * 4294967296.0);
                 }
@@ -320,7 +338,8 @@ static void launch_pass(int pass, const T *img, const int32_t *labels, StatParam
                         long long *acc, hipStream_t st, int nz)
 {
     dim3 grid(cdiv(sp.W, 64), cdiv(sp.H, 4 * StatRows<T>::value), nz);
-    if (sp.planar && sp.plane_stride == 0 && !sp.prescale) {         // one gray plane: channel 0 only (the others stay 0)
+    if (sp.planar && sp.plane_stride == 0 && !sp.prescale) {
+        grid.y = cdiv(sp.H, 4 * (pass == 1 ? StatRows<T, 1, 1>::value : StatRows<T, 1, 2>::value));         // one gray plane: channel 0 only (the others stay 0)
         if (pass == 1) hipLaunchKernelGGL((k_color_stats<T, 1, false, 1>), grid, 256, 0, st, img, labels, sp, mean32, acc);
         else hipLaunchKernelGGL((k_color_stats<T, 2, false, 1>), grid, 256, 0, st, img, labels, sp, mean32, acc);
         return;
