@@ -1153,12 +1153,17 @@ k_vol_assign_f32(VolState s, const float *__restrict__ vol, int32_t *__restrict_
 // by its lanes and reused by the next steps of the walk (L1 / L2), and the additions of a chain happen in exactly the order of the
 // serial loop: z, then y, then x ascending.  Same results bit for bit (the parity tests of the float32 volumes; the full-size
 // label map against scikit-image's).
-constexpr int VU_STEP = 4;          // (8 -- sixteen loads in flight per lane -- measured slower: 3.81 against 3.42 ms per sweep at config 5)
+constexpr int VU_STEP = 4;          // voxels of one 16-byte load
 // four consecutive 4-byte elements at a 4-byte aligned address: one global_load_dwordx4
 template <typename T> struct __attribute__((packed, aligned(4))) Quad {
     T v[4];
 };
 static_assert(VU_STEP == 4, "a round of the update is one Quad");
+// (quads of a lane requested per round, config 5, ms per sweep: 1 -> 3.01, 2 -> 2.03, 4 -> 1.81, 6 -> 1.84, 8 -> 1.82)
+#ifndef VOL_UPDATE_QUADS
+#define VOL_UPDATE_QUADS 4
+#endif
+constexpr int VU_QUADS = VOL_UPDATE_QUADS;
 
 // (lanes per workgroup, config 5, one box: 64 -> 3.26, 256 -> 2.93, 512 -> 3.13, 1 024 -> 3.89 ms per sweep; an eighth of the centroids
 // per XCD -- block index modulo 8 -> a fixed range -- 3.06 against 2.99: not kept)
@@ -1192,23 +1197,39 @@ k_vol_update_f32_lane(VolState s, const float *__restrict__ vol, const int32_t *
             // different boxes, so every load instruction touches 64 cache lines whatever its width; a quarter of the instructions.
             // Voxels past x1 are loaded -- the buffers end in padding -- and masked.  The values of a quad are requested only where
             // one of its labels is the lane's -- under half of a box's voxels: 3.01 against 3.25 ms per sweep at config 5, one box.)
-            for (int x = x0; x <= x1; x += VU_STEP) {
-                const Quad<int> lab = *reinterpret_cast<const Quad<int> *>(labels + row + x);
-#ifndef VOL_UPDATE_EAGER_VALUES
-                Quad<float> val = { { 0.f, 0.f, 0.f, 0.f } };
-                if (lab.v[0] == k || lab.v[1] == k || lab.v[2] == k || lab.v[3] == k) val = *reinterpret_cast<const Quad<float> *>(vol + row + x);
-#else
-                const Quad<float> val = *reinterpret_cast<const Quad<float> *>(vol + row + x);
-#endif
+            // (VU_QUADS quads per round, all requested before the first is added: a lane's consecutive quads lie in one or two cache
+            // lines, and requested together they are ONE trip to the L2 where one quad per round was a trip each -- the lines a wave
+            // touches in a round, 64 lanes x 2 arrays, do not survive in the L1 until its next round)
+            for (int x = x0; x <= x1; x += VU_STEP * VU_QUADS) {
+                Quad<int> lab[VU_QUADS];
+                Quad<float> val[VU_QUADS];
 #pragma unroll
-                for (int j = 0; j < VU_STEP; ++j) {
-                    const bool mine = lab.v[j] == k && x + j <= x1;
-                    sz = sz + (mine ? fz : 0.f);
-                    sy = sy + (mine ? fy : 0.f);
-                    sx = sx + (mine ? (float)(x + j) : 0.f);
-                    sv = sv + (mine ? val.v[j] : 0.f);
-                    cnt += mine ? 1 : 0;
+                for (int q = 0; q < VU_QUADS; ++q) {
+                    lab[q] = { { -1, -1, -1, -1 } };
+                    if (x + VU_STEP * q <= x1) lab[q] = *reinterpret_cast<const Quad<int> *>(labels + row + x + VU_STEP * q);
                 }
+#pragma unroll
+                for (int q = 0; q < VU_QUADS; ++q) {
+                    val[q] = { { 0.f, 0.f, 0.f, 0.f } };
+#ifndef VOL_UPDATE_EAGER_VALUES
+                    if (lab[q].v[0] == k || lab[q].v[1] == k || lab[q].v[2] == k || lab[q].v[3] == k)
+#else
+                    if (x + VU_STEP * q <= x1)
+#endif
+                        val[q] = *reinterpret_cast<const Quad<float> *>(vol + row + x + VU_STEP * q);
+                }
+#pragma unroll
+                for (int q = 0; q < VU_QUADS; ++q)
+#pragma unroll
+                    for (int j = 0; j < VU_STEP; ++j) {
+                        const int xx = x + VU_STEP * q + j;
+                        const bool mine = lab[q].v[j] == k && xx <= x1;
+                        sz = sz + (mine ? fz : 0.f);
+                        sy = sy + (mine ? fy : 0.f);
+                        sx = sx + (mine ? (float)xx : 0.f);
+                        sv = sv + (mine ? val[q].v[j] : 0.f);
+                        cnt += mine ? 1 : 0;
+                    }
             }
         }
     }
