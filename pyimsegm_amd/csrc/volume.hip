@@ -1655,6 +1655,28 @@ constexpr int VA_ROWS = 4;
 constexpr int VA_SLOTS = 64;
 constexpr int VA_DEPTH = 8;           // slices a workgroup walks (sums of a table slot stay far below 2^31: 8 192 voxels x 65 535)
 
+// The (up to) three neighbour pairs a voxel reports, both directions each: the six table cells a pair's labels hash to are looked at
+// TOGETHER -- one trip to memory -- and nearly always hold the label already (a pair of neighbouring supervoxels is reported by every
+// voxel along their common face); what is not found there goes through neighbour_insert.  (One pair after the other, each with
+// its own look: twenty-four dependent trips per wave of four rows, 4.6 ms for the 2^30 voxels of config 5.)
+__device__ __forceinline__ void neighbour_insert3(int32_t *table, int cap, int l, const int (&nb)[3], int *overflow)
+{
+    int seen[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        const int row = i < 3 ? l : nb[i - 3], val = i < 3 ? nb[i] : l;
+        seen[i] = val;                                             // (no pair: nothing to do)
+        if (nb[i % 3] >= 0)
+            seen[i] = __hip_atomic_load(table + (size_t)row * cap + ((((unsigned)val * 2654435761u) >> 7) & (unsigned)(cap - 1)),
+                                        __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        const int row = i < 3 ? l : nb[i - 3], val = i < 3 ? nb[i] : l;
+        if (nb[i % 3] >= 0 && seen[i] != val) neighbour_insert(table, cap, row, val, overflow);
+    }
+}
+
 template <int MODE>
 __device__ __forceinline__ void adjacency_report(int l, int nb, int words, uint32_t *bitmap, int32_t *table, int cap, int *overflow)
 {
@@ -1692,32 +1714,45 @@ k_vol_adjacency_runs(const int32_t *__restrict__ labels, int D, int H, int W, in
     const bool xin = x < W;
     const size_t plane = (size_t)H * W;
     const unsigned long long le = (lane == 63) ? ~0ULL : ((2ULL << lane) - 1ULL);
-    int lab[VA_ROWS + 1], behind[VA_ROWS + 1];
+    // (edge: the voxel right of the wave's last lane, fetched by that lane WITH the rows -- asked for row by row where it is used, it
+    // was a trip to memory per row and slice for the sake of one lane)
+    int lab[VA_ROWS + 1], behind[VA_ROWS + 1], edge[VA_ROWS], edge_behind[VA_ROWS];
+    const bool last = lane == 63 && x + 1 < W;
     {
         const int32_t *__restrict__ first = labels + ((size_t)z_first * H + y0) * W;
 #pragma unroll
         for (int r = 0; r <= VA_ROWS; ++r) lab[r] = (xin && y0 + r < H) ? first[(size_t)r * W + x] : -1;
+#pragma unroll
+        for (int r = 0; r < VA_ROWS; ++r) edge[r] = (last && y0 + r < H) ? first[(size_t)r * W + x + 1] : -1;
     }
     for (int z = z_first; z < z_end; ++z) {
         const int32_t *__restrict__ base = labels + ((size_t)z * H + y0) * W;          // (wave uniform)
 #pragma unroll
         for (int r = 0; r <= VA_ROWS; ++r) behind[r] = (xin && y0 + r < H && z + 1 < D) ? base[plane + (size_t)r * W + x] : -1;
 #pragma unroll
+        for (int r = 0; r < VA_ROWS; ++r) edge_behind[r] = (last && y0 + r < H && z + 1 < D) ? base[plane + (size_t)r * W + x + 1] : -1;
+#pragma unroll
         for (int r = 0; r < VA_ROWS; ++r) {
             const int y = y0 + r;
             const int l = lab[r];
             const bool act = l >= 0;                                   // (the active lanes of a row are lanes 0 .. nact - 1)
             int right = lane_next(l, -1);
-            if (lane == 63) right = (x + 1 < W && y < H) ? base[(size_t)r * W + x + 1] : -1;
+            if (lane == 63) right = edge[r];
             const int left = lane_prev(l, -2);
             const int below = lab[r + 1], back = behind[r];
             const int below_left = lane_prev(below, -2), back_left = lane_prev(back, -2);
-            if (act) {
-                if (right >= 0 && right != l) adjacency_report<MODE>(l, right, words, bitmap, table, cap, overflow);
-                if (below >= 0 && below != l && !(left == l && below_left == below))
-                    adjacency_report<MODE>(l, below, words, bitmap, table, cap, overflow);
-                if (back >= 0 && back != l && !(left == l && back_left == back))
-                    adjacency_report<MODE>(l, back, words, bitmap, table, cap, overflow);
+            const bool rep_right = act && right >= 0 && right != l;
+            const bool rep_below = act && below >= 0 && below != l && !(left == l && below_left == below);
+            const bool rep_back = act && back >= 0 && back != l && !(left == l && back_left == back);
+            if (MODE == 1) {
+                if (rep_right || rep_below || rep_back) {
+                    const int nb[3] = { rep_right ? right : -1, rep_below ? below : -1, rep_back ? back : -1 };
+                    neighbour_insert3(table, cap, l, nb, overflow);
+                }
+            } else {
+                if (rep_right) adjacency_report<MODE>(l, right, words, bitmap, table, cap, overflow);
+                if (rep_below) adjacency_report<MODE>(l, below, words, bitmap, table, cap, overflow);
+                if (rep_back) adjacency_report<MODE>(l, back, words, bitmap, table, cap, overflow);
             }
             const bool start = act && left != l;                       // (lane 0: left = -2)
             const unsigned long long starts = __ballot(start);
@@ -1751,6 +1786,8 @@ k_vol_adjacency_runs(const int32_t *__restrict__ labels, int D, int H, int W, in
         }
 #pragma unroll
         for (int r = 0; r <= VA_ROWS; ++r) lab[r] = behind[r];
+#pragma unroll
+        for (int r = 0; r < VA_ROWS; ++r) edge[r] = edge_behind[r];
     }
     __syncthreads();
     if (threadIdx.x < VA_SLOTS && h_key[threadIdx.x] >= 0) {
