@@ -1724,13 +1724,20 @@ k_vol_adjacency_runs(const int32_t *__restrict__ labels, int D, int H, int W, in
         for (int r = 0; r <= VA_ROWS; ++r) lab[r] = (xin && y0 + r < H) ? first[(size_t)r * W + x] : -1;
 #pragma unroll
         for (int r = 0; r < VA_ROWS; ++r) edge[r] = (last && y0 + r < H) ? first[(size_t)r * W + x + 1] : -1;
+#pragma unroll
+        for (int r = 0; r <= VA_ROWS; ++r) behind[r] = (xin && y0 + r < H && z_first + 1 < D) ? first[plane + (size_t)r * W + x] : -1;
+#pragma unroll
+        for (int r = 0; r < VA_ROWS; ++r) edge_behind[r] = (last && y0 + r < H && z_first + 1 < D) ? first[plane + (size_t)r * W + x + 1] : -1;
     }
     for (int z = z_first; z < z_end; ++z) {
+        // (the rows of slice z + 2 are requested HERE and used in the next turn: a turn does not wait for its own loads)
         const int32_t *__restrict__ base = labels + ((size_t)z * H + y0) * W;          // (wave uniform)
+        const bool more = z + 1 < z_end && z + 2 < D;
+        int ahead[VA_ROWS + 1], edge_ahead[VA_ROWS];
 #pragma unroll
-        for (int r = 0; r <= VA_ROWS; ++r) behind[r] = (xin && y0 + r < H && z + 1 < D) ? base[plane + (size_t)r * W + x] : -1;
+        for (int r = 0; r <= VA_ROWS; ++r) ahead[r] = (more && xin && y0 + r < H) ? base[2 * plane + (size_t)r * W + x] : -1;
 #pragma unroll
-        for (int r = 0; r < VA_ROWS; ++r) edge_behind[r] = (last && y0 + r < H && z + 1 < D) ? base[plane + (size_t)r * W + x + 1] : -1;
+        for (int r = 0; r < VA_ROWS; ++r) edge_ahead[r] = (more && last && y0 + r < H) ? base[2 * plane + (size_t)r * W + x + 1] : -1;
 #pragma unroll
         for (int r = 0; r < VA_ROWS; ++r) {
             const int y = y0 + r;
@@ -1785,9 +1792,15 @@ k_vol_adjacency_runs(const int32_t *__restrict__ labels, int D, int H, int W, in
             }
         }
 #pragma unroll
-        for (int r = 0; r <= VA_ROWS; ++r) lab[r] = behind[r];
+        for (int r = 0; r <= VA_ROWS; ++r) {
+            lab[r] = behind[r];
+            behind[r] = ahead[r];
+        }
 #pragma unroll
-        for (int r = 0; r < VA_ROWS; ++r) edge[r] = edge_behind[r];
+        for (int r = 0; r < VA_ROWS; ++r) {
+            edge[r] = edge_behind[r];
+            edge_behind[r] = edge_ahead[r];
+        }
     }
     __syncthreads();
     if (threadIdx.x < VA_SLOTS && h_key[threadIdx.x] >= 0) {
