@@ -931,15 +931,19 @@ __global__ void __launch_bounds__(256) k_first_voxel(const int32_t *__restrict__
 #pragma unroll
         for (int c = 0; c < 4; ++c) v[c] = p + c < n ? labels[p + c] : -1;
     }
+    // (the entries of the lane's run starts are requested together, then compared: one trip to memory, not one per voxel)
     int before = lane_prev(v[3], -2);
+    int have[4];
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
         const int l = v[c];
-        if (l > 0 && l < n_labels && l != before &&
-            p + c < __hip_atomic_load(first + l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
-            atomicMin(first + l, p + c);
+        have[c] = -1;                                              // (no run start here: nothing to compare with)
+        if (l > 0 && l < n_labels && l != before) have[c] = __hip_atomic_load(first + l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         before = l;
     }
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+        if (p + c < have[c]) atomicMin(first + v[c], p + c);
 }
 
 __global__ void __launch_bounds__(256) k_first_mark(const int32_t *__restrict__ first, int n_labels, uint32_t *bitmap)

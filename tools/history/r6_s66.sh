@@ -3,4 +3,4 @@
 REPO=${GRAFT_REPO_ROOT:-/root/repo}
 cd $REPO
 python -m pytest tests/test_gpu_fused.py tests/test_gpu_volume.py tests/test_gpu_zz_configs.py -m gpu -x -q > gpurun_out/pytest_s66.log 2>&1; grep -n "passed\|failed\|Error" gpurun_out/pytest_s66.log | tail -3
-bash tools/c5_kstats.sh | grep "total kernel\|adjacency"
+bash tools/c5_kstats.sh | grep "total kernel\|adjacency\|k_first_voxel"
