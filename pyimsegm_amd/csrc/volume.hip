@@ -473,10 +473,24 @@ k_vol_blur_yx32(const float *__restrict__ src, float *__restrict__ dst, int H, i
     const float *__restrict__ sl = src + (size_t)blockIdx.z * H * W;
     const bool extra = lane < 2 * RX;                          // the lanes that also serve the columns 64 .. TW - 1
     const int xa = vreflect(X0 - RX + lane, W), xb = extra ? vreflect(X0 - RX + 64 + lane, W) : 0;
-    for (int r = wave; r < TH; r += 4) {
-        const float *__restrict__ row = sl + (size_t)vreflect(Y0 - RY + r, H) * W;
-        A[r][lane] = row[xa];
-        if (extra) A[r][64 + lane] = row[xb];
+    // (a compile-time trip count: the rows of a wave are requested together and stored as they arrive -- `for (r = wave; r < TH; r += 4)`
+    // was a load, a wait and a store per row, ten trips to memory one after the other)
+    constexpr int TR = (TH + 3) / 4;
+    float a0[TR], a1[TR];
+#pragma unroll
+    for (int i = 0; i < TR; ++i) {
+        const int r = wave + 4 * i;
+        const float *__restrict__ row = sl + (size_t)vreflect(Y0 - RY + min(r, TH - 1), H) * W;
+        a0[i] = row[xa];
+        a1[i] = extra ? row[xb] : 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < TR; ++i) {
+        const int r = wave + 4 * i;
+        if (r < TH) {
+            A[r][lane] = a0[i];
+            if (extra) A[r][64 + lane] = a1[i];
+        }
     }
     __syncthreads();
 #pragma unroll
