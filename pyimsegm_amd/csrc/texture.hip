@@ -439,272 +439,10 @@ k_conv_battery_quad(const double *__restrict__ planes, int H, int W, const doubl
     const int ch = blockIdx.z;
     const double *src = planes + (size_t)ch * H * W;
     const int x0 = blockIdx.x * CV_TX, y0 = blockIdx.y * CV_TY;
-    // (requesting a thread's eighteen words together, as k_sep_battery_tall does, changed nothing here: 1 200 against 1 187 us -- four
-    // workgroups per CU cover one another's loads)
     for (int i = threadIdx.x; i < TW * TH; i += 256) {
         const int ty = i / TW, tx = i - ty * TW;
         const int gy = reflect_index(y0 + ty - R, H), gx = reflect_index(x0 + tx - R, W);
         tile[i] = src[(size_t)gy * W + gx];
-    }
-    __syncthreads();
-    const int lx = threadIdx.x & 63;
-    const int ly = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) * CV_ROWS;
-    double acc[NK][CV_ROWS];
-#pragma unroll
-    for (int k = 0; k < NK; ++k)
-#pragma unroll
-        for (int i = 0; i < CV_ROWS; ++i) acc[k][i] = 0.0;
-    // correlation form: out[y][x] = sum_{t, kx} Wc[t][kx] * in[y + t - r][x + kx - r]; the host passes the flipped kernels, so
-    // this equals ndimage.convolve.  The input value of tile row ly + ky meets weight row t = ky - i for output row i: a window of
-    // CV_ROWS weight rows slides down the kernel column, ONE new row of NK wave-uniform weights (a scalar load) per input value;
-    // the row loop is unrolled in groups of CV_ROWS, so the window lives in fixed scalar registers without any moves.
-    for (int kx = 0; kx < S; ++kx) {
-        const double *wk = wgt + (size_t)kx * Spad * NK;
-        double w[CV_ROWS][NK];
-#pragma unroll
-        for (int u = 0; u < CV_ROWS; ++u)
-#pragma unroll
-            for (int k = 0; k < NK; ++k) w[u][k] = 0.0;
-        for (int g = 0; g < Spad; g += CV_ROWS) {
-#pragma unroll
-            for (int u = 0; u < CV_ROWS; ++u) {
-                const int ky = g + u;
-#pragma unroll
-                for (int k = 0; k < NK; ++k) w[u][k] = wk[ky * NK + k];          // weight row t = ky into slot ky mod CV_ROWS
-                const double v = tile[(ly + ky) * tw + lx + kx];
-#pragma unroll
-                for (int i = 0; i < CV_ROWS; ++i)
-#pragma unroll
-                    for (int k = 0; k < NK; ++k) acc[k][i] = fma(w[(u - i + CV_ROWS) % CV_ROWS][k], v, acc[k][i]);
-            }
-        }
-    }
-    const int x = x0 + lx;
-#pragma unroll
-    for (int i = 0; i < CV_ROWS; ++i) {
-        const int y = y0 + ly + i;
-        if (x >= W || y >= H) continue;
-        double r = acc[0][i];
-#pragma unroll
-        for (int k = 1; k < NK; ++k) r = fmax(r, acc[k][i]);
-        if (r > clip) r = clip;
-        resp[(size_t)ch * H * W + (size_t)y * W + x] = r;
-    }
-}
-
-// ---- dense batteries of kernels with a point symmetry ------------------------------------------------------------------------
-// Every edge filter of the bank is odd and every bar filter even under the point reflection p -> -p, bit for bit (the rotated grid
-// of descriptors.py:924-928 is negated exactly): K(-p) = sign * K(p), so
-//     sum_p K(p) in(q + p)  =  sum_{p in half plane} K(p) * (in(q + p) + sign * in(q - p))  (+ the centre column as before),
-// and ONE addition per pair serves all NK kernels of the battery: 4 + 4 NK vector operations per step of 2 * 4 * NK multiply-adds
-// instead of 8 NK -- 1.7x fewer for NK = 6.  Layout as k_conv_battery: a lane owns one output column and CV_ROWS rows, the weight
-// rows slide through scalar registers.  Kernel column kx < r is paired with column 2r - kx: for the input row j of column A = lx + kx
-// the partner of output row i (weight row t = j - i) is row 2r - j + 2i of column B = lx + 2r - kx -- rows of one parity, so two
-// circular windows of four values (even / odd steps) hold them with ONE new LDS read per step; the step loop is unrolled by 8.
-constexpr int CVS_UNROLL = 8;
-__host__ __device__ static inline int conv_sym_padded_rows(int radius) { return ((2 * radius + 1 + CV_ROWS - 1 + CVS_UNROLL - 1) / CVS_UNROLL) * CVS_UNROLL; }
-
-template <int NK>
-__global__ void __launch_bounds__(256)
-k_conv_battery_sym(const double *__restrict__ planes, int H, int W, const double *__restrict__ wgt, int radius, double sign,
-                   double clip, double *__restrict__ resp)
-{
-    extern __shared__ double tile[];                 // [(CV_TY - CV_ROWS + Spad)][(CV_TX + 2r)]
-    const int Spad = conv_sym_padded_rows(radius);
-    const int tw = CV_TX + 2 * radius, th = CV_TY + 2 * radius, th_pad = CV_TY - CV_ROWS + Spad;
-    const int ch = blockIdx.z;
-    const double *src = planes + (size_t)ch * H * W;
-    const int x0 = blockIdx.x * CV_TX, y0 = blockIdx.y * CV_TY;
-    for (int i = threadIdx.x; i < tw * th_pad; i += 256) {
-        int ty = i / tw, tx = i - ty * tw;
-        // (rows behind the halo only ever meet zero weights: any finite value will do)
-        int gy = reflect_index(y0 + min(ty, th - 1) - radius, H), gx = reflect_index(x0 + tx - radius, W);
-        tile[i] = src[(size_t)gy * W + gx];
-    }
-    __syncthreads();
-    const int lx = threadIdx.x & 63;
-    const int ly = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) * CV_ROWS;
-    double acc[NK][CV_ROWS];
-#pragma unroll
-    for (int k = 0; k < NK; ++k)
-#pragma unroll
-        for (int i = 0; i < CV_ROWS; ++i) acc[k][i] = 0.0;
-    for (int kx = 0; kx < radius; ++kx) {
-        const double *wk = wgt + (size_t)kx * Spad * NK;
-        const double *colA = tile + lx + kx, *colB = tile + lx + 2 * radius - kx;
-        double w[CV_ROWS][NK];
-#pragma unroll
-        for (int u = 0; u < CV_ROWS; ++u)
-#pragma unroll
-            for (int k = 0; k < NK; ++k) w[u][k] = 0.0;
-        // partner rows of column B: window E serves the even steps (rows 2r - j + 2i, j even), O the odd ones; slot e mod 4
-        // takes the row read at even step number e, the output row i looks i even steps back.  Before the first step the windows
-        // hold the rows above 2r that meet non-zero weight rows (2r + 2 | 2r + 1, 2r + 3); every other start value only meets
-        // the zero rows of the padded weight table
-        double E[4] = { 0.0, 0.0, 0.0, colB[(size_t)(ly + 2 * radius + 2) * tw] };
-        double O[4] = { 0.0, 0.0, colB[(size_t)(ly + 2 * radius + 3) * tw], colB[(size_t)(ly + 2 * radius + 1) * tw] };
-        for (int g = 0; g < Spad; g += CVS_UNROLL) {
-#pragma unroll
-            for (int u = 0; u < CVS_UNROLL; ++u) {
-                const int j = g + u;
-#pragma unroll
-                for (int k = 0; k < NK; ++k) w[u % CV_ROWS][k] = wk[j * NK + k];         // weight row t = j into slot j mod CV_ROWS
-                const double a = colA[(size_t)(ly + j) * tw];
-                const double b = colB[(size_t)max(ly + 2 * radius - j, 0) * tw];
-                double sv[CV_ROWS];
-                if ((u & 1) == 0) {
-                    E[(u / 2) % 4] = b;
-#pragma unroll
-                    for (int i = 0; i < CV_ROWS; ++i) sv[i] = fma(sign, E[((u / 2) - i + 4) % 4], a);
-                } else {
-                    O[(u / 2) % 4] = b;
-#pragma unroll
-                    for (int i = 0; i < CV_ROWS; ++i) sv[i] = fma(sign, O[((u / 2) - i + 4) % 4], a);
-                }
-#pragma unroll
-                for (int i = 0; i < CV_ROWS; ++i)
-#pragma unroll
-                    for (int k = 0; k < NK; ++k) acc[k][i] = fma(w[(u - i + 2 * CV_ROWS) % CV_ROWS][k], sv[i], acc[k][i]);
-            }
-        }
-    }
-    {
-        // the centre column pairs with itself: the plain sum of k_conv_battery over its Spad rows
-        const double *wk = wgt + (size_t)radius * Spad * NK;
-        const double *col = tile + lx + radius;
-        double w[CV_ROWS][NK];
-#pragma unroll
-        for (int u = 0; u < CV_ROWS; ++u)
-#pragma unroll
-            for (int k = 0; k < NK; ++k) w[u][k] = 0.0;
-        for (int g = 0; g < Spad; g += CV_ROWS) {
-#pragma unroll
-            for (int u = 0; u < CV_ROWS; ++u) {
-                const int j = g + u;
-#pragma unroll
-                for (int k = 0; k < NK; ++k) w[u][k] = wk[j * NK + k];
-                const double v = col[(size_t)(ly + j) * tw];
-#pragma unroll
-                for (int i = 0; i < CV_ROWS; ++i)
-#pragma unroll
-                    for (int k = 0; k < NK; ++k) acc[k][i] = fma(w[(u - i + CV_ROWS) % CV_ROWS][k], v, acc[k][i]);
-            }
-        }
-    }
-    const int x = x0 + lx;
-#pragma unroll
-    for (int i = 0; i < CV_ROWS; ++i) {
-        const int y = y0 + ly + i;
-        if (x >= W || y >= H) continue;
-        double r = acc[0][i];
-#pragma unroll
-        for (int k = 1; k < NK; ++k) r = fmax(r, acc[k][i]);
-        if (r > clip) r = clip;
-        resp[(size_t)ch * H * W + (size_t)y * W + x] = r;
-    }
-}
-
-// ---- dense batteries whose kernels are mirror images of each other in pairs ------------------------------------------------------
-// The orientations theta and pi - theta of an edge / bar battery are mirror images: Kb(dy, dx) = m * Ka(dy, -dx) (m = +-1; to the
-// last bits of the rotated grid -- the host checks it to 1e-12 of the kernel's maximum and takes Ka's values for both).  Together
-// with the point symmetry K(-p) = sign * K(p), the four inputs of a quad (+-dy, +-dx) around the output,
-//     top = row c - y, bot = row c + y, A = column cx - x, B = column cx + x,
-// enter the two responses only through  U = (A + B)[top] + sign * (A + B)[bot]  and  V = (B - A)[top] - sign * (B - A)[bot]:
-//     Ra = WS * U + WD * V,    Rb = m * (WS * U - WD * V),    WS = (Ka(-y, x) + Ka(-y, -x)) / 2,  WD = (Ka(-y, x) - Ka(-y, -x)) / 2,
-// i.e. 2 additions + 2 multiply-adds per quad and PAIR of kernels where the point symmetry alone needs 2 + 4 (and the plain sum 8):
-// 652 vector operations per column pair, lane and 4 output rows for the three pairs of a Leung-Malik battery (544 multiply-adds
-// and U / V additions, 72 column sums / differences, 36 address steps) instead of 1120: 5.84 * 10^8 against 1.07 * 10^9 vector
-// instructions per launch at 2048^2 (profiles/rocprof_r04_cfg3_sq_counters.txt), 1.18 against 2.05 ms.
-// (The sums differ from the reference's order of additions in the last bits -- as every dense sum here does; the descriptors
-// stay 10^-9 from the reference run's, tolerance 10^-5.)  Table wq: [x = 0..R][t = 0..R][WS of the NP pairs | WD of the NP
-// pairs], t = R + dy the kernel row (the row of the output itself, t = R, halved by the host: its top and bottom coincide),
-// then the NP mirror signs m.  Layout as k_conv_battery: a lane owns one output column and CV_ROWS rows; everything is unrolled
-// over the rows (R is a compile-time constant), so the (row, output) combinations that would meet weight rows outside the
-// kernel are not computed at all and the weights need no padding.
-template <int NP, int R, bool CENTRE>
-__device__ __forceinline__ void quad_column(const double *colA, const double *colB, const double *__restrict__ w, double sign, double nsign,
-                                            double (&accS)[NP][CV_ROWS], double (&accD)[NP][CV_ROWS])
-{
-    constexpr int TW = CV_TX + 2 * R;
-    double sb[2 * R + CV_ROWS], db[2 * R + CV_ROWS];              // (A + B), (B - A) of the rows below: compile-time indices only
-#pragma unroll
-    for (int k = 1; k < CV_ROWS; ++k) {
-        const double a = colA[(2 * R + k) * TW];
-        if (CENTRE) {
-            sb[2 * R + k] = a;
-        } else {
-            const double b = colB[(2 * R + k) * TW];
-            sb[2 * R + k] = a + b;
-            db[2 * R + k] = b - a;
-        }
-    }
-#pragma unroll
-    for (int j = 0; j < R + CV_ROWS; ++j) {
-        double st, dt = 0.0;
-        {
-            const double a = colA[j * TW];
-            if (CENTRE) {
-                st = a;
-            } else {
-                const double b = colB[j * TW];
-                st = a + b;
-                dt = b - a;
-            }
-        }
-        if (j <= R) {
-            const double a = colA[(2 * R - j) * TW];
-            if (CENTRE) {
-                sb[2 * R - j] = a;
-            } else {
-                const double b = colB[(2 * R - j) * TW];
-                sb[2 * R - j] = a + b;
-                db[2 * R - j] = b - a;
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < CV_ROWS; ++i) {
-            const int t = j - i;
-            if (t < 0 || t > R) continue;
-            const int rho = 2 * R - j + 2 * i;
-            const double U = fma(sign, sb[rho], st);
-#pragma unroll
-            for (int k = 0; k < NP; ++k) accS[k][i] = fma(w[t * 2 * NP + k], U, accS[k][i]);
-            if (!CENTRE) {
-                const double V = fma(nsign, db[rho], dt);
-#pragma unroll
-                for (int k = 0; k < NP; ++k) accD[k][i] = fma(w[t * 2 * NP + NP + k], V, accD[k][i]);
-            }
-        }
-    }
-}
-
-template <int NP, int R>
-__global__ void __launch_bounds__(256)
-k_conv_battery_quad(const double *__restrict__ planes, int H, int W, const double *__restrict__ wq, double sign, double clip,
-                    double *__restrict__ resp)
-{
-    extern __shared__ double tile[];                 // [CV_TY + 2R][CV_TX + 2R]
-    constexpr int TW = CV_TX + 2 * R, TH = CV_TY + 2 * R;
-    const int ch = blockIdx.z;
-    const double *src = planes + (size_t)ch * H * W;
-    const int x0 = blockIdx.x * CV_TX, y0 = blockIdx.y * CV_TY;
-    // (the words of a thread are requested TOGETHER and stored as they arrive: as `for (i = threadIdx.x; i < TW * TH; i += 256)` the
-    // compiler kept a load, a wait and a store per turn -- eighteen trips to memory one after the other in front of every tile)
-    {
-        constexpr int NL = (TW * TH + 255) / 256;
-        double v[NL];
-#pragma unroll
-        for (int j = 0; j < NL; ++j) {
-            const int i = min((int)threadIdx.x + 256 * j, TW * TH - 1);
-            const int ty = i / TW, tx = i - ty * TW;
-            const int gy = reflect_index(y0 + ty - R, H), gx = reflect_index(x0 + tx - R, W);
-            v[j] = src[(size_t)gy * W + gx];
-        }
-#pragma unroll
-        for (int j = 0; j < NL; ++j) {
-            const int i = (int)threadIdx.x + 256 * j;
-            if (i < TW * TH) tile[i] = v[j];
-        }
     }
     __syncthreads();
     const int lx = threadIdx.x & 63;
@@ -955,7 +693,8 @@ k_sep_battery_tall(const double *__restrict__ planes, const double *__restrict__
     const int x0 = blockIdx.x * SPT_X, y0 = blockIdx.y * SPT_Y;
     constexpr int IN_W = SPT_X + 2 * SPT_R;
     {   // (a thread's words are requested TOGETHER and stored as they arrive: as `for (i = threadIdx.x; ...; i += 256)` the compiler kept a
-        // load, a wait and a store per turn -- a dozen trips to memory one after the other in front of every tile: 754 -> 650 us)
+        // load, a wait and a store per turn -- a dozen trips to memory one after the other in front of every tile: 754 -> 650 us.
+        // The same in k_conv_battery_quad changed nothing -- 1 200 against 1 187 us: four workgroups per CU cover one another's loads)
         constexpr int NL = (IN_W * SPT_TH + 255) / 256;
         double v[NL];
 #pragma unroll
