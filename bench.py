@@ -1346,6 +1346,13 @@ def bench_volume(args, group, shape=None, quick=False):
             latency_ms, latency_fit_ms = (time.perf_counter() - t_lat) * 1e3, fit_seconds[0] * 1e3
     classes_found = int(len(np.unique(segm[::4, ::16, ::16])))
     del segm
+    # the stage figures: one more un-overlapped volume on the session the latency was measured on, HERE -- behind the run with volumes
+    # in flight this thread's session is gone and its 90 GB are allocated again between the stage's events (seconds, once)
+    ctx.profile_enable(True)
+    ctx.profile_reset()
+    step()
+    stage_ms = {g: ctx.profile_get(g) for g in _hip.PROFILE_GROUPS}
+    ctx.profile_enable(False)
     if inflight > 1:
         ctx.close_idle_sessions()               # (the worker threads bring their own resident volumes)
     def do_step(state, index, stage):
@@ -1361,12 +1368,7 @@ def bench_volume(args, group, shape=None, quick=False):
     # (the clock of the fit: its share of the timed steps only -- SteadyRun runs first-use, warm-up, timed and cool-down steps)
     fit_seconds[0] = fit_seconds[0] * steps / (warmup + steps + 2 * inflight)
     fit_ms = fit_seconds[0] / steps * 1e3
-    ctx.profile_enable(True)
-    ctx.profile_reset()
-    step()
     pipe.estim_class_model = fit
-    stage_ms = {g: ctx.profile_get(g) for g in _hip.PROFILE_GROUPS}
-    ctx.profile_enable(False)
     if limiter is not None:
         try:
             limiter.restore_original_limits()
