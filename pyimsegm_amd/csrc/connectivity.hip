@@ -213,6 +213,8 @@ k_ccl_merge_rows(const int32_t *__restrict__ labels, int32_t *parent, int D, int
         if (mine && l[r] == cur && !(cont && up_left)) todo |= 2u << (3 * r);
         if (mine && bk[r] == cur && !(cont && back_left)) todo |= 4u << (3 * r);
     }
+    // (starting a union from the first voxels of the two runs -- found by votes over the rows in registers instead of one load
+    // each -- was measured: 9.4 against 8.7 ms; the first step of a walk hits the cache, the votes cost more)
     const int p0 = (int)(row0 + x);
     while (__any(todo != 0)) {
         int a[2] = { -1, -1 }, b[2] = { -1, -1 };
