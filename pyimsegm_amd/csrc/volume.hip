@@ -1174,6 +1174,8 @@ template <typename T> struct __attribute__((packed, aligned(4))) Quad {
 };
 static_assert(VU_STEP == 4, "a round of the update is one Quad");
 // (quads of a lane requested per round, config 5, ms per sweep: 1 -> 3.01, 2 -> 2.03, 4 -> 1.81, 6 -> 1.84, 8 -> 1.82)
+// (the walk as one sequence of rounds with the NEXT round's labels requested before this round's values -- one trip per round
+// instead of two -- measured 1.84 against 1.80: with four quads per round the trips are no longer what the kernel waits for)
 #ifndef VOL_UPDATE_QUADS
 #define VOL_UPDATE_QUADS 4
 #endif
