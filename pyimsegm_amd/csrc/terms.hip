@@ -129,16 +129,30 @@ k_adj_scan(const int *__restrict__ Kp, const int32_t *__restrict__ deg, const in
     if (threadIdx.x < 2) carry[threadIdx.x] = 0;
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int base = 0; base < K; base += 256) {
-        const int i = base + threadIdx.x;
-        const int v0 = i < K ? deg[i] : 0, v1 = i < K ? deg_low[i] : 0;
-        int i0 = v0, i1 = v1;
+    // (four consecutive entries per lane and turn: a turn is a trip to memory and three barriers whatever it carries -- 1 165 turns of
+    // 256 entries for the 298 116 supervoxels of config 5 were 0.94 ms)
+    constexpr int PER = 4;
+    for (int base = 0; base < K; base += 256 * PER) {
+        const int i = base + threadIdx.x * PER;
+        int v0[PER], v1[PER];
+#pragma unroll
+        for (int j = 0; j < PER; ++j) {
+            v0[j] = i + j < K ? deg[i + j] : 0;
+            v1[j] = i + j < K ? deg_low[i + j] : 0;
+        }
+        int t0 = 0, t1 = 0;
+#pragma unroll
+        for (int j = 0; j < PER; ++j) {
+            t0 += v0[j];
+            t1 += v1[j];
+        }
+        int i0 = t0, i1 = t1;
 #pragma unroll
         for (int off = 1; off < 64; off <<= 1) {
-            const int t0 = __shfl_up(i0, off, 64), t1 = __shfl_up(i1, off, 64);
+            const int u0 = __shfl_up(i0, off, 64), u1 = __shfl_up(i1, off, 64);
             if (lane >= off) {
-                i0 += t0;
-                i1 += t1;
+                i0 += u0;
+                i1 += u1;
             }
         }
         if (lane == 63) {
@@ -151,9 +165,15 @@ k_adj_scan(const int *__restrict__ Kp, const int32_t *__restrict__ deg, const in
             p0 += wsum[0][w];
             p1 += wsum[1][w];
         }
-        if (i < K) {
-            arc_start[i] = p0 + i0 - v0;
-            edge_start[i] = p1 + i1 - v1;
+        int e0 = p0 + i0 - t0, e1 = p1 + i1 - t1;             // exclusive prefix of the lane's first entry
+#pragma unroll
+        for (int j = 0; j < PER; ++j) {
+            if (i + j < K) {
+                arc_start[i + j] = e0;
+                edge_start[i + j] = e1;
+            }
+            e0 += v0[j];
+            e1 += v1[j];
         }
         __syncthreads();
         if (threadIdx.x == 255) {
