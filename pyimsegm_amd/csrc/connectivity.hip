@@ -566,15 +566,26 @@ k_kept_scan(const int32_t *__restrict__ parent, const int32_t *__restrict__ csiz
 // exclusive scan of the per-block counts by one workgroup; total -> counters[CNT_KEPT]
 __global__ void __launch_bounds__(1024) k_scan_blocksums(int32_t *blocksum, int nblocks, int32_t *counters)
 {
+    // (four consecutive counts per lane and turn: a turn costs a trip to memory and its barriers whatever it carries)
+    constexpr int PER = 4;
     __shared__ int carry;
     if (threadIdx.x == 0) carry = 0;
     __syncthreads();
-    for (int base = 0; base < nblocks; base += 1024) {
-        int i = base + threadIdx.x;
-        int v = i < nblocks ? blocksum[i] : 0;
+    for (int base = 0; base < nblocks; base += 1024 * PER) {
+        const int i = base + threadIdx.x * PER;
+        int v[PER], t = 0;
+#pragma unroll
+        for (int j = 0; j < PER; ++j) {
+            v[j] = i + j < nblocks ? blocksum[i + j] : 0;
+            t += v[j];
+        }
         int total;
-        int excl = block_exclusive_scan<16>(v, &total);
-        if (i < nblocks) blocksum[i] = carry + excl;
+        int excl = carry + block_exclusive_scan<16>(t, &total);
+#pragma unroll
+        for (int j = 0; j < PER; ++j) {
+            if (i + j < nblocks) blocksum[i + j] = excl;
+            excl += v[j];
+        }
         __syncthreads();
         if (threadIdx.x == 0) carry += total;
         __syncthreads();
